@@ -1,0 +1,48 @@
+"""Shared helpers for the tests: the shipped model_kwargs of the BASELINE configs
+(restated from the reference yamls, e.g. configs/fastenhancer/b.yaml:2-29 — data,
+not code) and golden loading."""
+import os
+
+import numpy as np
+
+from oracle.fe_oracle import FEConfig, FEOracle, fold_state_dict
+from oracle.weightgen import make_input, make_training_state_dict
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _kw(C1, ks, C2, F2, K, N, H, init, eps=1.0e-5):
+    return dict(
+        channels=C1, kernel_size=list(ks), stride=4,
+        rnnformer_kwargs=dict(num_blocks=K, channels=C2, freq=F2, num_heads=4, eps=eps,
+                              positional_embedding="train", attn_bias=False, post_act=False, pre_norm=False),
+        pre_post_init=init, n_fft=N, hop_size=H, win_size=N, window="hann", stft_normalized=False,
+        mask=None, activation="SiLU", activation_kwargs=dict(inplace=True), input_compression=0.3,
+        normalize_final_conv=True, weight_norm=True, resnet=False)
+
+
+# name -> (model_kwargs, sampling rate, golden seed)
+MODEL_KWARGS = {
+    "fe_t": (_kw(24, (8, 3, 3), 20, 16, 2, 512, 256, "linear_fixed"), 16000, 101),
+    "fe_b": (_kw(48, (8, 3, 3), 36, 24, 3, 512, 256, "linear_fixed"), 16000, 102),
+    "fe_s": (_kw(64, (8, 3, 3, 3), 48, 36, 3, 512, 256, "linear_fixed"), 16000, 105),
+    "fe_m": (_kw(96, (8, 3, 3, 3), 72, 48, 4, 512, 160, "linear_fixed"), 16000, 106),
+    "fe_l": (_kw(128, (8, 3, 3, 3, 3), 96, 64, 5, 512, 100, "linear_fixed"), 16000, 103),
+    "fe48_b": (_kw(48, (8, 3, 3), 36, 36, 3, 1024, 512, "linear"), 48000, 104),
+}
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+
+
+def build_oracle(name, dtype=np.float32):
+    kw, sr, seed = MODEL_KWARGS[name]
+    cfg = FEConfig.from_model_kwargs(kw)
+    sd = make_training_state_dict(cfg, seed)
+    fused = fold_state_dict(sd, cfg)
+    return cfg, sd, fused, FEOracle(cfg, fused, dtype)
+
+
+def rms(x):
+    return float(np.sqrt(np.mean(np.square(np.asarray(x, np.float64)))))

@@ -1,0 +1,103 @@
+"""Pin the CPU oracle (oracle/fe_oracle.py) against golden vectors produced by the
+imported reference (tools/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from common import MODEL_KWARGS, build_oracle, load_golden, rms
+from oracle.weightgen import make_input
+
+GOLDENS = ["fe_t", "fe_b", "fe_m", "fe_l", "fe48_b"]
+# fp32-vs-fp32 different summation orders: the reference's own fp32 noise floor is ~5e-7
+# relative; allow 20x that.
+REL = 1e-5
+
+
+def _close(a, b, rel=REL, what=""):
+    err = rms(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+    ref = rms(b)
+    assert err <= rel * max(ref, 1e-3), f"{what}: rms err {err:.3e} vs ref rms {ref:.3e}"
+
+
+@pytest.mark.parametrize("name", GOLDENS)
+def test_streaming_step_matches_reference(name):
+    g = load_golden(name)
+    cfg, sd, fused, orc = build_oracle(name)
+    B, hops, H = int(g["B"]), int(g["hops"]), cfg.hop_size
+    x = make_input(B, hops * H, int(g["seed"]) + 1000, int(g["sr"]))
+    caches = orc.initialize_cache(B)
+    outs = []
+    for t in range(hops):
+        o, *caches = orc.step(x[:, t * H:(t + 1) * H], *caches)
+        outs.append(o)
+    _close(np.stack(outs, 0), g["stream_wav_out"], what="wav_out")
+    _close(caches[0], g["stream_cache_stft"], what="cache_stft")
+    _close(caches[1], g["stream_cache_istft"], what="cache_istft")
+    for k in range(cfg.rf_blocks):
+        _close(caches[2 + k], g[f"stream_h{k}"], what=f"h{k}")
+
+
+@pytest.mark.parametrize("name", GOLDENS)
+def test_spec_chunk_matches_reference(name):
+    g = load_golden(name)
+    cfg, sd, fused, orc = build_oracle(name)
+    B, H = int(g["B"]), cfg.hop_size
+    x = make_input(B, int(g["hops"]) * H, int(g["seed"]) + 1000, int(g["sr"]))
+    cache = orc.initialize_cache(B)[0]
+    specs = []
+    for t in range(4):
+        s, cache = orc.stft_step(x[:, t * H:(t + 1) * H], cache)
+        specs.append(s)
+    spec = np.concatenate(specs, axis=2)
+    h0 = orc.initialize_cache(B)[2:]
+    y, h = orc.spec_forward(spec, h0)
+    _close(y, g["chunk_spec_out"], what="chunk spec")
+    _close(h[-1], g["chunk_h_last"], what="chunk h")
+
+
+@pytest.mark.parametrize("name", GOLDENS)
+def test_offline_matches_reference(name):
+    g = load_golden(name)
+    cfg, sd, fused, orc = build_oracle(name)
+    B, H = int(g["B"]), cfg.hop_size
+    x = make_input(B, int(g["hops"]) * H + 37, int(g["seed"]) + 2000, int(g["sr"]))
+    wav, spec = orc.offline_forward(x)
+    assert wav.shape == g["offline_wav"].shape and spec.shape == g["offline_spec"].shape
+    _close(wav, g["offline_wav"], what="offline wav")
+    _close(spec, g["offline_spec"], what="offline spec")
+
+
+@pytest.mark.parametrize("name", ["fe_t", "fe_b"])
+def test_driver_loop_matches_reference(name):
+    g = load_golden(name)
+    cfg, sd, fused, orc = build_oracle(name)
+    length = int(g["long_length"])
+    x = make_input(1, length, int(g["seed"]) + 3000, int(g["sr"]))
+    y = orc.enhance_stream(x)
+    assert y.shape == (1, length)
+    _close(y[0], g["long_wav_out"], rel=3e-5, what="long run")
+
+
+def test_fold_matches_reference_fused_state_dict():
+    g = load_golden("fe_t")
+    cfg, sd, fused, orc = build_oracle("fe_t")
+    keys = [k[len("fused."):] for k in g.files if k.startswith("fused.")]
+    assert sorted(keys) == sorted(fused.keys())
+    for k in keys:
+        np.testing.assert_allclose(fused[k], g["fused." + k], rtol=2e-6, atol=1e-7, err_msg=k)
+
+
+def test_latency_identity_stft_istft():
+    """docs/docs/onnx.md:37-72: streaming STFT->iSTFT reconstructs the input delayed by N-H."""
+    for name in ("fe_b", "fe_l", "fe48_b"):
+        cfg, sd, fused, orc = build_oracle(name, np.float64)
+        H, N = cfg.hop_size, cfg.n_fft
+        x = make_input(2, 20 * H, 7, 16000).astype(np.float64)
+        c1, c2 = orc.initialize_cache(2)[:2]
+        out = []
+        for t in range(20):
+            s, c1 = orc.stft_step(x[:, t * H:(t + 1) * H], c1)
+            o, c2 = orc.istft_step(s, c2)
+            out.append(o)
+        y = np.concatenate(out, 1)
+        d = N - H
+        np.testing.assert_allclose(y[:, N:], x[:, N - d:-d] if d else x[:, N:], atol=1e-6)

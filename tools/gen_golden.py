@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Runs only in the authoring container, where the reference checkout is mounted
+read-only at /root/reference.  Nothing from the reference (source, bytecode,
+pickled modules) is written to the repo: the fixtures are plain arrays (inputs
+are regenerated from seeds, so only expected OUTPUTS are stored).
+
+Import recipe, zero edits to reference files:
+  * ``functional/__init__.py`` pulls ``librosa.filters`` -> a stub module is
+    pre-inserted in ``sys.modules``;
+  * Python 3.10 rejects ``tp.Tuple[Tensor, Tensor, ...]`` used as a return
+    annotation in model.py -> the file is compiled with
+    ``from __future__ import annotations`` semantics into a fresh module;
+  * ``utils`` / ``wrappers`` / ``scripts.export_onnx`` are never imported
+    (torchaudio / onnx / librosa are absent); the 10-line wav->wav composition of
+    scripts/export_onnx.py:48-58 is driven step by step below.
+
+usage: PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [--ref /root/reference]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+import __future__ as _future
+
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+import yaml
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+from oracle.fe_oracle import FEConfig, fold_state_dict, linear_filterbank, stft_windows, training_state_dict_spec  # noqa: E402
+from oracle.weightgen import make_input, make_training_state_dict  # noqa: E402
+
+
+def import_reference_model(ref: str, rel: str, name: str) -> types.ModuleType:
+    if "librosa" not in sys.modules:
+        lib = types.ModuleType("librosa")
+        filt = types.ModuleType("librosa.filters")
+        filt.mel = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("librosa stub"))
+        lib.filters = filt
+        sys.modules["librosa"] = lib
+        sys.modules["librosa.filters"] = filt
+    if ref not in sys.path:
+        sys.path.insert(0, ref)
+    path = os.path.join(ref, rel)
+    src = open(path).read()
+    mod = types.ModuleType(name)
+    mod.__file__ = path
+    sys.modules[name] = mod      # dataclasses resolve cls.__module__ through sys.modules
+    code = compile(src, path, "exec", flags=_future.annotations.compiler_flag, dont_inherit=True)
+    exec(code, mod.__dict__)
+    return mod
+
+
+CONFIGS = {
+    # name: (yaml, seed, B, hops, long_hops)
+    "fe_t": ("configs/fastenhancer/t.yaml", 101, 2, 12, 200),
+    "fe_b": ("configs/fastenhancer/b.yaml", 102, 2, 12, 200),
+    "fe_m": ("configs/fastenhancer/m.yaml", 106, 1, 8, 0),
+    "fe_l": ("configs/fastenhancer/l.yaml", 103, 1, 6, 0),
+    "fe48_b": ("configs/fastenhancer_48khz/b.yaml", 104, 2, 8, 0),
+}
+
+
+def to_t(sd):
+    return {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+
+
+def gen_fastenhancer(ref: str, name: str, out_dir: str):
+    rel_yaml, seed, B, hops, long_hops = CONFIGS[name]
+    hps = yaml.safe_load(open(os.path.join(ref, rel_yaml)))
+    kw = hps["model_kwargs"]
+    sr = hps["data"]["sampling_rate"]
+    cfg = FEConfig.from_model_kwargs(kw)
+    mod = import_reference_model(ref, "models/fastenhancer/default/model.py", "ref_fe_model")
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+
+    model = mod.Model(**kw).eval()           # offline, training form
+    ref_sd = model.state_dict()
+    spec = training_state_dict_spec(cfg)
+    assert list(ref_sd.keys()) == list(spec.keys()), (
+        "state_dict schema drifted", [k for k in ref_sd if k not in spec], [k for k in spec if k not in ref_sd])
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(spec[k]), (k, v.shape, spec[k])
+    sd = make_training_state_dict(cfg, seed)
+    model.load_state_dict(to_t(sd), strict=True)
+
+    onnx_model = mod.ONNXModel(**kw).eval()  # streaming
+    onnx_model.load_state_dict(to_t(sd), strict=True)
+    onnx_model.remove_weight_reparameterizations()
+    fused_ref = {k: v.detach().numpy().copy() for k, v in onnx_model.state_dict().items()}
+
+    # ---- fold check (a20): my restatement vs the reference's fused state_dict
+    fused_mine = fold_state_dict(sd, cfg)
+    assert set(fused_mine) == set(fused_ref), (set(fused_mine) ^ set(fused_ref))
+    worst = 0.0
+    for k in fused_ref:
+        d = np.abs(fused_mine[k] - fused_ref[k]).max() / (np.abs(fused_ref[k]).max() + 1e-12)
+        worst = max(worst, d)
+    assert worst < 2e-6, worst
+    # windows (a1)
+    w, wi = stft_windows(cfg.n_fft, cfg.hop_size, cfg.win_size)
+    dw = np.abs(w - onnx_model.stft.window.numpy()).max()
+    dwi = np.abs(wi - onnx_model.stft.window_istft.numpy()).max() / np.abs(wi).max()
+    assert dw < 1e-6 and dwi < 1e-6, (dw, dwi)
+    # fixed filterbank formula
+    if kw.get("pre_post_init", None) == "linear_fixed":
+        fresh = mod.ONNXModel(**kw)
+        pre, post = linear_filterbank(cfg.F1, cfg.rf_freq)
+        assert np.abs(pre - fresh.rf_pre[0].weight.numpy()).max() < 1e-5
+        assert np.abs(post - fresh.rf_post[0].weight.numpy()).max() < 1e-5
+
+    out = {"seed": np.int64(seed), "B": np.int64(B), "hops": np.int64(hops), "sr": np.int64(sr),
+           "fold_worst_rel": np.float64(worst)}
+    H, N = cfg.hop_size, cfg.n_fft
+    x = torch.from_numpy(make_input(B, hops * H, seed + 1000, sr))
+
+    # ---- streaming wav->wav (a19): scripts/export_onnx.py:48-58 composition
+    with torch.no_grad():
+        caches = onnx_model.stft.initialize_cache(x)
+        caches += [torch.zeros(1, B * cfg.rf_freq, cfg.rf_channels) for _ in range(cfg.rf_blocks)]
+        cache_stft, cache_istft, *h = caches
+        outs, specs_in, specs_out = [], [], []
+        for t in range(hops):
+            wav_in = x[:, t * H:(t + 1) * H]
+            spec_in, cache_stft = onnx_model.stft(wav_in, cache_stft)
+            spec_out, *h = onnx_model(spec_in, *h)
+            wav_out, cache_istft = onnx_model.stft.inverse(spec_out, cache_istft)
+            outs.append(wav_out.numpy().copy())
+            specs_in.append(spec_in.numpy().copy())
+            specs_out.append(spec_out.numpy().copy())
+    out["stream_wav_out"] = np.stack(outs, 0)                    # [hops,B,H]
+    out["stream_cache_stft"] = cache_stft.numpy().copy()
+    out["stream_cache_istft"] = cache_istft.numpy().copy()
+    for k, hk in enumerate(h):
+        out[f"stream_h{k}"] = hk.numpy().copy()
+    out["stream_spec_in_last"] = specs_in[-1]
+    out["stream_spec_out_last"] = specs_out[-1]
+
+    # ---- spec->spec with a T-frame chunk (a4..a17; model.py:677-710), T=4 from zero state
+    with torch.no_grad():
+        spec_chunk = torch.from_numpy(np.concatenate(specs_in[:4], axis=2))   # [B,F0+1,4,2]
+        h0 = [torch.zeros(1, B * cfg.rf_freq, cfg.rf_channels) for _ in range(cfg.rf_blocks)]
+        spec_hat, *h4 = onnx_model(spec_chunk, *h0)
+    out["chunk_spec_out"] = spec_hat.numpy().copy()
+    out["chunk_h_last"] = h4[-1].numpy().copy()
+
+    # ---- offline Model.forward (a21, a27): Tw = hops*H + 37 exercises the Tw//H truncation
+    xo = torch.from_numpy(make_input(B, hops * H + 37, seed + 2000, sr))
+    with torch.no_grad():
+        wav_hat, spec_hat = model(xo)
+    out["offline_wav"] = wav_hat.numpy().copy()
+    out["offline_spec"] = spec_hat.numpy().copy()
+
+    # ---- long single-stream run through the driver loop of scripts/test_onnx.py:11-60 (a26)
+    if long_hops:
+        length = long_hops * H - 3 * H // 2 + 5            # deliberately not a multiple of H
+        xl = make_input(1, length, seed + 3000, sr)
+        wav = np.clip(xl, -1, 1)
+        wav = np.pad(wav, ((0, 0), (0, N)))
+        with torch.no_grad():
+            cache_stft, cache_istft = onnx_model.stft.initialize_cache(torch.zeros(1, 1))
+            h = [torch.zeros(1, cfg.rf_freq, cfg.rf_channels) for _ in range(cfg.rf_blocks)]
+            chunks = []
+            for idx in range(0, length + N - H, H):
+                wav_in = torch.from_numpy(wav[:, idx:idx + H])
+                spec_in, cache_stft = onnx_model.stft(wav_in, cache_stft)
+                spec_out, *h = onnx_model(spec_in, *h)
+                wav_out, cache_istft = onnx_model.stft.inverse(spec_out, cache_istft)
+                chunks.append(wav_out.numpy()[0].copy())
+        full = np.concatenate(chunks, 0)
+        s = N - H
+        out["long_length"] = np.int64(length)
+        out["long_wav_out"] = np.clip(full[s:s + length], -1.0, 1.0).astype(np.float32)
+
+    # ---- per-stage activations: only for the smallest config
+    if name == "fe_t":
+        for k in fused_ref:
+            out["fused." + k] = fused_ref[k]
+
+    path = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path, **out)
+    rms_in = float(np.sqrt((x.numpy() ** 2).mean()))
+    rms_out = float(np.sqrt((out["stream_wav_out"][4:] ** 2).mean()))
+    print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB) fold_worst={worst:.2e} "
+          f"in_rms={rms_in:.3f} out_rms={rms_out:.3f}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    for name in CONFIGS:
+        if args.only and name not in args.only:
+            continue
+        gen_fastenhancer(args.ref, name, args.out)
+
+
+if __name__ == "__main__":
+    main()
