@@ -1,0 +1,94 @@
+"""model_kwargs (yaml) -> FEConfig.  Mirrors the constructor signature of
+models/fastenhancer/default/model.py:384-403 and asserts the invariants that the
+HIP kernels specialise on (true for every shipped yaml, SURVEY.md top)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Dict, Optional, Sequence, Tuple
+
+
+@dataclass(frozen=True)
+class FEConfig:
+    channels: int = 64
+    kernel_size: Tuple[int, ...] = (8, 3, 3)
+    stride: int = 4
+    rf_blocks: int = 3
+    rf_channels: int = 32
+    rf_freq: int = 32
+    rf_heads: int = 4
+    rf_eps: float = 1e-8
+    positional_embedding: Optional[str] = "train"
+    n_fft: int = 512
+    hop_size: int = 256
+    win_size: int = 512
+    input_compression: float = 0.3
+    weight_norm: bool = False
+    normalize_final_conv: bool = False
+    pre_post_init: Optional[str] = None
+
+    @property
+    def F0(self) -> int:
+        return self.n_fft // 2
+
+    @property
+    def F1(self) -> int:
+        return self.n_fft // 2 // self.stride
+
+    @property
+    def n_layers(self) -> int:
+        return len(self.kernel_size) - 1
+
+    @property
+    def cache_len(self) -> int:
+        return self.n_fft - self.hop_size
+
+    @staticmethod
+    def from_model_kwargs(
+        channels: int = 64,
+        kernel_size: Sequence[int] = (8, 3, 3),
+        stride: int = 4,
+        rnnformer_kwargs: Optional[Dict[str, Any]] = None,
+        activation: str = "ReLU",
+        activation_kwargs: Optional[Dict[str, Any]] = None,
+        n_fft: int = 512,
+        hop_size: int = 256,
+        win_size: int = 512,
+        window: Optional[str] = "hann",
+        stft_normalized: bool = False,
+        mask: Optional[str] = None,
+        input_compression: float = 0.3,
+        weight_norm: bool = False,
+        normalize_final_conv: bool = False,
+        pre_post_init: Optional[str] = None,
+        resnet: bool = False,
+    ) -> "FEConfig":
+        rk = dict(rnnformer_kwargs or {})
+        # the reference raises / asserts on bad values (model.py:25-41,434-435; audio_modules.py:192-193);
+        # options the HIP path does not implement are rejected here instead of being silently ignored.
+        assert n_fft % 2 == 0, f"`n_fft` must be an even number, but given {n_fft}."
+        assert stft_normalized is False
+        assert n_fft >= win_size, f"n_fft({n_fft}) must be bigger than win_size({win_size})"
+        assert kernel_size[0] % stride == 0
+        assert (kernel_size[0] - stride) % 2 == 0
+        if mask is not None:
+            raise RuntimeError(f"model_kwargs.mask={mask} is not supported by the HIP path (every shipped yaml uses null).")
+        if activation != "SiLU":
+            raise RuntimeError(f"model_kwargs.activation={activation} is not supported by the HIP path (shipped: SiLU).")
+        if window != "hann":
+            raise RuntimeError(f"model_kwargs.window={window} is not supported by the HIP path (shipped: hann).")
+        if resnet:
+            raise RuntimeError("model_kwargs.resnet=True is not supported by the HIP path (shipped: False).")
+        for flag in ("attn_bias", "post_act", "pre_norm"):
+            if rk.get(flag, False):
+                raise RuntimeError(f"rnnformer_kwargs.{flag}=True is not supported by the HIP path (shipped: False).")
+        if rk.get("p_dropout", 0.0) != 0.0:
+            raise RuntimeError("dropout is a training-time option; inference path expects p_dropout=0")
+        return FEConfig(
+            channels=int(channels), kernel_size=tuple(int(k) for k in kernel_size), stride=int(stride),
+            rf_blocks=int(rk.get("num_blocks", 3)), rf_channels=int(rk.get("channels", 32)),
+            rf_freq=int(rk.get("freq", 32)), rf_heads=int(rk.get("num_heads", 4)),
+            rf_eps=float(rk.get("eps", 1e-8)), positional_embedding=rk.get("positional_embedding", "train"),
+            n_fft=int(n_fft), hop_size=int(hop_size), win_size=int(win_size),
+            input_compression=float(input_compression), weight_norm=bool(weight_norm),
+            normalize_final_conv=bool(normalize_final_conv), pre_post_init=pre_post_init,
+        )

@@ -1,0 +1,527 @@
+// fe_api.hip — C ABI (include/fastenhancer_hip.h), handle management, weight packing and
+// kernel dispatch for the FastEnhancer forward path on gfx950.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/fastenhancer_hip.h"
+#include "fe_kernels.hip.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define FE_HIP_CHECK(expr)                                                                  \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) return fail(FE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+struct Section {
+    std::string name;
+    size_t offset, count;
+    std::vector<int> shape;
+};
+
+struct Dims {
+    int C1, NL, C2, F2, KB, NFFT, HOP, F0, F1, HD;
+    int ks[FE_MAX_KERNELS];
+};
+
+// ---------------------------------------------------------------------------- dispatch table
+struct Impl {
+    int C1, NL, C2, F2, KB, NFFT, HOP;
+    size_t lds_bytes;
+    size_t dbg_floats;
+    int dbg_stages;
+    void (*launch)(const fe::FrameArgs&, bool spec_mode, hipStream_t, hipError_t*);
+    void (*dbg_stage)(int, int*, int*, size_t*);
+};
+
+template <class S>
+void launch_impl(const fe::FrameArgs& a, bool spec_mode, hipStream_t st, hipError_t* err) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fe::fe_frame_kernel<S, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)fe::Lds<S>::BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fe::fe_frame_kernel<S, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fe::Lds<S>::BYTES);
+        if (e != hipSuccess) { *err = e; return; }
+        attr_set = true;
+    }
+    dim3 grid(a.B), block(fe::kThreads);
+    if (spec_mode)
+        hipLaunchKernelGGL((fe::fe_frame_kernel<S, true>), grid, block, fe::Lds<S>::BYTES, st, a);
+    else
+        hipLaunchKernelGGL((fe::fe_frame_kernel<S, false>), grid, block, fe::Lds<S>::BYTES, st, a);
+    *err = hipGetLastError();
+}
+
+template <class S>
+void dbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
+    *rows = fe::DebugLayout<S>::rows(s);
+    *cols = fe::DebugLayout<S>::cols(s);
+    *off = fe::DebugLayout<S>::offset(s);
+}
+
+template <class S>
+Impl make_impl() {
+    return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, fe::Lds<S>::BYTES,
+                fe::DebugLayout<S>::total(), fe::DebugLayout<S>::n_stages, &launch_impl<S>, &dbg_stage_impl<S>};
+}
+
+// Shapes of the shipped yamls (configs/fastenhancer/*.yaml, configs/fastenhancer_48khz/*.yaml).
+//                      C1  NL  C2  F2 KB  NFFT  HOP
+using ShapeT   = fe::Shape<24, 2, 20, 16, 2, 512, 256>;
+using ShapeB   = fe::Shape<48, 2, 36, 24, 3, 512, 256>;
+using ShapeS   = fe::Shape<64, 3, 48, 36, 3, 512, 256>;
+using ShapeT48 = fe::Shape<24, 2, 20, 24, 2, 1024, 512>;
+using ShapeB48 = fe::Shape<48, 2, 36, 36, 3, 1024, 512>;
+
+const std::vector<Impl>& impls() {
+    static const std::vector<Impl> v = {
+        make_impl<ShapeT>(), make_impl<ShapeB>(), make_impl<ShapeS>(), make_impl<ShapeT48>(), make_impl<ShapeB48>(),
+    };
+    return v;
+}
+
+}  // namespace
+
+struct fe_handle {
+    fe_config cfg;
+    Dims d;
+    const Impl* impl = nullptr;
+    int device = 0;
+    std::vector<Section> sections;
+    size_t blob_floats = 0;
+    float* packed_dev = nullptr;
+    fe::PackedOffsets off{};
+    bool loaded = false;
+    std::vector<float> window, window_istft, twiddle;
+};
+
+namespace {
+
+void add_section(fe_handle* h, const std::string& name, std::vector<int> shape) {
+    size_t n = 1;
+    for (int s : shape) n *= (size_t)s;
+    size_t off = (h->blob_floats + 3) & ~(size_t)3;
+    h->sections.push_back(Section{name, off, n, shape});
+    h->blob_floats = off + n;
+}
+
+void build_sections(fe_handle* h) {
+    const Dims& d = h->d;
+    char nm[128];
+    add_section(h, "enc_pre.0.weight", {d.C1, 8, 2});
+    add_section(h, "enc_pre.0.bias", {d.C1});
+    for (int i = 0; i < d.NL; ++i) {
+        snprintf(nm, sizeof nm, "encoder.%d.0.weight", i); add_section(h, nm, {d.C1, d.C1, 3});
+        snprintf(nm, sizeof nm, "encoder.%d.0.bias", i); add_section(h, nm, {d.C1});
+    }
+    add_section(h, "rf_pre.0.weight", {d.F2, d.F1});
+    add_section(h, "rf_pre.1.weight", {d.C2, d.C1, 1});
+    add_section(h, "rf_pre.1.bias", {d.C2});
+    for (int k = 0; k < d.KB; ++k) {
+        auto key = [&](const char* s) { snprintf(nm, sizeof nm, "rf_block.%d.%s", k, s); return std::string(nm); };
+        if (k == 0) add_section(h, key("pe"), {d.F2, d.C2});
+        add_section(h, key("rnn.weight_ih_l0"), {3 * d.C2, d.C2});
+        add_section(h, key("rnn.weight_hh_l0"), {3 * d.C2, d.C2});
+        add_section(h, key("rnn.bias_ih_l0"), {3 * d.C2});
+        add_section(h, key("rnn.bias_hh_l0"), {3 * d.C2});
+        add_section(h, key("rnn_fc.weight"), {d.C2, d.C2});
+        add_section(h, key("rnn_fc.bias"), {d.C2});
+        add_section(h, key("attn.qkv.weight"), {3 * d.C2, d.C2});
+        add_section(h, key("attn_fc.weight"), {d.C2, d.C2});
+        add_section(h, key("attn_fc.bias"), {d.C2});
+    }
+    add_section(h, "rf_post.0.weight", {d.F1, d.F2});
+    add_section(h, "rf_post.1.weight", {d.C1, d.C2, 1});
+    add_section(h, "rf_post.1.bias", {d.C1});
+    for (int i = 0; i < d.NL; ++i) {
+        snprintf(nm, sizeof nm, "decoder.%d.0.weight", i); add_section(h, nm, {d.C1, 2 * d.C1, 1});
+        snprintf(nm, sizeof nm, "decoder.%d.0.bias", i); add_section(h, nm, {d.C1});
+        snprintf(nm, sizeof nm, "decoder.%d.2.weight", i); add_section(h, nm, {d.C1, d.C1, 3});
+        snprintf(nm, sizeof nm, "decoder.%d.2.bias", i); add_section(h, nm, {d.C1});
+    }
+    add_section(h, "dec_post.0.weight", {d.C1, 2 * d.C1, 1});
+    add_section(h, "dec_post.0.bias", {d.C1});
+    add_section(h, "dec_post.2.weight", {d.C1, 2, 8});
+    add_section(h, "dec_post.2.bias", {2});
+}
+
+// Window tables, ONNXSTFT.__init__ (functional/audio_modules.py:207-235).
+void build_tables(fe_handle* h) {
+    const int N = h->cfg.n_fft, H = h->cfg.hop_size, W = h->cfg.win_size;
+    std::vector<float> win(N, 0.0f);
+    const int pad = N - W;
+    for (int i = 0; i < W; ++i) {   // torch.hann_window(W), periodic
+        double v = 0.5 - 0.5 * std::cos(2.0 * M_PI * (double)i / (double)W);
+        win[pad / 2 + i] = (float)v;
+    }
+    const int K = (N + H - 1) / H;
+    const int L = H * (2 * K - 1) + (N - H);
+    std::vector<float> acc(L, 0.0f);
+    for (int j = 0; j < 2 * K - 1; ++j)
+        for (int n = 0; n < N; ++n) acc[j * H + n] += win[n] * win[n];
+    std::vector<float> wi(N);
+    for (int n = 0; n < N; ++n) wi[n] = win[n] / acc[(K - 1) * H + n];
+    h->window = win;
+    h->window_istft = wi;
+    h->twiddle.resize(N);   // N/2 complex
+    for (int k = 0; k < N / 2; ++k) {
+        double ang = -2.0 * M_PI * (double)k / (double)N;
+        h->twiddle[2 * k] = (float)std::cos(ang);
+        h->twiddle[2 * k + 1] = (float)std::sin(ang);
+    }
+}
+
+struct Packer {
+    std::vector<float> buf;
+    int alloc(size_t n) {
+        size_t off = (buf.size() + 63) & ~(size_t)63;   // 256-byte aligned sections
+        buf.resize(off + n, 0.0f);
+        return (int)off;
+    }
+    // B operand in fragment order: dst[(nt*KS + ks)*64 + lane] = B(k = 4ks + lane/16, n = 16nt + lane%16)
+    int pack_b(int K, int Ncols, const std::function<float(int, int)>& Bkn) {
+        const int KS = K / 4, NT = (Ncols + 15) / 16;
+        int off = alloc((size_t)NT * KS * 64);
+        for (int nt = 0; nt < NT; ++nt)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    int k = 4 * ks + lane / 16, n = 16 * nt + lane % 16;
+                    buf[off + ((size_t)nt * KS + ks) * 64 + lane] = n < Ncols ? Bkn(k, n) : 0.0f;
+                }
+        return off;
+    }
+    // A operand: dst[(mt*KS + ks)*64 + lane] = A(m = 16mt + lane%16, k = 4ks + lane/16)
+    int pack_a(int Mrows, int K, const std::function<float(int, int)>& Amk) {
+        const int KS = K / 4, MT = (Mrows + 15) / 16;
+        int off = alloc((size_t)MT * KS * 64);
+        for (int mt = 0; mt < MT; ++mt)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    int m = 16 * mt + lane % 16, k = 4 * ks + lane / 16;
+                    buf[off + ((size_t)mt * KS + ks) * 64 + lane] = m < Mrows ? Amk(m, k) : 0.0f;
+                }
+        return off;
+    }
+    int pack_bias(int n, const float* src) {
+        int np = ((n + 15) / 16) * 16;
+        int off = alloc(np);
+        for (int i = 0; i < n; ++i) buf[off + i] = src[i];
+        return off;
+    }
+    int raw(size_t n, const float* src) {
+        int off = alloc(n);
+        memcpy(&buf[off], src, n * sizeof(float));
+        return off;
+    }
+};
+
+const float* sec(const fe_handle* h, const std::vector<float>& blob, const std::string& name) {
+    for (const Section& s : h->sections)
+        if (s.name == name) return blob.data() + s.offset;
+    return nullptr;
+}
+
+int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float>* out) {
+    const Dims& d = h->d;
+    const int C1 = d.C1, C2 = d.C2, F1 = d.F1, F2 = d.F2;
+    Packer p;
+    fe::PackedOffsets& o = h->off;
+    char nm[128];
+    auto S = [&](const std::string& n) { return sec(h, blob, n); };
+
+    {   // enc_pre: weight (C1, 8, 2): B[k = t*8 + ch][n = co] = W[co][ch][t]
+        const float* w = S("enc_pre.0.weight");
+        o.enc_pre_w = p.pack_b(16, C1, [&](int k, int n) { return w[(n * 8 + (k & 7)) * 2 + (k >> 3)]; });
+        o.enc_pre_b = p.pack_bias(C1, S("enc_pre.0.bias"));
+    }
+    auto pack_k3 = [&](const float* w) {   // (Co, Ci, 3): k = tap*Ci + ci
+        return p.pack_b(3 * C1, C1, [&](int k, int n) { return w[(n * C1 + (k % C1)) * 3 + (k / C1)]; });
+    };
+    auto pack_1x1 = [&](const float* w, int Ci, int Co) {   // (Co, Ci[,1]): B[k=ci][n=co]
+        return p.pack_b(Ci, Co, [&](int k, int n) { return w[n * Ci + k]; });
+    };
+    for (int i = 0; i < d.NL; ++i) {
+        snprintf(nm, sizeof nm, "encoder.%d.0.weight", i); o.enc_w[i] = pack_k3(S(nm));
+        snprintf(nm, sizeof nm, "encoder.%d.0.bias", i); o.enc_b[i] = p.pack_bias(C1, S(nm));
+    }
+    {   // rf_pre: Linear (F2, F1) as A operand, then 1x1 conv (C2, C1)
+        const float* w = S("rf_pre.0.weight");
+        o.rfpre_lin = p.pack_a(F2, F1, [&](int m, int k) { return w[m * F1 + k]; });
+        o.rfpre_w = pack_1x1(S("rf_pre.1.weight"), C1, C2);
+        o.rfpre_b = p.pack_bias(C2, S("rf_pre.1.bias"));
+    }
+    for (int k = 0; k < d.KB; ++k) {
+        auto key = [&](const char* s) { snprintf(nm, sizeof nm, "rf_block.%d.%s", k, s); return std::string(nm); };
+        if (k == 0) o.blk_pe = p.raw((size_t)F2 * C2, S(key("pe")));
+        o.blk_wih[k] = pack_1x1(S(key("rnn.weight_ih_l0")), C2, 3 * C2);
+        o.blk_whh[k] = pack_1x1(S(key("rnn.weight_hh_l0")), C2, 3 * C2);
+        o.blk_bih[k] = p.pack_bias(3 * C2, S(key("rnn.bias_ih_l0")));
+        o.blk_bhh[k] = p.pack_bias(3 * C2, S(key("rnn.bias_hh_l0")));
+        o.blk_fc1_w[k] = pack_1x1(S(key("rnn_fc.weight")), C2, C2);
+        o.blk_fc1_b[k] = p.pack_bias(C2, S(key("rnn_fc.bias")));
+        o.blk_qkv[k] = pack_1x1(S(key("attn.qkv.weight")), C2, 3 * C2);
+        o.blk_fc2_w[k] = pack_1x1(S(key("attn_fc.weight")), C2, C2);
+        o.blk_fc2_b[k] = p.pack_bias(C2, S(key("attn_fc.bias")));
+    }
+    {
+        const float* w = S("rf_post.0.weight");   // (F1, F2)
+        o.rfpost_lin = p.pack_a(F1, F2, [&](int m, int k) { return w[m * F2 + k]; });
+        o.rfpost_w = pack_1x1(S("rf_post.1.weight"), C2, C1);
+        o.rfpost_b = p.pack_bias(C1, S("rf_post.1.bias"));
+    }
+    for (int i = 0; i < d.NL; ++i) {
+        snprintf(nm, sizeof nm, "decoder.%d.0.weight", i); o.dec1_w[i] = pack_1x1(S(nm), 2 * C1, C1);
+        snprintf(nm, sizeof nm, "decoder.%d.0.bias", i); o.dec1_b[i] = p.pack_bias(C1, S(nm));
+        snprintf(nm, sizeof nm, "decoder.%d.2.weight", i); o.dec3_w[i] = pack_k3(S(nm));
+        snprintf(nm, sizeof nm, "decoder.%d.2.bias", i); o.dec3_b[i] = p.pack_bias(C1, S(nm));
+    }
+    o.post1_w = pack_1x1(S("dec_post.0.weight"), 2 * C1, C1);
+    o.post1_b = p.pack_bias(C1, S("dec_post.0.bias"));
+    {   // transposed conv weight (C1, 2, 8): B[k = ci][n = co*8 + j]
+        const float* w = S("dec_post.2.weight");
+        o.post_t_w = p.pack_b(C1, 16, [&](int k, int n) { return w[k * 16 + n]; });
+        o.post_t_b = p.pack_bias(2, S("dec_post.2.bias"));
+    }
+    o.window = p.raw(h->window.size(), h->window.data());
+    o.window_istft = p.raw(h->window_istft.size(), h->window_istft.data());
+    o.twiddle = p.raw(h->twiddle.size(), h->twiddle.data());
+    o.total = (int)p.buf.size();
+    *out = std::move(p.buf);
+    return FE_OK;
+}
+
+int check_ready(const fe_handle* h) {
+    if (!h) return fail(FE_ERR_INVALID_ARG, "null handle");
+    if (!h->loaded) return fail(FE_ERR_NO_WEIGHTS, "fe_load_weights has not been called");
+    return FE_OK;
+}
+
+fe::FrameArgs base_args(fe_handle* h, int B, int T) {
+    fe::FrameArgs a{};
+    a.wp = h->packed_dev;
+    a.off = h->off;
+    a.B = B;
+    a.T = T;
+    a.compression = h->cfg.input_compression;
+    return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fe_last_error(void) { return g_err.c_str(); }
+const char* fe_version(void) { return "fastenhancer_hip 0.1 (gfx950)"; }
+
+int fe_create(const fe_config* cfg, fe_handle** out) {
+    if (!cfg || !out) return fail(FE_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->arch != FE_ARCH_FASTENHANCER)
+        return fail(FE_ERR_UNSUPPORTED_CONFIG, "arch %d is not built into this library", cfg->arch);
+    if (cfg->n_fft % 2 != 0) return fail(FE_ERR_INVALID_ARG, "`n_fft` must be an even number, but given %d.", cfg->n_fft);
+    if (cfg->win_size > cfg->n_fft) return fail(FE_ERR_INVALID_ARG, "n_fft(%d) must be bigger than win_size(%d)", cfg->n_fft, cfg->win_size);
+    if (cfg->hop_size <= 0 || cfg->hop_size > cfg->n_fft) return fail(FE_ERR_INVALID_ARG, "hop_size %d out of range", cfg->hop_size);
+    if (cfg->stride != 4) return fail(FE_ERR_UNSUPPORTED_CONFIG, "stride %d (every shipped config uses 4)", cfg->stride);
+    if (cfg->n_kernels < 2 || cfg->n_kernels > FE_MAX_KERNELS) return fail(FE_ERR_INVALID_ARG, "len(kernel_size)=%d", cfg->n_kernels);
+    if (cfg->kernel_size[0] != 8) return fail(FE_ERR_UNSUPPORTED_CONFIG, "kernel_size[0]=%d (shipped: 8)", cfg->kernel_size[0]);
+    for (int i = 1; i < cfg->n_kernels; ++i)
+        if (cfg->kernel_size[i] != 3) return fail(FE_ERR_UNSUPPORTED_CONFIG, "kernel_size[%d]=%d (shipped: 3)", i, cfg->kernel_size[i]);
+    if (cfg->rf_heads != 4) return fail(FE_ERR_UNSUPPORTED_CONFIG, "num_heads=%d (shipped: 4)", cfg->rf_heads);
+    if (!(cfg->input_compression > 0.0f && cfg->input_compression <= 1.0f)) return fail(FE_ERR_INVALID_ARG, "input_compression");
+
+    const Impl* impl = nullptr;
+    for (const Impl& im : impls())
+        if (im.C1 == cfg->channels && im.NL == cfg->n_kernels - 1 && im.C2 == cfg->rf_channels && im.F2 == cfg->rf_freq &&
+            im.KB == cfg->rf_blocks && im.NFFT == cfg->n_fft && im.HOP == cfg->hop_size)
+            impl = &im;
+    if (!impl)
+        return fail(FE_ERR_UNSUPPORTED_CONFIG,
+                    "no kernel compiled for channels=%d layers=%d rf_channels=%d rf_freq=%d rf_blocks=%d n_fft=%d hop=%d",
+                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size);
+    fe_handle* h = new fe_handle();
+    h->cfg = *cfg;
+    h->impl = impl;
+    h->d = Dims{impl->C1, impl->NL, impl->C2, impl->F2, impl->KB, impl->NFFT, impl->HOP, impl->NFFT / 2, impl->NFFT / 8, impl->C2 / 4, {0}};
+    for (int i = 0; i < cfg->n_kernels; ++i) h->d.ks[i] = cfg->kernel_size[i];
+    if (hipGetDevice(&h->device) != hipSuccess) h->device = -1;   // no GPU: sections/tables still usable
+    build_sections(h);
+    build_tables(h);
+    *out = h;
+    return FE_OK;
+}
+
+void fe_destroy(fe_handle* h) {
+    if (!h) return;
+    if (h->packed_dev) (void)hipFree(h->packed_dev);
+    delete h;
+}
+
+size_t fe_weight_floats(const fe_handle* h) { return h ? h->blob_floats : 0; }
+int fe_weight_sections(const fe_handle* h) { return h ? (int)h->sections.size() : 0; }
+
+int fe_weight_section(const fe_handle* h, int idx, const char** name, size_t* offset_floats, size_t* count_floats) {
+    if (!h || idx < 0 || idx >= (int)h->sections.size()) return fail(FE_ERR_INVALID_ARG, "section index %d", idx);
+    if (name) *name = h->sections[idx].name.c_str();
+    if (offset_floats) *offset_floats = h->sections[idx].offset;
+    if (count_floats) *count_floats = h->sections[idx].count;
+    return FE_OK;
+}
+
+int fe_load_weights(fe_handle* h, const float* blob_dev, size_t nfloats, void* stream) {
+    if (!h || !blob_dev) return fail(FE_ERR_INVALID_ARG, "null argument");
+    if (nfloats != h->blob_floats) return fail(FE_ERR_INVALID_ARG, "blob has %zu floats, expected %zu", nfloats, h->blob_floats);
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<float> blob(nfloats);
+    FE_HIP_CHECK(hipMemcpyAsync(blob.data(), blob_dev, nfloats * sizeof(float), hipMemcpyDeviceToHost, st));
+    FE_HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<float> packed;
+    int rc = pack_weights(h, blob, &packed);
+    if (rc != FE_OK) return rc;
+    if (h->packed_dev) { FE_HIP_CHECK(hipFree(h->packed_dev)); h->packed_dev = nullptr; }
+    FE_HIP_CHECK(hipMalloc(&h->packed_dev, packed.size() * sizeof(float)));
+    FE_HIP_CHECK(hipMemcpyAsync(h->packed_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    FE_HIP_CHECK(hipStreamSynchronize(st));
+    h->loaded = true;
+    return FE_OK;
+}
+
+size_t fe_state_floats(const fe_handle* h, int B) {
+    if (!h || B <= 0) return 0;
+    const Dims& d = h->d;
+    return (size_t)B * (2 * (size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2);
+}
+
+int fe_state_init(fe_handle* h, float* state_dev, int B, void* stream) {
+    if (!h || !state_dev || B <= 0) return fail(FE_ERR_INVALID_ARG, "bad argument");
+    FE_HIP_CHECK(hipMemsetAsync(state_dev, 0, fe_state_floats(h, B) * sizeof(float), (hipStream_t)stream));
+    return FE_OK;
+}
+
+static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* state, float* wav_out, size_t out_stride,
+                    int B, int T, float* dbg, void* stream) {
+    int rc = check_ready(h);
+    if (rc != FE_OK) return rc;
+    if (!wav_in || !state || !wav_out || B <= 0 || T <= 0) return fail(FE_ERR_INVALID_ARG, "bad argument");
+    const Dims& d = h->d;
+    if (in_stride < (size_t)T * d.HOP && B > 1) return fail(FE_ERR_INVALID_ARG, "in_stride %zu < T*H", in_stride);
+    if (out_stride < (size_t)T * d.HOP && B > 1) return fail(FE_ERR_INVALID_ARG, "out_stride %zu < T*H", out_stride);
+    fe::FrameArgs a = base_args(h, B, T);
+    const size_t ovl = (size_t)(d.NFFT - d.HOP);
+    a.wav_in = wav_in;
+    a.wav_out = wav_out;
+    a.in_stride = in_stride;
+    a.out_stride = out_stride;
+    a.cache_stft = state;
+    a.cache_istft = state + (size_t)B * ovl;
+    a.h = state + 2 * (size_t)B * ovl;
+    a.dbg = dbg;
+    a.dbg_stride = h->impl->dbg_floats;
+    hipError_t e = hipSuccess;
+    h->impl->launch(a, false, (hipStream_t)stream, &e);
+    if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return FE_OK;
+}
+
+int fe_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, float* state_dev, float* wav_out_dev, size_t out_stride,
+            int B, int T, void* stream) {
+    return run_step(h, wav_in_dev, in_stride, state_dev, wav_out_dev, out_stride, B, T, nullptr, stream);
+}
+
+int fe_debug_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, float* state_dev, float* wav_out_dev,
+                  size_t out_stride, int B, float* dbg_dev, void* stream) {
+    if (!dbg_dev) return fail(FE_ERR_INVALID_ARG, "null dbg buffer");
+    return run_step(h, wav_in_dev, in_stride, state_dev, wav_out_dev, out_stride, B, 1, dbg_dev, stream);
+}
+
+int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* spec_out_dev, int B, int T, void* stream) {
+    int rc = check_ready(h);
+    if (rc != FE_OK) return rc;
+    if (!spec_in_dev || !h_dev || !spec_out_dev || B <= 0 || T <= 0) return fail(FE_ERR_INVALID_ARG, "bad argument");
+    fe::FrameArgs a = base_args(h, B, T);
+    a.spec_in = spec_in_dev;
+    a.spec_out = spec_out_dev;
+    a.h = h_dev;
+    hipError_t e = hipSuccess;
+    h->impl->launch(a, true, (hipStream_t)stream, &e);
+    if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return FE_OK;
+}
+
+size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw) {
+    (void)h; (void)B; (void)Tw;
+    return 0;
+}
+
+int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_hat_dev, float* spec_hat_dev, float* work_dev,
+               void* stream) {
+    (void)h; (void)noisy_dev; (void)B; (void)Tw; (void)wav_hat_dev; (void)spec_hat_dev; (void)work_dev; (void)stream;
+    return fail(FE_ERR_UNSUPPORTED_CONFIG, "fe_offline: not built yet");
+}
+
+double fe_flops_per_frame(const fe_handle* h) {
+    if (!h) return 0.0;
+    const Dims& d = h->d;
+    const double C1 = d.C1, C2 = d.C2, F1 = d.F1, F2 = d.F2, K = d.KB;
+    double m = 2 * C1 * 8 * F1;
+    for (int i = 1; i <= d.NL; ++i) m += C1 * C1 * 3 * F1;
+    m += F1 * F2 * C1 + C1 * C2 * F2;
+    m += K * (C2 * C2 * 6 * F2 + C2 * C2 * F2 + C2 * C2 * 3 * F2 + 2 * F2 * C2 * F2 + C2 * C2 * F2);
+    m += F2 * F1 * C2 + C2 * C1 * F1;
+    for (int i = 1; i <= d.NL; ++i) m += 2 * C1 * C1 * F1 + C1 * C1 * 3 * F1;
+    m += 2 * C1 * C1 * F1 + C1 * 2 * 8 * F1;
+    return 2.0 * m + 2.0 * 2.5 * d.NFFT * std::log2((double)d.NFFT);
+}
+
+int fe_debug_stages(const fe_handle* h) { return h ? h->impl->dbg_stages : 0; }
+size_t fe_debug_floats(const fe_handle* h) { return h ? h->impl->dbg_floats : 0; }
+
+int fe_debug_stage(const fe_handle* h, int idx, const char** name, int* rows, int* cols, size_t* offset_floats) {
+    if (!h || idx < 0 || idx >= h->impl->dbg_stages) return fail(FE_ERR_INVALID_ARG, "stage index %d", idx);
+    static thread_local std::string nm;
+    const Dims& d = h->d;
+    char buf[64];
+    int s = idx;
+    if (s == 0) nm = "spec_in";
+    else if (s == 1) nm = "compressed";
+    else if (s == 2) nm = "enc_pre";
+    else if (s < 3 + d.NL) { snprintf(buf, sizeof buf, "encoder.%d", s - 3); nm = buf; }
+    else if (s == 3 + d.NL) nm = "rf_pre";
+    else if (s < 4 + d.NL + 2 * d.KB) {
+        int k = (s - 4 - d.NL) / 2, w = (s - 4 - d.NL) % 2;
+        snprintf(buf, sizeof buf, w == 0 ? "rf_block.%d.rnn" : "rf_block.%d", k); nm = buf;
+    } else if (s == 4 + d.NL + 2 * d.KB) nm = "rf_post";
+    else if (s < 5 + 2 * d.NL + 2 * d.KB) { snprintf(buf, sizeof buf, "decoder.%d", s - 5 - d.NL - 2 * d.KB); nm = buf; }
+    else if (s == 5 + 2 * d.NL + 2 * d.KB) nm = "mask";
+    else nm = "spec_out";
+    int r, c; size_t off;
+    h->impl->dbg_stage(idx, &r, &c, &off);
+    if (name) *name = nm.c_str();
+    if (rows) *rows = r;
+    if (cols) *cols = c;
+    if (offset_floats) *offset_floats = off;
+    return FE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,169 @@
+"""Engine: one fe_handle (C ABI) on one GPU + torch-tensor convenience around it.
+
+PyTorch is used for device memory and streams only; all arithmetic of the path
+runs in libfastenhancer_hip.so."""
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref, c_char_p, c_int, c_size_t, c_void_p
+from typing import Dict, List, Mapping, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from .config import FEConfig
+from .weights import check_fused, fold_state_dict
+
+
+def _ptr(t: Optional[Tensor]) -> c_void_p:
+    return c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream(device: torch.device) -> c_void_p:
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Engine:
+    """Owns the native handle for one model shape on one device."""
+
+    def __init__(self, cfg: FEConfig, device: Optional[torch.device] = None):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device) if device is not None else None
+        c = _lib.fe_config()
+        c.arch = _lib.FE_ARCH_FASTENHANCER
+        c.n_fft, c.hop_size, c.win_size = cfg.n_fft, cfg.hop_size, cfg.win_size
+        c.channels = cfg.channels
+        c.n_kernels = len(cfg.kernel_size)
+        for i, k in enumerate(cfg.kernel_size):
+            c.kernel_size[i] = k
+        c.stride = cfg.stride
+        c.rf_channels, c.rf_freq, c.rf_blocks, c.rf_heads = cfg.rf_channels, cfg.rf_freq, cfg.rf_blocks, cfg.rf_heads
+        c.input_compression = cfg.input_compression
+        self._h = c_void_p()
+        if self.device is not None and self.device.type == "cuda":
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.fe_create(byref(c), byref(self._h)), "fe_create")
+        else:
+            _lib.check(self.lib.fe_create(byref(c), byref(self._h)), "fe_create")
+        self.weight_floats = int(self.lib.fe_weight_floats(self._h))
+        self.sections = self._read_sections()
+        self.flops_per_frame = float(self.lib.fe_flops_per_frame(self._h))
+        self.loaded = False
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                self.lib.fe_destroy(h)
+            except Exception:
+                pass
+            self._h = c_void_p()
+
+    # ------------------------------------------------------------------ weights
+    def _read_sections(self) -> List[Tuple[str, int, int]]:
+        out = []
+        for i in range(self.lib.fe_weight_sections(self._h)):
+            name, off, cnt = c_char_p(), c_size_t(), c_size_t()
+            _lib.check(self.lib.fe_weight_section(self._h, i, byref(name), byref(off), byref(cnt)), "fe_weight_section")
+            out.append((name.value.decode(), int(off.value), int(cnt.value)))
+        return out
+
+    def make_blob(self, state_dict: Mapping[str, Tensor], strict: bool = True) -> Tensor:
+        """reference checkpoint (training or fused form) -> flat fp32 blob on the CPU."""
+        fused = fold_state_dict(state_dict, self.cfg)
+        check_fused(fused, self.cfg, strict=strict)
+        blob = torch.zeros(self.weight_floats, dtype=torch.float32)
+        for name, off, cnt in self.sections:
+            t = fused[name].contiguous().reshape(-1)
+            assert t.numel() == cnt, (name, t.numel(), cnt)
+            blob[off:off + cnt] = t
+        return blob
+
+    def load_blob(self, blob_dev: Tensor):
+        self._require_gpu()
+        assert blob_dev.is_cuda and blob_dev.dtype == torch.float32 and blob_dev.is_contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fe_load_weights(self._h, _ptr(blob_dev), blob_dev.numel(), _stream(self.device)), "fe_load_weights")
+        self.loaded = True
+
+    def load_state_dict(self, state_dict: Mapping[str, Tensor], strict: bool = True):
+        blob = self.make_blob(state_dict, strict=strict)
+        self.load_blob(blob.to(self.device))
+
+    # ------------------------------------------------------------------ state
+    def _require_gpu(self):
+        if self.device is None or self.device.type != "cuda" or not torch.cuda.is_available():
+            raise _lib.FEError("the FastEnhancer HIP path needs a GPU device (no CPU fallback); got device=%r" % (self.device,))
+
+    def state_floats(self, B: int) -> int:
+        return int(self.lib.fe_state_floats(self._h, B))
+
+    def new_state(self, B: int) -> Tensor:
+        self._require_gpu()
+        return torch.zeros(self.state_floats(B), dtype=torch.float32, device=self.device)
+
+    def split_state(self, state: Tensor, B: int) -> List[Tensor]:
+        """Views of the opaque state as the reference cache list
+        [cache_stft [B,N-H], cache_istft [B,N-H], K x h [1,B*F2,C2]] (scripts/export_onnx.py:43-46)."""
+        c = self.cfg
+        L = c.cache_len
+        out = [state[:B * L].view(B, L), state[B * L:2 * B * L].view(B, L)]
+        o = 2 * B * L
+        n = B * c.rf_freq * c.rf_channels
+        for _ in range(c.rf_blocks):
+            out.append(state[o:o + n].view(1, B * c.rf_freq, c.rf_channels))
+            o += n
+        return out
+
+    def pack_state(self, caches: List[Tensor], B: int) -> Tensor:
+        return torch.cat([t.reshape(-1).to(torch.float32) for t in caches]).contiguous()
+
+    # ------------------------------------------------------------------ compute
+    def step(self, wav_in: Tensor, state: Tensor, wav_out: Optional[Tensor] = None, T: int = 1) -> Tensor:
+        """wav_in [B, T*H] (row stride free) -> wav_out [B, T*H]; state updated in place."""
+        self._require_gpu()
+        B = wav_in.shape[0]
+        H = self.cfg.hop_size
+        assert wav_in.is_cuda and wav_in.dtype == torch.float32 and wav_in.stride(1) == 1 and wav_in.shape[1] == T * H
+        assert state.numel() == self.state_floats(B) and state.is_contiguous()
+        if wav_out is None:
+            wav_out = torch.empty(B, T * H, dtype=torch.float32, device=wav_in.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fe_step(self._h, _ptr(wav_in), wav_in.stride(0) if B > 1 else T * H, _ptr(state), _ptr(wav_out),
+                                        wav_out.stride(0) if B > 1 else T * H, B, T, _stream(self.device)), "fe_step")
+        return wav_out
+
+    def spec_step(self, spec: Tensor, h: Tensor) -> Tensor:
+        """spec [B, N/2+1, T, 2], h [K, B*F2, C2] (in place) -> spec_hat [B, N/2+1, T, 2]."""
+        self._require_gpu()
+        B, Fb, T, two = spec.shape
+        assert Fb == self.cfg.F0 + 1 and two == 2 and spec.is_contiguous() and h.is_contiguous()
+        out = torch.empty_like(spec)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fe_spec_step(self._h, _ptr(spec), _ptr(h), _ptr(out), B, T, _stream(self.device)), "fe_spec_step")
+        return out
+
+    def debug_stages(self) -> List[Tuple[str, int, int, int]]:
+        out = []
+        for i in range(self.lib.fe_debug_stages(self._h)):
+            name, r, c, off = c_char_p(), c_int(), c_int(), c_size_t()
+            _lib.check(self.lib.fe_debug_stage(self._h, i, byref(name), byref(r), byref(c), byref(off)), "fe_debug_stage")
+            out.append((name.value.decode(), r.value, c.value, int(off.value)))
+        return out
+
+    def debug_step(self, wav_in: Tensor, state: Tensor) -> Tuple[Tensor, Dict[str, Tensor]]:
+        self._require_gpu()
+        B = wav_in.shape[0]
+        H = self.cfg.hop_size
+        n = int(self.lib.fe_debug_floats(self._h))
+        dbg = torch.zeros(B, n, dtype=torch.float32, device=wav_in.device)
+        wav_out = torch.empty(B, H, dtype=torch.float32, device=wav_in.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fe_debug_step(self._h, _ptr(wav_in), wav_in.stride(0), _ptr(state), _ptr(wav_out), H, B,
+                                              _ptr(dbg), _stream(self.device)), "fe_debug_step")
+        taps = {}
+        for name, r, c, off in self.debug_stages():
+            taps[name] = dbg[:, off:off + r * c].view(B, r, c)
+        return wav_out, taps

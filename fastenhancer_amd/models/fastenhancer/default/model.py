@@ -1,0 +1,126 @@
+"""Host-side mirror of ``models.fastenhancer.default.model`` of the reference
+(models/fastenhancer/default/model.py): the classes ``ONNXModel`` (streaming,
+spec -> spec, caches threaded by the caller) and ``Model`` (offline wav -> wav),
+constructed from the yaml ``model_kwargs`` verbatim, e.g.
+
+    module = importlib.import_module(f"fastenhancer_amd.models.{hps.model}.model")
+    model = module.ONNXModel(**hps.model_kwargs)            # scripts/export_onnx.py:32-35
+    model.load_state_dict(ckpt["model"], strict=True)       # wrappers/ns.py:313
+    model.remove_weight_reparameterizations()               # scripts/export_onnx.py:78
+
+All arithmetic runs in libfastenhancer_hip.so on the GPU the model was moved to;
+these classes only hold the checkpoint and marshal torch tensors across the C ABI.
+They are inference-only (``.eval()``; no autograd, no training forward)."""
+from __future__ import annotations
+
+import typing as tp
+
+import torch
+from torch import Tensor
+
+from ....config import FEConfig
+from ....engine import Engine
+from ....weights import default_state_dict, fold_state_dict
+
+
+class STFTCaches:
+    """The ``.stft`` attribute of ONNXModel: ONNXSTFT.initialize_cache
+    (functional/audio_modules.py:238-241).  forward / inverse of the streaming STFT are fused
+    into the wav -> wav step (fastenhancer_amd/streaming.py), they are not separate launches."""
+
+    def __init__(self, cfg: FEConfig):
+        self.n_fft, self.hop_size, self.cache_len = cfg.n_fft, cfg.hop_size, cfg.cache_len
+
+    def initialize_cache(self, x: Tensor) -> tp.List[Tensor]:
+        return [torch.zeros(x.size(0), self.cache_len, dtype=torch.float32, device=x.device) for _ in range(2)]
+
+
+class ONNXModel:
+    def __init__(self, **model_kwargs):
+        self.cfg = FEConfig.from_model_kwargs(**model_kwargs)
+        self.input_compression = self.cfg.input_compression
+        self.rf_ch, self.rf_freq = self.cfg.rf_channels, self.cfg.rf_freq
+        self.stft = STFTCaches(self.cfg)
+        self.device = torch.device("cpu")
+        self._sd: tp.Dict[str, Tensor] = default_state_dict(self.cfg)
+        self._engine: tp.Optional[Engine] = None
+        self.training = False
+
+    # ---- nn.Module-like plumbing -----------------------------------------------------------
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise RuntimeError("fastenhancer_amd models are inference-only")
+        return self
+
+    def to(self, device):
+        self.device = torch.device(device)
+        self._engine = None
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    def state_dict(self) -> tp.Dict[str, Tensor]:
+        return dict(self._sd)
+
+    def load_state_dict(self, state_dict: tp.Mapping[str, Tensor], strict: bool = True):
+        from ....weights import check_fused
+        fused = fold_state_dict(state_dict, self.cfg)
+        check_fused(fused, self.cfg, strict=strict)
+        self._sd = {k: torch.as_tensor(v).detach().clone() for k, v in state_dict.items()}
+        self._engine = None
+        return self
+
+    def remove_weight_reparameterizations(self):
+        """model.py:532-608.  Folding happens when the blob is built; make it visible in state_dict()."""
+        self._sd = fold_state_dict(self._sd, self.cfg)
+
+    def flatten_parameters(self):
+        pass
+
+    def parameters(self):
+        return iter(self._sd.values())
+
+    @property
+    def engine(self) -> Engine:
+        if self._engine is None:
+            eng = Engine(self.cfg, self.device)
+            eng.load_state_dict(self._sd)     # raises without a GPU: no CPU fallback
+            self._engine = eng
+        return self._engine
+
+    # ---- reference API ---------------------------------------------------------------------
+    def initialize_cache(self, x: Tensor) -> tp.List[Tensor]:
+        """model.py:614-618, sized for the B = x.size(0) streams of the batch (b-major)."""
+        B = x.size(0)
+        return [torch.zeros(1, B * self.rf_freq, self.rf_ch, dtype=torch.float32, device=x.device)
+                for _ in range(self.cfg.rf_blocks)]
+
+    def forward(self, spec_noisy: Tensor, *args: Tensor):
+        """input/output: [B, n_fft//2+1, T_spec, 2]; returns (spec_hat, *cache_out)  (model.py:677-710).
+        Functional like the reference: the caches passed in are not modified."""
+        B = spec_noisy.size(0)
+        cfg = self.cfg
+        if len(args) == 0:
+            h = torch.zeros(cfg.rf_blocks, B * cfg.rf_freq, cfg.rf_channels, dtype=torch.float32, device=spec_noisy.device)
+        else:
+            assert len(args) == cfg.rf_blocks, f"expected {cfg.rf_blocks} caches, got {len(args)}"
+            h = torch.cat([c.reshape(1, B * cfg.rf_freq, cfg.rf_channels) for c in args], dim=0).contiguous().float()
+        spec_hat = self.engine.spec_step(spec_noisy.contiguous().float(), h)
+        return (spec_hat, *[h[k:k + 1] for k in range(cfg.rf_blocks)])
+
+    __call__ = forward
+
+
+class Model(ONNXModel):
+    """Offline wav -> wav model (model.py:713-735): forward(noisy [B, T_wav]) -> (wav_hat, spec_hat)."""
+
+    def forward(self, noisy: Tensor):
+        from ....offline import offline_forward
+        return offline_forward(self, noisy)
+
+    __call__ = forward

@@ -1,0 +1,202 @@
+"""Deployment transform on the host: reference checkpoint -> fused fp32 weight blob.
+
+Restates ONNXModel.remove_weight_reparameterizations
+(models/fastenhancer/default/model.py:532-608; RNNFormerBlock :215-231;
+ScaledConvTranspose1d :74-81): weight-norm removal, BatchNorm folding into the
+adjacent conv / linear, and baking scale/normalisation into the final transposed
+conv.  Accepts the training-form state_dict written by wrappers/ns.py:323-336
+(``checkpoint["model"]``) or an already fused one.  The result is laid out into
+the flat blob whose section table the C library reports (fe_weight_section), which
+is also what is broadcast over RCCL in multi-GPU runs.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Mapping, Optional
+
+import torch
+from torch import Tensor
+
+from .config import FEConfig
+
+BN_EPS = 1e-5  # nn.BatchNorm1d default, used by every conv BN of the reference
+
+
+def _f32(t) -> Tensor:
+    return torch.as_tensor(t).detach().to(device="cpu", dtype=torch.float32)
+
+
+def is_fused(sd: Mapping[str, Tensor]) -> bool:
+    return "enc_pre.0.bias" in sd
+
+
+def _weight_norm(g: Tensor, v: Tensor) -> Tensor:
+    # torch.nn.utils.parametrizations.weight_norm, dim=0: w = g * v / ||v|| (norm over all dims but 0)
+    norm = v.reshape(v.shape[0], -1).norm(dim=1).reshape([-1] + [1] * (v.dim() - 1))
+    return v * (g.reshape(norm.shape) / norm)
+
+
+def fold_state_dict(sd: Mapping[str, Tensor], cfg: FEConfig) -> Dict[str, Tensor]:
+    """Training-form -> fused-form state_dict (keys of SURVEY.md Appendix A.1 'Fused')."""
+    sd = {k: _f32(v) for k, v in sd.items() if torch.as_tensor(v).is_floating_point()}
+    if is_fused(sd):
+        return dict(sd)
+    out: Dict[str, Tensor] = {}
+
+    def conv_bn(conv: str, bn: str, dst: str):
+        # model.py:548-553: W' = W * gamma/std, b' = beta - mean*gamma/std
+        std = (sd[bn + ".running_var"] + BN_EPS).sqrt()
+        out[dst + ".weight"] = sd[conv + ".weight"] * (sd[bn + ".weight"] / std).view(-1, 1, 1)
+        out[dst + ".bias"] = sd[bn + ".bias"] - sd[bn + ".running_mean"] * sd[bn + ".weight"] / std
+
+    conv_bn("enc_pre.0", "enc_pre.1", "enc_pre.0")
+    for i in range(cfg.n_layers):
+        conv_bn(f"encoder.{i}.0", f"encoder.{i}.1", f"encoder.{i}.0")
+    out["rf_pre.0.weight"] = sd["rf_pre.0.weight"]
+    conv_bn("rf_pre.1", "rf_pre.2", "rf_pre.1")
+    for k in range(cfg.rf_blocks):
+        p = f"rf_block.{k}."
+        if p + "pe" in sd:
+            out[p + "pe"] = sd[p + "pe"]
+        for name in ("weight_ih_l0", "weight_hh_l0"):
+            g = p + f"rnn.parametrizations.{name}.original0"
+            if g in sd:
+                out[p + "rnn." + name] = _weight_norm(sd[g], sd[p + f"rnn.parametrizations.{name}.original1"])
+            else:
+                out[p + "rnn." + name] = sd[p + "rnn." + name]
+        out[p + "rnn.bias_ih_l0"] = sd[p + "rnn.bias_ih_l0"]
+        out[p + "rnn.bias_hh_l0"] = sd[p + "rnn.bias_hh_l0"]
+        g = p + "attn.qkv.parametrizations.weight.original0"
+        if g in sd:
+            out[p + "attn.qkv.weight"] = _weight_norm(sd[g], sd[p + "attn.qkv.parametrizations.weight.original1"])
+        else:
+            out[p + "attn.qkv.weight"] = sd[p + "attn.qkv.weight"]
+        for fc, norm in (("rnn_fc", "rnn_post_norm"), ("attn_fc", "attn_post_norm")):   # model.py:223-229
+            std = (sd[p + norm + ".running_var"] + cfg.rf_eps).sqrt()
+            out[p + fc + ".weight"] = sd[p + fc + ".weight"] * (sd[p + norm + ".weight"] / std).view(-1, 1)
+            out[p + fc + ".bias"] = sd[p + norm + ".bias"] - sd[p + norm + ".running_mean"] * sd[p + norm + ".weight"] / std
+    out["rf_post.0.weight"] = sd["rf_post.0.weight"]
+    conv_bn("rf_post.1", "rf_post.2", "rf_post.1")
+    for i in range(cfg.n_layers):
+        conv_bn(f"decoder.{i}.0", f"decoder.{i}.1", f"decoder.{i}.0")
+        conv_bn(f"decoder.{i}.3", f"decoder.{i}.4", f"decoder.{i}.2")
+    conv_bn("dec_post.0", "dec_post.1", "dec_post.0")
+    w = sd["dec_post.3.weight"]
+    scale = sd.get("dec_post.3.scale", torch.ones(1))
+    if cfg.normalize_final_conv:   # F.normalize(w, dim=(0,1,2)) * scale, model.py:74-79
+        w = w / w.norm().clamp_min(1e-12)
+    out["dec_post.2.weight"] = w * scale
+    out["dec_post.2.bias"] = sd["dec_post.3.bias"]
+    return out
+
+
+def expected_fused_shapes(cfg: FEConfig) -> Dict[str, tuple]:
+    C1, C2, F1, F2 = cfg.channels, cfg.rf_channels, cfg.F1, cfg.rf_freq
+    s: Dict[str, tuple] = {"enc_pre.0.weight": (C1, 2 * cfg.stride, cfg.kernel_size[0] // cfg.stride), "enc_pre.0.bias": (C1,)}
+    for i in range(cfg.n_layers):
+        s[f"encoder.{i}.0.weight"] = (C1, C1, cfg.kernel_size[i + 1])
+        s[f"encoder.{i}.0.bias"] = (C1,)
+    s["rf_pre.0.weight"] = (F2, F1)
+    s["rf_pre.1.weight"] = (C2, C1, 1)
+    s["rf_pre.1.bias"] = (C2,)
+    for k in range(cfg.rf_blocks):
+        p = f"rf_block.{k}."
+        if k == 0:
+            s[p + "pe"] = (F2, C2)
+        s[p + "rnn.weight_ih_l0"] = (3 * C2, C2)
+        s[p + "rnn.weight_hh_l0"] = (3 * C2, C2)
+        s[p + "rnn.bias_ih_l0"] = (3 * C2,)
+        s[p + "rnn.bias_hh_l0"] = (3 * C2,)
+        s[p + "rnn_fc.weight"] = (C2, C2)
+        s[p + "rnn_fc.bias"] = (C2,)
+        s[p + "attn.qkv.weight"] = (3 * C2, C2)
+        s[p + "attn_fc.weight"] = (C2, C2)
+        s[p + "attn_fc.bias"] = (C2,)
+    s["rf_post.0.weight"] = (F1, F2)
+    s["rf_post.1.weight"] = (C1, C2, 1)
+    s["rf_post.1.bias"] = (C1,)
+    for i in range(cfg.n_layers):
+        s[f"decoder.{i}.0.weight"] = (C1, 2 * C1, 1)
+        s[f"decoder.{i}.0.bias"] = (C1,)
+        s[f"decoder.{i}.2.weight"] = (C1, C1, cfg.kernel_size[cfg.n_layers - i])
+        s[f"decoder.{i}.2.bias"] = (C1,)
+    s["dec_post.0.weight"] = (C1, 2 * C1, 1)
+    s["dec_post.0.bias"] = (C1,)
+    s["dec_post.2.weight"] = (C1, 2, cfg.kernel_size[0])
+    s["dec_post.2.bias"] = (2,)
+    return s
+
+
+def check_fused(fused: Mapping[str, Tensor], cfg: FEConfig, strict: bool = True):
+    """load_state_dict(strict=True) semantics (wrappers/ns.py:313): missing / unexpected keys and
+    shape mismatches raise RuntimeError."""
+    exp = expected_fused_shapes(cfg)
+    missing = [k for k in exp if k not in fused]
+    unexpected = [k for k in fused if k not in exp]
+    errs = []
+    if missing:
+        errs.append("Missing key(s) in state_dict: " + ", ".join(missing))
+    if unexpected and strict:
+        errs.append("Unexpected key(s) in state_dict: " + ", ".join(unexpected))
+    for k, shp in exp.items():
+        if k in fused and tuple(fused[k].shape) != tuple(shp):
+            errs.append(f"size mismatch for {k}: checkpoint {tuple(fused[k].shape)} vs model {tuple(shp)}")
+    if errs:
+        raise RuntimeError("Error(s) in loading state_dict:\n\t" + "\n\t".join(errs))
+
+
+# ---------------------------------------------------------------- default initialisation
+def linear_filterbank(n_freq: int, n_filter: int):
+    """rf_pre_post_lin(init='linear*'), models/fastenhancer/default/model.py:308-380."""
+    delta = (n_freq - 1) / (n_filter - 1)
+    f_filter = torch.linspace(0, n_freq - 1, n_filter)
+    f_freqs = torch.linspace(0, n_freq - 1, n_freq)
+    down = (f_filter[1:, None] - f_freqs[None, :]) / delta
+    up = (f_freqs[None, :] - f_filter[:-1, None]) / delta
+    down = torch.cat([down, torch.ones(1, n_freq)], dim=0)
+    up = torch.cat([torch.ones(1, n_freq), up], dim=0)
+    pre = torch.clamp_min(torch.minimum(down, up), 0.0)
+    pre = pre / pre.sum(dim=1, keepdim=True)
+    post = pre.t()
+    post = post / post.sum(dim=1, keepdim=True)
+    return pre.contiguous(), post.contiguous()
+
+
+def positional_embedding(channels: int, freq: int) -> Tensor:
+    """calculate_positional_embedding, model.py:98-110."""
+    f = torch.arange(1, freq + 1, dtype=torch.float32) * (math.pi / freq)
+    c = torch.linspace(math.log(1), math.log(freq - 1), channels // 2, dtype=torch.float32).exp()
+    grid = f.view(-1, 1) * c.view(1, -1)
+    return torch.cat((grid.sin(), grid.cos()), dim=1)
+
+
+def default_state_dict(cfg: FEConfig, generator: Optional[torch.Generator] = None) -> Dict[str, Tensor]:
+    """A fresh *fused-form* state_dict with PyTorch-style default initialisation, so that a model
+    constructed from model_kwargs alone is runnable like the reference's (model.py:738-756).
+    (Values differ from torch's RNG stream; structure and distributions follow nn defaults.)"""
+    g = generator
+    shapes = expected_fused_shapes(cfg)
+    sd: Dict[str, Tensor] = {}
+    pre, post = (linear_filterbank(cfg.F1, cfg.rf_freq) if (cfg.pre_post_init or "").startswith("linear") else (None, None))
+    for k, shp in shapes.items():
+        fan_in = 1
+        for s in shp[1:]:
+            fan_in *= s
+        bound = 1.0 / math.sqrt(max(fan_in, 1))
+        if k == "rf_pre.0.weight" and pre is not None:
+            sd[k] = pre
+        elif k == "rf_post.0.weight" and post is not None:
+            sd[k] = post
+        elif k.endswith(".pe"):
+            sd[k] = positional_embedding(cfg.rf_channels, cfg.rf_freq)
+        elif k.endswith("bias") and ".rnn." not in k:
+            sd[k] = torch.zeros(shp)
+        elif ".rnn." in k:
+            b = 1.0 / math.sqrt(cfg.rf_channels)
+            sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * b
+        else:
+            sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * bound
+    if cfg.normalize_final_conv:
+        w = sd["dec_post.2.weight"]
+        sd["dec_post.2.weight"] = w / w.norm().clamp_min(1e-12)
+    return sd

@@ -1,0 +1,117 @@
+/*
+ * fastenhancer_hip.h — C ABI of libfastenhancer_hip.so (MI355X / gfx950).
+ *
+ * The reference (aask1357/fastenhancer) has no FFI: its inference boundary is the
+ * Python call surface of
+ *   - scripts/export_onnx.py:38-58      class Model: forward(wav_in, cache_stft, cache_istft, *cache_model)
+ *   - models/fastenhancer/default/model.py:677-710   ONNXModel.forward(spec, *cache)   (spec -> spec)
+ *   - models/fastenhancer/default/model.py:614-618   ONNXModel.initialize_cache
+ *   - functional/audio_modules.py:238-303            ONNXSTFT.initialize_cache / forward / inverse
+ *   - models/fastenhancer/default/model.py:532-608   remove_weight_reparameterizations (done on the host,
+ *                                                    fastenhancer_amd/weights.py; this library takes FUSED weights)
+ * This header is what a binding for that surface calls.  Plain C types only:
+ * device pointers are raw `float*`, the stream is a `hipStream_t` passed as `void*`.
+ *
+ * Ownership: the caller allocates and frees every device buffer.  The handle owns only its packed
+ * copy of the weights and constant tables.  All compute entry points are asynchronous on the given
+ * stream and return FE_OK or a negative code; fe_last_error() gives the text (thread-local).
+ * A handle is bound to the device that was current at fe_create(); it is not thread-safe.
+ */
+#ifndef FASTENHANCER_HIP_H
+#define FASTENHANCER_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FE_OK 0
+#define FE_ERR_INVALID_ARG (-1)
+#define FE_ERR_UNSUPPORTED_CONFIG (-2)
+#define FE_ERR_HIP (-3)
+#define FE_ERR_NO_WEIGHTS (-4)
+
+#define FE_ARCH_FASTENHANCER 0 /* models/fastenhancer/default/model.py */
+#define FE_ARCH_BSRNN 1        /* models/bsrnn/model.py (declared; see DESIGN.md for status) */
+
+#define FE_MAX_KERNELS 8
+
+/* Mirror of the yaml `model_kwargs` that select the architecture
+ * (configs/fastenhancer/b.yaml:2-29; defaults models/fastenhancer/default/model.py:384-403).
+ * Invariants of every shipped yaml are asserted by fe_create(): activation SiLU, mask null,
+ * stride 4, kernel_size[0] 8 and 3 afterwards, window hann, stft_normalized False, weight
+ * reparameterisations already removed (fused weights). */
+typedef struct fe_config {
+    int arch;                        /* FE_ARCH_* */
+    int n_fft, hop_size, win_size;   /* N, H, win (win <= N, N even) */
+    int channels;                    /* C1 */
+    int n_kernels;                   /* len(kernel_size) */
+    int kernel_size[FE_MAX_KERNELS]; /* [8,3,3] ... */
+    int stride;                      /* 4 */
+    int rf_channels, rf_freq, rf_blocks, rf_heads; /* C2, F2, K, NH */
+    float input_compression;         /* 0.3 */
+} fe_config;
+
+typedef struct fe_handle fe_handle;
+
+/* Model construction: ONNXModel.__init__ (model.py:383-521) + ONNXSTFT.__init__ window tables
+ * (functional/audio_modules.py:182-236).  FE_ERR_UNSUPPORTED_CONFIG if no kernel was compiled
+ * for this shape (shapes of all shipped fastenhancer yamls are compiled in). */
+int fe_create(const fe_config* cfg, fe_handle** out);
+void fe_destroy(fe_handle* h);
+
+/* Fused-weight blob (what an RCCL broadcast carries).  Sections are the fused state_dict tensors
+ * (SURVEY.md Appendix A.1 "Fused"), fp32, reference memory layout, concatenated in the order
+ * reported by fe_weight_section(); each section offset is a multiple of 4 floats. */
+size_t fe_weight_floats(const fe_handle* h);
+int fe_weight_sections(const fe_handle* h);
+int fe_weight_section(const fe_handle* h, int idx, const char** name, size_t* offset_floats, size_t* count_floats);
+/* load_state_dict (wrappers/ns.py:308-314) for already-fused weights: blob_dev is a DEVICE pointer.
+ * Synchronises the stream (load-time only); repacks into MFMA fragment order inside the handle. */
+int fe_load_weights(fe_handle* h, const float* blob_dev, size_t nfloats, void* stream);
+
+/* Per-stream state = the reference's cache list, concatenated:
+ *   cache_stft  [B, N-H] | cache_istft [B, N-H] | K x h [1, B*F2, C2]
+ * (scripts/export_onnx.py:43-46).  fe_state_init zeroes it (initialize_cache). */
+size_t fe_state_floats(const fe_handle* h, int B);
+int fe_state_init(fe_handle* h, float* state_dev, int B, void* stream);
+
+/* The wav->wav streaming step, scripts/export_onnx.py:48-58, for B independent streams and T
+ * consecutive hops per stream (T=1: one hop, as scripts/test_onnx.py:44-50 drives it).
+ *   wav_in [b*in_stride + t*H + n], wav_out [b*out_stride + t*H + n],  n < H, t < T, b < B.
+ * The state is updated in place. */
+int fe_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, float* state_dev,
+            float* wav_out_dev, size_t out_stride, int B, int T, void* stream);
+
+/* The spec->spec step, ONNXModel.forward (model.py:677-710): spec [B, N/2+1, T, 2] in and out,
+ * h_dev = the K GRU caches [K][B*F2][C2] (updated in place).  Any T >= 1. */
+int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* spec_out_dev,
+                 int B, int T, void* stream);
+
+/* Offline wav->wav, Model.forward (model.py:728-735) with CompressedSTFT
+ * (functional/audio_modules.py:70-164): noisy [B, Tw] -> wav_hat [B, H*(Tw/H)], spec_hat [B, N/2, T, 2],
+ * T = 1 + Tw/H.  work_dev: scratch of fe_offline_work_floats(B, Tw) floats. */
+size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw);
+int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_hat_dev,
+               float* spec_hat_dev, float* work_dev, void* stream);
+
+/* Analytic FLOPs of one frame (2*MACs of models/fastenhancer/default/macs.py:17-87 + FFTs). */
+double fe_flops_per_frame(const fe_handle* h);
+
+/* Debug: run ONE hop (T=1) and dump the named per-stage activations of every stream to dbg_dev.
+ * fe_debug_stages() reports name / rows / cols / offset of each dump ([rows][cols] row-major per
+ * stream, stream-major). Used by the parity tests to localise a mismatch. */
+int fe_debug_stages(const fe_handle* h);
+int fe_debug_stage(const fe_handle* h, int idx, const char** name, int* rows, int* cols, size_t* offset_floats);
+size_t fe_debug_floats(const fe_handle* h);   /* per stream */
+int fe_debug_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, float* state_dev,
+                  float* wav_out_dev, size_t out_stride, int B, float* dbg_dev, void* stream);
+
+const char* fe_last_error(void);
+const char* fe_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTENHANCER_HIP_H */
