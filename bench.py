@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — enhanced audio frames/s of the FastEnhancer streaming forward path on MI355X.
+
+One "step" = one pass of the hot path (scripts/export_onnx.py:48-58 of the reference: STFT ->
+model -> iSTFT with all caches) over one batch of synthetic input: ONE hop of H new samples for
+each of the B concurrent streams of this GPU (`--frames-per-step T` makes a step T hops per
+stream in one launch).  Workload = BASELINE.json configs[1]: FastEnhancer_B, 16 kHz, N=512,
+H=256, B=256 concurrent streams per GPU.  Multi-GPU: one process per GPU, the streams are
+sharded (256 per rank, weak scaling), the fused weight blob is broadcast once from rank 0 over
+RCCL, and there is no per-step collective (streams are independent).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
+`cpu_baseline` objects.  Inputs are resident in HBM before the timed region."""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from fastenhancer_amd import _lib  # noqa: E402
+from fastenhancer_amd.config import FEConfig  # noqa: E402
+from fastenhancer_amd.engine import Engine  # noqa: E402
+from fastenhancer_amd.parallel import broadcast_blob, shard_range, synthetic_streams  # noqa: E402
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak (256 CU x 2.4 GHz)
+
+WORKLOADS = {
+    # name: (model_kwargs builder args, sampling rate, description)
+    "fe_b": dict(C1=48, ks=(8, 3, 3), C2=36, F2=24, K=3, N=512, H=256, sr=16000, init="linear_fixed",
+                 desc="FastEnhancer_B 16kHz"),
+    "fe_t": dict(C1=24, ks=(8, 3, 3), C2=20, F2=16, K=2, N=512, H=256, sr=16000, init="linear_fixed",
+                 desc="FastEnhancer_T 16kHz"),
+    "fe_s": dict(C1=64, ks=(8, 3, 3, 3), C2=48, F2=36, K=3, N=512, H=256, sr=16000, init="linear_fixed",
+                 desc="FastEnhancer_S 16kHz"),
+    "fe48_b": dict(C1=48, ks=(8, 3, 3), C2=36, F2=36, K=3, N=1024, H=512, sr=48000, init="linear",
+                   desc="FastEnhancer_B 48kHz"),
+}
+
+
+def model_kwargs(w):
+    return dict(channels=w["C1"], kernel_size=list(w["ks"]), stride=4,
+                rnnformer_kwargs=dict(num_blocks=w["K"], channels=w["C2"], freq=w["F2"], num_heads=4, eps=1e-5,
+                                      positional_embedding="train", attn_bias=False, post_act=False, pre_norm=False),
+                pre_post_init=w["init"], n_fft=w["N"], hop_size=w["H"], win_size=w["N"], window="hann",
+                stft_normalized=False, mask=None, activation="SiLU", activation_kwargs=dict(inplace=True),
+                input_compression=0.3, normalize_final_conv=True, weight_norm=True, resnet=False)
+
+
+def cpu_baseline(workload: str, kw: dict, sr: int, B: int, budget_s: float):
+    """The numpy oracle (a port of the reference algorithm, oracle/fe_oracle.py) timed on the host
+    cores of this box on a bounded sample of the same workload."""
+    from oracle.fe_oracle import FEConfig as OCfg, FEOracle, fold_state_dict
+    from oracle.weightgen import make_input, make_training_state_dict
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    cfg = OCfg.from_model_kwargs(kw)
+    orc = FEOracle(cfg, fold_state_dict(make_training_state_dict(cfg, 2), cfg))
+    H = cfg.hop_size
+    max_hops = 64
+    x = make_input(B, max_hops * H, 1236, sr)
+    caches = orc.initialize_cache(B)
+    o, *caches = orc.step(x[:, :H], *caches)          # warm-up hop
+    t0 = time.perf_counter()
+    hops = 0
+    while hops < max_hops - 1 and (time.perf_counter() - t0) < budget_s:
+        o, *caches = orc.step(x[:, (hops + 1) * H:(hops + 2) * H], *caches)
+        hops += 1
+    dt = time.perf_counter() - t0
+    return {"value": B * hops / dt, "unit": "frames/s", "cores": int(threads), "kind": "port",
+            "sample": f"{hops} hops x {B} streams of {workload} through the numpy oracle (oracle/fe_oracle.py), "
+                      f"{dt:.1f} s, host has {os.cpu_count()} logical cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default="fe_b", choices=sorted(WORKLOADS))
+    ap.add_argument("--streams", type=int, default=256, help="concurrent streams per GPU")
+    ap.add_argument("--frames-per-step", type=int, default=1, help="hops per stream per launch (1 = per-hop streaming)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the FastEnhancer HIP path has no CPU fallback")
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus or world == 1, (world, args.gpus)
+
+    w = WORKLOADS[args.workload]
+    kw = model_kwargs(w)
+    cfg = FEConfig.from_model_kwargs(**kw)
+    eng = Engine(cfg, dev)
+
+    # ---- weights: rank 0 builds the seeded checkpoint, folds it, and broadcasts the blob (RCCL)
+    blob = torch.empty(eng.weight_floats, dtype=torch.float32, device=dev)
+    if rank == 0:
+        # no trained checkpoints offline: PyTorch-style random init of the fused weights; the final conv is
+        # scaled so that the complex mask is O(1) (the enhanced waveform has the level of the input)
+        from fastenhancer_amd.weights import default_state_dict
+        sd = default_state_dict(cfg, torch.Generator().manual_seed(2))
+        sd["dec_post.2.weight"] = sd["dec_post.2.weight"] * 12.0
+        blob.copy_(eng.make_blob(sd))
+    broadcast_blob(blob, src=0)
+    eng.load_blob(blob)
+
+    # ---- synthetic streams of this rank, step-major [steps, B, T*H], resident in HBM
+    B, T, H = args.streams, args.frames_per_step, cfg.hop_size
+    total_steps = args.warmup + args.steps
+    b0, b1 = shard_range(B * world, world, rank)
+    pool = min(total_steps, 64)                       # distinct steps of input; reused cyclically
+    x = synthetic_streams(b0, b1, pool * T * H, w["sr"], seed=1234 + 2).to(dev)         # [B, pool*T*H]
+    x = x.view(B, pool, T * H).permute(1, 0, 2).contiguous()                             # [pool, B, T*H]
+    out = torch.empty(B, T * H, dtype=torch.float32, device=dev)
+    state = eng.new_state(B)
+
+    lib = eng.lib
+    stream = torch.cuda.current_stream(dev)
+    sptr = ctypes.c_void_p(stream.cuda_stream)
+    xptr, optr, stptr = x.data_ptr(), ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(state.data_ptr())
+    step_bytes = B * T * H * 4
+
+    def run(n, first):
+        for i in range(n):
+            s = (first + i) % pool
+            rc = lib.fe_step(eng._h, ctypes.c_void_p(xptr + s * step_bytes), T * H, stptr, optr, T * H, B, T, sptr)
+            if rc != 0:
+                _lib.check(rc, "fe_step")
+
+    run(args.warmup, 0)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    run(args.steps, args.warmup)
+    ev1.record(stream)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps    # HIP events on the launch stream: avg per launch
+    if world > 1:
+        tt = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, kernel_ms = float(tt[0]), float(tt[1])
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        frames = B * world * T * args.steps
+        flops_per_launch = eng.flops_per_frame * B * T
+        achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+        res = {
+            "metric": "audio frames/sec (hop=256, 16kHz) FastEnhancer_B" if args.workload == "fe_b" else f"audio frames/sec {w['desc']}",
+            "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{w['desc']} (N={w['N']}, H={w['H']}), {B} concurrent streams per GPU, "
+                                   f"{T} hop(s) per stream per step, wav->wav streaming step with STFT/iSTFT and GRU caches",
+                       "streams_per_gpu": B, "frames_per_step": T, "parallelism": f"streams sharded dp{world}, RCCL weight broadcast",
+                       "weights": "seeded random checkpoint (no trained weights offline), BN/weight-norm folded"},
+            "rtf_per_stream": dt * w["sr"] / (args.steps * T * H * B * world) * world,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "kernel": "fe_frame_kernel", "kernel_ms": kernel_ms,
+                         "flops_per_frame": eng.flops_per_frame,
+                         "hbm_frac": (B * T * (2 * H * 4) + 2 * 4 * eng.state_floats(B)) / (kernel_ms * 1e-3) / 8e12},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.workload, kw, w["sr"], B, args.cpu_budget_s)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+"""CPU tests of the host logic and of the C ABI surface (no compute, no GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from common import MODEL_KWARGS, build_oracle, load_golden
+from fastenhancer_amd import _lib
+from fastenhancer_amd.config import FEConfig
+from fastenhancer_amd.engine import Engine
+from fastenhancer_amd.weights import check_fused, default_state_dict, expected_fused_shapes, fold_state_dict
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, "include", "fastenhancer_hip.h")).read()
+    declared = set(re.findall(r"\b(fe_[a-z_]+)\s*\(", header))
+    declared -= {"fe_handle", "fe_config"}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.fe_version()
+
+
+@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_s", "fe48_b"])
+def test_section_table_matches_fused_schema(name):
+    kw, sr, seed = MODEL_KWARGS[name]
+    cfg = FEConfig.from_model_kwargs(**kw)
+    eng = Engine(cfg, None)
+    exp = expected_fused_shapes(cfg)
+    assert [s[0] for s in eng.sections] == list(exp.keys())
+    end = 0
+    for (sname, off, cnt) in eng.sections:
+        assert cnt == int(np.prod(exp[sname])) and off % 4 == 0 and off >= end
+        end = off + cnt
+    assert end == eng.weight_floats
+    orc_cfg = build_oracle(name)[0]
+    assert eng.flops_per_frame == pytest.approx(orc_cfg.flops_per_frame())
+
+
+def test_flops_match_survey_table():
+    # T 1.938 M, B 8.392 M, 48k-B 16.04 M FLOPs per frame
+    for name, want in (("fe_t", 1.938e6), ("fe_b", 8.392e6), ("fe48_b", 16.04e6)):
+        eng = Engine(FEConfig.from_model_kwargs(**MODEL_KWARGS[name][0]), None)
+        assert eng.flops_per_frame == pytest.approx(want, rel=1e-3)
+
+
+def test_unsupported_shapes_are_rejected_with_a_message():
+    kw = dict(MODEL_KWARGS["fe_b"][0])
+    kw["channels"] = 40
+    with pytest.raises(_lib.FEError, match="no kernel compiled"):
+        Engine(FEConfig.from_model_kwargs(**kw), None)
+    lib = _lib.load()
+    c = _lib.fe_config()
+    c.arch, c.n_fft, c.hop_size, c.win_size = 0, 511, 256, 511
+    h = ctypes.c_void_p()
+    assert lib.fe_create(ctypes.byref(c), ctypes.byref(h)) < 0
+    assert b"even" in lib.fe_last_error()
+
+
+def test_config_rejects_what_the_reference_rejects():
+    kw = dict(MODEL_KWARGS["fe_b"][0])
+    with pytest.raises(AssertionError):
+        FEConfig.from_model_kwargs(**{**kw, "n_fft": 511})
+    with pytest.raises(AssertionError):
+        FEConfig.from_model_kwargs(**{**kw, "win_size": 1024})
+    with pytest.raises(RuntimeError):
+        FEConfig.from_model_kwargs(**{**kw, "mask": "softmax"})
+
+
+@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_l", "fe48_b"])
+def test_host_fold_matches_oracle_fold(name):
+    cfg_o, sd, fused_o, _ = build_oracle(name)
+    cfg = FEConfig.from_model_kwargs(**MODEL_KWARGS[name][0])
+    fused = fold_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, cfg)
+    assert set(fused) == set(fused_o)
+    for k in fused:
+        np.testing.assert_allclose(fused[k].numpy(), fused_o[k], rtol=3e-6, atol=1e-7, err_msg=k)
+    check_fused(fused, cfg)
+    # idempotent on fused input
+    again = fold_state_dict(fused, cfg)
+    for k in fused:
+        assert torch.equal(again[k], fused[k])
+
+
+def test_host_fold_matches_reference_fused_state_dict():
+    g = load_golden("fe_t")
+    cfg_o, sd, _, _ = build_oracle("fe_t")
+    cfg = FEConfig.from_model_kwargs(**MODEL_KWARGS["fe_t"][0])
+    fused = fold_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, cfg)
+    for k in fused:
+        np.testing.assert_allclose(fused[k].numpy(), g["fused." + k], rtol=3e-6, atol=1e-7, err_msg=k)
+
+
+def test_strict_loading_errors():
+    cfg = FEConfig.from_model_kwargs(**MODEL_KWARGS["fe_t"][0])
+    sd = default_state_dict(cfg)
+    check_fused(sd, cfg)
+    bad = dict(sd)
+    bad.pop("rf_post.1.bias")
+    with pytest.raises(RuntimeError, match="Missing key"):
+        check_fused(bad, cfg)
+    bad = dict(sd)
+    bad["extra.weight"] = torch.zeros(1)
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        check_fused(bad, cfg)
+    check_fused(bad, cfg, strict=False)
+    bad = dict(sd)
+    bad["enc_pre.0.weight"] = torch.zeros(3, 8, 2)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        check_fused(bad, cfg)
+
+
+def test_blob_roundtrip_layout():
+    cfg = FEConfig.from_model_kwargs(**MODEL_KWARGS["fe_b"][0])
+    eng = Engine(cfg, None)
+    sd = default_state_dict(cfg, torch.Generator().manual_seed(3))
+    blob = eng.make_blob(sd)
+    assert blob.dtype == torch.float32 and blob.numel() == eng.weight_floats
+    for name, off, cnt in eng.sections:
+        assert torch.equal(blob[off:off + cnt], sd[name].reshape(-1))
+
+
+def test_compute_without_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import importlib
+    mod = importlib.import_module("fastenhancer_amd.models.fastenhancer.default.model")
+    m = mod.ONNXModel(**MODEL_KWARGS["fe_t"][0])
+    caches = m.initialize_cache(torch.zeros(2, 1))
+    assert [tuple(c.shape) for c in caches] == [(1, 2 * 16, 20)] * 2
+    assert [tuple(c.shape) for c in m.stft.initialize_cache(torch.zeros(2, 1))] == [(2, 256)] * 2
+    with pytest.raises(_lib.FEError, match="no CPU fallback"):
+        m(torch.zeros(2, 257, 1, 2))

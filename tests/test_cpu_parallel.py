@@ -1,0 +1,73 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU plumbing: stream sharding + weight-blob
+broadcast; and sharding invariants."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from fastenhancer_amd.parallel import shard_range, synthetic_streams
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions_all_streams():
+    for n in (0, 1, 7, 256, 2048, 2049):
+        for world in (1, 2, 3, 8):
+            cuts = [shard_range(n, world, r) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in cuts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_synthetic_streams_do_not_depend_on_sharding():
+    full = synthetic_streams(0, 6, 500, 16000, seed=5)
+    a, b = synthetic_streams(0, 3, 500, 16000, seed=5), synthetic_streams(3, 6, 500, 16000, seed=5)
+    assert torch.equal(full, torch.cat([a, b]))
+    assert float(full.abs().max()) <= 1.0
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from common import MODEL_KWARGS
+    from fastenhancer_amd.config import FEConfig
+    from fastenhancer_amd.engine import Engine
+    from fastenhancer_amd.parallel import broadcast_blob, gather_frame_counts
+    from fastenhancer_amd.weights import default_state_dict
+    cfg = FEConfig.from_model_kwargs(**MODEL_KWARGS["fe_t"][0])
+    eng = Engine(cfg, None)
+    blob = torch.zeros(eng.weight_floats)
+    if rank == 0:
+        blob = eng.make_blob(default_state_dict(cfg, torch.Generator().manual_seed(11)))
+    broadcast_blob(blob, src=0)
+    b0, b1 = shard_range(9, world, rank)
+    frames, elapsed = gather_frame_counts((b1 - b0) * 10, 1.0 + rank, torch.device("cpu"))
+    q.put((rank, float(blob.double().sum()), int(blob.numel()), (b0, b1), frames, elapsed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_broadcast_and_sharding():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, n0, sh0, f0, e0), (r1, s1, n1, sh1, f1, e1) = res
+    assert s0 == s1 and s0 != 0.0 and n0 == n1          # every rank holds rank 0's blob
+    assert sh0 == (0, 5) and sh1 == (5, 9)
+    assert f0 == f1 == 90 and e0 == e1 == 2.0
