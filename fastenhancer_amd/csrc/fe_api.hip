@@ -48,6 +48,8 @@ struct Dims {
 struct Impl {
     int C1, NL, C2, F2, KB, NFFT, HOP;
     size_t lds_bytes;
+    int n_units, u_max;
+    bool staged;
     size_t dbg_floats;
     int dbg_stages;
     void (*launch)(const fe::FrameArgs&, bool spec_mode, hipStream_t, hipError_t*);
@@ -83,7 +85,7 @@ void dbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
 
 template <class S>
 Impl make_impl() {
-    return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, fe::Lds<S>::BYTES,
+    return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, fe::Lds<S>::BYTES, S::NU, S::U_MAX, fe::Lds<S>::STAGED,
                 fe::DebugLayout<S>::total(), fe::DebugLayout<S>::n_stages, &launch_impl<S>, &dbg_stage_impl<S>};
 }
 
@@ -195,10 +197,20 @@ void build_tables(fe_handle* h) {
 
 struct Packer {
     std::vector<float> buf;
+    std::vector<int> u_off, u_size;
     int alloc(size_t n) {
         size_t off = (buf.size() + 63) & ~(size_t)63;   // 256-byte aligned sections
         buf.resize(off + n, 0.0f);
         return (int)off;
+    }
+    // A unit = the arrays of one GEMM phase, contiguous, 1-KiB aligned and padded (staged into LDS as a whole).
+    void begin_unit() {
+        buf.resize((buf.size() + 255) & ~(size_t)255, 0.0f);
+        u_off.push_back((int)buf.size());
+    }
+    void end_unit() {
+        buf.resize((buf.size() + 255) & ~(size_t)255, 0.0f);
+        u_size.push_back((int)buf.size() - u_off.back());
     }
     // B operand in fragment order: dst[(nt*KS + ks)*64 + lane] = B(k = 4ks + lane/16, n = 16nt + lane%16)
     int pack_b(int K, int Ncols, const std::function<float(int, int)>& Bkn) {
@@ -251,58 +263,96 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
     char nm[128];
     auto S = [&](const std::string& n) { return sec(h, blob, n); };
 
-    {   // enc_pre: weight (C1, 8, 2): B[k = t*8 + ch][n = co] = W[co][ch][t]
-        const float* w = S("enc_pre.0.weight");
-        o.enc_pre_w = p.pack_b(16, C1, [&](int k, int n) { return w[(n * 8 + (k & 7)) * 2 + (k >> 3)]; });
-        o.enc_pre_b = p.pack_bias(C1, S("enc_pre.0.bias"));
-    }
     auto pack_k3 = [&](const float* w) {   // (Co, Ci, 3): k = tap*Ci + ci
         return p.pack_b(3 * C1, C1, [&](int k, int n) { return w[(n * C1 + (k % C1)) * 3 + (k / C1)]; });
     };
     auto pack_1x1 = [&](const float* w, int Ci, int Co) {   // (Co, Ci[,1]): B[k=ci][n=co]
         return p.pack_b(Ci, Co, [&](int k, int n) { return w[n * Ci + k]; });
     };
+    // Units are packed in the order the kernel consumes them (fe_frame_kernel: begin_unit()).
+    p.begin_unit();
+    {   // enc_pre: weight (C1, 8, 2): B[k = t*8 + ch][n = co] = W[co][ch][t]
+        const float* w = S("enc_pre.0.weight");
+        o.enc_pre_w = p.pack_b(16, C1, [&](int k, int n) { return w[(n * 8 + (k & 7)) * 2 + (k >> 3)]; });
+        o.enc_pre_b = p.pack_bias(C1, S("enc_pre.0.bias"));
+    }
+    p.end_unit();
     for (int i = 0; i < d.NL; ++i) {
+        p.begin_unit();
         snprintf(nm, sizeof nm, "encoder.%d.0.weight", i); o.enc_w[i] = pack_k3(S(nm));
         snprintf(nm, sizeof nm, "encoder.%d.0.bias", i); o.enc_b[i] = p.pack_bias(C1, S(nm));
+        p.end_unit();
     }
     {   // rf_pre: Linear (F2, F1) as A operand, then 1x1 conv (C2, C1)
         const float* w = S("rf_pre.0.weight");
+        p.begin_unit();
         o.rfpre_lin = p.pack_a(F2, F1, [&](int m, int k) { return w[m * F1 + k]; });
+        p.end_unit();
+        p.begin_unit();
         o.rfpre_w = pack_1x1(S("rf_pre.1.weight"), C1, C2);
         o.rfpre_b = p.pack_bias(C2, S("rf_pre.1.bias"));
+        p.end_unit();
     }
     for (int k = 0; k < d.KB; ++k) {
         auto key = [&](const char* s) { snprintf(nm, sizeof nm, "rf_block.%d.%s", k, s); return std::string(nm); };
-        if (k == 0) o.blk_pe = p.raw((size_t)F2 * C2, S(key("pe")));
+        p.begin_unit();   // GRU
         o.blk_wih[k] = pack_1x1(S(key("rnn.weight_ih_l0")), C2, 3 * C2);
         o.blk_whh[k] = pack_1x1(S(key("rnn.weight_hh_l0")), C2, 3 * C2);
         o.blk_bih[k] = p.pack_bias(3 * C2, S(key("rnn.bias_ih_l0")));
         o.blk_bhh[k] = p.pack_bias(3 * C2, S(key("rnn.bias_hh_l0")));
+        p.end_unit();
+        p.begin_unit();   // rnn_fc (+ positional embedding of block 0)
         o.blk_fc1_w[k] = pack_1x1(S(key("rnn_fc.weight")), C2, C2);
         o.blk_fc1_b[k] = p.pack_bias(C2, S(key("rnn_fc.bias")));
+        if (k == 0) o.blk_pe = p.raw((size_t)F2 * C2, S(key("pe")));
+        p.end_unit();
+        p.begin_unit();   // qkv
         o.blk_qkv[k] = pack_1x1(S(key("attn.qkv.weight")), C2, 3 * C2);
+        p.end_unit();
+        p.begin_unit();   // attn_fc
         o.blk_fc2_w[k] = pack_1x1(S(key("attn_fc.weight")), C2, C2);
         o.blk_fc2_b[k] = p.pack_bias(C2, S(key("attn_fc.bias")));
+        p.end_unit();
     }
     {
         const float* w = S("rf_post.0.weight");   // (F1, F2)
+        p.begin_unit();
         o.rfpost_lin = p.pack_a(F1, F2, [&](int m, int k) { return w[m * F2 + k]; });
+        p.end_unit();
+        p.begin_unit();
         o.rfpost_w = pack_1x1(S("rf_post.1.weight"), C2, C1);
         o.rfpost_b = p.pack_bias(C1, S("rf_post.1.bias"));
+        p.end_unit();
     }
     for (int i = 0; i < d.NL; ++i) {
+        p.begin_unit();
         snprintf(nm, sizeof nm, "decoder.%d.0.weight", i); o.dec1_w[i] = pack_1x1(S(nm), 2 * C1, C1);
         snprintf(nm, sizeof nm, "decoder.%d.0.bias", i); o.dec1_b[i] = p.pack_bias(C1, S(nm));
+        p.end_unit();
+        p.begin_unit();
         snprintf(nm, sizeof nm, "decoder.%d.2.weight", i); o.dec3_w[i] = pack_k3(S(nm));
         snprintf(nm, sizeof nm, "decoder.%d.2.bias", i); o.dec3_b[i] = p.pack_bias(C1, S(nm));
+        p.end_unit();
     }
+    p.begin_unit();
     o.post1_w = pack_1x1(S("dec_post.0.weight"), 2 * C1, C1);
     o.post1_b = p.pack_bias(C1, S("dec_post.0.bias"));
+    p.end_unit();
+    p.begin_unit();
     {   // transposed conv weight (C1, 2, 8): B[k = ci][n = co*8 + j]
         const float* w = S("dec_post.2.weight");
         o.post_t_w = p.pack_b(C1, 16, [&](int k, int n) { return w[k * 16 + n]; });
         o.post_t_b = p.pack_bias(2, S("dec_post.2.bias"));
+    }
+    p.end_unit();
+    o.n_units = (int)p.u_off.size();
+    if (o.n_units != h->impl->n_units || o.n_units > 64)
+        return fail(FE_ERR_INVALID_ARG, "internal: %d weight units packed, kernel expects %d", o.n_units, h->impl->n_units);
+    for (int u = 0; u < o.n_units; ++u) {
+        o.u_off[u] = p.u_off[u];
+        o.u_size[u] = p.u_size[u];
+        if (p.u_size[u] > h->impl->u_max)
+            return fail(FE_ERR_INVALID_ARG, "internal: weight unit %d has %d floats > LDS buffer %d", u, p.u_size[u], h->impl->u_max);
     }
     o.window = p.raw(h->window.size(), h->window.data());
     o.window_istft = p.raw(h->window_istft.size(), h->window_istft.data());
@@ -360,6 +410,8 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
         return fail(FE_ERR_UNSUPPORTED_CONFIG,
                     "no kernel compiled for channels=%d layers=%d rf_channels=%d rf_freq=%d rf_blocks=%d n_fft=%d hop=%d",
                     cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size);
+    if (impl->lds_bytes > 160 * 1024)
+        return fail(FE_ERR_UNSUPPORTED_CONFIG, "shape needs %zu bytes of LDS (> 160 KiB per CU)", impl->lds_bytes);
     fe_handle* h = new fe_handle();
     h->cfg = *cfg;
     h->impl = impl;
@@ -420,7 +472,7 @@ int fe_state_init(fe_handle* h, float* state_dev, int B, void* stream) {
 }
 
 static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* state, float* wav_out, size_t out_stride,
-                    int B, int T, float* dbg, void* stream) {
+                    int B, int T, float* dbg, unsigned long long* clk, void* stream) {
     int rc = check_ready(h);
     if (rc != FE_OK) return rc;
     if (!wav_in || !state || !wav_out || B <= 0 || T <= 0) return fail(FE_ERR_INVALID_ARG, "bad argument");
@@ -437,6 +489,7 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
     a.cache_istft = state + (size_t)B * ovl;
     a.h = state + 2 * (size_t)B * ovl;
     a.dbg = dbg;
+    a.clk = clk;
     a.dbg_stride = h->impl->dbg_floats;
     hipError_t e = hipSuccess;
     h->impl->launch(a, false, (hipStream_t)stream, &e);
@@ -446,13 +499,19 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
 
 int fe_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, float* state_dev, float* wav_out_dev, size_t out_stride,
             int B, int T, void* stream) {
-    return run_step(h, wav_in_dev, in_stride, state_dev, wav_out_dev, out_stride, B, T, nullptr, stream);
+    return run_step(h, wav_in_dev, in_stride, state_dev, wav_out_dev, out_stride, B, T, nullptr, nullptr, stream);
 }
 
 int fe_debug_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, float* state_dev, float* wav_out_dev,
                   size_t out_stride, int B, float* dbg_dev, void* stream) {
     if (!dbg_dev) return fail(FE_ERR_INVALID_ARG, "null dbg buffer");
-    return run_step(h, wav_in_dev, in_stride, state_dev, wav_out_dev, out_stride, B, 1, dbg_dev, stream);
+    return run_step(h, wav_in_dev, in_stride, state_dev, wav_out_dev, out_stride, B, 1, dbg_dev, nullptr, stream);
+}
+
+int fe_profile_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, float* state_dev, float* wav_out_dev,
+                    size_t out_stride, int B, int T, unsigned long long* clk_dev, void* stream) {
+    if (!clk_dev) return fail(FE_ERR_INVALID_ARG, "null clock buffer");
+    return run_step(h, wav_in_dev, in_stride, state_dev, wav_out_dev, out_stride, B, T, nullptr, clk_dev, stream);
 }
 
 int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* spec_out_dev, int B, int T, void* stream) {

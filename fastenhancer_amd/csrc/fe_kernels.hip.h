@@ -64,6 +64,20 @@ struct Shape {
     // packed-weight sizes (floats)
     static constexpr int KS_C = C1 / 4;           // k-steps over C1
     static constexpr int KS_2 = C2 / 4;           // k-steps over C2
+    // weight units (see PackedOffsets::u_off): enc_pre, NL enc, rf_pre lin+conv, KB x (gru, fc1, qkv, fc2),
+    // rf_post lin+conv, NL x (dec 1x1, dec k3), dec_post 1x1 + transposed conv
+    static constexpr int NU = 7 + 3 * NL + 4 * KB;
+    static constexpr int r256(int x) { return (x + 255) / 256 * 256; }
+    static constexpr int m2(int a, int b) { return a > b ? a : b; }
+    static constexpr int U_K3 = r256(NTC * 3 * KS_C * 64 + NTC * 16);
+    static constexpr int U_1X1 = r256(NTC * 2 * KS_C * 64 + NTC * 16);
+    static constexpr int U_GRU = r256(2 * (NT3 * KS_2 * 64 + 64) + 2 * NT3 * 16);
+    static constexpr int U_FC1 = r256(NT2 * KS_2 * 64 + NT2 * 16 + 64 + F2 * C2);
+    static constexpr int U_QKV = r256(NT3 * KS_2 * 64);
+    static constexpr int U_LIN1 = r256(MT2 * (F1 / 4) * 64);
+    static constexpr int U_LIN2 = r256(MTC * (F2 / 4) * 64);
+    static constexpr int U_RFC = r256(m2(NT2 * KS_C * 64 + NT2 * 16, NTC * KS_2 * 64 + NTC * 16) + 64);
+    static constexpr int U_MAX = m2(m2(m2(U_K3, U_1X1), m2(U_GRU, U_FC1)), m2(m2(U_QKV, U_LIN1), m2(U_LIN2, U_RFC)));
     static_assert(C1 % 4 == 0 && C2 % 4 == 0 && F2 % 4 == 0, "channel counts must be multiples of 4");
     static_assert(C2 % NH == 0, "C2 must be divisible by the 4 heads");
     static_assert(F1 % 64 == 0, "F1 must be a multiple of 64");
@@ -84,6 +98,10 @@ struct PackedOffsets {
     int post1_w, post1_b, post_t_w, post_t_b;
     int window, window_istft, twiddle;  // [N], [N], [N/2] float2
     int total;
+    // Weight "units" in consumption order (one per GEMM phase): [weights | bias ...], 256-float aligned
+    // and padded, so that a unit is staged into LDS by whole 1-KiB global_load_lds pieces.
+    int n_units;
+    int u_off[64], u_size[64];
 };
 
 struct FrameArgs {
@@ -98,39 +116,116 @@ struct FrameArgs {
     const float* spec_in;     // spec mode: [B][F0+1][T][2]
     float* spec_out;
     float* dbg;               // debug dumps or nullptr
+    unsigned long long* clk;  // phase cycle counters (block 0, thread 0) or nullptr
     size_t dbg_stride;        // floats per stream
     int B, T;
     float compression;
 };
 
 // ------------------------------------------------------------------------------------------
+#define FE_CLK(i) do { if (a.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.clk[(i)] = __builtin_readcyclecounter(); } while (0)
+
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
-// One MFMA panel: acc[MTP][NTP] += A-frags x B-frags over KS k-steps.
+// Weights / tables are read through ONE buffer resource: the per-lane part of every address is the
+// single VGPR `lane*4`; the section / tile / k-step part is a scalar (SGPR or immediate) offset.
+template <bool STAGED>
+struct WSrc {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int lane4;          // (threadIdx & 63) * 4  bytes
+    int li4;            // (lane & 15) * 4 bytes
+    const float* lds;   // STAGED: LDS copy of the current weight unit
+    int base;           // STAGED: absolute offset (floats) of the current unit in the packed buffer
+    __device__ __forceinline__ float at(int off_floats) const {          // + lane
+        if constexpr (STAGED) return lds[off_floats - base + (lane4 >> 2)];
+        else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane4, off_floats * 4, 0));
+    }
+    __device__ __forceinline__ float at16(int off_floats) const {        // + (lane & 15)
+        if constexpr (STAGED) return lds[off_floats - base + (li4 >> 2)];
+        else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, li4, off_floats * 4, 0));
+    }
+    __device__ __forceinline__ float gather(int off_floats_per_lane) const {   // arbitrary per-lane offset
+        if constexpr (STAGED) return lds[off_floats_per_lane - base];
+        else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off_floats_per_lane * 4, 0, 0));
+    }
+    __device__ __forceinline__ float scalar(int off_floats) const {
+        if constexpr (STAGED) return lds[off_floats - base];
+        else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, 0, off_floats * 4, 0));
+    }
+};
+
+// Asynchronous global -> LDS copy of one weight unit (n floats, multiple of 256): each wave issues
+// 1-KiB global_load_lds_dwordx4 pieces (LDS destination = wave-uniform base + lane*16).  Completion
+// is covered by the vmcnt(0) that __syncthreads() carries while an LDS-DMA is in flight.
+__device__ __forceinline__ void stage_unit(const float* gsrc, float* lds_dst, int n, int wave, int lane) {
+    for (int p = wave; p * 256 < n; p += kWaves) {
+        const float* g = gsrc + p * 256 + lane * 4;
+        float* l = lds_dst + p * 256;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    }
+}
+
+// Software-pipelined: operands are fetched in groups of G k-steps, D groups ahead of the MFMAs
+// that consume them; sched_barrier(0) pins "loads of group g+D before MFMAs of group g", so the
+// compiler's counted s_waitcnt leaves >= D*G*MTP*NTP MFMAs (32 cycles each) of cover over the L2
+// latency of the weight fetch.  (Left alone, hipcc sinks every load next to its MFMA.)
 template <int MTP, int NTP, int KS, typename AF, typename BF>
 __device__ __forceinline__ void mma_panel(f32x4 (&acc)[MTP][NTP], AF&& af, BF&& bf) {
-#pragma unroll 4
-    for (int ks = 0; ks < KS; ++ks) {
-        float a[MTP], b[NTP];
+    constexpr int G = (MTP * NTP >= 6) ? 2 : 4;      // k-steps per group
+    constexpr int D = 2;                             // prefetch distance in groups
+    constexpr int NG = (KS + G - 1) / G;
+    float a[D + 1][G][MTP], b[D + 1][G][NTP];
+    auto load_group = [&](int g, int slot) {
 #pragma unroll
-        for (int i = 0; i < MTP; ++i) a[i] = af(i, ks);
+        for (int kk = 0; kk < G; ++kk) {
+            const int ks = g * G + kk;
+            if (ks < KS) {
 #pragma unroll
-        for (int j = 0; j < NTP; ++j) b[j] = bf(j, ks);
+                for (int i = 0; i < MTP; ++i) a[slot][kk][i] = af(i, ks);
 #pragma unroll
-        for (int i = 0; i < MTP; ++i)
+                for (int j = 0; j < NTP; ++j) b[slot][kk][j] = bf(j, ks);
+            }
+        }
+    };
 #pragma unroll
-            for (int j = 0; j < NTP; ++j) acc[i][j] = FE_MFMA(a[i], b[j], acc[i][j]);
+    for (int d = 0; d < D; ++d)
+        if (d < NG) load_group(d, d);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + D < NG) load_group(g + D, (g + D) % (D + 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < G; ++kk) {
+            if (g * G + kk < KS) {
+#pragma unroll
+                for (int i = 0; i < MTP; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTP; ++j)
+                        acc[i][j] = FE_MFMA(a[g % (D + 1)][kk][i], b[g % (D + 1)][kk][j], acc[i][j]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 template <int MTP, int NTP>
-__device__ __forceinline__ void acc_init_bias(f32x4 (&acc)[MTP][NTP], const float* __restrict__ bias_lane, int nt0, int nt_stride, int nt_max) {
+__device__ __forceinline__ void acc_init_zero(f32x4 (&acc)[MTP][NTP]) {
+#pragma unroll
+    for (int j = 0; j < NTP; ++j)
+#pragma unroll
+        for (int i = 0; i < MTP; ++i) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+}
+
+// acc[.][j] = bias[16 * nt_j + (lane & 15)],  nt_j = min(nt0 + j * nt_stride, nt_max - 1)
+template <int MTP, int NTP, class WS>
+__device__ __forceinline__ void acc_init_bias(f32x4 (&acc)[MTP][NTP], const WS& w, int bias_off, int nt0, int nt_stride, int nt_max) {
 #pragma unroll
     for (int j = 0; j < NTP; ++j) {
         int nt = nt0 + j * nt_stride;
         nt = nt < nt_max ? nt : nt_max - 1;
-        float b = bias_lane ? bias_lane[nt * 16] : 0.0f;
+        float b = w.at16(bias_off + nt * 16);
 #pragma unroll
         for (int i = 0; i < MTP; ++i) acc[i][j] = f32x4{b, b, b, b};
     }
@@ -183,31 +278,43 @@ __device__ __forceinline__ void dbg_dump(const FrameArgs& a, int b, int stage, c
 // scratch arena whose sub-buffers are reused by the phases of a frame.
 template <class S>
 struct Lds {
+    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
     static constexpr int SC = 0;                                  // compressed spectrum [2][LDS_S]
     static constexpr int TW = SC + 2 * S::LDS_S;                  // twiddles float2[N/2]
     static constexpr int E = TW + S::NFFT;                        // skips: (NL+1) x ACT
     static constexpr int ARENA = E + (S::NL + 1) * S::ACT;
-    // phase A (STFT / iSTFT): two complex ping-pong buffers
+    // The arena is re-used by the phases of a frame (offsets relative to ARENA):
+    //   STFT / iSTFT : FFT_A, FFT_B                       (complex ping-pong)
+    //   rf_pre       : Y1 (aliases GI), X
+    //   blocks       : X, HL, GI, GH
+    //   rf_post      : X (read) -> Y2 -> W0               (Y2 must not overlap X nor W0)
+    //   decoder      : W0, W1, PT
     static constexpr int FFT_A = ARENA;
     static constexpr int FFT_B = FFT_A + 2 * S::NFFT;
-    static constexpr int END_FFT = FFT_B + 2 * S::NFFT;
-    // phase B (decoder): two conv work buffers + transposed-conv partials
-    static constexpr int W0 = ARENA;
-    static constexpr int W1 = W0 + S::ACT;
-    static constexpr int PT = W1 + S::ACT;                        // [F1][LDP]
-    static constexpr int END_CONV = PT + S::F1 * S::LDP;
-    // phase C (RNNFormer): placed after W0 so rf_post can write W0 while X is alive
-    static constexpr int X = W0 + S::ACT;                         // [F2P][LDX]
+    static constexpr int END_FFT = 4 * S::NFFT;
+    static constexpr int X = ARENA;                               // [F2P][LDX]
     static constexpr int HL = X + S::F2P * S::LDX;                // hidden state / attention out
     static constexpr int GI = HL + S::F2P * S::LDX;               // [F2P][LDG]  (also qkv)
     static constexpr int GH = GI + S::F2P * S::LDG;               // [F2P][LDG]
-    static constexpr int Y1 = GH + S::F2P * S::LDG;               // rf_pre: [F2P][LDC]; rf_post: [F1][LDX]
-    static constexpr int Y1_SIZE = (S::F2P * S::LDC > S::F1 * S::LDX) ? S::F2P * S::LDC : S::F1 * S::LDX;
-    static constexpr int END_RF = Y1 + Y1_SIZE;
-    static constexpr int TOTAL_ = (END_FFT > END_CONV ? END_FFT : END_CONV);
-    static constexpr int TOTAL = (TOTAL_ > END_RF ? TOTAL_ : END_RF);
+    static constexpr int END_RF = 2 * S::F2P * S::LDX + 2 * S::F2P * S::LDG;
+    static constexpr int Y1 = GI;                                 // rf_pre intermediate [F2P][LDC]
+    static constexpr int W0 = ARENA;
+    static constexpr int W1 = W0 + S::ACT;
+    static constexpr int PT = W1 + S::ACT;                        // [F1][LDP]
+    static constexpr int END_CONV = 2 * S::ACT + S::F1 * S::LDP;
+    static constexpr int Y2_OFF = cmax(2 * S::F2P * S::LDX, S::ACT);
+    static constexpr int Y2 = ARENA + Y2_OFF;                     // rf_post intermediate [F1][LDX]
+    static constexpr int END_Y2 = Y2_OFF + S::F1 * S::LDX;
+    static constexpr int ARENA_SIZE = cmax(cmax(END_FFT, END_RF), cmax(END_CONV, END_Y2));
+    static constexpr int NOSTAGE_TOTAL = ARENA + ARENA_SIZE;
+    // weights are staged through two LDS buffers (one GEMM phase ahead) whenever they fit
+    static constexpr bool STAGED = (size_t)(NOSTAGE_TOTAL + 2 * S::U_MAX) * 4 <= 160 * 1024;
+    static constexpr int WB0 = NOSTAGE_TOTAL;
+    static constexpr int WB1 = WB0 + S::U_MAX;
+    static constexpr int TOTAL = STAGED ? NOSTAGE_TOTAL + 2 * S::U_MAX : NOSTAGE_TOTAL;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
-    static_assert(2 * S::ACT >= 4 * S::NFFT, "FFT ping-pong buffers must not reach the transposed-conv partials");
+    static_assert(2 * S::ACT >= 2 * S::NFFT, "FFT_A must not reach the transposed-conv partials");
+    static_assert(S::F2P * S::LDC <= 2 * S::F2P * S::LDG, "rf_pre intermediate must fit in GI+GH");
 };
 
 // ------------------------------------------------------------------------------------------
@@ -240,12 +347,23 @@ __device__ __forceinline__ float2* fft_lds(float2* x, float2* y, const float2* t
 // conv-layout GEMM segment: this wave's m-tiles (wave + 4*i) x all NT n-tiles, K = 4*KS.
 //   a_lane : LDS pointer to A[(16*wave + (lane&15)) rows][(lane>>4) col] of the segment
 //   w_lane : packed weights + lane, at k-step 0 of this segment;  KS_TOT = k-steps per n-tile
-template <class S, int NT, int KS, int KS_TOT, int LDA>
-__device__ __forceinline__ void conv_seg(f32x4 (&acc)[S::MTPW][NT], const float* a_lane, const float* __restrict__ w_lane) {
+template <class S, int NT, int KS, int KS_TOT, int LDA, class WS>
+__device__ __forceinline__ void conv_seg(f32x4 (&acc)[S::MTPW][NT], const float* a_lane, const WS& w, int w_off) {
     mma_panel<S::MTPW, NT, KS>(
         acc,
         [&](int i, int ks) { return a_lane[(64 * i) * LDA + 4 * ks]; },
-        [&](int j, int ks) { return w_lane[(j * KS_TOT + ks) * 64]; });
+        [&](int j, int ks) { return w.at(w_off + (j * KS_TOT + ks) * 64); });
+}
+
+// Several K-segments (conv taps / concatenated inputs) accumulated in ONE software pipeline:
+// segment s reads its A rows through a_lane[s]; the packed weights hold the segments' k-steps
+// back to back (k-step index = s * KS_SEG + ks).
+template <class S, int NT, int NSEG, int KS_SEG, int LDA, class WS>
+__device__ __forceinline__ void conv_multi(f32x4 (&acc)[S::MTPW][NT], const float* const (&a_lane)[NSEG], const WS& w, int w_off) {
+    mma_panel<S::MTPW, NT, NSEG * KS_SEG>(
+        acc,
+        [&](int i, int ks) { return a_lane[ks / KS_SEG][(64 * i) * LDA + 4 * (ks % KS_SEG)]; },
+        [&](int j, int ks) { return w.at(w_off + (j * (NSEG * KS_SEG) + ks) * 64); });
 }
 
 // Epilogue of a conv-layout GEMM: optional SiLU, store to out[(row0 + m)][col] for col < NCOLS.
@@ -270,21 +388,21 @@ __device__ __forceinline__ void conv_store(const f32x4 (&acc)[S::MTPW][NT], floa
 }
 
 // token-layout GEMM: all MT2 m-tiles x this wave's n-tiles (wave + 4*j), A from LDS, B packed.
-template <class S, int NTPW, int KS, int LDA>
-__device__ __forceinline__ void tok_gemm(f32x4 (&acc)[S::MT2][NTPW], const float* a_lane, const float* __restrict__ w_lane, int NT, int wave) {
+template <class S, int NTPW, int KS, int LDA, class WS>
+__device__ __forceinline__ void tok_gemm(f32x4 (&acc)[S::MT2][NTPW], const float* a_lane, const WS& w, int w_off, int NT, int wave) {
     mma_panel<S::MT2, NTPW, KS>(
         acc,
         [&](int i, int ks) { return a_lane[(16 * i) * LDA + 4 * ks]; },
         [&](int j, int ks) {
             int nt = wave + 4 * j;
             nt = nt < NT ? nt : NT - 1;
-            return w_lane[(nt * KS + ks) * 64];
+            return w.at(w_off + (nt * KS + ks) * 64);
         });
 }
 
 // ------------------------------------------------------------------------------------------
 template <class S, bool SPEC_MODE>
-__global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) fe_frame_kernel(FrameArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = Lds<S>;
     constexpr int N = S::NFFT, H = S::HOP, OVL = S::OVL, F0 = S::F0, F1 = S::F1;
@@ -297,6 +415,12 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
     const int li = lane & 15, lg = lane >> 4;
     const int b = blockIdx.x;
     const float* __restrict__ wp = a.wp;
+    WSrc<Lds<S>::STAGED> wb;
+    wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, a.off.total * 4, 0x00020000);
+    wb.lane4 = lane * 4;
+    wb.li4 = (lane & 15) * 4;
+    wb.lds = nullptr;
+    wb.base = 0;
     const PackedOffsets& o = a.off;
 
     // ---- one-time: zero LDS (halo rows, pad rows), load twiddles
@@ -308,6 +432,9 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
     float2* fa = reinterpret_cast<float2*>(smem + L::FFT_A);
     float2* fb = reinterpret_cast<float2*>(smem + L::FFT_B);
     float* Ebuf = smem + L::E;
+    // weight units: unit `ucur` is consumed from LDS buffer (ucount & 1) while the next one streams in
+    int ucount = 0, ucur = 0;
+    if constexpr (L::STAGED) stage_unit(wp + a.off.u_off[0], smem + L::WB0, a.off.u_size[0], wave, lane);
     __syncthreads();
 
     float* cst = a.cache_stft + (size_t)b * OVL;
@@ -315,6 +442,22 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
 
 #pragma unroll 1
     for (int t = 0; t < a.T; ++t) {
+        // Called right after the barrier that precedes each GEMM phase, in the packer's unit order:
+        // selects the staged copy of this phase's weights and starts the DMA of the next phase's.
+        auto begin_unit = [&]() {
+            if constexpr (L::STAGED) {
+                const int slot = ucount & 1;
+                int un = ucur + 1;
+                const bool has_next = (un < S::NU) || (t + 1 < a.T);
+                if (un == S::NU) un = 0;
+                if (has_next) stage_unit(wp + o.u_off[un], smem + (slot ? L::WB0 : L::WB1), o.u_size[un], wave, lane);
+                wb.lds = smem + (slot ? L::WB1 : L::WB0);
+                wb.base = o.u_off[ucur];
+            }
+            ++ucount;
+            ucur = (ucur + 1 == S::NU) ? 0 : ucur + 1;
+        };
+        FE_CLK(0);
         // =========================== STFT (a3) ===========================
         if (!SPEC_MODE) {
             const float* win = wp + o.window;
@@ -327,7 +470,9 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
             __syncthreads();
             for (int m = tid; m < OVL; m += kThreads) cst[m] = fb[m + H].x;   // cache' = frame[H:]
             __syncthreads();
+            FE_CLK(1);
             float2* X = fft_lds<S, false>(fa, fb, tw);
+            FE_CLK(2);
             // spectrum bins 0..F0 (F0 = Nyquist, dropped by the model)
             if (a.dbg) {
                 float* dst = a.dbg + (size_t)b * a.dbg_stride + DebugLayout<S>::offset(0);
@@ -357,11 +502,12 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
             for (int f = tid; f < F0; f += kThreads) { dst[2 * f] = sc[2 + f]; dst[2 * f + 1] = sc[S::LDS_S + 2 + f]; }
         }
 
+        FE_CLK(3);
         // =========================== enc_pre (a5): strided conv as K=16 GEMM ===========================
         {
+            begin_unit();
             f32x4 acc[S::MTPW][S::NTC];
-            acc_init_bias<S::MTPW, S::NTC>(acc, wp + o.enc_pre_b + li, 0, 1, S::NTC);
-            const float* wl = wp + o.enc_pre_w + lane;
+            acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.enc_pre_b, 0, 1, S::NTC);
             // k = t*8 + s*2 + c  (weight (C1, 8, 2): channel index s*2+c, tap t);  A[m][k] = xpad[c][4(m+t)+s]
             mma_panel<S::MTPW, S::NTC, 4>(
                 acc,
@@ -371,23 +517,24 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
                     const int m = 16 * (wave + 4 * i) + li;
                     return sc[c * S::LDS_S + 4 * (m + tp) + s];
                 },
-                [&](int j, int ks) { return wl[(j * 4 + ks) * 64]; });
+                [&](int j, int ks) { return wb.at(o.enc_pre_w + (j * 4 + ks) * 64); });
             conv_store<S, S::NTC, C1, LDC, true>(acc, Ebuf, 1, wave, lane);
         }
         __syncthreads();
         dbg_dump<S>(a, b, 2, Ebuf + LDC, LDC);
 
+        FE_CLK(4);
         // =========================== encoder (a6): k=3 convs ===========================
 #pragma unroll
         for (int l = 0; l < S::NL; ++l) {
             const float* in = Ebuf + l * S::ACT;
             float* out = Ebuf + (l + 1) * S::ACT;
+            begin_unit();
             f32x4 acc[S::MTPW][S::NTC];
-            acc_init_bias<S::MTPW, S::NTC>(acc, wp + o.enc_b[l] + li, 0, 1, S::NTC);
-            const float* wl = wp + o.enc_w[l] + lane;
-#pragma unroll
-            for (int tap = 0; tap < 3; ++tap)
-                conv_seg<S, S::NTC, S::KS_C, 3 * S::KS_C, LDC>(acc, in + (16 * wave + li + tap) * LDC + lg, wl + tap * S::KS_C * 64);
+            acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.enc_b[l], 0, 1, S::NTC);
+            const float* const taps[3] = {in + (16 * wave + li + 0) * LDC + lg, in + (16 * wave + li + 1) * LDC + lg,
+                                          in + (16 * wave + li + 2) * LDC + lg};
+            conv_multi<S, S::NTC, 3, S::KS_C, LDC>(acc, taps, wb, o.enc_w[l]);
             conv_store<S, S::NTC, C1, LDC, true>(acc, out, 1, wave, lane);
             __syncthreads();
             dbg_dump<S>(a, b, 3 + l, out + LDC, LDC);
@@ -398,19 +545,21 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
         float* Gi = smem + L::GI;
         float* Gh = smem + L::GH;
         float* Y1 = smem + L::Y1;
+        float* Y2 = smem + L::Y2;
 
+        FE_CLK(5);
         // =========================== rf_pre (a7) ===========================
         {
             // Y1[f2][c1] = sum_f1 Wf[f2][f1] * E[f1][c1]      (A = packed filterbank, B = LDS)
             constexpr int NTPW = ceil_div(S::NTC, kWaves);
             constexpr int KS = F1 / 4;
             const float* Ein = Ebuf + S::NL * S::ACT + LDC;   // row 0 = bin 0
+            begin_unit();
             f32x4 acc[S::MT2][NTPW];
-            acc_init_bias<S::MT2, NTPW>(acc, nullptr, 0, 1, 1);
-            const float* al = wp + o.rfpre_lin + lane;
+            acc_init_zero<S::MT2, NTPW>(acc);
             mma_panel<S::MT2, NTPW, KS>(
                 acc,
-                [&](int i, int ks) { return al[(i * KS + ks) * 64]; },
+                [&](int i, int ks) { return wb.at(o.rfpre_lin + (i * KS + ks) * 64); },
                 [&](int j, int ks) {
                     int nt = wave + 4 * j;
                     nt = nt < S::NTC ? nt : S::NTC - 1;
@@ -435,9 +584,10 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
         {
             // X[f2][c2] = Y1[f2][:] . Wc[c2][:] + b
             constexpr int NTPW = ceil_div(S::NT2, kWaves);
+            begin_unit();
             f32x4 acc[S::MT2][NTPW];
-            acc_init_bias<S::MT2, NTPW>(acc, wp + o.rfpre_b + li, wave, 4, S::NT2);
-            tok_gemm<S, NTPW, S::KS_C, LDC>(acc, Y1 + li * LDC + lg, wp + o.rfpre_w + lane, S::NT2, wave);
+            acc_init_bias<S::MT2, NTPW>(acc, wb, o.rfpre_b, wave, 4, S::NT2);
+            tok_gemm<S, NTPW, S::KS_C, LDC>(acc, Y1 + li * LDC + lg, wb, o.rfpre_w, S::NT2, wave);
 #pragma unroll
             for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -456,6 +606,7 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
         __syncthreads();
         dbg_dump<S>(a, b, 3 + S::NL, Xb, LDX);
 
+        FE_CLK(6);
         // =========================== RNNFormer blocks (a9-a11) ===========================
 #pragma unroll 1
         for (int k = 0; k < S::KB; ++k) {
@@ -465,18 +616,20 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
                 Hl[f * LDX + c] = hg[i];
             }
             __syncthreads();
+            if (k == 0) FE_CLK(20);
             {
                 // gi = x W_ih^T + b_ih ; gh = h W_hh^T + b_hh
+                begin_unit();
                 constexpr int NTPW = ceil_div(S::NT3, kWaves);
 #pragma unroll
                 for (int which = 0; which < 2; ++which) {
                     f32x4 acc[S::MT2][NTPW];
-                    const float* bias = wp + (which == 0 ? o.blk_bih[k] : o.blk_bhh[k]) + li;
-                    const float* wsrc = wp + (which == 0 ? o.blk_wih[k] : o.blk_whh[k]) + lane;
+                    const int bias = which == 0 ? o.blk_bih[k] : o.blk_bhh[k];
+                    const int wsrc = which == 0 ? o.blk_wih[k] : o.blk_whh[k];
                     const float* asrc = (which == 0 ? Xb : Hl) + li * LDX + lg;
                     float* dst = which == 0 ? Gi : Gh;
-                    acc_init_bias<S::MT2, NTPW>(acc, bias, wave, 4, S::NT3);
-                    tok_gemm<S, NTPW, S::KS_2, LDX>(acc, asrc, wsrc, S::NT3, wave);
+                    acc_init_bias<S::MT2, NTPW>(acc, wb, bias, wave, 4, S::NT3);
+                    tok_gemm<S, NTPW, S::KS_2, LDX>(acc, asrc, wb, wsrc, S::NT3, wave);
 #pragma unroll
                     for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -493,6 +646,7 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
                 }
             }
             __syncthreads();
+            if (k == 0) FE_CLK(21);
             // gates (PyTorch order r,z,n) and state update
             for (int i = tid; i < F2 * C2; i += kThreads) {
                 int f = i / C2, c = i - f * C2;
@@ -507,13 +661,14 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
                 hg[i] = hn;
             }
             __syncthreads();
+            if (k == 0) FE_CLK(22);
             {
                 // x += rnn_fc(h') (+ pe in block 0)
                 constexpr int NTPW = ceil_div(S::NT2, kWaves);
+                begin_unit();
                 f32x4 acc[S::MT2][NTPW];
-                acc_init_bias<S::MT2, NTPW>(acc, wp + o.blk_fc1_b[k] + li, wave, 4, S::NT2);
-                tok_gemm<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, wp + o.blk_fc1_w[k] + lane, S::NT2, wave);
-                const float* pe = wp + o.blk_pe;
+                acc_init_bias<S::MT2, NTPW>(acc, wb, o.blk_fc1_b[k], wave, 4, S::NT2);
+                tok_gemm<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, wb, o.blk_fc1_w[k], S::NT2, wave);
 #pragma unroll
                 for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -526,7 +681,7 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
                                 const int row = 16 * i + 4 * lg + r;
                                 if (row < F2) {
                                     float v = acc[i][j][r] + Xb[row * LDX + col];
-                                    if (k == 0) v += pe[row * C2 + col];
+                                    if (k == 0) v += wb.gather(o.blk_pe + row * C2 + col);
                                     Xb[row * LDX + col] = v;
                                 }
                             }
@@ -535,12 +690,14 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
             }
             __syncthreads();
             dbg_dump<S>(a, b, 4 + S::NL + 2 * k, Xb, LDX);
+            if (k == 0) FE_CLK(23);
             {
                 // qkv = x W_qkv^T  -> Gi (rows per head interleaved [h][q|k|v][hd])
                 constexpr int NTPW = ceil_div(S::NT3, kWaves);
+                begin_unit();
                 f32x4 acc[S::MT2][NTPW];
-                acc_init_bias<S::MT2, NTPW>(acc, nullptr, 0, 1, 1);
-                tok_gemm<S, NTPW, S::KS_2, LDX>(acc, Xb + li * LDX + lg, wp + o.blk_qkv[k] + lane, S::NT3, wave);
+                acc_init_zero<S::MT2, NTPW>(acc);
+                tok_gemm<S, NTPW, S::KS_2, LDX>(acc, Xb + li * LDX + lg, wb, o.blk_qkv[k], S::NT3, wave);
 #pragma unroll
                 for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -556,13 +713,14 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
                     }
             }
             __syncthreads();
+            if (k == 0) FE_CLK(24);
             {
                 // attention: wave = head.  S^T[key][query] = K Q^T, softmax over keys, O^T = V^T P^T
                 const int hoff = wave * 3 * HD;
                 constexpr int KSD = ceil_div(HD, 4);
                 constexpr int MTD = ceil_div(HD, 16);
                 f32x4 sacc[S::MT2][S::MT2];
-                acc_init_bias<S::MT2, S::MT2>(sacc, nullptr, 0, 1, 1);
+                acc_init_zero<S::MT2, S::MT2>(sacc);
                 mma_panel<S::MT2, S::MT2, KSD>(
                     sacc,
                     [&](int i, int ks) {
@@ -609,7 +767,7 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
                         for (int r = 0; r < 4; ++r) sacc[i][j][r] *= inv;
                 }
                 f32x4 oacc[MTD][S::MT2];
-                acc_init_bias<MTD, S::MT2>(oacc, nullptr, 0, 1, 1);
+                acc_init_zero<MTD, S::MT2>(oacc);
                 // k-step (i, r): lane group lg supplies key = 16 i + 4 lg + r  (matches the C/D row map)
 #pragma unroll
                 for (int i = 0; i < S::MT2; ++i)
@@ -643,12 +801,14 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
                     }
             }
             __syncthreads();
+            if (k == 0) FE_CLK(25);
             {
                 // x += attn_fc(o)
                 constexpr int NTPW = ceil_div(S::NT2, kWaves);
+                begin_unit();
                 f32x4 acc[S::MT2][NTPW];
-                acc_init_bias<S::MT2, NTPW>(acc, wp + o.blk_fc2_b[k] + li, wave, 4, S::NT2);
-                tok_gemm<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, wp + o.blk_fc2_w[k] + lane, S::NT2, wave);
+                acc_init_bias<S::MT2, NTPW>(acc, wb, o.blk_fc2_b[k], wave, 4, S::NT2);
+                tok_gemm<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, wb, o.blk_fc2_w[k], S::NT2, wave);
 #pragma unroll
                 for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -665,29 +825,32 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
                     }
             }
             __syncthreads();
+            if (k == 0) FE_CLK(26);
             dbg_dump<S>(a, b, 5 + S::NL + 2 * k, Xb, LDX);
         }
 
+        FE_CLK(7);
         // =========================== rf_post (a13) ===========================
         float* W0 = smem + L::W0;
         float* W1 = smem + L::W1;
         {
             // Y2[f1][c2] = sum_f2 Wp[f1][f2] X[f2][c2]      (A packed, B = LDS tokens)
             constexpr int KS = F2 / 4;
+            begin_unit();
             f32x4 acc[S::MTPW][S::NT2];
-            acc_init_bias<S::MTPW, S::NT2>(acc, nullptr, 0, 1, 1);
-            const float* al = wp + o.rfpost_lin + lane;
+            acc_init_zero<S::MTPW, S::NT2>(acc);
             mma_panel<S::MTPW, S::NT2, KS>(
                 acc,
-                [&](int i, int ks) { return al[((wave + 4 * i) * KS + ks) * 64]; },
+                [&](int i, int ks) { return wb.at(o.rfpost_lin + ((wave + 4 * i) * KS + ks) * 64); },
                 [&](int j, int ks) { return Xb[(4 * ks + lg) * LDX + 16 * j + li]; });
-            conv_store<S, S::NT2, C2, LDX, false>(acc, Y1, 0, wave, lane);
+            conv_store<S, S::NT2, C2, LDX, false>(acc, Y2, 0, wave, lane);
         }
         __syncthreads();
         {
+            begin_unit();
             f32x4 acc[S::MTPW][S::NTC];
-            acc_init_bias<S::MTPW, S::NTC>(acc, wp + o.rfpost_b + li, 0, 1, S::NTC);
-            conv_seg<S, S::NTC, S::KS_2, S::KS_2, LDX>(acc, Y1 + (16 * wave + li) * LDX + lg, wp + o.rfpost_w + lane);
+            acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.rfpost_b, 0, 1, S::NTC);
+            conv_seg<S, S::NTC, S::KS_2, S::KS_2, LDX>(acc, Y2 + (16 * wave + li) * LDX + lg, wb, o.rfpost_w);
             conv_store<S, S::NTC, C1, LDC, false>(acc, W0, 1, wave, lane);
         }
         __syncthreads();
@@ -698,55 +861,59 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
         }
         dbg_dump<S>(a, b, 4 + S::NL + 2 * S::KB, W0 + LDC, LDC);
 
+        FE_CLK(8);
         // =========================== decoder (a14) ===========================
 #pragma unroll
         for (int l = 0; l < S::NL; ++l) {
             const float* skip = Ebuf + (S::NL - l) * S::ACT;
             {
+                begin_unit();
                 f32x4 acc[S::MTPW][S::NTC];
-                acc_init_bias<S::MTPW, S::NTC>(acc, wp + o.dec1_b[l] + li, 0, 1, S::NTC);
-                const float* wl = wp + o.dec1_w[l] + lane;
-                conv_seg<S, S::NTC, S::KS_C, 2 * S::KS_C, LDC>(acc, W0 + (16 * wave + li + 1) * LDC + lg, wl);
-                conv_seg<S, S::NTC, S::KS_C, 2 * S::KS_C, LDC>(acc, skip + (16 * wave + li + 1) * LDC + lg, wl + S::KS_C * 64);
+                acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.dec1_b[l], 0, 1, S::NTC);
+                const float* const segs[2] = {W0 + (16 * wave + li + 1) * LDC + lg, skip + (16 * wave + li + 1) * LDC + lg};
+                conv_multi<S, S::NTC, 2, S::KS_C, LDC>(acc, segs, wb, o.dec1_w[l]);
                 conv_store<S, S::NTC, C1, LDC, true>(acc, W1, 1, wave, lane);
             }
             __syncthreads();
             {
+                begin_unit();
                 f32x4 acc[S::MTPW][S::NTC];
-                acc_init_bias<S::MTPW, S::NTC>(acc, wp + o.dec3_b[l] + li, 0, 1, S::NTC);
-                const float* wl = wp + o.dec3_w[l] + lane;
-#pragma unroll
-                for (int tap = 0; tap < 3; ++tap)
-                    conv_seg<S, S::NTC, S::KS_C, 3 * S::KS_C, LDC>(acc, W1 + (16 * wave + li + tap) * LDC + lg, wl + tap * S::KS_C * 64);
+                acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.dec3_b[l], 0, 1, S::NTC);
+                const float* const taps[3] = {W1 + (16 * wave + li + 0) * LDC + lg, W1 + (16 * wave + li + 1) * LDC + lg,
+                                              W1 + (16 * wave + li + 2) * LDC + lg};
+                conv_multi<S, S::NTC, 3, S::KS_C, LDC>(acc, taps, wb, o.dec3_w[l]);
                 conv_store<S, S::NTC, C1, LDC, true>(acc, W0, 1, wave, lane);   // W0 was fully consumed before the barrier above
             }
             __syncthreads();
             dbg_dump<S>(a, b, 5 + S::NL + 2 * S::KB + l, W0 + LDC, LDC);
         }
 
+        FE_CLK(9);
         // =========================== dec_post (a15) ===========================
         float* PT = smem + L::PT;
         {
+            begin_unit();
             f32x4 acc[S::MTPW][S::NTC];
-            acc_init_bias<S::MTPW, S::NTC>(acc, wp + o.post1_b + li, 0, 1, S::NTC);
-            const float* wl = wp + o.post1_w + lane;
-            conv_seg<S, S::NTC, S::KS_C, 2 * S::KS_C, LDC>(acc, W0 + (16 * wave + li + 1) * LDC + lg, wl);
-            conv_seg<S, S::NTC, S::KS_C, 2 * S::KS_C, LDC>(acc, Ebuf + (16 * wave + li + 1) * LDC + lg, wl + S::KS_C * 64);
+            acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.post1_b, 0, 1, S::NTC);
+            const float* const segs[2] = {W0 + (16 * wave + li + 1) * LDC + lg, Ebuf + (16 * wave + li + 1) * LDC + lg};
+            conv_multi<S, S::NTC, 2, S::KS_C, LDC>(acc, segs, wb, o.post1_w);
             conv_store<S, S::NTC, C1, LDC, true>(acc, W1, 1, wave, lane);
         }
         __syncthreads();
         {
             // transposed conv as GEMM: P[i][co*8+j] = sum_ci x[i][ci] w[ci][co][j]
+            begin_unit();
             f32x4 acc[S::MTPW][1];
-            acc_init_bias<S::MTPW, 1>(acc, nullptr, 0, 1, 1);
-            conv_seg<S, 1, S::KS_C, S::KS_C, LDC>(acc, W1 + (16 * wave + li + 1) * LDC + lg, wp + o.post_t_w + lane);
+            acc_init_zero<S::MTPW, 1>(acc);
+            conv_seg<S, 1, S::KS_C, S::KS_C, LDC>(acc, W1 + (16 * wave + li + 1) * LDC + lg, wb, o.post_t_w);
             conv_store<S, 1, 16, S::LDP, false>(acc, PT, 0, wave, lane);
         }
         __syncthreads();
 
+        FE_CLK(10);
         // =========================== mask, un-compress (a16, a17), Hermitian spectrum ===========================
         {
-            const float b0 = wp[o.post_t_b], b1 = wp[o.post_t_b + 1];
+            const float b0 = wb.scalar(o.post_t_b), b1 = wb.scalar(o.post_t_b + 1);
             float* spo = SPEC_MODE ? a.spec_out + (size_t)b * (F0 + 1) * a.T * 2 : nullptr;
             for (int f = tid; f < F0; f += kThreads) {
                 const int q = f + 2, j1 = q & 3, i1 = q >> 2;
@@ -785,9 +952,11 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
         }
         __syncthreads();
 
+        FE_CLK(11);
         // =========================== iSTFT (a18) ===========================
         if (!SPEC_MODE) {
             float2* y = fft_lds<S, true>(fa, fb, tw);
+            FE_CLK(12);
             float2* spare = (y == fa) ? fb : fa;
             const float* wi = wp + o.window_istft;
             float* xo = reinterpret_cast<float*>(spare);
@@ -803,6 +972,7 @@ __global__ void __launch_bounds__(kThreads, 1) fe_frame_kernel(FrameArgs a) {
             for (int m = tid; m < OVL; m += kThreads) cis[m] = xo[m + H];
             __syncthreads();
         }
+        FE_CLK(13);
     }
 }
 

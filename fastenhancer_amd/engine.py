@@ -145,6 +145,18 @@ class Engine:
             _lib.check(self.lib.fe_spec_step(self._h, _ptr(spec), _ptr(h), _ptr(out), B, T, _stream(self.device)), "fe_spec_step")
         return out
 
+    def profile_step(self, wav_in: Tensor, state: Tensor, T: int = 1) -> Tensor:
+        """Phase cycle counters (int64[64]) of workgroup 0 for the last frame of the launch."""
+        self._require_gpu()
+        B = wav_in.shape[0]
+        H = self.cfg.hop_size
+        clk = torch.zeros(64, dtype=torch.int64, device=wav_in.device)
+        out = torch.empty(B, T * H, dtype=torch.float32, device=wav_in.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fe_profile_step(self._h, _ptr(wav_in), wav_in.stride(0), _ptr(state), _ptr(out), T * H, B, T,
+                                                _ptr(clk), _stream(self.device)), "fe_profile_step")
+        return clk
+
     def debug_stages(self) -> List[Tuple[str, int, int, int]]:
         out = []
         for i in range(self.lib.fe_debug_stages(self._h)):

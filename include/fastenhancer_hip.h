@@ -108,6 +108,11 @@ size_t fe_debug_floats(const fe_handle* h);   /* per stream */
 int fe_debug_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, float* state_dev,
                   float* wav_out_dev, size_t out_stride, int B, float* dbg_dev, void* stream);
 
+/* Profiling: like fe_step, and thread 0 of workgroup 0 stores the shader cycle counter (s_memtime) at
+ * the phase boundaries of the LAST frame into clk_dev[0..63] (see fe_kernels.hip.h, FE_CLK). */
+int fe_profile_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, float* state_dev,
+                    float* wav_out_dev, size_t out_stride, int B, int T, unsigned long long* clk_dev, void* stream);
+
 const char* fe_last_error(void);
 const char* fe_version(void);
 

@@ -31,7 +31,8 @@ def _assert_close(got, ref, what):
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     assert np.isfinite(got).all(), what
     err, r = rms(got - ref), rms(ref)
-    assert err < ABS_TOL and err <= REL_TOL * max(r, 1e-3), f"{what}: rms err {err:.3e}, ref rms {r:.3e}"
+    # absolute 1e-4 for audio-level signals (rms <= 1), relative 1e-4 always
+    assert err < ABS_TOL * max(1.0, r) and err <= REL_TOL * max(r, 1e-3), f"{what}: rms err {err:.3e}, ref rms {r:.3e}"
     return err / max(r, 1e-12)
 
 

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Phase breakdown of one frame (shader cycles of workgroup 0) via fe_profile_step."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from common import MODEL_KWARGS  # noqa: E402
+from fastenhancer_amd.config import FEConfig  # noqa: E402
+from fastenhancer_amd.engine import Engine  # noqa: E402
+from fastenhancer_amd.weights import default_state_dict  # noqa: E402
+
+NAMES = ["stft load", "fft", "spec dump", "compress", "enc_pre", "encoder", "rf_pre", "blocks", "rf_post", "decoder",
+         "dec_post", "mask", "ifft", "ola"]
+BLK = ["h load", "gi/gh gemm", "gates", "fc1", "qkv", "attention", "fc2"]
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "fe_b"
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    dev = torch.device("cuda:0")
+    cfg = FEConfig.from_model_kwargs(**MODEL_KWARGS[name][0])
+    eng = Engine(cfg, dev)
+    eng.load_state_dict(default_state_dict(cfg, torch.Generator().manual_seed(1)))
+    H = cfg.hop_size
+    T = 4
+    x = (0.1 * torch.randn(B, T * H, device=dev)).contiguous()
+    st = eng.new_state(B)
+    for _ in range(3):
+        clk = eng.profile_step(x, st, T=T)
+    torch.cuda.synchronize()
+    c = clk.cpu().numpy()
+    tot = c[13] - c[0]
+    print(f"{name} B={B}: frame = {tot} cycles")
+    for i in range(13):
+        d = c[i + 1] - c[i]
+        print(f"  {NAMES[i + 1] if False else NAMES[i]:12s}->{NAMES[i+1] if i+1 < len(NAMES) else 'end':12s} {d:8d} cyc  {100.0 * d / tot:5.1f}%")
+    print("  block 0 detail:")
+    prev = c[20]
+    for i, nm in enumerate(BLK[1:], start=21):
+        print(f"    {nm:12s} {c[i] - prev:8d} cyc")
+        prev = c[i]
+
+
+if __name__ == "__main__":
+    main()
