@@ -52,6 +52,7 @@ struct Impl {
     bool staged;
     size_t dbg_floats;
     int dbg_stages;
+    const fe::PackedOffsets* off;
     void (*launch)(const fe::FrameArgs&, bool spec_mode, hipStream_t, hipError_t*);
     void (*dbg_stage)(int, int*, int*, size_t*);
 };
@@ -85,8 +86,8 @@ void dbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
 
 template <class S>
 Impl make_impl() {
-    return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, fe::Lds<S>::BYTES, S::NU, S::U_MAX, fe::Lds<S>::STAGED,
-                fe::DebugLayout<S>::total(), fe::DebugLayout<S>::n_stages, &launch_impl<S>, &dbg_stage_impl<S>};
+    return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, fe::Lds<S>::BYTES, S::NU, fe::Pack<S>::umax(), fe::Lds<S>::STAGED,
+                fe::DebugLayout<S>::total(), fe::DebugLayout<S>::n_stages, &fe::Pack<S>::v, &launch_impl<S>, &dbg_stage_impl<S>};
 }
 
 // Shapes of the shipped yamls (configs/fastenhancer/*.yaml, configs/fastenhancer_48khz/*.yaml).
@@ -114,7 +115,6 @@ struct fe_handle {
     std::vector<Section> sections;
     size_t blob_floats = 0;
     float* packed_dev = nullptr;
-    fe::PackedOffsets off{};
     bool loaded = false;
     std::vector<float> window, window_istft, twiddle;
 };
@@ -195,58 +195,30 @@ void build_tables(fe_handle* h) {
     }
 }
 
+// Writes fragments at the compile-time offsets of fe::Pack<S>::v (the kernel uses the same table).
 struct Packer {
     std::vector<float> buf;
-    std::vector<int> u_off, u_size;
-    int alloc(size_t n) {
-        size_t off = (buf.size() + 63) & ~(size_t)63;   // 256-byte aligned sections
-        buf.resize(off + n, 0.0f);
-        return (int)off;
-    }
-    // A unit = the arrays of one GEMM phase, contiguous, 1-KiB aligned and padded (staged into LDS as a whole).
-    void begin_unit() {
-        buf.resize((buf.size() + 255) & ~(size_t)255, 0.0f);
-        u_off.push_back((int)buf.size());
-    }
-    void end_unit() {
-        buf.resize((buf.size() + 255) & ~(size_t)255, 0.0f);
-        u_size.push_back((int)buf.size() - u_off.back());
-    }
     // B operand in fragment order: dst[(nt*KS + ks)*64 + lane] = B(k = 4ks + lane/16, n = 16nt + lane%16)
-    int pack_b(int K, int Ncols, const std::function<float(int, int)>& Bkn) {
+    void pack_b(int off, int K, int Ncols, const std::function<float(int, int)>& Bkn) {
         const int KS = K / 4, NT = (Ncols + 15) / 16;
-        int off = alloc((size_t)NT * KS * 64);
         for (int nt = 0; nt < NT; ++nt)
             for (int ks = 0; ks < KS; ++ks)
                 for (int lane = 0; lane < 64; ++lane) {
                     int k = 4 * ks + lane / 16, n = 16 * nt + lane % 16;
                     buf[off + ((size_t)nt * KS + ks) * 64 + lane] = n < Ncols ? Bkn(k, n) : 0.0f;
                 }
-        return off;
     }
     // A operand: dst[(mt*KS + ks)*64 + lane] = A(m = 16mt + lane%16, k = 4ks + lane/16)
-    int pack_a(int Mrows, int K, const std::function<float(int, int)>& Amk) {
+    void pack_a(int off, int Mrows, int K, const std::function<float(int, int)>& Amk) {
         const int KS = K / 4, MT = (Mrows + 15) / 16;
-        int off = alloc((size_t)MT * KS * 64);
         for (int mt = 0; mt < MT; ++mt)
             for (int ks = 0; ks < KS; ++ks)
                 for (int lane = 0; lane < 64; ++lane) {
                     int m = 16 * mt + lane % 16, k = 4 * ks + lane / 16;
                     buf[off + ((size_t)mt * KS + ks) * 64 + lane] = m < Mrows ? Amk(m, k) : 0.0f;
                 }
-        return off;
     }
-    int pack_bias(int n, const float* src) {
-        int np = ((n + 15) / 16) * 16;
-        int off = alloc(np);
-        for (int i = 0; i < n; ++i) buf[off + i] = src[i];
-        return off;
-    }
-    int raw(size_t n, const float* src) {
-        int off = alloc(n);
-        memcpy(&buf[off], src, n * sizeof(float));
-        return off;
-    }
+    void raw(int off, size_t n, const float* src) { memcpy(&buf[off], src, n * sizeof(float)); }
 };
 
 const float* sec(const fe_handle* h, const std::vector<float>& blob, const std::string& name) {
@@ -258,106 +230,67 @@ const float* sec(const fe_handle* h, const std::vector<float>& blob, const std::
 int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float>* out) {
     const Dims& d = h->d;
     const int C1 = d.C1, C2 = d.C2, F1 = d.F1, F2 = d.F2;
+    const fe::PackedOffsets& o = *h->impl->off;
     Packer p;
-    fe::PackedOffsets& o = h->off;
+    p.buf.assign((size_t)o.total, 0.0f);
     char nm[128];
     auto S = [&](const std::string& n) { return sec(h, blob, n); };
-
-    auto pack_k3 = [&](const float* w) {   // (Co, Ci, 3): k = tap*Ci + ci
-        return p.pack_b(3 * C1, C1, [&](int k, int n) { return w[(n * C1 + (k % C1)) * 3 + (k / C1)]; });
+    auto pack_k3 = [&](int off, const float* w) {   // (Co, Ci, 3): k = tap*Ci + ci
+        p.pack_b(off, 3 * C1, C1, [&](int k, int n) { return w[(n * C1 + (k % C1)) * 3 + (k / C1)]; });
     };
-    auto pack_1x1 = [&](const float* w, int Ci, int Co) {   // (Co, Ci[,1]): B[k=ci][n=co]
-        return p.pack_b(Ci, Co, [&](int k, int n) { return w[n * Ci + k]; });
+    auto pack_1x1 = [&](int off, const float* w, int Ci, int Co) {   // (Co, Ci[,1]): B[k=ci][n=co]
+        p.pack_b(off, Ci, Co, [&](int k, int n) { return w[n * Ci + k]; });
     };
-    // Units are packed in the order the kernel consumes them (fe_frame_kernel: begin_unit()).
-    p.begin_unit();
     {   // enc_pre: weight (C1, 8, 2): B[k = t*8 + ch][n = co] = W[co][ch][t]
         const float* w = S("enc_pre.0.weight");
-        o.enc_pre_w = p.pack_b(16, C1, [&](int k, int n) { return w[(n * 8 + (k & 7)) * 2 + (k >> 3)]; });
-        o.enc_pre_b = p.pack_bias(C1, S("enc_pre.0.bias"));
+        p.pack_b(o.enc_pre_w, 16, C1, [&](int k, int n) { return w[(n * 8 + (k & 7)) * 2 + (k >> 3)]; });
+        p.raw(o.enc_pre_b, C1, S("enc_pre.0.bias"));
     }
-    p.end_unit();
     for (int i = 0; i < d.NL; ++i) {
-        p.begin_unit();
-        snprintf(nm, sizeof nm, "encoder.%d.0.weight", i); o.enc_w[i] = pack_k3(S(nm));
-        snprintf(nm, sizeof nm, "encoder.%d.0.bias", i); o.enc_b[i] = p.pack_bias(C1, S(nm));
-        p.end_unit();
+        snprintf(nm, sizeof nm, "encoder.%d.0.weight", i); pack_k3(o.enc_w[i], S(nm));
+        snprintf(nm, sizeof nm, "encoder.%d.0.bias", i); p.raw(o.enc_b[i], C1, S(nm));
     }
     {   // rf_pre: Linear (F2, F1) as A operand, then 1x1 conv (C2, C1)
         const float* w = S("rf_pre.0.weight");
-        p.begin_unit();
-        o.rfpre_lin = p.pack_a(F2, F1, [&](int m, int k) { return w[m * F1 + k]; });
-        p.end_unit();
-        p.begin_unit();
-        o.rfpre_w = pack_1x1(S("rf_pre.1.weight"), C1, C2);
-        o.rfpre_b = p.pack_bias(C2, S("rf_pre.1.bias"));
-        p.end_unit();
+        p.pack_a(o.rfpre_lin, F2, F1, [&](int m, int k) { return w[m * F1 + k]; });
+        pack_1x1(o.rfpre_w, S("rf_pre.1.weight"), C1, C2);
+        p.raw(o.rfpre_b, C2, S("rf_pre.1.bias"));
     }
     for (int k = 0; k < d.KB; ++k) {
         auto key = [&](const char* s) { snprintf(nm, sizeof nm, "rf_block.%d.%s", k, s); return std::string(nm); };
-        p.begin_unit();   // GRU
-        o.blk_wih[k] = pack_1x1(S(key("rnn.weight_ih_l0")), C2, 3 * C2);
-        o.blk_whh[k] = pack_1x1(S(key("rnn.weight_hh_l0")), C2, 3 * C2);
-        o.blk_bih[k] = p.pack_bias(3 * C2, S(key("rnn.bias_ih_l0")));
-        o.blk_bhh[k] = p.pack_bias(3 * C2, S(key("rnn.bias_hh_l0")));
-        p.end_unit();
-        p.begin_unit();   // rnn_fc (+ positional embedding of block 0)
-        o.blk_fc1_w[k] = pack_1x1(S(key("rnn_fc.weight")), C2, C2);
-        o.blk_fc1_b[k] = p.pack_bias(C2, S(key("rnn_fc.bias")));
-        if (k == 0) o.blk_pe = p.raw((size_t)F2 * C2, S(key("pe")));
-        p.end_unit();
-        p.begin_unit();   // qkv
-        o.blk_qkv[k] = pack_1x1(S(key("attn.qkv.weight")), C2, 3 * C2);
-        p.end_unit();
-        p.begin_unit();   // attn_fc
-        o.blk_fc2_w[k] = pack_1x1(S(key("attn_fc.weight")), C2, C2);
-        o.blk_fc2_b[k] = p.pack_bias(C2, S(key("attn_fc.bias")));
-        p.end_unit();
+        pack_1x1(o.blk_wih[k], S(key("rnn.weight_ih_l0")), C2, 3 * C2);
+        pack_1x1(o.blk_whh[k], S(key("rnn.weight_hh_l0")), C2, 3 * C2);
+        p.raw(o.blk_bih[k], 3 * C2, S(key("rnn.bias_ih_l0")));
+        p.raw(o.blk_bhh[k], 3 * C2, S(key("rnn.bias_hh_l0")));
+        pack_1x1(o.blk_fc1_w[k], S(key("rnn_fc.weight")), C2, C2);
+        p.raw(o.blk_fc1_b[k], C2, S(key("rnn_fc.bias")));
+        if (k == 0) p.raw(o.blk_pe, (size_t)F2 * C2, S(key("pe")));
+        pack_1x1(o.blk_qkv[k], S(key("attn.qkv.weight")), C2, 3 * C2);
+        pack_1x1(o.blk_fc2_w[k], S(key("attn_fc.weight")), C2, C2);
+        p.raw(o.blk_fc2_b[k], C2, S(key("attn_fc.bias")));
     }
     {
         const float* w = S("rf_post.0.weight");   // (F1, F2)
-        p.begin_unit();
-        o.rfpost_lin = p.pack_a(F1, F2, [&](int m, int k) { return w[m * F2 + k]; });
-        p.end_unit();
-        p.begin_unit();
-        o.rfpost_w = pack_1x1(S("rf_post.1.weight"), C2, C1);
-        o.rfpost_b = p.pack_bias(C1, S("rf_post.1.bias"));
-        p.end_unit();
+        p.pack_a(o.rfpost_lin, F1, F2, [&](int m, int k) { return w[m * F2 + k]; });
+        pack_1x1(o.rfpost_w, S("rf_post.1.weight"), C2, C1);
+        p.raw(o.rfpost_b, C1, S("rf_post.1.bias"));
     }
     for (int i = 0; i < d.NL; ++i) {
-        p.begin_unit();
-        snprintf(nm, sizeof nm, "decoder.%d.0.weight", i); o.dec1_w[i] = pack_1x1(S(nm), 2 * C1, C1);
-        snprintf(nm, sizeof nm, "decoder.%d.0.bias", i); o.dec1_b[i] = p.pack_bias(C1, S(nm));
-        p.end_unit();
-        p.begin_unit();
-        snprintf(nm, sizeof nm, "decoder.%d.2.weight", i); o.dec3_w[i] = pack_k3(S(nm));
-        snprintf(nm, sizeof nm, "decoder.%d.2.bias", i); o.dec3_b[i] = p.pack_bias(C1, S(nm));
-        p.end_unit();
+        snprintf(nm, sizeof nm, "decoder.%d.0.weight", i); pack_1x1(o.dec1_w[i], S(nm), 2 * C1, C1);
+        snprintf(nm, sizeof nm, "decoder.%d.0.bias", i); p.raw(o.dec1_b[i], C1, S(nm));
+        snprintf(nm, sizeof nm, "decoder.%d.2.weight", i); pack_k3(o.dec3_w[i], S(nm));
+        snprintf(nm, sizeof nm, "decoder.%d.2.bias", i); p.raw(o.dec3_b[i], C1, S(nm));
     }
-    p.begin_unit();
-    o.post1_w = pack_1x1(S("dec_post.0.weight"), 2 * C1, C1);
-    o.post1_b = p.pack_bias(C1, S("dec_post.0.bias"));
-    p.end_unit();
-    p.begin_unit();
+    pack_1x1(o.post1_w, S("dec_post.0.weight"), 2 * C1, C1);
+    p.raw(o.post1_b, C1, S("dec_post.0.bias"));
     {   // transposed conv weight (C1, 2, 8): B[k = ci][n = co*8 + j]
         const float* w = S("dec_post.2.weight");
-        o.post_t_w = p.pack_b(C1, 16, [&](int k, int n) { return w[k * 16 + n]; });
-        o.post_t_b = p.pack_bias(2, S("dec_post.2.bias"));
+        p.pack_b(o.post_t_w, C1, 16, [&](int k, int n) { return w[k * 16 + n]; });
+        p.raw(o.post_t_b, 2, S("dec_post.2.bias"));
     }
-    p.end_unit();
-    o.n_units = (int)p.u_off.size();
-    if (o.n_units != h->impl->n_units || o.n_units > 64)
-        return fail(FE_ERR_INVALID_ARG, "internal: %d weight units packed, kernel expects %d", o.n_units, h->impl->n_units);
-    for (int u = 0; u < o.n_units; ++u) {
-        o.u_off[u] = p.u_off[u];
-        o.u_size[u] = p.u_size[u];
-        if (p.u_size[u] > h->impl->u_max)
-            return fail(FE_ERR_INVALID_ARG, "internal: weight unit %d has %d floats > LDS buffer %d", u, p.u_size[u], h->impl->u_max);
-    }
-    o.window = p.raw(h->window.size(), h->window.data());
-    o.window_istft = p.raw(h->window_istft.size(), h->window_istft.data());
-    o.twiddle = p.raw(h->twiddle.size(), h->twiddle.data());
-    o.total = (int)p.buf.size();
+    p.raw(o.window, h->window.size(), h->window.data());
+    p.raw(o.window_istft, h->window_istft.size(), h->window_istft.data());
+    p.raw(o.twiddle, h->twiddle.size(), h->twiddle.data());
     *out = std::move(p.buf);
     return FE_OK;
 }
@@ -371,7 +304,6 @@ int check_ready(const fe_handle* h) {
 fe::FrameArgs base_args(fe_handle* h, int B, int T) {
     fe::FrameArgs a{};
     a.wp = h->packed_dev;
-    a.off = h->off;
     a.B = B;
     a.T = T;
     a.compression = h->cfg.input_compression;

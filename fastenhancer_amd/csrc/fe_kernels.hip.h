@@ -21,6 +21,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+#include <utility>
+
 namespace fe {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -29,6 +32,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{})
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 __host__ __device__ constexpr int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ constexpr int round_up(int a, int b) { return ceil_div(a, b) * b; }
@@ -64,28 +73,16 @@ struct Shape {
     // packed-weight sizes (floats)
     static constexpr int KS_C = C1 / 4;           // k-steps over C1
     static constexpr int KS_2 = C2 / 4;           // k-steps over C2
-    // weight units (see PackedOffsets::u_off): enc_pre, NL enc, rf_pre lin+conv, KB x (gru, fc1, qkv, fc2),
-    // rf_post lin+conv, NL x (dec 1x1, dec k3), dec_post 1x1 + transposed conv
-    static constexpr int NU = 7 + 3 * NL + 4 * KB;
-    static constexpr int r256(int x) { return (x + 255) / 256 * 256; }
-    static constexpr int m2(int a, int b) { return a > b ? a : b; }
-    static constexpr int U_K3 = r256(NTC * 3 * KS_C * 64 + NTC * 16);
-    static constexpr int U_1X1 = r256(NTC * 2 * KS_C * 64 + NTC * 16);
-    static constexpr int U_GRU = r256(2 * (NT3 * KS_2 * 64 + 64) + 2 * NT3 * 16);
-    static constexpr int U_FC1 = r256(NT2 * KS_2 * 64 + NT2 * 16 + 64 + F2 * C2);
-    static constexpr int U_QKV = r256(NT3 * KS_2 * 64);
-    static constexpr int U_LIN1 = r256(MT2 * (F1 / 4) * 64);
-    static constexpr int U_LIN2 = r256(MTC * (F2 / 4) * 64);
-    static constexpr int U_RFC = r256(m2(NT2 * KS_C * 64 + NT2 * 16, NTC * KS_2 * 64 + NTC * 16) + 64);
-    static constexpr int U_MAX = m2(m2(m2(U_K3, U_1X1), m2(U_GRU, U_FC1)), m2(m2(U_QKV, U_LIN1), m2(U_LIN2, U_RFC)));
+    static constexpr int NU = 7 + 3 * NL;        // LDS-staged weight units (Pack<S>)
     static_assert(C1 % 4 == 0 && C2 % 4 == 0 && F2 % 4 == 0, "channel counts must be multiples of 4");
     static_assert(C2 % NH == 0, "C2 must be divisible by the 4 heads");
     static_assert(F1 % 64 == 0, "F1 must be a multiple of 64");
     static_assert(LOG2N > 0, "n_fft must be 512 or 1024");
 };
 
-// Offsets (floats) of the packed weights inside the handle's device buffer.  Filled by the host
-// packer (fe_api.hip) with the same formulas.
+// Offsets (floats) of the packed weights inside the handle's device buffer.  The layout is a pure
+// function of the shape, evaluated at compile time and shared by the host packer (fe_api.hip) and the
+// kernel, where every offset folds into an instruction immediate / one SGPR add.
 struct PackedOffsets {
     int enc_pre_w, enc_pre_b;
     int enc_w[8], enc_b[8];
@@ -98,15 +95,56 @@ struct PackedOffsets {
     int post1_w, post1_b, post_t_w, post_t_b;
     int window, window_istft, twiddle;  // [N], [N], [N/2] float2
     int total;
-    // Weight "units" in consumption order (one per GEMM phase): [weights | bias ...], 256-float aligned
-    // and padded, so that a unit is staged into LDS by whole 1-KiB global_load_lds pieces.
+    // LDS-staged weight "units" in consumption order (one per conv-type GEMM phase): [weights | bias],
+    // 256-float aligned and padded, so that a unit is staged by whole 1-KiB global_load_lds pieces.
     int n_units;
-    int u_off[64], u_size[64];
+    int u_off[32], u_size[32];
+};
+
+template <class S>
+struct Pack {
+    static constexpr int szB(int K, int N) { return ceil_div(N, 16) * (K / 4) * 64; }   // B fragments
+    static constexpr int szA(int M, int K) { return ceil_div(M, 16) * (K / 4) * 64; }   // A fragments
+    static constexpr int szBias(int n) { return round_up(n, 16); }
+    static constexpr PackedOffsets make() {
+        PackedOffsets o{};
+        int cur = 0, nu = 0;
+        auto alloc = [&](int n) { cur = round_up(cur, 64); const int at = cur; cur += n; return at; };
+        auto ubegin = [&]() { cur = round_up(cur, 256); o.u_off[nu] = cur; };
+        auto uend = [&]() { cur = round_up(cur, 256); o.u_size[nu] = cur - o.u_off[nu]; ++nu; };
+        constexpr int C1 = S::C1, C2 = S::C2, F1 = S::F1, F2 = S::F2;
+        ubegin(); o.enc_pre_w = alloc(szB(16, C1)); o.enc_pre_b = alloc(szBias(C1)); uend();
+        for (int l = 0; l < S::NL; ++l) { ubegin(); o.enc_w[l] = alloc(szB(3 * C1, C1)); o.enc_b[l] = alloc(szBias(C1)); uend(); }
+        ubegin(); o.rfpre_lin = alloc(szA(F2, F1)); uend();
+        ubegin(); o.rfpre_w = alloc(szB(C1, C2)); o.rfpre_b = alloc(szBias(C2)); uend();
+        ubegin(); o.rfpost_lin = alloc(szA(F1, F2)); uend();
+        ubegin(); o.rfpost_w = alloc(szB(C2, C1)); o.rfpost_b = alloc(szBias(C1)); uend();
+        for (int l = 0; l < S::NL; ++l) {
+            ubegin(); o.dec1_w[l] = alloc(szB(2 * C1, C1)); o.dec1_b[l] = alloc(szBias(C1)); uend();
+            ubegin(); o.dec3_w[l] = alloc(szB(3 * C1, C1)); o.dec3_b[l] = alloc(szBias(C1)); uend();
+        }
+        ubegin(); o.post1_w = alloc(szB(2 * C1, C1)); o.post1_b = alloc(szBias(C1)); uend();
+        ubegin(); o.post_t_w = alloc(szB(C1, 16)); o.post_t_b = alloc(szBias(2)); uend();
+        o.n_units = nu;
+        // RNNFormer-block weights: read by each wave straight into registers (not staged)
+        for (int k = 0; k < S::KB; ++k) {
+            o.blk_wih[k] = alloc(szB(C2, 3 * C2)); o.blk_whh[k] = alloc(szB(C2, 3 * C2));
+            o.blk_bih[k] = alloc(szBias(3 * C2)); o.blk_bhh[k] = alloc(szBias(3 * C2));
+            o.blk_fc1_w[k] = alloc(szB(C2, C2)); o.blk_fc1_b[k] = alloc(szBias(C2));
+            if (k == 0) o.blk_pe = alloc(F2 * C2);
+            o.blk_qkv[k] = alloc(szB(C2, 3 * C2));
+            o.blk_fc2_w[k] = alloc(szB(C2, C2)); o.blk_fc2_b[k] = alloc(szBias(C2));
+        }
+        o.window = alloc(S::NFFT); o.window_istft = alloc(S::NFFT); o.twiddle = alloc(S::NFFT);
+        o.total = round_up(cur, 64);
+        return o;
+    }
+    static constexpr PackedOffsets v = make();
+    static constexpr int umax() { int m = 0; for (int u = 0; u < v.n_units; ++u) m = v.u_size[u] > m ? v.u_size[u] : m; return m; }
 };
 
 struct FrameArgs {
-    const float* wp;          // packed weights + tables
-    PackedOffsets off;
+    const float* wp;          // packed weights + tables (layout: Pack<S>::v)
     const float* wav_in;      // [b*in_stride + t*H + n]
     float* wav_out;
     size_t in_stride, out_stride;
@@ -125,8 +163,11 @@ struct FrameArgs {
 // ------------------------------------------------------------------------------------------
 #define FE_CLK(i) do { if (a.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.clk[(i)] = __builtin_readcyclecounter(); } while (0)
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// v_exp_f32 / v_rcp_f32 are 1-ulp hardware ops; the resulting activations are accurate to a few
+// 1e-7 (measured against the oracle per stage), far inside the 1e-4 waveform budget.
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 // Weights / tables are read through ONE buffer resource: the per-lane part of every address is the
 // single VGPR `lane*4`; the section / tile / k-step part is a scalar (SGPR or immediate) offset.
@@ -145,6 +186,16 @@ struct WSrc {
         if constexpr (STAGED) return lds[off_floats - base + (li4 >> 2)];
         else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, li4, off_floats * 4, 0));
     }
+    // always from global/L2 (weights that are not LDS-staged)
+    __device__ __forceinline__ float at_g(int off_floats) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane4, off_floats * 4, 0));
+    }
+    __device__ __forceinline__ float at16_g(int off_floats) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, li4, off_floats * 4, 0));
+    }
+    __device__ __forceinline__ float gather_g(int off_floats_per_lane) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off_floats_per_lane * 4, 0, 0));
+    }
     __device__ __forceinline__ float gather(int off_floats_per_lane) const {   // arbitrary per-lane offset
         if constexpr (STAGED) return lds[off_floats_per_lane - base];
         else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off_floats_per_lane * 4, 0, 0));
@@ -155,24 +206,37 @@ struct WSrc {
     }
 };
 
-// Asynchronous global -> LDS copy of one weight unit (n floats, multiple of 256): each wave issues
-// 1-KiB global_load_lds_dwordx4 pieces (LDS destination = wave-uniform base + lane*16).  Completion
-// is covered by the vmcnt(0) that __syncthreads() carries while an LDS-DMA is in flight.
-__device__ __forceinline__ void stage_unit(const float* gsrc, float* lds_dst, int n, int wave, int lane) {
-    for (int p = wave; p * 256 < n; p += kWaves) {
-        const float* g = gsrc + p * 256 + lane * 4;
-        float* l = lds_dst + p * 256;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+// Asynchronous global -> LDS copy of one weight unit (n floats, multiple of 256) in 1-KiB
+// global_load_lds_dwordx4 pieces (LDS destination = wave-uniform base + lane*16); wave w moves pieces
+// w, w+4, ...  Issuing a piece costs ~60-100 cycles of the wave's issue slot, so the pieces are
+// handed out one per k-group from inside the MFMA loop (mma_panel's `side`), where they hide in the
+// matrix pipe's shadow; dma_rest() issues whatever is left.  Completion is covered by the vmcnt(0)
+// that __syncthreads() carries while an LDS-DMA is in flight.
+struct DmaJob {
+    const float* g;   // + lane*4 already applied
+    float* l;
+    int n;            // floats
+    int p;            // next piece of this wave
+};
+__device__ __forceinline__ void dma_one(DmaJob& j) {
+    if (j.p * 256 < j.n) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(j.g + j.p * 256),
+                                         (__attribute__((address_space(3))) void*)(j.l + j.p * 256), 16, 0, 0);
     }
+    j.p += kWaves;
 }
+__device__ __forceinline__ void dma_rest(DmaJob& j) {
+    while (j.p * 256 < j.n) dma_one(j);
+}
+struct NoSide { __device__ __forceinline__ void operator()() const {} };
+struct DmaSide { DmaJob* j; __device__ __forceinline__ void operator()() const { dma_one(*j); } };
 
 // Software-pipelined: operands are fetched in groups of G k-steps, D groups ahead of the MFMAs
 // that consume them; sched_barrier(0) pins "loads of group g+D before MFMAs of group g", so the
 // compiler's counted s_waitcnt leaves >= D*G*MTP*NTP MFMAs (32 cycles each) of cover over the L2
 // latency of the weight fetch.  (Left alone, hipcc sinks every load next to its MFMA.)
-template <int MTP, int NTP, int KS, typename AF, typename BF>
-__device__ __forceinline__ void mma_panel(f32x4 (&acc)[MTP][NTP], AF&& af, BF&& bf) {
+template <int MTP, int NTP, int KS, typename AF, typename BF, typename SIDE>
+__device__ __forceinline__ void mma_panel(f32x4 (&acc)[MTP][NTP], AF&& af, BF&& bf, SIDE&& side) {
     constexpr int G = (MTP * NTP >= 6) ? 2 : 4;      // k-steps per group
     constexpr int D = 2;                             // prefetch distance in groups
     constexpr int NG = (KS + G - 1) / G;
@@ -195,6 +259,7 @@ __device__ __forceinline__ void mma_panel(f32x4 (&acc)[MTP][NTP], AF&& af, BF&& 
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         if (g + D < NG) load_group(g + D, (g + D) % (D + 1));
+        side();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < G; ++kk) {
@@ -296,7 +361,8 @@ struct Lds {
     static constexpr int HL = X + S::F2P * S::LDX;                // hidden state / attention out
     static constexpr int GI = HL + S::F2P * S::LDX;               // [F2P][LDG]  (also qkv)
     static constexpr int GH = GI + S::F2P * S::LDG;               // [F2P][LDG]
-    static constexpr int END_RF = 2 * S::F2P * S::LDX + 2 * S::F2P * S::LDG;
+    static constexpr int HS = GH + S::F2P * S::LDG;               // GRU hidden state of the current block [F2P][LDX]
+    static constexpr int END_RF = 3 * S::F2P * S::LDX + 2 * S::F2P * S::LDG;
     static constexpr int Y1 = GI;                                 // rf_pre intermediate [F2P][LDC]
     static constexpr int W0 = ARENA;
     static constexpr int W1 = W0 + S::ACT;
@@ -308,10 +374,10 @@ struct Lds {
     static constexpr int ARENA_SIZE = cmax(cmax(END_FFT, END_RF), cmax(END_CONV, END_Y2));
     static constexpr int NOSTAGE_TOTAL = ARENA + ARENA_SIZE;
     // weights are staged through two LDS buffers (one GEMM phase ahead) whenever they fit
-    static constexpr bool STAGED = (size_t)(NOSTAGE_TOTAL + 2 * S::U_MAX) * 4 <= 160 * 1024;
+    static constexpr bool STAGED = (size_t)(NOSTAGE_TOTAL + 2 * Pack<S>::umax()) * 4 <= 160 * 1024;
     static constexpr int WB0 = NOSTAGE_TOTAL;
-    static constexpr int WB1 = WB0 + S::U_MAX;
-    static constexpr int TOTAL = STAGED ? NOSTAGE_TOTAL + 2 * S::U_MAX : NOSTAGE_TOTAL;
+    static constexpr int WB1 = WB0 + Pack<S>::umax();
+    static constexpr int TOTAL = STAGED ? NOSTAGE_TOTAL + 2 * Pack<S>::umax() : NOSTAGE_TOTAL;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
     static_assert(2 * S::ACT >= 2 * S::NFFT, "FFT_A must not reach the transposed-conv partials");
     static_assert(S::F2P * S::LDC <= 2 * S::F2P * S::LDG, "rf_pre intermediate must fit in GI+GH");
@@ -348,22 +414,22 @@ __device__ __forceinline__ float2* fft_lds(float2* x, float2* y, const float2* t
 //   a_lane : LDS pointer to A[(16*wave + (lane&15)) rows][(lane>>4) col] of the segment
 //   w_lane : packed weights + lane, at k-step 0 of this segment;  KS_TOT = k-steps per n-tile
 template <class S, int NT, int KS, int KS_TOT, int LDA, class WS>
-__device__ __forceinline__ void conv_seg(f32x4 (&acc)[S::MTPW][NT], const float* a_lane, const WS& w, int w_off) {
+__device__ __forceinline__ void conv_seg(f32x4 (&acc)[S::MTPW][NT], const float* a_lane, const WS& w, int w_off, DmaJob& job) {
     mma_panel<S::MTPW, NT, KS>(
         acc,
         [&](int i, int ks) { return a_lane[(64 * i) * LDA + 4 * ks]; },
-        [&](int j, int ks) { return w.at(w_off + (j * KS_TOT + ks) * 64); });
+        [&](int j, int ks) { return w.at(w_off + (j * KS_TOT + ks) * 64); }, DmaSide{&job});
 }
 
 // Several K-segments (conv taps / concatenated inputs) accumulated in ONE software pipeline:
 // segment s reads its A rows through a_lane[s]; the packed weights hold the segments' k-steps
 // back to back (k-step index = s * KS_SEG + ks).
 template <class S, int NT, int NSEG, int KS_SEG, int LDA, class WS>
-__device__ __forceinline__ void conv_multi(f32x4 (&acc)[S::MTPW][NT], const float* const (&a_lane)[NSEG], const WS& w, int w_off) {
+__device__ __forceinline__ void conv_multi(f32x4 (&acc)[S::MTPW][NT], const float* const (&a_lane)[NSEG], const WS& w, int w_off, DmaJob& job) {
     mma_panel<S::MTPW, NT, NSEG * KS_SEG>(
         acc,
         [&](int i, int ks) { return a_lane[ks / KS_SEG][(64 * i) * LDA + 4 * (ks % KS_SEG)]; },
-        [&](int j, int ks) { return w.at(w_off + (j * (NSEG * KS_SEG) + ks) * 64); });
+        [&](int j, int ks) { return w.at(w_off + (j * (NSEG * KS_SEG) + ks) * 64); }, DmaSide{&job});
 }
 
 // Epilogue of a conv-layout GEMM: optional SiLU, store to out[(row0 + m)][col] for col < NCOLS.
@@ -389,7 +455,7 @@ __device__ __forceinline__ void conv_store(const f32x4 (&acc)[S::MTPW][NT], floa
 
 // token-layout GEMM: all MT2 m-tiles x this wave's n-tiles (wave + 4*j), A from LDS, B packed.
 template <class S, int NTPW, int KS, int LDA, class WS>
-__device__ __forceinline__ void tok_gemm(f32x4 (&acc)[S::MT2][NTPW], const float* a_lane, const WS& w, int w_off, int NT, int wave) {
+__device__ __forceinline__ void tok_gemm(f32x4 (&acc)[S::MT2][NTPW], const float* a_lane, const WS& w, int w_off, int NT, int wave, DmaJob& job) {
     mma_panel<S::MT2, NTPW, KS>(
         acc,
         [&](int i, int ks) { return a_lane[(16 * i) * LDA + 4 * ks]; },
@@ -397,7 +463,42 @@ __device__ __forceinline__ void tok_gemm(f32x4 (&acc)[S::MT2][NTPW], const float
             int nt = wave + 4 * j;
             nt = nt < NT ? nt : NT - 1;
             return w.at(w_off + (nt * KS + ks) * 64);
-        });
+        }, DmaSide{&job});
+}
+
+// Token GEMMs split the OUTPUT columns over the waves, so a wave's B fragments (weights) are private
+// to it: they are fetched straight from L2 into registers one phase ahead (tok_prefetch) and the GEMM
+// then runs with register-resident weights (tok_gemm_r) - no LDS staging, no load latency in the phase.
+template <int NTPW, int KS, class WS>
+__device__ __forceinline__ void tok_prefetch(float (&w)[NTPW][KS], const WS& src, int w_off, int NT, int wave) {
+#pragma unroll
+    for (int j = 0; j < NTPW; ++j) {
+        int nt = wave + 4 * j;
+        nt = nt < NT ? nt : NT - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) w[j][ks] = src.at_g(w_off + (nt * KS + ks) * 64);
+    }
+}
+template <int NTPW, class WS>
+__device__ __forceinline__ void bias_prefetch(float (&bv)[NTPW], const WS& src, int b_off, int NT, int wave) {
+#pragma unroll
+    for (int j = 0; j < NTPW; ++j) {
+        int nt = wave + 4 * j;
+        nt = nt < NT ? nt : NT - 1;
+        bv[j] = src.at16_g(b_off + nt * 16);
+    }
+}
+template <class S, int NTPW, int KS, int LDA>
+__device__ __forceinline__ void tok_gemm_r(f32x4 (&acc)[S::MT2][NTPW], const float* a_lane, const float (&w)[NTPW][KS]) {
+    mma_panel<S::MT2, NTPW, KS>(
+        acc, [&](int i, int ks) { return a_lane[(16 * i) * LDA + 4 * ks]; }, [&](int j, int ks) { return w[j][ks]; }, NoSide{});
+}
+template <int MTP, int NTP>
+__device__ __forceinline__ void acc_init_regs(f32x4 (&acc)[MTP][NTP], const float (&bv)[NTP]) {
+#pragma unroll
+    for (int j = 0; j < NTP; ++j)
+#pragma unroll
+        for (int i = 0; i < MTP; ++i) acc[i][j] = f32x4{bv[j], bv[j], bv[j], bv[j]};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -416,12 +517,13 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     const int b = blockIdx.x;
     const float* __restrict__ wp = a.wp;
     WSrc<Lds<S>::STAGED> wb;
-    wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, a.off.total * 4, 0x00020000);
+    constexpr PackedOffsets o = Pack<S>::v;
+    static_assert(o.n_units == S::NU, "unit count");
+    wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, o.total * 4, 0x00020000);
     wb.lane4 = lane * 4;
     wb.li4 = (lane & 15) * 4;
     wb.lds = nullptr;
     wb.base = 0;
-    const PackedOffsets& o = a.off;
 
     // ---- one-time: zero LDS (halo rows, pad rows), load twiddles
     for (int i = tid; i < L::TOTAL; i += kThreads) smem[i] = 0.0f;
@@ -432,9 +534,14 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     float2* fa = reinterpret_cast<float2*>(smem + L::FFT_A);
     float2* fb = reinterpret_cast<float2*>(smem + L::FFT_B);
     float* Ebuf = smem + L::E;
-    // weight units: unit `ucur` is consumed from LDS buffer (ucount & 1) while the next one streams in
-    int ucount = 0, ucur = 0;
-    if constexpr (L::STAGED) stage_unit(wp + a.off.u_off[0], smem + L::WB0, a.off.u_size[0], wave, lane);
+    // weight units: unit U of frame t is consumed from LDS buffer ((U + t*NU) & 1) while the next streams in
+    DmaJob job{wp + lane * 4, smem, 0, wave};
+    if constexpr (L::STAGED) {
+        job.g = wp + o.u_off[0] + lane * 4;
+        job.l = smem + L::WB0;
+        job.n = o.u_size[0];
+        dma_rest(job);
+    }
     __syncthreads();
 
     float* cst = a.cache_stft + (size_t)b * OVL;
@@ -442,21 +549,24 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 
 #pragma unroll 1
     for (int t = 0; t < a.T; ++t) {
-        // Called right after the barrier that precedes each GEMM phase, in the packer's unit order:
-        // selects the staged copy of this phase's weights and starts the DMA of the next phase's.
-        auto begin_unit = [&]() {
-            if constexpr (L::STAGED) {
-                const int slot = ucount & 1;
-                int un = ucur + 1;
-                const bool has_next = (un < S::NU) || (t + 1 < a.T);
-                if (un == S::NU) un = 0;
-                if (has_next) stage_unit(wp + o.u_off[un], smem + (slot ? L::WB0 : L::WB1), o.u_size[un], wave, lane);
-                wb.lds = smem + (slot ? L::WB1 : L::WB0);
-                wb.base = o.u_off[ucur];
-            }
-            ++ucount;
-            ucur = (ucur + 1 == S::NU) ? 0 : ucur + 1;
-        };
+        // begin_unit(U): called right after the barrier that precedes the GEMM phase of staged unit U:
+        // selects the LDS copy of this phase's weights and sets up the DMA job of the next unit.
+        const int fpar = (S::NU & 1) ? (t & 1) : 0;
+#define FE_BEGIN_UNIT(U)                                                                           \
+        do {                                                                                       \
+            if constexpr (L::STAGED) {                                                             \
+                constexpr int u_ = (U);                                                            \
+                constexpr int un_ = (u_ + 1 == S::NU) ? 0 : u_ + 1;                                \
+                const int slot_ = (u_ & 1) ^ fpar;                                                 \
+                const bool has_next_ = (u_ + 1 < S::NU) || (t + 1 < a.T);                          \
+                job.g = wp + o.u_off[un_] + lane * 4;                                              \
+                job.l = smem + (slot_ ? L::WB0 : L::WB1);                                          \
+                job.n = has_next_ ? o.u_size[un_] : 0;                                             \
+                job.p = wave;                                                                      \
+                wb.lds = smem + (slot_ ? L::WB1 : L::WB0);                                         \
+                wb.base = o.u_off[u_];                                                             \
+            }                                                                                      \
+        } while (0)
         FE_CLK(0);
         // =========================== STFT (a3) ===========================
         if (!SPEC_MODE) {
@@ -505,7 +615,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         FE_CLK(3);
         // =========================== enc_pre (a5): strided conv as K=16 GEMM ===========================
         {
-            begin_unit();
+            FE_BEGIN_UNIT(0);
             f32x4 acc[S::MTPW][S::NTC];
             acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.enc_pre_b, 0, 1, S::NTC);
             // k = t*8 + s*2 + c  (weight (C1, 8, 2): channel index s*2+c, tap t);  A[m][k] = xpad[c][4(m+t)+s]
@@ -517,7 +627,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     const int m = 16 * (wave + 4 * i) + li;
                     return sc[c * S::LDS_S + 4 * (m + tp) + s];
                 },
-                [&](int j, int ks) { return wb.at(o.enc_pre_w + (j * 4 + ks) * 64); });
+                [&](int j, int ks) { return wb.at(o.enc_pre_w + (j * 4 + ks) * 64); }, DmaSide{&job});
+            dma_rest(job);
             conv_store<S, S::NTC, C1, LDC, true>(acc, Ebuf, 1, wave, lane);
         }
         __syncthreads();
@@ -525,23 +636,25 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 
         FE_CLK(4);
         // =========================== encoder (a6): k=3 convs ===========================
-#pragma unroll
-        for (int l = 0; l < S::NL; ++l) {
+        static_for<S::NL>([&](auto l_) {
+            constexpr int l = decltype(l_)::value;
             const float* in = Ebuf + l * S::ACT;
             float* out = Ebuf + (l + 1) * S::ACT;
-            begin_unit();
+            FE_BEGIN_UNIT(1 + l);
             f32x4 acc[S::MTPW][S::NTC];
             acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.enc_b[l], 0, 1, S::NTC);
             const float* const taps[3] = {in + (16 * wave + li + 0) * LDC + lg, in + (16 * wave + li + 1) * LDC + lg,
                                           in + (16 * wave + li + 2) * LDC + lg};
-            conv_multi<S, S::NTC, 3, S::KS_C, LDC>(acc, taps, wb, o.enc_w[l]);
+            conv_multi<S, S::NTC, 3, S::KS_C, LDC>(acc, taps, wb, o.enc_w[l], job);
+            dma_rest(job);
             conv_store<S, S::NTC, C1, LDC, true>(acc, out, 1, wave, lane);
             __syncthreads();
             dbg_dump<S>(a, b, 3 + l, out + LDC, LDC);
-        }
+        });
 
         float* Xb = smem + L::X;
         float* Hl = smem + L::HL;
+        float* Hs = smem + L::HS;
         float* Gi = smem + L::GI;
         float* Gh = smem + L::GH;
         float* Y1 = smem + L::Y1;
@@ -549,12 +662,23 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 
         FE_CLK(5);
         // =========================== rf_pre (a7) ===========================
+        constexpr int NTPW2 = ceil_div(S::NT2, kWaves);
+        constexpr int HPT = ceil_div(F2 * C2, kThreads);   // hidden-state elements per thread
+        f32x4 xr[S::MT2][NTPW2];                           // residual stream x, this wave's output tiles
+        // register-resident weights of the RNNFormer-block GEMMs (this wave's output columns), each set
+        // prefetched from L2 one phase before the GEMM that uses it
+        constexpr int NTPW3 = ceil_div(S::NT3, kWaves);
+        float wg_i[NTPW3][S::KS_2], wg_h[NTPW3][S::KS_2], bg_i[NTPW3], bg_h[NTPW3];   // GRU
+        float w1[NTPW2][S::KS_2], b1[NTPW2];                                           // rnn_fc
+        float wq[NTPW3][S::KS_2];                                                      // qkv
+        float w2[NTPW2][S::KS_2], b2[NTPW2];                                           // attn_fc
+        float pe_r[S::MT2][NTPW2][4];                                                  // positional embedding (block 0)
         {
             // Y1[f2][c1] = sum_f1 Wf[f2][f1] * E[f1][c1]      (A = packed filterbank, B = LDS)
             constexpr int NTPW = ceil_div(S::NTC, kWaves);
             constexpr int KS = F1 / 4;
             const float* Ein = Ebuf + S::NL * S::ACT + LDC;   // row 0 = bin 0
-            begin_unit();
+            FE_BEGIN_UNIT(1 + S::NL);
             f32x4 acc[S::MT2][NTPW];
             acc_init_zero<S::MT2, NTPW>(acc);
             mma_panel<S::MT2, NTPW, KS>(
@@ -564,7 +688,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     int nt = wave + 4 * j;
                     nt = nt < S::NTC ? nt : S::NTC - 1;
                     return Ein[(4 * ks + lg) * LDC + 16 * nt + li];
-                });
+                }, DmaSide{&job});
+            dma_rest(job);
 #pragma unroll
             for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -584,16 +709,29 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         {
             // X[f2][c2] = Y1[f2][:] . Wc[c2][:] + b
             constexpr int NTPW = ceil_div(S::NT2, kWaves);
-            begin_unit();
+            FE_BEGIN_UNIT(2 + S::NL);
+            tok_prefetch<NTPW3, S::KS_2>(wg_i, wb, o.blk_wih[0], S::NT3, wave);
+            tok_prefetch<NTPW3, S::KS_2>(wg_h, wb, o.blk_whh[0], S::NT3, wave);
+            bias_prefetch<NTPW3>(bg_i, wb, o.blk_bih[0], S::NT3, wave);
+            bias_prefetch<NTPW3>(bg_h, wb, o.blk_bhh[0], S::NT3, wave);
+            // hidden state of block 0: fetched now, parked in LDS after the GEMM
+            float hpre[HPT];
+            {
+                const float* hg0 = a.h + (size_t)b * (F2 * C2);
+#pragma unroll
+                for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = i < F2 * C2 ? hg0[i] : 0.0f; }
+            }
             f32x4 acc[S::MT2][NTPW];
             acc_init_bias<S::MT2, NTPW>(acc, wb, o.rfpre_b, wave, 4, S::NT2);
-            tok_gemm<S, NTPW, S::KS_C, LDC>(acc, Y1 + li * LDC + lg, wb, o.rfpre_w, S::NT2, wave);
+            tok_gemm<S, NTPW, S::KS_C, LDC>(acc, Y1 + li * LDC + lg, wb, o.rfpre_w, S::NT2, wave, job);
+            dma_rest(job);
 #pragma unroll
             for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
                 for (int j = 0; j < NTPW; ++j) {
                     const int nt = wave + 4 * j;
                     const int col = 16 * nt + li;
+                    xr[i][j] = acc[i][j];
                     if (nt < S::NT2 && col < C2) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -602,34 +740,45 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                         }
                     }
                 }
+#pragma unroll
+            for (int q = 0; q < HPT; ++q) {
+                const int i = tid + q * kThreads;
+                if (i < F2 * C2) { const int f = i / C2; Hs[f * LDX + (i - f * C2)] = hpre[q]; }
+            }
         }
         __syncthreads();
         dbg_dump<S>(a, b, 3 + S::NL, Xb, LDX);
 
         FE_CLK(6);
         // =========================== RNNFormer blocks (a9-a11) ===========================
-#pragma unroll 1
-        for (int k = 0; k < S::KB; ++k) {
+        static_for<S::KB>([&](auto k_) {
+            constexpr int k = decltype(k_)::value;
             float* hg = a.h + ((size_t)k * a.B + b) * (F2 * C2);
-            for (int i = tid; i < F2 * C2; i += kThreads) {
-                int f = i / C2, c = i - f * C2;
-                Hl[f * LDX + c] = hg[i];
-            }
-            __syncthreads();
             if (k == 0) FE_CLK(20);
             {
-                // gi = x W_ih^T + b_ih ; gh = h W_hh^T + b_hh
-                begin_unit();
-                constexpr int NTPW = ceil_div(S::NT3, kWaves);
+                // gi = x W_ih^T + b_ih ; gh = h W_hh^T + b_hh   (weights already in registers)
+                constexpr int NTPW = NTPW3;
+                // prefetch for the next phase: rnn_fc weights (+ the positional embedding in block 0)
+                tok_prefetch<NTPW2, S::KS_2>(w1, wb, o.blk_fc1_w[k], S::NT2, wave);
+                bias_prefetch<NTPW2>(b1, wb, o.blk_fc1_b[k], S::NT2, wave);
+                if (k == 0) {
+#pragma unroll
+                    for (int i = 0; i < S::MT2; ++i)
+#pragma unroll
+                        for (int j = 0; j < NTPW2; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = 16 * i + 4 * lg + r, col = 16 * (wave + 4 * j) + li;
+                                pe_r[i][j][r] = (row < F2 && col < C2) ? wb.gather_g(o.blk_pe + row * C2 + col) : 0.0f;
+                            }
+                }
 #pragma unroll
                 for (int which = 0; which < 2; ++which) {
                     f32x4 acc[S::MT2][NTPW];
-                    const int bias = which == 0 ? o.blk_bih[k] : o.blk_bhh[k];
-                    const int wsrc = which == 0 ? o.blk_wih[k] : o.blk_whh[k];
-                    const float* asrc = (which == 0 ? Xb : Hl) + li * LDX + lg;
+                    const float* asrc = (which == 0 ? Xb : Hs) + li * LDX + lg;
                     float* dst = which == 0 ? Gi : Gh;
-                    acc_init_bias<S::MT2, NTPW>(acc, wb, bias, wave, 4, S::NT3);
-                    tok_gemm<S, NTPW, S::KS_2, LDX>(acc, asrc, wb, wsrc, S::NT3, wave);
+                    if (which == 0) { acc_init_regs<S::MT2, NTPW>(acc, bg_i); tok_gemm_r<S, NTPW, S::KS_2, LDX>(acc, asrc, wg_i); }
+                    else            { acc_init_regs<S::MT2, NTPW>(acc, bg_h); tok_gemm_r<S, NTPW, S::KS_2, LDX>(acc, asrc, wg_h); }
 #pragma unroll
                     for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -654,8 +803,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 const float* gh = Gh + f * LDG;
                 float r = sigmoid_f(gi[c] + gh[c]);
                 float z = sigmoid_f(gi[C2 + c] + gh[C2 + c]);
-                float n = tanhf(gi[2 * C2 + c] + r * gh[2 * C2 + c]);
-                float hp = Hl[f * LDX + c];
+                float n = tanh_f(gi[2 * C2 + c] + r * gh[2 * C2 + c]);
+                float hp = Hs[f * LDX + c];
                 float hn = (1.0f - z) * n + z * hp;
                 Hl[f * LDX + c] = hn;
                 hg[i] = hn;
@@ -664,11 +813,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             if (k == 0) FE_CLK(22);
             {
                 // x += rnn_fc(h') (+ pe in block 0)
-                constexpr int NTPW = ceil_div(S::NT2, kWaves);
-                begin_unit();
+                constexpr int NTPW = NTPW2;
+                tok_prefetch<NTPW3, S::KS_2>(wq, wb, o.blk_qkv[k], S::NT3, wave);      // for the next phase
                 f32x4 acc[S::MT2][NTPW];
-                acc_init_bias<S::MT2, NTPW>(acc, wb, o.blk_fc1_b[k], wave, 4, S::NT2);
-                tok_gemm<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, wb, o.blk_fc1_w[k], S::NT2, wave);
+                acc_init_regs<S::MT2, NTPW>(acc, b1);
+                tok_gemm_r<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, w1);
 #pragma unroll
                 for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -680,8 +829,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                             for (int r = 0; r < 4; ++r) {
                                 const int row = 16 * i + 4 * lg + r;
                                 if (row < F2) {
-                                    float v = acc[i][j][r] + Xb[row * LDX + col];
-                                    if (k == 0) v += wb.gather(o.blk_pe + row * C2 + col);
+                                    float v = acc[i][j][r] + xr[i][j][r];
+                                    if (k == 0) v += pe_r[i][j][r];
+                                    xr[i][j][r] = v;
                                     Xb[row * LDX + col] = v;
                                 }
                             }
@@ -693,11 +843,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             if (k == 0) FE_CLK(23);
             {
                 // qkv = x W_qkv^T  -> Gi (rows per head interleaved [h][q|k|v][hd])
-                constexpr int NTPW = ceil_div(S::NT3, kWaves);
-                begin_unit();
+                constexpr int NTPW = NTPW3;
+                tok_prefetch<NTPW2, S::KS_2>(w2, wb, o.blk_fc2_w[k], S::NT2, wave);     // for attn_fc
+                bias_prefetch<NTPW2>(b2, wb, o.blk_fc2_b[k], S::NT2, wave);
                 f32x4 acc[S::MT2][NTPW];
                 acc_init_zero<S::MT2, NTPW>(acc);
-                tok_gemm<S, NTPW, S::KS_2, LDX>(acc, Xb + li * LDX + lg, wb, o.blk_qkv[k], S::NT3, wave);
+                tok_gemm_r<S, NTPW, S::KS_2, LDX>(acc, Xb + li * LDX + lg, wq);
 #pragma unroll
                 for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -732,7 +883,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                         const int d = 4 * ks + lg;
                         float v = Gi[(16 * j + li) * LDG + hoff + (d < HD ? d : HD - 1)];
                         return d < HD ? v : 0.0f;
-                    });
+                    }, NoSide{});
                 const float scale = rsqrtf((float)HD);
 #pragma unroll
                 for (int j = 0; j < S::MT2; ++j) {
@@ -805,10 +956,26 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             {
                 // x += attn_fc(o)
                 constexpr int NTPW = ceil_div(S::NT2, kWaves);
-                begin_unit();
+                float hpre[HPT];
+                if (k + 1 < S::KB) {   // next block: GRU weights into registers, hidden state fetched now / parked after the GEMM
+                    tok_prefetch<NTPW3, S::KS_2>(wg_i, wb, o.blk_wih[k + 1], S::NT3, wave);
+                    tok_prefetch<NTPW3, S::KS_2>(wg_h, wb, o.blk_whh[k + 1], S::NT3, wave);
+                    bias_prefetch<NTPW3>(bg_i, wb, o.blk_bih[k + 1], S::NT3, wave);
+                    bias_prefetch<NTPW3>(bg_h, wb, o.blk_bhh[k + 1], S::NT3, wave);
+                    const float* hgn = hg + (size_t)a.B * (F2 * C2);
+#pragma unroll
+                    for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = i < F2 * C2 ? hgn[i] : 0.0f; }
+                }
                 f32x4 acc[S::MT2][NTPW];
-                acc_init_bias<S::MT2, NTPW>(acc, wb, o.blk_fc2_b[k], wave, 4, S::NT2);
-                tok_gemm<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, wb, o.blk_fc2_w[k], S::NT2, wave);
+                acc_init_regs<S::MT2, NTPW>(acc, b2);
+                tok_gemm_r<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, w2);
+                if (k + 1 < S::KB) {
+#pragma unroll
+                    for (int q = 0; q < HPT; ++q) {
+                        const int i = tid + q * kThreads;
+                        if (i < F2 * C2) { const int f = i / C2; Hs[f * LDX + (i - f * C2)] = hpre[q]; }
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -819,7 +986,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int row = 16 * i + 4 * lg + r;
-                                if (row < F2) Xb[row * LDX + col] += acc[i][j][r];
+                                if (row < F2) {
+                                    const float v = acc[i][j][r] + xr[i][j][r];
+                                    xr[i][j][r] = v;
+                                    Xb[row * LDX + col] = v;
+                                }
                             }
                         }
                     }
@@ -827,7 +998,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             __syncthreads();
             if (k == 0) FE_CLK(26);
             dbg_dump<S>(a, b, 5 + S::NL + 2 * k, Xb, LDX);
-        }
+        });
 
         FE_CLK(7);
         // =========================== rf_post (a13) ===========================
@@ -836,21 +1007,23 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         {
             // Y2[f1][c2] = sum_f2 Wp[f1][f2] X[f2][c2]      (A packed, B = LDS tokens)
             constexpr int KS = F2 / 4;
-            begin_unit();
+            FE_BEGIN_UNIT(3 + S::NL);
             f32x4 acc[S::MTPW][S::NT2];
             acc_init_zero<S::MTPW, S::NT2>(acc);
             mma_panel<S::MTPW, S::NT2, KS>(
                 acc,
                 [&](int i, int ks) { return wb.at(o.rfpost_lin + ((wave + 4 * i) * KS + ks) * 64); },
-                [&](int j, int ks) { return Xb[(4 * ks + lg) * LDX + 16 * j + li]; });
+                [&](int j, int ks) { return Xb[(4 * ks + lg) * LDX + 16 * j + li]; }, DmaSide{&job});
+            dma_rest(job);
             conv_store<S, S::NT2, C2, LDX, false>(acc, Y2, 0, wave, lane);
         }
         __syncthreads();
         {
-            begin_unit();
+            FE_BEGIN_UNIT(4 + S::NL);
             f32x4 acc[S::MTPW][S::NTC];
             acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.rfpost_b, 0, 1, S::NTC);
-            conv_seg<S, S::NTC, S::KS_2, S::KS_2, LDX>(acc, Y2 + (16 * wave + li) * LDX + lg, wb, o.rfpost_w);
+            conv_seg<S, S::NTC, S::KS_2, S::KS_2, LDX>(acc, Y2 + (16 * wave + li) * LDX + lg, wb, o.rfpost_w, job);
+            dma_rest(job);
             conv_store<S, S::NTC, C1, LDC, false>(acc, W0, 1, wave, lane);
         }
         __syncthreads();
@@ -863,49 +1036,53 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 
         FE_CLK(8);
         // =========================== decoder (a14) ===========================
-#pragma unroll
-        for (int l = 0; l < S::NL; ++l) {
+        static_for<S::NL>([&](auto l_) {
+            constexpr int l = decltype(l_)::value;
             const float* skip = Ebuf + (S::NL - l) * S::ACT;
             {
-                begin_unit();
+                FE_BEGIN_UNIT(5 + S::NL + 2 * l);
                 f32x4 acc[S::MTPW][S::NTC];
                 acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.dec1_b[l], 0, 1, S::NTC);
                 const float* const segs[2] = {W0 + (16 * wave + li + 1) * LDC + lg, skip + (16 * wave + li + 1) * LDC + lg};
-                conv_multi<S, S::NTC, 2, S::KS_C, LDC>(acc, segs, wb, o.dec1_w[l]);
+                conv_multi<S, S::NTC, 2, S::KS_C, LDC>(acc, segs, wb, o.dec1_w[l], job);
+                dma_rest(job);
                 conv_store<S, S::NTC, C1, LDC, true>(acc, W1, 1, wave, lane);
             }
             __syncthreads();
             {
-                begin_unit();
+                FE_BEGIN_UNIT(6 + S::NL + 2 * l);
                 f32x4 acc[S::MTPW][S::NTC];
                 acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.dec3_b[l], 0, 1, S::NTC);
                 const float* const taps[3] = {W1 + (16 * wave + li + 0) * LDC + lg, W1 + (16 * wave + li + 1) * LDC + lg,
                                               W1 + (16 * wave + li + 2) * LDC + lg};
-                conv_multi<S, S::NTC, 3, S::KS_C, LDC>(acc, taps, wb, o.dec3_w[l]);
+                conv_multi<S, S::NTC, 3, S::KS_C, LDC>(acc, taps, wb, o.dec3_w[l], job);
+                dma_rest(job);
                 conv_store<S, S::NTC, C1, LDC, true>(acc, W0, 1, wave, lane);   // W0 was fully consumed before the barrier above
             }
             __syncthreads();
             dbg_dump<S>(a, b, 5 + S::NL + 2 * S::KB + l, W0 + LDC, LDC);
-        }
+        });
 
         FE_CLK(9);
         // =========================== dec_post (a15) ===========================
         float* PT = smem + L::PT;
         {
-            begin_unit();
+            FE_BEGIN_UNIT(5 + 3 * S::NL);
             f32x4 acc[S::MTPW][S::NTC];
             acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.post1_b, 0, 1, S::NTC);
             const float* const segs[2] = {W0 + (16 * wave + li + 1) * LDC + lg, Ebuf + (16 * wave + li + 1) * LDC + lg};
-            conv_multi<S, S::NTC, 2, S::KS_C, LDC>(acc, segs, wb, o.post1_w);
+            conv_multi<S, S::NTC, 2, S::KS_C, LDC>(acc, segs, wb, o.post1_w, job);
+            dma_rest(job);
             conv_store<S, S::NTC, C1, LDC, true>(acc, W1, 1, wave, lane);
         }
         __syncthreads();
         {
             // transposed conv as GEMM: P[i][co*8+j] = sum_ci x[i][ci] w[ci][co][j]
-            begin_unit();
+            FE_BEGIN_UNIT(6 + 3 * S::NL);
             f32x4 acc[S::MTPW][1];
             acc_init_zero<S::MTPW, 1>(acc);
-            conv_seg<S, 1, S::KS_C, S::KS_C, LDC>(acc, W1 + (16 * wave + li + 1) * LDC + lg, wb, o.post_t_w);
+            conv_seg<S, 1, S::KS_C, S::KS_C, LDC>(acc, W1 + (16 * wave + li + 1) * LDC + lg, wb, o.post_t_w, job);
+            dma_rest(job);
             conv_store<S, 1, 16, S::LDP, false>(acc, PT, 0, wave, lane);
         }
         __syncthreads();
