@@ -84,6 +84,21 @@ def cpu_baseline(workload: str, kw: dict, sr: int, B: int, budget_s: float):
                       f"{dt:.1f} s, host has {os.cpu_count()} logical cores"}
 
 
+def measured_traffic(workload: str, B: int, T: int):
+    """HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE), if one
+    exists for exactly this configuration; None otherwise."""
+    best = None
+    for name in sorted(os.listdir(os.path.join(REPO, "profiles"))) if os.path.isdir(os.path.join(REPO, "profiles")) else []:
+        if name.startswith("pmc_") and name.endswith(".json"):
+            try:
+                d = json.load(open(os.path.join(REPO, "profiles", name)))
+            except Exception:
+                continue
+            if d.get("workload") == workload and d.get("streams_per_gpu") == B and d.get("frames_per_step") == T:
+                best = d.get("hbm_bytes_per_launch")
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,7 +202,9 @@ def main():
                        "weights": "seeded random checkpoint (no trained weights offline), BN/weight-norm folded"},
             "rtf_per_stream": dt * w["sr"] / (args.steps * T * H * B * world) * world,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": measured_traffic(args.workload, B, T),
+                         "algorithmic_flops_per_launch": flops_per_launch,
+                         "algorithmic_hbm_bytes_per_launch": B * T * (2 * H * 4) + 2 * 4 * eng.state_floats(B),
                          "kernel": "fe_frame_kernel", "kernel_ms": kernel_ms,
                          "flops_per_frame": eng.flops_per_frame,
                          "hbm_frac": (B * T * (2 * H * 4) + 2 * 4 * eng.state_floats(B)) / (kernel_ms * 1e-3) / 8e12},
