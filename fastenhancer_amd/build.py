@@ -1,39 +1,85 @@
-"""Build libfastenhancer_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libfastenhancer_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+One translation unit per compiled shape (csrc/fe_shapes.def) plus the C-ABI unit; they are compiled
+in parallel and linked into one shared library.  Objects are cached under csrc/_obj/ and rebuilt when
+any source they include changes."""
 from __future__ import annotations
 
+import concurrent.futures
+import hashlib
 import os
+import re
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libfastenhancer_hip.so")
-SOURCES = ["fe_api.hip"]
-DEPS = ["fe_api.hip", "fe_kernels.hip.h", os.path.join("..", "..", "include", "fastenhancer_hip.h")]
+COMMON_DEPS = ["fe_kernels.hip.h", "fe_impl.h", "fe_shapes.def", os.path.join("..", "..", "include", "fastenhancer_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
 def _hipcc() -> str:
-    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
-        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
             return cand
     return "hipcc"
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+def shapes():
+    out = []
+    for line in open(os.path.join(CSRC, "fe_shapes.def")):
+        m = re.match(r"\s*X\(\s*(\w+)\s*,(.*)\)\s*$", line)
+        if m:
+            out.append((m.group(1), ",".join(x.strip() for x in m.group(2).split(","))))
+    return out
+
+
+def _digest(paths, extra="") -> str:
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _compile(job):
+    src, obj, defs, stamp, key = job
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == key:
+        return obj, False
+    cmd = [_hipcc()] + FLAGS + defs + ["-c", "-x", "hip", src, "-o", obj]
+    subprocess.check_call(cmd)
+    open(stamp, "w").write(key)
+    return obj, True
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
-        return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print("[fastenhancer_amd] " + " ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ, exist_ok=True)
+    common = [os.path.join(CSRC, d) for d in COMMON_DEPS]
+    jobs = []
+    api = os.path.join(CSRC, "fe_api.hip")
+    jobs.append((api, os.path.join(OBJ, "fe_api.o"), [], os.path.join(OBJ, "fe_api.stamp"), _digest(common + [api], " ".join(FLAGS))))
+    tmpl = os.path.join(CSRC, "fe_shape.hip.in")
+    for name, args in shapes():
+        defs = [f"-DFE_SHAPE_NAME={name}", f"-DFE_SHAPE_ARGS={args}"]
+        jobs.append((tmpl, os.path.join(OBJ, f"fe_shape_{name}.o"), defs, os.path.join(OBJ, f"fe_shape_{name}.stamp"),
+                     _digest(common + [tmpl], " ".join(FLAGS + defs))))
+    if force:
+        for j in jobs:
+            if os.path.exists(j[3]):
+                os.remove(j[3])
+    workers = max(1, min(len(jobs), (os.cpu_count() or 2)))
+    rebuilt = False
+    with concurrent.futures.ThreadPoolExecutor(workers) as ex:
+        for obj, did in ex.map(_compile, jobs):
+            rebuilt |= did
+            if verbose and did:
+                print(f"[fastenhancer_amd] compiled {os.path.basename(obj)}", file=sys.stderr)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [j[1] for j in jobs]
+        subprocess.check_call(cmd)
+        if verbose:
+            print(f"[fastenhancer_amd] linked {LIB}", file=sys.stderr)
     return LIB
 
 

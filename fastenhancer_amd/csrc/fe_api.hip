@@ -11,7 +11,7 @@
 #include <vector>
 
 #include "../../include/fastenhancer_hip.h"
-#include "fe_kernels.hip.h"
+#include "fe_impl.h"
 
 namespace {
 
@@ -45,62 +45,15 @@ struct Dims {
 };
 
 // ---------------------------------------------------------------------------- dispatch table
-struct Impl {
-    int C1, NL, C2, F2, KB, NFFT, HOP;
-    size_t lds_bytes;
-    int n_units, u_max;
-    bool staged;
-    size_t dbg_floats;
-    int dbg_stages;
-    const fe::PackedOffsets* off;
-    void (*launch)(const fe::FrameArgs&, bool spec_mode, hipStream_t, hipError_t*);
-    void (*dbg_stage)(int, int*, int*, size_t*);
-};
+#define X(name, ...) extern "C" const fe::Impl* fe_impl_##name();
+#include "fe_shapes.def"
+#undef X
 
-template <class S>
-void launch_impl(const fe::FrameArgs& a, bool spec_mode, hipStream_t st, hipError_t* err) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fe::fe_frame_kernel<S, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)fe::Lds<S>::BYTES);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fe::fe_frame_kernel<S, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fe::Lds<S>::BYTES);
-        if (e != hipSuccess) { *err = e; return; }
-        attr_set = true;
-    }
-    dim3 grid(a.B), block(fe::kThreads);
-    if (spec_mode)
-        hipLaunchKernelGGL((fe::fe_frame_kernel<S, true>), grid, block, fe::Lds<S>::BYTES, st, a);
-    else
-        hipLaunchKernelGGL((fe::fe_frame_kernel<S, false>), grid, block, fe::Lds<S>::BYTES, st, a);
-    *err = hipGetLastError();
-}
-
-template <class S>
-void dbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
-    *rows = fe::DebugLayout<S>::rows(s);
-    *cols = fe::DebugLayout<S>::cols(s);
-    *off = fe::DebugLayout<S>::offset(s);
-}
-
-template <class S>
-Impl make_impl() {
-    return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, fe::Lds<S>::BYTES, S::NU, fe::Pack<S>::umax(), fe::Lds<S>::STAGED,
-                fe::DebugLayout<S>::total(), fe::DebugLayout<S>::n_stages, &fe::Pack<S>::v, &launch_impl<S>, &dbg_stage_impl<S>};
-}
-
-// Shapes of the shipped yamls (configs/fastenhancer/*.yaml, configs/fastenhancer_48khz/*.yaml).
-//                      C1  NL  C2  F2 KB  NFFT  HOP
-using ShapeT   = fe::Shape<24, 2, 20, 16, 2, 512, 256>;
-using ShapeB   = fe::Shape<48, 2, 36, 24, 3, 512, 256>;
-using ShapeS   = fe::Shape<64, 3, 48, 36, 3, 512, 256>;
-using ShapeT48 = fe::Shape<24, 2, 20, 24, 2, 1024, 512>;
-using ShapeB48 = fe::Shape<48, 2, 36, 36, 3, 1024, 512>;
-
-const std::vector<Impl>& impls() {
-    static const std::vector<Impl> v = {
-        make_impl<ShapeT>(), make_impl<ShapeB>(), make_impl<ShapeS>(), make_impl<ShapeT48>(), make_impl<ShapeB48>(),
+const std::vector<const fe::Impl*>& impls() {
+    static const std::vector<const fe::Impl*> v = {
+#define X(name, ...) fe_impl_##name(),
+#include "fe_shapes.def"
+#undef X
     };
     return v;
 }
@@ -110,11 +63,13 @@ const std::vector<Impl>& impls() {
 struct fe_handle {
     fe_config cfg;
     Dims d;
-    const Impl* impl = nullptr;
+    const fe::Impl* impl = nullptr;
     int device = 0;
     std::vector<Section> sections;
     size_t blob_floats = 0;
     float* packed_dev = nullptr;
+    float* skip_dev = nullptr;     // scratch for shapes whose skips do not fit in LDS
+    int skip_streams = 0;
     bool loaded = false;
     std::vector<float> window, window_istft, twiddle;
 };
@@ -258,10 +213,19 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
     }
     for (int k = 0; k < d.KB; ++k) {
         auto key = [&](const char* s) { snprintf(nm, sizeof nm, "rf_block.%d.%s", k, s); return std::string(nm); };
-        pack_1x1(o.blk_wih[k], S(key("rnn.weight_ih_l0")), C2, 3 * C2);
-        pack_1x1(o.blk_whh[k], S(key("rnn.weight_hh_l0")), C2, 3 * C2);
-        p.raw(o.blk_bih[k], 3 * C2, S(key("rnn.bias_ih_l0")));
-        p.raw(o.blk_bhh[k], 3 * C2, S(key("rnn.bias_hh_l0")));
+        {   // GRU (3*C2, C2), gate order r,z,n: one padded column block per gate
+            const int gsz = fe::ceil_div(C2, 16) * (C2 / 4) * 64, bsz = fe::round_up(C2, 16);
+            const float* wih = S(key("rnn.weight_ih_l0"));
+            const float* whh = S(key("rnn.weight_hh_l0"));
+            const float* bih = S(key("rnn.bias_ih_l0"));
+            const float* bhh = S(key("rnn.bias_hh_l0"));
+            for (int g = 0; g < 3; ++g) {
+                pack_1x1(o.blk_wih[k] + g * gsz, wih + (size_t)g * C2 * C2, C2, C2);
+                pack_1x1(o.blk_whh[k] + g * gsz, whh + (size_t)g * C2 * C2, C2, C2);
+                p.raw(o.blk_bih[k] + g * bsz, C2, bih + g * C2);
+                p.raw(o.blk_bhh[k] + g * bsz, C2, bhh + g * C2);
+            }
+        }
         pack_1x1(o.blk_fc1_w[k], S(key("rnn_fc.weight")), C2, C2);
         p.raw(o.blk_fc1_b[k], C2, S(key("rnn_fc.bias")));
         if (k == 0) p.raw(o.blk_pe, (size_t)F2 * C2, S(key("pe")));
@@ -301,12 +265,24 @@ int check_ready(const fe_handle* h) {
     return FE_OK;
 }
 
+// Scratch for the encoder outputs of shapes that keep them in global memory (grow-only; allocating
+// synchronises, so call once with the largest B before capturing graphs / timing).
+int ensure_scratch(fe_handle* h, int B) {
+    if (h->impl->skip_floats == 0 || B <= h->skip_streams) return FE_OK;
+    if (h->skip_dev) { FE_HIP_CHECK(hipDeviceSynchronize()); FE_HIP_CHECK(hipFree(h->skip_dev)); h->skip_dev = nullptr; h->skip_streams = 0; }
+    FE_HIP_CHECK(hipMalloc(&h->skip_dev, (size_t)B * h->impl->skip_floats * sizeof(float)));
+    FE_HIP_CHECK(hipMemset(h->skip_dev, 0, (size_t)B * h->impl->skip_floats * sizeof(float)));
+    h->skip_streams = B;
+    return FE_OK;
+}
+
 fe::FrameArgs base_args(fe_handle* h, int B, int T) {
     fe::FrameArgs a{};
     a.wp = h->packed_dev;
     a.B = B;
     a.T = T;
     a.compression = h->cfg.input_compression;
+    a.skip = h->skip_dev;
     return a;
 }
 
@@ -333,11 +309,11 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
     if (cfg->rf_heads != 4) return fail(FE_ERR_UNSUPPORTED_CONFIG, "num_heads=%d (shipped: 4)", cfg->rf_heads);
     if (!(cfg->input_compression > 0.0f && cfg->input_compression <= 1.0f)) return fail(FE_ERR_INVALID_ARG, "input_compression");
 
-    const Impl* impl = nullptr;
-    for (const Impl& im : impls())
-        if (im.C1 == cfg->channels && im.NL == cfg->n_kernels - 1 && im.C2 == cfg->rf_channels && im.F2 == cfg->rf_freq &&
-            im.KB == cfg->rf_blocks && im.NFFT == cfg->n_fft && im.HOP == cfg->hop_size)
-            impl = &im;
+    const fe::Impl* impl = nullptr;
+    for (const fe::Impl* im : impls())
+        if (im->C1 == cfg->channels && im->NL == cfg->n_kernels - 1 && im->C2 == cfg->rf_channels && im->F2 == cfg->rf_freq &&
+            im->KB == cfg->rf_blocks && im->NFFT == cfg->n_fft && im->HOP == cfg->hop_size)
+            impl = im;
     if (!impl)
         return fail(FE_ERR_UNSUPPORTED_CONFIG,
                     "no kernel compiled for channels=%d layers=%d rf_channels=%d rf_freq=%d rf_blocks=%d n_fft=%d hop=%d",
@@ -359,6 +335,7 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
 void fe_destroy(fe_handle* h) {
     if (!h) return;
     if (h->packed_dev) (void)hipFree(h->packed_dev);
+    if (h->skip_dev) (void)hipFree(h->skip_dev);
     delete h;
 }
 
@@ -411,6 +388,8 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
     const Dims& d = h->d;
     if (in_stride < (size_t)T * d.HOP && B > 1) return fail(FE_ERR_INVALID_ARG, "in_stride %zu < T*H", in_stride);
     if (out_stride < (size_t)T * d.HOP && B > 1) return fail(FE_ERR_INVALID_ARG, "out_stride %zu < T*H", out_stride);
+    rc = ensure_scratch(h, B);
+    if (rc != FE_OK) return rc;
     fe::FrameArgs a = base_args(h, B, T);
     const size_t ovl = (size_t)(d.NFFT - d.HOP);
     a.wav_in = wav_in;
@@ -450,6 +429,8 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
     int rc = check_ready(h);
     if (rc != FE_OK) return rc;
     if (!spec_in_dev || !h_dev || !spec_out_dev || B <= 0 || T <= 0) return fail(FE_ERR_INVALID_ARG, "bad argument");
+    rc = ensure_scratch(h, B);
+    if (rc != FE_OK) return rc;
     fe::FrameArgs a = base_args(h, B, T);
     a.spec_in = spec_in_dev;
     a.spec_out = spec_out_dev;

@@ -1,0 +1,58 @@
+// fe_impl.h — per-shape dispatch record shared by fe_api.hip and the per-shape translation units
+// (one fe_shape_<name>.hip per compiled shape, so that the shapes build in parallel).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fe_kernels.hip.h"
+
+namespace fe {
+
+struct Impl {
+    int C1, NL, C2, F2, KB, NFFT, HOP;
+    size_t lds_bytes;
+    int n_units, u_max;
+    bool staged;
+    size_t skip_floats;   // per stream, 0 when the skips stay in LDS
+    size_t dbg_floats;
+    int dbg_stages;
+    const PackedOffsets* off;
+    void (*launch)(const FrameArgs&, bool spec_mode, hipStream_t, hipError_t*);
+    void (*dbg_stage)(int, int*, int*, size_t*);
+};
+
+template <class S>
+void launch_impl(const FrameArgs& a, bool spec_mode, hipStream_t st, hipError_t* err) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fe_frame_kernel<S, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds<S>::BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fe_frame_kernel<S, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds<S>::BYTES);
+        if (e != hipSuccess) { *err = e; return; }
+        attr_set = true;
+    }
+    dim3 grid(a.B), block(kThreads);
+    if (spec_mode)
+        hipLaunchKernelGGL((fe_frame_kernel<S, true>), grid, block, Lds<S>::BYTES, st, a);
+    else
+        hipLaunchKernelGGL((fe_frame_kernel<S, false>), grid, block, Lds<S>::BYTES, st, a);
+    *err = hipGetLastError();
+}
+
+template <class S>
+void dbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
+    *rows = DebugLayout<S>::rows(s);
+    *cols = DebugLayout<S>::cols(s);
+    *off = DebugLayout<S>::offset(s);
+}
+
+template <class S>
+Impl make_impl() {
+    return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, Lds<S>::BYTES, S::NU, Pack<S>::umax(), Lds<S>::STAGED,
+                Lds<S>::SKIPS_LDS ? (size_t)0 : (size_t)(S::NL + 1) * S::F1 * S::C1,
+                DebugLayout<S>::total(), DebugLayout<S>::n_stages, &Pack<S>::v, &launch_impl<S>, &dbg_stage_impl<S>};
+}
+
+
+}  // namespace fe

@@ -128,8 +128,10 @@ struct Pack {
         o.n_units = nu;
         // RNNFormer-block weights: read by each wave straight into registers (not staged)
         for (int k = 0; k < S::KB; ++k) {
-            o.blk_wih[k] = alloc(szB(C2, 3 * C2)); o.blk_whh[k] = alloc(szB(C2, 3 * C2));
-            o.blk_bih[k] = alloc(szBias(3 * C2)); o.blk_bhh[k] = alloc(szBias(3 * C2));
+            // GRU weights packed per gate (r, z, n): tile index = gate * NT2 + channel-tile, so that the three
+            // gate pre-activations of one (row, channel) land in the same lane and the gates fuse into the epilogue
+            o.blk_wih[k] = alloc(3 * szB(C2, C2)); o.blk_whh[k] = alloc(3 * szB(C2, C2));
+            o.blk_bih[k] = alloc(3 * szBias(C2)); o.blk_bhh[k] = alloc(3 * szBias(C2));
             o.blk_fc1_w[k] = alloc(szB(C2, C2)); o.blk_fc1_b[k] = alloc(szBias(C2));
             if (k == 0) o.blk_pe = alloc(F2 * C2);
             o.blk_qkv[k] = alloc(szB(C2, 3 * C2));
@@ -151,6 +153,7 @@ struct FrameArgs {
     float* cache_stft;        // [B][OVL]
     float* cache_istft;       // [B][OVL]
     float* h;                 // [KB][B*F2][C2]
+    float* skip;              // global skip scratch [B][(NL+1)][F1*C1] (A-fragment order), shapes with !Lds::SKIPS_LDS
     const float* spec_in;     // spec mode: [B][F0+1][T][2]
     float* spec_out;
     float* dbg;               // debug dumps or nullptr
@@ -346,12 +349,19 @@ struct Lds {
     static constexpr int cmax(int a, int b) { return a > b ? a : b; }
     static constexpr int SC = 0;                                  // compressed spectrum [2][LDS_S]
     static constexpr int TW = SC + 2 * S::LDS_S;                  // twiddles float2[N/2]
-    static constexpr int E = TW + S::NFFT;                        // skips: (NL+1) x ACT
-    static constexpr int ARENA = E + (S::NL + 1) * S::ACT;
+    static constexpr int E = TW + S::NFFT;                        // skips: (NL+1) x ACT (when they fit)
+    // Encoder outputs ("skips") stay in LDS from the encoder to the decoder when the plan fits in 160 KiB;
+    // otherwise they live in a per-stream global scratch (L2-resident) in MFMA A-fragment order and the
+    // encoder ping-pongs through W0/W1 of the arena.
+    static constexpr int ARENA_SIZE_SKIPS_LDS =
+        cmax(cmax(4 * S::NFFT, 3 * S::F2P * S::LDX + S::F2P * S::LDG),
+             cmax(2 * S::ACT + S::F1 * S::LDP, cmax(S::F2P * S::LDX, S::ACT) + S::F1 * S::LDX));
+    static constexpr bool SKIPS_LDS = (size_t)(E + (S::NL + 1) * S::ACT + ARENA_SIZE_SKIPS_LDS) * 4 <= 160 * 1024;
+    static constexpr int ARENA = E + (SKIPS_LDS ? (S::NL + 1) * S::ACT : 0);
     // The arena is re-used by the phases of a frame (offsets relative to ARENA):
     //   STFT / iSTFT : FFT_A, FFT_B                       (complex ping-pong)
-    //   rf_pre       : Y1 (aliases GI), X
-    //   blocks       : X, HL, GI, GH
+    //   rf_pre       : Y1 (aliases the qkv buffer), X
+    //   blocks       : X, HL, HS, qkv
     //   rf_post      : X (read) -> Y2 -> W0               (Y2 must not overlap X nor W0)
     //   decoder      : W0, W1, PT
     static constexpr int FFT_A = ARENA;
@@ -359,16 +369,17 @@ struct Lds {
     static constexpr int END_FFT = 4 * S::NFFT;
     static constexpr int X = ARENA;                               // [F2P][LDX]
     static constexpr int HL = X + S::F2P * S::LDX;                // hidden state / attention out
-    static constexpr int GI = HL + S::F2P * S::LDX;               // [F2P][LDG]  (also qkv)
-    static constexpr int GH = GI + S::F2P * S::LDG;               // [F2P][LDG]
-    static constexpr int HS = GH + S::F2P * S::LDG;               // GRU hidden state of the current block [F2P][LDX]
-    static constexpr int END_RF = 3 * S::F2P * S::LDX + 2 * S::F2P * S::LDG;
+    static constexpr int HS = HL + S::F2P * S::LDX;               // GRU hidden state of the current block [F2P][LDX]
+    // qkv [F2P][LDG]; with global skips the last encoder output sits in W0 while rf_pre writes Y1 (= this buffer)
+    static constexpr int GI_OFF = SKIPS_LDS ? 3 * S::F2P * S::LDX : cmax(3 * S::F2P * S::LDX, S::ACT);
+    static constexpr int GI = ARENA + GI_OFF;
+    static constexpr int END_RF = GI_OFF + S::F2P * S::LDG;
     static constexpr int Y1 = GI;                                 // rf_pre intermediate [F2P][LDC]
     static constexpr int W0 = ARENA;
     static constexpr int W1 = W0 + S::ACT;
     static constexpr int PT = W1 + S::ACT;                        // [F1][LDP]
     static constexpr int END_CONV = 2 * S::ACT + S::F1 * S::LDP;
-    static constexpr int Y2_OFF = cmax(2 * S::F2P * S::LDX, S::ACT);
+    static constexpr int Y2_OFF = cmax(S::F2P * S::LDX, S::ACT);   // after X, after W0
     static constexpr int Y2 = ARENA + Y2_OFF;                     // rf_post intermediate [F1][LDX]
     static constexpr int END_Y2 = Y2_OFF + S::F1 * S::LDX;
     static constexpr int ARENA_SIZE = cmax(cmax(END_FFT, END_RF), cmax(END_CONV, END_Y2));
@@ -380,7 +391,7 @@ struct Lds {
     static constexpr int TOTAL = STAGED ? NOSTAGE_TOTAL + 2 * Pack<S>::umax() : NOSTAGE_TOTAL;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
     static_assert(2 * S::ACT >= 2 * S::NFFT, "FFT_A must not reach the transposed-conv partials");
-    static_assert(S::F2P * S::LDC <= 2 * S::F2P * S::LDG, "rf_pre intermediate must fit in GI+GH");
+    static_assert(S::F2P * S::LDC <= S::F2P * S::LDG, "rf_pre intermediate must fit in the qkv buffer");
 };
 
 // ------------------------------------------------------------------------------------------
@@ -433,8 +444,12 @@ __device__ __forceinline__ void conv_multi(f32x4 (&acc)[S::MTPW][NT], const floa
 }
 
 // Epilogue of a conv-layout GEMM: optional SiLU, store to out[(row0 + m)][col] for col < NCOLS.
+// gskip != nullptr: also store the value into a global skip buffer in A-fragment order
+//   gskip[((mt * KS_C + col/4) * 64 + (col%4) * 16 + m%16)],   mt = m / 16
+// (what the decoder's 1x1 conv later reads back as coalesced 256-byte A fragments).
 template <class S, int NT, int NCOLS, int LDO, bool ACT>
-__device__ __forceinline__ void conv_store(const f32x4 (&acc)[S::MTPW][NT], float* out, int row0, int wave, int lane) {
+__device__ __forceinline__ void conv_store(const f32x4 (&acc)[S::MTPW][NT], float* out, int row0, int wave, int lane,
+                                           float* gskip = nullptr) {
     const int li = lane & 15, lg = lane >> 4;
 #pragma unroll
     for (int i = 0; i < S::MTPW; ++i)
@@ -448,6 +463,7 @@ __device__ __forceinline__ void conv_store(const f32x4 (&acc)[S::MTPW][NT], floa
                     float v = acc[i][j][r];
                     if (ACT) v = silu_f(v);
                     out[(row0 + m) * LDO + col] = v;
+                    if (gskip != nullptr) gskip[((wave + 4 * i) * S::KS_C + (col >> 2)) * 64 + (col & 3) * 16 + 4 * lg + r] = v;
                 }
             }
         }
@@ -466,39 +482,56 @@ __device__ __forceinline__ void tok_gemm(f32x4 (&acc)[S::MT2][NTPW], const float
         }, DmaSide{&job});
 }
 
-// Token GEMMs split the OUTPUT columns over the waves, so a wave's B fragments (weights) are private
-// to it: they are fetched straight from L2 into registers one phase ahead (tok_prefetch) and the GEMM
-// then runs with register-resident weights (tok_gemm_r) - no LDS staging, no load latency in the phase.
-template <int NTPW, int KS, class WS>
-__device__ __forceinline__ void tok_prefetch(float (&w)[NTPW][KS], const WS& src, int w_off, int NT, int wave) {
+// Token GEMMs split the OUTPUT columns over the waves, so a wave's B fragments (weights) are private to
+// it.  TokW holds the fragments of this wave's column tiles ct = wave + 4j (NG column blocks per tile:
+// 3 for the per-gate packed GRU matrices, else 1; fragment tile index = g * NT + ct):
+//   REG = true : fetched from L2 into registers by fetch(), one phase before the GEMM that uses them
+//   REG = false: (shapes whose fragments do not fit in registers) fetched inside the GEMM's software pipeline
+template <int NTPW, int KS, int NG, bool REG, class WS>
+struct TokW {
+    float w[REG ? NTPW : 1][NG][REG ? KS : 1];
+    float bv[REG ? NTPW : 1][NG];
+    const WS* src;
+    int w_off, b_off, NT, wave;
+    __device__ __forceinline__ int tile(int j, int g) const {
+        int ct = wave + 4 * j;
+        ct = ct < NT ? ct : NT - 1;
+        return g * NT + ct;
+    }
+    __device__ __forceinline__ void fetch(const WS& s, int w_off_, int b_off_, int NT_, int wave_) {
+        src = &s; w_off = w_off_; b_off = b_off_; NT = NT_; wave = wave_;
+        if constexpr (REG) {
+#pragma unroll
+            for (int j = 0; j < NTPW; ++j)
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    bv[j][g] = b_off >= 0 ? s.at16_g(b_off + tile(j, g) * 16) : 0.0f;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) w[j][g][ks] = s.at_g(w_off + (tile(j, g) * KS + ks) * 64);
+                }
+        }
+    }
+    __device__ __forceinline__ float get(int j, int g, int ks) const {
+        if constexpr (REG) return w[j][g][ks];
+        else return src->at_g(w_off + (tile(j, g) * KS + ks) * 64);
+    }
+    __device__ __forceinline__ float bias(int j, int g) const {
+        if constexpr (REG) return bv[j][g];
+        else return b_off >= 0 ? src->at16_g(b_off + tile(j, g) * 16) : 0.0f;
+    }
+};
+
+// acc = bias + A(LDS tokens) x W  for this wave's column tiles
+template <class S, int NTPW, int KS, int LDA, class TW>
+__device__ __forceinline__ void tok_gemm_w(f32x4 (&acc)[S::MT2][NTPW], const float* a_lane, const TW& W) {
 #pragma unroll
     for (int j = 0; j < NTPW; ++j) {
-        int nt = wave + 4 * j;
-        nt = nt < NT ? nt : NT - 1;
+        const float bj = W.bias(j, 0);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) w[j][ks] = src.at_g(w_off + (nt * KS + ks) * 64);
+        for (int i = 0; i < S::MT2; ++i) acc[i][j] = f32x4{bj, bj, bj, bj};
     }
-}
-template <int NTPW, class WS>
-__device__ __forceinline__ void bias_prefetch(float (&bv)[NTPW], const WS& src, int b_off, int NT, int wave) {
-#pragma unroll
-    for (int j = 0; j < NTPW; ++j) {
-        int nt = wave + 4 * j;
-        nt = nt < NT ? nt : NT - 1;
-        bv[j] = src.at16_g(b_off + nt * 16);
-    }
-}
-template <class S, int NTPW, int KS, int LDA>
-__device__ __forceinline__ void tok_gemm_r(f32x4 (&acc)[S::MT2][NTPW], const float* a_lane, const float (&w)[NTPW][KS]) {
     mma_panel<S::MT2, NTPW, KS>(
-        acc, [&](int i, int ks) { return a_lane[(16 * i) * LDA + 4 * ks]; }, [&](int j, int ks) { return w[j][ks]; }, NoSide{});
-}
-template <int MTP, int NTP>
-__device__ __forceinline__ void acc_init_regs(f32x4 (&acc)[MTP][NTP], const float (&bv)[NTP]) {
-#pragma unroll
-    for (int j = 0; j < NTP; ++j)
-#pragma unroll
-        for (int i = 0; i < MTP; ++i) acc[i][j] = f32x4{bv[j], bv[j], bv[j], bv[j]};
+        acc, [&](int i, int ks) { return a_lane[(16 * i) * LDA + 4 * ks]; }, [&](int j, int ks) { return W.get(j, 0, ks); }, NoSide{});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -534,6 +567,23 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     float2* fa = reinterpret_cast<float2*>(smem + L::FFT_A);
     float2* fb = reinterpret_cast<float2*>(smem + L::FFT_B);
     float* Ebuf = smem + L::E;
+    constexpr bool SG = !L::SKIPS_LDS;               // skips in the global scratch
+    constexpr int SKIP_FLOATS = F1 * C1;             // one skip tensor in A-fragment order
+    float* W0 = smem + L::W0;
+    float* W1 = smem + L::W1;
+    float* skipg = SG ? a.skip + (size_t)b * ((S::NL + 1) * SKIP_FLOATS) : nullptr;
+    WSrc<false> skb;                                 // the same scratch as a buffer resource (coalesced fragment reads)
+    skb.rsrc = __builtin_amdgcn_make_buffer_rsrc(SG ? skipg : const_cast<float*>(a.wp), 0, SG ? (S::NL + 1) * SKIP_FLOATS * 4 : 4, 0x00020000);
+    skb.lane4 = lane * 4;
+    skb.li4 = (lane & 15) * 4;
+    skb.lds = nullptr;
+    skb.base = 0;
+    // LDS buffer that holds the output of enc_pre (l = 0) / encoder layer l-1; with global skips the encoder
+    // ping-pongs through W0/W1 such that the last output lands in W0
+    auto encbuf = [&](int l) -> float* {
+        if constexpr (!SG) return Ebuf + l * S::ACT;
+        else return ((l + (S::NL & 1)) & 1) ? W1 : W0;
+    };
     // weight units: unit U of frame t is consumed from LDS buffer ((U + t*NU) & 1) while the next streams in
     DmaJob job{wp + lane * 4, smem, 0, wave};
     if constexpr (L::STAGED) {
@@ -629,17 +679,23 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 },
                 [&](int j, int ks) { return wb.at(o.enc_pre_w + (j * 4 + ks) * 64); }, DmaSide{&job});
             dma_rest(job);
-            conv_store<S, S::NTC, C1, LDC, true>(acc, Ebuf, 1, wave, lane);
+            if constexpr (SG) {   // the arena was used by the FFT: restore the zero halo rows of both ping-pong buffers
+                for (int i = tid; i < 4 * LDC; i += kThreads) {
+                    const int q = i / LDC, c = i - q * LDC;
+                    ((q & 2) ? W1 : W0)[((q & 1) ? F1 + 1 : 0) * LDC + c] = 0.0f;
+                }
+            }
+            conv_store<S, S::NTC, C1, LDC, true>(acc, encbuf(0), 1, wave, lane, SG ? skipg : nullptr);
         }
         __syncthreads();
-        dbg_dump<S>(a, b, 2, Ebuf + LDC, LDC);
+        dbg_dump<S>(a, b, 2, encbuf(0) + LDC, LDC);
 
         FE_CLK(4);
         // =========================== encoder (a6): k=3 convs ===========================
         static_for<S::NL>([&](auto l_) {
             constexpr int l = decltype(l_)::value;
-            const float* in = Ebuf + l * S::ACT;
-            float* out = Ebuf + (l + 1) * S::ACT;
+            const float* in = encbuf(l);
+            float* out = encbuf(l + 1);
             FE_BEGIN_UNIT(1 + l);
             f32x4 acc[S::MTPW][S::NTC];
             acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.enc_b[l], 0, 1, S::NTC);
@@ -647,7 +703,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                                           in + (16 * wave + li + 2) * LDC + lg};
             conv_multi<S, S::NTC, 3, S::KS_C, LDC>(acc, taps, wb, o.enc_w[l], job);
             dma_rest(job);
-            conv_store<S, S::NTC, C1, LDC, true>(acc, out, 1, wave, lane);
+            conv_store<S, S::NTC, C1, LDC, true>(acc, out, 1, wave, lane, SG ? skipg + (l + 1) * SKIP_FLOATS : nullptr);
             __syncthreads();
             dbg_dump<S>(a, b, 3 + l, out + LDC, LDC);
         });
@@ -656,7 +712,6 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         float* Hl = smem + L::HL;
         float* Hs = smem + L::HS;
         float* Gi = smem + L::GI;
-        float* Gh = smem + L::GH;
         float* Y1 = smem + L::Y1;
         float* Y2 = smem + L::Y2;
 
@@ -665,19 +720,20 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         constexpr int NTPW2 = ceil_div(S::NT2, kWaves);
         constexpr int HPT = ceil_div(F2 * C2, kThreads);   // hidden-state elements per thread
         f32x4 xr[S::MT2][NTPW2];                           // residual stream x, this wave's output tiles
-        // register-resident weights of the RNNFormer-block GEMMs (this wave's output columns), each set
-        // prefetched from L2 one phase before the GEMM that uses it
+        // weights of the RNNFormer-block GEMMs (this wave's output columns): register-resident and prefetched
+        // one phase ahead when they fit (REGW), else streamed from L2 inside the GEMM pipeline
         constexpr int NTPW3 = ceil_div(S::NT3, kWaves);
-        float wg_i[NTPW3][S::KS_2], wg_h[NTPW3][S::KS_2], bg_i[NTPW3], bg_h[NTPW3];   // GRU
-        float w1[NTPW2][S::KS_2], b1[NTPW2];                                           // rnn_fc
-        float wq[NTPW3][S::KS_2];                                                      // qkv
-        float w2[NTPW2][S::KS_2], b2[NTPW2];                                           // attn_fc
+        constexpr bool REGW = (NTPW2 * 6 + NTPW3 + 2 * NTPW2) * S::KS_2 <= 160;
+        using WS = WSrc<Lds<S>::STAGED>;
+        TokW<NTPW2, S::KS_2, 3, REGW, WS> Wgi, Wgh;     // GRU gates (r,z,n): input and hidden matrices
+        TokW<NTPW2, S::KS_2, 1, REGW, WS> Wf1, Wf2;     // rnn_fc, attn_fc
+        TokW<NTPW3, S::KS_2, 1, REGW, WS> Wq;           // qkv
         float pe_r[S::MT2][NTPW2][4];                                                  // positional embedding (block 0)
         {
             // Y1[f2][c1] = sum_f1 Wf[f2][f1] * E[f1][c1]      (A = packed filterbank, B = LDS)
             constexpr int NTPW = ceil_div(S::NTC, kWaves);
             constexpr int KS = F1 / 4;
-            const float* Ein = Ebuf + S::NL * S::ACT + LDC;   // row 0 = bin 0
+            const float* Ein = encbuf(S::NL) + LDC;   // row 0 = bin 0
             FE_BEGIN_UNIT(1 + S::NL);
             f32x4 acc[S::MT2][NTPW];
             acc_init_zero<S::MT2, NTPW>(acc);
@@ -710,10 +766,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             // X[f2][c2] = Y1[f2][:] . Wc[c2][:] + b
             constexpr int NTPW = ceil_div(S::NT2, kWaves);
             FE_BEGIN_UNIT(2 + S::NL);
-            tok_prefetch<NTPW3, S::KS_2>(wg_i, wb, o.blk_wih[0], S::NT3, wave);
-            tok_prefetch<NTPW3, S::KS_2>(wg_h, wb, o.blk_whh[0], S::NT3, wave);
-            bias_prefetch<NTPW3>(bg_i, wb, o.blk_bih[0], S::NT3, wave);
-            bias_prefetch<NTPW3>(bg_h, wb, o.blk_bhh[0], S::NT3, wave);
+            Wgi.fetch(wb, o.blk_wih[0], o.blk_bih[0], S::NT2, wave);
+            Wgh.fetch(wb, o.blk_whh[0], o.blk_bhh[0], S::NT2, wave);
             // hidden state of block 0: fetched now, parked in LDS after the GEMM
             float hpre[HPT];
             {
@@ -756,11 +810,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             float* hg = a.h + ((size_t)k * a.B + b) * (F2 * C2);
             if (k == 0) FE_CLK(20);
             {
-                // gi = x W_ih^T + b_ih ; gh = h W_hh^T + b_hh   (weights already in registers)
-                constexpr int NTPW = NTPW3;
+                // GRU (nn.GRU gate order r,z,n; model.py:187,271), gates fused into the GEMM epilogue:
+                //   ax[.][g] = x W_i{g}^T + b_i{g},  ah[.][g] = h W_h{g}^T + b_h{g}   for this wave's channel tiles
+                //   r = s(ax0+ah0), z = s(ax1+ah1), n = tanh(ax2 + r*ah2), h' = (1-z) n + z h
                 // prefetch for the next phase: rnn_fc weights (+ the positional embedding in block 0)
-                tok_prefetch<NTPW2, S::KS_2>(w1, wb, o.blk_fc1_w[k], S::NT2, wave);
-                bias_prefetch<NTPW2>(b1, wb, o.blk_fc1_b[k], S::NT2, wave);
+                Wf1.fetch(wb, o.blk_fc1_w[k], o.blk_fc1_b[k], S::NT2, wave);
                 if (k == 0) {
 #pragma unroll
                     for (int i = 0; i < S::MT2; ++i)
@@ -773,51 +827,50 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                             }
                 }
 #pragma unroll
-                for (int which = 0; which < 2; ++which) {
-                    f32x4 acc[S::MT2][NTPW];
-                    const float* asrc = (which == 0 ? Xb : Hs) + li * LDX + lg;
-                    float* dst = which == 0 ? Gi : Gh;
-                    if (which == 0) { acc_init_regs<S::MT2, NTPW>(acc, bg_i); tok_gemm_r<S, NTPW, S::KS_2, LDX>(acc, asrc, wg_i); }
-                    else            { acc_init_regs<S::MT2, NTPW>(acc, bg_h); tok_gemm_r<S, NTPW, S::KS_2, LDX>(acc, asrc, wg_h); }
+                for (int j = 0; j < NTPW2; ++j) {
+                    const int ct = wave + 4 * j;
+                    f32x4 ax[S::MT2][3], ah[S::MT2][3];
 #pragma unroll
-                    for (int i = 0; i < S::MT2; ++i)
+                    for (int g = 0; g < 3; ++g) {
+                        const float bi = Wgi.bias(j, g), bh = Wgh.bias(j, g);
 #pragma unroll
-                        for (int j = 0; j < NTPW; ++j) {
-                            const int nt = wave + 4 * j;
-                            if (nt < S::NT3) {
+                        for (int i = 0; i < S::MT2; ++i) { ax[i][g] = f32x4{bi, bi, bi, bi}; ah[i][g] = f32x4{bh, bh, bh, bh}; }
+                    }
+                    mma_panel<S::MT2, 3, S::KS_2>(
+                        ax, [&](int i, int ks) { return Xb[(16 * i + li) * LDX + lg + 4 * ks]; },
+                        [&](int g, int ks) { return Wgi.get(j, g, ks); }, NoSide{});
+                    mma_panel<S::MT2, 3, S::KS_2>(
+                        ah, [&](int i, int ks) { return Hs[(16 * i + li) * LDX + lg + 4 * ks]; },
+                        [&](int g, int ks) { return Wgh.get(j, g, ks); }, NoSide{});
+                    const int c = 16 * ct + li;
+                    if (ct < S::NT2 && c < C2) {
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const int row = 16 * i + 4 * lg + r;
-                                    if (row < F2) dst[row * LDG + 16 * nt + li] = acc[i][j][r];
+                        for (int i = 0; i < S::MT2; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = 16 * i + 4 * lg + r;
+                                if (row < F2) {
+                                    const float rr = sigmoid_f(ax[i][0][r] + ah[i][0][r]);
+                                    const float zz = sigmoid_f(ax[i][1][r] + ah[i][1][r]);
+                                    const float nn = tanh_f(ax[i][2][r] + rr * ah[i][2][r]);
+                                    const float hp = Hs[row * LDX + c];
+                                    const float hn = (1.0f - zz) * nn + zz * hp;
+                                    Hl[row * LDX + c] = hn;
+                                    hg[row * C2 + c] = hn;
                                 }
                             }
-                        }
+                    }
                 }
             }
             __syncthreads();
             if (k == 0) FE_CLK(21);
-            // gates (PyTorch order r,z,n) and state update
-            for (int i = tid; i < F2 * C2; i += kThreads) {
-                int f = i / C2, c = i - f * C2;
-                const float* gi = Gi + f * LDG;
-                const float* gh = Gh + f * LDG;
-                float r = sigmoid_f(gi[c] + gh[c]);
-                float z = sigmoid_f(gi[C2 + c] + gh[C2 + c]);
-                float n = tanh_f(gi[2 * C2 + c] + r * gh[2 * C2 + c]);
-                float hp = Hs[f * LDX + c];
-                float hn = (1.0f - z) * n + z * hp;
-                Hl[f * LDX + c] = hn;
-                hg[i] = hn;
-            }
-            __syncthreads();
             if (k == 0) FE_CLK(22);
             {
                 // x += rnn_fc(h') (+ pe in block 0)
                 constexpr int NTPW = NTPW2;
-                tok_prefetch<NTPW3, S::KS_2>(wq, wb, o.blk_qkv[k], S::NT3, wave);      // for the next phase
+                Wq.fetch(wb, o.blk_qkv[k], -1, S::NT3, wave);      // for the next phase
                 f32x4 acc[S::MT2][NTPW];
-                acc_init_regs<S::MT2, NTPW>(acc, b1);
-                tok_gemm_r<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, w1);
+                tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf1);
 #pragma unroll
                 for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -844,11 +897,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             {
                 // qkv = x W_qkv^T  -> Gi (rows per head interleaved [h][q|k|v][hd])
                 constexpr int NTPW = NTPW3;
-                tok_prefetch<NTPW2, S::KS_2>(w2, wb, o.blk_fc2_w[k], S::NT2, wave);     // for attn_fc
-                bias_prefetch<NTPW2>(b2, wb, o.blk_fc2_b[k], S::NT2, wave);
+                Wf2.fetch(wb, o.blk_fc2_w[k], o.blk_fc2_b[k], S::NT2, wave);     // for attn_fc
                 f32x4 acc[S::MT2][NTPW];
-                acc_init_zero<S::MT2, NTPW>(acc);
-                tok_gemm_r<S, NTPW, S::KS_2, LDX>(acc, Xb + li * LDX + lg, wq);
+                tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Xb + li * LDX + lg, Wq);
 #pragma unroll
                 for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -958,17 +1009,14 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 constexpr int NTPW = ceil_div(S::NT2, kWaves);
                 float hpre[HPT];
                 if (k + 1 < S::KB) {   // next block: GRU weights into registers, hidden state fetched now / parked after the GEMM
-                    tok_prefetch<NTPW3, S::KS_2>(wg_i, wb, o.blk_wih[k + 1], S::NT3, wave);
-                    tok_prefetch<NTPW3, S::KS_2>(wg_h, wb, o.blk_whh[k + 1], S::NT3, wave);
-                    bias_prefetch<NTPW3>(bg_i, wb, o.blk_bih[k + 1], S::NT3, wave);
-                    bias_prefetch<NTPW3>(bg_h, wb, o.blk_bhh[k + 1], S::NT3, wave);
+                    Wgi.fetch(wb, o.blk_wih[k + 1], o.blk_bih[k + 1], S::NT2, wave);
+                    Wgh.fetch(wb, o.blk_whh[k + 1], o.blk_bhh[k + 1], S::NT2, wave);
                     const float* hgn = hg + (size_t)a.B * (F2 * C2);
 #pragma unroll
                     for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = i < F2 * C2 ? hgn[i] : 0.0f; }
                 }
                 f32x4 acc[S::MT2][NTPW];
-                acc_init_regs<S::MT2, NTPW>(acc, b2);
-                tok_gemm_r<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, w2);
+                tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf2);
                 if (k + 1 < S::KB) {
 #pragma unroll
                     for (int q = 0; q < HPT; ++q) {
@@ -1002,8 +1050,6 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 
         FE_CLK(7);
         // =========================== rf_post (a13) ===========================
-        float* W0 = smem + L::W0;
-        float* W1 = smem + L::W1;
         {
             // Y2[f1][c2] = sum_f2 Wp[f1][f2] X[f2][c2]      (A packed, B = LDS tokens)
             constexpr int KS = F2 / 4;
@@ -1038,13 +1084,24 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         // =========================== decoder (a14) ===========================
         static_for<S::NL>([&](auto l_) {
             constexpr int l = decltype(l_)::value;
-            const float* skip = Ebuf + (S::NL - l) * S::ACT;
+            const float* skip = Ebuf + (S::NL - l) * S::ACT;   // (LDS-resident skips)
             {
                 FE_BEGIN_UNIT(5 + S::NL + 2 * l);
                 f32x4 acc[S::MTPW][S::NTC];
                 acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.dec1_b[l], 0, 1, S::NTC);
-                const float* const segs[2] = {W0 + (16 * wave + li + 1) * LDC + lg, skip + (16 * wave + li + 1) * LDC + lg};
-                conv_multi<S, S::NTC, 2, S::KS_C, LDC>(acc, segs, wb, o.dec1_w[l], job);
+                if constexpr (!SG) {
+                    const float* const segs[2] = {W0 + (16 * wave + li + 1) * LDC + lg, skip + (16 * wave + li + 1) * LDC + lg};
+                    conv_multi<S, S::NTC, 2, S::KS_C, LDC>(acc, segs, wb, o.dec1_w[l], job);
+                } else {   // second K-segment = the skip, read back from the global scratch as A fragments
+                    const float* xa = W0 + (16 * wave + li + 1) * LDC + lg;
+                    mma_panel<S::MTPW, S::NTC, 2 * S::KS_C>(
+                        acc,
+                        [&](int i, int ks) {
+                            return ks < S::KS_C ? xa[(64 * i) * LDC + 4 * ks]
+                                                : skb.at_g((S::NL - l) * SKIP_FLOATS + ((wave + 4 * i) * S::KS_C + (ks - S::KS_C)) * 64);
+                        },
+                        [&](int j, int ks) { return wb.at(o.dec1_w[l] + (j * (2 * S::KS_C) + ks) * 64); }, DmaSide{&job});
+                }
                 dma_rest(job);
                 conv_store<S, S::NTC, C1, LDC, true>(acc, W1, 1, wave, lane);
             }
@@ -1070,8 +1127,18 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             FE_BEGIN_UNIT(5 + 3 * S::NL);
             f32x4 acc[S::MTPW][S::NTC];
             acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.post1_b, 0, 1, S::NTC);
-            const float* const segs[2] = {W0 + (16 * wave + li + 1) * LDC + lg, Ebuf + (16 * wave + li + 1) * LDC + lg};
-            conv_multi<S, S::NTC, 2, S::KS_C, LDC>(acc, segs, wb, o.post1_w, job);
+            if constexpr (!SG) {
+                const float* const segs[2] = {W0 + (16 * wave + li + 1) * LDC + lg, Ebuf + (16 * wave + li + 1) * LDC + lg};
+                conv_multi<S, S::NTC, 2, S::KS_C, LDC>(acc, segs, wb, o.post1_w, job);
+            } else {
+                const float* xa = W0 + (16 * wave + li + 1) * LDC + lg;
+                mma_panel<S::MTPW, S::NTC, 2 * S::KS_C>(
+                    acc,
+                    [&](int i, int ks) {
+                        return ks < S::KS_C ? xa[(64 * i) * LDC + 4 * ks] : skb.at_g(((wave + 4 * i) * S::KS_C + (ks - S::KS_C)) * 64);
+                    },
+                    [&](int j, int ks) { return wb.at(o.post1_w + (j * (2 * S::KS_C) + ks) * 64); }, DmaSide{&job});
+            }
             dma_rest(job);
             conv_store<S, S::NTC, C1, LDC, true>(acc, W1, 1, wave, lane);
         }

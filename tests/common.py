@@ -29,6 +29,9 @@ MODEL_KWARGS = {
     "fe_m": (_kw(96, (8, 3, 3, 3), 72, 48, 4, 512, 160, "linear_fixed"), 16000, 106),
     "fe_l": (_kw(128, (8, 3, 3, 3, 3), 96, 64, 5, 512, 100, "linear_fixed"), 16000, 103),
     "fe48_b": (_kw(48, (8, 3, 3), 36, 36, 3, 1024, 512, "linear"), 48000, 104),
+    "fe48_t": (_kw(24, (8, 3, 3), 20, 24, 2, 1024, 512, "linear"), 48000, 107),
+    "fe48_s": (_kw(64, (8, 3, 3, 3), 48, 48, 3, 1024, 512, "linear"), 48000, 108),
+    "fe48_m": (_kw(96, (8, 3, 3, 3), 72, 72, 4, 1024, 320, "linear"), 48000, 109),
 }
 
 

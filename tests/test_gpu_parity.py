@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 
 ABS_TOL = 1e-4
 REL_TOL = 1e-4
-GPU_SHAPES = ["fe_t", "fe_b", "fe48_b"]
+GPU_SHAPES = ["fe_t", "fe_b", "fe_m", "fe_l", "fe48_b"]          # shapes with reference goldens
+ALL_SHAPES = ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m"]
 
 
 def _dev():
@@ -98,12 +99,12 @@ def test_driver_loop_matches_reference_golden(name):
     assert np.array_equal(y1, y16), "chunked launches must be bit-identical to per-hop launches"
 
 
-@pytest.mark.parametrize("name", GPU_SHAPES)
+@pytest.mark.parametrize("name", ALL_SHAPES)
 def test_every_stage_matches_oracle(name):
-    """Per-stage activations (fe_debug_step) vs the oracle's taps on a fresh input, B=5."""
+    """Per-stage activations (fe_debug_step) vs the oracle's taps on a fresh input, B=3."""
     m, orc, cfg, sr, seed = _model(name)
     eng = m.engine
-    B, hops, H = 5, 4, cfg.hop_size
+    B, hops, H = 3, 4, cfg.hop_size
     x = make_input(B, hops * H, 4242, sr)
     xd = torch.from_numpy(x).to(_dev())
     state = eng.new_state(B)
@@ -122,6 +123,26 @@ def test_every_stage_matches_oracle(name):
                 ref = tap.transpose(0, 2, 1)
             _assert_close(dumps[sname].cpu().numpy(), ref, f"hop {t} stage {sname}")
         _assert_close(o_gpu.cpu().numpy(), o_ref, f"hop {t} wav_out")
+
+
+@pytest.mark.parametrize("name", ALL_SHAPES)
+def test_chunked_launch_is_bit_identical_to_per_hop_launches(name):
+    """T hops in one launch == T launches of one hop (also exercises re-use of the LDS / global scratch across frames)."""
+    m, orc, cfg, sr, seed = _model(name)
+    eng = m.engine
+    B, T, H = 4, 6, cfg.hop_size
+    x = torch.from_numpy(make_input(B, T * H, 31, sr)).to(_dev())
+    s1, s2 = eng.new_state(B), eng.new_state(B)
+    y1 = eng.step(x, s1, T=T)
+    y2 = torch.cat([eng.step(x[:, t * H:(t + 1) * H], s2, T=1) for t in range(T)], dim=1)
+    assert torch.equal(y1, y2) and torch.equal(s1, s2)
+    # and against the oracle
+    caches = orc.initialize_cache(B)
+    refs = []
+    for t in range(T):
+        o, *caches = orc.step(x.cpu().numpy()[:, t * H:(t + 1) * H], *caches)
+        refs.append(o)
+    _assert_close(y1.cpu().numpy(), np.concatenate(refs, 1), "chunk vs oracle")
 
 
 def test_full_size_batch_256_matches_oracle_and_is_stream_independent():

@@ -16,7 +16,7 @@ from fastenhancer_amd.weights import default_state_dict  # noqa: E402
 
 NAMES = ["stft load", "fft", "spec dump", "compress", "enc_pre", "encoder", "rf_pre", "blocks", "rf_post", "decoder",
          "dec_post", "mask", "ifft", "ola"]
-BLK = ["h load", "gi/gh gemm", "gates", "fc1", "qkv", "attention", "fc2"]
+BLK = ["-", "gru+gates", "(none)", "fc1", "qkv", "attention", "fc2"]
 
 
 def main():
