@@ -403,7 +403,8 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
     a.clk = clk;
     a.dbg_stride = h->impl->dbg_floats;
     hipError_t e = hipSuccess;
-    h->impl->launch(a, false, (hipStream_t)stream, &e);
+    a.mode = fe::FE_MODE_STREAM;
+    h->impl->launch(a, (hipStream_t)stream, &e);
     if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return FE_OK;
 }
@@ -436,20 +437,47 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
     a.spec_out = spec_out_dev;
     a.h = h_dev;
     hipError_t e = hipSuccess;
-    h->impl->launch(a, true, (hipStream_t)stream, &e);
+    a.mode = fe::FE_MODE_SPEC;
+    h->impl->launch(a, (hipStream_t)stream, &e);
     if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return FE_OK;
 }
 
 size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw) {
-    (void)h; (void)B; (void)Tw;
-    return 0;
+    if (!h || B <= 0 || Tw <= 0) return 0;
+    const Dims& d = h->d;
+    // GRU state (zero initial state, model.py:626-627) + overlap-add tail, both zeroed by fe_offline
+    return (size_t)B * ((size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2);
 }
 
 int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_hat_dev, float* spec_hat_dev, float* work_dev,
                void* stream) {
-    (void)h; (void)noisy_dev; (void)B; (void)Tw; (void)wav_hat_dev; (void)spec_hat_dev; (void)work_dev; (void)stream;
-    return fail(FE_ERR_UNSUPPORTED_CONFIG, "fe_offline: not built yet");
+    int rc = check_ready(h);
+    if (rc != FE_OK) return rc;
+    if (!noisy_dev || !wav_hat_dev || !spec_hat_dev || !work_dev || B <= 0) return fail(FE_ERR_INVALID_ARG, "bad argument");
+    const Dims& d = h->d;
+    if (Tw <= d.NFFT / 2)   // torch.stft reflect padding needs pad < length
+        return fail(FE_ERR_INVALID_ARG, "Tw=%d: reflect padding of n_fft/2=%d needs a longer input", Tw, d.NFFT / 2);
+    rc = ensure_scratch(h, B);
+    if (rc != FE_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    FE_HIP_CHECK(hipMemsetAsync(work_dev, 0, fe_offline_work_floats(h, B, Tw) * sizeof(float), st));
+    const int T = 1 + Tw / d.HOP;
+    fe::FrameArgs a = base_args(h, B, T);
+    a.mode = fe::FE_MODE_OFFLINE;
+    a.Tw = Tw;
+    a.wav_in = noisy_dev;
+    a.in_stride = (size_t)Tw;
+    a.wav_out = wav_hat_dev;
+    a.out_stride = (size_t)d.HOP * (T - 1);
+    a.spec_out = spec_hat_dev;
+    a.cache_istft = work_dev;
+    a.cache_stft = work_dev;   // unused in this mode
+    a.h = work_dev + (size_t)B * (d.NFFT - d.HOP);
+    hipError_t e = hipSuccess;
+    h->impl->launch(a, st, &e);
+    if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return FE_OK;
 }
 
 double fe_flops_per_frame(const fe_handle* h) {

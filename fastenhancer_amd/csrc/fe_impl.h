@@ -16,27 +16,21 @@ struct Impl {
     size_t dbg_floats;
     int dbg_stages;
     const PackedOffsets* off;
-    void (*launch)(const FrameArgs&, bool spec_mode, hipStream_t, hipError_t*);
+    void (*launch)(const FrameArgs&, hipStream_t, hipError_t*);
     void (*dbg_stage)(int, int*, int*, size_t*);
 };
 
 template <class S>
-void launch_impl(const FrameArgs& a, bool spec_mode, hipStream_t st, hipError_t* err) {
+void launch_impl(const FrameArgs& a, hipStream_t st, hipError_t* err) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fe_frame_kernel<S, false>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fe_frame_kernel<S>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds<S>::BYTES);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fe_frame_kernel<S, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds<S>::BYTES);
         if (e != hipSuccess) { *err = e; return; }
         attr_set = true;
     }
     dim3 grid(a.B), block(kThreads);
-    if (spec_mode)
-        hipLaunchKernelGGL((fe_frame_kernel<S, true>), grid, block, Lds<S>::BYTES, st, a);
-    else
-        hipLaunchKernelGGL((fe_frame_kernel<S, false>), grid, block, Lds<S>::BYTES, st, a);
+    hipLaunchKernelGGL((fe_frame_kernel<S>), grid, block, Lds<S>::BYTES, st, a);
     *err = hipGetLastError();
 }
 

@@ -30,6 +30,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define FE_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+constexpr int FE_MODE_STREAM = 0, FE_MODE_SPEC = 1, FE_MODE_OFFLINE = 2;
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
 
@@ -160,6 +161,8 @@ struct FrameArgs {
     unsigned long long* clk;  // phase cycle counters (block 0, thread 0) or nullptr
     size_t dbg_stride;        // floats per stream
     int B, T;
+    int mode;                 // FE_MODE_*
+    int Tw;                   // offline: samples per stream
     float compression;
 };
 
@@ -535,7 +538,11 @@ __device__ __forceinline__ void tok_gemm_w(f32x4 (&acc)[S::MT2][NTPW], const flo
 }
 
 // ------------------------------------------------------------------------------------------
-template <class S, bool SPEC_MODE>
+// a.mode (wave-uniform): FE_MODE_STREAM  wav->wav streaming step (scripts/export_onnx.py:48-58)
+//                        FE_MODE_SPEC    spec->spec step (model.py:677-710)
+//                        FE_MODE_OFFLINE Model.forward (model.py:728-735): centered STFT of the whole signal,
+//                                        zero initial GRU state, torch.istft-style normalised overlap-add
+template <class S>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) fe_frame_kernel(FrameArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = Lds<S>;
@@ -619,17 +626,32 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         } while (0)
         FE_CLK(0);
         // =========================== STFT (a3) ===========================
-        if (!SPEC_MODE) {
+        const int mode = a.mode;
+        if (mode != FE_MODE_SPEC) {
             const float* win = wp + o.window;
-            const float* xin = a.wav_in + (size_t)b * a.in_stride + (size_t)t * H;
-            for (int n = tid; n < N; n += kThreads) {
-                float v = (n < OVL) ? cst[n] : xin[n - OVL];
-                fb[n] = make_float2(v, 0.0f);          // raw frame kept in fb.x for the cache shift
-                fa[n] = make_float2(v * win[n], 0.0f);
+            if (mode == FE_MODE_STREAM) {
+                const float* xin = a.wav_in + (size_t)b * a.in_stride + (size_t)t * H;
+                for (int n = tid; n < N; n += kThreads) {
+                    float v = (n < OVL) ? cst[n] : xin[n - OVL];
+                    fb[n] = make_float2(v, 0.0f);          // raw frame kept in fb.x for the cache shift
+                    fa[n] = make_float2(v * win[n], 0.0f);
+                }
+            } else {
+                // torch.stft(center=True, pad_mode="reflect") (functional/audio_modules.py:78-80): frame t covers
+                // xp[tH : tH+N], xp = reflect_pad(x, N/2)
+                const float* xin = a.wav_in + (size_t)b * a.in_stride;
+                for (int n = tid; n < N; n += kThreads) {
+                    int idx = t * H + n - N / 2;
+                    idx = idx < 0 ? -idx : idx;
+                    idx = idx >= a.Tw ? 2 * (a.Tw - 1) - idx : idx;
+                    fa[n] = make_float2(xin[idx] * win[n], 0.0f);
+                }
             }
             __syncthreads();
-            for (int m = tid; m < OVL; m += kThreads) cst[m] = fb[m + H].x;   // cache' = frame[H:]
-            __syncthreads();
+            if (mode == FE_MODE_STREAM) {
+                for (int m = tid; m < OVL; m += kThreads) cst[m] = fb[m + H].x;   // cache' = frame[H:]
+                __syncthreads();
+            }
             FE_CLK(1);
             float2* X = fft_lds<S, false>(fa, fb, tw);
             FE_CLK(2);
@@ -1158,7 +1180,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         // =========================== mask, un-compress (a16, a17), Hermitian spectrum ===========================
         {
             const float b0 = wb.scalar(o.post_t_b), b1 = wb.scalar(o.post_t_b + 1);
-            float* spo = SPEC_MODE ? a.spec_out + (size_t)b * (F0 + 1) * a.T * 2 : nullptr;
+            float* spo = mode == FE_MODE_SPEC ? a.spec_out + (size_t)b * (F0 + 1) * a.T * 2 : nullptr;
+            float* sph = mode == FE_MODE_OFFLINE ? a.spec_out + (size_t)b * F0 * a.T * 2 : nullptr;   // spec_hat [B,F0,T,2]
             for (int f = tid; f < F0; f += kThreads) {
                 const int q = f + 2, j1 = q & 3, i1 = q >> 2;
                 float m0 = b0, m1 = b1;
@@ -1171,6 +1194,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     float* dst = a.dbg + (size_t)b * a.dbg_stride + DebugLayout<S>::offset(5 + 2 * S::NL + 2 * S::KB);
                     dst[2 * f] = m0; dst[2 * f + 1] = m1;
                 }
+                if (sph != nullptr) {   // Model.forward returns the masked spectrum in the compressed domain
+                    sph[((size_t)f * a.T + t) * 2] = yr;
+                    sph[((size_t)f * a.T + t) * 2 + 1] = yi;
+                }
                 const float mag = sqrtf(yr * yr + yi * yi);
                 const float g = powf(mag, 1.0f / a.compression - 1.0f);
                 yr *= g; yi *= g;
@@ -1179,7 +1206,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     dst[2 * f] = yr; dst[2 * f + 1] = yi;
                     if (f == 0) { dst[2 * F0] = 0.0f; dst[2 * F0 + 1] = 0.0f; }
                 }
-                if (SPEC_MODE) {
+                if (mode == FE_MODE_SPEC) {
                     spo[((size_t)f * a.T + t) * 2] = yr;
                     spo[((size_t)f * a.T + t) * 2 + 1] = yi;
                     if (f == 0) { spo[((size_t)F0 * a.T + t) * 2] = 0.0f; spo[((size_t)F0 * a.T + t) * 2 + 1] = 0.0f; }
@@ -1198,11 +1225,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 
         FE_CLK(11);
         // =========================== iSTFT (a18) ===========================
-        if (!SPEC_MODE) {
+        if (mode != FE_MODE_SPEC) {
             float2* y = fft_lds<S, true>(fa, fb, tw);
             FE_CLK(12);
             float2* spare = (y == fa) ? fb : fa;
-            const float* wi = wp + o.window_istft;
+            // streaming: synthesis window w / sum_k w^2 (steady state); offline: plain w, normalised below
+            const float* wi = wp + (mode == FE_MODE_STREAM ? o.window_istft : o.window);
             float* xo = reinterpret_cast<float*>(spare);
             const float invN = 1.0f / (float)N;
             for (int n = tid; n < N; n += kThreads) {
@@ -1211,8 +1239,30 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 xo[n] = v;
             }
             __syncthreads();
-            float* out = a.wav_out + (size_t)b * a.out_stride + (size_t)t * H;
-            for (int n = tid; n < H; n += kThreads) out[n] = xo[n];
+            if (mode == FE_MODE_STREAM) {
+                float* out = a.wav_out + (size_t)b * a.out_stride + (size_t)t * H;
+                for (int n = tid; n < H; n += kThreads) out[n] = xo[n];
+            } else {
+                // torch.istft(center=True) (functional/audio_modules.py:117-119): y = OLA / sum_t w^2, trimmed by N/2.
+                // After frame t the samples [tH, tH+H) of the overlap-add are final (all of [tH, tH+N) after the last frame).
+                const float* w = wp + o.window;
+                const int n_out = H * (a.T - 1);
+                const int emit = (t == a.T - 1) ? N : H;
+                float* out = a.wav_out + (size_t)b * a.out_stride;
+                for (int j = tid; j < emit; j += kThreads) {
+                    const int n = t * H + j;             // position in the un-trimmed overlap-add
+                    const int pos = n - N / 2;
+                    if (pos >= 0 && pos < n_out) {
+                        int t_lo = (n - N + H) / H;      // ceil((n - N + 1) / H)
+                        t_lo = t_lo < 0 ? 0 : t_lo;
+                        int t_hi = n / H;
+                        t_hi = t_hi > a.T - 1 ? a.T - 1 : t_hi;
+                        float env = 0.0f;
+                        for (int tt = t_lo; tt <= t_hi; ++tt) { const float wv = w[n - tt * H]; env += wv * wv; }
+                        out[pos] = xo[j] / env;
+                    }
+                }
+            }
             for (int m = tid; m < OVL; m += kThreads) cis[m] = xo[m + H];
             __syncthreads();
         }

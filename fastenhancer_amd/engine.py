@@ -145,6 +145,23 @@ class Engine:
             _lib.check(self.lib.fe_spec_step(self._h, _ptr(spec), _ptr(h), _ptr(out), B, T, _stream(self.device)), "fe_spec_step")
         return out
 
+    def offline(self, noisy: Tensor) -> Tuple[Tensor, Tensor]:
+        """Model.forward (model.py:728-735): noisy [B, Tw] -> (wav_hat [B, H*(Tw//H)], spec_hat [B, N/2, T, 2])."""
+        self._require_gpu()
+        if noisy.dim() == 3:            # [B, 1, Tw] -> [B, Tw]  (functional/audio_modules.py:73-74)
+            noisy = noisy.squeeze(1)
+        noisy = noisy.contiguous().float()
+        B, Tw = noisy.shape
+        cfg = self.cfg
+        T = 1 + Tw // cfg.hop_size
+        wav = torch.empty(B, cfg.hop_size * (T - 1), dtype=torch.float32, device=noisy.device)
+        spec = torch.empty(B, cfg.F0, T, 2, dtype=torch.float32, device=noisy.device)
+        work = torch.empty(int(self.lib.fe_offline_work_floats(self._h, B, Tw)), dtype=torch.float32, device=noisy.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fe_offline(self._h, _ptr(noisy), B, Tw, _ptr(wav), _ptr(spec), _ptr(work), _stream(self.device)),
+                       "fe_offline")
+        return wav, spec
+
     def profile_step(self, wav_in: Tensor, state: Tensor, T: int = 1) -> Tensor:
         """Phase cycle counters (int64[64]) of workgroup 0 for the last frame of the launch."""
         self._require_gpu()

@@ -217,3 +217,29 @@ def test_native_library_is_what_ran():
     assert isinstance(_lib.load(), ctypes.CDLL)
     with open("/proc/self/maps") as f:
         assert "libfastenhancer_hip.so" in f.read()
+
+
+@pytest.mark.parametrize("name", GPU_SHAPES)
+def test_offline_model_forward_matches_reference_golden(name):
+    """a21 / a27: Model.forward(noisy) -> (wav_hat, spec_hat) vs the reference's own output."""
+    g = load_golden(name)
+    m, orc, cfg, sr, seed = _model(name, "Model")
+    B, H = int(g["B"]), cfg.hop_size
+    x = torch.from_numpy(make_input(B, int(g["hops"]) * H + 37, seed + 2000, sr)).to(_dev())
+    wav_hat, spec_hat = m(x)
+    assert tuple(wav_hat.shape) == g["offline_wav"].shape and tuple(spec_hat.shape) == g["offline_spec"].shape
+    _assert_close(wav_hat.cpu().numpy(), g["offline_wav"], "offline wav")
+    _assert_close(spec_hat.cpu().numpy(), g["offline_spec"], "offline spec")
+    wav3, _ = m(x.unsqueeze(1))                       # [B, 1, Tw] input form
+    assert torch.equal(wav3, wav_hat)
+
+
+@pytest.mark.parametrize("name", ["fe_s", "fe48_t", "fe48_s", "fe48_m"])
+def test_offline_matches_oracle(name):
+    m, orc, cfg, sr, seed = _model(name, "Model")
+    H = cfg.hop_size
+    x = make_input(2, 9 * H + 11, 555, sr)
+    wav_ref, spec_ref = orc.offline_forward(x)
+    wav_hat, spec_hat = m(torch.from_numpy(x).to(_dev()))
+    _assert_close(wav_hat.cpu().numpy(), wav_ref, "offline wav")
+    _assert_close(spec_hat.cpu().numpy(), spec_ref, "offline spec")
