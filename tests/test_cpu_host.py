@@ -137,3 +137,30 @@ def test_compute_without_gpu_fails_loudly():
     assert [tuple(c.shape) for c in m.stft.initialize_cache(torch.zeros(2, 1))] == [(2, 256)] * 2
     with pytest.raises(_lib.FEError, match="no CPU fallback"):
         m(torch.zeros(2, 257, 1, 2))
+
+
+def test_cli_host_logic(tmp_path):
+    """config / checkpoint lookup and WAV I/O of the command-line callers (no GPU)."""
+    import yaml
+    from fastenhancer_amd.scripts.common import latest_checkpoint, load_hparams, read_wav, write_wav
+    d = tmp_path / "logs" / "run1"
+    d.mkdir(parents=True)
+    (d / "config.yaml").write_text(yaml.safe_dump({"model": "fastenhancer.default", "model_kwargs": MODEL_KWARGS["fe_t"][0],
+                                                   "data": {"sampling_rate": 16000}}))
+    for e in (20, 500, 100):
+        (d / f"{e:05d}.pth").write_bytes(b"")
+    (d / "notes.pth").write_bytes(b"")
+    assert os.path.basename(latest_checkpoint(str(d))) == "00500.pth"
+    assert latest_checkpoint(str(tmp_path / "missing")) is None
+    hps = load_hparams(None, "run1", log_root=str(tmp_path / "logs"))
+    assert hps["model_kwargs"]["channels"] == 24
+    with pytest.raises(ValueError):
+        load_hparams(None, None)
+    x = (0.5 * np.sin(np.arange(1000) / 10.0)).astype(np.float32)
+    write_wav(str(tmp_path / "a.wav"), 16000, x)
+    np.testing.assert_allclose(read_wav(str(tmp_path / "a.wav"), 16000), x)
+    from scipy.io import wavfile
+    wavfile.write(str(tmp_path / "b.wav"), 16000, (x * 32767).astype(np.int16))
+    np.testing.assert_allclose(read_wav(str(tmp_path / "b.wav"), 16000), x, atol=1e-4)
+    with pytest.raises(ValueError, match="sampling rate"):
+        read_wav(str(tmp_path / "a.wav"), 48000)

@@ -243,3 +243,31 @@ def test_offline_matches_oracle(name):
     wav_hat, spec_hat = m(torch.from_numpy(x).to(_dev()))
     _assert_close(wav_hat.cpu().numpy(), wav_ref, "offline wav")
     _assert_close(spec_hat.cpu().numpy(), spec_ref, "offline spec")
+
+
+def test_command_line_callers(tmp_path, monkeypatch):
+    """a26 / a27: the test_onnx.py- and test_pytorch.py-style callers on a reference-format checkpoint."""
+    import yaml
+    from scipy.io import wavfile
+    from fastenhancer_amd.scripts import test_offline, test_streaming
+    name = "fe_t"
+    kw, sr, seed = MODEL_KWARGS[name]
+    cfg, sd, fused, orc = build_oracle(name)
+    logs = tmp_path / "logs" / "run"
+    logs.mkdir(parents=True)
+    (logs / "config.yaml").write_text(yaml.safe_dump({"model": "fastenhancer.default", "model_kwargs": kw, "data": {"sampling_rate": sr}}))
+    torch.save({"model": {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, "epoch": 7}, str(logs / "00007.pth"))
+    noisy_dir = tmp_path / "noisy"
+    noisy_dir.mkdir()
+    x = make_input(1, 5000, 91, sr)[0]
+    wavfile.write(str(noisy_dir / "a.wav"), sr, x)
+    monkeypatch.chdir(tmp_path)
+    test_offline.main(["-n", "run", "-i", str(noisy_dir), "-o", str(tmp_path / "out")])
+    rate, y = wavfile.read(str(tmp_path / "out" / "a.wav"))
+    wav_ref, _ = orc.offline_forward(x[None])
+    assert rate == sr
+    _assert_close(y, wav_ref[0], "test_offline CLI")
+    test_streaming.main(["-n", "run", "--audio-path", str(noisy_dir / "a.wav"), "--save-output", "--output-path",
+                         str(tmp_path / "s.wav"), "--n-fft", "512", "--hop-size", "256", "--sr", "16000"])
+    rate, ys = wavfile.read(str(tmp_path / "s.wav"))
+    _assert_close(ys, orc.enhance_stream(x[None])[0], "test_streaming CLI")
