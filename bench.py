@@ -44,6 +44,10 @@ WORKLOADS = {
                  desc="FastEnhancer_S 16kHz"),
     "fe48_b": dict(C1=48, ks=(8, 3, 3), C2=36, F2=36, K=3, N=1024, H=512, sr=48000, init="linear",
                    desc="FastEnhancer_B 48kHz"),
+    "fe_m": dict(C1=96, ks=(8, 3, 3, 3), C2=72, F2=48, K=4, N=512, H=160, sr=16000, init="linear_fixed",
+                 desc="FastEnhancer_M 16kHz"),
+    "fe_l": dict(C1=128, ks=(8, 3, 3, 3, 3), C2=96, F2=64, K=5, N=512, H=100, sr=16000, init="linear_fixed",
+                 desc="FastEnhancer_L 16kHz"),
 }
 
 
@@ -57,31 +61,30 @@ def model_kwargs(w):
 
 
 def cpu_baseline(workload: str, kw: dict, sr: int, B: int, budget_s: float):
-    """The numpy oracle (a port of the reference algorithm, oracle/fe_oracle.py) timed on the host
-    cores of this box on a bounded sample of the same workload."""
-    from oracle.fe_oracle import FEConfig as OCfg, FEOracle, fold_state_dict
+    """The C/OpenMP oracle (oracle/fe_oracle.c, a port of the reference algorithm pinned on the reference's golden
+    vectors) timed on the host cores of this box on a bounded sample of the same workload: the same B streams, one
+    OpenMP thread per logical core, as many hops as fit in the budget."""
+    from oracle.c_oracle import COracle
+    from oracle.fe_oracle import FEConfig as OCfg, fold_state_dict
     from oracle.weightgen import make_input, make_training_state_dict
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count() or 1
+    threads = os.cpu_count() or 1
     cfg = OCfg.from_model_kwargs(kw)
-    orc = FEOracle(cfg, fold_state_dict(make_training_state_dict(cfg, 2), cfg))
+    co = COracle(cfg, fold_state_dict(make_training_state_dict(cfg, 2), cfg), threads=threads)
     H = cfg.hop_size
-    max_hops = 64
-    x = make_input(B, max_hops * H, 1236, sr)
-    caches = orc.initialize_cache(B)
-    o, *caches = orc.step(x[:, :H], *caches)          # warm-up hop
+    max_hops = 4096
+    x = make_input(B, 64 * H, 1236, sr)
+    cs, ci, h = co.initialize_cache(B)
+    co.step(x[:, :H], cs, ci, h)                      # warm-up hop
     t0 = time.perf_counter()
     hops = 0
-    while hops < max_hops - 1 and (time.perf_counter() - t0) < budget_s:
-        o, *caches = orc.step(x[:, (hops + 1) * H:(hops + 2) * H], *caches)
+    while hops < max_hops and (time.perf_counter() - t0) < budget_s:
+        t = hops % 64
+        co.step(x[:, t * H:(t + 1) * H], cs, ci, h)
         hops += 1
     dt = time.perf_counter() - t0
     return {"value": B * hops / dt, "unit": "frames/s", "cores": int(threads), "kind": "port",
-            "sample": f"{hops} hops x {B} streams of {workload} through the numpy oracle (oracle/fe_oracle.py), "
-                      f"{dt:.1f} s, host has {os.cpu_count()} logical cores"}
+            "sample": f"{hops} hops x {B} streams of {workload} through the C/OpenMP oracle (oracle/fe_oracle.c), "
+                      f"{dt:.1f} s wall, {threads} OpenMP threads = logical cores of the host"}
 
 
 def measured_traffic(workload: str, B: int, T: int):
@@ -108,7 +111,7 @@ def main():
     ap.add_argument("--streams", type=int, default=256, help="concurrent streams per GPU")
     ap.add_argument("--frames-per-step", type=int, default=1, help="hops per stream per launch (1 = per-hop streaming)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -101,3 +101,21 @@ def test_latency_identity_stft_istft():
         y = np.concatenate(out, 1)
         d = N - H
         np.testing.assert_allclose(y[:, N:], x[:, N - d:-d] if d else x[:, N:], atol=1e-6)
+
+
+@pytest.mark.parametrize("name", GOLDENS)
+def test_c_oracle_matches_reference(name):
+    """oracle/fe_oracle.c (the C/OpenMP restatement used as bench.py's cpu_baseline) vs the reference goldens."""
+    from oracle.c_oracle import COracle
+    g = load_golden(name)
+    cfg, sd, fused, orc = build_oracle(name)
+    co = COracle(cfg, fused, threads=2)
+    B, hops, H = int(g["B"]), int(g["hops"]), cfg.hop_size
+    x = make_input(B, hops * H, int(g["seed"]) + 1000, int(g["sr"]))
+    cs, ci, h = co.initialize_cache(B)
+    outs = [co.step(x[:, t * H:(t + 1) * H], cs, ci, h) for t in range(hops)]
+    _close(np.stack(outs, 0), g["stream_wav_out"], what="wav_out")
+    _close(cs, g["stream_cache_stft"], what="cache_stft")
+    _close(ci, g["stream_cache_istft"], what="cache_istft")
+    for k in range(cfg.rf_blocks):
+        _close(h[k], g[f"stream_h{k}"][0], what=f"h{k}")
