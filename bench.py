@@ -67,24 +67,35 @@ def cpu_baseline(workload: str, kw: dict, sr: int, B: int, budget_s: float):
     from oracle.c_oracle import COracle
     from oracle.fe_oracle import FEConfig as OCfg, fold_state_dict
     from oracle.weightgen import make_input, make_training_state_dict
-    threads = os.cpu_count() or 1
     cfg = OCfg.from_model_kwargs(kw)
-    co = COracle(cfg, fold_state_dict(make_training_state_dict(cfg, 2), cfg), threads=threads)
+    fused = fold_state_dict(make_training_state_dict(cfg, 2), cfg)
     H = cfg.hop_size
-    max_hops = 4096
     x = make_input(B, 64 * H, 1236, sr)
-    cs, ci, h = co.initialize_cache(B)
-    co.step(x[:, :H], cs, ci, h)                      # warm-up hop
-    t0 = time.perf_counter()
-    hops = 0
-    while hops < max_hops and (time.perf_counter() - t0) < budget_s:
-        t = hops % 64
-        co.step(x[:, t * H:(t + 1) * H], cs, ci, h)
-        hops += 1
-    dt = time.perf_counter() - t0
-    return {"value": B * hops / dt, "unit": "frames/s", "cores": int(threads), "kind": "port",
-            "sample": f"{hops} hops x {B} streams of {workload} through the C/OpenMP oracle (oracle/fe_oracle.c), "
-                      f"{dt:.1f} s wall, {threads} OpenMP threads = logical cores of the host"}
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    # the best OpenMP width depends on the host (SMT, container CPU quota): try a few, report the fastest
+    cands = sorted({min(avail, c) for c in (8, 16, 32, 64, 128, avail)})
+    best = None
+    for threads in cands:
+        co = COracle(cfg, fused, threads=threads)
+        cs, ci, h = co.initialize_cache(B)
+        co.step(x[:, :H], cs, ci, h)                      # warm-up hop
+        t0 = time.perf_counter()
+        hops = 0
+        while (time.perf_counter() - t0) < budget_s / len(cands):
+            t = hops % 64
+            co.step(x[:, t * H:(t + 1) * H], cs, ci, h)
+            hops += 1
+        dt = time.perf_counter() - t0
+        rate = B * hops / dt
+        if best is None or rate > best[0]:
+            best = (rate, threads, hops, dt)
+    rate, threads, hops, dt = best
+    return {"value": rate, "unit": "frames/s", "cores": int(threads), "kind": "port",
+            "sample": f"{hops} hops x {B} streams of {workload} through the C/OpenMP oracle (oracle/fe_oracle.c) in {dt:.1f} s with "
+                      f"{threads} OpenMP threads (fastest of {cands}; host exposes {avail} logical cores)"}
 
 
 def measured_traffic(workload: str, B: int, T: int):
