@@ -565,9 +565,17 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     wb.lds = nullptr;
     wb.base = 0;
 
-    // ---- one-time: zero LDS (halo rows, pad rows), load twiddles
-    for (int i = tid; i < L::TOTAL; i += kThreads) smem[i] = 0.0f;
-    __syncthreads();
+    // ---- one-time: zero what must be zero - the 2-bin halo of the compressed spectrum and the halo rows of the
+    // LDS-resident skip buffers (the work buffers' halos are re-zeroed per frame).  Everything else in LDS is either
+    // written before it is read, or only ever feeds MFMA rows / columns whose results are discarded (pad rows of the
+    // token buffers, pad columns), so it may start out as garbage.
+    for (int i = tid; i < 2 * S::LDS_S; i += kThreads) smem[L::SC + i] = 0.0f;
+    if constexpr (L::SKIPS_LDS) {
+        for (int i = tid; i < (S::NL + 1) * 2 * LDC; i += kThreads) {
+            const int e = i / (2 * LDC), q = i - e * (2 * LDC);
+            smem[L::E + e * S::ACT + (q >= LDC ? (F1 + 1) * LDC + (q - LDC) : q)] = 0.0f;
+        }
+    }
     float2* tw = reinterpret_cast<float2*>(smem + L::TW);
     for (int i = tid; i < N / 2; i += kThreads) tw[i] = reinterpret_cast<const float2*>(wp + o.twiddle)[i];
     float* sc = smem + L::SC;
