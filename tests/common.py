@@ -49,3 +49,20 @@ def build_oracle(name, dtype=np.float32):
 
 def rms(x):
     return float(np.sqrt(np.mean(np.square(np.asarray(x, np.float64)))))
+
+
+# ---------------------------------------------------------------- BSRNN (models/bsrnn, configs/others/bsrnn_*.yaml)
+BSRNN_KWARGS = {
+    "bsrnn_xxt": (dict(num_channels=16, num_layers=2, bias=True, affine=True, n_fft=512, hop_size=256, win_size=512, window="hann"), 16000, 202),
+    "bsrnn_xt": (dict(num_channels=16, num_layers=6, bias=True, affine=True, n_fft=512, hop_size=256, win_size=512, window="hann"), 16000, 201),
+    "bsrnn_t": (dict(num_channels=32, num_layers=6, bias=True, affine=True, n_fft=512, hop_size=256, win_size=512, window="hann"), 16000, 203),
+}
+
+
+def build_bsrnn_oracle(name, dtype=np.float32):
+    from oracle import bsrnn_oracle as bo
+    kw, sr, seed = BSRNN_KWARGS[name]
+    cfg = bo.BSRNNConfig.from_model_kwargs(kw)
+    sd = bo.make_training_state_dict(cfg, seed)
+    fused = bo.fold_state_dict(sd, cfg)
+    return cfg, sd, fused, bo.BSRNNOracle(cfg, fused, dtype)

@@ -119,3 +119,34 @@ def test_c_oracle_matches_reference(name):
     _close(ci, g["stream_cache_istft"], what="cache_istft")
     for k in range(cfg.rf_blocks):
         _close(h[k], g[f"stream_h{k}"][0], what=f"h{k}")
+
+
+# ------------------------------------------------------------------------------------------------ BSRNN
+@pytest.mark.parametrize("name", ["bsrnn_xxt", "bsrnn_xt"])
+def test_bsrnn_streaming_matches_reference(name):
+    from common import build_bsrnn_oracle
+    g = load_golden(name)
+    cfg, sd, fused, orc = build_bsrnn_oracle(name)
+    B, hops, H = int(g["B"]), int(g["hops"]), cfg.hop_size
+    x = make_input(B, hops * H, int(g["seed"]) + 1000, int(g["sr"]))
+    caches = orc.initialize_cache(B)
+    outs = []
+    for t in range(hops):
+        o, *caches = orc.step(x[:, t * H:(t + 1) * H], *caches)
+        outs.append(o)
+    _close(np.stack(outs, 0), g["stream_wav_out"], what="wav_out")
+    _close(caches[0], g["stream_cache_stft"], what="cache_stft")
+    _close(caches[1], g["stream_cache_istft"], what="cache_istft")
+    for i in range(2 * cfg.num_layers):
+        _close(caches[2 + i], g[f"stream_c{i}"], what=f"lstm cache {i}")
+
+
+@pytest.mark.parametrize("name", ["bsrnn_xxt", "bsrnn_xt"])
+def test_bsrnn_offline_matches_reference(name):
+    from common import build_bsrnn_oracle
+    g = load_golden(name)
+    cfg, sd, fused, orc = build_bsrnn_oracle(name)
+    x = make_input(int(g["B"]), int(g["hops"]) * cfg.hop_size + 37, int(g["seed"]) + 2000, int(g["sr"]))
+    wav, spec = orc.offline_forward(x)
+    _close(wav, g["offline_wav"], what="offline wav")
+    _close(spec, g["offline_spec"], what="offline spec")

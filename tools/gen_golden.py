@@ -194,6 +194,68 @@ def gen_fastenhancer(ref: str, name: str, out_dir: str):
           f"in_rms={rms_in:.3f} out_rms={rms_out:.3f}")
 
 
+BSRNN_CONFIGS = {
+    # name: (yaml, seed, B, hops)
+    "bsrnn_xt": ("configs/others/bsrnn_xt.yaml", 201, 2, 10),
+    "bsrnn_xxt": ("configs/others/bsrnn_xxt.yaml", 202, 2, 8),
+}
+
+
+def gen_bsrnn(ref: str, name: str, out_dir: str):
+    from oracle import bsrnn_oracle as bo
+    rel_yaml, seed, B, hops = BSRNN_CONFIGS[name]
+    hps = yaml.safe_load(open(os.path.join(ref, rel_yaml)))
+    kw = hps["model_kwargs"]
+    sr = hps["data"]["sampling_rate"]
+    cfg = bo.BSRNNConfig.from_model_kwargs(kw)
+    mod = import_reference_model(ref, "models/bsrnn/model.py", "ref_bsrnn_model")
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+    model = mod.Model(**kw).eval()                       # offline, training form (nn.LSTM)
+    ref_sd = model.state_dict()
+    spec = bo.training_state_dict_spec(cfg)
+    assert list(ref_sd.keys()) == list(spec.keys()), ([k for k in ref_sd if k not in spec], [k for k in spec if k not in ref_sd])
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(spec[k]), (k, v.shape, spec[k])
+    sd = bo.make_training_state_dict(cfg, seed)
+    model.load_state_dict(to_t(sd), strict=True)
+    onnx_model = mod.ONNXModel(**kw).eval()              # streaming (LSTMCell); load_state_dict renames rnn_time.*_l0
+    onnx_model.load_state_dict(to_t(sd), strict=True)
+    onnx_model.remove_weight_reparameterizations()
+    fused_ref = {k: v.detach().numpy().copy() for k, v in onnx_model.state_dict().items()}
+    fused_mine = bo.fold_state_dict(sd, cfg)
+    assert set(fused_mine) == set(fused_ref), (sorted(set(fused_mine) ^ set(fused_ref))[:10])
+    worst = max(np.abs(fused_mine[k] - fused_ref[k]).max() / (np.abs(fused_ref[k]).max() + 1e-12) for k in fused_ref)
+    assert worst < 3e-6, worst
+    out = {"seed": np.int64(seed), "B": np.int64(B), "hops": np.int64(hops), "sr": np.int64(sr), "fold_worst_rel": np.float64(worst)}
+    H = cfg.hop_size
+    x = torch.from_numpy(make_input(B, hops * H, seed + 1000, sr))
+    with torch.no_grad():
+        cache_stft, cache_istft = onnx_model.stft.initialize_cache(x)
+        cm = [torch.zeros(B * cfg.n_bands, cfg.hidden) for _ in range(2 * cfg.num_layers)]
+        outs = []
+        for t in range(hops):
+            spec_in, cache_stft = onnx_model.stft(x[:, t * H:(t + 1) * H], cache_stft)
+            spec_out, *cm = onnx_model(spec_in, *cm)
+            wav_out, cache_istft = onnx_model.stft.inverse(spec_out, cache_istft)
+            outs.append(wav_out.numpy().copy())
+    out["stream_wav_out"] = np.stack(outs, 0)
+    out["stream_cache_stft"] = cache_stft.numpy().copy()
+    out["stream_cache_istft"] = cache_istft.numpy().copy()
+    for i, t_ in enumerate(cm):
+        out[f"stream_c{i}"] = t_.numpy().copy()
+    out["stream_spec_out_last"] = spec_out.numpy().copy()
+    xo = torch.from_numpy(make_input(B, hops * H + 37, seed + 2000, sr))
+    with torch.no_grad():
+        wav_hat, spec_hat = model(xo)
+    out["offline_wav"] = wav_hat.numpy().copy()
+    out["offline_spec"] = spec_hat.numpy().copy()
+    path = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB) fold_worst={worst:.2e} "
+          f"out_rms={float(np.sqrt((out['stream_wav_out'][4:] ** 2).mean())):.3f}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -205,6 +267,10 @@ def main():
         if args.only and name not in args.only:
             continue
         gen_fastenhancer(args.ref, name, args.out)
+    for name in BSRNN_CONFIGS:
+        if args.only and name not in args.only:
+            continue
+        gen_bsrnn(args.ref, name, args.out)
 
 
 if __name__ == "__main__":
