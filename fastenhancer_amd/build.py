@@ -16,7 +16,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libfastenhancer_hip.so")
-COMMON_DEPS = ["fe_kernels.hip.h", "fe_impl.h", "fe_shapes.def", os.path.join("..", "..", "include", "fastenhancer_hip.h")]
+FE_DEPS = ["fe_kernels.hip.h", "fe_impl.h"]
+BSRNN_DEPS = ["fe_kernels.hip.h", "bsrnn_kernels.hip.h"]
+API_DEPS = ["fe_kernels.hip.h", "fe_impl.h", "fe_shapes.def", "bsrnn_kernels.hip.h", "fe_bsrnn_shapes.def",
+            os.path.join("..", "..", "include", "fastenhancer_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
@@ -27,10 +30,10 @@ def _hipcc() -> str:
     return "hipcc"
 
 
-def shapes():
+def shapes(fname="fe_shapes.def", macro="X"):
     out = []
-    for line in open(os.path.join(CSRC, "fe_shapes.def")):
-        m = re.match(r"\s*X\(\s*(\w+)\s*,(.*)\)\s*$", line)
+    for line in open(os.path.join(CSRC, fname)):
+        m = re.match(r"\s*" + macro + r"\(\s*(\w+)\s*,(.*)\)\s*$", line)
         if m:
             out.append((m.group(1), ",".join(x.strip() for x in m.group(2).split(","))))
     return out
@@ -55,15 +58,22 @@ def _compile(job):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    common = [os.path.join(CSRC, d) for d in COMMON_DEPS]
+    common = [os.path.join(CSRC, d) for d in FE_DEPS]
+    common_b = [os.path.join(CSRC, d) for d in BSRNN_DEPS]
+    common_api = [os.path.join(CSRC, d) for d in API_DEPS]
     jobs = []
     api = os.path.join(CSRC, "fe_api.hip")
-    jobs.append((api, os.path.join(OBJ, "fe_api.o"), [], os.path.join(OBJ, "fe_api.stamp"), _digest(common + [api], " ".join(FLAGS))))
+    jobs.append((api, os.path.join(OBJ, "fe_api.o"), [], os.path.join(OBJ, "fe_api.stamp"), _digest(common_api + [api], " ".join(FLAGS))))
     tmpl = os.path.join(CSRC, "fe_shape.hip.in")
     for name, args in shapes():
         defs = [f"-DFE_SHAPE_NAME={name}", f"-DFE_SHAPE_ARGS={args}"]
         jobs.append((tmpl, os.path.join(OBJ, f"fe_shape_{name}.o"), defs, os.path.join(OBJ, f"fe_shape_{name}.stamp"),
                      _digest(common + [tmpl], " ".join(FLAGS + defs))))
+    tmpl_b = os.path.join(CSRC, "fe_bsrnn_shape.hip.in")
+    for name, args in shapes("fe_bsrnn_shapes.def", "XB"):
+        defs = [f"-DFE_SHAPE_NAME={name}", f"-DFE_SHAPE_ARGS={args}"]
+        jobs.append((tmpl_b, os.path.join(OBJ, f"fe_bsrnn_{name}.o"), defs, os.path.join(OBJ, f"fe_bsrnn_{name}.stamp"),
+                     _digest(common_b + [tmpl_b], " ".join(FLAGS + defs))))
     if force:
         for j in jobs:
             if os.path.exists(j[3]):

@@ -92,3 +92,47 @@ class FEConfig:
             input_compression=float(input_compression), weight_norm=bool(weight_norm),
             normalize_final_conv=bool(normalize_final_conv), pre_post_init=pre_post_init,
         )
+
+
+BSRNN_SUBBANDS = (2,) + (3,) * 10 + (8,) * 12 + (16,) * 7 + (17,)     # models/bsrnn/model.py:107-111
+
+
+@dataclass(frozen=True)
+class BSRNNConfig:
+    """yaml model_kwargs of `model: bsrnn` (configs/others/bsrnn_xt.yaml:2-11; models/bsrnn/model.py:261-272)."""
+    num_channels: int = 16
+    num_layers: int = 6
+    bias: bool = True
+    affine: bool = True
+    n_fft: int = 512
+    hop_size: int = 256
+    win_size: int = 512
+    input_compression: float = 0.3
+
+    @property
+    def F0(self) -> int:
+        return self.n_fft // 2
+
+    @property
+    def cache_len(self) -> int:
+        return self.n_fft - self.hop_size
+
+    @property
+    def n_bands(self) -> int:
+        return len(BSRNN_SUBBANDS)
+
+    @property
+    def hidden(self) -> int:
+        return 2 * self.num_channels
+
+    @staticmethod
+    def from_model_kwargs(num_channels: int = 16, num_layers: int = 6, bias: bool = True, affine: bool = True,
+                          n_fft: int = 512, hop_size: int = 256, win_size: int = 512, window: str = "hann",
+                          input_compression: float = 0.3, onnx: bool = True) -> "BSRNNConfig":
+        if n_fft != 512:
+            raise RuntimeError(f"Only n_fft=512 is supported, but given {n_fft}")       # models/bsrnn/model.py:112-113
+        if window != "hann":
+            raise RuntimeError(f"model_kwargs.window={window} is not supported by the HIP path (shipped: hann).")
+        assert n_fft >= win_size, f"n_fft({n_fft}) must be bigger than win_size({win_size})"
+        return BSRNNConfig(int(num_channels), int(num_layers), bool(bias), bool(affine), int(n_fft), int(hop_size),
+                           int(win_size), float(input_compression))

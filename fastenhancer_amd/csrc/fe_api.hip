@@ -12,6 +12,7 @@
 
 #include "../../include/fastenhancer_hip.h"
 #include "fe_impl.h"
+#include "bsrnn_kernels.hip.h"
 
 namespace {
 
@@ -49,6 +50,18 @@ struct Dims {
 #include "fe_shapes.def"
 #undef X
 
+#define XB(name, ...) extern "C" const fe::BImpl* fe_bimpl_##name();
+#include "fe_bsrnn_shapes.def"
+#undef XB
+const std::vector<const fe::BImpl*>& bimpls() {
+    static const std::vector<const fe::BImpl*> v = {
+#define XB(name, ...) fe_bimpl_##name(),
+#include "fe_bsrnn_shapes.def"
+#undef XB
+    };
+    return v;
+}
+
 const std::vector<const fe::Impl*>& impls() {
     static const std::vector<const fe::Impl*> v = {
 #define X(name, ...) fe_impl_##name(),
@@ -64,6 +77,8 @@ struct fe_handle {
     fe_config cfg;
     Dims d;
     const fe::Impl* impl = nullptr;
+    const fe::BImpl* bimpl = nullptr;     // arch == FE_ARCH_BSRNN
+    fe::BOffsets boff{};
     int device = 0;
     std::vector<Section> sections;
     size_t blob_floats = 0;
@@ -259,6 +274,180 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
     return FE_OK;
 }
 
+
+// ============================================================================ BSRNN (models/bsrnn/model.py)
+const int kSub[31] = {2, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 16, 16, 16, 16, 16, 16, 16, 17};
+
+void build_sections_bsrnn(fe_handle* h) {
+    const int C = h->cfg.channels, L = h->cfg.rf_blocks, HH = 2 * C;
+    char nm[160];
+    for (int b = 0; b < 31; ++b) {
+        snprintf(nm, sizeof nm, "band_split.fc.%d.weight", b); add_section(h, nm, {C, 2 * kSub[b], 1});
+        snprintf(nm, sizeof nm, "band_split.fc.%d.bias", b); add_section(h, nm, {C});
+    }
+    for (int l = 0; l < L; ++l) {
+        snprintf(nm, sizeof nm, "rnn_time.%d.weight_ih", l); add_section(h, nm, {4 * HH, C});
+        snprintf(nm, sizeof nm, "rnn_time.%d.weight_hh", l); add_section(h, nm, {4 * HH, HH});
+        snprintf(nm, sizeof nm, "rnn_time.%d.bias_ih", l); add_section(h, nm, {4 * HH});
+        snprintf(nm, sizeof nm, "rnn_time.%d.bias_hh", l); add_section(h, nm, {4 * HH});
+        snprintf(nm, sizeof nm, "fc_time.%d.weight", l); add_section(h, nm, {C, HH});
+        snprintf(nm, sizeof nm, "fc_time.%d.bias", l); add_section(h, nm, {C});
+        for (const char* sfx : {"", "_reverse"}) {
+            snprintf(nm, sizeof nm, "rnn_freq.%d.weight_ih_l0%s", l, sfx); add_section(h, nm, {4 * HH, C});
+            snprintf(nm, sizeof nm, "rnn_freq.%d.weight_hh_l0%s", l, sfx); add_section(h, nm, {4 * HH, HH});
+            snprintf(nm, sizeof nm, "rnn_freq.%d.bias_ih_l0%s", l, sfx); add_section(h, nm, {4 * HH});
+            snprintf(nm, sizeof nm, "rnn_freq.%d.bias_hh_l0%s", l, sfx); add_section(h, nm, {4 * HH});
+        }
+        snprintf(nm, sizeof nm, "fc_freq.%d.weight", l); add_section(h, nm, {C, 2 * HH});
+        snprintf(nm, sizeof nm, "fc_freq.%d.bias", l); add_section(h, nm, {C});
+    }
+    for (const char* kind : {"mlp_mask", "mlp_residual"})
+        for (int b = 0; b < 31; ++b) {
+            snprintf(nm, sizeof nm, "mask_decoder.%s.%d.0.weight", kind, b); add_section(h, nm, {4 * C, C, 1});
+            snprintf(nm, sizeof nm, "mask_decoder.%s.%d.0.bias", kind, b); add_section(h, nm, {4 * C});
+            snprintf(nm, sizeof nm, "mask_decoder.%s.%d.2.weight", kind, b); add_section(h, nm, {4 * kSub[b], 4 * C, 1});
+            snprintf(nm, sizeof nm, "mask_decoder.%s.%d.2.bias", kind, b); add_section(h, nm, {4 * kSub[b]});
+        }
+}
+
+int create_bsrnn(const fe_config* cfg, fe_handle** out) {
+    if (cfg->n_fft != 512) return fail(FE_ERR_INVALID_ARG, "Only n_fft=512 is supported, but given %d", cfg->n_fft);
+    if (cfg->win_size > cfg->n_fft) return fail(FE_ERR_INVALID_ARG, "n_fft(%d) must be bigger than win_size(%d)", cfg->n_fft, cfg->win_size);
+    if (cfg->hop_size <= 0 || cfg->hop_size > cfg->n_fft) return fail(FE_ERR_INVALID_ARG, "hop_size %d out of range", cfg->hop_size);
+    const fe::BImpl* bi = nullptr;
+    for (const fe::BImpl* im : bimpls())
+        if (im->C == cfg->channels && im->NLAY == cfg->rf_blocks && im->HOP == cfg->hop_size) bi = im;
+    if (!bi)
+        return fail(FE_ERR_UNSUPPORTED_CONFIG, "no BSRNN kernel compiled for num_channels=%d num_layers=%d hop=%d", cfg->channels,
+                    cfg->rf_blocks, cfg->hop_size);
+    fe_handle* h = new fe_handle();
+    h->cfg = *cfg;
+    h->bimpl = bi;
+    h->d = Dims{cfg->channels, 0, 0, 0, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, cfg->n_fft / 2, 0, 0, {0}};
+    if (hipGetDevice(&h->device) != hipSuccess) h->device = -1;
+    build_sections_bsrnn(h);
+    build_tables(h);
+    *out = h;
+    return FE_OK;
+}
+
+int pack_weights_bsrnn(fe_handle* h, const std::vector<float>& blob, std::vector<float>* out) {
+    const int C = h->cfg.channels, L = h->cfg.rf_blocks, HH = 2 * C, G4 = 4 * HH, R = 4 * 257;
+    fe::BOffsets& o = h->boff;
+    std::vector<float> buf;
+    auto alloc = [&](size_t n) { size_t off = (buf.size() + 63) & ~(size_t)63; buf.resize(off + n, 0.0f); return (int)off; };
+    auto S = [&](const std::string& n) { return sec(h, blob, n); };
+    auto pack_b = [&](int K, int Ncols, const std::function<float(int, int)>& Bkn) {
+        const int KS = K / 4, NT = (Ncols + 15) / 16;
+        int off = alloc((size_t)NT * KS * 64);
+        for (int nt = 0; nt < NT; ++nt)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    int k = 4 * ks + lane / 16, n = 16 * nt + lane % 16;
+                    buf[off + ((size_t)nt * KS + ks) * 64 + lane] = n < Ncols ? Bkn(k, n) : 0.0f;
+                }
+        return off;
+    };
+    char nm[160];
+    o.bs_b = alloc(31 * C);
+    for (int b = 0; b < 31; ++b) {
+        snprintf(nm, sizeof nm, "band_split.fc.%d.weight", b);
+        const float* w = S(nm);                                   // (C, 2sub)
+        const int k2 = 2 * kSub[b];
+        o.bs_w[b] = alloc((size_t)k2 * C);
+        for (int k = 0; k < k2; ++k)
+            for (int c = 0; c < C; ++c) buf[o.bs_w[b] + k * C + c] = w[c * k2 + k];
+        snprintf(nm, sizeof nm, "band_split.fc.%d.bias", b);
+        memcpy(&buf[o.bs_b + b * C], S(nm), C * sizeof(float));
+    }
+    for (int l = 0; l < L; ++l) {
+        auto key = [&](const char* fmt) { snprintf(nm, sizeof nm, fmt, l); return std::string(nm); };
+        {   // time LSTM: K = [x (C) | h (HH)], N = 4HH gate rows (i,f,g,o)
+            const float* wih = S(key("rnn_time.%d.weight_ih"));
+            const float* whh = S(key("rnn_time.%d.weight_hh"));
+            o.t_w[l] = pack_b(C + HH, G4, [&](int k, int n) { return k < C ? wih[n * C + k] : whh[n * HH + (k - C)]; });
+            const float* bi = S(key("rnn_time.%d.bias_ih"));
+            const float* bh = S(key("rnn_time.%d.bias_hh"));
+            o.t_b[l] = alloc(G4);
+            for (int i = 0; i < G4; ++i) buf[o.t_b[l] + i] = bi[i] + bh[i];
+        }
+        {
+            const float* w = S(key("fc_time.%d.weight"));         // (C, HH)
+            o.tfc_w[l] = pack_b(HH, C, [&](int k, int n) { return w[n * HH + k]; });
+            o.tfc_b[l] = alloc(C);
+            memcpy(&buf[o.tfc_b[l]], S(key("fc_time.%d.bias")), C * sizeof(float));
+        }
+        for (int d = 0; d < 2; ++d) {
+            const char* sfx = d ? "_reverse" : "";
+            auto keyd = [&](const char* stem) { snprintf(nm, sizeof nm, "rnn_freq.%d.%s_l0%s", l, stem, sfx); return std::string(nm); };
+            const float* wih = S(keyd("weight_ih"));
+            o.f_wih[l][d] = pack_b(C, G4, [&](int k, int n) { return wih[n * C + k]; });
+            const float* bi = S(keyd("bias_ih"));
+            const float* bh = S(keyd("bias_hh"));
+            o.f_b[l][d] = alloc(G4);
+            for (int i = 0; i < G4; ++i) buf[o.f_b[l][d] + i] = bi[i] + bh[i];
+            o.f_whh[l][d] = alloc((size_t)G4 * HH);
+            memcpy(&buf[o.f_whh[l][d]], S(keyd("weight_hh")), (size_t)G4 * HH * sizeof(float));
+        }
+        {
+            const float* w = S(key("fc_freq.%d.weight"));         // (C, 2HH)
+            o.ffc_w[l] = pack_b(2 * HH, C, [&](int k, int n) { return w[n * 2 * HH + k]; });
+            o.ffc_b[l] = alloc(C);
+            memcpy(&buf[o.ffc_b[l]], S(key("fc_freq.%d.bias")), C * sizeof(float));
+        }
+    }
+    const char* kinds[2] = {"mlp_mask", "mlp_residual"};
+    for (int kind = 0; kind < 2; ++kind) {
+        o.m_w1[kind] = alloc((size_t)31 * C * 4 * C);
+        o.m_b1[kind] = alloc((size_t)31 * 4 * C);
+        o.m_w2[kind] = alloc((size_t)4 * C * R);
+        o.m_b2[kind] = alloc(R);
+        int row0 = 0;
+        for (int b = 0; b < 31; ++b) {
+            snprintf(nm, sizeof nm, "mask_decoder.%s.%d.0.weight", kinds[kind], b);
+            const float* w1 = S(nm);                              // (4C, C)
+            for (int k = 0; k < C; ++k)
+                for (int oo = 0; oo < 4 * C; ++oo) buf[o.m_w1[kind] + ((size_t)b * C + k) * 4 * C + oo] = w1[oo * C + k];
+            snprintf(nm, sizeof nm, "mask_decoder.%s.%d.0.bias", kinds[kind], b);
+            memcpy(&buf[o.m_b1[kind] + b * 4 * C], S(nm), 4 * C * sizeof(float));
+            snprintf(nm, sizeof nm, "mask_decoder.%s.%d.2.weight", kinds[kind], b);
+            const float* w2 = S(nm);                              // (4sub, 4C)
+            const int rows = 4 * kSub[b];
+            for (int r = 0; r < rows; ++r)
+                for (int k = 0; k < 4 * C; ++k) buf[o.m_w2[kind] + (size_t)k * R + row0 + r] = w2[r * 4 * C + k];
+            snprintf(nm, sizeof nm, "mask_decoder.%s.%d.2.bias", kinds[kind], b);
+            memcpy(&buf[o.m_b2[kind] + row0], S(nm), rows * sizeof(float));
+            row0 += rows;
+        }
+    }
+    o.window = alloc(h->window.size()); memcpy(&buf[o.window], h->window.data(), h->window.size() * sizeof(float));
+    o.window_istft = alloc(h->window_istft.size()); memcpy(&buf[o.window_istft], h->window_istft.data(), h->window_istft.size() * sizeof(float));
+    o.twiddle = alloc(h->twiddle.size()); memcpy(&buf[o.twiddle], h->twiddle.data(), h->twiddle.size() * sizeof(float));
+    o.total = (int)((buf.size() + 63) & ~(size_t)63);
+    buf.resize(o.total, 0.0f);
+    *out = std::move(buf);
+    return FE_OK;
+}
+
+size_t bsrnn_lstm_floats(const fe_handle* h, int B) { return (size_t)2 * h->cfg.rf_blocks * B * 31 * 2 * h->cfg.channels; }
+
+fe::BArgs bsrnn_args(fe_handle* h, int B, int T) {
+    fe::BArgs a{};
+    a.wp = h->packed_dev;
+    a.off = h->boff;
+    a.B = B;
+    a.T = T;
+    a.compression = h->cfg.input_compression;
+    return a;
+}
+
+int launch_bsrnn(fe_handle* h, const fe::BArgs& a, void* stream) {
+    hipError_t e = hipSuccess;
+    h->bimpl->launch(a, (hipStream_t)stream, &e);
+    if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return FE_OK;
+}
+
 int check_ready(const fe_handle* h) {
     if (!h) return fail(FE_ERR_INVALID_ARG, "null handle");
     if (!h->loaded) return fail(FE_ERR_NO_WEIGHTS, "fe_load_weights has not been called");
@@ -296,6 +485,7 @@ const char* fe_version(void) { return "fastenhancer_hip 0.1 (gfx950)"; }
 int fe_create(const fe_config* cfg, fe_handle** out) {
     if (!cfg || !out) return fail(FE_ERR_INVALID_ARG, "null argument");
     *out = nullptr;
+    if (cfg->arch == FE_ARCH_BSRNN) return create_bsrnn(cfg, out);
     if (cfg->arch != FE_ARCH_FASTENHANCER)
         return fail(FE_ERR_UNSUPPORTED_CONFIG, "arch %d is not built into this library", cfg->arch);
     if (cfg->n_fft % 2 != 0) return fail(FE_ERR_INVALID_ARG, "`n_fft` must be an even number, but given %d.", cfg->n_fft);
@@ -358,7 +548,7 @@ int fe_load_weights(fe_handle* h, const float* blob_dev, size_t nfloats, void* s
     FE_HIP_CHECK(hipMemcpyAsync(blob.data(), blob_dev, nfloats * sizeof(float), hipMemcpyDeviceToHost, st));
     FE_HIP_CHECK(hipStreamSynchronize(st));
     std::vector<float> packed;
-    int rc = pack_weights(h, blob, &packed);
+    int rc = h->bimpl ? pack_weights_bsrnn(h, blob, &packed) : pack_weights(h, blob, &packed);
     if (rc != FE_OK) return rc;
     if (h->packed_dev) { FE_HIP_CHECK(hipFree(h->packed_dev)); h->packed_dev = nullptr; }
     FE_HIP_CHECK(hipMalloc(&h->packed_dev, packed.size() * sizeof(float)));
@@ -371,6 +561,7 @@ int fe_load_weights(fe_handle* h, const float* blob_dev, size_t nfloats, void* s
 size_t fe_state_floats(const fe_handle* h, int B) {
     if (!h || B <= 0) return 0;
     const Dims& d = h->d;
+    if (h->bimpl) return (size_t)B * 2 * (size_t)(d.NFFT - d.HOP) + bsrnn_lstm_floats(h, B);
     return (size_t)B * (2 * (size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2);
 }
 
@@ -388,6 +579,15 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
     const Dims& d = h->d;
     if (in_stride < (size_t)T * d.HOP && B > 1) return fail(FE_ERR_INVALID_ARG, "in_stride %zu < T*H", in_stride);
     if (out_stride < (size_t)T * d.HOP && B > 1) return fail(FE_ERR_INVALID_ARG, "out_stride %zu < T*H", out_stride);
+    if (h->bimpl) {
+        if (dbg || clk) return fail(FE_ERR_UNSUPPORTED_CONFIG, "debug / profile dumps are not built for BSRNN");
+        fe::BArgs ba = bsrnn_args(h, B, T);
+        const size_t ovl_b = (size_t)(d.NFFT - d.HOP);
+        ba.mode = fe::FE_MODE_STREAM;
+        ba.wav_in = wav_in; ba.wav_out = wav_out; ba.in_stride = in_stride; ba.out_stride = out_stride;
+        ba.cache_stft = state; ba.cache_istft = state + (size_t)B * ovl_b; ba.lstm = state + 2 * (size_t)B * ovl_b;
+        return launch_bsrnn(h, ba, stream);
+    }
     rc = ensure_scratch(h, B);
     if (rc != FE_OK) return rc;
     fe::FrameArgs a = base_args(h, B, T);
@@ -430,6 +630,12 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
     int rc = check_ready(h);
     if (rc != FE_OK) return rc;
     if (!spec_in_dev || !h_dev || !spec_out_dev || B <= 0 || T <= 0) return fail(FE_ERR_INVALID_ARG, "bad argument");
+    if (h->bimpl) {
+        fe::BArgs ba = bsrnn_args(h, B, T);
+        ba.mode = fe::FE_MODE_SPEC;
+        ba.spec_in = spec_in_dev; ba.spec_out = spec_out_dev; ba.lstm = h_dev;
+        return launch_bsrnn(h, ba, stream);
+    }
     rc = ensure_scratch(h, B);
     if (rc != FE_OK) return rc;
     fe::FrameArgs a = base_args(h, B, T);
@@ -446,6 +652,7 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
 size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw) {
     if (!h || B <= 0 || Tw <= 0) return 0;
     const Dims& d = h->d;
+    if (h->bimpl) return (size_t)B * (size_t)(d.NFFT - d.HOP) + bsrnn_lstm_floats(h, B);
     // GRU state (zero initial state, model.py:626-627) + overlap-add tail, both zeroed by fe_offline
     return (size_t)B * ((size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2);
 }
@@ -458,11 +665,22 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
     const Dims& d = h->d;
     if (Tw <= d.NFFT / 2)   // torch.stft reflect padding needs pad < length
         return fail(FE_ERR_INVALID_ARG, "Tw=%d: reflect padding of n_fft/2=%d needs a longer input", Tw, d.NFFT / 2);
-    rc = ensure_scratch(h, B);
-    if (rc != FE_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     FE_HIP_CHECK(hipMemsetAsync(work_dev, 0, fe_offline_work_floats(h, B, Tw) * sizeof(float), st));
     const int T = 1 + Tw / d.HOP;
+    if (h->bimpl) {
+        fe::BArgs ba = bsrnn_args(h, B, T);
+        ba.mode = fe::FE_MODE_OFFLINE;
+        ba.Tw = Tw;
+        ba.wav_in = noisy_dev; ba.in_stride = (size_t)Tw;
+        ba.wav_out = wav_hat_dev; ba.out_stride = (size_t)d.HOP * (T - 1);
+        ba.spec_out = spec_hat_dev;
+        ba.cache_istft = work_dev; ba.cache_stft = work_dev;
+        ba.lstm = work_dev + (size_t)B * (d.NFFT - d.HOP);
+        return launch_bsrnn(h, ba, stream);
+    }
+    rc = ensure_scratch(h, B);
+    if (rc != FE_OK) return rc;
     fe::FrameArgs a = base_args(h, B, T);
     a.mode = fe::FE_MODE_OFFLINE;
     a.Tw = Tw;
@@ -483,6 +701,14 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
 double fe_flops_per_frame(const fe_handle* h) {
     if (!h) return 0.0;
     const Dims& d = h->d;
+    if (h->bimpl) {   // models/bsrnn/macs.py:18-51
+        const double C = h->cfg.channels, Hh = 2 * C, Lr = h->cfg.rf_blocks;
+        double m = 0;
+        for (int b = 0; b < 31; ++b) m += 2 * kSub[b] * C;
+        m += (C * Hh * 4 + Hh * Hh * 4 + Hh * C + (C * Hh * 4 + Hh * Hh * 4) * 2 + 2 * Hh * C) * 31 * Lr;
+        for (int b = 0; b < 31; ++b) m += (C * C * 4 + 4 * C * 4 * kSub[b]) * 2;
+        return 2.0 * m + 2.0 * 2.5 * d.NFFT * std::log2((double)d.NFFT);
+    }
     const double C1 = d.C1, C2 = d.C2, F1 = d.F1, F2 = d.F2, K = d.KB;
     double m = 2 * C1 * 8 * F1;
     for (int i = 1; i <= d.NL; ++i) m += C1 * C1 * 3 * F1;
@@ -494,11 +720,11 @@ double fe_flops_per_frame(const fe_handle* h) {
     return 2.0 * m + 2.0 * 2.5 * d.NFFT * std::log2((double)d.NFFT);
 }
 
-int fe_debug_stages(const fe_handle* h) { return h ? h->impl->dbg_stages : 0; }
-size_t fe_debug_floats(const fe_handle* h) { return h ? h->impl->dbg_floats : 0; }
+int fe_debug_stages(const fe_handle* h) { return (h && h->impl) ? h->impl->dbg_stages : 0; }
+size_t fe_debug_floats(const fe_handle* h) { return (h && h->impl) ? h->impl->dbg_floats : 0; }
 
 int fe_debug_stage(const fe_handle* h, int idx, const char** name, int* rows, int* cols, size_t* offset_floats) {
-    if (!h || idx < 0 || idx >= h->impl->dbg_stages) return fail(FE_ERR_INVALID_ARG, "stage index %d", idx);
+    if (!h || !h->impl || idx < 0 || idx >= h->impl->dbg_stages) return fail(FE_ERR_INVALID_ARG, "stage index %d", idx);
     static thread_local std::string nm;
     const Dims& d = h->d;
     char buf[64];

@@ -12,8 +12,8 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from .config import FEConfig
-from .weights import check_fused, fold_state_dict
+from .config import BSRNNConfig, FEConfig
+from .weights import (bsrnn_expected_fused_shapes, bsrnn_fold_state_dict, check_fused, check_shapes, fold_state_dict)
 
 
 def _ptr(t: Optional[Tensor]) -> c_void_p:
@@ -32,15 +32,20 @@ class Engine:
         self.cfg = cfg
         self.device = torch.device(device) if device is not None else None
         c = _lib.fe_config()
-        c.arch = _lib.FE_ARCH_FASTENHANCER
+        self.is_bsrnn = isinstance(cfg, BSRNNConfig)
         c.n_fft, c.hop_size, c.win_size = cfg.n_fft, cfg.hop_size, cfg.win_size
-        c.channels = cfg.channels
-        c.n_kernels = len(cfg.kernel_size)
-        for i, k in enumerate(cfg.kernel_size):
-            c.kernel_size[i] = k
-        c.stride = cfg.stride
-        c.rf_channels, c.rf_freq, c.rf_blocks, c.rf_heads = cfg.rf_channels, cfg.rf_freq, cfg.rf_blocks, cfg.rf_heads
         c.input_compression = cfg.input_compression
+        if self.is_bsrnn:
+            c.arch = _lib.FE_ARCH_BSRNN
+            c.channels, c.rf_blocks = cfg.num_channels, cfg.num_layers
+        else:
+            c.arch = _lib.FE_ARCH_FASTENHANCER
+            c.channels = cfg.channels
+            c.n_kernels = len(cfg.kernel_size)
+            for i, k in enumerate(cfg.kernel_size):
+                c.kernel_size[i] = k
+            c.stride = cfg.stride
+            c.rf_channels, c.rf_freq, c.rf_blocks, c.rf_heads = cfg.rf_channels, cfg.rf_freq, cfg.rf_blocks, cfg.rf_heads
         self._h = c_void_p()
         if self.device is not None and self.device.type == "cuda":
             with torch.cuda.device(self.device):
@@ -72,8 +77,12 @@ class Engine:
 
     def make_blob(self, state_dict: Mapping[str, Tensor], strict: bool = True) -> Tensor:
         """reference checkpoint (training or fused form) -> flat fp32 blob on the CPU."""
-        fused = fold_state_dict(state_dict, self.cfg)
-        check_fused(fused, self.cfg, strict=strict)
+        if self.is_bsrnn:
+            fused = bsrnn_fold_state_dict(state_dict, self.cfg)
+            check_shapes(fused, bsrnn_expected_fused_shapes(self.cfg), strict=strict)
+        else:
+            fused = fold_state_dict(state_dict, self.cfg)
+            check_fused(fused, self.cfg, strict=strict)
         blob = torch.zeros(self.weight_floats, dtype=torch.float32)
         for name, off, cnt in self.sections:
             t = fused[name].contiguous().reshape(-1)
@@ -111,6 +120,12 @@ class Engine:
         L = c.cache_len
         out = [state[:B * L].view(B, L), state[B * L:2 * B * L].view(B, L)]
         o = 2 * B * L
+        if self.is_bsrnn:          # 2 * num_layers LSTM caches (h, c) of shape [B*31, 2C]  (models/bsrnn/model.py:409-416)
+            n = B * c.n_bands * c.hidden
+            for _ in range(2 * c.num_layers):
+                out.append(state[o:o + n].view(B * c.n_bands, c.hidden))
+                o += n
+            return out
         n = B * c.rf_freq * c.rf_channels
         for _ in range(c.rf_blocks):
             out.append(state[o:o + n].view(1, B * c.rf_freq, c.rf_channels))
@@ -155,7 +170,7 @@ class Engine:
         cfg = self.cfg
         T = 1 + Tw // cfg.hop_size
         wav = torch.empty(B, cfg.hop_size * (T - 1), dtype=torch.float32, device=noisy.device)
-        spec = torch.empty(B, cfg.F0, T, 2, dtype=torch.float32, device=noisy.device)
+        spec = torch.empty(B, cfg.F0 + (1 if self.is_bsrnn else 0), T, 2, dtype=torch.float32, device=noisy.device)
         work = torch.empty(int(self.lib.fe_offline_work_floats(self._h, B, Tw)), dtype=torch.float32, device=noisy.device)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.fe_offline(self._h, _ptr(noisy), B, Tw, _ptr(wav), _ptr(spec), _ptr(work), _stream(self.device)),

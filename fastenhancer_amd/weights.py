@@ -200,3 +200,124 @@ def default_state_dict(cfg: FEConfig, generator: Optional[torch.Generator] = Non
         w = sd["dec_post.2.weight"]
         sd["dec_post.2.weight"] = w / w.norm().clamp_min(1e-12)
     return sd
+
+
+# ------------------------------------------------------------------------------------------------ BSRNN
+def _bn_wb(sd, prefix):
+    """x*w + b of an eval BatchNorm placed BEFORE a conv / LSTM (models/bsrnn/model.py:27-33)."""
+    std = (sd[prefix + ".running_var"] + BN_EPS).sqrt()
+    w = 1.0 / std
+    b = -sd[prefix + ".running_mean"] / std
+    if prefix + ".weight" in sd:
+        w = sd[prefix + ".weight"] * w
+        b = b * sd[prefix + ".weight"] + sd[prefix + ".bias"]
+    return w, b
+
+
+def bsrnn_expected_fused_shapes(cfg) -> Dict[str, tuple]:
+    from .config import BSRNN_SUBBANDS
+    C, Hh = cfg.num_channels, cfg.hidden
+    s: Dict[str, tuple] = {}
+    for b, sub in enumerate(BSRNN_SUBBANDS):
+        s[f"band_split.fc.{b}.weight"] = (C, 2 * sub, 1)
+        s[f"band_split.fc.{b}.bias"] = (C,)
+    for l in range(cfg.num_layers):
+        s[f"rnn_time.{l}.weight_ih"] = (4 * Hh, C)
+        s[f"rnn_time.{l}.weight_hh"] = (4 * Hh, Hh)
+        s[f"rnn_time.{l}.bias_ih"] = (4 * Hh,)
+        s[f"rnn_time.{l}.bias_hh"] = (4 * Hh,)
+        s[f"fc_time.{l}.weight"] = (C, Hh)
+        s[f"fc_time.{l}.bias"] = (C,)
+        for sfx in ("", "_reverse"):
+            s[f"rnn_freq.{l}.weight_ih_l0{sfx}"] = (4 * Hh, C)
+            s[f"rnn_freq.{l}.weight_hh_l0{sfx}"] = (4 * Hh, Hh)
+            s[f"rnn_freq.{l}.bias_ih_l0{sfx}"] = (4 * Hh,)
+            s[f"rnn_freq.{l}.bias_hh_l0{sfx}"] = (4 * Hh,)
+        s[f"fc_freq.{l}.weight"] = (C, 2 * Hh)
+        s[f"fc_freq.{l}.bias"] = (C,)
+    for kind in ("mlp_mask", "mlp_residual"):
+        for b, sub in enumerate(BSRNN_SUBBANDS):
+            p = f"mask_decoder.{kind}.{b}."
+            s[p + "0.weight"] = (4 * C, C, 1)
+            s[p + "0.bias"] = (4 * C,)
+            s[p + "2.weight"] = (4 * sub, 4 * C, 1)
+            s[p + "2.bias"] = (4 * sub,)
+    return s
+
+
+def bsrnn_fold_state_dict(sd: Mapping[str, Tensor], cfg) -> Dict[str, Tensor]:
+    """ONNXModel.remove_weight_reparameterizations of models/bsrnn/model.py:348-366 (fuse_bn_conv1d :14-42,
+    fuse_bn_rnn :45-82) + the rnn_time key rename of load_state_dict (:450-460).  Training-form or fused in, fused out."""
+    from .config import BSRNN_SUBBANDS
+    sd = {k: _f32(v) for k, v in sd.items() if torch.as_tensor(v).is_floating_point()}
+    if "band_split.norm.0.running_var" not in sd:
+        out = {}
+        for k, v in sd.items():     # accept nn.LSTM-style names of the offline model for the time LSTM
+            out[k[:-3] if (k.startswith("rnn_time.") and k.endswith("_l0")) else k] = v
+        return out
+    C = cfg.num_channels
+    out: Dict[str, Tensor] = {}
+
+    def conv(conv_key, bn_key, dst):
+        w, b = _bn_wb(sd, bn_key)
+        W = sd[conv_key + ".weight"]
+        bias = (W * b.view(1, -1, 1)).sum(dim=(1, 2))
+        if conv_key + ".bias" in sd:
+            bias = bias + sd[conv_key + ".bias"]
+        out[dst + ".weight"] = W * w.view(1, -1, 1)
+        out[dst + ".bias"] = bias
+
+    def rnn(src, bn_key, dst_w, dst_b, sfx=""):
+        w, b = _bn_wb(sd, bn_key)
+        W = sd[src + ".weight_ih_l0" + sfx]
+        out[dst_w] = W * w.view(1, -1)
+        out[dst_b] = sd[src + ".bias_ih_l0" + sfx] + W @ b
+
+    for b in range(len(BSRNN_SUBBANDS)):
+        conv(f"band_split.fc.{b}", f"band_split.norm.{b}", f"band_split.fc.{b}")
+    for l in range(cfg.num_layers):
+        rnn(f"rnn_time.{l}", f"norm_time.{l}", f"rnn_time.{l}.weight_ih", f"rnn_time.{l}.bias_ih")
+        out[f"rnn_time.{l}.weight_hh"] = sd[f"rnn_time.{l}.weight_hh_l0"]
+        out[f"rnn_time.{l}.bias_hh"] = sd[f"rnn_time.{l}.bias_hh_l0"]
+        out[f"fc_time.{l}.weight"] = sd[f"fc_time.{l}.weight"]
+        out[f"fc_time.{l}.bias"] = sd.get(f"fc_time.{l}.bias", torch.zeros(C))
+        for sfx in ("", "_reverse"):
+            rnn(f"rnn_freq.{l}", f"norm_freq.{l}", f"rnn_freq.{l}.weight_ih_l0{sfx}", f"rnn_freq.{l}.bias_ih_l0{sfx}", sfx)
+            out[f"rnn_freq.{l}.weight_hh_l0{sfx}"] = sd[f"rnn_freq.{l}.weight_hh_l0{sfx}"]
+            out[f"rnn_freq.{l}.bias_hh_l0{sfx}"] = sd[f"rnn_freq.{l}.bias_hh_l0{sfx}"]
+        out[f"fc_freq.{l}.weight"] = sd[f"fc_freq.{l}.weight"]
+        out[f"fc_freq.{l}.bias"] = sd.get(f"fc_freq.{l}.bias", torch.zeros(C))
+    for kind in ("mlp_mask", "mlp_residual"):
+        for b in range(len(BSRNN_SUBBANDS)):
+            p = f"mask_decoder.{kind}.{b}."
+            conv(p + "1", p + "0", p + "0")
+            out[p + "2.weight"] = sd[p + "3.weight"]
+            out[p + "2.bias"] = sd[p + "3.bias"]
+    return out
+
+
+def bsrnn_default_state_dict(cfg, generator: Optional[torch.Generator] = None) -> Dict[str, Tensor]:
+    """fresh fused-form state_dict with PyTorch-style uniform initialisation"""
+    sd = {}
+    for k, shp in bsrnn_expected_fused_shapes(cfg).items():
+        fan_in = 1
+        for s_ in shp[1:]:
+            fan_in *= s_
+        bound = 1.0 / math.sqrt(cfg.hidden if "rnn_" in k else max(fan_in, 1))
+        sd[k] = (torch.rand(shp, generator=generator) * 2 - 1) * bound
+    return sd
+
+
+def check_shapes(fused: Mapping[str, Tensor], exp: Mapping[str, tuple], strict: bool = True):
+    missing = [k for k in exp if k not in fused]
+    unexpected = [k for k in fused if k not in exp]
+    errs = []
+    if missing:
+        errs.append("Missing key(s) in state_dict: " + ", ".join(missing))
+    if unexpected and strict:
+        errs.append("Unexpected key(s) in state_dict: " + ", ".join(unexpected))
+    for k, shp in exp.items():
+        if k in fused and tuple(fused[k].shape) != tuple(shp):
+            errs.append(f"size mismatch for {k}: checkpoint {tuple(fused[k].shape)} vs model {tuple(shp)}")
+    if errs:
+        raise RuntimeError("Error(s) in loading state_dict:\n\t" + "\n\t".join(errs))

@@ -271,3 +271,75 @@ def test_command_line_callers(tmp_path, monkeypatch):
                          str(tmp_path / "s.wav"), "--n-fft", "512", "--hop-size", "256", "--sr", "16000"])
     rate, ys = wavfile.read(str(tmp_path / "s.wav"))
     _assert_close(ys, orc.enhance_stream(x[None])[0], "test_streaming CLI")
+
+
+# ------------------------------------------------------------------------------------------------ BSRNN (a22-a25)
+def _bsrnn(name, cls="ONNXModel"):
+    from common import BSRNN_KWARGS, build_bsrnn_oracle
+    kw, sr, seed = BSRNN_KWARGS[name]
+    cfg, sd, fused, orc = build_bsrnn_oracle(name)
+    mod = importlib.import_module("fastenhancer_amd.models.bsrnn.model")
+    m = getattr(mod, cls)(**kw).to(_dev()).eval()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return m, orc, cfg, sr, seed
+
+
+@pytest.mark.parametrize("name", ["bsrnn_xxt", "bsrnn_xt"])
+def test_bsrnn_streaming_matches_reference_golden(name):
+    from fastenhancer_amd.streaming import StreamingModel
+    g = load_golden(name)
+    m, orc, cfg, sr, seed = _bsrnn(name)
+    M = StreamingModel(m)
+    B, hops, H = int(g["B"]), int(g["hops"]), cfg.hop_size
+    x = torch.from_numpy(make_input(B, hops * H, seed + 1000, sr)).to(_dev())
+    caches = M.initialize_cache(x)
+    outs = []
+    for t in range(hops):
+        wav_out, *caches = M(x[:, t * H:(t + 1) * H], *caches)
+        outs.append(wav_out.cpu().numpy())
+    _assert_close(np.stack(outs, 0), g["stream_wav_out"], "wav_out")
+    _assert_close(caches[0].cpu().numpy(), g["stream_cache_stft"], "cache_stft")
+    _assert_close(caches[1].cpu().numpy(), g["stream_cache_istft"], "cache_istft")
+    for i in range(2 * cfg.num_layers):
+        _assert_close(caches[2 + i].cpu().numpy(), g[f"stream_c{i}"], f"lstm cache {i}")
+
+
+@pytest.mark.parametrize("name", ["bsrnn_xxt", "bsrnn_xt"])
+def test_bsrnn_offline_matches_reference_golden(name):
+    g = load_golden(name)
+    m, orc, cfg, sr, seed = _bsrnn(name, "Model")
+    x = torch.from_numpy(make_input(int(g["B"]), int(g["hops"]) * cfg.hop_size + 37, seed + 2000, sr)).to(_dev())
+    wav_hat, spec_hat = m(x)
+    _assert_close(wav_hat.cpu().numpy(), g["offline_wav"], "offline wav")
+    _assert_close(spec_hat.cpu().numpy(), g["offline_spec"], "offline spec")
+
+
+@pytest.mark.parametrize("name", ["bsrnn_xt", "bsrnn_t"])
+def test_bsrnn_batch_and_chunk_vs_oracle(name):
+    m, orc, cfg, sr, seed = _bsrnn(name)
+    eng = m.engine
+    B, T, H = 5, 5, cfg.hop_size
+    x = make_input(B, T * H, 77, sr)
+    xd = torch.from_numpy(x).to(_dev())
+    s1, s2 = eng.new_state(B), eng.new_state(B)
+    y1 = eng.step(xd, s1, T=T)
+    y2 = torch.cat([eng.step(xd[:, t * H:(t + 1) * H], s2, T=1) for t in range(T)], dim=1)
+    assert torch.equal(y1, y2) and torch.equal(s1, s2)
+    caches = orc.initialize_cache(B)
+    refs = []
+    for t in range(T):
+        o, *caches = orc.step(x[:, t * H:(t + 1) * H], *caches)
+        refs.append(o)
+    _assert_close(y1.cpu().numpy(), np.concatenate(refs, 1), "bsrnn chunk vs oracle")
+    for a_, b_ in zip(eng.split_state(s1, B), caches):
+        _assert_close(a_.cpu().numpy(), b_, "bsrnn cache")
+    # spec -> spec, T frames at once (the reference's LSTMCell path only takes T=1)
+    spec = []
+    c0 = orc.initialize_cache(B)[0]
+    for t in range(3):
+        s_, c0 = orc.stft_step(x[:, t * H:(t + 1) * H], c0)
+        spec.append(s_)
+    spec = np.concatenate(spec, axis=2)
+    ref_spec, _ = orc.spec_forward(spec, [np.zeros((B * cfg.n_bands, cfg.hidden), np.float32) for _ in range(2 * cfg.num_layers)])
+    got, *_ = m(torch.from_numpy(spec).to(_dev()), *m.initialize_cache(torch.zeros(B, 1, device=_dev())))
+    _assert_close(got.cpu().numpy(), ref_spec, "bsrnn spec chunk")
