@@ -44,6 +44,7 @@ WORKLOADS = {
                  desc="FastEnhancer_S 16kHz"),
     "fe48_b": dict(C1=48, ks=(8, 3, 3), C2=36, F2=36, K=3, N=1024, H=512, sr=48000, init="linear",
                    desc="FastEnhancer_B 48kHz"),
+    "bsrnn_xt": dict(bsrnn=True, C=16, L=6, N=512, H=256, sr=16000, desc="BSRNN (xt) 16kHz"),
     "fe_m": dict(C1=96, ks=(8, 3, 3, 3), C2=72, F2=48, K=4, N=512, H=160, sr=16000, init="linear_fixed",
                  desc="FastEnhancer_M 16kHz"),
     "fe_l": dict(C1=128, ks=(8, 3, 3, 3, 3), C2=96, F2=64, K=5, N=512, H=100, sr=16000, init="linear_fixed",
@@ -52,6 +53,9 @@ WORKLOADS = {
 
 
 def model_kwargs(w):
+    if w.get("bsrnn"):
+        return dict(num_channels=w["C"], num_layers=w["L"], bias=True, affine=True, n_fft=w["N"], hop_size=w["H"], win_size=w["N"],
+                    window="hann", input_compression=0.3)
     return dict(channels=w["C1"], kernel_size=list(w["ks"]), stride=4,
                 rnnformer_kwargs=dict(num_blocks=w["K"], channels=w["C2"], freq=w["F2"], num_heads=4, eps=1e-5,
                                       positional_embedding="train", attn_bias=False, post_act=False, pre_norm=False),
@@ -141,7 +145,11 @@ def main():
 
     w = WORKLOADS[args.workload]
     kw = model_kwargs(w)
-    cfg = FEConfig.from_model_kwargs(**kw)
+    if w.get("bsrnn"):
+        from fastenhancer_amd.config import BSRNNConfig
+        cfg = BSRNNConfig.from_model_kwargs(**kw)
+    else:
+        cfg = FEConfig.from_model_kwargs(**kw)
     eng = Engine(cfg, dev)
 
     # ---- weights: rank 0 builds the seeded checkpoint, folds it, and broadcasts the blob (RCCL)
@@ -149,9 +157,12 @@ def main():
     if rank == 0:
         # no trained checkpoints offline: PyTorch-style random init of the fused weights; the final conv is
         # scaled so that the complex mask is O(1) (the enhanced waveform has the level of the input)
-        from fastenhancer_amd.weights import default_state_dict
-        sd = default_state_dict(cfg, torch.Generator().manual_seed(2))
-        sd["dec_post.2.weight"] = sd["dec_post.2.weight"] * 12.0
+        from fastenhancer_amd.weights import bsrnn_default_state_dict, default_state_dict
+        if w.get("bsrnn"):
+            sd = bsrnn_default_state_dict(cfg, torch.Generator().manual_seed(2))
+        else:
+            sd = default_state_dict(cfg, torch.Generator().manual_seed(2))
+            sd["dec_post.2.weight"] = sd["dec_post.2.weight"] * 12.0
         blob.copy_(eng.make_blob(sd))
     broadcast_blob(blob, src=0)
     eng.load_blob(blob)
@@ -219,11 +230,11 @@ def main():
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": measured_traffic(args.workload, B, T),
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "algorithmic_hbm_bytes_per_launch": B * T * (2 * H * 4) + 2 * 4 * eng.state_floats(B),
-                         "kernel": "fe_frame_kernel", "kernel_ms": kernel_ms,
+                         "kernel": "bsrnn_frame_kernel" if w.get("bsrnn") else "fe_frame_kernel", "kernel_ms": kernel_ms,
                          "flops_per_frame": eng.flops_per_frame,
                          "hbm_frac": (B * T * (2 * H * 4) + 2 * 4 * eng.state_floats(B)) / (kernel_ms * 1e-3) / 8e12},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not w.get("bsrnn"):
             res["cpu_baseline"] = cpu_baseline(args.workload, kw, w["sr"], B, args.cpu_budget_s)
         print(json.dumps(res), flush=True)
     if world > 1:
