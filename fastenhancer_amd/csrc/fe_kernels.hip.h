@@ -173,6 +173,8 @@ struct FrameArgs {
 // 1e-7 (measured against the oracle per stage), far inside the 1e-4 waveform budget.
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// x^p for x > 0 through the 1-ulp hardware log2 / exp2 (v_log_f32, v_exp_f32); pow_f(0, p > 0) = 0
+__device__ __forceinline__ float pow_f(float x, float p) { return x > 0.0f ? __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x)) : 0.0f; }
 __device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 // Weights / tables are read through ONE buffer resource: the per-lane part of every address is the
@@ -398,8 +400,10 @@ struct Lds {
 };
 
 // ------------------------------------------------------------------------------------------
-// Complex radix-2 Stockham FFT of NFFT points over two LDS buffers; result ends in `dst`
-// returned pointer.  tw[k] = exp(-2*pi*i*k/N); inverse uses the conjugate.
+// Complex radix-2 Stockham FFT of NFFT points over two LDS buffers (autosort, no bit reversal); returns the
+// buffer that holds the result.  tw[k] = exp(-2*pi*i*k/N); INVERSE uses the conjugate.  (A radix-4 variant was
+// measured slower: its stride-4p stores are 16-way bank-conflicted for p = 1, 4 - each radix-2 stage costs
+// ~360 cycles, mostly barrier + LDS latency.)
 template <class S, bool INVERSE>
 __device__ __forceinline__ float2* fft_lds(float2* x, float2* y, const float2* tw) {
     constexpr int N = S::NFFT;
@@ -672,7 +676,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             for (int f = tid; f < F0; f += kThreads) {
                 float re = X[f].x, im = X[f].y;
                 float mag = fmaxf(sqrtf(re * re + im * im), 1.0e-5f);
-                float g = powf(mag, a.compression - 1.0f);
+                float g = pow_f(mag, a.compression - 1.0f);
                 sc[2 + f] = re * g;
                 sc[S::LDS_S + 2 + f] = im * g;
             }
@@ -681,7 +685,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             for (int f = tid; f < F0; f += kThreads) {
                 float re = sp[((size_t)f * a.T + t) * 2], im = sp[((size_t)f * a.T + t) * 2 + 1];
                 float mag = fmaxf(sqrtf(re * re + im * im), 1.0e-5f);
-                float g = powf(mag, a.compression - 1.0f);
+                float g = pow_f(mag, a.compression - 1.0f);
                 sc[2 + f] = re * g;
                 sc[S::LDS_S + 2 + f] = im * g;
             }
@@ -782,12 +786,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 for (int j = 0; j < NTPW; ++j) {
                     const int nt = wave + 4 * j;
                     const int col = 16 * nt + li;
-                    if (nt < S::NTC && col < C1) {
+                    if (nt < S::NTC && col < C1 && 16 * i + 4 * lg < F2) {   // F2 % 4 == 0: the 4 rows of a lane are valid together
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = 16 * i + 4 * lg + r;
-                            if (row < F2) Y1[row * LDC + col] = acc[i][j][r];
-                        }
+                        for (int r = 0; r < 4; ++r) Y1[(16 * i + 4 * lg + r) * LDC + col] = acc[i][j][r];
                     }
                 }
         }
@@ -816,12 +817,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     const int nt = wave + 4 * j;
                     const int col = 16 * nt + li;
                     xr[i][j] = acc[i][j];
-                    if (nt < S::NT2 && col < C2) {
+                    if (nt < S::NT2 && col < C2 && 16 * i + 4 * lg < F2) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = 16 * i + 4 * lg + r;
-                            if (row < F2) Xb[row * LDX + col] = acc[i][j][r];
-                        }
+                        for (int r = 0; r < 4; ++r) Xb[(16 * i + 4 * lg + r) * LDX + col] = acc[i][j][r];
                     }
                 }
 #pragma unroll
@@ -876,10 +874,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     if (ct < S::NT2 && c < C2) {
 #pragma unroll
                         for (int i = 0; i < S::MT2; ++i)
+                            if (16 * i + 4 * lg < F2) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int row = 16 * i + 4 * lg + r;
-                                if (row < F2) {
+                                {
                                     const float rr = sigmoid_f(ax[i][0][r] + ah[i][0][r]);
                                     const float zz = sigmoid_f(ax[i][1][r] + ah[i][1][r]);
                                     const float nn = tanh_f(ax[i][2][r] + rr * ah[i][2][r]);
@@ -888,6 +887,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                                     Hl[row * LDX + c] = hn;
                                     hg[row * C2 + c] = hn;
                                 }
+                            }
                             }
                     }
                 }
@@ -907,16 +907,13 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     for (int j = 0; j < NTPW; ++j) {
                         const int nt = wave + 4 * j;
                         const int col = 16 * nt + li;
-                        if (nt < S::NT2 && col < C2) {
+                        if (nt < S::NT2 && col < C2 && 16 * i + 4 * lg < F2) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                const int row = 16 * i + 4 * lg + r;
-                                if (row < F2) {
-                                    float v = acc[i][j][r] + xr[i][j][r];
-                                    if (k == 0) v += pe_r[i][j][r];
-                                    xr[i][j][r] = v;
-                                    Xb[row * LDX + col] = v;
-                                }
+                                float v = acc[i][j][r] + xr[i][j][r];
+                                if (k == 0) v += pe_r[i][j][r];
+                                xr[i][j][r] = v;
+                                Xb[(16 * i + 4 * lg + r) * LDX + col] = v;
                             }
                         }
                     }
@@ -935,12 +932,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll
                     for (int j = 0; j < NTPW; ++j) {
                         const int nt = wave + 4 * j;
-                        if (nt < S::NT3) {
+                        if (nt < S::NT3 && 16 * i + 4 * lg < F2) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = 16 * i + 4 * lg + r;
-                                if (row < F2) Gi[row * LDG + 16 * nt + li] = acc[i][j][r];
-                            }
+                            for (int r = 0; r < 4; ++r) Gi[(16 * i + 4 * lg + r) * LDG + 16 * nt + li] = acc[i][j][r];
                         }
                     }
             }
@@ -1060,15 +1054,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     for (int j = 0; j < NTPW; ++j) {
                         const int nt = wave + 4 * j;
                         const int col = 16 * nt + li;
-                        if (nt < S::NT2 && col < C2) {
+                        if (nt < S::NT2 && col < C2 && 16 * i + 4 * lg < F2) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                const int row = 16 * i + 4 * lg + r;
-                                if (row < F2) {
-                                    const float v = acc[i][j][r] + xr[i][j][r];
-                                    xr[i][j][r] = v;
-                                    Xb[row * LDX + col] = v;
-                                }
+                                const float v = acc[i][j][r] + xr[i][j][r];
+                                xr[i][j][r] = v;
+                                Xb[(16 * i + 4 * lg + r) * LDX + col] = v;
                             }
                         }
                     }
@@ -1207,7 +1198,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     sph[((size_t)f * a.T + t) * 2 + 1] = yi;
                 }
                 const float mag = sqrtf(yr * yr + yi * yi);
-                const float g = powf(mag, 1.0f / a.compression - 1.0f);
+                const float g = pow_f(mag, 1.0f / a.compression - 1.0f);
                 yr *= g; yi *= g;
                 if (a.dbg) {
                     float* dst = a.dbg + (size_t)b * a.dbg_stride + DebugLayout<S>::offset(6 + 2 * S::NL + 2 * S::KB);
