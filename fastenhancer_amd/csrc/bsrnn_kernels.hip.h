@@ -36,7 +36,7 @@ struct BOffsets {
     int bs_b;                  // [31][C]
     int t_w[8], t_b[8];        // time LSTM: B fragments, K = C + HH (x rows then h rows), N = 4*HH ; bias b_ih + b_hh
     int tfc_w[8], tfc_b[8];    // fc_time: B fragments K = HH, N = C
-    int f_wih[8][2], f_b[8][2], f_whh[8][2];   // band LSTM per direction: B fragments K = C, N = 4HH; bias; raw W_hh [4HH][HH]
+    int f_wih[8][2], f_b[8][2], f_whh[8][2];   // band LSTM per direction: B fragments K = C, N = 4HH; bias; W_hh as [rr][k][q] (thread order)
     int ffc_w[8], ffc_b[8];    // fc_freq: B fragments K = 2HH, N = C
     int m_w1[2], m_b1[2];      // mask decoder layer 1 per kind: [31][C][4C] (k-major), [31][4C]
     int m_w2[2], m_b2[2];      // layer 2 per kind: [4C][1028] (k-major over the global row index), [1028]
@@ -70,7 +70,7 @@ struct BLds {
     static constexpr int HN = HS + 32 * S::LDH;               // [32][LDH] new h (A operand of fc_time)
     static constexpr int XP = HN + 32 * S::LDH;               // [2][32][LDP] band-LSTM input projections
     static constexpr int YF = XP + 2 * 32 * S::LDP;           // [32][LDY] band-LSTM outputs (fwd | bwd)
-    static constexpr int HB = YF + 32 * S::LDY;               // [2 dirs][2 buffers][HH]
+    static constexpr int HB = (YF + 32 * S::LDY + 3) / 4 * 4;   // [2 dirs][2 buffers][HH], 16-byte aligned (float4 broadcast reads)
     static constexpr int H1 = HB + 4 * S::HH;                 // [2 kinds][31][4C]
     static constexpr int TOTAL = H1 + 2 * kBands * 4 * S::C;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             float2* Xf = fft_lds<S, false>(fa, fb, tw);
             for (int f = tid; f < kBins; f += kThreads) {
                 const float re = Xf[f].x, im = Xf[f].y;
-                const float g = powf(fmaxf(sqrtf(re * re + im * im), 1.0e-5f), a.compression - 1.0f);
+                const float g = pow_f(fmaxf(sqrtf(re * re + im * im), 1.0e-5f), a.compression - 1.0f);
                 sp[2 * f] = re * g;
                 sp[2 * f + 1] = im * g;
             }
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             const float* si = a.spec_in + (size_t)b * kBins * a.T * 2;
             for (int f = tid; f < kBins; f += kThreads) {
                 const float re = si[((size_t)f * a.T + t) * 2], im = si[((size_t)f * a.T + t) * 2 + 1];
-                const float g = powf(fmaxf(sqrtf(re * re + im * im), 1.0e-5f), a.compression - 1.0f);
+                const float g = pow_f(fmaxf(sqrtf(re * re + im * im), 1.0e-5f), a.compression - 1.0f);
                 sp[2 * f] = re * g;
                 sp[2 * f + 1] = im * g;
             }
@@ -271,9 +271,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll
             for (int rr = 0; rr < S::RPT; ++rr) {
                 const int j = (q >> 2) + 32 * rr;
-                const float* wr = wp + o.f_whh[l][d] + (gate * HH + j) * HH;
+                const float* wr = wp + o.f_whh[l][d] + rr * HH * (kThreads / 2) + q;   // [rr][k][q]: coalesced over the threads
 #pragma unroll
-                for (int k = 0; k < HH; ++k) wrow[rr][k] = wr[k];
+                for (int k = 0; k < HH; ++k) wrow[rr][k] = wr[k * (kThreads / 2)];
+                (void)j;
                 cstate[rr] = 0.0f;
             }
             if (tid < 4 * HH) Hb[tid] = 0.0f;                    // h = 0 for both directions, both buffers
@@ -287,12 +288,19 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 for (int rr = 0; rr < S::RPT; ++rr) {
                     const int j = (q >> 2) + 32 * rr;
                     float pre = XP[(d * 32 + band) * LDP + gate * HH + j];
+                    const float4* hp4 = reinterpret_cast<const float4*>(hprev);      // broadcast reads, 16 B each
 #pragma unroll
-                    for (int k = 0; k < HH; ++k) pre += wrow[rr][k] * hprev[k];
+                    for (int k = 0; k < HH / 4; ++k) {
+                        const float4 hv = hp4[k];
+                        pre += wrow[rr][4 * k] * hv.x + wrow[rr][4 * k + 1] * hv.y + wrow[rr][4 * k + 2] * hv.z + wrow[rr][4 * k + 3] * hv.w;
+                    }
                     const float act = gate == 2 ? tanh_f(pre) : sigmoid_f(pre);
-                    const int base = lane & ~3;
-                    const float ig = __shfl(act, base + 0), fg = __shfl(act, base + 1);
-                    const float gg = __shfl(act, base + 2), og = __shfl(act, base + 3);
+                    // the 4 gates of a unit sit in one quad: DPP quad_perm broadcasts (no LDS crossbar)
+                    const int ai = __builtin_bit_cast(int, act);
+                    const float ig = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, ai, 0x00, 0xf, 0xf, true));
+                    const float fg = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, ai, 0x55, 0xf, 0xf, true));
+                    const float gg = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, ai, 0xaa, 0xf, 0xf, true));
+                    const float og = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, ai, 0xff, 0xf, 0xf, true));
                     const float cn = fg * cstate[rr] + ig * gg;
                     cstate[rr] = cn;
                     if (gate == 0) {
@@ -331,41 +339,45 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             const int bb = rem / (4 * C), oo = rem - bb * (4 * C);
             const float* w = wp + o.m_w1[kind] + (bb * C) * (4 * C) + oo;
             float acc = wp[o.m_b1[kind] + bb * 4 * C + oo];
-#pragma unroll 4
+#pragma unroll 16
             for (int k = 0; k < C; ++k) acc += w[k * 4 * C] * X[bb * LDX + k];
             H1[i] = tanhf(acc);
         }
         __syncthreads();
         {
             constexpr int R = 4 * kBins;            // rows of the second layers (1028)
+            // item = (bin f, kind): GLU outputs (re, im) of that MLP for that bin -> MR[f][kind*2 + ri]  (reuses XP)
+            float* MR = XP;
+            for (int it = tid; it < 2 * kBins; it += kThreads) {
+                const int kind = it / kBins, f = it - kind * kBins;
+                int s0, sub;
+                const int bb = band_of(f, s0, sub);
+                const float* h1 = H1 + (kind * kBands + bb) * 4 * C;
+                const float* w2 = wp + o.m_w2[kind];
+                const int rowA0 = 4 * s0 + (f - s0) * 2, rowB0 = rowA0 + 2 * sub;
+                float va0 = wp[o.m_b2[kind] + rowA0], va1 = wp[o.m_b2[kind] + rowA0 + 1];
+                float vb0 = wp[o.m_b2[kind] + rowB0], vb1 = wp[o.m_b2[kind] + rowB0 + 1];
+#pragma unroll 16
+                for (int k = 0; k < 4 * C; ++k) {
+                    const float hv = h1[k];
+                    va0 += w2[k * R + rowA0] * hv;
+                    va1 += w2[k * R + rowA0 + 1] * hv;
+                    vb0 += w2[k * R + rowB0] * hv;
+                    vb1 += w2[k * R + rowB0 + 1] * hv;
+                }
+                MR[f * 4 + kind * 2 + 0] = va0 * (1.0f / (1.0f + expf(-vb0)));      // GLU(dim=1)
+                MR[f * 4 + kind * 2 + 1] = va1 * (1.0f / (1.0f + expf(-vb1)));
+            }
+            __syncthreads();
             float* spo = mode == FE_MODE_SPEC ? a.spec_out + (size_t)b * kBins * a.T * 2 : nullptr;
             float* sph = mode == FE_MODE_OFFLINE ? a.spec_out + (size_t)b * kBins * a.T * 2 : nullptr;
             for (int f = tid; f < kBins; f += kThreads) {
-                int s0, sub;
-                const int bb = band_of(f, s0, sub);
-                float mr[2][2];     // [kind][re/im]
-#pragma unroll
-                for (int kind = 0; kind < 2; ++kind)
-#pragma unroll
-                    for (int ri = 0; ri < 2; ++ri) {
-                        const int idx = (f - s0) * 2 + ri;
-                        const int rowA = 4 * s0 + idx, rowB = rowA + 2 * sub;
-                        float va = wp[o.m_b2[kind] + rowA], vb = wp[o.m_b2[kind] + rowB];
-                        const float* h1 = H1 + (kind * kBands + bb) * 4 * C;
-                        const float* w2 = wp + o.m_w2[kind];
-#pragma unroll 4
-                        for (int k = 0; k < 4 * C; ++k) {
-                            const float hv = h1[k];
-                            va += w2[k * R + rowA] * hv;
-                            vb += w2[k * R + rowB] * hv;
-                        }
-                        mr[kind][ri] = va * (1.0f / (1.0f + expf(-vb)));        // GLU(dim=1)
-                    }
                 const float xr = sp[2 * f], xi = sp[2 * f + 1];
-                float yr = xr * mr[0][0] - xi * mr[0][1] + mr[1][0];             // spec * mask + residual (:393-401)
-                float yi = xr * mr[0][1] + xi * mr[0][0] + mr[1][1];
+                const float* mr = MR + f * 4;
+                float yr = xr * mr[0] - xi * mr[1] + mr[2];             // spec * mask + residual (:393-401)
+                float yi = xr * mr[1] + xi * mr[0] + mr[3];
                 if (sph != nullptr) { sph[((size_t)f * a.T + t) * 2] = yr; sph[((size_t)f * a.T + t) * 2 + 1] = yi; }
-                const float g = powf(sqrtf(yr * yr + yi * yi), 1.0f / a.compression - 1.0f);
+                const float g = pow_f(sqrtf(yr * yr + yi * yi), 1.0f / a.compression - 1.0f);
                 yr *= g;
                 yi *= g;
                 if (mode == FE_MODE_SPEC) {

@@ -386,8 +386,17 @@ int pack_weights_bsrnn(fe_handle* h, const std::vector<float>& blob, std::vector
             const float* bh = S(keyd("bias_hh"));
             o.f_b[l][d] = alloc(G4);
             for (int i = 0; i < G4; ++i) buf[o.f_b[l][d] + i] = bi[i] + bh[i];
-            o.f_whh[l][d] = alloc((size_t)G4 * HH);
-            memcpy(&buf[o.f_whh[l][d]], S(keyd("weight_hh")), (size_t)G4 * HH * sizeof(float));
+            {   // recurrence weights in thread order: thread q = 4*(j%32) + gate holds rows (gate, j = q/4 + 32*rr)
+                const float* whh = S(keyd("weight_hh"));      // (4HH, HH), gate-major rows
+                o.f_whh[l][d] = alloc((size_t)G4 * HH);
+                const int RPT = G4 / 128;
+                for (int rr = 0; rr < RPT; ++rr)
+                    for (int k = 0; k < HH; ++k)
+                        for (int q = 0; q < 128; ++q) {
+                            const int gate = q & 3, j = (q >> 2) + 32 * rr;
+                            buf[o.f_whh[l][d] + ((size_t)rr * HH + k) * 128 + q] = whh[(size_t)(gate * HH + j) * HH + k];
+                        }
+            }
         }
         {
             const float* w = S(key("fc_freq.%d.weight"));         // (C, 2HH)
