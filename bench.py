@@ -141,7 +141,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the FastEnhancer HIP path has no CPU fallback")
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # launched by torch.distributed.run
+    if use_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus or world == 1, (world, args.gpus)
 
@@ -194,7 +195,7 @@ def main():
 
     run(args.warmup, 0)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -203,12 +204,12 @@ def main():
     run(args.steps, args.warmup)
     ev1.record(stream)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps    # HIP events on the launch stream: avg per launch
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, kernel_ms = float(tt[0]), float(tt[1])
@@ -227,7 +228,7 @@ def main():
                                    f"{T} hop(s) per stream per step, wav->wav streaming step with STFT/iSTFT and GRU caches",
                        "streams_per_gpu": B, "frames_per_step": T, "parallelism": f"streams sharded dp{world}, RCCL weight broadcast",
                        "weights": "seeded random checkpoint (no trained weights offline), BN/weight-norm folded"},
-            "rtf_per_stream": dt * w["sr"] / (args.steps * T * H * B * world) * world,
+            "rtf_per_stream": dt * w["sr"] / (args.steps * T * H * B * world),   # amortised: wall time / audio time / streams
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": measured_traffic(args.workload, B, T),
                          "algorithmic_flops_per_launch": flops_per_launch,
@@ -239,7 +240,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not w.get("bsrnn"):
             res["cpu_baseline"] = cpu_baseline(args.workload, kw, w["sr"], B, args.cpu_budget_s)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

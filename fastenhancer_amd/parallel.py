@@ -21,7 +21,7 @@ def shard_range(n_streams: int, world: int, rank: int) -> Tuple[int, int]:
 
 def broadcast_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
     """ncclBroadcast of the flat fp32 weight blob (<= 4.4 MB: latency-bound)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.broadcast(blob, src=src)
     return blob
 
