@@ -89,6 +89,7 @@ struct PackedOffsets {
     int enc_w[8], enc_b[8];
     int rfpre_lin, rfpre_w, rfpre_b;
     int blk_pe;                        // block 0 only, [F2][C2]
+    int blk_stride;                    // offset of block k+1's arrays minus block k's
     int blk_wih[8], blk_bih[8], blk_whh[8], blk_bhh[8];
     int blk_fc1_w[8], blk_fc1_b[8], blk_qkv[8], blk_fc2_w[8], blk_fc2_b[8];
     int rfpost_lin, rfpost_w, rfpost_b;
@@ -128,16 +129,17 @@ struct Pack {
         ubegin(); o.post_t_w = alloc(szB(C1, 16)); o.post_t_b = alloc(szBias(2)); uend();
         o.n_units = nu;
         // RNNFormer-block weights: read by each wave straight into registers (not staged)
-        for (int k = 0; k < S::KB; ++k) {
+        o.blk_pe = alloc(F2 * C2);
+        for (int k = 0; k < S::KB; ++k) {      // identical sizes per block: the offsets advance by blk_stride
             // GRU weights packed per gate (r, z, n): tile index = gate * NT2 + channel-tile, so that the three
             // gate pre-activations of one (row, channel) land in the same lane and the gates fuse into the epilogue
             o.blk_wih[k] = alloc(3 * szB(C2, C2)); o.blk_whh[k] = alloc(3 * szB(C2, C2));
             o.blk_bih[k] = alloc(3 * szBias(C2)); o.blk_bhh[k] = alloc(3 * szBias(C2));
             o.blk_fc1_w[k] = alloc(szB(C2, C2)); o.blk_fc1_b[k] = alloc(szBias(C2));
-            if (k == 0) o.blk_pe = alloc(F2 * C2);
             o.blk_qkv[k] = alloc(szB(C2, 3 * C2));
             o.blk_fc2_w[k] = alloc(szB(C2, C2)); o.blk_fc2_b[k] = alloc(szBias(C2));
         }
+        o.blk_stride = S::KB > 1 ? o.blk_wih[1] - o.blk_wih[0] : 0;
         o.window = alloc(S::NFFT); o.window_istft = alloc(S::NFFT); o.twiddle = alloc(S::NFFT);
         o.total = round_up(cur, 64);
         return o;
@@ -236,8 +238,17 @@ __device__ __forceinline__ void dma_one(DmaJob& j) {
 __device__ __forceinline__ void dma_rest(DmaJob& j) {
     while (j.p * 256 < j.n) dma_one(j);
 }
-struct NoSide { __device__ __forceinline__ void operator()() const {} };
-struct DmaSide { DmaJob* j; __device__ __forceinline__ void operator()() const { dma_one(*j); } };
+// `side(g, NG)`: a job run once per k-group g of a GEMM's software pipeline, in the matrix pipe's shadow
+struct NoSide { __device__ __forceinline__ void operator()(int, int) const {} };
+struct DmaSide { DmaJob* j; __device__ __forceinline__ void operator()(int, int) const { dma_one(*j); } };
+// fetch a slice of one / two TokW register sets per k-group (the next phase's weights)
+template <class TW>
+struct FetchSide { TW* w; __device__ __forceinline__ void operator()(int g, int ng) const { w->fetch_part(g, ng); } };
+template <class TA, class TB>
+struct FetchSide2 {
+    TA* a; TB* b;
+    __device__ __forceinline__ void operator()(int g, int ng) const { a->fetch_part(g, ng); b->fetch_part(g, ng); }
+};
 
 // Software-pipelined: operands are fetched in groups of G k-steps, D groups ahead of the MFMAs
 // that consume them; sched_barrier(0) pins "loads of group g+D before MFMAs of group g", so the
@@ -267,7 +278,7 @@ __device__ __forceinline__ void mma_panel(f32x4 (&acc)[MTP][NTP], AF&& af, BF&& 
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         if (g + D < NG) load_group(g + D, (g + D) % (D + 1));
-        side();
+        side(g, NG);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < G; ++kk) {
@@ -505,18 +516,29 @@ struct TokW {
         ct = ct < NT ? ct : NT - 1;
         return g * NT + ct;
     }
-    __device__ __forceinline__ void fetch(const WS& s, int w_off_, int b_off_, int NT_, int wave_) {
+    __device__ __forceinline__ void bind(const WS& s, int w_off_, int b_off_, int NT_, int wave_) {
         src = &s; w_off = w_off_; b_off = b_off_; NT = NT_; wave = wave_;
+    }
+    // element e of the flattened register set [NTPW][NG][KS + 1] (the +1 is the bias)
+    __device__ __forceinline__ void fetch_elem(int e) {
+        const int j = e / (NG * (KS + 1)), r = e - j * (NG * (KS + 1));
+        const int g = r / (KS + 1), ks = r - g * (KS + 1);
+        if (ks == KS) bv[j][g] = b_off >= 0 ? src->at16_g(b_off + tile(j, g) * 16) : 0.0f;
+        else w[j][g][ks] = src->at_g(w_off + (tile(j, g) * KS + ks) * 64);
+    }
+    // slice `part` of `parts` (all indices are compile-time constants once the caller's loops are unrolled)
+    __device__ __forceinline__ void fetch_part(int part, int parts) {
         if constexpr (REG) {
+            constexpr int TOT = NTPW * NG * (KS + 1);
+            const int per = (TOT + parts - 1) / parts;
 #pragma unroll
-            for (int j = 0; j < NTPW; ++j)
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    bv[j][g] = b_off >= 0 ? s.at16_g(b_off + tile(j, g) * 16) : 0.0f;
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) w[j][g][ks] = s.at_g(w_off + (tile(j, g) * KS + ks) * 64);
-                }
+            for (int q = 0; q < TOT; ++q)
+                if (q >= part * per && q < (part + 1) * per) fetch_elem(q);
         }
+    }
+    __device__ __forceinline__ void fetch(const WS& s, int w_off_, int b_off_, int NT_, int wave_) {
+        bind(s, w_off_, b_off_, NT_, wave_);
+        fetch_part(0, 1);
     }
     __device__ __forceinline__ float get(int j, int g, int ks) const {
         if constexpr (REG) return w[j][g][ks];
@@ -529,8 +551,8 @@ struct TokW {
 };
 
 // acc = bias + A(LDS tokens) x W  for this wave's column tiles
-template <class S, int NTPW, int KS, int LDA, class TW>
-__device__ __forceinline__ void tok_gemm_w(f32x4 (&acc)[S::MT2][NTPW], const float* a_lane, const TW& W) {
+template <class S, int NTPW, int KS, int LDA, class TW, class SIDE = NoSide>
+__device__ __forceinline__ void tok_gemm_w(f32x4 (&acc)[S::MT2][NTPW], const float* a_lane, const TW& W, SIDE side = SIDE{}) {
 #pragma unroll
     for (int j = 0; j < NTPW; ++j) {
         const float bj = W.bias(j, 0);
@@ -538,7 +560,7 @@ __device__ __forceinline__ void tok_gemm_w(f32x4 (&acc)[S::MT2][NTPW], const flo
         for (int i = 0; i < S::MT2; ++i) acc[i][j] = f32x4{bj, bj, bj, bj};
     }
     mma_panel<S::MT2, NTPW, KS>(
-        acc, [&](int i, int ks) { return a_lane[(16 * i) * LDA + 4 * ks]; }, [&](int j, int ks) { return W.get(j, 0, ks); }, NoSide{});
+        acc, [&](int i, int ks) { return a_lane[(16 * i) * LDA + 4 * ks]; }, [&](int j, int ks) { return W.get(j, 0, ks); }, side);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -833,16 +855,17 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 
         FE_CLK(6);
         // =========================== RNNFormer blocks (a9-a11) ===========================
-        static_for<S::KB>([&](auto k_) {
-            constexpr int k = decltype(k_)::value;
+#pragma unroll 1
+        for (int k = 0; k < S::KB; ++k) {      // (not unrolled: keeps register pressure and code size down)
             float* hg = a.h + ((size_t)k * a.B + b) * (F2 * C2);
+            const int kb = k * o.blk_stride;
             if (k == 0) FE_CLK(20);
             {
                 // GRU (nn.GRU gate order r,z,n; model.py:187,271), gates fused into the GEMM epilogue:
                 //   ax[.][g] = x W_i{g}^T + b_i{g},  ah[.][g] = h W_h{g}^T + b_h{g}   for this wave's channel tiles
                 //   r = s(ax0+ah0), z = s(ax1+ah1), n = tanh(ax2 + r*ah2), h' = (1-z) n + z h
                 // prefetch for the next phase: rnn_fc weights (+ the positional embedding in block 0)
-                Wf1.fetch(wb, o.blk_fc1_w[k], o.blk_fc1_b[k], S::NT2, wave);
+                Wf1.bind(wb, (o.blk_fc1_w[0] + kb), (o.blk_fc1_b[0] + kb), S::NT2, wave);   // fetched inside the GEMM below
                 if (k == 0) {
 #pragma unroll
                     for (int i = 0; i < S::MT2; ++i)
@@ -866,7 +889,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     }
                     mma_panel<S::MT2, 3, S::KS_2>(
                         ax, [&](int i, int ks) { return Xb[(16 * i + li) * LDX + lg + 4 * ks]; },
-                        [&](int g, int ks) { return Wgi.get(j, g, ks); }, NoSide{});
+                        [&](int g, int ks) { return Wgi.get(j, g, ks); }, FetchSide<decltype(Wf1)>{&Wf1});
                     mma_panel<S::MT2, 3, S::KS_2>(
                         ah, [&](int i, int ks) { return Hs[(16 * i + li) * LDX + lg + 4 * ks]; },
                         [&](int g, int ks) { return Wgh.get(j, g, ks); }, NoSide{});
@@ -898,9 +921,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             {
                 // x += rnn_fc(h') (+ pe in block 0)
                 constexpr int NTPW = NTPW2;
-                Wq.fetch(wb, o.blk_qkv[k], -1, S::NT3, wave);      // for the next phase
+                Wq.bind(wb, (o.blk_qkv[0] + kb), -1, S::NT3, wave);      // for the next phase, fetched inside the GEMM
                 f32x4 acc[S::MT2][NTPW];
-                tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf1);
+                tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf1, FetchSide<decltype(Wq)>{&Wq});
 #pragma unroll
                 for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -924,9 +947,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             {
                 // qkv = x W_qkv^T  -> Gi (rows per head interleaved [h][q|k|v][hd])
                 constexpr int NTPW = NTPW3;
-                Wf2.fetch(wb, o.blk_fc2_w[k], o.blk_fc2_b[k], S::NT2, wave);     // for attn_fc
+                Wf2.bind(wb, (o.blk_fc2_w[0] + kb), (o.blk_fc2_b[0] + kb), S::NT2, wave);     // for attn_fc, fetched inside the GEMM
                 f32x4 acc[S::MT2][NTPW];
-                tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Xb + li * LDX + lg, Wq);
+                tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Xb + li * LDX + lg, Wq, FetchSide<decltype(Wf2)>{&Wf2});
 #pragma unroll
                 for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -1033,14 +1056,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 constexpr int NTPW = ceil_div(S::NT2, kWaves);
                 float hpre[HPT];
                 if (k + 1 < S::KB) {   // next block: GRU weights into registers, hidden state fetched now / parked after the GEMM
-                    Wgi.fetch(wb, o.blk_wih[k + 1], o.blk_bih[k + 1], S::NT2, wave);
-                    Wgh.fetch(wb, o.blk_whh[k + 1], o.blk_bhh[k + 1], S::NT2, wave);
+                    Wgi.bind(wb, (o.blk_wih[0] + kb + o.blk_stride), (o.blk_bih[0] + kb + o.blk_stride), S::NT2, wave);     // fetched inside the GEMM below
+                    Wgh.bind(wb, (o.blk_whh[0] + kb + o.blk_stride), (o.blk_bhh[0] + kb + o.blk_stride), S::NT2, wave);
                     const float* hgn = hg + (size_t)a.B * (F2 * C2);
 #pragma unroll
                     for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = i < F2 * C2 ? hgn[i] : 0.0f; }
                 }
                 f32x4 acc[S::MT2][NTPW];
-                tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf2);
+                if (k + 1 < S::KB) tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf2, FetchSide2<decltype(Wgi), decltype(Wgh)>{&Wgi, &Wgh});
+                else tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf2);
                 if (k + 1 < S::KB) {
 #pragma unroll
                     for (int q = 0; q < HPT; ++q) {
@@ -1067,7 +1091,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             __syncthreads();
             if (k == 0) FE_CLK(26);
             dbg_dump<S>(a, b, 5 + S::NL + 2 * k, Xb, LDX);
-        });
+        }
 
         FE_CLK(7);
         // =========================== rf_post (a13) ===========================
