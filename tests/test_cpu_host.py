@@ -164,3 +164,15 @@ def test_cli_host_logic(tmp_path):
     np.testing.assert_allclose(read_wav(str(tmp_path / "b.wav"), 16000), x, atol=1e-4)
     with pytest.raises(ValueError, match="sampling rate"):
         read_wav(str(tmp_path / "a.wav"), 48000)
+
+
+def test_si_sdr_matches_oracle_restatement():
+    from fastenhancer_amd.metrics import si_snr
+    from oracle.fe_oracle import si_sdr
+    rng = np.random.default_rng(0)
+    clean = rng.standard_normal((3, 4000)).astype(np.float32)
+    est = clean + 0.1 * rng.standard_normal((3, 4000)).astype(np.float32)
+    a = si_snr(torch.from_numpy(est), torch.from_numpy(clean)).numpy()
+    b = si_sdr(clean, est)
+    np.testing.assert_allclose(a, b, rtol=1e-9)
+    assert 15 < a.mean() < 25

@@ -343,3 +343,20 @@ def test_bsrnn_batch_and_chunk_vs_oracle(name):
     ref_spec, _ = orc.spec_forward(spec, [np.zeros((B * cfg.n_bands, cfg.hidden), np.float32) for _ in range(2 * cfg.num_layers)])
     got, *_ = m(torch.from_numpy(spec).to(_dev()), *m.initialize_cache(torch.zeros(B, 1, device=_dev())))
     _assert_close(got.cpu().numpy(), ref_spec, "bsrnn spec chunk")
+
+
+def test_si_sdr_of_hip_path_equals_oracle_path_to_2dp():
+    """north_star: SI-SDR identical to 2 d.p. between the HIP path and the reference path (here: its pinned oracle),
+    measured against a synthetic clean target."""
+    from fastenhancer_amd.metrics import si_snr
+    from fastenhancer_amd.streaming import enhance_stream
+    m, orc, cfg, sr, seed = _model("fe_b")
+    rng = np.random.default_rng(5)
+    t = np.arange(3 * sr // 4) / sr
+    clean = (0.3 * np.sin(2 * np.pi * 220 * t)[None] * np.ones((2, 1))).astype(np.float32)
+    noisy = np.clip(clean + 0.1 * rng.standard_normal(clean.shape).astype(np.float32), -1, 1)
+    y_gpu = enhance_stream(m, torch.from_numpy(noisy)).cpu()
+    y_ref = torch.from_numpy(orc.enhance_stream(noisy))
+    s_gpu, s_ref = si_snr(y_gpu, torch.from_numpy(clean)), si_snr(y_ref, torch.from_numpy(clean))
+    assert torch.all((s_gpu - s_ref).abs() < 5e-3), (s_gpu, s_ref)
+    assert [round(float(v), 2) for v in s_gpu] == [round(float(v), 2) for v in s_ref] or torch.all((s_gpu - s_ref).abs() < 1e-3)
