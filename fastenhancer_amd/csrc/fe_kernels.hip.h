@@ -216,31 +216,39 @@ struct WSrc {
     }
 };
 
-// Asynchronous global -> LDS copy of one weight unit (n floats, multiple of 256) in 1-KiB
-// global_load_lds_dwordx4 pieces (LDS destination = wave-uniform base + lane*16); wave w moves pieces
-// w, w+4, ...  Issuing a piece costs ~60-100 cycles of the wave's issue slot, so the pieces are
-// handed out one per k-group from inside the MFMA loop (mma_panel's `side`), where they hide in the
-// matrix pipe's shadow; dma_rest() issues whatever is left.  Completion is covered by the vmcnt(0)
-// that __syncthreads() carries while an LDS-DMA is in flight.
-struct DmaJob {
-    const float* g;   // + lane*4 already applied
-    float* l;
-    int n;            // floats
-    int p;            // next piece of this wave
+// Staging of one weight unit (n floats, multiple of 256) from L2 into an LDS buffer, one GEMM phase ahead, in 1-KiB
+// pieces (wave w moves pieces w, w+4, ...).  Each piece is a buffer_load_dwordx4 into registers issued when the
+// previous phase starts (stage_begin) and a ds_write_b128 issued after that phase's GEMM (dma_rest): the L2 latency
+// hides behind the GEMM and the two instructions cost ~25 issue cycles per piece.  (The LDS-DMA form,
+// global_load_lds_dwordx4, was measured at ~130 issue cycles per piece inside the MFMA loop - 12 % of the frame -
+// and makes every __syncthreads() drain it.)
+template <int NPW>
+struct DmaJobT {
+    f32x4 r[NPW];     // this wave's pieces in flight
+    float* l;         // LDS destination of the unit
+    int npieces;      // 1-KiB pieces of the unit (0: nothing to stage)
+    int wave, lane;
 };
-__device__ __forceinline__ void dma_one(DmaJob& j) {
-    if (j.p * 256 < j.n) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(j.g + j.p * 256),
-                                         (__attribute__((address_space(3))) void*)(j.l + j.p * 256), 16, 0, 0);
+template <int NPW>
+__device__ __forceinline__ void stage_begin(DmaJobT<NPW>& j, __amdgpu_buffer_rsrc_t rsrc, int unit_off_floats) {
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int p = j.wave + kWaves * i;
+        if (p < j.npieces)
+            j.r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, j.lane * 16, (unit_off_floats + p * 256) * 4, 0));
     }
-    j.p += kWaves;
 }
-__device__ __forceinline__ void dma_rest(DmaJob& j) {
-    while (j.p * 256 < j.n) dma_one(j);
+template <int NPW>
+__device__ __forceinline__ void dma_rest(DmaJobT<NPW>& j) {      // commit the staged pieces to LDS
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int p = j.wave + kWaves * i;
+        if (p < j.npieces) *reinterpret_cast<f32x4*>(j.l + p * 256 + j.lane * 4) = j.r[i];
+    }
+    j.npieces = 0;
 }
 // `side(g, NG)`: a job run once per k-group g of a GEMM's software pipeline, in the matrix pipe's shadow
 struct NoSide { __device__ __forceinline__ void operator()(int, int) const {} };
-struct DmaSide { DmaJob* j; __device__ __forceinline__ void operator()(int, int) const { dma_one(*j); } };
 // fetch a slice of one / two TokW register sets per k-group (the next phase's weights)
 template <class TW>
 struct FetchSide { TW* w; __device__ __forceinline__ void operator()(int g, int ng) const { w->fetch_part(g, ng); } };
@@ -250,12 +258,64 @@ struct FetchSide2 {
     __device__ __forceinline__ void operator()(int g, int ng) const { a->fetch_part(g, ng); b->fetch_part(g, ng); }
 };
 
-// Software-pipelined: operands are fetched in groups of G k-steps, D groups ahead of the MFMAs
-// that consume them; sched_barrier(0) pins "loads of group g+D before MFMAs of group g", so the
-// compiler's counted s_waitcnt leaves >= D*G*MTP*NTP MFMAs (32 cycles each) of cover over the L2
-// latency of the weight fetch.  (Left alone, hipcc sinks every load next to its MFMA.)
+// Software-pipelined MFMA panel.  Operands of k-step ks+PD are fetched while k-step ks is multiplied (ring of PD
+// k-steps in registers), and the instruction stream is pinned with sched_group_barrier so that the fetches issue
+// one or two at a time right AFTER an MFMA - in the 32-cycle shadow of the matrix pipe - instead of in blocks
+// between MFMA groups (measured on the k=3 conv: 47 -> ~34 cycles per MFMA).  Left alone, hipcc sinks every
+// load next to its consumer and the loop runs at operand latency.
+// The fine-grained form is used for panels of up to 128 MFMAs (the scheduler's group solver makes hipcc's
+// compile time explode beyond that: FastEnhancer_L did not finish in an hour); larger panels use the group-blocked
+// form (operand groups two ahead, pinned with sched_barrier(0)).
 template <int MTP, int NTP, int KS, typename AF, typename BF, typename SIDE>
 __device__ __forceinline__ void mma_panel(f32x4 (&acc)[MTP][NTP], AF&& af, BF&& bf, SIDE&& side) {
+  if constexpr (KS * MTP * NTP <= 128) {
+    constexpr int PD = KS < 8 ? KS : 8;              // prefetch distance in k-steps
+    constexpr int NSG = (KS + 3) / 4;                // side-job slots (one per 4 k-steps)
+    float a[PD][MTP], b[PD][NTP];
+#pragma unroll
+    for (int ks = 0; ks < PD; ++ks) {
+#pragma unroll
+        for (int i = 0; i < MTP; ++i) a[ks][i] = af(i, ks);
+#pragma unroll
+        for (int j = 0; j < NTP; ++j) b[ks][j] = bf(j, ks);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        float av[MTP], bv[NTP];
+#pragma unroll
+        for (int i = 0; i < MTP; ++i) av[i] = a[ks % PD][i];
+#pragma unroll
+        for (int j = 0; j < NTP; ++j) bv[j] = b[ks % PD][j];
+        if (ks + PD < KS) {
+#pragma unroll
+            for (int i = 0; i < MTP; ++i) a[ks % PD][i] = af(i, ks + PD);
+#pragma unroll
+            for (int j = 0; j < NTP; ++j) b[ks % PD][j] = bf(j, ks + PD);
+        }
+        if ((ks & 3) == 0) side(ks >> 2, NSG);
+#pragma unroll
+        for (int i = 0; i < MTP; ++i)
+#pragma unroll
+            for (int j = 0; j < NTP; ++j) acc[i][j] = FE_MFMA(av[i], bv[j], acc[i][j]);
+    }
+    // instruction-stream shape: [prologue fetches] then per k-step { MFMA, fetch, fetch, MFMA, fetch, ... }
+    constexpr int LOADS = 0x100 | 0x020;             // DS read | VMEM read
+    constexpr int NM = MTP * NTP, NL = MTP + NTP;
+    __builtin_amdgcn_sched_group_barrier(LOADS, PD * NL, 0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            // distribute this k-step's NL fetches over its NM MFMAs
+            const int lo = (m * NL) / NM, hi = ((m + 1) * NL) / NM;
+            if (ks + PD < KS) {
+#pragma unroll
+                for (int q = lo; q < hi; ++q) __builtin_amdgcn_sched_group_barrier(LOADS, 1, 0);
+            }
+        }
+    }
+  } else {
     constexpr int G = (MTP * NTP >= 6) ? 2 : 4;      // k-steps per group
     constexpr int D = 2;                             // prefetch distance in groups
     constexpr int NG = (KS + G - 1) / G;
@@ -292,6 +352,7 @@ __device__ __forceinline__ void mma_panel(f32x4 (&acc)[MTP][NTP], AF&& af, BF&& 
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+  }
 }
 
 template <int MTP, int NTP>
@@ -442,23 +503,23 @@ __device__ __forceinline__ float2* fft_lds(float2* x, float2* y, const float2* t
 // conv-layout GEMM segment: this wave's m-tiles (wave + 4*i) x all NT n-tiles, K = 4*KS.
 //   a_lane : LDS pointer to A[(16*wave + (lane&15)) rows][(lane>>4) col] of the segment
 //   w_lane : packed weights + lane, at k-step 0 of this segment;  KS_TOT = k-steps per n-tile
-template <class S, int NT, int KS, int KS_TOT, int LDA, class WS>
-__device__ __forceinline__ void conv_seg(f32x4 (&acc)[S::MTPW][NT], const float* a_lane, const WS& w, int w_off, DmaJob& job) {
+template <class S, int NT, int KS, int KS_TOT, int LDA, class WS, class JOB>
+__device__ __forceinline__ void conv_seg(f32x4 (&acc)[S::MTPW][NT], const float* a_lane, const WS& w, int w_off, JOB& job) {
     mma_panel<S::MTPW, NT, KS>(
         acc,
         [&](int i, int ks) { return a_lane[(64 * i) * LDA + 4 * ks]; },
-        [&](int j, int ks) { return w.at(w_off + (j * KS_TOT + ks) * 64); }, DmaSide{&job});
+        [&](int j, int ks) { return w.at(w_off + (j * KS_TOT + ks) * 64); }, NoSide{});
 }
 
 // Several K-segments (conv taps / concatenated inputs) accumulated in ONE software pipeline:
 // segment s reads its A rows through a_lane[s]; the packed weights hold the segments' k-steps
 // back to back (k-step index = s * KS_SEG + ks).
-template <class S, int NT, int NSEG, int KS_SEG, int LDA, class WS>
-__device__ __forceinline__ void conv_multi(f32x4 (&acc)[S::MTPW][NT], const float* const (&a_lane)[NSEG], const WS& w, int w_off, DmaJob& job) {
+template <class S, int NT, int NSEG, int KS_SEG, int LDA, class WS, class JOB>
+__device__ __forceinline__ void conv_multi(f32x4 (&acc)[S::MTPW][NT], const float* const (&a_lane)[NSEG], const WS& w, int w_off, JOB& job) {
     mma_panel<S::MTPW, NT, NSEG * KS_SEG>(
         acc,
         [&](int i, int ks) { return a_lane[ks / KS_SEG][(64 * i) * LDA + 4 * (ks % KS_SEG)]; },
-        [&](int j, int ks) { return w.at(w_off + (j * (NSEG * KS_SEG) + ks) * 64); }, DmaSide{&job});
+        [&](int j, int ks) { return w.at(w_off + (j * (NSEG * KS_SEG) + ks) * 64); }, NoSide{});
 }
 
 // Epilogue of a conv-layout GEMM: optional SiLU, store to out[(row0 + m)][col] for col < NCOLS.
@@ -488,8 +549,8 @@ __device__ __forceinline__ void conv_store(const f32x4 (&acc)[S::MTPW][NT], floa
 }
 
 // token-layout GEMM: all MT2 m-tiles x this wave's n-tiles (wave + 4*j), A from LDS, B packed.
-template <class S, int NTPW, int KS, int LDA, class WS>
-__device__ __forceinline__ void tok_gemm(f32x4 (&acc)[S::MT2][NTPW], const float* a_lane, const WS& w, int w_off, int NT, int wave, DmaJob& job) {
+template <class S, int NTPW, int KS, int LDA, class WS, class JOB>
+__device__ __forceinline__ void tok_gemm(f32x4 (&acc)[S::MT2][NTPW], const float* a_lane, const WS& w, int w_off, int NT, int wave, JOB& job) {
     mma_panel<S::MT2, NTPW, KS>(
         acc,
         [&](int i, int ks) { return a_lane[(16 * i) * LDA + 4 * ks]; },
@@ -497,7 +558,7 @@ __device__ __forceinline__ void tok_gemm(f32x4 (&acc)[S::MT2][NTPW], const float
             int nt = wave + 4 * j;
             nt = nt < NT ? nt : NT - 1;
             return w.at(w_off + (nt * KS + ks) * 64);
-        }, DmaSide{&job});
+        }, NoSide{});
 }
 
 // Token GEMMs split the OUTPUT columns over the waves, so a wave's B fragments (weights) are private to
@@ -626,11 +687,16 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         else return ((l + (S::NL & 1)) & 1) ? W1 : W0;
     };
     // weight units: unit U of frame t is consumed from LDS buffer ((U + t*NU) & 1) while the next streams in
-    DmaJob job{wp + lane * 4, smem, 0, wave};
+    constexpr int NPW = L::STAGED ? ceil_div(ceil_div(Pack<S>::umax(), 256), kWaves) : 1;
+    DmaJobT<NPW> job;
+    job.l = smem;
+    job.npieces = 0;
+    job.wave = wave;
+    job.lane = lane;
     if constexpr (L::STAGED) {
-        job.g = wp + o.u_off[0] + lane * 4;
         job.l = smem + L::WB0;
-        job.n = o.u_size[0];
+        job.npieces = o.u_size[0] / 256;
+        stage_begin(job, wb.rsrc, o.u_off[0]);
         dma_rest(job);
     }
     __syncthreads();
@@ -650,10 +716,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 constexpr int un_ = (u_ + 1 == S::NU) ? 0 : u_ + 1;                                \
                 const int slot_ = (u_ & 1) ^ fpar;                                                 \
                 const bool has_next_ = (u_ + 1 < S::NU) || (t + 1 < a.T);                          \
-                job.g = wp + o.u_off[un_] + lane * 4;                                              \
                 job.l = smem + (slot_ ? L::WB0 : L::WB1);                                          \
-                job.n = has_next_ ? o.u_size[un_] : 0;                                             \
-                job.p = wave;                                                                      \
+                job.npieces = has_next_ ? o.u_size[un_] / 256 : 0;                                 \
+                stage_begin(job, wb.rsrc, o.u_off[un_]);                                           \
                 wb.lds = smem + (slot_ ? L::WB1 : L::WB0);                                         \
                 wb.base = o.u_off[u_];                                                             \
             }                                                                                      \
@@ -733,7 +798,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     const int m = 16 * (wave + 4 * i) + li;
                     return sc[c * S::LDS_S + 4 * (m + tp) + s];
                 },
-                [&](int j, int ks) { return wb.at(o.enc_pre_w + (j * 4 + ks) * 64); }, DmaSide{&job});
+                [&](int j, int ks) { return wb.at(o.enc_pre_w + (j * 4 + ks) * 64); }, NoSide{});
             dma_rest(job);
             if constexpr (SG) {   // the arena was used by the FFT: restore the zero halo rows of both ping-pong buffers
                 for (int i = tid; i < 4 * LDC; i += kThreads) {
@@ -752,15 +817,21 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             constexpr int l = decltype(l_)::value;
             const float* in = encbuf(l);
             float* out = encbuf(l + 1);
+            if (l == 0) FE_CLK(40);
             FE_BEGIN_UNIT(1 + l);
             f32x4 acc[S::MTPW][S::NTC];
             acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.enc_b[l], 0, 1, S::NTC);
             const float* const taps[3] = {in + (16 * wave + li + 0) * LDC + lg, in + (16 * wave + li + 1) * LDC + lg,
                                           in + (16 * wave + li + 2) * LDC + lg};
             conv_multi<S, S::NTC, 3, S::KS_C, LDC>(acc, taps, wb, o.enc_w[l], job);
+            __builtin_amdgcn_sched_barrier(0);
+            if (l == 0) FE_CLK(41);
             dma_rest(job);
             conv_store<S, S::NTC, C1, LDC, true>(acc, out, 1, wave, lane, SG ? skipg + (l + 1) * SKIP_FLOATS : nullptr);
+            __builtin_amdgcn_sched_barrier(0);
+            if (l == 0) FE_CLK(42);
             __syncthreads();
+            if (l == 0) FE_CLK(43);
             dbg_dump<S>(a, b, 3 + l, out + LDC, LDC);
         });
 
@@ -800,7 +871,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     int nt = wave + 4 * j;
                     nt = nt < S::NTC ? nt : S::NTC - 1;
                     return Ein[(4 * ks + lg) * LDC + 16 * nt + li];
-                }, DmaSide{&job});
+                }, NoSide{});
             dma_rest(job);
 #pragma unroll
             for (int i = 0; i < S::MT2; ++i)
@@ -1104,7 +1175,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             mma_panel<S::MTPW, S::NT2, KS>(
                 acc,
                 [&](int i, int ks) { return wb.at(o.rfpost_lin + ((wave + 4 * i) * KS + ks) * 64); },
-                [&](int j, int ks) { return Xb[(4 * ks + lg) * LDX + 16 * j + li]; }, DmaSide{&job});
+                [&](int j, int ks) { return Xb[(4 * ks + lg) * LDX + 16 * j + li]; }, NoSide{});
             dma_rest(job);
             conv_store<S, S::NT2, C2, LDX, false>(acc, Y2, 0, wave, lane);
         }
@@ -1145,7 +1216,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                             return ks < S::KS_C ? xa[(64 * i) * LDC + 4 * ks]
                                                 : skb.at_g((S::NL - l) * SKIP_FLOATS + ((wave + 4 * i) * S::KS_C + (ks - S::KS_C)) * 64);
                         },
-                        [&](int j, int ks) { return wb.at(o.dec1_w[l] + (j * (2 * S::KS_C) + ks) * 64); }, DmaSide{&job});
+                        [&](int j, int ks) { return wb.at(o.dec1_w[l] + (j * (2 * S::KS_C) + ks) * 64); }, NoSide{});
                 }
                 dma_rest(job);
                 conv_store<S, S::NTC, C1, LDC, true>(acc, W1, 1, wave, lane);
@@ -1182,7 +1253,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     [&](int i, int ks) {
                         return ks < S::KS_C ? xa[(64 * i) * LDC + 4 * ks] : skb.at_g(((wave + 4 * i) * S::KS_C + (ks - S::KS_C)) * 64);
                     },
-                    [&](int j, int ks) { return wb.at(o.post1_w + (j * (2 * S::KS_C) + ks) * 64); }, DmaSide{&job});
+                    [&](int j, int ks) { return wb.at(o.post1_w + (j * (2 * S::KS_C) + ks) * 64); }, NoSide{});
             }
             dma_rest(job);
             conv_store<S, S::NTC, C1, LDC, true>(acc, W1, 1, wave, lane);
