@@ -226,35 +226,56 @@ template <int NPW>
 struct DmaJobT {
     f32x4 r[NPW];     // this wave's pieces in flight
     float* l;         // LDS destination of the unit
-    int npieces;      // 1-KiB pieces of the unit (0: nothing to stage)
+    __amdgpu_buffer_rsrc_t rsrc;
+    int soff;         // byte offset of this wave's piece 0 in the packed weights
     int wave, lane;
 };
-template <int NPW>
-__device__ __forceinline__ void stage_begin(DmaJobT<NPW>& j, __amdgpu_buffer_rsrc_t rsrc, int unit_off_floats) {
-#pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-        const int p = j.wave + kWaves * i;
-        if (p < j.npieces)
-            j.r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, j.lane * 16, (unit_off_floats + p * 256) * 4, 0));
+// The loads of a unit of NP pieces ride in the software pipeline of the phase's GEMM as its side job, spread
+// over the k-groups (issued back to back they stall the wave: the vector-memory path takes 64 B/clk per CU, i.e.
+// 64 cycles per round of four 1-KiB pieces); commit() writes them to LDS after the GEMM.
+template <int NPW, int NP>
+struct StageSide {
+    DmaJobT<NPW>* j;
+    static constexpr int NPI = (NP + kWaves - 1) / kWaves;     // pieces per wave
+    static constexpr int loads(int g, int ng) {
+        int n = 0;
+        for (int i = 0; i < NPI; ++i) n += (i * ng / NPI == g) ? 1 : 0;
+        return n;
     }
-}
-template <int NPW>
-__device__ __forceinline__ void dma_rest(DmaJobT<NPW>& j) {      // commit the staged pieces to LDS
-#pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-        const int p = j.wave + kWaves * i;
-        if (p < j.npieces) *reinterpret_cast<f32x4*>(j.l + p * 256 + j.lane * 4) = j.r[i];
+    __device__ __forceinline__ void load(int i) const {
+        int voff = j->lane * 16;
+        if (4 * i + 3 >= NP) voff = (j->wave + kWaves * i < NP) ? voff : 0x40000000;     // out of range: reads 0, no traffic
+        j->r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(j->rsrc, voff, j->soff + i * (kWaves * 1024), 0));
     }
-    j.npieces = 0;
-}
+    __device__ __forceinline__ void operator()(int g, int ng) const {
+#pragma unroll
+        for (int i = 0; i < NPI; ++i)
+            if (i * ng / NPI == g) load(i);
+    }
+    __device__ __forceinline__ void commit() const {
+#pragma unroll
+        for (int i = 0; i < NPI; ++i) {
+            const int p = j->wave + kWaves * i;
+            if (4 * i + 3 < NP || p < NP) *reinterpret_cast<f32x4*>(j->l + p * 256 + j->lane * 4) = j->r[i];
+        }
+    }
+};
 // `side(g, NG)`: a job run once per k-group g of a GEMM's software pipeline, in the matrix pipe's shadow
-struct NoSide { __device__ __forceinline__ void operator()(int, int) const {} };
+struct NoSide {
+    static constexpr int loads(int, int) { return 0; }
+    __device__ __forceinline__ void operator()(int, int) const {}
+};
 // fetch a slice of one / two TokW register sets per k-group (the next phase's weights)
 template <class TW>
-struct FetchSide { TW* w; __device__ __forceinline__ void operator()(int g, int ng) const { w->fetch_part(g, ng); } };
+struct FetchSide {
+    TW* w;
+    static constexpr int loads(int g, int ng) { return TW::part_count(g, ng); }
+    __device__ __forceinline__ void operator()(int g, int ng) const { w->fetch_part(g, ng); }
+};
 template <class TA, class TB>
 struct FetchSide2 {
     TA* a; TB* b;
+    static constexpr int loads(int g, int ng) { return TA::part_count(g, ng) + TB::part_count(g, ng); }
     __device__ __forceinline__ void operator()(int g, int ng) const { a->fetch_part(g, ng); b->fetch_part(g, ng); }
 };
 
@@ -268,6 +289,7 @@ struct FetchSide2 {
 // form (operand groups two ahead, pinned with sched_barrier(0)).
 template <int MTP, int NTP, int KS, typename AF, typename BF, typename SIDE>
 __device__ __forceinline__ void mma_panel(f32x4 (&acc)[MTP][NTP], AF&& af, BF&& bf, SIDE&& side) {
+  using SIDE_T = std::remove_cv_t<std::remove_reference_t<SIDE>>;
   if constexpr (KS * MTP * NTP <= 128) {
     constexpr int PD = KS < 8 ? KS : 8;              // prefetch distance in k-steps
     constexpr int NSG = (KS + 3) / 4;                // side-job slots (one per 4 k-steps)
@@ -312,6 +334,13 @@ __device__ __forceinline__ void mma_panel(f32x4 (&acc)[MTP][NTP], AF&& af, BF&& 
             if (ks + PD < KS) {
 #pragma unroll
                 for (int q = lo; q < hi; ++q) __builtin_amdgcn_sched_group_barrier(LOADS, 1, 0);
+            }
+            // the side job's loads of this k-group, one per MFMA
+            {
+                const int g = ks >> 2, npos = (KS - 4 * g < 4 ? KS - 4 * g : 4) * NM, pos = (ks & 3) * NM + m;
+                const int sl = SIDE_T::loads(g, NSG);
+#pragma unroll
+                for (int q = (pos * sl) / npos; q < ((pos + 1) * sl) / npos; ++q) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
     }
@@ -503,23 +532,23 @@ __device__ __forceinline__ float2* fft_lds(float2* x, float2* y, const float2* t
 // conv-layout GEMM segment: this wave's m-tiles (wave + 4*i) x all NT n-tiles, K = 4*KS.
 //   a_lane : LDS pointer to A[(16*wave + (lane&15)) rows][(lane>>4) col] of the segment
 //   w_lane : packed weights + lane, at k-step 0 of this segment;  KS_TOT = k-steps per n-tile
-template <class S, int NT, int KS, int KS_TOT, int LDA, class WS, class JOB>
-__device__ __forceinline__ void conv_seg(f32x4 (&acc)[S::MTPW][NT], const float* a_lane, const WS& w, int w_off, JOB& job) {
+template <class S, int NT, int KS, int KS_TOT, int LDA, class WS, class SIDE>
+__device__ __forceinline__ void conv_seg(f32x4 (&acc)[S::MTPW][NT], const float* a_lane, const WS& w, int w_off, const SIDE& side) {
     mma_panel<S::MTPW, NT, KS>(
         acc,
         [&](int i, int ks) { return a_lane[(64 * i) * LDA + 4 * ks]; },
-        [&](int j, int ks) { return w.at(w_off + (j * KS_TOT + ks) * 64); }, NoSide{});
+        [&](int j, int ks) { return w.at(w_off + (j * KS_TOT + ks) * 64); }, side);
 }
 
 // Several K-segments (conv taps / concatenated inputs) accumulated in ONE software pipeline:
 // segment s reads its A rows through a_lane[s]; the packed weights hold the segments' k-steps
 // back to back (k-step index = s * KS_SEG + ks).
-template <class S, int NT, int NSEG, int KS_SEG, int LDA, class WS, class JOB>
-__device__ __forceinline__ void conv_multi(f32x4 (&acc)[S::MTPW][NT], const float* const (&a_lane)[NSEG], const WS& w, int w_off, JOB& job) {
+template <class S, int NT, int NSEG, int KS_SEG, int LDA, class WS, class SIDE>
+__device__ __forceinline__ void conv_multi(f32x4 (&acc)[S::MTPW][NT], const float* const (&a_lane)[NSEG], const WS& w, int w_off, const SIDE& side) {
     mma_panel<S::MTPW, NT, NSEG * KS_SEG>(
         acc,
         [&](int i, int ks) { return a_lane[ks / KS_SEG][(64 * i) * LDA + 4 * (ks % KS_SEG)]; },
-        [&](int j, int ks) { return w.at(w_off + (j * (NSEG * KS_SEG) + ks) * 64); }, NoSide{});
+        [&](int j, int ks) { return w.at(w_off + (j * (NSEG * KS_SEG) + ks) * 64); }, side);
 }
 
 // Epilogue of a conv-layout GEMM: optional SiLU, store to out[(row0 + m)][col] for col < NCOLS.
@@ -549,8 +578,8 @@ __device__ __forceinline__ void conv_store(const f32x4 (&acc)[S::MTPW][NT], floa
 }
 
 // token-layout GEMM: all MT2 m-tiles x this wave's n-tiles (wave + 4*j), A from LDS, B packed.
-template <class S, int NTPW, int KS, int LDA, class WS, class JOB>
-__device__ __forceinline__ void tok_gemm(f32x4 (&acc)[S::MT2][NTPW], const float* a_lane, const WS& w, int w_off, int NT, int wave, JOB& job) {
+template <class S, int NTPW, int KS, int LDA, class WS, class SIDE>
+__device__ __forceinline__ void tok_gemm(f32x4 (&acc)[S::MT2][NTPW], const float* a_lane, const WS& w, int w_off, int NT, int wave, const SIDE& side) {
     mma_panel<S::MT2, NTPW, KS>(
         acc,
         [&](int i, int ks) { return a_lane[(16 * i) * LDA + 4 * ks]; },
@@ -558,7 +587,7 @@ __device__ __forceinline__ void tok_gemm(f32x4 (&acc)[S::MT2][NTPW], const float
             int nt = wave + 4 * j;
             nt = nt < NT ? nt : NT - 1;
             return w.at(w_off + (nt * KS + ks) * 64);
-        }, NoSide{});
+        }, side);
 }
 
 // Token GEMMs split the OUTPUT columns over the waves, so a wave's B fragments (weights) are private to
@@ -586,6 +615,15 @@ struct TokW {
         const int g = r / (KS + 1), ks = r - g * (KS + 1);
         if (ks == KS) bv[j][g] = b_off >= 0 ? src->at16_g(b_off + tile(j, g) * 16) : 0.0f;
         else w[j][g][ks] = src->at_g(w_off + (tile(j, g) * KS + ks) * 64);
+    }
+    // number of loads fetch_part(part, parts) issues
+    static constexpr int part_count(int part, int parts) {
+        if (!REG) return 0;
+        const int TOT = NTPW * NG * (KS + 1), per = (TOT + parts - 1) / parts;
+        int lo = part * per, hi = (part + 1) * per;
+        lo = lo < TOT ? lo : TOT;
+        hi = hi < TOT ? hi : TOT;
+        return hi - lo;
     }
     // slice `part` of `parts` (all indices are compile-time constants once the caller's loops are unrolled)
     __device__ __forceinline__ void fetch_part(int part, int parts) {
@@ -690,14 +728,16 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     constexpr int NPW = L::STAGED ? ceil_div(ceil_div(Pack<S>::umax(), 256), kWaves) : 1;
     DmaJobT<NPW> job;
     job.l = smem;
-    job.npieces = 0;
+    job.rsrc = wb.rsrc;
+    job.soff = 0;
     job.wave = wave;
     job.lane = lane;
     if constexpr (L::STAGED) {
         job.l = smem + L::WB0;
-        job.npieces = o.u_size[0] / 256;
-        stage_begin(job, wb.rsrc, o.u_off[0]);
-        dma_rest(job);
+        job.soff = (o.u_off[0] + wave * 256) * 4;
+        const StageSide<NPW, o.u_size[0] / 256> st0{&job};
+        st0(0, 1);
+        st0.commit();
     }
     __syncthreads();
 
@@ -710,19 +750,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         // selects the LDS copy of this phase's weights and sets up the DMA job of the next unit.
         const int fpar = (S::NU & 1) ? (t & 1) : 0;
 #define FE_BEGIN_UNIT(U)                                                                           \
-        do {                                                                                       \
-            if constexpr (L::STAGED) {                                                             \
-                constexpr int u_ = (U);                                                            \
-                constexpr int un_ = (u_ + 1 == S::NU) ? 0 : u_ + 1;                                \
-                const int slot_ = (u_ & 1) ^ fpar;                                                 \
-                const bool has_next_ = (u_ + 1 < S::NU) || (t + 1 < a.T);                          \
-                job.l = smem + (slot_ ? L::WB0 : L::WB1);                                          \
-                job.npieces = has_next_ ? o.u_size[un_] / 256 : 0;                                 \
-                stage_begin(job, wb.rsrc, o.u_off[un_]);                                           \
-                wb.lds = smem + (slot_ ? L::WB1 : L::WB0);                                         \
-                wb.base = o.u_off[u_];                                                             \
-            }                                                                                      \
-        } while (0)
+        constexpr int fe_un_ = ((U) + 1 == S::NU) ? 0 : (U) + 1;                                   \
+        if constexpr (L::STAGED) {                                                                 \
+            const int slot_ = ((U) & 1) ^ fpar;                                                    \
+            job.l = smem + (slot_ ? L::WB0 : L::WB1);                                              \
+            job.soff = (o.u_off[fe_un_] + wave * 256) * 4;                                         \
+            wb.lds = smem + (slot_ ? L::WB1 : L::WB0);                                             \
+            wb.base = o.u_off[(U)];                                                                \
+        }                                                                                          \
+        const StageSide<NPW, L::STAGED ? o.u_size[fe_un_] / 256 : 0> stage{&job}
         FE_CLK(0);
         // =========================== STFT (a3) ===========================
         const int mode = a.mode;
@@ -798,8 +834,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     const int m = 16 * (wave + 4 * i) + li;
                     return sc[c * S::LDS_S + 4 * (m + tp) + s];
                 },
-                [&](int j, int ks) { return wb.at(o.enc_pre_w + (j * 4 + ks) * 64); }, NoSide{});
-            dma_rest(job);
+                [&](int j, int ks) { return wb.at(o.enc_pre_w + (j * 4 + ks) * 64); }, stage);
+            stage.commit();
             if constexpr (SG) {   // the arena was used by the FFT: restore the zero halo rows of both ping-pong buffers
                 for (int i = tid; i < 4 * LDC; i += kThreads) {
                     const int q = i / LDC, c = i - q * LDC;
@@ -823,10 +859,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.enc_b[l], 0, 1, S::NTC);
             const float* const taps[3] = {in + (16 * wave + li + 0) * LDC + lg, in + (16 * wave + li + 1) * LDC + lg,
                                           in + (16 * wave + li + 2) * LDC + lg};
-            conv_multi<S, S::NTC, 3, S::KS_C, LDC>(acc, taps, wb, o.enc_w[l], job);
+            conv_multi<S, S::NTC, 3, S::KS_C, LDC>(acc, taps, wb, o.enc_w[l], stage);
             __builtin_amdgcn_sched_barrier(0);
             if (l == 0) FE_CLK(41);
-            dma_rest(job);
+            stage.commit();
             conv_store<S, S::NTC, C1, LDC, true>(acc, out, 1, wave, lane, SG ? skipg + (l + 1) * SKIP_FLOATS : nullptr);
             __builtin_amdgcn_sched_barrier(0);
             if (l == 0) FE_CLK(42);
@@ -871,8 +907,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     int nt = wave + 4 * j;
                     nt = nt < S::NTC ? nt : S::NTC - 1;
                     return Ein[(4 * ks + lg) * LDC + 16 * nt + li];
-                }, NoSide{});
-            dma_rest(job);
+                }, stage);
+            stage.commit();
 #pragma unroll
             for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -901,8 +937,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             }
             f32x4 acc[S::MT2][NTPW];
             acc_init_bias<S::MT2, NTPW>(acc, wb, o.rfpre_b, wave, 4, S::NT2);
-            tok_gemm<S, NTPW, S::KS_C, LDC>(acc, Y1 + li * LDC + lg, wb, o.rfpre_w, S::NT2, wave, job);
-            dma_rest(job);
+            tok_gemm<S, NTPW, S::KS_C, LDC>(acc, Y1 + li * LDC + lg, wb, o.rfpre_w, S::NT2, wave, stage);
+            stage.commit();
 #pragma unroll
             for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -1175,8 +1211,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             mma_panel<S::MTPW, S::NT2, KS>(
                 acc,
                 [&](int i, int ks) { return wb.at(o.rfpost_lin + ((wave + 4 * i) * KS + ks) * 64); },
-                [&](int j, int ks) { return Xb[(4 * ks + lg) * LDX + 16 * j + li]; }, NoSide{});
-            dma_rest(job);
+                [&](int j, int ks) { return Xb[(4 * ks + lg) * LDX + 16 * j + li]; }, stage);
+            stage.commit();
             conv_store<S, S::NT2, C2, LDX, false>(acc, Y2, 0, wave, lane);
         }
         __syncthreads();
@@ -1184,8 +1220,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             FE_BEGIN_UNIT(4 + S::NL);
             f32x4 acc[S::MTPW][S::NTC];
             acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.rfpost_b, 0, 1, S::NTC);
-            conv_seg<S, S::NTC, S::KS_2, S::KS_2, LDX>(acc, Y2 + (16 * wave + li) * LDX + lg, wb, o.rfpost_w, job);
-            dma_rest(job);
+            conv_seg<S, S::NTC, S::KS_2, S::KS_2, LDX>(acc, Y2 + (16 * wave + li) * LDX + lg, wb, o.rfpost_w, stage);
+            stage.commit();
             conv_store<S, S::NTC, C1, LDC, false>(acc, W0, 1, wave, lane);
         }
         __syncthreads();
@@ -1207,7 +1243,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.dec1_b[l], 0, 1, S::NTC);
                 if constexpr (!SG) {
                     const float* const segs[2] = {W0 + (16 * wave + li + 1) * LDC + lg, skip + (16 * wave + li + 1) * LDC + lg};
-                    conv_multi<S, S::NTC, 2, S::KS_C, LDC>(acc, segs, wb, o.dec1_w[l], job);
+                    conv_multi<S, S::NTC, 2, S::KS_C, LDC>(acc, segs, wb, o.dec1_w[l], stage);
                 } else {   // second K-segment = the skip, read back from the global scratch as A fragments
                     const float* xa = W0 + (16 * wave + li + 1) * LDC + lg;
                     mma_panel<S::MTPW, S::NTC, 2 * S::KS_C>(
@@ -1216,9 +1252,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                             return ks < S::KS_C ? xa[(64 * i) * LDC + 4 * ks]
                                                 : skb.at_g((S::NL - l) * SKIP_FLOATS + ((wave + 4 * i) * S::KS_C + (ks - S::KS_C)) * 64);
                         },
-                        [&](int j, int ks) { return wb.at(o.dec1_w[l] + (j * (2 * S::KS_C) + ks) * 64); }, NoSide{});
+                        [&](int j, int ks) { return wb.at(o.dec1_w[l] + (j * (2 * S::KS_C) + ks) * 64); }, stage);
                 }
-                dma_rest(job);
+                stage.commit();
                 conv_store<S, S::NTC, C1, LDC, true>(acc, W1, 1, wave, lane);
             }
             __syncthreads();
@@ -1228,8 +1264,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.dec3_b[l], 0, 1, S::NTC);
                 const float* const taps[3] = {W1 + (16 * wave + li + 0) * LDC + lg, W1 + (16 * wave + li + 1) * LDC + lg,
                                               W1 + (16 * wave + li + 2) * LDC + lg};
-                conv_multi<S, S::NTC, 3, S::KS_C, LDC>(acc, taps, wb, o.dec3_w[l], job);
-                dma_rest(job);
+                conv_multi<S, S::NTC, 3, S::KS_C, LDC>(acc, taps, wb, o.dec3_w[l], stage);
+                stage.commit();
                 conv_store<S, S::NTC, C1, LDC, true>(acc, W0, 1, wave, lane);   // W0 was fully consumed before the barrier above
             }
             __syncthreads();
@@ -1245,7 +1281,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.post1_b, 0, 1, S::NTC);
             if constexpr (!SG) {
                 const float* const segs[2] = {W0 + (16 * wave + li + 1) * LDC + lg, Ebuf + (16 * wave + li + 1) * LDC + lg};
-                conv_multi<S, S::NTC, 2, S::KS_C, LDC>(acc, segs, wb, o.post1_w, job);
+                conv_multi<S, S::NTC, 2, S::KS_C, LDC>(acc, segs, wb, o.post1_w, stage);
             } else {
                 const float* xa = W0 + (16 * wave + li + 1) * LDC + lg;
                 mma_panel<S::MTPW, S::NTC, 2 * S::KS_C>(
@@ -1253,9 +1289,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     [&](int i, int ks) {
                         return ks < S::KS_C ? xa[(64 * i) * LDC + 4 * ks] : skb.at_g(((wave + 4 * i) * S::KS_C + (ks - S::KS_C)) * 64);
                     },
-                    [&](int j, int ks) { return wb.at(o.post1_w + (j * (2 * S::KS_C) + ks) * 64); }, NoSide{});
+                    [&](int j, int ks) { return wb.at(o.post1_w + (j * (2 * S::KS_C) + ks) * 64); }, stage);
             }
-            dma_rest(job);
+            stage.commit();
             conv_store<S, S::NTC, C1, LDC, true>(acc, W1, 1, wave, lane);
         }
         __syncthreads();
@@ -1264,8 +1300,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             FE_BEGIN_UNIT(6 + 3 * S::NL);
             f32x4 acc[S::MTPW][1];
             acc_init_zero<S::MTPW, 1>(acc);
-            conv_seg<S, 1, S::KS_C, S::KS_C, LDC>(acc, W1 + (16 * wave + li + 1) * LDC + lg, wb, o.post_t_w, job);
-            dma_rest(job);
+            conv_seg<S, 1, S::KS_C, S::KS_C, LDC>(acc, W1 + (16 * wave + li + 1) * LDC + lg, wb, o.post_t_w, stage);
+            stage.commit();
             conv_store<S, 1, 16, S::LDP, false>(acc, PT, 0, wave, lane);
         }
         __syncthreads();
