@@ -203,6 +203,10 @@ struct WSrc {
     __device__ __forceinline__ float at16_g(int off_floats) const {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, li4, off_floats * 4, 0));
     }
+    // explicit per-lane byte offset (an offset beyond the buffer reads 0 without touching memory)
+    __device__ __forceinline__ float at_gv(int off_floats, int voff_bytes) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_bytes, off_floats * 4, 0));
+    }
     __device__ __forceinline__ float gather_g(int off_floats_per_lane) const {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off_floats_per_lane * 4, 0, 0));
     }
@@ -265,6 +269,14 @@ struct NoSide {
     static constexpr int loads(int, int) { return 0; }
     __device__ __forceinline__ void operator()(int, int) const {}
 };
+template <class A, class B>
+struct Side2 {
+    A a; B b;
+    static constexpr int loads(int g, int ng) { return A::loads(g, ng) + B::loads(g, ng); }
+    __device__ __forceinline__ void operator()(int g, int ng) const { a(g, ng); b(g, ng); }
+};
+template <class A, class B>
+__device__ __forceinline__ Side2<A, B> side2(const A& a, const B& b) { return Side2<A, B>{a, b}; }
 // fetch a slice of one / two TokW register sets per k-group (the next phase's weights)
 template <class TW>
 struct FetchSide {
@@ -601,20 +613,24 @@ struct TokW {
     float bv[REG ? NTPW : 1][NG];
     const WS* src;
     int w_off, b_off, NT, wave;
+    int kill;          // 0x40000000: every load of this set is suppressed (reads 0), 0: normal
+    // column tiles beyond NT (waves left over when NT is not a multiple of 4) load zeros through an
+    // out-of-range buffer offset: no L2 / vector-memory traffic for work whose results are discarded
+    __device__ __forceinline__ int oob(int j) const { return wave + 4 * j < NT ? kill : 0x40000000; }
     __device__ __forceinline__ int tile(int j, int g) const {
         int ct = wave + 4 * j;
         ct = ct < NT ? ct : NT - 1;
         return g * NT + ct;
     }
-    __device__ __forceinline__ void bind(const WS& s, int w_off_, int b_off_, int NT_, int wave_) {
-        src = &s; w_off = w_off_; b_off = b_off_; NT = NT_; wave = wave_;
+    __device__ __forceinline__ void bind(const WS& s, int w_off_, int b_off_, int NT_, int wave_, bool live = true) {
+        src = &s; w_off = w_off_; b_off = b_off_; NT = NT_; wave = wave_; kill = live ? 0 : 0x40000000;
     }
     // element e of the flattened register set [NTPW][NG][KS + 1] (the +1 is the bias)
     __device__ __forceinline__ void fetch_elem(int e) {
         const int j = e / (NG * (KS + 1)), r = e - j * (NG * (KS + 1));
         const int g = r / (KS + 1), ks = r - g * (KS + 1);
-        if (ks == KS) bv[j][g] = b_off >= 0 ? src->at16_g(b_off + tile(j, g) * 16) : 0.0f;
-        else w[j][g][ks] = src->at_g(w_off + (tile(j, g) * KS + ks) * 64);
+        if (ks == KS) bv[j][g] = b_off >= 0 ? src->at_gv(b_off + tile(j, g) * 16, src->li4 + oob(j)) : 0.0f;
+        else w[j][g][ks] = src->at_gv(w_off + (tile(j, g) * KS + ks) * 64, src->lane4 + oob(j));
     }
     // number of loads fetch_part(part, parts) issues
     static constexpr int part_count(int part, int parts) {
@@ -641,11 +657,11 @@ struct TokW {
     }
     __device__ __forceinline__ float get(int j, int g, int ks) const {
         if constexpr (REG) return w[j][g][ks];
-        else return src->at_g(w_off + (tile(j, g) * KS + ks) * 64);
+        else return src->at_gv(w_off + (tile(j, g) * KS + ks) * 64, src->lane4 + oob(j));
     }
     __device__ __forceinline__ float bias(int j, int g) const {
         if constexpr (REG) return bv[j][g];
-        else return b_off >= 0 ? src->at16_g(b_off + tile(j, g) * 16) : 0.0f;
+        else return b_off >= 0 ? src->at_gv(b_off + tile(j, g) * 16, src->li4 + oob(j)) : 0.0f;
     }
 };
 
@@ -898,6 +914,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             constexpr int KS = F1 / 4;
             const float* Ein = encbuf(S::NL) + LDC;   // row 0 = bin 0
             FE_BEGIN_UNIT(1 + S::NL);
+            Wgi.bind(wb, o.blk_wih[0], o.blk_bih[0], S::NT2, wave);      // block 0's GRU input weights ride in this GEMM
             f32x4 acc[S::MT2][NTPW];
             acc_init_zero<S::MT2, NTPW>(acc);
             mma_panel<S::MT2, NTPW, KS>(
@@ -907,7 +924,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     int nt = wave + 4 * j;
                     nt = nt < S::NTC ? nt : S::NTC - 1;
                     return Ein[(4 * ks + lg) * LDC + 16 * nt + li];
-                }, stage);
+                }, side2(stage, FetchSide<decltype(Wgi)>{&Wgi}));
             stage.commit();
 #pragma unroll
             for (int i = 0; i < S::MT2; ++i)
@@ -926,8 +943,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             // X[f2][c2] = Y1[f2][:] . Wc[c2][:] + b
             constexpr int NTPW = ceil_div(S::NT2, kWaves);
             FE_BEGIN_UNIT(2 + S::NL);
-            Wgi.fetch(wb, o.blk_wih[0], o.blk_bih[0], S::NT2, wave);
-            Wgh.fetch(wb, o.blk_whh[0], o.blk_bhh[0], S::NT2, wave);
+            Wgh.bind(wb, o.blk_whh[0], o.blk_bhh[0], S::NT2, wave);      // ... and the hidden weights in this one
             // hidden state of block 0: fetched now, parked in LDS after the GEMM
             float hpre[HPT];
             {
@@ -937,7 +953,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             }
             f32x4 acc[S::MT2][NTPW];
             acc_init_bias<S::MT2, NTPW>(acc, wb, o.rfpre_b, wave, 4, S::NT2);
-            tok_gemm<S, NTPW, S::KS_C, LDC>(acc, Y1 + li * LDC + lg, wb, o.rfpre_w, S::NT2, wave, stage);
+            tok_gemm<S, NTPW, S::KS_C, LDC>(acc, Y1 + li * LDC + lg, wb, o.rfpre_w, S::NT2, wave, side2(stage, FetchSide<decltype(Wgh)>{&Wgh}));
             stage.commit();
 #pragma unroll
             for (int i = 0; i < S::MT2; ++i)
@@ -1054,9 +1070,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             {
                 // qkv = x W_qkv^T  -> Gi (rows per head interleaved [h][q|k|v][hd])
                 constexpr int NTPW = NTPW3;
-                Wf2.bind(wb, (o.blk_fc2_w[0] + kb), (o.blk_fc2_b[0] + kb), S::NT2, wave);     // for attn_fc, fetched inside the GEMM
+                // fetched inside the GEMM: attn_fc weights and the next block's GRU input weights
+                Wf2.bind(wb, (o.blk_fc2_w[0] + kb), (o.blk_fc2_b[0] + kb), S::NT2, wave);
+                Wgi.bind(wb, (o.blk_wih[0] + kb + o.blk_stride), (o.blk_bih[0] + kb + o.blk_stride), S::NT2, wave, k + 1 < S::KB);
                 f32x4 acc[S::MT2][NTPW];
-                tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Xb + li * LDX + lg, Wq, FetchSide<decltype(Wf2)>{&Wf2});
+                tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Xb + li * LDX + lg, Wq, FetchSide2<decltype(Wf2), decltype(Wgi)>{&Wf2, &Wgi});
 #pragma unroll
                 for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -1162,16 +1180,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 // x += attn_fc(o)
                 constexpr int NTPW = ceil_div(S::NT2, kWaves);
                 float hpre[HPT];
-                if (k + 1 < S::KB) {   // next block: GRU weights into registers, hidden state fetched now / parked after the GEMM
-                    Wgi.bind(wb, (o.blk_wih[0] + kb + o.blk_stride), (o.blk_bih[0] + kb + o.blk_stride), S::NT2, wave);     // fetched inside the GEMM below
-                    Wgh.bind(wb, (o.blk_whh[0] + kb + o.blk_stride), (o.blk_bhh[0] + kb + o.blk_stride), S::NT2, wave);
+                // next block: GRU hidden weights into registers inside the GEMM; hidden state fetched now / parked after it
+                Wgh.bind(wb, (o.blk_whh[0] + kb + o.blk_stride), (o.blk_bhh[0] + kb + o.blk_stride), S::NT2, wave, k + 1 < S::KB);
+                if (k + 1 < S::KB) {
                     const float* hgn = hg + (size_t)a.B * (F2 * C2);
 #pragma unroll
                     for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = i < F2 * C2 ? hgn[i] : 0.0f; }
                 }
                 f32x4 acc[S::MT2][NTPW];
-                if (k + 1 < S::KB) tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf2, FetchSide2<decltype(Wgi), decltype(Wgh)>{&Wgi, &Wgh});
-                else tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf2);
+                tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf2, FetchSide<decltype(Wgh)>{&Wgh});
                 if (k + 1 < S::KB) {
 #pragma unroll
                     for (int q = 0; q < HPT; ++q) {
