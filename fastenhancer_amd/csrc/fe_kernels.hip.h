@@ -417,6 +417,19 @@ __device__ __forceinline__ void acc_init_bias(f32x4 (&acc)[MTP][NTP], const WS& 
     }
 }
 
+// All-reduce over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the gfx950 row-swap VALU ops
+// (v_permlane32_swap / v_permlane16_swap) instead of ds_bpermute round trips through the LDS pipeline.
+// (inline asm: this hipcc's __builtin_amdgcn_permlane{16,32}_swap returns its first result twice; the s_nop covers
+//  the VALU-write -> permlane-swap read hazard the compiler would otherwise pad for)
+template <class OP>
+__device__ __forceinline__ float rows_allreduce(float x, OP op) {
+    float a = x, b = x;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));      // a = {lo|lo}, b = {hi|hi}
+    float c = op(a, b), d = c;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(c), "+v"(d));      // c = even rows twice, d = odd rows twice
+    return op(c, d);
+}
+
 // ------------------------------------------------------------------------------------------
 // Debug stage table (shared by host and device).
 template <class S>
@@ -1121,8 +1134,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                             sacc[i][j][r] = s;
                             mx = fmaxf(mx, s);
                         }
-                    mx = fmaxf(mx, __shfl_xor(mx, 16));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    mx = rows_allreduce(mx, [](float p, float q) { return fmaxf(p, q); });
                     float sum = 0.0f;
 #pragma unroll
                     for (int i = 0; i < S::MT2; ++i)
@@ -1132,9 +1144,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                             sacc[i][j][r] = p;
                             sum += p;
                         }
-                    sum += __shfl_xor(sum, 16);
-                    sum += __shfl_xor(sum, 32);
-                    const float inv = 1.0f / sum;
+                    sum = rows_allreduce(sum, [](float p, float q) { return p + q; });
+                    const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
                     for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
