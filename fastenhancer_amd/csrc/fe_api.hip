@@ -270,6 +270,39 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
     p.raw(o.window, h->window.size(), h->window.data());
     p.raw(o.window_istft, h->window_istft.size(), h->window_istft.data());
     p.raw(o.twiddle, h->twiddle.size(), h->twiddle.data());
+    {   // constant operands of the matrix-core DFT (fe::Dft in fe_kernels.hip.h), N = N1 * 32
+        const int N = h->cfg.n_fft, N1 = N / 32, KC = N1 / 2, MT = N1 / 16;
+        auto c32 = [](int a, int b) { return std::cos(2.0 * M_PI * (double)((a * b) % 32) / 32.0); };
+        auto s32 = [](int a, int b) { return std::sin(2.0 * M_PI * (double)((a * b) % 32) / 32.0); };
+        auto c1 = [&](int a, int b) { return std::cos(2.0 * M_PI * (double)((a * b) % N1) / (double)N1); };
+        auto s1 = [&](int a, int b) { return std::sin(2.0 * M_PI * (double)((a * b) % N1) / (double)N1); };
+        for (int q = 0; q < 2; ++q) {
+            // forward, 32-point stage: B[k = n2][n = k2] = Re (q = 0) / Im (q = 1) of W_32^(n2 k2)
+            p.pack_b(o.dft1 + q * (2 * 8 * 64), 32, 32, [&](int k, int n) { return (float)(q == 0 ? c32(k, n) : -s32(k, n)); });
+            // forward, N1-point stage, output half q: A[m = k1][k-step a*4MT + 4i + r, lane group lg]  <->  half a of
+            // G', row n1 = 16 i + 4 lg + r:   Re X: [cos | sin],  Im X: [-sin | cos]
+            p.pack_a(o.dft2 + q * (KC * 64), 16, 2 * N1, [&](int m, int k) {
+                const int ks = k / 4, lg = k % 4, a = ks / (4 * MT), i = (ks % (4 * MT)) / 4, r = ks % 4;
+                const int n1 = 16 * i + 4 * lg + r;
+                if (q == 0) return (float)(a ? s1(m, n1) : c1(m, n1));
+                return (float)(a ? c1(m, n1) : -s1(m, n1));
+            });
+            // inverse, N1-point stage (transposed), half q of H: B[k = (b, k1)][n = n1]:  Re H: [cos | -sin],  Im H: [sin | cos]
+            p.pack_b(o.dft3 + q * (MT * KC * 64), 2 * N1, N1, [&](int k, int n) {
+                const int b = k / N1, k1 = k % N1;
+                if (q == 0) return (float)(b ? -s1(n, k1) : c1(n, k1));
+                return (float)(b ? c1(n, k1) : s1(n, k1));
+            });
+            // inverse, 32-point stage (with the 1/N of irfft), per wave (p = q, jt): B[k-step a*4 + r, lane group lg][n = li]
+            // <-> half a of H', k2 = 16 jt + 4 lg + r, output sample column n2 = 16 p + li:  cos / N (a = 0), -sin / N (a = 1)
+            for (int jt = 0; jt < 2; ++jt)
+                p.pack_b(o.dft4 + (q * 2 + jt) * (8 * 64), 32, 16, [&](int k, int n) {
+                    const int ks = k / 4, lg = k % 4, a = ks / 4, r = ks % 4;
+                    const int k2 = 16 * jt + 4 * lg + r, n2 = 16 * q + n;
+                    return (float)((a ? -s32(k2, n2) : c32(k2, n2)) / (double)N);
+                });
+        }
+    }
     *out = std::move(p.buf);
     return FE_OK;
 }

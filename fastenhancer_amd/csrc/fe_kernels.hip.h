@@ -96,6 +96,7 @@ struct PackedOffsets {
     int dec1_w[8], dec1_b[8], dec3_w[8], dec3_b[8];
     int post1_w, post1_b, post_t_w, post_t_b;
     int window, window_istft, twiddle;  // [N], [N], [N/2] float2
+    int dft1, dft2, dft3, dft4;         // constant operands of the matrix-core DFT (see Dft<S>)
     int total;
     // LDS-staged weight "units" in consumption order (one per conv-type GEMM phase): [weights | bias],
     // 256-float aligned and padded, so that a unit is staged by whole 1-KiB global_load_lds pieces.
@@ -141,6 +142,10 @@ struct Pack {
         }
         o.blk_stride = S::KB > 1 ? o.blk_wih[1] - o.blk_wih[0] : 0;
         o.window = alloc(S::NFFT); o.window_istft = alloc(S::NFFT); o.twiddle = alloc(S::NFFT);
+        {
+            constexpr int N1 = S::NFFT / 32, KC = N1 / 2, MT = N1 / 16;
+            o.dft1 = alloc(2 * 2 * 8 * 64); o.dft2 = alloc(2 * KC * 64); o.dft3 = alloc(2 * MT * KC * 64); o.dft4 = alloc(2 * 2 * 8 * 64);
+        }
         o.total = round_up(cur, 64);
         return o;
     }
@@ -521,7 +526,7 @@ struct Lds {
     static constexpr int WB1 = WB0 + Pack<S>::umax();
     static constexpr int TOTAL = STAGED ? NOSTAGE_TOTAL + 2 * Pack<S>::umax() : NOSTAGE_TOTAL;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
-    static_assert(2 * S::ACT >= 2 * S::NFFT, "FFT_A must not reach the transposed-conv partials");
+    static_assert(2 * S::ACT >= 4 * S::NFFT, "the FFT buffers must not reach the transposed-conv partials");
     static_assert(S::F2P * S::LDC <= S::F2P * S::LDG, "rf_pre intermediate must fit in the qkv buffer");
 };
 
@@ -552,6 +557,166 @@ __device__ __forceinline__ float2* fft_lds(float2* x, float2* y, const float2* t
     }
     return x;
 }
+
+// ------------------------------------------------------------------------------------------
+// Real DFT / inverse real DFT of one frame on the matrix cores.  N = N1 * 32 (N1 = 16 or 32); with
+// n = n1 + N1 n2 and k = 32 k1 + k2 the transform factors (Cooley-Tukey, decimation in frequency) into
+//   forward:  G[n1][k2] = sum_n2 x[n1 + N1 n2] W_32^(n2 k2)              (N1 x 32) . (32 x 32)   real x complex
+//             X[32 k1 + k2] = sum_n1 W_N1^(n1 k1) (W_N^(n1 k2) G[n1][k2])   (16 x N1) . (N1 x 32)   complex x complex
+//   inverse:  H[n1][k2] = sum_k1 conj(W_N1^(n1 k1)) Y[32 k1 + k2]         (Y Hermitian-extended past N/2)
+//             y[n1 + N1 n2] = Re sum_k2 (conj(W_N^(n1 k2)) H[n1][k2]) conj(W_32^(n2 k2)) / N
+// Complex products are real GEMMs with the real and imaginary parts stacked along K.  Wave w owns the column
+// tile k2 in [16 jt, 16 jt + 16), jt = w & 1, and p = w >> 1 selects its output half.  The two stages of a
+// transform chain IN REGISTERS: the first stage's C/D fragments (row 4 lg + r, column li) are used directly as
+// the second stage's B (forward) / A (inverse, first stage computed transposed) fragments - a k-step then carries
+// the rows {r, 4 + r, 8 + r, 12 + r} instead of four consecutive ones, which only permutes the K order of the
+// constant operand (packed accordingly by fe_api.hip into Pack<S>::dft1..4).  The twiddle multiply happens on
+// those registers, so each wave computes both the real and the imaginary half of the first stage for its
+// column tile (2x redundant, 16 MFMAs) and there is no LDS exchange or barrier between the stages: one barrier
+// per transform instead of the log2 N of a radix-2 pass (each ~350 cycles at this size).
+template <class S>
+struct Dft {
+    static constexpr int N = S::NFFT, N1 = N / 32, MT = N1 / 16, KC = N1 / 2;
+    static constexpr bool PRELOAD3 = (N1 == 16);      // inverse first-stage constants in registers (else streamed from L2)
+    static_assert(N1 == 16 || N1 == 32, "DFT factorisation: N = 512 or 1024");
+    // y partial sums, index of sample n = n1 + N1 n2 (row n2, rotated by n2: the producer writes one row per lane)
+    __device__ static __forceinline__ int pidx(int n1, int n2) { return n2 * N1 + ((n1 + n2) & (N1 - 1)); }
+    __device__ static __forceinline__ float2 twid(const float2* tw, int idx) {     // W_N^idx, idx < N
+        float2 t = tw[idx & (N / 2 - 1)];
+        if (idx >= N / 2) { t.x = -t.x; t.y = -t.y; }
+        return t;
+    }
+
+    struct FwdConst { float c1[2][8], c2[KC]; };
+    struct InvConst { float c3[PRELOAD3 ? 2 * MT : 1][PRELOAD3 ? KC : 1], c4[8]; };
+    template <class WS>
+    __device__ static __forceinline__ void load(FwdConst& c, const WS& wb, const PackedOffsets& o, int wave) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) c.c1[a][ks] = wb.at_g(o.dft1 + ((a * 2 + (wave & 1)) * 8 + ks) * 64);
+#pragma unroll
+        for (int ks = 0; ks < KC; ++ks) c.c2[ks] = wb.at_g(o.dft2 + ((wave >> 1) * KC + ks) * 64);
+    }
+    template <class WS>
+    __device__ static __forceinline__ void load(InvConst& c, const WS& wb, const PackedOffsets& o, int wave) {
+        if constexpr (PRELOAD3) {
+#pragma unroll
+            for (int j = 0; j < 2 * MT; ++j)
+#pragma unroll
+                for (int ks = 0; ks < KC; ++ks) c.c3[j][ks] = wb.at_g(o.dft3 + (j * KC + ks) * 64);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) c.c4[ks] = wb.at_g(o.dft4 + (wave * 8 + ks) * 64);
+    }
+
+    // xw[N] (windowed frame) -> X = {Re[N/2], Im[N/2]} (bins 0 .. N/2-1), followed by a barrier.
+    // nyq != nullptr: also store bin N/2 there (debug dump only; for N1 = 32 it costs an extra reduction).
+    __device__ static __forceinline__ void forward(const float* xw, float* X, const float2* tw, const FwdConst& c,
+                                                   int wave, int lane, float* nyq) {
+        const int li = lane & 15, lg = lane >> 4, p = wave >> 1, jt = wave & 1, k2 = 16 * jt + li;
+        f32x4 g[MT][2];                                  // [.][0] = Re G, [.][1] = Im G, rows 16 i + 4 lg + r, column k2
+        acc_init_zero<MT, 2>(g);
+        mma_panel<MT, 2, 8>(g, [&](int i, int ks) { return xw[16 * i + li + N1 * (4 * ks + lg)]; },
+                            [&](int a2, int ks) { return c.c1[a2][ks]; }, NoSide{});
+        float gq[KC];                                    // k-step a * 4 MT + 4 i + r of the second stage
+        float2 tq[MT][4];                                // (twiddles fetched together, ahead of the panel's results)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tq[i][r] = twid(tw, (16 * i + 4 * lg + r) * k2);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float2 t = tq[i][r];
+                const float gr = g[i][0][r], gi = g[i][1][r];
+                gq[4 * i + r] = gr * t.x - gi * t.y;
+                gq[4 * MT + 4 * i + r] = gi * t.x + gr * t.y;
+            }
+        f32x4 e0 = {0.0f, 0.0f, 0.0f, 0.0f}, e1 = e0;    // two chains (dependent-MFMA latency is 40 cycles, issue 32)
+#pragma unroll
+        for (int ks = 0; ks < KC / 2; ++ks) {
+            e0 = FE_MFMA(c.c2[ks], gq[ks], e0);
+            e1 = FE_MFMA(c.c2[KC / 2 + ks], gq[KC / 2 + ks], e1);
+        }
+        float* Xp = X + p * (N / 2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k1 = 4 * lg + r;
+            if (k1 < N1 / 2) Xp[32 * k1 + k2] = e0[r] + e1[r];
+        }
+        if (nyq != nullptr && wave == 0) {
+            if constexpr (N1 == 16) {
+                if (lane == 32) { nyq[0] = e0[0] + e1[0]; nyq[1] = 0.0f; }       // k1 = 8, k2 = 0
+            } else {                                     // X[N/2] = sum (-1)^n x[n]
+                float sgn = 0.0f;
+                for (int n = lane; n < N; n += 64) sgn += (n & 1) ? -xw[n] : xw[n];
+                for (int d = 32; d >= 1; d >>= 1) sgn += __shfl_xor(sgn, d);
+                if (lane == 0) { nyq[0] = sgn; nyq[1] = 0.0f; }
+            }
+        }
+        __syncthreads();
+    }
+
+    // Y = {Re[N/2], Im[N/2]} (bins 0 .. N/2-1, bin N/2 = 0, Im Y[0] ignored) -> y[n] = P0[pidx] + P1[pidx]
+    // (P_jt = the partial sum over this wave pair's k2 tile), followed by a barrier.
+    template <class WS>
+    __device__ static __forceinline__ void inverse(const float* Y, float* P0, float* P1, const float2* tw, const InvConst& c,
+                                                   const WS& wb, const PackedOffsets& o, int wave, int lane) {
+        const int li = lane & 15, lg = lane >> 4, p = wave >> 1, jt = wave & 1, k2 = 16 * jt + li;
+        // first stage, transposed: H^T[k2][n1] = sum Y^T[k2][(b, k1)] C[(b, k1)][n1], both halves (columns j = q * MT + i)
+        float yq[KC];
+#pragma unroll
+        for (int ks = 0; ks < KC; ++ks) {
+            const int kl = 4 * ks + lg, b = kl / N1, k1 = kl % N1;
+            const int kk = 32 * k1 + k2;
+            const int m = kk <= N / 2 ? kk : N - kk;
+            const bool ok = m < N / 2;
+            const int mm = ok ? m : 0;
+            float v = Y[b * (N / 2) + mm];
+            if (b == 1) v = (kk > N / 2) ? -v : ((m == 0) ? 0.0f : v);
+            yq[ks] = ok ? v : 0.0f;
+        }
+        f32x4 h[1][2 * MT];
+        acc_init_zero<1, 2 * MT>(h);
+        mma_panel<1, 2 * MT, KC>(h, [&](int, int ks) { return yq[ks]; },
+                                 [&](int j, int ks) {
+                                     if constexpr (PRELOAD3) return c.c3[j][ks];
+                                     else return wb.at_g(o.dft3 + (j * KC + ks) * 64);
+                                 }, NoSide{});
+        // twiddle: element (k2' = 16 jt + 4 lg + r, n1 = 16 i + li) times conj(W_N^(n1 k2'))
+        float hq[MT][2][4];
+        float2 tq[MT][4];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tq[i][r] = twid(tw, (16 * i + li) * (16 * jt + 4 * lg + r));
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float2 t = tq[i][r];
+                const float hr = h[0][i][r], hi = h[0][MT + i][r];
+                hq[i][0][r] = hr * t.x + hi * t.y;
+                hq[i][1][r] = hi * t.x - hr * t.y;
+            }
+        // second stage: this wave's k2 tile (both halves, k-step a * 4 + r) x the n2 tile p
+        float* P = jt ? P1 : P0;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            f32x4 e0 = {0.0f, 0.0f, 0.0f, 0.0f}, e1 = e0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e0 = FE_MFMA(hq[i][0][r], c.c4[r], e0);
+                e1 = FE_MFMA(hq[i][1][r], c.c4[4 + r], e1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[pidx(16 * i + 4 * lg + r, 16 * p + li)] = e0[r] + e1[r];
+        }
+        __syncthreads();
+    }
+};
 
 // ------------------------------------------------------------------------------------------
 // conv-layout GEMM segment: this wave's m-tiles (wave + 4*i) x all NT n-tiles, K = 4*KS.
@@ -791,42 +956,88 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         FE_CLK(0);
         // =========================== STFT (a3) ===========================
         const int mode = a.mode;
+        // LDS quarters of the FFT arena (N floats each): q0 windowed frame, q1 raw frame (cache shift), q3 spectrum
+        // {Re[N/2], Im[N/2]};  iSTFT: q3 spectrum -> q0, q1 partial sums of y -> q2 windowed / overlap-added frame
+        float* q0 = reinterpret_cast<float*>(fa);
+        float* q1 = q0 + N;
+        float* q2 = reinterpret_cast<float*>(fb);
+        float* q3 = q2 + N;
+        // matrix-core DFT for N = 512; N = 1024 keeps the radix-2 LDS FFT (there the 128 MFMAs per frame and the
+        // 64 + 32 constant fragments per wave cost more - registers, spills - than the 20 radix-2 stages: measured
+        // 48 kHz FastEnhancer_B 82 -> 91 us)
+        constexpr bool MDFT = (N == 512);
+        constexpr int XS = MDFT ? 1 : 2;                 // element stride of the spectrum arrays below
+        const float* Xr = nullptr;
+        const float* Xi = nullptr;
         if (mode != FE_MODE_SPEC) {
+            typename Dft<S>::FwdConst dc;
+            if constexpr (MDFT) Dft<S>::load(dc, wb, o, wave);            // in flight while the frame is fetched
             const float* win = wp + o.window;
+            constexpr int NPT = N / kThreads;              // samples per thread; all global loads are issued before the
+            float fv[NPT], fw[NPT];                        // first LDS store (one memory round trip, not NPT)
             if (mode == FE_MODE_STREAM) {
                 const float* xin = a.wav_in + (size_t)b * a.in_stride + (size_t)t * H;
-                for (int n = tid; n < N; n += kThreads) {
-                    float v = (n < OVL) ? cst[n] : xin[n - OVL];
-                    fb[n] = make_float2(v, 0.0f);          // raw frame kept in fb.x for the cache shift
-                    fa[n] = make_float2(v * win[n], 0.0f);
+#pragma unroll
+                for (int q = 0; q < NPT; ++q) {
+                    const int n = tid + q * kThreads;
+                    fv[q] = (n < OVL) ? cst[n] : xin[n - OVL];
+                    fw[q] = win[n];
+                }
+#pragma unroll
+                for (int q = 0; q < NPT; ++q) {
+                    const int n = tid + q * kThreads;
+                    if constexpr (MDFT) {
+                        q1[n] = fv[q];                     // raw frame kept for the cache shift
+                        q0[n] = fv[q] * fw[q];
+                    } else {
+                        fb[n] = make_float2(fv[q], 0.0f);
+                        fa[n] = make_float2(fv[q] * fw[q], 0.0f);
+                    }
                 }
             } else {
                 // torch.stft(center=True, pad_mode="reflect") (functional/audio_modules.py:78-80): frame t covers
                 // xp[tH : tH+N], xp = reflect_pad(x, N/2)
                 const float* xin = a.wav_in + (size_t)b * a.in_stride;
-                for (int n = tid; n < N; n += kThreads) {
+#pragma unroll
+                for (int q = 0; q < NPT; ++q) {
+                    const int n = tid + q * kThreads;
                     int idx = t * H + n - N / 2;
                     idx = idx < 0 ? -idx : idx;
                     idx = idx >= a.Tw ? 2 * (a.Tw - 1) - idx : idx;
-                    fa[n] = make_float2(xin[idx] * win[n], 0.0f);
+                    fv[q] = xin[idx];
+                    fw[q] = win[n];
+                }
+#pragma unroll
+                for (int q = 0; q < NPT; ++q) {
+                    if constexpr (MDFT) q0[tid + q * kThreads] = fv[q] * fw[q];
+                    else fa[tid + q * kThreads] = make_float2(fv[q] * fw[q], 0.0f);
                 }
             }
             __syncthreads();
             if (mode == FE_MODE_STREAM) {
-                for (int m = tid; m < OVL; m += kThreads) cst[m] = fb[m + H].x;   // cache' = frame[H:]
-                __syncthreads();
+                for (int m = tid; m < OVL; m += kThreads) cst[m] = MDFT ? q1[m + H] : fb[m + H].x;   // cache' = frame[H:]
+                if constexpr (!MDFT) __syncthreads();       // (the FFT's first stage overwrites fb)
             }
             FE_CLK(1);
-            float2* X = fft_lds<S, false>(fa, fb, tw);
+            if constexpr (MDFT) {
+                float* nyq = a.dbg ? a.dbg + (size_t)b * a.dbg_stride + DebugLayout<S>::offset(0) + 2 * F0 : nullptr;
+                Dft<S>::forward(q0, q3, tw, dc, wave, lane, nyq);
+                Xr = q3;
+                Xi = q3 + N / 2;
+            } else {
+                const float2* X = fft_lds<S, false>(fa, fb, tw);
+                Xr = &X[0].x;
+                Xi = &X[0].y;
+            }
             FE_CLK(2);
             // spectrum bins 0..F0 (F0 = Nyquist, dropped by the model)
             if (a.dbg) {
                 float* dst = a.dbg + (size_t)b * a.dbg_stride + DebugLayout<S>::offset(0);
-                for (int f = tid; f <= F0; f += kThreads) { dst[2 * f] = X[f].x; dst[2 * f + 1] = X[f].y; }
+                for (int f = tid; f < F0 + (MDFT ? 0 : 1); f += kThreads) { dst[2 * f] = Xr[f * XS]; dst[2 * f + 1] = Xi[f * XS]; }
             }
             // =========================== compress (a4) ===========================
             for (int f = tid; f < F0; f += kThreads) {
-                float re = X[f].x, im = X[f].y;
+                float re = Xr[f * XS], im = Xi[f * XS];
                 float mag = fmaxf(sqrtf(re * re + im * im), 1.0e-5f);
                 float g = pow_f(mag, a.compression - 1.0f);
                 sc[2 + f] = re * g;
@@ -1335,6 +1546,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         __syncthreads();
 
         FE_CLK(10);
+        typename Dft<S>::InvConst idc;
+        if constexpr (MDFT) Dft<S>::load(idc, wb, o, wave);        // iSTFT constants, in flight during the mask phase
         // =========================== mask, un-compress (a16, a17), Hermitian spectrum ===========================
         {
             const float b0 = wb.scalar(o.post_t_b), b1 = wb.scalar(o.post_t_b + 1);
@@ -1369,7 +1582,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     spo[((size_t)f * a.T + t) * 2 + 1] = yi;
                     if (f == 0) { spo[((size_t)F0 * a.T + t) * 2] = 0.0f; spo[((size_t)F0 * a.T + t) * 2 + 1] = 0.0f; }
                 } else {
-                    if (f == 0) {
+                    if constexpr (MDFT) {
+                        q3[f] = yr;                  // (irfft ignores Im X[0]; the zero-padded Nyquist bin and the Hermitian
+                        q3[N / 2 + f] = yi;          //  upper half are implied by Dft<S>::inverse)
+                    } else if (f == 0) {
                         fa[0] = make_float2(yr, 0.0f);       // irfft ignores Im X[0]
                         fa[F0] = make_float2(0.0f, 0.0f);    // zero-padded Nyquist bin
                     } else {
@@ -1384,17 +1600,37 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         FE_CLK(11);
         // =========================== iSTFT (a18) ===========================
         if (mode != FE_MODE_SPEC) {
-            float2* y = fft_lds<S, true>(fa, fb, tw);
-            FE_CLK(12);
-            float2* spare = (y == fa) ? fb : fa;
             // streaming: synthesis window w / sum_k w^2 (steady state); offline: plain w, normalised below
             const float* wi = wp + (mode == FE_MODE_STREAM ? o.window_istft : o.window);
-            float* xo = reinterpret_cast<float*>(spare);
-            const float invN = 1.0f / (float)N;
-            for (int n = tid; n < N; n += kThreads) {
-                float v = y[n].x * invN * wi[n];
-                if (n < OVL) v += cis[n];
-                xo[n] = v;
+            constexpr int NPT = N / kThreads;
+            float ow[NPT], oc[NPT];                        // window / overlap tail: fetched across the inverse DFT
+#pragma unroll
+            for (int q = 0; q < NPT; ++q) {
+                const int n = tid + q * kThreads;
+                ow[q] = wi[n];
+                oc[q] = n < OVL ? cis[n] : 0.0f;
+            }
+            float* xo;
+            if constexpr (MDFT) {
+                Dft<S>::inverse(q3, q0, q1, tw, idc, wb, o, wave, lane);
+                FE_CLK(12);
+                xo = q2;
+#pragma unroll
+                for (int q = 0; q < NPT; ++q) {
+                    const int n = tid + q * kThreads;
+                    const int pi = Dft<S>::pidx(n & (Dft<S>::N1 - 1), n / Dft<S>::N1);
+                    xo[n] = (q0[pi] + q1[pi]) * ow[q] + oc[q];
+                }
+            } else {
+                const float2* y = fft_lds<S, true>(fa, fb, tw);
+                FE_CLK(12);
+                xo = reinterpret_cast<float*>((y == fa) ? fb : fa);
+                const float invN = 1.0f / (float)N;
+#pragma unroll
+                for (int q = 0; q < NPT; ++q) {
+                    const int n = tid + q * kThreads;
+                    xo[n] = y[n].x * invN * ow[q] + oc[q];
+                }
             }
             __syncthreads();
             if (mode == FE_MODE_STREAM) {
