@@ -20,18 +20,24 @@ struct Impl {
     void (*dbg_stage)(int, int*, int*, size_t*);
 };
 
-template <class S>
-void launch_impl(const FrameArgs& a, hipStream_t st, hipError_t* err) {
+template <class S, bool DBG>
+void launch_one(const FrameArgs& a, hipStream_t st, hipError_t* err) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fe_frame_kernel<S>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fe_frame_kernel<S, DBG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds<S>::BYTES);
         if (e != hipSuccess) { *err = e; return; }
         attr_set = true;
     }
     dim3 grid(a.B), block(kThreads);
-    hipLaunchKernelGGL((fe_frame_kernel<S>), grid, block, Lds<S>::BYTES, st, a);
+    hipLaunchKernelGGL((fe_frame_kernel<S, DBG>), grid, block, Lds<S>::BYTES, st, a);
     *err = hipGetLastError();
+}
+
+template <class S>
+void launch_impl(const FrameArgs& a, hipStream_t st, hipError_t* err) {
+    if (a.dbg != nullptr || a.clk != nullptr) launch_one<S, true>(a, st, err);     // fe_debug_step / fe_profile_step
+    else launch_one<S, false>(a, st, err);
 }
 
 template <class S>

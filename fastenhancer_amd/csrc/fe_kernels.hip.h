@@ -861,8 +861,12 @@ __device__ __forceinline__ void tok_gemm_w(f32x4 (&acc)[S::MT2][NTPW], const flo
 //                        FE_MODE_SPEC    spec->spec step (model.py:677-710)
 //                        FE_MODE_OFFLINE Model.forward (model.py:728-735): centered STFT of the whole signal,
 //                                        zero initial GRU state, torch.istft-style normalised overlap-add
-template <class S>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) fe_frame_kernel(FrameArgs a) {
+// DBG = false (the production instantiation): the per-stage debug dumps and cycle probes are compiled out - they
+// cost a scalar test + branch each (~40 per frame) and keep their pointers alive in SGPRs for the whole kernel.
+template <class S, bool DBG>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) fe_frame_kernel(FrameArgs a_in) {
+    FrameArgs a = a_in;
+    if constexpr (!DBG) { a.dbg = nullptr; a.clk = nullptr; }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = Lds<S>;
     constexpr int N = S::NFFT, H = S::HOP, OVL = S::OVL, F0 = S::F0, F1 = S::F1;
