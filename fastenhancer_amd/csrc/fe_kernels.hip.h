@@ -863,10 +863,14 @@ __device__ __forceinline__ void tok_gemm_w(f32x4 (&acc)[S::MT2][NTPW], const flo
 //                                        zero initial GRU state, torch.istft-style normalised overlap-add
 // DBG = false (the production instantiation): the per-stage debug dumps and cycle probes are compiled out - they
 // cost a scalar test + branch each (~40 per frame) and keep their pointers alive in SGPRs for the whole kernel.
-template <class S, bool DBG>
+// MODE >= 0: the mode is a compile-time constant (the streaming step gets its own instantiation, without the
+// spec / offline branches and their arguments); MODE = -1: a.mode decides at run time.
+template <class S, bool DBG, int MODE>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) fe_frame_kernel(FrameArgs a_in) {
     FrameArgs a = a_in;
     if constexpr (!DBG) { a.dbg = nullptr; a.clk = nullptr; }
+    if constexpr (MODE >= 0) a.mode = MODE;
+    if constexpr (MODE == FE_MODE_STREAM) { a.spec_in = nullptr; a.spec_out = nullptr; a.Tw = 0; }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = Lds<S>;
     constexpr int N = S::NFFT, H = S::HOP, OVL = S::OVL, F0 = S::F0, F1 = S::F1;
