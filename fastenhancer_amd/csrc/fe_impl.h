@@ -20,25 +20,25 @@ struct Impl {
     void (*dbg_stage)(int, int*, int*, size_t*);
 };
 
-template <class S, bool DBG, int MODE>
+template <class S, bool DBG, int MODE, bool T1>
 void launch_one(const FrameArgs& a, hipStream_t st, hipError_t* err) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fe_frame_kernel<S, DBG, MODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fe_frame_kernel<S, DBG, MODE, T1>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds<S>::BYTES);
         if (e != hipSuccess) { *err = e; return; }
         attr_set = true;
     }
     dim3 grid(a.B), block(kThreads);
-    hipLaunchKernelGGL((fe_frame_kernel<S, DBG, MODE>), grid, block, Lds<S>::BYTES, st, a);
+    hipLaunchKernelGGL((fe_frame_kernel<S, DBG, MODE, T1>), grid, block, Lds<S>::BYTES, st, a);
     *err = hipGetLastError();
 }
 
 template <class S>
 void launch_impl(const FrameArgs& a, hipStream_t st, hipError_t* err) {
-    if (a.dbg != nullptr || a.clk != nullptr) launch_one<S, true, -1>(a, st, err);     // fe_debug_step / fe_profile_step
-    else if (a.mode == FE_MODE_STREAM) launch_one<S, false, FE_MODE_STREAM>(a, st, err);   // the hot path
-    else launch_one<S, false, -1>(a, st, err);                                          // fe_spec_step / fe_offline
+    if (a.dbg != nullptr || a.clk != nullptr) launch_one<S, true, -1, false>(a, st, err);     // fe_debug_step / fe_profile_step
+    else if (a.mode == FE_MODE_STREAM && a.T == 1) launch_one<S, false, FE_MODE_STREAM, true>(a, st, err);   // the per-hop hot path
+    else launch_one<S, false, -1, false>(a, st, err);                             // chunked streaming, fe_spec_step, fe_offline
 }
 
 template <class S>

@@ -863,14 +863,16 @@ __device__ __forceinline__ void tok_gemm_w(f32x4 (&acc)[S::MT2][NTPW], const flo
 //                                        zero initial GRU state, torch.istft-style normalised overlap-add
 // DBG = false (the production instantiation): the per-stage debug dumps and cycle probes are compiled out - they
 // cost a scalar test + branch each (~40 per frame) and keep their pointers alive in SGPRs for the whole kernel.
-// MODE >= 0: the mode is a compile-time constant (the streaming step gets its own instantiation, without the
+// T1: a.T == 1 is a compile-time fact.  MODE >= 0: the mode is a compile-time constant (the streaming step gets its own instantiation, without the
 // spec / offline branches and their arguments); MODE = -1: a.mode decides at run time.
-template <class S, bool DBG, int MODE>
+template <class S, bool DBG, int MODE, bool T1>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) fe_frame_kernel(FrameArgs a_in) {
     FrameArgs a = a_in;
     if constexpr (!DBG) { a.dbg = nullptr; a.clk = nullptr; }
     if constexpr (MODE >= 0) a.mode = MODE;
     if constexpr (MODE == FE_MODE_STREAM) { a.spec_in = nullptr; a.spec_out = nullptr; a.Tw = 0; }
+    if constexpr (T1) a.T = 1;                       // one hop per launch (the per-hop driver loop): no frame loop, and the
+                                                     // last GEMM phase does not stage weights for a next frame
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = Lds<S>;
     constexpr int N = S::NFFT, H = S::HOP, OVL = S::OVL, F0 = S::F0, F1 = S::F1;
@@ -969,7 +971,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             wb.lds = smem + (slot_ ? L::WB1 : L::WB0);                                             \
             wb.base = o.u_off[(U)];                                                                \
         }                                                                                          \
-        const StageSide<NPW, L::STAGED ? o.u_size[fe_un_] / 256 : 0> stage{&job}
+        const StageSide<NPW, (L::STAGED && !(T1 && (U) + 1 == S::NU)) ? o.u_size[fe_un_] / 256 : 0> stage{&job}
         FE_CLK(0);
         // =========================== STFT (a3) ===========================
         const int mode = a.mode;
