@@ -76,8 +76,10 @@ struct BLds {
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
 };
 
-template <class S>
+// HOT: the per-hop streaming step (mode and T = 1 are compile-time facts: no frame loop, no spec / offline branches)
+template <class S, bool HOT>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) bsrnn_frame_kernel(BArgs a) {
+    const int aT = HOT ? 1 : a.T;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = BLds<S>;
     constexpr int N = S::NFFT, H = S::HOP, OVL = S::OVL, C = S::C, HH = S::HH, G4 = S::G4;
@@ -111,7 +113,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 
     float* cst = a.cache_stft + (size_t)b * OVL;
     float* cis = a.cache_istft + (size_t)b * OVL;
-    const int mode = a.mode;
+    const int mode = HOT ? FE_MODE_STREAM : a.mode;
     // band of each bin (for the mask decoder's row bookkeeping): bin f -> band start / width
     auto band_of = [&](int f, int& start, int& sub) {
         int s0 = 0;
@@ -126,7 +128,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     };
 
 #pragma unroll 1
-    for (int t = 0; t < a.T; ++t) {
+    for (int t = 0; t < aT; ++t) {
         // ============================ STFT + compress (all 257 bins; models/bsrnn/model.py:430-436) ============================
         if (mode != FE_MODE_SPEC) {
             const float* win = wp + o.window;
@@ -159,9 +161,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 sp[2 * f + 1] = im * g;
             }
         } else {
-            const float* si = a.spec_in + (size_t)b * kBins * a.T * 2;
+            const float* si = a.spec_in + (size_t)b * kBins * aT * 2;
             for (int f = tid; f < kBins; f += kThreads) {
-                const float re = si[((size_t)f * a.T + t) * 2], im = si[((size_t)f * a.T + t) * 2 + 1];
+                const float re = si[((size_t)f * aT + t) * 2], im = si[((size_t)f * aT + t) * 2 + 1];
                 const float g = pow_f(fmaxf(sqrtf(re * re + im * im), 1.0e-5f), a.compression - 1.0f);
                 sp[2 * f] = re * g;
                 sp[2 * f + 1] = im * g;
@@ -369,20 +371,20 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 MR[f * 4 + kind * 2 + 1] = va1 * (1.0f / (1.0f + expf(-vb1)));
             }
             __syncthreads();
-            float* spo = mode == FE_MODE_SPEC ? a.spec_out + (size_t)b * kBins * a.T * 2 : nullptr;
-            float* sph = mode == FE_MODE_OFFLINE ? a.spec_out + (size_t)b * kBins * a.T * 2 : nullptr;
+            float* spo = mode == FE_MODE_SPEC ? a.spec_out + (size_t)b * kBins * aT * 2 : nullptr;
+            float* sph = mode == FE_MODE_OFFLINE ? a.spec_out + (size_t)b * kBins * aT * 2 : nullptr;
             for (int f = tid; f < kBins; f += kThreads) {
                 const float xr = sp[2 * f], xi = sp[2 * f + 1];
                 const float* mr = MR + f * 4;
                 float yr = xr * mr[0] - xi * mr[1] + mr[2];             // spec * mask + residual (:393-401)
                 float yi = xr * mr[1] + xi * mr[0] + mr[3];
-                if (sph != nullptr) { sph[((size_t)f * a.T + t) * 2] = yr; sph[((size_t)f * a.T + t) * 2 + 1] = yi; }
+                if (sph != nullptr) { sph[((size_t)f * aT + t) * 2] = yr; sph[((size_t)f * aT + t) * 2 + 1] = yi; }
                 const float g = pow_f(sqrtf(yr * yr + yi * yi), 1.0f / a.compression - 1.0f);
                 yr *= g;
                 yi *= g;
                 if (mode == FE_MODE_SPEC) {
-                    spo[((size_t)f * a.T + t) * 2] = yr;
-                    spo[((size_t)f * a.T + t) * 2 + 1] = yi;
+                    spo[((size_t)f * aT + t) * 2] = yr;
+                    spo[((size_t)f * aT + t) * 2 + 1] = yi;
                 } else if (f == 0) {
                     fa[0] = make_float2(yr, 0.0f);
                 } else if (f == N / 2) {
@@ -413,8 +415,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 for (int n = tid; n < H; n += kThreads) out[n] = xo[n];
             } else {
                 const float* w = wp + o.window;
-                const int n_out = H * (a.T - 1);
-                const int emit = (t == a.T - 1) ? N : H;
+                const int n_out = H * (aT - 1);
+                const int emit = (t == aT - 1) ? N : H;
                 float* out = a.wav_out + (size_t)b * a.out_stride;
                 for (int j = tid; j < emit; j += kThreads) {
                     const int n = t * H + j, pos = n - N / 2;
@@ -422,7 +424,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                         int t_lo = (n - N + H) / H;
                         t_lo = t_lo < 0 ? 0 : t_lo;
                         int t_hi = n / H;
-                        t_hi = t_hi > a.T - 1 ? a.T - 1 : t_hi;
+                        t_hi = t_hi > aT - 1 ? aT - 1 : t_hi;
                         float env = 0.0f;
                         for (int tt = t_lo; tt <= t_hi; ++tt) { const float wv = w[n - tt * H]; env += wv * wv; }
                         out[pos] = xo[j] / env;
@@ -441,17 +443,23 @@ struct BImpl {
     void (*launch)(const BArgs&, hipStream_t, hipError_t*);
 };
 
-template <class S>
-void blaunch_impl(const BArgs& a, hipStream_t st, hipError_t* err) {
+template <class S, bool HOT>
+void blaunch_one(const BArgs& a, hipStream_t st, hipError_t* err) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bsrnn_frame_kernel<S>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bsrnn_frame_kernel<S, HOT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)BLds<S>::BYTES);
         if (e != hipSuccess) { *err = e; return; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((bsrnn_frame_kernel<S>), dim3(a.B), dim3(kThreads), BLds<S>::BYTES, st, a);
+    hipLaunchKernelGGL((bsrnn_frame_kernel<S, HOT>), dim3(a.B), dim3(kThreads), BLds<S>::BYTES, st, a);
     *err = hipGetLastError();
+}
+
+template <class S>
+void blaunch_impl(const BArgs& a, hipStream_t st, hipError_t* err) {
+    if (a.mode == FE_MODE_STREAM && a.T == 1) blaunch_one<S, true>(a, st, err);
+    else blaunch_one<S, false>(a, st, err);
 }
 
 template <class S>

@@ -324,7 +324,11 @@ def test_bsrnn_batch_and_chunk_vs_oracle(name):
     s1, s2 = eng.new_state(B), eng.new_state(B)
     y1 = eng.step(xd, s1, T=T)
     y2 = torch.cat([eng.step(xd[:, t * H:(t + 1) * H], s2, T=1) for t in range(T)], dim=1)
-    assert torch.equal(y1, y2) and torch.equal(s1, s2)
+    # chunked launch (generic instantiation) vs per-hop launches (the T = 1 instantiation of the same kernel): the two
+    # are compiled separately, so allow fp32 re-association noise (they are identical to ~1e-6; parity with the oracle
+    # below is the real check)
+    assert float((y1 - y2).abs().max()) <= 2e-6 * max(1.0, float(y1.abs().max())), float((y1 - y2).abs().max())
+    assert float((s1 - s2).abs().max()) <= 2e-6 * max(1.0, float(s1.abs().max())), float((s1 - s2).abs().max())
     caches = orc.initialize_cache(B)
     refs = []
     for t in range(T):
