@@ -1221,8 +1221,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 
         FE_CLK(6);
         // =========================== RNNFormer blocks (a9-a11) ===========================
-#pragma unroll 1
-        for (int k = 0; k < S::KB; ++k) {      // (not unrolled: keeps register pressure and code size down)
+        // small shapes: unrolled (block-0 special cases and every weight offset fold to constants; the per-hop
+        // FastEnhancer_B kernel drops from 256 to 174 VGPRs); big shapes: rolled, for register pressure and code size
+#pragma unroll (S::C1 <= 48 ? S::KB : 1)
+        for (int k = 0; k < S::KB; ++k) {
             float* hg = a.h + ((size_t)k * a.B + b) * (F2 * C2);
             const int kb = k * o.blk_stride;
             if (k == 0) FE_CLK(20);
