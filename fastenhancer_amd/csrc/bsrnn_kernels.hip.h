@@ -57,6 +57,7 @@ struct BArgs {
     float* spec_out;
     int B, T, mode, Tw;
     float compression;
+    unsigned long long* clk;  // fe_profile_step: cycle probes of workgroup 0 (PROF instantiation only)
 };
 
 template <class S>
@@ -77,7 +78,9 @@ struct BLds {
 };
 
 // HOT: the per-hop streaming step (mode and T = 1 are compile-time facts: no frame loop, no spec / offline branches)
-template <class S, bool HOT>
+#define BE_CLK(i) do { if constexpr (PROF) { if (blockIdx.x == 0 && threadIdx.x == 0) a.clk[(i)] = __builtin_readcyclecounter(); } } while (0)
+// PROF: cycle probes per phase (fe_profile_step, tools/gpu_phases_bsrnn.py)
+template <class S, bool HOT, bool PROF>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) bsrnn_frame_kernel(BArgs a) {
     const int aT = HOT ? 1 : a.T;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -129,6 +132,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 
 #pragma unroll 1
     for (int t = 0; t < aT; ++t) {
+        BE_CLK(0);
         // ============================ STFT + compress (all 257 bins; models/bsrnn/model.py:430-436) ============================
         if (mode != FE_MODE_SPEC) {
             const float* win = wp + o.window;
@@ -171,6 +175,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         }
         __syncthreads();
 
+        BE_CLK(1);
         // ============================ band split (BandSplit.forward, :136-153; BN folded) ============================
         for (int i = tid; i < kBands * C; i += kThreads) {
             const int bb = i / C, c = i - bb * C;
@@ -188,6 +193,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         for (int l = 0; l < S::NLAY; ++l) {
             float* hg = a.lstm + ((size_t)(2 * l) * a.B + b) * (kBands * HH);
             float* cg = a.lstm + ((size_t)(2 * l + 1) * a.B + b) * (kBands * HH);
+            if (l == 0) BE_CLK(2);
             // ---------------- time LSTM (LSTMCell over the 31 bands; :371-381): h -> LDS
             for (int i = tid; i < kBands * HH; i += kThreads) { const int r = i / HH; Hs[r * LDH + (i - r * HH)] = hg[i]; }
             __syncthreads();
@@ -226,6 +232,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 }
             }
             __syncthreads();
+            if (l == 0) BE_CLK(3);
             {
                 // fc_time + residual (:382-384): X += Hn W^T + b
                 constexpr int NITEM = 2 * S::NTC;
@@ -247,6 +254,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             }
             __syncthreads();
             {
+                if (l == 0) BE_CLK(4);
                 // ---------------- band LSTM (:386-390): input projections of all 31 bands, both directions
                 constexpr int NTP = 2 * (G4 / 16);       // n-tiles: direction-major
 #pragma unroll 1
@@ -281,6 +289,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             }
             if (tid < 4 * HH) Hb[tid] = 0.0f;                    // h = 0 for both directions, both buffers
             __syncthreads();
+            if (l == 0) BE_CLK(5);
 #pragma unroll 1
             for (int s = 0; s < kBands; ++s) {
                 const int band = d == 0 ? s : kBands - 1 - s;
@@ -289,13 +298,18 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll
                 for (int rr = 0; rr < S::RPT; ++rr) {
                     const int j = (q >> 2) + 32 * rr;
-                    float pre = XP[(d * 32 + band) * LDP + gate * HH + j];
                     const float4* hp4 = reinterpret_cast<const float4*>(hprev);      // broadcast reads, 16 B each
+                    // four partial sums: one serial chain of HH dependent FMAs per step is the recurrence's critical path
+                    float p0 = XP[(d * 32 + band) * LDP + gate * HH + j], p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
 #pragma unroll
                     for (int k = 0; k < HH / 4; ++k) {
                         const float4 hv = hp4[k];
-                        pre += wrow[rr][4 * k] * hv.x + wrow[rr][4 * k + 1] * hv.y + wrow[rr][4 * k + 2] * hv.z + wrow[rr][4 * k + 3] * hv.w;
+                        p0 += wrow[rr][4 * k] * hv.x;
+                        p1 += wrow[rr][4 * k + 1] * hv.y;
+                        p2 += wrow[rr][4 * k + 2] * hv.z;
+                        p3 += wrow[rr][4 * k + 3] * hv.w;
                     }
+                    const float pre = (p0 + p1) + (p2 + p3);
                     const float act = gate == 2 ? tanh_f(pre) : sigmoid_f(pre);
                     // the 4 gates of a unit sit in one quad: DPP quad_perm broadcasts (no LDS crossbar)
                     const int ai = __builtin_bit_cast(int, act);
@@ -313,6 +327,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 }
                 __syncthreads();
             }
+            if (l == 0) BE_CLK(6);
             {
                 // fc_freq + residual: X += Yf W^T + b
                 constexpr int NITEM = 2 * S::NTC;
@@ -333,8 +348,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 }
             }
             __syncthreads();
+            if (l == 0) BE_CLK(7);
         }
 
+        BE_CLK(8);
         // ============================ mask decoder (MaskDecoder.forward, :225-246) ============================
         for (int i = tid; i < 2 * kBands * 4 * C; i += kThreads) {
             const int kind = i / (kBands * 4 * C), rem = i - kind * (kBands * 4 * C);
@@ -343,9 +360,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             float acc = wp[o.m_b1[kind] + bb * 4 * C + oo];
 #pragma unroll 16
             for (int k = 0; k < C; ++k) acc += w[k * 4 * C] * X[bb * LDX + k];
-            H1[i] = tanhf(acc);
+            H1[i] = tanh_f(acc);
         }
         __syncthreads();
+        BE_CLK(9);
         {
             constexpr int R = 4 * kBins;            // rows of the second layers (1028)
             // item = (bin f, kind): GLU outputs (re, im) of that MLP for that bin -> MR[f][kind*2 + ri]  (reuses XP)
@@ -397,6 +415,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         }
         __syncthreads();
 
+        BE_CLK(10);
         // ============================ iSTFT (functional/audio_modules.py:259-303 / torch.istft) ============================
         if (mode != FE_MODE_SPEC) {
             float2* y = fft_lds<S, true>(fa, fb, tw);
@@ -434,6 +453,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             for (int m = tid; m < OVL; m += kThreads) cis[m] = xo[m + H];
             __syncthreads();
         }
+        BE_CLK(11);
     }
 }
 
@@ -443,23 +463,24 @@ struct BImpl {
     void (*launch)(const BArgs&, hipStream_t, hipError_t*);
 };
 
-template <class S, bool HOT>
+template <class S, bool HOT, bool PROF>
 void blaunch_one(const BArgs& a, hipStream_t st, hipError_t* err) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bsrnn_frame_kernel<S, HOT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bsrnn_frame_kernel<S, HOT, PROF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)BLds<S>::BYTES);
         if (e != hipSuccess) { *err = e; return; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((bsrnn_frame_kernel<S, HOT>), dim3(a.B), dim3(kThreads), BLds<S>::BYTES, st, a);
+    hipLaunchKernelGGL((bsrnn_frame_kernel<S, HOT, PROF>), dim3(a.B), dim3(kThreads), BLds<S>::BYTES, st, a);
     *err = hipGetLastError();
 }
 
 template <class S>
 void blaunch_impl(const BArgs& a, hipStream_t st, hipError_t* err) {
-    if (a.mode == FE_MODE_STREAM && a.T == 1) blaunch_one<S, true>(a, st, err);
-    else blaunch_one<S, false>(a, st, err);
+    if (a.clk != nullptr) blaunch_one<S, false, true>(a, st, err);                    // fe_profile_step
+    else if (a.mode == FE_MODE_STREAM && a.T == 1) blaunch_one<S, true, false>(a, st, err);
+    else blaunch_one<S, false, false>(a, st, err);
 }
 
 template <class S>

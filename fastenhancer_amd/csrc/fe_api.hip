@@ -622,8 +622,9 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
     if (in_stride < (size_t)T * d.HOP && B > 1) return fail(FE_ERR_INVALID_ARG, "in_stride %zu < T*H", in_stride);
     if (out_stride < (size_t)T * d.HOP && B > 1) return fail(FE_ERR_INVALID_ARG, "out_stride %zu < T*H", out_stride);
     if (h->bimpl) {
-        if (dbg || clk) return fail(FE_ERR_UNSUPPORTED_CONFIG, "debug / profile dumps are not built for BSRNN");
+        if (dbg) return fail(FE_ERR_UNSUPPORTED_CONFIG, "debug dumps are not built for BSRNN");
         fe::BArgs ba = bsrnn_args(h, B, T);
+        ba.clk = clk;
         const size_t ovl_b = (size_t)(d.NFFT - d.HOP);
         ba.mode = fe::FE_MODE_STREAM;
         ba.wav_in = wav_in; ba.wav_out = wav_out; ba.in_stride = in_stride; ba.out_stride = out_stride;
