@@ -954,10 +954,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     for (int t = 0; t < a.T; ++t) {
         // A loop-variant zero keeps the (many) wave-uniform offsets of a frame from being hoisted out of the frame
         // loop: hoisted, they sit in SGPRs for the whole kernel and spill to VGPR lanes by the hundred.
-        // (Measured: FastEnhancer_B 46.0 -> 44.1 us, T 21.2 -> 20.5 us; the big shapes lose - L 578 -> 627 us -
-        //  their frames re-derive far more offsets than they have SGPRs to save - so only the small ones do it.)
+        // (Measured on the kernels with a frame loop: FastEnhancer_B 46.0 -> 44.1 us per frame, T 21.2 -> 20.5 us,
+        //  S +29 %, M +1 %; L - whose frames re-derive far more offsets than it has SGPRs to save - loses 7 %.)
         int lz = 0;
-        if constexpr (S::C1 <= 48) asm volatile("" : "+s"(lz));
+        if constexpr (S::C1 <= 96) asm volatile("" : "+s"(lz));
         const int wave = wave0 + lz;
         // begin_unit(U): called right after the barrier that precedes the GEMM phase of staged unit U:
         // selects the LDS copy of this phase's weights and sets up the DMA job of the next unit.
