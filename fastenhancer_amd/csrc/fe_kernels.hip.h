@@ -1245,6 +1245,51 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                                 pe_r[i][j][r] = (row < F2 && col < C2) ? wb.gather_g(o.blk_pe + row * C2 + col) : 0.0f;
                             }
                 }
+                // Shapes with more than four column tiles and streamed weights (M: 5 tiles, L: 6): handing whole column
+                // tiles to the waves leaves them 2:1:1:1 / 2:2:1:1 loaded.  Their GRU phase - it writes only to LDS and
+                // the state, no register-resident residual - runs over (column tile, row-tile group) jobs instead,
+                // round-robin: 15 jobs -> 4:4:4:3, 12 jobs -> 3:3:3:3.
+                constexpr bool GBAL = !REGW && S::NT2 > 4;
+                if constexpr (GBAL) {
+                    constexpr int MG = (S::MT2 % 2 == 0 && (S::NT2 * (S::MT2 / 2)) % kWaves == 0) ? 2 : 1;   // row tiles per job
+                    constexpr int NMG = S::MT2 / MG, NJ = S::NT2 * NMG;
+                    const int wih = o.blk_wih[0] + kb, whh = o.blk_whh[0] + kb, bih = o.blk_bih[0] + kb, bhh = o.blk_bhh[0] + kb;
+#pragma unroll 1
+                    for (int q = wave; q < NJ; q += kWaves) {
+                        const int ct = q % S::NT2, m0 = (q / S::NT2) * MG;
+                        f32x4 ax[MG][3], ah[MG][3];
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            const float bi = wb.at_gv(bih + (g * S::NT2 + ct) * 16, wb.li4), bh = wb.at_gv(bhh + (g * S::NT2 + ct) * 16, wb.li4);
+#pragma unroll
+                            for (int i = 0; i < MG; ++i) { ax[i][g] = f32x4{bi, bi, bi, bi}; ah[i][g] = f32x4{bh, bh, bh, bh}; }
+                        }
+                        mma_panel<MG, 3, S::KS_2>(
+                            ax, [&](int i, int ks) { return Xb[(16 * (m0 + i) + li) * LDX + lg + 4 * ks]; },
+                            [&](int g, int ks) { return wb.at_g(wih + ((g * S::NT2 + ct) * S::KS_2 + ks) * 64); }, NoSide{});
+                        mma_panel<MG, 3, S::KS_2>(
+                            ah, [&](int i, int ks) { return Hs[(16 * (m0 + i) + li) * LDX + lg + 4 * ks]; },
+                            [&](int g, int ks) { return wb.at_g(whh + ((g * S::NT2 + ct) * S::KS_2 + ks) * 64); }, NoSide{});
+                        const int c = 16 * ct + li;
+                        if (c < C2) {
+#pragma unroll
+                            for (int i = 0; i < MG; ++i)
+                                if (16 * (m0 + i) + 4 * lg < F2) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const int row = 16 * (m0 + i) + 4 * lg + r;
+                                        const float rr = sigmoid_f(ax[i][0][r] + ah[i][0][r]);
+                                        const float zz = sigmoid_f(ax[i][1][r] + ah[i][1][r]);
+                                        const float nn = tanh_f(ax[i][2][r] + rr * ah[i][2][r]);
+                                        const float hp = Hs[row * LDX + c];
+                                        const float hn = (1.0f - zz) * nn + zz * hp;
+                                        Hl[row * LDX + c] = hn;
+                                        hg[row * C2 + c] = hn;
+                                    }
+                                }
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int j = 0; j < NTPW2; ++j) {
                     const int ct = wave + 4 * j;
