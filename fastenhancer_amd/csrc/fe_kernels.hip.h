@@ -767,6 +767,42 @@ __device__ __forceinline__ void conv_store(const f32x4 (&acc)[S::MTPW][NT], floa
         }
 }
 
+// Column-split conv GEMM for shapes whose conv weights are NOT staged in LDS and whose channel-tile count is a multiple
+// of 4 (S, L): this wave's NTC/4 column tiles x ALL row tiles.  Row-split, every wave streams every weight fragment
+// from L2 (4x redundant, 8 vector-memory loads per k-step for L); column-split, a wave's B fragments are private and the
+// shared operand is the activation tile in LDS (4 LDS + 2 L2 loads per k-step).  af(i, ks): A fragment of row tile i.
+template <class S, int KS, int NCOLS, int LDO, bool ACT, class AF, class WS, class SIDE>
+__device__ __forceinline__ void conv_nsplit(AF&& af, const WS& w, int w_off, int bias_off, const SIDE& side, float* out, int row0,
+                                            int wave, int lane, float* gskip) {
+    constexpr int MT = S::MTC, NTW = S::NTC / kWaves;
+    const int li = lane & 15, lg = lane >> 4;
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const float bj = w.at16(bias_off + (wave * NTW + j) * 16);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i][j] = f32x4{bj, bj, bj, bj};
+    }
+    mma_panel<MT, NTW, KS>(acc, af, [&](int j, int ks) { return w.at(w_off + ((wave * NTW + j) * KS + ks) * 64); }, side);
+    side.commit();
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int col = 16 * (wave * NTW + j) + li;
+            if (col < NCOLS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * i + 4 * lg + r;
+                    float v = acc[i][j][r];
+                    if (ACT) v = silu_f(v);
+                    out[(row0 + m) * LDO + col] = v;
+                    if (gskip != nullptr) gskip[(i * S::KS_C + (col >> 2)) * 64 + (col & 3) * 16 + 4 * lg + r] = v;
+                }
+            }
+        }
+}
+
 // token-layout GEMM: all MT2 m-tiles x this wave's n-tiles (wave + 4*j), A from LDS, B packed.
 template <class S, int NTPW, int KS, int LDA, class WS, class SIDE>
 __device__ __forceinline__ void tok_gemm(f32x4 (&acc)[S::MT2][NTPW], const float* a_lane, const WS& w, int w_off, int NT, int wave, const SIDE& side) {
@@ -914,6 +950,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     float2* fb = reinterpret_cast<float2*>(smem + L::FFT_B);
     float* Ebuf = smem + L::E;
     constexpr bool SG = !L::SKIPS_LDS;               // skips in the global scratch
+    constexpr bool NSPLIT = !L::STAGED && S::NTC % kWaves == 0;   // column-split conv GEMMs (see conv_nsplit)
     constexpr int SKIP_FLOATS = F1 * C1;             // one skip tensor in A-fragment order
     float* W0 = smem + L::W0;
     float* W1 = smem + L::W1;
@@ -1114,6 +1151,13 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             float* out = encbuf(l + 1);
             if (l == 0) FE_CLK(40);
             FE_BEGIN_UNIT(1 + l);
+            if constexpr (NSPLIT) {
+                const float* a0 = in + li * LDC + lg;
+                conv_nsplit<S, 3 * S::KS_C, C1, LDC, true>(
+                    [&](int i, int ks) { return a0[(16 * i + ks / S::KS_C) * LDC + 4 * (ks % S::KS_C)]; }, wb, o.enc_w[l], o.enc_b[l], stage,
+                    out, 1, wave, lane, SG ? skipg + (l + 1) * SKIP_FLOATS : nullptr);
+                if (l == 0) FE_CLK(41);
+            } else {
             f32x4 acc[S::MTPW][S::NTC];
             acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.enc_b[l], 0, 1, S::NTC);
             const float* const taps[3] = {in + (16 * wave + li + 0) * LDC + lg, in + (16 * wave + li + 1) * LDC + lg,
@@ -1123,6 +1167,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             if (l == 0) FE_CLK(41);
             stage.commit();
             conv_store<S, S::NTC, C1, LDC, true>(acc, out, 1, wave, lane, SG ? skipg + (l + 1) * SKIP_FLOATS : nullptr);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (l == 0) FE_CLK(42);
             __syncthreads();
@@ -1544,6 +1589,16 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             const float* skip = Ebuf + (S::NL - l) * S::ACT;   // (LDS-resident skips)
             {
                 FE_BEGIN_UNIT(5 + S::NL + 2 * l);
+                if constexpr (NSPLIT) {
+                    const float* xa0 = W0 + (li + 1) * LDC + lg;
+                    const float* sk0 = skip + (li + 1) * LDC + lg;
+                    conv_nsplit<S, 2 * S::KS_C, C1, LDC, true>(
+                        [&](int i, int ks) {
+                            if (ks < S::KS_C) return xa0[(16 * i) * LDC + 4 * ks];
+                            if constexpr (SG) return skb.at_g((S::NL - l) * SKIP_FLOATS + (i * S::KS_C + (ks - S::KS_C)) * 64);
+                            else return sk0[(16 * i) * LDC + 4 * (ks - S::KS_C)];
+                        }, wb, o.dec1_w[l], o.dec1_b[l], stage, W1, 1, wave, lane, nullptr);
+                } else {
                 f32x4 acc[S::MTPW][S::NTC];
                 acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.dec1_b[l], 0, 1, S::NTC);
                 if constexpr (!SG) {
@@ -1561,10 +1616,17 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 }
                 stage.commit();
                 conv_store<S, S::NTC, C1, LDC, true>(acc, W1, 1, wave, lane);
+                }
             }
             __syncthreads();
             {
                 FE_BEGIN_UNIT(6 + S::NL + 2 * l);
+                if constexpr (NSPLIT) {
+                    const float* a0 = W1 + li * LDC + lg;
+                    conv_nsplit<S, 3 * S::KS_C, C1, LDC, true>(
+                        [&](int i, int ks) { return a0[(16 * i + ks / S::KS_C) * LDC + 4 * (ks % S::KS_C)]; }, wb, o.dec3_w[l], o.dec3_b[l], stage,
+                        W0, 1, wave, lane, nullptr);
+                } else {
                 f32x4 acc[S::MTPW][S::NTC];
                 acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.dec3_b[l], 0, 1, S::NTC);
                 const float* const taps[3] = {W1 + (16 * wave + li + 0) * LDC + lg, W1 + (16 * wave + li + 1) * LDC + lg,
@@ -1572,6 +1634,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 conv_multi<S, S::NTC, 3, S::KS_C, LDC>(acc, taps, wb, o.dec3_w[l], stage);
                 stage.commit();
                 conv_store<S, S::NTC, C1, LDC, true>(acc, W0, 1, wave, lane);   // W0 was fully consumed before the barrier above
+                }
             }
             __syncthreads();
             dbg_dump<S>(a, b, 5 + S::NL + 2 * S::KB + l, W0 + LDC, LDC);
@@ -1582,6 +1645,16 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         float* PT = smem + L::PT;
         {
             FE_BEGIN_UNIT(5 + 3 * S::NL);
+            if constexpr (NSPLIT) {
+                const float* xa0 = W0 + (li + 1) * LDC + lg;
+                const float* sk0 = Ebuf + (li + 1) * LDC + lg;
+                conv_nsplit<S, 2 * S::KS_C, C1, LDC, true>(
+                    [&](int i, int ks) {
+                        if (ks < S::KS_C) return xa0[(16 * i) * LDC + 4 * ks];
+                        if constexpr (SG) return skb.at_g((i * S::KS_C + (ks - S::KS_C)) * 64);
+                        else return sk0[(16 * i) * LDC + 4 * (ks - S::KS_C)];
+                    }, wb, o.post1_w, o.post1_b, stage, W1, 1, wave, lane, nullptr);
+            } else {
             f32x4 acc[S::MTPW][S::NTC];
             acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.post1_b, 0, 1, S::NTC);
             if constexpr (!SG) {
@@ -1598,6 +1671,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             }
             stage.commit();
             conv_store<S, S::NTC, C1, LDC, true>(acc, W1, 1, wave, lane);
+            }
         }
         __syncthreads();
         {
