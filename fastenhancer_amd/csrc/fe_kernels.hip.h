@@ -771,30 +771,35 @@ __device__ __forceinline__ void conv_store(const f32x4 (&acc)[S::MTPW][NT], floa
 // of 4 (S, L): this wave's NTC/4 column tiles x ALL row tiles.  Row-split, every wave streams every weight fragment
 // from L2 (4x redundant, 8 vector-memory loads per k-step for L); column-split, a wave's B fragments are private and the
 // shared operand is the activation tile in LDS (4 LDS + 2 L2 loads per k-step).  af(i, ks): A fragment of row tile i.
-template <class S, int KS, int NCOLS, int LDO, bool ACT, class AF, class WS, class SIDE>
+// NS = 4: columns over the four waves; NS = 2 (6 channel tiles: M): a 2 x 2 split - wave (wm, wn) takes half the row
+// tiles x half the column tiles, weights 2x instead of 4x redundant.
+template <class S, int NS, int KS, int NCOLS, int LDO, bool ACT, class AF, class WS, class SIDE>
 __device__ __forceinline__ void conv_nsplit(AF&& af, const WS& w, int w_off, int bias_off, const SIDE& side, float* out, int row0,
                                             int wave, int lane, float* gskip) {
-    constexpr int MT = S::MTC, NTW = S::NTC / kWaves;
+    constexpr int MS = kWaves / NS, MT = S::MTC / MS, NTW = S::NTC / NS;
     const int li = lane & 15, lg = lane >> 4;
+    const int wn = NS == kWaves ? wave : wave % NS, m0 = NS == kWaves ? 0 : (wave / NS) * MT;   // (literals keep the offsets immediates)
     f32x4 acc[MT][NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
-        const float bj = w.at16(bias_off + (wave * NTW + j) * 16);
+        const float bj = w.at16(bias_off + (wn * NTW + j) * 16);
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[i][j] = f32x4{bj, bj, bj, bj};
     }
-    mma_panel<MT, NTW, KS>(acc, af, [&](int j, int ks) { return w.at(w_off + ((wave * NTW + j) * KS + ks) * 64); }, side);
+    mma_panel<MT, NTW, KS>(acc, [&](int i, int ks) { return af(m0 + i, ks); },
+                           [&](int j, int ks) { return w.at(w_off + ((wn * NTW + j) * KS + ks) * 64); }, side);
     side.commit();
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int ii = 0; ii < MT; ++ii)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
-            const int col = 16 * (wave * NTW + j) + li;
+            const int i = m0 + ii;
+            const int col = 16 * (wn * NTW + j) + li;
             if (col < NCOLS) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = 16 * i + 4 * lg + r;
-                    float v = acc[i][j][r];
+                    float v = acc[ii][j][r];
                     if (ACT) v = silu_f(v);
                     out[(row0 + m) * LDO + col] = v;
                     if (gskip != nullptr) gskip[(i * S::KS_C + (col >> 2)) * 64 + (col & 3) * 16 + 4 * lg + r] = v;
@@ -950,7 +955,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     float2* fb = reinterpret_cast<float2*>(smem + L::FFT_B);
     float* Ebuf = smem + L::E;
     constexpr bool SG = !L::SKIPS_LDS;               // skips in the global scratch
-    constexpr bool NSPLIT = !L::STAGED && S::NTC % kWaves == 0;   // column-split conv GEMMs (see conv_nsplit)
+    // column-split (NS = 4) or 2 x 2-split (NS = 2) conv GEMMs for the shapes whose conv weights are not staged (see conv_nsplit)
+    constexpr int NS = L::STAGED ? 1 : (S::NTC % 4 == 0 ? 4 : ((S::NTC % 2 == 0 && S::MTC % 2 == 0) ? 2 : 1));
+    constexpr bool NSPLIT = NS > 1;
     constexpr int SKIP_FLOATS = F1 * C1;             // one skip tensor in A-fragment order
     float* W0 = smem + L::W0;
     float* W1 = smem + L::W1;
@@ -1153,7 +1160,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             FE_BEGIN_UNIT(1 + l);
             if constexpr (NSPLIT) {
                 const float* a0 = in + li * LDC + lg;
-                conv_nsplit<S, 3 * S::KS_C, C1, LDC, true>(
+                conv_nsplit<S, NS, 3 * S::KS_C, C1, LDC, true>(
                     [&](int i, int ks) { return a0[(16 * i + ks / S::KS_C) * LDC + 4 * (ks % S::KS_C)]; }, wb, o.enc_w[l], o.enc_b[l], stage,
                     out, 1, wave, lane, SG ? skipg + (l + 1) * SKIP_FLOATS : nullptr);
                 if (l == 0) FE_CLK(41);
@@ -1592,7 +1599,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 if constexpr (NSPLIT) {
                     const float* xa0 = W0 + (li + 1) * LDC + lg;
                     const float* sk0 = skip + (li + 1) * LDC + lg;
-                    conv_nsplit<S, 2 * S::KS_C, C1, LDC, true>(
+                    conv_nsplit<S, NS, 2 * S::KS_C, C1, LDC, true>(
                         [&](int i, int ks) {
                             if (ks < S::KS_C) return xa0[(16 * i) * LDC + 4 * ks];
                             if constexpr (SG) return skb.at_g((S::NL - l) * SKIP_FLOATS + (i * S::KS_C + (ks - S::KS_C)) * 64);
@@ -1623,7 +1630,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 FE_BEGIN_UNIT(6 + S::NL + 2 * l);
                 if constexpr (NSPLIT) {
                     const float* a0 = W1 + li * LDC + lg;
-                    conv_nsplit<S, 3 * S::KS_C, C1, LDC, true>(
+                    conv_nsplit<S, NS, 3 * S::KS_C, C1, LDC, true>(
                         [&](int i, int ks) { return a0[(16 * i + ks / S::KS_C) * LDC + 4 * (ks % S::KS_C)]; }, wb, o.dec3_w[l], o.dec3_b[l], stage,
                         W0, 1, wave, lane, nullptr);
                 } else {
@@ -1648,7 +1655,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             if constexpr (NSPLIT) {
                 const float* xa0 = W0 + (li + 1) * LDC + lg;
                 const float* sk0 = Ebuf + (li + 1) * LDC + lg;
-                conv_nsplit<S, 2 * S::KS_C, C1, LDC, true>(
+                conv_nsplit<S, NS, 2 * S::KS_C, C1, LDC, true>(
                     [&](int i, int ks) {
                         if (ks < S::KS_C) return xa0[(16 * i) * LDC + 4 * ks];
                         if constexpr (SG) return skb.at_g((i * S::KS_C + (ks - S::KS_C)) * 64);
