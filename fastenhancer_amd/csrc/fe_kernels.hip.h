@@ -304,8 +304,10 @@ struct FetchSide2 {
 // The fine-grained form is used for panels of up to 128 MFMAs (the scheduler's group solver makes hipcc's
 // compile time explode beyond that: FastEnhancer_L did not finish in an hour); larger panels use the group-blocked
 // form (operand groups two ahead, pinned with sched_barrier(0)).
-template <int MTP, int NTP, int KS, typename AF, typename BF, typename SIDE>
-__device__ __forceinline__ void mma_panel(f32x4 (&acc)[MTP][NTP], AF&& af, BF&& bf, SIDE&& side) {
+// accsel(i, j, ks) -> the accumulator of tile (i, j) at k-step ks (a compile-time choice once unrolled): lets ONE
+// pipeline run two GEMMs back to back into different accumulator sets (the GRU's x and h halves).
+template <int MTP, int NTP, int KS, typename ACCSEL, typename AF, typename BF, typename SIDE>
+__device__ __forceinline__ void mma_panel_sel(ACCSEL&& accsel, AF&& af, BF&& bf, SIDE&& side) {
   using SIDE_T = std::remove_cv_t<std::remove_reference_t<SIDE>>;
   if constexpr (KS * MTP * NTP <= 128) {
     constexpr int PD = KS < 8 ? KS : 8;              // prefetch distance in k-steps
@@ -335,7 +337,7 @@ __device__ __forceinline__ void mma_panel(f32x4 (&acc)[MTP][NTP], AF&& af, BF&& 
 #pragma unroll
         for (int i = 0; i < MTP; ++i)
 #pragma unroll
-            for (int j = 0; j < NTP; ++j) acc[i][j] = FE_MFMA(av[i], bv[j], acc[i][j]);
+            for (int j = 0; j < NTP; ++j) { f32x4& c = accsel(i, j, ks); c = FE_MFMA(av[i], bv[j], c); }
     }
     // instruction-stream shape: [prologue fetches] then per k-step { MFMA, fetch, fetch, MFMA, fetch, ... }
     constexpr int LOADS = 0x100 | 0x020;             // DS read | VMEM read
@@ -393,12 +395,17 @@ __device__ __forceinline__ void mma_panel(f32x4 (&acc)[MTP][NTP], AF&& af, BF&& 
                 for (int i = 0; i < MTP; ++i)
 #pragma unroll
                     for (int j = 0; j < NTP; ++j)
-                        acc[i][j] = FE_MFMA(a[g % (D + 1)][kk][i], b[g % (D + 1)][kk][j], acc[i][j]);
+                    { f32x4& c = accsel(i, j, g * G + kk); c = FE_MFMA(a[g % (D + 1)][kk][i], b[g % (D + 1)][kk][j], c); }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
   }
+}
+
+template <int MTP, int NTP, int KS, typename AF, typename BF, typename SIDE>
+__device__ __forceinline__ void mma_panel(f32x4 (&acc)[MTP][NTP], AF&& af, BF&& bf, SIDE&& side) {
+    mma_panel_sel<MTP, NTP, KS>([&](int i, int j, int) -> f32x4& { return acc[i][j]; }, af, bf, side);
 }
 
 template <int MTP, int NTP>
@@ -1316,12 +1323,16 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll
                             for (int i = 0; i < MG; ++i) { ax[i][g] = f32x4{bi, bi, bi, bi}; ah[i][g] = f32x4{bh, bh, bh, bh}; }
                         }
-                        mma_panel<MG, 3, S::KS_2>(
-                            ax, [&](int i, int ks) { return Xb[(16 * (m0 + i) + li) * LDX + lg + 4 * ks]; },
-                            [&](int g, int ks) { return wb.at_g(wih + ((g * S::NT2 + ct) * S::KS_2 + ks) * 64); }, NoSide{});
-                        mma_panel<MG, 3, S::KS_2>(
-                            ah, [&](int i, int ks) { return Hs[(16 * (m0 + i) + li) * LDX + lg + 4 * ks]; },
-                            [&](int g, int ks) { return wb.at_g(whh + ((g * S::NT2 + ct) * S::KS_2 + ks) * 64); }, NoSide{});
+                        // x half then h half in ONE software pipeline (k-steps KS_2 .. 2 KS_2 - 1 accumulate into ah)
+                        constexpr int K2 = S::KS_2;
+                        mma_panel_sel<MG, 3, 2 * K2>(
+                            [&](int i, int g, int ks) -> f32x4& { return ks < K2 ? ax[i][g] : ah[i][g]; },
+                            [&](int i, int ks) {
+                                return ks < K2 ? Xb[(16 * (m0 + i) + li) * LDX + lg + 4 * ks] : Hs[(16 * (m0 + i) + li) * LDX + lg + 4 * (ks - K2)];
+                            },
+                            [&](int g, int ks) {
+                                return ks < K2 ? wb.at_g(wih + ((g * S::NT2 + ct) * K2 + ks) * 64) : wb.at_g(whh + ((g * S::NT2 + ct) * K2 + ks - K2) * 64);
+                            }, NoSide{});
                         const int c = 16 * ct + li;
                         if (c < C2) {
 #pragma unroll
