@@ -1363,12 +1363,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll
                         for (int i = 0; i < S::MT2; ++i) { ax[i][g] = f32x4{bi, bi, bi, bi}; ah[i][g] = f32x4{bh, bh, bh, bh}; }
                     }
-                    mma_panel<S::MT2, 3, S::KS_2>(
-                        ax, [&](int i, int ks) { return Xb[(16 * i + li) * LDX + lg + 4 * ks]; },
-                        [&](int g, int ks) { return Wgi.get(j, g, ks); }, FetchSide<decltype(Wf1)>{&Wf1});
-                    mma_panel<S::MT2, 3, S::KS_2>(
-                        ah, [&](int i, int ks) { return Hs[(16 * i + li) * LDX + lg + 4 * ks]; },
-                        [&](int g, int ks) { return Wgh.get(j, g, ks); }, NoSide{});
+                    // x half then h half in ONE software pipeline (k-steps KS_2 .. 2 KS_2 - 1 accumulate into ah)
+                    constexpr int K2 = S::KS_2;
+                    mma_panel_sel<S::MT2, 3, 2 * K2>(
+                        [&](int i, int g, int ks) -> f32x4& { return ks < K2 ? ax[i][g] : ah[i][g]; },
+                        [&](int i, int ks) { return ks < K2 ? Xb[(16 * i + li) * LDX + lg + 4 * ks] : Hs[(16 * i + li) * LDX + lg + 4 * (ks - K2)]; },
+                        [&](int g, int ks) { return ks < K2 ? Wgi.get(j, g, ks) : Wgh.get(j, g, ks - K2); }, FetchSide<decltype(Wf1)>{&Wf1});
                     const int c = 16 * ct + li;
                     if (ct < S::NT2 && c < C2) {
 #pragma unroll
