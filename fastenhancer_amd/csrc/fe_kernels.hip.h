@@ -499,7 +499,16 @@ struct Lds {
     static constexpr int ARENA_SIZE_SKIPS_LDS =
         cmax(cmax(4 * S::NFFT, 3 * S::F2P * S::LDX + S::F2P * S::LDG),
              cmax(2 * S::ACT + S::F1 * S::LDP, cmax(S::F2P * S::LDX, S::ACT) + S::F1 * S::LDX));
-    static constexpr bool SKIPS_LDS = (size_t)(E + (S::NL + 1) * S::ACT + ARENA_SIZE_SKIPS_LDS) * 4 <= 160 * 1024;
+    // Preference: skips in LDS + staged weights; else - for shapes that cannot use the column-split conv GEMMs (three
+    // channel tiles: 48 kHz B) - skips in the global scratch so that the weights can be staged; else skips in LDS with
+    // streamed weights; else everything global / streamed.
+    static constexpr bool FITS_SKIPS = (size_t)(E + (S::NL + 1) * S::ACT + ARENA_SIZE_SKIPS_LDS) * 4 <= 160 * 1024;
+    static constexpr bool FITS_SKIPS_STAGED = (size_t)(E + (S::NL + 1) * S::ACT + ARENA_SIZE_SKIPS_LDS + 2 * Pack<S>::umax()) * 4 <= 160 * 1024;
+    static constexpr int ARENA_SIZE_SKIPS_GLOBAL =
+        cmax(cmax(4 * S::NFFT, cmax(3 * S::F2P * S::LDX, S::ACT) + S::F2P * S::LDG),
+             cmax(2 * S::ACT + S::F1 * S::LDP, cmax(S::F2P * S::LDX, S::ACT) + S::F1 * S::LDX));
+    static constexpr bool FITS_GLOBAL_STAGED = (size_t)(E + ARENA_SIZE_SKIPS_GLOBAL + 2 * Pack<S>::umax()) * 4 <= 160 * 1024;
+    static constexpr bool SKIPS_LDS = FITS_SKIPS && (FITS_SKIPS_STAGED || !(FITS_GLOBAL_STAGED && S::NTC % 4 != 0 && S::NTC % 2 != 0));
     static constexpr int ARENA = E + (SKIPS_LDS ? (S::NL + 1) * S::ACT : 0);
     // The arena is re-used by the phases of a frame (offsets relative to ARENA):
     //   STFT / iSTFT : FFT_A, FFT_B                       (complex ping-pong)
