@@ -306,11 +306,12 @@ struct FetchSide2 {
 // form (operand groups two ahead, pinned with sched_barrier(0)).
 // accsel(i, j, ks) -> the accumulator of tile (i, j) at k-step ks (a compile-time choice once unrolled): lets ONE
 // pipeline run two GEMMs back to back into different accumulator sets (the GRU's x and h halves).
-template <int MTP, int NTP, int KS, typename ACCSEL, typename AF, typename BF, typename SIDE>
+template <int MTP, int NTP, int KS, int PDK = 8, typename ACCSEL, typename AF, typename BF, typename SIDE>
 __device__ __forceinline__ void mma_panel_sel(ACCSEL&& accsel, AF&& af, BF&& bf, SIDE&& side) {
   using SIDE_T = std::remove_cv_t<std::remove_reference_t<SIDE>>;
   if constexpr (KS * MTP * NTP <= 128) {
-    constexpr int PD = KS < 8 ? KS : 8;              // prefetch distance in k-steps
+    constexpr int PD = KS < PDK ? KS : PDK;          // prefetch distance in k-steps (PDK: 8 when operands stream from L2,
+                                                     // 3 when they all sit in LDS / registers - Lds<S>::PDK)
     constexpr int NSG = (KS + 3) / 4;                // side-job slots (one per 4 k-steps)
     float a[PD][MTP], b[PD][NTP];
 #pragma unroll
@@ -403,9 +404,9 @@ __device__ __forceinline__ void mma_panel_sel(ACCSEL&& accsel, AF&& af, BF&& bf,
   }
 }
 
-template <int MTP, int NTP, int KS, typename AF, typename BF, typename SIDE>
+template <int MTP, int NTP, int KS, int PDK = 8, typename AF, typename BF, typename SIDE>
 __device__ __forceinline__ void mma_panel(f32x4 (&acc)[MTP][NTP], AF&& af, BF&& bf, SIDE&& side) {
-    mma_panel_sel<MTP, NTP, KS>([&](int i, int j, int) -> f32x4& { return acc[i][j]; }, af, bf, side);
+    mma_panel_sel<MTP, NTP, KS, PDK>([&](int i, int j, int) -> f32x4& { return acc[i][j]; }, af, bf, side);
 }
 
 template <int MTP, int NTP>
@@ -541,6 +542,11 @@ struct Lds {
     static constexpr int WB0 = NOSTAGE_TOTAL;
     static constexpr int WB1 = WB0 + Pack<S>::umax();
     static constexpr int TOTAL = STAGED ? NOSTAGE_TOTAL + 2 * Pack<S>::umax() : NOSTAGE_TOTAL;
+    // software-pipeline depth of the fine-grained MFMA panels: with staged conv weights (and then register-resident
+    // block weights) every operand comes from LDS / registers, ~130 cycles away: 3 k-steps ahead is enough and a
+    // shorter pipeline fill after each barrier is worth 4.7 % on FastEnhancer_B (8 / 6 / 4 / 3 / 2 measured);
+    // operands streamed from L2 need the full 8.
+    static constexpr int PDK = STAGED ? 3 : 8;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
     static_assert(2 * S::ACT >= 4 * S::NFFT, "the FFT buffers must not reach the transposed-conv partials");
     static_assert(S::F2P * S::LDC <= S::F2P * S::LDG, "rf_pre intermediate must fit in the qkv buffer");
@@ -633,7 +639,7 @@ struct Dft {
         const int li = lane & 15, lg = lane >> 4, p = wave >> 1, jt = wave & 1, k2 = 16 * jt + li;
         f32x4 g[MT][2];                                  // [.][0] = Re G, [.][1] = Im G, rows 16 i + 4 lg + r, column k2
         acc_init_zero<MT, 2>(g);
-        mma_panel<MT, 2, 8>(g, [&](int i, int ks) { return xw[16 * i + li + N1 * (4 * ks + lg)]; },
+        mma_panel<MT, 2, 8, Lds<S>::PDK>(g, [&](int i, int ks) { return xw[16 * i + li + N1 * (4 * ks + lg)]; },
                             [&](int a2, int ks) { return c.c1[a2][ks]; }, NoSide{});
         float gq[KC];                                    // k-step a * 4 MT + 4 i + r of the second stage
         float2 tq[MT][4];                                // (twiddles fetched together, ahead of the panel's results)
@@ -696,7 +702,7 @@ struct Dft {
         }
         f32x4 h[1][2 * MT];
         acc_init_zero<1, 2 * MT>(h);
-        mma_panel<1, 2 * MT, KC>(h, [&](int, int ks) { return yq[ks]; },
+        mma_panel<1, 2 * MT, KC, Lds<S>::PDK>(h, [&](int, int ks) { return yq[ks]; },
                                  [&](int j, int ks) {
                                      if constexpr (PRELOAD3) return c.c3[j][ks];
                                      else return wb.at_g(o.dft3 + (j * KC + ks) * 64);
@@ -740,7 +746,7 @@ struct Dft {
 //   w_lane : packed weights + lane, at k-step 0 of this segment;  KS_TOT = k-steps per n-tile
 template <class S, int NT, int KS, int KS_TOT, int LDA, class WS, class SIDE>
 __device__ __forceinline__ void conv_seg(f32x4 (&acc)[S::MTPW][NT], const float* a_lane, const WS& w, int w_off, const SIDE& side) {
-    mma_panel<S::MTPW, NT, KS>(
+    mma_panel<S::MTPW, NT, KS, Lds<S>::PDK>(
         acc,
         [&](int i, int ks) { return a_lane[(64 * i) * LDA + 4 * ks]; },
         [&](int j, int ks) { return w.at(w_off + (j * KS_TOT + ks) * 64); }, side);
@@ -751,7 +757,7 @@ __device__ __forceinline__ void conv_seg(f32x4 (&acc)[S::MTPW][NT], const float*
 // back to back (k-step index = s * KS_SEG + ks).
 template <class S, int NT, int NSEG, int KS_SEG, int LDA, class WS, class SIDE>
 __device__ __forceinline__ void conv_multi(f32x4 (&acc)[S::MTPW][NT], const float* const (&a_lane)[NSEG], const WS& w, int w_off, const SIDE& side) {
-    mma_panel<S::MTPW, NT, NSEG * KS_SEG>(
+    mma_panel<S::MTPW, NT, NSEG * KS_SEG, Lds<S>::PDK>(
         acc,
         [&](int i, int ks) { return a_lane[ks / KS_SEG][(64 * i) * LDA + 4 * (ks % KS_SEG)]; },
         [&](int j, int ks) { return w.at(w_off + (j * (NSEG * KS_SEG) + ks) * 64); }, side);
@@ -802,7 +808,7 @@ __device__ __forceinline__ void conv_nsplit(AF&& af, const WS& w, int w_off, int
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[i][j] = f32x4{bj, bj, bj, bj};
     }
-    mma_panel<MT, NTW, KS>(acc, [&](int i, int ks) { return af(m0 + i, ks); },
+    mma_panel<MT, NTW, KS, Lds<S>::PDK>(acc, [&](int i, int ks) { return af(m0 + i, ks); },
                            [&](int j, int ks) { return w.at(w_off + ((wn * NTW + j) * KS + ks) * 64); }, side);
     side.commit();
 #pragma unroll
@@ -827,7 +833,7 @@ __device__ __forceinline__ void conv_nsplit(AF&& af, const WS& w, int w_off, int
 // token-layout GEMM: all MT2 m-tiles x this wave's n-tiles (wave + 4*j), A from LDS, B packed.
 template <class S, int NTPW, int KS, int LDA, class WS, class SIDE>
 __device__ __forceinline__ void tok_gemm(f32x4 (&acc)[S::MT2][NTPW], const float* a_lane, const WS& w, int w_off, int NT, int wave, const SIDE& side) {
-    mma_panel<S::MT2, NTPW, KS>(
+    mma_panel<S::MT2, NTPW, KS, Lds<S>::PDK>(
         acc,
         [&](int i, int ks) { return a_lane[(16 * i) * LDA + 4 * ks]; },
         [&](int j, int ks) {
@@ -909,7 +915,7 @@ __device__ __forceinline__ void tok_gemm_w(f32x4 (&acc)[S::MT2][NTPW], const flo
 #pragma unroll
         for (int i = 0; i < S::MT2; ++i) acc[i][j] = f32x4{bj, bj, bj, bj};
     }
-    mma_panel<S::MT2, NTPW, KS>(
+    mma_panel<S::MT2, NTPW, KS, Lds<S>::PDK>(
         acc, [&](int i, int ks) { return a_lane[(16 * i) * LDA + 4 * ks]; }, [&](int j, int ks) { return W.get(j, 0, ks); }, side);
 }
 
@@ -1145,7 +1151,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             f32x4 acc[S::MTPW][S::NTC];
             acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.enc_pre_b, 0, 1, S::NTC);
             // k = t*8 + s*2 + c  (weight (C1, 8, 2): channel index s*2+c, tap t);  A[m][k] = xpad[c][4(m+t)+s]
-            mma_panel<S::MTPW, S::NTC, 4>(
+            mma_panel<S::MTPW, S::NTC, 4, Lds<S>::PDK>(
                 acc,
                 [&](int i, int ks) {
                     const int kk = 4 * ks + lg;
@@ -1228,7 +1234,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             Wgi.bind(wb, o.blk_wih[0], o.blk_bih[0], S::NT2, wave);      // block 0's GRU input weights ride in this GEMM
             f32x4 acc[S::MT2][NTPW];
             acc_init_zero<S::MT2, NTPW>(acc);
-            mma_panel<S::MT2, NTPW, KS>(
+            mma_panel<S::MT2, NTPW, KS, Lds<S>::PDK>(
                 acc,
                 [&](int i, int ks) { return wb.at(o.rfpre_lin + (i * KS + ks) * 64); },
                 [&](int j, int ks) {
@@ -1334,7 +1340,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                         }
                         // x half then h half in ONE software pipeline (k-steps KS_2 .. 2 KS_2 - 1 accumulate into ah)
                         constexpr int K2 = S::KS_2;
-                        mma_panel_sel<MG, 3, 2 * K2>(
+                        mma_panel_sel<MG, 3, 2 * K2, Lds<S>::PDK>(
                             [&](int i, int g, int ks) -> f32x4& { return ks < K2 ? ax[i][g] : ah[i][g]; },
                             [&](int i, int ks) {
                                 return ks < K2 ? Xb[(16 * (m0 + i) + li) * LDX + lg + 4 * ks] : Hs[(16 * (m0 + i) + li) * LDX + lg + 4 * (ks - K2)];
@@ -1374,7 +1380,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     }
                     // x half then h half in ONE software pipeline (k-steps KS_2 .. 2 KS_2 - 1 accumulate into ah)
                     constexpr int K2 = S::KS_2;
-                    mma_panel_sel<S::MT2, 3, 2 * K2>(
+                    mma_panel_sel<S::MT2, 3, 2 * K2, Lds<S>::PDK>(
                         [&](int i, int g, int ks) -> f32x4& { return ks < K2 ? ax[i][g] : ah[i][g]; },
                         [&](int i, int ks) { return ks < K2 ? Xb[(16 * i + li) * LDX + lg + 4 * ks] : Hs[(16 * i + li) * LDX + lg + 4 * (ks - K2)]; },
                         [&](int g, int ks) { return ks < K2 ? Wgi.get(j, g, ks) : Wgh.get(j, g, ks - K2); }, FetchSide<decltype(Wf1)>{&Wf1});
@@ -1457,7 +1463,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 constexpr int MTD = ceil_div(HD, 16);
                 f32x4 sacc[S::MT2][S::MT2];
                 acc_init_zero<S::MT2, S::MT2>(sacc);
-                mma_panel<S::MT2, S::MT2, KSD>(
+                mma_panel<S::MT2, S::MT2, KSD, Lds<S>::PDK>(
                     sacc,
                     [&](int i, int ks) {
                         const int d = 4 * ks + lg;
@@ -1585,7 +1591,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             FE_BEGIN_UNIT(3 + S::NL);
             f32x4 acc[S::MTPW][S::NT2];
             acc_init_zero<S::MTPW, S::NT2>(acc);
-            mma_panel<S::MTPW, S::NT2, KS>(
+            mma_panel<S::MTPW, S::NT2, KS, Lds<S>::PDK>(
                 acc,
                 [&](int i, int ks) { return wb.at(o.rfpost_lin + ((wave + 4 * i) * KS + ks) * 64); },
                 [&](int j, int ks) { return Xb[(4 * ks + lg) * LDX + 16 * j + li]; }, stage);
@@ -1633,7 +1639,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     conv_multi<S, S::NTC, 2, S::KS_C, LDC>(acc, segs, wb, o.dec1_w[l], stage);
                 } else {   // second K-segment = the skip, read back from the global scratch as A fragments
                     const float* xa = W0 + (16 * wave + li + 1) * LDC + lg;
-                    mma_panel<S::MTPW, S::NTC, 2 * S::KS_C>(
+                    mma_panel<S::MTPW, S::NTC, 2 * S::KS_C, 8>(
                         acc,
                         [&](int i, int ks) {
                             return ks < S::KS_C ? xa[(64 * i) * LDC + 4 * ks]
@@ -1689,7 +1695,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 conv_multi<S, S::NTC, 2, S::KS_C, LDC>(acc, segs, wb, o.post1_w, stage);
             } else {
                 const float* xa = W0 + (16 * wave + li + 1) * LDC + lg;
-                mma_panel<S::MTPW, S::NTC, 2 * S::KS_C>(
+                mma_panel<S::MTPW, S::NTC, 2 * S::KS_C, 8>(
                     acc,
                     [&](int i, int ks) {
                         return ks < S::KS_C ? xa[(64 * i) * LDC + 4 * ks] : skb.at_g(((wave + 4 * i) * S::KS_C + (ks - S::KS_C)) * 64);
