@@ -1475,7 +1475,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                         float v = Gi[(16 * j + li) * LDG + hoff + (d < HD ? d : HD - 1)];
                         return d < HD ? v : 0.0f;
                     }, NoSide{});
-                const float scale = rsqrtf((float)HD);
+                const float scale = rsqrtf((float)HD) * 1.4426950408889634f;      // 1/sqrt(hd) * log2(e): softmax through exp2
 #pragma unroll
                 for (int j = 0; j < S::MT2; ++j) {
                     float mx = -INFINITY;
@@ -1485,7 +1485,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                         for (int r = 0; r < 4; ++r) {
                             const int key = 16 * i + 4 * lg + r;
                             float s = sacc[i][j][r] * scale;
-                            s = key < F2 ? s : -INFINITY;
+                            if (16 * i + 15 >= F2) s = key < F2 ? s : -INFINITY;      // (only the last key tile has padding rows)
                             sacc[i][j][r] = s;
                             mx = fmaxf(mx, s);
                         }
@@ -1495,7 +1495,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float p = __expf(sacc[i][j][r] - mx);
+                            float p = __builtin_amdgcn_exp2f(sacc[i][j][r] - mx);
                             sacc[i][j][r] = p;
                             sum += p;
                         }
