@@ -478,7 +478,10 @@ void blaunch_one(const BArgs& a, hipStream_t st, hipError_t* err) {
 
 template <class S>
 void blaunch_impl(const BArgs& a, hipStream_t st, hipError_t* err) {
-    if (a.clk != nullptr) blaunch_one<S, false, true>(a, st, err);                    // fe_profile_step
+    if (a.clk != nullptr) {                                                          // fe_profile_step
+        if (a.mode == FE_MODE_STREAM && a.T == 1) blaunch_one<S, true, true>(a, st, err);
+        else blaunch_one<S, false, true>(a, st, err);
+    }
     else if (a.mode == FE_MODE_STREAM && a.T == 1) blaunch_one<S, true, false>(a, st, err);
     else blaunch_one<S, false, false>(a, st, err);
 }
