@@ -1378,12 +1378,26 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll
                         for (int i = 0; i < S::MT2; ++i) { ax[i][g] = f32x4{bi, bi, bi, bi}; ah[i][g] = f32x4{bh, bh, bh, bh}; }
                     }
+                    // previous hidden state of this lane's outputs: read now, in flight under the GEMM (read in the epilogue,
+                    // each LDS round trip would be exposed: 8 outputs x ~120 cycles)
+                    float hprev[S::MT2][4];
+                    {
+                        const int cc = 16 * ct + li < C2 ? 16 * ct + li : C2 - 1;
+#pragma unroll
+                        for (int i = 0; i < S::MT2; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) hprev[i][r] = Hs[(16 * i + 4 * lg + r) * LDX + cc];
+                    }
                     // x half then h half in ONE software pipeline (k-steps KS_2 .. 2 KS_2 - 1 accumulate into ah)
                     constexpr int K2 = S::KS_2;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k == 0) FE_CLK(45);
                     mma_panel_sel<S::MT2, 3, 2 * K2, Lds<S>::PDK>(
                         [&](int i, int g, int ks) -> f32x4& { return ks < K2 ? ax[i][g] : ah[i][g]; },
                         [&](int i, int ks) { return ks < K2 ? Xb[(16 * i + li) * LDX + lg + 4 * ks] : Hs[(16 * i + li) * LDX + lg + 4 * (ks - K2)]; },
                         [&](int g, int ks) { return ks < K2 ? Wgi.get(j, g, ks) : Wgh.get(j, g, ks - K2); }, FetchSide<decltype(Wf1)>{&Wf1});
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k == 0) FE_CLK(46);
                     const int c = 16 * ct + li;
                     if (ct < S::NT2 && c < C2) {
 #pragma unroll
@@ -1396,8 +1410,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                                     const float rr = sigmoid_f(ax[i][0][r] + ah[i][0][r]);
                                     const float zz = sigmoid_f(ax[i][1][r] + ah[i][1][r]);
                                     const float nn = tanh_f(ax[i][2][r] + rr * ah[i][2][r]);
-                                    const float hp = Hs[row * LDX + c];
-                                    const float hn = (1.0f - zz) * nn + zz * hp;
+                                    const float hn = (1.0f - zz) * nn + zz * hprev[i][r];
                                     Hl[row * LDX + c] = hn;
                                     hg[row * C2 + c] = hn;
                                 }
@@ -1406,6 +1419,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     }
                 }
             }
+            if (k == 0) FE_CLK(47);
             __syncthreads();
             if (k == 0) FE_CLK(21);
             if (k == 0) FE_CLK(22);
