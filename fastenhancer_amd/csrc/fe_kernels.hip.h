@@ -1266,7 +1266,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             {
                 const float* hg0 = a.h + (size_t)b * (F2 * C2);
 #pragma unroll
-                for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = i < F2 * C2 ? hg0[i] : 0.0f; }
+                for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = hg0[i < F2 * C2 ? i : F2 * C2 - 1]; }   // (clamped, not predicated: no branch per load)
             }
             f32x4 acc[S::MT2][NTPW];
             acc_init_bias<S::MT2, NTPW>(acc, wb, o.rfpre_b, wave, 4, S::NT2);
@@ -1316,7 +1316,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int row = 16 * i + 4 * lg + r, col = 16 * (wave + 4 * j) + li;
-                                pe_r[i][j][r] = (row < F2 && col < C2) ? wb.gather_g(o.blk_pe + row * C2 + col) : 0.0f;
+                                pe_r[i][j][r] = wb.gather_g(o.blk_pe + (row < F2 ? row : F2 - 1) * C2 + (col < C2 ? col : C2 - 1));   // (pad rows / columns are never stored)
                             }
                 }
                 // Shapes with more than four column tiles and streamed weights (M: 5 tiles, L: 6): handing whole column
@@ -1565,7 +1565,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 if (k + 1 < S::KB) {
                     const float* hgn = hg + (size_t)a.B * (F2 * C2);
 #pragma unroll
-                    for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = i < F2 * C2 ? hgn[i] : 0.0f; }
+                    for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = hgn[i < F2 * C2 ? i : F2 * C2 - 1]; }
                 }
                 f32x4 acc[S::MT2][NTPW];
                 tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf2, FetchSide<decltype(Wgh)>{&Wgh});
