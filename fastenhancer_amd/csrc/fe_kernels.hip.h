@@ -1490,6 +1490,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                         return d < HD ? v : 0.0f;
                     }, NoSide{});
                 const float scale = rsqrtf((float)HD) * 1.4426950408889634f;      // 1/sqrt(hd) * log2(e): softmax through exp2
+                float inv_sum[S::MT2];
 #pragma unroll
                 for (int j = 0; j < S::MT2; ++j) {
                     float mx = -INFINITY;
@@ -1514,11 +1515,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                             sum += p;
                         }
                     sum = rows_allreduce(sum, [](float p, float q) { return p + q; });
-                    const float inv = __builtin_amdgcn_rcpf(sum);
-#pragma unroll
-                    for (int i = 0; i < S::MT2; ++i)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) sacc[i][j][r] *= inv;
+                    inv_sum[j] = __builtin_amdgcn_rcpf(sum);      // applied to O below: the P V MFMAs need not wait for it
                 }
                 f32x4 oacc[MTD][S::MT2];
                 acc_init_zero<MTD, S::MT2>(oacc);
@@ -1550,7 +1547,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int d = 16 * md + 4 * lg + r;
-                            if (d < HD && q < F2) Hl[q * LDX + wave * HD + d] = oacc[md][j][r];
+                            if (d < HD && q < F2) Hl[q * LDX + wave * HD + d] = oacc[md][j][r] * inv_sum[j];
                         }
                     }
             }
