@@ -310,7 +310,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                         p3 += wrow[rr][4 * k + 3] * hv.w;
                     }
                     const float pre = (p0 + p1) + (p2 + p3);
-                    const float act = gate == 2 ? tanh_f(pre) : sigmoid_f(pre);
+                    // one exp + one rcp for either activation: tanh(x) = 2 s(2x) - 1  (a select between tanh_f and sigmoid_f
+                    // evaluates both: four quarter-rate transcendentals on the recurrence's critical path)
+                    const bool is_g = gate == 2;
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre * (is_g ? -2.8853900817779268f : -1.4426950408889634f)));
+                    const float act = is_g ? 2.0f * sg - 1.0f : sg;
                     // the 4 gates of a unit sit in one quad: DPP quad_perm broadcasts (no LDS crossbar)
                     const int ai = __builtin_bit_cast(int, act);
                     const float ig = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, ai, 0x00, 0xf, 0xf, true));
