@@ -44,6 +44,12 @@ WORKLOADS = {
                  desc="FastEnhancer_S 16kHz"),
     "fe48_b": dict(C1=48, ks=(8, 3, 3), C2=36, F2=36, K=3, N=1024, H=512, sr=48000, init="linear",
                    desc="FastEnhancer_B 48kHz"),
+    "fe48_t": dict(C1=24, ks=(8, 3, 3), C2=20, F2=24, K=2, N=1024, H=512, sr=48000, init="linear",
+                   desc="FastEnhancer_T 48kHz"),
+    "fe48_s": dict(C1=64, ks=(8, 3, 3, 3), C2=48, F2=48, K=3, N=1024, H=512, sr=48000, init="linear",
+                   desc="FastEnhancer_S 48kHz"),
+    "fe48_m": dict(C1=96, ks=(8, 3, 3, 3), C2=72, F2=72, K=4, N=1024, H=320, sr=48000, init="linear",
+                   desc="FastEnhancer_M 48kHz"),
     "bsrnn_xt": dict(bsrnn=True, C=16, L=6, N=512, H=256, sr=16000, desc="BSRNN (xt) 16kHz"),
     "bsrnn_xxt": dict(bsrnn=True, C=16, L=2, N=512, H=256, sr=16000, desc="BSRNN (xxt) 16kHz"),
     "bsrnn_t": dict(bsrnn=True, C=32, L=6, N=512, H=256, sr=16000, desc="BSRNN (t) 16kHz"),
