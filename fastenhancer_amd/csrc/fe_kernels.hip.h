@@ -523,11 +523,17 @@ struct Lds {
     static constexpr int X = ARENA;                               // [F2P][LDX]
     static constexpr int HL = X + S::F2P * S::LDX;                // hidden state / attention out
     static constexpr int HS = HL + S::F2P * S::LDX;               // GRU hidden state of the current block [F2P][LDX]
-    // qkv [F2P][LDG]; with global skips the last encoder output sits in W0 while rf_pre writes Y1 (= this buffer)
+    // qkv [F2P][LDG]; with global skips the last encoder output sits in W0 while rf_pre writes Y1 (= this buffer).
+    // PERHEAD (48 kHz L: 96 tokens x 288 qkv columns = 111 KB): not even the global-skip plan fits with a full qkv
+    // buffer, so qkv is computed and consumed one head at a time ([F2P][3 hd + 2], all four waves on the same head) and
+    // the rf_pre intermediate sits behind W0, over the not yet live HL / HS.
+    static constexpr bool PERHEAD = (size_t)(E + ARENA_SIZE_SKIPS_GLOBAL) * 4 > 160 * 1024;
+    static constexpr int LDGX = PERHEAD ? 3 * S::HD + 2 : S::LDG;
     static constexpr int GI_OFF = SKIPS_LDS ? 3 * S::F2P * S::LDX : cmax(3 * S::F2P * S::LDX, S::ACT);
     static constexpr int GI = ARENA + GI_OFF;
-    static constexpr int END_RF = GI_OFF + S::F2P * S::LDG;
-    static constexpr int Y1 = GI;                                 // rf_pre intermediate [F2P][LDC]
+    static constexpr int Y1_OFF = PERHEAD ? cmax(S::F2P * S::LDX, S::ACT) : GI_OFF;
+    static constexpr int Y1 = ARENA + Y1_OFF;                     // rf_pre intermediate [F2P][LDC]
+    static constexpr int END_RF = cmax(GI_OFF + S::F2P * LDGX, Y1_OFF + S::F2P * S::LDC);
     static constexpr int W0 = ARENA;
     static constexpr int W1 = W0 + S::ACT;
     static constexpr int PT = W1 + S::ACT;                        // [F1][LDP]
@@ -549,7 +555,8 @@ struct Lds {
     static constexpr int PDK = STAGED ? 3 : 8;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
     static_assert(2 * S::ACT >= 4 * S::NFFT, "the FFT buffers must not reach the transposed-conv partials");
-    static_assert(S::F2P * S::LDC <= S::F2P * S::LDG, "rf_pre intermediate must fit in the qkv buffer");
+    static_assert(PERHEAD || S::F2P * S::LDC <= S::F2P * S::LDG, "rf_pre intermediate must fit in the qkv buffer");
+    static_assert(!PERHEAD || !SKIPS_LDS, "per-head qkv implies global skips");
 };
 
 // ------------------------------------------------------------------------------------------
@@ -919,6 +926,96 @@ __device__ __forceinline__ void tok_gemm_w(f32x4 (&acc)[S::MT2][NTPW], const flo
         acc, [&](int i, int ks) { return a_lane[(16 * i) * LDA + 4 * ks]; }, [&](int j, int ks) { return W.get(j, 0, ks); }, side);
 }
 
+// Attention of one head for the query tiles q0, q0 + qstride, ... (NQ of them; tiles >= MT2 are skipped):
+//   S^T[key][query] = K Q^T, softmax over keys in registers, O^T = V^T P^T with the C/D row map as the k-permutation.
+// G holds q | k | v of the head at columns hoff, hoff + HD, hoff + 2 HD (row stride LDG); O -> Hl[query][head * HD + d].
+template <class S, int NQ, int LDG>
+__device__ __forceinline__ void attention_head(const float* G, float* Hl, int hoff, int head, int q0, int qstride, int lane) {
+    constexpr int HD = S::HD, F2 = S::F2, LDX = S::LDX;
+    constexpr int KSD = ceil_div(HD, 4);
+    constexpr int MTD = ceil_div(HD, 16);
+    const int li = lane & 15, lg = lane >> 4;
+    int qt[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) { qt[j] = q0 + qstride * j; qt[j] = qt[j] < S::MT2 ? qt[j] : S::MT2 - 1; }
+    f32x4 sacc[S::MT2][NQ];
+    acc_init_zero<S::MT2, NQ>(sacc);
+    mma_panel<S::MT2, NQ, KSD, Lds<S>::PDK>(
+        sacc,
+        [&](int i, int ks) {
+            const int d = 4 * ks + lg;
+            float v = G[(16 * i + li) * LDG + hoff + HD + (d < HD ? d : HD - 1)];
+            return d < HD ? v : 0.0f;
+        },
+        [&](int j, int ks) {
+            const int d = 4 * ks + lg;
+            float v = G[(16 * qt[j] + li) * LDG + hoff + (d < HD ? d : HD - 1)];
+            return d < HD ? v : 0.0f;
+        }, NoSide{});
+    const float scale = rsqrtf((float)HD) * 1.4426950408889634f;      // 1/sqrt(hd) * log2(e): softmax through exp2
+    float inv_sum[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < S::MT2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * i + 4 * lg + r;
+                float sv = sacc[i][j][r] * scale;
+                if (16 * i + 15 >= F2) sv = key < F2 ? sv : -INFINITY;      // (only the last key tile has padding rows)
+                sacc[i][j][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = rows_allreduce(mx, [](float p, float q) { return fmaxf(p, q); });
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < S::MT2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = __builtin_amdgcn_exp2f(sacc[i][j][r] - mx);
+                sacc[i][j][r] = p;
+                sum += p;
+            }
+        sum = rows_allreduce(sum, [](float p, float q) { return p + q; });
+        inv_sum[j] = __builtin_amdgcn_rcpf(sum);      // applied to O below: the P V MFMAs need not wait for it
+    }
+    f32x4 oacc[MTD][NQ];
+    acc_init_zero<MTD, NQ>(oacc);
+    // k-step (i, r): lane group lg supplies key = 16 i + 4 lg + r  (matches the C/D row map)
+#pragma unroll
+    for (int i = 0; i < S::MT2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int key = 16 * i + 4 * lg + r;
+            key = key < F2 ? key : F2 - 1;
+            float av[MTD];
+#pragma unroll
+            for (int md = 0; md < MTD; ++md) {
+                int d = 16 * md + li;
+                d = d < HD ? d : HD - 1;
+                av[md] = G[key * LDG + hoff + 2 * HD + d];
+            }
+#pragma unroll
+            for (int md = 0; md < MTD; ++md)
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) oacc[md][j] = FE_MFMA(av[md], sacc[i][j][r], oacc[md][j]);
+        }
+    // O[query][head*HD + d]  (into Hl, dead after rnn_fc)
+#pragma unroll
+    for (int md = 0; md < MTD; ++md)
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int q = 16 * qt[j] + li;
+            const bool live = q0 + qstride * j < S::MT2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = 16 * md + 4 * lg + r;
+                if (live && d < HD && q < F2) Hl[q * LDX + head * HD + d] = oacc[md][j][r] * inv_sum[j];
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------
 // a.mode (wave-uniform): FE_MODE_STREAM  wav->wav streaming step (scripts/export_onnx.py:48-58)
 //                        FE_MODE_SPEC    spec->spec step (model.py:677-710)
@@ -940,7 +1037,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     using L = Lds<S>;
     constexpr int N = S::NFFT, H = S::HOP, OVL = S::OVL, F0 = S::F0, F1 = S::F1;
     constexpr int C1 = S::C1, C2 = S::C2, F2 = S::F2, HD = S::HD;
-    constexpr int LDC = S::LDC, LDX = S::LDX, LDG = S::LDG;
+    constexpr int LDC = S::LDC, LDX = S::LDX, LDG = L::LDGX;
 
     const int tid0 = threadIdx.x;
     const int tid = tid0;
@@ -1284,6 +1381,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                         for (int r = 0; r < 4; ++r) Xb[(16 * i + 4 * lg + r) * LDX + col] = acc[i][j][r];
                     }
                 }
+            if constexpr (L::PERHEAD) __syncthreads();       // (there Y1, still being read by slower waves, lies over HS)
 #pragma unroll
             for (int q = 0; q < HPT; ++q) {
                 const int i = tid + q * kThreads;
@@ -1455,6 +1553,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 // fetched inside the GEMM: attn_fc weights and the next block's GRU input weights
                 Wf2.bind(wb, (o.blk_fc2_w[0] + kb), (o.blk_fc2_b[0] + kb), S::NT2, wave);
                 Wgi.bind(wb, (o.blk_wih[0] + kb + o.blk_stride), (o.blk_bih[0] + kb + o.blk_stride), S::NT2, wave, k + 1 < S::KB);
+                if constexpr (!L::PERHEAD) {
                 f32x4 acc[S::MT2][NTPW];
                 tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Xb + li * LDX + lg, Wq, FetchSide2<decltype(Wf2), decltype(Wgi)>{&Wf2, &Wgi});
 #pragma unroll
@@ -1467,89 +1566,45 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                             for (int r = 0; r < 4; ++r) Gi[(16 * i + 4 * lg + r) * LDG + 16 * nt + li] = acc[i][j][r];
                         }
                     }
-            }
-            __syncthreads();
-            if (k == 0) FE_CLK(24);
-            {
-                // attention: wave = head.  S^T[key][query] = K Q^T, softmax over keys, O^T = V^T P^T
-                const int hoff = wave * 3 * HD;
-                constexpr int KSD = ceil_div(HD, 4);
-                constexpr int MTD = ceil_div(HD, 16);
-                f32x4 sacc[S::MT2][S::MT2];
-                acc_init_zero<S::MT2, S::MT2>(sacc);
-                mma_panel<S::MT2, S::MT2, KSD, Lds<S>::PDK>(
-                    sacc,
-                    [&](int i, int ks) {
-                        const int d = 4 * ks + lg;
-                        float v = Gi[(16 * i + li) * LDG + hoff + HD + (d < HD ? d : HD - 1)];
-                        return d < HD ? v : 0.0f;
-                    },
-                    [&](int j, int ks) {
-                        const int d = 4 * ks + lg;
-                        float v = Gi[(16 * j + li) * LDG + hoff + (d < HD ? d : HD - 1)];
-                        return d < HD ? v : 0.0f;
-                    }, NoSide{});
-                const float scale = rsqrtf((float)HD) * 1.4426950408889634f;      // 1/sqrt(hd) * log2(e): softmax through exp2
-                float inv_sum[S::MT2];
-#pragma unroll
-                for (int j = 0; j < S::MT2; ++j) {
-                    float mx = -INFINITY;
-#pragma unroll
-                    for (int i = 0; i < S::MT2; ++i)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int key = 16 * i + 4 * lg + r;
-                            float s = sacc[i][j][r] * scale;
-                            if (16 * i + 15 >= F2) s = key < F2 ? s : -INFINITY;      // (only the last key tile has padding rows)
-                            sacc[i][j][r] = s;
-                            mx = fmaxf(mx, s);
-                        }
-                    mx = rows_allreduce(mx, [](float p, float q) { return fmaxf(p, q); });
-                    float sum = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < S::MT2; ++i)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float p = __builtin_amdgcn_exp2f(sacc[i][j][r] - mx);
-                            sacc[i][j][r] = p;
-                            sum += p;
-                        }
-                    sum = rows_allreduce(sum, [](float p, float q) { return p + q; });
-                    inv_sum[j] = __builtin_amdgcn_rcpf(sum);      // applied to O below: the P V MFMAs need not wait for it
                 }
-                f32x4 oacc[MTD][S::MT2];
-                acc_init_zero<MTD, S::MT2>(oacc);
-                // k-step (i, r): lane group lg supplies key = 16 i + 4 lg + r  (matches the C/D row map)
+            }
+            if constexpr (!L::PERHEAD) {
+                __syncthreads();
+                if (k == 0) FE_CLK(24);
+                // attention: wave = head
+                attention_head<S, S::MT2, LDG>(Gi, Hl, wave * 3 * HD, wave, 0, 1, lane);
+            } else {
+                // one head at a time, all four waves on it: its 3 hd qkv columns (column tiles t0 .. t1 of the packed
+                // weight, (tile, row-tile group) jobs round-robin) -> Gi[F2P][3 hd + 2], then its attention with the
+                // query tiles split over the waves
+                constexpr int MGq = S::MT2 % 2 == 0 ? 2 : 1, NMGq = S::MT2 / MGq;
+                constexpr int NQW = ceil_div(S::MT2, kWaves);
+#pragma unroll 1
+                for (int hh = 0; hh < S::NH; ++hh) {
+                    const int c_lo = 3 * HD * hh, t0 = c_lo / 16, nth = (c_lo + 3 * HD - 1) / 16 - t0 + 1;
+                    const int wq = o.blk_qkv[0] + kb;
+#pragma unroll 1
+                    for (int q = wave; q < nth * NMGq; q += kWaves) {
+                        const int ct = t0 + q % nth, m0 = (q / nth) * MGq;
+                        f32x4 acc[MGq][1];
+                        acc_init_zero<MGq, 1>(acc);
+                        mma_panel<MGq, 1, S::KS_2, Lds<S>::PDK>(
+                            acc, [&](int i, int ks) { return Xb[(16 * (m0 + i) + li) * LDX + lg + 4 * ks]; },
+                            [&](int, int ks) { return wb.at_g(wq + (ct * S::KS_2 + ks) * 64); }, NoSide{});
+                        const int cl = 16 * ct + li - c_lo;
+                        if (cl >= 0 && cl < 3 * HD) {
 #pragma unroll
-                for (int i = 0; i < S::MT2; ++i)
+                            for (int i = 0; i < MGq; ++i)
+                                if (16 * (m0 + i) + 4 * lg < F2) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        int key = 16 * i + 4 * lg + r;
-                        key = key < F2 ? key : F2 - 1;
-                        float av[MTD];
-#pragma unroll
-                        for (int md = 0; md < MTD; ++md) {
-                            int d = 16 * md + li;
-                            d = d < HD ? d : HD - 1;
-                            av[md] = Gi[key * LDG + hoff + 2 * HD + d];
+                                    for (int r = 0; r < 4; ++r) Gi[(16 * (m0 + i) + 4 * lg + r) * LDG + cl] = acc[i][0][r];
+                                }
                         }
-#pragma unroll
-                        for (int md = 0; md < MTD; ++md)
-#pragma unroll
-                            for (int j = 0; j < S::MT2; ++j) oacc[md][j] = FE_MFMA(av[md], sacc[i][j][r], oacc[md][j]);
                     }
-                // O[query][h*HD + d]  (into Hl, dead after rnn_fc)
-#pragma unroll
-                for (int md = 0; md < MTD; ++md)
-#pragma unroll
-                    for (int j = 0; j < S::MT2; ++j) {
-                        const int q = 16 * j + li;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int d = 16 * md + 4 * lg + r;
-                            if (d < HD && q < F2) Hl[q * LDX + wave * HD + d] = oacc[md][j][r] * inv_sum[j];
-                        }
-                    }
+                    __syncthreads();
+                    attention_head<S, NQW, LDG>(Gi, Hl, 0, hh, wave, kWaves, lane);
+                    if (hh + 1 < S::NH) __syncthreads();           // (the next head overwrites Gi)
+                }
             }
             __syncthreads();
             if (k == 0) FE_CLK(25);

@@ -32,6 +32,7 @@ MODEL_KWARGS = {
     "fe48_t": (_kw(24, (8, 3, 3), 20, 24, 2, 1024, 512, "linear"), 48000, 107),
     "fe48_s": (_kw(64, (8, 3, 3, 3), 48, 48, 3, 1024, 512, "linear"), 48000, 108),
     "fe48_m": (_kw(96, (8, 3, 3, 3), 72, 72, 4, 1024, 320, "linear"), 48000, 109),
+    "fe48_l": (_kw(128, (8, 3, 3, 3, 3), 96, 96, 5, 1024, 200, "linear"), 48000, 110),
 }
 
 

@@ -66,6 +66,7 @@ CONFIGS = {
     "fe_m": ("configs/fastenhancer/m.yaml", 106, 1, 8, 0),
     "fe_l": ("configs/fastenhancer/l.yaml", 103, 1, 6, 0),
     "fe48_b": ("configs/fastenhancer_48khz/b.yaml", 104, 2, 8, 0),
+    "fe48_l": ("configs/fastenhancer_48khz/l.yaml", 110, 1, 5, 0),
 }
 
 
