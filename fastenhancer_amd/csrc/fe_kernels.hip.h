@@ -246,9 +246,11 @@ template <int NPW, int NP>
 struct StageSide {
     DmaJobT<NPW>* j;
     static constexpr int NPI = (NP + kWaves - 1) / kWaves;     // pieces per wave
+    // piece i rides in k-group slot(i, ng): spread over the first 2/3 of the GEMM so that the last one has landed by commit()
+    static constexpr int slot(int i, int ng) { const int span = (2 * ng + 2) / 3 > 0 ? (2 * ng + 2) / 3 : 1; return i * span / NPI; }
     static constexpr int loads(int g, int ng) {
         int n = 0;
-        for (int i = 0; i < NPI; ++i) n += (i * ng / NPI == g) ? 1 : 0;
+        for (int i = 0; i < NPI; ++i) n += (slot(i, ng) == g) ? 1 : 0;
         return n;
     }
     __device__ __forceinline__ void load(int i) const {
@@ -259,7 +261,7 @@ struct StageSide {
     __device__ __forceinline__ void operator()(int g, int ng) const {
 #pragma unroll
         for (int i = 0; i < NPI; ++i)
-            if (i * ng / NPI == g) load(i);
+            if (slot(i, ng) == g) load(i);
     }
     __device__ __forceinline__ void commit() const {
 #pragma unroll
