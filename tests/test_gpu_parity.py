@@ -173,6 +173,28 @@ def test_full_size_batch_256_matches_oracle_and_is_stream_independent():
     assert torch.equal(out, out2) and torch.equal(state, state2)
 
 
+def test_more_streams_than_cus_and_strided_buffers():
+    """600 streams (more workgroups than the 256 CUs, BASELINE config 4 uses 512) through row-strided in / out buffers."""
+    m, orc, cfg, sr, seed = _model("fe_t")
+    eng = m.engine
+    B, hops, H = 600, 3, cfg.hop_size
+    x = make_input(B, hops * H, 4242, sr)
+    big_in = torch.zeros(B, hops * H + 64, device=_dev())
+    big_in[:, :hops * H] = torch.from_numpy(x).to(_dev())
+    big_out = torch.full((B, hops * H + 32), 7.0, device=_dev())
+    state = eng.new_state(B)
+    for t in range(hops):       # per-hop launches on views: in stride T*H+64, out stride T*H+32
+        eng.step(big_in[:, t * H:(t + 1) * H], state, wav_out=big_out[:, t * H:(t + 1) * H], T=1)
+    assert float(big_out[:, hops * H:].min()) == 7.0            # nothing written past the rows
+    sel = [0, 1, 255, 256, 257, 511, 599]
+    caches = orc.initialize_cache(len(sel))
+    refs = []
+    for t in range(hops):
+        o, *caches = orc.step(x[sel, t * H:(t + 1) * H], *caches)
+        refs.append(o)
+    _assert_close(big_out[sel, :hops * H].cpu().numpy(), np.concatenate(refs, axis=1), "600 streams, strided")
+
+
 def test_edge_inputs():
     m, orc, cfg, sr, seed = _model("fe_b")
     eng = m.engine
