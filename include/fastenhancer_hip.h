@@ -109,7 +109,9 @@ int fe_debug_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, float
                   float* wav_out_dev, size_t out_stride, int B, float* dbg_dev, void* stream);
 
 /* Profiling: like fe_step, and thread 0 of workgroup 0 stores the shader cycle counter (s_memtime) at
- * the phase boundaries of the LAST frame into clk_dev[0..63] (see fe_kernels.hip.h, FE_CLK). */
+ * the phase boundaries of the LAST frame into clk_dev[0..63] (see fe_kernels.hip.h, FE_CLK; BSRNN:
+ * bsrnn_kernels.hip.h, BE_CLK).  Runs the debug / profile instantiation of the kernel, not the one fe_step runs;
+ * tools/gpu_phases.py and tools/gpu_phases_bsrnn.py print the table. */
 int fe_profile_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, float* state_dev,
                     float* wav_out_dev, size_t out_stride, int B, int T, unsigned long long* clk_dev, void* stream);
 
