@@ -1,0 +1,25 @@
+#!/bin/bash
+# rocprofv3 --kernel-trace --stats for every bench workload (kernel time per shape), run through gpurun from the repo root:
+#   tools/profile_shapes.sh <tag>   -> gpurun_out/shapes_<tag>.txt
+set -u
+TAG=${1:-r1}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/shapes_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+SUM=$ROOT/gpurun_out/shapes_$TAG.txt
+echo "# rocprofv3 --kernel-trace --stats, bench.py --no-cpu-baseline --steps 200 --warmup 20 --workload <w> (256 streams, 1 hop per launch)" > "$SUM"
+for w in fe_t fe_b fe_s fe_m fe_l fe48_t fe48_b fe48_s fe48_m fe48_l bsrnn_xxt bsrnn_xt bsrnn_t; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$w" -o s -- python $ROOT/bench.py --no-cpu-baseline --steps 200 --warmup 20 --workload $w > "$OUT/$w.json" 2> "$OUT/$w.err"
+  python - "$OUT/$w" "$w" "$OUT/$w.json" >> "$SUM" <<'PY'
+import csv, glob, json, sys
+d, w, j = sys.argv[1:4]
+line = open(j).read().strip().splitlines()[-1]
+b = json.loads(line)
+for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "frame_kernel" in row["Name"]:
+            print(f"{w:10s} {row['Name'][:70]:70s} calls={row['Calls']} avg_ns={float(row['AverageNs']):.0f}  bench under tracer: {b['value']:.0f} frames/s, frac {b['roofline']['frac']:.4f}")
+PY
+done
+cat "$SUM"
