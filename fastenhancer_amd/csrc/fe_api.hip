@@ -234,6 +234,12 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
             const float* whh = S(key("rnn.weight_hh_l0"));
             const float* bih = S(key("rnn.bias_ih_l0"));
             const float* bhh = S(key("rnn.bias_hh_l0"));
+            if (o.gru_flat) {   // one (3 C2)-column matrix, rows r | z | n as stored by nn.GRU
+                pack_1x1(o.blk_wih[k], wih, C2, 3 * C2);
+                pack_1x1(o.blk_whh[k], whh, C2, 3 * C2);
+                p.raw(o.blk_bih[k], 3 * C2, bih);
+                p.raw(o.blk_bhh[k], 3 * C2, bhh);
+            } else
             for (int g = 0; g < 3; ++g) {
                 pack_1x1(o.blk_wih[k] + g * gsz, wih + (size_t)g * C2 * C2, C2, C2);
                 pack_1x1(o.blk_whh[k] + g * gsz, whh + (size_t)g * C2 * C2, C2, C2);

@@ -75,6 +75,13 @@ struct Shape {
     static constexpr int KS_C = C1 / 4;           // k-steps over C1
     static constexpr int KS_2 = C2 / 4;           // k-steps over C2
     static constexpr int NU = 7 + 3 * NL;        // LDS-staged weight units (Pack<S>)
+    // RNNFormer-block weight fragments held in registers per wave (this wave's column tiles)
+    static constexpr int NTPW2 = ceil_div(NT2, kWaves), NTPW3 = ceil_div(NT3, kWaves);
+    // "flat" GRU gate GEMM: C2 not a multiple of 16 (T: 20, B: 36) pads every gate to whole column tiles (B: 3 x 48
+    // columns = 9 tiles, one wave idle); the gates as ONE 3 C2-column matrix need ceil(3 C2 / 16) tiles (B: 7) spread
+    // like the qkv GEMM.  r, z, n of a channel then sit in different lanes: the pre-activations cross through LDS
+    // and the gate math runs element-per-thread over all 256 threads.  (Register-resident weights only.)
+    static constexpr bool GFLAT = (C2 % 16 != 0) && (3 * NTPW3 + 2 * NTPW2) * KS_2 <= 160;
     static_assert(C1 % 4 == 0 && C2 % 4 == 0 && F2 % 4 == 0, "channel counts must be multiples of 4");
     static_assert(C2 % NH == 0, "C2 must be divisible by the 4 heads");
     static_assert(F1 % 64 == 0, "F1 must be a multiple of 64");
@@ -97,6 +104,7 @@ struct PackedOffsets {
     int post1_w, post1_b, post_t_w, post_t_b;
     int window, window_istft, twiddle;  // [N], [N], [N/2] float2
     int dft1, dft2, dft3, dft4;         // constant operands of the matrix-core DFT (see Dft<S>)
+    int gru_flat;                       // 1: GRU weights / biases packed as one (3 C2)-column matrix (Shape::GFLAT)
     int total;
     // LDS-staged weight "units" in consumption order (one per conv-type GEMM phase): [weights | bias],
     // 256-float aligned and padded, so that a unit is staged by whole 1-KiB global_load_lds pieces.
@@ -134,6 +142,7 @@ struct Pack {
         for (int k = 0; k < S::KB; ++k) {      // identical sizes per block: the offsets advance by blk_stride
             // GRU weights packed per gate (r, z, n): tile index = gate * NT2 + channel-tile, so that the three
             // gate pre-activations of one (row, channel) land in the same lane and the gates fuse into the epilogue
+            // (GFLAT shapes: one flat (3 C2)-column matrix in the same, larger, allocation)
             o.blk_wih[k] = alloc(3 * szB(C2, C2)); o.blk_whh[k] = alloc(3 * szB(C2, C2));
             o.blk_bih[k] = alloc(3 * szBias(C2)); o.blk_bhh[k] = alloc(3 * szBias(C2));
             o.blk_fc1_w[k] = alloc(szB(C2, C2)); o.blk_fc1_b[k] = alloc(szBias(C2));
@@ -141,6 +150,7 @@ struct Pack {
             o.blk_fc2_w[k] = alloc(szB(C2, C2)); o.blk_fc2_b[k] = alloc(szBias(C2));
         }
         o.blk_stride = S::KB > 1 ? o.blk_wih[1] - o.blk_wih[0] : 0;
+        o.gru_flat = S::GFLAT ? 1 : 0;
         o.window = alloc(S::NFFT); o.window_istft = alloc(S::NFFT); o.twiddle = alloc(S::NFFT);
         {
             constexpr int N1 = S::NFFT / 32, KC = N1 / 2, MT = N1 / 16;
@@ -1318,9 +1328,13 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         // weights of the RNNFormer-block GEMMs (this wave's output columns): register-resident and prefetched
         // one phase ahead when they fit (REGW), else streamed from L2 inside the GEMM pipeline
         constexpr int NTPW3 = ceil_div(S::NT3, kWaves);
-        constexpr bool REGW = (NTPW2 * 6 + NTPW3 + 2 * NTPW2) * S::KS_2 <= 160;
+        constexpr bool GFLAT = S::GFLAT;
+        constexpr bool REGW = GFLAT || (NTPW2 * 6 + NTPW3 + 2 * NTPW2) * S::KS_2 <= 160;
         using WS = WSrc<Lds<S>::STAGED>;
-        TokW<NTPW2, S::KS_2, 3, REGW, WS> Wgi, Wgh;     // GRU gates (r,z,n): input and hidden matrices
+        // GRU gates (r,z,n), input and hidden matrices: three column blocks per channel tile, or (GFLAT) one flat matrix
+        constexpr int GNT = GFLAT ? S::NT3 : S::NT2;
+        std::conditional_t<GFLAT, TokW<NTPW3, S::KS_2, 1, REGW, WS>, TokW<NTPW2, S::KS_2, 3, REGW, WS>> Wgi, Wgh;
+        float hkeep[GFLAT ? HPT : 1];                   // GFLAT: previous hidden state of this thread's gate elements
         TokW<NTPW2, S::KS_2, 1, REGW, WS> Wf1, Wf2;     // rnn_fc, attn_fc
         TokW<NTPW3, S::KS_2, 1, REGW, WS> Wq;           // qkv
         float pe_r[S::MT2][NTPW2][4];                                                  // positional embedding (block 0)
@@ -1330,7 +1344,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             constexpr int KS = F1 / 4;
             const float* Ein = encbuf(S::NL) + LDC;   // row 0 = bin 0
             FE_BEGIN_UNIT(1 + S::NL);
-            Wgi.bind(wb, o.blk_wih[0], o.blk_bih[0], S::NT2, wave);      // block 0's GRU input weights ride in this GEMM
+            Wgi.bind(wb, o.blk_wih[0], o.blk_bih[0], GNT, wave);      // block 0's GRU input weights ride in this GEMM
             f32x4 acc[S::MT2][NTPW];
             acc_init_zero<S::MT2, NTPW>(acc);
             mma_panel<S::MT2, NTPW, KS, Lds<S>::PDK>(
@@ -1359,7 +1373,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             // X[f2][c2] = Y1[f2][:] . Wc[c2][:] + b
             constexpr int NTPW = ceil_div(S::NT2, kWaves);
             FE_BEGIN_UNIT(2 + S::NL);
-            Wgh.bind(wb, o.blk_whh[0], o.blk_bhh[0], S::NT2, wave);      // ... and the hidden weights in this one
+            Wgh.bind(wb, o.blk_whh[0], o.blk_bhh[0], GNT, wave);      // ... and the hidden weights in this one
             // hidden state of block 0: fetched now, parked in LDS after the GEMM
             float hpre[HPT];
             {
@@ -1388,6 +1402,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             for (int q = 0; q < HPT; ++q) {
                 const int i = tid + q * kThreads;
                 if (i < F2 * C2) { const int f = i / C2; Hs[f * LDX + (i - f * C2)] = hpre[q]; }
+                if constexpr (GFLAT) hkeep[q] = hpre[q];
             }
         }
         __syncthreads();
@@ -1424,7 +1439,81 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 // the state, no register-resident residual - runs over (column tile, row-tile group) jobs instead,
                 // round-robin: 15 jobs -> 4:4:4:3, 12 jobs -> 3:3:3:3.
                 constexpr bool GBAL = !REGW && S::NT2 > 4;
-                if constexpr (GBAL) {
+                if constexpr (GFLAT) {
+                    // gates as one (3 C2)-column GEMM over this wave's flat column tiles (see Shape::GFLAT); the
+                    // pre-activations cross through LDS: r | z | n_x -> Gi[row][0 .. 3 C2), n_h -> Hl[row][c]
+                    constexpr int K2 = S::KS_2;
+                    f32x4 ax[S::MT2][NTPW3], ah[S::MT2][NTPW3];
+#pragma unroll
+                    for (int j = 0; j < NTPW3; ++j) {
+                        const float bi = Wgi.bias(j, 0), bh = Wgh.bias(j, 0);
+#pragma unroll
+                        for (int i = 0; i < S::MT2; ++i) { ax[i][j] = f32x4{bi, bi, bi, bi}; ah[i][j] = f32x4{bh, bh, bh, bh}; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k == 0) FE_CLK(45);
+                    mma_panel_sel<S::MT2, NTPW3, 2 * K2, Lds<S>::PDK>(
+                        [&](int i, int j, int ks) -> f32x4& { return ks < K2 ? ax[i][j] : ah[i][j]; },
+                        [&](int i, int ks) { return ks < K2 ? Xb[(16 * i + li) * LDX + lg + 4 * ks] : Hs[(16 * i + li) * LDX + lg + 4 * (ks - K2)]; },
+                        [&](int j, int ks) { return ks < K2 ? Wgi.get(j, 0, ks) : Wgh.get(j, 0, ks - K2); }, FetchSide<decltype(Wf1)>{&Wf1});
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k == 0) FE_CLK(46);
+                    // (pad rows / columns of Gi are written too - they are never read; Hl's rows are narrower)
+                    {
+                        float* gdst = Gi + (4 * lg) * LDG + 16 * wave + li;
+#pragma unroll
+                        for (int j = 0; j < NTPW3; ++j) {
+                            const int g = 16 * (wave + 4 * j) + li;
+                            const bool rz = g < 2 * C2, nh = !rz && g < 3 * C2;
+                            // lanes without an n_h value store into Hl's pad column: no predicate on the stores
+                            float* hdst = Hl + (4 * lg) * LDX + (nh ? g - 2 * C2 : C2);
+                            if (wave + 4 * j < S::NT3) {
+#pragma unroll
+                                for (int i = 0; i < S::MT2; ++i)
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const float sx = ax[i][j][r], sh = ah[i][j][r];
+                                        gdst[(16 * i + r) * LDG + 64 * j] = rz ? sx + sh : sx;
+                                        hdst[(16 * i + r) * LDX] = sh;
+                                    }
+                            }
+                        }
+                    }
+                    if (k == 0) FE_CLK(48);
+                    __syncthreads();
+                    if (k == 0) FE_CLK(49);
+                    {
+                        // element e = row * C2 + c per thread, HPT rounds; loads first, the gate chains interleave
+                        float gr[HPT], gz[HPT], gn[HPT], gh[HPT];
+                        int eo[HPT];
+#pragma unroll
+                        for (int q = 0; q < HPT; ++q) {
+                            int e = tid + q * kThreads;
+                            e = e < F2 * C2 ? e : F2 * C2 - 1;
+                            const int row = e / C2, c = e - row * C2;
+                            eo[q] = row * LDX + c;
+                            gr[q] = Gi[row * LDG + c];
+                            gz[q] = Gi[row * LDG + C2 + c];
+                            gn[q] = Gi[row * LDG + 2 * C2 + c];
+                            gh[q] = Hl[eo[q]];
+                        }
+                        float hn[HPT];
+#pragma unroll
+                        for (int q = 0; q < HPT; ++q) {
+                            const float rr = sigmoid_f(gr[q]);
+                            const float zz = sigmoid_f(gz[q]);
+                            const float nn = tanh_f(gn[q] + rr * gh[q]);
+                            hn[q] = (1.0f - zz) * nn + zz * hkeep[q];
+                        }
+#pragma unroll
+                        for (int q = 0; q < HPT; ++q) asm volatile("" : "+v"(hn[q]));   // (keeps the chains out of the store predicate)
+#pragma unroll
+                        for (int q = 0; q < HPT; ++q) {
+                            const int e = tid + q * kThreads;
+                            if ((q + 1) * kThreads <= F2 * C2 || e < F2 * C2) { Hl[eo[q]] = hn[q]; hg[e] = hn[q]; }
+                        }
+                    }
+                } else if constexpr (GBAL) {
                     constexpr int MG = (S::MT2 % 2 == 0 && (S::NT2 * (S::MT2 / 2)) % kWaves == 0) ? 2 : 1;   // row tiles per job
                     constexpr int NMG = S::MT2 / MG, NJ = S::NT2 * NMG;
                     const int wih = o.blk_wih[0] + kb, whh = o.blk_whh[0] + kb, bih = o.blk_bih[0] + kb, bhh = o.blk_bhh[0] + kb;
@@ -1554,7 +1643,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 constexpr int NTPW = NTPW3;
                 // fetched inside the GEMM: attn_fc weights and the next block's GRU input weights
                 Wf2.bind(wb, (o.blk_fc2_w[0] + kb), (o.blk_fc2_b[0] + kb), S::NT2, wave);
-                Wgi.bind(wb, (o.blk_wih[0] + kb + o.blk_stride), (o.blk_bih[0] + kb + o.blk_stride), S::NT2, wave, k + 1 < S::KB);
+                Wgi.bind(wb, (o.blk_wih[0] + kb + o.blk_stride), (o.blk_bih[0] + kb + o.blk_stride), GNT, wave, k + 1 < S::KB);
                 if constexpr (!L::PERHEAD) {
                 f32x4 acc[S::MT2][NTPW];
                 tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Xb + li * LDX + lg, Wq, FetchSide2<decltype(Wf2), decltype(Wgi)>{&Wf2, &Wgi});
@@ -1615,7 +1704,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 constexpr int NTPW = ceil_div(S::NT2, kWaves);
                 float hpre[HPT];
                 // next block: GRU hidden weights into registers inside the GEMM; hidden state fetched now / parked after it
-                Wgh.bind(wb, (o.blk_whh[0] + kb + o.blk_stride), (o.blk_bhh[0] + kb + o.blk_stride), S::NT2, wave, k + 1 < S::KB);
+                Wgh.bind(wb, (o.blk_whh[0] + kb + o.blk_stride), (o.blk_bhh[0] + kb + o.blk_stride), GNT, wave, k + 1 < S::KB);
                 if (k + 1 < S::KB) {
                     const float* hgn = hg + (size_t)a.B * (F2 * C2);
 #pragma unroll
@@ -1628,6 +1717,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     for (int q = 0; q < HPT; ++q) {
                         const int i = tid + q * kThreads;
                         if (i < F2 * C2) { const int f = i / C2; Hs[f * LDX + (i - f * C2)] = hpre[q]; }
+                        if constexpr (GFLAT) hkeep[q] = hpre[q];
                     }
                 }
 #pragma unroll

@@ -41,6 +41,8 @@ def main():
         print(f"  {NAMES[i + 1] if False else NAMES[i]:12s}->{NAMES[i+1] if i+1 < len(NAMES) else 'end':12s} {d:8d} cyc  {100.0 * d / tot:5.1f}%")
     print("  enc layer 0: gemm %d, epilogue %d, barrier %d" % (c[41]-c[40], c[42]-c[41], c[43]-c[42]))
     print("  block 0 GRU: setup %d, gemm %d, epilogue %d, barrier %d" % (c[45]-c[20], c[46]-c[45], c[47]-c[46], c[21]-c[47]))
+    if c[48] and c[49]:
+        print("  block 0 GRU (flat gates): store %d, barrier %d, gate math %d" % (c[48]-c[46], c[49]-c[48], c[47]-c[49]))
     print("  block 0 detail:")
     prev = c[20]
     for i, nm in enumerate(BLK[1:], start=21):
