@@ -1443,17 +1443,21 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     // gates as one (3 C2)-column GEMM over this wave's flat column tiles (see Shape::GFLAT); the
                     // pre-activations cross through LDS: r | z | n_x -> Gi[row][0 .. 3 C2), n_h -> Hl[row][c]
                     constexpr int K2 = S::KS_2;
+                    // column tiles 4 j .. 4 j + 3 (this j of the four waves) that hold only r / z columns sum x and h
+                    // parts in ONE accumulator
+                    auto pure_rz = [](int j) constexpr { return 16 * (4 * j + 4) <= 2 * C2; };
                     f32x4 ax[S::MT2][NTPW3], ah[S::MT2][NTPW3];
 #pragma unroll
                     for (int j = 0; j < NTPW3; ++j) {
                         const float bi = Wgi.bias(j, 0), bh = Wgh.bias(j, 0);
+                        const float b0 = pure_rz(j) ? bi + bh : bi;
 #pragma unroll
-                        for (int i = 0; i < S::MT2; ++i) { ax[i][j] = f32x4{bi, bi, bi, bi}; ah[i][j] = f32x4{bh, bh, bh, bh}; }
+                        for (int i = 0; i < S::MT2; ++i) { ax[i][j] = f32x4{b0, b0, b0, b0}; ah[i][j] = f32x4{bh, bh, bh, bh}; }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (k == 0) FE_CLK(45);
                     mma_panel_sel<S::MT2, NTPW3, 2 * K2, Lds<S>::PDK>(
-                        [&](int i, int j, int ks) -> f32x4& { return ks < K2 ? ax[i][j] : ah[i][j]; },
+                        [&](int i, int j, int ks) -> f32x4& { return ks < K2 || pure_rz(j) ? ax[i][j] : ah[i][j]; },
                         [&](int i, int ks) { return ks < K2 ? Xb[(16 * i + li) * LDX + lg + 4 * ks] : Hs[(16 * i + li) * LDX + lg + 4 * (ks - K2)]; },
                         [&](int j, int ks) { return ks < K2 ? Wgi.get(j, 0, ks) : Wgh.get(j, 0, ks - K2); }, FetchSide<decltype(Wf1)>{&Wf1});
                     __builtin_amdgcn_sched_barrier(0);
@@ -1467,7 +1471,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                             const bool rz = g < 2 * C2, nh = !rz && g < 3 * C2;
                             // lanes without an n_h value store into Hl's pad column: no predicate on the stores
                             float* hdst = Hl + (4 * lg) * LDX + (nh ? g - 2 * C2 : C2);
-                            if (wave + 4 * j < S::NT3) {
+                            if (pure_rz(j)) {
+#pragma unroll
+                                for (int i = 0; i < S::MT2; ++i)
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) gdst[(16 * i + r) * LDG + 64 * j] = ax[i][j][r];
+                            } else if (wave + 4 * j < S::NT3) {
 #pragma unroll
                                 for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
