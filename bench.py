@@ -44,6 +44,8 @@ WORKLOADS = {
                  desc="FastEnhancer_S 16kHz"),
     "fe48_b": dict(C1=48, ks=(8, 3, 3), C2=36, F2=36, K=3, N=1024, H=512, sr=48000, init="linear",
                    desc="FastEnhancer_B 48kHz"),
+    "fe48_b_h480": dict(C1=48, ks=(8, 3, 3), C2=36, F2=36, K=3, N=1024, H=480, sr=48000, init="linear",
+                        desc="FastEnhancer_B 48kHz at a 10 ms hop (BASELINE config 4 wording)"),
     "fe48_l": dict(C1=128, ks=(8, 3, 3, 3, 3), C2=96, F2=96, K=5, N=1024, H=200, sr=48000, init="linear",
                    desc="FastEnhancer_L 48kHz"),
     "fe48_t": dict(C1=24, ks=(8, 3, 3), C2=20, F2=24, K=2, N=1024, H=512, sr=48000, init="linear",

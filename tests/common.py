@@ -33,6 +33,7 @@ MODEL_KWARGS = {
     "fe48_s": (_kw(64, (8, 3, 3, 3), 48, 48, 3, 1024, 512, "linear"), 48000, 108),
     "fe48_m": (_kw(96, (8, 3, 3, 3), 72, 72, 4, 1024, 320, "linear"), 48000, 109),
     "fe48_l": (_kw(128, (8, 3, 3, 3, 3), 96, 96, 5, 1024, 200, "linear"), 48000, 110),
+    "fe48_b_h480": (_kw(48, (8, 3, 3), 36, 36, 3, 1024, 480, "linear"), 48000, 111),   # BASELINE config 4's "hop=480"
 }
 
 

@@ -17,8 +17,8 @@ pytestmark = pytest.mark.gpu
 
 ABS_TOL = 1e-4
 REL_TOL = 1e-4
-GPU_SHAPES = ["fe_t", "fe_b", "fe_m", "fe_l", "fe48_b", "fe48_l"]          # shapes with reference goldens
-ALL_SHAPES = ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m", "fe48_l"]
+GPU_SHAPES = ["fe_t", "fe_b", "fe_m", "fe_l", "fe48_b", "fe48_l", "fe48_b_h480"]          # shapes with reference goldens
+ALL_SHAPES = ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m", "fe48_l", "fe48_b_h480"]
 
 
 def _dev():

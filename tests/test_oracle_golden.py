@@ -6,7 +6,7 @@ import pytest
 from common import MODEL_KWARGS, build_oracle, load_golden, rms
 from oracle.weightgen import make_input
 
-GOLDENS = ["fe_t", "fe_b", "fe_m", "fe_l", "fe48_b", "fe48_l"]
+GOLDENS = ["fe_t", "fe_b", "fe_m", "fe_l", "fe48_b", "fe48_l", "fe48_b_h480"]
 # fp32-vs-fp32 different summation orders: the reference's own fp32 noise floor is ~5e-7
 # relative; allow 20x that.
 REL = 1e-5

@@ -67,6 +67,8 @@ CONFIGS = {
     "fe_l": ("configs/fastenhancer/l.yaml", 103, 1, 6, 0),
     "fe48_b": ("configs/fastenhancer_48khz/b.yaml", 104, 2, 8, 0),
     "fe48_l": ("configs/fastenhancer_48khz/l.yaml", 110, 1, 5, 0),
+    # BASELINE.json config 4 words the 48 kHz case as "hop=480" (every shipped 48 kHz yaml uses 512): b.yaml with hop_size overridden
+    "fe48_b_h480": ("configs/fastenhancer_48khz/b.yaml", 111, 2, 8, 0, {"hop_size": 480}),
 }
 
 
@@ -75,9 +77,11 @@ def to_t(sd):
 
 
 def gen_fastenhancer(ref: str, name: str, out_dir: str):
-    rel_yaml, seed, B, hops, long_hops = CONFIGS[name]
+    rel_yaml, seed, B, hops, long_hops = CONFIGS[name][:5]
     hps = yaml.safe_load(open(os.path.join(ref, rel_yaml)))
     kw = hps["model_kwargs"]
+    if len(CONFIGS[name]) > 5:
+        kw.update(CONFIGS[name][5])
     sr = hps["data"]["sampling_rate"]
     cfg = FEConfig.from_model_kwargs(kw)
     mod = import_reference_model(ref, "models/fastenhancer/default/model.py", "ref_fe_model")
