@@ -14,8 +14,9 @@ from fastenhancer_amd.config import FEConfig  # noqa: E402
 from fastenhancer_amd.engine import Engine  # noqa: E402
 from fastenhancer_amd.weights import default_state_dict  # noqa: E402
 
-NAMES = ["stft load", "fft", "spec dump", "compress", "enc_pre", "encoder", "rf_pre", "blocks", "rf_post", "decoder",
-         "dec_post", "mask", "ifft", "ola"]
+# interval i = probe i -> probe i + 1
+NAMES = ["frame load + window", "forward DFT", "compress", "enc_pre", "encoder", "rf_pre", "RNNFormer blocks", "rf_post",
+         "decoder", "dec_post + transposed conv", "mask + un-compress", "inverse DFT", "overlap-add + store"]
 BLK = ["-", "gru+gates", "(none)", "fc1", "qkv", "attention", "fc2"]
 
 
@@ -38,7 +39,7 @@ def main():
     print(f"{name} B={B}: frame = {tot} cycles")
     for i in range(13):
         d = c[i + 1] - c[i]
-        print(f"  {NAMES[i + 1] if False else NAMES[i]:12s}->{NAMES[i+1] if i+1 < len(NAMES) else 'end':12s} {d:8d} cyc  {100.0 * d / tot:5.1f}%")
+        print(f"  {NAMES[i]:28s} {d:8d} cyc  {100.0 * d / tot:5.1f}%")
     print("  enc layer 0: gemm %d, epilogue %d, barrier %d" % (c[41]-c[40], c[42]-c[41], c[43]-c[42]))
     print("  block 0 GRU: setup %d, gemm %d, epilogue %d, barrier %d" % (c[45]-c[20], c[46]-c[45], c[47]-c[46], c[21]-c[47]))
     if c[48] and c[49]:
