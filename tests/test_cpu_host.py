@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.fe_version()
 
 
-@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m"])
+@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m", "fe48_l", "fe48_b_h480"])
 def test_section_table_matches_fused_schema(name):
     kw, sr, seed = MODEL_KWARGS[name]
     cfg = FEConfig.from_model_kwargs(**kw)
