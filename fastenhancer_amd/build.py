@@ -20,7 +20,7 @@ FE_DEPS = ["fe_kernels.hip.h", "fe_impl.h"]
 BSRNN_DEPS = ["fe_kernels.hip.h", "bsrnn_kernels.hip.h"]
 API_DEPS = ["fe_kernels.hip.h", "fe_impl.h", "fe_shapes.def", "bsrnn_kernels.hip.h", "fe_bsrnn_shapes.def",
             os.path.join("..", "..", "include", "fastenhancer_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("FE_EXTRA_DEFS", "").split()   # e.g. -DFE_PROBE_HOT
 
 
 def _hipcc() -> str:

@@ -36,7 +36,11 @@ void launch_one(const FrameArgs& a, hipStream_t st, hipError_t* err) {
 
 template <class S>
 void launch_impl(const FrameArgs& a, hipStream_t st, hipError_t* err) {
+#ifdef FE_PROBE_HOT
+    if (a.dbg != nullptr) launch_one<S, true, -1, false>(a, st, err);
+#else
     if (a.dbg != nullptr || a.clk != nullptr) launch_one<S, true, -1, false>(a, st, err);     // fe_debug_step / fe_profile_step
+#endif
     else if (a.mode == FE_MODE_STREAM && a.T == 1) launch_one<S, false, FE_MODE_STREAM, true>(a, st, err);   // the per-hop hot path
     else launch_one<S, false, -1, false>(a, st, err);                             // chunked streaming, fe_spec_step, fe_offline
 }

@@ -1040,7 +1040,11 @@ __device__ __forceinline__ void attention_head(const float* G, float* Hl, int ho
 template <class S, bool DBG, int MODE, bool T1>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) fe_frame_kernel(FrameArgs a_in) {
     FrameArgs a = a_in;
+#ifdef FE_PROBE_HOT          // measurement builds: the production instantiations keep the cycle probes (tools/gpu_phases.py ... 1)
+    if constexpr (!DBG) a.dbg = nullptr;
+#else
     if constexpr (!DBG) { a.dbg = nullptr; a.clk = nullptr; }
+#endif
     if constexpr (MODE >= 0) a.mode = MODE;
     if constexpr (MODE == FE_MODE_STREAM) { a.spec_in = nullptr; a.spec_out = nullptr; a.Tw = 0; }
     if constexpr (T1) a.T = 1;                       // one hop per launch (the per-hop driver loop): no frame loop, and the

@@ -28,7 +28,7 @@ def main():
     eng = Engine(cfg, dev)
     eng.load_state_dict(default_state_dict(cfg, torch.Generator().manual_seed(1)))
     H = cfg.hop_size
-    T = 4
+    T = int(sys.argv[3]) if len(sys.argv) > 3 else 4     # 1: the per-hop kernel (needs a build with FE_EXTRA_DEFS=-DFE_PROBE_HOT)
     x = (0.1 * torch.randn(B, T * H, device=dev)).contiguous()
     st = eng.new_state(B)
     for _ in range(3):
