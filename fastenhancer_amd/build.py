@@ -20,7 +20,11 @@ FE_DEPS = ["fe_kernels.hip.h", "fe_impl.h"]
 BSRNN_DEPS = ["fe_kernels.hip.h", "bsrnn_kernels.hip.h"]
 API_DEPS = ["fe_kernels.hip.h", "fe_impl.h", "fe_shapes.def", "bsrnn_kernels.hip.h", "fe_bsrnn_shapes.def",
             os.path.join("..", "..", "include", "fastenhancer_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("FE_EXTRA_DEFS", "").split()   # e.g. -DFE_PROBE_HOT
+# -amdgpu-mfma-vgpr-form: MFMA accumulators in VGPRs instead of AGPRs - every epilogue read of an AGPR accumulator is a
+# v_accvgpr_read, a VALU instruction that the fp32 matrix path cannot overlap (~600 of them per wave and frame on
+# FastEnhancer_B: +1.8 %, 48 kHz B +2.6 %, T +2.3 %, the big shapes +1 %).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+FLAGS += os.environ.get("FE_EXTRA_DEFS", "").split()   # e.g. -DFE_PROBE_HOT (tools/gpu_phases.py <shape> <streams> 1)
 
 
 def _hipcc() -> str:
