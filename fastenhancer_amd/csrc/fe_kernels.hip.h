@@ -974,18 +974,18 @@ __device__ __forceinline__ void attention_head(const float* G, float* Hl, int ho
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = 16 * i + 4 * lg + r;
-                float sv = sacc[i][j][r] * scale;
+                float sv = sacc[i][j][r];                                    // raw score: the (positive) scale commutes with the max
                 if (16 * i + 15 >= F2) sv = key < F2 ? sv : -INFINITY;      // (only the last key tile has padding rows)
                 sacc[i][j][r] = sv;
                 mx = fmaxf(mx, sv);
             }
-        mx = rows_allreduce(mx, [](float p, float q) { return fmaxf(p, q); });
+        mx = rows_allreduce(mx, [](float p, float q) { return fmaxf(p, q); }) * scale;
         float sum = 0.0f;
 #pragma unroll
         for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float p = __builtin_amdgcn_exp2f(sacc[i][j][r] - mx);
+                float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[i][j][r], scale, -mx));
                 sacc[i][j][r] = p;
                 sum += p;
             }
