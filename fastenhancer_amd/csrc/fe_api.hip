@@ -273,6 +273,17 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
         p.pack_b(o.post_t_w, C1, 16, [&](int k, int n) { return w[k * 16 + n]; });
         p.raw(o.post_t_b, 2, S("dec_post.2.bias"));
     }
+    {   // scaled conv trunk (fe_kernels.hip.h, kSiluScale): biases of the SiLU layers, entry weights, exit weights
+        const float c = fe::kSiluScale;
+        auto szB = [](int K, int N) { return (size_t)fe::ceil_div(N, 16) * (K / 4) * 64; };
+        auto scale = [&](int off, size_t n, float f) { for (size_t i = 0; i < n; ++i) p.buf[(size_t)off + i] *= f; };
+        scale(o.enc_pre_w, szB(16, C1), c); scale(o.enc_pre_b, C1, c);
+        for (int i = 0; i < d.NL; ++i) { scale(o.enc_b[i], C1, c); scale(o.dec1_b[i], C1, c); scale(o.dec3_b[i], C1, c); }
+        scale(o.rfpre_w, szB(C1, C2), 1.0f / c);                                  // encoder -> RNNFormer: back to true scale
+        scale(o.rfpost_w, szB(C2, C1), c); scale(o.rfpost_b, C1, c);              // RNNFormer -> decoder: scaled again
+        scale(o.post1_b, C1, c);
+        scale(o.post_t_w, szB(C1, 16), 1.0f / c);                                 // transposed conv: true-scale mask
+    }
     p.raw(o.window, h->window.size(), h->window.data());
     p.raw(o.window_istft, h->window_istft.size(), h->window_istft.data());
     p.raw(o.twiddle, h->twiddle.size(), h->twiddle.data());

@@ -190,6 +190,14 @@ struct FrameArgs {
 // 1e-7 (measured against the oracle per stage), far inside the 1e-4 waveform budget.
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// The conv trunk (enc_pre .. encoder, rf_post .. decoder .. dec_post) carries its activations SCALED by
+// kSiluScale = -log2(e): with u = kSiluScale * v the SiLU is  kSiluScale * silu(v) = u / (1 + 2^u)  - one VALU multiply
+// less per element than x * rcp(1 + exp2(x * -log2 e)), and VALU instructions are not hidden by anything on this path
+// (DESIGN.md §3).  A conv fed by scaled activations produces scaled pre-activations from UNCHANGED weights; the host
+// packer (fe_api.hip) scales the biases, the first layer's weights (enc_pre, rf_post's 1x1) and un-scales at the two
+// exits (rf_pre's 1x1, the transposed conv).  Debug dumps of those stages are un-scaled on the way out.
+constexpr float kSiluScale = -1.4426950408889634f;
+__device__ __forceinline__ float silu_scaled_f(float u) { return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u)); }
 // x^p for x > 0 through the 1-ulp hardware log2 / exp2 (v_log_f32, v_exp_f32); pow_f(0, p > 0) = 0
 __device__ __forceinline__ float pow_f(float x, float p) { return x > 0.0f ? __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x)) : 0.0f; }
 __device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
@@ -491,9 +499,12 @@ __device__ __forceinline__ void dbg_dump(const FrameArgs& a, int b, int stage, c
     using D = DebugLayout<S>;
     const int rows = D::rows(stage), cols = D::cols(stage);
     float* dst = a.dbg + (size_t)b * a.dbg_stride + D::offset(stage);
+    // conv-trunk stages (enc_pre, encoder.i, rf_post, decoder.i) live scaled by kSiluScale
+    const bool trunk = (stage >= 2 && stage < 3 + S::NL) || (stage >= 4 + S::NL + 2 * S::KB && stage < 5 + 2 * S::NL + 2 * S::KB);
+    const float sc = trunk ? 1.0f / kSiluScale : 1.0f;
     for (int i = threadIdx.x; i < rows * cols; i += kThreads) {
         int r = i / cols, c = i - r * cols;
-        dst[i] = src[r * ld + c];
+        dst[i] = src[r * ld + c] * sc;
     }
 }
 
@@ -800,7 +811,7 @@ __device__ __forceinline__ void conv_store(const f32x4 (&acc)[S::MTPW][NT], floa
                 for (int r = 0; r < 4; ++r) {
                     const int m = 16 * (wave + 4 * i) + 4 * lg + r;
                     float v = acc[i][j][r];
-                    if (ACT) v = silu_f(v);
+                    if (ACT) v = silu_scaled_f(v);
                     out[(row0 + m) * LDO + col] = v;
                     if (gskip != nullptr) gskip[((wave + 4 * i) * S::KS_C + (col >> 2)) * 64 + (col & 3) * 16 + 4 * lg + r] = v;
                 }
@@ -841,7 +852,7 @@ __device__ __forceinline__ void conv_nsplit(AF&& af, const WS& w, int w_off, int
                 for (int r = 0; r < 4; ++r) {
                     const int m = 16 * i + 4 * lg + r;
                     float v = acc[ii][j][r];
-                    if (ACT) v = silu_f(v);
+                    if (ACT) v = silu_scaled_f(v);
                     out[(row0 + m) * LDO + col] = v;
                     if (gskip != nullptr) gskip[(i * S::KS_C + (col >> 2)) * 64 + (col & 3) * 16 + 4 * lg + r] = v;
                 }
