@@ -189,6 +189,10 @@ struct Packer {
                 }
     }
     void raw(int off, size_t n, const float* src) { memcpy(&buf[off], src, n * sizeof(float)); }
+    void rep4(int off, size_t n, const float* src) {   // [n][4]: each value four times (16-byte accumulator initialisers)
+        for (size_t i = 0; i < n; ++i)
+            for (int r = 0; r < 4; ++r) buf[(size_t)off + 4 * i + r] = src[i];
+    }
 };
 
 const float* sec(const fe_handle* h, const std::vector<float>& blob, const std::string& name) {
@@ -214,17 +218,17 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
     {   // enc_pre: weight (C1, 8, 2): B[k = t*8 + ch][n = co] = W[co][ch][t]
         const float* w = S("enc_pre.0.weight");
         p.pack_b(o.enc_pre_w, 16, C1, [&](int k, int n) { return w[(n * 8 + (k & 7)) * 2 + (k >> 3)]; });
-        p.raw(o.enc_pre_b, C1, S("enc_pre.0.bias"));
+        p.rep4(o.enc_pre_b, C1, S("enc_pre.0.bias"));
     }
     for (int i = 0; i < d.NL; ++i) {
         snprintf(nm, sizeof nm, "encoder.%d.0.weight", i); pack_k3(o.enc_w[i], S(nm));
-        snprintf(nm, sizeof nm, "encoder.%d.0.bias", i); p.raw(o.enc_b[i], C1, S(nm));
+        snprintf(nm, sizeof nm, "encoder.%d.0.bias", i); p.rep4(o.enc_b[i], C1, S(nm));
     }
     {   // rf_pre: Linear (F2, F1) as A operand, then 1x1 conv (C2, C1)
         const float* w = S("rf_pre.0.weight");
         p.pack_a(o.rfpre_lin, F2, F1, [&](int m, int k) { return w[m * F1 + k]; });
         pack_1x1(o.rfpre_w, S("rf_pre.1.weight"), C1, C2);
-        p.raw(o.rfpre_b, C2, S("rf_pre.1.bias"));
+        p.rep4(o.rfpre_b, C2, S("rf_pre.1.bias"));
     }
     for (int k = 0; k < d.KB; ++k) {
         auto key = [&](const char* s) { snprintf(nm, sizeof nm, "rf_block.%d.%s", k, s); return std::string(nm); };
@@ -258,16 +262,16 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
         const float* w = S("rf_post.0.weight");   // (F1, F2)
         p.pack_a(o.rfpost_lin, F1, F2, [&](int m, int k) { return w[m * F2 + k]; });
         pack_1x1(o.rfpost_w, S("rf_post.1.weight"), C2, C1);
-        p.raw(o.rfpost_b, C1, S("rf_post.1.bias"));
+        p.rep4(o.rfpost_b, C1, S("rf_post.1.bias"));
     }
     for (int i = 0; i < d.NL; ++i) {
         snprintf(nm, sizeof nm, "decoder.%d.0.weight", i); pack_1x1(o.dec1_w[i], S(nm), 2 * C1, C1);
-        snprintf(nm, sizeof nm, "decoder.%d.0.bias", i); p.raw(o.dec1_b[i], C1, S(nm));
+        snprintf(nm, sizeof nm, "decoder.%d.0.bias", i); p.rep4(o.dec1_b[i], C1, S(nm));
         snprintf(nm, sizeof nm, "decoder.%d.2.weight", i); pack_k3(o.dec3_w[i], S(nm));
-        snprintf(nm, sizeof nm, "decoder.%d.2.bias", i); p.raw(o.dec3_b[i], C1, S(nm));
+        snprintf(nm, sizeof nm, "decoder.%d.2.bias", i); p.rep4(o.dec3_b[i], C1, S(nm));
     }
     pack_1x1(o.post1_w, S("dec_post.0.weight"), 2 * C1, C1);
-    p.raw(o.post1_b, C1, S("dec_post.0.bias"));
+    p.rep4(o.post1_b, C1, S("dec_post.0.bias"));
     {   // transposed conv weight (C1, 2, 8): B[k = ci][n = co*8 + j]
         const float* w = S("dec_post.2.weight");
         p.pack_b(o.post_t_w, C1, 16, [&](int k, int n) { return w[k * 16 + n]; });
@@ -277,11 +281,11 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
         const float c = fe::kSiluScale;
         auto szB = [](int K, int N) { return (size_t)fe::ceil_div(N, 16) * (K / 4) * 64; };
         auto scale = [&](int off, size_t n, float f) { for (size_t i = 0; i < n; ++i) p.buf[(size_t)off + i] *= f; };
-        scale(o.enc_pre_w, szB(16, C1), c); scale(o.enc_pre_b, C1, c);
-        for (int i = 0; i < d.NL; ++i) { scale(o.enc_b[i], C1, c); scale(o.dec1_b[i], C1, c); scale(o.dec3_b[i], C1, c); }
+        scale(o.enc_pre_w, szB(16, C1), c); scale(o.enc_pre_b, 4 * C1, c);       // (biases: 4x replicated tables)
+        for (int i = 0; i < d.NL; ++i) { scale(o.enc_b[i], 4 * C1, c); scale(o.dec1_b[i], 4 * C1, c); scale(o.dec3_b[i], 4 * C1, c); }
         scale(o.rfpre_w, szB(C1, C2), 1.0f / c);                                  // encoder -> RNNFormer: back to true scale
-        scale(o.rfpost_w, szB(C2, C1), c); scale(o.rfpost_b, C1, c);              // RNNFormer -> decoder: scaled again
-        scale(o.post1_b, C1, c);
+        scale(o.rfpost_w, szB(C2, C1), c); scale(o.rfpost_b, 4 * C1, c);              // RNNFormer -> decoder: scaled again
+        scale(o.post1_b, 4 * C1, c);
         scale(o.post_t_w, szB(C1, 16), 1.0f / c);                                 // transposed conv: true-scale mask
     }
     p.raw(o.window, h->window.size(), h->window.data());

@@ -124,17 +124,19 @@ struct Pack {
         auto ubegin = [&]() { cur = round_up(cur, 256); o.u_off[nu] = cur; };
         auto uend = [&]() { cur = round_up(cur, 256); o.u_size[nu] = cur - o.u_off[nu]; ++nu; };
         constexpr int C1 = S::C1, C2 = S::C2, F1 = S::F1, F2 = S::F2;
-        ubegin(); o.enc_pre_w = alloc(szB(16, C1)); o.enc_pre_b = alloc(szBias(C1)); uend();
-        for (int l = 0; l < S::NL; ++l) { ubegin(); o.enc_w[l] = alloc(szB(3 * C1, C1)); o.enc_b[l] = alloc(szBias(C1)); uend(); }
+        // conv-type biases are stored 4x replicated ([channel][4]): one 16-byte read initialises the four accumulator
+        // rows of a lane - replicating in registers costs three v_mov per tile, and VALU work is never hidden here
+        ubegin(); o.enc_pre_w = alloc(szB(16, C1)); o.enc_pre_b = alloc(4 * szBias(C1)); uend();
+        for (int l = 0; l < S::NL; ++l) { ubegin(); o.enc_w[l] = alloc(szB(3 * C1, C1)); o.enc_b[l] = alloc(4 * szBias(C1)); uend(); }
         ubegin(); o.rfpre_lin = alloc(szA(F2, F1)); uend();
-        ubegin(); o.rfpre_w = alloc(szB(C1, C2)); o.rfpre_b = alloc(szBias(C2)); uend();
+        ubegin(); o.rfpre_w = alloc(szB(C1, C2)); o.rfpre_b = alloc(4 * szBias(C2)); uend();
         ubegin(); o.rfpost_lin = alloc(szA(F1, F2)); uend();
-        ubegin(); o.rfpost_w = alloc(szB(C2, C1)); o.rfpost_b = alloc(szBias(C1)); uend();
+        ubegin(); o.rfpost_w = alloc(szB(C2, C1)); o.rfpost_b = alloc(4 * szBias(C1)); uend();
         for (int l = 0; l < S::NL; ++l) {
-            ubegin(); o.dec1_w[l] = alloc(szB(2 * C1, C1)); o.dec1_b[l] = alloc(szBias(C1)); uend();
-            ubegin(); o.dec3_w[l] = alloc(szB(3 * C1, C1)); o.dec3_b[l] = alloc(szBias(C1)); uend();
+            ubegin(); o.dec1_w[l] = alloc(szB(2 * C1, C1)); o.dec1_b[l] = alloc(4 * szBias(C1)); uend();
+            ubegin(); o.dec3_w[l] = alloc(szB(3 * C1, C1)); o.dec3_b[l] = alloc(4 * szBias(C1)); uend();
         }
-        ubegin(); o.post1_w = alloc(szB(2 * C1, C1)); o.post1_b = alloc(szBias(C1)); uend();
+        ubegin(); o.post1_w = alloc(szB(2 * C1, C1)); o.post1_b = alloc(4 * szBias(C1)); uend();
         ubegin(); o.post_t_w = alloc(szB(C1, 16)); o.post_t_b = alloc(szBias(2)); uend();
         o.n_units = nu;
         // RNNFormer-block weights: read by each wave straight into registers (not staged)
@@ -214,6 +216,10 @@ struct WSrc {
     __device__ __forceinline__ float at(int off_floats) const {          // + lane
         if constexpr (STAGED) return lds[off_floats - base + (lane4 >> 2)];
         else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane4, off_floats * 4, 0));
+    }
+    __device__ __forceinline__ f32x4 at16x4(int off_floats) const {      // 4x replicated table: + 4 (lane & 15), 16 bytes
+        if constexpr (STAGED) return *reinterpret_cast<const f32x4*>(lds + (off_floats - base) + li4);
+        else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, li4 * 4, off_floats * 4, 0));
     }
     __device__ __forceinline__ float at16(int off_floats) const {        // + (lane & 15)
         if constexpr (STAGED) return lds[off_floats - base + (li4 >> 2)];
@@ -437,16 +443,16 @@ __device__ __forceinline__ void acc_init_zero(f32x4 (&acc)[MTP][NTP]) {
         for (int i = 0; i < MTP; ++i) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 }
 
-// acc[.][j] = bias[16 * nt_j + (lane & 15)],  nt_j = min(nt0 + j * nt_stride, nt_max - 1)
+// acc[.][j] = bias[16 * nt_j + (lane & 15)] (4x replicated table),  nt_j = min(nt0 + j * nt_stride, nt_max - 1)
 template <int MTP, int NTP, class WS>
 __device__ __forceinline__ void acc_init_bias(f32x4 (&acc)[MTP][NTP], const WS& w, int bias_off, int nt0, int nt_stride, int nt_max) {
 #pragma unroll
     for (int j = 0; j < NTP; ++j) {
         int nt = nt0 + j * nt_stride;
         nt = nt < nt_max ? nt : nt_max - 1;
-        float b = w.at16(bias_off + nt * 16);
+        const f32x4 b = w.at16x4(bias_off + nt * 64);
 #pragma unroll
-        for (int i = 0; i < MTP; ++i) acc[i][j] = f32x4{b, b, b, b};
+        for (int i = 0; i < MTP; ++i) acc[i][j] = b;
     }
 }
 
@@ -834,9 +840,9 @@ __device__ __forceinline__ void conv_nsplit(AF&& af, const WS& w, int w_off, int
     f32x4 acc[MT][NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
-        const float bj = w.at16(bias_off + (wn * NTW + j) * 16);
+        const f32x4 bj = w.at16x4(bias_off + (wn * NTW + j) * 64);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i][j] = f32x4{bj, bj, bj, bj};
+        for (int i = 0; i < MT; ++i) acc[i][j] = bj;
     }
     mma_panel<MT, NTW, KS, Lds<S>::PDK>(acc, [&](int i, int ks) { return af(m0 + i, ks); },
                            [&](int j, int ks) { return w.at(w_off + ((wn * NTW + j) * KS + ks) * 64); }, side);
