@@ -1444,6 +1444,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 //   r = s(ax0+ah0), z = s(ax1+ah1), n = tanh(ax2 + r*ah2), h' = (1-z) n + z h
                 // prefetch for the next phase: rnn_fc weights (+ the positional embedding in block 0)
                 Wf1.bind(wb, (o.blk_fc1_w[0] + kb), (o.blk_fc1_b[0] + kb), S::NT2, wave);   // fetched inside the GEMM below
+                // GFLAT: the qkv weights ride in this (long) GEMM too, attn_fc's in rnn_fc's - fetched one short phase
+                // ahead they were still in flight when their GEMM started
+                if constexpr (GFLAT) Wq.bind(wb, (o.blk_qkv[0] + kb), -1, S::NT3, wave);
                 if (k == 0) {
 #pragma unroll
                     for (int i = 0; i < S::MT2; ++i)
@@ -1480,7 +1483,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     mma_panel_sel<S::MT2, NTPW3, 2 * K2, Lds<S>::PDK>(
                         [&](int i, int j, int ks) -> f32x4& { return ks < K2 || pure_rz(j) ? ax[i][j] : ah[i][j]; },
                         [&](int i, int ks) { return ks < K2 ? Xb[(16 * i + li) * LDX + lg + 4 * ks] : Hs[(16 * i + li) * LDX + lg + 4 * (ks - K2)]; },
-                        [&](int j, int ks) { return ks < K2 ? Wgi.get(j, 0, ks) : Wgh.get(j, 0, ks - K2); }, FetchSide<decltype(Wf1)>{&Wf1});
+                        [&](int j, int ks) { return ks < K2 ? Wgi.get(j, 0, ks) : Wgh.get(j, 0, ks - K2); },
+                        FetchSide2<decltype(Wf1), decltype(Wq)>{&Wf1, &Wq});
                     __builtin_amdgcn_sched_barrier(0);
                     if (k == 0) FE_CLK(46);
                     // (pad rows / columns of Gi are written too - they are never read; Hl's rows are narrower)
@@ -1645,9 +1649,14 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             {
                 // x += rnn_fc(h') (+ pe in block 0)
                 constexpr int NTPW = NTPW2;
-                Wq.bind(wb, (o.blk_qkv[0] + kb), -1, S::NT3, wave);      // for the next phase, fetched inside the GEMM
                 f32x4 acc[S::MT2][NTPW];
-                tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf1, FetchSide<decltype(Wq)>{&Wq});
+                if constexpr (GFLAT) {
+                    Wf2.bind(wb, (o.blk_fc2_w[0] + kb), (o.blk_fc2_b[0] + kb), S::NT2, wave);
+                    tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf1, FetchSide<decltype(Wf2)>{&Wf2});
+                } else {
+                    Wq.bind(wb, (o.blk_qkv[0] + kb), -1, S::NT3, wave);      // for the next phase, fetched inside the GEMM
+                    tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf1, FetchSide<decltype(Wq)>{&Wq});
+                }
 #pragma unroll
                 for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -1672,21 +1681,30 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 // qkv = x W_qkv^T  -> Gi (rows per head interleaved [h][q|k|v][hd])
                 constexpr int NTPW = NTPW3;
                 // fetched inside the GEMM: attn_fc weights and the next block's GRU input weights
-                Wf2.bind(wb, (o.blk_fc2_w[0] + kb), (o.blk_fc2_b[0] + kb), S::NT2, wave);
+                if constexpr (!GFLAT) Wf2.bind(wb, (o.blk_fc2_w[0] + kb), (o.blk_fc2_b[0] + kb), S::NT2, wave);
                 Wgi.bind(wb, (o.blk_wih[0] + kb + o.blk_stride), (o.blk_bih[0] + kb + o.blk_stride), GNT, wave, k + 1 < S::KB);
                 if constexpr (!L::PERHEAD) {
                 f32x4 acc[S::MT2][NTPW];
-                tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Xb + li * LDX + lg, Wq, FetchSide2<decltype(Wf2), decltype(Wgi)>{&Wf2, &Wgi});
+                __builtin_amdgcn_sched_barrier(0);
+                if (k == 0) FE_CLK(50);
+                if constexpr (GFLAT) tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Xb + li * LDX + lg, Wq, FetchSide<decltype(Wgi)>{&Wgi});
+                else tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Xb + li * LDX + lg, Wq, FetchSide2<decltype(Wf2), decltype(Wgi)>{&Wf2, &Wgi});
+                __builtin_amdgcn_sched_barrier(0);
+                if (k == 0) FE_CLK(51);
+                {
+                    // (pad rows of Gi are written too - never read; one base address, immediate offsets, no predicates)
+                    float* gdst = Gi + (4 * lg) * LDG + 16 * wave + li;
 #pragma unroll
-                for (int i = 0; i < S::MT2; ++i)
+                    for (int j = 0; j < NTPW; ++j)
+                        if (wave + 4 * j < S::NT3) {
 #pragma unroll
-                    for (int j = 0; j < NTPW; ++j) {
-                        const int nt = wave + 4 * j;
-                        if (nt < S::NT3 && 16 * i + 4 * lg < F2) {
+                            for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) Gi[(16 * i + 4 * lg + r) * LDG + 16 * nt + li] = acc[i][j][r];
+                                for (int r = 0; r < 4; ++r) gdst[(16 * i + r) * LDG + 64 * j] = acc[i][j][r];
                         }
-                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (k == 0) FE_CLK(52);
                 }
             }
             if constexpr (!L::PERHEAD) {

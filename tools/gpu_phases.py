@@ -44,6 +44,8 @@ def main():
     print("  block 0 GRU: setup %d, gemm %d, epilogue %d, barrier %d" % (c[45]-c[20], c[46]-c[45], c[47]-c[46], c[21]-c[47]))
     if c[48] and c[49]:
         print("  block 0 GRU (flat gates): store %d, barrier %d, gate math %d" % (c[48]-c[46], c[49]-c[48], c[47]-c[49]))
+    if c[50] and c[52]:
+        print("  block 0 qkv: setup %d, gemm %d, store %d, barrier %d" % (c[50]-c[23], c[51]-c[50], c[52]-c[51], c[24]-c[52]))
     print("  block 0 detail:")
     prev = c[20]
     for i, nm in enumerate(BLK[1:], start=21):
