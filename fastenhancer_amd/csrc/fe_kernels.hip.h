@@ -1359,6 +1359,20 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         TokW<NTPW2, S::KS_2, 1, REGW, WS> Wf1, Wf2;     // rnn_fc, attn_fc
         TokW<NTPW3, S::KS_2, 1, REGW, WS> Wq;           // qkv
         float pe_r[S::MT2][NTPW2][4];                                                  // positional embedding (block 0)
+        // Unpredicated epilogue stores into the [F2P][C2 + 2] token buffers: pad rows are real rows, and lanes whose
+        // column lies beyond C2 (the last channel tile; the wave without a tile) aim at the pad column - one select
+        // per lane instead of an exec-masked block with its own address arithmetic per store group.
+        auto tok_dst = [&](float* base, int j) {
+            const int col = 16 * (wave + 4 * j) + li;
+            return base + (4 * lg) * LDX + (col < C2 ? col : C2);
+        };
+        // LDS slot of hidden-state element tid + q * 256 (elements past F2 * C2 park in row 0's pad column)
+        int hs_off[HPT];
+#pragma unroll
+        for (int q = 0; q < HPT; ++q) {
+            const int i = tid + q * kThreads, f = i / C2;
+            hs_off[q] = i < F2 * C2 ? f * LDX + (i - f * C2) : C2;
+        }
         {
             // Y1[f2][c1] = sum_f1 Wf[f2][f1] * E[f1][c1]      (A = packed filterbank, B = LDS)
             constexpr int NTPW = ceil_div(S::NTC, kWaves);
@@ -1410,19 +1424,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
                 for (int j = 0; j < NTPW; ++j) {
-                    const int nt = wave + 4 * j;
-                    const int col = 16 * nt + li;
                     xr[i][j] = acc[i][j];
-                    if (nt < S::NT2 && col < C2 && 16 * i + 4 * lg < F2) {
+                    float* xd = tok_dst(Xb, j);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) Xb[(16 * i + 4 * lg + r) * LDX + col] = acc[i][j][r];
-                    }
+                    for (int r = 0; r < 4; ++r) xd[(16 * i + r) * LDX] = acc[i][j][r];
                 }
             if constexpr (L::PERHEAD) __syncthreads();       // (there Y1, still being read by slower waves, lies over HS)
 #pragma unroll
             for (int q = 0; q < HPT; ++q) {
-                const int i = tid + q * kThreads;
-                if (i < F2 * C2) { const int f = i / C2; Hs[f * LDX + (i - f * C2)] = hpre[q]; }
+                Hs[hs_off[q]] = hpre[q];
                 if constexpr (GFLAT) hkeep[q] = hpre[q];
             }
         }
@@ -1661,16 +1671,13 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
                     for (int j = 0; j < NTPW; ++j) {
-                        const int nt = wave + 4 * j;
-                        const int col = 16 * nt + li;
-                        if (nt < S::NT2 && col < C2 && 16 * i + 4 * lg < F2) {
+                        float* xd = tok_dst(Xb, j);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                float v = acc[i][j][r] + xr[i][j][r];
-                                if (k == 0) v += pe_r[i][j][r];
-                                xr[i][j][r] = v;
-                                Xb[(16 * i + 4 * lg + r) * LDX + col] = v;
-                            }
+                        for (int r = 0; r < 4; ++r) {
+                            float v = acc[i][j][r] + xr[i][j][r];
+                            if (k == 0) v += pe_r[i][j][r];
+                            xr[i][j][r] = v;
+                            xd[(16 * i + r) * LDX] = v;
                         }
                     }
             }
@@ -1763,8 +1770,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 if (k + 1 < S::KB) {
 #pragma unroll
                     for (int q = 0; q < HPT; ++q) {
-                        const int i = tid + q * kThreads;
-                        if (i < F2 * C2) { const int f = i / C2; Hs[f * LDX + (i - f * C2)] = hpre[q]; }
+                        Hs[hs_off[q]] = hpre[q];
                         if constexpr (GFLAT) hkeep[q] = hpre[q];
                     }
                 }
@@ -1772,15 +1778,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
                     for (int j = 0; j < NTPW; ++j) {
-                        const int nt = wave + 4 * j;
-                        const int col = 16 * nt + li;
-                        if (nt < S::NT2 && col < C2 && 16 * i + 4 * lg < F2) {
+                        float* xd = tok_dst(Xb, j);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float v = acc[i][j][r] + xr[i][j][r];
-                                xr[i][j][r] = v;
-                                Xb[(16 * i + 4 * lg + r) * LDX + col] = v;
-                            }
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = acc[i][j][r] + xr[i][j][r];
+                            xr[i][j][r] = v;
+                            xd[(16 * i + r) * LDX] = v;
                         }
                     }
             }
