@@ -261,12 +261,35 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
     {
         const float* w = S("rf_post.0.weight");   // (F1, F2)
         p.pack_a(o.rfpost_lin, F1, F2, [&](int m, int k) { return w[m * F2 + k]; });
-        pack_1x1(o.rfpost_w, S("rf_post.1.weight"), C2, C1);
-        p.rep4(o.rfpost_b, C1, S("rf_post.1.bias"));
+        p.raw(o.rfpost_w, (size_t)C1 * C2, S("rf_post.1.weight"));      // plain copies: the debug dump of the rf_post stage
+        p.raw(o.rfpost_b, C1, S("rf_post.1.bias"));
     }
     for (int i = 0; i < d.NL; ++i) {
+        if (i == 0) {
+            // rf_post's 1x1 conv (C2 -> C1, affine, no activation) feeds only this layer's x half: folded in.
+            //   v = Wd_x (Wrp y + brp) + Wd_s skip + bd  =  (Wd_x Wrp) y + Wd_s skip + (bd + Wd_x brp)
+            // K = C2 (filterbank output, true scale: weights carry kSiluScale) + C1 (skip, already scaled)
+            const float* wrp = S("rf_post.1.weight");     // (C1, C2)
+            const float* brp = S("rf_post.1.bias");
+            const float* wd = S("decoder.0.0.weight");    // (C1, 2 C1): [n][0 .. C1) x, [n][C1 .. 2 C1) skip
+            const float* bd = S("decoder.0.0.bias");
+            std::vector<float> wf((size_t)C1 * C2), bf(C1);
+            for (int n = 0; n < C1; ++n) {
+                for (int k = 0; k < C2; ++k) {
+                    double acc = 0.0;
+                    for (int m = 0; m < C1; ++m) acc += (double)wd[(size_t)n * 2 * C1 + m] * wrp[(size_t)m * C2 + k];
+                    wf[(size_t)n * C2 + k] = (float)(acc * fe::kSiluScale);
+                }
+                double acc = bd[n];
+                for (int m = 0; m < C1; ++m) acc += (double)wd[(size_t)n * 2 * C1 + m] * brp[m];
+                bf[n] = (float)acc;
+            }
+            p.pack_b(o.dec1_w[0], C2 + C1, C1, [&](int k, int n) { return k < C2 ? wf[(size_t)n * C2 + k] : wd[(size_t)n * 2 * C1 + C1 + (k - C2)]; });
+            p.rep4(o.dec1_b[0], C1, bf.data());
+        } else {
         snprintf(nm, sizeof nm, "decoder.%d.0.weight", i); pack_1x1(o.dec1_w[i], S(nm), 2 * C1, C1);
         snprintf(nm, sizeof nm, "decoder.%d.0.bias", i); p.rep4(o.dec1_b[i], C1, S(nm));
+        }
         snprintf(nm, sizeof nm, "decoder.%d.2.weight", i); pack_k3(o.dec3_w[i], S(nm));
         snprintf(nm, sizeof nm, "decoder.%d.2.bias", i); p.rep4(o.dec3_b[i], C1, S(nm));
     }
@@ -284,7 +307,7 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
         scale(o.enc_pre_w, szB(16, C1), c); scale(o.enc_pre_b, 4 * C1, c);       // (biases: 4x replicated tables)
         for (int i = 0; i < d.NL; ++i) { scale(o.enc_b[i], 4 * C1, c); scale(o.dec1_b[i], 4 * C1, c); scale(o.dec3_b[i], 4 * C1, c); }
         scale(o.rfpre_w, szB(C1, C2), 1.0f / c);                                  // encoder -> RNNFormer: back to true scale
-        scale(o.rfpost_w, szB(C2, C1), c); scale(o.rfpost_b, 4 * C1, c);              // RNNFormer -> decoder: scaled again
+        // (RNNFormer -> decoder: rf_post's 1x1 is folded into decoder.0.0 above, with the scale)
         scale(o.post1_b, 4 * C1, c);
         scale(o.post_t_w, szB(C1, 16), 1.0f / c);                                 // transposed conv: true-scale mask
     }

@@ -74,7 +74,7 @@ struct Shape {
     // packed-weight sizes (floats)
     static constexpr int KS_C = C1 / 4;           // k-steps over C1
     static constexpr int KS_2 = C2 / 4;           // k-steps over C2
-    static constexpr int NU = 7 + 3 * NL;        // LDS-staged weight units (Pack<S>)
+    static constexpr int NU = 6 + 3 * NL;        // LDS-staged weight units (Pack<S>)
     // RNNFormer-block weight fragments held in registers per wave (this wave's column tiles)
     static constexpr int NTPW2 = ceil_div(NT2, kWaves), NTPW3 = ceil_div(NT3, kWaves);
     // "flat" GRU gate GEMM: C2 not a multiple of 16 (T: 20, B: 36) pads every gate to whole column tiles (B: 3 x 48
@@ -131,7 +131,8 @@ struct Pack {
         ubegin(); o.rfpre_lin = alloc(szA(F2, F1)); uend();
         ubegin(); o.rfpre_w = alloc(szB(C1, C2)); o.rfpre_b = alloc(4 * szBias(C2)); uend();
         ubegin(); o.rfpost_lin = alloc(szA(F1, F2)); uend();
-        ubegin(); o.rfpost_w = alloc(szB(C2, C1)); o.rfpost_b = alloc(4 * szBias(C1)); uend();
+        // (rf_post's 1x1 conv has no unit: the host folds it into decoder layer 0's 1x1, whose first K-segment is the
+        //  filterbank output - dec1_w[0] holds (C2 + C1) x C1; the plain copy below only serves the debug dump)
         for (int l = 0; l < S::NL; ++l) {
             ubegin(); o.dec1_w[l] = alloc(szB(2 * C1, C1)); o.dec1_b[l] = alloc(4 * szBias(C1)); uend();
             ubegin(); o.dec3_w[l] = alloc(szB(3 * C1, C1)); o.dec3_b[l] = alloc(4 * szBias(C1)); uend();
@@ -139,6 +140,7 @@ struct Pack {
         ubegin(); o.post1_w = alloc(szB(2 * C1, C1)); o.post1_b = alloc(4 * szBias(C1)); uend();
         ubegin(); o.post_t_w = alloc(szB(C1, 16)); o.post_t_b = alloc(szBias(2)); uend();
         o.n_units = nu;
+        o.rfpost_w = alloc(C1 * C2); o.rfpost_b = alloc(szBias(C1));      // plain [C1][C2] / [C1], true scale (debug only)
         // RNNFormer-block weights: read by each wave straight into registers (not staged)
         o.blk_pe = alloc(F2 * C2);
         for (int k = 0; k < S::KB; ++k) {      // identical sizes per block: the offsets advance by blk_stride
@@ -1808,21 +1810,25 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             conv_store<S, S::NT2, C2, LDX, false>(acc, Y2, 0, wave, lane);
         }
         __syncthreads();
-        {
-            FE_BEGIN_UNIT(4 + S::NL);
-            f32x4 acc[S::MTPW][S::NTC];
-            acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.rfpost_b, 0, 1, S::NTC);
-            conv_seg<S, S::NTC, S::KS_2, S::KS_2, LDX>(acc, Y2 + (16 * wave + li) * LDX + lg, wb, o.rfpost_w, stage);
-            stage.commit();
-            conv_store<S, S::NTC, C1, LDC, false>(acc, W0, 1, wave, lane);
-        }
-        __syncthreads();
-        // W1 overlaps the token arena: re-zero its halo rows (row 0 and F1+1)
-        for (int i = tid; i < 2 * LDC; i += kThreads) {
+        // rf_post's 1x1 conv (C2 -> C1, no activation) is folded into decoder layer 0's 1x1 on the host: that layer
+        // reads the filterbank output Y2 as its first K-segment (one GEMM phase and 3 C2 / 4 k-steps less per frame).
+        // Buffer roles from here on: Wy (= W0) takes the 1x1 outputs - the k=3 convs read it with its zero halo rows -
+        // and Wx (= W1, whose first rows Y2 occupies until layer 0's 1x1 has consumed it) the k=3 outputs.
+        float* const Wx = W1;
+        float* const Wy = W0;
+        for (int i = tid; i < 2 * LDC; i += kThreads) {          // Wy lay under the token arena: zero its halo rows 0 and F1+1
             int r = i / LDC, c = i - r * LDC;
-            W1[(r ? F1 + 1 : 0) * LDC + c] = 0.0f;
+            Wy[(r ? F1 + 1 : 0) * LDC + c] = 0.0f;
         }
-        dbg_dump<S>(a, b, 4 + S::NL + 2 * S::KB, W0 + LDC, LDC);
+        if (a.dbg != nullptr) {                                  // the rf_post stage no longer exists: recompute it for the dump
+            float* dst = a.dbg + (size_t)b * a.dbg_stride + DebugLayout<S>::offset(4 + S::NL + 2 * S::KB);
+            for (int i = tid; i < F1 * C1; i += kThreads) {
+                const int f = i / C1, n = i - f * C1;
+                float v = wp[o.rfpost_b + n];
+                for (int kk = 0; kk < C2; ++kk) v += Y2[f * LDX + kk] * wp[o.rfpost_w + n * C2 + kk];
+                dst[i] = v;
+            }
+        }
 
         FE_CLK(8);
         // =========================== decoder (a14) ===========================
@@ -1830,80 +1836,82 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             constexpr int l = decltype(l_)::value;
             const float* skip = Ebuf + (S::NL - l) * S::ACT;   // (LDS-resident skips)
             {
-                FE_BEGIN_UNIT(5 + S::NL + 2 * l);
+                // 1x1 conv on cat([x, skip]): two K-segments, never materialised.  Layer 0: x = rf_post's filterbank
+                // output Y2 [F1][C2] with rf_post's 1x1 folded into this layer's weights; later layers: x = Wx [F1][C1].
+                FE_BEGIN_UNIT(4 + S::NL + 2 * l);
+                constexpr int K0 = (l == 0) ? S::KS_2 : S::KS_C;       // k-steps of the x segment
+                constexpr int LD0 = (l == 0) ? LDX : LDC;
                 if constexpr (NSPLIT) {
-                    const float* xa0 = W0 + (li + 1) * LDC + lg;
+                    const float* xa0 = (l == 0) ? Y2 + li * LDX + lg : Wx + (li + 1) * LDC + lg;
                     const float* sk0 = skip + (li + 1) * LDC + lg;
-                    conv_nsplit<S, NS, 2 * S::KS_C, C1, LDC, true>(
+                    conv_nsplit<S, NS, K0 + S::KS_C, C1, LDC, true>(
                         [&](int i, int ks) {
-                            if (ks < S::KS_C) return xa0[(16 * i) * LDC + 4 * ks];
-                            if constexpr (SG) return skb.at_g((S::NL - l) * SKIP_FLOATS + (i * S::KS_C + (ks - S::KS_C)) * 64);
-                            else return sk0[(16 * i) * LDC + 4 * (ks - S::KS_C)];
-                        }, wb, o.dec1_w[l], o.dec1_b[l], stage, W1, 1, wave, lane, nullptr);
+                            if (ks < K0) return xa0[(16 * i) * LD0 + 4 * ks];
+                            if constexpr (SG) return skb.at_g((S::NL - l) * SKIP_FLOATS + (i * S::KS_C + (ks - K0)) * 64);
+                            else return sk0[(16 * i) * LDC + 4 * (ks - K0)];
+                        }, wb, o.dec1_w[l], o.dec1_b[l], stage, Wy, 1, wave, lane, nullptr);
                 } else {
-                f32x4 acc[S::MTPW][S::NTC];
-                acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.dec1_b[l], 0, 1, S::NTC);
-                if constexpr (!SG) {
-                    const float* const segs[2] = {W0 + (16 * wave + li + 1) * LDC + lg, skip + (16 * wave + li + 1) * LDC + lg};
-                    conv_multi<S, S::NTC, 2, S::KS_C, LDC>(acc, segs, wb, o.dec1_w[l], stage);
-                } else {   // second K-segment = the skip, read back from the global scratch as A fragments
-                    const float* xa = W0 + (16 * wave + li + 1) * LDC + lg;
-                    mma_panel<S::MTPW, S::NTC, 2 * S::KS_C, 8>(
+                    f32x4 acc[S::MTPW][S::NTC];
+                    acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.dec1_b[l], 0, 1, S::NTC);
+                    const float* xa = (l == 0) ? Y2 + (16 * wave + li) * LDX + lg : Wx + (16 * wave + li + 1) * LDC + lg;
+                    const float* sk = skip + (16 * wave + li + 1) * LDC + lg;
+                    // (SG: the skip comes back from the global scratch as A fragments, 8 k-steps ahead)
+                    mma_panel<S::MTPW, S::NTC, K0 + S::KS_C, SG ? 8 : Lds<S>::PDK>(
                         acc,
                         [&](int i, int ks) {
-                            return ks < S::KS_C ? xa[(64 * i) * LDC + 4 * ks]
-                                                : skb.at_g((S::NL - l) * SKIP_FLOATS + ((wave + 4 * i) * S::KS_C + (ks - S::KS_C)) * 64);
+                            if (ks < K0) return xa[(64 * i) * LD0 + 4 * ks];
+                            if constexpr (SG) return skb.at_g((S::NL - l) * SKIP_FLOATS + ((wave + 4 * i) * S::KS_C + (ks - K0)) * 64);
+                            else return sk[(64 * i) * LDC + 4 * (ks - K0)];
                         },
-                        [&](int j, int ks) { return wb.at(o.dec1_w[l] + (j * (2 * S::KS_C) + ks) * 64); }, stage);
-                }
-                stage.commit();
-                conv_store<S, S::NTC, C1, LDC, true>(acc, W1, 1, wave, lane);
+                        [&](int j, int ks) { return wb.at(o.dec1_w[l] + (j * (K0 + S::KS_C) + ks) * 64); }, stage);
+                    stage.commit();
+                    conv_store<S, S::NTC, C1, LDC, true>(acc, Wy, 1, wave, lane);
                 }
             }
             __syncthreads();
             {
-                FE_BEGIN_UNIT(6 + S::NL + 2 * l);
+                FE_BEGIN_UNIT(5 + S::NL + 2 * l);
                 if constexpr (NSPLIT) {
-                    const float* a0 = W1 + li * LDC + lg;
+                    const float* a0 = Wy + li * LDC + lg;
                     conv_nsplit<S, NS, 3 * S::KS_C, C1, LDC, true>(
                         [&](int i, int ks) { return a0[(16 * i + ks / S::KS_C) * LDC + 4 * (ks % S::KS_C)]; }, wb, o.dec3_w[l], o.dec3_b[l], stage,
-                        W0, 1, wave, lane, nullptr);
+                        Wx, 1, wave, lane, nullptr);
                 } else {
                 f32x4 acc[S::MTPW][S::NTC];
                 acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.dec3_b[l], 0, 1, S::NTC);
-                const float* const taps[3] = {W1 + (16 * wave + li + 0) * LDC + lg, W1 + (16 * wave + li + 1) * LDC + lg,
-                                              W1 + (16 * wave + li + 2) * LDC + lg};
+                const float* const taps[3] = {Wy + (16 * wave + li + 0) * LDC + lg, Wy + (16 * wave + li + 1) * LDC + lg,
+                                              Wy + (16 * wave + li + 2) * LDC + lg};
                 conv_multi<S, S::NTC, 3, S::KS_C, LDC>(acc, taps, wb, o.dec3_w[l], stage);
                 stage.commit();
-                conv_store<S, S::NTC, C1, LDC, true>(acc, W0, 1, wave, lane);   // W0 was fully consumed before the barrier above
+                conv_store<S, S::NTC, C1, LDC, true>(acc, Wx, 1, wave, lane);   // Wx (and Y2 under it) was fully consumed before the barrier above
                 }
             }
             __syncthreads();
-            dbg_dump<S>(a, b, 5 + S::NL + 2 * S::KB + l, W0 + LDC, LDC);
+            dbg_dump<S>(a, b, 5 + S::NL + 2 * S::KB + l, Wx + LDC, LDC);
         });
 
         FE_CLK(9);
         // =========================== dec_post (a15) ===========================
         float* PT = smem + L::PT;
         {
-            FE_BEGIN_UNIT(5 + 3 * S::NL);
+            FE_BEGIN_UNIT(4 + 3 * S::NL);
             if constexpr (NSPLIT) {
-                const float* xa0 = W0 + (li + 1) * LDC + lg;
+                const float* xa0 = Wx + (li + 1) * LDC + lg;
                 const float* sk0 = Ebuf + (li + 1) * LDC + lg;
                 conv_nsplit<S, NS, 2 * S::KS_C, C1, LDC, true>(
                     [&](int i, int ks) {
                         if (ks < S::KS_C) return xa0[(16 * i) * LDC + 4 * ks];
                         if constexpr (SG) return skb.at_g((i * S::KS_C + (ks - S::KS_C)) * 64);
                         else return sk0[(16 * i) * LDC + 4 * (ks - S::KS_C)];
-                    }, wb, o.post1_w, o.post1_b, stage, W1, 1, wave, lane, nullptr);
+                    }, wb, o.post1_w, o.post1_b, stage, Wy, 1, wave, lane, nullptr);
             } else {
             f32x4 acc[S::MTPW][S::NTC];
             acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.post1_b, 0, 1, S::NTC);
             if constexpr (!SG) {
-                const float* const segs[2] = {W0 + (16 * wave + li + 1) * LDC + lg, Ebuf + (16 * wave + li + 1) * LDC + lg};
+                const float* const segs[2] = {Wx + (16 * wave + li + 1) * LDC + lg, Ebuf + (16 * wave + li + 1) * LDC + lg};
                 conv_multi<S, S::NTC, 2, S::KS_C, LDC>(acc, segs, wb, o.post1_w, stage);
             } else {
-                const float* xa = W0 + (16 * wave + li + 1) * LDC + lg;
+                const float* xa = Wx + (16 * wave + li + 1) * LDC + lg;
                 mma_panel<S::MTPW, S::NTC, 2 * S::KS_C, 8>(
                     acc,
                     [&](int i, int ks) {
@@ -1912,16 +1920,16 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     [&](int j, int ks) { return wb.at(o.post1_w + (j * (2 * S::KS_C) + ks) * 64); }, stage);
             }
             stage.commit();
-            conv_store<S, S::NTC, C1, LDC, true>(acc, W1, 1, wave, lane);
+            conv_store<S, S::NTC, C1, LDC, true>(acc, Wy, 1, wave, lane);
             }
         }
         __syncthreads();
         {
             // transposed conv as GEMM: P[i][co*8+j] = sum_ci x[i][ci] w[ci][co][j]
-            FE_BEGIN_UNIT(6 + 3 * S::NL);
+            FE_BEGIN_UNIT(5 + 3 * S::NL);
             f32x4 acc[S::MTPW][1];
             acc_init_zero<S::MTPW, 1>(acc);
-            conv_seg<S, 1, S::KS_C, S::KS_C, LDC>(acc, W1 + (16 * wave + li + 1) * LDC + lg, wb, o.post_t_w, stage);
+            conv_seg<S, 1, S::KS_C, S::KS_C, LDC>(acc, Wy + (16 * wave + li + 1) * LDC + lg, wb, o.post_t_w, stage);
             stage.commit();
             conv_store<S, 1, 16, S::LDP, false>(acc, PT, 0, wave, lane);
         }
