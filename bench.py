@@ -129,6 +129,28 @@ def measured_traffic(workload: str, B: int, T: int):
     return best
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` (no launcher): start N ranks of this script, one per GPU, under torch.distributed.run
+    (the command line the driver itself uses), rendezvous on 127.0.0.1; rank 0 prints the JSON line.  Never falls
+    back to fewer ranks: fewer than N devices, or a rank that fails to come up, is a non-zero exit."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        print(f"bench.py: --gpus {n} needs {n} visible MI355X devices, this box has {have}; refusing to measure fewer ranks "
+              f"under an n_gpus={n} label", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,22 +161,32 @@ def main():
     ap.add_argument("--frames-per-step", type=int, default=1, help="hops per stream per launch (1 = per-hop streaming)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
+    ap.add_argument("--clock-ramp-ms", type=float, default=250.0,
+                    help="untimed launches of the same step BEFORE the counted warm-up, until this much GPU time has passed "
+                         "(brings the shader clock and the caches to steady state; reported as clock_ramp_steps)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # started by torch.distributed.run
+    if not launched and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the FastEnhancer HIP path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} has no GPU (local_rank {local_rank}, {torch.cuda.device_count()} visible)")
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
-    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # launched by torch.distributed.run
+    use_dist = launched
     if use_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert world == args.gpus or world == 1, (world, args.gpus)
+        assert dist.get_world_size() == world
 
     w = WORKLOADS[args.workload]
     kw = model_kwargs(w)
@@ -177,7 +209,18 @@ def main():
             sd = default_state_dict(cfg, torch.Generator().manual_seed(2))
             sd["dec_post.2.weight"] = sd["dec_post.2.weight"] * 12.0
         blob.copy_(eng.make_blob(sd))
-    broadcast_blob(blob, src=0)
+    torch.cuda.synchronize(dev)
+    tb0 = time.perf_counter()
+    broadcast_blob(blob, src=0)                       # the path's only collective: one ncclBroadcast over xGMI
+    torch.cuda.synchronize(dev)
+    bcast_ms = (time.perf_counter() - tb0) * 1e3      # (first collective of the communicator: includes RCCL's lazy init)
+    rccl_world = dist.get_world_size() if use_dist else 1
+    if use_dist:                                      # every rank must now hold rank 0's bytes
+        chk = torch.stack([blob.double().sum(), blob.double().abs().sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi), "weight broadcast: ranks disagree"
     eng.load_blob(blob)
 
     # ---- synthetic streams of this rank, step-major [steps, B, T*H], resident in HBM
@@ -203,6 +246,20 @@ def main():
             if rc != 0:
                 _lib.check(rc, "fe_step")
 
+    # untimed clock ramp: a 20-step run is otherwise measured on a GPU that is still raising its shader clock and
+    # filling its instruction / TLB caches (r1: 39.3 us per step in the driver's 20-step run, 34.5 us in steady state)
+    ramp_steps = 0
+    if args.clock_ramp_ms > 0:
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record(stream)
+        while True:
+            run(50, 0)
+            ramp_steps += 50
+            r1.record(stream)
+            r1.synchronize()
+            if r0.elapsed_time(r1) >= args.clock_ramp_ms or ramp_steps >= 100000:
+                break
+        state.zero_()
     run(args.warmup, 0)
     torch.cuda.synchronize(dev)
     if use_dist:
@@ -221,8 +278,13 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / args.steps    # HIP events on the launch stream: avg per launch
     if use_dist:
         tt = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=dev)
+        per_rank = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(per_rank, tt[:1].clone() / args.steps * 1e3)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        per_rank_ms = [float(v) for v in per_rank]
         dt, kernel_ms = float(tt[0]), float(tt[1])
+    else:
+        per_rank_ms = [dt / args.steps * 1e3]
     assert torch.isfinite(out).all()
 
     if rank == 0:
@@ -232,6 +294,8 @@ def main():
         res = {
             "metric": "audio frames/sec (hop=256, 16kHz) FastEnhancer_B" if args.workload == "fe_b" else f"audio frames/sec {w['desc']}",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "clock_ramp_steps": ramp_steps, "rccl_world_size": rccl_world, "weight_broadcast_ms": bcast_ms,
+            "per_rank_ms_per_step": per_rank_ms,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{w['desc']} (N={w['N']}, H={w['H']}), {B} concurrent streams per GPU, "

@@ -582,11 +582,18 @@ class FEOracle:
 
 
 # --------------------------------------------------------------------------- metrics
-def si_sdr(clean: Array, enhanced: Array, eps: float = 1e-7) -> Array:
-    """scripts/metrics_ns.py:43-52: SI-SDR in dB, no mean subtraction, eps 1e-7."""
-    clean = np.asarray(clean, np.float64)
-    enhanced = np.asarray(enhanced, np.float64)
-    alpha = (enhanced * clean).sum(-1, keepdims=True) / ((clean ** 2).sum(-1, keepdims=True) + eps)
+def si_sdr(clean: Array, enhanced: Array, mask: Optional[Array] = None, eps: float = 1e-7) -> Array:
+    """scripts/metrics_ns.py:38-52 (si_snr(s1 = enhanced, s2 = clean, mask)): SI-SDR in dB, no mean subtraction, eps 1e-7,
+    fp32 like its inputs; the function does not mask the signals (its caller does, :128,134) and line 52's masked mean of
+    the per-utterance constant returns that constant.  Pinned on the reference function's outputs (tests/golden/si_snr.npz)."""
+    clean = np.asarray(clean, np.float32)
+    enhanced = np.asarray(enhanced, np.float32)
+    if mask is None:
+        mask = np.ones_like(clean)
+    mask = np.asarray(mask, np.float32)
+    eps = np.float32(eps)
+    alpha = (enhanced * clean).sum(-1, keepdims=True, dtype=np.float32) / ((clean * clean).sum(-1, keepdims=True, dtype=np.float32) + eps)
     target = alpha * clean
     noise = enhanced - target
-    return 10.0 * np.log10((target ** 2).sum(-1) / ((noise ** 2).sum(-1) + eps) + eps)
+    snr = np.log10((target * target).sum(-1, keepdims=True, dtype=np.float32) / ((noise * noise).sum(-1, keepdims=True, dtype=np.float32) + eps) + eps)
+    return (np.float32(10.0) * (snr * mask).sum(1, dtype=np.float32) / mask.sum(1, dtype=np.float32)).astype(np.float32)

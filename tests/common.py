@@ -57,6 +57,7 @@ def rms(x):
 BSRNN_KWARGS = {
     "bsrnn_xxt": (dict(num_channels=16, num_layers=2, bias=True, affine=True, n_fft=512, hop_size=256, win_size=512, window="hann"), 16000, 202),
     "bsrnn_xt": (dict(num_channels=16, num_layers=6, bias=True, affine=True, n_fft=512, hop_size=256, win_size=512, window="hann"), 16000, 201),
+    "bsrnn_s": (dict(num_channels=64, num_layers=6, bias=True, affine=True, n_fft=512, hop_size=256, win_size=512, window="hann"), 16000, 204),
     "bsrnn_t": (dict(num_channels=32, num_layers=6, bias=True, affine=True, n_fft=512, hop_size=256, win_size=512, window="hann"), 16000, 203),
 }
 

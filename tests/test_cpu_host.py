@@ -166,13 +166,17 @@ def test_cli_host_logic(tmp_path):
         read_wav(str(tmp_path / "a.wav"), 48000)
 
 
-def test_si_sdr_matches_oracle_restatement():
-    from fastenhancer_amd.metrics import si_snr
+def test_si_sdr_is_pinned_on_the_reference_function():
+    """f3: tests/golden/si_snr.npz holds outputs of the reference's own si_snr (scripts/metrics_ns.py:38-52)."""
+    from fastenhancer_amd.metrics import masked_si_snr, si_snr
     from oracle.fe_oracle import si_sdr
-    rng = np.random.default_rng(0)
-    clean = rng.standard_normal((3, 4000)).astype(np.float32)
-    est = clean + 0.1 * rng.standard_normal((3, 4000)).astype(np.float32)
-    a = si_snr(torch.from_numpy(est), torch.from_numpy(clean)).numpy()
-    b = si_sdr(clean, est)
-    np.testing.assert_allclose(a, b, rtol=1e-9)
-    assert 15 < a.mean() < 25
+    g = load_golden("si_snr")
+    clean, est, lens = g["clean"], g["est"], g["lens"]
+    mask = (np.arange(clean.shape[1])[None] < lens[:, None]).astype(np.float32)
+    tc, te, tm = torch.from_numpy(clean), torch.from_numpy(est), torch.from_numpy(mask)
+    for got, want in ((si_snr(te, tc), g["full"]), (si_snr(te * tm, tc * tm, tm), g["masked"]), (si_snr(te, tc, tm), g["fn_only"]),
+                      (masked_si_snr(te, tc, torch.from_numpy(lens)), g["masked"])):
+        np.testing.assert_allclose(got.numpy(), want, rtol=2e-6, atol=2e-5)
+    for got, want in ((si_sdr(clean, est), g["full"]), (si_sdr(clean * mask, est * mask, mask), g["masked"]), (si_sdr(clean, est, mask), g["fn_only"])):
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-5)
+    assert not np.allclose(g["masked"][1:], g["fn_only"][1:], atol=1e-3)      # masking inside vs outside differ: the pin can tell

@@ -173,6 +173,86 @@ def test_full_size_batch_256_matches_oracle_and_is_stream_independent():
     assert torch.equal(out, out2) and torch.equal(state, state2)
 
 
+def _full_size_check(m, orc, cfg, sr, B, hops, sample, what):
+    """B streams x hops: oracle parity on `sample`, and bitwise stream independence on ALL streams - the batch is run
+    a second time with the streams in reversed order (every stream then sits in a different workgroup / state slot /
+    scratch slot), which must give the same bits."""
+    eng = m.engine
+    H = cfg.hop_size
+    x = make_input(B, hops * H, 4711, sr)
+    xd = torch.from_numpy(x).to(_dev())
+    state = eng.new_state(B)
+    outs = [eng.step(xd[:, t * H:(t + 1) * H], state, T=1).clone() for t in range(hops)]      # the per-hop kernel
+    out = torch.cat(outs, dim=1)
+    xr = xd.flip(0).contiguous()
+    state_r = eng.new_state(B)
+    out_r = torch.cat([eng.step(xr[:, t * H:(t + 1) * H], state_r, T=1).clone() for t in range(hops)], dim=1)
+    assert torch.equal(out_r.flip(0), out), f"{what}: a stream's output depends on its position in the batch"
+    for a_, b_ in zip(eng.split_state(state, B), eng.split_state(state_r, B)):
+        rows = a_.shape[-2] // B
+        a2 = a_.reshape(B, rows, -1)
+        b2 = b_.reshape(B, rows, -1)
+        assert torch.equal(b2.flip(0), a2), f"{what}: state depends on the position in the batch"
+    caches = orc.initialize_cache(len(sample))
+    refs = []
+    for t in range(hops):
+        o, *caches = orc.step(x[sample, t * H:(t + 1) * H], *caches)
+        refs.append(o)
+    _assert_close(out[sample].cpu().numpy(), np.concatenate(refs, axis=1), f"{what} wav_out")
+    for a_, b_ in zip(eng.split_state(state, B), caches):
+        rows = a_.shape[-2] // B
+        got = a_.reshape(B, rows, -1)[sample].reshape(b_.shape)
+        _assert_close(got.cpu().numpy(), b_, f"{what} cache")
+
+
+def test_full_size_fastenhancer_l_256_streams():
+    """BASELINE config 3's per-GPU share: FastEnhancer_L, 256 streams (global skip scratch indexed per stream)."""
+    m, orc, cfg, sr, seed = _model("fe_l")
+    _full_size_check(m, orc, cfg, sr, 256, 3, [0, 1, 17, 100, 128, 200, 254, 255], "fe_l B=256")
+
+
+def test_full_size_48khz_hop480_512_streams():
+    """BASELINE config 4: 48 kHz FastEnhancer_B at a 10 ms hop, 512 streams (two rounds of workgroups)."""
+    m, orc, cfg, sr, seed = _model("fe48_b_h480")
+    _full_size_check(m, orc, cfg, sr, 512, 4, [0, 1, 255, 256, 257, 300, 510, 511], "fe48_b_h480 B=512")
+
+
+def test_full_size_bsrnn_xt_256_streams():
+    """BASELINE config 5: BSRNN-xt, 256 streams."""
+    m, orc, cfg, sr, seed = _bsrnn("bsrnn_xt")
+    _full_size_check(m, orc, cfg, sr, 256, 4, [0, 1, 17, 128, 254, 255], "bsrnn_xt B=256")
+
+
+def test_win_size_smaller_than_n_fft():
+    """ONNXSTFT pads a shorter window to n_fft (functional/audio_modules.py:213-217); no shipped yaml uses it."""
+    from oracle.fe_oracle import FEConfig as OCfg, FEOracle, fold_state_dict
+    from oracle.weightgen import make_training_state_dict
+    kw = dict(MODEL_KWARGS["fe_b"][0])
+    kw["win_size"] = 400
+    ocfg = OCfg.from_model_kwargs(kw)
+    sd = make_training_state_dict(ocfg, 321)
+    orc = FEOracle(ocfg, fold_state_dict(sd, ocfg), np.float32)
+    mod = importlib.import_module("fastenhancer_amd.models.fastenhancer.default.model")
+    m = mod.ONNXModel(**kw).to(_dev()).eval()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    B, hops, H = 3, 6, ocfg.hop_size
+    x = make_input(B, hops * H, 99, 16000)
+    state = m.engine.new_state(B)
+    out = m.engine.step(torch.from_numpy(x).to(_dev()), state, T=hops)
+    caches = orc.initialize_cache(B)
+    refs = []
+    for t in range(hops):
+        o, *caches = orc.step(x[:, t * H:(t + 1) * H], *caches)
+        refs.append(o)
+    _assert_close(out.cpu().numpy(), np.concatenate(refs, 1), "win_size=400 wav_out")
+    mo = mod.Model(**kw).to(_dev()).eval()
+    mo.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    xo = make_input(2, 7 * H + 5, 98, 16000)
+    wav_ref, spec_ref = orc.offline_forward(xo)
+    wav_hat, spec_hat = mo(torch.from_numpy(xo).to(_dev()))
+    _assert_close(wav_hat.cpu().numpy(), wav_ref, "win_size=400 offline wav")
+
+
 def test_more_streams_than_cus_and_strided_buffers():
     """600 streams (more workgroups than the 256 CUs, BASELINE config 4 uses 512) through row-strided in / out buffers."""
     m, orc, cfg, sr, seed = _model("fe_t")

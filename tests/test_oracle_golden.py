@@ -122,7 +122,7 @@ def test_c_oracle_matches_reference(name):
 
 
 # ------------------------------------------------------------------------------------------------ BSRNN
-@pytest.mark.parametrize("name", ["bsrnn_xxt", "bsrnn_xt"])
+@pytest.mark.parametrize("name", ["bsrnn_xxt", "bsrnn_xt", "bsrnn_t", "bsrnn_s"])
 def test_bsrnn_streaming_matches_reference(name):
     from common import build_bsrnn_oracle
     g = load_golden(name)
@@ -141,7 +141,7 @@ def test_bsrnn_streaming_matches_reference(name):
         _close(caches[2 + i], g[f"stream_c{i}"], what=f"lstm cache {i}")
 
 
-@pytest.mark.parametrize("name", ["bsrnn_xxt", "bsrnn_xt"])
+@pytest.mark.parametrize("name", ["bsrnn_xxt", "bsrnn_xt", "bsrnn_t", "bsrnn_s"])
 def test_bsrnn_offline_matches_reference(name):
     from common import build_bsrnn_oracle
     g = load_golden(name)

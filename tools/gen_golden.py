@@ -203,6 +203,8 @@ BSRNN_CONFIGS = {
     # name: (yaml, seed, B, hops)
     "bsrnn_xt": ("configs/others/bsrnn_xt.yaml", 201, 2, 10),
     "bsrnn_xxt": ("configs/others/bsrnn_xxt.yaml", 202, 2, 8),
+    "bsrnn_t": ("configs/others/bsrnn_t.yaml", 203, 1, 6),
+    "bsrnn_s": ("configs/others/bsrnn_s.yaml", 204, 1, 5),
 }
 
 
@@ -261,6 +263,35 @@ def gen_bsrnn(ref: str, name: str, out_dir: str):
           f"out_rms={float(np.sqrt((out['stream_wav_out'][4:] ** 2).mean())):.3f}")
 
 
+def gen_si_snr(ref: str, out_dir: str):
+    """SI-SDR of the reference's evaluation script: `si_snr` / `product` are closures inside main() of
+    scripts/metrics_ns.py (which imports torchaudio / pesq / pystoi at its top), so the two function definitions
+    (:38-52) are compiled out of the file's text at generation time; only their inputs' seeds and their outputs are stored."""
+    import textwrap
+    lines = open(os.path.join(ref, "scripts", "metrics_ns.py")).read().splitlines()
+    start = next(i for i, l in enumerate(lines) if l.strip().startswith("def product("))
+    end = next(i for i, l in enumerate(lines) if i > start and l.strip().startswith("# Load the model"))
+    ns = {"torch": torch}
+    exec(compile(textwrap.dedent("\n".join(lines[start:end])), "metrics_ns.si_snr", "exec"), ns)
+    ref_fn = ns["si_snr"]
+    rng = np.random.default_rng(77)
+    B, L = 5, 4000
+    clean = (0.3 * np.sin(2 * np.pi * rng.uniform(100, 900, (B, 1)) * np.arange(L)[None] / 16000.0)
+             + 0.05 * rng.standard_normal((B, L))).astype(np.float32)
+    est = (clean * rng.uniform(0.5, 1.5, (B, 1)) + rng.uniform(0.01, 0.2, (B, 1)) * rng.standard_normal((B, L))).astype(np.float32)
+    lens = np.array([4000, 3800, 2560, 1000, 256], np.int64)
+    mask = (np.arange(L)[None] < lens[:, None]).astype(np.float32)
+    with torch.no_grad():
+        full = ref_fn(torch.from_numpy(est), torch.from_numpy(clean), torch.ones(B, L)).numpy()
+        # the evaluation loop's use (:125-137): both signals masked by the caller
+        masked = ref_fn(torch.from_numpy(est * mask), torch.from_numpy(clean * mask), torch.from_numpy(mask)).numpy()
+        # the function alone on UN-masked signals with a mask (what distinguishes masking inside from masking outside)
+        fn_only = ref_fn(torch.from_numpy(est), torch.from_numpy(clean), torch.from_numpy(mask)).numpy()
+    path = os.path.join(out_dir, "si_snr.npz")
+    np.savez_compressed(path, clean=clean, est=est, lens=lens, full=full, masked=masked, fn_only=fn_only)
+    print(f"si_snr: wrote {path}; values {full.round(3)}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -276,6 +307,8 @@ def main():
         if args.only and name not in args.only:
             continue
         gen_bsrnn(args.ref, name, args.out)
+    if not args.only or "si_snr" in args.only:
+        gen_si_snr(args.ref, args.out)
 
 
 if __name__ == "__main__":
