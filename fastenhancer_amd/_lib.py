@@ -37,6 +37,10 @@ SYMBOLS = {
     "fe_spec_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fe_offline_work_floats": (c_size_t, [c_void_p, c_int, c_int]),
     "fe_offline": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fe_stft_step": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "fe_istft_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "fe_stft_offline": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "fe_istft_offline": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "fe_flops_per_frame": (c_double, [c_void_p]),
     "fe_debug_stages": (c_int, [c_void_p]),
     "fe_debug_stage": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int), POINTER(c_int), POINTER(c_size_t)]),

@@ -18,7 +18,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libfastenhancer_hip.so")
 FE_DEPS = ["fe_kernels.hip.h", "fe_impl.h"]
 BSRNN_DEPS = ["fe_kernels.hip.h", "bsrnn_kernels.hip.h"]
-API_DEPS = ["fe_kernels.hip.h", "fe_impl.h", "fe_shapes.def", "bsrnn_kernels.hip.h", "fe_bsrnn_shapes.def",
+API_DEPS = ["fe_kernels.hip.h", "fe_impl.h", "fe_shapes.def", "bsrnn_kernels.hip.h", "fe_bsrnn_shapes.def", "stft_kernels.hip.h",
             os.path.join("..", "..", "include", "fastenhancer_hip.h")]
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in VGPRs instead of AGPRs - every epilogue read of an AGPR accumulator is a
 # v_accvgpr_read, a VALU instruction that the fp32 matrix path cannot overlap (~600 of them per wave and frame on
@@ -89,9 +89,24 @@ def build(force: bool = False, verbose: bool = True) -> str:
             rebuilt |= did
             if verbose and did:
                 print(f"[fastenhancer_amd] compiled {os.path.basename(obj)}", file=sys.stderr)
-    if rebuilt or not os.path.exists(LIB):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [j[1] for j in jobs]
+    # objects of shapes that are no longer in the .def files must not linger (nor their stamps)
+    wanted = {os.path.basename(j[1]) for j in jobs} | {os.path.basename(j[3]) for j in jobs}
+    for f in os.listdir(OBJ):
+        if f not in wanted and (f.endswith(".o") or f.endswith(".stamp")):      # (link.key is neither)
+            os.remove(os.path.join(OBJ, f))
+    # relink whenever the library is missing or older than ANY object (a link that failed after the objects were
+    # compiled leaves rebuilt == False on the next run), to a temporary name that replaces the library only on success;
+    # the digest of all object keys is kept next to the library so that a changed object SET relinks too
+    link_key = hashlib.sha256(" ".join(sorted(j[4] + os.path.basename(j[1]) for j in jobs)).encode()).hexdigest()[:16]
+    key_file = os.path.join(OBJ, "link.key")
+    stale = (not os.path.exists(LIB) or not os.path.exists(key_file) or open(key_file).read() != link_key
+             or any(os.path.getmtime(j[1]) > os.path.getmtime(LIB) for j in jobs))
+    if rebuilt or stale:
+        tmp = LIB + ".tmp"
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + [j[1] for j in jobs]
         subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
+        open(key_file, "w").write(link_key)
         if verbose:
             print(f"[fastenhancer_amd] linked {LIB}", file=sys.stderr)
     return LIB

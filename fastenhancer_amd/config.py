@@ -65,11 +65,21 @@ class FEConfig:
         rk = dict(rnnformer_kwargs or {})
         # the reference raises / asserts on bad values (model.py:25-41,434-435; audio_modules.py:192-193);
         # options the HIP path does not implement are rejected here instead of being silently ignored.
-        assert n_fft % 2 == 0, f"`n_fft` must be an even number, but given {n_fft}."
-        assert stft_normalized is False
-        assert n_fft >= win_size, f"n_fft({n_fft}) must be bigger than win_size({win_size})"
-        assert kernel_size[0] % stride == 0
-        assert (kernel_size[0] - stride) % 2 == 0
+        # (explicit raises of the reference's exception type: a bare `assert` disappears under `python -O`)
+        def require(cond, msg=""):
+            if not cond:
+                raise AssertionError(msg)
+        require(n_fft % 2 == 0, f"`n_fft` must be an even number, but given {n_fft}.")
+        require(stft_normalized is False, "stft_normalized must be False")
+        require(n_fft >= win_size, f"n_fft({n_fft}) must be bigger than win_size({win_size})")
+        require(kernel_size[0] % stride == 0, "kernel_size[0] must be a multiple of stride")
+        require((kernel_size[0] - stride) % 2 == 0, "kernel_size[0] - stride must be even")
+        if pre_post_init not in (None, "linear", "linear_fixed"):
+            raise RuntimeError(f"model_kwargs.pre_post_init={pre_post_init} is not supported by the HIP path "
+                               "(shipped: linear, linear_fixed; the mel initialisations need librosa).")
+        if rk.get("positional_embedding", "train") not in ("train", "fixed"):
+            raise RuntimeError(f"rnnformer_kwargs.positional_embedding={rk.get('positional_embedding')} is not supported by "
+                               "the HIP path (shipped: train; the kernel always adds rf_block.0.pe).")
         if mask is not None:
             raise RuntimeError(f"model_kwargs.mask={mask} is not supported by the HIP path (every shipped yaml uses null).")
         if activation != "SiLU":
@@ -133,6 +143,7 @@ class BSRNNConfig:
             raise RuntimeError(f"Only n_fft=512 is supported, but given {n_fft}")       # models/bsrnn/model.py:112-113
         if window != "hann":
             raise RuntimeError(f"model_kwargs.window={window} is not supported by the HIP path (shipped: hann).")
-        assert n_fft >= win_size, f"n_fft({n_fft}) must be bigger than win_size({win_size})"
+        if n_fft < win_size:
+            raise AssertionError(f"n_fft({n_fft}) must be bigger than win_size({win_size})")
         return BSRNNConfig(int(num_channels), int(num_layers), bool(bias), bool(affine), int(n_fft), int(hop_size),
                            int(win_size), float(input_compression))

@@ -8,6 +8,8 @@
 // product each) runs on the vector ALUs with one gate row per thread whose W_hh row stays in registers for the
 // whole layer, the four gates of a hidden unit sitting in adjacent lanes (quad shuffles, no LDS round trip).
 #pragma once
+#include <atomic>
+
 #include "fe_kernels.hip.h"
 
 namespace fe {
@@ -469,12 +471,14 @@ struct BImpl {
 
 template <class S, bool HOT, bool PROF>
 void blaunch_one(const BArgs& a, hipStream_t st, hipError_t* err) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<bool> attr_set[64];           // per device (see fe_impl.h::launch_one)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev].load(std::memory_order_relaxed)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bsrnn_frame_kernel<S, HOT, PROF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)BLds<S>::BYTES);
         if (e != hipSuccess) { *err = e; return; }
-        attr_set = true;
+        attr_set[dev].store(true, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL((bsrnn_frame_kernel<S, HOT, PROF>), dim3(a.B), dim3(kThreads), BLds<S>::BYTES, st, a);
     *err = hipGetLastError();

@@ -13,6 +13,7 @@
 #include "../../include/fastenhancer_hip.h"
 #include "fe_impl.h"
 #include "bsrnn_kernels.hip.h"
+#include "stft_kernels.hip.h"
 
 namespace {
 
@@ -83,6 +84,7 @@ struct fe_handle {
     std::vector<Section> sections;
     size_t blob_floats = 0;
     float* packed_dev = nullptr;
+    float* tables_dev = nullptr;   // [window | window_istft | twiddle] for the stand-alone STFT launches (lazy)
     float* skip_dev = nullptr;     // scratch for shapes whose skips do not fit in LDS
     int skip_streams = 0;
     bool loaded = false;
@@ -612,6 +614,7 @@ void fe_destroy(fe_handle* h) {
     if (!h) return;
     if (h->packed_dev) (void)hipFree(h->packed_dev);
     if (h->skip_dev) (void)hipFree(h->skip_dev);
+    if (h->tables_dev) (void)hipFree(h->tables_dev);
     delete h;
 }
 
@@ -781,6 +784,102 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
     a.h = work_dev + (size_t)B * (d.NFFT - d.HOP);
     hipError_t e = hipSuccess;
     h->impl->launch(a, st, &e);
+    if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return FE_OK;
+}
+
+// ---------------------------------------------------------------------------- stand-alone STFT / iSTFT
+static int ensure_tables(fe_handle* h, hipStream_t st) {
+    if (h->tables_dev) return FE_OK;
+    const size_t N = (size_t)h->cfg.n_fft;
+    std::vector<float> t(3 * N);
+    memcpy(&t[0], h->window.data(), N * sizeof(float));
+    memcpy(&t[N], h->window_istft.data(), N * sizeof(float));
+    memcpy(&t[2 * N], h->twiddle.data(), N * sizeof(float));
+    FE_HIP_CHECK(hipMalloc(&h->tables_dev, 3 * N * sizeof(float)));
+    FE_HIP_CHECK(hipMemcpyAsync(h->tables_dev, t.data(), 3 * N * sizeof(float), hipMemcpyHostToDevice, st));
+    FE_HIP_CHECK(hipStreamSynchronize(st));
+    return FE_OK;
+}
+
+#define FE_STFT_LAUNCH(kernel, a, grid, st)                                                         \
+    do {                                                                                            \
+        if (h->cfg.n_fft == 512) hipLaunchKernelGGL((fe::kernel<512>), grid, dim3(fe::kThreads), 0, st, a);        \
+        else if (h->cfg.n_fft == 1024) hipLaunchKernelGGL((fe::kernel<1024>), grid, dim3(fe::kThreads), 0, st, a); \
+        else return fail(FE_ERR_UNSUPPORTED_CONFIG, "n_fft=%d (stand-alone STFT kernels: 512, 1024)", h->cfg.n_fft); \
+        hipError_t e_ = hipGetLastError();                                                          \
+        if (e_ != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e_));  \
+    } while (0)
+
+static fe::StftArgs stft_args(const fe_handle* h, int B) {
+    fe::StftArgs a{};
+    a.tables = h->tables_dev;
+    a.B = B;
+    a.T = 1;
+    a.H = h->cfg.hop_size;
+    a.compression = 1.0f;
+    a.eps = 1.0e-5f;
+    return a;
+}
+
+int fe_stft_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, const float* cache_in_dev, float* cache_out_dev,
+                 float* spec_out_dev, int B, void* stream) {
+    if (!h || !wav_in_dev || !cache_in_dev || !cache_out_dev || !spec_out_dev || B <= 0) return fail(FE_ERR_INVALID_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_tables(h, st);
+    if (rc != FE_OK) return rc;
+    fe::StftArgs a = stft_args(h, B);
+    a.wav_in = wav_in_dev; a.in_stride = in_stride; a.cache_in = cache_in_dev; a.cache_out = cache_out_dev; a.spec = spec_out_dev;
+    FE_STFT_LAUNCH(stft_step_kernel, a, dim3(B), st);
+    return FE_OK;
+}
+
+int fe_istft_step(fe_handle* h, const float* spec_in_dev, const float* cache_in_dev, float* cache_out_dev, float* wav_out_dev,
+                  size_t out_stride, int B, void* stream) {
+    if (!h || !spec_in_dev || !cache_in_dev || !cache_out_dev || !wav_out_dev || B <= 0) return fail(FE_ERR_INVALID_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_tables(h, st);
+    if (rc != FE_OK) return rc;
+    fe::StftArgs a = stft_args(h, B);
+    a.spec = const_cast<float*>(spec_in_dev); a.cache_in = cache_in_dev; a.cache_out = cache_out_dev;
+    a.wav_out = wav_out_dev; a.out_stride = out_stride;
+    FE_STFT_LAUNCH(istft_step_kernel, a, dim3(B), st);
+    return FE_OK;
+}
+
+int fe_stft_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, int F, int compress, float* spec_out_dev, void* stream) {
+    if (!h || !noisy_dev || !spec_out_dev || B <= 0) return fail(FE_ERR_INVALID_ARG, "bad argument");
+    const int N = h->cfg.n_fft, H = h->cfg.hop_size;
+    if (Tw <= N / 2) return fail(FE_ERR_INVALID_ARG, "Tw=%d: reflect padding of n_fft/2=%d needs a longer input", Tw, N / 2);
+    if (F != N / 2 && F != N / 2 + 1) return fail(FE_ERR_INVALID_ARG, "F=%d (n_fft/2 or n_fft/2+1)", F);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_tables(h, st);
+    if (rc != FE_OK) return rc;
+    fe::StftArgs a = stft_args(h, B);
+    a.T = 1 + Tw / H; a.Tw = Tw; a.F = F;
+    a.wav_in = noisy_dev; a.in_stride = (size_t)Tw; a.spec = spec_out_dev;
+    a.compression = compress ? h->cfg.input_compression : 1.0f;
+    FE_STFT_LAUNCH(stft_frames_kernel, a, dim3(a.T, B), st);
+    return FE_OK;
+}
+
+int fe_istft_offline(fe_handle* h, const float* spec_in_dev, int B, int T, int F, int compress, float* wav_out_dev,
+                     float* frames_dev, void* stream) {
+    if (!h || !spec_in_dev || !wav_out_dev || !frames_dev || B <= 0 || T <= 1) return fail(FE_ERR_INVALID_ARG, "bad argument");
+    const int N = h->cfg.n_fft, H = h->cfg.hop_size;
+    if (F != N / 2 && F != N / 2 + 1) return fail(FE_ERR_INVALID_ARG, "F=%d (n_fft/2 or n_fft/2+1)", F);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_tables(h, st);
+    if (rc != FE_OK) return rc;
+    fe::StftArgs a = stft_args(h, B);
+    a.T = T; a.F = F;
+    a.spec = const_cast<float*>(spec_in_dev); a.frames = frames_dev;
+    a.compression = compress ? h->cfg.input_compression : 1.0f;
+    FE_STFT_LAUNCH(istft_frames_kernel, a, dim3(T, B), st);
+    const int n_out = H * (T - 1);
+    hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
+                       frames_dev, h->tables_dev, wav_out_dev, (size_t)n_out, N, H, T);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return FE_OK;
 }

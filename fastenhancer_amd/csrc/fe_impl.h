@@ -3,9 +3,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "fe_kernels.hip.h"
 
 namespace fe {
+
+constexpr int kMaxDevices = 64;
 
 struct Impl {
     int C1, NL, C2, F2, KB, NFFT, HOP;
@@ -22,12 +26,16 @@ struct Impl {
 
 template <class S, bool DBG, int MODE, bool T1>
 void launch_one(const FrameArgs& a, hipStream_t st, hipError_t* err) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the opt-in for > 64 KiB of dynamic LDS is a per-device function attribute: one flag per device, set once
+    // (an engine may live on any GPU of the process; relaxed atomics - setting it twice is harmless)
+    static std::atomic<bool> attr_set[kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    if (!attr_set[dev].load(std::memory_order_relaxed)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fe_frame_kernel<S, DBG, MODE, T1>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds<S>::BYTES);
         if (e != hipSuccess) { *err = e; return; }
-        attr_set = true;
+        attr_set[dev].store(true, std::memory_order_relaxed);
     }
     dim3 grid(a.B), block(kThreads);
     hipLaunchKernelGGL((fe_frame_kernel<S, DBG, MODE, T1>), grid, block, Lds<S>::BYTES, st, a);

@@ -177,6 +177,63 @@ class Engine:
                        "fe_offline")
         return wav, spec
 
+    # ------------------------------------------------------------------ stand-alone STFT / iSTFT (the `.stft` modules)
+    def stft_step(self, wav_in: Tensor, cache: Tensor) -> Tuple[Tensor, Tensor]:
+        """ONNXSTFT.forward: wav_in [B, H], cache [B, N-H] -> (spec [B, N/2+1, 1, 2], cache'); inputs untouched."""
+        self._require_gpu()
+        B, c = wav_in.shape[0], self.cfg
+        wav_in = wav_in.to(self.device, torch.float32)
+        cache = cache.to(self.device, torch.float32).contiguous()
+        assert wav_in.shape[1] == c.hop_size and wav_in.stride(1) == 1 and tuple(cache.shape) == (B, c.cache_len)
+        spec = torch.empty(B, c.n_fft // 2 + 1, 1, 2, dtype=torch.float32, device=self.device)
+        cache_out = torch.empty_like(cache)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fe_stft_step(self._h, _ptr(wav_in), wav_in.stride(0) if B > 1 else c.hop_size, _ptr(cache),
+                                             _ptr(cache_out), _ptr(spec), B, _stream(self.device)), "fe_stft_step")
+        return spec, cache_out
+
+    def istft_step(self, spec: Tensor, cache: Tensor) -> Tuple[Tensor, Tensor]:
+        """ONNXSTFT.inverse: spec [B, N/2+1, 1, 2], cache [B, N-H] -> (wav_out [B, H], cache'); inputs untouched."""
+        self._require_gpu()
+        B, c = spec.shape[0], self.cfg
+        spec = spec.to(self.device, torch.float32).contiguous()
+        cache = cache.to(self.device, torch.float32).contiguous()
+        assert tuple(spec.shape) == (B, c.n_fft // 2 + 1, 1, 2) and tuple(cache.shape) == (B, c.cache_len)
+        wav = torch.empty(B, c.hop_size, dtype=torch.float32, device=self.device)
+        cache_out = torch.empty_like(cache)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fe_istft_step(self._h, _ptr(spec), _ptr(cache), _ptr(cache_out), _ptr(wav), c.hop_size, B,
+                                              _stream(self.device)), "fe_istft_step")
+        return wav, cache_out
+
+    def stft_offline(self, x: Tensor, discard_last: bool, compress: bool = True) -> Tensor:
+        """CompressedSTFT.forward: x [B, Tw] or [B, 1, Tw] -> [B, F, T, 2], T = 1 + Tw // H."""
+        self._require_gpu()
+        if x.dim() == 3:
+            x = x.squeeze(1)
+        x = x.to(self.device, torch.float32).contiguous()
+        B, Tw = x.shape
+        c = self.cfg
+        F = c.n_fft // 2 + (0 if discard_last else 1)
+        spec = torch.empty(B, F, 1 + Tw // c.hop_size, 2, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fe_stft_offline(self._h, _ptr(x), B, Tw, F, int(compress), _ptr(spec), _stream(self.device)), "fe_stft_offline")
+        return spec
+
+    def istft_offline(self, spec: Tensor, compress: bool = True) -> Tensor:
+        """CompressedSTFT.inverse: spec [B, F, T, 2] (compressed domain) -> wav [B, H * (T - 1)]."""
+        self._require_gpu()
+        spec = spec.to(self.device, torch.float32).contiguous()
+        B, F, T, two = spec.shape
+        c = self.cfg
+        assert two == 2
+        wav = torch.empty(B, c.hop_size * (T - 1), dtype=torch.float32, device=self.device)
+        frames = torch.empty(B * T * c.n_fft, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fe_istft_offline(self._h, _ptr(spec), B, T, F, int(compress), _ptr(wav), _ptr(frames),
+                                                 _stream(self.device)), "fe_istft_offline")
+        return wav
+
     def profile_step(self, wav_in: Tensor, state: Tensor, T: int = 1) -> Tensor:
         """Phase cycle counters (int64[64]) of workgroup 0 for the last frame of the launch."""
         self._require_gpu()

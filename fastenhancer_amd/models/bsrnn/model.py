@@ -11,7 +11,7 @@ from torch import Tensor
 from ...config import BSRNNConfig
 from ...engine import Engine
 from ...weights import bsrnn_default_state_dict, bsrnn_expected_fused_shapes, bsrnn_fold_state_dict, check_shapes
-from ..fastenhancer.default.model import STFTCaches
+from ...stft import CompressedSTFT, ONNXSTFT
 
 
 class ONNXModel:
@@ -19,11 +19,15 @@ class ONNXModel:
         self.cfg = BSRNNConfig.from_model_kwargs(**model_kwargs)
         self.input_compression = self.cfg.input_compression
         self.num_layers = self.cfg.num_layers
-        self.stft = STFTCaches(self.cfg)
+        self.stft = self.get_stft()
         self.device = torch.device("cpu")
         self._sd: tp.Dict[str, Tensor] = bsrnn_default_state_dict(self.cfg)
         self._engine: tp.Optional[Engine] = None
         self.training = False
+
+    def get_stft(self):
+        """models/bsrnn/model.py:323-329"""
+        return ONNXSTFT(self, self.cfg)
 
     def eval(self):
         return self
@@ -90,6 +94,10 @@ class ONNXModel:
 
 class Model(ONNXModel):
     """Offline wav -> wav (models/bsrnn/model.py:463-483): forward(noisy) -> (wav_hat, spec_hat [B, 257, T, 2])."""
+
+    def get_stft(self):
+        """models/bsrnn/model.py:467-475: CompressedSTFT keeping all 257 bins"""
+        return CompressedSTFT(self, self.cfg, discard_last_freq_bin=False)
 
     def forward(self, noisy: Tensor):
         return self.engine.offline(noisy.to(self.engine.device))

@@ -20,19 +20,8 @@ from torch import Tensor
 
 from ....config import FEConfig
 from ....engine import Engine
+from ....stft import CompressedSTFT, ONNXSTFT
 from ....weights import default_state_dict, fold_state_dict
-
-
-class STFTCaches:
-    """The ``.stft`` attribute of ONNXModel: ONNXSTFT.initialize_cache
-    (functional/audio_modules.py:238-241).  forward / inverse of the streaming STFT are fused
-    into the wav -> wav step (fastenhancer_amd/streaming.py), they are not separate launches."""
-
-    def __init__(self, cfg: FEConfig):
-        self.n_fft, self.hop_size, self.cache_len = cfg.n_fft, cfg.hop_size, cfg.cache_len
-
-    def initialize_cache(self, x: Tensor) -> tp.List[Tensor]:
-        return [torch.zeros(x.size(0), self.cache_len, dtype=torch.float32, device=x.device) for _ in range(2)]
 
 
 class ONNXModel:
@@ -40,11 +29,15 @@ class ONNXModel:
         self.cfg = FEConfig.from_model_kwargs(**model_kwargs)
         self.input_compression = self.cfg.input_compression
         self.rf_ch, self.rf_freq = self.cfg.rf_channels, self.cfg.rf_freq
-        self.stft = STFTCaches(self.cfg)
+        self.stft = self.get_stft()
         self.device = torch.device("cpu")
         self._sd: tp.Dict[str, Tensor] = default_state_dict(self.cfg)
         self._engine: tp.Optional[Engine] = None
         self.training = False
+
+    def get_stft(self):
+        """model.py:523-530: the streaming model carries an ONNXSTFT"""
+        return ONNXSTFT(self, self.cfg)
 
     # ---- nn.Module-like plumbing -----------------------------------------------------------
     def eval(self):
@@ -119,8 +112,14 @@ class ONNXModel:
 class Model(ONNXModel):
     """Offline wav -> wav model (model.py:713-735): forward(noisy [B, T_wav]) -> (wav_hat, spec_hat)."""
 
+    def get_stft(self):
+        """model.py:717-726: CompressedSTFT(compression=input_compression, discard_last_freq_bin=True)"""
+        return CompressedSTFT(self, self.cfg, discard_last_freq_bin=True)
+
     def forward(self, noisy: Tensor):
-        from ....offline import offline_forward
-        return offline_forward(self, noisy)
+        """One fused launch sequence (fe_offline): centered STFT, all T frames, envelope-normalised overlap-add;
+        returns (wav_hat [B, H*(Tw//H)], spec_hat [B, F0, T, 2]).  ``self.stft`` / ``self.stft.inverse`` give the
+        front / back end alone."""
+        return self.engine.offline(noisy.to(self.engine.device))
 
     __call__ = forward

@@ -22,23 +22,58 @@ class StreamingModel:
         """model: a fastenhancer_amd ONNXModel (weights already loaded)."""
         self.model = model
         self.cfg: FEConfig = model.cfg
+        self._buf: tp.List[tp.Optional[Tensor]] = [None, None]     # two state buffers of the C ABI, used alternately
+        self._views: tp.List[tp.Optional[tp.List[Tensor]]] = [None, None]
+        self._B = 0
 
     @property
     def engine(self) -> Engine:
         return self.model.engine
 
+    def _ensure(self, B: int, device):
+        if self._buf[0] is None or self._B != B or self._buf[0].device != device:
+            eng = self.engine
+            self._buf = [eng.new_state(B), eng.new_state(B)]
+            self._views = [eng.split_state(self._buf[0], B), eng.split_state(self._buf[1], B)]
+            self._B = B
+
     def initialize_cache(self, x: Tensor) -> tp.List[Tensor]:
+        """scripts/export_onnx.py:43-46: [cache_stft, cache_istft] ++ model caches (zeros).  On the model's GPU the
+        tensors are views of ONE state buffer of the C ABI, so forward() need not re-pack them."""
+        if x.is_cuda:
+            self._ensure(x.size(0), x.device)
+            self._buf[0].zero_()
+            return list(self._views[0])
         cache_list = self.model.stft.initialize_cache(x)
         cache_list.extend(self.model.initialize_cache(x))
         return cache_list
 
+    def _which(self, caches) -> int:
+        """index of the state buffer the given cache tensors are exactly the views of, else -1"""
+        for i in (0, 1):
+            v = self._views[i]
+            if v is not None and len(v) == len(caches) and all(
+                    c.data_ptr() == w.data_ptr() and c.shape == w.shape and c.dtype == w.dtype and c.is_contiguous()
+                    for c, w in zip(caches, v)):
+                return i
+        return -1
+
     def forward(self, wav_in: Tensor, cache_stft: Tensor, cache_istft: Tensor, *cache_model: Tensor):
-        """wav_in [B, H]; functional: returns new cache tensors, inputs untouched."""
+        """wav_in [B, H]; functional like the reference: returns new cache tensors, the ones passed in are untouched.
+        Caches that are the views handed out by initialize_cache() / the previous call (the driver loop of
+        scripts/test_onnx.py) cost one device copy into the other state buffer; foreign tensors are packed first."""
         eng = self.engine
         B = wav_in.size(0)
-        state = eng.pack_state([cache_stft, cache_istft, *cache_model], B)
-        wav_out = eng.step(wav_in.contiguous().float(), state, T=1)
-        return (wav_out, *eng.split_state(state, B))
+        caches = [cache_stft, cache_istft, *cache_model]
+        self._ensure(B, eng.device)
+        src = self._which(caches)
+        dst = 1 - src if src >= 0 else 0
+        if src >= 0:
+            self._buf[dst].copy_(self._buf[src])
+        else:
+            torch.cat([t.reshape(-1).to(eng.device, torch.float32) for t in caches], out=self._buf[dst])
+        wav_out = eng.step(wav_in.to(eng.device, torch.float32), self._buf[dst], T=1)
+        return (wav_out, *self._views[dst])
 
     __call__ = forward
 

@@ -147,27 +147,26 @@ def check_fused(fused: Mapping[str, Tensor], cfg: FEConfig, strict: bool = True)
 
 # ---------------------------------------------------------------- default initialisation
 def linear_filterbank(n_freq: int, n_filter: int):
-    """rf_pre_post_lin(init='linear*'), models/fastenhancer/default/model.py:308-380."""
-    delta = (n_freq - 1) / (n_filter - 1)
-    f_filter = torch.linspace(0, n_freq - 1, n_filter)
-    f_freqs = torch.linspace(0, n_freq - 1, n_freq)
-    down = (f_filter[1:, None] - f_freqs[None, :]) / delta
-    up = (f_freqs[None, :] - f_filter[:-1, None]) / delta
-    down = torch.cat([down, torch.ones(1, n_freq)], dim=0)
-    up = torch.cat([torch.ones(1, n_freq), up], dim=0)
-    pre = torch.clamp_min(torch.minimum(down, up), 0.0)
-    pre = pre / pre.sum(dim=1, keepdim=True)
-    post = pre.t()
-    post = post / post.sum(dim=1, keepdim=True)
-    return pre.contiguous(), post.contiguous()
+    """The 'linear' / 'linear_fixed' initialisation of rf_pre / rf_post (what rf_pre_post_lin builds,
+    models/fastenhancer/default/model.py:308-380), from its definition: n_filter triangular filters whose centres are
+    evenly spaced over the n_freq input bins (first on bin 0, last on bin n_freq-1), each reaching zero at its
+    neighbours' centres; rows normalised to unit sum.  rf_post is the transpose, again row-normalised."""
+    centres = torch.arange(n_filter, dtype=torch.float64) * ((n_freq - 1) / (n_filter - 1))
+    bins = torch.arange(n_freq, dtype=torch.float64)
+    width = (n_freq - 1) / (n_filter - 1)
+    tri = (1.0 - (bins[None, :] - centres[:, None]).abs() / width).clamp_min(0.0)      # [n_filter, n_freq]
+    pre = tri / tri.sum(dim=1, keepdim=True)
+    post = pre.t() / pre.t().sum(dim=1, keepdim=True)
+    return pre.float().contiguous(), post.float().contiguous()
 
 
 def positional_embedding(channels: int, freq: int) -> Tensor:
-    """calculate_positional_embedding, model.py:98-110."""
-    f = torch.arange(1, freq + 1, dtype=torch.float32) * (math.pi / freq)
-    c = torch.linspace(math.log(1), math.log(freq - 1), channels // 2, dtype=torch.float32).exp()
-    grid = f.view(-1, 1) * c.view(1, -1)
-    return torch.cat((grid.sin(), grid.cos()), dim=1)
+    """Initial value of rf_block.0.pe (calculate_positional_embedding, model.py:98-110): for sub-band f = 1..F at angle
+    pi f / F, channels//2 log-spaced multipliers from 1 to F-1; sines in the first half of the channels, cosines in the second."""
+    angle = math.pi * torch.arange(1, freq + 1, dtype=torch.float32) / freq
+    mult = torch.exp(torch.linspace(0.0, math.log(freq - 1), channels // 2, dtype=torch.float32))
+    phase = angle[:, None] * mult[None, :]
+    return torch.cat((torch.sin(phase), torch.cos(phase)), dim=1)
 
 
 def default_state_dict(cfg: FEConfig, generator: Optional[torch.Generator] = None) -> Dict[str, Tensor]:
@@ -257,6 +256,16 @@ def bsrnn_fold_state_dict(sd: Mapping[str, Tensor], cfg) -> Dict[str, Tensor]:
         return out
     C = cfg.num_channels
     out: Dict[str, Tensor] = {}
+    # the time LSTM's keys come as nn.LSTM names (`*_l0`: a checkpoint of the offline Model) or already renamed to the
+    # LSTMCell names (the state_dict of the reference's ONNXModel before remove_weight_reparameterizations, :450-460)
+    missing = []
+
+    def tkey(l, stem):
+        for cand in (f"rnn_time.{l}.{stem}_l0", f"rnn_time.{l}.{stem}"):
+            if cand in sd:
+                return cand
+        missing.append(f"rnn_time.{l}.{stem}[_l0]")
+        return None
 
     def conv(conv_key, bn_key, dst):
         w, b = _bn_wb(sd, bn_key)
@@ -267,22 +276,26 @@ def bsrnn_fold_state_dict(sd: Mapping[str, Tensor], cfg) -> Dict[str, Tensor]:
         out[dst + ".weight"] = W * w.view(1, -1, 1)
         out[dst + ".bias"] = bias
 
-    def rnn(src, bn_key, dst_w, dst_b, sfx=""):
+    def rnn(wkey, bkey, bn_key, dst_w, dst_b):
         w, b = _bn_wb(sd, bn_key)
-        W = sd[src + ".weight_ih_l0" + sfx]
+        W = sd[wkey]
         out[dst_w] = W * w.view(1, -1)
-        out[dst_b] = sd[src + ".bias_ih_l0" + sfx] + W @ b
+        out[dst_b] = sd[bkey] + W @ b
 
     for b in range(len(BSRNN_SUBBANDS)):
         conv(f"band_split.fc.{b}", f"band_split.norm.{b}", f"band_split.fc.{b}")
     for l in range(cfg.num_layers):
-        rnn(f"rnn_time.{l}", f"norm_time.{l}", f"rnn_time.{l}.weight_ih", f"rnn_time.{l}.bias_ih")
-        out[f"rnn_time.{l}.weight_hh"] = sd[f"rnn_time.{l}.weight_hh_l0"]
-        out[f"rnn_time.{l}.bias_hh"] = sd[f"rnn_time.{l}.bias_hh_l0"]
+        keys = [tkey(l, stem) for stem in ("weight_ih", "bias_ih", "weight_hh", "bias_hh")]
+        if None in keys:
+            continue
+        rnn(keys[0], keys[1], f"norm_time.{l}", f"rnn_time.{l}.weight_ih", f"rnn_time.{l}.bias_ih")
+        out[f"rnn_time.{l}.weight_hh"] = sd[keys[2]]
+        out[f"rnn_time.{l}.bias_hh"] = sd[keys[3]]
         out[f"fc_time.{l}.weight"] = sd[f"fc_time.{l}.weight"]
         out[f"fc_time.{l}.bias"] = sd.get(f"fc_time.{l}.bias", torch.zeros(C))
         for sfx in ("", "_reverse"):
-            rnn(f"rnn_freq.{l}", f"norm_freq.{l}", f"rnn_freq.{l}.weight_ih_l0{sfx}", f"rnn_freq.{l}.bias_ih_l0{sfx}", sfx)
+            rnn(f"rnn_freq.{l}.weight_ih_l0{sfx}", f"rnn_freq.{l}.bias_ih_l0{sfx}", f"norm_freq.{l}",
+                f"rnn_freq.{l}.weight_ih_l0{sfx}", f"rnn_freq.{l}.bias_ih_l0{sfx}")
             out[f"rnn_freq.{l}.weight_hh_l0{sfx}"] = sd[f"rnn_freq.{l}.weight_hh_l0{sfx}"]
             out[f"rnn_freq.{l}.bias_hh_l0{sfx}"] = sd[f"rnn_freq.{l}.bias_hh_l0{sfx}"]
         out[f"fc_freq.{l}.weight"] = sd[f"fc_freq.{l}.weight"]
@@ -293,6 +306,8 @@ def bsrnn_fold_state_dict(sd: Mapping[str, Tensor], cfg) -> Dict[str, Tensor]:
             conv(p + "1", p + "0", p + "0")
             out[p + "2.weight"] = sd[p + "3.weight"]
             out[p + "2.bias"] = sd[p + "3.bias"]
+    if missing:
+        raise RuntimeError("Error(s) in loading state_dict:\n\tMissing key(s) in state_dict: " + ", ".join(missing))
     return out
 
 

@@ -96,6 +96,26 @@ size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw);
 int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_hat_dev,
                float* spec_hat_dev, float* work_dev, void* stream);
 
+/* The STFT front / back ends as launches of their own - the modules the reference exposes as `model.stft` and that
+ * scripts/export_onnx.py:55-57 composes line by line (inside fe_step / fe_offline they are fused into the frame kernel).
+ * No weights needed.  Streaming, one hop (ONNXSTFT.forward / .inverse, functional/audio_modules.py:243-303):
+ *   fe_stft_step : wav_in [b*in_stride + n] (n < H), cache_in [B, N-H] -> spec [B, N/2+1, 1, 2], cache_out [B, N-H]
+ *   fe_istft_step: spec [B, N/2+1, 1, 2], cache_in [B, N-H] -> wav_out [b*out_stride + n] (n < H), cache_out [B, N-H]
+ * Functional like the reference: cache_in is not modified unless cache_out aliases it. */
+int fe_stft_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, const float* cache_in_dev, float* cache_out_dev,
+                 float* spec_out_dev, int B, void* stream);
+int fe_istft_step(fe_handle* h, const float* spec_in_dev, const float* cache_in_dev, float* cache_out_dev,
+                  float* wav_out_dev, size_t out_stride, int B, void* stream);
+/* Offline, centered (CompressedSTFT.forward / .inverse, functional/audio_modules.py:124-164 over STFT :70-119), one
+ * workgroup per (stream, frame):
+ *   fe_stft_offline : noisy [B, Tw] -> spec [B, F, T, 2], T = 1 + Tw/H; F = N/2 (discard_last_freq_bin) or N/2+1;
+ *                     compress != 0: X *= max(|X|, 1e-5)^(c-1) with c = input_compression
+ *   fe_istft_offline: spec [B, F, T, 2] (complex) -> wav [B, H*(T-1)]; compress != 0: X *= |X|^(1/c-1) first;
+ *                     frames_dev: scratch of B*T*N floats */
+int fe_stft_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, int F, int compress, float* spec_out_dev, void* stream);
+int fe_istft_offline(fe_handle* h, const float* spec_in_dev, int B, int T, int F, int compress, float* wav_out_dev,
+                     float* frames_dev, void* stream);
+
 /* Analytic FLOPs of one frame (2*MACs of models/fastenhancer/default/macs.py:17-87 + FFTs). */
 double fe_flops_per_frame(const fe_handle* h);
 

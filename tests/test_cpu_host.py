@@ -180,3 +180,32 @@ def test_si_sdr_is_pinned_on_the_reference_function():
     for got, want in ((si_sdr(clean, est), g["full"]), (si_sdr(clean * mask, est * mask, mask), g["masked"]), (si_sdr(clean, est, mask), g["fn_only"])):
         np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-5)
     assert not np.allclose(g["masked"][1:], g["fn_only"][1:], atol=1e-3)      # masking inside vs outside differ: the pin can tell
+
+
+def test_bsrnn_fold_accepts_both_time_lstm_key_forms_and_names_missing_keys():
+    """a state_dict of the reference's ONNXModel BEFORE remove_weight_reparameterizations has BN stats and
+    the time LSTM already renamed (no `_l0`); the offline Model's has `_l0`.  Both must fold to the same tensors."""
+    from common import BSRNN_KWARGS
+    from fastenhancer_amd.config import BSRNNConfig
+    from fastenhancer_amd.weights import bsrnn_fold_state_dict
+    from oracle import bsrnn_oracle as bo
+    kw = BSRNN_KWARGS["bsrnn_xxt"][0]
+    cfg = BSRNNConfig.from_model_kwargs(**kw)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in bo.make_training_state_dict(bo.BSRNNConfig.from_model_kwargs(kw), 5).items()}
+    a = bsrnn_fold_state_dict(sd, cfg)
+    renamed = {(k[:-3] if k.startswith("rnn_time.") and k.endswith("_l0") else k): v for k, v in sd.items()}
+    assert any(k.startswith("rnn_time.") and not k.endswith("_l0") for k in renamed)
+    b = bsrnn_fold_state_dict(renamed, cfg)
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+    broken = {k: v for k, v in sd.items() if not k.startswith("rnn_time.0.weight_hh")}
+    with pytest.raises(RuntimeError, match="Missing key"):
+        bsrnn_fold_state_dict(broken, cfg)
+
+
+def test_config_rejects_unsupported_initialisations():
+    kw = dict(MODEL_KWARGS["fe_b"][0])
+    with pytest.raises(RuntimeError, match="pre_post_init"):
+        FEConfig.from_model_kwargs(**{**kw, "pre_post_init": "mel"})
+    rk = dict(kw["rnnformer_kwargs"], positional_embedding=None)
+    with pytest.raises(RuntimeError, match="positional_embedding"):
+        FEConfig.from_model_kwargs(**{**kw, "rnnformer_kwargs": rk})

@@ -71,3 +71,14 @@ def test_gloo_world2_broadcast_and_sharding():
     assert s0 == s1 and s0 != 0.0 and n0 == n1          # every rank holds rank 0's blob
     assert sh0 == (0, 5) and sh1 == (5, 9)
     assert f0 == f1 == 90 and e0 == e1 == 2.0
+
+
+def test_bench_refuses_to_measure_fewer_ranks_than_asked():
+    """`python bench.py --gpus N` starts N ranks itself; with fewer than N devices it must fail loudly, never run 1 rank."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "needs 2 visible" in r.stderr and r.stdout.strip() == ""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

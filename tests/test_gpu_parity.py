@@ -145,6 +145,96 @@ def test_chunked_launch_is_bit_identical_to_per_hop_launches(name):
     _assert_close(y1.cpu().numpy(), np.concatenate(refs, 1), "chunk vs oracle")
 
 
+@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_l", "fe48_b_h480"])
+def test_export_onnx_composition_runs_line_for_line(name):
+    """scripts/export_onnx.py:55-57 on the mirror: spec, cache = model.stft(wav_in, cache); spec, *c = model(spec, *c);
+    wav_out, cache = model.stft.inverse(spec, cache) - against the reference's own per-hop outputs (goldens)."""
+    g = load_golden(name)
+    m, orc, cfg, sr, seed = _model(name)
+    B, hops, H = int(g["B"]), int(g["hops"]), cfg.hop_size
+    x = torch.from_numpy(make_input(B, hops * H, seed + 1000, sr)).to(_dev())
+    cache_stft, cache_istft = m.stft.initialize_cache(x)
+    cache_model = m.initialize_cache(x)
+    outs = []
+    for t in range(hops):
+        wav_in = x[:, t * H:(t + 1) * H]
+        keep = cache_stft.clone()
+        spec_in, cache_stft_new = m.stft(wav_in, cache_stft)
+        assert torch.equal(cache_stft, keep), "stft.forward must not modify its input cache"
+        cache_stft = cache_stft_new
+        spec_out, *cache_model = m(spec_in, *cache_model)
+        wav_out, cache_istft = m.stft.inverse(spec_out, cache_istft)
+        outs.append(wav_out.cpu().numpy())
+    _assert_close(spec_in.cpu().numpy(), g["stream_spec_in_last"], "stft.forward spec (last hop)")
+    _assert_close(spec_out.cpu().numpy(), g["stream_spec_out_last"], "model spec_out (last hop)")
+    _assert_close(np.stack(outs, 0), g["stream_wav_out"], "composed wav_out")
+    _assert_close(cache_stft.cpu().numpy(), g["stream_cache_stft"], "cache_stft")
+    _assert_close(cache_istft.cpu().numpy(), g["stream_cache_istft"], "cache_istft")
+
+
+@pytest.mark.parametrize("name", ["fe_b", "fe_m", "fe48_b"])
+def test_standalone_stft_modules_match_oracle(name):
+    """ONNXSTFT.forward / .inverse incl. a non-zero Nyquist bin, and CompressedSTFT.forward / .inverse (Model.stft)."""
+    m, orc, cfg, sr, seed = _model(name)
+    mo, *_ = _model(name, "Model")
+    B, H, N = 3, cfg.hop_size, cfg.n_fft
+    x = make_input(B, 5 * H + 19, 808, sr)
+    cache = (0.1 * np.random.default_rng(3).standard_normal((B, N - H))).astype(np.float32)
+    spec_ref, cache_ref = orc.stft_step(x[:, :H], cache)
+    spec, cache_new = m.stft(torch.from_numpy(x[:, :H]).to(_dev()), torch.from_numpy(cache).to(_dev()))
+    _assert_close(spec.cpu().numpy(), spec_ref, "stft.forward")
+    assert np.array_equal(cache_new.cpu().numpy(), cache_ref)
+    sp = (0.5 * np.random.default_rng(4).standard_normal((B, N // 2 + 1, 1, 2))).astype(np.float32)     # Im X[0], X[N/2] != 0
+    wav_ref, c2_ref = orc.istft_step(sp.copy(), cache)
+    wav, c2 = m.stft.inverse(torch.from_numpy(sp).to(_dev()), torch.from_numpy(cache).to(_dev()))
+    _assert_close(wav.cpu().numpy(), wav_ref, "stft.inverse wav")
+    _assert_close(c2.cpu().numpy(), c2_ref, "stft.inverse cache")
+    # offline: spec = Model.stft(noisy) is what the oracle's offline path feeds its model_forward; inverse(stft(x)) == x
+    xd = torch.from_numpy(x).to(_dev())
+    cs = mo.stft(xd)
+    T = 1 + x.shape[1] // H
+    assert tuple(cs.shape) == (B, N // 2, T, 2)
+    xp = np.pad(x, ((0, 0), (N // 2, N // 2)), mode="reflect")
+    fr = np.stack([xp[:, t * H:t * H + N] for t in range(T)], axis=1) * orc.window
+    X = np.fft.rfft(fr, axis=2)[:, :, :-1].transpose(0, 2, 1)
+    mag = np.maximum(np.abs(X), 1e-5)
+    Xc = X * mag ** (cfg.input_compression - 1.0)
+    _assert_close(cs.cpu().numpy(), np.stack([Xc.real, Xc.imag], -1), "CompressedSTFT.forward")
+    back = mo.stft.inverse(torch.view_as_complex(cs.contiguous()))
+    ref = x[:, :H * (T - 1)].copy()
+    # (the dropped Nyquist bin makes the round trip approximate; noise input keeps little energy there)
+    Xf = np.fft.rfft(fr, axis=2)
+    Xf[:, :, -1] = 0
+    fr2 = np.fft.irfft(Xf, n=N, axis=2) * orc.window
+    full = np.zeros((B, (T - 1) * H + N))
+    env = np.zeros((T - 1) * H + N)
+    for t in range(T):
+        full[:, t * H:t * H + N] += fr2[:, t]
+        env[t * H:t * H + N] += orc.window.astype(np.float64) ** 2
+    _assert_close(back.cpu().numpy(), (full / env)[:, N // 2:N // 2 + H * (T - 1)], "CompressedSTFT.inverse")
+    assert ref.shape == tuple(back.shape)
+
+
+def test_streaming_model_reuses_its_state_buffer_and_stays_functional():
+    """the driver-loop form `wav_out, *caches = M(wav_in, *caches)` must not re-pack the caches, must not modify the
+    tensors it was given, and must equal the packed path bit for bit"""
+    from fastenhancer_amd.streaming import StreamingModel
+    m, orc, cfg, sr, seed = _model("fe_b")
+    M1, M2 = StreamingModel(m), StreamingModel(m)
+    B, hops, H = 3, 5, cfg.hop_size
+    x = torch.from_numpy(make_input(B, hops * H, 12, sr)).to(_dev())
+    c1 = M1.initialize_cache(x)
+    c2 = [t.clone() for t in M2.initialize_cache(x)]            # foreign tensors: the packing path
+    for t in range(hops):
+        before = [t_.clone() for t_ in c1]
+        o1, *n1 = M1(x[:, t * H:(t + 1) * H], *c1)
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(c1, before)), "input caches were modified"
+        assert M1._which(n1) >= 0, "returned caches are not views of the state buffer"
+        o2, *n2 = M2(x[:, t * H:(t + 1) * H], *c2)
+        assert torch.equal(o1, o2) and all(torch.equal(a_, b_) for a_, b_ in zip(n1, n2))
+        c1, c2 = n1, [t_.clone() for t_ in n2]
+
+
 def test_full_size_batch_256_matches_oracle_and_is_stream_independent():
     """BASELINE config 2: FastEnhancer_B, 256 concurrent streams."""
     m, orc, cfg, sr, seed = _model("fe_b")
