@@ -6,7 +6,8 @@ import os
 from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfastenhancer_hip.so")
+# FASTENHANCER_HIP_LIB: a side build of the same library (ab/lib_<tag>.so from FE_BUILD_TAG=<tag> python -m fastenhancer_amd.build)
+LIB_PATH = os.environ.get("FASTENHANCER_HIP_LIB") or os.path.join(HERE, "libfastenhancer_hip.so")
 FE_MAX_KERNELS = 8
 
 FE_OK = 0

@@ -14,8 +14,11 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(CSRC, "_obj")
-LIB = os.path.join(HERE, "libfastenhancer_hip.so")
+# FE_BUILD_TAG=<tag>: a side build (measurement variants, A/B candidates) with its own object cache, linked to
+# ab/lib_<tag>.so instead of the in-tree library (tools/ab_bench.sh, tools/gpu_phases.py swap it in on the GPU box)
+_TAG = os.environ.get("FE_BUILD_TAG", "")
+OBJ = os.path.join(CSRC, "_obj" + ("_" + _TAG if _TAG else ""))
+LIB = os.path.join(HERE, "libfastenhancer_hip.so") if not _TAG else os.path.join(os.path.dirname(HERE), "ab", f"lib_{_TAG}.so")
 FE_DEPS = ["fe_kernels.hip.h", "fe_impl.h"]
 BSRNN_DEPS = ["fe_kernels.hip.h", "bsrnn_kernels.hip.h"]
 API_DEPS = ["fe_kernels.hip.h", "fe_impl.h", "fe_shapes.def", "bsrnn_kernels.hip.h", "fe_bsrnn_shapes.def", "stft_kernels.hip.h",
@@ -62,6 +65,7 @@ def _compile(job):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
     common = [os.path.join(CSRC, d) for d in FE_DEPS]
     common_b = [os.path.join(CSRC, d) for d in BSRNN_DEPS]
     common_api = [os.path.join(CSRC, d) for d in API_DEPS]

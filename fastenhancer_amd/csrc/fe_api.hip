@@ -81,6 +81,7 @@ struct fe_handle {
     const fe::BImpl* bimpl = nullptr;     // arch == FE_ARCH_BSRNN
     fe::BOffsets boff{};
     int device = 0;
+    int max_wgs = 256;             // CUs of the device: one resident workgroup per CU (persistent grid above that)
     std::vector<Section> sections;
     size_t blob_floats = 0;
     float* packed_dev = nullptr;
@@ -542,14 +543,15 @@ int check_ready(const fe_handle* h) {
     return FE_OK;
 }
 
-// Scratch for the encoder outputs of shapes that keep them in global memory (grow-only; allocating
-// synchronises, so call once with the largest B before capturing graphs / timing).
-int ensure_scratch(fe_handle* h, int B) {
-    if (h->impl->skip_floats == 0 || B <= h->skip_streams) return FE_OK;
-    if (h->skip_dev) { FE_HIP_CHECK(hipDeviceSynchronize()); FE_HIP_CHECK(hipFree(h->skip_dev)); h->skip_dev = nullptr; h->skip_streams = 0; }
-    FE_HIP_CHECK(hipMalloc(&h->skip_dev, (size_t)B * h->impl->skip_floats * sizeof(float)));
-    FE_HIP_CHECK(hipMemset(h->skip_dev, 0, (size_t)B * h->impl->skip_floats * sizeof(float)));
-    h->skip_streams = B;
+// Scratch for the encoder outputs of shapes that keep them in global memory: one slot per resident WORKGROUP (the
+// grid never exceeds max_wgs), allocated once by fe_load_weights - nothing is allocated, freed or synchronised inside
+// the compute calls (they can be captured into HIP graphs).  The slots belong to the handle: launches of one handle
+// must be stream-ordered (one stream, or event-ordered streams); concurrent launches need one handle each.
+int ensure_scratch(fe_handle* h, int) {
+    if (h->impl->skip_floats == 0 || h->skip_dev) return FE_OK;
+    FE_HIP_CHECK(hipMalloc(&h->skip_dev, (size_t)h->max_wgs * h->impl->skip_floats * sizeof(float)));
+    FE_HIP_CHECK(hipMemset(h->skip_dev, 0, (size_t)h->max_wgs * h->impl->skip_floats * sizeof(float)));
+    h->skip_streams = h->max_wgs;
     return FE_OK;
 }
 
@@ -604,6 +606,10 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
     h->d = Dims{impl->C1, impl->NL, impl->C2, impl->F2, impl->KB, impl->NFFT, impl->HOP, impl->NFFT / 2, impl->NFFT / 8, impl->C2 / 4, {0}};
     for (int i = 0; i < cfg->n_kernels; ++i) h->d.ks[i] = cfg->kernel_size[i];
     if (hipGetDevice(&h->device) != hipSuccess) h->device = -1;   // no GPU: sections/tables still usable
+    else {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->max_wgs = cus;
+    }
     build_sections(h);
     build_tables(h);
     *out = h;
@@ -643,6 +649,7 @@ int fe_load_weights(fe_handle* h, const float* blob_dev, size_t nfloats, void* s
     FE_HIP_CHECK(hipMalloc(&h->packed_dev, packed.size() * sizeof(float)));
     FE_HIP_CHECK(hipMemcpyAsync(h->packed_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, st));
     FE_HIP_CHECK(hipStreamSynchronize(st));
+    if (h->impl) { rc = ensure_scratch(h, 0); if (rc != FE_OK) return rc; }
     h->loaded = true;
     return FE_OK;
 }
@@ -694,7 +701,7 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
     a.dbg_stride = h->impl->dbg_floats;
     hipError_t e = hipSuccess;
     a.mode = fe::FE_MODE_STREAM;
-    h->impl->launch(a, (hipStream_t)stream, &e);
+    h->impl->launch(a, h->max_wgs, (hipStream_t)stream, &e);
     if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return FE_OK;
 }
@@ -734,7 +741,7 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
     a.h = h_dev;
     hipError_t e = hipSuccess;
     a.mode = fe::FE_MODE_SPEC;
-    h->impl->launch(a, (hipStream_t)stream, &e);
+    h->impl->launch(a, h->max_wgs, (hipStream_t)stream, &e);
     if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return FE_OK;
 }
@@ -783,7 +790,7 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
     a.cache_stft = work_dev;   // unused in this mode
     a.h = work_dev + (size_t)B * (d.NFFT - d.HOP);
     hipError_t e = hipSuccess;
-    h->impl->launch(a, st, &e);
+    h->impl->launch(a, h->max_wgs, st, &e);
     if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return FE_OK;
 }

@@ -20,37 +20,43 @@ struct Impl {
     size_t dbg_floats;
     int dbg_stages;
     const PackedOffsets* off;
-    void (*launch)(const FrameArgs&, hipStream_t, hipError_t*);
+    void (*launch)(const FrameArgs&, int max_wgs, hipStream_t, hipError_t*);
     void (*dbg_stage)(int, int*, int*, size_t*);
 };
 
-template <class S, bool DBG, int MODE, bool T1>
-void launch_one(const FrameArgs& a, hipStream_t st, hipError_t* err) {
+template <class S, bool DBG, int MODE, bool T1, bool PERSIST>
+void launch_one(const FrameArgs& a, int grid_x, hipStream_t st, hipError_t* err) {
     // the opt-in for > 64 KiB of dynamic LDS is a per-device function attribute: one flag per device, set once
     // (an engine may live on any GPU of the process; relaxed atomics - setting it twice is harmless)
     static std::atomic<bool> attr_set[kMaxDevices];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
     if (!attr_set[dev].load(std::memory_order_relaxed)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fe_frame_kernel<S, DBG, MODE, T1>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fe_frame_kernel<S, DBG, MODE, T1, PERSIST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds<S>::BYTES);
         if (e != hipSuccess) { *err = e; return; }
         attr_set[dev].store(true, std::memory_order_relaxed);
     }
-    dim3 grid(a.B), block(kThreads);
-    hipLaunchKernelGGL((fe_frame_kernel<S, DBG, MODE, T1>), grid, block, Lds<S>::BYTES, st, a);
+    dim3 grid(grid_x), block(kThreads);
+    hipLaunchKernelGGL((fe_frame_kernel<S, DBG, MODE, T1, PERSIST>), grid, block, Lds<S>::BYTES, st, a);
     *err = hipGetLastError();
 }
 
+// max_wgs: workgroups that are resident at once (one per CU: 129+ KiB of LDS and waves_per_eu(1,1)); a batch with more
+// streams runs on a grid of max_wgs PERSISTENT workgroups, each walking its streams b, b + grid, ...
 template <class S>
-void launch_impl(const FrameArgs& a, hipStream_t st, hipError_t* err) {
+void launch_impl(const FrameArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
+    const int grid = a.B < max_wgs ? a.B : max_wgs;
 #ifdef FE_PROBE_HOT
-    if (a.dbg != nullptr) launch_one<S, true, -1, false>(a, st, err);
+    if (a.dbg != nullptr) launch_one<S, true, -1, false, true>(a, grid, st, err);
 #else
-    if (a.dbg != nullptr || a.clk != nullptr) launch_one<S, true, -1, false>(a, st, err);     // fe_debug_step / fe_profile_step
+    if (a.dbg != nullptr || a.clk != nullptr) launch_one<S, true, -1, false, true>(a, grid, st, err);     // fe_debug_step / fe_profile_step
 #endif
-    else if (a.mode == FE_MODE_STREAM && a.T == 1) launch_one<S, false, FE_MODE_STREAM, true>(a, st, err);   // the per-hop hot path
-    else launch_one<S, false, -1, false>(a, st, err);                             // chunked streaming, fe_spec_step, fe_offline
+    else if (a.mode == FE_MODE_STREAM && a.T == 1) {                                   // the per-hop hot path
+        if (grid == a.B) launch_one<S, false, FE_MODE_STREAM, true, false>(a, grid, st, err);
+        else launch_one<S, false, FE_MODE_STREAM, true, true>(a, grid, st, err);
+    }
+    else launch_one<S, false, -1, false, true>(a, grid, st, err);                        // chunked streaming, fe_spec_step, fe_offline
 }
 
 template <class S>

@@ -1056,7 +1056,11 @@ __device__ __forceinline__ void attention_head(const float* G, float* Hl, int ho
 // cost a scalar test + branch each (~40 per frame) and keep their pointers alive in SGPRs for the whole kernel.
 // T1: a.T == 1 is a compile-time fact.  MODE >= 0: the mode is a compile-time constant (the streaming step gets its own instantiation, without the
 // spec / offline branches and their arguments); MODE = -1: a.mode decides at run time.
-template <class S, bool DBG, int MODE, bool T1>
+// PERSIST: the grid is smaller than the batch (more streams than CUs): each workgroup walks the streams blockIdx.x,
+// blockIdx.x + gridDim.x, ... and keeps what does not depend on the stream - twiddles, zeroed halos, the staged weight
+// pipeline (the last phase of a stream's last frame stages unit 0 for the next stream) - instead of paying the kernel
+// prologue and a workgroup launch per stream.  PERSIST = false: one stream per workgroup, no stream loop.
+template <class S, bool DBG, int MODE, bool T1, bool PERSIST>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) fe_frame_kernel(FrameArgs a_in) {
     FrameArgs a = a_in;
 #ifdef FE_PROBE_HOT          // measurement builds: the production instantiations keep the cycle probes (tools/gpu_phases.py ... 1)
@@ -1080,7 +1084,6 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     const int wave0 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave = wave0;
     const int li = lane & 15, lg = lane >> 4;
-    const int b = blockIdx.x;
     const float* __restrict__ wp = a.wp;
     WSrc<Lds<S>::STAGED> wb;
     constexpr PackedOffsets o = Pack<S>::v;
@@ -1115,7 +1118,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     constexpr int SKIP_FLOATS = F1 * C1;             // one skip tensor in A-fragment order
     float* W0 = smem + L::W0;
     float* W1 = smem + L::W1;
-    float* skipg = SG ? a.skip + (size_t)b * ((S::NL + 1) * SKIP_FLOATS) : nullptr;
+    float* skipg = SG ? a.skip + (size_t)blockIdx.x * ((S::NL + 1) * SKIP_FLOATS) : nullptr;      // per workgroup, not per stream
     WSrc<false> skb;                                 // the same scratch as a buffer resource (coalesced fragment reads)
     skb.rsrc = __builtin_amdgcn_make_buffer_rsrc(SG ? skipg : const_cast<float*>(a.wp), 0, SG ? (S::NL + 1) * SKIP_FLOATS * 4 : 4, 0x00020000);
     skb.lane4 = lane * 4;
@@ -1145,11 +1148,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     }
     __syncthreads();
 
+    int b = blockIdx.x;
+    int fc = 0;                                      // frames done by this workgroup (staging-buffer parity)
+#pragma unroll 1
+    do {
     float* cst = a.cache_stft + (size_t)b * OVL;
     float* cis = a.cache_istft + (size_t)b * OVL;
 
 #pragma unroll 1
-    for (int t = 0; t < a.T; ++t) {
+    for (int t = 0; t < a.T; ++t, ++fc) {
         // A loop-variant zero keeps the (many) wave-uniform offsets of a frame from being hoisted out of the frame
         // loop: hoisted, they sit in SGPRs for the whole kernel and spill to VGPR lanes by the hundred.
         // (Measured on the kernels with a frame loop: FastEnhancer_B 46.0 -> 44.1 us per frame, T 21.2 -> 20.5 us,
@@ -1159,7 +1166,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         const int wave = wave0 + lz;
         // begin_unit(U): called right after the barrier that precedes the GEMM phase of staged unit U:
         // selects the LDS copy of this phase's weights and sets up the DMA job of the next unit.
-        const int fpar = (S::NU & 1) ? (t & 1) : 0;
+        const int fpar = (S::NU & 1) ? ((PERSIST ? fc : t) & 1) : 0;
 #define FE_BEGIN_UNIT(U)                                                                           \
         constexpr int fe_un_ = ((U) + 1 == S::NU) ? 0 : (U) + 1;                                   \
         if constexpr (L::STAGED) {                                                                 \
@@ -1169,7 +1176,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             wb.lds = smem + (slot_ ? L::WB1 : L::WB0);                                             \
             wb.base = o.u_off[(U)];                                                                \
         }                                                                                          \
-        const StageSide<NPW, (L::STAGED && !(T1 && (U) + 1 == S::NU)) ? o.u_size[fe_un_] / 256 : 0> stage{&job}
+        const StageSide<NPW, (L::STAGED && !(T1 && !PERSIST && (U) + 1 == S::NU)) ? o.u_size[fe_un_] / 256 : 0> stage{&job}
         FE_CLK(0);
         // =========================== STFT (a3) ===========================
         const int mode = a.mode;
@@ -2052,6 +2059,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         }
         FE_CLK(13);
     }
+    b += gridDim.x;
+    } while (PERSIST && b < a.B);
 }
 
 }  // namespace fe
