@@ -57,6 +57,7 @@ WORKLOADS = {
     "bsrnn_xt": dict(bsrnn=True, C=16, L=6, N=512, H=256, sr=16000, desc="BSRNN (xt) 16kHz"),
     "bsrnn_xxt": dict(bsrnn=True, C=16, L=2, N=512, H=256, sr=16000, desc="BSRNN (xxt) 16kHz"),
     "bsrnn_t": dict(bsrnn=True, C=32, L=6, N=512, H=256, sr=16000, desc="BSRNN (t) 16kHz"),
+    "bsrnn_s": dict(bsrnn=True, C=64, L=6, N=512, H=256, sr=16000, desc="BSRNN (s) 16kHz"),
     "fe_m": dict(C1=96, ks=(8, 3, 3, 3), C2=72, F2=48, K=4, N=512, H=160, sr=16000, init="linear_fixed",
                  desc="FastEnhancer_M 16kHz"),
     "fe_l": dict(C1=128, ks=(8, 3, 3, 3, 3), C2=96, F2=64, K=5, N=512, H=100, sr=16000, init="linear_fixed",

@@ -1,12 +1,20 @@
 // bsrnn_kernels.hip.h — BSRNN (models/bsrnn/model.py of the reference) streaming / offline forward for gfx950.
 //
-// Same execution model as fe_kernels.hip.h: one workgroup (256 threads) owns one stream and runs the whole frame
+// Same execution model as fe_kernels.hip.h: one workgroup (256 threads) owns one stream at a time and runs the whole frame
 //   STFT -> compress (all 257 bins) -> band split (31 bands) -> L x [time-LSTM, bidirectional band-LSTM]
 //        -> per-band mask/residual MLPs (GLU) -> complex mask + residual -> un-compress -> iSTFT
-// with every activation in LDS.  The batched contractions (LSTM gate pre-activations of the 31 bands, the fc layers)
-// run on the fp32 matrix cores; the band-LSTM recurrence (31 sequential steps per direction, a 1 x 2C by 2C x 8C
-// product each) runs on the vector ALUs with one gate row per thread whose W_hh row stays in registers for the
-// whole layer, the four gates of a hidden unit sitting in adjacent lanes (quad shuffles, no LDS round trip).
+// with every activation in LDS.
+//  * The batched contractions (time-LSTM gate pre-activations of the 31 bands, the band-LSTM input projections, the fc
+//    layers) run on the fp32 matrix cores.  For num_channels = 16 (xt / xxt) a wave's weight fragments of a whole layer
+//    (130 registers) are prefetched from L2 while the previous layer's band recurrence - a latency chain that leaves the
+//    vector-memory path idle - is running; the GEMM phases then feed from registers and LDS only.
+//  * The band-LSTM recurrence (31 sequential steps per direction, a 1 x 2C by 2C x 8C product each) runs on the vector
+//    ALUs with one gate row per thread whose W_hh row stays in registers for the whole layer (C <= 32; C = 64 streams
+//    it from L2), packed fp32 FMAs, the four gates of a hidden unit in adjacent lanes (DPP quad broadcasts).  Gate rows
+//    are packed pre-scaled by -log2(e) (i, f, o) / -2 log2(e) (g), so every activation is rcp(1 + exp2(pre)).
+//  * Band split and the per-band MLPs (every band has its own weights: M = 1, each weight is used once per frame) are
+//    vector-ALU dot products over 16-byte weight loads, software-pipelined one row ahead: these phases are bound by the
+//    L2 -> CU path (780 KB of MLP weights per frame for xt), not by arithmetic.
 #pragma once
 #include <atomic>
 
@@ -14,9 +22,15 @@
 
 namespace fe {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int kBands = 31;
 constexpr int kBins = 257;
+constexpr int kMlpRows = 4 * kBins;       // rows of the second MLP layers over all bands (1028)
+constexpr int kBsKP = 36;                 // band-split K (2 * sub <= 34) padded to whole 16-byte loads
 __device__ __constant__ const int c_sub[kBands] = {2, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 16, 16, 16, 16, 16, 16, 16, 17};
+__device__ __constant__ const int c_start[kBands] = {0, 2, 5, 8, 11, 14, 17, 20, 23, 26, 29, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120,
+                                                     128, 144, 160, 176, 192, 208, 224, 240};
 
 // compile-time shape: C = num_channels, NLAY = num_layers (n_fft = 512 is fixed by the model: models/bsrnn/model.py:112)
 template <int C_, int NLAY_, int HOP_>
@@ -26,22 +40,37 @@ struct BShape {
     static constexpr int G4 = 4 * HH;           // gate rows
     static constexpr int OVL = NFFT - HOP;
     static constexpr int LDX = C + 2, LDH = HH + 2, LDY = 2 * HH + 2, LDP = G4 + 2;
+    static constexpr int LDH1 = 4 * C + 4;      // MLP hidden rows (16-byte aligned, bands 4 banks apart)
     static constexpr int NCT = HH / 16;         // hidden-unit tiles
     static constexpr int NTC = C / 16;          // channel tiles
-    static constexpr int RPT = (2 * G4) / kThreads;   // gate rows per thread in the band-LSTM recurrence (both directions)
-    static_assert(C % 16 == 0 && (RPT == 1 || RPT == 2), "num_channels must be 16 or 32");
+    static constexpr int KSC = C / 4, KSH = HH / 4, KS1 = KSC + KSH;
+    static constexpr int RPT = HH / 32;         // gate rows per thread in the band recurrence (128 threads per direction)
+    static constexpr bool REGW = (C == 16);     // a layer's GEMM weight fragments live in registers (prefetched a layer ahead)
+    static constexpr bool WREG = (C <= 32);     // recurrence weights register-resident (else streamed from L2 every step)
+    static constexpr bool XPG = (C > 32);       // band-LSTM input projections in a global scratch (do not fit in LDS)
+    // band recurrence, work split of a quad of lanes (one hidden unit): KSPLIT = false: lane g holds gate row g over the
+    // whole K = HH (reads all of h); KSPLIT = true: lane q holds a quarter of K for all four gate rows (reads HH/4 of h,
+    // two DPP adds per gate to sum the quarters).  A lone wave per SIMD issues an instruction every ~5.5 cycles, so a step
+    // costs its instruction count: at HH = 32 the extra 11 reduction instructions outweigh 6 fewer LDS reads (measured
+    // 881 vs 813 cycles per step), at HH = 64 the 12 fewer LDS reads and no second pass win (1535 vs 1746).
+    static constexpr bool KSPLIT = (C >= 32);
+    static constexpr int NIPW = (2 * G4 / 16) / kWaves;   // input-projection column tiles per wave
+    static_assert(C == 16 || C == 32 || C == 64, "num_channels must be 16, 32 or 64");
 };
 
 // offsets (floats) into the packed weight buffer; filled by the host packer (fe_api.hip)
 struct BOffsets {
-    int bs_w[kBands];          // band split: [2*sub][C]  (k-major)
-    int bs_b;                  // [31][C]
-    int t_w[8], t_b[8];        // time LSTM: B fragments, K = C + HH (x rows then h rows), N = 4*HH ; bias b_ih + b_hh
+    int bs_w, bs_b;            // band split: [kBsKP/4][31*C] float4 (k-major, rows zero-padded to kBsKP), [31][C]
+    int t_w[8], t_b[8];        // time LSTM: B fragments, K = C + HH (x rows then h rows), N = 4*HH, tile (gate*NCT + ct); bias b_ih + b_hh [4][HH]
     int tfc_w[8], tfc_b[8];    // fc_time: B fragments K = HH, N = C
-    int f_wih[8][2], f_b[8][2], f_whh[8][2];   // band LSTM per direction: B fragments K = C, N = 4HH; bias; W_hh as [rr][k][q] (thread order)
+    int f_wih[8][2], f_b[8][2], f_whh[8][2];   // band LSTM per direction: B fragments K = C, N = 4HH; bias; W_hh in thread order:
+                               // KSPLIT: [rr][gate * HH/4 + kk][thread 4u + q] = W_hh[gate * HH + u + 32 rr][q * HH/4 + kk]
+                               // else:   [rr][k][thread 4u + gate]            = W_hh[gate * HH + u + 32 rr][k]     (streamed shapes: k in float4 groups)
     int ffc_w[8], ffc_b[8];    // fc_freq: B fragments K = 2HH, N = C
-    int m_w1[2], m_b1[2];      // mask decoder layer 1 per kind: [31][C][4C] (k-major), [31][4C]
-    int m_w2[2], m_b2[2];      // layer 2 per kind: [4C][1028] (k-major over the global row index), [1028]
+    int m_w1[2], m_b1[2];      // mask decoder layer 1 per kind: [31][C/4][4C] float4 (per band k-major: coalesced over the outputs), [31][4C]
+    int m_w2[2], m_b2[2];      // layer 2 per kind: [4C/4][1028] float4 (k-major over the global row index), [1028]
+    int row_band;              // int[1028]: band of each layer-2 row
+    int bin_row, bin_2sub;     // int[257]: first "a" row of a bin (its (re, im) pair), 2 * sub of its band (distance to the gate rows)
     int window, window_istft, twiddle;
     int total;
 };
@@ -57,13 +86,31 @@ struct BArgs {
     float* lstm;              // [2*NLAY][B*31][HH]  (h0, c0, h1, c1, ...)
     const float* spec_in;     // spec mode [B][257][T][2]
     float* spec_out;
+    float* xp_scratch;        // XPG shapes: [grid][2][32][G4]
+    float* dbg;               // per-stage dumps (DBG instantiation) or nullptr
+    size_t dbg_stride;
     int B, T, mode, Tw;
     float compression;
     unsigned long long* clk;  // fe_profile_step: cycle probes of workgroup 0 (PROF instantiation only)
 };
 
+// debug stage table: spec_in, compressed, band_split, (layer.l.time, layer.l.freq)..., mask_mlp, spec_out
+template <class S>
+struct BDebugLayout {
+    static constexpr int n_stages = 3 + 2 * S::NLAY + 2;
+    __host__ __device__ static constexpr int rows(int s) { return (s <= 1 || s >= 3 + 2 * S::NLAY) ? kBins : kBands; }
+    __host__ __device__ static constexpr int cols(int s) { return s <= 1 ? 2 : (s < 3 + 2 * S::NLAY ? S::C : (s == 3 + 2 * S::NLAY ? 4 : 2)); }
+    __host__ __device__ static constexpr size_t offset(int s) {
+        size_t o = 0;
+        for (int i = 0; i < s; ++i) o += (size_t)rows(i) * cols(i);
+        return o;
+    }
+    __host__ __device__ static constexpr size_t total() { return offset(n_stages); }
+};
+
 template <class S>
 struct BLds {
+    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
     static constexpr int SP = 0;                              // compressed spectrum [257][2]
     static constexpr int TW = SP + 2 * kBins + 2;             // twiddles
     static constexpr int FA = TW + S::NFFT;                   // FFT ping-pong
@@ -71,28 +118,34 @@ struct BLds {
     static constexpr int X = FB + 2 * S::NFFT;                // [32][LDX] band features
     static constexpr int HS = X + 32 * S::LDX;                // [32][LDH] time-LSTM h (A operand)
     static constexpr int HN = HS + 32 * S::LDH;               // [32][LDH] new h (A operand of fc_time)
-    static constexpr int XP = HN + 32 * S::LDH;               // [2][32][LDP] band-LSTM input projections
-    static constexpr int YF = XP + 2 * 32 * S::LDP;           // [32][LDY] band-LSTM outputs (fwd | bwd)
+    static constexpr int YF = HN + 32 * S::LDH;               // [32][LDY] band-LSTM outputs (fwd | bwd)
     static constexpr int HB = (YF + 32 * S::LDY + 3) / 4 * 4;   // [2 dirs][2 buffers][HH], 16-byte aligned (float4 broadcast reads)
-    static constexpr int H1 = HB + 4 * S::HH;                 // [2 kinds][31][4C]
-    static constexpr int TOTAL = H1 + 2 * kBands * 4 * S::C;
+    static constexpr int XP = HB + 4 * S::HH;                 // [2][32][LDP] band-LSTM input projections (LDS-resident shapes)
+    static constexpr int XP_SIZE = S::XPG ? 0 : 2 * 32 * S::LDP;
+    // after the layers the HS / HN / YF / XP region is dead: the MLP hidden layer and the layer-2 pre-activations alias it
+    static constexpr int H1 = (HS + 3) / 4 * 4;               // [2 kinds][31][LDH1]
+    static constexpr int PRE = H1 + 2 * kBands * S::LDH1;     // [2][1028]
+    static constexpr int TOTAL = cmax(XP + XP_SIZE, PRE + 2 * kMlpRows);
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
+    static_assert(BYTES <= 160 * 1024, "BSRNN LDS plan exceeds 160 KiB");
 };
 
-// HOT: the per-hop streaming step (mode and T = 1 are compile-time facts: no frame loop, no spec / offline branches)
 #define BE_CLK(i) do { if constexpr (PROF) { if (blockIdx.x == 0 && threadIdx.x == 0) a.clk[(i)] = __builtin_readcyclecounter(); } } while (0)
-// PROF: cycle probes per phase (fe_profile_step, tools/gpu_phases_bsrnn.py)
-template <class S, bool HOT, bool PROF>
+
+// HOT: the per-hop streaming step (mode and T = 1 are compile-time facts: no frame loop, no spec / offline branches)
+// PROF: cycle probes per phase (fe_profile_step, tools/gpu_phases_bsrnn.py);  DBG: per-stage dumps (fe_debug_step)
+template <class S, bool HOT, bool PROF, bool DBG>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) bsrnn_frame_kernel(BArgs a) {
     const int aT = HOT ? 1 : a.T;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = BLds<S>;
     constexpr int N = S::NFFT, H = S::HOP, OVL = S::OVL, C = S::C, HH = S::HH, G4 = S::G4;
-    constexpr int LDX = S::LDX, LDH = S::LDH, LDY = S::LDY, LDP = S::LDP;
+    constexpr int LDX = S::LDX, LDH = S::LDH, LDY = S::LDY, LDP = S::LDP, LDH1 = S::LDH1;
+    constexpr int KSC = S::KSC, KSH = S::KSH, KS1 = S::KS1;
+    constexpr bool REGW = S::REGW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
-    const int b = blockIdx.x;
     const float* __restrict__ wp = a.wp;
     const BOffsets& o = a.off;
     WSrc<false> wb;
@@ -109,27 +162,88 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     float* X = smem + L::X;
     float* Hs = smem + L::HS;
     float* Hn = smem + L::HN;
-    float* XP = smem + L::XP;
     float* Yf = smem + L::YF;
     float* Hb = smem + L::HB;
+    float* XPl = smem + L::XP;
     float* H1 = smem + L::H1;
+    float* PRE = smem + L::PRE;
+    float* XPg = S::XPG ? a.xp_scratch + (size_t)blockIdx.x * (2 * 32 * G4) : nullptr;
     for (int i = tid; i < N / 2; i += kThreads) tw[i] = reinterpret_cast<const float2*>(wp + o.twiddle)[i];
     __syncthreads();
 
+    const int mode = HOT ? FE_MODE_STREAM : a.mode;
+    // band recurrence: a quad of lanes <-> (direction, hidden unit); lane rgate of the quad holds a quarter of K for all four gates
+    const int rd = wave >> 1;                // direction (wave-uniform: waves 0, 1 forward, waves 2, 3 backward)
+    const int rq = tid & 127;                // gate row within the direction's 128-thread group
+    const int rgate = rq & 3;
+
+    // ---- a layer's register-resident weight set (REGW): this wave's fragments / this thread's recurrence row
+    constexpr int NFC1 = REGW ? KSH : 1, NFC2 = REGW ? 2 * KSH : 1, NIP = S::NIPW;
+    float Wt[REGW ? 4 : 1][REGW ? KS1 : 1], Wtb[REGW ? 4 : 1];
+    float Wf1[NFC1], Wf1b, Wf2[NFC2], Wf2b, Wf2n[NFC2], Wf2bn;
+    float Wip[REGW ? NIP : 1][REGW ? KSC : 1], Wipb[REGW ? NIP : 1];
+    float Whh[S::WREG ? S::RPT : 1][S::WREG ? HH : 1], Whhn[REGW ? HH : 1];
+    Wf1b = Wf2b = Wf2bn = 0.0f;
+    // this wave's time-LSTM item (REGW: exactly one per wave)
+    const int t_mt = wave / S::NCT, t_ct = wave % S::NCT;
+    // element e of layer l's prefetch list (compile-time e): Wt, Wtb, Wf1, Wip, Wipb go in place (dead during the
+    // recurrence that hides the fetch), W_hh / fc_freq into the *n set (still in use; handed over at the layer boundary)
+    constexpr int E_WT = 0, E_WTB = E_WT + 4 * KS1, E_F1 = E_WTB + 4, E_F1B = E_F1 + KSH, E_IP = E_F1B + 1, E_IPB = E_IP + NIP * KSC,
+                  E_HH = E_IPB + NIP, E_F2 = E_HH + HH, E_F2B = E_F2 + 2 * KSH, E_END = E_F2B + 1;
+    auto fetch_elem = [&](auto e_, int l, auto first_) {
+        constexpr int e = decltype(e_)::value;
+        constexpr bool first = decltype(first_)::value;
+        if constexpr (!REGW) return;
+        else if constexpr (e < E_WTB) { constexpr int g = e / KS1, ks = e % KS1; Wt[g][ks] = wb.at_g(o.t_w[l] + ((g * S::NCT + t_ct) * KS1 + ks) * 64); }
+        else if constexpr (e < E_F1) { constexpr int g = e - E_WTB; Wtb[g] = wb.at16_g(o.t_b[l] + g * HH + t_ct * 16); }
+        else if constexpr (e < E_F1B) { constexpr int ks = e - E_F1; Wf1[ks] = wb.at_g(o.tfc_w[l] + ks * 64); }
+        else if constexpr (e < E_IP) Wf1b = wb.at16_g(o.tfc_b[l]);
+        else if constexpr (e < E_IPB) {
+            constexpr int jj = (e - E_IP) / KSC, ks = (e - E_IP) % KSC;
+            const int nt = wave + kWaves * jj, d = nt / (G4 / 16), ntd = nt - d * (G4 / 16);
+            Wip[jj][ks] = wb.at_g(o.f_wih[l][d] + (ntd * KSC + ks) * 64);
+        }
+        else if constexpr (e < E_HH) {
+            constexpr int jj = e - E_IPB;
+            const int nt = wave + kWaves * jj, d = nt / (G4 / 16), ntd = nt - d * (G4 / 16);
+            Wipb[jj] = wb.at16_g(o.f_b[l][d] + ntd * 16);
+        }
+        else if constexpr (e < E_F2) {
+            constexpr int k = e - E_HH;
+            const float v = wp[o.f_whh[l][rd] + k * 128 + rq];
+            if constexpr (first) Whh[0][k] = v; else Whhn[k] = v;
+        }
+        else if constexpr (e < E_F2B) {
+            constexpr int ks = e - E_F2;
+            const float v = wb.at_g(o.ffc_w[l] + ks * 64);
+            if constexpr (first) Wf2[ks] = v; else Wf2n[ks] = v;
+        }
+        else { const float v = wb.at16_g(o.ffc_b[l]); if constexpr (first) Wf2b = v; else Wf2bn = v; }
+    };
+    // slice `part` of `parts` of the list
+    auto fetch_part = [&](auto part_, auto parts_, int l, auto first_) {
+        constexpr int part = decltype(part_)::value, parts = decltype(parts_)::value;
+        constexpr int per = (E_END + parts - 1) / parts, lo = part * per, hi = (lo + per < E_END) ? lo + per : E_END;
+        static_for<(hi > lo ? hi - lo : 0)>([&](auto i_) { fetch_elem(std::integral_constant<int, lo + decltype(i_)::value>{}, l, first_); });
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+
+    int b = blockIdx.x;
+#pragma unroll 1
+    do {
     float* cst = a.cache_stft + (size_t)b * OVL;
     float* cis = a.cache_istft + (size_t)b * OVL;
-    const int mode = HOT ? FE_MODE_STREAM : a.mode;
-    // band of each bin (for the mask decoder's row bookkeeping): bin f -> band start / width
-    auto band_of = [&](int f, int& start, int& sub) {
-        int s0 = 0;
-#pragma unroll 1
-        for (int bb = 0; bb < kBands; ++bb) {
-            const int sb = c_sub[bb];
-            if (f < s0 + sb) { start = s0; sub = sb; return bb; }
-            s0 += sb;
+    float* dbg = DBG ? a.dbg + (size_t)b * a.dbg_stride : nullptr;
+    auto dump = [&](int stage, const float* src, int ld) {
+        if constexpr (DBG) {
+            using D = BDebugLayout<S>;
+            const int rows = D::rows(stage), cols = D::cols(stage);
+            float* dst = dbg + D::offset(stage);
+            for (int i = tid; i < rows * cols; i += kThreads) { const int r = i / cols, c = i - r * cols; dst[i] = src[r * ld + c]; }
         }
-        start = 0; sub = 1;
-        return 0;
     };
 
 #pragma unroll 1
@@ -155,11 +269,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 }
             }
             __syncthreads();
+            if constexpr (REGW) fetch_part(I0{}, I3{}, 0, std::true_type{});   // layer 0's weights: in flight across the FFT (three bursts:
+                                                                                 // a wave keeps at most 63 vector-memory loads in flight)
             if (mode == FE_MODE_STREAM) {
                 for (int m = tid; m < OVL; m += kThreads) cst[m] = fb[m + H].x;
                 __syncthreads();
             }
             float2* Xf = fft_lds<S, false>(fa, fb, tw);
+            if constexpr (REGW) fetch_part(I1{}, I3{}, 0, std::true_type{});
+            if constexpr (DBG) { for (int f = tid; f < kBins; f += kThreads) { dbg[2 * f] = Xf[f].x; dbg[2 * f + 1] = Xf[f].y; } }
             for (int f = tid; f < kBins; f += kThreads) {
                 const float re = Xf[f].x, im = Xf[f].y;
                 const float g = pow_f(fmaxf(sqrtf(re * re + im * im), 1.0e-5f), a.compression - 1.0f);
@@ -167,69 +285,104 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 sp[2 * f + 1] = im * g;
             }
         } else {
+            if constexpr (REGW) { fetch_part(I0{}, I3{}, 0, std::true_type{}); fetch_part(I1{}, I3{}, 0, std::true_type{}); }
             const float* si = a.spec_in + (size_t)b * kBins * aT * 2;
             for (int f = tid; f < kBins; f += kThreads) {
                 const float re = si[((size_t)f * aT + t) * 2], im = si[((size_t)f * aT + t) * 2 + 1];
+                if constexpr (DBG) { dbg[2 * f] = re; dbg[2 * f + 1] = im; }
                 const float g = pow_f(fmaxf(sqrtf(re * re + im * im), 1.0e-5f), a.compression - 1.0f);
                 sp[2 * f] = re * g;
                 sp[2 * f + 1] = im * g;
             }
         }
         __syncthreads();
+        if constexpr (REGW) fetch_part(I2{}, I3{}, 0, std::true_type{});
+        dump(1, sp, 2);
 
         BE_CLK(1);
         // ============================ band split (BandSplit.forward, :136-153; BN folded) ============================
+        // thread <-> (band, channel): its zero-padded weight row of kBsKP floats as nine 16-byte loads, all in flight at once
         for (int i = tid; i < kBands * C; i += kThreads) {
-            const int bb = i / C, c = i - bb * C;
-            int s0 = 0;
-            for (int q = 0; q < bb; ++q) s0 += c_sub[q];
-            const int k2 = 2 * c_sub[bb];
-            const float* w = wp + o.bs_w[bb] + c;
-            float acc = wp[o.bs_b + bb * C + c];
-            for (int k = 0; k < k2; ++k) acc += w[k * C] * sp[2 * s0 + k];      // input index f*2 + ri
-            X[bb * LDX + c] = acc;
+            const int bb = i / C;
+            const float4* w4 = reinterpret_cast<const float4*>(wp + o.bs_w) + i;      // [k/4][band * C + c] float4: coalesced over the threads
+            float4 wv[kBsKP / 4];
+#pragma unroll
+            for (int k = 0; k < kBsKP / 4; ++k) wv[k] = w4[k * (kBands * C)];
+            // first bin of the band (2, 10 x 3, 12 x 8, 7 x 16, 17 bins), computed - a table lookup would be a dependent load
+            const int s0 = bb == 0 ? 0 : (bb <= 10 ? 3 * bb - 1 : (bb <= 22 ? 8 * bb - 56 : 16 * bb - 240));
+            const float* s = sp + 2 * s0;                      // input index f*2 + ri
+            float a0 = wp[o.bs_b + i], a1 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < kBsKP / 4; ++k) {
+                a0 += wv[k].x * s[4 * k] + wv[k].z * s[4 * k + 2];
+                a1 += wv[k].y * s[4 * k + 1] + wv[k].w * s[4 * k + 3];
+            }
+            X[bb * LDX + (i - bb * C)] = a0 + a1;
+        }
+        // time-LSTM state of layer 0 (the later layers' is fetched under the previous layer's recurrence)
+        constexpr int HPT = (kBands * HH + kThreads - 1) / kThreads;
+        float hpre[HPT];
+        {
+            const float* hg0 = a.lstm + (size_t)b * (kBands * HH);
+#pragma unroll
+            for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = hg0[i < kBands * HH ? i : kBands * HH - 1]; }
+#pragma unroll
+            for (int q = 0; q < HPT; ++q) {
+                const int i = tid + q * kThreads, r = i / HH;
+                if (i < kBands * HH) Hs[r * LDH + (i - r * HH)] = hpre[q];
+            }
         }
         __syncthreads();
+        dump(2, X, LDX);
 
 #pragma unroll 1
         for (int l = 0; l < S::NLAY; ++l) {
             float* hg = a.lstm + ((size_t)(2 * l) * a.B + b) * (kBands * HH);
             float* cg = a.lstm + ((size_t)(2 * l + 1) * a.B + b) * (kBands * HH);
             if (l == 0) BE_CLK(2);
-            // ---------------- time LSTM (LSTMCell over the 31 bands; :371-381): h -> LDS
-            for (int i = tid; i < kBands * HH; i += kThreads) { const int r = i / HH; Hs[r * LDH + (i - r * HH)] = hg[i]; }
-            __syncthreads();
+            // ---------------- time LSTM (LSTMCell over the 31 bands; :371-381)
+            // items (m-tile, hidden tile): 4 gate accumulators each; gates fused into the epilogue (order i,f,g,o);
+            // gate rows are packed pre-scaled, so sigma(v) = rcp(1 + exp2(pre)) and tanh(v) = 2 rcp(1 + exp2(pre)) - 1
             {
-                // items (m-tile, hidden tile): 4 gate accumulators each; gates fused into the epilogue (order i,f,g,o)
                 constexpr int NITEM = 2 * S::NCT;
-#pragma unroll 1
-                for (int it = wave; it < NITEM; it += kWaves) {
-                    const int mt = it / S::NCT, ct = it - mt * S::NCT;
+                auto item = [&](int mt, int ct, auto wtf, auto wtbf) {
+                    // previous cell state of this lane's outputs: in flight under the GEMM
+                    float cprev[4];
+                    const int j = 16 * ct + li;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const int row = 16 * mt + 4 * lg + r; cprev[r] = cg[(row < kBands ? row : kBands - 1) * HH + j]; }
                     f32x4 acc[1][4];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float bv = wb.at16_g(o.t_b[l] + g * HH + ct * 16);
-                        acc[0][g] = f32x4{bv, bv, bv, bv};
-                    }
+                    for (int g = 0; g < 4; ++g) { const float bv = wtbf(g); acc[0][g] = f32x4{bv, bv, bv, bv}; }
                     const float* xa = X + (16 * mt + li) * LDX + lg;
                     const float* ha = Hs + (16 * mt + li) * LDH + lg;
-                    constexpr int KSX = C / 4, KSH = HH / 4;
-                    mma_panel<1, 4, KSX + KSH>(
-                        acc, [&](int, int ks) { return ks < KSX ? xa[4 * ks] : ha[4 * (ks - KSX)]; },
-                        [&](int g, int ks) { return wb.at_g(o.t_w[l] + ((g * S::NCT + ct) * (KSX + KSH) + ks) * 64); }, NoSide{});
-                    const int j = 16 * ct + li;
+                    mma_panel<1, 4, KS1, REGW ? 3 : 8>(
+                        acc, [&](int, int ks) { return ks < KSC ? xa[4 * ks] : ha[4 * (ks - KSC)]; }, wtf, NoSide{});
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * mt + 4 * lg + r;
+                        const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[0][0][r]));
+                        const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[0][1][r]));
+                        const float gg = 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[0][2][r])) - 1.0f;
+                        const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[0][3][r]));
+                        const float cn = fg * cprev[r] + ig * gg;
+                        const float hn = og * tanh_f(cn);
                         if (row < kBands) {
-                            const float ig = sigmoid_f(acc[0][0][r]), fg = sigmoid_f(acc[0][1][r]);
-                            const float gg = tanh_f(acc[0][2][r]), og = sigmoid_f(acc[0][3][r]);
-                            const float cn = fg * cg[row * HH + j] + ig * gg;
-                            const float hn = og * tanh_f(cn);
                             cg[row * HH + j] = cn;
                             hg[row * HH + j] = hn;
                             Hn[row * LDH + j] = hn;
                         }
+                    }
+                };
+                if constexpr (REGW) {
+                    static_assert(!REGW || NITEM == kWaves, "one time-LSTM item per wave");
+                    item(t_mt, t_ct, [&](int g, int ks) { return Wt[g][ks]; }, [&](int g) { return Wtb[g]; });
+                } else {
+#pragma unroll 1
+                    for (int it = wave; it < NITEM; it += kWaves) {
+                        const int mt = it / S::NCT, ct = it - mt * S::NCT;
+                        item(mt, ct, [&](int g, int ks) { return wb.at_g(o.t_w[l] + ((g * S::NCT + ct) * KS1 + ks) * 64); },
+                             [&](int g) { return wb.at16_g(o.t_b[l] + g * HH + ct * 16); });
                     }
                 }
             }
@@ -242,11 +395,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 for (int it = wave; it < NITEM; it += kWaves) {
                     const int mt = it / S::NTC, nt = it - mt * S::NTC;
                     f32x4 acc[1][1];
-                    const float bv = wb.at16_g(o.tfc_b[l] + nt * 16);
+                    float bv;
+                    if constexpr (REGW) bv = Wf1b; else bv = wb.at16_g(o.tfc_b[l] + nt * 16);
                     acc[0][0] = f32x4{bv, bv, bv, bv};
                     const float* ha = Hn + (16 * mt + li) * LDH + lg;
-                    mma_panel<1, 1, HH / 4>(acc, [&](int, int ks) { return ha[4 * ks]; },
-                                            [&](int, int ks) { return wb.at_g(o.tfc_w[l] + (nt * (HH / 4) + ks) * 64); }, NoSide{});
+                    mma_panel<1, 1, KSH, REGW ? 3 : 8>(acc, [&](int, int ks) { return ha[4 * ks]; },
+                                        [&](int, int ks) {
+                                            if constexpr (REGW) return Wf1[ks];
+                                            else return wb.at_g(o.tfc_w[l] + (nt * KSH + ks) * 64);
+                                        }, NoSide{});
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * mt + 4 * lg + r;
@@ -255,69 +412,145 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 }
             }
             __syncthreads();
+            dump(3 + 2 * l, X, LDX);
             {
                 if (l == 0) BE_CLK(4);
                 // ---------------- band LSTM (:386-390): input projections of all 31 bands, both directions
                 constexpr int NTP = 2 * (G4 / 16);       // n-tiles: direction-major
-#pragma unroll 1
-                for (int nt = wave; nt < NTP; nt += kWaves) {
+                auto proj = [&](int nt, auto wf, float bv) {
                     const int d = nt / (G4 / 16), ntd = nt - d * (G4 / 16);
                     f32x4 acc[2][1];
-                    const float bv = wb.at16_g(o.f_b[l][d] + ntd * 16);
                     acc[0][0] = f32x4{bv, bv, bv, bv};
                     acc[1][0] = acc[0][0];
-                    mma_panel<2, 1, C / 4>(acc, [&](int i, int ks) { return X[(16 * i + li) * LDX + lg + 4 * ks]; },
-                                           [&](int, int ks) { return wb.at_g(o.f_wih[l][d] + (ntd * (C / 4) + ks) * 64); }, NoSide{});
+                    mma_panel<2, 1, KSC, REGW ? 3 : 8>(acc, [&](int i, int ks) { return X[(16 * i + li) * LDX + lg + 4 * ks]; }, wf, NoSide{});
+                    float* dst = S::XPG ? XPg : XPl;
+                    constexpr int ld = S::XPG ? G4 : LDP;
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) XP[(d * 32 + 16 * i + 4 * lg + r) * LDP + 16 * ntd + li] = acc[i][0][r];
+                        for (int r = 0; r < 4; ++r) dst[(d * 32 + 16 * i + 4 * lg + r) * ld + 16 * ntd + li] = acc[i][0][r];
+                };
+                if constexpr (REGW) {
+                    static_for<S::NIPW>([&](auto jj_) {
+                        constexpr int jj = decltype(jj_)::value;
+                        proj(wave + kWaves * jj, [&](int, int ks) { return Wip[jj][ks]; }, Wipb[jj]);
+                    });
+                } else {
+#pragma unroll 1
+                    for (int nt = wave; nt < NTP; nt += kWaves) {
+                        const int d = nt / (G4 / 16), ntd = nt - d * (G4 / 16);
+                        proj(nt, [&](int, int ks) { return wb.at_g(o.f_wih[l][d] + (ntd * KSC + ks) * 64); }, wb.at16_g(o.f_b[l][d] + ntd * 16));
+                    }
                 }
             }
-            // recurrence: thread <-> (direction, hidden unit j, gate) with the 4 gates of a unit in adjacent lanes
-            const int d = tid / (kThreads / 2);
-            const int q = tid - d * (kThreads / 2);             // 0..127
-            const int gate = q & 3;
-            float wrow[S::RPT][HH];
+            // recurrence weights (register shapes without the layer-ahead prefetch: loaded here)
             float cstate[S::RPT];
 #pragma unroll
-            for (int rr = 0; rr < S::RPT; ++rr) {
-                const int j = (q >> 2) + 32 * rr;
-                const float* wr = wp + o.f_whh[l][d] + rr * HH * (kThreads / 2) + q;   // [rr][k][q]: coalesced over the threads
-#pragma unroll
-                for (int k = 0; k < HH; ++k) wrow[rr][k] = wr[k * (kThreads / 2)];
-                (void)j;
-                cstate[rr] = 0.0f;
-            }
-            if (tid < 4 * HH) Hb[tid] = 0.0f;                    // h = 0 for both directions, both buffers
-            __syncthreads();
-            if (l == 0) BE_CLK(5);
-#pragma unroll 1
-            for (int s = 0; s < kBands; ++s) {
-                const int band = d == 0 ? s : kBands - 1 - s;
-                const float* hprev = Hb + (d * 2 + (s & 1)) * HH;
-                float* hnext = Hb + (d * 2 + ((s + 1) & 1)) * HH;
+            for (int rr = 0; rr < S::RPT; ++rr) cstate[rr] = 0.0f;
+            if constexpr (S::WREG && !REGW) {
 #pragma unroll
                 for (int rr = 0; rr < S::RPT; ++rr) {
-                    const int j = (q >> 2) + 32 * rr;
-                    const float4* hp4 = reinterpret_cast<const float4*>(hprev);      // broadcast reads, 16 B each
-                    // four partial sums: one serial chain of HH dependent FMAs per step is the recurrence's critical path
-                    float p0 = XP[(d * 32 + band) * LDP + gate * HH + j], p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+                    const float* wr = wp + o.f_whh[l][rd] + rr * HH * 128 + rq;   // [rr][k][q]: coalesced over the threads
 #pragma unroll
-                    for (int k = 0; k < HH / 4; ++k) {
-                        const float4 hv = hp4[k];
-                        p0 += wrow[rr][4 * k] * hv.x;
-                        p1 += wrow[rr][4 * k + 1] * hv.y;
-                        p2 += wrow[rr][4 * k + 2] * hv.z;
-                        p3 += wrow[rr][4 * k + 3] * hv.w;
+                    for (int k = 0; k < HH; ++k) Whh[rr][k] = wr[k * 128];
+                }
+            }
+            if (tid < 4 * HH) Hb[tid] = 0.0f;                    // h = 0 for both directions, both buffers
+            if constexpr (4 * HH > kThreads) { if (tid + kThreads < 4 * HH) Hb[tid + kThreads] = 0.0f; }
+            if constexpr (S::XPG) __threadfence_block();
+            __syncthreads();
+            if (l == 0) BE_CLK(5);
+            // next layer's time-LSTM hidden state: fetched now, parked in Hs after the recurrence
+            if (l + 1 < S::NLAY) {
+                const float* hgn = a.lstm + ((size_t)(2 * l + 2) * a.B + b) * (kBands * HH);
+#pragma unroll
+                for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = hgn[i < kBands * HH ? i : kBands * HH - 1]; }
+            }
+            auto xp_at = [&](int s, int rr) -> float {
+                const int band = rd == 0 ? s : kBands - 1 - s;
+                const int col = rgate * HH + (rq >> 2) + 32 * rr;
+                if constexpr (S::XPG) return XPg[(rd * 32 + band) * G4 + col];
+                else return XPl[(rd * 32 + band) * LDP + col];
+            };
+            float xp_next[S::RPT];
+#pragma unroll
+            for (int rr = 0; rr < S::RPT; ++rr) xp_next[rr] = xp_at(0, rr);
+            // One step of both scans (work split: see BShape::KSPLIT).  With KSPLIT a lane reads HH/4 floats of h from LDS
+            // instead of all HH; the quarters are summed across the quad with two DPP adds per gate; lane rgate then finishes
+            // gate rgate.  Either way the four activations of a unit are exchanged with DPP quad broadcasts, ALL four lanes
+            // compute the (identical) cell / hidden update and store it - no exec-masked block, no branch.
+            auto rec_step = [&](int s) {
+                const int band = rd == 0 ? s : kBands - 1 - s;
+                constexpr int Q = S::KSPLIT ? HH / 4 : HH;   // floats of h per lane
+                const float4* hp4 = reinterpret_cast<const float4*>(Hb + (rd * 2 + (s & 1)) * HH + (S::KSPLIT ? rgate * Q : 0));
+                float* hnext = Hb + (rd * 2 + ((s + 1) & 1)) * HH;
+                float xp_cur[S::RPT];
+#pragma unroll
+                for (int rr = 0; rr < S::RPT; ++rr) { xp_cur[rr] = xp_next[rr]; xp_next[rr] = xp_at(s + 1 < kBands ? s + 1 : s, rr); }
+                float4 hq[Q / 4];
+#pragma unroll
+                for (int k = 0; k < Q / 4; ++k) hq[k] = hp4[k];
+#pragma unroll
+                for (int rr = 0; rr < S::RPT; ++rr) {
+                    const int j = (rq >> 2) + 32 * rr;
+                    float mine;
+                    if constexpr (!S::KSPLIT) {
+                        // this lane's gate row over the whole K: two chains of packed FMAs
+                        f32x2 p0 = {0.0f, 0.0f}, p1 = {0.0f, 0.0f};
+                        if constexpr (S::WREG) {
+#pragma unroll
+                            for (int k = 0; k < Q / 4; ++k) {
+                                p0 += f32x2{Whh[rr][4 * k], Whh[rr][4 * k + 1]} * f32x2{hq[k].x, hq[k].y};
+                                p1 += f32x2{Whh[rr][4 * k + 2], Whh[rr][4 * k + 3]} * f32x2{hq[k].z, hq[k].w};
+                            }
+                        } else {
+                            const float4* w4 = reinterpret_cast<const float4*>(wp + o.f_whh[l][rd]) + (size_t)rr * (Q / 4) * 128 + rq;
+#pragma unroll 8
+                            for (int k = 0; k < Q / 4; ++k) {
+                                const float4 wv = w4[(size_t)k * 128];
+                                p0 += f32x2{wv.x, wv.y} * f32x2{hq[k].x, hq[k].y};
+                                p1 += f32x2{wv.z, wv.w} * f32x2{hq[k].z, hq[k].w};
+                            }
+                        }
+                        const f32x2 ps = p0 + p1;
+                        mine = ps.x + ps.y;
+                    } else {
+                    f32x2 p[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) p[g] = f32x2{0.0f, 0.0f};
+                    if constexpr (S::WREG) {
+#pragma unroll
+                        for (int k = 0; k < Q / 4; ++k)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                p[g] += f32x2{Whh[rr][g * Q + 4 * k], Whh[rr][g * Q + 4 * k + 1]} * f32x2{hq[k].x, hq[k].y};
+                                p[g] += f32x2{Whh[rr][g * Q + 4 * k + 2], Whh[rr][g * Q + 4 * k + 3]} * f32x2{hq[k].z, hq[k].w};
+                            }
+                    } else {
+                        // streamed: [rr][gate][k/4][128 threads] float4
+                        const float4* w4 = reinterpret_cast<const float4*>(wp + o.f_whh[l][rd]) + (size_t)rr * 4 * (Q / 4) * 128 + rq;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+#pragma unroll
+                            for (int k = 0; k < Q / 4; ++k) {
+                                const float4 wv = w4[(size_t)(g * (Q / 4) + k) * 128];
+                                p[g] += f32x2{wv.x, wv.y} * f32x2{hq[k].x, hq[k].y};
+                                p[g] += f32x2{wv.z, wv.w} * f32x2{hq[k].z, hq[k].w};
+                            }
                     }
-                    const float pre = (p0 + p1) + (p2 + p3);
-                    // one exp + one rcp for either activation: tanh(x) = 2 s(2x) - 1  (a select between tanh_f and sigmoid_f
-                    // evaluates both: four quarter-rate transcendentals on the recurrence's critical path)
-                    const bool is_g = gate == 2;
-                    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre * (is_g ? -2.8853900817779268f : -1.4426950408889634f)));
-                    const float act = is_g ? 2.0f * sg - 1.0f : sg;
-                    // the 4 gates of a unit sit in one quad: DPP quad_perm broadcasts (no LDS crossbar)
+                    float sg4[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v = p[g].x + p[g].y;
+                        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+                        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+                        sg4[g] = v;
+                    }
+                    mine = rgate == 0 ? sg4[0] : (rgate == 1 ? sg4[1] : (rgate == 2 ? sg4[2] : sg4[3]));
+                    }
+                    const float pre = mine + xp_cur[rr];
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre));
+                    const float act = rgate == 2 ? 2.0f * sg - 1.0f : sg;
                     const int ai = __builtin_bit_cast(int, act);
                     const float ig = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, ai, 0x00, 0xf, 0xf, true));
                     const float fg = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, ai, 0x55, 0xf, 0xf, true));
@@ -325,13 +558,28 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     const float og = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, ai, 0xff, 0xf, 0xf, true));
                     const float cn = fg * cstate[rr] + ig * gg;
                     cstate[rr] = cn;
-                    if (gate == 0) {
-                        const float hn = og * tanh_f(cn);
-                        hnext[j] = hn;
-                        Yf[band * LDY + d * HH + j] = hn;
-                    }
+                    const float hn = og * (2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * cn)) - 1.0f);
+                    hnext[j] = hn;                                  // (the four lanes of the quad store the same value)
+                    Yf[band * LDY + rd * HH + j] = hn;
                 }
                 __syncthreads();
+            };
+            if constexpr (REGW) {
+                // the next layer's weights ride under this latency chain, in three bursts (a wave keeps at most 63 loads in flight)
+                const bool more = l + 1 < S::NLAY;
+                const int ln = more ? l + 1 : l;
+                if (more) fetch_part(I0{}, I3{}, ln, std::false_type{});
+#pragma unroll 1
+                for (int s = 0; s < 10; ++s) rec_step(s);
+                if (more) fetch_part(I1{}, I3{}, ln, std::false_type{});
+#pragma unroll 1
+                for (int s = 10; s < 20; ++s) rec_step(s);
+                if (more) fetch_part(I2{}, I3{}, ln, std::false_type{});
+#pragma unroll 1
+                for (int s = 20; s < kBands; ++s) rec_step(s);
+            } else {
+#pragma unroll 1
+                for (int s = 0; s < kBands; ++s) rec_step(s);
             }
             if (l == 0) BE_CLK(6);
             {
@@ -341,11 +589,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 for (int it = wave; it < NITEM; it += kWaves) {
                     const int mt = it / S::NTC, nt = it - mt * S::NTC;
                     f32x4 acc[1][1];
-                    const float bv = wb.at16_g(o.ffc_b[l] + nt * 16);
+                    float bv;
+                    if constexpr (REGW) bv = Wf2b; else bv = wb.at16_g(o.ffc_b[l] + nt * 16);
                     acc[0][0] = f32x4{bv, bv, bv, bv};
                     const float* ya = Yf + (16 * mt + li) * LDY + lg;
-                    mma_panel<1, 1, 2 * HH / 4>(acc, [&](int, int ks) { return ya[4 * ks]; },
-                                                [&](int, int ks) { return wb.at_g(o.ffc_w[l] + (nt * (2 * HH / 4) + ks) * 64); }, NoSide{});
+                    mma_panel<1, 1, 2 * KSH, REGW ? 3 : 8>(acc, [&](int, int ks) { return ya[4 * ks]; },
+                                            [&](int, int ks) {
+                                                if constexpr (REGW) return Wf2[ks];
+                                                else return wb.at_g(o.ffc_w[l] + (nt * (2 * KSH) + ks) * 64);
+                                            }, NoSide{});
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * mt + 4 * lg + r;
@@ -353,59 +605,170 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     }
                 }
             }
+            if (l + 1 < S::NLAY) {
+                // park the next layer's hidden state / hand the prefetched W_hh and fc_freq sets over
+#pragma unroll
+                for (int q = 0; q < HPT; ++q) {
+                    const int i = tid + q * kThreads, r = i / HH;
+                    if (i < kBands * HH) Hs[r * LDH + (i - r * HH)] = hpre[q];
+                }
+                if constexpr (REGW) {
+#pragma unroll
+                    for (int k = 0; k < HH; ++k) Whh[0][k] = Whhn[k];
+#pragma unroll
+                    for (int k = 0; k < NFC2; ++k) Wf2[k] = Wf2n[k];
+                    Wf2b = Wf2bn;
+                }
+            }
             __syncthreads();
+            dump(4 + 2 * l, X, LDX);
             if (l == 0) BE_CLK(7);
         }
 
         BE_CLK(8);
         // ============================ mask decoder (MaskDecoder.forward, :225-246) ============================
-        for (int i = tid; i < 2 * kBands * 4 * C; i += kThreads) {
-            const int kind = i / (kBands * 4 * C), rem = i - kind * (kBands * 4 * C);
-            const int bb = rem / (4 * C), oo = rem - bb * (4 * C);
-            const float* w = wp + o.m_w1[kind] + (bb * C) * (4 * C) + oo;
-            float acc = wp[o.m_b1[kind] + bb * 4 * C + oo];
-#pragma unroll 16
-            for (int k = 0; k < C; ++k) acc += w[k * 4 * C] * X[bb * LDX + k];
-            H1[i] = tanh_f(acc);
+        // Every workgroup streams the same 780 KB (xt) of MLP weights once per frame.  Started together, the workgroups of
+        // an XCD would all ask its L2 for the same lines at the same time (one channel busy, fifteen idle): each workgroup
+        // therefore walks the rows in its own rotation.  Rows are software-pipelined D rows ahead of the FMAs (register ring).
+        // layer 1: thread <-> output (kind, band, o): a wave covers 64 consecutive outputs of ONE band (4C >= 64), so the
+        // X reads are LDS broadcasts
+        {
+            constexpr int NOUT = 2 * kBands * 4 * C, ROUNDS = (NOUT + kThreads - 1) / kThreads, R4 = C / 4;
+            constexpr int D = R4 <= 4 ? 8 : (R4 <= 8 ? 4 : 2);      // rows in flight: under load the L2 round trip is ~1 us, the ring holds 32 KB per wave
+            const int rot = (int)(blockIdx.x >> 3) % ROUNDS;
+            auto out_of = [&](int r) { int rr = r + rot; rr = rr >= ROUNDS ? rr - ROUNDS : rr; return tid + rr * kThreads; };
+            auto load_row = [&](int r, float4 (&wv)[R4], float& bias) {
+                if (r < ROUNDS) {
+                    const int i = out_of(r), ii = i < NOUT ? i : NOUT - 1;
+                    const int kind = ii / (kBands * 4 * C), rem = ii - kind * (kBands * 4 * C);
+                    const int bb = rem / (4 * C), oo = rem - bb * (4 * C);
+                    const float4* w4 = reinterpret_cast<const float4*>(wp + o.m_w1[kind]) + (size_t)bb * R4 * (4 * C) + oo;   // [band][k/4][o] float4
+#pragma unroll
+                    for (int k = 0; k < R4; ++k) wv[k] = w4[k * (4 * C)];
+                    bias = wp[o.m_b1[kind] + rem];
+                }
+            };
+            float4 ring[D][R4];
+            float rb[D];
+#pragma unroll
+            for (int jj = 0; jj < D; ++jj) { rb[jj] = 0.0f; load_row(jj, ring[jj], rb[jj]); }
+#pragma unroll 1
+            for (int g = 0; g * D < ROUNDS; ++g) {
+#pragma unroll
+                for (int jj = 0; jj < D; ++jj) {
+                    const int r = g * D + jj;
+                    if (r < ROUNDS) {
+                        const int i = out_of(r), ii = i < NOUT ? i : NOUT - 1;
+                        const int kind = ii / (kBands * 4 * C), rem = ii - kind * (kBands * 4 * C);
+                        const int bb = rem / (4 * C), oo = rem - bb * (4 * C);
+                        const float* xr = X + bb * LDX;
+                        float acc0 = rb[jj], acc1 = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < R4; ++k) {
+                            acc0 += ring[jj][k].x * xr[4 * k] + ring[jj][k].z * xr[4 * k + 2];
+                            acc1 += ring[jj][k].y * xr[4 * k + 1] + ring[jj][k].w * xr[4 * k + 3];
+                        }
+                        if (i < NOUT) H1[(kind * kBands + bb) * LDH1 + oo] = tanh_f(acc0 + acc1);
+                    }
+                    load_row(r + D, ring[jj], rb[jj]);
+                }
+            }
         }
         __syncthreads();
         BE_CLK(9);
         {
-            constexpr int R = 4 * kBins;            // rows of the second layers (1028)
-            // item = (bin f, kind): GLU outputs (re, im) of that MLP for that bin -> MR[f][kind*2 + ri]  (reuses XP)
-            float* MR = XP;
-            for (int it = tid; it < 2 * kBins; it += kThreads) {
-                const int kind = it / kBins, f = it - kind * kBins;
-                int s0, sub;
-                const int bb = band_of(f, s0, sub);
-                const float* h1 = H1 + (kind * kBands + bb) * 4 * C;
-                const float* w2 = wp + o.m_w2[kind];
-                const int rowA0 = 4 * s0 + (f - s0) * 2, rowB0 = rowA0 + 2 * sub;
-                float va0 = wp[o.m_b2[kind] + rowA0], va1 = wp[o.m_b2[kind] + rowA0 + 1];
-                float vb0 = wp[o.m_b2[kind] + rowB0], vb1 = wp[o.m_b2[kind] + rowB0 + 1];
-#pragma unroll 16
-                for (int k = 0; k < 4 * C; ++k) {
-                    const float hv = h1[k];
-                    va0 += w2[k * R + rowA0] * hv;
-                    va1 += w2[k * R + rowA0 + 1] * hv;
-                    vb0 += w2[k * R + rowB0] * hv;
-                    vb1 += w2[k * R + rowB0 + 1] * hv;
+            // layer 2: thread <-> output row (kind, r), K = 4C in chunks of 16 sixteen-byte loads; pipeline items are (row, chunk)
+            // pairs, two items ahead; the hidden vector of the row's band is read from LDS (bands sit 4 banks apart)
+            constexpr int K4 = 4 * C / 4;          // 16-byte loads per row
+            constexpr int CH = K4 < 16 ? K4 : 16;  // loads per chunk (C = 64: a row is 4 chunks)
+            constexpr int NCH = K4 / CH;
+            constexpr int NROW = 2 * kMlpRows, ROUNDS = (NROW + kThreads - 1) / kThreads, NIT = ROUNDS * NCH, D = 3;
+            const int* row_band = reinterpret_cast<const int*>(wp + o.row_band);
+            const int rot = (int)(blockIdx.x >> 3) % ROUNDS;
+            auto out_of = [&](int r) { int rr = r + rot; rr = rr >= ROUNDS ? rr - ROUNDS : rr; return tid + rr * kThreads; };
+            // the bins' row tables for the GLU below: fetched now (a dependent load there would be exposed)
+            constexpr int FPT = (kBins + kThreads - 1) / kThreads;
+            int bra[FPT], brg[FPT];
+            {
+                const int* bin_row = reinterpret_cast<const int*>(wp + o.bin_row);
+                const int* bin_2sub = reinterpret_cast<const int*>(wp + o.bin_2sub);
+#pragma unroll
+                for (int q = 0; q < FPT; ++q) {
+                    const int f = tid + q * kThreads < kBins ? tid + q * kThreads : kBins - 1;
+                    bra[q] = bin_row[f];
+                    brg[q] = bin_2sub[f];
                 }
-                MR[f * 4 + kind * 2 + 0] = va0 * (1.0f / (1.0f + expf(-vb0)));      // GLU(dim=1)
-                MR[f * 4 + kind * 2 + 1] = va1 * (1.0f / (1.0f + expf(-vb1)));
+            }
+            auto load_item = [&](int it, float4 (&wv)[CH], int& band, float& bias) {
+                if (it < NIT) {
+                    const int r = it / NCH, ch = it - r * NCH;
+                    const int i = out_of(r), ii = i < NROW ? i : NROW - 1;
+                    const int kind = ii / kMlpRows, row = ii - kind * kMlpRows;
+                    const float4* w4 = reinterpret_cast<const float4*>(wp + o.m_w2[kind]) + (size_t)(ch * CH) * kMlpRows + row;   // [k/4][row] float4
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) wv[k] = w4[(size_t)k * kMlpRows];
+                    band = row_band[row];                  // (the row's band and bias ride along: no dependent loads at compute time)
+                    bias = wp[o.m_b2[kind] + row];
+                }
+            };
+            float4 ring[D][CH];
+            int rbnd[D];
+            float rbias[D];
+#pragma unroll
+            for (int jj = 0; jj < D; ++jj) { rbnd[jj] = 0; rbias[jj] = 0.0f; load_item(jj, ring[jj], rbnd[jj], rbias[jj]); }
+            float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll 1
+            for (int g = 0; g * D < NIT; ++g) {
+#pragma unroll
+                for (int jj = 0; jj < D; ++jj) {
+                    const int it = g * D + jj;
+                    if (it < NIT) {
+                        const int r = it / NCH, ch = it - r * NCH;
+                        const int i = out_of(r), ii = i < NROW ? i : NROW - 1;
+                        const int kind = ii / kMlpRows, row = ii - kind * kMlpRows;
+                        const float4* h4 = reinterpret_cast<const float4*>(H1 + (kind * kBands + rbnd[jj]) * LDH1) + ch * CH;
+                        if (ch == 0) { acc0 = rbias[jj]; acc1 = 0.0f; }
+#pragma unroll
+                        for (int k = 0; k < CH; ++k) {
+                            const float4 hv = h4[k];
+                            acc0 += ring[jj][k].x * hv.x + ring[jj][k].z * hv.z;
+                            acc1 += ring[jj][k].y * hv.y + ring[jj][k].w * hv.w;
+                        }
+                        if (ch == NCH - 1 && i < NROW) PRE[i] = acc0 + acc1;
+                    }
+                    load_item(it + D, ring[jj], rbnd[jj], rbias[jj]);
+                }
             }
             __syncthreads();
+            // GLU(dim=1) per band: rows [0, 2 sub) are values, rows [2 sub, 4 sub) their gates; then spec * mask + residual (:393-401)
             float* spo = mode == FE_MODE_SPEC ? a.spec_out + (size_t)b * kBins * aT * 2 : nullptr;
             float* sph = mode == FE_MODE_OFFLINE ? a.spec_out + (size_t)b * kBins * aT * 2 : nullptr;
-            for (int f = tid; f < kBins; f += kThreads) {
+#pragma unroll
+            for (int q = 0; q < FPT; ++q) {
+                const int f = tid + q * kThreads;
+                if (f >= kBins) break;
+                const int ra = bra[q], rg = ra + brg[q];
+                float mr[4];
+#pragma unroll
+                for (int kind = 0; kind < 2; ++kind)
+#pragma unroll
+                    for (int ri = 0; ri < 2; ++ri)
+                        mr[kind * 2 + ri] = PRE[kind * kMlpRows + ra + ri] * sigmoid_f(PRE[kind * kMlpRows + rg + ri]);
+                if constexpr (DBG) {
+                    float* dst = dbg + BDebugLayout<S>::offset(3 + 2 * S::NLAY) + 4 * f;
+                    dst[0] = mr[0]; dst[1] = mr[1]; dst[2] = mr[2]; dst[3] = mr[3];
+                }
                 const float xr = sp[2 * f], xi = sp[2 * f + 1];
-                const float* mr = MR + f * 4;
-                float yr = xr * mr[0] - xi * mr[1] + mr[2];             // spec * mask + residual (:393-401)
+                float yr = xr * mr[0] - xi * mr[1] + mr[2];
                 float yi = xr * mr[1] + xi * mr[0] + mr[3];
                 if (sph != nullptr) { sph[((size_t)f * aT + t) * 2] = yr; sph[((size_t)f * aT + t) * 2 + 1] = yi; }
                 const float g = pow_f(sqrtf(yr * yr + yi * yi), 1.0f / a.compression - 1.0f);
                 yr *= g;
                 yi *= g;
+                if constexpr (DBG) {
+                    float* dst = dbg + BDebugLayout<S>::offset(4 + 2 * S::NLAY) + 2 * f;
+                    dst[0] = yr; dst[1] = yi;
+                }
                 if (mode == FE_MODE_SPEC) {
                     spo[((size_t)f * aT + t) * 2] = yr;
                     spo[((size_t)f * aT + t) * 2 + 1] = yi;
@@ -461,40 +824,60 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         }
         BE_CLK(11);
     }
+    b += gridDim.x;
+    } while (b < a.B);
 }
 
 struct BImpl {
     int C, NLAY, HOP;
     size_t lds_bytes;
-    void (*launch)(const BArgs&, hipStream_t, hipError_t*);
+    size_t xp_floats;         // global scratch per workgroup (0: the input projections stay in LDS)
+    size_t dbg_floats;
+    int dbg_stages;
+    bool whh_regs;            // W_hh packing: [rr][k'][128] floats (register shapes) or [rr][k'/4][128] float4 (streamed)
+    bool ksplit;              // thread <-> (unit, K quarter) holding all four gates (BShape::KSPLIT) or (unit, gate) over the whole K
+    void (*launch)(const BArgs&, int max_wgs, hipStream_t, hipError_t*);
+    void (*dbg_stage)(int, int*, int*, size_t*);
 };
 
-template <class S, bool HOT, bool PROF>
-void blaunch_one(const BArgs& a, hipStream_t st, hipError_t* err) {
+template <class S, bool HOT, bool PROF, bool DBG>
+void blaunch_one(const BArgs& a, int grid, hipStream_t st, hipError_t* err) {
     static std::atomic<bool> attr_set[64];           // per device (see fe_impl.h::launch_one)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev].load(std::memory_order_relaxed)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bsrnn_frame_kernel<S, HOT, PROF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bsrnn_frame_kernel<S, HOT, PROF, DBG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)BLds<S>::BYTES);
         if (e != hipSuccess) { *err = e; return; }
         attr_set[dev].store(true, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((bsrnn_frame_kernel<S, HOT, PROF>), dim3(a.B), dim3(kThreads), BLds<S>::BYTES, st, a);
+    hipLaunchKernelGGL((bsrnn_frame_kernel<S, HOT, PROF, DBG>), dim3(grid), dim3(kThreads), BLds<S>::BYTES, st, a);
     *err = hipGetLastError();
 }
 
 template <class S>
-void blaunch_impl(const BArgs& a, hipStream_t st, hipError_t* err) {
-    if (a.clk != nullptr) {                                                          // fe_profile_step
-        if (a.mode == FE_MODE_STREAM && a.T == 1) blaunch_one<S, true, true>(a, st, err);
-        else blaunch_one<S, false, true>(a, st, err);
+void blaunch_impl(const BArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
+    const int grid = a.B < max_wgs ? a.B : max_wgs;      // more streams than CUs: persistent workgroups walk b, b + grid, ...
+    if (a.dbg != nullptr) blaunch_one<S, false, false, true>(a, grid, st, err);                 // fe_debug_step
+    else if (a.clk != nullptr) {                                                                // fe_profile_step
+        if (a.mode == FE_MODE_STREAM && a.T == 1) blaunch_one<S, true, true, false>(a, grid, st, err);
+        else blaunch_one<S, false, true, false>(a, grid, st, err);
     }
-    else if (a.mode == FE_MODE_STREAM && a.T == 1) blaunch_one<S, true, false>(a, st, err);
-    else blaunch_one<S, false, false>(a, st, err);
+    else if (a.mode == FE_MODE_STREAM && a.T == 1) blaunch_one<S, true, false, false>(a, grid, st, err);
+    else blaunch_one<S, false, false, false>(a, grid, st, err);
 }
 
 template <class S>
-BImpl make_bimpl() { return BImpl{S::C, S::NLAY, S::HOP, BLds<S>::BYTES, &blaunch_impl<S>}; }
+void bdbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
+    *rows = BDebugLayout<S>::rows(s);
+    *cols = BDebugLayout<S>::cols(s);
+    *off = BDebugLayout<S>::offset(s);
+}
+
+template <class S>
+BImpl make_bimpl() {
+    return BImpl{S::C, S::NLAY, S::HOP, BLds<S>::BYTES, S::XPG ? (size_t)2 * 32 * S::G4 : (size_t)0,
+                 BDebugLayout<S>::total(), BDebugLayout<S>::n_stages, S::WREG, S::KSPLIT, &blaunch_impl<S>, &bdbg_stage_impl<S>};
+}
 
 }  // namespace fe

@@ -405,6 +405,10 @@ int create_bsrnn(const fe_config* cfg, fe_handle** out) {
     h->bimpl = bi;
     h->d = Dims{cfg->channels, 0, 0, 0, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, cfg->n_fft / 2, 0, 0, {0}};
     if (hipGetDevice(&h->device) != hipSuccess) h->device = -1;
+    else {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->max_wgs = cus;
+    }
     build_sections_bsrnn(h);
     build_tables(h);
     *out = h;
@@ -413,6 +417,7 @@ int create_bsrnn(const fe_config* cfg, fe_handle** out) {
 
 int pack_weights_bsrnn(fe_handle* h, const std::vector<float>& blob, std::vector<float>* out) {
     const int C = h->cfg.channels, L = h->cfg.rf_blocks, HH = 2 * C, G4 = 4 * HH, R = 4 * 257;
+    const bool whh_regs = h->bimpl->whh_regs;
     fe::BOffsets& o = h->boff;
     std::vector<float> buf;
     auto alloc = [&](size_t n) { size_t off = (buf.size() + 63) & ~(size_t)63; buf.resize(off + n, 0.0f); return (int)off; };
@@ -428,28 +433,34 @@ int pack_weights_bsrnn(fe_handle* h, const std::vector<float>& blob, std::vector
                 }
         return off;
     };
+    // LSTM gate rows (order i, f, g, o) are packed pre-scaled: with pre' = s_g * pre the kernel evaluates every gate as
+    // rcp(1 + exp2(pre')): sigma(v) for s = -log2(e), and tanh(v) = 2 rcp(1 + exp2(-2 log2(e) v)) - 1 for the cell gate g
+    const double kL2E = 1.4426950408889634;
+    auto gscale = [&](int row) { return (float)((row / HH) == 2 ? -2.0 * kL2E : -kL2E); };
     char nm[160];
-    o.bs_b = alloc(31 * C);
-    for (int b = 0; b < 31; ++b) {
-        snprintf(nm, sizeof nm, "band_split.fc.%d.weight", b);
-        const float* w = S(nm);                                   // (C, 2sub)
-        const int k2 = 2 * kSub[b];
-        o.bs_w[b] = alloc((size_t)k2 * C);
-        for (int k = 0; k < k2; ++k)
-            for (int c = 0; c < C; ++c) buf[o.bs_w[b] + k * C + c] = w[c * k2 + k];
-        snprintf(nm, sizeof nm, "band_split.fc.%d.bias", b);
-        memcpy(&buf[o.bs_b + b * C], S(nm), C * sizeof(float));
+    {   // band split: [k/4][band*C + c] float4 - thread (band, c) reads its zero-padded row as 16-byte loads coalesced over the threads
+        o.bs_w = alloc((size_t)31 * C * fe::kBsKP);
+        o.bs_b = alloc(31 * C);
+        for (int b = 0; b < 31; ++b) {
+            snprintf(nm, sizeof nm, "band_split.fc.%d.weight", b);
+            const float* w = S(nm);                                   // (C, 2sub)
+            const int k2 = 2 * kSub[b];
+            for (int c = 0; c < C; ++c)
+                for (int k = 0; k < k2; ++k) buf[o.bs_w + (((size_t)(k / 4) * 31 * C) + b * C + c) * 4 + (k & 3)] = w[c * k2 + k];
+            snprintf(nm, sizeof nm, "band_split.fc.%d.bias", b);
+            memcpy(&buf[o.bs_b + b * C], S(nm), C * sizeof(float));
+        }
     }
     for (int l = 0; l < L; ++l) {
         auto key = [&](const char* fmt) { snprintf(nm, sizeof nm, fmt, l); return std::string(nm); };
         {   // time LSTM: K = [x (C) | h (HH)], N = 4HH gate rows (i,f,g,o)
             const float* wih = S(key("rnn_time.%d.weight_ih"));
             const float* whh = S(key("rnn_time.%d.weight_hh"));
-            o.t_w[l] = pack_b(C + HH, G4, [&](int k, int n) { return k < C ? wih[n * C + k] : whh[n * HH + (k - C)]; });
+            o.t_w[l] = pack_b(C + HH, G4, [&](int k, int n) { return gscale(n) * (k < C ? wih[n * C + k] : whh[n * HH + (k - C)]); });
             const float* bi = S(key("rnn_time.%d.bias_ih"));
             const float* bh = S(key("rnn_time.%d.bias_hh"));
             o.t_b[l] = alloc(G4);
-            for (int i = 0; i < G4; ++i) buf[o.t_b[l] + i] = bi[i] + bh[i];
+            for (int i = 0; i < G4; ++i) buf[o.t_b[l] + i] = gscale(i) * (bi[i] + bh[i]);
         }
         {
             const float* w = S(key("fc_time.%d.weight"));         // (C, HH)
@@ -461,20 +472,28 @@ int pack_weights_bsrnn(fe_handle* h, const std::vector<float>& blob, std::vector
             const char* sfx = d ? "_reverse" : "";
             auto keyd = [&](const char* stem) { snprintf(nm, sizeof nm, "rnn_freq.%d.%s_l0%s", l, stem, sfx); return std::string(nm); };
             const float* wih = S(keyd("weight_ih"));
-            o.f_wih[l][d] = pack_b(C, G4, [&](int k, int n) { return wih[n * C + k]; });
+            o.f_wih[l][d] = pack_b(C, G4, [&](int k, int n) { return gscale(n) * wih[n * C + k]; });
             const float* bi = S(keyd("bias_ih"));
             const float* bh = S(keyd("bias_hh"));
             o.f_b[l][d] = alloc(G4);
-            for (int i = 0; i < G4; ++i) buf[o.f_b[l][d] + i] = bi[i] + bh[i];
-            {   // recurrence weights in thread order: thread q = 4*(j%32) + gate holds rows (gate, j = q/4 + 32*rr)
+            for (int i = 0; i < G4; ++i) buf[o.f_b[l][d] + i] = gscale(i) * (bi[i] + bh[i]);
+            {   // recurrence weights in thread order.  Thread t (0..127) of a direction = 4 u + q, hidden unit u (+ 32 rr).
+                // KSPLIT shapes: q = K-quarter; the thread holds, for all four gates g, W_hh[g*HH + u + 32 rr][q*HH/4 + kk] at
+                //   [rr][g*HH/4 + kk][t].  Otherwise q = gate: it holds row W_hh[q*HH + u + 32 rr][k] at [rr][k][t].
+                // (streamed shapes: the k index in float4 groups)
                 const float* whh = S(keyd("weight_hh"));      // (4HH, HH), gate-major rows
                 o.f_whh[l][d] = alloc((size_t)G4 * HH);
-                const int RPT = G4 / 128;
+                const int RPT = HH / 32, Q = HH / 4;
+                const bool ksplit = h->bimpl->ksplit;
                 for (int rr = 0; rr < RPT; ++rr)
-                    for (int k = 0; k < HH; ++k)
-                        for (int q = 0; q < 128; ++q) {
-                            const int gate = q & 3, j = (q >> 2) + 32 * rr;
-                            buf[o.f_whh[l][d] + ((size_t)rr * HH + k) * 128 + q] = whh[(size_t)(gate * HH + j) * HH + k];
+                    for (int kp = 0; kp < HH; ++kp)
+                        for (int t = 0; t < 128; ++t) {
+                            const int u = (t >> 2) + 32 * rr, q = t & 3;
+                            const int row = ksplit ? (kp / Q) * HH + u : q * HH + u;
+                            const int k = ksplit ? q * Q + (kp % Q) : kp;
+                            const float v = gscale(row) * whh[(size_t)row * HH + k];
+                            if (whh_regs) buf[o.f_whh[l][d] + ((size_t)rr * HH + kp) * 128 + t] = v;
+                            else buf[o.f_whh[l][d] + ((((size_t)rr * (HH / 4)) + kp / 4) * 128 + t) * 4 + (kp & 3)] = v;
                         }
             }
         }
@@ -487,26 +506,48 @@ int pack_weights_bsrnn(fe_handle* h, const std::vector<float>& blob, std::vector
     }
     const char* kinds[2] = {"mlp_mask", "mlp_residual"};
     for (int kind = 0; kind < 2; ++kind) {
-        o.m_w1[kind] = alloc((size_t)31 * C * 4 * C);
+        o.m_w1[kind] = alloc((size_t)31 * 4 * C * C);      // [band][k/4][o] float4
         o.m_b1[kind] = alloc((size_t)31 * 4 * C);
-        o.m_w2[kind] = alloc((size_t)4 * C * R);
+        o.m_w2[kind] = alloc((size_t)R * 4 * C);           // [k/4][global row] float4
         o.m_b2[kind] = alloc(R);
         int row0 = 0;
         for (int b = 0; b < 31; ++b) {
             snprintf(nm, sizeof nm, "mask_decoder.%s.%d.0.weight", kinds[kind], b);
-            const float* w1 = S(nm);                              // (4C, C)
-            for (int k = 0; k < C; ++k)
-                for (int oo = 0; oo < 4 * C; ++oo) buf[o.m_w1[kind] + ((size_t)b * C + k) * 4 * C + oo] = w1[oo * C + k];
+            {
+                const float* w1 = S(nm);                                  // (4C, C) -> [k/4][o] float4 per band
+                for (int oo = 0; oo < 4 * C; ++oo)
+                    for (int k = 0; k < C; ++k)
+                        buf[o.m_w1[kind] + (((size_t)b * (C / 4) + k / 4) * (4 * C) + oo) * 4 + (k & 3)] = w1[oo * C + k];
+            }
             snprintf(nm, sizeof nm, "mask_decoder.%s.%d.0.bias", kinds[kind], b);
             memcpy(&buf[o.m_b1[kind] + b * 4 * C], S(nm), 4 * C * sizeof(float));
             snprintf(nm, sizeof nm, "mask_decoder.%s.%d.2.weight", kinds[kind], b);
-            const float* w2 = S(nm);                              // (4sub, 4C)
             const int rows = 4 * kSub[b];
-            for (int r = 0; r < rows; ++r)
-                for (int k = 0; k < 4 * C; ++k) buf[o.m_w2[kind] + (size_t)k * R + row0 + r] = w2[r * 4 * C + k];
+            {
+                const float* w2 = S(nm);                                  // (4sub, 4C) -> [k/4][global row] float4
+                for (int r = 0; r < rows; ++r)
+                    for (int k = 0; k < 4 * C; ++k)
+                        buf[o.m_w2[kind] + ((size_t)(k / 4) * R + row0 + r) * 4 + (k & 3)] = w2[r * 4 * C + k];
+            }
             snprintf(nm, sizeof nm, "mask_decoder.%s.%d.2.bias", kinds[kind], b);
             memcpy(&buf[o.m_b2[kind] + row0], S(nm), rows * sizeof(float));
             row0 += rows;
+        }
+    }
+    {   // index tables (ints stored in the float buffer): band of a layer-2 row; a bin's first value row and 2*sub of its band
+        o.row_band = alloc(R);
+        o.bin_row = alloc(257);
+        o.bin_2sub = alloc(257);
+        int row0 = 0, f0 = 0;
+        for (int b = 0; b < 31; ++b) {
+            for (int r = 0; r < 4 * kSub[b]; ++r) { const int v = b; memcpy(&buf[o.row_band + row0 + r], &v, 4); }
+            for (int f = 0; f < kSub[b]; ++f) {
+                const int ra = 4 * f0 + 2 * f, s2 = 2 * kSub[b];
+                memcpy(&buf[o.bin_row + f0 + f], &ra, 4);
+                memcpy(&buf[o.bin_2sub + f0 + f], &s2, 4);
+            }
+            row0 += 4 * kSub[b];
+            f0 += kSub[b];
         }
     }
     o.window = alloc(h->window.size()); memcpy(&buf[o.window], h->window.data(), h->window.size() * sizeof(float));
@@ -522,6 +563,7 @@ size_t bsrnn_lstm_floats(const fe_handle* h, int B) { return (size_t)2 * h->cfg.
 
 fe::BArgs bsrnn_args(fe_handle* h, int B, int T) {
     fe::BArgs a{};
+    a.xp_scratch = h->skip_dev;
     a.wp = h->packed_dev;
     a.off = h->boff;
     a.B = B;
@@ -532,7 +574,7 @@ fe::BArgs bsrnn_args(fe_handle* h, int B, int T) {
 
 int launch_bsrnn(fe_handle* h, const fe::BArgs& a, void* stream) {
     hipError_t e = hipSuccess;
-    h->bimpl->launch(a, (hipStream_t)stream, &e);
+    h->bimpl->launch(a, h->max_wgs, (hipStream_t)stream, &e);
     if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return FE_OK;
 }
@@ -548,9 +590,10 @@ int check_ready(const fe_handle* h) {
 // the compute calls (they can be captured into HIP graphs).  The slots belong to the handle: launches of one handle
 // must be stream-ordered (one stream, or event-ordered streams); concurrent launches need one handle each.
 int ensure_scratch(fe_handle* h, int) {
-    if (h->impl->skip_floats == 0 || h->skip_dev) return FE_OK;
-    FE_HIP_CHECK(hipMalloc(&h->skip_dev, (size_t)h->max_wgs * h->impl->skip_floats * sizeof(float)));
-    FE_HIP_CHECK(hipMemset(h->skip_dev, 0, (size_t)h->max_wgs * h->impl->skip_floats * sizeof(float)));
+    const size_t per_wg = h->bimpl ? h->bimpl->xp_floats : h->impl->skip_floats;     // (BSRNN: band-LSTM input projections of the C = 64 shape)
+    if (per_wg == 0 || h->skip_dev) return FE_OK;
+    FE_HIP_CHECK(hipMalloc(&h->skip_dev, (size_t)h->max_wgs * per_wg * sizeof(float)));
+    FE_HIP_CHECK(hipMemset(h->skip_dev, 0, (size_t)h->max_wgs * per_wg * sizeof(float)));
     h->skip_streams = h->max_wgs;
     return FE_OK;
 }
@@ -649,7 +692,8 @@ int fe_load_weights(fe_handle* h, const float* blob_dev, size_t nfloats, void* s
     FE_HIP_CHECK(hipMalloc(&h->packed_dev, packed.size() * sizeof(float)));
     FE_HIP_CHECK(hipMemcpyAsync(h->packed_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, st));
     FE_HIP_CHECK(hipStreamSynchronize(st));
-    if (h->impl) { rc = ensure_scratch(h, 0); if (rc != FE_OK) return rc; }
+    rc = ensure_scratch(h, 0);
+    if (rc != FE_OK) return rc;
     h->loaded = true;
     return FE_OK;
 }
@@ -676,9 +720,10 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
     if (in_stride < (size_t)T * d.HOP && B > 1) return fail(FE_ERR_INVALID_ARG, "in_stride %zu < T*H", in_stride);
     if (out_stride < (size_t)T * d.HOP && B > 1) return fail(FE_ERR_INVALID_ARG, "out_stride %zu < T*H", out_stride);
     if (h->bimpl) {
-        if (dbg) return fail(FE_ERR_UNSUPPORTED_CONFIG, "debug dumps are not built for BSRNN");
         fe::BArgs ba = bsrnn_args(h, B, T);
         ba.clk = clk;
+        ba.dbg = dbg;
+        ba.dbg_stride = h->bimpl->dbg_floats;
         const size_t ovl_b = (size_t)(d.NFFT - d.HOP);
         ba.mode = fe::FE_MODE_STREAM;
         ba.wav_in = wav_in; ba.wav_out = wav_out; ba.in_stride = in_stride; ba.out_stride = out_stride;
@@ -913,12 +958,29 @@ double fe_flops_per_frame(const fe_handle* h) {
     return 2.0 * m + 2.0 * 2.5 * d.NFFT * std::log2((double)d.NFFT);
 }
 
-int fe_debug_stages(const fe_handle* h) { return (h && h->impl) ? h->impl->dbg_stages : 0; }
-size_t fe_debug_floats(const fe_handle* h) { return (h && h->impl) ? h->impl->dbg_floats : 0; }
+int fe_debug_stages(const fe_handle* h) { return !h ? 0 : (h->bimpl ? h->bimpl->dbg_stages : (h->impl ? h->impl->dbg_stages : 0)); }
+size_t fe_debug_floats(const fe_handle* h) { return !h ? 0 : (h->bimpl ? h->bimpl->dbg_floats : (h->impl ? h->impl->dbg_floats : 0)); }
 
 int fe_debug_stage(const fe_handle* h, int idx, const char** name, int* rows, int* cols, size_t* offset_floats) {
-    if (!h || !h->impl || idx < 0 || idx >= h->impl->dbg_stages) return fail(FE_ERR_INVALID_ARG, "stage index %d", idx);
+    if (!h || idx < 0 || idx >= fe_debug_stages(h)) return fail(FE_ERR_INVALID_ARG, "stage index %d", idx);
     static thread_local std::string nm;
+    if (h->bimpl) {   // spec_in, compressed, band_split, (layer.l.time, layer.l.freq)..., mask_mlp, spec_out
+        const int L = h->cfg.rf_blocks;
+        char bufn[64];
+        if (idx == 0) nm = "spec_in";
+        else if (idx == 1) nm = "compressed";
+        else if (idx == 2) nm = "band_split";
+        else if (idx < 3 + 2 * L) { snprintf(bufn, sizeof bufn, (idx - 3) % 2 == 0 ? "layer.%d.time" : "layer.%d.freq", (idx - 3) / 2); nm = bufn; }
+        else if (idx == 3 + 2 * L) nm = "mask_mlp";
+        else nm = "spec_out";
+        int r, c; size_t off;
+        h->bimpl->dbg_stage(idx, &r, &c, &off);
+        if (name) *name = nm.c_str();
+        if (rows) *rows = r;
+        if (cols) *cols = c;
+        if (offset_floats) *offset_floats = off;
+        return FE_OK;
+    }
     const Dims& d = h->d;
     char buf[64];
     int s = idx;

@@ -265,6 +265,8 @@ class BSRNNOracle:
                 taps[f"layer.{l}.freq"] = x.copy()
         xd = x.transpose(1, 2, 3, 0)                       # [B,31,C,T]
         mask, res = self.mask_decoder(xd)
+        if taps is not None:
+            taps["mask_mlp"] = np.concatenate([mask, res], axis=3)      # [B,257,T,4]: mask (re, im), residual (re, im)
         y = np.stack([spec[..., 0] * mask[..., 0] - spec[..., 1] * mask[..., 1],
                       spec[..., 0] * mask[..., 1] + spec[..., 1] * mask[..., 0]], axis=3) + res
         return y.astype(self.dtype), cache_out

@@ -477,7 +477,32 @@ def _bsrnn(name, cls="ONNXModel"):
     return m, orc, cfg, sr, seed
 
 
-@pytest.mark.parametrize("name", ["bsrnn_xxt", "bsrnn_xt"])
+@pytest.mark.parametrize("name", ["bsrnn_xxt", "bsrnn_xt", "bsrnn_t", "bsrnn_s"])
+def test_bsrnn_every_stage_matches_oracle(name):
+    """Per-stage activations (fe_debug_step): band split, each layer's time- / band-LSTM half, the mask MLPs."""
+    m, orc, cfg, sr, seed = _bsrnn(name)
+    eng = m.engine
+    B, hops, H = 3, 3, cfg.hop_size
+    x = make_input(B, hops * H, 515, sr)
+    xd = torch.from_numpy(x).to(_dev())
+    state = eng.new_state(B)
+    caches = orc.initialize_cache(B)
+    names = [s_[0] for s_ in eng.debug_stages()]
+    assert names == ["spec_in", "compressed", "band_split"] + [f"layer.{l}.{h}" for l in range(cfg.num_layers) for h in ("time", "freq")] + ["mask_mlp", "spec_out"]
+    for t in range(hops):
+        taps = {}
+        o_ref, *caches = orc.step(x[:, t * H:(t + 1) * H], *caches, taps=taps)
+        o_gpu, dumps = eng.debug_step(xd[:, t * H:(t + 1) * H], state)
+        for sname in names:
+            tap = taps[sname]
+            ref = tap[:, :, 0, :] if sname in ("spec_in", "spec_out", "compressed", "mask_mlp") else tap[0]
+            _assert_close(dumps[sname].cpu().numpy(), ref, f"{name} hop {t} stage {sname}")
+        _assert_close(o_gpu.cpu().numpy(), o_ref, f"{name} hop {t} wav_out")
+    for a_, b_ in zip(eng.split_state(state, B), caches):
+        _assert_close(a_.cpu().numpy(), b_, f"{name} cache after debug steps")
+
+
+@pytest.mark.parametrize("name", ["bsrnn_xxt", "bsrnn_xt", "bsrnn_t", "bsrnn_s"])
 def test_bsrnn_streaming_matches_reference_golden(name):
     from fastenhancer_amd.streaming import StreamingModel
     g = load_golden(name)
@@ -497,7 +522,7 @@ def test_bsrnn_streaming_matches_reference_golden(name):
         _assert_close(caches[2 + i].cpu().numpy(), g[f"stream_c{i}"], f"lstm cache {i}")
 
 
-@pytest.mark.parametrize("name", ["bsrnn_xxt", "bsrnn_xt"])
+@pytest.mark.parametrize("name", ["bsrnn_xxt", "bsrnn_xt", "bsrnn_t", "bsrnn_s"])
 def test_bsrnn_offline_matches_reference_golden(name):
     g = load_golden(name)
     m, orc, cfg, sr, seed = _bsrnn(name, "Model")
@@ -507,7 +532,7 @@ def test_bsrnn_offline_matches_reference_golden(name):
     _assert_close(spec_hat.cpu().numpy(), g["offline_spec"], "offline spec")
 
 
-@pytest.mark.parametrize("name", ["bsrnn_xt", "bsrnn_t"])
+@pytest.mark.parametrize("name", ["bsrnn_xt", "bsrnn_t", "bsrnn_s"])
 def test_bsrnn_batch_and_chunk_vs_oracle(name):
     m, orc, cfg, sr, seed = _bsrnn(name)
     eng = m.engine
