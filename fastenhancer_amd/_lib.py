@@ -36,6 +36,7 @@ SYMBOLS = {
     "fe_state_init": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "fe_step": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "fe_spec_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "fe_set_time_pipeline": (c_int, [c_void_p, c_int]),
     "fe_offline_work_floats": (c_size_t, [c_void_p, c_int, c_int]),
     "fe_offline": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fe_stft_step": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

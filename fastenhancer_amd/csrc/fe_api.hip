@@ -82,6 +82,8 @@ struct fe_handle {
     fe::BOffsets boff{};
     int device = 0;
     int max_wgs = 256;             // CUs of the device: one resident workgroup per CU (persistent grid above that)
+    int pipe_frames = -1;          // fe_set_time_pipeline (-1: chosen from the model size)
+    unsigned int* pipe_flags_dev = nullptr;   // fe_spec_step's frame counters [max_wgs][KB] (fe_offline keeps its own in the work buffer)
     std::vector<Section> sections;
     size_t blob_floats = 0;
     float* packed_dev = nullptr;
@@ -610,6 +612,8 @@ fe::FrameArgs base_args(fe_handle* h, int B, int T) {
 
 }  // namespace
 
+static int ensure_tables(fe_handle* h, hipStream_t st);
+
 extern "C" {
 
 const char* fe_last_error(void) { return g_err.c_str(); }
@@ -664,6 +668,7 @@ void fe_destroy(fe_handle* h) {
     if (h->packed_dev) (void)hipFree(h->packed_dev);
     if (h->skip_dev) (void)hipFree(h->skip_dev);
     if (h->tables_dev) (void)hipFree(h->tables_dev);
+    if (h->pipe_flags_dev) (void)hipFree(h->pipe_flags_dev);
     delete h;
 }
 
@@ -768,6 +773,28 @@ int fe_profile_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, flo
     return run_step(h, wav_in_dev, in_stride, state_dev, wav_out_dev, out_stride, B, T, nullptr, clk_dev, stream);
 }
 
+// workgroups per stream of a time-pipelined launch (0: one workgroup walks the frames of a stream)
+static int pipe_width(const fe_handle* h, int B, int T) {
+    if (!h->impl || h->pipe_frames == 0 || h->pipe_frames == 1 || T < 4 || 2 * B > h->max_wgs) return 0;
+    // automatic width: a hand-off (counter round trip + state fetch + the h half of the GRU + gates + publish) takes
+    // ~2.6 us whatever the model; a frame takes ~4 us per MFLOP/frame at the measured kernel efficiency: that many frames
+    // are worth having in flight (measured optimum: T 8-12, B 16, 48 kHz B 24, L > 24), more only adds pollers
+    int want = h->pipe_frames;
+    if (want < 0) {
+        want = (int)(fe_flops_per_frame(h) / 6.0e5) + 2;
+        want = want < 8 ? 8 : (want > 64 ? 64 : want);
+    }
+    int p = h->max_wgs / B;
+    p = p < want ? p : want;
+    return p < T ? p : T;
+}
+
+int fe_set_time_pipeline(fe_handle* h, int frames_in_flight) {
+    if (!h) return fail(FE_ERR_INVALID_ARG, "bad argument");
+    h->pipe_frames = frames_in_flight;
+    return FE_OK;
+}
+
 int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* spec_out_dev, int B, int T, void* stream) {
     int rc = check_ready(h);
     if (rc != FE_OK) return rc;
@@ -786,6 +813,14 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
     a.h = h_dev;
     hipError_t e = hipSuccess;
     a.mode = fe::FE_MODE_SPEC;
+    if (const int P = pipe_width(h, B, T)) {
+        const size_t nflags = (size_t)h->max_wgs * h->d.KB;
+        if (!h->pipe_flags_dev) FE_HIP_CHECK(hipMalloc(&h->pipe_flags_dev, nflags * sizeof(unsigned int)));
+        FE_HIP_CHECK(hipMemsetAsync(h->pipe_flags_dev, 0, (size_t)B * h->d.KB * sizeof(unsigned int), (hipStream_t)stream));
+        a.pipe_flags = h->pipe_flags_dev;
+        a.pipe_p = P;
+        h->impl->launch_pipe(a, (hipStream_t)stream, &e);
+    } else
     h->impl->launch(a, h->max_wgs, (hipStream_t)stream, &e);
     if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return FE_OK;
@@ -795,8 +830,12 @@ size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw) {
     if (!h || B <= 0 || Tw <= 0) return 0;
     const Dims& d = h->d;
     if (h->bimpl) return (size_t)B * (size_t)(d.NFFT - d.HOP) + bsrnn_lstm_floats(h, B);
-    // GRU state (zero initial state, model.py:626-627) + overlap-add tail, both zeroed by fe_offline
-    return (size_t)B * ((size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2);
+    // GRU state (zero initial state, model.py:626-627) + overlap-add tail, both zeroed by fe_offline; time-pipelined
+    // launches: + the frame counters [B][KB] and the windowed output frames [B][T][N]
+    size_t n = (size_t)B * ((size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2);
+    const int T = 1 + Tw / d.HOP;
+    if (pipe_width(h, B, T)) n += (((size_t)B * d.KB + 3) & ~(size_t)3) + (size_t)B * T * d.NFFT;
+    return n;
 }
 
 int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_hat_dev, float* spec_hat_dev, float* work_dev,
@@ -808,8 +847,13 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
     if (Tw <= d.NFFT / 2)   // torch.stft reflect padding needs pad < length
         return fail(FE_ERR_INVALID_ARG, "Tw=%d: reflect padding of n_fft/2=%d needs a longer input", Tw, d.NFFT / 2);
     hipStream_t st = (hipStream_t)stream;
-    FE_HIP_CHECK(hipMemsetAsync(work_dev, 0, fe_offline_work_floats(h, B, Tw) * sizeof(float), st));
     const int T = 1 + Tw / d.HOP;
+    {   // zero the state, the tail and the frame counters (not the frames: every element is written)
+        size_t nz = (size_t)B * ((size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2);
+        if (h->bimpl) nz = fe_offline_work_floats(h, B, Tw);
+        else if (pipe_width(h, B, T)) nz += ((size_t)B * d.KB + 3) & ~(size_t)3;
+        FE_HIP_CHECK(hipMemsetAsync(work_dev, 0, nz * sizeof(float), st));
+    }
     if (h->bimpl) {
         fe::BArgs ba = bsrnn_args(h, B, T);
         ba.mode = fe::FE_MODE_OFFLINE;
@@ -835,6 +879,22 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
     a.cache_stft = work_dev;   // unused in this mode
     a.h = work_dev + (size_t)B * (d.NFFT - d.HOP);
     hipError_t e = hipSuccess;
+    if (const int P = pipe_width(h, B, T)) {
+        rc = ensure_tables(h, st);
+        if (rc != FE_OK) return rc;
+        float* flags = a.h + (size_t)d.KB * B * d.F2 * d.C2;
+        a.pipe_flags = reinterpret_cast<unsigned int*>(flags);
+        a.frames = flags + (((size_t)B * d.KB + 3) & ~(size_t)3);
+        a.pipe_p = P;
+        h->impl->launch_pipe(a, st, &e);
+        if (e != hipSuccess) return fail(FE_ERR_HIP, "cooperative kernel launch: %s", hipGetErrorString(e));
+        const int n_out = d.HOP * (T - 1);
+        hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
+                           a.frames, h->tables_dev, wav_hat_dev, (size_t)n_out, d.NFFT, d.HOP, T);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+        return FE_OK;
+    }
     h->impl->launch(a, h->max_wgs, st, &e);
     if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return FE_OK;

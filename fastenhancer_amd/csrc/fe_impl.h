@@ -21,6 +21,7 @@ struct Impl {
     int dbg_stages;
     const PackedOffsets* off;
     void (*launch)(const FrameArgs&, int max_wgs, hipStream_t, hipError_t*);
+    void (*launch_pipe)(const FrameArgs&, hipStream_t, hipError_t*);     // time-pipelined offline / spec launch (a.pipe_p workgroups per stream)
     void (*dbg_stage)(int, int*, int*, size_t*);
 };
 
@@ -59,6 +60,24 @@ void launch_impl(const FrameArgs& a, int max_wgs, hipStream_t st, hipError_t* er
     else launch_one<S, false, -1, false, true>(a, grid, st, err);                        // chunked streaming, fe_spec_step, fe_offline
 }
 
+// Time-pipelined launch: B * pipe_p workgroups that wait on each other inside the kernel - a cooperative launch, so
+// that the runtime guarantees (or refuses) their co-residency instead of a spin-wait deadlock.
+template <class S>
+void launch_pipe_impl(const FrameArgs& a, hipStream_t st, hipError_t* err) {
+    auto* fn = &fe_frame_kernel<S, false, -1, false, true, true>;
+    static std::atomic<bool> attr_set[kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    if (!attr_set[dev].load(std::memory_order_relaxed)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds<S>::BYTES);
+        if (e != hipSuccess) { *err = e; return; }
+        attr_set[dev].store(true, std::memory_order_relaxed);
+    }
+    FrameArgs args = a;
+    void* kargs[] = {&args};
+    *err = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(a.B * a.pipe_p), dim3(kThreads), kargs, (unsigned int)Lds<S>::BYTES, st);
+}
+
 template <class S>
 void dbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
     *rows = DebugLayout<S>::rows(s);
@@ -70,7 +89,7 @@ template <class S>
 Impl make_impl() {
     return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, Lds<S>::BYTES, S::NU, Pack<S>::umax(), Lds<S>::STAGED,
                 Lds<S>::SKIPS_LDS ? (size_t)0 : (size_t)(S::NL + 1) * S::F1 * S::C1,
-                DebugLayout<S>::total(), DebugLayout<S>::n_stages, &Pack<S>::v, &launch_impl<S>, &dbg_stage_impl<S>};
+                DebugLayout<S>::total(), DebugLayout<S>::n_stages, &Pack<S>::v, &launch_impl<S>, &launch_pipe_impl<S>, &dbg_stage_impl<S>};
 }
 
 

@@ -185,6 +185,10 @@ struct FrameArgs {
     int mode;                 // FE_MODE_*
     int Tw;                   // offline: samples per stream
     float compression;
+    // time-pipelined launches (PIPE instantiation): P workgroups per stream, workgroup p runs frames p, p + P, ...
+    unsigned int* pipe_flags; // [B][KB]: number of frames whose block-k GRU state has been published (zeroed before the launch)
+    float* frames;            // offline: [B][T][N] windowed output frames (overlap-added by istft_ola_kernel afterwards)
+    int pipe_p;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1060,7 +1064,13 @@ __device__ __forceinline__ void attention_head(const float* G, float* Hl, int ho
 // blockIdx.x + gridDim.x, ... and keeps what does not depend on the stream - twiddles, zeroed halos, the staged weight
 // pipeline (the last phase of a stream's last frame stages unit 0 for the next stream) - instead of paying the kernel
 // prologue and a workgroup launch per stream.  PERSIST = false: one stream per workgroup, no stream loop.
-template <class S, bool DBG, int MODE, bool T1, bool PERSIST>
+// PIPE (offline / spec -> spec with T >> 1): the frames of ONE stream are spread over P co-resident workgroups (one per
+// CU), workgroup p running frames p, p + P, ...  Everything in a frame but the GRU state is independent of the other
+// frames, so the workgroups run their frames concurrently, staggered by the one true dependency: frame t's GRU in block
+// k needs h_k(t-1).  The producer publishes it through global memory (agent-scope stores, then a release on a per-(stream,
+// block) frame counter), the consumer spins on the counter (acquire) before it fetches the state.  The serial chain is
+// T x (state round trip + one GRU phase) instead of T x (whole frame): ~12 frames in flight for FastEnhancer_B.
+template <class S, bool DBG, int MODE, bool T1, bool PERSIST, bool PIPE = false>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) fe_frame_kernel(FrameArgs a_in) {
     FrameArgs a = a_in;
 #ifdef FE_PROBE_HOT          // measurement builds: the production instantiations keep the cycle probes (tools/gpu_phases.py ... 1)
@@ -1148,15 +1158,45 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     }
     __syncthreads();
 
-    int b = blockIdx.x;
+    int b = PIPE ? (int)blockIdx.x / a.pipe_p : (int)blockIdx.x;
+    const int t_first = PIPE ? (int)blockIdx.x - b * a.pipe_p : 0, t_step = PIPE ? a.pipe_p : 1;
     int fc = 0;                                      // frames done by this workgroup (staging-buffer parity)
+    // GRU state exchange between the workgroups of a stream (PIPE): agent-scope accesses (not served from a stale L1 / L2 line)
+    auto ld_state = [](const float* p) -> float {
+        if constexpr (PIPE) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return *p;
+    };
+    auto st_state = [](float* p, float v) {
+        if constexpr (PIPE) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *p = v;
+    };
 #pragma unroll 1
     do {
     float* cst = a.cache_stft + (size_t)b * OVL;
     float* cis = a.cache_istft + (size_t)b * OVL;
+    unsigned int* pflag = PIPE ? a.pipe_flags + (size_t)b * S::KB : nullptr;
+    // wait until the block-k state of frame t-1 is published (all threads call; thread 0 polls)
+    auto pipe_wait = [&](int k, int t) {
+        if constexpr (PIPE) {
+            if (t > 0) {
+                if (tid == 0) {
+                    while (__hip_atomic_load(pflag + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)t) __builtin_amdgcn_s_sleep(1);
+                }
+                __syncthreads();
+            }
+        }
+    };
+    // publish frame t's block-k state: every thread's state stores have left the CU, then one release store of the counter
+    auto pipe_publish = [&](int k, int t) {
+        if constexpr (PIPE) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0) (gfx9 encoding: lgkmcnt / expcnt left alone)
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(pflag + k, (unsigned int)(t + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
 
 #pragma unroll 1
-    for (int t = 0; t < a.T; ++t, ++fc) {
+    for (int t = t_first; t < a.T; t += t_step, ++fc) {
         // A loop-variant zero keeps the (many) wave-uniform offsets of a frame from being hoisted out of the frame
         // loop: hoisted, they sit in SGPRs for the whole kernel and spill to VGPR lanes by the hundred.
         // (Measured on the kernels with a frame loop: FastEnhancer_B 46.0 -> 44.1 us per frame, T 21.2 -> 20.5 us,
@@ -1166,7 +1206,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         const int wave = wave0 + lz;
         // begin_unit(U): called right after the barrier that precedes the GEMM phase of staged unit U:
         // selects the LDS copy of this phase's weights and sets up the DMA job of the next unit.
-        const int fpar = (S::NU & 1) ? ((PERSIST ? fc : t) & 1) : 0;
+        const int fpar = (S::NU & 1) ? (((PERSIST || PIPE) ? fc : t) & 1) : 0;
 #define FE_BEGIN_UNIT(U)                                                                           \
         constexpr int fe_un_ = ((U) + 1 == S::NU) ? 0 : (U) + 1;                                   \
         if constexpr (L::STAGED) {                                                                 \
@@ -1176,7 +1216,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             wb.lds = smem + (slot_ ? L::WB1 : L::WB0);                                             \
             wb.base = o.u_off[(U)];                                                                \
         }                                                                                          \
-        const StageSide<NPW, (L::STAGED && !(T1 && !PERSIST && (U) + 1 == S::NU)) ? o.u_size[fe_un_] / 256 : 0> stage{&job}
+        const StageSide<NPW, (L::STAGED && !(T1 && !PERSIST && !PIPE && (U) + 1 == S::NU)) ? o.u_size[fe_un_] / 256 : 0> stage{&job}
         FE_CLK(0);
         // =========================== STFT (a3) ===========================
         const int mode = a.mode;
@@ -1420,7 +1460,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             Wgh.bind(wb, o.blk_whh[0], o.blk_bhh[0], GNT, wave);      // ... and the hidden weights in this one
             // hidden state of block 0: fetched now, parked in LDS after the GEMM
             float hpre[HPT];
-            {
+            if constexpr (!PIPE) {     // (PIPE: the state is fetched as late as possible, inside the GRU phase)
                 const float* hg0 = a.h + (size_t)b * (F2 * C2);
 #pragma unroll
                 for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = hg0[i < F2 * C2 ? i : F2 * C2 - 1]; }   // (clamped, not predicated: no branch per load)
@@ -1439,10 +1479,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     for (int r = 0; r < 4; ++r) xd[(16 * i + r) * LDX] = acc[i][j][r];
                 }
             if constexpr (L::PERHEAD) __syncthreads();       // (there Y1, still being read by slower waves, lies over HS)
+            if constexpr (!PIPE) {
 #pragma unroll
             for (int q = 0; q < HPT; ++q) {
                 Hs[hs_off[q]] = hpre[q];
                 if constexpr (GFLAT) hkeep[q] = hpre[q];
+            }
             }
         }
         __syncthreads();
@@ -1482,6 +1524,23 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 // the state, no register-resident residual - runs over (column tile, row-tile group) jobs instead,
                 // round-robin: 15 jobs -> 4:4:4:3, 12 jobs -> 3:3:3:3.
                 constexpr bool GBAL = !REGW && S::NT2 > 4;
+                // PIPE: wait for frame t-1's state of this block, fetch it, park it in Hs (one barrier) - here, at the last
+                // moment, so that the hand-off chain from frame to frame is wait -> fetch -> h-half GEMM -> gates -> publish
+                auto pipe_fetch_state = [&]() {
+                    if constexpr (PIPE) {
+                        float hq_[HPT];
+                        pipe_wait(k, t);
+#pragma unroll
+                        for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hq_[q] = ld_state(hg + (i < F2 * C2 ? i : F2 * C2 - 1)); }
+#pragma unroll
+                        for (int q = 0; q < HPT; ++q) {
+                            Hs[hs_off[q]] = hq_[q];
+                            if constexpr (GFLAT) hkeep[q] = hq_[q];
+                        }
+                        __syncthreads();
+                    }
+                };
+                if constexpr (!(GFLAT && PIPE)) pipe_fetch_state();
                 if constexpr (GFLAT) {
                     // gates as one (3 C2)-column GEMM over this wave's flat column tiles (see Shape::GFLAT); the
                     // pre-activations cross through LDS: r | z | n_x -> Gi[row][0 .. 3 C2), n_h -> Hl[row][c]
@@ -1499,6 +1558,18 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (k == 0) FE_CLK(45);
+                    if constexpr (PIPE) {
+                        // the x half does not need the previous frame: it runs before the wait
+                        mma_panel_sel<S::MT2, NTPW3, K2, Lds<S>::PDK>(
+                            [&](int i, int j, int) -> f32x4& { return ax[i][j]; },
+                            [&](int i, int ks) { return Xb[(16 * i + li) * LDX + lg + 4 * ks]; },
+                            [&](int j, int ks) { return Wgi.get(j, 0, ks); }, FetchSide2<decltype(Wf1), decltype(Wq)>{&Wf1, &Wq});
+                        pipe_fetch_state();
+                        mma_panel_sel<S::MT2, NTPW3, K2, Lds<S>::PDK>(
+                            [&](int i, int j, int) -> f32x4& { return pure_rz(j) ? ax[i][j] : ah[i][j]; },
+                            [&](int i, int ks) { return Hs[(16 * i + li) * LDX + lg + 4 * ks]; },
+                            [&](int j, int ks) { return Wgh.get(j, 0, ks); }, NoSide{});
+                    } else
                     mma_panel_sel<S::MT2, NTPW3, 2 * K2, Lds<S>::PDK>(
                         [&](int i, int j, int ks) -> f32x4& { return ks < K2 || pure_rz(j) ? ax[i][j] : ah[i][j]; },
                         [&](int i, int ks) { return ks < K2 ? Xb[(16 * i + li) * LDX + lg + 4 * ks] : Hs[(16 * i + li) * LDX + lg + 4 * (ks - K2)]; },
@@ -1563,7 +1634,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll
                         for (int q = 0; q < HPT; ++q) {
                             const int e = tid + q * kThreads;
-                            if ((q + 1) * kThreads <= F2 * C2 || e < F2 * C2) { Hl[eo[q]] = hn[q]; hg[e] = hn[q]; }
+                            if ((q + 1) * kThreads <= F2 * C2 || e < F2 * C2) { Hl[eo[q]] = hn[q]; st_state(hg + e, hn[q]); }
                         }
                     }
                 } else if constexpr (GBAL) {
@@ -1604,7 +1675,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                                         const float hp = Hs[row * LDX + c];
                                         const float hn = (1.0f - zz) * nn + zz * hp;
                                         Hl[row * LDX + c] = hn;
-                                        hg[row * C2 + c] = hn;
+                                        st_state(hg + row * C2 + c, hn);
                                     }
                                 }
                         }
@@ -1654,7 +1725,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                                     const float nn = tanh_f(ax[i][2][r] + rr * ah[i][2][r]);
                                     const float hn = (1.0f - zz) * nn + zz * hprev[i][r];
                                     Hl[row * LDX + c] = hn;
-                                    hg[row * C2 + c] = hn;
+                                    st_state(hg + row * C2 + c, hn);
                                 }
                             }
                             }
@@ -1662,7 +1733,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 }
             }
             if (k == 0) FE_CLK(47);
-            __syncthreads();
+            if constexpr (PIPE) pipe_publish(k, t);      // (its barrier is this phase's barrier)
+            else __syncthreads();
             if (k == 0) FE_CLK(21);
             if (k == 0) FE_CLK(22);
             {
@@ -1769,14 +1841,14 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 float hpre[HPT];
                 // next block: GRU hidden weights into registers inside the GEMM; hidden state fetched now / parked after it
                 Wgh.bind(wb, (o.blk_whh[0] + kb + o.blk_stride), (o.blk_bhh[0] + kb + o.blk_stride), GNT, wave, k + 1 < S::KB);
-                if (k + 1 < S::KB) {
+                if (!PIPE && k + 1 < S::KB) {
                     const float* hgn = hg + (size_t)a.B * (F2 * C2);
 #pragma unroll
                     for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = hgn[i < F2 * C2 ? i : F2 * C2 - 1]; }
                 }
                 f32x4 acc[S::MT2][NTPW];
                 tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf2, FetchSide<decltype(Wgh)>{&Wgh});
-                if (k + 1 < S::KB) {
+                if (!PIPE && k + 1 < S::KB) {
 #pragma unroll
                     for (int q = 0; q < HPT; ++q) {
                         Hs[hs_off[q]] = hpre[q];
@@ -2005,7 +2077,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             for (int q = 0; q < NPT; ++q) {
                 const int n = tid + q * kThreads;
                 ow[q] = wi[n];
-                oc[q] = n < OVL ? cis[n] : 0.0f;
+                oc[q] = (!PIPE && n < OVL) ? cis[n] : 0.0f;
             }
             float* xo;
             if constexpr (MDFT) {
@@ -2030,7 +2102,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 }
             }
             __syncthreads();
-            if (mode == FE_MODE_STREAM) {
+            if constexpr (PIPE) {
+                // the frames overlap-add in a separate launch (istft_ola_kernel): no tail is carried from frame to frame
+                float* fr = a.frames + ((size_t)b * a.T + t) * N;
+                for (int n = tid; n < N; n += kThreads) fr[n] = xo[n];
+            } else if (mode == FE_MODE_STREAM) {
                 float* out = a.wav_out + (size_t)b * a.out_stride + (size_t)t * H;
                 for (int n = tid; n < H; n += kThreads) out[n] = xo[n];
             } else {
@@ -2054,12 +2130,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     }
                 }
             }
-            for (int m = tid; m < OVL; m += kThreads) cis[m] = xo[m + H];
+            if constexpr (!PIPE) { for (int m = tid; m < OVL; m += kThreads) cis[m] = xo[m + H]; }
             __syncthreads();
         }
         FE_CLK(13);
     }
-    b += gridDim.x;
+    b += PIPE ? a.B : (int)gridDim.x;
     } while (PERSIST && b < a.B);
 }
 

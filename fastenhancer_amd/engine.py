@@ -150,6 +150,10 @@ class Engine:
                                         wav_out.stride(0) if B > 1 else T * H, B, T, _stream(self.device)), "fe_step")
         return wav_out
 
+    def set_time_pipeline(self, frames_in_flight: int):
+        """fe_set_time_pipeline: workgroups per stream in offline / spec launches with T >= 4 (0 = one workgroup per stream)."""
+        _lib.check(self.lib.fe_set_time_pipeline(self._h, int(frames_in_flight)), "fe_set_time_pipeline")
+
     def spec_step(self, spec: Tensor, h: Tensor) -> Tensor:
         """spec [B, N/2+1, T, 2], h [K, B*F2, C2] (in place) -> spec_hat [B, N/2+1, T, 2]."""
         self._require_gpu()

@@ -89,6 +89,13 @@ int fe_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, float* stat
 int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* spec_out_dev,
                  int B, int T, void* stream);
 
+/* Time pipelining of fe_offline / fe_spec_step (T >= 4 frames per stream, at most half as many streams as CUs): the
+ * frames of a stream are spread over up to `frames_in_flight` co-resident workgroups that hand the GRU state of each
+ * RNNFormer block from frame to frame through global memory (everything else in a frame is independent of the other
+ * frames).  Negative (the default) = a width chosen from the model size (8 .. 64); 0 or 1 = off (one workgroup walks the
+ * T frames of a stream).  Results agree to fp32 rounding. */
+int fe_set_time_pipeline(fe_handle* h, int frames_in_flight);
+
 /* Offline wav->wav, Model.forward (model.py:728-735) with CompressedSTFT
  * (functional/audio_modules.py:70-164): noisy [B, Tw] -> wav_hat [B, H*(Tw/H)], spec_hat [B, N/2, T, 2],
  * T = 1 + Tw/H.  work_dev: scratch of fe_offline_work_floats(B, Tw) floats. */

@@ -427,6 +427,53 @@ def test_offline_model_forward_matches_reference_golden(name):
     assert torch.equal(wav3, wav_hat)
 
 
+@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_m", "fe48_b"])
+def test_time_pipelined_offline_and_spec_agree_with_the_serial_walk(name):
+    """fe_offline / fe_spec_step with T >= 4 spread a stream's frames over co-resident workgroups that hand the GRU state
+    from frame to frame (fe_set_time_pipeline); one workgroup walking the frames serially must give the same result, and
+    both must match the oracle on a long utterance (many state hand-offs, every workgroup several frames)."""
+    m, orc, cfg, sr, seed = _model(name, "Model")
+    eng = m.engine
+    H = cfg.hop_size
+    x = make_input(2, 150 * H + 29, 606, sr)
+    xd = torch.from_numpy(x).to(_dev())
+    eng.set_time_pipeline(16)
+    wav_p, spec_p = m(xd)
+    wav_p2, spec_p2 = m(xd)
+    assert torch.equal(wav_p, wav_p2) and torch.equal(spec_p, spec_p2), "pipelined launch is not deterministic"
+    eng.set_time_pipeline(3)
+    wav_p3, spec_p3 = m(xd)
+    eng.set_time_pipeline(0)
+    wav_s, spec_s = m(xd)
+    eng.set_time_pipeline(-1)
+    wav_ref, spec_ref = orc.offline_forward(x)
+    for got_w, got_s, what in ((wav_p, spec_p, "pipelined x16"), (wav_p3, spec_p3, "pipelined x3"), (wav_s, spec_s, "serial")):
+        _assert_close(got_w.cpu().numpy(), wav_ref, f"{what} offline wav")
+        _assert_close(got_s.cpu().numpy(), spec_ref, f"{what} offline spec")
+    assert float((wav_p - wav_s).abs().max()) <= 2e-5 * max(1.0, float(wav_s.abs().max()))
+    # spec -> spec with carried state: two chunks of 20 frames, pipelined vs serial, caches included
+    mo, *_ = _model(name)
+    cache = orc.initialize_cache(2)[0]
+    specs = []
+    for t in range(40):
+        s_, cache = orc.stft_step(x[:, t * H:(t + 1) * H], cache)
+        specs.append(s_)
+    spec = torch.from_numpy(np.concatenate(specs, axis=2)).to(_dev())
+    outs = {}
+    for width in (16, 0):
+        mo.engine.set_time_pipeline(width)
+        h = mo.initialize_cache(spec)
+        o1, *h = mo(spec[:, :, :20].contiguous(), *h)
+        o2, *h = mo(spec[:, :, 20:].contiguous(), *h)
+        outs[width] = (torch.cat([o1, o2], dim=2), h)
+    mo.engine.set_time_pipeline(-1)
+    ref, href = orc.spec_forward(np.concatenate(specs, axis=2), orc.initialize_cache(2)[2:])
+    for width in (16, 0):
+        _assert_close(outs[width][0].cpu().numpy(), ref, f"spec chunks, pipeline {width}")
+        for a_, b_ in zip(outs[width][1], href):
+            _assert_close(a_.cpu().numpy(), b_, f"spec chunk caches, pipeline {width}")
+
+
 @pytest.mark.parametrize("name", ["fe_s", "fe48_t", "fe48_s", "fe48_m"])
 def test_offline_matches_oracle(name):
     m, orc, cfg, sr, seed = _model(name, "Model")

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Offline Model.forward (fe_offline) timing: one workgroup walking a stream's frames vs the time-pipelined launch.
+usage: tools/gpu_offline_timing.py [shape] [seconds of audio] [streams]"""
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from common import MODEL_KWARGS  # noqa: E402
+from fastenhancer_amd.config import FEConfig  # noqa: E402
+from fastenhancer_amd.engine import Engine  # noqa: E402
+from fastenhancer_amd.weights import default_state_dict  # noqa: E402
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "fe_b"
+    secs = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
+    B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    kw, sr, _ = MODEL_KWARGS[name]
+    dev = torch.device("cuda:0")
+    cfg = FEConfig.from_model_kwargs(**kw)
+    eng = Engine(cfg, dev)
+    eng.load_state_dict(default_state_dict(cfg, torch.Generator().manual_seed(1)))
+    x = 0.1 * torch.randn(B, int(secs * sr), device=dev)
+    T = 1 + x.shape[1] // cfg.hop_size
+    res = {}
+    for width in (0, 4, 8, 12, 16, 24, 32, 48, 64, -1):
+        eng.set_time_pipeline(width)
+        for _ in range(3):
+            eng.offline(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 10
+        for _ in range(n):
+            eng.offline(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        res[width] = dt
+        print(f"{name} B={B} {secs:.1f} s ({T} frames): frames in flight {width:2d}: {dt * 1e3:8.3f} ms  "
+              f"({B * T / dt / 1e3:8.1f} k frames/s, RTF {dt / secs / B:.5f}, x{res[0] / dt:5.2f} vs serial)")
+
+
+if __name__ == "__main__":
+    main()
