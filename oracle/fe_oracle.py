@@ -53,6 +53,14 @@ class FEConfig:
     normalize_final_conv: bool = False
     weight_norm: bool = False
     resnet: bool = False
+    # models/fastenhancer/time_kernel/model.py (configs/ablation/time_kernel_b.yaml): the encoder / decoder k=3 convs are
+    # causal Conv2d with kernel_size_time taps over time (1 = the default model); final_scale "exp": scale.exp()
+    kernel_size_time: int = 1
+    final_scale_exp: bool = False
+
+    @property
+    def time_kernel(self) -> bool:
+        return self.kernel_size_time > 1
 
     @staticmethod
     def from_model_kwargs(kw: dict) -> "FEConfig":
@@ -64,7 +72,9 @@ class FEConfig:
         assert kw.get("window", "hann") == "hann"
         return FEConfig(
             channels=kw.get("channels", 64),
-            kernel_size=tuple(kw.get("kernel_size", (8, 3, 3))),
+            kernel_size=tuple(kw["kernel_size_freq"]) if "kernel_size_freq" in kw else tuple(kw.get("kernel_size", (8, 3, 3))),
+            kernel_size_time=int(kw.get("kernel_size_time", 3)) if "kernel_size_freq" in kw else 1,
+            final_scale_exp=("kernel_size_freq" in kw and kw.get("final_scale", "exp") == "exp"),
             stride=kw.get("stride", 4),
             rf_blocks=rk.get("num_blocks", 3),
             rf_channels=rk.get("channels", 32),
@@ -103,12 +113,12 @@ class FEConfig:
         k0 = self.kernel_size[0]
         m = 2 * C1 * k0 * F1
         for k in self.kernel_size[1:]:
-            m += C1 * C1 * k * F1
+            m += C1 * C1 * k * self.kernel_size_time * F1
         m += F1 * F2 * C1 + C1 * C2 * F2
         m += K * (C2 * C2 * 6 * F2 + C2 * C2 * F2 + C2 * C2 * 3 * F2 + 2 * F2 * C2 * F2 + C2 * C2 * F2)
         m += F2 * F1 * C2 + C2 * C1 * F1
         for k in self.kernel_size[1:]:
-            m += 2 * C1 * C1 * F1 + C1 * C1 * k * F1
+            m += 2 * C1 * C1 * F1 + C1 * C1 * k * self.kernel_size_time * F1
         m += 2 * C1 * C1 * F1 + C1 * 2 * k0 * F1
         return m
 
@@ -242,6 +252,42 @@ def linear_filterbank(n_freq: int, n_filter: int) -> Tuple[Array, Array]:
     return np.ascontiguousarray(pre), np.ascontiguousarray(post)
 
 
+def linear_filterbank_tk(n_freq: int, n_filter: int, sr: int = 16000) -> Tuple[Array, Array]:
+    """rf_pre_post_lin with init 'linear*' of the time_kernel variant, models/fastenhancer/time_kernel/model.py:477-489:
+    centres and bins on Hz axes, slope 1 / (sr/2 / n_filter) (not the default model's (n_freq-1)/(n_filter-1) bins);
+    post = pre^T taken BEFORE pre is normalised, each then row-normalised."""
+    f32 = np.float32
+    half = sr // 2
+    f_filter = np.linspace(0, half, n_filter, dtype=np.float64).astype(f32)
+    delta_f = f32(half / n_filter)
+    f_freqs = np.linspace(0, half, n_freq, dtype=np.float64).astype(f32)
+    down = (f_filter[1:, None] - f_freqs[None, :]) / delta_f
+    down = np.concatenate([down, np.ones((1, n_freq), f32)], axis=0)
+    up = (f_freqs[None, :] - f_filter[:-1, None]) / delta_f
+    up = np.concatenate([np.ones((1, n_freq), f32), up], axis=0)
+    pre = np.maximum(f32(0), np.minimum(down, up)).astype(f32)
+    post = pre.T
+    pre = pre / pre.sum(axis=1, keepdims=True)
+    post = post / post.sum(axis=1, keepdims=True)
+    return np.ascontiguousarray(pre), np.ascontiguousarray(post)
+
+
+def causal_conv2d(x: Array, w: Array, b: Array, cache: Optional[Array]) -> Tuple[Array, Array]:
+    """CausalConv2d.forward, models/fastenhancer/time_kernel/model.py:119-148: x [B,C,T,F], w [Co,Ci,kt,kf], cache
+    [B,Ci,kt-1,F] (None = zeros) -> (out [B,Co,T,F], cache_out = the last kt-1 frames of cat(cache, x))."""
+    B, Ci, T, F = x.shape
+    Co, _, kt, kf = w.shape
+    if cache is None:
+        cache = np.zeros((B, Ci, kt - 1, F), x.dtype)
+    xc = np.concatenate([cache.astype(x.dtype), x], axis=2)            # [B,Ci,T+kt-1,F]
+    out = np.zeros((B, Co, T, F), x.dtype)
+    for dt in range(kt):
+        xs = xc[:, :, dt:dt + T].transpose(0, 2, 1, 3).reshape(B * T, Ci, F)
+        out += conv1d(xs, w[:, :, dt, :], None, (kf - 1) // 2).reshape(B, T, Co, F).transpose(0, 2, 1, 3)
+    out += b[None, :, None, None]
+    return out, xc[:, :, -(kt - 1):].copy()
+
+
 def positional_embedding(channels: int, freq: int) -> Array:
     """calculate_positional_embedding, models/fastenhancer/default/model.py:98-110."""
     f = np.arange(1, freq + 1, dtype=np.float32) * np.float32(math.pi / freq)
@@ -278,7 +324,7 @@ def fold_state_dict(sd: Dict[str, Array], cfg: FEConfig) -> Dict[str, Array]:
     def conv_bn(conv: str, bn: str, dst: str):
         g, shift = _bn_scale_shift(sd, bn, bn_eps)
         w = sd[conv + ".weight"].astype(np.float32)
-        out[dst + ".weight"] = w * g.reshape(-1, 1, 1)
+        out[dst + ".weight"] = w * g.reshape((-1,) + (1,) * (w.ndim - 1))
         out[dst + ".bias"] = shift
 
     conv_bn("enc_pre.0", "enc_pre.1", "enc_pre.0")
@@ -316,6 +362,8 @@ def fold_state_dict(sd: Dict[str, Array], cfg: FEConfig) -> Dict[str, Array]:
     conv_bn("dec_post.0", "dec_post.1", "dec_post.0")
     w = sd["dec_post.3.weight"].astype(np.float32)
     scale = sd["dec_post.3.scale"].astype(np.float32) if "dec_post.3.scale" in sd else np.ones(1, np.float32)
+    if cfg.final_scale_exp:               # time_kernel/model.py:95,105 (exp_scale)
+        scale = np.exp(scale)
     if cfg.normalize_final_conv:
         # F.normalize(w, dim=(0,1,2)): w / max(||w||_2, 1e-12)
         w = w / max(float(np.sqrt((w.astype(np.float32) ** 2).sum())), 1e-12)
@@ -340,11 +388,13 @@ def training_state_dict_spec(cfg: FEConfig) -> Dict[str, Tuple[int, ...]]:
 
     spec["enc_pre.0.weight"] = (C1, 2 * S, cfg.kernel_size[0] // S)
     bn("enc_pre.1", C1)
+    tk = cfg.time_kernel
+    one = (1, 1) if tk else (1,)          # the time_kernel variant's 1x1 convs are Conv2d
     for i in range(cfg.n_layers):
-        spec[f"encoder.{i}.0.weight"] = (C1, C1, cfg.kernel_size[i + 1])
+        spec[f"encoder.{i}.0.weight"] = (C1, C1, cfg.kernel_size_time, cfg.kernel_size[i + 1]) if tk else (C1, C1, cfg.kernel_size[i + 1])
         bn(f"encoder.{i}.1", C1)
     spec["rf_pre.0.weight"] = (F2, F1)
-    spec["rf_pre.1.weight"] = (C2, C1, 1)
+    spec["rf_pre.1.weight"] = (C2, C1) + one
     bn("rf_pre.2", C2)
     for k in range(cfg.rf_blocks):
         p = f"rf_block.{k}."
@@ -370,12 +420,13 @@ def training_state_dict_spec(cfg: FEConfig) -> Dict[str, Tuple[int, ...]]:
         spec[p + "attn_fc.weight"] = (C2, C2)
         bn(p + "attn_post_norm", C2)
     spec["rf_post.0.weight"] = (F1, F2)
-    spec["rf_post.1.weight"] = (C1, C2, 1)
+    spec["rf_post.1.weight"] = (C1, C2) + one
     bn("rf_post.2", C1)
     for i in range(cfg.n_layers):
-        spec[f"decoder.{i}.0.weight"] = (C1, 2 * C1, 1)
+        spec[f"decoder.{i}.0.weight"] = (C1, 2 * C1) + one
         bn(f"decoder.{i}.1", C1)
-        spec[f"decoder.{i}.3.weight"] = (C1, C1, cfg.kernel_size[cfg.n_layers - i])
+        kf = cfg.kernel_size[cfg.n_layers - i]
+        spec[f"decoder.{i}.3.weight"] = (C1, C1, cfg.kernel_size_time, kf) if tk else (C1, C1, kf)
         bn(f"decoder.{i}.4", C1)
     spec["dec_post.0.weight"] = (C1, 2 * C1, 1)
     bn("dec_post.1", C1)
@@ -407,7 +458,11 @@ class FEOracle:
     def initialize_cache(self, B: int) -> List[Array]:
         c = self.cfg
         caches = [np.zeros((B, c.n_fft - c.hop_size), self.dtype), np.zeros((B, c.n_fft - c.hop_size), self.dtype)]
-        caches += [np.zeros((1, B * c.rf_freq, c.rf_channels), self.dtype) for _ in range(c.rf_blocks)]
+        hs = [np.zeros((1, B * c.rf_freq, c.rf_channels), self.dtype) for _ in range(c.rf_blocks)]
+        if c.time_kernel:     # (B, C1, kt-1, F1) per causal conv (time_kernel/model.py:138-139, sized for B streams)
+            tkc = lambda: [np.zeros((B, c.channels, c.kernel_size_time - 1, c.F1), self.dtype) for _ in range(c.n_layers)]
+            return caches + tkc() + hs + tkc()
+        caches += hs
         return caches
 
     # ---- a3: ONNXSTFT.forward (functional/audio_modules.py:243-257)
@@ -437,6 +492,25 @@ class FEOracle:
                       ) -> Tuple[Array, List[Array]]:
         c, w = self.cfg, self.w
         B, F0, T, _ = spec.shape
+        tk = c.time_kernel
+        nl = c.n_layers
+        C1, F1 = c.channels, c.F1
+        # time_kernel: the cache list is [encoder caches, GRU states, decoder caches] (time_kernel/model.py:746-754)
+        enc_c = dec_c = None
+        if tk and h_list is not None:
+            assert len(h_list) == 2 * nl + c.rf_blocks
+            enc_c, dec_c = h_list[:nl], h_list[nl + c.rf_blocks:]
+            h_list = h_list[nl:nl + c.rf_blocks]
+        enc_c_out, dec_c_out = [], []
+        w1 = (lambda key: w[key][:, :, 0, 0][:, :, None]) if tk else (lambda key: w[key])     # Conv2d 1x1 -> Conv1d form
+
+        def k3(x2, key, cache):       # x2 [B*T,C1,F1] -> same; causal time taps when tk
+            if not tk:
+                kf = w[key + ".weight"].shape[-1]
+                return conv1d(x2, w[key + ".weight"], w[key + ".bias"], (kf - 1) // 2), None
+            x4 = x2.reshape(B, T, C1, F1).transpose(0, 2, 1, 3)
+            y4, cache_out = causal_conv2d(x4, w[key + ".weight"], w[key + ".bias"], cache)
+            return y4.transpose(0, 2, 1, 3).reshape(B * T, C1, F1), cache_out
         x = spec.transpose(0, 2, 3, 1).reshape(B * T, 2, F0)
         pad0 = (c.kernel_size[0] - c.stride) // 2
         x = silu(strided_conv1d(x, w["enc_pre.0.weight"], w["enc_pre.0.bias"], c.stride, pad0))
@@ -444,14 +518,15 @@ class FEOracle:
         if taps is not None:
             taps["enc_pre"] = x.copy()
         for i in range(c.n_layers):
-            k = c.kernel_size[i + 1]
-            x = silu(conv1d(x, w[f"encoder.{i}.0.weight"], w[f"encoder.{i}.0.bias"], (k - 1) // 2))
+            x, co = k3(x, f"encoder.{i}.0", None if enc_c is None else enc_c[i])
+            x = silu(x)
+            enc_c_out.append(co)
             enc_outs.append(x)
             if taps is not None:
                 taps[f"encoder.{i}"] = x.copy()
         # rf_pre: Linear over the freq axis then 1x1 conv (model.py:458-465, :646)
         x = x @ w["rf_pre.0.weight"].T                                   # [BT,C1,F2]
-        x = conv1d(x, w["rf_pre.1.weight"], w["rf_pre.1.bias"], 0)       # [BT,C2,F2]
+        x = conv1d(x, w1("rf_pre.1.weight"), w["rf_pre.1.bias"], 0)      # [BT,C2,F2]
         C2, F2 = c.rf_channels, c.rf_freq
         x = x.reshape(B, T, C2, F2).transpose(1, 0, 3, 2)                # [T,B,F2,C2]
         x = np.ascontiguousarray(x)
@@ -482,14 +557,15 @@ class FEOracle:
                 taps[f"rf_block.{k}"] = x.copy()
         x = x.transpose(1, 0, 3, 2).reshape(B * T, C2, F2)
         x = x @ w["rf_post.0.weight"].T                                  # [BT,C2,F1]
-        x = conv1d(x, w["rf_post.1.weight"], w["rf_post.1.bias"], 0)     # [BT,C1,F1]
+        x = conv1d(x, w1("rf_post.1.weight"), w["rf_post.1.bias"], 0)    # [BT,C1,F1]
         if taps is not None:
             taps["rf_post"] = x.copy()
         for i in range(c.n_layers):
-            k = c.kernel_size[c.n_layers - i]
             x = np.concatenate([x, enc_outs.pop(-1)], axis=1)
-            x = silu(conv1d(x, w[f"decoder.{i}.0.weight"], w[f"decoder.{i}.0.bias"], 0))
-            x = silu(conv1d(x, w[f"decoder.{i}.2.weight"], w[f"decoder.{i}.2.bias"], (k - 1) // 2))
+            x = silu(conv1d(x, w1(f"decoder.{i}.0.weight"), w[f"decoder.{i}.0.bias"], 0))
+            x, co = k3(x, f"decoder.{i}.2", None if dec_c is None else dec_c[i])
+            x = silu(x)
+            dec_c_out.append(co)
             if taps is not None:
                 taps[f"decoder.{i}"] = x.copy()
         x = np.concatenate([x, enc_outs.pop(-1)], axis=1)
@@ -498,6 +574,8 @@ class FEOracle:
         mask = x.reshape(B, T, 2, F0).transpose(0, 3, 1, 2)              # [B,F0,T,2]
         if taps is not None:
             taps["mask"] = mask.copy()
+        if tk:
+            h_out = enc_c_out + h_out + dec_c_out
         return np.ascontiguousarray(mask), h_out
 
     # ---- a4, a17: ONNXModel.forward (model.py:677-710)

@@ -19,14 +19,14 @@ from typing import Dict
 
 import numpy as np
 
-from .fe_oracle import FEConfig, linear_filterbank, positional_embedding, training_state_dict_spec
+from .fe_oracle import FEConfig, linear_filterbank, linear_filterbank_tk, positional_embedding, training_state_dict_spec
 
 
 def make_training_state_dict(cfg: FEConfig, seed: int) -> Dict[str, np.ndarray]:
     """Training-form state_dict with seeded values."""
     rng = np.random.Generator(np.random.PCG64(seed))
     spec = training_state_dict_spec(cfg)
-    pre, post = linear_filterbank(cfg.F1, cfg.rf_freq)
+    pre, post = (linear_filterbank_tk if cfg.time_kernel else linear_filterbank)(cfg.F1, cfg.rf_freq)
     pe = positional_embedding(cfg.rf_channels, cfg.rf_freq)
     sd: Dict[str, np.ndarray] = {}
     for key, shape in spec.items():

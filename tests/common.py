@@ -21,6 +21,14 @@ def _kw(C1, ks, C2, F2, K, N, H, init, eps=1.0e-5):
         normalize_final_conv=True, weight_norm=True, resnet=False)
 
 
+def _kw_tk(C1, ksf, kt, C2, F2, K, N, H, init, eps=1.0e-5):
+    """configs/ablation/time_kernel_b.yaml:2-29 (model: fastenhancer.time_kernel)"""
+    kw = _kw(C1, ksf, C2, F2, K, N, H, init, eps)
+    del kw["kernel_size"], kw["resnet"]
+    kw.update(kernel_size_freq=list(ksf), kernel_size_time=kt, final_scale=True)
+    return kw
+
+
 # name -> (model_kwargs, sampling rate, golden seed)
 MODEL_KWARGS = {
     "fe_t": (_kw(24, (8, 3, 3), 20, 16, 2, 512, 256, "linear_fixed"), 16000, 101),
@@ -34,7 +42,11 @@ MODEL_KWARGS = {
     "fe48_m": (_kw(96, (8, 3, 3, 3), 72, 72, 4, 1024, 320, "linear"), 48000, 109),
     "fe48_l": (_kw(128, (8, 3, 3, 3, 3), 96, 96, 5, 1024, 200, "linear"), 48000, 110),
     "fe48_b_h480": (_kw(48, (8, 3, 3), 36, 36, 3, 1024, 480, "linear"), 48000, 111),   # BASELINE config 4's "hop=480"
+    "fe_tk_b": (_kw_tk(48, (8, 3, 3), 3, 36, 24, 3, 512, 256, "linear_fixed"), 16000, 120),   # configs/ablation/time_kernel_b.yaml
 }
+# which module of the reference a name belongs to (the yaml's `model:` key)
+MODEL_MODULE = {name: "fastenhancer.default" for name in MODEL_KWARGS}
+MODEL_MODULE["fe_tk_b"] = "fastenhancer.time_kernel"
 
 
 def load_golden(name):

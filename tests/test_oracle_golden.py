@@ -7,6 +7,7 @@ from common import MODEL_KWARGS, build_oracle, load_golden, rms
 from oracle.weightgen import make_input
 
 GOLDENS = ["fe_t", "fe_b", "fe_m", "fe_l", "fe48_b", "fe48_l", "fe48_b_h480"]
+ORACLE_GOLDENS = GOLDENS + ["fe_tk_b"]           # (the C oracle restates the default model only)
 # fp32-vs-fp32 different summation orders: the reference's own fp32 noise floor is ~5e-7
 # relative; allow 20x that.
 REL = 1e-5
@@ -18,7 +19,7 @@ def _close(a, b, rel=REL, what=""):
     assert err <= rel * max(ref, 1e-3), f"{what}: rms err {err:.3e} vs ref rms {ref:.3e}"
 
 
-@pytest.mark.parametrize("name", GOLDENS)
+@pytest.mark.parametrize("name", ORACLE_GOLDENS)
 def test_streaming_step_matches_reference(name):
     g = load_golden(name)
     cfg, sd, fused, orc = build_oracle(name)
@@ -32,11 +33,13 @@ def test_streaming_step_matches_reference(name):
     _close(np.stack(outs, 0), g["stream_wav_out"], what="wav_out")
     _close(caches[0], g["stream_cache_stft"], what="cache_stft")
     _close(caches[1], g["stream_cache_istft"], what="cache_istft")
-    for k in range(cfg.rf_blocks):
-        _close(caches[2 + k], g[f"stream_h{k}"], what=f"h{k}")
+    n_model_caches = cfg.rf_blocks + (2 * cfg.n_layers if cfg.time_kernel else 0)     # time_kernel: + the causal convs' frame caches
+    assert len(caches) == 2 + n_model_caches
+    for k in range(n_model_caches):
+        _close(caches[2 + k], g[f"stream_h{k}"], what=f"model cache {k}")
 
 
-@pytest.mark.parametrize("name", GOLDENS)
+@pytest.mark.parametrize("name", ORACLE_GOLDENS)
 def test_spec_chunk_matches_reference(name):
     g = load_golden(name)
     cfg, sd, fused, orc = build_oracle(name)
@@ -54,7 +57,7 @@ def test_spec_chunk_matches_reference(name):
     _close(h[-1], g["chunk_h_last"], what="chunk h")
 
 
-@pytest.mark.parametrize("name", GOLDENS)
+@pytest.mark.parametrize("name", ORACLE_GOLDENS)
 def test_offline_matches_reference(name):
     g = load_golden(name)
     cfg, sd, fused, orc = build_oracle(name)
@@ -66,7 +69,7 @@ def test_offline_matches_reference(name):
     _close(spec, g["offline_spec"], what="offline spec")
 
 
-@pytest.mark.parametrize("name", ["fe_t", "fe_b"])
+@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_tk_b"])
 def test_driver_loop_matches_reference(name):
     g = load_golden(name)
     cfg, sd, fused, orc = build_oracle(name)

@@ -35,11 +35,19 @@ import yaml
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
-from oracle.fe_oracle import FEConfig, fold_state_dict, linear_filterbank, stft_windows, training_state_dict_spec  # noqa: E402
+from oracle.fe_oracle import (FEConfig, fold_state_dict, linear_filterbank, linear_filterbank_tk, stft_windows,  # noqa: E402
+                              training_state_dict_spec)
 from oracle.weightgen import make_input, make_training_state_dict  # noqa: E402
 
 
 def import_reference_model(ref: str, rel: str, name: str) -> types.ModuleType:
+    if "torchaudio" not in sys.modules:      # models/fastenhancer/time_kernel/model.py:11 (only its mel initialisation calls it)
+        ta = types.ModuleType("torchaudio")
+        taf = types.ModuleType("torchaudio.functional")
+        taf.melscale_fbanks = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("torchaudio stub"))
+        ta.functional = taf
+        sys.modules["torchaudio"] = ta
+        sys.modules["torchaudio.functional"] = taf
     if "librosa" not in sys.modules:
         lib = types.ModuleType("librosa")
         filt = types.ModuleType("librosa.filters")
@@ -69,6 +77,8 @@ CONFIGS = {
     "fe48_l": ("configs/fastenhancer_48khz/l.yaml", 110, 1, 5, 0),
     # BASELINE.json config 4 words the 48 kHz case as "hop=480" (every shipped 48 kHz yaml uses 512): b.yaml with hop_size overridden
     "fe48_b_h480": ("configs/fastenhancer_48khz/b.yaml", 111, 2, 8, 0, {"hop_size": 480}),
+    # the time_kernel ablation (causal Conv2d with a 3-frame time kernel and (kt-1)-frame caches)
+    "fe_tk_b": ("configs/ablation/time_kernel_b.yaml", 120, 2, 10, 120),
 }
 
 
@@ -84,7 +94,9 @@ def gen_fastenhancer(ref: str, name: str, out_dir: str):
         kw.update(CONFIGS[name][5])
     sr = hps["data"]["sampling_rate"]
     cfg = FEConfig.from_model_kwargs(kw)
-    mod = import_reference_model(ref, "models/fastenhancer/default/model.py", "ref_fe_model")
+    tk = hps["model"] == "fastenhancer.time_kernel"
+    assert tk == cfg.time_kernel
+    mod = import_reference_model(ref, f"models/{hps['model'].replace('.', '/')}/model.py", "ref_fe_model_" + hps["model"].split(".")[-1])
     torch.manual_seed(0)
     torch.set_num_threads(1)
 
@@ -105,6 +117,7 @@ def gen_fastenhancer(ref: str, name: str, out_dir: str):
 
     # ---- fold check (a20): my restatement vs the reference's fused state_dict
     fused_mine = fold_state_dict(sd, cfg)
+    fused_ref.pop("dec_post.2.scale", None)      # (the time_kernel variant keeps the - then unused - scale parameter in its state_dict)
     assert set(fused_mine) == set(fused_ref), (set(fused_mine) ^ set(fused_ref))
     worst = 0.0
     for k in fused_ref:
@@ -119,7 +132,7 @@ def gen_fastenhancer(ref: str, name: str, out_dir: str):
     # fixed filterbank formula
     if kw.get("pre_post_init", None) == "linear_fixed":
         fresh = mod.ONNXModel(**kw)
-        pre, post = linear_filterbank(cfg.F1, cfg.rf_freq)
+        pre, post = (linear_filterbank_tk if tk else linear_filterbank)(cfg.F1, cfg.rf_freq)
         assert np.abs(pre - fresh.rf_pre[0].weight.numpy()).max() < 1e-5
         assert np.abs(post - fresh.rf_post[0].weight.numpy()).max() < 1e-5
 
@@ -131,7 +144,14 @@ def gen_fastenhancer(ref: str, name: str, out_dir: str):
     # ---- streaming wav->wav (a19): scripts/export_onnx.py:48-58 composition
     with torch.no_grad():
         caches = onnx_model.stft.initialize_cache(x)
-        caches += [torch.zeros(1, B * cfg.rf_freq, cfg.rf_channels) for _ in range(cfg.rf_blocks)]
+
+        def model_caches(nb):       # the model's cache list sized for nb streams (its own initialize_cache is written for 1)
+            hs = [torch.zeros(1, nb * cfg.rf_freq, cfg.rf_channels) for _ in range(cfg.rf_blocks)]
+            if not tk:
+                return hs
+            cc = lambda: [torch.zeros(nb, cfg.channels, cfg.kernel_size_time - 1, cfg.F1) for _ in range(cfg.n_layers)]
+            return cc() + hs + cc()
+        caches += model_caches(B)
         cache_stft, cache_istft, *h = caches
         outs, specs_in, specs_out = [], [], []
         for t in range(hops):
@@ -153,7 +173,7 @@ def gen_fastenhancer(ref: str, name: str, out_dir: str):
     # ---- spec->spec with a T-frame chunk (a4..a17; model.py:677-710), T=4 from zero state
     with torch.no_grad():
         spec_chunk = torch.from_numpy(np.concatenate(specs_in[:4], axis=2))   # [B,F0+1,4,2]
-        h0 = [torch.zeros(1, B * cfg.rf_freq, cfg.rf_channels) for _ in range(cfg.rf_blocks)]
+        h0 = model_caches(B)
         spec_hat, *h4 = onnx_model(spec_chunk, *h0)
     out["chunk_spec_out"] = spec_hat.numpy().copy()
     out["chunk_h_last"] = h4[-1].numpy().copy()
@@ -173,7 +193,7 @@ def gen_fastenhancer(ref: str, name: str, out_dir: str):
         wav = np.pad(wav, ((0, 0), (0, N)))
         with torch.no_grad():
             cache_stft, cache_istft = onnx_model.stft.initialize_cache(torch.zeros(1, 1))
-            h = [torch.zeros(1, cfg.rf_freq, cfg.rf_channels) for _ in range(cfg.rf_blocks)]
+            h = model_caches(1)
             chunks = []
             for idx in range(0, length + N - H, H):
                 wav_in = torch.from_numpy(wav[:, idx:idx + H])
