@@ -62,6 +62,8 @@ WORKLOADS = {
                  desc="FastEnhancer_M 16kHz"),
     "fe_l": dict(C1=128, ks=(8, 3, 3, 3, 3), C2=96, F2=64, K=5, N=512, H=100, sr=16000, init="linear_fixed",
                  desc="FastEnhancer_L 16kHz"),
+    "fe_tk_b": dict(C1=48, ks=(8, 3, 3), kt=3, C2=36, F2=24, K=3, N=512, H=256, sr=16000, init="linear_fixed",
+                    desc="FastEnhancer_B with a 3-frame causal time kernel (configs/ablation/time_kernel_b.yaml)"),
 }
 
 
@@ -69,6 +71,11 @@ def model_kwargs(w):
     if w.get("bsrnn"):
         return dict(num_channels=w["C"], num_layers=w["L"], bias=True, affine=True, n_fft=w["N"], hop_size=w["H"], win_size=w["N"],
                     window="hann", input_compression=0.3)
+    if w.get("kt"):
+        kw = model_kwargs({k: v for k, v in w.items() if k != "kt"})
+        del kw["kernel_size"], kw["resnet"]
+        kw.update(kernel_size_freq=list(w["ks"]), kernel_size_time=w["kt"], final_scale=True)
+        return kw
     return dict(channels=w["C1"], kernel_size=list(w["ks"]), stride=4,
                 rnnformer_kwargs=dict(num_blocks=w["K"], channels=w["C2"], freq=w["F2"], num_heads=4, eps=1e-5,
                                       positional_embedding="train", attn_bias=False, post_act=False, pre_norm=False),
@@ -194,6 +201,9 @@ def main():
     if w.get("bsrnn"):
         from fastenhancer_amd.config import BSRNNConfig
         cfg = BSRNNConfig.from_model_kwargs(**kw)
+    elif w.get("kt"):
+        from fastenhancer_amd.config import time_kernel_config
+        cfg = time_kernel_config(**kw)
     else:
         cfg = FEConfig.from_model_kwargs(**kw)
     eng = Engine(cfg, dev)
@@ -312,7 +322,7 @@ def main():
                          "flops_per_frame": eng.flops_per_frame,
                          "hbm_frac": (B * T * (2 * H * 4) + 2 * 4 * eng.state_floats(B)) / (kernel_ms * 1e-3) / 8e12},
         }
-        if world == 1 and not args.no_cpu_baseline and not w.get("bsrnn"):
+        if world == 1 and not args.no_cpu_baseline and not w.get("bsrnn") and not w.get("kt"):
             res["cpu_baseline"] = cpu_baseline(args.workload, kw, w["sr"], B, args.cpu_budget_s)
         print(json.dumps(res), flush=True)
     if use_dist:

@@ -25,6 +25,14 @@ class FEConfig:
     weight_norm: bool = False
     normalize_final_conv: bool = False
     pre_post_init: Optional[str] = None
+    # `model: fastenhancer.time_kernel` (models/fastenhancer/time_kernel/model.py): the k = 3 convs of the encoder / decoder
+    # are causal Conv2d with kernel_size_time taps over time and (kernel_size_time - 1)-frame input caches; 1 = the default model
+    kernel_size_time: int = 1
+    final_scale_exp: bool = False        # final_scale: "exp" (the final conv's scale parameter is stored as its log)
+
+    @property
+    def time_kernel(self) -> bool:
+        return self.kernel_size_time > 1
 
     @property
     def F0(self) -> int:
@@ -102,6 +110,28 @@ class FEConfig:
             input_compression=float(input_compression), weight_norm=bool(weight_norm),
             normalize_final_conv=bool(normalize_final_conv), pre_post_init=pre_post_init,
         )
+
+
+def time_kernel_config(channels: int = 64, kernel_size_freq: Sequence[int] = (8, 3, 3), kernel_size_time: int = 3, stride: int = 4,
+                       rnnformer_kwargs: Optional[Dict[str, Any]] = None, activation: str = "ReLU",
+                       activation_kwargs: Optional[Dict[str, Any]] = None, n_fft: int = 512, hop_size: int = 160,
+                       win_size: int = 400, window: Optional[str] = "povey", stft_normalized: bool = False,
+                       mask: Optional[str] = None, input_compression: float = 0.25, weight_norm: bool = False,
+                       final_scale: Any = "exp", normalize_final_conv: bool = False,
+                       pre_post_init: Optional[str] = None) -> FEConfig:
+    """yaml model_kwargs of `model: fastenhancer.time_kernel` (configs/ablation/time_kernel_b.yaml:2-29; defaults of
+    models/fastenhancer/time_kernel/model.py:503-524) -> FEConfig with kernel_size_time set."""
+    if final_scale not in (True, False, "exp"):
+        raise AssertionError(f"final_scale={final_scale}")
+    if int(kernel_size_time) < 1:
+        raise AssertionError(f"kernel_size_time={kernel_size_time}")
+    base = FEConfig.from_model_kwargs(channels=channels, kernel_size=kernel_size_freq, stride=stride, rnnformer_kwargs=rnnformer_kwargs,
+                                      activation=activation, activation_kwargs=activation_kwargs, n_fft=n_fft, hop_size=hop_size,
+                                      win_size=win_size, window=window, stft_normalized=stft_normalized, mask=mask,
+                                      input_compression=input_compression, weight_norm=weight_norm,
+                                      normalize_final_conv=normalize_final_conv, pre_post_init=pre_post_init, resnet=False)
+    import dataclasses
+    return dataclasses.replace(base, kernel_size_time=int(kernel_size_time), final_scale_exp=(final_scale == "exp"))
 
 
 BSRNN_SUBBANDS = (2,) + (3,) * 10 + (8,) * 12 + (16,) * 7 + (17,)     # models/bsrnn/model.py:107-111

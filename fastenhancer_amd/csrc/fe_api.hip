@@ -44,6 +44,7 @@ struct Section {
 struct Dims {
     int C1, NL, C2, F2, KB, NFFT, HOP, F0, F1, HD;
     int ks[FE_MAX_KERNELS];
+    int KT = 1;                // kernel_size_time (time_kernel variant)
 };
 
 // ---------------------------------------------------------------------------- dispatch table
@@ -110,7 +111,8 @@ void build_sections(fe_handle* h) {
     add_section(h, "enc_pre.0.weight", {d.C1, 8, 2});
     add_section(h, "enc_pre.0.bias", {d.C1});
     for (int i = 0; i < d.NL; ++i) {
-        snprintf(nm, sizeof nm, "encoder.%d.0.weight", i); add_section(h, nm, {d.C1, d.C1, 3});
+        snprintf(nm, sizeof nm, "encoder.%d.0.weight", i);
+        if (d.KT > 1) add_section(h, nm, {d.C1, d.C1, d.KT, 3}); else add_section(h, nm, {d.C1, d.C1, 3});
         snprintf(nm, sizeof nm, "encoder.%d.0.bias", i); add_section(h, nm, {d.C1});
     }
     add_section(h, "rf_pre.0.weight", {d.F2, d.F1});
@@ -135,7 +137,8 @@ void build_sections(fe_handle* h) {
     for (int i = 0; i < d.NL; ++i) {
         snprintf(nm, sizeof nm, "decoder.%d.0.weight", i); add_section(h, nm, {d.C1, 2 * d.C1, 1});
         snprintf(nm, sizeof nm, "decoder.%d.0.bias", i); add_section(h, nm, {d.C1});
-        snprintf(nm, sizeof nm, "decoder.%d.2.weight", i); add_section(h, nm, {d.C1, d.C1, 3});
+        snprintf(nm, sizeof nm, "decoder.%d.2.weight", i);
+        if (d.KT > 1) add_section(h, nm, {d.C1, d.C1, d.KT, 3}); else add_section(h, nm, {d.C1, d.C1, 3});
         snprintf(nm, sizeof nm, "decoder.%d.2.bias", i); add_section(h, nm, {d.C1});
     }
     add_section(h, "dec_post.0.weight", {d.C1, 2 * d.C1, 1});
@@ -214,8 +217,15 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
     p.buf.assign((size_t)o.total, 0.0f);
     char nm[128];
     auto S = [&](const std::string& n) { return sec(h, blob, n); };
-    auto pack_k3 = [&](int off, const float* w) {   // (Co, Ci, 3): k = tap*Ci + ci
-        p.pack_b(off, 3 * C1, C1, [&](int k, int n) { return w[(n * C1 + (k % C1)) * 3 + (k / C1)]; });
+    // (Co, Ci, 3), or (Co, Ci, KT, 3) for the time_kernel variant: one B operand per time tap, k = freq_tap*Ci + ci.
+    // Units are in consumption order: unit 0 multiplies the CURRENT frame = time index KT-1 of the causal kernel, unit j the
+    // frame j steps back = time index KT-1-j
+    const int KT = d.KT;
+    auto pack_k3 = [&](const int* offs, const float* w) {
+        for (int j = 0; j < KT; ++j) {
+            const int dt = KT - 1 - j;
+            p.pack_b(offs[j], 3 * C1, C1, [&](int k, int n) { return w[((size_t)(n * C1 + (k % C1)) * KT + dt) * 3 + (k / C1)]; });
+        }
     };
     auto pack_1x1 = [&](int off, const float* w, int Ci, int Co) {   // (Co, Ci[,1]): B[k=ci][n=co]
         p.pack_b(off, Ci, Co, [&](int k, int n) { return w[n * Ci + k]; });
@@ -226,7 +236,7 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
         p.rep4(o.enc_pre_b, C1, S("enc_pre.0.bias"));
     }
     for (int i = 0; i < d.NL; ++i) {
-        snprintf(nm, sizeof nm, "encoder.%d.0.weight", i); pack_k3(o.enc_w[i], S(nm));
+        snprintf(nm, sizeof nm, "encoder.%d.0.weight", i); pack_k3(&o.enc_w[i * KT], S(nm));
         snprintf(nm, sizeof nm, "encoder.%d.0.bias", i); p.rep4(o.enc_b[i], C1, S(nm));
     }
     {   // rf_pre: Linear (F2, F1) as A operand, then 1x1 conv (C2, C1)
@@ -295,7 +305,7 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
         snprintf(nm, sizeof nm, "decoder.%d.0.weight", i); pack_1x1(o.dec1_w[i], S(nm), 2 * C1, C1);
         snprintf(nm, sizeof nm, "decoder.%d.0.bias", i); p.rep4(o.dec1_b[i], C1, S(nm));
         }
-        snprintf(nm, sizeof nm, "decoder.%d.2.weight", i); pack_k3(o.dec3_w[i], S(nm));
+        snprintf(nm, sizeof nm, "decoder.%d.2.weight", i); pack_k3(&o.dec3_w[i * KT], S(nm));
         snprintf(nm, sizeof nm, "decoder.%d.2.bias", i); p.rep4(o.dec3_b[i], C1, S(nm));
     }
     pack_1x1(o.post1_w, S("dec_post.0.weight"), 2 * C1, C1);
@@ -637,20 +647,22 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
     if (!(cfg->input_compression > 0.0f && cfg->input_compression <= 1.0f)) return fail(FE_ERR_INVALID_ARG, "input_compression");
 
     const fe::Impl* impl = nullptr;
+    const int kt = cfg->kernel_size_time > 1 ? cfg->kernel_size_time : 1;
     for (const fe::Impl* im : impls())
         if (im->C1 == cfg->channels && im->NL == cfg->n_kernels - 1 && im->C2 == cfg->rf_channels && im->F2 == cfg->rf_freq &&
-            im->KB == cfg->rf_blocks && im->NFFT == cfg->n_fft && im->HOP == cfg->hop_size)
+            im->KB == cfg->rf_blocks && im->NFFT == cfg->n_fft && im->HOP == cfg->hop_size && im->KT == kt)
             impl = im;
     if (!impl)
         return fail(FE_ERR_UNSUPPORTED_CONFIG,
-                    "no kernel compiled for channels=%d layers=%d rf_channels=%d rf_freq=%d rf_blocks=%d n_fft=%d hop=%d",
-                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size);
+                    "no kernel compiled for channels=%d layers=%d rf_channels=%d rf_freq=%d rf_blocks=%d n_fft=%d hop=%d kernel_size_time=%d",
+                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, kt);
     if (impl->lds_bytes > 160 * 1024)
         return fail(FE_ERR_UNSUPPORTED_CONFIG, "shape needs %zu bytes of LDS (> 160 KiB per CU)", impl->lds_bytes);
     fe_handle* h = new fe_handle();
     h->cfg = *cfg;
     h->impl = impl;
     h->d = Dims{impl->C1, impl->NL, impl->C2, impl->F2, impl->KB, impl->NFFT, impl->HOP, impl->NFFT / 2, impl->NFFT / 8, impl->C2 / 4, {0}};
+    h->d.KT = impl->KT;
     for (int i = 0; i < cfg->n_kernels; ++i) h->d.ks[i] = cfg->kernel_size[i];
     if (hipGetDevice(&h->device) != hipSuccess) h->device = -1;   // no GPU: sections/tables still usable
     else {
@@ -703,11 +715,17 @@ int fe_load_weights(fe_handle* h, const float* blob_dev, size_t nfloats, void* s
     return FE_OK;
 }
 
+// time_kernel variant: floats of the causal convs' frame caches per stream (2 NL layers x [KT-1][F1][C1])
+static size_t tk_floats(const fe_handle* h) {
+    const Dims& d = h->d;
+    return h->bimpl ? 0 : (size_t)2 * d.NL * (d.KT - 1) * d.F1 * d.C1;
+}
+
 size_t fe_state_floats(const fe_handle* h, int B) {
     if (!h || B <= 0) return 0;
     const Dims& d = h->d;
     if (h->bimpl) return (size_t)B * 2 * (size_t)(d.NFFT - d.HOP) + bsrnn_lstm_floats(h, B);
-    return (size_t)B * (2 * (size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2);
+    return (size_t)B * (2 * (size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2 + tk_floats(h));
 }
 
 int fe_state_init(fe_handle* h, float* state_dev, int B, void* stream) {
@@ -746,6 +764,7 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
     a.cache_stft = state;
     a.cache_istft = state + (size_t)B * ovl;
     a.h = state + 2 * (size_t)B * ovl;
+    a.tk = a.h + (size_t)d.KB * B * d.F2 * d.C2;
     a.dbg = dbg;
     a.clk = clk;
     a.dbg_stride = h->impl->dbg_floats;
@@ -776,6 +795,7 @@ int fe_profile_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, flo
 // workgroups per stream of a time-pipelined launch (0: one workgroup walks the frames of a stream)
 static int pipe_width(const fe_handle* h, int B, int T) {
     if (!h->impl || h->pipe_frames == 0 || h->pipe_frames == 1 || T < 4 || 2 * B > h->max_wgs) return 0;
+    if (h->d.KT > 1) return 0;     // (the time_kernel convs carry whole input frames from frame to frame: one workgroup walks them)
     // automatic width: a hand-off (counter round trip + state fetch + the h half of the GRU + gates + publish) takes
     // ~2.6 us whatever the model; a frame takes ~4 us per MFLOP/frame at the measured kernel efficiency: that many frames
     // are worth having in flight (measured optimum: T 8-12, B 16, 48 kHz B 24, L > 24), more only adds pollers
@@ -811,6 +831,7 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
     a.spec_in = spec_in_dev;
     a.spec_out = spec_out_dev;
     a.h = h_dev;
+    a.tk = h_dev + (size_t)h->d.KB * B * h->d.F2 * h->d.C2;
     hipError_t e = hipSuccess;
     a.mode = fe::FE_MODE_SPEC;
     if (const int P = pipe_width(h, B, T)) {
@@ -832,7 +853,7 @@ size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw) {
     if (h->bimpl) return (size_t)B * (size_t)(d.NFFT - d.HOP) + bsrnn_lstm_floats(h, B);
     // GRU state (zero initial state, model.py:626-627) + overlap-add tail, both zeroed by fe_offline; time-pipelined
     // launches: + the frame counters [B][KB] and the windowed output frames [B][T][N]
-    size_t n = (size_t)B * ((size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2);
+    size_t n = (size_t)B * ((size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2 + tk_floats(h));
     const int T = 1 + Tw / d.HOP;
     if (pipe_width(h, B, T)) n += (((size_t)B * d.KB + 3) & ~(size_t)3) + (size_t)B * T * d.NFFT;
     return n;
@@ -849,7 +870,7 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
     hipStream_t st = (hipStream_t)stream;
     const int T = 1 + Tw / d.HOP;
     {   // zero the state, the tail and the frame counters (not the frames: every element is written)
-        size_t nz = (size_t)B * ((size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2);
+        size_t nz = (size_t)B * ((size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2 + tk_floats(h));
         if (h->bimpl) nz = fe_offline_work_floats(h, B, Tw);
         else if (pipe_width(h, B, T)) nz += ((size_t)B * d.KB + 3) & ~(size_t)3;
         FE_HIP_CHECK(hipMemsetAsync(work_dev, 0, nz * sizeof(float), st));
@@ -878,6 +899,7 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
     a.cache_istft = work_dev;
     a.cache_stft = work_dev;   // unused in this mode
     a.h = work_dev + (size_t)B * (d.NFFT - d.HOP);
+    a.tk = a.h + (size_t)d.KB * B * d.F2 * d.C2;
     hipError_t e = hipSuccess;
     if (const int P = pipe_width(h, B, T)) {
         rc = ensure_tables(h, st);
@@ -1008,12 +1030,13 @@ double fe_flops_per_frame(const fe_handle* h) {
         return 2.0 * m + 2.0 * 2.5 * d.NFFT * std::log2((double)d.NFFT);
     }
     const double C1 = d.C1, C2 = d.C2, F1 = d.F1, F2 = d.F2, K = d.KB;
+    const double KT = d.KT;
     double m = 2 * C1 * 8 * F1;
-    for (int i = 1; i <= d.NL; ++i) m += C1 * C1 * 3 * F1;
+    for (int i = 1; i <= d.NL; ++i) m += C1 * C1 * 3 * KT * F1;
     m += F1 * F2 * C1 + C1 * C2 * F2;
     m += K * (C2 * C2 * 6 * F2 + C2 * C2 * F2 + C2 * C2 * 3 * F2 + 2 * F2 * C2 * F2 + C2 * C2 * F2);
     m += F2 * F1 * C2 + C2 * C1 * F1;
-    for (int i = 1; i <= d.NL; ++i) m += 2 * C1 * C1 * F1 + C1 * C1 * 3 * F1;
+    for (int i = 1; i <= d.NL; ++i) m += 2 * C1 * C1 * F1 + C1 * C1 * 3 * KT * F1;
     m += 2 * C1 * C1 * F1 + C1 * 2 * 8 * F1;
     return 2.0 * m + 2.0 * 2.5 * d.NFFT * std::log2((double)d.NFFT);
 }

@@ -44,10 +44,12 @@ __host__ __device__ constexpr int ceil_div(int a, int b) { return (a + b - 1) / 
 __host__ __device__ constexpr int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
 // ------------------------------------------------------------------------------------------
-// Compile-time shape of one model (the yaml model_kwargs).  NL = len(kernel_size)-1.
-template <int C1_, int NL_, int C2_, int F2_, int KB_, int NFFT_, int HOP_>
+// Compile-time shape of one model (the yaml model_kwargs).  NL = len(kernel_size)-1.  KT = kernel_size_time of the
+// `fastenhancer.time_kernel` variant (models/fastenhancer/time_kernel/model.py: the k = 3 convs are causal Conv2d with KT
+// taps over time); KT = 1 is the default model.
+template <int C1_, int NL_, int C2_, int F2_, int KB_, int NFFT_, int HOP_, int KT_ = 1>
 struct Shape {
-    static constexpr int C1 = C1_, NL = NL_, C2 = C2_, F2 = F2_, KB = KB_, NFFT = NFFT_, HOP = HOP_;
+    static constexpr int C1 = C1_, NL = NL_, C2 = C2_, F2 = F2_, KB = KB_, NFFT = NFFT_, HOP = HOP_, KT = KT_;
     static constexpr int NH = 4;
     static constexpr int HD = C2 / NH;
     static constexpr int F0 = NFFT / 2;
@@ -74,7 +76,14 @@ struct Shape {
     // packed-weight sizes (floats)
     static constexpr int KS_C = C1 / 4;           // k-steps over C1
     static constexpr int KS_2 = C2 / 4;           // k-steps over C2
-    static constexpr int NU = 6 + 3 * NL;        // LDS-staged weight units (Pack<S>)
+    static constexpr int NU = 6 + NL * (2 * KT + 1);   // LDS-staged weight units (Pack<S>): a k = 3 conv is one unit per time tap
+    // unit indices in consumption order
+    static constexpr int U_ENC = 1;                                  // + l * KT + tap
+    static constexpr int U_RFPRE = 1 + NL * KT;                      // filterbank, then the 1x1
+    static constexpr int U_RFPOST = 3 + NL * KT;
+    static constexpr int U_DEC = 4 + NL * KT;                        // + l * (KT + 1): the 1x1, then + 1 + tap: the k = 3 conv
+    static constexpr int U_POST = 4 + NL * (2 * KT + 1);             // dec_post 1x1, then the transposed conv
+    static constexpr int TKQ = (KT - 1) * (F0 / 4) * C1;             // floats of one conv's frame cache per stream: [KT-1][F1][C1]
     // RNNFormer-block weight fragments held in registers per wave (this wave's column tiles)
     static constexpr int NTPW2 = ceil_div(NT2, kWaves), NTPW3 = ceil_div(NT3, kWaves);
     // "flat" GRU gate GEMM: C2 not a multiple of 16 (T: 20, B: 36) pads every gate to whole column tiles (B: 3 x 48
@@ -93,14 +102,14 @@ struct Shape {
 // kernel, where every offset folds into an instruction immediate / one SGPR add.
 struct PackedOffsets {
     int enc_pre_w, enc_pre_b;
-    int enc_w[8], enc_b[8];
+    int enc_w[16], enc_b[8];            // enc_w / dec3_w: [layer * KT + tap], taps in consumption order (tap 0 = the current frame)
     int rfpre_lin, rfpre_w, rfpre_b;
     int blk_pe;                        // block 0 only, [F2][C2]
     int blk_stride;                    // offset of block k+1's arrays minus block k's
     int blk_wih[8], blk_bih[8], blk_whh[8], blk_bhh[8];
     int blk_fc1_w[8], blk_fc1_b[8], blk_qkv[8], blk_fc2_w[8], blk_fc2_b[8];
     int rfpost_lin, rfpost_w, rfpost_b;
-    int dec1_w[8], dec1_b[8], dec3_w[8], dec3_b[8];
+    int dec1_w[8], dec1_b[8], dec3_w[16], dec3_b[8];
     int post1_w, post1_b, post_t_w, post_t_b;
     int window, window_istft, twiddle;  // [N], [N], [N/2] float2
     int dft1, dft2, dft3, dft4;         // constant operands of the matrix-core DFT (see Dft<S>)
@@ -127,7 +136,12 @@ struct Pack {
         // conv-type biases are stored 4x replicated ([channel][4]): one 16-byte read initialises the four accumulator
         // rows of a lane - replicating in registers costs three v_mov per tile, and VALU work is never hidden here
         ubegin(); o.enc_pre_w = alloc(szB(16, C1)); o.enc_pre_b = alloc(4 * szBias(C1)); uend();
-        for (int l = 0; l < S::NL; ++l) { ubegin(); o.enc_w[l] = alloc(szB(3 * C1, C1)); o.enc_b[l] = alloc(4 * szBias(C1)); uend(); }
+        for (int l = 0; l < S::NL; ++l)
+            for (int tp = 0; tp < S::KT; ++tp) {
+                ubegin(); o.enc_w[l * S::KT + tp] = alloc(szB(3 * C1, C1));
+                if (tp == 0) o.enc_b[l] = alloc(4 * szBias(C1));
+                uend();
+            }
         ubegin(); o.rfpre_lin = alloc(szA(F2, F1)); uend();
         ubegin(); o.rfpre_w = alloc(szB(C1, C2)); o.rfpre_b = alloc(4 * szBias(C2)); uend();
         ubegin(); o.rfpost_lin = alloc(szA(F1, F2)); uend();
@@ -135,7 +149,11 @@ struct Pack {
         //  filterbank output - dec1_w[0] holds (C2 + C1) x C1; the plain copy below only serves the debug dump)
         for (int l = 0; l < S::NL; ++l) {
             ubegin(); o.dec1_w[l] = alloc(szB(2 * C1, C1)); o.dec1_b[l] = alloc(4 * szBias(C1)); uend();
-            ubegin(); o.dec3_w[l] = alloc(szB(3 * C1, C1)); o.dec3_b[l] = alloc(4 * szBias(C1)); uend();
+            for (int tp = 0; tp < S::KT; ++tp) {
+                ubegin(); o.dec3_w[l * S::KT + tp] = alloc(szB(3 * C1, C1));
+                if (tp == 0) o.dec3_b[l] = alloc(4 * szBias(C1));
+                uend();
+            }
         }
         ubegin(); o.post1_w = alloc(szB(2 * C1, C1)); o.post1_b = alloc(4 * szBias(C1)); uend();
         ubegin(); o.post_t_w = alloc(szB(C1, 16)); o.post_t_b = alloc(szBias(2)); uend();
@@ -175,6 +193,7 @@ struct FrameArgs {
     float* cache_stft;        // [B][OVL]
     float* cache_istft;       // [B][OVL]
     float* h;                 // [KB][B*F2][C2]
+    float* tk;                // time_kernel variant: the causal convs' frame caches [2 NL][B][KT-1][F1][C1] (encoder layers, then decoder)
     float* skip;              // global skip scratch [B][(NL+1)][F1*C1] (A-fragment order), shapes with !Lds::SKIPS_LDS
     const float* spec_in;     // spec mode: [B][F0+1][T][2]
     float* spec_out;
@@ -582,7 +601,12 @@ struct Lds {
     static constexpr bool STAGED = (size_t)(NOSTAGE_TOTAL + 2 * Pack<S>::umax()) * 4 <= 160 * 1024;
     static constexpr int WB0 = NOSTAGE_TOTAL;
     static constexpr int WB1 = WB0 + Pack<S>::umax();
-    static constexpr int TOTAL = STAGED ? NOSTAGE_TOTAL + 2 * Pack<S>::umax() : NOSTAGE_TOTAL;
+    static constexpr int TOTAL_KT1 = STAGED ? NOSTAGE_TOTAL + 2 * Pack<S>::umax() : NOSTAGE_TOTAL;
+    // time_kernel variant: the previous KT-1 input frames of the conv being computed, activation layout with halo rows
+    static constexpr int CA = TOTAL_KT1;
+    static constexpr int TOTAL = TOTAL_KT1 + (S::KT - 1) * S::ACT;
+    static_assert(S::KT == 1 || (STAGED && SKIPS_LDS), "the time_kernel variant is built for shapes with staged weights and LDS-resident skips");
+    static_assert((size_t)TOTAL * 4 <= 160 * 1024, "LDS plan exceeds 160 KiB");
     // software-pipeline depth of the fine-grained MFMA panels: with staged conv weights (and then register-resident
     // block weights) every operand comes from LDS / registers, ~130 cycles away: 3 k-steps ahead is enough and a
     // shorter pipeline fill after each barrier is worth 4.7 % on FastEnhancer_B (8 / 6 / 4 / 3 / 2 measured);
@@ -1115,6 +1139,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             smem[L::E + e * S::ACT + (q >= LDC ? (F1 + 1) * LDC + (q - LDC) : q)] = 0.0f;
         }
     }
+    if constexpr (S::KT > 1) {                       // frame-cache arena: its halo rows must read as zero
+        for (int i = tid; i < (S::KT - 1) * S::ACT; i += kThreads) smem[L::CA + i] = 0.0f;
+    }
     float2* tw = reinterpret_cast<float2*>(smem + L::TW);
     for (int i = tid; i < N / 2; i += kThreads) tw[i] = reinterpret_cast<const float2*>(wp + o.twiddle)[i];
     float* sc = smem + L::SC;
@@ -1351,6 +1378,61 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         __syncthreads();
         dbg_dump<S>(a, b, 2, encbuf(0) + LDC, LDC);
 
+        // ---- time_kernel variant (CausalConv2d, models/fastenhancer/time_kernel/model.py:119-148): a k = 3 conv over frequency
+        // with KT taps over time = KT staged sub-phases accumulating into the same registers.  Tap 0 reads the current
+        // frame (`in`, already in LDS); meanwhile the conv's cache - its input of the previous KT-1 frames, [KT-1][F1][C1]
+        // per stream in the state - streams from HBM into registers (in flight under tap 0's MFMAs), is parked in the
+        // cache arena (activation layout) and feeds taps 1 .. KT-1.  The new cache (old slots shifted by one, this
+        // frame's input appended) is written back from the same registers / from `in`.
+        auto k3_time = [&](auto u0_, const float* in, float* out, int lidx, const int* w_off, int b_off) {
+            if constexpr (S::KT > 1) {
+            constexpr int U0 = decltype(u0_)::value;
+            constexpr int KT = S::KT, Q4 = F1 * C1 / 4;          // float4s per cache slot
+            constexpr int CPT = (KT - 1) * Q4 / kThreads, NPT = Q4 / kThreads;
+            static_assert(Q4 % kThreads == 0, "cache slots are moved by whole float4 rounds");
+            float* CAb = smem + L::CA;
+            float4* tkg = reinterpret_cast<float4*>(a.tk + ((size_t)lidx * a.B + b) * S::TKQ);
+            f32x4 acc[S::MTPW][S::NTC];
+            float4 creg[CPT];
+            static_for<KT>([&](auto s_) {
+                constexpr int sub = decltype(s_)::value;
+                FE_BEGIN_UNIT(U0 + sub);
+                if constexpr (sub == 0) {
+                    acc_init_bias<S::MTPW, S::NTC>(acc, wb, b_off, 0, 1, S::NTC);
+#pragma unroll
+                    for (int q = 0; q < CPT; ++q) creg[q] = tkg[tid + q * kThreads];
+                }
+                const float* src = sub == 0 ? in : CAb + (KT - 1 - sub) * S::ACT;     // tap 1 <-> frame t-1 = the newest slot
+                const float* const taps[3] = {src + (16 * wave + li + 0) * LDC + lg, src + (16 * wave + li + 1) * LDC + lg,
+                                              src + (16 * wave + li + 2) * LDC + lg};
+                conv_multi<S, S::NTC, 3, S::KS_C, LDC>(acc, taps, wb, w_off[sub], stage);
+                stage.commit();
+                if constexpr (sub == 0) {
+#pragma unroll
+                    for (int q = 0; q < CPT; ++q) {
+                        const int e4 = tid + q * kThreads, slot = e4 / Q4, r = e4 - slot * Q4;
+                        const int f = (4 * r) / C1, c = 4 * r - f * C1;
+                        float2* d2 = reinterpret_cast<float2*>(CAb + slot * S::ACT + (f + 1) * LDC + c);      // (rows are 8-byte aligned)
+                        // (the state holds the reference's activations; the conv trunk works on them scaled by kSiluScale)
+                        d2[0] = make_float2(creg[q].x * kSiluScale, creg[q].y * kSiluScale);
+                        d2[1] = make_float2(creg[q].z * kSiluScale, creg[q].w * kSiluScale);
+                        if (slot >= 1) tkg[e4 - Q4] = creg[q];                     // shift: slot j <- old slot j + 1
+                    }
+#pragma unroll
+                    for (int q = 0; q < NPT; ++q) {                                 // newest slot <- this frame's input
+                        const int r = tid + q * kThreads, f = (4 * r) / C1, c = 4 * r - f * C1;
+                        const float2* s2 = reinterpret_cast<const float2*>(in + (f + 1) * LDC + c);
+                        const float2 v0 = s2[0], v1 = s2[1];
+                        constexpr float un = 1.0f / kSiluScale;
+                        tkg[(KT - 2) * Q4 + r] = make_float4(v0.x * un, v0.y * un, v1.x * un, v1.y * un);
+                    }
+                }
+                if constexpr (sub + 1 < KT) __syncthreads();
+            });
+            conv_store<S, S::NTC, C1, LDC, true>(acc, out, 1, wave, lane);
+            }
+        };
+
         FE_CLK(4);
         // =========================== encoder (a6): k=3 convs ===========================
         static_for<S::NL>([&](auto l_) {
@@ -1358,7 +1440,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             const float* in = encbuf(l);
             float* out = encbuf(l + 1);
             if (l == 0) FE_CLK(40);
-            FE_BEGIN_UNIT(1 + l);
+            if constexpr (S::KT > 1) {
+                k3_time(std::integral_constant<int, S::U_ENC + l * S::KT>{}, in, out, l, &o.enc_w[l * S::KT], o.enc_b[l]);
+            } else {
+            FE_BEGIN_UNIT(S::U_ENC + l);
             if constexpr (NSPLIT) {
                 const float* a0 = in + li * LDC + lg;
                 conv_nsplit<S, NS, 3 * S::KS_C, C1, LDC, true>(
@@ -1375,6 +1460,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             if (l == 0) FE_CLK(41);
             stage.commit();
             conv_store<S, S::NTC, C1, LDC, true>(acc, out, 1, wave, lane, SG ? skipg + (l + 1) * SKIP_FLOATS : nullptr);
+            }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (l == 0) FE_CLK(42);
@@ -1427,7 +1513,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             constexpr int NTPW = ceil_div(S::NTC, kWaves);
             constexpr int KS = F1 / 4;
             const float* Ein = encbuf(S::NL) + LDC;   // row 0 = bin 0
-            FE_BEGIN_UNIT(1 + S::NL);
+            FE_BEGIN_UNIT(S::U_RFPRE);
             Wgi.bind(wb, o.blk_wih[0], o.blk_bih[0], GNT, wave);      // block 0's GRU input weights ride in this GEMM
             f32x4 acc[S::MT2][NTPW];
             acc_init_zero<S::MT2, NTPW>(acc);
@@ -1456,7 +1542,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         {
             // X[f2][c2] = Y1[f2][:] . Wc[c2][:] + b
             constexpr int NTPW = ceil_div(S::NT2, kWaves);
-            FE_BEGIN_UNIT(2 + S::NL);
+            FE_BEGIN_UNIT(S::U_RFPRE + 1);
             Wgh.bind(wb, o.blk_whh[0], o.blk_bhh[0], GNT, wave);      // ... and the hidden weights in this one
             // hidden state of block 0: fetched now, parked in LDS after the GEMM
             float hpre[HPT];
@@ -1878,7 +1964,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         {
             // Y2[f1][c2] = sum_f2 Wp[f1][f2] X[f2][c2]      (A packed, B = LDS tokens)
             constexpr int KS = F2 / 4;
-            FE_BEGIN_UNIT(3 + S::NL);
+            FE_BEGIN_UNIT(S::U_RFPOST);
             f32x4 acc[S::MTPW][S::NT2];
             acc_init_zero<S::MTPW, S::NT2>(acc);
             mma_panel<S::MTPW, S::NT2, KS, Lds<S>::PDK>(
@@ -1917,7 +2003,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             {
                 // 1x1 conv on cat([x, skip]): two K-segments, never materialised.  Layer 0: x = rf_post's filterbank
                 // output Y2 [F1][C2] with rf_post's 1x1 folded into this layer's weights; later layers: x = Wx [F1][C1].
-                FE_BEGIN_UNIT(4 + S::NL + 2 * l);
+                FE_BEGIN_UNIT(S::U_DEC + l * (S::KT + 1));
                 constexpr int K0 = (l == 0) ? S::KS_2 : S::KS_C;       // k-steps of the x segment
                 constexpr int LD0 = (l == 0) ? LDX : LDC;
                 if constexpr (NSPLIT) {
@@ -1948,8 +2034,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 }
             }
             __syncthreads();
-            {
-                FE_BEGIN_UNIT(5 + S::NL + 2 * l);
+            if constexpr (S::KT > 1) {
+                k3_time(std::integral_constant<int, S::U_DEC + l * (S::KT + 1) + 1>{}, Wy, Wx, S::NL + l, &o.dec3_w[l * S::KT], o.dec3_b[l]);
+            } else {
+                FE_BEGIN_UNIT(S::U_DEC + l * (S::KT + 1) + 1);
                 if constexpr (NSPLIT) {
                     const float* a0 = Wy + li * LDC + lg;
                     conv_nsplit<S, NS, 3 * S::KS_C, C1, LDC, true>(
@@ -1973,7 +2061,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         // =========================== dec_post (a15) ===========================
         float* PT = smem + L::PT;
         {
-            FE_BEGIN_UNIT(4 + 3 * S::NL);
+            FE_BEGIN_UNIT(S::U_POST);
             if constexpr (NSPLIT) {
                 const float* xa0 = Wx + (li + 1) * LDC + lg;
                 const float* sk0 = Ebuf + (li + 1) * LDC + lg;
@@ -2005,7 +2093,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         __syncthreads();
         {
             // transposed conv as GEMM: P[i][co*8+j] = sum_ci x[i][ci] w[ci][co][j]
-            FE_BEGIN_UNIT(5 + 3 * S::NL);
+            FE_BEGIN_UNIT(S::U_POST + 1);
             f32x4 acc[S::MTPW][1];
             acc_init_zero<S::MTPW, 1>(acc);
             conv_seg<S, 1, S::KS_C, S::KS_C, LDC>(acc, Wy + (16 * wave + li + 1) * LDC + lg, wb, o.post_t_w, stage);

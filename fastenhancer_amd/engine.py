@@ -46,6 +46,7 @@ class Engine:
                 c.kernel_size[i] = k
             c.stride = cfg.stride
             c.rf_channels, c.rf_freq, c.rf_blocks, c.rf_heads = cfg.rf_channels, cfg.rf_freq, cfg.rf_blocks, cfg.rf_heads
+            c.kernel_size_time = cfg.kernel_size_time
         self._h = c_void_p()
         if self.device is not None and self.device.type == "cuda":
             with torch.cuda.device(self.device):
@@ -127,13 +128,35 @@ class Engine:
                 o += n
             return out
         n = B * c.rf_freq * c.rf_channels
+        hs = []
         for _ in range(c.rf_blocks):
-            out.append(state[o:o + n].view(1, B * c.rf_freq, c.rf_channels))
+            hs.append(state[o:o + n].view(1, B * c.rf_freq, c.rf_channels))
             o += n
-        return out
+        if not c.time_kernel:
+            return out + hs
+        # time_kernel variant: the causal convs' frame caches, kept as [B, kt-1, F1, C1]; the reference tensors
+        # (B, C1, kt-1, F1) are permuted views of them, and its cache list is encoder caches, GRU states, decoder caches
+        # (models/fastenhancer/time_kernel/model.py:746-754)
+        tk = []
+        n = B * (c.kernel_size_time - 1) * c.F1 * c.channels
+        for _ in range(2 * c.n_layers):
+            tk.append(state[o:o + n].view(B, c.kernel_size_time - 1, c.F1, c.channels).permute(0, 3, 1, 2))
+            o += n
+        return out + tk[:c.n_layers] + hs + tk[c.n_layers:]
+
+    def model_state_order(self, caches: List[Tensor]) -> List[Tensor]:
+        """the model's cache list (reference order) -> flat pieces in the order of the C ABI state (h ..., then the conv caches)"""
+        c = self.cfg
+        if self.is_bsrnn or not c.time_kernel:
+            return [t.reshape(-1) for t in caches]
+        nl, K = c.n_layers, c.rf_blocks
+        assert len(caches) == 2 * nl + K, f"expected {2 * nl + K} caches, got {len(caches)}"
+        conv = lambda t: t.permute(0, 2, 3, 1).reshape(-1)          # (B, C1, kt-1, F1) -> [B, kt-1, F1, C1]
+        return [t.reshape(-1) for t in caches[nl:nl + K]] + [conv(t) for t in caches[:nl]] + [conv(t) for t in caches[nl + K:]]
 
     def pack_state(self, caches: List[Tensor], B: int) -> Tensor:
-        return torch.cat([t.reshape(-1).to(torch.float32) for t in caches]).contiguous()
+        pieces = [t.reshape(-1) for t in caches[:2]] + self.model_state_order(list(caches[2:]))
+        return torch.cat([t.to(torch.float32) for t in pieces]).contiguous()
 
     # ------------------------------------------------------------------ compute
     def step(self, wav_in: Tensor, state: Tensor, wav_out: Optional[Tensor] = None, T: int = 1) -> Tensor:
@@ -154,11 +177,17 @@ class Engine:
         """fe_set_time_pipeline: workgroups per stream in offline / spec launches with T >= 4 (0 = one workgroup per stream)."""
         _lib.check(self.lib.fe_set_time_pipeline(self._h, int(frames_in_flight)), "fe_set_time_pipeline")
 
+    def model_state_floats(self, B: int) -> int:
+        """floats of the model's own caches (fe_spec_step's h_dev): the state without the two STFT caches"""
+        return self.state_floats(B) - 2 * B * self.cfg.cache_len
+
     def spec_step(self, spec: Tensor, h: Tensor) -> Tensor:
-        """spec [B, N/2+1, T, 2], h [K, B*F2, C2] (in place) -> spec_hat [B, N/2+1, T, 2]."""
+        """spec [B, N/2+1, T, 2], h = the model caches in C ABI order (K x [B*F2, C2]; time_kernel: + the conv caches),
+        updated in place -> spec_hat [B, N/2+1, T, 2]."""
         self._require_gpu()
         B, Fb, T, two = spec.shape
         assert Fb == self.cfg.F0 + 1 and two == 2 and spec.is_contiguous() and h.is_contiguous()
+        assert h.numel() == self.model_state_floats(B), (h.numel(), self.model_state_floats(B))
         out = torch.empty_like(spec)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.fe_spec_step(self._h, _ptr(spec), _ptr(h), _ptr(out), B, T, _stream(self.device)), "fe_spec_step")

@@ -25,8 +25,9 @@ from ....weights import default_state_dict, fold_state_dict
 
 
 class ONNXModel:
-    def __init__(self, **model_kwargs):
-        self.cfg = FEConfig.from_model_kwargs(**model_kwargs)
+    def __init__(self, _cfg: tp.Optional[FEConfig] = None, **model_kwargs):
+        # (_cfg: a ready FEConfig - how the time_kernel variant's mirror, whose yaml keys differ, constructs this class)
+        self.cfg = _cfg if _cfg is not None else FEConfig.from_model_kwargs(**model_kwargs)
         self.input_compression = self.cfg.input_compression
         self.rf_ch, self.rf_freq = self.cfg.rf_channels, self.cfg.rf_freq
         self.stft = self.get_stft()
@@ -88,23 +89,30 @@ class ONNXModel:
 
     # ---- reference API ---------------------------------------------------------------------
     def initialize_cache(self, x: Tensor) -> tp.List[Tensor]:
-        """model.py:614-618, sized for the B = x.size(0) streams of the batch (b-major)."""
-        B = x.size(0)
-        return [torch.zeros(1, B * self.rf_freq, self.rf_ch, dtype=torch.float32, device=x.device)
-                for _ in range(self.cfg.rf_blocks)]
+        """model.py:614-618, sized for the B = x.size(0) streams of the batch (b-major).  (time_kernel variant: + the
+        causal convs' frame caches, in its order encoder / GRU / decoder - time_kernel/model.py:746-754)"""
+        B, c = x.size(0), self.cfg
+        hs = [torch.zeros(1, B * self.rf_freq, self.rf_ch, dtype=torch.float32, device=x.device) for _ in range(c.rf_blocks)]
+        if not c.time_kernel:
+            return hs
+        cc = lambda: [torch.zeros(B, c.channels, c.kernel_size_time - 1, c.F1, dtype=torch.float32, device=x.device) for _ in range(c.n_layers)]
+        return cc() + hs + cc()
 
     def forward(self, spec_noisy: Tensor, *args: Tensor):
         """input/output: [B, n_fft//2+1, T_spec, 2]; returns (spec_hat, *cache_out)  (model.py:677-710).
         Functional like the reference: the caches passed in are not modified."""
         B = spec_noisy.size(0)
-        cfg = self.cfg
+        cfg, eng = self.cfg, self.engine
+        n_caches = cfg.rf_blocks + (2 * cfg.n_layers if cfg.time_kernel else 0)
         if len(args) == 0:
-            h = torch.zeros(cfg.rf_blocks, B * cfg.rf_freq, cfg.rf_channels, dtype=torch.float32, device=spec_noisy.device)
+            h = torch.zeros(eng.model_state_floats(B), dtype=torch.float32, device=eng.device)
         else:
-            assert len(args) == cfg.rf_blocks, f"expected {cfg.rf_blocks} caches, got {len(args)}"
-            h = torch.cat([c.reshape(1, B * cfg.rf_freq, cfg.rf_channels) for c in args], dim=0).contiguous().float()
-        spec_hat = self.engine.spec_step(spec_noisy.contiguous().float(), h)
-        return (spec_hat, *[h[k:k + 1] for k in range(cfg.rf_blocks)])
+            assert len(args) == n_caches, f"expected {n_caches} caches, got {len(args)}"
+            h = torch.cat([t.to(eng.device, torch.float32) for t in eng.model_state_order(list(args))]).contiguous()
+        spec_hat = eng.spec_step(spec_noisy.to(eng.device).contiguous().float(), h)
+        # the updated caches as views of h, in the reference's list order
+        dummy = torch.empty(2 * B * cfg.cache_len, dtype=torch.float32, device=h.device)
+        return (spec_hat, *eng.split_state(torch.cat([dummy, h]), B)[2:])
 
     __call__ = forward
 

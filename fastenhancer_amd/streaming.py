@@ -53,7 +53,7 @@ class StreamingModel:
         for i in (0, 1):
             v = self._views[i]
             if v is not None and len(v) == len(caches) and all(
-                    c.data_ptr() == w.data_ptr() and c.shape == w.shape and c.dtype == w.dtype and c.is_contiguous()
+                    c.data_ptr() == w.data_ptr() and c.shape == w.shape and c.dtype == w.dtype and c.stride() == w.stride()
                     for c, w in zip(caches, v)):
                 return i
         return -1
@@ -71,7 +71,7 @@ class StreamingModel:
         if src >= 0:
             self._buf[dst].copy_(self._buf[src])
         else:
-            torch.cat([t.reshape(-1).to(eng.device, torch.float32) for t in caches], out=self._buf[dst])
+            self._buf[dst].copy_(eng.pack_state([t.to(eng.device) for t in caches], B))
         wav_out = eng.step(wav_in.to(eng.device, torch.float32), self._buf[dst], T=1)
         return (wav_out, *self._views[dst])
 

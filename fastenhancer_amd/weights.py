@@ -40,13 +40,16 @@ def fold_state_dict(sd: Mapping[str, Tensor], cfg: FEConfig) -> Dict[str, Tensor
     """Training-form -> fused-form state_dict (keys of SURVEY.md Appendix A.1 'Fused')."""
     sd = {k: _f32(v) for k, v in sd.items() if torch.as_tensor(v).is_floating_point()}
     if is_fused(sd):
-        return dict(sd)
+        sd = dict(sd)
+        sd.pop("dec_post.2.scale", None)     # (the time_kernel variant's fused state_dict still lists the folded-in scale)
+        return sd
     out: Dict[str, Tensor] = {}
 
     def conv_bn(conv: str, bn: str, dst: str):
         # model.py:548-553: W' = W * gamma/std, b' = beta - mean*gamma/std
         std = (sd[bn + ".running_var"] + BN_EPS).sqrt()
-        out[dst + ".weight"] = sd[conv + ".weight"] * (sd[bn + ".weight"] / std).view(-1, 1, 1)
+        w = sd[conv + ".weight"]           # Conv1d (Co, Ci, k) or - time_kernel variant - Conv2d (Co, Ci, kt, kf)
+        out[dst + ".weight"] = w * (sd[bn + ".weight"] / std).view([-1] + [1] * (w.dim() - 1))
         out[dst + ".bias"] = sd[bn + ".bias"] - sd[bn + ".running_mean"] * sd[bn + ".weight"] / std
 
     conv_bn("enc_pre.0", "enc_pre.1", "enc_pre.0")
@@ -83,6 +86,8 @@ def fold_state_dict(sd: Mapping[str, Tensor], cfg: FEConfig) -> Dict[str, Tensor
     conv_bn("dec_post.0", "dec_post.1", "dec_post.0")
     w = sd["dec_post.3.weight"]
     scale = sd.get("dec_post.3.scale", torch.ones(1))
+    if cfg.final_scale_exp:        # time_kernel/model.py:95 (exp_scale)
+        scale = scale.exp()
     if cfg.normalize_final_conv:   # F.normalize(w, dim=(0,1,2)) * scale, model.py:74-79
         w = w / w.norm().clamp_min(1e-12)
     out["dec_post.2.weight"] = w * scale
@@ -92,12 +97,14 @@ def fold_state_dict(sd: Mapping[str, Tensor], cfg: FEConfig) -> Dict[str, Tensor
 
 def expected_fused_shapes(cfg: FEConfig) -> Dict[str, tuple]:
     C1, C2, F1, F2 = cfg.channels, cfg.rf_channels, cfg.F1, cfg.rf_freq
+    tk, kt = cfg.time_kernel, cfg.kernel_size_time
+    one = (1, 1) if tk else (1,)       # the time_kernel variant's 1x1 convs are Conv2d
     s: Dict[str, tuple] = {"enc_pre.0.weight": (C1, 2 * cfg.stride, cfg.kernel_size[0] // cfg.stride), "enc_pre.0.bias": (C1,)}
     for i in range(cfg.n_layers):
-        s[f"encoder.{i}.0.weight"] = (C1, C1, cfg.kernel_size[i + 1])
+        s[f"encoder.{i}.0.weight"] = (C1, C1, kt, cfg.kernel_size[i + 1]) if tk else (C1, C1, cfg.kernel_size[i + 1])
         s[f"encoder.{i}.0.bias"] = (C1,)
     s["rf_pre.0.weight"] = (F2, F1)
-    s["rf_pre.1.weight"] = (C2, C1, 1)
+    s["rf_pre.1.weight"] = (C2, C1) + one
     s["rf_pre.1.bias"] = (C2,)
     for k in range(cfg.rf_blocks):
         p = f"rf_block.{k}."
@@ -113,12 +120,13 @@ def expected_fused_shapes(cfg: FEConfig) -> Dict[str, tuple]:
         s[p + "attn_fc.weight"] = (C2, C2)
         s[p + "attn_fc.bias"] = (C2,)
     s["rf_post.0.weight"] = (F1, F2)
-    s["rf_post.1.weight"] = (C1, C2, 1)
+    s["rf_post.1.weight"] = (C1, C2) + one
     s["rf_post.1.bias"] = (C1,)
     for i in range(cfg.n_layers):
-        s[f"decoder.{i}.0.weight"] = (C1, 2 * C1, 1)
+        s[f"decoder.{i}.0.weight"] = (C1, 2 * C1) + one
         s[f"decoder.{i}.0.bias"] = (C1,)
-        s[f"decoder.{i}.2.weight"] = (C1, C1, cfg.kernel_size[cfg.n_layers - i])
+        kf = cfg.kernel_size[cfg.n_layers - i]
+        s[f"decoder.{i}.2.weight"] = (C1, C1, kt, kf) if tk else (C1, C1, kf)
         s[f"decoder.{i}.2.bias"] = (C1,)
     s["dec_post.0.weight"] = (C1, 2 * C1, 1)
     s["dec_post.0.bias"] = (C1,)
@@ -160,6 +168,25 @@ def linear_filterbank(n_freq: int, n_filter: int):
     return pre.float().contiguous(), post.float().contiguous()
 
 
+def linear_filterbank_time_kernel(n_freq: int, n_filter: int, sr: int = 16000):
+    """The time_kernel variant's 'linear' / 'linear_fixed' initialisation (models/fastenhancer/time_kernel/model.py:477-489):
+    triangles on Hz axes whose edges have slope 1 / w with w = (sr/2) / n_filter, while their zero crossings sit on the
+    neighbouring centres (spacing s = (sr/2) / (n_filter - 1)): filter i is (s - |f - c_i|) / w, peak s / w > 1, clamped at 0;
+    the first / last filter has no rising / falling edge.  rf_post is the transpose of these UN-normalised triangles; both
+    are then row-normalised."""
+    half = float(sr // 2)
+    centres = torch.linspace(0.0, half, n_filter, dtype=torch.float64)
+    bins = torch.linspace(0.0, half, n_freq, dtype=torch.float64)
+    w, s = half / n_filter, half / (n_filter - 1)
+    d = bins[None, :] - centres[:, None]                                                # [n_filter, n_freq]
+    rising = torch.cat([torch.ones(1, n_freq, dtype=torch.float64), (s + d[1:]) / w], dim=0)
+    falling = torch.cat([(s - d[:-1]) / w, torch.ones(1, n_freq, dtype=torch.float64)], dim=0)
+    tri = torch.minimum(rising, falling).clamp_min(0.0)
+    pre = tri / tri.sum(dim=1, keepdim=True)
+    post = tri.t() / tri.t().sum(dim=1, keepdim=True)
+    return pre.float().contiguous(), post.float().contiguous()
+
+
 def positional_embedding(channels: int, freq: int) -> Tensor:
     """Initial value of rf_block.0.pe (calculate_positional_embedding, model.py:98-110): for sub-band f = 1..F at angle
     pi f / F, channels//2 log-spaced multipliers from 1 to F-1; sines in the first half of the channels, cosines in the second."""
@@ -176,7 +203,8 @@ def default_state_dict(cfg: FEConfig, generator: Optional[torch.Generator] = Non
     g = generator
     shapes = expected_fused_shapes(cfg)
     sd: Dict[str, Tensor] = {}
-    pre, post = (linear_filterbank(cfg.F1, cfg.rf_freq) if (cfg.pre_post_init or "").startswith("linear") else (None, None))
+    fb = linear_filterbank_time_kernel if cfg.time_kernel else linear_filterbank
+    pre, post = (fb(cfg.F1, cfg.rf_freq) if (cfg.pre_post_init or "").startswith("linear") else (None, None))
     for k, shp in shapes.items():
         fan_in = 1
         for s in shp[1:]:

@@ -51,6 +51,11 @@ typedef struct fe_config {
     int stride;                      /* 4 */
     int rf_channels, rf_freq, rf_blocks, rf_heads; /* C2, F2, K, NH */
     float input_compression;         /* 0.3 */
+    int kernel_size_time;            /* `model: fastenhancer.time_kernel` (models/fastenhancer/time_kernel/model.py): time taps of
+                                      * the causal k = 3 Conv2d layers (3 in configs/ablation/time_kernel_b.yaml); 0 or 1 = the
+                                      * default model.  The state then also holds the convs' (kernel_size_time - 1)-frame input
+                                      * caches: ... | K x h | 2 (n_kernels - 1) x [B, kernel_size_time - 1, F1, C1] (encoder layers, then
+                                      * decoder layers; fe_spec_step's h_dev likewise: K x h, then the caches) */
 } fe_config;
 
 typedef struct fe_handle fe_handle;

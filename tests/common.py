@@ -81,3 +81,10 @@ def build_bsrnn_oracle(name, dtype=np.float32):
     sd = bo.make_training_state_dict(cfg, seed)
     fused = bo.fold_state_dict(sd, cfg)
     return cfg, sd, fused, bo.BSRNNOracle(cfg, fused, dtype)
+
+
+def product_config(name):
+    """the HIP path's FEConfig for a MODEL_KWARGS entry (the time_kernel variant's yaml has its own keys)"""
+    from fastenhancer_amd.config import FEConfig as PCfg, time_kernel_config
+    kw = MODEL_KWARGS[name][0]
+    return time_kernel_config(**kw) if MODEL_MODULE[name] == "fastenhancer.time_kernel" else PCfg.from_model_kwargs(**kw)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from common import MODEL_KWARGS, build_oracle, load_golden
+from common import MODEL_KWARGS, build_oracle, load_golden, product_config
 from fastenhancer_amd import _lib
 from fastenhancer_amd.config import FEConfig
 from fastenhancer_amd.engine import Engine
@@ -27,10 +27,9 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.fe_version()
 
 
-@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m", "fe48_l", "fe48_b_h480"])
+@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m", "fe48_l", "fe48_b_h480", "fe_tk_b"])
 def test_section_table_matches_fused_schema(name):
-    kw, sr, seed = MODEL_KWARGS[name]
-    cfg = FEConfig.from_model_kwargs(**kw)
+    cfg = product_config(name)
     eng = Engine(cfg, None)
     exp = expected_fused_shapes(cfg)
     assert [s[0] for s in eng.sections] == list(exp.keys())
@@ -73,10 +72,10 @@ def test_config_rejects_what_the_reference_rejects():
         FEConfig.from_model_kwargs(**{**kw, "mask": "softmax"})
 
 
-@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_l", "fe48_b"])
+@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_l", "fe48_b", "fe_tk_b"])
 def test_host_fold_matches_oracle_fold(name):
     cfg_o, sd, fused_o, _ = build_oracle(name)
-    cfg = FEConfig.from_model_kwargs(**MODEL_KWARGS[name][0])
+    cfg = product_config(name)
     fused = fold_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, cfg)
     assert set(fused) == set(fused_o)
     for k in fused:
@@ -209,3 +208,33 @@ def test_config_rejects_unsupported_initialisations():
     rk = dict(kw["rnnformer_kwargs"], positional_embedding=None)
     with pytest.raises(RuntimeError, match="positional_embedding"):
         FEConfig.from_model_kwargs(**{**kw, "rnnformer_kwargs": rk})
+
+
+def test_time_kernel_mirror_state_layout_and_defaults():
+    """fastenhancer.time_kernel mirror: yaml kwargs -> config, cache list in the reference's order / shapes, default
+    initialisation (its own filterbank formula), packing of the cache list into the C ABI state order and back."""
+    import importlib
+    from common import MODEL_MODULE
+    from fastenhancer_amd.weights import linear_filterbank_time_kernel
+    from oracle.fe_oracle import linear_filterbank_tk
+    kw = MODEL_KWARGS["fe_tk_b"][0]
+    mod = importlib.import_module(f"fastenhancer_amd.models.{MODEL_MODULE['fe_tk_b']}.model")
+    m = mod.ONNXModel(**kw)
+    cfg = m.cfg
+    assert cfg.time_kernel and cfg.kernel_size_time == 3 and cfg.kernel_size == (8, 3, 3) and not cfg.final_scale_exp
+    caches = m.initialize_cache(torch.zeros(2, 1))
+    assert [tuple(c.shape) for c in caches] == [(2, 48, 2, 64)] * 2 + [(1, 48, 36)] * 3 + [(2, 48, 2, 64)] * 2
+    pre, post = linear_filterbank_time_kernel(64, 24)
+    pre_o, post_o = linear_filterbank_tk(64, 24)
+    np.testing.assert_allclose(pre.numpy(), pre_o, atol=2e-6)
+    np.testing.assert_allclose(post.numpy(), post_o, atol=2e-6)
+    np.testing.assert_allclose(m.state_dict()["rf_pre.0.weight"].numpy(), pre_o, atol=2e-6)
+    eng = Engine(cfg, None)
+    B = 2
+    assert eng.state_floats(B) == B * (2 * 256 + 3 * 24 * 36 + 4 * 2 * 64 * 48)
+    rng = np.random.default_rng(0)
+    full = [torch.from_numpy(rng.standard_normal(s_).astype(np.float32)) for s_ in [(B, 256)] * 2 + [tuple(c.shape) for c in caches]]
+    state = eng.pack_state(full, B)
+    back = eng.split_state(state, B)
+    assert len(back) == len(full) and all(torch.equal(a, b) for a, b in zip(back, full))
+    assert eng.flops_per_frame == pytest.approx(build_oracle("fe_tk_b")[0].flops_per_frame())

@@ -10,15 +10,15 @@ import numpy as np
 import pytest
 import torch
 
-from common import MODEL_KWARGS, build_oracle, load_golden, rms
+from common import MODEL_KWARGS, MODEL_MODULE, build_oracle, load_golden, rms
 from oracle.weightgen import make_input
 
 pytestmark = pytest.mark.gpu
 
 ABS_TOL = 1e-4
 REL_TOL = 1e-4
-GPU_SHAPES = ["fe_t", "fe_b", "fe_m", "fe_l", "fe48_b", "fe48_l", "fe48_b_h480"]          # shapes with reference goldens
-ALL_SHAPES = ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m", "fe48_l", "fe48_b_h480"]
+GPU_SHAPES = ["fe_t", "fe_b", "fe_m", "fe_l", "fe48_b", "fe48_l", "fe48_b_h480", "fe_tk_b"]          # shapes with reference goldens
+ALL_SHAPES = ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m", "fe48_l", "fe48_b_h480", "fe_tk_b"]
 
 
 def _dev():
@@ -40,7 +40,7 @@ def _assert_close(got, ref, what):
 def _model(name, cls="ONNXModel"):
     kw, sr, seed = MODEL_KWARGS[name]
     cfg, sd, fused, orc = build_oracle(name)
-    mod = importlib.import_module("fastenhancer_amd.models.fastenhancer.default.model")
+    mod = importlib.import_module(f"fastenhancer_amd.models.{MODEL_MODULE[name]}.model")
     m = getattr(mod, cls)(**kw).to(_dev()).eval()
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     return m, orc, cfg, sr, seed
@@ -62,8 +62,8 @@ def test_streaming_step_matches_reference_golden(name):
     _assert_close(np.stack(outs, 0), g["stream_wav_out"], "wav_out")
     _assert_close(caches[0].cpu().numpy(), g["stream_cache_stft"], "cache_stft")
     _assert_close(caches[1].cpu().numpy(), g["stream_cache_istft"], "cache_istft")
-    for k in range(cfg.rf_blocks):
-        _assert_close(caches[2 + k].cpu().numpy(), g[f"stream_h{k}"], f"h{k}")
+    for k in range(len(caches) - 2):         # the GRU states (time_kernel variant: encoder conv caches, GRU states, decoder conv caches)
+        _assert_close(caches[2 + k].cpu().numpy(), g[f"stream_h{k}"], f"model cache {k}")
 
 
 @pytest.mark.parametrize("name", GPU_SHAPES)
