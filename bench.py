@@ -95,12 +95,12 @@ def cpu_baseline(workload: str, kw: dict, sr: int, B: int, budget_s: float):
     fused = fold_state_dict(make_training_state_dict(cfg, 2), cfg)
     H = cfg.hop_size
     x = make_input(B, 64 * H, 1236, sr)
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    # the best OpenMP width depends on the host (SMT, container CPU quota): try a few, report the fastest
-    cands = sorted({min(avail, c) for c in (8, 16, 32, 64, 128, avail)})
+    avail, quota = host_cpus()
+    # the OpenMP width is bounded by the container's CPU quota (cgroup cpu.max), not by the logical cores the host shows:
+    # on the round-2 GPU boxes 256 logical cores are visible but the quota is 16 CPUs - the oracle scales 14.9x from 1 to
+    # 16 threads and is throttled beyond (tools/cpu_scaling_probe.py); try the widths up to the quota, report the fastest
+    cap = avail if quota is None else max(1, min(avail, int(quota + 0.5)))
+    cands = sorted({min(cap, c) for c in (max(1, cap // 2), cap)} | ({min(avail, 2 * cap)} if quota is not None else set()))
     best = None
     for threads in cands:
         co = COracle(cfg, fused, threads=threads)
@@ -119,7 +119,63 @@ def cpu_baseline(workload: str, kw: dict, sr: int, B: int, budget_s: float):
     rate, threads, hops, dt = best
     return {"value": rate, "unit": "frames/s", "cores": int(threads), "kind": "port",
             "sample": f"{hops} hops x {B} streams of {workload} through the C/OpenMP oracle (oracle/fe_oracle.c) in {dt:.1f} s with "
-                      f"{threads} OpenMP threads (fastest of {cands}; host exposes {avail} logical cores)"}
+                      f"{threads} OpenMP threads (fastest of {cands}; the host shows {avail} logical cores, the container's "
+                      f"cgroup CPU quota is {'unlimited' if quota is None else f'{quota:g} CPUs'})"}
+
+
+def host_cpus():
+    """(logical cores this process may run on, cgroup CPU quota in CPUs or None)"""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(period)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except Exception:
+            pass
+    return avail, quota
+
+
+def cpu_baseline_bsrnn(workload: str, kw: dict, sr: int, B: int, budget_s: float):
+    """BSRNN workloads: the numpy oracle (oracle/bsrnn_oracle.py, pinned on the reference's golden vectors) on ONE host
+    core (BLAS threads limited to 1: a scalar port, stated as such), on a bounded sample of the same workload."""
+    from oracle import bsrnn_oracle as bo
+    from oracle.weightgen import make_input
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:
+        threadpool_limits = None
+    cfg = bo.BSRNNConfig.from_model_kwargs(kw)
+    orc = bo.BSRNNOracle(cfg, bo.fold_state_dict(bo.make_training_state_dict(cfg, 2), cfg), np.float32)
+    H = cfg.hop_size
+    Bs = min(B, 64)                                   # a 64-stream sample keeps a hop under a second
+    x = make_input(Bs, 8 * H, 1236, sr)
+    ctx = threadpool_limits(limits=1) if threadpool_limits else None
+    try:
+        caches = orc.initialize_cache(Bs)
+        _, *caches = orc.step(x[:, :H], *caches)
+        t0 = time.perf_counter()
+        hops = 0
+        while (time.perf_counter() - t0) < budget_s:
+            t = hops % 8
+            _, *caches = orc.step(x[:, t * H:(t + 1) * H], *caches)
+            hops += 1
+        dt = time.perf_counter() - t0
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+    return {"value": Bs * hops / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{hops} hops x {Bs} streams of {workload} through the numpy oracle (oracle/bsrnn_oracle.py) in {dt:.1f} s on one "
+                      f"core (BLAS limited to 1 thread{'' if threadpool_limits else ' - threadpoolctl missing, not enforced'})"}
 
 
 def measured_traffic(workload: str, B: int, T: int):
@@ -322,7 +378,9 @@ def main():
                          "flops_per_frame": eng.flops_per_frame,
                          "hbm_frac": (B * T * (2 * H * 4) + 2 * 4 * eng.state_floats(B)) / (kernel_ms * 1e-3) / 8e12},
         }
-        if world == 1 and not args.no_cpu_baseline and not w.get("bsrnn") and not w.get("kt"):
+        if world == 1 and not args.no_cpu_baseline and w.get("bsrnn"):
+            res["cpu_baseline"] = cpu_baseline_bsrnn(args.workload, kw, w["sr"], B, args.cpu_budget_s)
+        elif world == 1 and not args.no_cpu_baseline and not w.get("kt"):
             res["cpu_baseline"] = cpu_baseline(args.workload, kw, w["sr"], B, args.cpu_budget_s)
         print(json.dumps(res), flush=True)
     if use_dist:

@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 SUM=$ROOT/gpurun_out/shapes_$TAG.txt
 echo "# rocprofv3 --kernel-trace --stats, bench.py --no-cpu-baseline --steps 200 --warmup 20 --workload <w> (256 streams, 1 hop per launch)" > "$SUM"
-for w in fe_t fe_b fe_s fe_m fe_l fe48_t fe48_b fe48_b_h480 fe48_s fe48_m fe48_l bsrnn_xxt bsrnn_xt bsrnn_t; do
+for w in fe_t fe_b fe_s fe_m fe_l fe48_t fe48_b fe48_b_h480 fe48_s fe48_m fe48_l fe_tk_b bsrnn_xxt bsrnn_xt bsrnn_t bsrnn_s; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$w" -o s -- python $ROOT/bench.py --no-cpu-baseline --steps 200 --warmup 20 --workload $w > "$OUT/$w.json" 2> "$OUT/$w.err"
   python - "$OUT/$w" "$w" "$OUT/$w.json" >> "$SUM" <<'PY'
 import csv, glob, json, sys

@@ -15,7 +15,7 @@ def main():
         print("\n## kernel stats (--kernel-trace --stats)")
         for row in csv.DictReader(open(f)):
             name = row["Name"]
-            if "fe_frame_kernel" in name or float(row["Percentage"]) > 0.5:
+            if "frame_kernel" in name or float(row["Percentage"]) > 0.5:
                 print(f"{name[:90]:90s} calls={row['Calls']} avg_ns={float(row['AverageNs']):.0f} "
                       f"min_ns={row['MinNs']} max_ns={row['MaxNs']} pct={row['Percentage']}")
     for f in sorted(glob.glob(os.path.join(out, "*.json"))):
@@ -29,7 +29,7 @@ def main():
     for f in sorted(glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
         acc = defaultdict(list)
         for row in csv.DictReader(open(f)):
-            if "fe_frame_kernel" not in row.get("Kernel_Name", ""):
+            if "frame_kernel" not in row.get("Kernel_Name", ""):
                 continue
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, v in sorted(acc.items()):
