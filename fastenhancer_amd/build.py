@@ -37,13 +37,53 @@ def _hipcc() -> str:
     return "hipcc"
 
 
+# Shapes beyond the shipped yamls: `python -m fastenhancer_amd.build --add-shape C1,NL,C2,F2,KB,NFFT,HOP[,KT]` appends a line
+# to this (git-ignored, optional) file and rebuilds; fe_api.hip includes it after fe_shapes.def.  FE_LOCAL_DEF overrides the path.
+LOCAL_DEF = os.environ.get("FE_LOCAL_DEF") or os.path.join(CSRC, "fe_shapes_local.def")
+
+
 def shapes(fname="fe_shapes.def", macro="X"):
     out = []
-    for line in open(os.path.join(CSRC, fname)):
-        m = re.match(r"\s*" + macro + r"\(\s*(\w+)\s*,(.*)\)\s*$", line)
-        if m:
-            out.append((m.group(1), ",".join(x.strip() for x in m.group(2).split(","))))
+    files = [os.path.join(CSRC, fname)]
+    if fname == "fe_shapes.def" and os.path.exists(LOCAL_DEF):
+        files.append(LOCAL_DEF)
+    for f in files:
+        for line in open(f):
+            m = re.match(r"\s*" + macro + r"\(\s*(\w+)\s*,(.*)\)\s*$", line)
+            if m:
+                out.append((m.group(1), ",".join(x.strip() for x in m.group(2).split(","))))
     return out
+
+
+def add_shape(spec: str) -> str:
+    """`C1,NL,C2,F2,KB,NFFT,HOP[,KT]` (channels, len(kernel_size)-1, rnnformer channels / freq / num_blocks, n_fft, hop_size,
+    kernel_size_time) -> a line in the local shape list.  The kernel template's constraints are checked here with a
+    readable message (hipcc would report them as failed static_asserts): stride 4 and kernel_size [8, 3, ...] are fixed."""
+    v = [int(x) for x in spec.replace(" ", "").split(",")]
+    if len(v) not in (7, 8):
+        raise SystemExit("--add-shape wants C1,NL,C2,F2,KB,NFFT,HOP[,KT]")
+    C1, NL, C2, F2, KB, NFFT, HOP = v[:7]
+    KT = v[7] if len(v) == 8 else 1
+    errs = []
+    if C1 % 4 or C2 % 4 or F2 % 4:
+        errs.append("channels, rnnformer channels and rnnformer freq must be multiples of 4")
+    if C2 % 4 or (C2 // 4) < 1:
+        errs.append("rnnformer channels must be divisible by the 4 heads")
+    if NFFT not in (512, 1024):
+        errs.append("n_fft must be 512 or 1024")
+    if not (0 < HOP <= NFFT):
+        errs.append("0 < hop_size <= n_fft")
+    if not (1 <= NL <= 7 and 1 <= KB <= 8 and 1 <= KT <= 4 and NL * KT <= 16):
+        errs.append("1 <= layers <= 7, 1 <= num_blocks <= 8, 1 <= kernel_size_time <= 4")
+    if errs:
+        raise SystemExit("unsupported shape: " + "; ".join(errs))
+    args = ",".join(str(x) for x in v)
+    if any(a == args or (len(v) == 7 and a == args + ",1") for _, a in shapes()):
+        return ""
+    name = "U" + "_".join(str(x) for x in v)
+    with open(LOCAL_DEF, "a") as f:
+        f.write(f"X({name}, {', '.join(str(x) for x in v)})\n")
+    return name
 
 
 def _digest(paths, extra="") -> str:
@@ -57,6 +97,13 @@ def _compile(job):
     src, obj, defs, stamp, key = job
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == key:
         return obj, False
+    if _TAG:       # side build: a translation unit the main build already compiled with the same key is taken from its cache
+        mobj, mstamp = os.path.join(CSRC, "_obj", os.path.basename(obj)), os.path.join(CSRC, "_obj", os.path.basename(stamp))
+        if os.path.exists(mobj) and os.path.exists(mstamp) and open(mstamp).read() == key:
+            import shutil
+            shutil.copyfile(mobj, obj)
+            open(stamp, "w").write(key)
+            return obj, True
     cmd = [_hipcc()] + FLAGS + defs + ["-c", "-x", "hip", src, "-o", obj]
     subprocess.check_call(cmd)
     open(stamp, "w").write(key)
@@ -68,10 +115,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     common = [os.path.join(CSRC, d) for d in FE_DEPS]
     common_b = [os.path.join(CSRC, d) for d in BSRNN_DEPS]
-    common_api = [os.path.join(CSRC, d) for d in API_DEPS]
+    common_api = [os.path.join(CSRC, d) for d in API_DEPS] + ([LOCAL_DEF] if os.path.exists(LOCAL_DEF) else [])
     jobs = []
     api = os.path.join(CSRC, "fe_api.hip")
-    jobs.append((api, os.path.join(OBJ, "fe_api.o"), [], os.path.join(OBJ, "fe_api.stamp"), _digest(common_api + [api], " ".join(FLAGS))))
+    api_defs = [f'-DFE_LOCAL_DEF="{LOCAL_DEF}"'] if os.path.exists(LOCAL_DEF) else []
+    jobs.append((api, os.path.join(OBJ, "fe_api.o"), api_defs, os.path.join(OBJ, "fe_api.stamp"), _digest(common_api + [api], " ".join(FLAGS + api_defs))))
     tmpl = os.path.join(CSRC, "fe_shape.hip.in")
     for name, args in shapes():
         defs = [f"-DFE_SHAPE_NAME={name}", f"-DFE_SHAPE_ARGS={args}"]
@@ -117,4 +165,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
+    if "--add-shape" in sys.argv:
+        added = add_shape(sys.argv[sys.argv.index("--add-shape") + 1])
+        print(f"[fastenhancer_amd] {'added shape ' + added if added else 'shape already compiled'}", file=sys.stderr)
     build(force="--force" in sys.argv)

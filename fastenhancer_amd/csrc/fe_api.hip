@@ -50,6 +50,9 @@ struct Dims {
 // ---------------------------------------------------------------------------- dispatch table
 #define X(name, ...) extern "C" const fe::Impl* fe_impl_##name();
 #include "fe_shapes.def"
+#ifdef FE_LOCAL_DEF          // shapes added with `python -m fastenhancer_amd.build --add-shape ...`
+#include FE_LOCAL_DEF
+#endif
 #undef X
 
 #define XB(name, ...) extern "C" const fe::BImpl* fe_bimpl_##name();
@@ -68,6 +71,9 @@ const std::vector<const fe::Impl*>& impls() {
     static const std::vector<const fe::Impl*> v = {
 #define X(name, ...) fe_impl_##name(),
 #include "fe_shapes.def"
+#ifdef FE_LOCAL_DEF
+#include FE_LOCAL_DEF
+#endif
 #undef X
     };
     return v;
@@ -654,7 +660,9 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
             impl = im;
     if (!impl)
         return fail(FE_ERR_UNSUPPORTED_CONFIG,
-                    "no kernel compiled for channels=%d layers=%d rf_channels=%d rf_freq=%d rf_blocks=%d n_fft=%d hop=%d kernel_size_time=%d",
+                    "no kernel compiled for channels=%d layers=%d rf_channels=%d rf_freq=%d rf_blocks=%d n_fft=%d hop=%d kernel_size_time=%d "
+                    "(build it: python -m fastenhancer_amd.build --add-shape %d,%d,%d,%d,%d,%d,%d,%d)",
+                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, kt,
                     cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, kt);
     if (impl->lds_bytes > 160 * 1024)
         return fail(FE_ERR_UNSUPPORTED_CONFIG, "shape needs %zu bytes of LDS (> 160 KiB per CU)", impl->lds_bytes);

@@ -629,3 +629,50 @@ def test_si_sdr_of_hip_path_equals_oracle_path_to_2dp():
     s_gpu, s_ref = si_snr(y_gpu, torch.from_numpy(clean)), si_snr(y_ref, torch.from_numpy(clean))
     assert torch.all((s_gpu - s_ref).abs() < 5e-3), (s_gpu, s_ref)
     assert [round(float(v), 2) for v in s_gpu] == [round(float(v), 2) for v in s_ref] or torch.all((s_gpu - s_ref).abs() < 1e-3)
+
+
+def test_shape_outside_the_shipped_yamls_builds_and_matches_the_oracle(tmp_path):
+    """SURVEY's hop-generic / shape-generic note: a model_kwargs no yaml ships (40 channels, 28 x 20 RNNFormer, 2 blocks,
+    hop 128) is rejected with the build command in the message, `--add-shape` compiles its kernel (side build: the in-tree
+    library is untouched), and the result matches the oracle."""
+    import os
+    import subprocess
+    import sys
+    from fastenhancer_amd import _lib
+    from fastenhancer_amd.config import FEConfig
+    from fastenhancer_amd.engine import Engine
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    kw = dict(MODEL_KWARGS["fe_b"][0])
+    kw.update(channels=40, hop_size=128, rnnformer_kwargs=dict(kw["rnnformer_kwargs"], num_blocks=2, channels=28, freq=20))
+    with pytest.raises(_lib.FEError, match="--add-shape 40,2,28,20,2,512,128,1"):
+        Engine(FEConfig.from_model_kwargs(**kw), _dev())
+    env = dict(os.environ, FE_BUILD_TAG="addshape", FE_LOCAL_DEF=str(tmp_path / "local.def"))
+    r = subprocess.run([sys.executable, "-m", "fastenhancer_amd.build", "--add-shape", "40,2,28,20,2,512,128"], cwd=repo, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    child = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')
+from common import MODEL_KWARGS, rms
+from oracle.fe_oracle import FEConfig as OCfg, FEOracle, fold_state_dict
+from oracle.weightgen import make_input, make_training_state_dict
+import importlib
+kw = dict(MODEL_KWARGS['fe_b'][0]); kw.update(channels=40, hop_size=128, rnnformer_kwargs=dict(kw['rnnformer_kwargs'], num_blocks=2, channels=28, freq=20))
+ocfg = OCfg.from_model_kwargs(kw); sd = make_training_state_dict(ocfg, 77); orc = FEOracle(ocfg, fold_state_dict(sd, ocfg), np.float32)
+m = importlib.import_module('fastenhancer_amd.models.fastenhancer.default.model').ONNXModel(**kw).to('cuda:0').eval()
+m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+B, hops, H = 5, 8, 128
+x = make_input(B, hops * H, 3, 16000)
+st = m.engine.new_state(B)
+out = m.engine.step(torch.from_numpy(x).cuda(), st, T=hops).cpu().numpy()
+c = orc.initialize_cache(B); refs = []
+for t in range(hops):
+    o, *c = orc.step(x[:, t * H:(t + 1) * H], *c); refs.append(o)
+ref = np.concatenate(refs, 1)
+err, r = rms(out - ref), rms(ref)
+assert err < 1e-4 * r and err < 1e-4, (err, r)
+print('added-shape parity ok', err, r)
+""" % (repo, repo)
+    r = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, FASTENHANCER_HIP_LIB=os.path.join(repo, "ab", "lib_addshape.so")),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "added-shape parity ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
