@@ -338,10 +338,10 @@ def main():
     run(args.steps, args.warmup)
     ev1.record(stream)
     torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0                     # this rank's K steps, device-complete; the MAX over ranks is taken below
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps    # HIP events on the launch stream: avg per launch
     if use_dist:
         tt = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=dev)
