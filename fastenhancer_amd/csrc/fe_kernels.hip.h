@@ -1002,15 +1002,29 @@ __device__ __forceinline__ void attention_head(const float* G, float* Hl, int ho
     mma_panel<S::MT2, NQ, KSD, Lds<S>::PDK>(
         sacc,
         [&](int i, int ks) {
-            const int d = 4 * ks + lg;
-            float v = G[(16 * i + li) * LDG + hoff + HD + (d < HD ? d : HD - 1)];
-            return d < HD ? v : 0.0f;
+            // (K side unmasked: for d >= HD it reads the head's first v columns - finite values that meet the Q side's zeros)
+            return G[(16 * i + li) * LDG + hoff + HD + 4 * ks + lg];
         },
         [&](int j, int ks) {
             const int d = 4 * ks + lg;
             float v = G[(16 * qt[j] + li) * LDG + hoff + (d < HD ? d : HD - 1)];
             return d < HD ? v : 0.0f;
         }, NoSide{});
+    // the V fragments of the P V product: requested now, in flight under the softmax (they do not depend on it)
+    float av[S::MT2][4][MTD];
+#pragma unroll
+    for (int i = 0; i < S::MT2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int key = 16 * i + 4 * lg + r;
+            key = key < F2 ? key : F2 - 1;
+#pragma unroll
+            for (int md = 0; md < MTD; ++md) {
+                int d = 16 * md + li;
+                d = d < HD ? d : HD - 1;
+                av[i][r][md] = G[key * LDG + hoff + 2 * HD + d];
+            }
+        }
     const float scale = rsqrtf((float)HD) * 1.4426950408889634f;      // 1/sqrt(hd) * log2(e): softmax through exp2
     float inv_sum[NQ];
 #pragma unroll
@@ -1045,21 +1059,11 @@ __device__ __forceinline__ void attention_head(const float* G, float* Hl, int ho
 #pragma unroll
     for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int key = 16 * i + 4 * lg + r;
-            key = key < F2 ? key : F2 - 1;
-            float av[MTD];
-#pragma unroll
-            for (int md = 0; md < MTD; ++md) {
-                int d = 16 * md + li;
-                d = d < HD ? d : HD - 1;
-                av[md] = G[key * LDG + hoff + 2 * HD + d];
-            }
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int md = 0; md < MTD; ++md)
 #pragma unroll
-                for (int j = 0; j < NQ; ++j) oacc[md][j] = FE_MFMA(av[md], sacc[i][j][r], oacc[md][j]);
-        }
+                for (int j = 0; j < NQ; ++j) oacc[md][j] = FE_MFMA(av[i][r][md], sacc[i][j][r], oacc[md][j]);
     // O[query][head*HD + d]  (into Hl, dead after rnn_fc)
 #pragma unroll
     for (int md = 0; md < MTD; ++md)
