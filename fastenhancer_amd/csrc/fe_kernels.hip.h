@@ -662,7 +662,7 @@ __device__ __forceinline__ float2* fft_lds(float2* x, float2* y, const float2* t
 // those registers, so each wave computes both the real and the imaginary half of the first stage for its
 // column tile (2x redundant, 16 MFMAs) and there is no LDS exchange or barrier between the stages: one barrier
 // per transform instead of the log2 N of a radix-2 pass (each ~350 cycles at this size).
-template <class S>
+template <class S, int PDK = Lds<S>::PDK>      // (PDK given explicitly by shapes that have no Lds<S> plan: BSRNN)
 struct Dft {
     static constexpr int N = S::NFFT, N1 = N / 32, MT = N1 / 16, KC = N1 / 2;
     static constexpr bool PRELOAD3 = (N1 == 16);      // inverse first-stage constants in registers (else streamed from L2)
@@ -705,7 +705,7 @@ struct Dft {
         const int li = lane & 15, lg = lane >> 4, p = wave >> 1, jt = wave & 1, k2 = 16 * jt + li;
         f32x4 g[MT][2];                                  // [.][0] = Re G, [.][1] = Im G, rows 16 i + 4 lg + r, column k2
         acc_init_zero<MT, 2>(g);
-        mma_panel<MT, 2, 8, Lds<S>::PDK>(g, [&](int i, int ks) { return xw[16 * i + li + N1 * (4 * ks + lg)]; },
+        mma_panel<MT, 2, 8, PDK>(g, [&](int i, int ks) { return xw[16 * i + li + N1 * (4 * ks + lg)]; },
                             [&](int a2, int ks) { return c.c1[a2][ks]; }, NoSide{});
         float gq[KC];                                    // k-step a * 4 MT + 4 i + r of the second stage
         float2 tq[MT][4];                                // (twiddles fetched together, ahead of the panel's results)
@@ -768,7 +768,7 @@ struct Dft {
         }
         f32x4 h[1][2 * MT];
         acc_init_zero<1, 2 * MT>(h);
-        mma_panel<1, 2 * MT, KC, Lds<S>::PDK>(h, [&](int, int ks) { return yq[ks]; },
+        mma_panel<1, 2 * MT, KC, PDK>(h, [&](int, int ks) { return yq[ks]; },
                                  [&](int j, int ks) {
                                      if constexpr (PRELOAD3) return c.c3[j][ks];
                                      else return wb.at_g(o.dft3 + (j * KC + ks) * 64);
@@ -1257,10 +1257,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         float* q1 = q0 + N;
         float* q2 = reinterpret_cast<float*>(fb);
         float* q3 = q2 + N;
-        // matrix-core DFT for N = 512; N = 1024 keeps the radix-2 LDS FFT (there the 128 MFMAs per frame and the
-        // 64 + 32 constant fragments per wave cost more - registers, spills - than the 20 radix-2 stages: measured
-        // 48 kHz FastEnhancer_B 82 -> 91 us)
-        constexpr bool MDFT = (N == 512);
+        // matrix-core DFT (N = 512, and N = 1024 for all but the largest shape; r2 same-box A/B against the radix-2 LDS FFT
+        // with its 20 barrier-separated stages per frame: 48 kHz T +9 %, B +3 % (+4 % at hop 480), S +2.8 %, M +0.6 %,
+        // L -0.2 % - there the 64 + 32 constant fragments per wave meet a kernel that already spills.  In r1, before the
+        // per-hop instantiation freed its registers, the same switch had cost 48 kHz B 82 -> 91 us.)
+        constexpr bool MDFT = (N == 512) || (S::C1 < 128);
         constexpr int XS = MDFT ? 1 : 2;                 // element stride of the spectrum arrays below
         const float* Xr = nullptr;
         const float* Xi = nullptr;
