@@ -849,6 +849,12 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
         a.pipe_flags = h->pipe_flags_dev;
         a.pipe_p = P;
         h->impl->launch_pipe(a, (hipStream_t)stream, &e);
+        if (e != hipSuccess) {     // the runtime refused co-residency (GPU shared with other work): walk the frames serially
+            (void)hipGetLastError();
+            a.pipe_p = 0;
+            a.pipe_flags = nullptr;
+            h->impl->launch(a, h->max_wgs, (hipStream_t)stream, &e);
+        }
     } else
     h->impl->launch(a, h->max_wgs, (hipStream_t)stream, &e);
     if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
@@ -917,7 +923,15 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
         a.frames = flags + (((size_t)B * d.KB + 3) & ~(size_t)3);
         a.pipe_p = P;
         h->impl->launch_pipe(a, st, &e);
-        if (e != hipSuccess) return fail(FE_ERR_HIP, "cooperative kernel launch: %s", hipGetErrorString(e));
+        if (e != hipSuccess) {     // the runtime refused co-residency (GPU shared with other work): walk the frames serially
+            (void)hipGetLastError();
+            a.pipe_p = 0;
+            a.pipe_flags = nullptr;
+            a.frames = nullptr;
+            h->impl->launch(a, h->max_wgs, st, &e);
+            if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+            return FE_OK;
+        }
         const int n_out = d.HOP * (T - 1);
         hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
                            a.frames, h->tables_dev, wav_hat_dev, (size_t)n_out, d.NFFT, d.HOP, T);
