@@ -225,6 +225,8 @@ def main():
     ap.add_argument("--frames-per-step", type=int, default=1, help="hops per stream per launch (1 = per-hop streaming)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the K timed steps (K launches, each on its own input hop) into ONE HIP graph and time its replay")
     ap.add_argument("--clock-ramp-ms", type=float, default=250.0,
                     help="untimed launches of the same step BEFORE the counted warm-up, until this much GPU time has passed "
                          "(brings the shader clock and the caches to steady state; reported as clock_ramp_steps)")
@@ -333,9 +335,26 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    graph = None
+    if args.graph:
+        cap = torch.cuda.Stream(dev)
+        graph = torch.cuda.CUDAGraph()
+        keep = state.clone()
+        with torch.cuda.graph(graph, stream=cap):
+            csptr = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            for i in range(args.steps):
+                s_ = (args.warmup + i) % pool
+                rc = lib.fe_step(eng._h, ctypes.c_void_p(xptr + s_ * step_bytes), T * H, stptr, optr, T * H, B, T, csptr)
+                if rc != 0:
+                    _lib.check(rc, "fe_step")
+        state.copy_(keep)
+        torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     ev0.record(stream)
-    run(args.steps, args.warmup)
+    if graph is not None:
+        graph.replay()
+    else:
+        run(args.steps, args.warmup)
     ev1.record(stream)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0                     # this rank's K steps, device-complete; the MAX over ranks is taken below

@@ -676,3 +676,38 @@ print('added-shape parity ok', err, r)
     r = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, FASTENHANCER_HIP_LIB=os.path.join(repo, "ab", "lib_addshape.so")),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "added-shape parity ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_bsrnn_more_streams_than_cus():
+    """persistent BSRNN workgroups: 300 streams on 256 CUs (workgroups 0..43 walk two streams each)"""
+    m, orc, cfg, sr, seed = _bsrnn("bsrnn_xxt")
+    _full_size_check(m, orc, cfg, sr, 300, 3, [0, 1, 43, 44, 255, 256, 257, 299], "bsrnn_xxt B=300")
+
+
+def test_steps_can_be_captured_into_a_hip_graph():
+    """no allocation, free or synchronisation inside fe_step: a burst of per-hop launches captured into a HIP graph
+    (torch.cuda.CUDAGraph on the capture stream) replays to the same bits as the eager launches, for the LDS-skip (B),
+    global-skip (M: per-workgroup scratch allocated at load time) and BSRNN kernels"""
+    for name, loader in (("fe_b", _model), ("fe_m", _model), ("bsrnn_xt", _bsrnn)):
+        m, orc, cfg, sr, seed = loader(name)
+        eng = m.engine
+        B, hops, H = 7, 5, cfg.hop_size
+        x = torch.from_numpy(make_input(B, hops * H, 21, sr)).to(_dev())
+        s_eager = eng.new_state(B)
+        y_eager = torch.cat([eng.step(x[:, t * H:(t + 1) * H], s_eager, T=1) for t in range(hops)], dim=1)
+        s_graph = eng.new_state(B)
+        y_graph = torch.empty(B, hops * H, device=_dev())
+        eng.step(x[:, :H], eng.new_state(B), T=1)           # (first launch outside the capture: sets the function attribute)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for t in range(hops):
+                eng.step(x[:, t * H:(t + 1) * H], s_graph, wav_out=y_graph[:, t * H:(t + 1) * H], T=1)
+        s_graph.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y_graph, y_eager) and torch.equal(s_graph, s_eager), name
+        g.replay()                                           # a second replay continues the streams (state carried)
+        torch.cuda.synchronize()
+        y2 = torch.cat([eng.step(x[:, t * H:(t + 1) * H], s_eager, T=1) for t in range(hops)], dim=1)
+        assert torch.equal(y_graph, y2) and torch.equal(s_graph, s_eager), name
