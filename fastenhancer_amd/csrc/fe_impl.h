@@ -47,7 +47,8 @@ void launch_one(const FrameArgs& a, int grid_x, hipStream_t st, hipError_t* err)
 // streams runs on a grid of max_wgs PERSISTENT workgroups, each walking its streams b, b + grid, ...
 template <class S>
 void launch_impl(const FrameArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
-    const int grid = a.B < max_wgs ? a.B : max_wgs;
+    const int slots = max_wgs * Lds<S>::OCC;         // resident workgroups
+    const int grid = a.B < slots ? a.B : slots;
 #ifdef FE_PROBE_HOT
     if (a.dbg != nullptr) launch_one<S, true, -1, false, true>(a, grid, st, err);
 #else

@@ -613,6 +613,9 @@ struct Lds {
     // operands streamed from L2 need the full 8.
     static constexpr int PDK = STAGED ? 3 : 8;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
+    // workgroups per CU: small shapes (FastEnhancer_T: 62 KiB) fit twice - with more streams than CUs two workgroups share a
+    // CU and fill each other's barrier / latency stalls (one wave per SIMD each); everything else owns its CU
+    static constexpr int OCC = (2 * BYTES <= 160 * 1024) ? 2 : 1;
     static_assert(2 * S::ACT >= 4 * S::NFFT, "the FFT buffers must not reach the transposed-conv partials");
     static_assert(PERHEAD || S::F2P * S::LDC <= S::F2P * S::LDG, "rf_pre intermediate must fit in the qkv buffer");
     static_assert(!PERHEAD || !SKIPS_LDS, "per-head qkv implies global skips");
@@ -1099,7 +1102,7 @@ __device__ __forceinline__ void attention_head(const float* G, float* Hl, int ho
 // block) frame counter), the consumer spins on the counter (acquire) before it fetches the state.  The serial chain is
 // T x (state round trip + one GRU phase) instead of T x (whole frame): ~12 frames in flight for FastEnhancer_B.
 template <class S, bool DBG, int MODE, bool T1, bool PERSIST, bool PIPE = false>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) fe_frame_kernel(FrameArgs a_in) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, Lds<S>::OCC))) fe_frame_kernel(FrameArgs a_in) {
     FrameArgs a = a_in;
 #ifdef FE_PROBE_HOT          // measurement builds: the production instantiations keep the cycle probes (tools/gpu_phases.py ... 1)
     if constexpr (!DBG) a.dbg = nullptr;
