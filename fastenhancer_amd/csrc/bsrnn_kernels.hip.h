@@ -134,15 +134,19 @@ struct BLds {
 
 // HOT: the per-hop streaming step (mode and T = 1 are compile-time facts: no frame loop, no spec / offline branches)
 // PROF: cycle probes per phase (fe_profile_step, tools/gpu_phases_bsrnn.py);  DBG: per-stage dumps (fe_debug_step)
-template <class S, bool HOT, bool PROF, bool DBG>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) bsrnn_frame_kernel(BArgs a) {
+// OCC2: the two-workgroups-per-CU build for batches with more streams than CUs (shapes whose LDS plan fits twice: xt /
+// xxt).  A frame is a latency chain (186 barrier-separated recurrence steps); a second workgroup on the CU runs its own
+// chain in the gaps.  It has to live in 256 registers per wave: no register-resident layer weights (streamed inside the
+// GEMM pipelines like the larger shapes), shorter MLP weight rings - the other workgroup covers those latencies.
+template <class S, bool HOT, bool PROF, bool DBG, bool OCC2 = false>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, OCC2 ? 2 : 1))) bsrnn_frame_kernel(BArgs a) {
     const int aT = HOT ? 1 : a.T;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = BLds<S>;
     constexpr int N = S::NFFT, H = S::HOP, OVL = S::OVL, C = S::C, HH = S::HH, G4 = S::G4;
     constexpr int LDX = S::LDX, LDH = S::LDH, LDY = S::LDY, LDP = S::LDP, LDH1 = S::LDH1;
     constexpr int KSC = S::KSC, KSH = S::KSH, KS1 = S::KS1;
-    constexpr bool REGW = S::REGW;
+    constexpr bool REGW = S::REGW && !OCC2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
@@ -634,7 +638,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         // X reads are LDS broadcasts
         {
             constexpr int NOUT = 2 * kBands * 4 * C, ROUNDS = (NOUT + kThreads - 1) / kThreads, R4 = C / 4;
-            constexpr int D = R4 <= 4 ? 8 : (R4 <= 8 ? 4 : 2);      // rows in flight: under load the L2 round trip is ~1 us, the ring holds 32 KB per wave
+            constexpr int D = OCC2 ? 2 : (R4 <= 4 ? 8 : (R4 <= 8 ? 4 : 2));      // rows in flight: under load the L2 round trip is ~1 us, the ring holds 32 KB per wave
             const int rot = (int)(blockIdx.x >> 3) % ROUNDS;
             auto out_of = [&](int r) { int rr = r + rot; rr = rr >= ROUNDS ? rr - ROUNDS : rr; return tid + rr * kThreads; };
             auto load_row = [&](int r, float4 (&wv)[R4], float& bias) {
@@ -682,7 +686,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             constexpr int K4 = 4 * C / 4;          // 16-byte loads per row
             constexpr int CH = K4 < 16 ? K4 : 16;  // loads per chunk (C = 64: a row is 4 chunks)
             constexpr int NCH = K4 / CH;
-            constexpr int NROW = 2 * kMlpRows, ROUNDS = (NROW + kThreads - 1) / kThreads, NIT = ROUNDS * NCH, D = 3;
+            constexpr int NROW = 2 * kMlpRows, ROUNDS = (NROW + kThreads - 1) / kThreads, NIT = ROUNDS * NCH, D = OCC2 ? 1 : 3;
             const int* row_band = reinterpret_cast<const int*>(wp + o.row_band);
             const int rot = (int)(blockIdx.x >> 3) % ROUNDS;
             auto out_of = [&](int r) { int rr = r + rot; rr = rr >= ROUNDS ? rr - ROUNDS : rr; return tid + rr * kThreads; };
@@ -840,23 +844,30 @@ struct BImpl {
     void (*dbg_stage)(int, int*, int*, size_t*);
 };
 
-template <class S, bool HOT, bool PROF, bool DBG>
+template <class S, bool HOT, bool PROF, bool DBG, bool OCC2 = false>
 void blaunch_one(const BArgs& a, int grid, hipStream_t st, hipError_t* err) {
     static std::atomic<bool> attr_set[64];           // per device (see fe_impl.h::launch_one)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev].load(std::memory_order_relaxed)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bsrnn_frame_kernel<S, HOT, PROF, DBG>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bsrnn_frame_kernel<S, HOT, PROF, DBG, OCC2>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)BLds<S>::BYTES);
         if (e != hipSuccess) { *err = e; return; }
         attr_set[dev].store(true, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((bsrnn_frame_kernel<S, HOT, PROF, DBG>), dim3(grid), dim3(kThreads), BLds<S>::BYTES, st, a);
+    hipLaunchKernelGGL((bsrnn_frame_kernel<S, HOT, PROF, DBG, OCC2>), dim3(grid), dim3(kThreads), BLds<S>::BYTES, st, a);
     *err = hipGetLastError();
 }
 
 template <class S>
 void blaunch_impl(const BArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
+    constexpr bool FITS2 = 2 * BLds<S>::BYTES <= 160 * 1024 && !S::XPG;
+    if (FITS2 && a.B > max_wgs && a.dbg == nullptr && a.clk == nullptr) {      // two workgroups per CU, persistent above 2 x #CUs streams
+        const int grid2 = a.B < 2 * max_wgs ? a.B : 2 * max_wgs;
+        if (a.mode == FE_MODE_STREAM && a.T == 1) blaunch_one<S, true, false, false, FITS2>(a, grid2, st, err);
+        else blaunch_one<S, false, false, false, FITS2>(a, grid2, st, err);
+        return;
+    }
     const int grid = a.B < max_wgs ? a.B : max_wgs;      // more streams than CUs: persistent workgroups walk b, b + grid, ...
     if (a.dbg != nullptr) blaunch_one<S, false, false, true>(a, grid, st, err);                 // fe_debug_step
     else if (a.clk != nullptr) {                                                                // fe_profile_step
