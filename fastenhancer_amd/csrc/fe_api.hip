@@ -2,9 +2,11 @@
 // kernel dispatch for the FastEnhancer forward path on gfx950.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -85,6 +87,7 @@ struct fe_handle {
     fe_config cfg;
     Dims d;
     const fe::Impl* impl = nullptr;
+    const fe::Impl* impl_many = nullptr;  // low-LDS companion (two workgroups per CU) for batches above #CUs streams, if compiled
     const fe::BImpl* bimpl = nullptr;     // arch == FE_ARCH_BSRNN
     fe::BOffsets boff{};
     int device = 0;
@@ -608,10 +611,17 @@ int check_ready(const fe_handle* h) {
 // the compute calls (they can be captured into HIP graphs).  The slots belong to the handle: launches of one handle
 // must be stream-ordered (one stream, or event-ordered streams); concurrent launches need one handle each.
 int ensure_scratch(fe_handle* h, int) {
-    const size_t per_wg = h->bimpl ? h->bimpl->xp_floats : h->impl->skip_floats;     // (BSRNN: band-LSTM input projections of the C = 64 shape)
-    if (per_wg == 0 || h->skip_dev) return FE_OK;
-    FE_HIP_CHECK(hipMalloc(&h->skip_dev, (size_t)h->max_wgs * per_wg * sizeof(float)));
-    FE_HIP_CHECK(hipMemset(h->skip_dev, 0, (size_t)h->max_wgs * per_wg * sizeof(float)));
+    // (BSRNN: band-LSTM input projections of the C = 64 shape; FastEnhancer: the larger of the shape's own plan and its
+    // low-LDS companion's, which runs two workgroups per CU)
+    size_t floats = 0;
+    if (h->bimpl) floats = (size_t)h->max_wgs * h->bimpl->xp_floats;
+    else {
+        floats = (size_t)h->max_wgs * h->impl->occ * h->impl->skip_floats;
+        if (h->impl_many) floats = std::max(floats, (size_t)h->max_wgs * h->impl_many->occ * h->impl_many->skip_floats);
+    }
+    if (floats == 0 || h->skip_dev) return FE_OK;
+    FE_HIP_CHECK(hipMalloc(&h->skip_dev, floats * sizeof(float)));
+    FE_HIP_CHECK(hipMemset(h->skip_dev, 0, floats * sizeof(float)));
     h->skip_streams = h->max_wgs;
     return FE_OK;
 }
@@ -656,8 +666,13 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
     const int kt = cfg->kernel_size_time > 1 ? cfg->kernel_size_time : 1;
     for (const fe::Impl* im : impls())
         if (im->C1 == cfg->channels && im->NL == cfg->n_kernels - 1 && im->C2 == cfg->rf_channels && im->F2 == cfg->rf_freq &&
-            im->KB == cfg->rf_blocks && im->NFFT == cfg->n_fft && im->HOP == cfg->hop_size && im->KT == kt)
+            im->KB == cfg->rf_blocks && im->NFFT == cfg->n_fft && im->HOP == cfg->hop_size && im->KT == kt && im->LOW == 0)
             impl = im;
+    const fe::Impl* impl_many = nullptr;
+    for (const fe::Impl* im : impls())
+        if (impl && im->LOW >= 1 && im->occ >= 2 && im->C1 == impl->C1 && im->NL == impl->NL && im->C2 == impl->C2 && im->F2 == impl->F2 &&
+            im->KB == impl->KB && im->NFFT == impl->NFFT && im->HOP == impl->HOP && im->KT == impl->KT)
+            impl_many = im;
     if (!impl)
         return fail(FE_ERR_UNSUPPORTED_CONFIG,
                     "no kernel compiled for channels=%d layers=%d rf_channels=%d rf_freq=%d rf_blocks=%d n_fft=%d hop=%d kernel_size_time=%d "
@@ -669,6 +684,7 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
     fe_handle* h = new fe_handle();
     h->cfg = *cfg;
     h->impl = impl;
+    h->impl_many = std::getenv("FE_NO_LOWLDS") ? nullptr : impl_many;      // (FE_NO_LOWLDS: A/B switch of tools/ab_lowlds.sh)
     h->d = Dims{impl->C1, impl->NL, impl->C2, impl->F2, impl->KB, impl->NFFT, impl->HOP, impl->NFFT / 2, impl->NFFT / 8, impl->C2 / 4, {0}};
     h->d.KT = impl->KT;
     for (int i = 0; i < cfg->n_kernels; ++i) h->d.ks[i] = cfg->kernel_size[i];
@@ -778,7 +794,12 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
     a.dbg_stride = h->impl->dbg_floats;
     hipError_t e = hipSuccess;
     a.mode = fe::FE_MODE_STREAM;
-    h->impl->launch(a, h->max_wgs, (hipStream_t)stream, &e);
+    // per-hop launches above #CUs streams: the low-LDS companion (two workgroups per CU; same packed weights - Pack<S> does
+    // not depend on LOW), where one is compiled and measured faster
+    const fe::Impl* im = h->impl;
+    if (h->impl_many && T == 1 && B > h->max_wgs && (h->impl_many->many_persist || B <= h->max_wgs * h->impl_many->occ) && !dbg && !clk)
+        im = h->impl_many;
+    im->launch(a, h->max_wgs, (hipStream_t)stream, &e);
     if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return FE_OK;
 }

@@ -47,9 +47,11 @@ __host__ __device__ constexpr int round_up(int a, int b) { return ceil_div(a, b)
 // Compile-time shape of one model (the yaml model_kwargs).  NL = len(kernel_size)-1.  KT = kernel_size_time of the
 // `fastenhancer.time_kernel` variant (models/fastenhancer/time_kernel/model.py: the k = 3 convs are causal Conv2d with KT
 // taps over time); KT = 1 is the default model.
-template <int C1_, int NL_, int C2_, int F2_, int KB_, int NFFT_, int HOP_, int KT_ = 1>
+// LOW = 1: the low-LDS build of the same model (weights read from L2 instead of staged through LDS) whose plan fits twice
+// per CU: the companion kernel for batches with more streams than CUs, where two workgroups per CU fill each other's stalls.
+template <int C1_, int NL_, int C2_, int F2_, int KB_, int NFFT_, int HOP_, int KT_ = 1, int LOW_ = 0>
 struct Shape {
-    static constexpr int C1 = C1_, NL = NL_, C2 = C2_, F2 = F2_, KB = KB_, NFFT = NFFT_, HOP = HOP_, KT = KT_;
+    static constexpr int C1 = C1_, NL = NL_, C2 = C2_, F2 = F2_, KB = KB_, NFFT = NFFT_, HOP = HOP_, KT = KT_, LOW = LOW_;
     static constexpr int NH = 4;
     static constexpr int HD = C2 / NH;
     static constexpr int F0 = NFFT / 2;
@@ -563,7 +565,7 @@ struct Lds {
         cmax(cmax(4 * S::NFFT, cmax(3 * S::F2P * S::LDX, S::ACT) + S::F2P * S::LDG),
              cmax(2 * S::ACT + S::F1 * S::LDP, cmax(S::F2P * S::LDX, S::ACT) + S::F1 * S::LDX));
     static constexpr bool FITS_GLOBAL_STAGED = (size_t)(E + ARENA_SIZE_SKIPS_GLOBAL + 2 * Pack<S>::umax()) * 4 <= 160 * 1024;
-    static constexpr bool SKIPS_LDS = FITS_SKIPS && (FITS_SKIPS_STAGED || !(FITS_GLOBAL_STAGED && S::NTC % 4 != 0 && S::NTC % 2 != 0));
+    static constexpr bool SKIPS_LDS = S::LOW != 2 && FITS_SKIPS && (S::LOW == 1 || FITS_SKIPS_STAGED || !(FITS_GLOBAL_STAGED && S::NTC % 4 != 0 && S::NTC % 2 != 0));
     static constexpr int ARENA = E + (SKIPS_LDS ? (S::NL + 1) * S::ACT : 0);
     // The arena is re-used by the phases of a frame (offsets relative to ARENA):
     //   STFT / iSTFT : FFT_A, FFT_B                       (complex ping-pong)
@@ -598,7 +600,7 @@ struct Lds {
     static constexpr int ARENA_SIZE = cmax(cmax(END_FFT, END_RF), cmax(END_CONV, END_Y2));
     static constexpr int NOSTAGE_TOTAL = ARENA + ARENA_SIZE;
     // weights are staged through two LDS buffers (one GEMM phase ahead) whenever they fit
-    static constexpr bool STAGED = (size_t)(NOSTAGE_TOTAL + 2 * Pack<S>::umax()) * 4 <= 160 * 1024;
+    static constexpr bool STAGED = !S::LOW && (size_t)(NOSTAGE_TOTAL + 2 * Pack<S>::umax()) * 4 <= 160 * 1024;
     static constexpr int WB0 = NOSTAGE_TOTAL;
     static constexpr int WB1 = WB0 + Pack<S>::umax();
     static constexpr int TOTAL_KT1 = STAGED ? NOSTAGE_TOTAL + 2 * Pack<S>::umax() : NOSTAGE_TOTAL;
@@ -611,11 +613,16 @@ struct Lds {
     // block weights) every operand comes from LDS / registers, ~130 cycles away: 3 k-steps ahead is enough and a
     // shorter pipeline fill after each barrier is worth 4.7 % on FastEnhancer_B (8 / 6 / 4 / 3 / 2 measured);
     // operands streamed from L2 need the full 8.
-    static constexpr int PDK = STAGED ? 3 : 8;
+    // low-LDS companions (two workgroups per CU share the latency hiding; r2 same-box A/B at 512 / 1024 streams: B 8 -> 5:
+    // +5 % / -0.6 %, S and 48 kHz B 8 -> 4: +2.6 % / +5 % at 512)
+    static constexpr int PDK = STAGED ? 3 : (S::LOW == 1 ? 5 : (S::LOW == 2 ? 4 : 8));
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
     // workgroups per CU: small shapes (FastEnhancer_T: 62 KiB) fit twice - with more streams than CUs two workgroups share a
     // CU and fill each other's barrier / latency stalls (one wave per SIMD each); everything else owns its CU
     static constexpr int OCC = (2 * BYTES <= 160 * 1024) ? 2 : 1;
+    // a companion's PERSISTENT instantiation (more streams than 2 x #CUs) is only used where it beats the shape's own
+    // kernel: S spills 92 VGPRs there (3.54 M frames/s at 1024 streams against 3.65 M), B / 48 kHz B gain 8 % / 5 %
+    static constexpr bool MANY_PERSIST = !(S::LOW == 2 && S::C1 >= 64);
     static_assert(2 * S::ACT >= 4 * S::NFFT, "the FFT buffers must not reach the transposed-conv partials");
     static_assert(PERHEAD || S::F2P * S::LDC <= S::F2P * S::LDG, "rf_pre intermediate must fit in the qkv buffer");
     static_assert(!PERHEAD || !SKIPS_LDS, "per-head qkv implies global skips");
@@ -1102,7 +1109,7 @@ __device__ __forceinline__ void attention_head(const float* G, float* Hl, int ho
 // block) frame counter), the consumer spins on the counter (acquire) before it fetches the state.  The serial chain is
 // T x (state round trip + one GRU phase) instead of T x (whole frame): ~12 frames in flight for FastEnhancer_B.
 template <class S, bool DBG, int MODE, bool T1, bool PERSIST, bool PIPE = false>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, Lds<S>::OCC))) fe_frame_kernel(FrameArgs a_in) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(Lds<S>::OCC, Lds<S>::OCC))) fe_frame_kernel(FrameArgs a_in) {
     FrameArgs a = a_in;
 #ifdef FE_PROBE_HOT          // measurement builds: the production instantiations keep the cycle probes (tools/gpu_phases.py ... 1)
     if constexpr (!DBG) a.dbg = nullptr;
@@ -1121,7 +1128,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 
     const int tid0 = threadIdx.x;
     const int tid = tid0;
-    const int lane = tid & 63;
+    const int lane0 = tid & 63;
+    const int lane = lane0;
     const int wave0 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave = wave0;
     const int li = lane & 15, lg = lane >> 4;
@@ -1238,6 +1246,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         int lz = 0;
         if constexpr (S::C1 <= 96) asm volatile("" : "+s"(lz));
         const int wave = wave0 + lz;
+        // LOW = 2 companions (256 VGPRs, operands streamed from L2): the same for the per-lane offsets - hoisted out of the
+        // stream loop they stay live through the whole frame and the persistent instantiation spills (S: 167 -> 92 VGPRs,
+        // 48 kHz B: 73 -> 14; +12 % / +15 % at 1024 streams).  Kernels that fit anyway pay for the re-derived offsets
+        // (B companion -3 %, T -7 %): not applied there.
+        int lzv = 0;
+        if constexpr (PERSIST && S::LOW == 2) asm volatile("" : "+v"(lzv));
+        const int tid = tid0 + lzv;
+        const int lane = lane0 + lzv;
+        const int li = lane & 15, lg = lane >> 4;
         // begin_unit(U): called right after the barrier that precedes the GEMM phase of staged unit U:
         // selects the LDS copy of this phase's weights and sets up the DMA job of the next unit.
         const int fpar = (S::NU & 1) ? (((PERSIST || PIPE) ? fc : t) & 1) : 0;

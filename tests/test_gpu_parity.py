@@ -308,6 +308,15 @@ def test_full_size_48khz_hop480_512_streams():
     _full_size_check(m, orc, cfg, sr, 512, 4, [0, 1, 255, 256, 257, 300, 510, 511], "fe48_b_h480 B=512")
 
 
+@pytest.mark.parametrize("name,B", [("fe_b", 300), ("fe_b", 1100), ("fe_s", 520), ("fe48_t", 700), ("fe48_b", 600), ("fe48_b_h480", 1030)])
+def test_low_lds_companion_above_cus(name, B):
+    """above #CUs streams fe_step switches to the shape's low-LDS companion (two workgroups per CU, weights streamed from
+    L2, fe_shapes.def LOW): up to 2 x #CUs streams one workgroup per stream, beyond that persistent workgroups that walk
+    several streams.  Same packed weights, same state; oracle parity and position independence as everywhere else."""
+    m, orc, cfg, sr, seed = _model(name)
+    _full_size_check(m, orc, cfg, sr, B, 3, [0, 1, 255, 256, 257, B // 2, B - 2, B - 1], f"{name} B={B} (low-LDS companion)")
+
+
 def test_full_size_bsrnn_xt_256_streams():
     """BASELINE config 5: BSRNN-xt, 256 streams."""
     m, orc, cfg, sr, seed = _bsrnn("bsrnn_xt")
