@@ -83,6 +83,21 @@ def build_bsrnn_oracle(name, dtype=np.float32):
     return cfg, sd, fused, bo.BSRNNOracle(cfg, fused, dtype)
 
 
+# configs/others/fspen.yaml:2-16
+FSPEN_KWARGS = (dict(channels=[4, 16, 32], kernel_size=[6, 8, 6], stride=[2, 2, 2],
+                     dpe_kwargs=dict(num_blocks=3, channels=16, freq=32, groups=8, norm="LayerNorm-FreqChannels"),
+                     n_fft=512, hop_size=256, win_size=512, window="hann", input_compression=0.3), 16000, 301)
+
+
+def build_fspen_oracle(dtype=np.float32):
+    from oracle import fspen_oracle as fo
+    kw, sr, seed = FSPEN_KWARGS
+    cfg = fo.FSPENConfig.from_model_kwargs(kw)
+    sd = fo.make_training_state_dict(cfg, seed)
+    fused = fo.fold_state_dict(sd, cfg)
+    return cfg, sd, fused, fo.FSPENOracle(cfg, fused, dtype)
+
+
 def product_config(name):
     """the HIP path's FEConfig for a MODEL_KWARGS entry (the time_kernel variant's yaml has its own keys)"""
     from fastenhancer_amd.config import FEConfig as PCfg, time_kernel_config

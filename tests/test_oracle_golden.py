@@ -153,3 +153,26 @@ def test_bsrnn_offline_matches_reference(name):
     wav, spec = orc.offline_forward(x)
     _close(wav, g["offline_wav"], what="offline wav")
     _close(spec, g["offline_spec"], what="offline spec")
+
+
+def test_fspen_streaming_and_offline_match_reference():
+    """models/fspen/model.py (SURVEY.md §8(f) rank 4) - golden = the imported reference (tools/gen_golden.py::gen_fspen)"""
+    from common import build_fspen_oracle
+    g = load_golden("fspen")
+    cfg, sd, fused, orc = build_fspen_oracle()
+    B, hops, H = int(g["B"]), int(g["hops"]), cfg.hop_size
+    x = make_input(B, hops * H, int(g["seed"]) + 1000, int(g["sr"]))
+    caches = orc.initialize_cache(B)
+    outs = []
+    for t in range(hops):
+        o, *caches = orc.step(x[:, t * H:(t + 1) * H], *caches)
+        outs.append(o)
+    _close(np.stack(outs, 0), g["stream_wav_out"], what="wav_out")
+    _close(caches[0], g["stream_cache_stft"], what="cache_stft")
+    _close(caches[1], g["stream_cache_istft"], what="cache_istft")
+    for i in range(cfg.n_caches):
+        _close(caches[2 + i], g[f"stream_c{i}"], what=f"inter GRU cache {i}")
+    xo = make_input(B, hops * H + 37, int(g["seed"]) + 2000, int(g["sr"]))
+    wav, spec = orc.offline_forward(xo)
+    _close(wav, g["offline_wav"], what="offline wav")
+    _close(spec, g["offline_spec"], what="offline spec")

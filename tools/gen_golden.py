@@ -283,6 +283,62 @@ def gen_bsrnn(ref: str, name: str, out_dir: str):
           f"out_rms={float(np.sqrt((out['stream_wav_out'][4:] ** 2).mean())):.3f}")
 
 
+def gen_fspen(ref: str, out_dir: str):
+    """the FSPEN baseline (configs/others/fspen.yaml, models/fspen/model.py)."""
+    from oracle import fspen_oracle as fo
+    seed, B, hops = 301, 2, 10
+    hps = yaml.safe_load(open(os.path.join(ref, "configs/others/fspen.yaml")))
+    kw = hps["model_kwargs"]
+    sr = hps["data"]["sampling_rate"]
+    cfg = fo.FSPENConfig.from_model_kwargs(kw)
+    mod = import_reference_model(ref, "models/fspen/model.py", "ref_fspen_model")
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+    model = mod.Model(**kw).eval()
+    ref_sd = model.state_dict()
+    spec = fo.training_state_dict_spec(cfg)
+    assert list(ref_sd.keys()) == list(spec.keys()), ([k for k in ref_sd if k not in spec], [k for k in spec if k not in ref_sd])
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(spec[k]), (k, v.shape, spec[k])
+    sd = fo.make_training_state_dict(cfg, seed)
+    model.load_state_dict(to_t(sd), strict=True)
+    onnx_model = mod.ONNXModel(**kw).eval()
+    onnx_model.load_state_dict(to_t(sd), strict=True)
+    onnx_model.remove_weight_reparameterizations()
+    fused_ref = {k: v.detach().numpy().copy() for k, v in onnx_model.state_dict().items()}
+    fused_mine = fo.fold_state_dict(sd, cfg)
+    assert set(fused_mine) == set(fused_ref), (sorted(set(fused_mine) ^ set(fused_ref))[:10])
+    worst = max(np.abs(fused_mine[k] - fused_ref[k]).max() / (np.abs(fused_ref[k]).max() + 1e-12) for k in fused_ref)
+    assert worst < 3e-6, worst
+    out = {"seed": np.int64(seed), "B": np.int64(B), "hops": np.int64(hops), "sr": np.int64(sr), "fold_worst_rel": np.float64(worst)}
+    H = cfg.hop_size
+    x = torch.from_numpy(make_input(B, hops * H, seed + 1000, sr))
+    with torch.no_grad():
+        cache_stft, cache_istft = onnx_model.stft.initialize_cache(x)
+        cm = [torch.zeros(1, B * (cfg.freq // cfg.groups), cfg.dpe_channels) for _ in range(cfg.n_caches)]
+        outs = []
+        for t in range(hops):
+            spec_in, cache_stft = onnx_model.stft(x[:, t * H:(t + 1) * H], cache_stft)
+            spec_out, *cm = onnx_model(spec_in, *cm)
+            wav_out, cache_istft = onnx_model.stft.inverse(spec_out, cache_istft)
+            outs.append(wav_out.numpy().copy())
+    out["stream_wav_out"] = np.stack(outs, 0)
+    out["stream_cache_stft"] = cache_stft.numpy().copy()
+    out["stream_cache_istft"] = cache_istft.numpy().copy()
+    for i, t_ in enumerate(cm):
+        out[f"stream_c{i}"] = t_.numpy().copy()
+    out["stream_spec_out_last"] = spec_out.numpy().copy()
+    xo = torch.from_numpy(make_input(B, hops * H + 37, seed + 2000, sr))
+    with torch.no_grad():
+        wav_hat, spec_hat = model(xo)
+    out["offline_wav"] = wav_hat.numpy().copy()
+    out["offline_spec"] = spec_hat.numpy().copy()
+    path = os.path.join(out_dir, "fspen.npz")
+    np.savez_compressed(path, **out)
+    print(f"fspen: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB) fold_worst={worst:.2e} "
+          f"in_rms={float(np.sqrt((x.numpy() ** 2).mean())):.3f} out_rms={float(np.sqrt((out['stream_wav_out'][4:] ** 2).mean())):.3f}")
+
+
 def gen_si_snr(ref: str, out_dir: str):
     """SI-SDR of the reference's evaluation script: `si_snr` / `product` are closures inside main() of
     scripts/metrics_ns.py (which imports torchaudio / pesq / pystoi at its top), so the two function definitions
@@ -329,6 +385,8 @@ def main():
         gen_bsrnn(args.ref, name, args.out)
     if not args.only or "si_snr" in args.only:
         gen_si_snr(args.ref, args.out)
+    if not args.only or "fspen" in args.only:
+        gen_fspen(args.ref, args.out)
 
 
 if __name__ == "__main__":
