@@ -58,6 +58,7 @@ WORKLOADS = {
     "bsrnn_xxt": dict(bsrnn=True, C=16, L=2, N=512, H=256, sr=16000, desc="BSRNN (xxt) 16kHz"),
     "bsrnn_t": dict(bsrnn=True, C=32, L=6, N=512, H=256, sr=16000, desc="BSRNN (t) 16kHz"),
     "bsrnn_s": dict(bsrnn=True, C=64, L=6, N=512, H=256, sr=16000, desc="BSRNN (s) 16kHz"),
+    "fspen": dict(fspen=True, N=512, H=256, sr=16000, desc="FSPEN 16kHz (configs/others/fspen.yaml)"),
     "fe_m": dict(C1=96, ks=(8, 3, 3, 3), C2=72, F2=48, K=4, N=512, H=160, sr=16000, init="linear_fixed",
                  desc="FastEnhancer_M 16kHz"),
     "fe_l": dict(C1=128, ks=(8, 3, 3, 3, 3), C2=96, F2=64, K=5, N=512, H=100, sr=16000, init="linear_fixed",
@@ -68,6 +69,10 @@ WORKLOADS = {
 
 
 def model_kwargs(w):
+    if w.get("fspen"):
+        return dict(channels=[4, 16, 32], kernel_size=[6, 8, 6], stride=[2, 2, 2],
+                    dpe_kwargs=dict(num_blocks=3, channels=16, freq=32, groups=8, norm="LayerNorm-FreqChannels"),
+                    n_fft=w["N"], hop_size=w["H"], win_size=w["N"], window="hann", input_compression=0.3)
     if w.get("bsrnn"):
         return dict(num_channels=w["C"], num_layers=w["L"], bias=True, affine=True, n_fft=w["N"], hop_size=w["H"], win_size=w["N"],
                     window="hann", input_compression=0.3)
@@ -143,6 +148,30 @@ def host_cpus():
         except Exception:
             pass
     return avail, quota
+
+
+def cpu_baseline_fspen(kw: dict, sr: int, B: int, budget_s: float):
+    """FSPEN: the numpy oracle (oracle/fspen_oracle.py, pinned on the reference's golden vectors) on ONE host core."""
+    from oracle import fspen_oracle as fo
+    from oracle.weightgen import make_input
+    try:
+        torch.set_num_threads(1)
+    except Exception:
+        pass
+    cfg = fo.FSPENConfig.from_model_kwargs(kw)
+    orc = fo.FSPENOracle(cfg, fo.fold_state_dict(fo.make_training_state_dict(cfg, 2), cfg), np.float32)
+    Bs = min(B, 16)
+    H = cfg.hop_size
+    x = make_input(Bs, 64 * H, 5, sr)
+    caches = orc.initialize_cache(Bs)
+    t0 = time.perf_counter()
+    hops = 0
+    while hops < 64 and (hops < 2 or time.perf_counter() - t0 < budget_s):
+        _, *caches = orc.step(x[:, hops * H:(hops + 1) * H], *caches)
+        hops += 1
+    dt = time.perf_counter() - t0
+    return {"value": hops * Bs / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{hops} hops x {Bs} streams of fspen through the numpy oracle (oracle/fspen_oracle.py) in {dt:.1f} s on one host core"}
 
 
 def cpu_baseline_bsrnn(workload: str, kw: dict, sr: int, B: int, budget_s: float):
@@ -256,7 +285,10 @@ def main():
 
     w = WORKLOADS[args.workload]
     kw = model_kwargs(w)
-    if w.get("bsrnn"):
+    if w.get("fspen"):
+        from fastenhancer_amd.config import FSPENConfig
+        cfg = FSPENConfig.from_model_kwargs(**kw)
+    elif w.get("bsrnn"):
         from fastenhancer_amd.config import BSRNNConfig
         cfg = BSRNNConfig.from_model_kwargs(**kw)
     elif w.get("kt"):
@@ -271,8 +303,10 @@ def main():
     if rank == 0:
         # no trained checkpoints offline: PyTorch-style random init of the fused weights; the final conv is
         # scaled so that the complex mask is O(1) (the enhanced waveform has the level of the input)
-        from fastenhancer_amd.weights import bsrnn_default_state_dict, default_state_dict
-        if w.get("bsrnn"):
+        from fastenhancer_amd.weights import bsrnn_default_state_dict, default_state_dict, fspen_default_state_dict
+        if w.get("fspen"):
+            sd = fspen_default_state_dict(cfg, torch.Generator().manual_seed(2))
+        elif w.get("bsrnn"):
             sd = bsrnn_default_state_dict(cfg, torch.Generator().manual_seed(2))
         else:
             sd = default_state_dict(cfg, torch.Generator().manual_seed(2))
@@ -393,11 +427,13 @@ def main():
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": measured_traffic(args.workload, B, T),
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "algorithmic_hbm_bytes_per_launch": B * T * (2 * H * 4) + 2 * 4 * eng.state_floats(B),
-                         "kernel": "bsrnn_frame_kernel" if w.get("bsrnn") else "fe_frame_kernel", "kernel_ms": kernel_ms,
+                         "kernel": "fspen_frame_kernel" if w.get("fspen") else ("bsrnn_frame_kernel" if w.get("bsrnn") else "fe_frame_kernel"), "kernel_ms": kernel_ms,
                          "flops_per_frame": eng.flops_per_frame,
                          "hbm_frac": (B * T * (2 * H * 4) + 2 * 4 * eng.state_floats(B)) / (kernel_ms * 1e-3) / 8e12},
         }
-        if world == 1 and not args.no_cpu_baseline and w.get("bsrnn"):
+        if world == 1 and not args.no_cpu_baseline and w.get("fspen"):
+            res["cpu_baseline"] = cpu_baseline_fspen(kw, w["sr"], B, args.cpu_budget_s)
+        elif world == 1 and not args.no_cpu_baseline and w.get("bsrnn"):
             res["cpu_baseline"] = cpu_baseline_bsrnn(args.workload, kw, w["sr"], B, args.cpu_budget_s)
         elif world == 1 and not args.no_cpu_baseline and not w.get("kt"):
             res["cpu_baseline"] = cpu_baseline(args.workload, kw, w["sr"], B, args.cpu_budget_s)

@@ -13,6 +13,7 @@ FE_MAX_KERNELS = 8
 FE_OK = 0
 FE_ARCH_FASTENHANCER = 0
 FE_ARCH_BSRNN = 1
+FE_ARCH_FSPEN = 2
 
 
 class fe_config(ctypes.Structure):

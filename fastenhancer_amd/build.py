@@ -21,7 +21,8 @@ OBJ = os.path.join(CSRC, "_obj" + ("_" + _TAG if _TAG else ""))
 LIB = os.path.join(HERE, "libfastenhancer_hip.so") if not _TAG else os.path.join(os.path.dirname(HERE), "ab", f"lib_{_TAG}.so")
 FE_DEPS = ["fe_kernels.hip.h", "fe_impl.h"]
 BSRNN_DEPS = ["fe_kernels.hip.h", "bsrnn_kernels.hip.h"]
-API_DEPS = ["fe_kernels.hip.h", "fe_impl.h", "fe_shapes.def", "bsrnn_kernels.hip.h", "fe_bsrnn_shapes.def", "stft_kernels.hip.h",
+FSPEN_DEPS = ["fe_kernels.hip.h", "fspen_kernels.hip.h"]
+API_DEPS = ["fe_kernels.hip.h", "fe_impl.h", "fe_shapes.def", "bsrnn_kernels.hip.h", "fe_bsrnn_shapes.def", "stft_kernels.hip.h", "fspen_kernels.hip.h",
             os.path.join("..", "..", "include", "fastenhancer_hip.h")]
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in VGPRs instead of AGPRs - every epilogue read of an AGPR accumulator is a
 # v_accvgpr_read, a VALU instruction that the fp32 matrix path cannot overlap (~600 of them per wave and frame on
@@ -130,6 +131,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
         defs = [f"-DFE_SHAPE_NAME={name}", f"-DFE_SHAPE_ARGS={args}"]
         jobs.append((tmpl_b, os.path.join(OBJ, f"fe_bsrnn_{name}.o"), defs, os.path.join(OBJ, f"fe_bsrnn_{name}.stamp"),
                      _digest(common_b + [tmpl_b], " ".join(FLAGS + defs))))
+    fsp = os.path.join(CSRC, "fe_fspen.hip")
+    jobs.append((fsp, os.path.join(OBJ, "fe_fspen.o"), [], os.path.join(OBJ, "fe_fspen.stamp"),
+                 _digest([os.path.join(CSRC, d) for d in FSPEN_DEPS] + [fsp], " ".join(FLAGS))))
     if force:
         for j in jobs:
             if os.path.exists(j[3]):

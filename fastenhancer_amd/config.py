@@ -177,3 +177,51 @@ class BSRNNConfig:
             raise AssertionError(f"n_fft({n_fft}) must be bigger than win_size({win_size})")
         return BSRNNConfig(int(num_channels), int(num_layers), bool(bias), bool(affine), int(n_fft), int(hop_size),
                            int(win_size), float(input_compression))
+
+
+@dataclass(frozen=True)
+class FSPENConfig:
+    """yaml model_kwargs of `model: fspen` (configs/others/fspen.yaml:2-16; models/fspen/model.py:201-212, DPEConfig :191-197).
+    One architecture is compiled (the yaml's); fe_create rejects any other."""
+    channels: tuple = (4, 16, 32)
+    kernel_size: tuple = (6, 8, 6)
+    stride: tuple = (2, 2, 2)
+    num_blocks: int = 3
+    dpe_channels: int = 16
+    freq: int = 32
+    groups: int = 8
+    norm: str = "LayerNorm-FreqChannels"
+    n_fft: int = 512
+    hop_size: int = 256
+    win_size: int = 512
+    input_compression: float = 0.3
+
+    @property
+    def F0(self) -> int:
+        return self.n_fft // 2
+
+    @property
+    def cache_len(self) -> int:
+        return self.n_fft - self.hop_size
+
+    @property
+    def n_caches(self) -> int:
+        return self.num_blocks * self.groups
+
+    @staticmethod
+    def from_model_kwargs(channels=(4, 16, 32), kernel_size=(6, 8, 6), stride=(2, 2, 2), dpe_kwargs=None, n_fft: int = 512,
+                          hop_size: int = 256, win_size: int = 512, window: str = "hann",
+                          input_compression: float = 0.3) -> "FSPENConfig":
+        if n_fft != 512:
+            raise AssertionError(f"Only n_fft == 512 is allowed, but given {n_fft}.")      # models/fspen/model.py:214
+        if window != "hann":
+            raise RuntimeError(f"model_kwargs.window={window} is not supported by the HIP path (shipped: hann).")
+        d = dict(dpe_kwargs or {})
+        norm = d.get("norm", "LayerNorm-FreqChannels")
+        if norm not in ("LayerNorm-FreqChannels", "LayerNorm-Channels", "CustomLayerNorm"):
+            raise RuntimeError(f"dpe_kwargs.norm {norm} is not supported")               # models/fspen/model.py:156-157
+        if norm != "LayerNorm-FreqChannels":
+            raise RuntimeError(f"dpe_kwargs.norm {norm} is not supported by the HIP path (shipped: LayerNorm-FreqChannels).")
+        return FSPENConfig(tuple(int(c) for c in channels), tuple(int(k) for k in kernel_size), tuple(int(x) for x in stride),
+                           int(d.get("num_blocks", 3)), int(d.get("channels", 16)), int(d.get("freq", 32)), int(d.get("groups", 8)),
+                           norm, int(n_fft), int(hop_size), int(win_size), float(input_compression))

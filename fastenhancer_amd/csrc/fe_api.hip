@@ -15,6 +15,7 @@
 #include "../../include/fastenhancer_hip.h"
 #include "fe_impl.h"
 #include "bsrnn_kernels.hip.h"
+#include "fspen_kernels.hip.h"
 #include "stft_kernels.hip.h"
 
 namespace {
@@ -60,6 +61,8 @@ struct Dims {
 #define XB(name, ...) extern "C" const fe::BImpl* fe_bimpl_##name();
 #include "fe_bsrnn_shapes.def"
 #undef XB
+extern "C" const fe::FImpl* fe_fimpl_h256();
+
 const std::vector<const fe::BImpl*>& bimpls() {
     static const std::vector<const fe::BImpl*> v = {
 #define XB(name, ...) fe_bimpl_##name(),
@@ -89,6 +92,7 @@ struct fe_handle {
     const fe::Impl* impl = nullptr;
     const fe::Impl* impl_many = nullptr;  // low-LDS companion (two workgroups per CU) for batches above #CUs streams, if compiled
     const fe::BImpl* bimpl = nullptr;     // arch == FE_ARCH_BSRNN
+    const fe::FImpl* fimpl = nullptr;     // arch == FE_ARCH_FSPEN
     fe::BOffsets boff{};
     int device = 0;
     int max_wgs = 256;             // CUs of the device: one resident workgroup per CU (persistent grid above that)
@@ -580,6 +584,220 @@ int pack_weights_bsrnn(fe_handle* h, const std::vector<float>& blob, std::vector
     return FE_OK;
 }
 
+// ============================================================================ FSPEN (models/fspen/model.py)
+// fused state_dict of ONNXModel after remove_weight_reparameterizations (:299-340), reference layouts
+const int kSeK[5] = {4, 7, 11, 20, 40};                   // SubbandEncoder kernels (:41-44)
+const int kSdN[5] = {2, 3, 5, 10, 20};                    // SubbandDecoder outputs per row (:70)
+
+void build_sections_fspen(fe_handle* h) {
+    char nm[160];
+    for (int i = 0; i < 5; ++i) {
+        snprintf(nm, sizeof nm, "subband_encoder.conv%d.0.weight", i + 1); add_section(h, nm, {32, 1, kSeK[i]});
+        snprintf(nm, sizeof nm, "subband_encoder.conv%d.0.bias", i + 1); add_section(h, nm, {32});
+    }
+    for (int i = 0; i < 5; ++i) {
+        snprintf(nm, sizeof nm, "subband_decoder.lin%d.0.weight", i + 1); add_section(h, nm, {kSdN[i], 64});
+        snprintf(nm, sizeof nm, "subband_decoder.lin%d.0.bias", i + 1); add_section(h, nm, {kSdN[i]});
+    }
+    const int C1[3] = {4, 16, 32}, K[3] = {6, 8, 6};
+    for (int i = 0; i < 3; ++i) {
+        snprintf(nm, sizeof nm, "fullband_encoder.%d.0.weight", i); add_section(h, nm, {C1[i], i == 0 ? 2 : C1[i - 1], K[i]});
+        snprintf(nm, sizeof nm, "fullband_encoder.%d.0.bias", i); add_section(h, nm, {C1[i]});
+    }
+    add_section(h, "fullband_encoder_post.weight", {32, 32, 1});
+    add_section(h, "feature_merge.0.weight", {32, 64});
+    add_section(h, "feature_merge.2.weight", {16, 32, 1});
+    add_section(h, "feature_merge.2.bias", {16});
+    for (int b = 0; b < 3; ++b) {
+        auto gru = [&](const std::string& p, const char* sfx) {
+            add_section(h, p + ".weight_ih_l0" + sfx, {48, 16});
+            add_section(h, p + ".weight_hh_l0" + sfx, {48, 16});
+            add_section(h, p + ".bias_ih_l0" + sfx, {48});
+            add_section(h, p + ".bias_hh_l0" + sfx, {48});
+        };
+        snprintf(nm, sizeof nm, "dpe_blocks.%d.", b);
+        const std::string p = nm;
+        gru(p + "intra_rnn", "");
+        gru(p + "intra_rnn", "_reverse");
+        add_section(h, p + "intra_fc.weight", {16, 32});
+        add_section(h, p + "intra_fc.bias", {16});
+        add_section(h, p + "intra_ln.weight", {32, 16});
+        add_section(h, p + "intra_ln.bias", {32, 16});
+        for (int g = 0; g < 8; ++g) gru(p + "inter_rnn.inter_rnn." + std::to_string(g), "");
+        for (int g = 0; g < 8; ++g) {
+            add_section(h, p + "inter_rnn.inter_fc." + std::to_string(g) + ".weight", {16, 16});
+            add_section(h, p + "inter_rnn.inter_fc." + std::to_string(g) + ".bias", {16});
+        }
+    }
+    add_section(h, "feature_split.0.weight", {32, 16, 1});
+    add_section(h, "feature_split.0.bias", {32});
+    add_section(h, "feature_split.1.weight", {64, 32});
+    for (int j = 0; j < 3; ++j) {
+        const int i = 2 - j, cin = C1[i], cout = i == 0 ? 2 : C1[i - 1];
+        snprintf(nm, sizeof nm, "fullband_decoder.%d.0.weight", j); add_section(h, nm, {cin, 2 * cin, 1});
+        snprintf(nm, sizeof nm, "fullband_decoder.%d.1.weight", j); add_section(h, nm, {cin, cout, K[i]});
+        snprintf(nm, sizeof nm, "fullband_decoder.%d.1.bias", j); add_section(h, nm, {cout});
+    }
+}
+
+int create_fspen(const fe_config* cfg, fe_handle** out) {
+    if (cfg->n_fft != 512) return fail(FE_ERR_INVALID_ARG, "Only n_fft == 512 is allowed, but given %d", cfg->n_fft);
+    if (cfg->win_size > cfg->n_fft) return fail(FE_ERR_INVALID_ARG, "n_fft(%d) must be bigger than win_size(%d)", cfg->n_fft, cfg->win_size);
+    // the one architecture of configs/others/fspen.yaml: channels [4, 16, 32], kernel_size [6, 8, 6], stride 2, DPE 3 x (16 ch, 32 bands, 8 groups)
+    const bool ok = cfg->channels == 32 && cfg->n_kernels == 3 && cfg->kernel_size[0] == 6 && cfg->kernel_size[1] == 8 && cfg->kernel_size[2] == 6 &&
+                    cfg->stride == 2 && cfg->rf_channels == 16 && cfg->rf_freq == 32 && cfg->rf_blocks == 3 && cfg->rf_heads == 8;
+    const fe::FImpl* fi = (ok && cfg->hop_size == 256) ? fe_fimpl_h256() : nullptr;
+    if (!fi)
+        return fail(FE_ERR_UNSUPPORTED_CONFIG, "no FSPEN kernel compiled for channels[-1]=%d kernels=%d dpe=(%d blocks, %d ch, %d bands, %d groups) hop=%d "
+                    "(configs/others/fspen.yaml is the compiled architecture)", cfg->channels, cfg->n_kernels, cfg->rf_blocks, cfg->rf_channels,
+                    cfg->rf_freq, cfg->rf_heads, cfg->hop_size);
+    fe_handle* h = new fe_handle();
+    h->cfg = *cfg;
+    h->fimpl = fi;
+    h->d = Dims{32, 0, 16, 32, 3, cfg->n_fft, cfg->hop_size, cfg->n_fft / 2, 0, 0, {0}};
+    if (hipGetDevice(&h->device) != hipSuccess) h->device = -1;
+    else {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->max_wgs = cus;
+    }
+    build_sections_fspen(h);
+    build_tables(h);
+    *out = h;
+    return FE_OK;
+}
+
+// k-major repack of the fused weights at the compile-time offsets of fe::FPk (fspen_kernels.hip.h)
+int pack_weights_fspen(fe_handle* h, const std::vector<float>& blob, std::vector<float>* out) {
+    using P = fe::FPk;
+    std::vector<float> buf(P::TOTAL, 0.0f);
+    auto S = [&](const std::string& n) { return sec(h, blob, n); };
+    char nm[160];
+    for (int i = 0; i < 512; ++i) { buf[P::WINDOW + i] = h->window[i]; buf[P::WINDOW_I + i] = h->window_istft[i]; buf[P::TW + i] = h->twiddle[i]; }
+    for (int i = 0, row = 0; i < 5; row += kSeK[i], ++i) {
+        snprintf(nm, sizeof nm, "subband_encoder.conv%d.0.weight", i + 1);
+        const float* w = S(nm);                                       // (32, 1, K)
+        snprintf(nm, sizeof nm, "subband_encoder.conv%d.0.bias", i + 1);
+        const float* b = S(nm);
+        for (int ch = 0; ch < 32; ++ch) {
+            for (int k = 0; k < kSeK[i]; ++k) buf[P::SE_W + (row + k) * 32 + ch] = w[ch * kSeK[i] + k];
+            buf[P::SE_B + i * 32 + ch] = b[ch];
+        }
+    }
+    // Conv1d (Cout, Cin, K) -> [(c*K + k)][Cout]
+    auto conv = [&](const char* key, int cout, int cin, int K, int dst_w, int dst_b) {
+        const float* w = S(std::string(key) + ".weight");
+        for (int o = 0; o < cout; ++o)
+            for (int c = 0; c < cin; ++c)
+                for (int k = 0; k < K; ++k) buf[dst_w + (c * K + k) * cout + o] = w[(o * cin + c) * K + k];
+        if (dst_b >= 0) { const float* b = S(std::string(key) + ".bias"); for (int o = 0; o < cout; ++o) buf[dst_b + o] = b[o]; }
+    };
+    conv("fullband_encoder.0.0", 4, 2, 6, P::FE0_W, P::FE0_B);
+    conv("fullband_encoder.1.0", 16, 4, 8, P::FE1_W, P::FE1_B);
+    conv("fullband_encoder.2.0", 32, 16, 6, P::FE2_W, P::FE2_B);
+    conv("fullband_encoder_post", 32, 32, 1, P::POST_W, -1);
+    {   // feature_merge.0 Linear (32 out j, 64 in i) -> [i][j]
+        const float* w = S("feature_merge.0.weight");
+        for (int j = 0; j < 32; ++j) for (int i = 0; i < 64; ++i) buf[P::MG1_W + i * 32 + j] = w[j * 64 + i];
+    }
+    conv("feature_merge.2", 16, 32, 1, P::MG2_W, P::MG2_B);
+    // GRU (gate order r, z, n): W_ih^T [k][48]; bias = b_ih + (b_hh for r, z); b_hh of n kept apart (it sits inside r * (...))
+    auto gru_ih = [&](const std::string& p, const char* sfx, int dst_w, int dst_gb, int dst_hn) {
+        const float* wi = S(p + ".weight_ih_l0" + sfx);
+        const float* bi = S(p + ".bias_ih_l0" + sfx);
+        const float* bh = S(p + ".bias_hh_l0" + sfx);
+        for (int g = 0; g < 48; ++g) {
+            for (int k = 0; k < 16; ++k) buf[dst_w + k * 48 + g] = wi[g * 16 + k];
+            buf[dst_gb + g] = bi[g] + (g < 32 ? bh[g] : 0.0f);
+        }
+        for (int c = 0; c < 16; ++c) buf[dst_hn + c] = bh[32 + c];
+    };
+    for (int b = 0; b < 3; ++b) {
+        const int D = P::DPE + b * P::D_SIZE;
+        snprintf(nm, sizeof nm, "dpe_blocks.%d.", b);
+        const std::string p = nm;
+        for (int d = 0; d < 2; ++d) {
+            const char* sfx = d ? "_reverse" : "";
+            gru_ih(p + "intra_rnn", sfx, D + P::D_IH + d * 768, D + P::D_GB + d * 48, D + P::D_HN + d * 16);
+            const float* wh = S(p + "intra_rnn.weight_hh_l0" + sfx);       // (48, 16) -> [gate][k][unit]
+            for (int gate = 0; gate < 3; ++gate)
+                for (int k = 0; k < 16; ++k)
+                    for (int c = 0; c < 16; ++c) buf[D + P::D_HH + ((d * 3 + gate) * 16 + k) * 16 + c] = wh[(gate * 16 + c) * 16 + k];
+        }
+        {
+            const float* w = S(p + "intra_fc.weight");                      // (16, 32) -> [k][c]
+            const float* bb = S(p + "intra_fc.bias");
+            for (int c = 0; c < 16; ++c) { for (int k = 0; k < 32; ++k) buf[D + P::D_FC_W + k * 16 + c] = w[c * 32 + k]; buf[D + P::D_FC_B + c] = bb[c]; }
+            const float* lw = S(p + "intra_ln.weight");
+            const float* lb = S(p + "intra_ln.bias");
+            for (int i = 0; i < 512; ++i) { buf[D + P::D_LN_W + i] = lw[i]; buf[D + P::D_LN_B + i] = lb[i]; }
+        }
+        for (int g = 0; g < 8; ++g) {
+            const int Gb = D + P::D_G + g * P::G_SIZE;
+            const std::string q = p + "inter_rnn.inter_rnn." + std::to_string(g);
+            gru_ih(q, "", Gb + P::G_IH, Gb + P::G_GB, Gb + P::G_HN);
+            const float* wh = S(q + ".weight_hh_l0");
+            for (int gg = 0; gg < 48; ++gg) for (int k = 0; k < 16; ++k) buf[Gb + P::G_HH + k * 48 + gg] = wh[gg * 16 + k];
+            const float* fw = S(p + "inter_rnn.inter_fc." + std::to_string(g) + ".weight");
+            const float* fb = S(p + "inter_rnn.inter_fc." + std::to_string(g) + ".bias");
+            for (int c = 0; c < 16; ++c) { for (int k = 0; k < 16; ++k) buf[Gb + P::G_FC_W + k * 16 + c] = fw[c * 16 + k]; buf[Gb + P::G_FC_B + c] = fb[c]; }
+        }
+    }
+    conv("feature_split.0", 32, 16, 1, P::SP1_W, P::SP1_B);
+    {   // feature_split.1 Linear (64 out j, 32 in f) -> [f][j]
+        const float* w = S("feature_split.1.weight");
+        for (int j = 0; j < 64; ++j) for (int f = 0; f < 32; ++f) buf[P::SP2_W + f * 64 + j] = w[j * 32 + f];
+    }
+    {   // sub-band decoder (SubbandDecoder.forward, :83-95): bin -> (layer, output o of its row): one weight column per bin
+        const int base[5] = {0, 16, 32, 64, 128}, k0[5] = {0, 1, 4, 8, 16}, keep[5] = {16, 16, 32, 64, 129};
+        for (int i = 0; i < 5; ++i) {
+            snprintf(nm, sizeof nm, "subband_decoder.lin%d.0.weight", i + 1);
+            const float* w = S(nm);                                   // (n, 64)
+            snprintf(nm, sizeof nm, "subband_decoder.lin%d.0.bias", i + 1);
+            const float* bb = S(nm);
+            for (int q = 0; q < keep[i]; ++q) {
+                const int bin = base[i] + q, o = (k0[i] + q) % kSdN[i];
+                for (int k = 0; k < 64; ++k) buf[P::SD_W + k * 260 + bin] = w[o * 64 + k];
+                buf[P::SD_B + bin] = bb[o];
+            }
+        }
+    }
+    // ConvTranspose1d (Cin, Cout, K) -> [(c*K + k)][Cout]
+    auto convt = [&](const char* key, int cin, int cout, int K, int dst_w, int dst_b) {
+        const float* w = S(std::string(key) + ".weight");
+        const float* b = S(std::string(key) + ".bias");
+        for (int c = 0; c < cin; ++c)
+            for (int o = 0; o < cout; ++o)
+                for (int k = 0; k < K; ++k) buf[dst_w + (c * K + k) * cout + o] = w[(c * cout + o) * K + k];
+        for (int o = 0; o < cout; ++o) buf[dst_b + o] = b[o];
+    };
+    conv("fullband_decoder.0.0", 32, 64, 1, P::FD0_W, -1);
+    convt("fullband_decoder.0.1", 32, 16, 6, P::FD0_T, P::FD0_B);
+    conv("fullband_decoder.1.0", 16, 32, 1, P::FD1_W, -1);
+    convt("fullband_decoder.1.1", 16, 4, 8, P::FD1_T, P::FD1_B);
+    conv("fullband_decoder.2.0", 4, 8, 1, P::FD2_W, -1);
+    convt("fullband_decoder.2.1", 4, 2, 6, P::FD2_T, P::FD2_B);
+    *out = std::move(buf);
+    return FE_OK;
+}
+
+size_t fspen_gru_floats(int B) { return (size_t)B * fe::FShape<256>::CACHE_FLOATS; }
+
+fe::FArgs fspen_args(fe_handle* h, int B, int T) {
+    fe::FArgs a{};
+    a.wp = h->packed_dev;
+    a.B = B;
+    a.T = T;
+    a.compression = h->cfg.input_compression;
+    return a;
+}
+
+int launch_fspen(fe_handle* h, const fe::FArgs& a, void* stream) {
+    hipError_t e = hipSuccess;
+    h->fimpl->launch(a, h->max_wgs, (hipStream_t)stream, &e);
+    if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return FE_OK;
+}
+
 size_t bsrnn_lstm_floats(const fe_handle* h, int B) { return (size_t)2 * h->cfg.rf_blocks * B * 31 * 2 * h->cfg.channels; }
 
 fe::BArgs bsrnn_args(fe_handle* h, int B, int T) {
@@ -614,7 +832,8 @@ int ensure_scratch(fe_handle* h, int) {
     // (BSRNN: band-LSTM input projections of the C = 64 shape; FastEnhancer: the larger of the shape's own plan and its
     // low-LDS companion's, which runs two workgroups per CU)
     size_t floats = 0;
-    if (h->bimpl) floats = (size_t)h->max_wgs * h->bimpl->xp_floats;
+    if (h->fimpl) floats = 0;
+    else if (h->bimpl) floats = (size_t)h->max_wgs * h->bimpl->xp_floats;
     else {
         floats = (size_t)h->max_wgs * h->impl->occ * h->impl->skip_floats;
         if (h->impl_many) floats = std::max(floats, (size_t)h->max_wgs * h->impl_many->occ * h->impl_many->skip_floats);
@@ -649,6 +868,7 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
     if (!cfg || !out) return fail(FE_ERR_INVALID_ARG, "null argument");
     *out = nullptr;
     if (cfg->arch == FE_ARCH_BSRNN) return create_bsrnn(cfg, out);
+    if (cfg->arch == FE_ARCH_FSPEN) return create_fspen(cfg, out);
     if (cfg->arch != FE_ARCH_FASTENHANCER)
         return fail(FE_ERR_UNSUPPORTED_CONFIG, "arch %d is not built into this library", cfg->arch);
     if (cfg->n_fft % 2 != 0) return fail(FE_ERR_INVALID_ARG, "`n_fft` must be an even number, but given %d.", cfg->n_fft);
@@ -727,7 +947,7 @@ int fe_load_weights(fe_handle* h, const float* blob_dev, size_t nfloats, void* s
     FE_HIP_CHECK(hipMemcpyAsync(blob.data(), blob_dev, nfloats * sizeof(float), hipMemcpyDeviceToHost, st));
     FE_HIP_CHECK(hipStreamSynchronize(st));
     std::vector<float> packed;
-    int rc = h->bimpl ? pack_weights_bsrnn(h, blob, &packed) : pack_weights(h, blob, &packed);
+    int rc = h->fimpl ? pack_weights_fspen(h, blob, &packed) : (h->bimpl ? pack_weights_bsrnn(h, blob, &packed) : pack_weights(h, blob, &packed));
     if (rc != FE_OK) return rc;
     if (h->packed_dev) { FE_HIP_CHECK(hipFree(h->packed_dev)); h->packed_dev = nullptr; }
     FE_HIP_CHECK(hipMalloc(&h->packed_dev, packed.size() * sizeof(float)));
@@ -742,12 +962,13 @@ int fe_load_weights(fe_handle* h, const float* blob_dev, size_t nfloats, void* s
 // time_kernel variant: floats of the causal convs' frame caches per stream (2 NL layers x [KT-1][F1][C1])
 static size_t tk_floats(const fe_handle* h) {
     const Dims& d = h->d;
-    return h->bimpl ? 0 : (size_t)2 * d.NL * (d.KT - 1) * d.F1 * d.C1;
+    return (h->bimpl || h->fimpl) ? 0 : (size_t)2 * d.NL * (d.KT - 1) * d.F1 * d.C1;
 }
 
 size_t fe_state_floats(const fe_handle* h, int B) {
     if (!h || B <= 0) return 0;
     const Dims& d = h->d;
+    if (h->fimpl) return (size_t)B * 2 * (size_t)(d.NFFT - d.HOP) + fspen_gru_floats(B);
     if (h->bimpl) return (size_t)B * 2 * (size_t)(d.NFFT - d.HOP) + bsrnn_lstm_floats(h, B);
     return (size_t)B * (2 * (size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2 + tk_floats(h));
 }
@@ -766,6 +987,17 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
     const Dims& d = h->d;
     if (in_stride < (size_t)T * d.HOP && B > 1) return fail(FE_ERR_INVALID_ARG, "in_stride %zu < T*H", in_stride);
     if (out_stride < (size_t)T * d.HOP && B > 1) return fail(FE_ERR_INVALID_ARG, "out_stride %zu < T*H", out_stride);
+    if (h->fimpl) {
+        fe::FArgs fa = fspen_args(h, B, T);
+        fa.clk = clk;
+        fa.dbg = dbg;
+        fa.dbg_stride = h->fimpl->dbg_floats;
+        const size_t ovl_b = (size_t)(d.NFFT - d.HOP);
+        fa.mode = fe::FE_MODE_STREAM;
+        fa.wav_in = wav_in; fa.wav_out = wav_out; fa.in_stride = in_stride; fa.out_stride = out_stride;
+        fa.cache_stft = state; fa.cache_istft = state + (size_t)B * ovl_b; fa.gru = state + 2 * (size_t)B * ovl_b;
+        return launch_fspen(h, fa, stream);
+    }
     if (h->bimpl) {
         fe::BArgs ba = bsrnn_args(h, B, T);
         ba.clk = clk;
@@ -848,6 +1080,12 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
     int rc = check_ready(h);
     if (rc != FE_OK) return rc;
     if (!spec_in_dev || !h_dev || !spec_out_dev || B <= 0 || T <= 0) return fail(FE_ERR_INVALID_ARG, "bad argument");
+    if (h->fimpl) {
+        fe::FArgs fa = fspen_args(h, B, T);
+        fa.mode = fe::FE_MODE_SPEC;
+        fa.spec_in = spec_in_dev; fa.spec_out = spec_out_dev; fa.gru = h_dev;
+        return launch_fspen(h, fa, stream);
+    }
     if (h->bimpl) {
         fe::BArgs ba = bsrnn_args(h, B, T);
         ba.mode = fe::FE_MODE_SPEC;
@@ -885,6 +1123,7 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
 size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw) {
     if (!h || B <= 0 || Tw <= 0) return 0;
     const Dims& d = h->d;
+    if (h->fimpl) return (size_t)B * (size_t)(d.NFFT - d.HOP) + fspen_gru_floats(B);
     if (h->bimpl) return (size_t)B * (size_t)(d.NFFT - d.HOP) + bsrnn_lstm_floats(h, B);
     // GRU state (zero initial state, model.py:626-627) + overlap-add tail, both zeroed by fe_offline; time-pipelined
     // launches: + the frame counters [B][KB] and the windowed output frames [B][T][N]
@@ -906,9 +1145,20 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
     const int T = 1 + Tw / d.HOP;
     {   // zero the state, the tail and the frame counters (not the frames: every element is written)
         size_t nz = (size_t)B * ((size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2 + tk_floats(h));
-        if (h->bimpl) nz = fe_offline_work_floats(h, B, Tw);
+        if (h->bimpl || h->fimpl) nz = fe_offline_work_floats(h, B, Tw);
         else if (pipe_width(h, B, T)) nz += ((size_t)B * d.KB + 3) & ~(size_t)3;
         FE_HIP_CHECK(hipMemsetAsync(work_dev, 0, nz * sizeof(float), st));
+    }
+    if (h->fimpl) {
+        fe::FArgs fa = fspen_args(h, B, T);
+        fa.mode = fe::FE_MODE_OFFLINE;
+        fa.Tw = Tw;
+        fa.wav_in = noisy_dev; fa.in_stride = (size_t)Tw;
+        fa.wav_out = wav_hat_dev; fa.out_stride = (size_t)d.HOP * (T - 1);
+        fa.spec_out = spec_hat_dev;
+        fa.cache_istft = work_dev; fa.cache_stft = work_dev;
+        fa.gru = work_dev + (size_t)B * (d.NFFT - d.HOP);
+        return launch_fspen(h, fa, stream);
     }
     if (h->bimpl) {
         fe::BArgs ba = bsrnn_args(h, B, T);
@@ -1064,6 +1314,18 @@ int fe_istft_offline(fe_handle* h, const float* spec_in_dev, int B, int T, int F
 double fe_flops_per_frame(const fe_handle* h) {
     if (!h) return 0.0;
     const Dims& d = h->d;
+    if (h->fimpl) {   // models/fspen/macs.py:36-141 with T = 1 (switches as committed: conv output lengths, no BN / LN / bias terms)
+        const double C1[3] = {4, 16, 32}, K[3] = {6, 8, 6}, C2 = 16;
+        double F = 257, m = 0;
+        for (int i = 0; i < 3; ++i) { F = std::floor(F / 2); m += (i == 0 ? 2 : C1[i - 1]) * C1[i] * F * K[i]; }
+        m += 32 * 32 * F + 32 * (4 * 8 + 7 * 6 + 11 * 6 + 20 * 6 + 40 * 6) + 32 * 64 * 32 + 32 * C2 * 32;
+        const double gru = (C2 + C2) * C2 * 3 + C2 * 3;
+        m += 3 * (gru * 2 + 2 * C2 * C2 + C2 + gru + C2 * C2 + C2) * 32;
+        m += C2 * 32 * 32 + 32 * 32 * 64 + 32 * (8 * 2 + 6 * 3 + 8 * 5 + 8 * 10 + 8 * 20);
+        for (int i = 2; i >= 0; --i) { m += C1[i] * (i == 0 ? 2 : C1[i - 1]) * F * K[i]; F = i == 0 ? F * 2 + 1 : F * 2; }
+        m += 257 * 8;
+        return 2.0 * m + 2.0 * 2.5 * d.NFFT * std::log2((double)d.NFFT);
+    }
     if (h->bimpl) {   // models/bsrnn/macs.py:18-51
         const double C = h->cfg.channels, Hh = 2 * C, Lr = h->cfg.rf_blocks;
         double m = 0;
@@ -1084,12 +1346,24 @@ double fe_flops_per_frame(const fe_handle* h) {
     return 2.0 * m + 2.0 * 2.5 * d.NFFT * std::log2((double)d.NFFT);
 }
 
-int fe_debug_stages(const fe_handle* h) { return !h ? 0 : (h->bimpl ? h->bimpl->dbg_stages : (h->impl ? h->impl->dbg_stages : 0)); }
-size_t fe_debug_floats(const fe_handle* h) { return !h ? 0 : (h->bimpl ? h->bimpl->dbg_floats : (h->impl ? h->impl->dbg_floats : 0)); }
+int fe_debug_stages(const fe_handle* h) { return !h ? 0 : h->fimpl ? h->fimpl->dbg_stages : (h->bimpl ? h->bimpl->dbg_stages : (h->impl ? h->impl->dbg_stages : 0)); }
+size_t fe_debug_floats(const fe_handle* h) { return !h ? 0 : h->fimpl ? h->fimpl->dbg_floats : (h->bimpl ? h->bimpl->dbg_floats : (h->impl ? h->impl->dbg_floats : 0)); }
 
 int fe_debug_stage(const fe_handle* h, int idx, const char** name, int* rows, int* cols, size_t* offset_floats) {
     if (!h || idx < 0 || idx >= fe_debug_stages(h)) return fail(FE_ERR_INVALID_ARG, "stage index %d", idx);
     static thread_local std::string nm;
+    if (h->fimpl) {
+        static const char* const names[16] = {"spec_in", "compressed", "subband_encoder", "fullband_encoder.2", "feature_merge", "dpe.0.intra",
+                                              "dpe.0.inter", "dpe.1.intra", "dpe.1.inter", "dpe.2.intra", "dpe.2.inter", "feature_split",
+                                              "fullband_decoder.0", "fullband_decoder.1", "mask", "spec_out"};
+        int r, c; size_t off;
+        h->fimpl->dbg_stage(idx, &r, &c, &off);
+        if (name) *name = names[idx];
+        if (rows) *rows = r;
+        if (cols) *cols = c;
+        if (offset_floats) *offset_floats = off;
+        return FE_OK;
+    }
     if (h->bimpl) {   // spec_in, compressed, band_split, (layer.l.time, layer.l.freq)..., mask_mlp, spec_out
         const int L = h->cfg.rf_blocks;
         char bufn[64];

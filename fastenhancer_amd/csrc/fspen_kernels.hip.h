@@ -1,0 +1,804 @@
+// fspen_kernels.hip.h — the FSPEN baseline model (models/fspen/model.py of the reference, configs/others/fspen.yaml) as one
+// fused per-frame kernel for gfx950: STFT -> compress -> sub-band / full-band encoders -> feature merge -> 3 x DPE (intra
+// bidirectional GRU over the 32 sub-bands, LayerNorm, 8 grouped inter GRUs over time with their states in the stream state)
+// -> feature split -> sub-band / full-band decoders -> masks -> un-compress -> iSTFT.  SURVEY.md §8(f) rank 4.
+//
+// The model is tiny (0.9 MMAC per frame, 79 k weights) and most of it is M = 1 work per stream: one workgroup per stream,
+// every activation in 54 KB of LDS (three workgroups per CU), VALU dot products with weights packed k-major by the host
+// (fe_api.hip::pack_weights_fspen) so that the lanes of a wave read consecutive floats, and a wave-per-direction
+// recurrence for the intra GRU (W_hh of a direction in 48 registers of lanes 0..15, h broadcast with v_readlane).
+// It is latency-bound (96 dependent GRU steps per frame), not a GEMM: no MFMA here.
+#pragma once
+#include "fe_kernels.hip.h"
+
+namespace fe {
+
+// fixed architecture of configs/others/fspen.yaml (the only shipped yaml; fe_create rejects anything else)
+template <int HOP_>
+struct FShape {
+    static constexpr int HOP = HOP_, NFFT = 512, LOG2N = 9, OVL = NFFT - HOP;
+    static constexpr int BINS = 257;
+    static constexpr int NB = 3, C = 16, F = 32, G = 8, FG = F / G;       // DPE: blocks, channels, sub-bands, groups
+    static constexpr int NCACHE = NB * G;
+    static constexpr int CACHE_FLOATS = NCACHE * FG * C;                  // per stream
+};
+
+// ---- packed weights (floats), filled by the host packer; all matrices k-major: [k][outputs]
+struct FPk {
+    static constexpr int WINDOW = 0, WINDOW_I = 512, TW = 1024;           // twiddles float2[256]
+    static constexpr int SE_W = 1536;                                     // sub-band encoder: 5 x [K_i][32], K = 4, 7, 11, 20, 40
+    static constexpr int SE_B = SE_W + 82 * 32;                           // 5 x [32]
+    static constexpr int FE0_W = SE_B + 160;                              // [(c*6 + k)][4]     c < 2
+    static constexpr int FE0_B = FE0_W + 48;
+    static constexpr int FE1_W = FE0_B + 4;                               // [(c*8 + k)][16]    c < 4
+    static constexpr int FE1_B = FE1_W + 512;
+    static constexpr int FE2_W = FE1_B + 16;                              // [(c*6 + k)][32]    c < 16
+    static constexpr int FE2_B = FE2_W + 3072;
+    static constexpr int POST_W = FE2_B + 32;                             // [c][32]
+    static constexpr int MG1_W = POST_W + 1024;                           // feature_merge.0: [i < 64][j < 32]
+    static constexpr int MG2_W = MG1_W + 2048;                            // feature_merge.2: [ch < 32][c < 16]
+    static constexpr int MG2_B = MG2_W + 512;
+    static constexpr int DPE = MG2_B + 16;
+    // per DPE block:
+    static constexpr int D_IH = 0;                                        // intra W_ih^T [d][k][48]
+    static constexpr int D_GB = D_IH + 2 * 768;                           // [d][48]: b_ih + (b_hh for r, z | 0 for n)
+    static constexpr int D_HH = D_GB + 96;                                // intra W_hh: [d][gate][k][16 units]
+    static constexpr int D_HN = D_HH + 2 * 768;                           // [d][16]: b_hh of the n gate
+    static constexpr int D_FC_W = D_HN + 32;                              // intra_fc^T [k < 32][c]
+    static constexpr int D_FC_B = D_FC_W + 512;
+    static constexpr int D_LN_W = D_FC_B + 16;                            // [f][c]
+    static constexpr int D_LN_B = D_LN_W + 512;
+    static constexpr int D_G = D_LN_B + 512;                              // 8 groups x { ih [k][48], hh [k][48], gb [48], hn [16], fc^T [k][16], fcb [16] }
+    static constexpr int G_IH = 0, G_HH = 768, G_GB = 1536, G_HN = 1584, G_FC_W = 1600, G_FC_B = 1856, G_SIZE = 1872;
+    static constexpr int D_SIZE = D_G + 8 * G_SIZE;
+    static constexpr int SP1_W = DPE + 3 * D_SIZE;                        // feature_split.0^T [c < 16][ch < 32]
+    static constexpr int SP1_B = SP1_W + 512;
+    static constexpr int SP2_W = SP1_B + 32;                              // feature_split.1^T [f < 32][j < 64]
+    static constexpr int SD_W = SP2_W + 2048;                             // sub-band decoder, one column per bin: [k < 64][260]
+    static constexpr int SD_B = SD_W + 64 * 260;                          // [260]
+    static constexpr int FD0_W = SD_B + 260;                              // decoder 1x1 ^T: [c < 64][32]
+    static constexpr int FD0_T = FD0_W + 2048;                            // transposed conv [(c*6 + k)][16]   c < 32
+    static constexpr int FD0_B = FD0_T + 3072;
+    static constexpr int FD1_W = FD0_B + 16;                              // [c < 32][16]
+    static constexpr int FD1_T = FD1_W + 512;                             // [(c*8 + k)][4]    c < 16
+    static constexpr int FD1_B = FD1_T + 512;
+    static constexpr int FD2_W = FD1_B + 4;                               // [c < 8][4]
+    static constexpr int FD2_T = FD2_W + 32;                              // [(c*6 + k)][2]    c < 4
+    static constexpr int FD2_B = FD2_T + 48;
+    static constexpr int TOTAL = (FD2_B + 2 + 3) / 4 * 4;
+};
+
+struct FArgs {
+    const float* wp;
+    const float* wav_in;
+    float* wav_out;
+    size_t in_stride, out_stride;
+    float* cache_stft;
+    float* cache_istft;
+    float* gru;               // [24][B*4][16] inter-GRU states (block-major, then group): ONNXModel.initialize_cache order
+    const float* spec_in;     // spec mode [B][257][T][2]
+    float* spec_out;
+    float* dbg;
+    size_t dbg_stride;
+    int B, T, mode, Tw;
+    float compression;
+    unsigned long long* clk;
+};
+
+// debug stages (fe_debug_step): name, rows, cols as dumped (row-major)
+struct FDebugLayout {
+    static constexpr int n_stages = 16;
+    // 0 spec_in [257][2], 1 compressed [257][2], 2 subband_encoder [32 ch][32], 3 fullband_encoder.2 [32][32],
+    // 4 feature_merge [16 c][32 f], 5+2b dpe.b.intra [32 f][16 c], 6+2b dpe.b.inter, 11 feature_split [32][64],
+    // 12 fullband_decoder.0 [16][64], 13 fullband_decoder.1 [4][128], 14 mask [257][3] (full re, im, sub), 15 spec_out [257][2]
+    __host__ __device__ static constexpr int rows(int s) {
+        return (s <= 1 || s >= 14) ? 257 : (s == 2 || s == 3 || s == 11) ? 32 : s == 4 ? 16 : s == 12 ? 16 : s == 13 ? 4 : 32;
+    }
+    __host__ __device__ static constexpr int cols(int s) {
+        return (s <= 1 || s == 15) ? 2 : s == 14 ? 3 : (s == 2 || s == 3 || s == 4) ? 32 : s == 11 ? 64 : s == 12 ? 64 : s == 13 ? 128 : 16;
+    }
+    __host__ __device__ static constexpr size_t offset(int s) {
+        size_t o = 0;
+        for (int i = 0; i < s; ++i) o += (size_t)rows(i) * cols(i);
+        return o;
+    }
+    __host__ __device__ static constexpr size_t total() { return offset(n_stages); }
+};
+
+struct FLds {
+    // live for the whole frame
+    static constexpr int SP = 0;                   // compressed spectrum [257][2]
+    static constexpr int TW = SP + 516;            // twiddles float2[256]
+    static constexpr int E0 = TW + 512;            // fullband_encoder.0 out [4][134]  (3 zero columns either side: next conv's padding)
+    static constexpr int E1 = E0 + 4 * 134;        // fullband_encoder.1 out [16][68]  (2 either side)
+    static constexpr int E2 = E1 + 16 * 68;        // fullband_encoder.2 out [32][32]
+    static constexpr int CAT = E2 + 1024;          // [32][64]: fullband_encoder_post | sub-band encoder
+    static constexpr int SB = CAT + 2048;          // ---- phase scratch
+    static constexpr int FA = SB, FB = SB + 1024;
+    static constexpr int MAGP = SB + 2048;         // |X| [1 + 257 + 5] zero padded
+    static constexpr int EIN = MAGP + 264;         // compressed re / im planes [2][264] (2 zero columns left, 5 right)
+    static constexpr int M1 = SB;                  // feature_merge linear out [32][32]
+    static constexpr int XA = SB + 1024, XB = SB + 1536;      // DPE tokens [32 f][16 c], ping-pong
+    static constexpr int GI = SB + 2048;           // intra GRU input projections [2][32][48]
+    static constexpr int HSEQ = SB + 5120;         // intra GRU outputs [32][32] (fwd | bwd)
+    static constexpr int Y = SB + 6144;            // intra_fc out / inter scratch [32][16]
+    static constexpr int HPREV = SB + 6656, HN = SB + 7168, RED = SB + 7680;
+    static constexpr int S1 = SB + 2048;           // feature_split conv out [32][32]
+    static constexpr int S2 = SB + 3072;           // feature_split out [32][64]
+    static constexpr int MSUB = SB + 5120;         // sub-band mask [260]
+    static constexpr int T2 = SB, D2 = SB + 1024;  // decoder 0: 1x1 out [32][32], transposed conv out [16][64]
+    static constexpr int T1 = SB + 5632, D1 = SB + 6656, T0 = SB + 7168;
+    static constexpr int MF = SB + 2048;           // full-band mask [2][258]
+    static constexpr int TOTAL = SB + 7696;
+    static_assert(SB % 2 == 0 && TW % 2 == 0, "float2 alignment");
+    static_assert((size_t)TOTAL * 4 <= 64 * 1024, "static LDS");
+};
+
+__device__ __forceinline__ float elu_f(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+#define FS_CLK(i) do { if constexpr (PROF) { if (blockIdx.x == 0 && threadIdx.x == 0) a.clk[(i)] = __builtin_readcyclecounter(); } } while (0)
+
+template <class S, bool PROF, bool DBG>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) fspen_frame_kernel(FArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[FLds::TOTAL];
+    using L = FLds;
+    using P = FPk;
+    constexpr int N = S::NFFT, H = S::HOP, OVL = S::OVL, BINS = S::BINS;
+    const int tid0 = threadIdx.x;
+    const int tid = tid0;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* __restrict__ wp0 = a.wp;
+    const float* __restrict__ wp = wp0;
+    const int mode = a.mode, aT = a.T;
+
+    float* sp = smem + L::SP;
+    float2* tw = reinterpret_cast<float2*>(smem + L::TW);
+    float2* fa = reinterpret_cast<float2*>(smem + L::FA);
+    float2* fb = reinterpret_cast<float2*>(smem + L::FB);
+    float* e0 = smem + L::E0;
+    float* e1 = smem + L::E1;
+    float* e2 = smem + L::E2;
+    float* cat = smem + L::CAT;
+    for (int i = tid; i < N / 2; i += kThreads) tw[i] = reinterpret_cast<const float2*>(wp + P::TW)[i];
+    // the zero columns of the padded encoder outputs are written once (the convs only write the interior)
+    for (int i = tid; i < 4 * 134; i += kThreads) e0[i] = 0.0f;
+    for (int i = tid; i < 16 * 68; i += kThreads) e1[i] = 0.0f;
+    __syncthreads();
+
+    int b = blockIdx.x;
+#pragma unroll 1
+    do {
+    float* cst = a.cache_stft + (size_t)b * OVL;
+    float* cis = a.cache_istft + (size_t)b * OVL;
+    float* dbg = DBG ? a.dbg + (size_t)b * a.dbg_stride : nullptr;
+    // dump(stage, f): element (r, c) of the stage = f(r, c)
+    auto dump = [&](int stage, auto&& f) {
+        if constexpr (DBG) {
+            const int rows = FDebugLayout::rows(stage), cols = FDebugLayout::cols(stage);
+            float* dst = dbg + FDebugLayout::offset(stage);
+            for (int i = tid; i < rows * cols; i += kThreads) { const int r = i / cols, c = i - r * cols; dst[i] = f(r, c); }
+        }
+    };
+
+#pragma unroll 1
+    for (int t = 0; t < aT; ++t) {
+        // a loop-variant zero on the weight pointer: the weights sit at compile-time offsets, and hoisted out of the frame /
+        // stream loops their loads would stay live for the whole kernel (512 VGPRs, 229 spilled SGPRs without it)
+        // (the same for the thread index: ~250 hoisted LDS addresses otherwise)
+        int lz = 0, lzv = 0;
+        asm volatile("" : "+s"(lz));
+        asm volatile("" : "+v"(lzv));
+        const float* __restrict__ wp = wp0 + lz;
+        const int tid = tid0 + lzv;
+        const int lane = tid & 63;
+        FS_CLK(0);
+        // ============================ STFT + compress (models/fspen/model.py:409-417) ============================
+        float* magp = smem + L::MAGP;
+        float* ein = smem + L::EIN;
+        if (mode != FE_MODE_SPEC) {
+            const float* win = wp + P::WINDOW;
+            if (mode == FE_MODE_STREAM) {
+                const float* xin = a.wav_in + (size_t)b * a.in_stride + (size_t)t * H;
+                for (int n = tid; n < N; n += kThreads) {
+                    const float v = (n < OVL) ? cst[n] : xin[n - OVL];
+                    fb[n] = make_float2(v, 0.0f);
+                    fa[n] = make_float2(v * win[n], 0.0f);
+                }
+            } else {
+                const float* xin = a.wav_in + (size_t)b * a.in_stride;
+                for (int n = tid; n < N; n += kThreads) {
+                    int idx = t * H + n - N / 2;
+                    idx = idx < 0 ? -idx : idx;
+                    idx = idx >= a.Tw ? 2 * (a.Tw - 1) - idx : idx;
+                    fa[n] = make_float2(xin[idx] * win[n], 0.0f);
+                }
+            }
+            __syncthreads();
+            if (mode == FE_MODE_STREAM) {
+                for (int m = tid; m < OVL; m += kThreads) cst[m] = fb[m + H].x;
+                __syncthreads();
+            }
+            float2* Xf = fft_lds<S, false>(fa, fb, tw);
+            if constexpr (DBG) { for (int f = tid; f < BINS; f += kThreads) { dbg[2 * f] = Xf[f].x; dbg[2 * f + 1] = Xf[f].y; } }
+            for (int f = tid; f < 264; f += kThreads) {
+                float re = 0.0f, im = 0.0f;
+                if (f < BINS) {
+                    re = Xf[f].x; im = Xf[f].y;
+                    const float g = pow_f(fmaxf(sqrtf(re * re + im * im), 1.0e-5f), a.compression - 1.0f);
+                    re *= g; im *= g;
+                    sp[2 * f] = re; sp[2 * f + 1] = im;
+                }
+                // planes with 2 zero columns on the left (conv padding), |X| with 1
+                if (f + 2 < 264) { ein[f + 2] = re; ein[264 + f + 2] = im; }
+                if (f + 1 < 264) magp[f + 1] = sqrtf(re * re + im * im);
+            }
+            if (tid < 2) { ein[tid] = 0.0f; ein[264 + tid] = 0.0f; }
+            if (tid == 0) magp[0] = 0.0f;
+        } else {
+            const float* si = a.spec_in + (size_t)b * BINS * aT * 2;
+            for (int f = tid; f < 264; f += kThreads) {
+                float re = 0.0f, im = 0.0f;
+                if (f < BINS) {
+                    re = si[((size_t)f * aT + t) * 2]; im = si[((size_t)f * aT + t) * 2 + 1];
+                    if constexpr (DBG) { dbg[2 * f] = re; dbg[2 * f + 1] = im; }
+                    const float g = pow_f(fmaxf(sqrtf(re * re + im * im), 1.0e-5f), a.compression - 1.0f);
+                    re *= g; im *= g;
+                    sp[2 * f] = re; sp[2 * f + 1] = im;
+                }
+                if (f + 2 < 264) { ein[f + 2] = re; ein[264 + f + 2] = im; }
+                if (f + 1 < 264) magp[f + 1] = sqrtf(re * re + im * im);
+            }
+            if (tid < 2) { ein[tid] = 0.0f; ein[264 + tid] = 0.0f; }
+            if (tid == 0) magp[0] = 0.0f;
+        }
+        __syncthreads();
+        dump(1, [&](int r, int c) { return sp[2 * r + c]; });
+
+        FS_CLK(1);
+        // ============================ sub-band encoder (SubbandEncoder.forward, :58-66) + full-band conv 0 ============================
+        {   // 32 channels x 32 positions; position -> (segment, j): 8 of segment 0, then 6 each
+            const int ch = tid & 31;
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                const int pos = (tid >> 5) + 8 * q;
+                int seg, j;
+                if (pos < 8) { seg = 0; j = pos; } else { seg = 1 + (pos - 8) / 6; j = (pos - 8) - (seg - 1) * 6; }
+                // segment: kernel K, stride, first padded-|X| index, weight row offset
+                const int K = seg == 0 ? 4 : seg == 1 ? 7 : seg == 2 ? 11 : seg == 3 ? 20 : 40;
+                const int st = seg == 0 ? 2 : seg == 1 ? 3 : seg == 2 ? 5 : seg == 3 ? 10 : 20;
+                const int base = (seg == 0 ? 0 : seg == 1 ? 14 : seg == 2 ? 31 : seg == 3 ? 62 : 123) + st * j;
+                const int wrow = seg == 0 ? 0 : seg == 1 ? 4 : seg == 2 ? 11 : seg == 3 ? 22 : 42;
+                const float* w = wp + P::SE_W + wrow * 32 + ch;
+                float acc = wp[P::SE_B + seg * 32 + ch];
+                for (int k = 0; k < K; ++k) acc = fmaf(w[k * 32], magp[base + k], acc);
+                cat[ch * 64 + 32 + pos] = fmaxf(acc, 0.0f);
+            }
+        }
+        {   // fullband_encoder.0: Conv1d(2 -> 4, k 6, s 2, p 2) + folded BN + ELU -> e0[o][3 + j], j < 128
+            const int o = tid & 3;
+            float wr[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) wr[i] = wp[P::FE0_W + i * 4 + o];
+            const float bias = wp[P::FE0_B + o];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int j = (tid >> 2) + 64 * q;
+                float acc = bias;
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) acc = fmaf(wr[c * 6 + k], ein[c * 264 + 2 * j + k], acc);
+                e0[o * 134 + 3 + j] = elu_f(acc);
+            }
+        }
+        __syncthreads();
+        dump(2, [&](int r, int c) { return cat[r * 64 + 32 + c]; });
+        {   // fullband_encoder.1: Conv1d(4 -> 16, k 8, s 2, p 3) -> e1[o][2 + j], j < 64
+            const int o = tid & 15;
+            float acc[4];
+            const float bias = wp[P::FE1_B + o];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = bias;
+#pragma unroll 4
+            for (int ck = 0; ck < 32; ++ck) {
+                const float w = wp[P::FE1_W + ck * 16 + o];
+                const int c = ck >> 3, k = ck & 7;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(w, e0[c * 134 + 2 * ((tid >> 4) + 16 * q) + k], acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e1[o * 68 + 2 + (tid >> 4) + 16 * q] = elu_f(acc[q]);
+        }
+        __syncthreads();
+        {   // fullband_encoder.2: Conv1d(16 -> 32, k 6, s 2, p 2) -> e2[o][j], j < 32
+            const int o = tid & 31;
+            float acc[4];
+            const float bias = wp[P::FE2_B + o];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = bias;
+#pragma unroll 1
+            for (int c = 0; c < 16; ++c)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const float w = wp[P::FE2_W + (c * 6 + k) * 32 + o];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = fmaf(w, e1[c * 68 + 2 * ((tid >> 5) + 8 * q) + k], acc[q]);
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e2[o * 32 + (tid >> 5) + 8 * q] = elu_f(acc[q]);
+        }
+        __syncthreads();
+        dump(3, [&](int r, int c) { return e2[r * 32 + c]; });
+        {   // fullband_encoder_post: 1x1 (32 -> 32), no bias -> cat[o][f], f < 32
+            const int o = tid & 31;
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+            for (int c = 0; c < 32; ++c) {
+                const float w = wp[P::POST_W + c * 32 + o];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(w, e2[c * 32 + (tid >> 5) + 8 * q], acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cat[o * 64 + (tid >> 5) + 8 * q] = acc[q];
+        }
+        __syncthreads();
+
+        FS_CLK(2);
+        // ============================ feature merge (:246-250): Linear(64 -> 32) over the band axis, ELU, 1x1 (32 -> 16) ============================
+        float* m1 = smem + L::M1;
+        {
+            const int j = tid & 31;
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+            for (int i = 0; i < 64; ++i) {
+                const float w = wp[P::MG1_W + i * 32 + j];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(w, cat[((tid >> 5) + 8 * q) * 64 + i], acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m1[((tid >> 5) + 8 * q) * 32 + j] = elu_f(acc[q]);
+        }
+        __syncthreads();
+        float* x = smem + L::XA;          // tokens [f][c]
+        float* xn = smem + L::XB;
+        {
+            const int c = tid & 15;
+            float acc[2];
+            acc[0] = acc[1] = wp[P::MG2_B + c];
+#pragma unroll 4
+            for (int ch = 0; ch < 32; ++ch) {
+                const float w = wp[P::MG2_W + ch * 16 + c];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[q] = fmaf(w, m1[ch * 32 + (tid >> 4) + 16 * q], acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) x[((tid >> 4) + 16 * q) * 16 + c] = acc[q];
+        }
+        __syncthreads();
+        dump(4, [&](int r, int c) { return x[c * 16 + r]; });
+
+        FS_CLK(3);
+        // ============================ 3 x DPE (DPE.forward, :172-189) ============================
+        float* gi = smem + L::GI;
+        float* hseq = smem + L::HSEQ;
+        float* hprev = smem + L::HPREV;
+        float* hn = smem + L::HN;
+        float* red = smem + L::RED;
+#pragma unroll 1
+        for (int blk = 0; blk < S::NB; ++blk) {
+            const float* wd = wp + P::DPE + blk * P::D_SIZE;
+            // inter-GRU states of this block: [g][B*4][16] -> hprev[f][16]   (in flight across the intra GRU)
+            float hp[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int f = (tid >> 4) + 16 * q, g = f >> 2;
+                hp[q] = a.gru[(((size_t)(blk * S::G + g) * a.B + b) * S::FG + (f & 3)) * S::C + (tid & 15)];
+            }
+            // ---- intra GRU input projections: gi[d][f][g48] = x[f] . W_ih^T + bias
+            if (tid < 192) {
+                const int g48 = tid % 48, fq = tid / 48;
+#pragma unroll 1
+                for (int d = 0; d < 2; ++d) {
+                    float w[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) w[k] = wd[P::D_IH + (d * 16 + k) * 48 + g48];
+                    const float bias = wd[P::D_GB + d * 48 + g48];
+#pragma unroll 2
+                    for (int r = 0; r < 8; ++r) {
+                        const int f = fq + 4 * r;
+                        float acc = bias;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) acc = fmaf(w[k], x[f * 16 + k], acc);
+                        gi[(d * 32 + f) * 48 + g48] = acc;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) hprev[((tid >> 4) + 16 * q) * 16 + (tid & 15)] = hp[q];
+            __syncthreads();
+            // ---- the recurrence: wave d walks direction d; lane c < 16 owns hidden unit c (its three gate rows in registers)
+            if (wave < 2) {
+                const int d = wave, c = lane & 15;
+                float wr[16], wz[16], wn[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    wr[k] = wd[P::D_HH + ((d * 3 + 0) * 16 + k) * 16 + c];
+                    wz[k] = wd[P::D_HH + ((d * 3 + 1) * 16 + k) * 16 + c];
+                    wn[k] = wd[P::D_HH + ((d * 3 + 2) * 16 + k) * 16 + c];
+                }
+                const float bhn = wd[P::D_HN + d * 16 + c];
+                float h = 0.0f;
+                const float* gd = gi + d * 32 * 48;
+                int f = d ? 31 : 0;
+                float g_r = gd[f * 48 + c], g_z = gd[f * 48 + 16 + c], g_n = gd[f * 48 + 32 + c];
+#pragma unroll 1
+                for (int s = 0; s < 32; ++s) {
+                    const int fnx = d ? (s < 31 ? f - 1 : f) : (s < 31 ? f + 1 : f);
+                    const float n_r = gd[fnx * 48 + c], n_z = gd[fnx * 48 + 16 + c], n_n = gd[fnx * 48 + 32 + c];      // next step's x side
+                    float ar = 0.0f, az = 0.0f, an = bhn;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const float hk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, h), k));
+                        ar = fmaf(wr[k], hk, ar);
+                        az = fmaf(wz[k], hk, az);
+                        an = fmaf(wn[k], hk, an);
+                    }
+                    const float r = sigmoid_f(g_r + ar);
+                    const float z = sigmoid_f(g_z + az);
+                    const float n = tanh_f(g_n + r * an);
+                    h = (1.0f - z) * n + z * h;
+                    if (lane < 16) hseq[f * 32 + d * 16 + c] = h;
+                    f = fnx; g_r = n_r; g_z = n_z; g_n = n_n;
+                }
+            }
+            __syncthreads();
+            // ---- intra_fc + LayerNorm([F, C]) + residual
+            float yv[2];
+            {
+                const int c = tid & 15;
+                yv[0] = yv[1] = wd[P::D_FC_B + c];
+#pragma unroll 4
+                for (int k = 0; k < 32; ++k) {
+                    const float w = wd[P::D_FC_W + k * 16 + c];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) yv[q] = fmaf(w, hseq[((tid >> 4) + 16 * q) * 32 + k], yv[q]);
+                }
+            }
+            float s0 = wave_sum(yv[0] + yv[1]);
+            if (lane == 0) red[wave] = s0;
+            __syncthreads();
+            const float mean = (red[0] + red[1] + red[2] + red[3]) * (1.0f / 512.0f);
+            const float d0 = yv[0] - mean, d1 = yv[1] - mean;
+            float s1 = wave_sum(d0 * d0 + d1 * d1);
+            if (lane == 0) red[4 + wave] = s1;
+            __syncthreads();
+            const float inv_std = __builtin_amdgcn_rsqf((red[4] + red[5] + red[6] + red[7]) * (1.0f / 512.0f) + 1.0e-5f);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int i = ((tid >> 4) + 16 * q) * 16 + (tid & 15);
+                xn[i] = (q ? d1 : d0) * inv_std * wd[P::D_LN_W + i] + wd[P::D_LN_B + i] + x[i];
+            }
+            __syncthreads();
+            dump(5 + 2 * blk, [&](int r, int c) { return xn[r * 16 + c]; });
+            // ---- inter path (InterRNNPathExtension.forward, :122-138): group g = f / 4 has its own GRU (one step per frame) and fc
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int f = (tid >> 4) + 16 * q, c = tid & 15;
+                const float* wg = wd + P::D_G + (f >> 2) * P::G_SIZE;
+                float ir = wg[P::G_GB + c], iz = wg[P::G_GB + 16 + c], in_ = wg[P::G_GB + 32 + c];
+                float hr = 0.0f, hz = 0.0f, hnn = wg[P::G_HN + c];
+#pragma unroll 4
+                for (int k = 0; k < 16; ++k) {
+                    const float xv = xn[f * 16 + k], hv = hprev[f * 16 + k];
+                    ir = fmaf(wg[P::G_IH + k * 48 + c], xv, ir);
+                    iz = fmaf(wg[P::G_IH + k * 48 + 16 + c], xv, iz);
+                    in_ = fmaf(wg[P::G_IH + k * 48 + 32 + c], xv, in_);
+                    hr = fmaf(wg[P::G_HH + k * 48 + c], hv, hr);
+                    hz = fmaf(wg[P::G_HH + k * 48 + 16 + c], hv, hz);
+                    hnn = fmaf(wg[P::G_HH + k * 48 + 32 + c], hv, hnn);
+                }
+                const float r = sigmoid_f(ir + hr);
+                const float z = sigmoid_f(iz + hz);
+                const float n = tanh_f(in_ + r * hnn);
+                const float hnew = (1.0f - z) * n + z * hprev[f * 16 + c];
+                hn[f * 16 + c] = hnew;
+                a.gru[(((size_t)(blk * S::G + (f >> 2)) * a.B + b) * S::FG + (f & 3)) * S::C + c] = hnew;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int f = (tid >> 4) + 16 * q, c = tid & 15;
+                const float* wg = wd + P::D_G + (f >> 2) * P::G_SIZE;
+                float acc = wg[P::G_FC_B + c];
+#pragma unroll 4
+                for (int k = 0; k < 16; ++k) acc = fmaf(wg[P::G_FC_W + k * 16 + c], hn[f * 16 + k], acc);
+                x[f * 16 + c] = acc + 2.0f * xn[f * 16 + c];          // + x_in inside the path extension, + x_in again in DPE.forward
+            }
+            __syncthreads();
+            dump(6 + 2 * blk, [&](int r, int c) { return x[r * 16 + c]; });
+        }
+
+        FS_CLK(4);
+        // ============================ feature split (:256-260): 1x1 (16 -> 32), Linear(32 -> 64) over the band axis, ELU ============================
+        float* s1 = smem + L::S1;
+        float* s2 = smem + L::S2;
+        {
+            const int ch = tid & 31;
+            float acc[4];
+            const float bias = wp[P::SP1_B + ch];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = bias;
+#pragma unroll 4
+            for (int c = 0; c < 16; ++c) {
+                const float w = wp[P::SP1_W + c * 32 + ch];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(w, x[((tid >> 5) + 8 * q) * 16 + c], acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s1[ch * 32 + (tid >> 5) + 8 * q] = acc[q];
+        }
+        __syncthreads();
+        {
+            const int j = tid & 63;
+            float acc[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = 0.0f;
+#pragma unroll 2
+            for (int f = 0; f < 32; ++f) {
+                const float w = wp[P::SP2_W + f * 64 + j];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] = fmaf(w, s1[((tid >> 6) + 4 * q) * 32 + f], acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s2[((tid >> 6) + 4 * q) * 64 + j] = elu_f(acc[q]);
+        }
+        __syncthreads();
+        dump(11, [&](int r, int c) { return s2[r * 64 + c]; });
+
+        FS_CLK(5);
+        // ============================ sub-band decoder (SubbandDecoder.forward, :83-95): one output per bin ============================
+        float* msub = smem + L::MSUB;
+        for (int bin = tid; bin < BINS; bin += kThreads) {
+            // bin -> (linear layer, flattened index) -> input row of the [32 + zero row][64] matrix
+            int row;
+            if (bin < 16) row = bin / 2;
+            else if (bin < 32) row = 8 + (bin - 16 + 1) / 3;
+            else if (bin < 64) row = 13 + (bin - 32 + 4) / 5;
+            else if (bin < 128) row = 19 + (bin - 64 + 8) / 10;
+            else row = 25 + (bin - 128 + 16) / 20;
+            float acc = wp[P::SD_B + bin];
+            if (row < 32) {
+                for (int k = 0; k < 32; ++k) acc = fmaf(wp[P::SD_W + k * 260 + bin], cat[k * 64 + 32 + row], acc);
+                for (int k = 0; k < 32; ++k) acc = fmaf(wp[P::SD_W + (32 + k) * 260 + bin], s2[k * 64 + 32 + row], acc);
+            }
+            msub[bin] = fmaxf(acc, 0.0f);
+        }
+        // ============================ full-band decoder (:262-277, :397-400) ============================
+        float* t2 = smem + L::T2;
+        {   // decoder 0: 1x1 over cat(x_full, enc_out[2]) (64 -> 32)
+            const int o = tid & 31;
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+            for (int c = 0; c < 32; ++c) {
+                const float w0 = wp[P::FD0_W + c * 32 + o], w1 = wp[P::FD0_W + (32 + c) * 32 + o];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f = (tid >> 5) + 8 * q;
+                    acc[q] = fmaf(w0, s2[c * 64 + f], acc[q]);
+                    acc[q] = fmaf(w1, e2[c * 32 + f], acc[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t2[o * 32 + (tid >> 5) + 8 * q] = acc[q];
+        }
+        __syncthreads();
+        float* d2 = smem + L::D2;
+        {   // ConvTranspose1d(32 -> 16, k 6, s 2, p 2) + folded BN + ELU: y[o][p] += x[c][f] w[c][o][k], p = 2 f + k - 2
+            const int o = tid & 15;
+            float acc[4];
+            const float bias = wp[P::FD0_B + o];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = bias;
+#pragma unroll 1
+            for (int c = 0; c < 32; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int p = (tid >> 4) + 16 * q, k0 = p & 1;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const int k = k0 + 2 * i, f = (p + 2 - k) >> 1;
+                        if (f >= 0 && f < 32) acc[q] = fmaf(wp[P::FD0_T + (c * 6 + k) * 16 + o], t2[c * 32 + f], acc[q]);
+                    }
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d2[o * 64 + (tid >> 4) + 16 * q] = elu_f(acc[q]);
+        }
+        __syncthreads();
+        dump(12, [&](int r, int c) { return d2[r * 64 + c]; });
+        float* t1 = smem + L::T1;
+        {   // decoder 1: 1x1 over cat(d2, enc_out[1]) (32 -> 16)
+            const int o = tid & 15;
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+            for (int c = 0; c < 16; ++c) {
+                const float w0 = wp[P::FD1_W + c * 16 + o], w1 = wp[P::FD1_W + (16 + c) * 16 + o];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f = (tid >> 4) + 16 * q;
+                    acc[q] = fmaf(w0, d2[c * 64 + f], acc[q]);
+                    acc[q] = fmaf(w1, e1[c * 68 + 2 + f], acc[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t1[o * 64 + (tid >> 4) + 16 * q] = acc[q];
+        }
+        __syncthreads();
+        float* d1 = smem + L::D1;
+        {   // ConvTranspose1d(16 -> 4, k 8, s 2, p 3) + folded BN + ELU: p = 2 f + k - 3
+            const int o = tid & 3;
+            float acc[2];
+            acc[0] = acc[1] = wp[P::FD1_B + o];
+#pragma unroll 1
+            for (int c = 0; c < 16; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int p = (tid >> 2) + 64 * q, k0 = (p + 1) & 1;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = k0 + 2 * i, f = (p + 3 - k) >> 1;
+                        if (f >= 0 && f < 64) acc[q] = fmaf(wp[P::FD1_T + (c * 8 + k) * 4 + o], t1[c * 64 + f], acc[q]);
+                    }
+                }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) d1[o * 128 + (tid >> 2) + 64 * q] = elu_f(acc[q]);
+        }
+        __syncthreads();
+        dump(13, [&](int r, int c) { return d1[r * 128 + c]; });
+        float* t0 = smem + L::T0;
+        {   // decoder 2: 1x1 over cat(d1, enc_out[0]) (8 -> 4)
+            const int o = tid & 3;
+            float acc[2] = {0.0f, 0.0f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float w0 = wp[P::FD2_W + c * 4 + o], w1 = wp[P::FD2_W + (4 + c) * 4 + o];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int f = (tid >> 2) + 64 * q;
+                    acc[q] = fmaf(w0, d1[c * 128 + f], acc[q]);
+                    acc[q] = fmaf(w1, e0[c * 134 + 3 + f], acc[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) t0[o * 128 + (tid >> 2) + 64 * q] = acc[q];
+        }
+        __syncthreads();
+        float* mf = smem + L::MF;
+        for (int i = tid; i < 2 * BINS; i += kThreads) {
+            // ConvTranspose1d(4 -> 2, k 6, s 2, p 2, output_padding 1) + bias: p = 2 f + k - 2, p < 257
+            const int o = i & 1, p = i >> 1, k0 = p & 1;
+            float acc = wp[P::FD2_B + o];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int k = k0 + 2 * j, f = (p + 2 - k) >> 1;
+                    if (f >= 0 && f < 128) acc = fmaf(wp[P::FD2_T + (c * 6 + k) * 2 + o], t0[c * 128 + f], acc);
+                }
+            mf[o * 258 + p] = acc;
+        }
+        __syncthreads();
+        dump(14, [&](int r, int c) { return c < 2 ? mf[c * 258 + r] : msub[r]; });
+
+        FS_CLK(6);
+        // ============================ masks (:401-407), un-compress (:422-428), iSTFT ============================
+        {
+            float* spo = mode == FE_MODE_SPEC ? a.spec_out + (size_t)b * BINS * aT * 2
+                                              : (mode == FE_MODE_OFFLINE ? a.spec_out + (size_t)b * BINS * aT * 2 : nullptr);
+            for (int f = tid; f < BINS; f += kThreads) {
+                const float sr = sp[2 * f], si = sp[2 * f + 1], mr = mf[f], mi = mf[258 + f];
+                const float o_r = sr * mr - si * mi, o_i = sr * mi + si * mr;
+                const float mfm = sqrtf(mr * mr + mi * mi);
+                const float mm = (msub[f] + mfm) * 0.5f;
+                float yr = o_r / mfm * mm, yi = o_i / mfm * mm;
+                if (mode == FE_MODE_OFFLINE) {          // Model.forward returns the COMPRESSED spectrum (spec_out of model_forward)
+                    spo[((size_t)f * aT + t) * 2] = yr;
+                    spo[((size_t)f * aT + t) * 2 + 1] = yi;
+                }
+                const float g = pow_f(sqrtf(yr * yr + yi * yi), 1.0f / a.compression - 1.0f);
+                yr *= g; yi *= g;
+                if constexpr (DBG) { float* d = dbg + FDebugLayout::offset(15); d[2 * f] = yr; d[2 * f + 1] = yi; }
+                if (mode == FE_MODE_SPEC) {
+                    spo[((size_t)f * aT + t) * 2] = yr;
+                    spo[((size_t)f * aT + t) * 2 + 1] = yi;
+                } else if (f == 0) {
+                    fa[0] = make_float2(yr, 0.0f);
+                } else if (f == N / 2) {
+                    fa[N / 2] = make_float2(yr, 0.0f);        // irfft keeps only Re X[N/2]
+                } else {
+                    fa[f] = make_float2(yr, yi);
+                    fa[N - f] = make_float2(yr, -yi);
+                }
+            }
+        }
+        __syncthreads();
+        if (mode != FE_MODE_SPEC) {
+            float2* yv = fft_lds<S, true>(fa, fb, tw);
+            float2* spare = (yv == fa) ? fb : fa;
+            const float* wi = wp + (mode == FE_MODE_STREAM ? P::WINDOW_I : P::WINDOW);
+            float* xo = reinterpret_cast<float*>(spare);
+            const float invN = 1.0f / (float)N;
+            for (int n = tid; n < N; n += kThreads) {
+                float v = yv[n].x * invN * wi[n];
+                if (n < OVL) v += cis[n];
+                xo[n] = v;
+            }
+            __syncthreads();
+            if (mode == FE_MODE_STREAM) {
+                float* out = a.wav_out + (size_t)b * a.out_stride + (size_t)t * H;
+                for (int n = tid; n < H; n += kThreads) out[n] = xo[n];
+            } else {
+                const float* w = wp + P::WINDOW;
+                const int n_out = H * (aT - 1);
+                const int emit = (t == aT - 1) ? N : H;
+                float* out = a.wav_out + (size_t)b * a.out_stride;
+                for (int j = tid; j < emit; j += kThreads) {
+                    const int n = t * H + j, pos = n - N / 2;
+                    if (pos >= 0 && pos < n_out) {
+                        int t_lo = (n - N + H) / H;
+                        t_lo = t_lo < 0 ? 0 : t_lo;
+                        int t_hi = n / H;
+                        t_hi = t_hi > aT - 1 ? aT - 1 : t_hi;
+                        float env = 0.0f;
+                        for (int tt = t_lo; tt <= t_hi; ++tt) { const float wv = w[n - tt * H]; env += wv * wv; }
+                        out[pos] = xo[j] / env;
+                    }
+                }
+            }
+            for (int m = tid; m < OVL; m += kThreads) cis[m] = xo[m + H];
+            __syncthreads();
+        }
+        FS_CLK(7);
+    }
+    b += gridDim.x;
+    } while (b < a.B);
+}
+
+struct FImpl {
+    int HOP;
+    size_t lds_bytes;
+    size_t dbg_floats;
+    int dbg_stages;
+    size_t packed_floats;
+    void (*launch)(const FArgs&, int max_wgs, hipStream_t, hipError_t*);
+    void (*dbg_stage)(int, int*, int*, size_t*);
+};
+
+template <class S>
+void flaunch_impl(const FArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
+    constexpr int OCC = (160 * 1024) / (FLds::TOTAL * 4);          // workgroups per CU (LDS-limited)
+    const int slots = max_wgs * OCC;
+    const int grid = a.B < slots ? a.B : slots;                    // more streams than slots: persistent workgroups walk b, b + grid, ...
+    if (a.dbg != nullptr) hipLaunchKernelGGL((fspen_frame_kernel<S, false, true>), dim3(grid), dim3(kThreads), 0, st, a);
+    else if (a.clk != nullptr) hipLaunchKernelGGL((fspen_frame_kernel<S, true, false>), dim3(grid), dim3(kThreads), 0, st, a);
+    else hipLaunchKernelGGL((fspen_frame_kernel<S, false, false>), dim3(grid), dim3(kThreads), 0, st, a);
+    *err = hipGetLastError();
+}
+
+inline void fdbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
+    *rows = FDebugLayout::rows(s);
+    *cols = FDebugLayout::cols(s);
+    *off = FDebugLayout::offset(s);
+}
+
+template <class S>
+FImpl make_fimpl() {
+    return FImpl{S::HOP, (size_t)FLds::TOTAL * 4, FDebugLayout::total(), FDebugLayout::n_stages, (size_t)FPk::TOTAL, &flaunch_impl<S>, &fdbg_stage_impl};
+}
+
+}  // namespace fe

@@ -364,3 +364,105 @@ def check_shapes(fused: Mapping[str, Tensor], exp: Mapping[str, tuple], strict: 
             errs.append(f"size mismatch for {k}: checkpoint {tuple(fused[k].shape)} vs model {tuple(shp)}")
     if errs:
         raise RuntimeError("Error(s) in loading state_dict:\n\t" + "\n\t".join(errs))
+
+
+# ------------------------------------------------------------------------------------------------ FSPEN
+FSPEN_SUB_ENC_K = (4, 7, 11, 20, 40)      # SubbandEncoder kernels (models/fspen/model.py:41-44)
+FSPEN_SUB_DEC_N = (2, 3, 5, 10, 20)       # SubbandDecoder outputs per row (:70)
+
+
+def fspen_expected_fused_shapes(cfg) -> Dict[str, tuple]:
+    """fused state_dict of models/fspen/model.py::ONNXModel after remove_weight_reparameterizations (:299-340)."""
+    C1, K, C2, Fq = cfg.channels, cfg.kernel_size, cfg.dpe_channels, cfg.freq
+    sh: Dict[str, tuple] = {}
+    for i, k in enumerate(FSPEN_SUB_ENC_K):
+        sh[f"subband_encoder.conv{i + 1}.0.weight"] = (C1[-1], 1, k)
+        sh[f"subband_encoder.conv{i + 1}.0.bias"] = (C1[-1],)
+    for i, n in enumerate(FSPEN_SUB_DEC_N):
+        sh[f"subband_decoder.lin{i + 1}.0.weight"] = (n, 2 * C1[-1])
+        sh[f"subband_decoder.lin{i + 1}.0.bias"] = (n,)
+    for i in range(len(C1)):
+        sh[f"fullband_encoder.{i}.0.weight"] = (C1[i], 2 if i == 0 else C1[i - 1], K[i])
+        sh[f"fullband_encoder.{i}.0.bias"] = (C1[i],)
+    sh["fullband_encoder_post.weight"] = (C1[-1], C1[-1], 1)
+    sh["feature_merge.0.weight"] = (Fq, 64)
+    sh["feature_merge.2.weight"] = (C2, C1[-1], 1)
+    sh["feature_merge.2.bias"] = (C2,)
+
+    def gru(p, sfx=""):
+        sh[f"{p}.weight_ih_l0{sfx}"] = (3 * C2, C2)
+        sh[f"{p}.weight_hh_l0{sfx}"] = (3 * C2, C2)
+        sh[f"{p}.bias_ih_l0{sfx}"] = (3 * C2,)
+        sh[f"{p}.bias_hh_l0{sfx}"] = (3 * C2,)
+
+    for b in range(cfg.num_blocks):
+        p = f"dpe_blocks.{b}."
+        gru(p + "intra_rnn")
+        gru(p + "intra_rnn", "_reverse")
+        sh[p + "intra_fc.weight"] = (C2, 2 * C2)
+        sh[p + "intra_fc.bias"] = (C2,)
+        sh[p + "intra_ln.weight"] = (Fq, C2)
+        sh[p + "intra_ln.bias"] = (Fq, C2)
+        for g in range(cfg.groups):
+            gru(p + f"inter_rnn.inter_rnn.{g}")
+        for g in range(cfg.groups):
+            sh[p + f"inter_rnn.inter_fc.{g}.weight"] = (C2, C2)
+            sh[p + f"inter_rnn.inter_fc.{g}.bias"] = (C2,)
+    sh["feature_split.0.weight"] = (C1[-1], C2, 1)
+    sh["feature_split.0.bias"] = (C1[-1],)
+    sh["feature_split.1.weight"] = (64, Fq)
+    for j, i in enumerate(range(len(C1) - 1, -1, -1)):
+        cin, cout = C1[i], (2 if i == 0 else C1[i - 1])
+        sh[f"fullband_decoder.{j}.0.weight"] = (cin, 2 * cin, 1)
+        sh[f"fullband_decoder.{j}.1.weight"] = (cin, cout, K[i])
+        sh[f"fullband_decoder.{j}.1.bias"] = (cout,)
+    return sh
+
+
+def fspen_fold_state_dict(sd: Mapping[str, Tensor], cfg, eps: float = 1e-5) -> Dict[str, Tensor]:
+    """ONNXModel.remove_weight_reparameterizations of models/fspen/model.py:299-340: the BatchNorm that FOLLOWS each full-band
+    encoder conv / decoder transposed conv scales the conv's output channels (dim 0 of a Conv1d weight, dim 1 of a
+    ConvTranspose1d weight) and becomes its bias.  A dict without BatchNorm statistics is taken as already fused."""
+    sd = {k: torch.as_tensor(v) for k, v in sd.items()}
+    n = len(cfg.channels)
+    if "fullband_encoder.0.1.running_var" not in sd:
+        return {k: v.detach().to(torch.float32) for k, v in sd.items() if v.is_floating_point()}
+    bn_prefixes = tuple(f"fullband_encoder.{i}.1." for i in range(n)) + tuple(f"fullband_decoder.{j}.2." for j in range(n - 1))
+    out: Dict[str, Tensor] = {k: v.detach().to(torch.float32).clone() for k, v in sd.items()
+                              if v.is_floating_point() and not k.startswith(bn_prefixes)}
+
+    def scale_shift(p):
+        std = torch.sqrt(sd[p + "running_var"].float() + eps)
+        g = sd[p + "weight"].float() / std
+        return g, sd[p + "bias"].float() - sd[p + "running_mean"].float() * g
+
+    for i in range(n):
+        g, b = scale_shift(f"fullband_encoder.{i}.1.")
+        out[f"fullband_encoder.{i}.0.weight"] = sd[f"fullband_encoder.{i}.0.weight"].float() * g.view(-1, 1, 1)
+        out[f"fullband_encoder.{i}.0.bias"] = b
+    for j in range(n - 1):
+        g, b = scale_shift(f"fullband_decoder.{j}.2.")
+        out[f"fullband_decoder.{j}.1.weight"] = sd[f"fullband_decoder.{j}.1.weight"].float() * g.view(1, -1, 1)
+        out[f"fullband_decoder.{j}.1.bias"] = b
+    return out
+
+
+def fspen_default_state_dict(cfg, generator: Optional[torch.Generator] = None) -> Dict[str, Tensor]:
+    """Random fused weights of the right shapes (benchmarks, smoke tests): small fan-in-scaled matrices; the last transposed
+    conv gets a bias so that the complex mask stays away from the 0 / 0 of `out_full / mask_full_mag`."""
+    g = generator or torch.Generator().manual_seed(0)
+    sd: Dict[str, Tensor] = {}
+    last = f"fullband_decoder.{len(cfg.channels) - 1}.1."
+    for k, shp in fspen_expected_fused_shapes(cfg).items():
+        if k == last + "bias":
+            sd[k] = torch.tensor([0.6, 0.2])
+        elif k.endswith("intra_ln.weight"):
+            sd[k] = torch.ones(shp)
+        elif len(shp) == 1 or k.endswith("intra_ln.bias"):
+            sd[k] = 0.05 * torch.randn(shp, generator=g)
+        else:
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            sd[k] = torch.randn(shp, generator=g) * (0.5 / fan_in ** 0.5)
+    return sd

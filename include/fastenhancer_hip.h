@@ -33,7 +33,9 @@ extern "C" {
 #define FE_ERR_NO_WEIGHTS (-4)
 
 #define FE_ARCH_FASTENHANCER 0 /* models/fastenhancer/default/model.py */
-#define FE_ARCH_BSRNN 1        /* models/bsrnn/model.py (declared; see DESIGN.md for status) */
+#define FE_ARCH_BSRNN 1        /* models/bsrnn/model.py: channels = num_channels, rf_blocks = num_layers */
+#define FE_ARCH_FSPEN 2        /* models/fspen/model.py (configs/others/fspen.yaml): channels = channels[-1], kernel_size / n_kernels / stride
+                                * as in the yaml, rf_channels / rf_freq / rf_blocks / rf_heads = dpe_kwargs channels / freq / num_blocks / groups */
 
 #define FE_MAX_KERNELS 8
 

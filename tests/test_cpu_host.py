@@ -238,3 +238,40 @@ def test_time_kernel_mirror_state_layout_and_defaults():
     back = eng.split_state(state, B)
     assert len(back) == len(full) and all(torch.equal(a, b) for a, b in zip(back, full))
     assert eng.flops_per_frame == pytest.approx(build_oracle("fe_tk_b")[0].flops_per_frame())
+
+
+def test_fspen_host_side_without_gpu():
+    """FSPEN (models/fspen/model.py): the host fold equals the oracle's (which tools/gen_golden.py checked against the reference's
+    fused state_dict), the C ABI's section table is exactly the fused schema, the blob layout round-trips, flops follow
+    models/fspen/macs.py, and other architectures are rejected with a message."""
+    from common import FSPEN_KWARGS
+    from fastenhancer_amd import _lib
+    from fastenhancer_amd.config import FSPENConfig
+    from fastenhancer_amd.engine import Engine
+    from fastenhancer_amd.weights import fspen_expected_fused_shapes, fspen_fold_state_dict
+    from oracle import fspen_oracle as fo
+    kw, sr, seed = FSPEN_KWARGS
+    cfg = FSPENConfig.from_model_kwargs(**kw)
+    ocfg = fo.FSPENConfig.from_model_kwargs(kw)
+    sd = fo.make_training_state_dict(ocfg, seed)
+    mine = fspen_fold_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, cfg)
+    ref = fo.fold_state_dict(sd, ocfg)
+    assert set(mine) == set(ref) == set(fspen_expected_fused_shapes(cfg))
+    for k in ref:
+        assert tuple(mine[k].shape) == fspen_expected_fused_shapes(cfg)[k]
+        np.testing.assert_allclose(mine[k].numpy(), ref[k], rtol=2e-6, atol=1e-7, err_msg=k)
+    again = fspen_fold_state_dict(mine, cfg)              # an already fused dict passes through
+    assert all(torch.equal(again[k], mine[k]) for k in mine)
+    eng = Engine(cfg, None)
+    assert {n for n, _, _ in eng.sections} == set(ref)
+    blob = eng.make_blob({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    for n, off, cnt in eng.sections:
+        np.testing.assert_array_equal(blob[off:off + cnt].numpy(), mine[n].reshape(-1).numpy())
+    assert abs(eng.flops_per_frame - ocfg.flops_per_frame()) < 1.0
+    assert eng.state_floats(3) == 3 * (2 * 256 + 24 * 4 * 16)
+    with pytest.raises(_lib.FEError, match="no FSPEN kernel compiled"):
+        Engine(FSPENConfig.from_model_kwargs(**dict(kw, hop_size=128)), None)
+    with pytest.raises(RuntimeError, match="is not supported"):
+        FSPENConfig.from_model_kwargs(**dict(kw, dpe_kwargs=dict(kw["dpe_kwargs"], norm="BatchNorm")))
+    with pytest.raises(AssertionError, match="Only n_fft == 512"):
+        FSPENConfig.from_model_kwargs(**dict(kw, n_fft=1024))

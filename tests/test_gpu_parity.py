@@ -720,3 +720,98 @@ def test_steps_can_be_captured_into_a_hip_graph():
         torch.cuda.synchronize()
         y2 = torch.cat([eng.step(x[:, t * H:(t + 1) * H], s_eager, T=1) for t in range(hops)], dim=1)
         assert torch.equal(y_graph, y2) and torch.equal(s_graph, s_eager), name
+
+
+# ------------------------------------------------------------------------------------------------ FSPEN
+def _fspen(cls="ONNXModel"):
+    from common import FSPEN_KWARGS, build_fspen_oracle
+    kw, sr, seed = FSPEN_KWARGS
+    cfg, sd, fused, orc = build_fspen_oracle()
+    mod = importlib.import_module("fastenhancer_amd.models.fspen.model")
+    m = getattr(mod, cls)(**kw).to(_dev()).eval()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return m, orc, cfg, sr, seed
+
+
+def test_fspen_every_stage_matches_oracle():
+    """fe_debug_step taps of the FSPEN kernel against the oracle's (models/fspen/model.py:342-407), three hops with state."""
+    m, orc, cfg, sr, seed = _fspen()
+    eng = m.engine
+    B, hops, H = 3, 3, cfg.hop_size
+    x = make_input(B, hops * H, 616, sr)
+    xd = torch.from_numpy(x).to(_dev())
+    state = eng.new_state(B)
+    caches = orc.initialize_cache(B)
+    names = [s_[0] for s_ in eng.debug_stages()]
+    assert names == (["spec_in", "compressed", "subband_encoder", "fullband_encoder.2", "feature_merge"]
+                     + [f"dpe.{b}.{h}" for b in range(cfg.num_blocks) for h in ("intra", "inter")]
+                     + ["feature_split", "fullband_decoder.0", "fullband_decoder.1", "mask", "spec_out"])
+    for t in range(hops):
+        taps = {}
+        o_ref, *caches = orc.step(x[:, t * H:(t + 1) * H], *caches, taps=taps)
+        o_gpu, dumps = eng.debug_step(xd[:, t * H:(t + 1) * H], state)
+        for sname in names:
+            tap = taps[sname]
+            if sname in ("spec_in", "spec_out", "compressed", "mask"):
+                ref = tap[:, :, 0, :]                      # [B, 257, T = 1, c]
+            elif sname.startswith("dpe."):
+                ref = tap[0]                               # [T = 1, B, F, C]
+            else:
+                ref = tap                                  # [B * T, C, F]
+            _assert_close(dumps[sname].cpu().numpy(), ref, f"fspen hop {t} stage {sname}")
+        _assert_close(o_gpu.cpu().numpy(), o_ref, f"fspen hop {t} wav_out")
+    for a_, b_ in zip(eng.split_state(state, B), caches):
+        _assert_close(a_.cpu().numpy(), b_, "fspen cache after debug steps")
+
+
+def test_fspen_streaming_matches_reference_golden():
+    """scripts/export_onnx.py:48-58 composition with `model: fspen`: 10 hops x 2 streams, all 24 inter-GRU caches."""
+    from fastenhancer_amd.streaming import StreamingModel
+    g = load_golden("fspen")
+    m, orc, cfg, sr, seed = _fspen()
+    M = StreamingModel(m)
+    B, hops, H = int(g["B"]), int(g["hops"]), cfg.hop_size
+    x = torch.from_numpy(make_input(B, hops * H, seed + 1000, sr)).to(_dev())
+    caches = M.initialize_cache(x)
+    outs = []
+    for t in range(hops):
+        wav_out, *caches = M(x[:, t * H:(t + 1) * H], *caches)
+        outs.append(wav_out.cpu().numpy())
+    _assert_close(np.stack(outs, 0), g["stream_wav_out"], "wav_out")
+    _assert_close(caches[0].cpu().numpy(), g["stream_cache_stft"], "cache_stft")
+    _assert_close(caches[1].cpu().numpy(), g["stream_cache_istft"], "cache_istft")
+    for i in range(cfg.n_caches):
+        _assert_close(caches[2 + i].cpu().numpy(), g[f"stream_c{i}"], f"inter GRU cache {i}")
+    # the model mirror's own spec -> spec call (ONNXModel.forward) on the last hop's input
+    m2, *_ = _fspen()
+    c0 = orc.initialize_cache(B)
+    spec_in, _ = orc.stft_step(make_input(B, hops * H, seed + 1000, sr)[:, :H], c0[0])
+    ref, ref_c = orc.spec_forward(spec_in, c0[2:])
+    got, *got_c = m2(torch.from_numpy(spec_in).to(_dev()), *m2.initialize_cache(torch.zeros(B, 1, device=_dev())))
+    _assert_close(got.cpu().numpy(), ref, "fspen spec -> spec")
+    for a_, b_ in zip(got_c, ref_c):
+        _assert_close(a_.cpu().numpy(), b_, "fspen spec -> spec cache")
+
+
+def test_fspen_offline_matches_reference_golden():
+    g = load_golden("fspen")
+    m, orc, cfg, sr, seed = _fspen("Model")
+    x = torch.from_numpy(make_input(int(g["B"]), int(g["hops"]) * cfg.hop_size + 37, seed + 2000, sr)).to(_dev())
+    wav_hat, spec_hat = m(x)
+    _assert_close(wav_hat.cpu().numpy(), g["offline_wav"], "offline wav")
+    _assert_close(spec_hat.cpu().numpy(), g["offline_spec"], "offline spec")
+
+
+@pytest.mark.parametrize("B", [256, 1000])
+def test_fspen_full_size(B):
+    """256 streams (one workgroup per CU) and 1000 (three per CU, then persistent): oracle parity on a sample, bitwise
+    position independence on all streams; chunked launch == per-hop launches"""
+    m, orc, cfg, sr, seed = _fspen()
+    _full_size_check(m, orc, cfg, sr, B, 3, [0, 1, 17, 255, B // 2, B - 2, B - 1], f"fspen B={B}")
+    eng = m.engine
+    H = cfg.hop_size
+    xd = torch.from_numpy(make_input(5, 4 * H, 78, sr)).to(_dev())
+    s1, s2 = eng.new_state(5), eng.new_state(5)
+    y1 = eng.step(xd, s1, T=4)
+    y2 = torch.cat([eng.step(xd[:, t * H:(t + 1) * H], s2, T=1) for t in range(4)], dim=1)
+    assert torch.equal(y1, y2) and torch.equal(s1, s2)
