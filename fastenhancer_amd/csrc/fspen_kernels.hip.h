@@ -142,10 +142,44 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Software-pipelined dot products of the big-K phases: the weights of a thread's outputs arrive in NCH chunks of CH floats; chunk
+// 0 is fetched by the caller BEFORE the barrier that ends the previous phase (wa), chunk i + 1 streams into the other register
+// buffer while chunk i multiplies.  wf(ch, j): weight j of chunk ch; xf(ch, j, q): the input it multiplies for output q (ch is
+// a run-time value, j / q compile-time: per-FMA LDS offsets are immediates).  2 CH + Q registers instead of K.
+template <int NCH, int CH, int Q, class WF, class XF>
+__device__ __forceinline__ void fs_pipe(float (&acc)[Q], float (&wa)[CH], WF&& wf, XF&& xf) {
+    float wb[CH];
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ch += 2) {
+        if (ch + 1 < NCH) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) wb[j] = wf(ch + 1, j);
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) acc[q] = fmaf(wa[j], xf(ch, j, q), acc[q]);
+        if (ch + 1 < NCH) {
+            if (ch + 2 < NCH) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) wa[j] = wf(ch + 2, j);
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+#pragma unroll
+                for (int q = 0; q < Q; ++q) acc[q] = fmaf(wb[j], xf(ch + 1, j, q), acc[q]);
+        }
+    }
+}
+
+#ifndef FS_WPE
+#define FS_WPE 2          // waves per SIMD = workgroups per CU of the register budget (256 VGPRs; 3 would fit the LDS plan but spills: -18 % at 256 streams)
+#endif
+
 #define FS_CLK(i) do { if constexpr (PROF) { if (blockIdx.x == 0 && threadIdx.x == 0) a.clk[(i)] = __builtin_readcyclecounter(); } } while (0)
 
 template <class S, bool PROF, bool DBG>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) fspen_frame_kernel(FArgs a) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(FS_WPE, FS_WPE))) fspen_frame_kernel(FArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[FLds::TOTAL];
     using L = FLds;
     using P = FPk;
@@ -257,96 +291,132 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3
             if (tid < 2) { ein[tid] = 0.0f; ein[264 + tid] = 0.0f; }
             if (tid == 0) magp[0] = 0.0f;
         }
+        // Weights sit in global memory (316 KB, L2-resident) at compile-time offsets, k-major.  Every phase FETCHES ALL ITS WEIGHTS
+        // IN ONE BURST BEFORE THE BARRIER THAT ENDS THE PREVIOUS PHASE (FS_LDW): one memory round trip per phase, overlapped with
+        // the barrier, instead of one per k-step (a lone wave per SIMD has nothing else to hide an L2 access behind).
+#define FS_LDW(arr, K, base, stride)                                                                \
+        float arr[K];                                                                               \
+        _Pragma("unroll") for (int k_ = 0; k_ < (K); ++k_) arr[k_] = wp[(base) + k_ * (stride)]
+        // sub-band encoder: thread (ch = tid & 31, position group tid >> 5); its four positions (one per q) belong to segments
+        // with kernels <= 4, 11, 20, 40: fixed-size bursts, taps past the segment's kernel masked
+        auto se_geom = [&](int q, int& K, int& base, int& wrow, int& seg) {
+            const int pos = (tid >> 5) + 8 * q;
+            int j;
+            if (pos < 8) { seg = 0; j = pos; } else { seg = 1 + (pos - 8) / 6; j = (pos - 8) - (seg - 1) * 6; }
+            K = seg == 0 ? 4 : seg == 1 ? 7 : seg == 2 ? 11 : seg == 3 ? 20 : 40;
+            const int st = seg == 0 ? 2 : seg == 1 ? 3 : seg == 2 ? 5 : seg == 3 ? 10 : 20;
+            base = (seg == 0 ? 0 : seg == 1 ? 14 : seg == 2 ? 31 : seg == 3 ? 62 : 123) + st * j;
+            wrow = seg == 0 ? 0 : seg == 1 ? 4 : seg == 2 ? 11 : seg == 3 ? 22 : 42;
+        };
+        float se_w0[4], se_w1[11], se_w2[20], se_w3[40], se_b[4];
+        {
+            const int ch = tid & 31;
+            int K, base, wrow, seg;
+            se_geom(0, K, base, wrow, seg); se_b[0] = wp[P::SE_B + seg * 32 + ch];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) se_w0[k] = wp[P::SE_W + (wrow + (k < K ? k : 0)) * 32 + ch];
+            se_geom(1, K, base, wrow, seg); se_b[1] = wp[P::SE_B + seg * 32 + ch];
+#pragma unroll
+            for (int k = 0; k < 11; ++k) se_w1[k] = wp[P::SE_W + (wrow + (k < K ? k : 0)) * 32 + ch];
+            se_geom(2, K, base, wrow, seg); se_b[2] = wp[P::SE_B + seg * 32 + ch];
+#pragma unroll
+            for (int k = 0; k < 20; ++k) se_w2[k] = wp[P::SE_W + (wrow + (k < K ? k : 0)) * 32 + ch];
+            se_geom(3, K, base, wrow, seg); se_b[3] = wp[P::SE_B + seg * 32 + ch];
+#pragma unroll
+            for (int k = 0; k < 40; ++k) se_w3[k] = wp[P::SE_W + (wrow + (k < K ? k : 0)) * 32 + ch];
+        }
+        FS_LDW(fe0_w, 12, P::FE0_W + (tid & 3), 4);
+        const float fe0_b = wp[P::FE0_B + (tid & 3)];
         __syncthreads();
         dump(1, [&](int r, int c) { return sp[2 * r + c]; });
 
         FS_CLK(1);
         // ============================ sub-band encoder (SubbandEncoder.forward, :58-66) + full-band conv 0 ============================
-        {   // 32 channels x 32 positions; position -> (segment, j): 8 of segment 0, then 6 each
+        {
             const int ch = tid & 31;
-#pragma unroll 1
-            for (int q = 0; q < 4; ++q) {
-                const int pos = (tid >> 5) + 8 * q;
-                int seg, j;
-                if (pos < 8) { seg = 0; j = pos; } else { seg = 1 + (pos - 8) / 6; j = (pos - 8) - (seg - 1) * 6; }
-                // segment: kernel K, stride, first padded-|X| index, weight row offset
-                const int K = seg == 0 ? 4 : seg == 1 ? 7 : seg == 2 ? 11 : seg == 3 ? 20 : 40;
-                const int st = seg == 0 ? 2 : seg == 1 ? 3 : seg == 2 ? 5 : seg == 3 ? 10 : 20;
-                const int base = (seg == 0 ? 0 : seg == 1 ? 14 : seg == 2 ? 31 : seg == 3 ? 62 : 123) + st * j;
-                const int wrow = seg == 0 ? 0 : seg == 1 ? 4 : seg == 2 ? 11 : seg == 3 ? 22 : 42;
-                const float* w = wp + P::SE_W + wrow * 32 + ch;
-                float acc = wp[P::SE_B + seg * 32 + ch];
-                for (int k = 0; k < K; ++k) acc = fmaf(w[k * 32], magp[base + k], acc);
-                cat[ch * 64 + 32 + pos] = fmaxf(acc, 0.0f);
-            }
+            auto run4 = [&]() {
+                int K, base, wrow, seg;
+                {   se_geom(0, K, base, wrow, seg); float acc = se_b[0];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc = fmaf(k < K ? se_w0[k] : 0.0f, magp[base + (k < K ? k : 0)], acc);
+                    cat[ch * 64 + 32 + (tid >> 5)] = fmaxf(acc, 0.0f); }
+                {   se_geom(1, K, base, wrow, seg); float acc = se_b[1];
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) acc = fmaf(k < K ? se_w1[k] : 0.0f, magp[base + (k < K ? k : 0)], acc);
+                    cat[ch * 64 + 32 + (tid >> 5) + 8] = fmaxf(acc, 0.0f); }
+                {   se_geom(2, K, base, wrow, seg); float acc = se_b[2];
+#pragma unroll
+                    for (int k = 0; k < 20; ++k) acc = fmaf(k < K ? se_w2[k] : 0.0f, magp[base + (k < K ? k : 0)], acc);
+                    cat[ch * 64 + 32 + (tid >> 5) + 16] = fmaxf(acc, 0.0f); }
+                {   se_geom(3, K, base, wrow, seg); float acc = se_b[3];
+#pragma unroll
+                    for (int k = 0; k < 40; ++k) acc = fmaf(k < K ? se_w3[k] : 0.0f, magp[base + (k < K ? k : 0)], acc);
+                    cat[ch * 64 + 32 + (tid >> 5) + 24] = fmaxf(acc, 0.0f); }
+            };
+            run4();
         }
         {   // fullband_encoder.0: Conv1d(2 -> 4, k 6, s 2, p 2) + folded BN + ELU -> e0[o][3 + j], j < 128
             const int o = tid & 3;
-            float wr[12];
-#pragma unroll
-            for (int i = 0; i < 12; ++i) wr[i] = wp[P::FE0_W + i * 4 + o];
-            const float bias = wp[P::FE0_B + o];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int j = (tid >> 2) + 64 * q;
-                float acc = bias;
+                float acc = fe0_b;
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) acc = fmaf(wr[c * 6 + k], ein[c * 264 + 2 * j + k], acc);
+                    for (int k = 0; k < 6; ++k) acc = fmaf(fe0_w[c * 6 + k], ein[c * 264 + 2 * j + k], acc);
                 e0[o * 134 + 3 + j] = elu_f(acc);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);      // (keeps the next phase's weight burst from being hoisted above this phase's arithmetic)
+        FS_LDW(fe1_w, 32, P::FE1_W + (tid & 15), 16);
+        const float fe1_b = wp[P::FE1_B + (tid & 15)];
         __syncthreads();
         dump(2, [&](int r, int c) { return cat[r * 64 + 32 + c]; });
         {   // fullband_encoder.1: Conv1d(4 -> 16, k 8, s 2, p 3) -> e1[o][2 + j], j < 64
             const int o = tid & 15;
             float acc[4];
-            const float bias = wp[P::FE1_B + o];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = bias;
-#pragma unroll 4
+            for (int q = 0; q < 4; ++q) acc[q] = fe1_b;
+#pragma unroll
             for (int ck = 0; ck < 32; ++ck) {
-                const float w = wp[P::FE1_W + ck * 16 + o];
                 const int c = ck >> 3, k = ck & 7;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = fmaf(w, e0[c * 134 + 2 * ((tid >> 4) + 16 * q) + k], acc[q]);
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(fe1_w[ck], e0[c * 134 + 2 * ((tid >> 4) + 16 * q) + k], acc[q]);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) e1[o * 68 + 2 + (tid >> 4) + 16 * q] = elu_f(acc[q]);
         }
+        __builtin_amdgcn_sched_barrier(0);      // (keeps the next phase's weight burst from being hoisted above this phase's arithmetic)
+        FS_LDW(fe2_w, 12, P::FE2_W + (tid & 31), 32);          // chunk 0 of 8 (2 channels x 6 taps each)
+        const float fe2_b = wp[P::FE2_B + (tid & 31)];
         __syncthreads();
         {   // fullband_encoder.2: Conv1d(16 -> 32, k 6, s 2, p 2) -> e2[o][j], j < 32
             const int o = tid & 31;
-            float acc[4];
-            const float bias = wp[P::FE2_B + o];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = bias;
-#pragma unroll 1
-            for (int c = 0; c < 16; ++c)
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    const float w = wp[P::FE2_W + (c * 6 + k) * 32 + o];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] = fmaf(w, e1[c * 68 + 2 * ((tid >> 5) + 8 * q) + k], acc[q]);
-                }
+            float acc[4] = {fe2_b, fe2_b, fe2_b, fe2_b};
+            const float* wcol = wp + P::FE2_W + o;
+            const float* xin = e1 + 2 * (tid >> 5);
+            fs_pipe<8, 12, 4>(acc, fe2_w, [&](int ch, int j) { return wcol[(ch * 12 + j) * 32]; },
+                              [&](int ch, int j, int q) { return xin[ch * 136 + (j / 6) * 68 + 16 * q + (j % 6)]; });
 #pragma unroll
             for (int q = 0; q < 4; ++q) e2[o * 32 + (tid >> 5) + 8 * q] = elu_f(acc[q]);
         }
+        __builtin_amdgcn_sched_barrier(0);      // (keeps the next phase's weight burst from being hoisted above this phase's arithmetic)
+        FS_LDW(post_w, 32, P::POST_W + (tid & 31), 32);
         __syncthreads();
         dump(3, [&](int r, int c) { return e2[r * 32 + c]; });
         {   // fullband_encoder_post: 1x1 (32 -> 32), no bias -> cat[o][f], f < 32
             const int o = tid & 31;
             float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 4
-            for (int c = 0; c < 32; ++c) {
-                const float w = wp[P::POST_W + c * 32 + o];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = fmaf(w, e2[c * 32 + (tid >> 5) + 8 * q], acc[q]);
-            }
+            for (int c = 0; c < 32; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(post_w[c], e2[c * 32 + (tid >> 5) + 8 * q], acc[q]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) cat[o * 64 + (tid >> 5) + 8 * q] = acc[q];
         }
+        __builtin_amdgcn_sched_barrier(0);      // (keeps the next phase's weight burst from being hoisted above this phase's arithmetic)
+        FS_LDW(mg1_w, 16, P::MG1_W + (tid & 31), 32);          // chunk 0 of 4
         __syncthreads();
 
         FS_CLK(2);
@@ -355,28 +425,26 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3
         {
             const int j = tid & 31;
             float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 4
-            for (int i = 0; i < 64; ++i) {
-                const float w = wp[P::MG1_W + i * 32 + j];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = fmaf(w, cat[((tid >> 5) + 8 * q) * 64 + i], acc[q]);
-            }
+            const float* wcol = wp + P::MG1_W + j;
+            const float* xin = cat + (tid >> 5) * 64;
+            fs_pipe<4, 16, 4>(acc, mg1_w, [&](int ch, int jj) { return wcol[(ch * 16 + jj) * 32]; },
+                              [&](int ch, int jj, int q) { return xin[q * 512 + ch * 16 + jj]; });
 #pragma unroll
             for (int q = 0; q < 4; ++q) m1[((tid >> 5) + 8 * q) * 32 + j] = elu_f(acc[q]);
         }
+        __builtin_amdgcn_sched_barrier(0);      // (keeps the next phase's weight burst from being hoisted above this phase's arithmetic)
+        FS_LDW(mg2_w, 32, P::MG2_W + (tid & 15), 16);
+        const float mg2_b = wp[P::MG2_B + (tid & 15)];
         __syncthreads();
         float* x = smem + L::XA;          // tokens [f][c]
         float* xn = smem + L::XB;
         {
             const int c = tid & 15;
-            float acc[2];
-            acc[0] = acc[1] = wp[P::MG2_B + c];
-#pragma unroll 4
-            for (int ch = 0; ch < 32; ++ch) {
-                const float w = wp[P::MG2_W + ch * 16 + c];
+            float acc[2] = {mg2_b, mg2_b};
 #pragma unroll
-                for (int q = 0; q < 2; ++q) acc[q] = fmaf(w, m1[ch * 32 + (tid >> 4) + 16 * q], acc[q]);
-            }
+            for (int ch = 0; ch < 32; ++ch)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[q] = fmaf(mg2_w[ch], m1[ch * 32 + (tid >> 4) + 16 * q], acc[q]);
 #pragma unroll
             for (int q = 0; q < 2; ++q) x[((tid >> 4) + 16 * q) * 16 + c] = acc[q];
         }
@@ -403,43 +471,57 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3
             // ---- intra GRU input projections: gi[d][f][g48] = x[f] . W_ih^T + bias
             if (tid < 192) {
                 const int g48 = tid % 48, fq = tid / 48;
-#pragma unroll 1
-                for (int d = 0; d < 2; ++d) {
-                    float w[16];
+                float w[32];
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) w[k] = wd[P::D_IH + (d * 16 + k) * 48 + g48];
-                    const float bias = wd[P::D_GB + d * 48 + g48];
+                for (int k = 0; k < 32; ++k) w[k] = wd[P::D_IH + k * 48 + g48];
+                const float bias0 = wd[P::D_GB + g48], bias1 = wd[P::D_GB + 48 + g48];
 #pragma unroll 2
-                    for (int r = 0; r < 8; ++r) {
-                        const int f = fq + 4 * r;
-                        float acc = bias;
+                for (int r = 0; r < 8; ++r) {
+                    const int f = fq + 4 * r;
+                    float a0 = bias0, a1 = bias1;
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) acc = fmaf(w[k], x[f * 16 + k], acc);
-                        gi[(d * 32 + f) * 48 + g48] = acc;
-                    }
+                    for (int k = 0; k < 16; ++k) { const float xv = x[f * 16 + k]; a0 = fmaf(w[k], xv, a0); a1 = fmaf(w[16 + k], xv, a1); }
+                    gi[f * 48 + g48] = a0;
+                    gi[(32 + f) * 48 + g48] = a1;
                 }
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) hprev[((tid >> 4) + 16 * q) * 16 + (tid & 15)] = hp[q];
+            __builtin_amdgcn_sched_barrier(0);
+            // recurrence weights of this wave's direction (waves 0, 1) and everybody's intra_fc / LayerNorm weights: fetched before the barrier
+            // (fetched by all four waves - waves 2 / 3 get a copy of direction 0 / 1: a conditional definition would be carried
+            //  around the block loop as 49 live registers)
+            float wr[16], wz[16], wn[16];
+            {
+                const int c = lane & 15, dsel = wave & 1;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    wr[k] = wd[P::D_HH + ((dsel * 3 + 0) * 16 + k) * 16 + c];
+                    wz[k] = wd[P::D_HH + ((dsel * 3 + 1) * 16 + k) * 16 + c];
+                    wn[k] = wd[P::D_HH + ((dsel * 3 + 2) * 16 + k) * 16 + c];
+                }
+            }
+            const float bhn = wd[P::D_HN + (wave & 1) * 16 + (lane & 15)];
+            FS_LDW(fc_w, 32, (int)(wd - wp) + P::D_FC_W + (tid & 15), 16);
+            const float fc_b = wd[P::D_FC_B + (tid & 15)];
+            float ln_w[2], ln_b[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int i = ((tid >> 4) + 16 * q) * 16 + (tid & 15);
+                ln_w[q] = wd[P::D_LN_W + i]; ln_b[q] = wd[P::D_LN_B + i];
+            }
             __syncthreads();
+            if (blk == 0) FS_CLK(8);
             // ---- the recurrence: wave d walks direction d; lane c < 16 owns hidden unit c (its three gate rows in registers)
             if (wave < 2) {
                 const int d = wave, c = lane & 15;
-                float wr[16], wz[16], wn[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    wr[k] = wd[P::D_HH + ((d * 3 + 0) * 16 + k) * 16 + c];
-                    wz[k] = wd[P::D_HH + ((d * 3 + 1) * 16 + k) * 16 + c];
-                    wn[k] = wd[P::D_HH + ((d * 3 + 2) * 16 + k) * 16 + c];
-                }
-                const float bhn = wd[P::D_HN + d * 16 + c];
                 float h = 0.0f;
                 const float* gd = gi + d * 32 * 48;
                 int f = d ? 31 : 0;
                 float g_r = gd[f * 48 + c], g_z = gd[f * 48 + 16 + c], g_n = gd[f * 48 + 32 + c];
 #pragma unroll 1
-                for (int s = 0; s < 32; ++s) {
-                    const int fnx = d ? (s < 31 ? f - 1 : f) : (s < 31 ? f + 1 : f);
+                for (int s_ = 0; s_ < 32; ++s_) {
+                    const int fnx = d ? (s_ < 31 ? f - 1 : f) : (s_ < 31 ? f + 1 : f);
                     const float n_r = gd[fnx * 48 + c], n_z = gd[fnx * 48 + 16 + c], n_n = gd[fnx * 48 + 32 + c];      // next step's x side
                     float ar = 0.0f, az = 0.0f, an = bhn;
 #pragma unroll
@@ -458,17 +540,20 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3
                 }
             }
             __syncthreads();
+            if (blk == 0) FS_CLK(9);
             // ---- intra_fc + LayerNorm([F, C]) + residual
-            float yv[2];
-            {
-                const int c = tid & 15;
-                yv[0] = yv[1] = wd[P::D_FC_B + c];
-#pragma unroll 4
-                for (int k = 0; k < 32; ++k) {
-                    const float w = wd[P::D_FC_W + k * 16 + c];
+            float yv[2] = {fc_b, fc_b};
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) yv[q] = fmaf(w, hseq[((tid >> 4) + 16 * q) * 32 + k], yv[q]);
-                }
+            for (int k = 0; k < 32; ++k)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) yv[q] = fmaf(fc_w[k], hseq[((tid >> 4) + 16 * q) * 32 + k], yv[q]);
+            __builtin_amdgcn_sched_barrier(0);
+            // inter GRU (group of row f = tid >> 4) weights of the first of this thread's two rows: in flight across the LayerNorm
+            const float* wg0 = wd + P::D_G + (tid >> 6) * P::G_SIZE;              // rows 0..15: groups 0..3 = wave
+            float gi0[48];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                gi0[k] = wg0[P::G_IH + k * 48 + (tid & 15)]; gi0[16 + k] = wg0[P::G_IH + k * 48 + 16 + (tid & 15)]; gi0[32 + k] = wg0[P::G_IH + k * 48 + 32 + (tid & 15)];
             }
             float s0 = wave_sum(yv[0] + yv[1]);
             if (lane == 0) red[wave] = s0;
@@ -482,26 +567,34 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int i = ((tid >> 4) + 16 * q) * 16 + (tid & 15);
-                xn[i] = (q ? d1 : d0) * inv_std * wd[P::D_LN_W + i] + wd[P::D_LN_B + i] + x[i];
+                xn[i] = (q ? d1 : d0) * inv_std * ln_w[q] + ln_b[q] + x[i];
             }
             __syncthreads();
             dump(5 + 2 * blk, [&](int r, int c) { return xn[r * 16 + c]; });
+            if (blk == 0) FS_CLK(10);
             // ---- inter path (InterRNNPathExtension.forward, :122-138): group g = f / 4 has its own GRU (one step per frame) and fc
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int f = (tid >> 4) + 16 * q, c = tid & 15;
                 const float* wg = wd + P::D_G + (f >> 2) * P::G_SIZE;
+                float wi[48], wh[48];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (q == 0) { wi[k] = gi0[k]; wi[16 + k] = gi0[16 + k]; wi[32 + k] = gi0[32 + k]; }
+                    else { wi[k] = wg[P::G_IH + k * 48 + c]; wi[16 + k] = wg[P::G_IH + k * 48 + 16 + c]; wi[32 + k] = wg[P::G_IH + k * 48 + 32 + c]; }
+                    wh[k] = wg[P::G_HH + k * 48 + c]; wh[16 + k] = wg[P::G_HH + k * 48 + 16 + c]; wh[32 + k] = wg[P::G_HH + k * 48 + 32 + c];
+                }
                 float ir = wg[P::G_GB + c], iz = wg[P::G_GB + 16 + c], in_ = wg[P::G_GB + 32 + c];
                 float hr = 0.0f, hz = 0.0f, hnn = wg[P::G_HN + c];
-#pragma unroll 4
+#pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const float xv = xn[f * 16 + k], hv = hprev[f * 16 + k];
-                    ir = fmaf(wg[P::G_IH + k * 48 + c], xv, ir);
-                    iz = fmaf(wg[P::G_IH + k * 48 + 16 + c], xv, iz);
-                    in_ = fmaf(wg[P::G_IH + k * 48 + 32 + c], xv, in_);
-                    hr = fmaf(wg[P::G_HH + k * 48 + c], hv, hr);
-                    hz = fmaf(wg[P::G_HH + k * 48 + 16 + c], hv, hz);
-                    hnn = fmaf(wg[P::G_HH + k * 48 + 32 + c], hv, hnn);
+                    ir = fmaf(wi[k], xv, ir);
+                    iz = fmaf(wi[16 + k], xv, iz);
+                    in_ = fmaf(wi[32 + k], xv, in_);
+                    hr = fmaf(wh[k], hv, hr);
+                    hz = fmaf(wh[16 + k], hv, hz);
+                    hnn = fmaf(wh[32 + k], hv, hnn);
                 }
                 const float r = sigmoid_f(ir + hr);
                 const float z = sigmoid_f(iz + hz);
@@ -509,19 +602,29 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3
                 const float hnew = (1.0f - z) * n + z * hprev[f * 16 + c];
                 hn[f * 16 + c] = hnew;
                 a.gru[(((size_t)(blk * S::G + (f >> 2)) * a.B + b) * S::FG + (f & 3)) * S::C + c] = hnew;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float ifc_w[2][16], ifc_b[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float* wg = wd + P::D_G + (((tid >> 4) + 16 * q) >> 2) * P::G_SIZE;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) ifc_w[q][k] = wg[P::G_FC_W + k * 16 + (tid & 15)];
+                ifc_b[q] = wg[P::G_FC_B + (tid & 15)];
             }
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int f = (tid >> 4) + 16 * q, c = tid & 15;
-                const float* wg = wd + P::D_G + (f >> 2) * P::G_SIZE;
-                float acc = wg[P::G_FC_B + c];
-#pragma unroll 4
-                for (int k = 0; k < 16; ++k) acc = fmaf(wg[P::G_FC_W + k * 16 + c], hn[f * 16 + k], acc);
+                float acc = ifc_b[q];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc = fmaf(ifc_w[q][k], hn[f * 16 + k], acc);
                 x[f * 16 + c] = acc + 2.0f * xn[f * 16 + c];          // + x_in inside the path extension, + x_in again in DPE.forward
             }
             __syncthreads();
             dump(6 + 2 * blk, [&](int r, int c) { return x[r * 16 + c]; });
+            if (blk == 0) FS_CLK(11);
         }
 
         FS_CLK(4);
@@ -530,134 +633,209 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3
         float* s2 = smem + L::S2;
         {
             const int ch = tid & 31;
+            FS_LDW(w, 16, P::SP1_W + ch, 32);
             float acc[4];
             const float bias = wp[P::SP1_B + ch];
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[q] = bias;
-#pragma unroll 4
-            for (int c = 0; c < 16; ++c) {
-                const float w = wp[P::SP1_W + c * 32 + ch];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = fmaf(w, x[((tid >> 5) + 8 * q) * 16 + c], acc[q]);
-            }
+            for (int c = 0; c < 16; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(w[c], x[((tid >> 5) + 8 * q) * 16 + c], acc[q]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) s1[ch * 32 + (tid >> 5) + 8 * q] = acc[q];
         }
+        __builtin_amdgcn_sched_barrier(0);      // (keeps the next phase's weight burst from being hoisted above this phase's arithmetic)
+        FS_LDW(sp2_w, 32, P::SP2_W + (tid & 63), 64);
         __syncthreads();
         {
             const int j = tid & 63;
             float acc[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc[q] = 0.0f;
-#pragma unroll 2
-            for (int f = 0; f < 32; ++f) {
-                const float w = wp[P::SP2_W + f * 64 + j];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) acc[q] = fmaf(w, s1[((tid >> 6) + 4 * q) * 32 + f], acc[q]);
-            }
+            for (int f = 0; f < 32; ++f)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] = fmaf(sp2_w[f], s1[((tid >> 6) + 4 * q) * 32 + f], acc[q]);
 #pragma unroll
             for (int q = 0; q < 8; ++q) s2[((tid >> 6) + 4 * q) * 64 + j] = elu_f(acc[q]);
         }
+        __builtin_amdgcn_sched_barrier(0);      // (keeps the next phase's weight burst from being hoisted above this phase's arithmetic)
+        FS_LDW(sd_w, 16, P::SD_W + tid, 260);                  // sub-band decoder column of bin = tid, chunk 0 of 4
+        const float sd_b = wp[P::SD_B + tid];
         __syncthreads();
         dump(11, [&](int r, int c) { return s2[r * 64 + c]; });
 
         FS_CLK(5);
         // ============================ sub-band decoder (SubbandDecoder.forward, :83-95): one output per bin ============================
         float* msub = smem + L::MSUB;
-        for (int bin = tid; bin < BINS; bin += kThreads) {
-            // bin -> (linear layer, flattened index) -> input row of the [32 + zero row][64] matrix
-            int row;
-            if (bin < 16) row = bin / 2;
-            else if (bin < 32) row = 8 + (bin - 16 + 1) / 3;
-            else if (bin < 64) row = 13 + (bin - 32 + 4) / 5;
-            else if (bin < 128) row = 19 + (bin - 64 + 8) / 10;
-            else row = 25 + (bin - 128 + 16) / 20;
-            float acc = wp[P::SD_B + bin];
-            if (row < 32) {
-                for (int k = 0; k < 32; ++k) acc = fmaf(wp[P::SD_W + k * 260 + bin], cat[k * 64 + 32 + row], acc);
-                for (int k = 0; k < 32; ++k) acc = fmaf(wp[P::SD_W + (32 + k) * 260 + bin], s2[k * 64 + 32 + row], acc);
-            }
-            msub[bin] = fmaxf(acc, 0.0f);
+        // bin -> (linear layer, flattened index) -> input row of the [32 + zero row][64] matrix
+        auto sd_row = [](int bin) {
+            if (bin < 16) return bin / 2;
+            if (bin < 32) return 8 + (bin - 16 + 1) / 3;
+            if (bin < 64) return 13 + (bin - 32 + 4) / 5;
+            if (bin < 128) return 19 + (bin - 64 + 8) / 10;
+            return 25 + (bin - 128 + 16) / 20;
+        };
+        {
+            const int row = sd_row(tid);
+            const bool zero_row = row >= 32;                      // lin5's F.pad row: ReLU(bias)
+            const int rc = zero_row ? 0 : row;
+            float acc[1] = {0.0f};
+            const float* wcol = wp + P::SD_W + tid;
+            // k < 32: x_sub1 (cat[k][32 + row]); k >= 32: x_sub2 (s2[k - 32][32 + row]); both are [32][64] arrays, chunks 0, 1 | 2, 3
+            fs_pipe<4, 16, 1>(acc, sd_w, [&](int ch, int j) { return wcol[(ch * 16 + j) * 260]; },
+                              [&](int ch, int j, int) { const float* src = ch < 2 ? cat : s2 - 32 * 64; return src[(ch * 16 + j) * 64 + 32 + rc]; });
+            msub[tid] = fmaxf(sd_b + (zero_row ? 0.0f : acc[0]), 0.0f);
+            if (tid == 0) msub[256] = fmaxf(wp[P::SD_B + 256], 0.0f);          // bin 256 reads the zero row too
         }
+        __builtin_amdgcn_sched_barrier(0);
         // ============================ full-band decoder (:262-277, :397-400) ============================
         float* t2 = smem + L::T2;
-        {   // decoder 0: 1x1 over cat(x_full, enc_out[2]) (64 -> 32)
+        {   // decoder 0: 1x1 over cat(x_full, enc_out[2]) (64 -> 32): chunks 0, 1 from s2[c][f] (row stride 64), 2, 3 from e2[c][f] (32)
             const int o = tid & 31;
+            FS_LDW(w0, 16, P::FD0_W + o, 32);
             float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 4
-            for (int c = 0; c < 32; ++c) {
-                const float w0 = wp[P::FD0_W + c * 32 + o], w1 = wp[P::FD0_W + (32 + c) * 32 + o];
+            const float* wcol = wp + P::FD0_W + o;
+            const int f0 = tid >> 5;
+            fs_pipe<4, 16, 4>(acc, w0, [&](int ch, int j) { return wcol[(ch * 16 + j) * 32]; },
+                              [&](int ch, int j, int q) {
+                                  return ch < 2 ? s2[(ch * 16 + j) * 64 + f0 + 8 * q] : e2[((ch - 2) * 16 + j) * 32 + f0 + 8 * q];
+                              });
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int f = (tid >> 5) + 8 * q;
-                    acc[q] = fmaf(w0, s2[c * 64 + f], acc[q]);
-                    acc[q] = fmaf(w1, e2[c * 32 + f], acc[q]);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) t2[o * 32 + (tid >> 5) + 8 * q] = acc[q];
+            for (int q = 0; q < 4; ++q) t2[o * 32 + f0 + 8 * q] = acc[q];
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // transposed convs: output p takes the taps k = k0, k0 + 2, ... (k0 = parity of p + padding), input f = (p + pad - k) / 2; all
+        // of a thread's outputs share the parity, hence the taps' weights; out-of-range inputs are clamped and multiplied by 0
+        float fd0_t[12];                                         // chunk 0 of 8: 4 channels x 3 taps
+        {
+            const int k0 = (tid >> 4) & 1;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) fd0_t[j] = wp[P::FD0_T + ((j / 3) * 6 + k0 + 2 * (j % 3)) * 16 + (tid & 15)];
+        }
+        const float fd0_b = wp[P::FD0_B + (tid & 15)];
         __syncthreads();
         float* d2 = smem + L::D2;
         {   // ConvTranspose1d(32 -> 16, k 6, s 2, p 2) + folded BN + ELU: y[o][p] += x[c][f] w[c][o][k], p = 2 f + k - 2
-            const int o = tid & 15;
-            float acc[4];
-            const float bias = wp[P::FD0_B + o];
+            const int o = tid & 15, k0 = (tid >> 4) & 1;
+            // per (output q, tap i): clamped input column and its 0 / 1 mask
+            int fcol[4][3];
+            float fm[4][3];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = bias;
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int f = ((tid >> 4) + 16 * q + 2 - k0 - 2 * i) >> 1;
+                    const bool ok = f >= 0 && f < 32;
+                    fcol[q][i] = ok ? f : 0;
+                    fm[q][i] = ok ? 1.0f : 0.0f;
+                }
+            float acc3[12];                                       // [q][tap] partial sums (masked at the end)
+#pragma unroll
+            for (int i = 0; i < 12; ++i) acc3[i] = 0.0f;
+            const float* wcol = wp + P::FD0_T + o;
+            // Q = 12 "outputs" (q, tap): weight j = (channel j / 3 of the chunk, tap j % 3) only feeds the outputs of its own tap
+            float wb[12];
 #pragma unroll 1
-            for (int c = 0; c < 32; ++c)
+            for (int ch = 0; ch < 8; ch += 2) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int p = (tid >> 4) + 16 * q, k0 = p & 1;
+                for (int j = 0; j < 12; ++j) wb[j] = wcol[(((ch + 1) * 4 + j / 3) * 6 + k0 + 2 * (j % 3)) * 16];
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const int k = k0 + 2 * i, f = (p + 2 - k) >> 1;
-                        if (f >= 0 && f < 32) acc[q] = fmaf(wp[P::FD0_T + (c * 6 + k) * 16 + o], t2[c * 32 + f], acc[q]);
-                    }
+                for (int j = 0; j < 12; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc3[q * 3 + j % 3] = fmaf(fd0_t[j], t2[(ch * 4 + j / 3) * 32 + fcol[q][j % 3]], acc3[q * 3 + j % 3]);
+                if (ch + 2 < 8) {
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) fd0_t[j] = wcol[(((ch + 2) * 4 + j / 3) * 6 + k0 + 2 * (j % 3)) * 16];
                 }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) d2[o * 64 + (tid >> 4) + 16 * q] = elu_f(acc[q]);
+                for (int j = 0; j < 12; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc3[q * 3 + j % 3] = fmaf(wb[j], t2[((ch + 1) * 4 + j / 3) * 32 + fcol[q][j % 3]], acc3[q * 3 + j % 3]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float acc = fd0_b;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc = fmaf(fm[q][i], acc3[q * 3 + i], acc);
+                d2[o * 64 + (tid >> 4) + 16 * q] = elu_f(acc);
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);      // (keeps the next phase's weight burst from being hoisted above this phase's arithmetic)
+        FS_LDW(fd1_w, 32, P::FD1_W + (tid & 15), 16);
         __syncthreads();
         dump(12, [&](int r, int c) { return d2[r * 64 + c]; });
         float* t1 = smem + L::T1;
         {   // decoder 1: 1x1 over cat(d2, enc_out[1]) (32 -> 16)
             const int o = tid & 15;
             float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 4
-            for (int c = 0; c < 16; ++c) {
-                const float w0 = wp[P::FD1_W + c * 16 + o], w1 = wp[P::FD1_W + (16 + c) * 16 + o];
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int f = (tid >> 4) + 16 * q;
-                    acc[q] = fmaf(w0, d2[c * 64 + f], acc[q]);
-                    acc[q] = fmaf(w1, e1[c * 68 + 2 + f], acc[q]);
+                    acc[q] = fmaf(fd1_w[c], d2[c * 64 + f], acc[q]);
+                    acc[q] = fmaf(fd1_w[16 + c], e1[c * 68 + 2 + f], acc[q]);
                 }
-            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) t1[o * 64 + (tid >> 4) + 16 * q] = acc[q];
         }
+        __builtin_amdgcn_sched_barrier(0);      // (keeps the next phase's weight burst from being hoisted above this phase's arithmetic)
+        float fd1_t[16];                                         // chunk 0 of 4: 4 channels x 4 taps
+        {
+            const int k0 = ((tid >> 2) + 1) & 1;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) fd1_t[j] = wp[P::FD1_T + ((j / 4) * 8 + k0 + 2 * (j % 4)) * 4 + (tid & 3)];
+        }
+        const float fd1_b = wp[P::FD1_B + (tid & 3)];
         __syncthreads();
         float* d1 = smem + L::D1;
         {   // ConvTranspose1d(16 -> 4, k 8, s 2, p 3) + folded BN + ELU: p = 2 f + k - 3
-            const int o = tid & 3;
-            float acc[2];
-            acc[0] = acc[1] = wp[P::FD1_B + o];
+            const int o = tid & 3, k0 = ((tid >> 2) + 1) & 1;
+            int fcol[2][4];
+            float fm[2][4];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int f = ((tid >> 2) + 64 * q + 3 - k0 - 2 * i) >> 1;
+                    const bool ok = f >= 0 && f < 64;
+                    fcol[q][i] = ok ? f : 0;
+                    fm[q][i] = ok ? 1.0f : 0.0f;
+                }
+            float acc4[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc4[i] = 0.0f;
+            const float* wcol = wp + P::FD1_T + o;
+            float wb[16];
 #pragma unroll 1
-            for (int c = 0; c < 16; ++c)
+            for (int ch = 0; ch < 4; ch += 2) {
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int p = (tid >> 2) + 64 * q, k0 = (p + 1) & 1;
+                for (int j = 0; j < 16; ++j) wb[j] = wcol[(((ch + 1) * 4 + j / 4) * 8 + k0 + 2 * (j % 4)) * 4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int k = k0 + 2 * i, f = (p + 3 - k) >> 1;
-                        if (f >= 0 && f < 64) acc[q] = fmaf(wp[P::FD1_T + (c * 8 + k) * 4 + o], t1[c * 64 + f], acc[q]);
-                    }
+                for (int j = 0; j < 16; ++j)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) acc4[q * 4 + j % 4] = fmaf(fd1_t[j], t1[(ch * 4 + j / 4) * 64 + fcol[q][j % 4]], acc4[q * 4 + j % 4]);
+                if (ch + 2 < 4) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) fd1_t[j] = wcol[(((ch + 2) * 4 + j / 4) * 8 + k0 + 2 * (j % 4)) * 4];
                 }
 #pragma unroll
-            for (int q = 0; q < 2; ++q) d1[o * 128 + (tid >> 2) + 64 * q] = elu_f(acc[q]);
+                for (int j = 0; j < 16; ++j)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) acc4[q * 4 + j % 4] = fmaf(wb[j], t1[((ch + 1) * 4 + j / 4) * 64 + fcol[q][j % 4]], acc4[q * 4 + j % 4]);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float acc = fd1_b;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = fmaf(fm[q][i], acc4[q * 4 + i], acc);
+                d1[o * 128 + (tid >> 2) + 64 * q] = elu_f(acc);
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);      // (keeps the next phase's weight burst from being hoisted above this phase's arithmetic)
+        FS_LDW(fd2_w, 8, P::FD2_W + (tid & 3), 4);
         __syncthreads();
         dump(13, [&](int r, int c) { return d1[r * 128 + c]; });
         float* t0 = smem + L::T0;
@@ -665,31 +843,42 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3
             const int o = tid & 3;
             float acc[2] = {0.0f, 0.0f};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float w0 = wp[P::FD2_W + c * 4 + o], w1 = wp[P::FD2_W + (4 + c) * 4 + o];
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int f = (tid >> 2) + 64 * q;
-                    acc[q] = fmaf(w0, d1[c * 128 + f], acc[q]);
-                    acc[q] = fmaf(w1, e0[c * 134 + 3 + f], acc[q]);
+                    acc[q] = fmaf(fd2_w[c], d1[c * 128 + f], acc[q]);
+                    acc[q] = fmaf(fd2_w[4 + c], e0[c * 134 + 3 + f], acc[q]);
                 }
-            }
 #pragma unroll
             for (int q = 0; q < 2; ++q) t0[o * 128 + (tid >> 2) + 64 * q] = acc[q];
         }
-        __syncthreads();
-        float* mf = smem + L::MF;
-        for (int i = tid; i < 2 * BINS; i += kThreads) {
-            // ConvTranspose1d(4 -> 2, k 6, s 2, p 2, output_padding 1) + bias: p = 2 f + k - 2, p < 257
-            const int o = i & 1, p = i >> 1, k0 = p & 1;
-            float acc = wp[P::FD2_B + o];
+        __builtin_amdgcn_sched_barrier(0);      // (keeps the next phase's weight burst from being hoisted above this phase's arithmetic)
+        float fd2_t[12];
+        {
+            const int k0 = (tid >> 1) & 1;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int k = k0 + 2 * j, f = (p + 2 - k) >> 1;
-                    if (f >= 0 && f < 128) acc = fmaf(wp[P::FD2_T + (c * 6 + k) * 2 + o], t0[c * 128 + f], acc);
-                }
+                for (int j = 0; j < 3; ++j) fd2_t[c * 3 + j] = wp[P::FD2_T + (c * 6 + k0 + 2 * j) * 2 + (tid & 1)];
+        }
+        const float fd2_b = wp[P::FD2_B + (tid & 1)];
+        __syncthreads();
+        float* mf = smem + L::MF;
+        for (int i = tid; i < 2 * BINS; i += kThreads) {
+            // ConvTranspose1d(4 -> 2, k 6, s 2, p 2, output_padding 1) + bias: p = 2 f + k - 2, p < 257   (i = tid + 256 q: same o, same parity)
+            const int o = i & 1, p = i >> 1, k0 = p & 1;
+            float acc = fd2_b;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int f = (p + 2 - k0 - 2 * j) >> 1;
+                const bool ok = f >= 0 && f < 128;
+                const int fc = ok ? f : 0;
+                float part = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) part = fmaf(fd2_t[c * 3 + j], t0[c * 128 + fc], part);
+                acc += ok ? part : 0.0f;
+            }
             mf[o * 258 + p] = acc;
         }
         __syncthreads();
@@ -781,7 +970,8 @@ struct FImpl {
 
 template <class S>
 void flaunch_impl(const FArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
-    constexpr int OCC = (160 * 1024) / (FLds::TOTAL * 4);          // workgroups per CU (LDS-limited)
+    constexpr int OCC_LDS = (160 * 1024) / (FLds::TOTAL * 4);      // workgroups per CU: LDS- and register-limited
+    constexpr int OCC = OCC_LDS < FS_WPE ? OCC_LDS : FS_WPE;
     const int slots = max_wgs * OCC;
     const int grid = a.B < slots ? a.B : slots;                    // more streams than slots: persistent workgroups walk b, b + grid, ...
     if (a.dbg != nullptr) hipLaunchKernelGGL((fspen_frame_kernel<S, false, true>), dim3(grid), dim3(kThreads), 0, st, a);
