@@ -179,7 +179,7 @@ __device__ __forceinline__ void fs_pipe(float (&acc)[Q], float (&wa)[CH], WF&& w
 #define FS_CLK(i) do { if constexpr (PROF) { if (blockIdx.x == 0 && threadIdx.x == 0) a.clk[(i)] = __builtin_readcyclecounter(); } } while (0)
 
 template <class S, bool PROF, bool DBG>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(FS_WPE, FS_WPE))) fspen_frame_kernel(FArgs a) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(DBG ? 1 : FS_WPE, DBG ? 1 : FS_WPE))) fspen_frame_kernel(FArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[FLds::TOTAL];
     using L = FLds;
     using P = FPk;
@@ -208,8 +208,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
     int b = blockIdx.x;
 #pragma unroll 1
     do {
-    float* cst = a.cache_stft + (size_t)b * OVL;
-    float* cis = a.cache_istft + (size_t)b * OVL;
+    // (per-stream pointers are derived from the kernel arguments where they are used, not kept live through the frame: with ~70
+    //  spilled SGPRs a cache pointer computed here reached the iSTFT corrupted in the debug instantiation - memory fault)
     float* dbg = DBG ? a.dbg + (size_t)b * a.dbg_stride : nullptr;
     // dump(stage, f): element (r, c) of the stage = f(r, c)
     auto dump = [&](int stage, auto&& f) {
@@ -237,6 +237,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
         float* ein = smem + L::EIN;
         if (mode != FE_MODE_SPEC) {
             const float* win = wp + P::WINDOW;
+            float* cst = a.cache_stft + (size_t)b * OVL;
             if (mode == FE_MODE_STREAM) {
                 const float* xin = a.wav_in + (size_t)b * a.in_stride + (size_t)t * H;
                 for (int n = tid; n < N; n += kThreads) {
@@ -919,6 +920,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
         if (mode != FE_MODE_SPEC) {
             float2* yv = fft_lds<S, true>(fa, fb, tw);
             float2* spare = (yv == fa) ? fb : fa;
+            float* cis = a.cache_istft + (size_t)b * OVL;
             const float* wi = wp + (mode == FE_MODE_STREAM ? P::WINDOW_I : P::WINDOW);
             float* xo = reinterpret_cast<float*>(spare);
             const float invN = 1.0f / (float)N;
