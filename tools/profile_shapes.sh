@@ -9,9 +9,12 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 SUM=$ROOT/gpurun_out/shapes_$TAG.txt
 echo "# rocprofv3 --kernel-trace --stats, bench.py --no-cpu-baseline --steps 200 --warmup 20 --workload <w> (256 streams, 1 hop per launch)" > "$SUM"
-for w in fe_t fe_b fe_s fe_m fe_l fe48_t fe48_b fe48_b_h480 fe48_s fe48_m fe48_l fe_tk_b bsrnn_xxt bsrnn_xt bsrnn_t bsrnn_s; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$w" -o s -- python $ROOT/bench.py --no-cpu-baseline --steps 200 --warmup 20 --workload $w > "$OUT/$w.json" 2> "$OUT/$w.err"
-  python - "$OUT/$w" "$w" "$OUT/$w.json" >> "$SUM" <<'PY'
+# "<workload>[:streams]" (default 256 streams); the :1024 lines run the low-LDS companions / two-workgroups-per-CU builds
+for ws in fe_t fe_b fe_s fe_m fe_l fe48_t fe48_b fe48_b_h480 fe48_s fe48_m fe48_l fe_tk_b bsrnn_xxt bsrnn_xt bsrnn_t bsrnn_s fspen \
+          fe_t:1024 fe_b:1024 fe_s:512 fe48_t:1024 fe48_b:1024 fe48_b_h480:512 bsrnn_xxt:1024 bsrnn_xt:1024 fspen:4096; do
+  w=${ws%%:*}; st=256; [[ $ws == *:* ]] && st=${ws##*:}
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$ws" -o s -- python $ROOT/bench.py --no-cpu-baseline --steps 200 --warmup 20 --workload $w --streams $st > "$OUT/$ws.json" 2> "$OUT/$ws.err"
+  python - "$OUT/$ws" "$ws" "$OUT/$ws.json" >> "$SUM" <<'PY'
 import csv, glob, json, sys
 d, w, j = sys.argv[1:4]
 line = open(j).read().strip().splitlines()[-1]
@@ -19,7 +22,7 @@ b = json.loads(line)
 for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         if "frame_kernel" in row["Name"]:
-            print(f"{w:10s} {row['Name'][:70]:70s} calls={row['Calls']} avg_ns={float(row['AverageNs']):.0f}  bench under tracer: {b['value']:.0f} frames/s, frac {b['roofline']['frac']:.4f}")
+            print(f"{w:16s} {row['Name'][:70]:70s} calls={row['Calls']} avg_ns={float(row['AverageNs']):.0f}  bench under tracer: {b['value']:.0f} frames/s, frac {b['roofline']['frac']:.4f}")
 PY
 done
 cat "$SUM"
