@@ -44,9 +44,16 @@ struct BShape {
     static constexpr int NCT = HH / 16;         // hidden-unit tiles
     static constexpr int NTC = C / 16;          // channel tiles
     static constexpr int KSC = C / 4, KSH = HH / 4, KS1 = KSC + KSH;
-    static constexpr int RPT = HH / 32;         // gate rows per thread in the band recurrence (128 threads per direction)
+    // C = 64: W_hh of a direction is 256 KB - streamed from L2 every step it made the recurrence 87 % of the frame (32 k cycles
+    // per step, the L2 -> CU path saturated by 256 workgroups).  SEQD: the two directions run one after the other on all 256
+    // threads, each with its W_hh register-resident (256 floats per thread, fetched once per layer and direction: 31 x less
+    // L2 traffic, 62 instead of 31 barrier steps per layer).
+    static constexpr bool SEQD = (C == 64);
+    static constexpr int NTD = SEQD ? 256 : 128;          // threads of a direction
+    static constexpr int UPP = NTD / 4;                   // hidden units per pass (a quad of lanes per unit)
+    static constexpr int RPT = HH / UPP;                  // units (gate-row sets) per thread in the band recurrence
     static constexpr bool REGW = (C == 16);     // a layer's GEMM weight fragments live in registers (prefetched a layer ahead)
-    static constexpr bool WREG = (C <= 32);     // recurrence weights register-resident (else streamed from L2 every step)
+    static constexpr bool WREG = true;          // recurrence weights register-resident (C = 64: one direction at a time, SEQD)
     static constexpr bool XPG = (C > 32);       // band-LSTM input projections in a global scratch (do not fit in LDS)
     // band recurrence, work split of a quad of lanes (one hidden unit): KSPLIT = false: lane g holds gate row g over the
     // whole K = HH (reads all of h); KSPLIT = true: lane q holds a quarter of K for all four gate rows (reads HH/4 of h,
@@ -177,8 +184,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 
     const int mode = HOT ? FE_MODE_STREAM : a.mode;
     // band recurrence: a quad of lanes <-> (direction, hidden unit); lane rgate of the quad holds a quarter of K for all four gates
-    const int rd = wave >> 1;                // direction (wave-uniform: waves 0, 1 forward, waves 2, 3 backward)
-    const int rq = tid & 127;                // gate row within the direction's 128-thread group
+    const int rd0 = wave >> 1;               // direction (wave-uniform: waves 0, 1 forward, waves 2, 3 backward; SEQD: a loop over both)
+    const int rq = tid & (S::NTD - 1);       // thread within the direction's group
     const int rgate = rq & 3;
 
     // ---- a layer's register-resident weight set (REGW): this wave's fragments / this thread's recurrence row
@@ -214,7 +221,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         }
         else if constexpr (e < E_F2) {
             constexpr int k = e - E_HH;
-            const float v = wp[o.f_whh[l][rd] + k * 128 + rq];
+            const float v = wp[o.f_whh[l][rd0] + k * 128 + rq];
             if constexpr (first) Whh[0][k] = v; else Whhn[k] = v;
         }
         else if constexpr (e < E_F2B) {
@@ -449,16 +456,16 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             }
             // recurrence weights (register shapes without the layer-ahead prefetch: loaded here)
             float cstate[S::RPT];
-#pragma unroll
-            for (int rr = 0; rr < S::RPT; ++rr) cstate[rr] = 0.0f;
-            if constexpr (S::WREG && !REGW) {
+            int rd = rd0;                                           // direction of the scan this thread works on
+            auto load_whh = [&](int d) {
 #pragma unroll
                 for (int rr = 0; rr < S::RPT; ++rr) {
-                    const float* wr = wp + o.f_whh[l][rd] + rr * HH * 128 + rq;   // [rr][k][q]: coalesced over the threads
+                    const float* wr = wp + o.f_whh[l][d] + rr * HH * S::NTD + rq;   // [rr][k][thread]: coalesced over the threads
 #pragma unroll
-                    for (int k = 0; k < HH; ++k) Whh[rr][k] = wr[k * 128];
+                    for (int k = 0; k < HH; ++k) Whh[rr][k] = wr[k * S::NTD];
                 }
-            }
+            };
+            if constexpr (S::WREG && !REGW && !S::SEQD) load_whh(rd);
             if (tid < 4 * HH) Hb[tid] = 0.0f;                    // h = 0 for both directions, both buffers
             if constexpr (4 * HH > kThreads) { if (tid + kThreads < 4 * HH) Hb[tid + kThreads] = 0.0f; }
             if constexpr (S::XPG) __threadfence_block();
@@ -472,13 +479,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             }
             auto xp_at = [&](int s, int rr) -> float {
                 const int band = rd == 0 ? s : kBands - 1 - s;
-                const int col = rgate * HH + (rq >> 2) + 32 * rr;
+                const int col = rgate * HH + (rq >> 2) + S::UPP * rr;
                 if constexpr (S::XPG) return XPg[(rd * 32 + band) * G4 + col];
                 else return XPl[(rd * 32 + band) * LDP + col];
             };
             float xp_next[S::RPT];
-#pragma unroll
-            for (int rr = 0; rr < S::RPT; ++rr) xp_next[rr] = xp_at(0, rr);
             // One step of both scans (work split: see BShape::KSPLIT).  With KSPLIT a lane reads HH/4 floats of h from LDS
             // instead of all HH; the quarters are summed across the quad with two DPP adds per gate; lane rgate then finishes
             // gate rgate.  Either way the four activations of a unit are exchanged with DPP quad broadcasts, ALL four lanes
@@ -496,7 +501,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 for (int k = 0; k < Q / 4; ++k) hq[k] = hp4[k];
 #pragma unroll
                 for (int rr = 0; rr < S::RPT; ++rr) {
-                    const int j = (rq >> 2) + 32 * rr;
+                    const int j = (rq >> 2) + S::UPP * rr;
                     float mine;
                     if constexpr (!S::KSPLIT) {
                         // this lane's gate row over the whole K: two chains of packed FMAs
@@ -508,10 +513,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                                 p1 += f32x2{Whh[rr][4 * k + 2], Whh[rr][4 * k + 3]} * f32x2{hq[k].z, hq[k].w};
                             }
                         } else {
-                            const float4* w4 = reinterpret_cast<const float4*>(wp + o.f_whh[l][rd]) + (size_t)rr * (Q / 4) * 128 + rq;
+                            const float4* w4 = reinterpret_cast<const float4*>(wp + o.f_whh[l][rd]) + (size_t)rr * (Q / 4) * S::NTD + rq;
 #pragma unroll 8
                             for (int k = 0; k < Q / 4; ++k) {
-                                const float4 wv = w4[(size_t)k * 128];
+                                const float4 wv = w4[(size_t)k * S::NTD];
                                 p0 += f32x2{wv.x, wv.y} * f32x2{hq[k].x, hq[k].y};
                                 p1 += f32x2{wv.z, wv.w} * f32x2{hq[k].z, hq[k].w};
                             }
@@ -532,12 +537,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                             }
                     } else {
                         // streamed: [rr][gate][k/4][128 threads] float4
-                        const float4* w4 = reinterpret_cast<const float4*>(wp + o.f_whh[l][rd]) + (size_t)rr * 4 * (Q / 4) * 128 + rq;
+                        const float4* w4 = reinterpret_cast<const float4*>(wp + o.f_whh[l][rd]) + (size_t)rr * 4 * (Q / 4) * S::NTD + rq;
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
 #pragma unroll
                             for (int k = 0; k < Q / 4; ++k) {
-                                const float4 wv = w4[(size_t)(g * (Q / 4) + k) * 128];
+                                const float4 wv = w4[(size_t)(g * (Q / 4) + k) * S::NTD];
                                 p[g] += f32x2{wv.x, wv.y} * f32x2{hq[k].x, hq[k].y};
                                 p[g] += f32x2{wv.z, wv.w} * f32x2{hq[k].z, hq[k].w};
                             }
@@ -568,6 +573,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 }
                 __syncthreads();
             };
+#pragma unroll 1
+            for (int dd = 0; dd < (S::SEQD ? 2 : 1); ++dd) {
+            if constexpr (S::SEQD) { rd = dd; load_whh(dd); }      // (the previous direction's last step ended with a barrier)
+#pragma unroll
+            for (int rr = 0; rr < S::RPT; ++rr) { cstate[rr] = 0.0f; xp_next[rr] = xp_at(0, rr); }
             if constexpr (REGW) {
                 // the next layer's weights ride under this latency chain, in three bursts (a wave keeps at most 63 loads in flight)
                 const bool more = l + 1 < S::NLAY;
@@ -584,6 +594,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             } else {
 #pragma unroll 1
                 for (int s = 0; s < kBands; ++s) rec_step(s);
+            }
             }
             if (l == 0) BE_CLK(6);
             {
@@ -840,6 +851,7 @@ struct BImpl {
     int dbg_stages;
     bool whh_regs;            // W_hh packing: [rr][k'][128] floats (register shapes) or [rr][k'/4][128] float4 (streamed)
     bool ksplit;              // thread <-> (unit, K quarter) holding all four gates (BShape::KSPLIT) or (unit, gate) over the whole K
+    int rec_threads;          // threads of one direction of the band recurrence (BShape::NTD)
     void (*launch)(const BArgs&, int max_wgs, hipStream_t, hipError_t*);
     void (*dbg_stage)(int, int*, int*, size_t*);
 };
@@ -888,7 +900,7 @@ void bdbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
 template <class S>
 BImpl make_bimpl() {
     return BImpl{S::C, S::NLAY, S::HOP, BLds<S>::BYTES, S::XPG ? (size_t)2 * 32 * S::G4 : (size_t)0,
-                 BDebugLayout<S>::total(), BDebugLayout<S>::n_stages, S::WREG, S::KSPLIT, &blaunch_impl<S>, &bdbg_stage_impl<S>};
+                 BDebugLayout<S>::total(), BDebugLayout<S>::n_stages, S::WREG, S::KSPLIT, S::NTD, &blaunch_impl<S>, &bdbg_stage_impl<S>};
 }
 
 }  // namespace fe

@@ -502,23 +502,24 @@ int pack_weights_bsrnn(fe_handle* h, const std::vector<float>& blob, std::vector
             const float* bh = S(keyd("bias_hh"));
             o.f_b[l][d] = alloc(G4);
             for (int i = 0; i < G4; ++i) buf[o.f_b[l][d] + i] = gscale(i) * (bi[i] + bh[i]);
-            {   // recurrence weights in thread order.  Thread t (0..127) of a direction = 4 u + q, hidden unit u (+ 32 rr).
+            {   // recurrence weights in thread order.  Thread t (0..NTD-1; NTD = 128, or 256 for C = 64) of a direction = 4 u + q, hidden unit u (+ NTD/4 rr).
                 // KSPLIT shapes: q = K-quarter; the thread holds, for all four gates g, W_hh[g*HH + u + 32 rr][q*HH/4 + kk] at
                 //   [rr][g*HH/4 + kk][t].  Otherwise q = gate: it holds row W_hh[q*HH + u + 32 rr][k] at [rr][k][t].
                 // (streamed shapes: the k index in float4 groups)
                 const float* whh = S(keyd("weight_hh"));      // (4HH, HH), gate-major rows
                 o.f_whh[l][d] = alloc((size_t)G4 * HH);
-                const int RPT = HH / 32, Q = HH / 4;
+                const int NTD = h->bimpl->rec_threads, UPP = NTD / 4;      // threads of a direction (256 for C = 64: SEQD), units per pass
+                const int RPT = HH / UPP, Q = HH / 4;
                 const bool ksplit = h->bimpl->ksplit;
                 for (int rr = 0; rr < RPT; ++rr)
                     for (int kp = 0; kp < HH; ++kp)
-                        for (int t = 0; t < 128; ++t) {
-                            const int u = (t >> 2) + 32 * rr, q = t & 3;
+                        for (int t = 0; t < NTD; ++t) {
+                            const int u = (t >> 2) + UPP * rr, q = t & 3;
                             const int row = ksplit ? (kp / Q) * HH + u : q * HH + u;
                             const int k = ksplit ? q * Q + (kp % Q) : kp;
                             const float v = gscale(row) * whh[(size_t)row * HH + k];
-                            if (whh_regs) buf[o.f_whh[l][d] + ((size_t)rr * HH + kp) * 128 + t] = v;
-                            else buf[o.f_whh[l][d] + ((((size_t)rr * (HH / 4)) + kp / 4) * 128 + t) * 4 + (kp & 3)] = v;
+                            if (whh_regs) buf[o.f_whh[l][d] + ((size_t)rr * HH + kp) * NTD + t] = v;
+                            else buf[o.f_whh[l][d] + ((((size_t)rr * (HH / 4)) + kp / 4) * NTD + t) * 4 + (kp & 3)] = v;
                         }
             }
         }
