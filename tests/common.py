@@ -103,3 +103,15 @@ def product_config(name):
     from fastenhancer_amd.config import FEConfig as PCfg, time_kernel_config
     kw = MODEL_KWARGS[name][0]
     return time_kernel_config(**kw) if MODEL_MODULE[name] == "fastenhancer.time_kernel" else PCfg.from_model_kwargs(**kw)
+
+
+# configs/others/lisennet.yaml:2-8
+LISENNET_KWARGS = (dict(num_channels=16, n_blocks=2, n_fft=512, hop_size=256, win_size=512, input_compression=0.3), 16000, 401)
+
+
+def build_lisennet_oracle(dtype=np.float32):
+    from oracle import lisennet_oracle as lo
+    kw, sr, seed = LISENNET_KWARGS
+    cfg = lo.LiSenNetConfig.from_model_kwargs(kw)
+    sd = lo.make_state_dict(cfg, seed)
+    return cfg, sd, sd, lo.LiSenNetOracle(cfg, sd, dtype)

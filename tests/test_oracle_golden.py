@@ -176,3 +176,43 @@ def test_fspen_streaming_and_offline_match_reference():
     wav, spec = orc.offline_forward(xo)
     _close(wav, g["offline_wav"], what="offline wav")
     _close(spec, g["offline_spec"], what="offline spec")
+
+
+def test_lisennet_streaming_and_offline_match_reference():
+    """models/lisennet/model.py (SURVEY.md §8(f) rank 4) - golden = the imported reference (tools/gen_golden.py::gen_lisennet).
+    Streaming: 10 hops x 2 streams with all 9 model caches.  Offline: Model.forward's phase features are ill-conditioned on frame 0
+    (a frame that reflect padding makes symmetric has a real spectrum; an all-zero frame has atan2(+-0, +-0)), so the oracle is
+    pinned through the reference's own features (model_forward, mask, iSTFT) and its feature extraction on all other frames."""
+    from common import build_lisennet_oracle
+    g = load_golden("lisennet")
+    cfg, sd, _, orc = build_lisennet_oracle()
+    B, hops, H = int(g["B"]), int(g["hops"]), cfg.hop_size
+    x = make_input(B, hops * H, int(g["seed"]) + 1000, int(g["sr"]))
+    caches = orc.initialize_cache(B)
+    outs = []
+    for t in range(hops):
+        o, *caches = orc.step(x[:, t * H:(t + 1) * H], *caches)
+        outs.append(o)
+    _close(np.stack(outs, 0), g["stream_wav_out"], what="wav_out")
+    _close(caches[0], g["stream_cache_stft"], what="cache_stft")
+    _close(caches[1], g["stream_cache_istft"], what="cache_istft")
+    for i in range(cfg.n_caches):
+        _close(caches[2 + i], g[f"stream_c{i}"], what=f"model cache {i}")
+    xo = make_input(B, hops * H + 37, int(g["seed"]) + 2000, int(g["sr"]))
+    xo[:, :int(g["offline_leading_zeros"])] = 0.0
+    wav, spec = orc.offline_forward(xo, feat=g["offline_feat"])
+    _close(wav, g["offline_wav"], what="offline wav")
+    _close(spec, g["offline_spec"], what="offline spec")
+    # the oracle's own feature extraction (torch.diff convention): every frame but the ill-conditioned first one
+    N = cfg.n_fft
+    xp = np.pad(xo, ((0, 0), (N // 2, N // 2)), mode="reflect")
+    T = 1 + xo.shape[1] // H
+    X = np.fft.rfft(np.stack([xp[:, t * H:t * H + N] for t in range(T)], axis=1) * orc.window, axis=2)
+    sp = np.stack([X.real, X.imag], axis=-1).astype(np.float32).transpose(0, 2, 1, 3) + np.float32(0.0)
+    sp = sp * np.maximum(np.sqrt(sp[..., 0:1] ** 2 + sp[..., 1:2] ** 2), np.float32(1e-5)) ** np.float32(cfg.input_compression - 1.0)
+    feat, _ = orc.features(sp, None, False)
+    ref = g["offline_feat"]
+    assert np.abs(feat[:, 0] - ref[:, 0]).max() < 1e-4
+    d = np.abs(feat[:, :, 1:] - ref[:, :, 1:])
+    d[:, 2, 0] = 0.0          # ifd of frame 1 looks back at frame 0's phase
+    assert d.max() < 2e-3, d.max()

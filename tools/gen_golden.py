@@ -339,6 +339,71 @@ def gen_fspen(ref: str, out_dir: str):
           f"in_rms={float(np.sqrt((x.numpy() ** 2).mean())):.3f} out_rms={float(np.sqrt((out['stream_wav_out'][4:] ** 2).mean())):.3f}")
 
 
+def gen_lisennet(ref: str, out_dir: str):
+    """the LiSenNet baseline (configs/others/lisennet.yaml, models/lisennet/model.py)."""
+    from oracle import lisennet_oracle as lo
+    seed, B, hops = 401, 2, 10
+    hps = yaml.safe_load(open(os.path.join(ref, "configs/others/lisennet.yaml")))
+    kw = hps["model_kwargs"]
+    sr = hps["data"]["sampling_rate"]
+    cfg = lo.LiSenNetConfig.from_model_kwargs(kw)
+    mod = import_reference_model(ref, "models/lisennet/model.py", "ref_lisennet_model")
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+    model = mod.Model(**kw).eval()
+    ref_sd = model.state_dict()
+    spec = lo.state_dict_spec(cfg)
+    assert list(ref_sd.keys()) == list(spec.keys()), ([k for k in ref_sd if k not in spec], [k for k in spec if k not in ref_sd])
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(spec[k]), (k, v.shape, spec[k])
+    sd = lo.make_state_dict(cfg, seed)
+    model.load_state_dict(to_t(sd), strict=True)
+    onnx_model = mod.ONNXModel(**kw).eval()
+    onnx_model.load_state_dict(to_t(sd), strict=True)
+    onnx_model.remove_weight_reparameterizations()         # (a no-op for this model)
+    out = {"seed": np.int64(seed), "B": np.int64(B), "hops": np.int64(hops), "sr": np.int64(sr)}
+    H = cfg.hop_size
+    x = torch.from_numpy(make_input(B, hops * H, seed + 1000, sr))
+    with torch.no_grad():
+        cache_stft, cache_istft = onnx_model.stft.initialize_cache(x)
+        cm = [torch.zeros(*s_) for s_ in cfg.cache_shapes(B)]           # the model's own initialize_cache is written for one stream
+        outs = []
+        for t in range(hops):
+            spec_in, cache_stft = onnx_model.stft(x[:, t * H:(t + 1) * H], cache_stft)
+            spec_out, *cm = onnx_model(spec_in, *cm)
+            wav_out, cache_istft = onnx_model.stft.inverse(spec_out, cache_istft)
+            outs.append(wav_out.numpy().copy())
+    out["stream_wav_out"] = np.stack(outs, 0)
+    out["stream_cache_stft"] = cache_stft.numpy().copy()
+    out["stream_cache_istft"] = cache_istft.numpy().copy()
+    for i, t_ in enumerate(cm):
+        out[f"stream_c{i}"] = t_.numpy().copy()
+    out["stream_spec_out_last"] = spec_out.numpy().copy()
+    # Model.forward's phase features are ILL-CONDITIONED on frame 0 of any signal: torch.stft(center=True, pad_mode="reflect") makes
+    # that frame symmetric about its centre, its spectrum real up to rounding noise, its phases 0 / pi at random, and the wrapped
+    # phase differences +-pi by the last bit of atan2 (two runs of the reference on different BLAS builds would not agree).  The
+    # offline vector therefore starts with 300 samples of silence: an all-zero frame 0 has phase atan2(0, 0) = 0 everywhere.
+    xo_np = make_input(B, hops * H + 37, seed + 2000, sr)
+    xo_np[:, :300] = 0.0
+    xo = torch.from_numpy(xo_np)
+    with torch.no_grad():
+        wav_hat, spec_hat = model(xo)
+        # ... and even the all-zero frame is not portable: torch.stft returns -0.0 in its upper bins (atan2(0, -0.0) = pi), numpy's
+        # rfft and the GPU's FFT +0.0.  The reference's own features of the vector are therefore stored too: the oracle is pinned
+        # on Model.forward through them (model_forward, masking, iSTFT), its feature extraction on every frame but the first.
+        xs = model.stft(xo)
+        xc = torch.view_as_complex(xs).transpose(1, 2)
+        pha = xc.angle()
+        out["offline_feat"] = torch.stack([xc.abs(), model.cal_gd(pha) / torch.pi, model.cal_ifd(pha) / torch.pi], dim=1).numpy().copy()
+    out["offline_wav"] = wav_hat.numpy().copy()
+    out["offline_spec"] = spec_hat.numpy().copy()
+    out["offline_leading_zeros"] = np.int64(300)
+    path = os.path.join(out_dir, "lisennet.npz")
+    np.savez_compressed(path, **out)
+    print(f"lisennet: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB) "
+          f"in_rms={float(np.sqrt((x.numpy() ** 2).mean())):.3f} out_rms={float(np.sqrt((out['stream_wav_out'][4:] ** 2).mean())):.3f}")
+
+
 def gen_si_snr(ref: str, out_dir: str):
     """SI-SDR of the reference's evaluation script: `si_snr` / `product` are closures inside main() of
     scripts/metrics_ns.py (which imports torchaudio / pesq / pystoi at its top), so the two function definitions
@@ -387,6 +452,8 @@ def main():
         gen_si_snr(args.ref, args.out)
     if not args.only or "fspen" in args.only:
         gen_fspen(args.ref, args.out)
+    if not args.only or "lisennet" in args.only:
+        gen_lisennet(args.ref, args.out)
 
 
 if __name__ == "__main__":
