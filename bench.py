@@ -59,6 +59,7 @@ WORKLOADS = {
     "bsrnn_t": dict(bsrnn=True, C=32, L=6, N=512, H=256, sr=16000, desc="BSRNN (t) 16kHz"),
     "bsrnn_s": dict(bsrnn=True, C=64, L=6, N=512, H=256, sr=16000, desc="BSRNN (s) 16kHz"),
     "fspen": dict(fspen=True, N=512, H=256, sr=16000, desc="FSPEN 16kHz (configs/others/fspen.yaml)"),
+    "lisennet": dict(lisennet=True, N=512, H=256, sr=16000, desc="LiSenNet 16kHz (configs/others/lisennet.yaml)"),
     "fe_m": dict(C1=96, ks=(8, 3, 3, 3), C2=72, F2=48, K=4, N=512, H=160, sr=16000, init="linear_fixed",
                  desc="FastEnhancer_M 16kHz"),
     "fe_l": dict(C1=128, ks=(8, 3, 3, 3, 3), C2=96, F2=64, K=5, N=512, H=100, sr=16000, init="linear_fixed",
@@ -69,6 +70,8 @@ WORKLOADS = {
 
 
 def model_kwargs(w):
+    if w.get("lisennet"):
+        return dict(num_channels=16, n_blocks=2, n_fft=w["N"], hop_size=w["H"], win_size=w["N"], input_compression=0.3)
     if w.get("fspen"):
         return dict(channels=[4, 16, 32], kernel_size=[6, 8, 6], stride=[2, 2, 2],
                     dpe_kwargs=dict(num_blocks=3, channels=16, freq=32, groups=8, norm="LayerNorm-FreqChannels"),
@@ -150,16 +153,22 @@ def host_cpus():
     return avail, quota
 
 
-def cpu_baseline_fspen(kw: dict, sr: int, B: int, budget_s: float):
-    """FSPEN: the numpy oracle (oracle/fspen_oracle.py, pinned on the reference's golden vectors) on ONE host core."""
-    from oracle import fspen_oracle as fo
+def cpu_baseline_fspen(kw: dict, sr: int, B: int, budget_s: float, lisennet: bool = False):
+    """FSPEN / LiSenNet: the numpy oracle (oracle/fspen_oracle.py, oracle/lisennet_oracle.py, pinned on the reference's golden vectors)
+    on ONE host core."""
     from oracle.weightgen import make_input
     try:
         torch.set_num_threads(1)
     except Exception:
         pass
-    cfg = fo.FSPENConfig.from_model_kwargs(kw)
-    orc = fo.FSPENOracle(cfg, fo.fold_state_dict(fo.make_training_state_dict(cfg, 2), cfg), np.float32)
+    if lisennet:
+        from oracle import lisennet_oracle as lo
+        cfg = lo.LiSenNetConfig.from_model_kwargs(kw)
+        orc = lo.LiSenNetOracle(cfg, lo.make_state_dict(cfg, 2), np.float32)
+    else:
+        from oracle import fspen_oracle as fo
+        cfg = fo.FSPENConfig.from_model_kwargs(kw)
+        orc = fo.FSPENOracle(cfg, fo.fold_state_dict(fo.make_training_state_dict(cfg, 2), cfg), np.float32)
     Bs = min(B, 16)
     H = cfg.hop_size
     x = make_input(Bs, 64 * H, 5, sr)
@@ -171,7 +180,8 @@ def cpu_baseline_fspen(kw: dict, sr: int, B: int, budget_s: float):
         hops += 1
     dt = time.perf_counter() - t0
     return {"value": hops * Bs / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{hops} hops x {Bs} streams of fspen through the numpy oracle (oracle/fspen_oracle.py) in {dt:.1f} s on one host core"}
+            "sample": f"{hops} hops x {Bs} streams of {'lisennet' if lisennet else 'fspen'} through the numpy oracle "
+                      f"(oracle/{'lisennet' if lisennet else 'fspen'}_oracle.py) in {dt:.1f} s on one host core"}
 
 
 def cpu_baseline_bsrnn(workload: str, kw: dict, sr: int, B: int, budget_s: float):
@@ -285,7 +295,10 @@ def main():
 
     w = WORKLOADS[args.workload]
     kw = model_kwargs(w)
-    if w.get("fspen"):
+    if w.get("lisennet"):
+        from fastenhancer_amd.config import LiSenNetConfig
+        cfg = LiSenNetConfig.from_model_kwargs(**kw)
+    elif w.get("fspen"):
         from fastenhancer_amd.config import FSPENConfig
         cfg = FSPENConfig.from_model_kwargs(**kw)
     elif w.get("bsrnn"):
@@ -303,8 +316,10 @@ def main():
     if rank == 0:
         # no trained checkpoints offline: PyTorch-style random init of the fused weights; the final conv is
         # scaled so that the complex mask is O(1) (the enhanced waveform has the level of the input)
-        from fastenhancer_amd.weights import bsrnn_default_state_dict, default_state_dict, fspen_default_state_dict
-        if w.get("fspen"):
+        from fastenhancer_amd.weights import bsrnn_default_state_dict, default_state_dict, fspen_default_state_dict, lisennet_default_state_dict
+        if w.get("lisennet"):
+            sd = lisennet_default_state_dict(cfg, torch.Generator().manual_seed(2))
+        elif w.get("fspen"):
             sd = fspen_default_state_dict(cfg, torch.Generator().manual_seed(2))
         elif w.get("bsrnn"):
             sd = bsrnn_default_state_dict(cfg, torch.Generator().manual_seed(2))
@@ -427,12 +442,12 @@ def main():
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": measured_traffic(args.workload, B, T),
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "algorithmic_hbm_bytes_per_launch": B * T * (2 * H * 4) + 2 * 4 * eng.state_floats(B),
-                         "kernel": "fspen_frame_kernel" if w.get("fspen") else ("bsrnn_frame_kernel" if w.get("bsrnn") else "fe_frame_kernel"), "kernel_ms": kernel_ms,
+                         "kernel": "lisennet_frame_kernel" if w.get("lisennet") else "fspen_frame_kernel" if w.get("fspen") else ("bsrnn_frame_kernel" if w.get("bsrnn") else "fe_frame_kernel"), "kernel_ms": kernel_ms,
                          "flops_per_frame": eng.flops_per_frame,
                          "hbm_frac": (B * T * (2 * H * 4) + 2 * 4 * eng.state_floats(B)) / (kernel_ms * 1e-3) / 8e12},
         }
-        if world == 1 and not args.no_cpu_baseline and w.get("fspen"):
-            res["cpu_baseline"] = cpu_baseline_fspen(kw, w["sr"], B, args.cpu_budget_s)
+        if world == 1 and not args.no_cpu_baseline and (w.get("fspen") or w.get("lisennet")):
+            res["cpu_baseline"] = cpu_baseline_fspen(kw, w["sr"], B, args.cpu_budget_s, lisennet=bool(w.get("lisennet")))
         elif world == 1 and not args.no_cpu_baseline and w.get("bsrnn"):
             res["cpu_baseline"] = cpu_baseline_bsrnn(args.workload, kw, w["sr"], B, args.cpu_budget_s)
         elif world == 1 and not args.no_cpu_baseline and not w.get("kt"):

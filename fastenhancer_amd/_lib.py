@@ -14,6 +14,7 @@ FE_OK = 0
 FE_ARCH_FASTENHANCER = 0
 FE_ARCH_BSRNN = 1
 FE_ARCH_FSPEN = 2
+FE_ARCH_LISENNET = 3
 
 
 class fe_config(ctypes.Structure):

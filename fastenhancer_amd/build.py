@@ -22,7 +22,8 @@ LIB = os.path.join(HERE, "libfastenhancer_hip.so") if not _TAG else os.path.join
 FE_DEPS = ["fe_kernels.hip.h", "fe_impl.h"]
 BSRNN_DEPS = ["fe_kernels.hip.h", "bsrnn_kernels.hip.h"]
 FSPEN_DEPS = ["fe_kernels.hip.h", "fspen_kernels.hip.h"]
-API_DEPS = ["fe_kernels.hip.h", "fe_impl.h", "fe_shapes.def", "bsrnn_kernels.hip.h", "fe_bsrnn_shapes.def", "stft_kernels.hip.h", "fspen_kernels.hip.h",
+LISENNET_DEPS = ["fe_kernels.hip.h", "fspen_kernels.hip.h", "lisennet_kernels.hip.h"]
+API_DEPS = ["fe_kernels.hip.h", "fe_impl.h", "fe_shapes.def", "bsrnn_kernels.hip.h", "fe_bsrnn_shapes.def", "stft_kernels.hip.h", "fspen_kernels.hip.h", "lisennet_kernels.hip.h",
             os.path.join("..", "..", "include", "fastenhancer_hip.h")]
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in VGPRs instead of AGPRs - every epilogue read of an AGPR accumulator is a
 # v_accvgpr_read, a VALU instruction that the fp32 matrix path cannot overlap (~600 of them per wave and frame on
@@ -134,6 +135,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     fsp = os.path.join(CSRC, "fe_fspen.hip")
     jobs.append((fsp, os.path.join(OBJ, "fe_fspen.o"), [], os.path.join(OBJ, "fe_fspen.stamp"),
                  _digest([os.path.join(CSRC, d) for d in FSPEN_DEPS] + [fsp], " ".join(FLAGS))))
+    lsn = os.path.join(CSRC, "fe_lisennet.hip")
+    jobs.append((lsn, os.path.join(OBJ, "fe_lisennet.o"), [], os.path.join(OBJ, "fe_lisennet.stamp"),
+                 _digest([os.path.join(CSRC, d) for d in LISENNET_DEPS] + [lsn], " ".join(FLAGS))))
     if force:
         for j in jobs:
             if os.path.exists(j[3]):

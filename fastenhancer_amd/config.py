@@ -3,6 +3,7 @@ models/fastenhancer/default/model.py:384-403 and asserts the invariants that the
 HIP kernels specialise on (true for every shipped yaml, SURVEY.md top)."""
 from __future__ import annotations
 
+import typing as tp
 from dataclasses import dataclass
 from typing import Any, Dict, Optional, Sequence, Tuple
 
@@ -225,3 +226,51 @@ class FSPENConfig:
         return FSPENConfig(tuple(int(c) for c in channels), tuple(int(k) for k in kernel_size), tuple(int(x) for x in stride),
                            int(d.get("num_blocks", 3)), int(d.get("channels", 16)), int(d.get("freq", 32)), int(d.get("groups", 8)),
                            norm, int(n_fft), int(hop_size), int(win_size), float(input_compression))
+
+
+@dataclass(frozen=True)
+class LiSenNetConfig:
+    """yaml model_kwargs of `model: lisennet` (configs/others/lisennet.yaml:2-8; models/lisennet/model.py:313-323).
+    One architecture is compiled (the yaml's: 16 channels, 2 blocks, n_fft 512, hop 256); fe_create rejects any other."""
+    num_channels: int = 16
+    n_blocks: int = 2
+    n_fft: int = 512
+    hop_size: int = 256
+    win_size: int = 512
+    input_compression: float = 0.3
+
+    @property
+    def F0(self) -> int:
+        return self.n_fft // 2
+
+    @property
+    def cache_len(self) -> int:
+        return self.n_fft - self.hop_size
+
+    @property
+    def hidden(self) -> int:
+        return self.num_channels // 2 * 3
+
+    @property
+    def n_caches(self) -> int:
+        return 1 + 3 + 2 * self.n_blocks + 1
+
+    def cache_shapes(self, B: int):
+        """ONNXModel.initialize_cache (models/lisennet/model.py:380-396), sized for B streams"""
+        C, F = self.num_channels, self.n_fft // 2 + 1
+        sh = [(B, 1, F), (B, C // 4, 1, F), (B, C // 2, 1, F // 2), (B, C // 4 * 3, 1, F // 4)]
+        for _ in range(self.n_blocks):
+            sh += [(1, B * (F // 8), self.hidden), (B, 2 * C, 2, F // 8)]
+        sh.append((B, C // 4, 1, F - 1))
+        return sh
+
+    @staticmethod
+    def from_model_kwargs(num_channels: int = 16, n_blocks: int = 2, n_fft: int = 512, hop_size: int = 256, win_size: int = 512,
+                          window: tp.Optional[str] = "hann", input_compression: float = 0.3, normalized: bool = False) -> "LiSenNetConfig":
+        if window != "hann":
+            raise RuntimeError(f"model_kwargs.window={window} is not supported by the HIP path (shipped: hann).")
+        if normalized:
+            raise RuntimeError("model_kwargs.normalized=True is not supported by the HIP path (shipped: False).")
+        if n_fft < win_size:
+            raise AssertionError(f"n_fft({n_fft}) must be bigger than win_size({win_size})")
+        return LiSenNetConfig(int(num_channels), int(n_blocks), int(n_fft), int(hop_size), int(win_size), float(input_compression))

@@ -16,6 +16,7 @@
 #include "fe_impl.h"
 #include "bsrnn_kernels.hip.h"
 #include "fspen_kernels.hip.h"
+#include "lisennet_kernels.hip.h"
 #include "stft_kernels.hip.h"
 
 namespace {
@@ -62,6 +63,7 @@ struct Dims {
 #include "fe_bsrnn_shapes.def"
 #undef XB
 extern "C" const fe::FImpl* fe_fimpl_h256();
+extern "C" const fe::LImpl* fe_limpl_h256();
 
 const std::vector<const fe::BImpl*>& bimpls() {
     static const std::vector<const fe::BImpl*> v = {
@@ -93,6 +95,7 @@ struct fe_handle {
     const fe::Impl* impl_many = nullptr;  // low-LDS companion (two workgroups per CU) for batches above #CUs streams, if compiled
     const fe::BImpl* bimpl = nullptr;     // arch == FE_ARCH_BSRNN
     const fe::FImpl* fimpl = nullptr;     // arch == FE_ARCH_FSPEN
+    const fe::LImpl* limpl = nullptr;     // arch == FE_ARCH_LISENNET
     fe::BOffsets boff{};
     int device = 0;
     int max_wgs = 256;             // CUs of the device: one resident workgroup per CU (persistent grid above that)
@@ -799,6 +802,224 @@ int launch_fspen(fe_handle* h, const fe::FArgs& a, void* stream) {
     return FE_OK;
 }
 
+// ============================================================================ LiSenNet (models/lisennet/model.py)
+// the checkpoint as it is (remove_weight_reparameterizations is a no-op, :476-477), reference layouts, module order
+void build_sections_lisennet(fe_handle* h) {
+    const int C = 16, c1 = 4, c2 = 8, c3 = 12, F = 257, Hd = 24, nf = 32;
+    auto dsconv = [&](const std::string& p, int cin, int cout, int nfq) {
+        add_section(h, p + ".low_conv.weight", {cout, cin, 2, 3});
+        add_section(h, p + ".low_conv.bias", {cout});
+        add_section(h, p + ".high_conv.weight", {cout, cin, 2, 5});
+        add_section(h, p + ".high_conv.bias", {cout});
+        add_section(h, p + ".norm.gamma", {1, 1, 1, nfq / 2});
+        add_section(h, p + ".norm.beta", {1, 1, 1, nfq / 2});
+        add_section(h, p + ".act.weight", {cout});
+    };
+    auto gru = [&](const std::string& p, int i, int hd, bool bi) {
+        for (const char* sfx : {"", "_reverse"}) {
+            if (!bi && sfx[0]) break;
+            add_section(h, p + ".weight_ih_l0" + sfx, {3 * hd, i});
+            add_section(h, p + ".weight_hh_l0" + sfx, {3 * hd, hd});
+            add_section(h, p + ".bias_ih_l0" + sfx, {3 * hd});
+            add_section(h, p + ".bias_hh_l0" + sfx, {3 * hd});
+        }
+    };
+    add_section(h, "encoder.conv_1.0.weight", {c1, 3, 1, 1});
+    add_section(h, "encoder.conv_1.0.bias", {c1});
+    add_section(h, "encoder.conv_1.1.gamma", {1, 1, 1, F});
+    add_section(h, "encoder.conv_1.1.beta", {1, 1, 1, F});
+    add_section(h, "encoder.conv_1.2.weight", {c1});
+    dsconv("encoder.conv_2", c1, c2, F);
+    dsconv("encoder.conv_3", c2, c3, F / 2);
+    dsconv("encoder.conv_4", c3, C, F / 4);
+    for (int b = 0; b < 2; ++b) {
+        const std::string p = "blocks." + std::to_string(b) + ".";
+        add_section(h, p + "dp_rnn_attn.intra_norm.weight", {nf, C});
+        add_section(h, p + "dp_rnn_attn.intra_norm.bias", {nf, C});
+        gru(p + "dp_rnn_attn.intra_rnn_attn.rnn", C, Hd / 2, true);
+        add_section(h, p + "dp_rnn_attn.intra_rnn_attn.dense.weight", {C, Hd});
+        add_section(h, p + "dp_rnn_attn.intra_rnn_attn.dense.bias", {C});
+        add_section(h, p + "dp_rnn_attn.inter_norm.weight", {nf, C});
+        add_section(h, p + "dp_rnn_attn.inter_norm.bias", {nf, C});
+        gru(p + "dp_rnn_attn.inter_rnn_attn.rnn", C, Hd, false);
+        add_section(h, p + "dp_rnn_attn.inter_rnn_attn.dense.weight", {C, Hd});
+        add_section(h, p + "dp_rnn_attn.inter_rnn_attn.dense.bias", {C});
+        add_section(h, p + "conv_glu.norm.gamma", {1, C, 1, nf});
+        add_section(h, p + "conv_glu.norm.beta", {1, C, 1, nf});
+        add_section(h, p + "conv_glu.fc1.weight", {4 * C, C, 1, 1});
+        add_section(h, p + "conv_glu.fc1.bias", {4 * C});
+        add_section(h, p + "conv_glu.dwconv.weight", {2 * C, 1, 3, 3});
+        add_section(h, p + "conv_glu.dwconv.bias", {2 * C});
+        add_section(h, p + "conv_glu.fc2.weight", {C, 2 * C, 1, 1});
+        add_section(h, p + "conv_glu.fc2.bias", {C});
+    }
+    const int ucin[3] = {2 * C, 2 * c3, 2 * c2}, ucout[3] = {c3, c2, c1};
+    for (int i = 0; i < 3; ++i) {
+        const std::string p = "decoder.up" + std::to_string(i + 1) + ".";
+        add_section(h, p + "low_conv.weight", {ucout[i], ucin[i], 1, 3});
+        add_section(h, p + "low_conv.bias", {ucout[i]});
+        add_section(h, p + "high_conv.conv.weight", {3 * ucout[i], ucin[i], 1, 3});
+        add_section(h, p + "high_conv.conv.bias", {3 * ucout[i]});
+    }
+    add_section(h, "decoder.mask_conv.0.weight", {2, c1, 2, 2});
+    add_section(h, "decoder.mask_conv.0.bias", {2});
+    add_section(h, "decoder.mask_conv.1.gamma", {1, 1, 1, F});
+    add_section(h, "decoder.mask_conv.1.beta", {1, 1, 1, F});
+    add_section(h, "decoder.mask_conv.2.weight", {2});
+    add_section(h, "decoder.mask_conv.3.weight", {2, 2, 1, 1});
+    add_section(h, "decoder.mask_conv.3.bias", {2});
+    add_section(h, "decoder.lsigmoid.slope", {F, 1, 1});
+}
+
+int create_lisennet(const fe_config* cfg, fe_handle** out) {
+    if (cfg->win_size > cfg->n_fft) return fail(FE_ERR_INVALID_ARG, "n_fft(%d) must be bigger than win_size(%d)", cfg->n_fft, cfg->win_size);
+    const fe::LImpl* li = (cfg->channels == 16 && cfg->rf_blocks == 2 && cfg->n_fft == 512 && cfg->hop_size == 256) ? fe_limpl_h256() : nullptr;
+    if (!li)
+        return fail(FE_ERR_UNSUPPORTED_CONFIG, "no LiSenNet kernel compiled for num_channels=%d n_blocks=%d n_fft=%d hop=%d "
+                    "(configs/others/lisennet.yaml is the compiled architecture)", cfg->channels, cfg->rf_blocks, cfg->n_fft, cfg->hop_size);
+    fe_handle* h = new fe_handle();
+    h->cfg = *cfg;
+    h->limpl = li;
+    h->d = Dims{16, 0, 16, 32, 2, cfg->n_fft, cfg->hop_size, cfg->n_fft / 2, 0, 0, {0}};
+    if (hipGetDevice(&h->device) != hipSuccess) h->device = -1;
+    else {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->max_wgs = cus;
+    }
+    build_sections_lisennet(h);
+    build_tables(h);
+    *out = h;
+    return FE_OK;
+}
+
+// k-major repack at the compile-time offsets of fe::LPk (lisennet_kernels.hip.h)
+int pack_weights_lisennet(fe_handle* h, const std::vector<float>& blob, std::vector<float>* out) {
+    using P = fe::LPk;
+    std::vector<float> buf(P::TOTAL, 0.0f);
+    auto S = [&](const std::string& n) { return sec(h, blob, n); };
+    auto copy = [&](const std::string& n, int dst, int cnt) { const float* w = S(n); for (int i = 0; i < cnt; ++i) buf[dst + i] = w[i]; };
+    for (int i = 0; i < 512; ++i) { buf[P::WINDOW + i] = h->window[i]; buf[P::WINDOW_I + i] = h->window_istft[i]; buf[P::TW + i] = h->twiddle[i]; }
+    {
+        const float* w = S("encoder.conv_1.0.weight");            // (4, 3, 1, 1) -> [c][o]
+        for (int o = 0; o < 4; ++o) for (int c = 0; c < 3; ++c) buf[P::C1_W + c * 4 + o] = w[o * 3 + c];
+        copy("encoder.conv_1.0.bias", P::C1_B, 4);
+        copy("encoder.conv_1.1.gamma", P::C1_G, 257);
+        copy("encoder.conv_1.1.beta", P::C1_BE, 257);
+        copy("encoder.conv_1.2.weight", P::C1_P, 4);
+    }
+    // Conv2d (O, Cin, KT, KF) -> [((c*KT + dt)*KF + df)][O]
+    auto conv = [&](const std::string& key, int O, int Cin, int KT, int KF, int dst_w, int dst_b) {
+        const float* w = S(key + ".weight");
+        for (int o = 0; o < O; ++o)
+            for (int c = 0; c < Cin; ++c)
+                for (int dt = 0; dt < KT; ++dt)
+                    for (int df = 0; df < KF; ++df) buf[dst_w + ((c * KT + dt) * KF + df) * O + o] = w[((o * Cin + c) * KT + dt) * KF + df];
+        if (dst_b >= 0) copy(key + ".bias", dst_b, O);
+    };
+    auto dsconv = [&](const std::string& p, int cin, int cout, int half, int lo, int hi, int bl, int bh, int g, int be, int pr) {
+        conv(p + ".low_conv", cout, cin, 2, 3, lo, bl);
+        conv(p + ".high_conv", cout, cin, 2, 5, hi, bh);
+        copy(p + ".norm.gamma", g, 2 * half);
+        copy(p + ".norm.beta", be, 2 * half);
+        copy(p + ".act.weight", pr, cout);
+    };
+    dsconv("encoder.conv_2", 4, 8, 64, P::D2_LO, P::D2_HI, P::D2_BL, P::D2_BH, P::D2_G, P::D2_BE, P::D2_P);
+    dsconv("encoder.conv_3", 8, 12, 32, P::D3_LO, P::D3_HI, P::D3_BL, P::D3_BH, P::D3_G, P::D3_BE, P::D3_P);
+    dsconv("encoder.conv_4", 12, 16, 16, P::D4_LO, P::D4_HI, P::D4_BL, P::D4_BH, P::D4_G, P::D4_BE, P::D4_P);
+    for (int b = 0; b < 2; ++b) {
+        const int D = P::BLK + b * P::B_SIZE;
+        const std::string p = "blocks." + std::to_string(b) + ".";
+        copy(p + "dp_rnn_attn.intra_norm.weight", D + P::B_N1W, 512);
+        copy(p + "dp_rnn_attn.intra_norm.bias", D + P::B_N1B, 512);
+        for (int d = 0; d < 2; ++d) {
+            const std::string sfx = d ? "_reverse" : "";
+            const std::string q = p + "dp_rnn_attn.intra_rnn_attn.rnn.";
+            const float* wi = S(q + "weight_ih_l0" + sfx);        // (36, 16)
+            const float* wh = S(q + "weight_hh_l0" + sfx);        // (36, 12)
+            const float* bi = S(q + "bias_ih_l0" + sfx);
+            const float* bh = S(q + "bias_hh_l0" + sfx);
+            for (int g = 0; g < 36; ++g) {
+                for (int k = 0; k < 16; ++k) buf[D + P::B_IH + (d * 16 + k) * 36 + g] = wi[g * 16 + k];
+                buf[D + P::B_GB + d * 36 + g] = bi[g] + (g < 24 ? bh[g] : 0.0f);
+            }
+            for (int gate = 0; gate < 3; ++gate)
+                for (int k = 0; k < 12; ++k)
+                    for (int c = 0; c < 12; ++c) buf[D + P::B_HH + ((d * 3 + gate) * 12 + k) * 12 + c] = wh[(gate * 12 + c) * 12 + k];
+            for (int c = 0; c < 12; ++c) buf[D + P::B_HN + d * 12 + c] = bh[24 + c];
+        }
+        {
+            const float* w = S(p + "dp_rnn_attn.intra_rnn_attn.dense.weight");     // (16, 24) -> [k][d]
+            for (int d = 0; d < 16; ++d) for (int k = 0; k < 24; ++k) buf[D + P::B_D1W + k * 16 + d] = w[d * 24 + k];
+            copy(p + "dp_rnn_attn.intra_rnn_attn.dense.bias", D + P::B_D1B, 16);
+        }
+        copy(p + "dp_rnn_attn.inter_norm.weight", D + P::B_N2W, 512);
+        copy(p + "dp_rnn_attn.inter_norm.bias", D + P::B_N2B, 512);
+        {
+            const std::string q = p + "dp_rnn_attn.inter_rnn_attn.rnn.";
+            const float* wi = S(q + "weight_ih_l0");              // (72, 16)
+            const float* wh = S(q + "weight_hh_l0");              // (72, 24)
+            const float* bi = S(q + "bias_ih_l0");
+            const float* bh = S(q + "bias_hh_l0");
+            for (int g = 0; g < 72; ++g) {
+                for (int k = 0; k < 16; ++k) buf[D + P::B_XIH + k * 72 + g] = wi[g * 16 + k];
+                for (int k = 0; k < 24; ++k) buf[D + P::B_XHH + k * 72 + g] = wh[g * 24 + k];
+                buf[D + P::B_XGB + g] = bi[g] + (g < 48 ? bh[g] : 0.0f);
+            }
+            for (int c = 0; c < 24; ++c) buf[D + P::B_XHN + c] = bh[48 + c];
+            const float* w = S(p + "dp_rnn_attn.inter_rnn_attn.dense.weight");
+            for (int d = 0; d < 16; ++d) for (int k = 0; k < 24; ++k) buf[D + P::B_D2W + k * 16 + d] = w[d * 24 + k];
+            copy(p + "dp_rnn_attn.inter_rnn_attn.dense.bias", D + P::B_D2B, 16);
+        }
+        copy(p + "conv_glu.norm.gamma", D + P::B_GG, 512);        // (1, 16, 1, 32) -> [d][f]
+        copy(p + "conv_glu.norm.beta", D + P::B_GBE, 512);
+        {
+            const float* w = S(p + "conv_glu.fc1.weight");        // (64, 16, 1, 1) -> [d][o]
+            for (int o = 0; o < 64; ++o) for (int d = 0; d < 16; ++d) buf[D + P::B_F1W + d * 64 + o] = w[o * 16 + d];
+            copy(p + "conv_glu.fc1.bias", D + P::B_F1B, 64);
+            const float* dw = S(p + "conv_glu.dwconv.weight");    // (32, 1, 3, 3) -> [(dt*3 + df)][ch]
+            for (int c = 0; c < 32; ++c) for (int j = 0; j < 9; ++j) buf[D + P::B_DW + j * 32 + c] = dw[c * 9 + j];
+            copy(p + "conv_glu.dwconv.bias", D + P::B_DWB, 32);
+            const float* w2 = S(p + "conv_glu.fc2.weight");       // (16, 32, 1, 1) -> [ch][d]
+            for (int d = 0; d < 16; ++d) for (int c = 0; c < 32; ++c) buf[D + P::B_F2W + c * 16 + d] = w2[d * 32 + c];
+            copy(p + "conv_glu.fc2.bias", D + P::B_F2B, 16);
+        }
+    }
+    conv("decoder.up1.low_conv", 12, 32, 1, 3, P::U1_LO, P::U1_BL);
+    conv("decoder.up1.high_conv.conv", 36, 32, 1, 3, P::U1_HI, P::U1_BH);
+    conv("decoder.up2.low_conv", 8, 24, 1, 3, P::U2_LO, P::U2_BL);
+    conv("decoder.up2.high_conv.conv", 24, 24, 1, 3, P::U2_HI, P::U2_BH);
+    conv("decoder.up3.low_conv", 4, 16, 1, 3, P::U3_LO, P::U3_BL);
+    conv("decoder.up3.high_conv.conv", 12, 16, 1, 3, P::U3_HI, P::U3_BH);
+    conv("decoder.mask_conv.0", 2, 4, 2, 2, P::M0_W, P::M0_B);
+    copy("decoder.mask_conv.1.gamma", P::M_G, 257);
+    copy("decoder.mask_conv.1.beta", P::M_BE, 257);
+    copy("decoder.mask_conv.2.weight", P::M_P, 2);
+    {
+        const float* w = S("decoder.mask_conv.3.weight");          // (2, 2, 1, 1) -> [c][o]
+        for (int o = 0; o < 2; ++o) for (int c = 0; c < 2; ++c) buf[P::M3_W + c * 2 + o] = w[o * 2 + c];
+        copy("decoder.mask_conv.3.bias", P::M3_B, 2);
+        copy("decoder.lsigmoid.slope", P::SLOPE, 257);
+    }
+    *out = std::move(buf);
+    return FE_OK;
+}
+
+fe::LArgs lisennet_args(fe_handle* h, int B, int T) {
+    fe::LArgs a{};
+    a.wp = h->packed_dev;
+    a.B = B;
+    a.T = T;
+    a.compression = h->cfg.input_compression;
+    return a;
+}
+
+int launch_lisennet(fe_handle* h, const fe::LArgs& a, void* stream) {
+    hipError_t e = hipSuccess;
+    h->limpl->launch(a, h->max_wgs, (hipStream_t)stream, &e);
+    if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return FE_OK;
+}
+
 size_t bsrnn_lstm_floats(const fe_handle* h, int B) { return (size_t)2 * h->cfg.rf_blocks * B * 31 * 2 * h->cfg.channels; }
 
 fe::BArgs bsrnn_args(fe_handle* h, int B, int T) {
@@ -833,7 +1054,7 @@ int ensure_scratch(fe_handle* h, int) {
     // (BSRNN: band-LSTM input projections of the C = 64 shape; FastEnhancer: the larger of the shape's own plan and its
     // low-LDS companion's, which runs two workgroups per CU)
     size_t floats = 0;
-    if (h->fimpl) floats = 0;
+    if (h->fimpl || h->limpl) floats = 0;
     else if (h->bimpl) floats = (size_t)h->max_wgs * h->bimpl->xp_floats;
     else {
         floats = (size_t)h->max_wgs * h->impl->occ * h->impl->skip_floats;
@@ -870,6 +1091,7 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
     *out = nullptr;
     if (cfg->arch == FE_ARCH_BSRNN) return create_bsrnn(cfg, out);
     if (cfg->arch == FE_ARCH_FSPEN) return create_fspen(cfg, out);
+    if (cfg->arch == FE_ARCH_LISENNET) return create_lisennet(cfg, out);
     if (cfg->arch != FE_ARCH_FASTENHANCER)
         return fail(FE_ERR_UNSUPPORTED_CONFIG, "arch %d is not built into this library", cfg->arch);
     if (cfg->n_fft % 2 != 0) return fail(FE_ERR_INVALID_ARG, "`n_fft` must be an even number, but given %d.", cfg->n_fft);
@@ -948,7 +1170,7 @@ int fe_load_weights(fe_handle* h, const float* blob_dev, size_t nfloats, void* s
     FE_HIP_CHECK(hipMemcpyAsync(blob.data(), blob_dev, nfloats * sizeof(float), hipMemcpyDeviceToHost, st));
     FE_HIP_CHECK(hipStreamSynchronize(st));
     std::vector<float> packed;
-    int rc = h->fimpl ? pack_weights_fspen(h, blob, &packed) : (h->bimpl ? pack_weights_bsrnn(h, blob, &packed) : pack_weights(h, blob, &packed));
+    int rc = h->limpl ? pack_weights_lisennet(h, blob, &packed) : h->fimpl ? pack_weights_fspen(h, blob, &packed) : (h->bimpl ? pack_weights_bsrnn(h, blob, &packed) : pack_weights(h, blob, &packed));
     if (rc != FE_OK) return rc;
     if (h->packed_dev) { FE_HIP_CHECK(hipFree(h->packed_dev)); h->packed_dev = nullptr; }
     FE_HIP_CHECK(hipMalloc(&h->packed_dev, packed.size() * sizeof(float)));
@@ -963,12 +1185,13 @@ int fe_load_weights(fe_handle* h, const float* blob_dev, size_t nfloats, void* s
 // time_kernel variant: floats of the causal convs' frame caches per stream (2 NL layers x [KT-1][F1][C1])
 static size_t tk_floats(const fe_handle* h) {
     const Dims& d = h->d;
-    return (h->bimpl || h->fimpl) ? 0 : (size_t)2 * d.NL * (d.KT - 1) * d.F1 * d.C1;
+    return (h->bimpl || h->fimpl || h->limpl) ? 0 : (size_t)2 * d.NL * (d.KT - 1) * d.F1 * d.C1;
 }
 
 size_t fe_state_floats(const fe_handle* h, int B) {
     if (!h || B <= 0) return 0;
     const Dims& d = h->d;
+    if (h->limpl) return (size_t)B * (2 * (size_t)(d.NFFT - d.HOP) + h->limpl->cache_floats);
     if (h->fimpl) return (size_t)B * 2 * (size_t)(d.NFFT - d.HOP) + fspen_gru_floats(B);
     if (h->bimpl) return (size_t)B * 2 * (size_t)(d.NFFT - d.HOP) + bsrnn_lstm_floats(h, B);
     return (size_t)B * (2 * (size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2 + tk_floats(h));
@@ -988,6 +1211,17 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
     const Dims& d = h->d;
     if (in_stride < (size_t)T * d.HOP && B > 1) return fail(FE_ERR_INVALID_ARG, "in_stride %zu < T*H", in_stride);
     if (out_stride < (size_t)T * d.HOP && B > 1) return fail(FE_ERR_INVALID_ARG, "out_stride %zu < T*H", out_stride);
+    if (h->limpl) {
+        fe::LArgs la = lisennet_args(h, B, T);
+        la.clk = clk;
+        la.dbg = dbg;
+        la.dbg_stride = h->limpl->dbg_floats;
+        const size_t ovl_b = (size_t)(d.NFFT - d.HOP);
+        la.mode = fe::FE_MODE_STREAM;
+        la.wav_in = wav_in; la.wav_out = wav_out; la.in_stride = in_stride; la.out_stride = out_stride;
+        la.cache_stft = state; la.cache_istft = state + (size_t)B * ovl_b; la.cache = state + 2 * (size_t)B * ovl_b;
+        return launch_lisennet(h, la, stream);
+    }
     if (h->fimpl) {
         fe::FArgs fa = fspen_args(h, B, T);
         fa.clk = clk;
@@ -1081,6 +1315,12 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
     int rc = check_ready(h);
     if (rc != FE_OK) return rc;
     if (!spec_in_dev || !h_dev || !spec_out_dev || B <= 0 || T <= 0) return fail(FE_ERR_INVALID_ARG, "bad argument");
+    if (h->limpl) {
+        fe::LArgs la = lisennet_args(h, B, T);
+        la.mode = fe::FE_MODE_SPEC;
+        la.spec_in = spec_in_dev; la.spec_out = spec_out_dev; la.cache = h_dev;
+        return launch_lisennet(h, la, stream);
+    }
     if (h->fimpl) {
         fe::FArgs fa = fspen_args(h, B, T);
         fa.mode = fe::FE_MODE_SPEC;
@@ -1124,6 +1364,7 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
 size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw) {
     if (!h || B <= 0 || Tw <= 0) return 0;
     const Dims& d = h->d;
+    if (h->limpl) return (size_t)B * ((size_t)(d.NFFT - d.HOP) + h->limpl->cache_floats);
     if (h->fimpl) return (size_t)B * (size_t)(d.NFFT - d.HOP) + fspen_gru_floats(B);
     if (h->bimpl) return (size_t)B * (size_t)(d.NFFT - d.HOP) + bsrnn_lstm_floats(h, B);
     // GRU state (zero initial state, model.py:626-627) + overlap-add tail, both zeroed by fe_offline; time-pipelined
@@ -1146,9 +1387,20 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
     const int T = 1 + Tw / d.HOP;
     {   // zero the state, the tail and the frame counters (not the frames: every element is written)
         size_t nz = (size_t)B * ((size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2 + tk_floats(h));
-        if (h->bimpl || h->fimpl) nz = fe_offline_work_floats(h, B, Tw);
+        if (h->bimpl || h->fimpl || h->limpl) nz = fe_offline_work_floats(h, B, Tw);
         else if (pipe_width(h, B, T)) nz += ((size_t)B * d.KB + 3) & ~(size_t)3;
         FE_HIP_CHECK(hipMemsetAsync(work_dev, 0, nz * sizeof(float), st));
+    }
+    if (h->limpl) {
+        fe::LArgs la = lisennet_args(h, B, T);
+        la.mode = fe::FE_MODE_OFFLINE;
+        la.Tw = Tw;
+        la.wav_in = noisy_dev; la.in_stride = (size_t)Tw;
+        la.wav_out = wav_hat_dev; la.out_stride = (size_t)d.HOP * (T - 1);
+        la.spec_out = spec_hat_dev;
+        la.cache_istft = work_dev; la.cache_stft = work_dev;
+        la.cache = work_dev + (size_t)B * (d.NFFT - d.HOP);
+        return launch_lisennet(h, la, stream);
     }
     if (h->fimpl) {
         fe::FArgs fa = fspen_args(h, B, T);
@@ -1315,6 +1567,26 @@ int fe_istft_offline(fe_handle* h, const float* spec_in_dev, int B, int T, int F
 double fe_flops_per_frame(const fe_handle* h) {
     if (!h) return 0.0;
     const Dims& d = h->d;
+    if (h->limpl) {   // models/lisennet/macs.py:8-66 with T = 1
+        const double C = 16, Nb = 2, F1 = 257;
+        double m = 3 * (C / 4) * F1;
+        const double co[3] = {C / 2, C / 4 * 3, C}, fi[3] = {257, 128, 64};
+        for (int i = 0; i < 3; ++i) {
+            const double f = fi[i], fq = std::floor(f / 4), fhi = std::floor((f - fq + 2 - 5) / 3) + 1;
+            m += (2 * 3 * fq + 2 * 5 * fhi) * co[i] * co[i];
+        }
+        auto gru = [](double i, double hd) { return (i + hd) * hd * 3 + hd * 3; };
+        const double hh = 24, ff = 32;
+        for (int b = 0; b < (int)Nb; ++b) {
+            m += (gru(C, hh / 2) * 2 + hh * C + gru(C, hh) + hh * C) * ff;
+            m += (C * C * 4 + C * 2 * 3 + C * 2 + C * 2 * C) * ff;
+        }
+        double c_in = C, f = 32, c_out = 0;
+        for (double c_o : {C / 4 * 3, C / 2, C / 4}) { c_out = c_o; m += (3 * (f / 2) + 3 * 3 * (f / 2)) * c_in * 2 * c_out; c_in = c_out; f *= 2; }
+        f += 1;
+        m += (c_out * 2 * 2 * 2 + 2 * 2 + 2 * 2) * f;
+        return 2.0 * m + 2.0 * 2.5 * d.NFFT * std::log2((double)d.NFFT);
+    }
     if (h->fimpl) {   // models/fspen/macs.py:36-141 with T = 1 (switches as committed: conv output lengths, no BN / LN / bias terms)
         const double C1[3] = {4, 16, 32}, K[3] = {6, 8, 6}, C2 = 16;
         double F = 257, m = 0;
@@ -1347,12 +1619,24 @@ double fe_flops_per_frame(const fe_handle* h) {
     return 2.0 * m + 2.0 * 2.5 * d.NFFT * std::log2((double)d.NFFT);
 }
 
-int fe_debug_stages(const fe_handle* h) { return !h ? 0 : h->fimpl ? h->fimpl->dbg_stages : (h->bimpl ? h->bimpl->dbg_stages : (h->impl ? h->impl->dbg_stages : 0)); }
-size_t fe_debug_floats(const fe_handle* h) { return !h ? 0 : h->fimpl ? h->fimpl->dbg_floats : (h->bimpl ? h->bimpl->dbg_floats : (h->impl ? h->impl->dbg_floats : 0)); }
+int fe_debug_stages(const fe_handle* h) { return !h ? 0 : h->limpl ? h->limpl->dbg_stages : h->fimpl ? h->fimpl->dbg_stages : (h->bimpl ? h->bimpl->dbg_stages : (h->impl ? h->impl->dbg_stages : 0)); }
+size_t fe_debug_floats(const fe_handle* h) { return !h ? 0 : h->limpl ? h->limpl->dbg_floats : h->fimpl ? h->fimpl->dbg_floats : (h->bimpl ? h->bimpl->dbg_floats : (h->impl ? h->impl->dbg_floats : 0)); }
 
 int fe_debug_stage(const fe_handle* h, int idx, const char** name, int* rows, int* cols, size_t* offset_floats) {
     if (!h || idx < 0 || idx >= fe_debug_stages(h)) return fail(FE_ERR_INVALID_ARG, "stage index %d", idx);
     static thread_local std::string nm;
+    if (h->limpl) {
+        static const char* const names[16] = {"spec_in", "compressed", "features", "encoder.conv_1", "encoder.conv_2", "encoder.conv_3", "encoder.conv_4",
+                                              "blocks.0.intra", "blocks.0.inter", "blocks.0", "blocks.1.intra", "blocks.1.inter", "blocks.1",
+                                              "decoder.up3", "mask", "spec_out"};
+        int r, c; size_t off;
+        h->limpl->dbg_stage(idx, &r, &c, &off);
+        if (name) *name = names[idx];
+        if (rows) *rows = r;
+        if (cols) *cols = c;
+        if (offset_floats) *offset_floats = off;
+        return FE_OK;
+    }
     if (h->fimpl) {
         static const char* const names[16] = {"spec_in", "compressed", "subband_encoder", "fullband_encoder.2", "feature_merge", "dpe.0.intra",
                                               "dpe.0.inter", "dpe.1.intra", "dpe.1.inter", "dpe.2.intra", "dpe.2.inter", "feature_split",

@@ -1,0 +1,785 @@
+// lisennet_kernels.hip.h — the LiSenNet baseline model (models/lisennet/model.py of the reference, configs/others/lisennet.yaml) as
+// one fused per-frame kernel for gfx950: STFT -> compress -> magnitude / group-delay / instantaneous-frequency-deviation features
+// -> encoder (1x1 + three causal two-frame DSConvs, each with a (channel, freq) LayerNorm and PReLU) -> 2 x DPR (LayerNorm,
+// bidirectional GRU over the 32 sub-bands, LayerNorm, GRU over time, ConvolutionalGLU with a causal three-frame depthwise conv and
+// Mish) -> MaskDecoder (three sub-pixel up-convolutions with skips, causal two-frame mask conv, LayerNorm, PReLU, learnable sigmoid)
+// -> complex mask -> un-compress -> iSTFT.  SURVEY.md §8(f) rank 4.
+//
+// Like FSPEN it is a tiny M = 1 model (one workgroup per stream, activations in LDS, VALU dot products over k-major packed
+// weights, a wave per direction for the intra GRU) - latency-bound, no MFMA.  The frame caches of the causal convs, the inter-GRU
+// states and the previous frame's phase are the model's caches, laid out per cache tensor as the reference's
+// (ONNXModel.initialize_cache, :380-396, sized for B streams).
+#pragma once
+#include "fspen_kernels.hip.h"
+
+namespace fe {
+
+template <int HOP_>
+struct LShape {
+    static constexpr int HOP = HOP_, NFFT = 512, LOG2N = 9, OVL = NFFT - HOP, BINS = 257;
+    static constexpr int C = 16, C1 = 4, C2 = 8, C3 = 12, NB = 2, HD = 24, HI = 12, NF = 32;     // channels, blocks, GRU sizes, sub-bands
+    // per-stream cache sizes in the order of the reference's cache list
+    static constexpr int K_PHA = 257, K_E2 = C1 * 257, K_E3 = C2 * 128, K_E4 = C3 * 64, K_H = NF * HD, K_GLU = 2 * C * 2 * NF, K_DEC = C1 * 256;
+    static constexpr int CACHE_FLOATS = K_PHA + K_E2 + K_E3 + K_E4 + NB * (K_H + K_GLU) + K_DEC;
+};
+
+// ---- packed weights (floats); conv weights k-major: [(c, dt, df)][out]
+struct LPk {
+    static constexpr int WINDOW = 0, WINDOW_I = 512, TW = 1024;
+    static constexpr int C1_W = 1536;                    // conv_1: [c < 3][4]
+    static constexpr int C1_B = C1_W + 12, C1_G = C1_B + 4, C1_BE = C1_G + 260, C1_P = C1_BE + 260;      // bias, gamma[257], beta[257], PReLU[4]
+    // DSConv i (cin -> cout, half = output bins per branch): low [(c*2+dt)*3+df][cout], high [(c*2+dt)*5+k][cout], biases, gamma / beta [2 half], PReLU
+    static constexpr int D2 = C1_P + 4;
+    static constexpr int D2_LO = D2, D2_HI = D2_LO + 4 * 6 * 8, D2_BL = D2_HI + 4 * 10 * 8, D2_BH = D2_BL + 8, D2_G = D2_BH + 8, D2_BE = D2_G + 128, D2_P = D2_BE + 128;
+    static constexpr int D3 = D2_P + 8;
+    static constexpr int D3_LO = D3, D3_HI = D3_LO + 8 * 6 * 12, D3_BL = D3_HI + 8 * 10 * 12, D3_BH = D3_BL + 12, D3_G = D3_BH + 12, D3_BE = D3_G + 64, D3_P = D3_BE + 64;
+    static constexpr int D4 = D3_P + 12;
+    static constexpr int D4_LO = D4, D4_HI = D4_LO + 12 * 6 * 16, D4_BL = D4_HI + 12 * 10 * 16, D4_BH = D4_BL + 16, D4_G = D4_BH + 16, D4_BE = D4_G + 32, D4_P = D4_BE + 32;
+    static constexpr int BLK = D4_P + 16;
+    // per DPR block
+    static constexpr int B_N1W = 0, B_N1B = 512;                                 // intra_norm [f][d]
+    static constexpr int B_IH = 1024;                                            // intra W_ih^T [dir][k < 16][36]
+    static constexpr int B_GB = B_IH + 2 * 16 * 36;                              // [dir][36]: b_ih + (b_hh for r, z)
+    static constexpr int B_HH = B_GB + 72;                                       // intra W_hh [dir][gate][k < 12][12 units]
+    static constexpr int B_HN = B_HH + 2 * 3 * 12 * 12;                          // [dir][12] b_hh of n
+    static constexpr int B_D1W = B_HN + 24, B_D1B = B_D1W + 24 * 16;             // intra dense^T [k < 24][16]
+    static constexpr int B_N2W = B_D1B + 16, B_N2B = B_N2W + 512;                // inter_norm
+    static constexpr int B_XIH = B_N2B + 512;                                    // inter W_ih^T [k < 16][72]
+    static constexpr int B_XHH = B_XIH + 16 * 72;                                // inter W_hh^T [k < 24][72]
+    static constexpr int B_XGB = B_XHH + 24 * 72, B_XHN = B_XGB + 72;            // [72], [24]
+    static constexpr int B_D2W = B_XHN + 24, B_D2B = B_D2W + 24 * 16;            // inter dense^T [k < 24][16]
+    static constexpr int B_GG = B_D2B + 16, B_GBE = B_GG + 512;                  // conv_glu norm gamma / beta [c][f]
+    static constexpr int B_F1W = B_GBE + 512, B_F1B = B_F1W + 16 * 64;           // fc1^T [d < 16][64]
+    static constexpr int B_DW = B_F1B + 64, B_DWB = B_DW + 9 * 32;               // dwconv [(dt*3+df)][32 ch]
+    static constexpr int B_F2W = B_DWB + 32, B_F2B = B_F2W + 32 * 16;            // fc2^T [ch < 32][16]
+    static constexpr int B_SIZE = (B_F2B + 16 + 3) / 4 * 4;
+    // decoder: USConv i (cin -> cout): low [(c*3+df)][cout], high [(c*3+df)][3*cout], biases
+    static constexpr int U1 = BLK + 2 * B_SIZE;
+    static constexpr int U1_LO = U1, U1_HI = U1_LO + 32 * 3 * 12, U1_BL = U1_HI + 32 * 3 * 36, U1_BH = U1_BL + 12;
+    static constexpr int U2 = U1_BH + 36;
+    static constexpr int U2_LO = U2, U2_HI = U2_LO + 24 * 3 * 8, U2_BL = U2_HI + 24 * 3 * 24, U2_BH = U2_BL + 8;
+    static constexpr int U3 = U2_BH + 24;
+    static constexpr int U3_LO = U3, U3_HI = U3_LO + 16 * 3 * 4, U3_BL = U3_HI + 16 * 3 * 12, U3_BH = U3_BL + 4;
+    static constexpr int M0_W = U3_BH + 12;                                      // mask_conv.0 [(c*2+dt)*2+df][2]
+    static constexpr int M0_B = M0_W + 32, M_G = M0_B + 2, M_BE = M_G + 260, M_P = M_BE + 260;
+    static constexpr int M3_W = M_P + 2, M3_B = M3_W + 4, SLOPE = M3_B + 2;       // mask_conv.3 [c][o], bias, lsigmoid slope [257]
+    static constexpr int TOTAL = (SLOPE + 260 + 3) / 4 * 4;
+};
+
+struct LArgs {
+    const float* wp;
+    const float* wav_in;
+    float* wav_out;
+    size_t in_stride, out_stride;
+    float* cache_stft;
+    float* cache_istft;
+    float* cache;             // the model caches, cache-major: [pha B x 257][enc2 B x 4 x 257][enc3 B x 8 x 128][enc4 B x 12 x 64]
+                              //   { [h B*32 x 24][glu B x 32 x 2 x 32] } x 2  [dec B x 4 x 256]
+    const float* spec_in;
+    float* spec_out;
+    float* dbg;
+    size_t dbg_stride;
+    int B, T, mode, Tw;
+    float compression;
+    unsigned long long* clk;
+};
+
+// debug stages: 0 spec_in [257][2], 1 compressed [257][2], 2 features [3][257], 3 encoder.conv_1 [4][257], 4 encoder.conv_2 [8][128],
+// 5 encoder.conv_3 [12][64], 6 encoder.conv_4 [16][32], 7+3b blocks.b.intra [32][16], 8+3b blocks.b.inter [32][16], 9+3b blocks.b [16][32],
+// 13 decoder.up3 [4][256], 14 mask [257][2], 15 spec_out [257][2]
+struct LDebugLayout {
+    static constexpr int n_stages = 16;
+    __host__ __device__ static constexpr int rows(int s) {
+        return (s <= 1 || s >= 14) ? 257 : s == 2 ? 3 : s == 3 ? 4 : s == 4 ? 8 : s == 5 ? 12 : s == 6 ? 16 : s == 13 ? 4 : ((s - 7) % 3 == 2 ? 16 : 32);
+    }
+    __host__ __device__ static constexpr int cols(int s) {
+        return (s <= 1 || s >= 14) ? 2 : (s == 2 || s == 3) ? 257 : s == 4 ? 128 : s == 5 ? 64 : s == 6 ? 32 : s == 13 ? 256 : ((s - 7) % 3 == 2 ? 32 : 16);
+    }
+    __host__ __device__ static constexpr size_t offset(int s) {
+        size_t o = 0;
+        for (int i = 0; i < s; ++i) o += (size_t)rows(i) * cols(i);
+        return o;
+    }
+    __host__ __device__ static constexpr size_t total() { return offset(n_stages); }
+};
+
+struct LLds {
+    static constexpr int SP = 0;                    // compressed spectrum [257][2]
+    static constexpr int TW = SP + 516;
+    static constexpr int X2 = TW + 512;             // encoder.conv_2 out [8][128]   (skip of up3)
+    static constexpr int X3 = X2 + 1024;            // encoder.conv_3 out [12][64]   (skip of up2)
+    static constexpr int X4 = X3 + 768;             // encoder.conv_4 out [16][32]   (skip of up1)
+    static constexpr int RED = X4 + 512;            // block-reduction slots [16]
+    static constexpr int SB = RED + 16;             // ---- phase scratch
+    static constexpr int FA = SB, FB = SB + 1024;
+    static constexpr int FEAT = SB + 2048;          // features [3][260]  /  phases [260] behind them
+    static constexpr int PHA = FEAT + 780;
+    static constexpr int X1 = SB;                   // conv_1 out, current frame [4][260] (after the FFT buffers are dead)
+    static constexpr int X1P = SB + 1040;           // previous frame (cache)
+    static constexpr int XP = SB + 3100;            // previous-frame copy of the current DSConv's input [<= 12 x 64 .. 8 x 128 = 1024]
+    static constexpr int Y = SB + 4200;             // DSConv pre-norm output [<= 1024]
+    // DPR blocks
+    static constexpr int XT = SB;                   // tokens [32 f][16 d]
+    static constexpr int YN = SB + 512;             // normalised tokens
+    static constexpr int GI = SB + 1024;            // intra input projections [2][32][36]
+    static constexpr int HSEQ = SB + 3328;          // [32][24]
+    static constexpr int HP = SB + 4096;            // inter GRU state [32][24]
+    static constexpr int HN = SB + 4864;
+    static constexpr int Z = SB + 512;              // conv_glu: normalised [16][32]  (aliases YN)
+    static constexpr int XX = SB + 1024;            // fc1 first half, three frames [3][32 ch][32 f]
+    static constexpr int V = SB + 4096;             // fc1 second half [32][32]
+    static constexpr int G = SB + 5120;             // gated [32][32]
+    static constexpr int YD = SB + 6144;            // block output [16 d][32 f]
+    // decoder
+    static constexpr int U1 = SB;                   // [12][64]
+    static constexpr int U2 = SB + 768;             // [8][128]
+    static constexpr int U3 = SB + 1792;            // [4][256]
+    static constexpr int U3P = SB + 2816;           // previous frame (cache) [4][256]
+    static constexpr int MY = SB + 3840;            // mask conv out [2][260]
+    static constexpr int MK = SB + 4360;            // mask [2][260]
+    static constexpr int TOTAL = SB + 6656;
+    static_assert(SB % 2 == 0 && TW % 2 == 0, "float2 alignment");
+    static_assert((size_t)TOTAL * 4 <= 64 * 1024, "static LDS");
+};
+
+__device__ __forceinline__ float mish_f(float x) {
+    const float sp_ = x > 20.0f ? x : log1pf(__expf(x));       // softplus (torch's threshold 20)
+    return x * tanh_f(sp_);
+}
+
+#define LS_CLK(i) do { if constexpr (PROF) { if (blockIdx.x == 0 && threadIdx.x == 0) a.clk[(i)] = __builtin_readcyclecounter(); } } while (0)
+
+template <class S, bool PROF, bool DBG>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(DBG ? 1 : 2, DBG ? 1 : 2))) lisennet_frame_kernel(LArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[LLds::TOTAL];
+    using L = LLds;
+    using P = LPk;
+    constexpr int N = S::NFFT, H = S::HOP, OVL = S::OVL, BINS = S::BINS;
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const float* __restrict__ wp0 = a.wp;
+    const int mode = a.mode, aT = a.T;
+    float* sp = smem + L::SP;
+    float2* tw = reinterpret_cast<float2*>(smem + L::TW);
+    float2* fa = reinterpret_cast<float2*>(smem + L::FA);
+    float2* fb = reinterpret_cast<float2*>(smem + L::FB);
+    float* x2 = smem + L::X2;
+    float* x3 = smem + L::X3;
+    float* x4 = smem + L::X4;
+    float* red = smem + L::RED;
+    for (int i = tid0; i < N / 2; i += kThreads) tw[i] = reinterpret_cast<const float2*>(wp0 + P::TW)[i];
+    __syncthreads();
+
+    int b = blockIdx.x;
+#pragma unroll 1
+    do {
+    float* dbg = DBG ? a.dbg + (size_t)b * a.dbg_stride : nullptr;
+    auto dump = [&](int stage, auto&& f) {
+        if constexpr (DBG) {
+            const int rows = LDebugLayout::rows(stage), cols = LDebugLayout::cols(stage);
+            float* dst = dbg + LDebugLayout::offset(stage);
+            for (int i = tid0; i < rows * cols; i += kThreads) { const int r = i / cols, c = i - r * cols; dst[i] = f(r, c); }
+        }
+    };
+    // per-stream cache pointers (cache-major state)
+    auto cache_ptr = [&](int off_floats_per_stream_sum, int per_stream) -> float* {
+        return a.cache + (size_t)off_floats_per_stream_sum * a.B + (size_t)b * per_stream;
+    };
+
+#pragma unroll 1
+    for (int t = 0; t < aT; ++t) {
+        // loop-variant zeros on the weight pointer and the thread index (see fspen_kernels.hip.h)
+        int lz = 0, lzv = 0;
+        asm volatile("" : "+s"(lz));
+        asm volatile("" : "+v"(lzv));
+        const float* __restrict__ wp = wp0 + lz;
+        const int tid = tid0 + lzv;
+        const int lane = tid & 63;
+        int red_slot = 0;
+        // sum over the workgroup (every thread gets it); two alternating slot sets, one barrier per call
+        auto block_sum = [&](float v) -> float {
+            v = wave_sum(v);
+            float* r = red + 4 * red_slot;
+            if (lane == 0) r[wave] = v;
+            __syncthreads();
+            red_slot ^= 1;
+            return (r[0] + r[1]) + (r[2] + r[3]);
+        };
+        // LayerNorm statistics over n values, each thread contributing `cnt` values v[]: returns (mean, 1 / sqrt(var + eps)), two-pass
+        auto ln_stats = [&](const float* v, int cnt, float inv_n, float& mean, float& rstd) {
+            float s_ = 0.0f;
+            for (int i = 0; i < cnt; ++i) s_ += v[i];
+            mean = block_sum(s_) * inv_n;
+            float q_ = 0.0f;
+            for (int i = 0; i < cnt; ++i) { const float d = v[i] - mean; q_ = fmaf(d, d, q_); }
+            rstd = 1.0f / sqrtf(block_sum(q_) * inv_n + 1.0e-5f);
+        };
+
+        LS_CLK(0);
+        // ============================ STFT + compress + phase features (models/lisennet/model.py:441-456 / :512-524) ============================
+        float* feat = smem + L::FEAT;
+        float* phs = smem + L::PHA;
+        if (mode != FE_MODE_SPEC) {
+            const float* win = wp + P::WINDOW;
+            float* cst = a.cache_stft + (size_t)b * OVL;
+            if (mode == FE_MODE_STREAM) {
+                const float* xin = a.wav_in + (size_t)b * a.in_stride + (size_t)t * H;
+                for (int n = tid; n < N; n += kThreads) {
+                    const float v = (n < OVL) ? cst[n] : xin[n - OVL];
+                    fb[n] = make_float2(v, 0.0f);
+                    fa[n] = make_float2(v * win[n], 0.0f);
+                }
+            } else {
+                const float* xin = a.wav_in + (size_t)b * a.in_stride;
+                for (int n = tid; n < N; n += kThreads) {
+                    int idx = t * H + n - N / 2;
+                    idx = idx < 0 ? -idx : idx;
+                    idx = idx >= a.Tw ? 2 * (a.Tw - 1) - idx : idx;
+                    fa[n] = make_float2(xin[idx] * win[n], 0.0f);
+                }
+            }
+            __syncthreads();
+            if (mode == FE_MODE_STREAM) {
+                for (int m = tid; m < OVL; m += kThreads) cst[m] = fb[m + H].x;
+                __syncthreads();
+            }
+            float2* Xf = fft_lds<S, false>(fa, fb, tw);
+            if constexpr (DBG) { for (int f = tid; f < BINS; f += kThreads) { dbg[2 * f] = Xf[f].x; dbg[2 * f + 1] = Xf[f].y; } }
+            for (int f = tid; f < BINS; f += kThreads) {
+                float re = Xf[f].x + 0.0f, im = Xf[f].y + 0.0f;           // (+ 0.0f: a -0.0 would turn atan2(0, -0.0) into pi)
+                const float g = pow_f(fmaxf(sqrtf(re * re + im * im), 1.0e-5f), a.compression - 1.0f);
+                re *= g; im *= g;
+                sp[2 * f] = re; sp[2 * f + 1] = im;
+            }
+        } else {
+            const float* si = a.spec_in + (size_t)b * BINS * aT * 2;
+            for (int f = tid; f < BINS; f += kThreads) {
+                float re = si[((size_t)f * aT + t) * 2], im = si[((size_t)f * aT + t) * 2 + 1];
+                if constexpr (DBG) { dbg[2 * f] = re; dbg[2 * f + 1] = im; }
+                const float g = pow_f(fmaxf(sqrtf(re * re + im * im), 1.0e-5f), a.compression - 1.0f);
+                re *= g; im *= g;
+                sp[2 * f] = re; sp[2 * f + 1] = im;
+            }
+        }
+        __syncthreads();
+        dump(1, [&](int r, int c) { return sp[2 * r + c]; });
+        {
+            float* cpha = cache_ptr(0, S::K_PHA);
+            // offline: the previous frame's phase of frame 0 is the prepended zero (torch.diff(prepend = 0), :506-507); the work buffer is zeroed
+            for (int f = tid; f < BINS; f += kThreads) phs[f] = atan2f(sp[2 * f + 1], sp[2 * f]);
+            __syncthreads();
+            const float sgn = mode == FE_MODE_OFFLINE ? 1.0f : -1.0f;        // Model: current - previous (torch.diff); ONNXModel: previous - current
+            constexpr float kInvPi = 0.31830988618379067f;
+            for (int f = tid; f < BINS; f += kThreads) {
+                const float re = sp[2 * f], im = sp[2 * f + 1], ph = phs[f];
+                const float dgd = sgn * (ph - (f > 0 ? phs[f - 1] : 0.0f));
+                const float dif = sgn * (ph - cpha[f]) - 6.283185307179586f * ((float)H / (float)N) * (float)f;
+                feat[f] = sqrtf(re * re + im * im);
+                feat[260 + f] = atan2f(sinf(dgd), cosf(dgd)) * kInvPi;
+                feat[520 + f] = atan2f(sinf(dif), cosf(dif)) * kInvPi;
+                cpha[f] = ph;
+            }
+        }
+        __syncthreads();
+        dump(2, [&](int r, int c) { return feat[r * 260 + c]; });
+
+        LS_CLK(1);
+        // ============================ encoder (Encoder.forward, :269-274) ============================
+        float* x1 = smem + L::X1;
+        float* x1p = smem + L::X1P;
+        {   // conv_1: 1x1 (3 -> 4), LayerNorm over (channel, freq) with a per-frequency affine, PReLU   (FFT buffers are dead: x1 aliases them)
+            float v[5];
+            int cnt = 0;
+            for (int i = tid; i < 4 * BINS; i += kThreads, ++cnt) {
+                const int o = i / BINS, f = i - o * BINS;
+                float acc = wp[P::C1_B + o];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc = fmaf(wp[P::C1_W + c * 4 + o], feat[c * 260 + f], acc);
+                v[cnt] = acc;
+            }
+            float mean, rstd;
+            ln_stats(v, cnt, 1.0f / (4.0f * BINS), mean, rstd);
+            float* c2 = cache_ptr(S::K_PHA, S::K_E2);
+            cnt = 0;
+            for (int i = tid; i < 4 * BINS; i += kThreads, ++cnt) {
+                const int o = i / BINS, f = i - o * BINS;
+                float y = (v[cnt] - mean) * rstd * wp[P::C1_G + f] + wp[P::C1_BE + f];
+                y = y >= 0.0f ? y : y * wp[P::C1_P + o];
+                x1p[o * 260 + f] = c2[i];           // previous frame (the cache) in, this frame out
+                c2[i] = y;
+                x1[o * 260 + f] = y;
+            }
+        }
+        __syncthreads();
+        dump(3, [&](int r, int c) { return x1[r * 260 + c]; });
+        // DSConv (:190-208): causal two-frame conv, the bins split into a low quarter (k 3, stride 1) and the rest (k 5, stride 3), both
+        // zero padded by one bin AFTER the split; LayerNorm over (channel, freq), per-frequency affine, PReLU
+        auto dsconv = [&](auto CIN_, auto COUT_, auto FIN_, const float* cur, const float* prev, int ld_in, float* out, float* cache_io, float* prev_out,
+                          int w_lo, int w_hi, int b_lo, int b_hi, int g_, int be_, int p_) {
+            constexpr int CIN = decltype(CIN_)::value, COUT = decltype(COUT_)::value, FIN = decltype(FIN_)::value;
+            constexpr int LOWF = FIN / 4, HALF = LOWF, FO = 2 * HALF, NOUT = COUT * FO, PER = (NOUT + kThreads - 1) / kThreads;
+            float v[PER];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int i = tid + q * kThreads;
+                const int o = i % COUT, f = i / COUT;            // consecutive threads: consecutive output channels (weights coalesced)
+                float acc = 0.0f;
+                if (i < NOUT) {
+                    if (f < HALF) {
+                        acc = wp[b_lo + o];
+                        for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                            for (int df = 0; df < 3; ++df) {
+                                const int fi = f + df - 1;
+                                const bool ok = fi >= 0 && fi < LOWF;
+                                const int fc = ok ? fi : 0;
+                                const float w0 = wp[w_lo + ((c * 2 + 0) * 3 + df) * COUT + o], w1 = wp[w_lo + ((c * 2 + 1) * 3 + df) * COUT + o];
+                                const float s_ = fmaf(w0, prev[c * ld_in + fc], w1 * cur[c * ld_in + fc]);
+                                acc += ok ? s_ : 0.0f;
+                            }
+                    } else {
+                        const int j = f - HALF;
+                        acc = wp[b_hi + o];
+                        for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                            for (int k = 0; k < 5; ++k) {
+                                const int fi = 3 * j + k - 1;                 // index into the high slice [LOWF, FIN)
+                                const bool ok = fi >= 0 && fi < FIN - LOWF;
+                                const int fc = LOWF + (ok ? fi : 0);
+                                const float w0 = wp[w_hi + ((c * 2 + 0) * 5 + k) * COUT + o], w1 = wp[w_hi + ((c * 2 + 1) * 5 + k) * COUT + o];
+                                const float s_ = fmaf(w0, prev[c * ld_in + fc], w1 * cur[c * ld_in + fc]);
+                                acc += ok ? s_ : 0.0f;
+                            }
+                    }
+                }
+                v[q] = acc;
+            }
+            float mean, rstd;
+            ln_stats(v, PER, 1.0f / (float)NOUT, mean, rstd);          // (threads past NOUT contribute zeros: corrected below)
+            constexpr int PADN = PER * kThreads - NOUT;                  // zero contributions: mean is exact, the variance needs - PADN * mean^2
+            if constexpr (PADN > 0) {
+                const float var = 1.0f / (rstd * rstd) - 1.0e-5f - (float)PADN / (float)NOUT * mean * mean;
+                rstd = 1.0f / sqrtf(var + 1.0e-5f);
+            }
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int i = tid + q * kThreads;
+                if (i < NOUT) {
+                    const int o = i % COUT, f = i / COUT;
+                    float y = (v[q] - mean) * rstd * wp[g_ + f] + wp[be_ + f];
+                    y = y >= 0.0f ? y : y * wp[p_ + o];
+                    out[o * FO + f] = y;
+                    if (cache_io) { prev_out[o * FO + f] = cache_io[o * FO + f]; cache_io[o * FO + f] = y; }
+                }
+            }
+            __syncthreads();
+        };
+        using I4 = std::integral_constant<int, 4>;
+        using I8 = std::integral_constant<int, 8>;
+        using I12 = std::integral_constant<int, 12>;
+        using I16 = std::integral_constant<int, 16>;
+        using I64 = std::integral_constant<int, 64>;
+        using I128 = std::integral_constant<int, 128>;
+        using I257 = std::integral_constant<int, 257>;
+        float* xp = smem + L::XP;
+        dsconv(I4{}, I8{}, I257{}, x1, x1p, 260, x2, cache_ptr(S::K_PHA + S::K_E2, S::K_E3), xp, P::D2_LO, P::D2_HI, P::D2_BL, P::D2_BH, P::D2_G, P::D2_BE, P::D2_P);
+        dump(4, [&](int r, int c) { return x2[r * 128 + c]; });
+        {
+            float* xq = smem + L::Y;       // previous frame of x3's input is in xp (x2's cache); x3's own cache lands in xq
+            dsconv(I8{}, I12{}, I128{}, x2, xp, 128, x3, cache_ptr(S::K_PHA + S::K_E2 + S::K_E3, S::K_E4), xq, P::D3_LO, P::D3_HI, P::D3_BL, P::D3_BH, P::D3_G, P::D3_BE, P::D3_P);
+            dump(5, [&](int r, int c) { return x3[r * 64 + c]; });
+            dsconv(I12{}, I16{}, I64{}, x3, xq, 64, x4, nullptr, nullptr, P::D4_LO, P::D4_HI, P::D4_BL, P::D4_BH, P::D4_G, P::D4_BE, P::D4_P);
+            dump(6, [&](int r, int c) { return x4[r * 32 + c]; });
+        }
+
+        LS_CLK(2);
+        // ============================ 2 x DPR (DPR.forward, :151-159) ============================
+        float* xt = smem + L::XT;
+        float* yn = smem + L::YN;
+        float* gi = smem + L::GI;
+        float* hseq = smem + L::HSEQ;
+        float* hp = smem + L::HP;
+        float* hn = smem + L::HN;
+        float* yd = smem + L::YD;
+        // tokens [f][d] of the block input (b, d, t, f) -> (b, t, f, d)
+        for (int q = 0; q < 2; ++q) { const int i = tid + 256 * q, f = i >> 4, d = i & 15; xt[i] = x4[d * 32 + f]; }
+        __syncthreads();
+        constexpr int OFF_BLK = S::K_PHA + S::K_E2 + S::K_E3 + S::K_E4;
+#pragma unroll 1
+        for (int blk = 0; blk < S::NB; ++blk) {
+            const float* wd = wp + P::BLK + blk * P::B_SIZE;
+            float* ch = cache_ptr(OFF_BLK + blk * (S::K_H + S::K_GLU), S::K_H);                  // [32][24] rows b*32 + f
+            float* cg = cache_ptr(OFF_BLK + blk * (S::K_H + S::K_GLU) + S::K_H, S::K_GLU);       // [32 ch][2][32 f]
+            // inter GRU state -> LDS (in flight across the intra path)
+            float hpre[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) hpre[q] = ch[tid + 256 * q];
+            // ---- intra_norm: nn.LayerNorm((32, 16)) over the whole token matrix
+            {
+                float v[2] = {xt[tid], xt[tid + 256]};
+                float mean, rstd;
+                ln_stats(v, 2, 1.0f / 512.0f, mean, rstd);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { const int i = tid + 256 * q; yn[i] = (v[q] - mean) * rstd * wd[P::B_N1W + i] + wd[P::B_N1B + i]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) hp[tid + 256 * q] = hpre[q];
+            __syncthreads();
+            // ---- intra GRU input projections gi[dir][f][36]
+            for (int i = tid; i < 2 * 32 * 36; i += kThreads) {
+                const int g36 = i % 36, f = (i / 36) & 31, d = i / (36 * 32);
+                float acc = wd[P::B_GB + d * 36 + g36];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc = fmaf(wd[P::B_IH + (d * 16 + k) * 36 + g36], yn[f * 16 + k], acc);
+                gi[i] = acc;
+            }
+            // recurrence weights (all waves fetch; waves 2, 3 a copy: no conditional definitions)
+            float wr[12], wz[12], wn[12];
+            {
+                const int c = (lane & 15) < 12 ? (lane & 15) : 0, dsel = wave & 1;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    wr[k] = wd[P::B_HH + ((dsel * 3 + 0) * 12 + k) * 12 + c];
+                    wz[k] = wd[P::B_HH + ((dsel * 3 + 1) * 12 + k) * 12 + c];
+                    wn[k] = wd[P::B_HH + ((dsel * 3 + 2) * 12 + k) * 12 + c];
+                }
+            }
+            const float bhn = wd[P::B_HN + (wave & 1) * 12 + ((lane & 15) < 12 ? (lane & 15) : 0)];
+            __syncthreads();
+            if (wave < 2) {
+                const int d = wave, c = (lane & 15) < 12 ? (lane & 15) : 0;
+                float h = 0.0f;
+                const float* gd = gi + d * 32 * 36;
+                int f = d ? 31 : 0;
+#pragma unroll 1
+                for (int s_ = 0; s_ < 32; ++s_) {
+                    const float g_r = gd[f * 36 + c], g_z = gd[f * 36 + 12 + c], g_n = gd[f * 36 + 24 + c];
+                    float ar = 0.0f, az = 0.0f, an = bhn;
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) {
+                        const float hk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, h), k));
+                        ar = fmaf(wr[k], hk, ar);
+                        az = fmaf(wz[k], hk, az);
+                        an = fmaf(wn[k], hk, an);
+                    }
+                    const float r = sigmoid_f(g_r + ar);
+                    const float z = sigmoid_f(g_z + az);
+                    const float n = tanh_f(g_n + r * an);
+                    h = (1.0f - z) * n + z * h;
+                    if (lane < 12) hseq[f * 24 + d * 12 + c] = h;
+                    f += d ? -1 : 1;
+                }
+            }
+            __syncthreads();
+            // ---- intra dense (24 -> 16) + residual
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int i = tid + 256 * q, f = i >> 4, d = i & 15;
+                float acc = wd[P::B_D1B + d];
+#pragma unroll
+                for (int k = 0; k < 24; ++k) acc = fmaf(wd[P::B_D1W + k * 16 + d], hseq[f * 24 + k], acc);
+                xt[i] += acc;
+            }
+            __syncthreads();
+            dump(7 + 3 * blk, [&](int r, int c) { return xt[r * 16 + c]; });
+            // ---- inter_norm + inter GRU over time (one step; state [32][24]) + dense + residual
+            {
+                float v[2] = {xt[tid], xt[tid + 256]};
+                float mean, rstd;
+                ln_stats(v, 2, 1.0f / 512.0f, mean, rstd);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { const int i = tid + 256 * q; yn[i] = (v[q] - mean) * rstd * wd[P::B_N2W + i] + wd[P::B_N2B + i]; }
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int q = 0; q < 3; ++q) {
+                const int i = tid + 256 * q, f = i / 24, c = i - f * 24;
+                float ir = wd[P::B_XGB + c], iz = wd[P::B_XGB + 24 + c], in_ = wd[P::B_XGB + 48 + c];
+                float hr = 0.0f, hz = 0.0f, hnn = wd[P::B_XHN + c];
+#pragma unroll 4
+                for (int k = 0; k < 16; ++k) {
+                    const float xv = yn[f * 16 + k];
+                    ir = fmaf(wd[P::B_XIH + k * 72 + c], xv, ir);
+                    iz = fmaf(wd[P::B_XIH + k * 72 + 24 + c], xv, iz);
+                    in_ = fmaf(wd[P::B_XIH + k * 72 + 48 + c], xv, in_);
+                }
+#pragma unroll 4
+                for (int k = 0; k < 24; ++k) {
+                    const float hv = hp[f * 24 + k];
+                    hr = fmaf(wd[P::B_XHH + k * 72 + c], hv, hr);
+                    hz = fmaf(wd[P::B_XHH + k * 72 + 24 + c], hv, hz);
+                    hnn = fmaf(wd[P::B_XHH + k * 72 + 48 + c], hv, hnn);
+                }
+                const float r = sigmoid_f(ir + hr);
+                const float z = sigmoid_f(iz + hz);
+                const float n = tanh_f(in_ + r * hnn);
+                const float hnew = (1.0f - z) * n + z * hp[i];
+                hn[i] = hnew;
+                ch[i] = hnew;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int i = tid + 256 * q, f = i >> 4, d = i & 15;
+                float acc = wd[P::B_D2B + d];
+#pragma unroll
+                for (int k = 0; k < 24; ++k) acc = fmaf(wd[P::B_D2W + k * 16 + d], hn[f * 24 + k], acc);
+                xt[i] += acc;
+            }
+            __syncthreads();
+            dump(8 + 3 * blk, [&](int r, int c) { return xt[r * 16 + c]; });
+            // ---- ConvolutionalGLU (:120-136) on (b, d, t, f): CustomLayerNorm over (d, f) with gamma / beta [d][f]
+            float* z = smem + L::Z;
+            float* xx = smem + L::XX;
+            float* vv = smem + L::V;
+            float* gg = smem + L::G;
+            {
+                float v[2] = {xt[tid], xt[tid + 256]};
+                float mean, rstd;
+                ln_stats(v, 2, 1.0f / 512.0f, mean, rstd);
+                // the previous two frames of fc1's first half (the cache) -> xx[0], xx[1]; in flight across fc1
+                float cpre[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) cpre[q] = cg[tid + 256 * q];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int i = tid + 256 * q, f = i >> 4, d = i & 15;
+                    z[d * 32 + f] = (v[q] - mean) * rstd * wd[P::B_GG + d * 32 + f] + wd[P::B_GBE + d * 32 + f];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const int i = tid + 256 * q, chn = i >> 6, dt = (i >> 5) & 1, f = i & 31; xx[(dt * 32 + chn) * 32 + f] = cpre[q]; }
+            }
+            __syncthreads();
+            // fc1: 1x1 (16 -> 64): channels 0..31 -> xx[2] (and the new cache), 32..63 -> v
+#pragma unroll 1
+            for (int q = 0; q < 8; ++q) {
+                const int i = tid + 256 * q, o = i & 63, f = i >> 6;
+                float acc = wd[P::B_F1B + o];
+#pragma unroll
+                for (int d = 0; d < 16; ++d) acc = fmaf(wd[P::B_F1W + d * 64 + o], z[d * 32 + f], acc);
+                if (o < 32) xx[(64 + o) * 32 + f] = acc; else vv[(o - 32) * 32 + f] = acc;
+            }
+            __syncthreads();
+            // new cache = frames (t-1, t); depthwise 3 x 3 over (time, freq), Mish, gate
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                const int i = tid + 256 * q, chn = i >> 5, f = i & 31;
+                float acc = wd[P::B_DWB + chn];
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                    for (int df = 0; df < 3; ++df) {
+                        const int fi = f + df - 1;
+                        const bool ok = fi >= 0 && fi < 32;
+                        const float xv = xx[(dt * 32 + chn) * 32 + (ok ? fi : 0)];
+                        acc = fmaf(wd[P::B_DW + (dt * 3 + df) * 32 + chn], ok ? xv : 0.0f, acc);
+                    }
+                gg[i] = mish_f(acc) * vv[i];
+                cg[(chn * 2 + 0) * 32 + f] = xx[(32 + chn) * 32 + f];
+                cg[(chn * 2 + 1) * 32 + f] = xx[(64 + chn) * 32 + f];
+            }
+            __syncthreads();
+            // fc2: 1x1 (32 -> 16) + residual -> block output (b, d, t, f) and the next block's tokens
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int i = tid + 256 * q, f = i >> 4, d = i & 15;
+                float acc = wd[P::B_F2B + d];
+#pragma unroll 8
+                for (int c = 0; c < 32; ++c) acc = fmaf(wd[P::B_F2W + c * 16 + d], gg[c * 32 + f], acc);
+                acc += xt[i];
+                xt[i] = acc;
+                yd[d * 32 + f] = acc;
+            }
+            __syncthreads();
+            dump(9 + 3 * blk, [&](int r, int c) { return yd[r * 32 + c]; });
+        }
+
+        LS_CLK(3);
+        // ============================ MaskDecoder (:295-309) ============================
+        // USConv (:218-226): input = cat(x, skip) over channels; low half of the bins: conv k 3; high half: conv k 3 to 3 x cout
+        // channels, pixel-shuffled over frequency (SPConvTranspose2d, :240-246): out[c][3 w + r] = conv[r * cout + c][w]
+        auto usconv = [&](auto CX_, auto COUT_, auto FIN_, const float* xa, const float* skip, float* out, int w_lo, int w_hi, int b_lo, int b_hi) {
+            constexpr int CX = decltype(CX_)::value, COUT = decltype(COUT_)::value, FIN = decltype(FIN_)::value;
+            constexpr int LOWF = FIN / 2, FO = LOWF + 3 * LOWF, NOUT = COUT * FO, CIN = 2 * CX;
+            for (int i = tid; i < NOUT; i += kThreads) {
+                const int c = i % COUT, fo = i / COUT;
+                const bool low = fo < LOWF;
+                const int w = low ? fo : (fo - LOWF) / 3, r = low ? 0 : (fo - LOWF) - 3 * w;
+                const int oc = low ? c : r * COUT + c, nout = low ? COUT : 3 * COUT;
+                const int wofs = low ? w_lo : w_hi, base = low ? 0 : LOWF;
+                float acc = wp[(low ? b_lo : b_hi) + oc];
+#pragma unroll 1
+                for (int ci = 0; ci < CIN; ++ci) {
+                    const float* src = ci < CX ? xa + ci * FIN : skip + (ci - CX) * FIN;
+#pragma unroll
+                    for (int df = 0; df < 3; ++df) {
+                        const int fi = w + df - 1;
+                        const bool ok = fi >= 0 && fi < LOWF;
+                        const float xv = src[base + (ok ? fi : 0)];
+                        acc = fmaf(wp[wofs + (ci * 3 + df) * nout + oc], ok ? xv : 0.0f, acc);
+                    }
+                }
+                out[c * FO + fo] = acc;
+            }
+            __syncthreads();
+        };
+        float* u1 = smem + L::U1;
+        float* u2 = smem + L::U2;
+        float* u3 = smem + L::U3;
+        float* u3p = smem + L::U3P;
+        {   // yd lives at SB + 6144: u1 / u2 / u3 below it
+            using I32 = std::integral_constant<int, 32>;
+            usconv(I16{}, I12{}, I32{}, yd, x4, u1, P::U1_LO, P::U1_HI, P::U1_BL, P::U1_BH);
+            usconv(I12{}, I8{}, I64{}, u1, x3, u2, P::U2_LO, P::U2_HI, P::U2_BL, P::U2_BH);
+            usconv(I8{}, I4{}, I128{}, u2, x2, u3, P::U3_LO, P::U3_HI, P::U3_BL, P::U3_BH);
+        }
+        dump(13, [&](int r, int c) { return u3[r * 256 + c]; });
+        float* my = smem + L::MY;
+        float* mk = smem + L::MK;
+        {
+            float* cd = cache_ptr(OFF_BLK + S::NB * (S::K_H + S::K_GLU), S::K_DEC);
+            for (int i = tid; i < 4 * 256; i += kThreads) { u3p[i] = cd[i]; cd[i] = u3[i]; }
+            __syncthreads();
+            // mask_conv.0: Conv2d(4 -> 2, (2, 2), padding (0, 1)) over (previous, current) frame: 257 output bins
+            float v[3];
+            int cnt = 0;
+            for (int i = tid; i < 2 * BINS; i += kThreads, ++cnt) {
+                const int o = i & 1, f = i >> 1;
+                float acc = wp[P::M0_B + o];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int df = 0; df < 2; ++df) {
+                        const int fi = f + df - 1;
+                        const bool ok = fi >= 0 && fi < 256;
+                        const int fc = ok ? fi : 0;
+                        const float s_ = fmaf(wp[P::M0_W + ((c * 2 + 0) * 2 + df) * 2 + o], u3p[c * 256 + fc], wp[P::M0_W + ((c * 2 + 1) * 2 + df) * 2 + o] * u3[c * 256 + fc]);
+                        acc += ok ? s_ : 0.0f;
+                    }
+                v[cnt] = acc;
+            }
+            float mean, rstd;
+            ln_stats(v, cnt, 1.0f / (2.0f * BINS), mean, rstd);
+            cnt = 0;
+            for (int i = tid; i < 2 * BINS; i += kThreads, ++cnt) {
+                const int o = i & 1, f = i >> 1;
+                float y = (v[cnt] - mean) * rstd * wp[P::M_G + f] + wp[P::M_BE + f];
+                my[o * 260 + f] = y >= 0.0f ? y : y * wp[P::M_P + o];
+            }
+            __syncthreads();
+            for (int i = tid; i < 2 * BINS; i += kThreads) {
+                const int o = i & 1, f = i >> 1;
+                const float y = wp[P::M3_B + o] + wp[P::M3_W + 0 * 2 + o] * my[f] + wp[P::M3_W + 1 * 2 + o] * my[260 + f];
+                mk[o * 260 + f] = sigmoid_f(wp[P::SLOPE + f] * y);
+            }
+            __syncthreads();
+        }
+        dump(14, [&](int r, int c) { return mk[c * 260 + r]; });
+
+        LS_CLK(4);
+        // ============================ mask, un-compress, iSTFT ============================
+        {
+            float* spo = mode == FE_MODE_STREAM ? nullptr : a.spec_out + (size_t)b * BINS * aT * 2;
+            for (int f = tid; f < BINS; f += kThreads) {
+                const float sr = sp[2 * f], si = sp[2 * f + 1], mr = mk[f], mi = mk[260 + f];
+                float yr = sr * mr - si * mi, yi = sr * mi + si * mr;
+                if (mode == FE_MODE_OFFLINE) {          // Model.forward returns the compressed spec_hat
+                    spo[((size_t)f * aT + t) * 2] = yr;
+                    spo[((size_t)f * aT + t) * 2 + 1] = yi;
+                }
+                const float g = pow_f(sqrtf(yr * yr + yi * yi), 1.0f / a.compression - 1.0f);
+                yr *= g; yi *= g;
+                if constexpr (DBG) { float* d = dbg + LDebugLayout::offset(15); d[2 * f] = yr; d[2 * f + 1] = yi; }
+                if (mode == FE_MODE_SPEC) {
+                    spo[((size_t)f * aT + t) * 2] = yr;
+                    spo[((size_t)f * aT + t) * 2 + 1] = yi;
+                } else if (f == 0) {
+                    fa[0] = make_float2(yr, 0.0f);
+                } else if (f == N / 2) {
+                    fa[N / 2] = make_float2(yr, 0.0f);
+                } else {
+                    fa[f] = make_float2(yr, yi);
+                    fa[N - f] = make_float2(yr, -yi);
+                }
+            }
+        }
+        __syncthreads();
+        if (mode != FE_MODE_SPEC) {
+            float2* yv = fft_lds<S, true>(fa, fb, tw);
+            float2* spare = (yv == fa) ? fb : fa;
+            float* cis = a.cache_istft + (size_t)b * OVL;
+            const float* wi = wp + (mode == FE_MODE_STREAM ? P::WINDOW_I : P::WINDOW);
+            float* xo = reinterpret_cast<float*>(spare);
+            const float invN = 1.0f / (float)N;
+            for (int n = tid; n < N; n += kThreads) {
+                float v = yv[n].x * invN * wi[n];
+                if (n < OVL) v += cis[n];
+                xo[n] = v;
+            }
+            __syncthreads();
+            if (mode == FE_MODE_STREAM) {
+                float* out = a.wav_out + (size_t)b * a.out_stride + (size_t)t * H;
+                for (int n = tid; n < H; n += kThreads) out[n] = xo[n];
+            } else {
+                const float* w = wp + P::WINDOW;
+                const int n_out = H * (aT - 1);
+                const int emit = (t == aT - 1) ? N : H;
+                float* out = a.wav_out + (size_t)b * a.out_stride;
+                for (int j = tid; j < emit; j += kThreads) {
+                    const int n = t * H + j, pos = n - N / 2;
+                    if (pos >= 0 && pos < n_out) {
+                        int t_lo = (n - N + H) / H;
+                        t_lo = t_lo < 0 ? 0 : t_lo;
+                        int t_hi = n / H;
+                        t_hi = t_hi > aT - 1 ? aT - 1 : t_hi;
+                        float env = 0.0f;
+                        for (int tt = t_lo; tt <= t_hi; ++tt) { const float wv = w[n - tt * H]; env += wv * wv; }
+                        out[pos] = xo[j] / env;
+                    }
+                }
+            }
+            for (int m = tid; m < OVL; m += kThreads) cis[m] = xo[m + H];
+            __syncthreads();
+        }
+        LS_CLK(5);
+    }
+    b += gridDim.x;
+    } while (b < a.B);
+}
+
+struct LImpl {
+    int HOP;
+    size_t lds_bytes;
+    size_t dbg_floats;
+    int dbg_stages;
+    size_t packed_floats;
+    size_t cache_floats;      // model caches per stream
+    void (*launch)(const LArgs&, int max_wgs, hipStream_t, hipError_t*);
+    void (*dbg_stage)(int, int*, int*, size_t*);
+};
+
+template <class S>
+void llaunch_impl(const LArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
+    constexpr int OCC_LDS = (160 * 1024) / (LLds::TOTAL * 4);
+    constexpr int OCC = OCC_LDS < 2 ? OCC_LDS : 2;                 // (256 VGPRs per wave: two workgroups per CU)
+    const int slots = max_wgs * OCC;
+    const int grid = a.B < slots ? a.B : slots;
+    if (a.dbg != nullptr) hipLaunchKernelGGL((lisennet_frame_kernel<S, false, true>), dim3(grid), dim3(kThreads), 0, st, a);
+    else if (a.clk != nullptr) hipLaunchKernelGGL((lisennet_frame_kernel<S, true, false>), dim3(grid), dim3(kThreads), 0, st, a);
+    else hipLaunchKernelGGL((lisennet_frame_kernel<S, false, false>), dim3(grid), dim3(kThreads), 0, st, a);
+    *err = hipGetLastError();
+}
+
+inline void ldbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
+    *rows = LDebugLayout::rows(s);
+    *cols = LDebugLayout::cols(s);
+    *off = LDebugLayout::offset(s);
+}
+
+template <class S>
+LImpl make_limpl() {
+    return LImpl{S::HOP, (size_t)LLds::TOTAL * 4, LDebugLayout::total(), LDebugLayout::n_stages, (size_t)LPk::TOTAL, (size_t)S::CACHE_FLOATS,
+                 &llaunch_impl<S>, &ldbg_stage_impl};
+}
+
+}  // namespace fe

@@ -12,9 +12,9 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from .config import BSRNNConfig, FEConfig, FSPENConfig
+from .config import BSRNNConfig, FEConfig, FSPENConfig, LiSenNetConfig
 from .weights import (bsrnn_expected_fused_shapes, bsrnn_fold_state_dict, check_fused, check_shapes, fold_state_dict,
-                      fspen_expected_fused_shapes, fspen_fold_state_dict)
+                      fspen_expected_fused_shapes, fspen_fold_state_dict, lisennet_expected_shapes, lisennet_state_dict)
 
 
 def _ptr(t: Optional[Tensor]) -> c_void_p:
@@ -35,9 +35,13 @@ class Engine:
         c = _lib.fe_config()
         self.is_bsrnn = isinstance(cfg, BSRNNConfig)
         self.is_fspen = isinstance(cfg, FSPENConfig)
+        self.is_lisennet = isinstance(cfg, LiSenNetConfig)
         c.n_fft, c.hop_size, c.win_size = cfg.n_fft, cfg.hop_size, cfg.win_size
         c.input_compression = cfg.input_compression
-        if self.is_fspen:
+        if self.is_lisennet:
+            c.arch = _lib.FE_ARCH_LISENNET
+            c.channels, c.rf_blocks = cfg.num_channels, cfg.n_blocks
+        elif self.is_fspen:
             c.arch = _lib.FE_ARCH_FSPEN
             c.channels = cfg.channels[-1]
             c.n_kernels = len(cfg.kernel_size)
@@ -91,7 +95,10 @@ class Engine:
 
     def make_blob(self, state_dict: Mapping[str, Tensor], strict: bool = True) -> Tensor:
         """reference checkpoint (training or fused form) -> flat fp32 blob on the CPU."""
-        if self.is_fspen:
+        if self.is_lisennet:
+            fused = lisennet_state_dict(state_dict, self.cfg)
+            check_shapes(fused, lisennet_expected_shapes(self.cfg), strict=strict)
+        elif self.is_fspen:
             fused = fspen_fold_state_dict(state_dict, self.cfg)
             check_shapes(fused, fspen_expected_fused_shapes(self.cfg), strict=strict)
         elif self.is_bsrnn:
@@ -137,6 +144,14 @@ class Engine:
         L = c.cache_len
         out = [state[:B * L].view(B, L), state[B * L:2 * B * L].view(B, L)]
         o = 2 * B * L
+        if self.is_lisennet:       # the reference's cache list, each tensor sized for B streams (models/lisennet/model.py:380-396)
+            for shp in c.cache_shapes(B):
+                n = 1
+                for d_ in shp:
+                    n *= d_
+                out.append(state[o:o + n].view(*shp))
+                o += n
+            return out
         if self.is_fspen:          # num_blocks * groups inter-GRU states [1, B * freq/groups, C]  (models/fspen/model.py:293-297, :111-116)
             n = B * (c.freq // c.groups) * c.dpe_channels
             for _ in range(c.n_caches):
@@ -169,7 +184,7 @@ class Engine:
     def model_state_order(self, caches: List[Tensor]) -> List[Tensor]:
         """the model's cache list (reference order) -> flat pieces in the order of the C ABI state (h ..., then the conv caches)"""
         c = self.cfg
-        if self.is_bsrnn or self.is_fspen or not c.time_kernel:
+        if self.is_bsrnn or self.is_fspen or self.is_lisennet or not c.time_kernel:
             return [t.reshape(-1) for t in caches]
         nl, K = c.n_layers, c.rf_blocks
         assert len(caches) == 2 * nl + K, f"expected {2 * nl + K} caches, got {len(caches)}"
@@ -225,7 +240,7 @@ class Engine:
         cfg = self.cfg
         T = 1 + Tw // cfg.hop_size
         wav = torch.empty(B, cfg.hop_size * (T - 1), dtype=torch.float32, device=noisy.device)
-        spec = torch.empty(B, cfg.F0 + (1 if (self.is_bsrnn or self.is_fspen) else 0), T, 2, dtype=torch.float32, device=noisy.device)
+        spec = torch.empty(B, cfg.F0 + (1 if (self.is_bsrnn or self.is_fspen or self.is_lisennet) else 0), T, 2, dtype=torch.float32, device=noisy.device)
         work = torch.empty(int(self.lib.fe_offline_work_floats(self._h, B, Tw)), dtype=torch.float32, device=noisy.device)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.fe_offline(self._h, _ptr(noisy), B, Tw, _ptr(wav), _ptr(spec), _ptr(work), _stream(self.device)),

@@ -466,3 +466,97 @@ def fspen_default_state_dict(cfg, generator: Optional[torch.Generator] = None) -
                 fan_in *= d
             sd[k] = torch.randn(shp, generator=g) * (0.5 / fan_in ** 0.5)
     return sd
+
+
+# ------------------------------------------------------------------------------------------------ LiSenNet
+def lisennet_expected_shapes(cfg) -> Dict[str, tuple]:
+    """state_dict of models/lisennet/model.py::ONNXModel (nothing is folded: remove_weight_reparameterizations is a no-op, :476-477)."""
+    C, F, Hd = cfg.num_channels, cfg.n_fft // 2 + 1, cfg.hidden
+    c1, c2, c3 = C // 4, C // 2, C // 4 * 3
+    nf = F // 8
+    sh: Dict[str, tuple] = {}
+
+    def dsconv(p, cin, cout, nfq):
+        sh[p + ".low_conv.weight"] = (cout, cin, 2, 3)
+        sh[p + ".low_conv.bias"] = (cout,)
+        sh[p + ".high_conv.weight"] = (cout, cin, 2, 5)
+        sh[p + ".high_conv.bias"] = (cout,)
+        sh[p + ".norm.gamma"] = (1, 1, 1, nfq // 2)
+        sh[p + ".norm.beta"] = (1, 1, 1, nfq // 2)
+        sh[p + ".act.weight"] = (cout,)
+
+    def gru(p, i, h, bi):
+        for sfx in (("", "_reverse") if bi else ("",)):
+            sh[f"{p}.weight_ih_l0{sfx}"] = (3 * h, i)
+            sh[f"{p}.weight_hh_l0{sfx}"] = (3 * h, h)
+            sh[f"{p}.bias_ih_l0{sfx}"] = (3 * h,)
+            sh[f"{p}.bias_hh_l0{sfx}"] = (3 * h,)
+
+    sh["encoder.conv_1.0.weight"] = (c1, 3, 1, 1)
+    sh["encoder.conv_1.0.bias"] = (c1,)
+    sh["encoder.conv_1.1.gamma"] = (1, 1, 1, F)
+    sh["encoder.conv_1.1.beta"] = (1, 1, 1, F)
+    sh["encoder.conv_1.2.weight"] = (c1,)
+    dsconv("encoder.conv_2", c1, c2, F)
+    dsconv("encoder.conv_3", c2, c3, F // 2)
+    dsconv("encoder.conv_4", c3, C, F // 4)
+    for b in range(cfg.n_blocks):
+        p = f"blocks.{b}."
+        sh[p + "dp_rnn_attn.intra_norm.weight"] = (nf, C)
+        sh[p + "dp_rnn_attn.intra_norm.bias"] = (nf, C)
+        gru(p + "dp_rnn_attn.intra_rnn_attn.rnn", C, Hd // 2, True)
+        sh[p + "dp_rnn_attn.intra_rnn_attn.dense.weight"] = (C, Hd)
+        sh[p + "dp_rnn_attn.intra_rnn_attn.dense.bias"] = (C,)
+        sh[p + "dp_rnn_attn.inter_norm.weight"] = (nf, C)
+        sh[p + "dp_rnn_attn.inter_norm.bias"] = (nf, C)
+        gru(p + "dp_rnn_attn.inter_rnn_attn.rnn", C, Hd, False)
+        sh[p + "dp_rnn_attn.inter_rnn_attn.dense.weight"] = (C, Hd)
+        sh[p + "dp_rnn_attn.inter_rnn_attn.dense.bias"] = (C,)
+        sh[p + "conv_glu.norm.gamma"] = (1, C, 1, nf)
+        sh[p + "conv_glu.norm.beta"] = (1, C, 1, nf)
+        sh[p + "conv_glu.fc1.weight"] = (4 * C, C, 1, 1)
+        sh[p + "conv_glu.fc1.bias"] = (4 * C,)
+        sh[p + "conv_glu.dwconv.weight"] = (2 * C, 1, 3, 3)
+        sh[p + "conv_glu.dwconv.bias"] = (2 * C,)
+        sh[p + "conv_glu.fc2.weight"] = (C, 2 * C, 1, 1)
+        sh[p + "conv_glu.fc2.bias"] = (C,)
+    for i, (cin, cout) in enumerate(((2 * C, c3), (2 * c3, c2), (2 * c2, c1))):
+        p = f"decoder.up{i + 1}."
+        sh[p + "low_conv.weight"] = (cout, cin, 1, 3)
+        sh[p + "low_conv.bias"] = (cout,)
+        sh[p + "high_conv.conv.weight"] = (3 * cout, cin, 1, 3)
+        sh[p + "high_conv.conv.bias"] = (3 * cout,)
+    sh["decoder.mask_conv.0.weight"] = (2, c1, 2, 2)
+    sh["decoder.mask_conv.0.bias"] = (2,)
+    sh["decoder.mask_conv.1.gamma"] = (1, 1, 1, F)
+    sh["decoder.mask_conv.1.beta"] = (1, 1, 1, F)
+    sh["decoder.mask_conv.2.weight"] = (2,)
+    sh["decoder.mask_conv.3.weight"] = (2, 2, 1, 1)
+    sh["decoder.mask_conv.3.bias"] = (2,)
+    sh["decoder.lsigmoid.slope"] = (F, 1, 1)
+    return sh
+
+
+def lisennet_state_dict(sd: Mapping[str, Tensor], cfg) -> Dict[str, Tensor]:
+    """the checkpoint's floating-point tensors as fp32 (there is no reparameterisation to remove)"""
+    return {k: torch.as_tensor(v).detach().to(torch.float32) for k, v in sd.items() if torch.as_tensor(v).is_floating_point()}
+
+
+def lisennet_default_state_dict(cfg, generator: Optional[torch.Generator] = None) -> Dict[str, Tensor]:
+    """Random weights of the right shapes (benchmarks, smoke tests): unit norms, PReLU 0.25, fan-in-scaled matrices."""
+    g = generator or torch.Generator().manual_seed(0)
+    sd: Dict[str, Tensor] = {}
+    for k, shp in lisennet_expected_shapes(cfg).items():
+        leaf = k.split(".")[-1]
+        if leaf == "gamma" or k.endswith("_norm.weight") or leaf == "slope":
+            sd[k] = torch.ones(shp)
+        elif leaf == "beta" or k.endswith("_norm.bias") or "bias" in leaf:
+            sd[k] = 0.05 * torch.randn(shp, generator=g)
+        elif k.endswith("act.weight") or k.endswith("conv_1.2.weight") or k.endswith("mask_conv.2.weight"):
+            sd[k] = torch.full(shp, 0.25)
+        else:
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            sd[k] = torch.randn(shp, generator=g) * (1.0 / fan_in ** 0.5)
+    return sd

@@ -37,6 +37,8 @@ extern "C" {
 #define FE_ARCH_FSPEN 2        /* models/fspen/model.py (configs/others/fspen.yaml): channels = channels[-1], kernel_size / n_kernels / stride
                                 * as in the yaml, rf_channels / rf_freq / rf_blocks / rf_heads = dpe_kwargs channels / freq / num_blocks / groups */
 
+#define FE_ARCH_LISENNET 3     /* models/lisennet/model.py (configs/others/lisennet.yaml): channels = num_channels, rf_blocks = n_blocks */
+
 #define FE_MAX_KERNELS 8
 
 /* Mirror of the yaml `model_kwargs` that select the architecture

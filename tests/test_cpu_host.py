@@ -275,3 +275,31 @@ def test_fspen_host_side_without_gpu():
         FSPENConfig.from_model_kwargs(**dict(kw, dpe_kwargs=dict(kw["dpe_kwargs"], norm="BatchNorm")))
     with pytest.raises(AssertionError, match="Only n_fft == 512"):
         FSPENConfig.from_model_kwargs(**dict(kw, n_fft=1024))
+
+
+def test_lisennet_host_side_without_gpu():
+    """LiSenNet (models/lisennet/model.py): the C ABI's section table is the checkpoint schema, the blob layout round-trips, flops
+    follow models/lisennet/macs.py, the state is the reference's cache list, other architectures are rejected with a message."""
+    from common import LISENNET_KWARGS
+    from fastenhancer_amd import _lib
+    from fastenhancer_amd.config import LiSenNetConfig
+    from fastenhancer_amd.engine import Engine
+    from fastenhancer_amd.weights import lisennet_expected_shapes
+    from oracle import lisennet_oracle as lo
+    kw, sr, seed = LISENNET_KWARGS
+    cfg = LiSenNetConfig.from_model_kwargs(**kw)
+    ocfg = lo.LiSenNetConfig.from_model_kwargs(kw)
+    sd = lo.make_state_dict(ocfg, seed)
+    assert {k: tuple(v.shape) for k, v in sd.items()} == lisennet_expected_shapes(cfg) == lo.state_dict_spec(ocfg)
+    eng = Engine(cfg, None)
+    assert {n for n, _, _ in eng.sections} == set(sd)
+    blob = eng.make_blob({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    for n, off, cnt in eng.sections:
+        np.testing.assert_array_equal(blob[off:off + cnt].numpy(), sd[n].reshape(-1))
+    assert abs(eng.flops_per_frame - ocfg.flops_per_frame()) < 1.0
+    assert eng.state_floats(3) == 3 * 2 * 256 + sum(int(np.prod(s)) for s in cfg.cache_shapes(3))
+    assert cfg.cache_shapes(2) == ocfg.cache_shapes(2)
+    with pytest.raises(_lib.FEError, match="no LiSenNet kernel compiled"):
+        Engine(LiSenNetConfig.from_model_kwargs(**dict(kw, n_blocks=3)), None)
+    with pytest.raises(RuntimeError, match="not supported"):
+        LiSenNetConfig.from_model_kwargs(**dict(kw, normalized=True))
