@@ -327,6 +327,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
                 if (i < NOUT) {
                     if (f < HALF) {
                         acc = wp[b_lo + o];
+#pragma unroll 4
                         for (int c = 0; c < CIN; ++c)
 #pragma unroll
                             for (int df = 0; df < 3; ++df) {
@@ -340,6 +341,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
                     } else {
                         const int j = f - HALF;
                         acc = wp[b_hi + o];
+#pragma unroll 4
                         for (int c = 0; c < CIN; ++c)
 #pragma unroll
                             for (int k = 0; k < 5; ++k) {
@@ -426,6 +428,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
             for (int q = 0; q < 3; ++q) hp[tid + 256 * q] = hpre[q];
             __syncthreads();
             // ---- intra GRU input projections gi[dir][f][36]
+#pragma unroll 3
             for (int i = tid; i < 2 * 32 * 36; i += kThreads) {
                 const int g36 = i % 36, f = (i / 36) & 31, d = i / (36 * 32);
                 float acc = wd[P::B_GB + d * 36 + g36];
@@ -446,6 +449,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
             }
             const float bhn = wd[P::B_HN + (wave & 1) * 12 + ((lane & 15) < 12 ? (lane & 15) : 0)];
             __syncthreads();
+            if (blk == 0) LS_CLK(6);
             if (wave < 2) {
                 const int d = wave, c = (lane & 15) < 12 ? (lane & 15) : 0;
                 float h = 0.0f;
@@ -471,6 +475,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
                 }
             }
             __syncthreads();
+            if (blk == 0) LS_CLK(7);
             // ---- intra dense (24 -> 16) + residual
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -482,6 +487,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
             }
             __syncthreads();
             dump(7 + 3 * blk, [&](int r, int c) { return xt[r * 16 + c]; });
+            if (blk == 0) LS_CLK(8);
             // ---- inter_norm + inter GRU over time (one step; state [32][24]) + dense + residual
             {
                 float v[2] = {xt[tid], xt[tid + 256]};
@@ -496,14 +502,14 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
                 const int i = tid + 256 * q, f = i / 24, c = i - f * 24;
                 float ir = wd[P::B_XGB + c], iz = wd[P::B_XGB + 24 + c], in_ = wd[P::B_XGB + 48 + c];
                 float hr = 0.0f, hz = 0.0f, hnn = wd[P::B_XHN + c];
-#pragma unroll 4
+#pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const float xv = yn[f * 16 + k];
                     ir = fmaf(wd[P::B_XIH + k * 72 + c], xv, ir);
                     iz = fmaf(wd[P::B_XIH + k * 72 + 24 + c], xv, iz);
                     in_ = fmaf(wd[P::B_XIH + k * 72 + 48 + c], xv, in_);
                 }
-#pragma unroll 4
+#pragma unroll
                 for (int k = 0; k < 24; ++k) {
                     const float hv = hp[f * 24 + k];
                     hr = fmaf(wd[P::B_XHH + k * 72 + c], hv, hr);
@@ -528,6 +534,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
             }
             __syncthreads();
             dump(8 + 3 * blk, [&](int r, int c) { return xt[r * 16 + c]; });
+            if (blk == 0) LS_CLK(9);
             // ---- ConvolutionalGLU (:120-136) on (b, d, t, f): CustomLayerNorm over (d, f) with gamma / beta [d][f]
             float* z = smem + L::Z;
             float* xx = smem + L::XX;
@@ -551,7 +558,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
             }
             __syncthreads();
             // fc1: 1x1 (16 -> 64): channels 0..31 -> xx[2] (and the new cache), 32..63 -> v
-#pragma unroll 1
+#pragma unroll 2
             for (int q = 0; q < 8; ++q) {
                 const int i = tid + 256 * q, o = i & 63, f = i >> 6;
                 float acc = wd[P::B_F1B + o];
@@ -560,6 +567,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
                 if (o < 32) xx[(64 + o) * 32 + f] = acc; else vv[(o - 32) * 32 + f] = acc;
             }
             __syncthreads();
+            if (blk == 0) LS_CLK(10);
             // new cache = frames (t-1, t); depthwise 3 x 3 over (time, freq), Mish, gate
 #pragma unroll 1
             for (int q = 0; q < 4; ++q) {
@@ -584,7 +592,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
             for (int q = 0; q < 2; ++q) {
                 const int i = tid + 256 * q, f = i >> 4, d = i & 15;
                 float acc = wd[P::B_F2B + d];
-#pragma unroll 8
+#pragma unroll
                 for (int c = 0; c < 32; ++c) acc = fmaf(wd[P::B_F2W + c * 16 + d], gg[c * 32 + f], acc);
                 acc += xt[i];
                 xt[i] = acc;
@@ -592,6 +600,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
             }
             __syncthreads();
             dump(9 + 3 * blk, [&](int r, int c) { return yd[r * 32 + c]; });
+            if (blk == 0) LS_CLK(11);
         }
 
         LS_CLK(3);
@@ -608,7 +617,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
                 const int oc = low ? c : r * COUT + c, nout = low ? COUT : 3 * COUT;
                 const int wofs = low ? w_lo : w_hi, base = low ? 0 : LOWF;
                 float acc = wp[(low ? b_lo : b_hi) + oc];
-#pragma unroll 1
+#pragma unroll 8
                 for (int ci = 0; ci < CIN; ++ci) {
                     const float* src = ci < CX ? xa + ci * FIN : skip + (ci - CX) * FIN;
 #pragma unroll
