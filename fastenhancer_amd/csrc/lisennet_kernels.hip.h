@@ -137,7 +137,9 @@ struct LLds {
     static constexpr int U3P = SB + 2816;           // previous frame (cache) [4][256]
     static constexpr int MY = SB + 3840;            // mask conv out [2][260]
     static constexpr int MK = SB + 4360;            // mask [2][260]
-    static constexpr int TOTAL = SB + 6656;
+    static constexpr int WST = SB + 6656;           // weight staging area of the conv phases (one layer's weights at a time)
+    static constexpr int WST_SIZE = 4672;
+    static constexpr int TOTAL = WST + WST_SIZE;
     static_assert(SB % 2 == 0 && TW % 2 == 0, "float2 alignment");
     static_assert((size_t)TOTAL * 4 <= 64 * 1024, "static LDS");
 };
@@ -213,6 +215,14 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
             float q_ = 0.0f;
             for (int i = 0; i < cnt; ++i) { const float d = v[i] - mean; q_ = fmaf(d, d, q_); }
             rstd = 1.0f / sqrtf(block_sum(q_) * inv_n + 1.0e-5f);
+        };
+
+        // a conv layer's weights (a contiguous block of the packed buffer) -> LDS in one coalesced burst: the layers then read them
+        // with LDS latency instead of an L2 round trip per tap (all threads call; ends with a barrier)
+        float* wst = smem + L::WST;
+        auto stage = [&](int base, int n) {
+            for (int i = tid; i < n; i += kThreads) wst[i] = wp[base + i];
+            __syncthreads();
         };
 
         LS_CLK(0);
@@ -318,6 +328,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
                           int w_lo, int w_hi, int b_lo, int b_hi, int g_, int be_, int p_) {
             constexpr int CIN = decltype(CIN_)::value, COUT = decltype(COUT_)::value, FIN = decltype(FIN_)::value;
             constexpr int LOWF = FIN / 4, HALF = LOWF, FO = 2 * HALF, NOUT = COUT * FO, PER = (NOUT + kThreads - 1) / kThreads;
+            stage(w_lo, p_ + COUT - w_lo);                      // [low | high | biases | gamma | beta | PReLU] of this layer
+            const float* ws = wst - w_lo;
             float v[PER];
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
@@ -326,7 +338,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
                 float acc = 0.0f;
                 if (i < NOUT) {
                     if (f < HALF) {
-                        acc = wp[b_lo + o];
+                        acc = ws[b_lo + o];
 #pragma unroll 4
                         for (int c = 0; c < CIN; ++c)
 #pragma unroll
@@ -334,13 +346,13 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
                                 const int fi = f + df - 1;
                                 const bool ok = fi >= 0 && fi < LOWF;
                                 const int fc = ok ? fi : 0;
-                                const float w0 = wp[w_lo + ((c * 2 + 0) * 3 + df) * COUT + o], w1 = wp[w_lo + ((c * 2 + 1) * 3 + df) * COUT + o];
+                                const float w0 = ws[w_lo + ((c * 2 + 0) * 3 + df) * COUT + o], w1 = ws[w_lo + ((c * 2 + 1) * 3 + df) * COUT + o];
                                 const float s_ = fmaf(w0, prev[c * ld_in + fc], w1 * cur[c * ld_in + fc]);
                                 acc += ok ? s_ : 0.0f;
                             }
                     } else {
                         const int j = f - HALF;
-                        acc = wp[b_hi + o];
+                        acc = ws[b_hi + o];
 #pragma unroll 4
                         for (int c = 0; c < CIN; ++c)
 #pragma unroll
@@ -348,7 +360,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
                                 const int fi = 3 * j + k - 1;                 // index into the high slice [LOWF, FIN)
                                 const bool ok = fi >= 0 && fi < FIN - LOWF;
                                 const int fc = LOWF + (ok ? fi : 0);
-                                const float w0 = wp[w_hi + ((c * 2 + 0) * 5 + k) * COUT + o], w1 = wp[w_hi + ((c * 2 + 1) * 5 + k) * COUT + o];
+                                const float w0 = ws[w_hi + ((c * 2 + 0) * 5 + k) * COUT + o], w1 = ws[w_hi + ((c * 2 + 1) * 5 + k) * COUT + o];
                                 const float s_ = fmaf(w0, prev[c * ld_in + fc], w1 * cur[c * ld_in + fc]);
                                 acc += ok ? s_ : 0.0f;
                             }
@@ -368,8 +380,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
                 const int i = tid + q * kThreads;
                 if (i < NOUT) {
                     const int o = i % COUT, f = i / COUT;
-                    float y = (v[q] - mean) * rstd * wp[g_ + f] + wp[be_ + f];
-                    y = y >= 0.0f ? y : y * wp[p_ + o];
+                    float y = (v[q] - mean) * rstd * ws[g_ + f] + ws[be_ + f];
+                    y = y >= 0.0f ? y : y * ws[p_ + o];
                     out[o * FO + f] = y;
                     if (cache_io) { prev_out[o * FO + f] = cache_io[o * FO + f]; cache_io[o * FO + f] = y; }
                 }
@@ -427,14 +439,26 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
 #pragma unroll
             for (int q = 0; q < 3; ++q) hp[tid + 256 * q] = hpre[q];
             __syncthreads();
-            // ---- intra GRU input projections gi[dir][f][36]
-#pragma unroll 3
-            for (int i = tid; i < 2 * 32 * 36; i += kThreads) {
-                const int g36 = i % 36, f = (i / 36) & 31, d = i / (36 * 32);
-                float acc = wd[P::B_GB + d * 36 + g36];
+            // ---- intra GRU input projections gi[dir][f][36]: thread (gate row g36, f group): its 2 x 16 weights in registers, 5 rows of tokens
+            {
+                const int g36 = tid % 36, fq = tid / 36;                 // 252 threads, fq < 7
+                float wq[32];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) acc = fmaf(wd[P::B_IH + (d * 16 + k) * 36 + g36], yn[f * 16 + k], acc);
-                gi[i] = acc;
+                for (int k = 0; k < 32; ++k) wq[k] = wd[P::B_IH + k * 36 + g36];
+                const float bq0 = wd[P::B_GB + g36], bq1 = wd[P::B_GB + 36 + g36];
+                if (tid < 252) {
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) {
+                        const int f = fq + 7 * r;
+                        if (f < 32) {
+                            float a0 = bq0, a1 = bq1;
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) { const float xv = yn[f * 16 + k]; a0 = fmaf(wq[k], xv, a0); a1 = fmaf(wq[16 + k], xv, a1); }
+                            gi[f * 36 + g36] = a0;
+                            gi[(32 + f) * 36 + g36] = a1;
+                        }
+                    }
+                }
             }
             // recurrence weights (all waves fetch; waves 2, 3 a copy: no conditional definitions)
             float wr[12], wz[12], wn[12];
@@ -497,31 +521,41 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
                 for (int q = 0; q < 2; ++q) { const int i = tid + 256 * q; yn[i] = (v[q] - mean) * rstd * wd[P::B_N2W + i] + wd[P::B_N2B + i]; }
             }
             __syncthreads();
+            {   // ONE GRU for all sub-bands: thread (hidden unit c, row group fg) keeps the unit's three gate rows (3 x (16 + 24) weights)
+                // in registers and walks the rows f = fg, fg + 10, ...
+                const int c = tid % 24, fg = tid / 24;                  // 240 threads, fg < 10
+                float wi[48], wh[72];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { wi[k] = wd[P::B_XIH + k * 72 + c]; wi[16 + k] = wd[P::B_XIH + k * 72 + 24 + c]; wi[32 + k] = wd[P::B_XIH + k * 72 + 48 + c]; }
+#pragma unroll
+                for (int k = 0; k < 24; ++k) { wh[k] = wd[P::B_XHH + k * 72 + c]; wh[24 + k] = wd[P::B_XHH + k * 72 + 24 + c]; wh[48 + k] = wd[P::B_XHH + k * 72 + 48 + c]; }
+                const float b_r = wd[P::B_XGB + c], b_z = wd[P::B_XGB + 24 + c], b_n = wd[P::B_XGB + 48 + c], b_hn = wd[P::B_XHN + c];
+                if (tid < 240) {
 #pragma unroll 1
-            for (int q = 0; q < 3; ++q) {
-                const int i = tid + 256 * q, f = i / 24, c = i - f * 24;
-                float ir = wd[P::B_XGB + c], iz = wd[P::B_XGB + 24 + c], in_ = wd[P::B_XGB + 48 + c];
-                float hr = 0.0f, hz = 0.0f, hnn = wd[P::B_XHN + c];
+                    for (int f = fg; f < 32; f += 10) {
+                        float ir = b_r, iz = b_z, in_ = b_n, hr = 0.0f, hz = 0.0f, hnn = b_hn;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const float xv = yn[f * 16 + k];
-                    ir = fmaf(wd[P::B_XIH + k * 72 + c], xv, ir);
-                    iz = fmaf(wd[P::B_XIH + k * 72 + 24 + c], xv, iz);
-                    in_ = fmaf(wd[P::B_XIH + k * 72 + 48 + c], xv, in_);
-                }
+                        for (int k = 0; k < 16; ++k) {
+                            const float xv = yn[f * 16 + k];
+                            ir = fmaf(wi[k], xv, ir);
+                            iz = fmaf(wi[16 + k], xv, iz);
+                            in_ = fmaf(wi[32 + k], xv, in_);
+                        }
 #pragma unroll
-                for (int k = 0; k < 24; ++k) {
-                    const float hv = hp[f * 24 + k];
-                    hr = fmaf(wd[P::B_XHH + k * 72 + c], hv, hr);
-                    hz = fmaf(wd[P::B_XHH + k * 72 + 24 + c], hv, hz);
-                    hnn = fmaf(wd[P::B_XHH + k * 72 + 48 + c], hv, hnn);
+                        for (int k = 0; k < 24; ++k) {
+                            const float hv = hp[f * 24 + k];
+                            hr = fmaf(wh[k], hv, hr);
+                            hz = fmaf(wh[24 + k], hv, hz);
+                            hnn = fmaf(wh[48 + k], hv, hnn);
+                        }
+                        const float r = sigmoid_f(ir + hr);
+                        const float z = sigmoid_f(iz + hz);
+                        const float n = tanh_f(in_ + r * hnn);
+                        const float hnew = (1.0f - z) * n + z * hp[f * 24 + c];
+                        hn[f * 24 + c] = hnew;
+                        ch[f * 24 + c] = hnew;
+                    }
                 }
-                const float r = sigmoid_f(ir + hr);
-                const float z = sigmoid_f(iz + hz);
-                const float n = tanh_f(in_ + r * hnn);
-                const float hnew = (1.0f - z) * n + z * hp[i];
-                hn[i] = hnew;
-                ch[i] = hnew;
             }
             __syncthreads();
 #pragma unroll
@@ -610,13 +644,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
         auto usconv = [&](auto CX_, auto COUT_, auto FIN_, const float* xa, const float* skip, float* out, int w_lo, int w_hi, int b_lo, int b_hi) {
             constexpr int CX = decltype(CX_)::value, COUT = decltype(COUT_)::value, FIN = decltype(FIN_)::value;
             constexpr int LOWF = FIN / 2, FO = LOWF + 3 * LOWF, NOUT = COUT * FO, CIN = 2 * CX;
+            stage(w_lo, b_hi + 3 * COUT - w_lo);                // [low | high | low bias | high bias]
+            const float* ws = wst - w_lo;
             for (int i = tid; i < NOUT; i += kThreads) {
                 const int c = i % COUT, fo = i / COUT;
                 const bool low = fo < LOWF;
                 const int w = low ? fo : (fo - LOWF) / 3, r = low ? 0 : (fo - LOWF) - 3 * w;
                 const int oc = low ? c : r * COUT + c, nout = low ? COUT : 3 * COUT;
                 const int wofs = low ? w_lo : w_hi, base = low ? 0 : LOWF;
-                float acc = wp[(low ? b_lo : b_hi) + oc];
+                float acc = ws[(low ? b_lo : b_hi) + oc];
 #pragma unroll 8
                 for (int ci = 0; ci < CIN; ++ci) {
                     const float* src = ci < CX ? xa + ci * FIN : skip + (ci - CX) * FIN;
@@ -625,7 +661,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
                         const int fi = w + df - 1;
                         const bool ok = fi >= 0 && fi < LOWF;
                         const float xv = src[base + (ok ? fi : 0)];
-                        acc = fmaf(wp[wofs + (ci * 3 + df) * nout + oc], ok ? xv : 0.0f, acc);
+                        acc = fmaf(ws[wofs + (ci * 3 + df) * nout + oc], ok ? xv : 0.0f, acc);
                     }
                 }
                 out[c * FO + fo] = acc;
