@@ -1118,6 +1118,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
 #endif
     if constexpr (MODE >= 0) a.mode = MODE;
     if constexpr (MODE == FE_MODE_STREAM) { a.spec_in = nullptr; a.spec_out = nullptr; a.Tw = 0; }
+    FE_CLK(62);                                      // kernel entry (tools/gpu_phases.py: prologue = probe 0 - probe 62)
     if constexpr (T1) a.T = 1;                       // one hop per launch (the per-hop driver loop): no frame loop, and the
                                                      // last GEMM phase does not stage weights for a next frame
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -2250,6 +2251,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
     }
     b += PIPE ? a.B : (int)gridDim.x;
     } while (PERSIST && b < a.B);
+    FE_CLK(63);
 }
 
 }  // namespace fe

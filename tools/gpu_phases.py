@@ -36,6 +36,8 @@ def main():
     torch.cuda.synchronize()
     c = clk.cpu().numpy()
     tot = c[13] - c[0]
+    if c[62] and c[63]:
+        print(f"kernel entry -> first frame {c[0] - c[62]} cycles, last probe -> kernel end {c[63] - c[13]} cycles, entry -> end {c[63] - c[62]}")
     print(f"{name} B={B}: frame = {tot} cycles")
     for i in range(13):
         d = c[i + 1] - c[i]
