@@ -134,6 +134,19 @@ struct FLds {
     static_assert((size_t)TOTAL * 4 <= 64 * 1024, "static LDS");
 };
 
+// Read-only view of the packed weights through ONE buffer resource with 32-bit indices.  With plain pointers every far constant
+// offset became its own 64-bit `base + constant` SGPR pair, hoisted to the kernel entry and spilled to VGPR lanes by the dozen; a
+// buffer load takes the constant in its immediate / scalar-offset field instead.
+struct WView {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int base;                  // floats (goes into the load's vector offset together with the index: a block offset in the SCALAR offset
+                               // made every vector offset loop-invariant, hoisted and kept live - measured slower)
+    __device__ __forceinline__ float operator[](int i) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (base + i) * 4, 0, 0));
+    }
+    __device__ __forceinline__ WView operator+(int off) const { return WView{rsrc, base + off}; }
+};
+
 __device__ __forceinline__ float elu_f(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -172,6 +185,24 @@ __device__ __forceinline__ void fs_pipe(float (&acc)[Q], float (&wa)[CH], WF&& w
     }
 }
 
+// The values of rows 0, 1, 2 of a wave (16 lanes each), per column, broadcast to all four rows: three gfx950 row-swap VALU ops
+// (see rows_allreduce in fe_kernels.hip.h for the inline-asm form)
+__device__ __forceinline__ void rows_gather3(float x, float& r0, float& r1, float& r2) {
+    float a = x, b = x;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));      // a = [x0 x1 x0 x1], b = [x2 x3 x2 x3]
+    float c = a, d = a;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(c), "+v"(d));      // c = [x0 x0 x0 x0], d = [x1 x1 x1 x1]
+    float e = b, f = b;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(e), "+v"(f));      // e = [x2 x2 x2 x2]
+    r0 = c; r1 = d; r2 = e;
+}
+
+// lane k of the caller's own 16-lane row, in every lane of that row (DPP row_newbcast: folds into the consuming VALU op)
+template <int K>
+__device__ __forceinline__ float row_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + K, 0xf, 0xf, true));
+}
+
 #ifndef FS_WPE
 #define FS_WPE 2          // waves per SIMD = workgroups per CU of the register budget (256 VGPRs; 3 would fit the LDS plan but spills: -18 % at 256 streams)
 #endif
@@ -179,7 +210,7 @@ __device__ __forceinline__ void fs_pipe(float (&acc)[Q], float (&wa)[CH], WF&& w
 #define FS_CLK(i) do { if constexpr (PROF) { if (blockIdx.x == 0 && threadIdx.x == 0) a.clk[(i)] = __builtin_readcyclecounter(); } } while (0)
 
 template <class S, bool PROF, bool DBG>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(DBG ? 1 : FS_WPE, DBG ? 1 : FS_WPE))) fspen_frame_kernel(FArgs a) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(FS_WPE, FS_WPE))) fspen_frame_kernel(FArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[FLds::TOTAL];
     using L = FLds;
     using P = FPk;
@@ -188,7 +219,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
     const int tid = tid0;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* __restrict__ wp0 = a.wp;
-    const float* __restrict__ wp = wp0;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, FPk::TOTAL * 4, 0x00020000);
     const int mode = a.mode, aT = a.T;
 
     float* sp = smem + L::SP;
@@ -199,7 +230,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
     float* e1 = smem + L::E1;
     float* e2 = smem + L::E2;
     float* cat = smem + L::CAT;
-    for (int i = tid; i < N / 2; i += kThreads) tw[i] = reinterpret_cast<const float2*>(wp + P::TW)[i];
+    for (int i = tid; i < N / 2; i += kThreads) tw[i] = reinterpret_cast<const float2*>(wp0 + P::TW)[i];
     // the zero columns of the padded encoder outputs are written once (the convs only write the interior)
     for (int i = tid; i < 4 * 134; i += kThreads) e0[i] = 0.0f;
     for (int i = tid; i < 16 * 68; i += kThreads) e1[i] = 0.0f;
@@ -228,7 +259,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
         int lz = 0, lzv = 0;
         asm volatile("" : "+s"(lz));
         asm volatile("" : "+v"(lzv));
-        const float* __restrict__ wp = wp0 + lz;
+        const WView wp{wrsrc, lz};
         const int tid = tid0 + lzv;
         const int lane = tid & 63;
         FS_CLK(0);
@@ -236,7 +267,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
         float* magp = smem + L::MAGP;
         float* ein = smem + L::EIN;
         if (mode != FE_MODE_SPEC) {
-            const float* win = wp + P::WINDOW;
+            const WView win = wp + P::WINDOW;
             float* cst = a.cache_stft + (size_t)b * OVL;
             if (mode == FE_MODE_STREAM) {
                 const float* xin = a.wav_in + (size_t)b * a.in_stride + (size_t)t * H;
@@ -395,7 +426,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
         {   // fullband_encoder.2: Conv1d(16 -> 32, k 6, s 2, p 2) -> e2[o][j], j < 32
             const int o = tid & 31;
             float acc[4] = {fe2_b, fe2_b, fe2_b, fe2_b};
-            const float* wcol = wp + P::FE2_W + o;
+            const WView wcol = wp + P::FE2_W + o;
             const float* xin = e1 + 2 * (tid >> 5);
             fs_pipe<8, 12, 4>(acc, fe2_w, [&](int ch, int j) { return wcol[(ch * 12 + j) * 32]; },
                               [&](int ch, int j, int q) { return xin[ch * 136 + (j / 6) * 68 + 16 * q + (j % 6)]; });
@@ -426,7 +457,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
         {
             const int j = tid & 31;
             float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            const float* wcol = wp + P::MG1_W + j;
+            const WView wcol = wp + P::MG1_W + j;
             const float* xin = cat + (tid >> 5) * 64;
             fs_pipe<4, 16, 4>(acc, mg1_w, [&](int ch, int jj) { return wcol[(ch * 16 + jj) * 32]; },
                               [&](int ch, int jj, int q) { return xin[q * 512 + ch * 16 + jj]; });
@@ -461,7 +492,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
         float* red = smem + L::RED;
 #pragma unroll 1
         for (int blk = 0; blk < S::NB; ++blk) {
-            const float* wd = wp + P::DPE + blk * P::D_SIZE;
+            const WView wd = wp + (P::DPE + blk * P::D_SIZE);
             // inter-GRU states of this block: [g][B*4][16] -> hprev[f][16]   (in flight across the intra GRU)
             float hp[2];
 #pragma unroll
@@ -492,18 +523,16 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
             // recurrence weights of this wave's direction (waves 0, 1) and everybody's intra_fc / LayerNorm weights: fetched before the barrier
             // (fetched by all four waves - waves 2 / 3 get a copy of direction 0 / 1: a conditional definition would be carried
             //  around the block loop as 49 live registers)
-            float wr[16], wz[16], wn[16];
+            // lane = (gate row = lane / 16: r, z, n, (r again), hidden unit c = lane % 16): ONE gate row of 16 weights per lane
+            float wg_[16];
+            const int g_row = (lane >> 4) < 3 ? (lane >> 4) : 0;
             {
                 const int c = lane & 15, dsel = wave & 1;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    wr[k] = wd[P::D_HH + ((dsel * 3 + 0) * 16 + k) * 16 + c];
-                    wz[k] = wd[P::D_HH + ((dsel * 3 + 1) * 16 + k) * 16 + c];
-                    wn[k] = wd[P::D_HH + ((dsel * 3 + 2) * 16 + k) * 16 + c];
-                }
+                for (int k = 0; k < 16; ++k) wg_[k] = wd[P::D_HH + ((dsel * 3 + g_row) * 16 + k) * 16 + c];
             }
-            const float bhn = wd[P::D_HN + (wave & 1) * 16 + (lane & 15)];
-            FS_LDW(fc_w, 32, (int)(wd - wp) + P::D_FC_W + (tid & 15), 16);
+            const float bhn = (lane >> 4) == 2 ? wd[P::D_HN + (wave & 1) * 16 + (lane & 15)] : 0.0f;
+            FS_LDW(fc_w, 32, (P::DPE + blk * P::D_SIZE) + P::D_FC_W + (tid & 15), 16);
             const float fc_b = wd[P::D_FC_B + (tid & 15)];
             float ln_w[2], ln_b[2];
 #pragma unroll
@@ -513,31 +542,31 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
             }
             __syncthreads();
             if (blk == 0) FS_CLK(8);
-            // ---- the recurrence: wave d walks direction d; lane c < 16 owns hidden unit c (its three gate rows in registers)
+            // ---- the recurrence: wave d walks direction d.  The 48 gate rows of a step sit one per lane (rows of 16 lanes = gates r, z,
+            // n; the fourth row repeats r): 16 FMAs per lane with h broadcast inside each row by DPP (h is kept replicated in all rows),
+            // then the three gate values of a unit are gathered to every row with three row-swap ops and every row updates its copy
+            // of h.  (First version: lane c computed all three gates of unit c - 48 FMAs, 16 v_readlane + 17 hazard nops per step:
+            // 620 cycles per step.)
             if (wave < 2) {
                 const int d = wave, c = lane & 15;
+                const bool is_n = (lane >> 4) == 2;
                 float h = 0.0f;
                 const float* gd = gi + d * 32 * 48;
                 int f = d ? 31 : 0;
-                float g_r = gd[f * 48 + c], g_z = gd[f * 48 + 16 + c], g_n = gd[f * 48 + 32 + c];
+                float g_own = gd[f * 48 + g_row * 16 + c], g_n = gd[f * 48 + 32 + c];
 #pragma unroll 1
                 for (int s_ = 0; s_ < 32; ++s_) {
                     const int fnx = d ? (s_ < 31 ? f - 1 : f) : (s_ < 31 ? f + 1 : f);
-                    const float n_r = gd[fnx * 48 + c], n_z = gd[fnx * 48 + 16 + c], n_n = gd[fnx * 48 + 32 + c];      // next step's x side
-                    float ar = 0.0f, az = 0.0f, an = bhn;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const float hk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, h), k));
-                        ar = fmaf(wr[k], hk, ar);
-                        az = fmaf(wz[k], hk, az);
-                        an = fmaf(wn[k], hk, an);
-                    }
-                    const float r = sigmoid_f(g_r + ar);
-                    const float z = sigmoid_f(g_z + az);
-                    const float n = tanh_f(g_n + r * an);
+                    const float n_own = gd[fnx * 48 + g_row * 16 + c], n_n = gd[fnx * 48 + 32 + c];      // next step's x side
+                    float acc = bhn;
+                    static_for<16>([&](auto k_) { constexpr int k = decltype(k_)::value; acc = fmaf(wg_[k], row_bcast<k>(h), acc); });
+                    const float x_ = is_n ? acc : sigmoid_f(g_own + acc);
+                    float r, z, pn;
+                    rows_gather3(x_, r, z, pn);
+                    const float n = tanh_f(g_n + r * pn);
                     h = (1.0f - z) * n + z * h;
                     if (lane < 16) hseq[f * 32 + d * 16 + c] = h;
-                    f = fnx; g_r = n_r; g_z = n_z; g_n = n_n;
+                    f = fnx; g_own = n_own; g_n = n_n;
                 }
             }
             __syncthreads();
@@ -550,7 +579,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
                 for (int q = 0; q < 2; ++q) yv[q] = fmaf(fc_w[k], hseq[((tid >> 4) + 16 * q) * 32 + k], yv[q]);
             __builtin_amdgcn_sched_barrier(0);
             // inter GRU (group of row f = tid >> 4) weights of the first of this thread's two rows: in flight across the LayerNorm
-            const float* wg0 = wd + P::D_G + (tid >> 6) * P::G_SIZE;              // rows 0..15: groups 0..3 = wave
+            const WView wg0 = wd + P::D_G + (tid >> 6) * P::G_SIZE;              // rows 0..15: groups 0..3 = wave
             float gi0[48];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
@@ -577,7 +606,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int f = (tid >> 4) + 16 * q, c = tid & 15;
-                const float* wg = wd + P::D_G + (f >> 2) * P::G_SIZE;
+                const WView wg = wd + P::D_G + (f >> 2) * P::G_SIZE;
                 float wi[48], wh[48];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
@@ -609,7 +638,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
             float ifc_w[2][16], ifc_b[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const float* wg = wd + P::D_G + (((tid >> 4) + 16 * q) >> 2) * P::G_SIZE;
+                const WView wg = wd + P::D_G + (((tid >> 4) + 16 * q) >> 2) * P::G_SIZE;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) ifc_w[q][k] = wg[P::G_FC_W + k * 16 + (tid & 15)];
                 ifc_b[q] = wg[P::G_FC_B + (tid & 15)];
@@ -683,7 +712,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
             const bool zero_row = row >= 32;                      // lin5's F.pad row: ReLU(bias)
             const int rc = zero_row ? 0 : row;
             float acc[1] = {0.0f};
-            const float* wcol = wp + P::SD_W + tid;
+            const WView wcol = wp + P::SD_W + tid;
             // k < 32: x_sub1 (cat[k][32 + row]); k >= 32: x_sub2 (s2[k - 32][32 + row]); both are [32][64] arrays, chunks 0, 1 | 2, 3
             fs_pipe<4, 16, 1>(acc, sd_w, [&](int ch, int j) { return wcol[(ch * 16 + j) * 260]; },
                               [&](int ch, int j, int) { const float* src = ch < 2 ? cat : s2 - 32 * 64; return src[(ch * 16 + j) * 64 + 32 + rc]; });
@@ -697,7 +726,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
             const int o = tid & 31;
             FS_LDW(w0, 16, P::FD0_W + o, 32);
             float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            const float* wcol = wp + P::FD0_W + o;
+            const WView wcol = wp + P::FD0_W + o;
             const int f0 = tid >> 5;
             fs_pipe<4, 16, 4>(acc, w0, [&](int ch, int j) { return wcol[(ch * 16 + j) * 32]; },
                               [&](int ch, int j, int q) {
@@ -735,7 +764,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
             float acc3[12];                                       // [q][tap] partial sums (masked at the end)
 #pragma unroll
             for (int i = 0; i < 12; ++i) acc3[i] = 0.0f;
-            const float* wcol = wp + P::FD0_T + o;
+            const WView wcol = wp + P::FD0_T + o;
             // Q = 12 "outputs" (q, tap): weight j = (channel j / 3 of the chunk, tap j % 3) only feeds the outputs of its own tap
             float wb[12];
 #pragma unroll 1
@@ -808,7 +837,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
             float acc4[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc4[i] = 0.0f;
-            const float* wcol = wp + P::FD1_T + o;
+            const WView wcol = wp + P::FD1_T + o;
             float wb[16];
 #pragma unroll 1
             for (int ch = 0; ch < 4; ch += 2) {
@@ -921,7 +950,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
             float2* yv = fft_lds<S, true>(fa, fb, tw);
             float2* spare = (yv == fa) ? fb : fa;
             float* cis = a.cache_istft + (size_t)b * OVL;
-            const float* wi = wp + (mode == FE_MODE_STREAM ? P::WINDOW_I : P::WINDOW);
+            const WView wi = wp + (mode == FE_MODE_STREAM ? P::WINDOW_I : P::WINDOW);
             float* xo = reinterpret_cast<float*>(spare);
             const float invN = 1.0f / (float)N;
             for (int n = tid; n < N; n += kThreads) {
@@ -934,7 +963,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
                 float* out = a.wav_out + (size_t)b * a.out_stride + (size_t)t * H;
                 for (int n = tid; n < H; n += kThreads) out[n] = xo[n];
             } else {
-                const float* w = wp + P::WINDOW;
+                const WView w = wp + P::WINDOW;
                 const int n_out = H * (aT - 1);
                 const int emit = (t == aT - 1) ? N : H;
                 float* out = a.wav_out + (size_t)b * a.out_stride;

@@ -152,7 +152,7 @@ __device__ __forceinline__ float mish_f(float x) {
 #define LS_CLK(i) do { if constexpr (PROF) { if (blockIdx.x == 0 && threadIdx.x == 0) a.clk[(i)] = __builtin_readcyclecounter(); } } while (0)
 
 template <class S, bool PROF, bool DBG>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(DBG ? 1 : 2, DBG ? 1 : 2))) lisennet_frame_kernel(LArgs a) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) lisennet_frame_kernel(LArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[LLds::TOTAL];
     using L = LLds;
     using P = LPk;
@@ -461,40 +461,35 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
                 }
             }
             // recurrence weights (all waves fetch; waves 2, 3 a copy: no conditional definitions)
-            float wr[12], wz[12], wn[12];
+            // lane = (gate row = lane / 16: r, z, n, (r again), hidden unit c = lane % 16, 12 used): one gate row of 12 weights per lane
+            float wg_[12];
+            const int g_row = (lane >> 4) < 3 ? (lane >> 4) : 0;
+            const int c12 = (lane & 15) < 12 ? (lane & 15) : 0;
             {
-                const int c = (lane & 15) < 12 ? (lane & 15) : 0, dsel = wave & 1;
+                const int dsel = wave & 1;
 #pragma unroll
-                for (int k = 0; k < 12; ++k) {
-                    wr[k] = wd[P::B_HH + ((dsel * 3 + 0) * 12 + k) * 12 + c];
-                    wz[k] = wd[P::B_HH + ((dsel * 3 + 1) * 12 + k) * 12 + c];
-                    wn[k] = wd[P::B_HH + ((dsel * 3 + 2) * 12 + k) * 12 + c];
-                }
+                for (int k = 0; k < 12; ++k) wg_[k] = wd[P::B_HH + ((dsel * 3 + g_row) * 12 + k) * 12 + c12];
             }
-            const float bhn = wd[P::B_HN + (wave & 1) * 12 + ((lane & 15) < 12 ? (lane & 15) : 0)];
+            const float bhn = (lane >> 4) == 2 ? wd[P::B_HN + (wave & 1) * 12 + c12] : 0.0f;
             __syncthreads();
             if (blk == 0) LS_CLK(6);
-            if (wave < 2) {
-                const int d = wave, c = (lane & 15) < 12 ? (lane & 15) : 0;
+            if (wave < 2) {      // (gates one per lane, DPP row broadcasts of h, row-swap gather: see fspen_kernels.hip.h)
+                const int d = wave;
+                const bool is_n = (lane >> 4) == 2;
                 float h = 0.0f;
                 const float* gd = gi + d * 32 * 36;
                 int f = d ? 31 : 0;
 #pragma unroll 1
                 for (int s_ = 0; s_ < 32; ++s_) {
-                    const float g_r = gd[f * 36 + c], g_z = gd[f * 36 + 12 + c], g_n = gd[f * 36 + 24 + c];
-                    float ar = 0.0f, az = 0.0f, an = bhn;
-#pragma unroll
-                    for (int k = 0; k < 12; ++k) {
-                        const float hk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, h), k));
-                        ar = fmaf(wr[k], hk, ar);
-                        az = fmaf(wz[k], hk, az);
-                        an = fmaf(wn[k], hk, an);
-                    }
-                    const float r = sigmoid_f(g_r + ar);
-                    const float z = sigmoid_f(g_z + az);
-                    const float n = tanh_f(g_n + r * an);
+                    const float g_own = gd[f * 36 + g_row * 12 + c12], g_n = gd[f * 36 + 24 + c12];
+                    float acc = bhn;
+                    static_for<12>([&](auto k_) { constexpr int k = decltype(k_)::value; acc = fmaf(wg_[k], row_bcast<k>(h), acc); });
+                    const float x_ = is_n ? acc : sigmoid_f(g_own + acc);
+                    float r, z, pn;
+                    rows_gather3(x_, r, z, pn);
+                    const float n = tanh_f(g_n + r * pn);
                     h = (1.0f - z) * n + z * h;
-                    if (lane < 12) hseq[f * 24 + d * 12 + c] = h;
+                    if (lane < 12) hseq[f * 24 + d * 12 + lane] = h;
                     f += d ? -1 : 1;
                 }
             }
