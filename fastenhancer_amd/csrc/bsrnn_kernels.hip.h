@@ -547,15 +547,29 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                                 p[g] += f32x2{wv.z, wv.w} * f32x2{hq[k].z, hq[k].w};
                             }
                     }
-                    float sg4[4];
+                    if constexpr (S::SEQD) {      // (C = 64: 256 register-resident weights per thread; the exchange below costs it 6 %)
+                        float sg4[4];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float v = p[g].x + p[g].y;
-                        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
-                        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
-                        sg4[g] = v;
+                        for (int g = 0; g < 4; ++g) {
+                            float v = p[g].x + p[g].y;
+                            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+                            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+                            sg4[g] = v;
+                        }
+                        mine = rgate == 0 ? sg4[0] : (rgate == 1 ? sg4[1] : (rgate == 2 ? sg4[2] : sg4[3]));
+                    } else {
+                    // lane q of the quad wants the quad-wide sum of gate q: a 4 x 4 transpose-reduce in two exchange steps (three DPP
+                    // adds) instead of four butterflies and a four-way select (which hipcc lowered to a divergent switch: ~30
+                    // instructions of exec-mask juggling per unit and step)
+                    const float s0 = p[0].x + p[0].y, s1 = p[1].x + p[1].y, s2 = p[2].x + p[2].y, s3 = p[3].x + p[3].y;
+                    const bool q1 = (rgate & 1) != 0, q2 = (rgate & 2) != 0;
+                    float a_m = q1 ? s1 : s0, b_m = q1 ? s3 : s2;
+                    const float a_o = q1 ? s0 : s1, b_o = q1 ? s2 : s3;
+                    a_m += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a_o), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+                    b_m += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b_o), 0xB1, 0xf, 0xf, true));
+                    const float m_ = q2 ? b_m : a_m, o_ = q2 ? a_m : b_m;
+                    mine = m_ + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, o_), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
                     }
-                    mine = rgate == 0 ? sg4[0] : (rgate == 1 ? sg4[1] : (rgate == 2 ? sg4[2] : sg4[3]));
                     }
                     const float pre = mine + xp_cur[rr];
                     const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre));
