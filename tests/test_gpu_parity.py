@@ -911,3 +911,24 @@ def test_lisennet_full_size(B):
     y1 = eng.step(xd, s1, T=4)
     y2 = torch.cat([eng.step(xd[:, t * H:(t + 1) * H], s2, T=1) for t in range(4)], dim=1)
     assert torch.equal(y1, y2) and torch.equal(s1, s2)
+
+
+@pytest.mark.parametrize("which", ["fspen", "lisennet"])
+def test_baseline_models_long_run_has_no_state_drift(which):
+    """60 hops (0.96 s) of two streams through the per-hop kernel against the oracle: the GRU states and the causal-conv frame caches are
+    carried through the stream state the whole way (the goldens stop at 10 hops)"""
+    m, orc, cfg, sr, seed = _fspen() if which == "fspen" else _lisennet()
+    eng = m.engine
+    B, hops, H = 2, 60, cfg.hop_size
+    x = make_input(B, hops * H, 4321, sr)
+    xd = torch.from_numpy(x).to(_dev())
+    state = eng.new_state(B)
+    caches = orc.initialize_cache(B)
+    got, ref = [], []
+    for t in range(hops):
+        got.append(eng.step(xd[:, t * H:(t + 1) * H], state, T=1).cpu().numpy())
+        o, *caches = orc.step(x[:, t * H:(t + 1) * H], *caches)
+        ref.append(o)
+    _assert_close(np.concatenate(got[-20:], axis=1), np.concatenate(ref[-20:], axis=1), f"{which} hops 40..59")
+    for a_, b_ in zip(eng.split_state(state, B), caches):
+        _assert_close(a_.cpu().numpy(), b_, f"{which} cache after 60 hops")
