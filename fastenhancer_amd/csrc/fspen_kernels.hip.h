@@ -989,6 +989,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
     } while (b < a.B);
 }
 
+#undef FS_LDW
+
 struct FImpl {
     int HOP;
     size_t lds_bytes;

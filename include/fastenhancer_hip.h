@@ -82,7 +82,13 @@ int fe_load_weights(fe_handle* h, const float* blob_dev, size_t nfloats, void* s
 
 /* Per-stream state = the reference's cache list, concatenated:
  *   cache_stft  [B, N-H] | cache_istft [B, N-H] | K x h [1, B*F2, C2]
- * (scripts/export_onnx.py:43-46).  fe_state_init zeroes it (initialize_cache). */
+ * (scripts/export_onnx.py:43-46).  fe_state_init zeroes it (initialize_cache).  The model part (what fe_spec_step takes as
+ * h_dev) per architecture, every tensor sized for B streams and laid out as the reference's:
+ *   FE_ARCH_FASTENHANCER  K x h [1, B*F2, C2]  (kernel_size_time > 1: + the conv caches, see fe_config)
+ *   FE_ARCH_BSRNN         2 * num_layers x [B*31, 2C]: h0, c0, h1, c1, ...              (models/bsrnn/model.py:409-416)
+ *   FE_ARCH_FSPEN         num_blocks * groups x [1, B*freq/groups, C] inter-GRU states  (models/fspen/model.py:293-297)
+ *   FE_ARCH_LISENNET      [B,1,257] phase | [B,4,1,257] [B,8,1,128] [B,12,1,64] encoder frames | n_blocks x ([1,B*32,24] GRU,
+ *                         [B,32,2,32] ConvGLU frames) | [B,4,1,256] decoder frame     (models/lisennet/model.py:380-396) */
 size_t fe_state_floats(const fe_handle* h, int B);
 int fe_state_init(fe_handle* h, float* state_dev, int B, void* stream);
 
