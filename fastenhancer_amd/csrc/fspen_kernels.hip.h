@@ -204,13 +204,16 @@ __device__ __forceinline__ float row_bcast(float v) {
 }
 
 #ifndef FS_WPE
-#define FS_WPE 2          // waves per SIMD = workgroups per CU of the register budget (256 VGPRs; 3 would fit the LDS plan but spills: -18 % at 256 streams)
+#define FS_WPE 3          // waves per SIMD = workgroups per CU of the register budget (168 VGPRs: what the 54 KB LDS plan allows too).
+                          // The debug instantiation (per-stage dumps) is built for 2: at 3 it needs 49 VGPR spills and computed the
+                          // feature split wrong (register-pressure dependent, not reproduced in the production instantiations, which
+                          // the parity tests cover at 2 - 8192 streams)
 #endif
 
 #define FS_CLK(i) do { if constexpr (PROF) { if (blockIdx.x == 0 && threadIdx.x == 0) a.clk[(i)] = __builtin_readcyclecounter(); } } while (0)
 
 template <class S, bool PROF, bool DBG>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(FS_WPE, FS_WPE))) fspen_frame_kernel(FArgs a) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(DBG ? 2 : FS_WPE, DBG ? 2 : FS_WPE))) fspen_frame_kernel(FArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[FLds::TOTAL];
     using L = FLds;
     using P = FPk;
@@ -578,13 +581,17 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
 #pragma unroll
                 for (int q = 0; q < 2; ++q) yv[q] = fmaf(fc_w[k], hseq[((tid >> 4) + 16 * q) * 32 + k], yv[q]);
             __builtin_amdgcn_sched_barrier(0);
-            // inter GRU (group of row f = tid >> 4) weights of the first of this thread's two rows: in flight across the LayerNorm
-            const WView wg0 = wd + P::D_G + (tid >> 6) * P::G_SIZE;              // rows 0..15: groups 0..3 = wave
-            float gi0[48];
+            // inter GRUs: thread (group g = tid / 16 < 8, hidden unit c) keeps the unit's three gate rows of its group's GRU (96 weights) in
+            // registers - fetched here, in flight across the LayerNorm - and walks the group's 4 sub-band rows (threads 128.. idle)
+            const int ig_ = (tid >> 4) & 7;
+            const WView wgi = wd + P::D_G + ig_ * P::G_SIZE;
+            float wi[48], wh[48];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                gi0[k] = wg0[P::G_IH + k * 48 + (tid & 15)]; gi0[16 + k] = wg0[P::G_IH + k * 48 + 16 + (tid & 15)]; gi0[32 + k] = wg0[P::G_IH + k * 48 + 32 + (tid & 15)];
+                wi[k] = wgi[P::G_IH + k * 48 + (tid & 15)]; wi[16 + k] = wgi[P::G_IH + k * 48 + 16 + (tid & 15)]; wi[32 + k] = wgi[P::G_IH + k * 48 + 32 + (tid & 15)];
+                wh[k] = wgi[P::G_HH + k * 48 + (tid & 15)]; wh[16 + k] = wgi[P::G_HH + k * 48 + 16 + (tid & 15)]; wh[32 + k] = wgi[P::G_HH + k * 48 + 32 + (tid & 15)];
             }
+            const float gb_r = wgi[P::G_GB + (tid & 15)], gb_z = wgi[P::G_GB + 16 + (tid & 15)], gb_n = wgi[P::G_GB + 32 + (tid & 15)], gb_hn = wgi[P::G_HN + (tid & 15)];
             float s0 = wave_sum(yv[0] + yv[1]);
             if (lane == 0) red[wave] = s0;
             __syncthreads();
@@ -603,36 +610,29 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
             dump(5 + 2 * blk, [&](int r, int c) { return xn[r * 16 + c]; });
             if (blk == 0) FS_CLK(10);
             // ---- inter path (InterRNNPathExtension.forward, :122-138): group g = f / 4 has its own GRU (one step per frame) and fc
+            if (tid < 128) {
+                const int c = tid & 15;
+#pragma unroll 1
+                for (int fl = 0; fl < S::FG; ++fl) {
+                    const int f = ig_ * S::FG + fl;
+                    float ir = gb_r, iz = gb_z, in_ = gb_n, hr = 0.0f, hz = 0.0f, hnn = gb_hn;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int f = (tid >> 4) + 16 * q, c = tid & 15;
-                const WView wg = wd + P::D_G + (f >> 2) * P::G_SIZE;
-                float wi[48], wh[48];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    if (q == 0) { wi[k] = gi0[k]; wi[16 + k] = gi0[16 + k]; wi[32 + k] = gi0[32 + k]; }
-                    else { wi[k] = wg[P::G_IH + k * 48 + c]; wi[16 + k] = wg[P::G_IH + k * 48 + 16 + c]; wi[32 + k] = wg[P::G_IH + k * 48 + 32 + c]; }
-                    wh[k] = wg[P::G_HH + k * 48 + c]; wh[16 + k] = wg[P::G_HH + k * 48 + 16 + c]; wh[32 + k] = wg[P::G_HH + k * 48 + 32 + c];
+                    for (int k = 0; k < 16; ++k) {
+                        const float xv = xn[f * 16 + k], hv = hprev[f * 16 + k];
+                        ir = fmaf(wi[k], xv, ir);
+                        iz = fmaf(wi[16 + k], xv, iz);
+                        in_ = fmaf(wi[32 + k], xv, in_);
+                        hr = fmaf(wh[k], hv, hr);
+                        hz = fmaf(wh[16 + k], hv, hz);
+                        hnn = fmaf(wh[32 + k], hv, hnn);
+                    }
+                    const float r = sigmoid_f(ir + hr);
+                    const float z = sigmoid_f(iz + hz);
+                    const float n = tanh_f(in_ + r * hnn);
+                    const float hnew = (1.0f - z) * n + z * hprev[f * 16 + c];
+                    hn[f * 16 + c] = hnew;
+                    a.gru[(((size_t)(blk * S::G + ig_) * a.B + b) * S::FG + fl) * S::C + c] = hnew;
                 }
-                float ir = wg[P::G_GB + c], iz = wg[P::G_GB + 16 + c], in_ = wg[P::G_GB + 32 + c];
-                float hr = 0.0f, hz = 0.0f, hnn = wg[P::G_HN + c];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const float xv = xn[f * 16 + k], hv = hprev[f * 16 + k];
-                    ir = fmaf(wi[k], xv, ir);
-                    iz = fmaf(wi[16 + k], xv, iz);
-                    in_ = fmaf(wi[32 + k], xv, in_);
-                    hr = fmaf(wh[k], hv, hr);
-                    hz = fmaf(wh[16 + k], hv, hz);
-                    hnn = fmaf(wh[32 + k], hv, hnn);
-                }
-                const float r = sigmoid_f(ir + hr);
-                const float z = sigmoid_f(iz + hz);
-                const float n = tanh_f(in_ + r * hnn);
-                const float hnew = (1.0f - z) * n + z * hprev[f * 16 + c];
-                hn[f * 16 + c] = hnew;
-                a.gru[(((size_t)(blk * S::G + (f >> 2)) * a.B + b) * S::FG + (f & 3)) * S::C + c] = hnew;
-                __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);
             float ifc_w[2][16], ifc_b[2];

@@ -798,9 +798,9 @@ def test_fspen_offline_matches_reference_golden():
     _assert_close(spec_hat.cpu().numpy(), g["offline_spec"], "offline spec")
 
 
-@pytest.mark.parametrize("B", [256, 1000])
+@pytest.mark.parametrize("B", [256, 600, 1000])
 def test_fspen_full_size(B):
-    """256 streams (one workgroup per CU) and 1000 (three per CU, then persistent): oracle parity on a sample, bitwise
+    """256 streams (one workgroup per CU), 600 (three per CU) and 1000 (persistent): oracle parity on a sample, bitwise
     position independence on all streams; chunked launch == per-hop launches"""
     m, orc, cfg, sr, seed = _fspen()
     _full_size_check(m, orc, cfg, sr, B, 3, [0, 1, 17, 255, B // 2, B - 2, B - 1], f"fspen B={B}")
