@@ -204,16 +204,13 @@ __device__ __forceinline__ float row_bcast(float v) {
 }
 
 #ifndef FS_WPE
-#define FS_WPE 3          // waves per SIMD = workgroups per CU of the register budget (168 VGPRs: what the 54 KB LDS plan allows too).
-                          // The debug instantiation (per-stage dumps) is built for 2: at 3 it needs 49 VGPR spills and computed the
-                          // feature split wrong (register-pressure dependent, not reproduced in the production instantiations, which
-                          // the parity tests cover at 2 - 8192 streams)
+#define FS_WPE 3          // waves per SIMD = workgroups per CU of the register budget (168 VGPRs: what the 54 KB LDS plan allows too)
 #endif
 
 #define FS_CLK(i) do { if constexpr (PROF) { if (blockIdx.x == 0 && threadIdx.x == 0) a.clk[(i)] = __builtin_readcyclecounter(); } } while (0)
 
 template <class S, bool PROF, bool DBG>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(DBG ? 2 : FS_WPE, DBG ? 2 : FS_WPE))) fspen_frame_kernel(FArgs a) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(FS_WPE, FS_WPE))) fspen_frame_kernel(FArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[FLds::TOTAL];
     using L = FLds;
     using P = FPk;
@@ -242,15 +239,20 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D
     int b = blockIdx.x;
 #pragma unroll 1
     do {
-    // (per-stream pointers are derived from the kernel arguments where they are used, not kept live through the frame: with ~70
-    //  spilled SGPRs a cache pointer computed here reached the iSTFT corrupted in the debug instantiation - memory fault)
+    // (per-stream pointers are derived from the kernel arguments where they are used, not kept live through the frame)
     float* dbg = DBG ? a.dbg + (size_t)b * a.dbg_stride : nullptr;
     // dump(stage, f): element (r, c) of the stage = f(r, c)
     auto dump = [&](int stage, auto&& f) {
         if constexpr (DBG) {
-            const int rows = FDebugLayout::rows(stage), cols = FDebugLayout::cols(stage);
+            const int rows = FDebugLayout::rows(stage), cols = FDebugLayout::cols(stage), n = rows * cols;
             float* dst = dbg + FDebugLayout::offset(stage);
-            for (int i = tid; i < rows * cols; i += kThreads) { const int r = i / cols, c = i - r * cols; dst[i] = f(r, c); }
+            // full trip counts and a clamped index: only the store is predicated (no long partially-executed loop bodies)
+            for (int i0_ = 0; i0_ < n; i0_ += kThreads) {
+                const int i = i0_ + tid, ic = i < n ? i : n - 1;
+                const int r = ic / cols, c = ic - r * cols;
+                const float v = f(r, c);
+                if (i < n) dst[i] = v;
+            }
         }
     };
 

@@ -178,9 +178,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
     float* dbg = DBG ? a.dbg + (size_t)b * a.dbg_stride : nullptr;
     auto dump = [&](int stage, auto&& f) {
         if constexpr (DBG) {
-            const int rows = LDebugLayout::rows(stage), cols = LDebugLayout::cols(stage);
+            const int rows = LDebugLayout::rows(stage), cols = LDebugLayout::cols(stage), n = rows * cols;
             float* dst = dbg + LDebugLayout::offset(stage);
-            for (int i = tid0; i < rows * cols; i += kThreads) { const int r = i / cols, c = i - r * cols; dst[i] = f(r, c); }
+            // full trip counts and a clamped index: only the store is predicated (no long partially-executed loop bodies)
+            for (int i0_ = 0; i0_ < n; i0_ += kThreads) {
+                const int i = i0_ + tid0, ic = i < n ? i : n - 1;
+                const int r = ic / cols, c = ic - r * cols;
+                const float v = f(r, c);
+                if (i < n) dst[i] = v;
+            }
         }
     };
     // per-stream cache pointers (cache-major state)
@@ -446,21 +452,19 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
                 for (int k = 0; k < 32; ++k) wq[k] = wd[P::B_IH + k * 36 + g36];
                 const float bq0 = wd[P::B_GB + g36], bq1 = wd[P::B_GB + 36 + g36];
-                if (tid < 252) {
+                // all 256 threads run all five rows: a row index past the end is clamped to row 31 and threads 252.. repeat rows of group 0
+                // (identical values stored twice) - no partially-executed region around register-heavy code (a VGPR spilled and
+                // reloaded inside one loses its inactive lanes: see DESIGN.md)
 #pragma unroll
-                    for (int r = 0; r < 5; ++r) {
-                        const int f = fq + 7 * r;
-                        if (f < 32) {
-                            float a0 = bq0, a1 = bq1;
+                for (int r = 0; r < 5; ++r) {
+                    const int f = (fq + 7 * r) < 32 ? (fq + 7 * r) : 31;
+                    float a0 = bq0, a1 = bq1;
 #pragma unroll
-                            for (int k = 0; k < 16; ++k) { const float xv = yn[f * 16 + k]; a0 = fmaf(wq[k], xv, a0); a1 = fmaf(wq[16 + k], xv, a1); }
-                            gi[f * 36 + g36] = a0;
-                            gi[(32 + f) * 36 + g36] = a1;
-                        }
-                    }
+                    for (int k = 0; k < 16; ++k) { const float xv = yn[f * 16 + k]; a0 = fmaf(wq[k], xv, a0); a1 = fmaf(wq[16 + k], xv, a1); }
+                    gi[f * 36 + g36] = a0;
+                    gi[(32 + f) * 36 + g36] = a1;
                 }
             }
-            // recurrence weights (all waves fetch; waves 2, 3 a copy: no conditional definitions)
             // lane = (gate row = lane / 16: r, z, n, (r again), hidden unit c = lane % 16, 12 used): one gate row of 12 weights per lane
             float wg_[12];
             const int g_row = (lane >> 4) < 3 ? (lane >> 4) : 0;
@@ -525,31 +529,31 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
                 for (int k = 0; k < 24; ++k) { wh[k] = wd[P::B_XHH + k * 72 + c]; wh[24 + k] = wd[P::B_XHH + k * 72 + 24 + c]; wh[48 + k] = wd[P::B_XHH + k * 72 + 48 + c]; }
                 const float b_r = wd[P::B_XGB + c], b_z = wd[P::B_XGB + 24 + c], b_n = wd[P::B_XGB + 48 + c], b_hn = wd[P::B_XHN + c];
-                if (tid < 240) {
+                // (uniform trip count, clamped row; threads 240.. repeat rows of group 0: identical values stored twice - see above)
 #pragma unroll 1
-                    for (int f = fg; f < 32; f += 10) {
-                        float ir = b_r, iz = b_z, in_ = b_n, hr = 0.0f, hz = 0.0f, hnn = b_hn;
+                for (int r = 0; r < 4; ++r) {
+                    const int f = (fg + 10 * r) < 32 ? (fg + 10 * r) : 31;
+                    float ir = b_r, iz = b_z, in_ = b_n, hr = 0.0f, hz = 0.0f, hnn = b_hn;
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) {
-                            const float xv = yn[f * 16 + k];
-                            ir = fmaf(wi[k], xv, ir);
-                            iz = fmaf(wi[16 + k], xv, iz);
-                            in_ = fmaf(wi[32 + k], xv, in_);
-                        }
-#pragma unroll
-                        for (int k = 0; k < 24; ++k) {
-                            const float hv = hp[f * 24 + k];
-                            hr = fmaf(wh[k], hv, hr);
-                            hz = fmaf(wh[24 + k], hv, hz);
-                            hnn = fmaf(wh[48 + k], hv, hnn);
-                        }
-                        const float r = sigmoid_f(ir + hr);
-                        const float z = sigmoid_f(iz + hz);
-                        const float n = tanh_f(in_ + r * hnn);
-                        const float hnew = (1.0f - z) * n + z * hp[f * 24 + c];
-                        hn[f * 24 + c] = hnew;
-                        ch[f * 24 + c] = hnew;
+                    for (int k = 0; k < 16; ++k) {
+                        const float xv = yn[f * 16 + k];
+                        ir = fmaf(wi[k], xv, ir);
+                        iz = fmaf(wi[16 + k], xv, iz);
+                        in_ = fmaf(wi[32 + k], xv, in_);
                     }
+#pragma unroll
+                    for (int k = 0; k < 24; ++k) {
+                        const float hv = hp[f * 24 + k];
+                        hr = fmaf(wh[k], hv, hr);
+                        hz = fmaf(wh[24 + k], hv, hz);
+                        hnn = fmaf(wh[48 + k], hv, hnn);
+                    }
+                    const float rg = sigmoid_f(ir + hr);
+                    const float z = sigmoid_f(iz + hz);
+                    const float n = tanh_f(in_ + rg * hnn);
+                    const float hnew = (1.0f - z) * n + z * hp[f * 24 + c];
+                    hn[f * 24 + c] = hnew;
+                    ch[f * 24 + c] = hnew;
                 }
             }
             __syncthreads();
