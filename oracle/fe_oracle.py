@@ -57,6 +57,13 @@ class FEConfig:
     # causal Conv2d with kernel_size_time taps over time (1 = the default model); final_scale "exp": scale.exp()
     kernel_size_time: int = 1
     final_scale_exp: bool = False
+    # models/fastenhancer/dprnn/model.py (configs/ablation/dprnn_*.yaml): the blocks' attention is a bidirectional GRU over the
+    # sub-band axis with channels_frnn hidden units per direction (0 = the default RNNFormer block); no positional embedding
+    channels_frnn: int = 0
+
+    @property
+    def dprnn(self) -> bool:
+        return self.channels_frnn > 0
 
     @property
     def time_kernel(self) -> bool:
@@ -64,7 +71,8 @@ class FEConfig:
 
     @staticmethod
     def from_model_kwargs(kw: dict) -> "FEConfig":
-        rk = dict(kw.get("rnnformer_kwargs", {}))
+        dp = "dprnn_kwargs" in kw
+        rk = dict(kw.get("dprnn_kwargs" if dp else "rnnformer_kwargs", {}))
         for flag in ("attn_bias", "post_act", "pre_norm"):
             assert not rk.get(flag, False), f"rnnformer_kwargs.{flag}=True is not restated"
         assert rk.get("p_dropout", 0.0) == 0.0
@@ -74,20 +82,21 @@ class FEConfig:
             channels=kw.get("channels", 64),
             kernel_size=tuple(kw["kernel_size_freq"]) if "kernel_size_freq" in kw else tuple(kw.get("kernel_size", (8, 3, 3))),
             kernel_size_time=int(kw.get("kernel_size_time", 3)) if "kernel_size_freq" in kw else 1,
-            final_scale_exp=("kernel_size_freq" in kw and kw.get("final_scale", "exp") == "exp"),
+            final_scale_exp=(("kernel_size_freq" in kw or dp) and kw.get("final_scale", "exp") == "exp"),
+            channels_frnn=int(rk.get("channels_frnn", 16)) if dp else 0,
             stride=kw.get("stride", 4),
             rf_blocks=rk.get("num_blocks", 3),
             rf_channels=rk.get("channels", 32),
             rf_freq=rk.get("freq", 32),
             rf_heads=rk.get("num_heads", 4),
-            rf_eps=rk.get("eps", 1e-8),
+            rf_eps=rk.get("eps", 1e-5 if dp else 1e-8),
             n_fft=kw.get("n_fft", 512),
             hop_size=kw.get("hop_size", 256),
             win_size=kw.get("win_size", 512),
             input_compression=kw.get("input_compression", 0.3),
             activation=kw.get("activation", "ReLU"),
             mask=kw.get("mask", None),
-            positional_embedding=rk.get("positional_embedding", "train"),
+            positional_embedding=None if dp else rk.get("positional_embedding", "train"),
             pre_post_init=kw.get("pre_post_init", None),
             normalize_final_conv=kw.get("normalize_final_conv", False),
             weight_norm=kw.get("weight_norm", False),
@@ -115,7 +124,11 @@ class FEConfig:
         for k in self.kernel_size[1:]:
             m += C1 * C1 * k * self.kernel_size_time * F1
         m += F1 * F2 * C1 + C1 * C2 * F2
-        m += K * (C2 * C2 * 6 * F2 + C2 * C2 * F2 + C2 * C2 * 3 * F2 + 2 * F2 * C2 * F2 + C2 * C2 * F2)
+        if self.dprnn:      # time GRU + fc, then the BiGRU over the F2 sub-bands (input and hidden products of both directions) + fc
+            H = self.channels_frnn
+            m += K * (C2 * C2 * 6 * F2 + C2 * C2 * F2 + 2 * 3 * H * (C2 + H) * F2 + 2 * H * C2 * F2)
+        else:
+            m += K * (C2 * C2 * 6 * F2 + C2 * C2 * F2 + C2 * C2 * 3 * F2 + 2 * F2 * C2 * F2 + C2 * C2 * F2)
         m += F2 * F1 * C2 + C2 * C1 * F1
         for k in self.kernel_size[1:]:
             m += 2 * C1 * C1 * F1 + C1 * C1 * k * self.kernel_size_time * F1
@@ -233,6 +246,20 @@ def mhsa(x: Array, w_qkv: Array, num_heads: int) -> Array:
     return o.transpose(0, 2, 1, 3).reshape(M, F, C)
 
 
+def bigru_over_rows(x: Array, w: Dict[str, Array], p: str) -> Array:
+    """nn.GRU(C, H, bidirectional=True, batch_first=True) over axis 1 with zero initial state
+    (DPRNN.forward, models/fastenhancer/dprnn/model.py:239-241).  x [M,F,C] -> [M,F,2H] (forward | reverse)."""
+    M, F, _ = x.shape
+    H = w[p + "weight_hh_l0"].shape[1]
+    out = np.empty((M, F, 2 * H), x.dtype)
+    for d, sfx in enumerate(("", "_reverse")):
+        h = np.zeros((M, H), x.dtype)
+        for f in (range(F) if d == 0 else range(F - 1, -1, -1)):
+            h = gru_step(x[:, f], h, w[p + "weight_ih_l0" + sfx], w[p + "weight_hh_l0" + sfx], w[p + "bias_ih_l0" + sfx], w[p + "bias_hh_l0" + sfx])
+            out[:, f, d * H:(d + 1) * H] = h
+    return out
+
+
 # --------------------------------------------------------------------------- weight transform
 def linear_filterbank(n_freq: int, n_filter: int) -> Tuple[Array, Array]:
     """rf_pre_post_lin with init 'linear*', models/fastenhancer/default/model.py:308-380.
@@ -309,6 +336,25 @@ def _weight_norm(g: Array, v: Array) -> Array:
     return (v * (g.reshape(norm.shape) / norm)).astype(np.float32)
 
 
+# models/fastenhancer/dprnn/model.py:412-436 module names <-> this file's (rf_pre / rf_block / rf_post, rnn = trnn)
+_DPRNN_NAMES = (("dprnn_pre.", "rf_pre."), ("dprnn_post.", "rf_post."), ("dprnn_block.", "rf_block."), (".trnn_fc.", ".rnn_fc."),
+                (".trnn_post_norm.", ".rnn_post_norm."), (".trnn.", ".rnn."))
+
+
+def canonical_key(k: str) -> str:
+    for a, b in _DPRNN_NAMES:
+        k = k.replace(a, b)
+    return k
+
+
+def reference_key(k: str, cfg: "FEConfig") -> str:
+    """this file's state_dict key -> the reference module's (they differ for the dprnn variant only)"""
+    if cfg.dprnn:
+        for a, b in _DPRNN_NAMES:
+            k = k.replace(b, a)
+    return k
+
+
 def fold_state_dict(sd: Dict[str, Array], cfg: FEConfig) -> Dict[str, Array]:
     """ONNXModel.remove_weight_reparameterizations,
     models/fastenhancer/default/model.py:532-608 (+ :215-231 for the RNNFormer
@@ -316,6 +362,8 @@ def fold_state_dict(sd: Dict[str, Array], cfg: FEConfig) -> Dict[str, Array]:
     state_dict and returns the fused-form dict.  A dict that
     is already fused (has 'enc_pre.0.bias') is returned unchanged (as float32)."""
     sd = {k: np.asarray(v) for k, v in sd.items()}
+    if cfg.dprnn:
+        sd = {canonical_key(k): v for k, v in sd.items()}
     if "enc_pre.0.bias" in sd:
         return {k: v.astype(np.float32) for k, v in sd.items() if v.dtype.kind == "f"}
     out: Dict[str, Array] = {}
@@ -344,12 +392,22 @@ def fold_state_dict(sd: Dict[str, Array], cfg: FEConfig) -> Dict[str, Array]:
                 out[p + "rnn." + name] = sd[p + "rnn." + name].astype(np.float32)
         out[p + "rnn.bias_ih_l0"] = sd[p + "rnn.bias_ih_l0"].astype(np.float32)
         out[p + "rnn.bias_hh_l0"] = sd[p + "rnn.bias_hh_l0"].astype(np.float32)
-        key0 = p + "attn.qkv.parametrizations.weight.original0"
-        if key0 in sd:
-            out[p + "attn.qkv.weight"] = _weight_norm(sd[key0], sd[p + "attn.qkv.parametrizations.weight.original1"])
+        if cfg.dprnn:      # DPRNN.remove_weight_reparameterizations, dprnn/model.py:172-192
+            for name in ("weight_ih_l0", "weight_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse"):
+                key0 = p + f"frnn.parametrizations.{name}.original0"
+                if key0 in sd:
+                    out[p + "frnn." + name] = _weight_norm(sd[key0], sd[p + f"frnn.parametrizations.{name}.original1"])
+                else:
+                    out[p + "frnn." + name] = sd[p + "frnn." + name].astype(np.float32)
+            for name in ("bias_ih_l0", "bias_hh_l0", "bias_ih_l0_reverse", "bias_hh_l0_reverse"):
+                out[p + "frnn." + name] = sd[p + "frnn." + name].astype(np.float32)
         else:
-            out[p + "attn.qkv.weight"] = sd[p + "attn.qkv.weight"].astype(np.float32)
-        for fc, norm in (("rnn_fc", "rnn_post_norm"), ("attn_fc", "attn_post_norm")):
+            key0 = p + "attn.qkv.parametrizations.weight.original0"
+            if key0 in sd:
+                out[p + "attn.qkv.weight"] = _weight_norm(sd[key0], sd[p + "attn.qkv.parametrizations.weight.original1"])
+            else:
+                out[p + "attn.qkv.weight"] = sd[p + "attn.qkv.weight"].astype(np.float32)
+        for fc, norm in (("rnn_fc", "rnn_post_norm"), ("frnn_fc", "frnn_post_norm")) if cfg.dprnn else (("rnn_fc", "rnn_post_norm"), ("attn_fc", "attn_post_norm")):
             std = np.sqrt(sd[p + norm + ".running_var"].astype(np.float32) + np.float32(cfg.rf_eps))
             g = sd[p + norm + ".weight"] / std
             out[p + fc + ".weight"] = (sd[p + fc + ".weight"] * g.reshape(-1, 1)).astype(np.float32)
@@ -412,6 +470,20 @@ def training_state_dict_spec(cfg: FEConfig) -> Dict[str, Tuple[int, ...]]:
             spec[p + "rnn.weight_hh_l0"] = (3 * C2, C2)
         spec[p + "rnn_fc.weight"] = (C2, C2)
         bn(p + "rnn_post_norm", C2)
+        if cfg.dprnn:      # nn.GRU(bidirectional) registers biases first, then the (parametrized) weights, like the time GRU
+            H = cfg.channels_frnn
+            for sfx in ("", "_reverse"):
+                spec[p + "frnn.bias_ih_l0" + sfx] = (3 * H,)
+                spec[p + "frnn.bias_hh_l0" + sfx] = (3 * H,)
+            for name, cols in (("weight_ih_l0", C2), ("weight_hh_l0", H), ("weight_ih_l0_reverse", C2), ("weight_hh_l0_reverse", H)):
+                if cfg.weight_norm:
+                    spec[p + f"frnn.parametrizations.{name}.original0"] = (3 * H, 1)
+                    spec[p + f"frnn.parametrizations.{name}.original1"] = (3 * H, cols)
+                else:
+                    spec[p + "frnn." + name] = (3 * H, cols)
+            spec[p + "frnn_fc.weight"] = (C2, 2 * H)
+            bn(p + "frnn_post_norm", C2)
+            continue
         if cfg.weight_norm:
             spec[p + "attn.qkv.parametrizations.weight.original0"] = (3 * C2, 1)
             spec[p + "attn.qkv.parametrizations.weight.original1"] = (3 * C2, C2)
@@ -550,8 +622,12 @@ class FEOracle:
                 x = x + w[p + "pe"]
             if taps is not None:
                 taps[f"rf_block.{k}.rnn"] = x.copy()
-            a = mhsa(x.reshape(T * B, F2, C2), w[p + "attn.qkv.weight"], c.rf_heads)
-            a = a @ w[p + "attn_fc.weight"].T + w[p + "attn_fc.bias"]
+            if c.dprnn:
+                a = bigru_over_rows(x.reshape(T * B, F2, C2), w, p + "frnn.")
+                a = a @ w[p + "frnn_fc.weight"].T + w[p + "frnn_fc.bias"]
+            else:
+                a = mhsa(x.reshape(T * B, F2, C2), w[p + "attn.qkv.weight"], c.rf_heads)
+                a = a @ w[p + "attn_fc.weight"].T + w[p + "attn_fc.bias"]
             x = a.reshape(T, B, F2, C2) + x
             if taps is not None:
                 taps[f"rf_block.{k}"] = x.copy()

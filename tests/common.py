@@ -29,6 +29,16 @@ def _kw_tk(C1, ksf, kt, C2, F2, K, N, H, init, eps=1.0e-5):
     return kw
 
 
+def _kw_dprnn(C1, ks, C2, H2, F2, K, N, H):
+    """configs/ablation/dprnn_b.yaml:2-27 (model: fastenhancer.dprnn)"""
+    return dict(
+        channels=C1, kernel_size=list(ks), stride=4,
+        dprnn_kwargs=dict(num_blocks=K, channels=C2, channels_frnn=H2, freq=F2, eps=1.0e-5, pre_norm=False),
+        pre_post_init="linear_fixed", n_fft=N, hop_size=H, win_size=N, window="hann", stft_normalized=False,
+        mask=None, activation="SiLU", activation_kwargs=dict(inplace=True), input_compression=0.3, final_scale=True,
+        normalize_final_conv=True, weight_norm=True)
+
+
 # name -> (model_kwargs, sampling rate, golden seed)
 MODEL_KWARGS = {
     "fe_t": (_kw(24, (8, 3, 3), 20, 16, 2, 512, 256, "linear_fixed"), 16000, 101),
@@ -43,9 +53,15 @@ MODEL_KWARGS = {
     "fe48_l": (_kw(128, (8, 3, 3, 3, 3), 96, 96, 5, 1024, 200, "linear"), 48000, 110),
     "fe48_b_h480": (_kw(48, (8, 3, 3), 36, 36, 3, 1024, 480, "linear"), 48000, 111),   # BASELINE config 4's "hop=480"
     "fe_tk_b": (_kw_tk(48, (8, 3, 3), 3, 36, 24, 3, 512, 256, "linear_fixed"), 16000, 120),   # configs/ablation/time_kernel_b.yaml
+    # configs/ablation/dprnn_{t,b,s,m,l}.yaml
+    "fe_dprnn_t": (_kw_dprnn(24, (8, 3, 3), 20, 10, 16, 2, 512, 256), 16000, 130),
+    "fe_dprnn_b": (_kw_dprnn(48, (8, 3, 3), 36, 18, 24, 3, 512, 256), 16000, 131),
+    "fe_dprnn_s": (_kw_dprnn(64, (8, 3, 3, 3), 48, 24, 36, 3, 512, 256), 16000, 133),
+    "fe_dprnn_m": (_kw_dprnn(96, (8, 3, 3, 3), 72, 36, 48, 4, 512, 160), 16000, 134),
+    "fe_dprnn_l": (_kw_dprnn(128, (8, 3, 3, 3, 3), 96, 48, 64, 5, 512, 100), 16000, 132),
 }
 # which module of the reference a name belongs to (the yaml's `model:` key)
-MODEL_MODULE = {name: "fastenhancer.default" for name in MODEL_KWARGS}
+MODEL_MODULE = {name: ("fastenhancer.dprnn" if "dprnn" in name else "fastenhancer.default") for name in MODEL_KWARGS}
 MODEL_MODULE["fe_tk_b"] = "fastenhancer.time_kernel"
 
 

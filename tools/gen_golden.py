@@ -35,7 +35,7 @@ import yaml
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
-from oracle.fe_oracle import (FEConfig, fold_state_dict, linear_filterbank, linear_filterbank_tk, stft_windows,  # noqa: E402
+from oracle.fe_oracle import (FEConfig, canonical_key, fold_state_dict, reference_key, linear_filterbank, linear_filterbank_tk, stft_windows,  # noqa: E402
                               training_state_dict_spec)
 from oracle.weightgen import make_input, make_training_state_dict  # noqa: E402
 
@@ -79,6 +79,10 @@ CONFIGS = {
     "fe48_b_h480": ("configs/fastenhancer_48khz/b.yaml", 111, 2, 8, 0, {"hop_size": 480}),
     # the time_kernel ablation (causal Conv2d with a 3-frame time kernel and (kt-1)-frame caches)
     "fe_tk_b": ("configs/ablation/time_kernel_b.yaml", 120, 2, 10, 120),
+    # the dprnn ablation (models/fastenhancer/dprnn): a bidirectional GRU over the sub-bands instead of the attention
+    "fe_dprnn_t": ("configs/ablation/dprnn_t.yaml", 130, 2, 10, 0),
+    "fe_dprnn_b": ("configs/ablation/dprnn_b.yaml", 131, 2, 10, 120),
+    "fe_dprnn_l": ("configs/ablation/dprnn_l.yaml", 132, 1, 5, 0),
 }
 
 
@@ -103,17 +107,19 @@ def gen_fastenhancer(ref: str, name: str, out_dir: str):
     model = mod.Model(**kw).eval()           # offline, training form
     ref_sd = model.state_dict()
     spec = training_state_dict_spec(cfg)
+    spec = {reference_key(k, cfg): v for k, v in spec.items()}
     assert list(ref_sd.keys()) == list(spec.keys()), (
         "state_dict schema drifted", [k for k in ref_sd if k not in spec], [k for k in spec if k not in ref_sd])
     for k, v in ref_sd.items():
         assert tuple(v.shape) == tuple(spec[k]), (k, v.shape, spec[k])
     sd = make_training_state_dict(cfg, seed)
-    model.load_state_dict(to_t(sd), strict=True)
+    sd_ref_names = {reference_key(k, cfg): v for k, v in sd.items()}
+    model.load_state_dict(to_t(sd_ref_names), strict=True)
 
     onnx_model = mod.ONNXModel(**kw).eval()  # streaming
-    onnx_model.load_state_dict(to_t(sd), strict=True)
+    onnx_model.load_state_dict(to_t(sd_ref_names), strict=True)
     onnx_model.remove_weight_reparameterizations()
-    fused_ref = {k: v.detach().numpy().copy() for k, v in onnx_model.state_dict().items()}
+    fused_ref = {canonical_key(k): v.detach().numpy().copy() for k, v in onnx_model.state_dict().items()}
 
     # ---- fold check (a20): my restatement vs the reference's fused state_dict
     fused_mine = fold_state_dict(sd, cfg)
@@ -132,9 +138,9 @@ def gen_fastenhancer(ref: str, name: str, out_dir: str):
     # fixed filterbank formula
     if kw.get("pre_post_init", None) == "linear_fixed":
         fresh = mod.ONNXModel(**kw)
-        pre, post = (linear_filterbank_tk if tk else linear_filterbank)(cfg.F1, cfg.rf_freq)
-        assert np.abs(pre - fresh.rf_pre[0].weight.numpy()).max() < 1e-5
-        assert np.abs(post - fresh.rf_post[0].weight.numpy()).max() < 1e-5
+        pre, post = (linear_filterbank_tk if tk or cfg.dprnn else linear_filterbank)(cfg.F1, cfg.rf_freq)
+        assert np.abs(pre - (fresh.dprnn_pre if cfg.dprnn else fresh.rf_pre)[0].weight.numpy()).max() < 1e-5
+        assert np.abs(post - (fresh.dprnn_post if cfg.dprnn else fresh.rf_post)[0].weight.numpy()).max() < 1e-5
 
     out = {"seed": np.int64(seed), "B": np.int64(B), "hops": np.int64(hops), "sr": np.int64(sr),
            "fold_worst_rel": np.float64(worst)}
