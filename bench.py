@@ -66,6 +66,11 @@ WORKLOADS = {
                  desc="FastEnhancer_L 16kHz"),
     "fe_tk_b": dict(C1=48, ks=(8, 3, 3), kt=3, C2=36, F2=24, K=3, N=512, H=256, sr=16000, init="linear_fixed",
                     desc="FastEnhancer_B with a 3-frame causal time kernel (configs/ablation/time_kernel_b.yaml)"),
+    # the dprnn ablation (configs/ablation/dprnn_{t,b,l}.yaml): a bidirectional GRU over the sub-bands instead of the attention
+    "fe_dprnn_t": dict(C1=24, ks=(8, 3, 3), frnn=10, C2=20, F2=16, K=2, N=512, H=256, sr=16000, init="linear_fixed", desc="FastEnhancer_T, dprnn blocks"),
+    "fe_dprnn_b": dict(C1=48, ks=(8, 3, 3), frnn=18, C2=36, F2=24, K=3, N=512, H=256, sr=16000, init="linear_fixed", desc="FastEnhancer_B, dprnn blocks"),
+    "fe_dprnn_l": dict(C1=128, ks=(8, 3, 3, 3, 3), frnn=48, C2=96, F2=64, K=5, N=512, H=100, sr=16000, init="linear_fixed",
+                       desc="FastEnhancer_L, dprnn blocks"),
 }
 
 
@@ -79,6 +84,11 @@ def model_kwargs(w):
     if w.get("bsrnn"):
         return dict(num_channels=w["C"], num_layers=w["L"], bias=True, affine=True, n_fft=w["N"], hop_size=w["H"], win_size=w["N"],
                     window="hann", input_compression=0.3)
+    if w.get("frnn"):
+        kw = model_kwargs({k: v for k, v in w.items() if k != "frnn"})
+        del kw["rnnformer_kwargs"], kw["resnet"]
+        kw.update(dprnn_kwargs=dict(num_blocks=w["K"], channels=w["C2"], channels_frnn=w["frnn"], freq=w["F2"], eps=1e-5, pre_norm=False), final_scale=True)
+        return kw
     if w.get("kt"):
         kw = model_kwargs({k: v for k, v in w.items() if k != "kt"})
         del kw["kernel_size"], kw["resnet"]
@@ -307,6 +317,9 @@ def main():
     elif w.get("kt"):
         from fastenhancer_amd.config import time_kernel_config
         cfg = time_kernel_config(**kw)
+    elif w.get("frnn"):
+        from fastenhancer_amd.config import dprnn_config
+        cfg = dprnn_config(**kw)
     else:
         cfg = FEConfig.from_model_kwargs(**kw)
     eng = Engine(cfg, dev)
@@ -450,7 +463,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline_fspen(kw, w["sr"], B, args.cpu_budget_s, lisennet=bool(w.get("lisennet")))
         elif world == 1 and not args.no_cpu_baseline and w.get("bsrnn"):
             res["cpu_baseline"] = cpu_baseline_bsrnn(args.workload, kw, w["sr"], B, args.cpu_budget_s)
-        elif world == 1 and not args.no_cpu_baseline and not w.get("kt"):
+        elif world == 1 and not args.no_cpu_baseline and not w.get("kt") and not w.get("frnn"):
             res["cpu_baseline"] = cpu_baseline(args.workload, kw, w["sr"], B, args.cpu_budget_s)
         print(json.dumps(res), flush=True)
     if use_dist:

@@ -62,10 +62,10 @@ def add_shape(spec: str) -> str:
     kernel_size_time) -> a line in the local shape list.  The kernel template's constraints are checked here with a
     readable message (hipcc would report them as failed static_asserts): stride 4 and kernel_size [8, 3, ...] are fixed."""
     v = [int(x) for x in spec.replace(" ", "").split(",")]
-    if len(v) not in (7, 8):
-        raise SystemExit("--add-shape wants C1,NL,C2,F2,KB,NFFT,HOP[,KT]")
+    if len(v) not in (7, 8, 10):
+        raise SystemExit("--add-shape wants C1,NL,C2,F2,KB,NFFT,HOP[,KT[,0,FR]]  (FR = 1: the dprnn variant)")
     C1, NL, C2, F2, KB, NFFT, HOP = v[:7]
-    KT = v[7] if len(v) == 8 else 1
+    KT = v[7] if len(v) >= 8 else 1
     errs = []
     if C1 % 4 or C2 % 4 or F2 % 4:
         errs.append("channels, rnnformer channels and rnnformer freq must be multiples of 4")

@@ -30,6 +30,13 @@ class FEConfig:
     # are causal Conv2d with kernel_size_time taps over time and (kernel_size_time - 1)-frame input caches; 1 = the default model
     kernel_size_time: int = 1
     final_scale_exp: bool = False        # final_scale: "exp" (the final conv's scale parameter is stored as its log)
+    # `model: fastenhancer.dprnn` (models/fastenhancer/dprnn/model.py): the blocks' attention is a bidirectional GRU over the
+    # sub-bands with channels_frnn hidden units per direction; 0 = the default RNNFormer block
+    channels_frnn: int = 0
+
+    @property
+    def dprnn(self) -> bool:
+        return self.channels_frnn > 0
 
     @property
     def time_kernel(self) -> bool:
@@ -133,6 +140,32 @@ def time_kernel_config(channels: int = 64, kernel_size_freq: Sequence[int] = (8,
                                       normalize_final_conv=normalize_final_conv, pre_post_init=pre_post_init, resnet=False)
     import dataclasses
     return dataclasses.replace(base, kernel_size_time=int(kernel_size_time), final_scale_exp=(final_scale == "exp"))
+
+
+def dprnn_config(channels: int = 64, kernel_size: Sequence[int] = (8, 3, 3), stride: int = 4, dprnn_kwargs: Optional[Dict[str, Any]] = None,
+                 activation: str = "ReLU", activation_kwargs: Optional[Dict[str, Any]] = None, n_fft: int = 512, hop_size: int = 256,
+                 win_size: int = 512, window: Optional[str] = "hann", stft_normalized: bool = False, mask: Optional[str] = None,
+                 input_compression: float = 0.3, weight_norm: bool = False, final_scale: Any = "exp", normalize_final_conv: bool = False,
+                 pre_post_init: Optional[str] = None) -> FEConfig:
+    """yaml model_kwargs of `model: fastenhancer.dprnn` (configs/ablation/dprnn_b.yaml:2-27; defaults of
+    models/fastenhancer/dprnn/model.py:327-357) -> FEConfig with channels_frnn set."""
+    if final_scale not in (True, False, "exp"):
+        raise AssertionError(f"final_scale={final_scale}")
+    dk = dict(dprnn_kwargs or {})
+    if dk.get("pre_norm", False):
+        raise RuntimeError("dprnn_kwargs.pre_norm=True is not supported by the HIP path (shipped: False).")
+    C2, H = int(dk.get("channels", 32)), int(dk.get("channels_frnn", 16))
+    if 2 * H != C2:
+        raise RuntimeError(f"dprnn_kwargs.channels_frnn={H} is not supported by the HIP path: the kernels are built for "
+                           f"channels_frnn = channels / 2 (every shipped dprnn yaml; channels={C2}).")
+    rk = dict(num_blocks=dk.get("num_blocks", 3), channels=C2, freq=dk.get("freq", 32), num_heads=4, eps=dk.get("eps", 1e-5))
+    base = FEConfig.from_model_kwargs(channels=channels, kernel_size=kernel_size, stride=stride, rnnformer_kwargs=rk,
+                                      activation=activation, activation_kwargs=activation_kwargs, n_fft=n_fft, hop_size=hop_size,
+                                      win_size=win_size, window=window, stft_normalized=stft_normalized, mask=mask,
+                                      input_compression=input_compression, weight_norm=weight_norm,
+                                      normalize_final_conv=normalize_final_conv, pre_post_init=pre_post_init, resnet=False)
+    import dataclasses
+    return dataclasses.replace(base, channels_frnn=H, positional_embedding=None, final_scale_exp=(final_scale == "exp"))
 
 
 BSRNN_SUBBANDS = (2,) + (3,) * 10 + (8,) * 12 + (16,) * 7 + (17,)     # models/bsrnn/model.py:107-111

@@ -49,6 +49,7 @@ struct Dims {
     int C1, NL, C2, F2, KB, NFFT, HOP, F0, F1, HD;
     int ks[FE_MAX_KERNELS];
     int KT = 1;                // kernel_size_time (time_kernel variant)
+    int FR = 0;                // 1: dprnn variant (sub-band GRU of C2 / 2 hidden units per direction instead of the attention)
 };
 
 // ---------------------------------------------------------------------------- dispatch table
@@ -136,13 +137,25 @@ void build_sections(fe_handle* h) {
     add_section(h, "rf_pre.1.bias", {d.C2});
     for (int k = 0; k < d.KB; ++k) {
         auto key = [&](const char* s) { snprintf(nm, sizeof nm, "rf_block.%d.%s", k, s); return std::string(nm); };
-        if (k == 0) add_section(h, key("pe"), {d.F2, d.C2});
+        if (k == 0 && !d.FR) add_section(h, key("pe"), {d.F2, d.C2});
         add_section(h, key("rnn.weight_ih_l0"), {3 * d.C2, d.C2});
         add_section(h, key("rnn.weight_hh_l0"), {3 * d.C2, d.C2});
         add_section(h, key("rnn.bias_ih_l0"), {3 * d.C2});
         add_section(h, key("rnn.bias_hh_l0"), {3 * d.C2});
         add_section(h, key("rnn_fc.weight"), {d.C2, d.C2});
         add_section(h, key("rnn_fc.bias"), {d.C2});
+        if (d.FR) {     // DPRNN's fused state_dict (models/fastenhancer/dprnn/model.py:159-161), module names as the default model's
+            const int H = d.C2 / 2;
+            for (const char* sfx : {"", "_reverse"}) {
+                add_section(h, key((std::string("frnn.weight_ih_l0") + sfx).c_str()), {3 * H, d.C2});
+                add_section(h, key((std::string("frnn.weight_hh_l0") + sfx).c_str()), {3 * H, H});
+                add_section(h, key((std::string("frnn.bias_ih_l0") + sfx).c_str()), {3 * H});
+                add_section(h, key((std::string("frnn.bias_hh_l0") + sfx).c_str()), {3 * H});
+            }
+            add_section(h, key("frnn_fc.weight"), {d.C2, d.C2});
+            add_section(h, key("frnn_fc.bias"), {d.C2});
+            continue;
+        }
         add_section(h, key("attn.qkv.weight"), {3 * d.C2, d.C2});
         add_section(h, key("attn_fc.weight"), {d.C2, d.C2});
         add_section(h, key("attn_fc.bias"), {d.C2});
@@ -284,6 +297,32 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
         }
         pack_1x1(o.blk_fc1_w[k], S(key("rnn_fc.weight")), C2, C2);
         p.raw(o.blk_fc1_b[k], C2, S(key("rnn_fc.bias")));
+        if (d.FR) {
+            // sub-band GRU: the input weights of both directions as one (3 C2)-column matrix [direction][r|z|n][unit] in the qkv
+            // slot, its bias = b_ih + (r, z only) b_hh; hidden weights [direction][j][gate][unit]; b_hn.  (The block has no
+            // positional embedding: blk_pe stays zero.)
+            const int H = C2 / 2;
+            std::vector<float> wih((size_t)3 * C2 * C2), bi((size_t)3 * C2);
+            for (int dir = 0; dir < 2; ++dir) {
+                const char* sfx = dir ? "_reverse" : "";
+                const float* w = S(key((std::string("frnn.weight_ih_l0") + sfx).c_str()));
+                const float* whh = S(key((std::string("frnn.weight_hh_l0") + sfx).c_str()));
+                const float* bih = S(key((std::string("frnn.bias_ih_l0") + sfx).c_str()));
+                const float* bhh = S(key((std::string("frnn.bias_hh_l0") + sfx).c_str()));
+                std::copy(w, w + (size_t)3 * H * C2, wih.begin() + (size_t)dir * 3 * H * C2);
+                for (int r = 0; r < 3 * H; ++r) bi[(size_t)dir * 3 * H + r] = bih[r] + (r < 2 * H ? bhh[r] : 0.0f);
+                float* dst = p.buf.data() + o.blk_fhh[k] + (size_t)dir * H * 3 * H;
+                for (int j = 0; j < H; ++j)
+                    for (int g = 0; g < 3; ++g)
+                        for (int u = 0; u < H; ++u) dst[((size_t)j * 3 + g) * H + u] = whh[((size_t)g * H + u) * H + j];
+                for (int u = 0; u < H; ++u) p.buf[o.blk_fbhn[k] + (size_t)dir * H + u] = bhh[2 * H + u];
+            }
+            pack_1x1(o.blk_qkv[k], wih.data(), C2, 3 * C2);
+            p.raw(o.blk_qkv_b[k], 3 * C2, bi.data());
+            pack_1x1(o.blk_fc2_w[k], S(key("frnn_fc.weight")), C2, C2);
+            p.raw(o.blk_fc2_b[k], C2, S(key("frnn_fc.bias")));
+            continue;
+        }
         if (k == 0) p.raw(o.blk_pe, (size_t)F2 * C2, S(key("pe")));
         pack_1x1(o.blk_qkv[k], S(key("attn.qkv.weight")), C2, 3 * C2);
         pack_1x1(o.blk_fc2_w[k], S(key("attn_fc.weight")), C2, C2);
@@ -1107,21 +1146,25 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
 
     const fe::Impl* impl = nullptr;
     const int kt = cfg->kernel_size_time > 1 ? cfg->kernel_size_time : 1;
+    const int fr = cfg->channels_frnn > 0 ? 1 : 0;
+    if (fr && 2 * cfg->channels_frnn != cfg->rf_channels)
+        return fail(FE_ERR_UNSUPPORTED_CONFIG, "channels_frnn=%d with channels=%d (the dprnn kernels are built for channels_frnn = channels / 2, every shipped yaml)",
+                    cfg->channels_frnn, cfg->rf_channels);
     for (const fe::Impl* im : impls())
         if (im->C1 == cfg->channels && im->NL == cfg->n_kernels - 1 && im->C2 == cfg->rf_channels && im->F2 == cfg->rf_freq &&
-            im->KB == cfg->rf_blocks && im->NFFT == cfg->n_fft && im->HOP == cfg->hop_size && im->KT == kt && im->LOW == 0)
+            im->KB == cfg->rf_blocks && im->NFFT == cfg->n_fft && im->HOP == cfg->hop_size && im->KT == kt && im->LOW == 0 && im->FR == fr)
             impl = im;
     const fe::Impl* impl_many = nullptr;
     for (const fe::Impl* im : impls())
         if (impl && im->LOW >= 1 && im->occ >= 2 && im->C1 == impl->C1 && im->NL == impl->NL && im->C2 == impl->C2 && im->F2 == impl->F2 &&
-            im->KB == impl->KB && im->NFFT == impl->NFFT && im->HOP == impl->HOP && im->KT == impl->KT)
+            im->KB == impl->KB && im->NFFT == impl->NFFT && im->HOP == impl->HOP && im->KT == impl->KT && im->FR == impl->FR)
             impl_many = im;
     if (!impl)
         return fail(FE_ERR_UNSUPPORTED_CONFIG,
-                    "no kernel compiled for channels=%d layers=%d rf_channels=%d rf_freq=%d rf_blocks=%d n_fft=%d hop=%d kernel_size_time=%d "
-                    "(build it: python -m fastenhancer_amd.build --add-shape %d,%d,%d,%d,%d,%d,%d,%d)",
-                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, kt,
-                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, kt);
+                    "no kernel compiled for channels=%d layers=%d rf_channels=%d rf_freq=%d rf_blocks=%d n_fft=%d hop=%d kernel_size_time=%d%s "
+                    "(build it: python -m fastenhancer_amd.build --add-shape %d,%d,%d,%d,%d,%d,%d,%d%s)",
+                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, kt, fr ? " dprnn" : "",
+                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, kt, fr ? ",0,1" : "");
     if (impl->lds_bytes > 160 * 1024)
         return fail(FE_ERR_UNSUPPORTED_CONFIG, "shape needs %zu bytes of LDS (> 160 KiB per CU)", impl->lds_bytes);
     fe_handle* h = new fe_handle();
@@ -1130,6 +1173,7 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
     h->impl_many = std::getenv("FE_NO_LOWLDS") ? nullptr : impl_many;      // (FE_NO_LOWLDS: A/B switch of tools/ab_lowlds.sh)
     h->d = Dims{impl->C1, impl->NL, impl->C2, impl->F2, impl->KB, impl->NFFT, impl->HOP, impl->NFFT / 2, impl->NFFT / 8, impl->C2 / 4, {0}};
     h->d.KT = impl->KT;
+    h->d.FR = impl->FR;
     for (int i = 0; i < cfg->n_kernels; ++i) h->d.ks[i] = cfg->kernel_size[i];
     if (hipGetDevice(&h->device) != hipSuccess) h->device = -1;   // no GPU: sections/tables still usable
     else {
@@ -1612,6 +1656,10 @@ double fe_flops_per_frame(const fe_handle* h) {
     double m = 2 * C1 * 8 * F1;
     for (int i = 1; i <= d.NL; ++i) m += C1 * C1 * 3 * KT * F1;
     m += F1 * F2 * C1 + C1 * C2 * F2;
+    if (d.FR) {       // time GRU + fc, then the sub-band GRU (input and hidden products of both directions) + fc
+        const double H = C2 / 2;
+        m += K * (C2 * C2 * 6 * F2 + C2 * C2 * F2 + 2 * 3 * H * (C2 + H) * F2 + 2 * H * C2 * F2);
+    } else
     m += K * (C2 * C2 * 6 * F2 + C2 * C2 * F2 + C2 * C2 * 3 * F2 + 2 * F2 * C2 * F2 + C2 * C2 * F2);
     m += F2 * F1 * C2 + C2 * C1 * F1;
     for (int i = 1; i <= d.NL; ++i) m += 2 * C1 * C1 * F1 + C1 * C1 * 3 * KT * F1;

@@ -12,7 +12,7 @@ namespace fe {
 constexpr int kMaxDevices = 64;
 
 struct Impl {
-    int C1, NL, C2, F2, KB, NFFT, HOP, KT, LOW;
+    int C1, NL, C2, F2, KB, NFFT, HOP, KT, LOW, FR;
     size_t lds_bytes;
     int occ;              // resident workgroups per CU
     bool many_persist;    // companion: also used beyond occ x #CUs streams (persistent workgroups)
@@ -90,7 +90,7 @@ void dbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
 
 template <class S>
 Impl make_impl() {
-    return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, S::KT, S::LOW, Lds<S>::BYTES, Lds<S>::OCC, Lds<S>::MANY_PERSIST, S::NU, Pack<S>::umax(), Lds<S>::STAGED,
+    return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, S::KT, S::LOW, S::FRNN ? 1 : 0, Lds<S>::BYTES, Lds<S>::OCC, Lds<S>::MANY_PERSIST, S::NU, Pack<S>::umax(), Lds<S>::STAGED,
                 Lds<S>::SKIPS_LDS ? (size_t)0 : (size_t)(S::NL + 1) * S::F1 * S::C1,
                 DebugLayout<S>::total(), DebugLayout<S>::n_stages, &Pack<S>::v, &launch_impl<S>, &launch_pipe_impl<S>, &dbg_stage_impl<S>};
 }

@@ -49,9 +49,13 @@ __host__ __device__ constexpr int round_up(int a, int b) { return ceil_div(a, b)
 // taps over time); KT = 1 is the default model.
 // LOW = 1: the low-LDS build of the same model (weights read from L2 instead of staged through LDS) whose plan fits twice
 // per CU: the companion kernel for batches with more streams than CUs, where two workgroups per CU fill each other's stalls.
-template <int C1_, int NL_, int C2_, int F2_, int KB_, int NFFT_, int HOP_, int KT_ = 1, int LOW_ = 0>
+// FR = 1: the `fastenhancer.dprnn` variant (models/fastenhancer/dprnn/model.py:135-247): the block's attention is a bidirectional
+// GRU over the F2 sub-bands, C2 / 2 hidden units per direction, zero initial state every frame; no positional embedding.
+template <int C1_, int NL_, int C2_, int F2_, int KB_, int NFFT_, int HOP_, int KT_ = 1, int LOW_ = 0, int FR_ = 0>
 struct Shape {
     static constexpr int C1 = C1_, NL = NL_, C2 = C2_, F2 = F2_, KB = KB_, NFFT = NFFT_, HOP = HOP_, KT = KT_, LOW = LOW_;
+    static constexpr bool FRNN = FR_ != 0;
+    static constexpr int HF = C2_ / 2;            // dprnn: hidden units per direction of the sub-band GRU
     static constexpr int NH = 4;
     static constexpr int HD = C2 / NH;
     static constexpr int F0 = NFFT / 2;
@@ -110,6 +114,10 @@ struct PackedOffsets {
     int blk_stride;                    // offset of block k+1's arrays minus block k's
     int blk_wih[8], blk_bih[8], blk_whh[8], blk_bhh[8];
     int blk_fc1_w[8], blk_fc1_b[8], blk_qkv[8], blk_fc2_w[8], blk_fc2_b[8];
+    // dprnn variant: blk_qkv holds the sub-band GRU's input weights of both directions as one (3 C2)-column matrix (columns
+    // [direction][gate r|z|n][unit]), blk_qkv_b its bias (b_ih, plus b_hh for r and z), blk_fhh the hidden weights
+    // [direction][j][gate][unit] (a lane = a unit reads consecutive floats), blk_fbhn b_hn [direction][unit]
+    int blk_qkv_b[8], blk_fhh[8], blk_fbhn[8];
     int rfpost_lin, rfpost_w, rfpost_b;
     int dec1_w[8], dec1_b[8], dec3_w[16], dec3_b[8];
     int post1_w, post1_b, post_t_w, post_t_b;
@@ -172,6 +180,9 @@ struct Pack {
             o.blk_fc1_w[k] = alloc(szB(C2, C2)); o.blk_fc1_b[k] = alloc(szBias(C2));
             o.blk_qkv[k] = alloc(szB(C2, 3 * C2));
             o.blk_fc2_w[k] = alloc(szB(C2, C2)); o.blk_fc2_b[k] = alloc(szBias(C2));
+            if (S::FRNN) {
+                o.blk_qkv_b[k] = alloc(szBias(3 * C2)); o.blk_fhh[k] = alloc(2 * S::HF * 3 * S::HF); o.blk_fbhn[k] = alloc(2 * S::HF);
+            }
         }
         o.blk_stride = S::KB > 1 ? o.blk_wih[1] - o.blk_wih[0] : 0;
         o.gru_flat = S::GFLAT ? 1 : 0;
@@ -1619,7 +1630,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 Wf1.bind(wb, (o.blk_fc1_w[0] + kb), (o.blk_fc1_b[0] + kb), S::NT2, wave);   // fetched inside the GEMM below
                 // GFLAT: the qkv weights ride in this (long) GEMM too, attn_fc's in rnn_fc's - fetched one short phase
                 // ahead they were still in flight when their GEMM started
-                if constexpr (GFLAT) Wq.bind(wb, (o.blk_qkv[0] + kb), -1, S::NT3, wave);
+                if constexpr (GFLAT) Wq.bind(wb, (o.blk_qkv[0] + kb), (S::FRNN ? o.blk_qkv_b[0] + kb : -1), S::NT3, wave);
                 if (k == 0) {
 #pragma unroll
                     for (int i = 0; i < S::MT2; ++i)
@@ -1857,7 +1868,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     Wf2.bind(wb, (o.blk_fc2_w[0] + kb), (o.blk_fc2_b[0] + kb), S::NT2, wave);
                     tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf1, FetchSide<decltype(Wf2)>{&Wf2});
                 } else {
-                    Wq.bind(wb, (o.blk_qkv[0] + kb), -1, S::NT3, wave);      // for the next phase, fetched inside the GEMM
+                    Wq.bind(wb, (o.blk_qkv[0] + kb), (S::FRNN ? o.blk_qkv_b[0] + kb : -1), S::NT3, wave);      // for the next phase, fetched inside the GEMM
                     tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf1, FetchSide<decltype(Wq)>{&Wq});
                 }
 #pragma unroll
@@ -1907,7 +1918,55 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 if (k == 0) FE_CLK(52);
                 }
             }
-            if constexpr (!L::PERHEAD) {
+            if constexpr (S::FRNN) {
+                // dprnn variant (models/fastenhancer/dprnn/model.py:239-241): bidirectional GRU over the F2 sub-bands, zero initial
+                // state.  Gi holds the input pre-activations [f][direction][r|z|n][unit] (+ b_ih, + b_hh for r, z); wave = direction,
+                // lane = hidden unit with its 3 H hidden weights in registers; the step's h goes to Hl[f][direction * H + unit] -
+                // the row the next step reads back as broadcasts (LDS operations of one wave execute in order) and frnn_fc's input.
+                static_assert(!L::PERHEAD && L::HL % 2 == 0 && S::LDX % 2 == 0 && S::HF % 2 == 0 && S::HF <= 64, "dprnn: sub-band GRU layout");
+                constexpr int H = S::HF;
+                const int u = lane < H ? lane : H - 1;           // lanes >= H shadow unit H - 1 (same loads, same stores: no partial-exec region)
+                const int dirw = wave & 1;
+                float fw[3][H], fbn;
+                {
+                    const int base = o.blk_fhh[0] + kb + dirw * (H * 3 * H);
+#pragma unroll
+                    for (int j = 0; j < H; ++j)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) fw[g][j] = wb.at_gv(base + (j * 3 + g) * H, u * 4);
+                    fbn = wb.at_gv(o.blk_fbhn[0] + kb + dirw * H, u * 4);
+                }
+                __syncthreads();
+                if (k == 0) FE_CLK(24);
+                if (wave < 2) {
+                    const float* gcol = Gi + dirw * (3 * H) + u;
+                    float* hrow = Hl + dirw * H;
+                    int f = dirw ? F2 - 1 : 0;
+                    const int df = dirw ? -1 : 1;
+                    float gr = gcol[f * LDG], gz = gcol[f * LDG + H], gn = gcol[f * LDG + 2 * H];
+                    float hcur = 0.0f;
+#pragma unroll 1
+                    for (int st = 0; st < F2; ++st) {
+                        const int fn = st + 1 < F2 ? f + df : f;
+                        const float gr1 = gcol[fn * LDG], gz1 = gcol[fn * LDG + H], gn1 = gcol[fn * LDG + 2 * H];
+                        float ar = gr, az = gz, an = fbn;
+                        if (st > 0) {
+                            const float* hp = hrow + (f - df) * LDX;
+#pragma unroll
+                            for (int j = 0; j < H; j += 2) {
+                                const float2 hv = *reinterpret_cast<const float2*>(hp + j);
+                                ar = fmaf(fw[0][j], hv.x, ar); az = fmaf(fw[1][j], hv.x, az); an = fmaf(fw[2][j], hv.x, an);
+                                ar = fmaf(fw[0][j + 1], hv.y, ar); az = fmaf(fw[1][j + 1], hv.y, az); an = fmaf(fw[2][j + 1], hv.y, an);
+                            }
+                        }
+                        const float r = sigmoid_f(ar), z = sigmoid_f(az);
+                        const float nn = tanh_f(gn + r * an);
+                        hcur = (1.0f - z) * nn + z * hcur;
+                        hrow[f * LDX + u] = hcur;
+                        f += df; gr = gr1; gz = gz1; gn = gn1;
+                    }
+                }
+            } else if constexpr (!L::PERHEAD) {
                 __syncthreads();
                 if (k == 0) FE_CLK(24);
                 // attention: wave = head

@@ -64,6 +64,7 @@ class Engine:
             c.stride = cfg.stride
             c.rf_channels, c.rf_freq, c.rf_blocks, c.rf_heads = cfg.rf_channels, cfg.rf_freq, cfg.rf_blocks, cfg.rf_heads
             c.kernel_size_time = cfg.kernel_size_time
+            c.channels_frnn = cfg.channels_frnn
         self._h = c_void_p()
         if self.device is not None and self.device.type == "cuda":
             with torch.cuda.device(self.device):

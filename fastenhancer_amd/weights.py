@@ -36,9 +36,21 @@ def _weight_norm(g: Tensor, v: Tensor) -> Tensor:
     return v * (g.reshape(norm.shape) / norm)
 
 
+_DPRNN_NAMES = (("dprnn_pre.", "rf_pre."), ("dprnn_post.", "rf_post."), ("dprnn_block.", "rf_block."), (".trnn_fc.", ".rnn_fc."),
+                (".trnn_post_norm.", ".rnn_post_norm."), (".trnn.", ".rnn."))
+
+
+def dprnn_canonical_key(k: str) -> str:
+    for a, b in _DPRNN_NAMES:
+        k = k.replace(a, b)
+    return k
+
+
 def fold_state_dict(sd: Mapping[str, Tensor], cfg: FEConfig) -> Dict[str, Tensor]:
     """Training-form -> fused-form state_dict (keys of SURVEY.md Appendix A.1 'Fused')."""
     sd = {k: _f32(v) for k, v in sd.items() if torch.as_tensor(v).is_floating_point()}
+    if cfg.dprnn:      # the dprnn variant's module names (models/fastenhancer/dprnn/model.py:412-436) -> the default model's
+        sd = {dprnn_canonical_key(k): v for k, v in sd.items()}
     if is_fused(sd):
         sd = dict(sd)
         sd.pop("dec_post.2.scale", None)     # (the time_kernel variant's fused state_dict still lists the folded-in scale)
@@ -69,12 +81,21 @@ def fold_state_dict(sd: Mapping[str, Tensor], cfg: FEConfig) -> Dict[str, Tensor
                 out[p + "rnn." + name] = sd[p + "rnn." + name]
         out[p + "rnn.bias_ih_l0"] = sd[p + "rnn.bias_ih_l0"]
         out[p + "rnn.bias_hh_l0"] = sd[p + "rnn.bias_hh_l0"]
-        g = p + "attn.qkv.parametrizations.weight.original0"
-        if g in sd:
-            out[p + "attn.qkv.weight"] = _weight_norm(sd[g], sd[p + "attn.qkv.parametrizations.weight.original1"])
+        if cfg.dprnn:      # DPRNN.remove_weight_reparameterizations, dprnn/model.py:172-192
+            for name in ("weight_ih_l0", "weight_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse"):
+                g = p + f"frnn.parametrizations.{name}.original0"
+                out[p + "frnn." + name] = (_weight_norm(sd[g], sd[p + f"frnn.parametrizations.{name}.original1"]) if g in sd
+                                           else sd[p + "frnn." + name])
+            for name in ("bias_ih_l0", "bias_hh_l0", "bias_ih_l0_reverse", "bias_hh_l0_reverse"):
+                out[p + "frnn." + name] = sd[p + "frnn." + name]
         else:
-            out[p + "attn.qkv.weight"] = sd[p + "attn.qkv.weight"]
-        for fc, norm in (("rnn_fc", "rnn_post_norm"), ("attn_fc", "attn_post_norm")):   # model.py:223-229
+            g = p + "attn.qkv.parametrizations.weight.original0"
+            if g in sd:
+                out[p + "attn.qkv.weight"] = _weight_norm(sd[g], sd[p + "attn.qkv.parametrizations.weight.original1"])
+            else:
+                out[p + "attn.qkv.weight"] = sd[p + "attn.qkv.weight"]
+        for fc, norm in ((("rnn_fc", "rnn_post_norm"), ("frnn_fc", "frnn_post_norm")) if cfg.dprnn
+                         else (("rnn_fc", "rnn_post_norm"), ("attn_fc", "attn_post_norm"))):   # model.py:223-229
             std = (sd[p + norm + ".running_var"] + cfg.rf_eps).sqrt()
             out[p + fc + ".weight"] = sd[p + fc + ".weight"] * (sd[p + norm + ".weight"] / std).view(-1, 1)
             out[p + fc + ".bias"] = sd[p + norm + ".bias"] - sd[p + norm + ".running_mean"] * sd[p + norm + ".weight"] / std
@@ -108,7 +129,7 @@ def expected_fused_shapes(cfg: FEConfig) -> Dict[str, tuple]:
     s["rf_pre.1.bias"] = (C2,)
     for k in range(cfg.rf_blocks):
         p = f"rf_block.{k}."
-        if k == 0:
+        if k == 0 and not cfg.dprnn:
             s[p + "pe"] = (F2, C2)
         s[p + "rnn.weight_ih_l0"] = (3 * C2, C2)
         s[p + "rnn.weight_hh_l0"] = (3 * C2, C2)
@@ -116,6 +137,16 @@ def expected_fused_shapes(cfg: FEConfig) -> Dict[str, tuple]:
         s[p + "rnn.bias_hh_l0"] = (3 * C2,)
         s[p + "rnn_fc.weight"] = (C2, C2)
         s[p + "rnn_fc.bias"] = (C2,)
+        if cfg.dprnn:
+            H = cfg.channels_frnn
+            for sfx in ("", "_reverse"):
+                s[p + "frnn.weight_ih_l0" + sfx] = (3 * H, C2)
+                s[p + "frnn.weight_hh_l0" + sfx] = (3 * H, H)
+                s[p + "frnn.bias_ih_l0" + sfx] = (3 * H,)
+                s[p + "frnn.bias_hh_l0" + sfx] = (3 * H,)
+            s[p + "frnn_fc.weight"] = (C2, 2 * H)
+            s[p + "frnn_fc.bias"] = (C2,)
+            continue
         s[p + "attn.qkv.weight"] = (3 * C2, C2)
         s[p + "attn_fc.weight"] = (C2, C2)
         s[p + "attn_fc.bias"] = (C2,)
@@ -203,7 +234,7 @@ def default_state_dict(cfg: FEConfig, generator: Optional[torch.Generator] = Non
     g = generator
     shapes = expected_fused_shapes(cfg)
     sd: Dict[str, Tensor] = {}
-    fb = linear_filterbank_time_kernel if cfg.time_kernel else linear_filterbank
+    fb = linear_filterbank_time_kernel if cfg.time_kernel or cfg.dprnn else linear_filterbank
     pre, post = (fb(cfg.F1, cfg.rf_freq) if (cfg.pre_post_init or "").startswith("linear") else (None, None))
     for k, shp in shapes.items():
         fan_in = 1
@@ -216,10 +247,10 @@ def default_state_dict(cfg: FEConfig, generator: Optional[torch.Generator] = Non
             sd[k] = post
         elif k.endswith(".pe"):
             sd[k] = positional_embedding(cfg.rf_channels, cfg.rf_freq)
-        elif k.endswith("bias") and ".rnn." not in k:
+        elif k.endswith("bias") and ".rnn." not in k and ".frnn." not in k:
             sd[k] = torch.zeros(shp)
-        elif ".rnn." in k:
-            b = 1.0 / math.sqrt(cfg.rf_channels)
+        elif ".rnn." in k or ".frnn." in k:
+            b = 1.0 / math.sqrt(cfg.channels_frnn if ".frnn." in k else cfg.rf_channels)
             sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * b
         else:
             sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * bound

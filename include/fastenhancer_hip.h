@@ -60,6 +60,11 @@ typedef struct fe_config {
                                       * default model.  The state then also holds the convs' (kernel_size_time - 1)-frame input
                                       * caches: ... | K x h | 2 (n_kernels - 1) x [B, kernel_size_time - 1, F1, C1] (encoder layers, then
                                       * decoder layers; fe_spec_step's h_dev likewise: K x h, then the caches) */
+    int channels_frnn;               /* `model: fastenhancer.dprnn` (models/fastenhancer/dprnn/model.py:135-247; configs/ablation/dprnn_*.yaml):
+                                      * hidden units per direction of the bidirectional sub-band GRU that replaces the attention
+                                      * (must be rf_channels / 2, as in every shipped yaml); 0 = the default RNNFormer block.
+                                      * rf_heads is ignored.  Weight sections: rf_block.k.frnn.{weight,bias}_{ih,hh}_l0[_reverse],
+                                      * rf_block.k.frnn_fc.{weight,bias} instead of attn.qkv / attn_fc, no pe; state as the default model */
 } fe_config;
 
 typedef struct fe_handle fe_handle;

@@ -27,7 +27,8 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.fe_version()
 
 
-@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m", "fe48_l", "fe48_b_h480", "fe_tk_b"])
+@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m", "fe48_l", "fe48_b_h480", "fe_tk_b",
+                                  "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_s", "fe_dprnn_m", "fe_dprnn_l"])
 def test_section_table_matches_fused_schema(name):
     cfg = product_config(name)
     eng = Engine(cfg, None)
@@ -72,7 +73,7 @@ def test_config_rejects_what_the_reference_rejects():
         FEConfig.from_model_kwargs(**{**kw, "mask": "softmax"})
 
 
-@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_l", "fe48_b", "fe_tk_b"])
+@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_l", "fe48_b", "fe_tk_b", "fe_dprnn_b"])
 def test_host_fold_matches_oracle_fold(name):
     cfg_o, sd, fused_o, _ = build_oracle(name)
     cfg = product_config(name)
@@ -238,6 +239,34 @@ def test_time_kernel_mirror_state_layout_and_defaults():
     back = eng.split_state(state, B)
     assert len(back) == len(full) and all(torch.equal(a, b) for a, b in zip(back, full))
     assert eng.flops_per_frame == pytest.approx(build_oracle("fe_tk_b")[0].flops_per_frame())
+
+
+def test_dprnn_mirror_loads_the_reference_module_names():
+    """fastenhancer.dprnn mirror: yaml kwargs -> config (channels_frnn, no positional embedding, its own filterbank formula);
+    a checkpoint with the reference's module names (dprnn_pre / dprnn_block.k.trnn / frnn / dprnn_post, training form) folds
+    to the same fused weights as the oracle's fold; channels_frnn != channels / 2 is rejected with a message."""
+    import importlib
+    from common import MODEL_MODULE
+    from fastenhancer_amd.config import dprnn_config
+    from oracle.fe_oracle import linear_filterbank_tk, reference_key
+    kw = MODEL_KWARGS["fe_dprnn_b"][0]
+    mod = importlib.import_module(f"fastenhancer_amd.models.{MODEL_MODULE['fe_dprnn_b']}.model")
+    m = mod.ONNXModel(**kw)
+    cfg = m.cfg
+    assert cfg.dprnn and cfg.channels_frnn == 18 and cfg.positional_embedding is None and not cfg.final_scale_exp and cfg.rf_eps == 1e-5
+    assert [tuple(c.shape) for c in m.initialize_cache(torch.zeros(2, 1))] == [(1, 2 * 24, 36)] * 3
+    pre_o, _ = linear_filterbank_tk(64, 24)
+    np.testing.assert_allclose(m.state_dict()["rf_pre.0.weight"].numpy(), pre_o, atol=2e-6)
+    cfg_o, sd, fused_o, _ = build_oracle("fe_dprnn_b")
+    ref_named = {reference_key(k, cfg_o): torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    assert any(k.startswith("dprnn_block.0.trnn.") for k in ref_named) and any(".frnn.parametrizations." in k for k in ref_named)
+    m.load_state_dict(ref_named, strict=True)
+    fused = fold_state_dict(ref_named, cfg)
+    assert set(fused) == set(fused_o) and "rf_block.0.pe" not in fused
+    for k in fused:
+        np.testing.assert_allclose(fused[k].numpy(), fused_o[k], rtol=3e-6, atol=1e-7, err_msg=k)
+    with pytest.raises(RuntimeError, match="channels_frnn"):
+        dprnn_config(**{**kw, "dprnn_kwargs": dict(kw["dprnn_kwargs"], channels_frnn=16)})
 
 
 def test_fspen_host_side_without_gpu():

@@ -17,8 +17,9 @@ pytestmark = pytest.mark.gpu
 
 ABS_TOL = 1e-4
 REL_TOL = 1e-4
-GPU_SHAPES = ["fe_t", "fe_b", "fe_m", "fe_l", "fe48_b", "fe48_l", "fe48_b_h480", "fe_tk_b"]          # shapes with reference goldens
-ALL_SHAPES = ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m", "fe48_l", "fe48_b_h480", "fe_tk_b"]
+GPU_SHAPES = ["fe_t", "fe_b", "fe_m", "fe_l", "fe48_b", "fe48_l", "fe48_b_h480", "fe_tk_b", "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_l"]          # shapes with reference goldens
+ALL_SHAPES = ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m", "fe48_l", "fe48_b_h480", "fe_tk_b",
+              "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_s", "fe_dprnn_m", "fe_dprnn_l"]
 
 
 def _dev():
@@ -85,7 +86,7 @@ def test_spec_step_matches_reference_golden(name):
     _assert_close(h[-1].cpu().numpy(), g["chunk_h_last"], "h_last")
 
 
-@pytest.mark.parametrize("name", ["fe_t", "fe_b"])
+@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_dprnn_b"])
 def test_driver_loop_matches_reference_golden(name):
     from fastenhancer_amd.streaming import enhance_stream
     g = load_golden(name)
@@ -432,7 +433,7 @@ def test_offline_model_forward_matches_reference_golden(name):
     assert torch.equal(wav3, wav_hat)
 
 
-@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_m", "fe48_b"])
+@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_m", "fe48_b", "fe_dprnn_b"])
 def test_time_pipelined_offline_and_spec_agree_with_the_serial_walk(name):
     """fe_offline / fe_spec_step with T >= 4 spread a stream's frames over co-resident workgroups that hand the GRU state
     from frame to frame (fe_set_time_pipeline); one workgroup walking the frames serially must give the same result, and
