@@ -69,6 +69,8 @@ WORKLOADS = {
     # the dprnn ablation (configs/ablation/dprnn_{t,b,l}.yaml): a bidirectional GRU over the sub-bands instead of the attention
     "fe_dprnn_t": dict(C1=24, ks=(8, 3, 3), frnn=10, C2=20, F2=16, K=2, N=512, H=256, sr=16000, init="linear_fixed", desc="FastEnhancer_T, dprnn blocks"),
     "fe_dprnn_b": dict(C1=48, ks=(8, 3, 3), frnn=18, C2=36, F2=24, K=3, N=512, H=256, sr=16000, init="linear_fixed", desc="FastEnhancer_B, dprnn blocks"),
+    "fe_dprnn_s": dict(C1=64, ks=(8, 3, 3, 3), frnn=24, C2=48, F2=36, K=3, N=512, H=256, sr=16000, init="linear_fixed", desc="FastEnhancer_S, dprnn blocks"),
+    "fe_dprnn_m": dict(C1=96, ks=(8, 3, 3, 3), frnn=36, C2=72, F2=48, K=4, N=512, H=160, sr=16000, init="linear_fixed", desc="FastEnhancer_M, dprnn blocks"),
     "fe_dprnn_l": dict(C1=128, ks=(8, 3, 3, 3, 3), frnn=48, C2=96, F2=64, K=5, N=512, H=100, sr=16000, init="linear_fixed",
                        desc="FastEnhancer_L, dprnn blocks"),
 }
