@@ -65,6 +65,14 @@ class FEConfig:
     def dprnn(self) -> bool:
         return self.channels_frnn > 0
 
+    # models/fastenhancer/dptransformer/model.py (configs/ablation/dpt_*.yaml): the blocks' time GRU is a causal attention over
+    # the last `lookbehind` frames (K / V caches [B*F2, NH, lookbehind, hd] per block) with a learned positional bias [NH, L+1]
+    lookbehind: int = 0
+
+    @property
+    def dpt(self) -> bool:
+        return self.lookbehind > 0
+
     @property
     def time_kernel(self) -> bool:
         return self.kernel_size_time > 1
@@ -72,7 +80,11 @@ class FEConfig:
     @staticmethod
     def from_model_kwargs(kw: dict) -> "FEConfig":
         dp = "dprnn_kwargs" in kw
-        rk = dict(kw.get("dprnn_kwargs" if dp else "rnnformer_kwargs", {}))
+        dt = "dpt_kwargs" in kw
+        rk = dict(kw.get("dprnn_kwargs" if dp else ("dpt_kwargs" if dt else "rnnformer_kwargs"), {}))
+        if dt:
+            assert "pre_norm" in rk, "DPTConfig.pre_norm defaults to True (dptransformer/model.py:417): not restated"
+
         for flag in ("attn_bias", "post_act", "pre_norm"):
             assert not rk.get(flag, False), f"rnnformer_kwargs.{flag}=True is not restated"
         assert rk.get("p_dropout", 0.0) == 0.0
@@ -82,7 +94,8 @@ class FEConfig:
             channels=kw.get("channels", 64),
             kernel_size=tuple(kw["kernel_size_freq"]) if "kernel_size_freq" in kw else tuple(kw.get("kernel_size", (8, 3, 3))),
             kernel_size_time=int(kw.get("kernel_size_time", 3)) if "kernel_size_freq" in kw else 1,
-            final_scale_exp=(("kernel_size_freq" in kw or dp) and kw.get("final_scale", "exp") == "exp"),
+            final_scale_exp=(("kernel_size_freq" in kw or dp or dt) and kw.get("final_scale", "exp") == "exp"),
+            lookbehind=int(rk.get("lookbehind", 16)) if dt else 0,
             channels_frnn=int(rk.get("channels_frnn", 16)) if dp else 0,
             stride=kw.get("stride", 4),
             rf_blocks=rk.get("num_blocks", 3),
@@ -124,7 +137,9 @@ class FEConfig:
         for k in self.kernel_size[1:]:
             m += C1 * C1 * k * self.kernel_size_time * F1
         m += F1 * F2 * C1 + C1 * C2 * F2
-        if self.dprnn:      # time GRU + fc, then the BiGRU over the F2 sub-bands (input and hidden products of both directions) + fc
+        if self.dpt:        # time attention (qkv, L+1 scores and weighted values per token) + fc, then the sub-band attention + fc
+            m += K * (C2 * C2 * 3 * F2 + 2 * (self.lookbehind + 1) * C2 * F2 + C2 * C2 * F2 + C2 * C2 * 3 * F2 + 2 * F2 * C2 * F2 + C2 * C2 * F2)
+        elif self.dprnn:    # time GRU + fc, then the BiGRU over the F2 sub-bands (input and hidden products of both directions) + fc
             H = self.channels_frnn
             m += K * (C2 * C2 * 6 * F2 + C2 * C2 * F2 + 2 * 3 * H * (C2 + H) * F2 + 2 * H * C2 * F2)
         else:
@@ -246,6 +261,37 @@ def mhsa(x: Array, w_qkv: Array, num_heads: int) -> Array:
     return o.transpose(0, 2, 1, 3).reshape(M, F, C)
 
 
+def causal_time_attention(x: Array, w_qkv: Array, pe: Array, num_heads: int, lookbehind: int,
+                          h_k: Optional[Array], h_v: Optional[Array]) -> Tuple[Array, Array, Array]:
+    """CausalAttention.forward, models/fastenhancer/dptransformer/model.py:200-236.  x [M,T,C] (M = B*F2), pe [NH,L+1] (column L
+    = the current frame), caches [M,NH,L,hd] or None.  With caches every frame attends to the L cached frames and itself
+    (zero-initialised caches take part: score = pe, value 0); without, frames before the start are masked out
+    (expand_attn_map, :151-171).  The reference's cached branch is written for T = 1; T > 1 here is T such steps."""
+    M, T, C = x.shape
+    L, hd = lookbehind, C // num_heads
+    scale = x.dtype.type(hd ** -0.5)
+    qkv = (x @ w_qkv.T).reshape(M, T, num_heads, 3 * hd).transpose(0, 2, 1, 3)          # [M,NH,T,3hd]
+    q, k, v = qkv[..., :hd], qkv[..., hd:2 * hd], qkv[..., 2 * hd:]
+    masked = h_k is None
+    if masked:
+        h_k = np.zeros((M, num_heads, L, hd), x.dtype)
+        h_v = np.zeros((M, num_heads, L, hd), x.dtype)
+    kk = np.concatenate([h_k, k], axis=2)                                                 # [M,NH,L+T,hd]
+    vv = np.concatenate([h_v, v], axis=2)
+    out = np.empty((M, num_heads, T, hd), x.dtype)
+    for t in range(T):
+        kw, vw = kk[:, :, t:t + L + 1], vv[:, :, t:t + L + 1]                             # the window of frame t
+        a = pe[None] + scale * np.einsum("mnd,mnjd->mnj", q[:, :, t], kw)                 # [M,NH,L+1]
+        if masked and t < L:
+            a[:, :, :L - t] = -np.inf
+        a = a - a.max(axis=2, keepdims=True)
+        e = np.exp(a)
+        a = e / e.sum(axis=2, keepdims=True)
+        out[:, :, t] = np.einsum("mnj,mnjd->mnd", a, vw)
+    keep = min(L, T) if masked else L       # (without caches the reference returns k[:, :, -L:] of the T frames it saw)
+    return out.transpose(0, 2, 1, 3).reshape(M, T, C), kk[:, :, -keep:].copy(), vv[:, :, -keep:].copy()
+
+
 def bigru_over_rows(x: Array, w: Dict[str, Array], p: str) -> Array:
     """nn.GRU(C, H, bidirectional=True, batch_first=True) over axis 1 with zero initial state
     (DPRNN.forward, models/fastenhancer/dprnn/model.py:239-241).  x [M,F,C] -> [M,F,2H] (forward | reverse)."""
@@ -341,16 +387,29 @@ _DPRNN_NAMES = (("dprnn_pre.", "rf_pre."), ("dprnn_post.", "rf_post."), ("dprnn_
                 (".trnn_post_norm.", ".rnn_post_norm."), (".trnn.", ".rnn."))
 
 
+# models/fastenhancer/dptransformer/model.py:580-610 module names <-> this file's (the model-level `pe` is `time_pe` here)
+_DPT_NAMES = (("dpt_pre.", "rf_pre."), ("dpt_post.", "rf_post."), ("dpt_block.", "rf_block."), (".time_fc.", ".rnn_fc."),
+              (".time_post_norm.", ".rnn_post_norm."), (".freq_attn.", ".attn."), (".freq_fc.", ".attn_fc."),
+              (".freq_post_norm.", ".attn_post_norm."))
+
+
 def canonical_key(k: str) -> str:
-    for a, b in _DPRNN_NAMES:
+    if k == "pe":
+        return "time_pe"
+    for a, b in _DPRNN_NAMES + _DPT_NAMES:
         k = k.replace(a, b)
     return k
 
 
 def reference_key(k: str, cfg: "FEConfig") -> str:
-    """this file's state_dict key -> the reference module's (they differ for the dprnn variant only)"""
+    """this file's state_dict key -> the reference module's (they differ for the dprnn / dptransformer variants only)"""
     if cfg.dprnn:
         for a, b in _DPRNN_NAMES:
+            k = k.replace(b, a)
+    if cfg.dpt:
+        if k == "time_pe":
+            return "pe"
+        for a, b in _DPT_NAMES:
             k = k.replace(b, a)
     return k
 
@@ -362,7 +421,7 @@ def fold_state_dict(sd: Dict[str, Array], cfg: FEConfig) -> Dict[str, Array]:
     state_dict and returns the fused-form dict.  A dict that
     is already fused (has 'enc_pre.0.bias') is returned unchanged (as float32)."""
     sd = {k: np.asarray(v) for k, v in sd.items()}
-    if cfg.dprnn:
+    if cfg.dprnn or cfg.dpt:
         sd = {canonical_key(k): v for k, v in sd.items()}
     if "enc_pre.0.bias" in sd:
         return {k: v.astype(np.float32) for k, v in sd.items() if v.dtype.kind == "f"}
@@ -380,18 +439,27 @@ def fold_state_dict(sd: Dict[str, Array], cfg: FEConfig) -> Dict[str, Array]:
         conv_bn(f"encoder.{i}.0", f"encoder.{i}.1", f"encoder.{i}.0")
     out["rf_pre.0.weight"] = sd["rf_pre.0.weight"].astype(np.float32)
     conv_bn("rf_pre.1", "rf_pre.2", "rf_pre.1")
+    if cfg.dpt:
+        out["time_pe"] = sd["time_pe"].astype(np.float32)
     for k in range(cfg.rf_blocks):
         p = f"rf_block.{k}."
         if p + "pe" in sd:
             out[p + "pe"] = sd[p + "pe"].astype(np.float32)
-        for name in ("weight_ih_l0", "weight_hh_l0"):
-            key0 = p + f"rnn.parametrizations.{name}.original0"
+        if cfg.dpt:        # DPTBlock.remove_weight_reparameterizations, dptransformer/model.py:323-336
+            key0 = p + "time_attn.qkv.parametrizations.weight.original0"
             if key0 in sd:
-                out[p + "rnn." + name] = _weight_norm(sd[key0], sd[p + f"rnn.parametrizations.{name}.original1"])
+                out[p + "time_attn.qkv.weight"] = _weight_norm(sd[key0], sd[p + "time_attn.qkv.parametrizations.weight.original1"])
             else:
-                out[p + "rnn." + name] = sd[p + "rnn." + name].astype(np.float32)
-        out[p + "rnn.bias_ih_l0"] = sd[p + "rnn.bias_ih_l0"].astype(np.float32)
-        out[p + "rnn.bias_hh_l0"] = sd[p + "rnn.bias_hh_l0"].astype(np.float32)
+                out[p + "time_attn.qkv.weight"] = sd[p + "time_attn.qkv.weight"].astype(np.float32)
+        else:
+            for name in ("weight_ih_l0", "weight_hh_l0"):
+                key0 = p + f"rnn.parametrizations.{name}.original0"
+                if key0 in sd:
+                    out[p + "rnn." + name] = _weight_norm(sd[key0], sd[p + f"rnn.parametrizations.{name}.original1"])
+                else:
+                    out[p + "rnn." + name] = sd[p + "rnn." + name].astype(np.float32)
+            out[p + "rnn.bias_ih_l0"] = sd[p + "rnn.bias_ih_l0"].astype(np.float32)
+            out[p + "rnn.bias_hh_l0"] = sd[p + "rnn.bias_hh_l0"].astype(np.float32)
         if cfg.dprnn:      # DPRNN.remove_weight_reparameterizations, dprnn/model.py:172-192
             for name in ("weight_ih_l0", "weight_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse"):
                 key0 = p + f"frnn.parametrizations.{name}.original0"
@@ -444,6 +512,8 @@ def training_state_dict_spec(cfg: FEConfig) -> Dict[str, Tuple[int, ...]]:
         spec[prefix + ".running_var"] = (c,)
         spec[prefix + ".num_batches_tracked"] = ()
 
+    if cfg.dpt:          # the model's own parameter precedes its submodules in state_dict()
+        spec["time_pe"] = (cfg.rf_heads, cfg.lookbehind + 1)
     spec["enc_pre.0.weight"] = (C1, 2 * S, cfg.kernel_size[0] // S)
     bn("enc_pre.1", C1)
     tk = cfg.time_kernel
@@ -458,16 +528,23 @@ def training_state_dict_spec(cfg: FEConfig) -> Dict[str, Tuple[int, ...]]:
         p = f"rf_block.{k}."
         if k == 0 and cfg.positional_embedding is not None:
             spec[p + "pe"] = (F2, C2)
-        spec[p + "rnn.bias_ih_l0"] = (3 * C2,)
-        spec[p + "rnn.bias_hh_l0"] = (3 * C2,)
-        if cfg.weight_norm:
-            spec[p + "rnn.parametrizations.weight_ih_l0.original0"] = (3 * C2, 1)
-            spec[p + "rnn.parametrizations.weight_ih_l0.original1"] = (3 * C2, C2)
-            spec[p + "rnn.parametrizations.weight_hh_l0.original0"] = (3 * C2, 1)
-            spec[p + "rnn.parametrizations.weight_hh_l0.original1"] = (3 * C2, C2)
+        if cfg.dpt:
+            if cfg.weight_norm:
+                spec[p + "time_attn.qkv.parametrizations.weight.original0"] = (3 * C2, 1)
+                spec[p + "time_attn.qkv.parametrizations.weight.original1"] = (3 * C2, C2)
+            else:
+                spec[p + "time_attn.qkv.weight"] = (3 * C2, C2)
         else:
-            spec[p + "rnn.weight_ih_l0"] = (3 * C2, C2)
-            spec[p + "rnn.weight_hh_l0"] = (3 * C2, C2)
+            spec[p + "rnn.bias_ih_l0"] = (3 * C2,)
+            spec[p + "rnn.bias_hh_l0"] = (3 * C2,)
+            if cfg.weight_norm:
+                spec[p + "rnn.parametrizations.weight_ih_l0.original0"] = (3 * C2, 1)
+                spec[p + "rnn.parametrizations.weight_ih_l0.original1"] = (3 * C2, C2)
+                spec[p + "rnn.parametrizations.weight_hh_l0.original0"] = (3 * C2, 1)
+                spec[p + "rnn.parametrizations.weight_hh_l0.original1"] = (3 * C2, C2)
+            else:
+                spec[p + "rnn.weight_ih_l0"] = (3 * C2, C2)
+                spec[p + "rnn.weight_hh_l0"] = (3 * C2, C2)
         spec[p + "rnn_fc.weight"] = (C2, C2)
         bn(p + "rnn_post_norm", C2)
         if cfg.dprnn:      # nn.GRU(bidirectional) registers biases first, then the (parametrized) weights, like the time GRU
@@ -531,6 +608,8 @@ class FEOracle:
         c = self.cfg
         caches = [np.zeros((B, c.n_fft - c.hop_size), self.dtype), np.zeros((B, c.n_fft - c.hop_size), self.dtype)]
         hs = [np.zeros((1, B * c.rf_freq, c.rf_channels), self.dtype) for _ in range(c.rf_blocks)]
+        if c.dpt:      # DPTBlock.initialize_cache (dptransformer/model.py:194-198, sized for B streams): h_k, h_v per block
+            hs = [np.zeros((B * c.rf_freq, c.rf_heads, c.lookbehind, c.rf_channels // c.rf_heads), self.dtype) for _ in range(2 * c.rf_blocks)]
         if c.time_kernel:     # (B, C1, kt-1, F1) per causal conv (time_kernel/model.py:138-139, sized for B streams)
             tkc = lambda: [np.zeros((B, c.channels, c.kernel_size_time - 1, c.F1), self.dtype) for _ in range(c.n_layers)]
             return caches + tkc() + hs + tkc()
@@ -607,15 +686,23 @@ class FEOracle:
         h_out = []
         for k in range(c.rf_blocks):
             p = f"rf_block.{k}."
-            h = np.zeros((B * F2, C2), self.dtype) if h_list is None else h_list[k][0].astype(self.dtype).copy()
-            # GRU over time (model.py:266-277), batch index b*F2+f
-            xs = x.reshape(T, B * F2, C2)
-            ys = np.empty_like(xs)
-            for t in range(T):
-                h = gru_step(xs[t], h, w[p + "rnn.weight_ih_l0"], w[p + "rnn.weight_hh_l0"],
-                             w[p + "rnn.bias_ih_l0"], w[p + "rnn.bias_hh_l0"])
-                ys[t] = h
-            h_out.append(h[None].copy())
+            if c.dpt:
+                # time attention per sub-band (dptransformer/model.py:378-389), batch index b*F2+f
+                xs = x.transpose(1, 2, 0, 3).reshape(B * F2, T, C2)
+                hk, hv = (None, None) if h_list is None else (h_list[2 * k].astype(self.dtype), h_list[2 * k + 1].astype(self.dtype))
+                ys, hk, hv = causal_time_attention(xs, w[p + "time_attn.qkv.weight"], w["time_pe"], c.rf_heads, c.lookbehind, hk, hv)
+                ys = ys.reshape(B, F2, T, C2).transpose(2, 0, 1, 3).reshape(T, B * F2, C2)
+                h_out += [hk, hv]
+            else:
+                h = np.zeros((B * F2, C2), self.dtype) if h_list is None else h_list[k][0].astype(self.dtype).copy()
+                # GRU over time (model.py:266-277), batch index b*F2+f
+                xs = x.reshape(T, B * F2, C2)
+                ys = np.empty_like(xs)
+                for t in range(T):
+                    h = gru_step(xs[t], h, w[p + "rnn.weight_ih_l0"], w[p + "rnn.weight_hh_l0"],
+                                 w[p + "rnn.bias_ih_l0"], w[p + "rnn.bias_hh_l0"])
+                    ys[t] = h
+                h_out.append(h[None].copy())
             y = ys @ w[p + "rnn_fc.weight"].T + w[p + "rnn_fc.bias"]
             x = y.reshape(T, B, F2, C2) + x
             if (p + "pe") in w:                                          # model.py:279-280

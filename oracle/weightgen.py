@@ -26,7 +26,7 @@ def make_training_state_dict(cfg: FEConfig, seed: int) -> Dict[str, np.ndarray]:
     """Training-form state_dict with seeded values."""
     rng = np.random.Generator(np.random.PCG64(seed))
     spec = training_state_dict_spec(cfg)
-    pre, post = (linear_filterbank_tk if cfg.time_kernel or cfg.dprnn else linear_filterbank)(cfg.F1, cfg.rf_freq)
+    pre, post = (linear_filterbank_tk if cfg.time_kernel or cfg.dprnn or cfg.dpt else linear_filterbank)(cfg.F1, cfg.rf_freq)
     pe = positional_embedding(cfg.rf_channels, cfg.rf_freq)
     sd: Dict[str, np.ndarray] = {}
     for key, shape in spec.items():
@@ -42,6 +42,8 @@ def make_training_state_dict(cfg: FEConfig, seed: int) -> Dict[str, np.ndarray]:
             v = pre + 0.01 * rng.standard_normal(shape)
         elif key == "rf_post.0.weight":
             v = post + 0.01 * rng.standard_normal(shape)
+        elif key == "time_pe":                          # the dptransformer variant's positional bias [NH, L+1]
+            v = positional_embedding(cfg.rf_heads, cfg.lookbehind + 1).T + 0.05 * rng.standard_normal(shape)
         elif leaf == "pe":
             v = pe + 0.05 * rng.standard_normal(shape)
         elif leaf == "original0":                       # weight-norm gain g

@@ -39,6 +39,17 @@ def _kw_dprnn(C1, ks, C2, H2, F2, K, N, H):
         normalize_final_conv=True, weight_norm=True)
 
 
+def _kw_dpt(C1, ks, C2, F2, K, N, H):
+    """configs/ablation/dpt_b.yaml:2-31 (model: fastenhancer.dptransformer)"""
+    return dict(
+        channels=C1, kernel_size=list(ks), stride=4,
+        dpt_kwargs=dict(num_blocks=K, channels=C2, freq=F2, num_heads=4, eps=1.0e-5, positional_embedding="train", attn_bias=False,
+                        post_act=False, pre_norm=False, lookbehind=31),
+        pre_post_init="linear_fixed", n_fft=N, hop_size=H, win_size=N, window="hann", stft_normalized=False,
+        mask=None, activation="SiLU", activation_kwargs=dict(inplace=True), input_compression=0.3, final_scale=True,
+        normalize_final_conv=True, final_scale_init="one", weight_norm=True)
+
+
 # name -> (model_kwargs, sampling rate, golden seed)
 MODEL_KWARGS = {
     "fe_t": (_kw(24, (8, 3, 3), 20, 16, 2, 512, 256, "linear_fixed"), 16000, 101),
@@ -59,9 +70,15 @@ MODEL_KWARGS = {
     "fe_dprnn_s": (_kw_dprnn(64, (8, 3, 3, 3), 48, 24, 36, 3, 512, 256), 16000, 133),
     "fe_dprnn_m": (_kw_dprnn(96, (8, 3, 3, 3), 72, 36, 48, 4, 512, 160), 16000, 134),
     "fe_dprnn_l": (_kw_dprnn(128, (8, 3, 3, 3, 3), 96, 48, 64, 5, 512, 100), 16000, 132),
+    # configs/ablation/dpt_{t,b,s,m}.yaml
+    "fe_dpt_t": (_kw_dpt(24, (8, 3, 3), 20, 16, 2, 512, 256), 16000, 140),
+    "fe_dpt_b": (_kw_dpt(48, (8, 3, 3), 36, 24, 3, 512, 256), 16000, 141),
+    "fe_dpt_s": (_kw_dpt(64, (8, 3, 3, 3), 48, 36, 3, 512, 256), 16000, 143),
+    "fe_dpt_m": (_kw_dpt(96, (8, 3, 3, 3), 72, 48, 4, 512, 160), 16000, 142),
 }
 # which module of the reference a name belongs to (the yaml's `model:` key)
-MODEL_MODULE = {name: ("fastenhancer.dprnn" if "dprnn" in name else "fastenhancer.default") for name in MODEL_KWARGS}
+MODEL_MODULE = {name: ("fastenhancer.dprnn" if "dprnn" in name else "fastenhancer.dptransformer" if "dpt" in name else "fastenhancer.default")
+                for name in MODEL_KWARGS}
 MODEL_MODULE["fe_tk_b"] = "fastenhancer.time_kernel"
 
 

@@ -7,7 +7,7 @@ from common import MODEL_KWARGS, build_oracle, load_golden, rms
 from oracle.weightgen import make_input
 
 GOLDENS = ["fe_t", "fe_b", "fe_m", "fe_l", "fe48_b", "fe48_l", "fe48_b_h480"]
-ORACLE_GOLDENS = GOLDENS + ["fe_tk_b", "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_l"]           # (the C oracle restates the default model only)
+ORACLE_GOLDENS = GOLDENS + ["fe_tk_b", "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_l", "fe_dpt_t", "fe_dpt_b", "fe_dpt_m"]           # (the C oracle restates the default model only)
 # fp32-vs-fp32 different summation orders: the reference's own fp32 noise floor is ~5e-7
 # relative; allow 20x that.
 REL = 1e-5
@@ -34,9 +34,12 @@ def test_streaming_step_matches_reference(name):
     _close(caches[0], g["stream_cache_stft"], what="cache_stft")
     _close(caches[1], g["stream_cache_istft"], what="cache_istft")
     n_model_caches = cfg.rf_blocks + (2 * cfg.n_layers if cfg.time_kernel else 0)     # time_kernel: + the causal convs' frame caches
+    if cfg.dpt:
+        n_model_caches = 2 * cfg.rf_blocks                                              # dptransformer: K and V caches per block
     assert len(caches) == 2 + n_model_caches
     for k in range(n_model_caches):
-        _close(caches[2 + k], g[f"stream_h{k}"], what=f"model cache {k}")
+        if f"stream_h{k}" in g.files:                                                   # (dpt_b / dpt_m goldens hold the first and last block's only)
+            _close(caches[2 + k], g[f"stream_h{k}"], what=f"model cache {k}")
 
 
 @pytest.mark.parametrize("name", ORACLE_GOLDENS)
@@ -51,7 +54,7 @@ def test_spec_chunk_matches_reference(name):
         s, cache = orc.stft_step(x[:, t * H:(t + 1) * H], cache)
         specs.append(s)
     spec = np.concatenate(specs, axis=2)
-    h0 = orc.initialize_cache(B)[2:]
+    h0 = None if cfg.dpt else orc.initialize_cache(B)[2:]      # (dptransformer: the reference's chunk runs without caches, start masked)
     y, h = orc.spec_forward(spec, h0)
     _close(y, g["chunk_spec_out"], what="chunk spec")
     _close(h[-1], g["chunk_h_last"], what="chunk h")
@@ -69,7 +72,7 @@ def test_offline_matches_reference(name):
     _close(spec, g["offline_spec"], what="offline spec")
 
 
-@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_tk_b", "fe_dprnn_b"])
+@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_tk_b", "fe_dprnn_b", "fe_dpt_b"])
 def test_driver_loop_matches_reference(name):
     g = load_golden(name)
     cfg, sd, fused, orc = build_oracle(name)

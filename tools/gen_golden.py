@@ -83,6 +83,11 @@ CONFIGS = {
     "fe_dprnn_t": ("configs/ablation/dprnn_t.yaml", 130, 2, 10, 0),
     "fe_dprnn_b": ("configs/ablation/dprnn_b.yaml", 131, 2, 10, 120),
     "fe_dprnn_l": ("configs/ablation/dprnn_l.yaml", 132, 1, 5, 0),
+    # the dptransformer ablation (models/fastenhancer/dptransformer): causal attention over the last 31 frames instead of the time GRU
+    # (40 hops: the K / V caches hold 31 frames)
+    "fe_dpt_t": ("configs/ablation/dpt_t.yaml", 140, 2, 40, 0),
+    "fe_dpt_b": ("configs/ablation/dpt_b.yaml", 141, 2, 40, 120),
+    "fe_dpt_m": ("configs/ablation/dpt_m.yaml", 142, 1, 36, 0),
 }
 
 
@@ -138,9 +143,10 @@ def gen_fastenhancer(ref: str, name: str, out_dir: str):
     # fixed filterbank formula
     if kw.get("pre_post_init", None) == "linear_fixed":
         fresh = mod.ONNXModel(**kw)
-        pre, post = (linear_filterbank_tk if tk or cfg.dprnn else linear_filterbank)(cfg.F1, cfg.rf_freq)
-        assert np.abs(pre - (fresh.dprnn_pre if cfg.dprnn else fresh.rf_pre)[0].weight.numpy()).max() < 1e-5
-        assert np.abs(post - (fresh.dprnn_post if cfg.dprnn else fresh.rf_post)[0].weight.numpy()).max() < 1e-5
+        pre, post = (linear_filterbank_tk if tk or cfg.dprnn or cfg.dpt else linear_filterbank)(cfg.F1, cfg.rf_freq)
+        fpre, fpost = (fresh.dprnn_pre, fresh.dprnn_post) if cfg.dprnn else ((fresh.dpt_pre, fresh.dpt_post) if cfg.dpt else (fresh.rf_pre, fresh.rf_post))
+        assert np.abs(pre - fpre[0].weight.numpy()).max() < 1e-5
+        assert np.abs(post - fpost[0].weight.numpy()).max() < 1e-5
 
     out = {"seed": np.int64(seed), "B": np.int64(B), "hops": np.int64(hops), "sr": np.int64(sr),
            "fold_worst_rel": np.float64(worst)}
@@ -153,6 +159,8 @@ def gen_fastenhancer(ref: str, name: str, out_dir: str):
 
         def model_caches(nb):       # the model's cache list sized for nb streams (its own initialize_cache is written for 1)
             hs = [torch.zeros(1, nb * cfg.rf_freq, cfg.rf_channels) for _ in range(cfg.rf_blocks)]
+            if cfg.dpt:
+                hs = [torch.zeros(nb * cfg.rf_freq, cfg.rf_heads, cfg.lookbehind, cfg.rf_channels // cfg.rf_heads) for _ in range(2 * cfg.rf_blocks)]
             if not tk:
                 return hs
             cc = lambda: [torch.zeros(nb, cfg.channels, cfg.kernel_size_time - 1, cfg.F1) for _ in range(cfg.n_layers)]
@@ -172,6 +180,8 @@ def gen_fastenhancer(ref: str, name: str, out_dir: str):
     out["stream_cache_stft"] = cache_stft.numpy().copy()
     out["stream_cache_istft"] = cache_istft.numpy().copy()
     for k, hk in enumerate(h):
+        if cfg.dpt and name != "fe_dpt_t" and 2 <= k < len(h) - 2:
+            continue          # (K / V caches are large: all blocks for dpt_t, the first and the last block's for the bigger shapes)
         out[f"stream_h{k}"] = hk.numpy().copy()
     out["stream_spec_in_last"] = specs_in[-1]
     out["stream_spec_out_last"] = specs_out[-1]
@@ -180,7 +190,8 @@ def gen_fastenhancer(ref: str, name: str, out_dir: str):
     with torch.no_grad():
         spec_chunk = torch.from_numpy(np.concatenate(specs_in[:4], axis=2))   # [B,F0+1,4,2]
         h0 = model_caches(B)
-        spec_hat, *h4 = onnx_model(spec_chunk, *h0)
+        # (the dptransformer variant's cached branch is written for T = 1: its chunk runs without caches, i.e. with the start masked)
+        spec_hat, *h4 = onnx_model(spec_chunk) if cfg.dpt else onnx_model(spec_chunk, *h0)
     out["chunk_spec_out"] = spec_hat.numpy().copy()
     out["chunk_h_last"] = h4[-1].numpy().copy()
 
