@@ -69,6 +69,12 @@ WORKLOADS = {
     # the dprnn ablation (configs/ablation/dprnn_{t,b,l}.yaml): a bidirectional GRU over the sub-bands instead of the attention
     "fe_dprnn_t": dict(C1=24, ks=(8, 3, 3), frnn=10, C2=20, F2=16, K=2, N=512, H=256, sr=16000, init="linear_fixed", desc="FastEnhancer_T, dprnn blocks"),
     "fe_dprnn_b": dict(C1=48, ks=(8, 3, 3), frnn=18, C2=36, F2=24, K=3, N=512, H=256, sr=16000, init="linear_fixed", desc="FastEnhancer_B, dprnn blocks"),
+    # the dptransformer ablation (configs/ablation/dpt_{t,b,s,m}.yaml): causal attention over the last 31 frames instead of the time GRU;
+    # its K / V caches make the step HBM-bound (`roofline.hbm_frac`)
+    "fe_dpt_t": dict(C1=24, ks=(8, 3, 3), dpt=31, C2=20, F2=16, K=2, N=512, H=256, sr=16000, init="linear_fixed", desc="FastEnhancer_T, dual-path transformer blocks"),
+    "fe_dpt_b": dict(C1=48, ks=(8, 3, 3), dpt=31, C2=36, F2=24, K=3, N=512, H=256, sr=16000, init="linear_fixed", desc="FastEnhancer_B, dual-path transformer blocks"),
+    "fe_dpt_s": dict(C1=64, ks=(8, 3, 3, 3), dpt=31, C2=48, F2=36, K=3, N=512, H=256, sr=16000, init="linear_fixed", desc="FastEnhancer_S, dual-path transformer blocks"),
+    "fe_dpt_m": dict(C1=96, ks=(8, 3, 3, 3), dpt=31, C2=72, F2=48, K=4, N=512, H=160, sr=16000, init="linear_fixed", desc="FastEnhancer_M, dual-path transformer blocks"),
     "fe_dprnn_s": dict(C1=64, ks=(8, 3, 3, 3), frnn=24, C2=48, F2=36, K=3, N=512, H=256, sr=16000, init="linear_fixed", desc="FastEnhancer_S, dprnn blocks"),
     "fe_dprnn_m": dict(C1=96, ks=(8, 3, 3, 3), frnn=36, C2=72, F2=48, K=4, N=512, H=160, sr=16000, init="linear_fixed", desc="FastEnhancer_M, dprnn blocks"),
     "fe_dprnn_l": dict(C1=128, ks=(8, 3, 3, 3, 3), frnn=48, C2=96, F2=64, K=5, N=512, H=100, sr=16000, init="linear_fixed",
@@ -86,6 +92,12 @@ def model_kwargs(w):
     if w.get("bsrnn"):
         return dict(num_channels=w["C"], num_layers=w["L"], bias=True, affine=True, n_fft=w["N"], hop_size=w["H"], win_size=w["N"],
                     window="hann", input_compression=0.3)
+    if w.get("dpt"):
+        kw = model_kwargs({k: v for k, v in w.items() if k != "dpt"})
+        rk = kw.pop("rnnformer_kwargs")
+        del kw["resnet"]
+        kw.update(dpt_kwargs=dict(rk, lookbehind=w["dpt"]), final_scale=True, final_scale_init="one")
+        return kw
     if w.get("frnn"):
         kw = model_kwargs({k: v for k, v in w.items() if k != "frnn"})
         del kw["rnnformer_kwargs"], kw["resnet"]
@@ -322,6 +334,9 @@ def main():
     elif w.get("frnn"):
         from fastenhancer_amd.config import dprnn_config
         cfg = dprnn_config(**kw)
+    elif w.get("dpt"):
+        from fastenhancer_amd.config import dpt_config
+        cfg = dpt_config(**kw)
     else:
         cfg = FEConfig.from_model_kwargs(**kw)
     eng = Engine(cfg, dev)
@@ -465,7 +480,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline_fspen(kw, w["sr"], B, args.cpu_budget_s, lisennet=bool(w.get("lisennet")))
         elif world == 1 and not args.no_cpu_baseline and w.get("bsrnn"):
             res["cpu_baseline"] = cpu_baseline_bsrnn(args.workload, kw, w["sr"], B, args.cpu_budget_s)
-        elif world == 1 and not args.no_cpu_baseline and not w.get("kt") and not w.get("frnn"):
+        elif world == 1 and not args.no_cpu_baseline and not w.get("kt") and not w.get("frnn") and not w.get("dpt"):
             res["cpu_baseline"] = cpu_baseline(args.workload, kw, w["sr"], B, args.cpu_budget_s)
         print(json.dumps(res), flush=True)
     if use_dist:

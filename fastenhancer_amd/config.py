@@ -38,6 +38,14 @@ class FEConfig:
     def dprnn(self) -> bool:
         return self.channels_frnn > 0
 
+    # `model: fastenhancer.dptransformer` (models/fastenhancer/dptransformer/model.py): the blocks' time GRU is a causal attention
+    # over the last `lookbehind` frames (K / V caches per block) with a learned positional bias; 0 = the default block
+    lookbehind: int = 0
+
+    @property
+    def dpt(self) -> bool:
+        return self.lookbehind > 0
+
     @property
     def time_kernel(self) -> bool:
         return self.kernel_size_time > 1
@@ -166,6 +174,33 @@ def dprnn_config(channels: int = 64, kernel_size: Sequence[int] = (8, 3, 3), str
                                       normalize_final_conv=normalize_final_conv, pre_post_init=pre_post_init, resnet=False)
     import dataclasses
     return dataclasses.replace(base, channels_frnn=H, positional_embedding=None, final_scale_exp=(final_scale == "exp"))
+
+
+def dpt_config(channels: int = 64, kernel_size: Sequence[int] = (8, 3, 3), stride: int = 4, dpt_kwargs: Optional[Dict[str, Any]] = None,
+               activation: str = "ReLU", activation_kwargs: Optional[Dict[str, Any]] = None, n_fft: int = 512, hop_size: int = 256,
+               win_size: int = 512, window: Optional[str] = "hann", stft_normalized: bool = False, mask: Optional[str] = None,
+               input_compression: float = 0.3, weight_norm: bool = False, final_scale: Any = "exp", normalize_final_conv: bool = False,
+               final_scale_init: str = "1/sqrt(fan_in)", pre_post_init: Optional[str] = None) -> FEConfig:
+    """yaml model_kwargs of `model: fastenhancer.dptransformer` (configs/ablation/dpt_b.yaml:2-31; defaults of
+    models/fastenhancer/dptransformer/model.py:408-419, 520-545) -> FEConfig with lookbehind set.  (final_scale_init only
+    shapes the initial value of the final conv's scale.)"""
+    if final_scale not in (True, False, "exp"):
+        raise AssertionError(f"final_scale={final_scale}")
+    dk = dict(dpt_kwargs or {})
+    if dk.get("pre_norm", True):
+        raise RuntimeError("dpt_kwargs.pre_norm=True (the reference's default) is not supported by the HIP path (shipped yamls: False).")
+    L = int(dk.get("lookbehind", 16))
+    if L != 31:
+        raise RuntimeError(f"dpt_kwargs.lookbehind={L} is not supported by the HIP path (every shipped dpt yaml uses 31).")
+    rk = {k: v for k, v in dk.items() if k != "lookbehind"}
+    rk.setdefault("eps", 1e-8)
+    base = FEConfig.from_model_kwargs(channels=channels, kernel_size=kernel_size, stride=stride, rnnformer_kwargs=rk,
+                                      activation=activation, activation_kwargs=activation_kwargs, n_fft=n_fft, hop_size=hop_size,
+                                      win_size=win_size, window=window, stft_normalized=stft_normalized, mask=mask,
+                                      input_compression=input_compression, weight_norm=weight_norm,
+                                      normalize_final_conv=normalize_final_conv, pre_post_init=pre_post_init, resnet=False)
+    import dataclasses
+    return dataclasses.replace(base, lookbehind=L, final_scale_exp=(final_scale == "exp"))
 
 
 BSRNN_SUBBANDS = (2,) + (3,) * 10 + (8,) * 12 + (16,) * 7 + (17,)     # models/bsrnn/model.py:107-111

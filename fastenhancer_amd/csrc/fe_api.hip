@@ -50,6 +50,9 @@ struct Dims {
     int ks[FE_MAX_KERNELS];
     int KT = 1;                // kernel_size_time (time_kernel variant)
     int FR = 0;                // 1: dprnn variant (sub-band GRU of C2 / 2 hidden units per direction instead of the attention)
+    int TA = 0;                // > 0: dptransformer variant (causal attention over the last TA frames instead of the time GRU)
+    // model-state floats per stream: KB GRU states [F2][C2], or (dptransformer) 2 KB caches [F2][NH][TA][HD]
+    size_t hstate() const { return (size_t)KB * F2 * C2 * (TA ? 2 * TA : 1); }
 };
 
 // ---------------------------------------------------------------------------- dispatch table
@@ -135,13 +138,17 @@ void build_sections(fe_handle* h) {
     add_section(h, "rf_pre.0.weight", {d.F2, d.F1});
     add_section(h, "rf_pre.1.weight", {d.C2, d.C1, 1});
     add_section(h, "rf_pre.1.bias", {d.C2});
+    if (d.TA) add_section(h, "time_pe", {4, d.TA + 1});      // the dptransformer model's positional bias (its `pe` parameter)
     for (int k = 0; k < d.KB; ++k) {
         auto key = [&](const char* s) { snprintf(nm, sizeof nm, "rf_block.%d.%s", k, s); return std::string(nm); };
         if (k == 0 && !d.FR) add_section(h, key("pe"), {d.F2, d.C2});
+        if (d.TA) add_section(h, key("time_attn.qkv.weight"), {3 * d.C2, d.C2});
+        else {
         add_section(h, key("rnn.weight_ih_l0"), {3 * d.C2, d.C2});
         add_section(h, key("rnn.weight_hh_l0"), {3 * d.C2, d.C2});
         add_section(h, key("rnn.bias_ih_l0"), {3 * d.C2});
         add_section(h, key("rnn.bias_hh_l0"), {3 * d.C2});
+        }
         add_section(h, key("rnn_fc.weight"), {d.C2, d.C2});
         add_section(h, key("rnn_fc.bias"), {d.C2});
         if (d.FR) {     // DPRNN's fused state_dict (models/fastenhancer/dprnn/model.py:159-161), module names as the default model's
@@ -274,8 +281,15 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
         pack_1x1(o.rfpre_w, S("rf_pre.1.weight"), C1, C2);
         p.rep4(o.rfpre_b, C2, S("rf_pre.1.bias"));
     }
+    if (d.TA) {     // [NH][L + 1] -> [NH][32]
+        const float* tp = S("time_pe");
+        for (int hh = 0; hh < 4; ++hh)
+            for (int j = 0; j <= d.TA; ++j) p.buf[o.tpe + hh * 32 + j] = tp[hh * (d.TA + 1) + j];
+    }
     for (int k = 0; k < d.KB; ++k) {
         auto key = [&](const char* s) { snprintf(nm, sizeof nm, "rf_block.%d.%s", k, s); return std::string(nm); };
+        if (d.TA) pack_1x1(o.blk_tqkv[k], S(key("time_attn.qkv.weight")), C2, 3 * C2);
+        else
         {   // GRU (3*C2, C2), gate order r,z,n: one padded column block per gate
             const int gsz = fe::ceil_div(C2, 16) * (C2 / 4) * 64, bsz = fe::round_up(C2, 16);
             const float* wih = S(key("rnn.weight_ih_l0"));
@@ -1150,21 +1164,24 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
     if (fr && 2 * cfg->channels_frnn != cfg->rf_channels)
         return fail(FE_ERR_UNSUPPORTED_CONFIG, "channels_frnn=%d with channels=%d (the dprnn kernels are built for channels_frnn = channels / 2, every shipped yaml)",
                     cfg->channels_frnn, cfg->rf_channels);
+    const int ta = cfg->lookbehind > 0 ? cfg->lookbehind : 0;
+    if (ta && ta != 31) return fail(FE_ERR_UNSUPPORTED_CONFIG, "lookbehind=%d (the dptransformer kernels are built for 31, every shipped yaml)", ta);
+    if (ta && fr) return fail(FE_ERR_INVALID_ARG, "channels_frnn and lookbehind are exclusive");
     for (const fe::Impl* im : impls())
         if (im->C1 == cfg->channels && im->NL == cfg->n_kernels - 1 && im->C2 == cfg->rf_channels && im->F2 == cfg->rf_freq &&
-            im->KB == cfg->rf_blocks && im->NFFT == cfg->n_fft && im->HOP == cfg->hop_size && im->KT == kt && im->LOW == 0 && im->FR == fr)
+            im->KB == cfg->rf_blocks && im->NFFT == cfg->n_fft && im->HOP == cfg->hop_size && im->KT == kt && im->LOW == 0 && im->FR == fr && im->TA == ta)
             impl = im;
     const fe::Impl* impl_many = nullptr;
     for (const fe::Impl* im : impls())
         if (impl && im->LOW >= 1 && im->occ >= 2 && im->C1 == impl->C1 && im->NL == impl->NL && im->C2 == impl->C2 && im->F2 == impl->F2 &&
-            im->KB == impl->KB && im->NFFT == impl->NFFT && im->HOP == impl->HOP && im->KT == impl->KT && im->FR == impl->FR)
+            im->KB == impl->KB && im->NFFT == impl->NFFT && im->HOP == impl->HOP && im->KT == impl->KT && im->FR == impl->FR && im->TA == impl->TA)
             impl_many = im;
     if (!impl)
         return fail(FE_ERR_UNSUPPORTED_CONFIG,
                     "no kernel compiled for channels=%d layers=%d rf_channels=%d rf_freq=%d rf_blocks=%d n_fft=%d hop=%d kernel_size_time=%d%s "
                     "(build it: python -m fastenhancer_amd.build --add-shape %d,%d,%d,%d,%d,%d,%d,%d%s)",
-                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, kt, fr ? " dprnn" : "",
-                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, kt, fr ? ",0,1" : "");
+                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, kt, fr ? " dprnn" : (ta ? " dptransformer" : ""),
+                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, kt, fr ? ",0,1" : (ta ? ",0,0,31" : ""));
     if (impl->lds_bytes > 160 * 1024)
         return fail(FE_ERR_UNSUPPORTED_CONFIG, "shape needs %zu bytes of LDS (> 160 KiB per CU)", impl->lds_bytes);
     fe_handle* h = new fe_handle();
@@ -1174,6 +1191,7 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
     h->d = Dims{impl->C1, impl->NL, impl->C2, impl->F2, impl->KB, impl->NFFT, impl->HOP, impl->NFFT / 2, impl->NFFT / 8, impl->C2 / 4, {0}};
     h->d.KT = impl->KT;
     h->d.FR = impl->FR;
+    h->d.TA = impl->TA;
     for (int i = 0; i < cfg->n_kernels; ++i) h->d.ks[i] = cfg->kernel_size[i];
     if (hipGetDevice(&h->device) != hipSuccess) h->device = -1;   // no GPU: sections/tables still usable
     else {
@@ -1238,7 +1256,7 @@ size_t fe_state_floats(const fe_handle* h, int B) {
     if (h->limpl) return (size_t)B * (2 * (size_t)(d.NFFT - d.HOP) + h->limpl->cache_floats);
     if (h->fimpl) return (size_t)B * 2 * (size_t)(d.NFFT - d.HOP) + fspen_gru_floats(B);
     if (h->bimpl) return (size_t)B * 2 * (size_t)(d.NFFT - d.HOP) + bsrnn_lstm_floats(h, B);
-    return (size_t)B * (2 * (size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2 + tk_floats(h));
+    return (size_t)B * (2 * (size_t)(d.NFFT - d.HOP) + d.hstate() + tk_floats(h));
 }
 
 int fe_state_init(fe_handle* h, float* state_dev, int B, void* stream) {
@@ -1299,7 +1317,7 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
     a.cache_stft = state;
     a.cache_istft = state + (size_t)B * ovl;
     a.h = state + 2 * (size_t)B * ovl;
-    a.tk = a.h + (size_t)d.KB * B * d.F2 * d.C2;
+    a.tk = a.h + (size_t)B * d.hstate();
     a.dbg = dbg;
     a.clk = clk;
     a.dbg_stride = h->impl->dbg_floats;
@@ -1336,6 +1354,7 @@ int fe_profile_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, flo
 static int pipe_width(const fe_handle* h, int B, int T) {
     if (!h->impl || h->pipe_frames == 0 || h->pipe_frames == 1 || T < 4 || 2 * B > h->max_wgs) return 0;
     if (h->d.KT > 1) return 0;     // (the time_kernel convs carry whole input frames from frame to frame: one workgroup walks them)
+    if (h->d.TA) return 0;         // (so do the dptransformer variant's K / V caches)
     // automatic width: a hand-off (counter round trip + state fetch + the h half of the GRU + gates + publish) takes
     // ~2.6 us whatever the model; a frame takes ~4 us per MFLOP/frame at the measured kernel efficiency: that many frames
     // are worth having in flight (measured optimum: T 8-12, B 16, 48 kHz B 24, L > 24), more only adds pollers
@@ -1383,7 +1402,7 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
     a.spec_in = spec_in_dev;
     a.spec_out = spec_out_dev;
     a.h = h_dev;
-    a.tk = h_dev + (size_t)h->d.KB * B * h->d.F2 * h->d.C2;
+    a.tk = h_dev + (size_t)B * h->d.hstate();
     hipError_t e = hipSuccess;
     a.mode = fe::FE_MODE_SPEC;
     if (const int P = pipe_width(h, B, T)) {
@@ -1413,7 +1432,7 @@ size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw) {
     if (h->bimpl) return (size_t)B * (size_t)(d.NFFT - d.HOP) + bsrnn_lstm_floats(h, B);
     // GRU state (zero initial state, model.py:626-627) + overlap-add tail, both zeroed by fe_offline; time-pipelined
     // launches: + the frame counters [B][KB] and the windowed output frames [B][T][N]
-    size_t n = (size_t)B * ((size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2 + tk_floats(h));
+    size_t n = (size_t)B * ((size_t)(d.NFFT - d.HOP) + d.hstate() + tk_floats(h));
     const int T = 1 + Tw / d.HOP;
     if (pipe_width(h, B, T)) n += (((size_t)B * d.KB + 3) & ~(size_t)3) + (size_t)B * T * d.NFFT;
     return n;
@@ -1430,7 +1449,7 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
     hipStream_t st = (hipStream_t)stream;
     const int T = 1 + Tw / d.HOP;
     {   // zero the state, the tail and the frame counters (not the frames: every element is written)
-        size_t nz = (size_t)B * ((size_t)(d.NFFT - d.HOP) + (size_t)d.KB * d.F2 * d.C2 + tk_floats(h));
+        size_t nz = (size_t)B * ((size_t)(d.NFFT - d.HOP) + d.hstate() + tk_floats(h));
         if (h->bimpl || h->fimpl || h->limpl) nz = fe_offline_work_floats(h, B, Tw);
         else if (pipe_width(h, B, T)) nz += ((size_t)B * d.KB + 3) & ~(size_t)3;
         FE_HIP_CHECK(hipMemsetAsync(work_dev, 0, nz * sizeof(float), st));
@@ -1481,12 +1500,12 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
     a.cache_istft = work_dev;
     a.cache_stft = work_dev;   // unused in this mode
     a.h = work_dev + (size_t)B * (d.NFFT - d.HOP);
-    a.tk = a.h + (size_t)d.KB * B * d.F2 * d.C2;
+    a.tk = a.h + (size_t)B * d.hstate();
     hipError_t e = hipSuccess;
     if (const int P = pipe_width(h, B, T)) {
         rc = ensure_tables(h, st);
         if (rc != FE_OK) return rc;
-        float* flags = a.h + (size_t)d.KB * B * d.F2 * d.C2;
+        float* flags = a.h + (size_t)B * d.hstate();
         a.pipe_flags = reinterpret_cast<unsigned int*>(flags);
         a.frames = flags + (((size_t)B * d.KB + 3) & ~(size_t)3);
         a.pipe_p = P;
@@ -1656,7 +1675,8 @@ double fe_flops_per_frame(const fe_handle* h) {
     double m = 2 * C1 * 8 * F1;
     for (int i = 1; i <= d.NL; ++i) m += C1 * C1 * 3 * KT * F1;
     m += F1 * F2 * C1 + C1 * C2 * F2;
-    if (d.FR) {       // time GRU + fc, then the sub-band GRU (input and hidden products of both directions) + fc
+    if (d.TA) m += K * (C2 * C2 * 3 * F2 + 2 * (d.TA + 1) * C2 * F2 + C2 * C2 * F2 + C2 * C2 * 3 * F2 + 2 * F2 * C2 * F2 + C2 * C2 * F2);
+    else if (d.FR) {  // time GRU + fc, then the sub-band GRU (input and hidden products of both directions) + fc
         const double H = C2 / 2;
         m += K * (C2 * C2 * 6 * F2 + C2 * C2 * F2 + 2 * 3 * H * (C2 + H) * F2 + 2 * H * C2 * F2);
     } else

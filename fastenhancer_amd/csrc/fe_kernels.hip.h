@@ -51,10 +51,16 @@ __host__ __device__ constexpr int round_up(int a, int b) { return ceil_div(a, b)
 // per CU: the companion kernel for batches with more streams than CUs, where two workgroups per CU fill each other's stalls.
 // FR = 1: the `fastenhancer.dprnn` variant (models/fastenhancer/dprnn/model.py:135-247): the block's attention is a bidirectional
 // GRU over the F2 sub-bands, C2 / 2 hidden units per direction, zero initial state every frame; no positional embedding.
-template <int C1_, int NL_, int C2_, int F2_, int KB_, int NFFT_, int HOP_, int KT_ = 1, int LOW_ = 0, int FR_ = 0>
+// TA = L > 0: the `fastenhancer.dptransformer` variant (models/fastenhancer/dptransformer/model.py:175-236): the block's time GRU is
+// a causal attention over the last L frames (K / V caches [F2][NH][L][HD] per block and stream in the state) with a learned
+// positional bias [NH][L + 1].
+template <int C1_, int NL_, int C2_, int F2_, int KB_, int NFFT_, int HOP_, int KT_ = 1, int LOW_ = 0, int FR_ = 0, int TA_ = 0>
 struct Shape {
     static constexpr int C1 = C1_, NL = NL_, C2 = C2_, F2 = F2_, KB = KB_, NFFT = NFFT_, HOP = HOP_, KT = KT_, LOW = LOW_;
     static constexpr bool FRNN = FR_ != 0;
+    static constexpr bool TATT = TA_ != 0;
+    static constexpr int LB = TA_;                // dptransformer: lookbehind
+    static constexpr int HSTATE = TATT ? 2 * LB * F2_ * C2_ : F2_ * C2_;      // model-state floats per block and stream
     static constexpr int HF = C2_ / 2;            // dprnn: hidden units per direction of the sub-band GRU
     static constexpr int NH = 4;
     static constexpr int HD = C2 / NH;
@@ -118,6 +124,8 @@ struct PackedOffsets {
     // [direction][gate r|z|n][unit]), blk_qkv_b its bias (b_ih, plus b_hh for r and z), blk_fhh the hidden weights
     // [direction][j][gate][unit] (a lane = a unit reads consecutive floats), blk_fbhn b_hn [direction][unit]
     int blk_qkv_b[8], blk_fhh[8], blk_fbhn[8];
+    // dptransformer variant: the time attention's qkv weights per block, the model's positional bias [NH][32] (slot L = current frame)
+    int blk_tqkv[8], tpe;
     int rfpost_lin, rfpost_w, rfpost_b;
     int dec1_w[8], dec1_b[8], dec3_w[16], dec3_b[8];
     int post1_w, post1_b, post_t_w, post_t_b;
@@ -183,7 +191,9 @@ struct Pack {
             if (S::FRNN) {
                 o.blk_qkv_b[k] = alloc(szBias(3 * C2)); o.blk_fhh[k] = alloc(2 * S::HF * 3 * S::HF); o.blk_fbhn[k] = alloc(2 * S::HF);
             }
+            if (S::TATT) o.blk_tqkv[k] = alloc(szB(C2, 3 * C2));
         }
+        if (S::TATT) o.tpe = alloc(S::NH * 32);
         o.blk_stride = S::KB > 1 ? o.blk_wih[1] - o.blk_wih[0] : 0;
         o.gru_flat = S::GFLAT ? 1 : 0;
         o.window = alloc(S::NFFT); o.window_istft = alloc(S::NFFT); o.twiddle = alloc(S::NFFT);
@@ -505,6 +515,16 @@ __device__ __forceinline__ float rows_allreduce(float x, OP op) {
     float c = op(a, b), d = c;
     asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(c), "+v"(d));      // c = even rows twice, d = odd rows twice
     return op(c, d);
+}
+
+// All-reduce over the 16 lanes of each DPP row (rotate by 8, 4, 2, 1 - every lane ends with the row's result).
+template <class OP>
+__device__ __forceinline__ float row16_allreduce(float x, OP op) {
+    x = op(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false)));   // row_ror:8
+    x = op(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false)));   // row_ror:4
+    x = op(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xf, 0xf, false)));   // row_ror:2
+    x = op(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false)));   // row_ror:1
+    return x;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1551,7 +1571,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
             constexpr int KS = F1 / 4;
             const float* Ein = encbuf(S::NL) + LDC;   // row 0 = bin 0
             FE_BEGIN_UNIT(S::U_RFPRE);
-            Wgi.bind(wb, o.blk_wih[0], o.blk_bih[0], GNT, wave);      // block 0's GRU input weights ride in this GEMM
+            Wgi.bind(wb, o.blk_wih[0], o.blk_bih[0], GNT, wave, !S::TATT);      // block 0's GRU input weights ride in this GEMM
             f32x4 acc[S::MT2][NTPW];
             acc_init_zero<S::MT2, NTPW>(acc);
             mma_panel<S::MT2, NTPW, KS, Lds<S>::PDK>(
@@ -1580,10 +1600,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
             // X[f2][c2] = Y1[f2][:] . Wc[c2][:] + b
             constexpr int NTPW = ceil_div(S::NT2, kWaves);
             FE_BEGIN_UNIT(S::U_RFPRE + 1);
-            Wgh.bind(wb, o.blk_whh[0], o.blk_bhh[0], GNT, wave);      // ... and the hidden weights in this one
+            Wgh.bind(wb, o.blk_whh[0], o.blk_bhh[0], GNT, wave, !S::TATT);      // ... and the hidden weights in this one
             // hidden state of block 0: fetched now, parked in LDS after the GEMM
             float hpre[HPT];
-            if constexpr (!PIPE) {     // (PIPE: the state is fetched as late as possible, inside the GRU phase)
+            if constexpr (!PIPE && !S::TATT) {     // (PIPE: the state is fetched as late as possible, inside the GRU phase)
                 const float* hg0 = a.h + (size_t)b * (F2 * C2);
 #pragma unroll
                 for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = hg0[i < F2 * C2 ? i : F2 * C2 - 1]; }   // (clamped, not predicated: no branch per load)
@@ -1602,7 +1622,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     for (int r = 0; r < 4; ++r) xd[(16 * i + r) * LDX] = acc[i][j][r];
                 }
             if constexpr (L::PERHEAD) __syncthreads();       // (there Y1, still being read by slower waves, lies over HS)
-            if constexpr (!PIPE) {
+            if constexpr (!PIPE && !S::TATT) {
 #pragma unroll
             for (int q = 0; q < HPT; ++q) {
                 Hs[hs_off[q]] = hpre[q];
@@ -1622,6 +1642,109 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
             float* hg = a.h + ((size_t)k * a.B + b) * (F2 * C2);
             const int kb = k * o.blk_stride;
             if (k == 0) FE_CLK(20);
+            if constexpr (S::TATT) {
+                // dptransformer variant (models/fastenhancer/dptransformer/model.py:200-236, 378-389): causal attention over time per
+                // sub-band and head.  Phase A: q | k | v of the frame = x W^T -> Gi (the layout of the sub-band attention's qkv).
+                static_assert(!L::PERHEAD && !PIPE && S::LB == 31, "dptransformer: full qkv buffer, one workgroup per stream, lookbehind 31");
+                TokW<NTPW3, S::KS_2, 1, REGW, WS> Wtq;
+                Wtq.fetch(wb, (o.blk_tqkv[0] + kb), -1, S::NT3, wave);
+                Wf1.bind(wb, (o.blk_fc1_w[0] + kb), (o.blk_fc1_b[0] + kb), S::NT2, wave);   // fetched inside the GEMM below
+                if constexpr (GFLAT) Wq.bind(wb, (o.blk_qkv[0] + kb), -1, S::NT3, wave);
+                if (k == 0) {
+#pragma unroll
+                    for (int i = 0; i < S::MT2; ++i)
+#pragma unroll
+                        for (int j = 0; j < NTPW2; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = 16 * i + 4 * lg + r, col = 16 * (wave + 4 * j) + li;
+                                pe_r[i][j][r] = wb.gather_g(o.blk_pe + (row < F2 ? row : F2 - 1) * C2 + (col < C2 ? col : C2 - 1));
+                            }
+                }
+                {
+                    f32x4 acc[S::MT2][NTPW3];
+                    if constexpr (GFLAT) tok_gemm_w<S, NTPW3, S::KS_2, LDX>(acc, Xb + li * LDX + lg, Wtq, FetchSide2<decltype(Wf1), decltype(Wq)>{&Wf1, &Wq});
+                    else tok_gemm_w<S, NTPW3, S::KS_2, LDX>(acc, Xb + li * LDX + lg, Wtq, FetchSide<decltype(Wf1)>{&Wf1});
+                    float* gdst = Gi + (4 * lg) * LDG + 16 * wave + li;
+#pragma unroll
+                    for (int j = 0; j < NTPW3; ++j)
+                        if (wave + 4 * j < S::NT3) {
+#pragma unroll
+                            for (int i = 0; i < S::MT2; ++i)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) gdst[(16 * i + r) * LDG + 64 * j] = acc[i][j][r];
+                        }
+                }
+                __syncthreads();
+                {
+                    // Phase B: 16 lanes per (sub-band, head); lane l owns window positions l and l + 16 of the 32 (position 31 = this
+                    // frame, read from Gi; the others = cache slots, oldest first).  Scores / softmax / weighted values reduce over the
+                    // 16-lane DPP row; the lane also moves its two slots one position down (the reference's k[:, :, -L:]).  A slot
+                    // whose first K element is +inf is masked (how a cache-less run marks frames before the start), as are, in
+                    // offline mode, the slots older than the utterance.
+                    constexpr int LBK = S::LB, PAIRS = F2 * S::NH;
+                    const size_t cstride = (size_t)F2 * C2 * LBK;                    // one cache tensor of one stream: [F2][NH][L][HD]
+                    float* kc = a.h + ((size_t)(2 * k) * a.B + b) * cstride;
+                    float* vc = a.h + ((size_t)(2 * k + 1) * a.B + b) * cstride;
+                    const int grp = tid >> 4, l16 = tid & 15;
+                    const int mask_lo = (a.mode == FE_MODE_OFFLINE) ? (LBK - t > 0 ? LBK - t : 0) : 0;
+                    const float sc = __builtin_amdgcn_rsqf((float)HD);               // (hd)^-0.5
+                    constexpr int NIT = ceil_div(PAIRS, 16);
+#pragma unroll 1
+                    for (int it = 0; it < NIT; ++it) {
+                        int p = grp + 16 * it;
+                        const bool live = p < PAIRS;
+                        p = live ? p : PAIRS - 1;                                   // (idle groups of the last round shadow the last pair, stores predicated)
+                        const int f = p / S::NH, hh = p - f * S::NH;
+                        const float* qk = Gi + f * LDG + hh * 3 * HD;
+                        float* kp = kc + (size_t)p * (LBK * HD);
+                        float* vp = vc + (size_t)p * (LBK * HD);
+                        const int j1 = l16 + 16;                                    // slot 31 = the current frame
+                        const int j1c = j1 < LBK ? j1 : LBK - 1;
+                        float k0[HD], k1[HD], v0[HD], v1[HD];
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) k0[d] = kp[l16 * HD + d];
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) k1[d] = kp[j1c * HD + d];
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) v0[d] = vp[l16 * HD + d];
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) v1[d] = vp[j1c * HD + d];
+                        if (j1 == LBK) {
+#pragma unroll
+                            for (int d = 0; d < HD; ++d) { k1[d] = qk[HD + d]; v1[d] = qk[2 * HD + d]; }
+                        }
+                        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) { const float qd = qk[d]; s0 = fmaf(qd, k0[d], s0); s1 = fmaf(qd, k1[d], s1); }
+                        const float ninf = -__builtin_inff();
+                        s0 = (l16 < mask_lo || k0[0] == __builtin_inff()) ? ninf : fmaf(sc, s0, wb.gather_g(o.tpe + hh * 32 + l16));
+                        s1 = (j1 < mask_lo || (j1 < LBK && k1[0] == __builtin_inff())) ? ninf : fmaf(sc, s1, wb.gather_g(o.tpe + hh * 32 + j1));
+                        const float mx = row16_allreduce(fmaxf(s0, s1), [](float x, float y) { return fmaxf(x, y); });
+                        const float e0 = __expf(s0 - mx), e1 = __expf(s1 - mx);
+                        const float inv = __builtin_amdgcn_rcpf(row16_allreduce(e0 + e1, [](float x, float y) { return x + y; }));
+                        float od = 0.0f;       // output element d = l16 (+ 16)
+                        float od2 = 0.0f;
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) {
+                            const float sum = row16_allreduce(e0 * v0[d] + e1 * v1[d], [](float x, float y) { return x + y; });
+                            if (d < 16) od = (l16 == d) ? sum : od; else od2 = (l16 == d - 16) ? sum : od2;
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every cache load of this pair has landed before its slots are overwritten
+                        if (live) {
+                            if (l16 < HD) Hl[f * LDX + hh * HD + l16] = od * inv;
+                            if (HD > 16 && l16 + 16 < HD) Hl[f * LDX + hh * HD + l16 + 16] = od2 * inv;
+                            // shift: slot j -> j - 1 (slot 0 drops out); every load of this pair has completed (the stores use their data)
+                            if (l16 >= 1) {
+#pragma unroll
+                                for (int d = 0; d < HD; ++d) { kp[(l16 - 1) * HD + d] = k0[d]; vp[(l16 - 1) * HD + d] = v0[d]; }
+                            }
+#pragma unroll
+                            for (int d = 0; d < HD; ++d) { kp[(j1 - 1) * HD + d] = k1[d]; vp[(j1 - 1) * HD + d] = v1[d]; }
+                        }
+                    }
+                }
+            } else
             {
                 // GRU (nn.GRU gate order r,z,n; model.py:187,271), gates fused into the GEMM epilogue:
                 //   ax[.][g] = x W_i{g}^T + b_i{g},  ah[.][g] = h W_h{g}^T + b_h{g}   for this wave's channel tiles
@@ -1893,7 +2016,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 constexpr int NTPW = NTPW3;
                 // fetched inside the GEMM: attn_fc weights and the next block's GRU input weights
                 if constexpr (!GFLAT) Wf2.bind(wb, (o.blk_fc2_w[0] + kb), (o.blk_fc2_b[0] + kb), S::NT2, wave);
-                Wgi.bind(wb, (o.blk_wih[0] + kb + o.blk_stride), (o.blk_bih[0] + kb + o.blk_stride), GNT, wave, k + 1 < S::KB);
+                Wgi.bind(wb, (o.blk_wih[0] + kb + o.blk_stride), (o.blk_bih[0] + kb + o.blk_stride), GNT, wave, k + 1 < S::KB && !S::TATT);
                 if constexpr (!L::PERHEAD) {
                 f32x4 acc[S::MT2][NTPW];
                 __builtin_amdgcn_sched_barrier(0);
@@ -2012,15 +2135,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 constexpr int NTPW = ceil_div(S::NT2, kWaves);
                 float hpre[HPT];
                 // next block: GRU hidden weights into registers inside the GEMM; hidden state fetched now / parked after it
-                Wgh.bind(wb, (o.blk_whh[0] + kb + o.blk_stride), (o.blk_bhh[0] + kb + o.blk_stride), GNT, wave, k + 1 < S::KB);
-                if (!PIPE && k + 1 < S::KB) {
+                Wgh.bind(wb, (o.blk_whh[0] + kb + o.blk_stride), (o.blk_bhh[0] + kb + o.blk_stride), GNT, wave, k + 1 < S::KB && !S::TATT);
+                if (!PIPE && !S::TATT && k + 1 < S::KB) {
                     const float* hgn = hg + (size_t)a.B * (F2 * C2);
 #pragma unroll
                     for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = hgn[i < F2 * C2 ? i : F2 * C2 - 1]; }
                 }
                 f32x4 acc[S::MT2][NTPW];
                 tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf2, FetchSide<decltype(Wgh)>{&Wgh});
-                if (!PIPE && k + 1 < S::KB) {
+                if (!PIPE && !S::TATT && k + 1 < S::KB) {
 #pragma unroll
                     for (int q = 0; q < HPT; ++q) {
                         Hs[hs_off[q]] = hpre[q];

@@ -65,6 +65,7 @@ class Engine:
             c.rf_channels, c.rf_freq, c.rf_blocks, c.rf_heads = cfg.rf_channels, cfg.rf_freq, cfg.rf_blocks, cfg.rf_heads
             c.kernel_size_time = cfg.kernel_size_time
             c.channels_frnn = cfg.channels_frnn
+            c.lookbehind = cfg.lookbehind
         self._h = c_void_p()
         if self.device is not None and self.device.type == "cuda":
             with torch.cuda.device(self.device):
@@ -163,6 +164,12 @@ class Engine:
             n = B * c.n_bands * c.hidden
             for _ in range(2 * c.num_layers):
                 out.append(state[o:o + n].view(B * c.n_bands, c.hidden))
+                o += n
+            return out
+        if c.dpt:     # K and V caches per block, [B*F2, NH, L, hd] (models/fastenhancer/dptransformer/model.py:194-198)
+            n = B * c.rf_freq * c.rf_channels * c.lookbehind
+            for _ in range(2 * c.rf_blocks):
+                out.append(state[o:o + n].view(B * c.rf_freq, c.rf_heads, c.lookbehind, c.rf_channels // c.rf_heads))
                 o += n
             return out
         n = B * c.rf_freq * c.rf_channels

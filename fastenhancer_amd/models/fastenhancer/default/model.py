@@ -92,6 +92,9 @@ class ONNXModel:
         """model.py:614-618, sized for the B = x.size(0) streams of the batch (b-major).  (time_kernel variant: + the
         causal convs' frame caches, in its order encoder / GRU / decoder - time_kernel/model.py:746-754)"""
         B, c = x.size(0), self.cfg
+        if c.dpt:     # dptransformer variant: h_k, h_v per block (dptransformer/model.py:194-198, 740-744)
+            return [torch.zeros(B * c.rf_freq, c.rf_heads, c.lookbehind, c.rf_channels // c.rf_heads, dtype=torch.float32, device=x.device)
+                    for _ in range(2 * c.rf_blocks)]
         hs = [torch.zeros(1, B * self.rf_freq, self.rf_ch, dtype=torch.float32, device=x.device) for _ in range(c.rf_blocks)]
         if not c.time_kernel:
             return hs
@@ -103,9 +106,17 @@ class ONNXModel:
         Functional like the reference: the caches passed in are not modified."""
         B = spec_noisy.size(0)
         cfg, eng = self.cfg, self.engine
-        n_caches = cfg.rf_blocks + (2 * cfg.n_layers if cfg.time_kernel else 0)
+        n_caches = 2 * cfg.rf_blocks if cfg.dpt else cfg.rf_blocks + (2 * cfg.n_layers if cfg.time_kernel else 0)
         if len(args) == 0:
             h = torch.zeros(eng.model_state_floats(B), dtype=torch.float32, device=eng.device)
+            if cfg.dpt:
+                # the dptransformer variant without caches masks the frames before the start (dptransformer/model.py:216-218)
+                # instead of attending to zero caches: marked by +inf in the first element of every K slot (fe_config.lookbehind).
+                # (The caches returned keep all L slots, the not-yet-filled ones still marked; the reference returns min(T, L) slots.)
+                n = B * cfg.rf_freq * cfg.rf_channels * cfg.lookbehind
+                hd = cfg.rf_channels // cfg.rf_heads
+                for k in range(cfg.rf_blocks):
+                    h[2 * k * n:(2 * k + 1) * n].view(-1, hd)[:, 0] = float("inf")
         else:
             assert len(args) == n_caches, f"expected {n_caches} caches, got {len(args)}"
             h = torch.cat([t.to(eng.device, torch.float32) for t in eng.model_state_order(list(args))]).contiguous()

@@ -46,11 +46,27 @@ def dprnn_canonical_key(k: str) -> str:
     return k
 
 
+# models/fastenhancer/dptransformer/model.py:580-610 module names -> the default model's (the model-level `pe` is `time_pe`)
+_DPT_NAMES = (("dpt_pre.", "rf_pre."), ("dpt_post.", "rf_post."), ("dpt_block.", "rf_block."), (".time_fc.", ".rnn_fc."),
+              (".time_post_norm.", ".rnn_post_norm."), (".freq_attn.", ".attn."), (".freq_fc.", ".attn_fc."),
+              (".freq_post_norm.", ".attn_post_norm."))
+
+
+def dpt_canonical_key(k: str) -> str:
+    if k == "pe":
+        return "time_pe"
+    for a, b in _DPT_NAMES:
+        k = k.replace(a, b)
+    return k
+
+
 def fold_state_dict(sd: Mapping[str, Tensor], cfg: FEConfig) -> Dict[str, Tensor]:
     """Training-form -> fused-form state_dict (keys of SURVEY.md Appendix A.1 'Fused')."""
     sd = {k: _f32(v) for k, v in sd.items() if torch.as_tensor(v).is_floating_point()}
     if cfg.dprnn:      # the dprnn variant's module names (models/fastenhancer/dprnn/model.py:412-436) -> the default model's
         sd = {dprnn_canonical_key(k): v for k, v in sd.items()}
+    if cfg.dpt:
+        sd = {dpt_canonical_key(k): v for k, v in sd.items()}
     if is_fused(sd):
         sd = dict(sd)
         sd.pop("dec_post.2.scale", None)     # (the time_kernel variant's fused state_dict still lists the folded-in scale)
@@ -69,18 +85,25 @@ def fold_state_dict(sd: Mapping[str, Tensor], cfg: FEConfig) -> Dict[str, Tensor
         conv_bn(f"encoder.{i}.0", f"encoder.{i}.1", f"encoder.{i}.0")
     out["rf_pre.0.weight"] = sd["rf_pre.0.weight"]
     conv_bn("rf_pre.1", "rf_pre.2", "rf_pre.1")
+    if cfg.dpt:
+        out["time_pe"] = sd["time_pe"]
     for k in range(cfg.rf_blocks):
         p = f"rf_block.{k}."
         if p + "pe" in sd:
             out[p + "pe"] = sd[p + "pe"]
-        for name in ("weight_ih_l0", "weight_hh_l0"):
-            g = p + f"rnn.parametrizations.{name}.original0"
-            if g in sd:
-                out[p + "rnn." + name] = _weight_norm(sd[g], sd[p + f"rnn.parametrizations.{name}.original1"])
-            else:
-                out[p + "rnn." + name] = sd[p + "rnn." + name]
-        out[p + "rnn.bias_ih_l0"] = sd[p + "rnn.bias_ih_l0"]
-        out[p + "rnn.bias_hh_l0"] = sd[p + "rnn.bias_hh_l0"]
+        if cfg.dpt:        # DPTBlock.remove_weight_reparameterizations, dptransformer/model.py:323-336
+            g = p + "time_attn.qkv.parametrizations.weight.original0"
+            out[p + "time_attn.qkv.weight"] = (_weight_norm(sd[g], sd[p + "time_attn.qkv.parametrizations.weight.original1"]) if g in sd
+                                               else sd[p + "time_attn.qkv.weight"])
+        else:
+            for name in ("weight_ih_l0", "weight_hh_l0"):
+                g = p + f"rnn.parametrizations.{name}.original0"
+                if g in sd:
+                    out[p + "rnn." + name] = _weight_norm(sd[g], sd[p + f"rnn.parametrizations.{name}.original1"])
+                else:
+                    out[p + "rnn." + name] = sd[p + "rnn." + name]
+            out[p + "rnn.bias_ih_l0"] = sd[p + "rnn.bias_ih_l0"]
+            out[p + "rnn.bias_hh_l0"] = sd[p + "rnn.bias_hh_l0"]
         if cfg.dprnn:      # DPRNN.remove_weight_reparameterizations, dprnn/model.py:172-192
             for name in ("weight_ih_l0", "weight_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse"):
                 g = p + f"frnn.parametrizations.{name}.original0"
@@ -127,14 +150,19 @@ def expected_fused_shapes(cfg: FEConfig) -> Dict[str, tuple]:
     s["rf_pre.0.weight"] = (F2, F1)
     s["rf_pre.1.weight"] = (C2, C1) + one
     s["rf_pre.1.bias"] = (C2,)
+    if cfg.dpt:
+        s["time_pe"] = (cfg.rf_heads, cfg.lookbehind + 1)
     for k in range(cfg.rf_blocks):
         p = f"rf_block.{k}."
         if k == 0 and not cfg.dprnn:
             s[p + "pe"] = (F2, C2)
-        s[p + "rnn.weight_ih_l0"] = (3 * C2, C2)
-        s[p + "rnn.weight_hh_l0"] = (3 * C2, C2)
-        s[p + "rnn.bias_ih_l0"] = (3 * C2,)
-        s[p + "rnn.bias_hh_l0"] = (3 * C2,)
+        if cfg.dpt:
+            s[p + "time_attn.qkv.weight"] = (3 * C2, C2)
+        else:
+            s[p + "rnn.weight_ih_l0"] = (3 * C2, C2)
+            s[p + "rnn.weight_hh_l0"] = (3 * C2, C2)
+            s[p + "rnn.bias_ih_l0"] = (3 * C2,)
+            s[p + "rnn.bias_hh_l0"] = (3 * C2,)
         s[p + "rnn_fc.weight"] = (C2, C2)
         s[p + "rnn_fc.bias"] = (C2,)
         if cfg.dprnn:
@@ -234,7 +262,7 @@ def default_state_dict(cfg: FEConfig, generator: Optional[torch.Generator] = Non
     g = generator
     shapes = expected_fused_shapes(cfg)
     sd: Dict[str, Tensor] = {}
-    fb = linear_filterbank_time_kernel if cfg.time_kernel or cfg.dprnn else linear_filterbank
+    fb = linear_filterbank_time_kernel if cfg.time_kernel or cfg.dprnn or cfg.dpt else linear_filterbank
     pre, post = (fb(cfg.F1, cfg.rf_freq) if (cfg.pre_post_init or "").startswith("linear") else (None, None))
     for k, shp in shapes.items():
         fan_in = 1
@@ -245,6 +273,8 @@ def default_state_dict(cfg: FEConfig, generator: Optional[torch.Generator] = Non
             sd[k] = pre
         elif k == "rf_post.0.weight" and post is not None:
             sd[k] = post
+        elif k == "time_pe":       # calculate_positional_embedding(num_heads, lookbehind + 1), transposed (dptransformer/model.py:582-586)
+            sd[k] = positional_embedding(cfg.rf_heads, cfg.lookbehind + 1).t().contiguous()
         elif k.endswith(".pe"):
             sd[k] = positional_embedding(cfg.rf_channels, cfg.rf_freq)
         elif k.endswith("bias") and ".rnn." not in k and ".frnn." not in k:

@@ -65,6 +65,13 @@ typedef struct fe_config {
                                       * (must be rf_channels / 2, as in every shipped yaml); 0 = the default RNNFormer block.
                                       * rf_heads is ignored.  Weight sections: rf_block.k.frnn.{weight,bias}_{ih,hh}_l0[_reverse],
                                       * rf_block.k.frnn_fc.{weight,bias} instead of attn.qkv / attn_fc, no pe; state as the default model */
+    int lookbehind;                  /* `model: fastenhancer.dptransformer` (models/fastenhancer/dptransformer/model.py; configs/ablation/dpt_*.yaml):
+                                      * frames of history of the causal time attention that replaces the time GRU (31 in every shipped
+                                      * yaml, the only value compiled); 0 = the default block.  Weight sections: time_pe [NH, L+1] (the model's
+                                      * `pe`), rf_block.k.time_attn.qkv.weight instead of rnn.*.  State (and fe_spec_step's h_dev): per
+                                      * block the K cache then the V cache, each [B*F2, NH, L, C2/NH], oldest frame first
+                                      * (DPTBlock.initialize_cache, :194-198).  A cache slot whose first K element is +inf does not take part
+                                      * (how a run "without caches", :216-218, marks the frames before the start; zero caches do take part) */
 } fe_config;
 
 typedef struct fe_handle fe_handle;

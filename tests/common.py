@@ -133,10 +133,12 @@ def build_fspen_oracle(dtype=np.float32):
 
 def product_config(name):
     """the HIP path's FEConfig for a MODEL_KWARGS entry (the time_kernel variant's yaml has its own keys)"""
-    from fastenhancer_amd.config import FEConfig as PCfg, dprnn_config, time_kernel_config
+    from fastenhancer_amd.config import FEConfig as PCfg, dprnn_config, dpt_config, time_kernel_config
     kw = MODEL_KWARGS[name][0]
     if MODEL_MODULE[name] == "fastenhancer.dprnn":
         return dprnn_config(**kw)
+    if MODEL_MODULE[name] == "fastenhancer.dptransformer":
+        return dpt_config(**kw)
     return time_kernel_config(**kw) if MODEL_MODULE[name] == "fastenhancer.time_kernel" else PCfg.from_model_kwargs(**kw)
 
 

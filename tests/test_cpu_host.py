@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 
 @pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m", "fe48_l", "fe48_b_h480", "fe_tk_b",
-                                  "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_s", "fe_dprnn_m", "fe_dprnn_l"])
+                                  "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_s", "fe_dprnn_m", "fe_dprnn_l", "fe_dpt_t", "fe_dpt_b", "fe_dpt_s", "fe_dpt_m"])
 def test_section_table_matches_fused_schema(name):
     cfg = product_config(name)
     eng = Engine(cfg, None)
@@ -73,7 +73,7 @@ def test_config_rejects_what_the_reference_rejects():
         FEConfig.from_model_kwargs(**{**kw, "mask": "softmax"})
 
 
-@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_l", "fe48_b", "fe_tk_b", "fe_dprnn_b"])
+@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_l", "fe48_b", "fe_tk_b", "fe_dprnn_b", "fe_dpt_b"])
 def test_host_fold_matches_oracle_fold(name):
     cfg_o, sd, fused_o, _ = build_oracle(name)
     cfg = product_config(name)
@@ -267,6 +267,37 @@ def test_dprnn_mirror_loads_the_reference_module_names():
         np.testing.assert_allclose(fused[k].numpy(), fused_o[k], rtol=3e-6, atol=1e-7, err_msg=k)
     with pytest.raises(RuntimeError, match="channels_frnn"):
         dprnn_config(**{**kw, "dprnn_kwargs": dict(kw["dprnn_kwargs"], channels_frnn=16)})
+
+
+def test_dptransformer_mirror_loads_the_reference_module_names():
+    """fastenhancer.dptransformer mirror: config (lookbehind 31, per-block K / V caches), a checkpoint with the reference's module
+    names (dpt_pre / dpt_block.k.time_attn / freq_attn / dpt_post / pe) folds to the oracle's fused weights; state size; pre_norm
+    (the reference's default) and other lookbehinds are rejected with a message."""
+    import importlib
+    from common import MODEL_MODULE
+    from fastenhancer_amd.config import dpt_config
+    from oracle.fe_oracle import reference_key
+    kw = MODEL_KWARGS["fe_dpt_b"][0]
+    mod = importlib.import_module(f"fastenhancer_amd.models.{MODEL_MODULE['fe_dpt_b']}.model")
+    m = mod.ONNXModel(**kw)
+    cfg = m.cfg
+    assert cfg.dpt and cfg.lookbehind == 31 and cfg.rf_eps == 1e-5 and not cfg.final_scale_exp
+    assert [tuple(c.shape) for c in m.initialize_cache(torch.zeros(2, 1))] == [(2 * 24, 4, 31, 9)] * 6
+    assert tuple(m.state_dict()["time_pe"].shape) == (4, 32)
+    cfg_o, sd, fused_o, _ = build_oracle("fe_dpt_b")
+    ref_named = {reference_key(k, cfg_o): torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    assert "pe" in ref_named and any(k.startswith("dpt_block.0.time_attn.qkv.parametrizations") for k in ref_named) and "dpt_block.0.freq_fc.weight" in ref_named
+    m.load_state_dict(ref_named, strict=True)
+    fused = fold_state_dict(ref_named, cfg)
+    assert set(fused) == set(fused_o)
+    for k in fused:
+        np.testing.assert_allclose(fused[k].numpy(), fused_o[k], rtol=3e-6, atol=1e-7, err_msg=k)
+    eng = Engine(cfg, None)
+    assert eng.state_floats(3) == 3 * (2 * 256 + 6 * 24 * 36 * 31)
+    with pytest.raises(RuntimeError, match="pre_norm"):
+        dpt_config(**{**kw, "dpt_kwargs": {k: v for k, v in kw["dpt_kwargs"].items() if k != "pre_norm"}})
+    with pytest.raises(RuntimeError, match="lookbehind"):
+        dpt_config(**{**kw, "dpt_kwargs": dict(kw["dpt_kwargs"], lookbehind=16)})
 
 
 def test_fspen_host_side_without_gpu():
