@@ -177,6 +177,27 @@ def host_cpus():
     return avail, quota
 
 
+def cpu_baseline_variant(kw: dict, sr: int, B: int, budget_s: float):
+    """The time_kernel / dprnn / dptransformer variants: the numpy oracle (oracle/fe_oracle.py, pinned on the reference's golden
+    vectors of each variant; the C/OpenMP oracle restates the default model only) on ONE host core."""
+    from oracle.fe_oracle import FEConfig as OCfg, FEOracle, fold_state_dict
+    from oracle.weightgen import make_input, make_training_state_dict
+    cfg = OCfg.from_model_kwargs(kw)
+    orc = FEOracle(cfg, fold_state_dict(make_training_state_dict(cfg, 2), cfg), np.float32)
+    Bs = min(B, 16)
+    H = cfg.hop_size
+    x = make_input(Bs, 64 * H, 5, sr)
+    caches = orc.initialize_cache(Bs)
+    t0 = time.perf_counter()
+    hops = 0
+    while hops < 64 and (hops < 2 or time.perf_counter() - t0 < budget_s):
+        _, *caches = orc.step(x[:, hops * H:(hops + 1) * H], *caches)
+        hops += 1
+    dt = time.perf_counter() - t0
+    return {"value": hops * Bs / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{hops} hops x {Bs} streams through the numpy oracle (oracle/fe_oracle.py) in {dt:.1f} s on one core"}
+
+
 def cpu_baseline_fspen(kw: dict, sr: int, B: int, budget_s: float, lisennet: bool = False):
     """FSPEN / LiSenNet: the numpy oracle (oracle/fspen_oracle.py, oracle/lisennet_oracle.py, pinned on the reference's golden vectors)
     on ONE host core."""
@@ -480,7 +501,9 @@ def main():
             res["cpu_baseline"] = cpu_baseline_fspen(kw, w["sr"], B, args.cpu_budget_s, lisennet=bool(w.get("lisennet")))
         elif world == 1 and not args.no_cpu_baseline and w.get("bsrnn"):
             res["cpu_baseline"] = cpu_baseline_bsrnn(args.workload, kw, w["sr"], B, args.cpu_budget_s)
-        elif world == 1 and not args.no_cpu_baseline and not w.get("kt") and not w.get("frnn") and not w.get("dpt"):
+        elif world == 1 and not args.no_cpu_baseline and (w.get("kt") or w.get("frnn") or w.get("dpt")):
+            res["cpu_baseline"] = cpu_baseline_variant(kw, w["sr"], B, min(args.cpu_budget_s, 10.0))
+        elif world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.workload, kw, w["sr"], B, args.cpu_budget_s)
         print(json.dumps(res), flush=True)
     if use_dist:
