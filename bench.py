@@ -477,6 +477,13 @@ def main():
         frames = B * world * T * args.steps
         flops_per_launch = eng.flops_per_frame * B * T
         achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+        # algorithmic HBM bytes of a launch: the hop in and out, the state read and written back (dptransformer: its K / V caches
+        # are rings - all read, one slot of 31 written per frame)
+        state_bytes = 4 * eng.state_floats(B)
+        alg_bytes = B * T * (2 * H * 4) + 2 * state_bytes
+        if w.get("dpt"):
+            cache_bytes = 4 * B * 2 * w["K"] * w["F2"] * w["C2"] * w["dpt"]
+            alg_bytes = B * T * (2 * H * 4) + state_bytes + (state_bytes - cache_bytes) + T * cache_bytes // w["dpt"]
         res = {
             "metric": "audio frames/sec (hop=256, 16kHz) FastEnhancer_B" if args.workload == "fe_b" else f"audio frames/sec {w['desc']}",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -492,10 +499,10 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": measured_traffic(args.workload, B, T),
                          "algorithmic_flops_per_launch": flops_per_launch,
-                         "algorithmic_hbm_bytes_per_launch": B * T * (2 * H * 4) + 2 * 4 * eng.state_floats(B),
+                         "algorithmic_hbm_bytes_per_launch": alg_bytes,
                          "kernel": "lisennet_frame_kernel" if w.get("lisennet") else "fspen_frame_kernel" if w.get("fspen") else ("bsrnn_frame_kernel" if w.get("bsrnn") else "fe_frame_kernel"), "kernel_ms": kernel_ms,
                          "flops_per_frame": eng.flops_per_frame,
-                         "hbm_frac": (B * T * (2 * H * 4) + 2 * 4 * eng.state_floats(B)) / (kernel_ms * 1e-3) / 8e12},
+                         "hbm_frac": alg_bytes / (kernel_ms * 1e-3) / 8e12},
         }
         if world == 1 and not args.no_cpu_baseline and (w.get("fspen") or w.get("lisennet")):
             res["cpu_baseline"] = cpu_baseline_fspen(kw, w["sr"], B, args.cpu_budget_s, lisennet=bool(w.get("lisennet")))

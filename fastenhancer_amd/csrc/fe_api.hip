@@ -51,8 +51,8 @@ struct Dims {
     int KT = 1;                // kernel_size_time (time_kernel variant)
     int FR = 0;                // 1: dprnn variant (sub-band GRU of C2 / 2 hidden units per direction instead of the attention)
     int TA = 0;                // > 0: dptransformer variant (causal attention over the last TA frames instead of the time GRU)
-    // model-state floats per stream: KB GRU states [F2][C2], or (dptransformer) 2 KB caches [F2][NH][TA][HD]
-    size_t hstate() const { return (size_t)KB * F2 * C2 * (TA ? 2 * TA : 1); }
+    // model-state floats per stream: KB GRU states [F2][C2], or (dptransformer) 2 KB caches [F2][NH][TA][HD] + the ring head
+    size_t hstate() const { return (size_t)KB * F2 * C2 * (TA ? 2 * TA : 1) + (TA ? 1 : 0); }
 };
 
 // ---------------------------------------------------------------------------- dispatch table

@@ -1269,6 +1269,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
         }
     };
 
+    int ring_head0 = 0;                              // dptransformer: slot of the oldest cached frame when this launch starts
+    if constexpr (S::TATT) ring_head0 = (int)a.h[(size_t)a.B * S::KB * S::HSTATE + b];
 #pragma unroll 1
     for (int t = t_first; t < a.T; t += t_step, ++fc) {
         // A loop-variant zero keeps the (many) wave-uniform offsets of a frame from being hoisted out of the frame
@@ -1678,10 +1680,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 __syncthreads();
                 {
                     // Phase B: 16 lanes per (sub-band, head); lane l owns window positions l and l + 16 of the 32 (position 31 = this
-                    // frame, read from Gi; the others = cache slots, oldest first).  Scores / softmax / weighted values reduce over the
-                    // 16-lane DPP row; the lane also moves its two slots one position down (the reference's k[:, :, -L:]).  A slot
-                    // whose first K element is +inf is masked (how a cache-less run marks frames before the start), as are, in
-                    // offline mode, the slots older than the utterance.
+                    // frame, read from Gi; the others = the cached frames, oldest first).  Scores / softmax / weighted values reduce over
+                    // the 16-lane DPP row.  Each cache is a RING over its 31 slots: window position j lives in slot (head + j) mod 31,
+                    // the frame's k / v overwrite slot `head` (the oldest), then head advances - one slot written per pair and frame
+                    // instead of the reference's shift of all 31 (k[:, :, -L:]), which would double the HBM traffic of this HBM-bound
+                    // step.  With head = 0 the ring IS the reference's cache tensor.  A slot whose first K element is +inf is masked
+                    // (how a cache-less run marks frames before the start), as are, in offline mode, the slots older than the utterance.
                     constexpr int LBK = S::LB, PAIRS = F2 * S::NH;
                     const size_t cstride = (size_t)F2 * C2 * LBK;                    // one cache tensor of one stream: [F2][NH][L][HD]
                     float* kc = a.h + ((size_t)(2 * k) * a.B + b) * cstride;
@@ -1689,6 +1693,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     const int grp = tid >> 4, l16 = tid & 15;
                     const int mask_lo = (a.mode == FE_MODE_OFFLINE) ? (LBK - t > 0 ? LBK - t : 0) : 0;
                     const float sc = __builtin_amdgcn_rsqf((float)HD);               // (hd)^-0.5
+                    const int head = (ring_head0 + t) % LBK;
+                    const int j1 = l16 + 16;                                        // position 31 = the current frame
+                    int sl0 = head + l16, sl1 = head + (j1 < LBK ? j1 : LBK - 1);
+                    sl0 = sl0 >= LBK ? sl0 - LBK : sl0;
+                    sl1 = sl1 >= LBK ? sl1 - LBK : sl1;
                     constexpr int NIT = ceil_div(PAIRS, 16);
 #pragma unroll 1
                     for (int it = 0; it < NIT; ++it) {
@@ -1699,17 +1708,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                         const float* qk = Gi + f * LDG + hh * 3 * HD;
                         float* kp = kc + (size_t)p * (LBK * HD);
                         float* vp = vc + (size_t)p * (LBK * HD);
-                        const int j1 = l16 + 16;                                    // slot 31 = the current frame
-                        const int j1c = j1 < LBK ? j1 : LBK - 1;
                         float k0[HD], k1[HD], v0[HD], v1[HD];
 #pragma unroll
-                        for (int d = 0; d < HD; ++d) k0[d] = kp[l16 * HD + d];
+                        for (int d = 0; d < HD; ++d) k0[d] = kp[sl0 * HD + d];
 #pragma unroll
-                        for (int d = 0; d < HD; ++d) k1[d] = kp[j1c * HD + d];
+                        for (int d = 0; d < HD; ++d) k1[d] = kp[sl1 * HD + d];
 #pragma unroll
-                        for (int d = 0; d < HD; ++d) v0[d] = vp[l16 * HD + d];
+                        for (int d = 0; d < HD; ++d) v0[d] = vp[sl0 * HD + d];
 #pragma unroll
-                        for (int d = 0; d < HD; ++d) v1[d] = vp[j1c * HD + d];
+                        for (int d = 0; d < HD; ++d) v1[d] = vp[sl1 * HD + d];
                         if (j1 == LBK) {
 #pragma unroll
                             for (int d = 0; d < HD; ++d) { k1[d] = qk[HD + d]; v1[d] = qk[2 * HD + d]; }
@@ -1730,19 +1737,17 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                             const float sum = row16_allreduce(e0 * v0[d] + e1 * v1[d], [](float x, float y) { return x + y; });
                             if (d < 16) od = (l16 == d) ? sum : od; else od2 = (l16 == d - 16) ? sum : od2;
                         }
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every cache load of this pair has landed before its slots are overwritten
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every cache load of this pair has landed before the oldest slot is overwritten
                         if (live) {
                             if (l16 < HD) Hl[f * LDX + hh * HD + l16] = od * inv;
                             if (HD > 16 && l16 + 16 < HD) Hl[f * LDX + hh * HD + l16 + 16] = od2 * inv;
-                            // shift: slot j -> j - 1 (slot 0 drops out); every load of this pair has completed (the stores use their data)
-                            if (l16 >= 1) {
+                            if (j1 == LBK) {                                  // the lane that holds the frame's k / v
 #pragma unroll
-                                for (int d = 0; d < HD; ++d) { kp[(l16 - 1) * HD + d] = k0[d]; vp[(l16 - 1) * HD + d] = v0[d]; }
+                                for (int d = 0; d < HD; ++d) { kp[head * HD + d] = k1[d]; vp[head * HD + d] = v1[d]; }
                             }
-#pragma unroll
-                            for (int d = 0; d < HD; ++d) { kp[(j1 - 1) * HD + d] = k1[d]; vp[(j1 - 1) * HD + d] = v1[d]; }
                         }
                     }
+                    if (k == S::KB - 1 && tid == 0) a.h[(size_t)a.B * S::KB * S::HSTATE + b] = (float)((head + 1) % LBK);
                 }
             } else
             {

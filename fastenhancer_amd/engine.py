@@ -167,9 +167,21 @@ class Engine:
                 o += n
             return out
         if c.dpt:     # K and V caches per block, [B*F2, NH, L, hd] (models/fastenhancer/dptransformer/model.py:194-198)
+            # In the state every cache is a ring over its L slots with one head per stream (include/fastenhancer_hip.h,
+            # fe_config.lookbehind): the reference's tensors (oldest frame first) are the rings rotated left by head - copies,
+            # unless every head is 0 (a fresh or freshly packed state), when they are views
             n = B * c.rf_freq * c.rf_channels * c.lookbehind
+            L, hd = c.lookbehind, c.rf_channels // c.rf_heads
+            heads = state[o + 2 * c.rf_blocks * n:o + 2 * c.rf_blocks * n + B]
+            rot = bool((heads != 0).any())
+            if rot:
+                idx = (heads.long()[:, None] + torch.arange(L, device=state.device)[None, :]) % L            # [B, L]
+                idx = idx[:, None, None, :, None].expand(B, c.rf_freq, c.rf_heads, L, hd)
             for _ in range(2 * c.rf_blocks):
-                out.append(state[o:o + n].view(B * c.rf_freq, c.rf_heads, c.lookbehind, c.rf_channels // c.rf_heads))
+                t = state[o:o + n].view(B, c.rf_freq, c.rf_heads, L, hd)
+                if rot:
+                    t = torch.gather(t, 3, idx)
+                out.append(t.reshape(B * c.rf_freq, c.rf_heads, L, hd))
                 o += n
             return out
         n = B * c.rf_freq * c.rf_channels
@@ -192,6 +204,9 @@ class Engine:
     def model_state_order(self, caches: List[Tensor]) -> List[Tensor]:
         """the model's cache list (reference order) -> flat pieces in the order of the C ABI state (h ..., then the conv caches)"""
         c = self.cfg
+        if not (self.is_bsrnn or self.is_fspen or self.is_lisennet) and c.dpt:      # reference-order caches = rings with head 0
+            B = caches[0].shape[0] // c.rf_freq
+            return [t.reshape(-1) for t in caches] + [torch.zeros(B, dtype=torch.float32, device=caches[0].device)]
         if self.is_bsrnn or self.is_fspen or self.is_lisennet or not c.time_kernel:
             return [t.reshape(-1) for t in caches]
         nl, K = c.n_layers, c.rf_blocks

@@ -25,6 +25,9 @@ class StreamingModel:
         self._buf: tp.List[tp.Optional[Tensor]] = [None, None]     # two state buffers of the C ABI, used alternately
         self._views: tp.List[tp.Optional[tp.List[Tensor]]] = [None, None]
         self._B = 0
+        # dptransformer variant: its K / V caches are rings in the state, the tensors handed out are rotated copies - the
+        # tensors of the last call are recognised by identity instead of by address
+        self._handed: tp.Tuple[int, tp.List[Tensor]] = (-1, [])
 
     @property
     def engine(self) -> Engine:
@@ -50,6 +53,8 @@ class StreamingModel:
 
     def _which(self, caches) -> int:
         """index of the state buffer the given cache tensors are exactly the views of, else -1"""
+        if self._handed[0] >= 0 and len(caches) == len(self._handed[1]) and all(c is w for c, w in zip(caches, self._handed[1])):
+            return self._handed[0]
         for i in (0, 1):
             v = self._views[i]
             if v is not None and len(v) == len(caches) and all(
@@ -73,6 +78,10 @@ class StreamingModel:
         else:
             self._buf[dst].copy_(eng.pack_state([t.to(eng.device) for t in caches], B))
         wav_out = eng.step(wav_in.to(eng.device, torch.float32), self._buf[dst], T=1)
+        if getattr(self.cfg, "dpt", False):
+            out = eng.split_state(self._buf[dst], B)
+            self._handed = (dst, out)
+            return (wav_out, *out)
         return (wav_out, *self._views[dst])
 
     __call__ = forward

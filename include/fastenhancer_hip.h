@@ -69,9 +69,14 @@ typedef struct fe_config {
                                       * frames of history of the causal time attention that replaces the time GRU (31 in every shipped
                                       * yaml, the only value compiled); 0 = the default block.  Weight sections: time_pe [NH, L+1] (the model's
                                       * `pe`), rf_block.k.time_attn.qkv.weight instead of rnn.*.  State (and fe_spec_step's h_dev): per
-                                      * block the K cache then the V cache, each [B*F2, NH, L, C2/NH], oldest frame first
-                                      * (DPTBlock.initialize_cache, :194-198).  A cache slot whose first K element is +inf does not take part
-                                      * (how a run "without caches", :216-218, marks the frames before the start; zero caches do take part) */
+                                      * block the K cache then the V cache, each [B*F2, NH, L, C2/NH] (DPTBlock.initialize_cache, :194-198),
+                                      * then B floats `head`: every cache is a ring over its L slots - the frame that is t steps old sits
+                                      * in slot (head + L - t) mod L, a step overwrites slot `head` and advances it (one slot written per
+                                      * frame instead of the reference's shift of all L).  head = 0 (fe_state_init, or caches copied in from
+                                      * the reference) is exactly the reference's tensor, oldest frame first; to read the caches back in
+                                      * that order rotate each [.., L, ..] axis left by head.  A cache slot whose first K element is +inf
+                                      * does not take part (how a run "without caches", :216-218, marks the frames before the start; zero
+                                      * caches do take part) */
 } fe_config;
 
 typedef struct fe_handle fe_handle;

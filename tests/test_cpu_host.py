@@ -293,7 +293,7 @@ def test_dptransformer_mirror_loads_the_reference_module_names():
     for k in fused:
         np.testing.assert_allclose(fused[k].numpy(), fused_o[k], rtol=3e-6, atol=1e-7, err_msg=k)
     eng = Engine(cfg, None)
-    assert eng.state_floats(3) == 3 * (2 * 256 + 6 * 24 * 36 * 31)
+    assert eng.state_floats(3) == 3 * (2 * 256 + 6 * 24 * 36 * 31 + 1)      # + the ring head per stream
     with pytest.raises(RuntimeError, match="pre_norm"):
         dpt_config(**{**kw, "dpt_kwargs": {k: v for k, v in kw["dpt_kwargs"].items() if k != "pre_norm"}})
     with pytest.raises(RuntimeError, match="lookbehind"):
