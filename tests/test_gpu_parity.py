@@ -312,6 +312,15 @@ def test_full_size_48khz_hop480_512_streams():
     _full_size_check(m, orc, cfg, sr, 512, 4, [0, 1, 255, 256, 257, 300, 510, 511], "fe48_b_h480 B=512")
 
 
+@pytest.mark.parametrize("name,B,hops", [("fe_dprnn_b", 256, 3), ("fe_dprnn_l", 300, 2), ("fe_dpt_b", 256, 35), ("fe_dpt_t", 700, 4), ("fe_dpt_m", 260, 2)])
+def test_full_size_block_variants(name, B, hops):
+    """the dprnn / dptransformer variants at full batch sizes (one workgroup per stream, and persistent workgroups above #CUs):
+    oracle parity on sample streams, bitwise position independence on all; 35 hops of dpt_b take its K / V rings (31 slots)
+    through a wrap."""
+    m, orc, cfg, sr, seed = _model(name)
+    _full_size_check(m, orc, cfg, sr, B, hops, [0, 1, 17, B // 2, B - 2, B - 1], f"{name} B={B}")
+
+
 @pytest.mark.parametrize("name,B", [("fe_b", 300), ("fe_b", 1100), ("fe_s", 520), ("fe48_t", 700), ("fe48_b", 600), ("fe48_b_h480", 1030)])
 def test_low_lds_companion_above_cus(name, B):
     """above #CUs streams fe_step switches to the shape's low-LDS companion (two workgroups per CU, weights streamed from
