@@ -312,6 +312,32 @@ def test_full_size_48khz_hop480_512_streams():
     _full_size_check(m, orc, cfg, sr, 512, 4, [0, 1, 255, 256, 257, 300, 510, 511], "fe48_b_h480 B=512")
 
 
+def test_dptransformer_cacheless_chunk_longer_than_the_lookbehind():
+    """`ONNXModel(spec)` without caches on 40 frames (> lookbehind 31): frames before the start are masked, not attended to as
+    zeros (dptransformer/model.py:216-218); then the returned caches continue the stream like the oracle's, and a second
+    chunk WITH those caches equals the oracle's continuation."""
+    m, orc, cfg, sr, seed = _model("fe_dpt_t")
+    B, H, T = 2, cfg.hop_size, 40
+    x = make_input(B, (T + 6) * H, 99, sr)
+    cache = orc.initialize_cache(B)[0]
+    specs = []
+    for t in range(T + 6):
+        s_, cache = orc.stft_step(x[:, t * H:(t + 1) * H], cache)
+        specs.append(s_)
+    spec = np.concatenate(specs, axis=2)
+    y_ref, h_ref = orc.spec_forward(spec[:, :, :T], None)
+    spec_d = torch.from_numpy(spec).to(_dev())
+    y, *h = m(spec_d[:, :, :T].contiguous())
+    _assert_close(y.cpu().numpy(), y_ref, "cache-less chunk of 40 frames")
+    zero = orc.spec_forward(spec[:, :, :T], orc.initialize_cache(B)[2:])[0]
+    assert rms(zero - y_ref) > 1e-3 * rms(y_ref), "masked and zero-cache starts must differ (else this test checks nothing)"
+    for a_, b_ in zip(h, h_ref):
+        _assert_close(a_.cpu().numpy(), b_, "caches after the cache-less chunk")
+    y2_ref, _ = orc.spec_forward(spec[:, :, T:], h_ref)
+    y2, *_ = m(spec_d[:, :, T:].contiguous(), *h)
+    _assert_close(y2.cpu().numpy(), y2_ref, "continuation with the returned caches")
+
+
 @pytest.mark.parametrize("name,B,hops", [("fe_dprnn_b", 256, 3), ("fe_dprnn_l", 300, 2), ("fe_dpt_b", 256, 35), ("fe_dpt_t", 700, 4), ("fe_dpt_m", 260, 2)])
 def test_full_size_block_variants(name, B, hops):
     """the dprnn / dptransformer variants at full batch sizes (one workgroup per stream, and persistent workgroups above #CUs):
