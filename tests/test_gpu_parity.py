@@ -522,11 +522,11 @@ def test_time_pipelined_offline_and_spec_agree_with_the_serial_walk(name):
             _assert_close(a_.cpu().numpy(), b_, f"spec chunk caches, pipeline {width}")
 
 
-@pytest.mark.parametrize("name", ["fe_s", "fe48_t", "fe48_s", "fe48_m"])
+@pytest.mark.parametrize("name", ["fe_s", "fe48_t", "fe48_s", "fe48_m", "fe_dprnn_s", "fe_dprnn_m", "fe_dpt_s"])
 def test_offline_matches_oracle(name):
     m, orc, cfg, sr, seed = _model(name, "Model")
     H = cfg.hop_size
-    x = make_input(2, 9 * H + 11, 555, sr)
+    x = make_input(2, (38 if cfg.dpt else 9) * H + 11, 555, sr)        # (dptransformer: more frames than its lookbehind)
     wav_ref, spec_ref = orc.offline_forward(x)
     wav_hat, spec_hat = m(torch.from_numpy(x).to(_dev()))
     _assert_close(wav_hat.cpu().numpy(), wav_ref, "offline wav")
