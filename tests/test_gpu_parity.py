@@ -956,6 +956,29 @@ def test_lisennet_full_size(B):
     assert torch.equal(y1, y2) and torch.equal(s1, s2)
 
 
+@pytest.mark.parametrize("name,hops,T", [("fe_dpt_t", 400, 1), ("fe_dpt_t", 400, 7), ("fe_dprnn_t", 300, 1), ("fe_tk_b", 150, 3)])
+def test_block_variants_long_run_has_no_state_drift(name, hops, T):
+    """hundreds of hops of two streams (per-hop launches, or chunks of T hops) against the oracle: the dptransformer variant's K / V
+    rings go round a dozen times (and chunks of 7 do not divide 31), the GRU / conv-cache variants carry their states"""
+    m, orc, cfg, sr, seed = _model(name)
+    eng = m.engine
+    B, H = 2, cfg.hop_size
+    hops -= hops % T
+    x = make_input(B, hops * H, 1234, sr)
+    xd = torch.from_numpy(x).to(_dev())
+    state = eng.new_state(B)
+    caches = orc.initialize_cache(B)
+    got, ref = [], []
+    for t in range(0, hops, T):
+        got.append(eng.step(xd[:, t * H:(t + T) * H], state, T=T).cpu().numpy())
+    for t in range(hops):
+        o, *caches = orc.step(x[:, t * H:(t + 1) * H], *caches)
+        ref.append(o)
+    _assert_close(np.concatenate(got, axis=1)[:, -40 * H:], np.concatenate(ref[-40:], axis=1), f"{name} last 40 hops of {hops}")
+    for a_, b_ in zip(eng.split_state(state, B), caches):
+        _assert_close(a_.cpu().numpy(), b_, f"{name} cache after {hops} hops")
+
+
 @pytest.mark.parametrize("which", ["fspen", "lisennet"])
 def test_baseline_models_long_run_has_no_state_drift(which):
     """60 hops (0.96 s) of two streams through the per-hop kernel against the oracle: the GRU states and the causal-conv frame caches are
