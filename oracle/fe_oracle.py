@@ -73,12 +73,18 @@ class FEConfig:
     def dpt(self) -> bool:
         return self.lookbehind > 0
 
+    # models/fastenhancer/ln/model.py (configs/ablation/ln_b.yaml): GroupNorm(1, C) after every conv (statistics over the
+    # channels and sub-bands of a frame) and LayerNorm over (F2, C2) after the blocks' fc layers instead of the BatchNorms -
+    # nothing folds into the convs, which carry their own biases
+    ln: bool = False
+
     @property
     def time_kernel(self) -> bool:
         return self.kernel_size_time > 1
 
     @staticmethod
-    def from_model_kwargs(kw: dict) -> "FEConfig":
+    def from_model_kwargs(kw: dict, variant: Optional[str] = None) -> "FEConfig":
+        """variant: the last component of the yaml's `model:` key where the kwargs alone do not tell (`ln`)"""
         dp = "dprnn_kwargs" in kw
         dt = "dpt_kwargs" in kw
         rk = dict(kw.get("dprnn_kwargs" if dp else ("dpt_kwargs" if dt else "rnnformer_kwargs"), {}))
@@ -94,7 +100,8 @@ class FEConfig:
             channels=kw.get("channels", 64),
             kernel_size=tuple(kw["kernel_size_freq"]) if "kernel_size_freq" in kw else tuple(kw.get("kernel_size", (8, 3, 3))),
             kernel_size_time=int(kw.get("kernel_size_time", 3)) if "kernel_size_freq" in kw else 1,
-            final_scale_exp=(("kernel_size_freq" in kw or dp or dt) and kw.get("final_scale", "exp") == "exp"),
+            final_scale_exp=(("kernel_size_freq" in kw or dp or dt or variant == "ln") and kw.get("final_scale", "exp") == "exp"),
+            ln=(variant == "ln"),
             lookbehind=int(rk.get("lookbehind", 16)) if dt else 0,
             channels_frnn=int(rk.get("channels_frnn", 16)) if dp else 0,
             stride=kw.get("stride", 4),
@@ -261,6 +268,26 @@ def mhsa(x: Array, w_qkv: Array, num_heads: int) -> Array:
     return o.transpose(0, 2, 1, 3).reshape(M, F, C)
 
 
+def group_norm1(x: Array, g: Array, b: Array, eps: float = 1e-5) -> Array:
+    """nn.GroupNorm(1, C) on x [M,C,F] (models/fastenhancer/ln/model.py:427 ...): per sample, statistics over (C, F), biased
+    variance, per-channel affine."""
+    m = x.mean(axis=(1, 2), keepdims=True)
+    d = x - m
+    v = (d * d).mean(axis=(1, 2), keepdims=True)
+    return d / np.sqrt(v + x.dtype.type(eps)) * g[None, :, None] + b[None, :, None]
+
+
+def layer_norm_fc(x: Array, g: Array, b: Array, eps: float) -> Array:
+    """LayerNorm of models/fastenhancer/ln/model.py:16-37 on x [..., F, C], statistics over (F, C) - AS WRITTEN there:
+    `w = inv_std.mul(self.weight); x = diff.addcmul(w, self.bias)`, and torch.addcmul(input, t1, t2) = input + t1 * t2, so the
+    output is  (x - mean) + inv_std * weight * bias  - the centred input is NOT scaled by inv_std * weight.  Restated as is
+    (the deployed checkpoints were trained with it)."""
+    m = x.mean(axis=(-2, -1), keepdims=True)
+    d = x - m
+    v = (d * d).mean(axis=(-2, -1), keepdims=True)
+    return d + (g / np.sqrt(v + x.dtype.type(eps))) * b
+
+
 def causal_time_attention(x: Array, w_qkv: Array, pe: Array, num_heads: int, lookbehind: int,
                           h_k: Optional[Array], h_v: Optional[Array]) -> Tuple[Array, Array, Array]:
     """CausalAttention.forward, models/fastenhancer/dptransformer/model.py:200-236.  x [M,T,C] (M = B*F2), pe [NH,L+1] (column L
@@ -423,6 +450,8 @@ def fold_state_dict(sd: Dict[str, Array], cfg: FEConfig) -> Dict[str, Array]:
     sd = {k: np.asarray(v) for k, v in sd.items()}
     if cfg.dprnn or cfg.dpt:
         sd = {canonical_key(k): v for k, v in sd.items()}
+    if cfg.ln:
+        return _fold_state_dict_ln(sd, cfg)
     if "enc_pre.0.bias" in sd:
         return {k: v.astype(np.float32) for k, v in sd.items() if v.dtype.kind == "f"}
     out: Dict[str, Array] = {}
@@ -498,10 +527,87 @@ def fold_state_dict(sd: Dict[str, Array], cfg: FEConfig) -> Dict[str, Array]:
     return out
 
 
+def _fold_state_dict_ln(sd: Dict[str, Array], cfg: FEConfig) -> Dict[str, Array]:
+    """ONNXModel.remove_weight_reparameterizations of the ln variant (models/fastenhancer/ln/model.py:524-533, 239-245, 116-135):
+    only the weight norms of the GRU / qkv matrices and the final conv's normalisation + scale go away; every norm layer stays.
+    Fused keys = the training keys, except the final conv: dec_post.3.{weight,scale,bias} -> dec_post.2.{weight,bias}."""
+    if "dec_post.2.weight" in sd:
+        return {k: v.astype(np.float32) for k, v in sd.items() if v.dtype.kind == "f"}
+    out: Dict[str, Array] = {}
+    for k, v in sd.items():
+        if v.dtype.kind != "f" or ".parametrizations." in k or k.startswith("dec_post.3."):
+            continue
+        out[k] = v.astype(np.float32)
+    for k in range(cfg.rf_blocks):
+        p = f"rf_block.{k}."
+        for mod, name in (("rnn", "weight_ih_l0"), ("rnn", "weight_hh_l0"), ("attn.qkv", "weight")):
+            key0 = p + f"{mod}.parametrizations.{name}.original0"
+            if key0 in sd:
+                out[p + f"{mod}.{name}"] = _weight_norm(sd[key0], sd[p + f"{mod}.parametrizations.{name}.original1"])
+    w = sd["dec_post.3.weight"].astype(np.float32)
+    scale = sd["dec_post.3.scale"].astype(np.float32) if "dec_post.3.scale" in sd else np.ones(1, np.float32)
+    if cfg.final_scale_exp:
+        scale = np.exp(scale)
+    if cfg.normalize_final_conv:
+        w = w / max(float(np.sqrt((w.astype(np.float32) ** 2).sum())), 1e-12)
+    out["dec_post.2.weight"] = (w * scale).astype(np.float32)
+    out["dec_post.2.bias"] = sd["dec_post.3.bias"].astype(np.float32)
+    return out
+
+
+def _training_state_dict_spec_ln(cfg: FEConfig) -> Dict[str, Tuple[int, ...]]:
+    C1, C2, F1, F2, S = cfg.channels, cfg.rf_channels, cfg.F1, cfg.rf_freq, cfg.stride
+    spec: Dict[str, Tuple[int, ...]] = {}
+
+    def wb(prefix, wshape, bias=True):
+        spec[prefix + ".weight"] = wshape
+        if bias:
+            spec[prefix + ".bias"] = (wshape[0],)
+
+    wb("enc_pre.0", (C1, 2 * S, cfg.kernel_size[0] // S)); wb("enc_pre.1", (C1,))
+    for i in range(cfg.n_layers):
+        wb(f"encoder.{i}.0", (C1, C1, cfg.kernel_size[i + 1])); wb(f"encoder.{i}.1", (C1,))
+    spec["rf_pre.0.weight"] = (F2, F1)
+    wb("rf_pre.1", (C2, C1, 1)); wb("rf_pre.2", (C2,))
+    for k in range(cfg.rf_blocks):
+        p = f"rf_block.{k}."
+        if k == 0 and cfg.positional_embedding is not None:
+            spec[p + "pe"] = (F2, C2)
+        spec[p + "rnn.bias_ih_l0"] = (3 * C2,)
+        spec[p + "rnn.bias_hh_l0"] = (3 * C2,)
+        for name in ("weight_ih_l0", "weight_hh_l0"):
+            if cfg.weight_norm:
+                spec[p + f"rnn.parametrizations.{name}.original0"] = (3 * C2, 1)
+                spec[p + f"rnn.parametrizations.{name}.original1"] = (3 * C2, C2)
+            else:
+                spec[p + "rnn." + name] = (3 * C2, C2)
+        spec[p + "rnn_fc.weight"] = (C2, C2)
+        wb(p + "rnn_post_norm", (C2,))
+        if cfg.weight_norm:
+            spec[p + "attn.qkv.parametrizations.weight.original0"] = (3 * C2, 1)
+            spec[p + "attn.qkv.parametrizations.weight.original1"] = (3 * C2, C2)
+        else:
+            spec[p + "attn.qkv.weight"] = (3 * C2, C2)
+        spec[p + "attn_fc.weight"] = (C2, C2)
+        wb(p + "attn_post_norm", (C2,))
+    spec["rf_post.0.weight"] = (F1, F2)
+    wb("rf_post.1", (C1, C2, 1)); wb("rf_post.2", (C1,))
+    for i in range(cfg.n_layers):
+        wb(f"decoder.{i}.0", (C1, 2 * C1, 1)); wb(f"decoder.{i}.1", (C1,))
+        wb(f"decoder.{i}.3", (C1, C1, cfg.kernel_size[cfg.n_layers - i]), bias=False); wb(f"decoder.{i}.4", (C1,))
+    wb("dec_post.0", (C1, 2 * C1, 1), bias=False); wb("dec_post.1", (C1,))
+    spec["dec_post.3.weight"] = (C1, 2, cfg.kernel_size[0])
+    spec["dec_post.3.bias"] = (2,)
+    spec["dec_post.3.scale"] = (1,)
+    return spec
+
+
 def training_state_dict_spec(cfg: FEConfig) -> Dict[str, Tuple[int, ...]]:
     """Key -> shape of the training-form checkpoint, in
     the reference's state_dict order.  Pinned against the imported reference by
     tools/gen_golden.py."""
+    if cfg.ln:
+        return _training_state_dict_spec_ln(cfg)
     C1, C2, F1, F2, S = cfg.channels, cfg.rf_channels, cfg.F1, cfg.rf_freq, cfg.stride
     spec: Dict[str, Tuple[int, ...]] = {}
 
@@ -639,8 +745,67 @@ class FEOracle:
         return x[:, :c.hop_size].copy(), x[:, c.hop_size:].copy()
 
     # ---- a5..a16: ONNXModel.model_forward (model.py:620-675)
+    def _model_forward_ln(self, spec: Array, h_list: Optional[List[Array]], taps: Optional[dict]) -> Tuple[Array, List[Array]]:
+        """ONNXModel.model_forward of the ln variant (models/fastenhancer/ln/model.py:546-602): conv + bias -> GroupNorm(1, C)
+        -> SiLU everywhere the default model has conv -> BatchNorm -> SiLU, LayerNorm over (F2, C2) after the blocks' fc layers."""
+        c, w = self.cfg, self.w
+        B, F0, T, _ = spec.shape
+        C2, F2 = c.rf_channels, c.rf_freq
+        tap = (lambda k, v: taps.__setitem__(k, v.copy())) if taps is not None else (lambda k, v: None)
+        gn = lambda x, key: group_norm1(x, w[key + ".weight"], w[key + ".bias"])
+        bias = lambda key: w[key + ".bias"] if (key + ".bias") in w else None
+        cv = lambda x, key: conv1d(x, w[key + ".weight"], bias(key), (w[key + ".weight"].shape[-1] - 1) // 2)
+        x = spec.transpose(0, 2, 3, 1).reshape(B * T, 2, F0)
+        pad0 = (c.kernel_size[0] - c.stride) // 2
+        x = silu(gn(strided_conv1d(x, w["enc_pre.0.weight"], w["enc_pre.0.bias"], c.stride, pad0), "enc_pre.1"))
+        enc_outs = [x]
+        tap("enc_pre", x)
+        for i in range(c.n_layers):
+            x = silu(gn(cv(x, f"encoder.{i}.0"), f"encoder.{i}.1"))
+            enc_outs.append(x)
+            tap(f"encoder.{i}", x)
+        x = x @ w["rf_pre.0.weight"].T
+        x = gn(cv(x, "rf_pre.1"), "rf_pre.2")
+        x = np.ascontiguousarray(x.reshape(B, T, C2, F2).transpose(1, 0, 3, 2))          # [T,B,F2,C2]
+        tap("rf_pre", x)
+        h_out = []
+        for k in range(c.rf_blocks):
+            p = f"rf_block.{k}."
+            h = np.zeros((B * F2, C2), self.dtype) if h_list is None else h_list[k][0].astype(self.dtype).copy()
+            xs = x.reshape(T, B * F2, C2)
+            ys = np.empty_like(xs)
+            for t in range(T):
+                h = gru_step(xs[t], h, w[p + "rnn.weight_ih_l0"], w[p + "rnn.weight_hh_l0"], w[p + "rnn.bias_ih_l0"], w[p + "rnn.bias_hh_l0"])
+                ys[t] = h
+            h_out.append(h[None].copy())
+            y = (ys @ w[p + "rnn_fc.weight"].T).reshape(T, B, F2, C2)
+            x = layer_norm_fc(y, w[p + "rnn_post_norm.weight"], w[p + "rnn_post_norm.bias"], c.rf_eps) + x
+            if (p + "pe") in w:
+                x = x + w[p + "pe"]
+            tap(f"rf_block.{k}.rnn", x)
+            a = mhsa(x.reshape(T * B, F2, C2), w[p + "attn.qkv.weight"], c.rf_heads) @ w[p + "attn_fc.weight"].T
+            x = layer_norm_fc(a.reshape(T, B, F2, C2), w[p + "attn_post_norm.weight"], w[p + "attn_post_norm.bias"], c.rf_eps) + x
+            tap(f"rf_block.{k}", x)
+        x = x.transpose(1, 0, 3, 2).reshape(B * T, C2, F2)
+        x = x @ w["rf_post.0.weight"].T
+        x = gn(cv(x, "rf_post.1"), "rf_post.2")
+        tap("rf_post", x)
+        for i in range(c.n_layers):
+            x = np.concatenate([x, enc_outs.pop(-1)], axis=1)
+            x = silu(gn(cv(x, f"decoder.{i}.0"), f"decoder.{i}.1"))
+            x = silu(gn(cv(x, f"decoder.{i}.3"), f"decoder.{i}.4"))
+            tap(f"decoder.{i}", x)
+        x = np.concatenate([x, enc_outs.pop(-1)], axis=1)
+        x = silu(gn(cv(x, "dec_post.0"), "dec_post.1"))
+        x = conv_transpose1d(x, w["dec_post.2.weight"], w["dec_post.2.bias"], c.stride, pad0)
+        mask = np.ascontiguousarray(x.reshape(B, T, 2, F0).transpose(0, 3, 1, 2))
+        tap("mask", mask)
+        return mask, h_out
+
     def model_forward(self, spec: Array, h_list: Optional[List[Array]], taps: Optional[dict] = None
                       ) -> Tuple[Array, List[Array]]:
+        if self.cfg.ln:
+            return self._model_forward_ln(spec, h_list, taps)
         c, w = self.cfg, self.w
         B, F0, T, _ = spec.shape
         tk = c.time_kernel

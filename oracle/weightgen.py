@@ -26,7 +26,7 @@ def make_training_state_dict(cfg: FEConfig, seed: int) -> Dict[str, np.ndarray]:
     """Training-form state_dict with seeded values."""
     rng = np.random.Generator(np.random.PCG64(seed))
     spec = training_state_dict_spec(cfg)
-    pre, post = (linear_filterbank_tk if cfg.time_kernel or cfg.dprnn or cfg.dpt else linear_filterbank)(cfg.F1, cfg.rf_freq)
+    pre, post = (linear_filterbank_tk if cfg.time_kernel or cfg.dprnn or cfg.dpt or cfg.ln else linear_filterbank)(cfg.F1, cfg.rf_freq)
     pe = positional_embedding(cfg.rf_channels, cfg.rf_freq)
     sd: Dict[str, np.ndarray] = {}
     for key, shape in spec.items():
@@ -50,6 +50,8 @@ def make_training_state_dict(cfg: FEConfig, seed: int) -> Dict[str, np.ndarray]:
             v = rng.uniform(0.6, 1.1, shape)
         elif leaf == "scale":
             v = np.full(shape, 2.0 * (cfg.channels / 24.0) ** 0.6)  # keeps the enhanced RMS ~ the input RMS
+            if cfg.ln:                                              # (normalised activations; the output goes with mask^(1/0.3))
+                v = v / 2.7
         elif "bias" in leaf:                            # BN beta, GRU biases, final conv bias
             v = 0.1 * rng.standard_normal(shape)
         elif len(shape) == 1:                           # BN gamma

@@ -70,6 +70,8 @@ MODEL_KWARGS = {
     "fe_dprnn_s": (_kw_dprnn(64, (8, 3, 3, 3), 48, 24, 36, 3, 512, 256), 16000, 133),
     "fe_dprnn_m": (_kw_dprnn(96, (8, 3, 3, 3), 72, 36, 48, 4, 512, 160), 16000, 134),
     "fe_dprnn_l": (_kw_dprnn(128, (8, 3, 3, 3, 3), 96, 48, 64, 5, 512, 100), 16000, 132),
+    # configs/ablation/ln_b.yaml (model: fastenhancer.ln - the default model's kwargs + final_scale / final_scale_init)
+    "fe_ln_b": ({**{k: v for k, v in _kw(48, (8, 3, 3), 36, 24, 3, 512, 256, "linear_fixed").items()}, "final_scale": True, "final_scale_init": "one"}, 16000, 150),
     # configs/ablation/dpt_{t,b,s,m}.yaml
     "fe_dpt_t": (_kw_dpt(24, (8, 3, 3), 20, 16, 2, 512, 256), 16000, 140),
     "fe_dpt_b": (_kw_dpt(48, (8, 3, 3), 36, 24, 3, 512, 256), 16000, 141),
@@ -77,7 +79,8 @@ MODEL_KWARGS = {
     "fe_dpt_m": (_kw_dpt(96, (8, 3, 3, 3), 72, 48, 4, 512, 160), 16000, 142),
 }
 # which module of the reference a name belongs to (the yaml's `model:` key)
-MODEL_MODULE = {name: ("fastenhancer.dprnn" if "dprnn" in name else "fastenhancer.dptransformer" if "dpt" in name else "fastenhancer.default")
+MODEL_MODULE = {name: ("fastenhancer.dprnn" if "dprnn" in name else "fastenhancer.dptransformer" if "dpt" in name else
+                       "fastenhancer.ln" if name == "fe_ln_b" else "fastenhancer.default")
                 for name in MODEL_KWARGS}
 MODEL_MODULE["fe_tk_b"] = "fastenhancer.time_kernel"
 
@@ -88,7 +91,7 @@ def load_golden(name):
 
 def build_oracle(name, dtype=np.float32):
     kw, sr, seed = MODEL_KWARGS[name]
-    cfg = FEConfig.from_model_kwargs(kw)
+    cfg = FEConfig.from_model_kwargs(kw, variant=MODEL_MODULE[name].split(".")[-1])
     sd = make_training_state_dict(cfg, seed)
     fused = fold_state_dict(sd, cfg)
     return cfg, sd, fused, FEOracle(cfg, fused, dtype)

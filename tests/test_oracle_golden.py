@@ -7,7 +7,7 @@ from common import MODEL_KWARGS, build_oracle, load_golden, rms
 from oracle.weightgen import make_input
 
 GOLDENS = ["fe_t", "fe_b", "fe_m", "fe_l", "fe48_b", "fe48_l", "fe48_b_h480"]
-ORACLE_GOLDENS = GOLDENS + ["fe_tk_b", "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_l", "fe_dpt_t", "fe_dpt_b", "fe_dpt_m"]           # (the C oracle restates the default model only)
+ORACLE_GOLDENS = GOLDENS + ["fe_tk_b", "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_l", "fe_dpt_t", "fe_dpt_b", "fe_dpt_m", "fe_ln_b"]           # (the C oracle restates the default model only)
 # fp32-vs-fp32 different summation orders: the reference's own fp32 noise floor is ~5e-7
 # relative; allow 20x that.
 REL = 1e-5
@@ -72,7 +72,7 @@ def test_offline_matches_reference(name):
     _close(spec, g["offline_spec"], what="offline spec")
 
 
-@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_tk_b", "fe_dprnn_b", "fe_dpt_b"])
+@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_tk_b", "fe_dprnn_b", "fe_dpt_b", "fe_ln_b"])
 def test_driver_loop_matches_reference(name):
     g = load_golden(name)
     cfg, sd, fused, orc = build_oracle(name)

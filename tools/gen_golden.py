@@ -88,6 +88,8 @@ CONFIGS = {
     "fe_dpt_t": ("configs/ablation/dpt_t.yaml", 140, 2, 40, 0),
     "fe_dpt_b": ("configs/ablation/dpt_b.yaml", 141, 2, 40, 120),
     "fe_dpt_m": ("configs/ablation/dpt_m.yaml", 142, 1, 36, 0),
+    # the ln ablation (models/fastenhancer/ln): GroupNorm / LayerNorm instead of the (folded) BatchNorms
+    "fe_ln_b": ("configs/ablation/ln_b.yaml", 150, 2, 10, 120),
 }
 
 
@@ -102,7 +104,7 @@ def gen_fastenhancer(ref: str, name: str, out_dir: str):
     if len(CONFIGS[name]) > 5:
         kw.update(CONFIGS[name][5])
     sr = hps["data"]["sampling_rate"]
-    cfg = FEConfig.from_model_kwargs(kw)
+    cfg = FEConfig.from_model_kwargs(kw, variant=hps["model"].split(".")[-1])
     tk = hps["model"] == "fastenhancer.time_kernel"
     assert tk == cfg.time_kernel
     mod = import_reference_model(ref, f"models/{hps['model'].replace('.', '/')}/model.py", "ref_fe_model_" + hps["model"].split(".")[-1])
@@ -129,6 +131,8 @@ def gen_fastenhancer(ref: str, name: str, out_dir: str):
     # ---- fold check (a20): my restatement vs the reference's fused state_dict
     fused_mine = fold_state_dict(sd, cfg)
     fused_ref.pop("dec_post.2.scale", None)      # (the time_kernel variant keeps the - then unused - scale parameter in its state_dict)
+    if cfg.ln:                                   # (no module is replaced there: the final conv keeps its index 3 and its folded-in scale)
+        fused_ref = {k.replace("dec_post.3.", "dec_post.2."): v for k, v in fused_ref.items() if k != "dec_post.3.scale"}
     assert set(fused_mine) == set(fused_ref), (set(fused_mine) ^ set(fused_ref))
     worst = 0.0
     for k in fused_ref:
@@ -143,7 +147,7 @@ def gen_fastenhancer(ref: str, name: str, out_dir: str):
     # fixed filterbank formula
     if kw.get("pre_post_init", None) == "linear_fixed":
         fresh = mod.ONNXModel(**kw)
-        pre, post = (linear_filterbank_tk if tk or cfg.dprnn or cfg.dpt else linear_filterbank)(cfg.F1, cfg.rf_freq)
+        pre, post = (linear_filterbank_tk if tk or cfg.dprnn or cfg.dpt or cfg.ln else linear_filterbank)(cfg.F1, cfg.rf_freq)
         fpre, fpost = (fresh.dprnn_pre, fresh.dprnn_post) if cfg.dprnn else ((fresh.dpt_pre, fresh.dpt_post) if cfg.dpt else (fresh.rf_pre, fresh.rf_post))
         assert np.abs(pre - fpre[0].weight.numpy()).max() < 1e-5
         assert np.abs(post - fpost[0].weight.numpy()).max() < 1e-5
