@@ -22,7 +22,7 @@ class fe_config(ctypes.Structure):
         ("arch", c_int), ("n_fft", c_int), ("hop_size", c_int), ("win_size", c_int),
         ("channels", c_int), ("n_kernels", c_int), ("kernel_size", c_int * FE_MAX_KERNELS),
         ("stride", c_int), ("rf_channels", c_int), ("rf_freq", c_int), ("rf_blocks", c_int),
-        ("rf_heads", c_int), ("input_compression", c_float), ("kernel_size_time", c_int), ("channels_frnn", c_int), ("lookbehind", c_int),
+        ("rf_heads", c_int), ("input_compression", c_float), ("kernel_size_time", c_int), ("channels_frnn", c_int), ("lookbehind", c_int), ("ln", c_int), ("rf_eps", c_float),
     ]
 
 

@@ -62,7 +62,7 @@ def add_shape(spec: str) -> str:
     kernel_size_time) -> a line in the local shape list.  The kernel template's constraints are checked here with a
     readable message (hipcc would report them as failed static_asserts): stride 4 and kernel_size [8, 3, ...] are fixed."""
     v = [int(x) for x in spec.replace(" ", "").split(",")]
-    if len(v) not in (7, 8, 10, 11):
+    if len(v) not in (7, 8, 10, 11, 12):
         raise SystemExit("--add-shape wants C1,NL,C2,F2,KB,NFFT,HOP[,KT[,0,FR[,TA]]]  (FR = 1: the dprnn variant, TA = 31: the dptransformer variant)")
     C1, NL, C2, F2, KB, NFFT, HOP = v[:7]
     KT = v[7] if len(v) >= 8 else 1

@@ -46,6 +46,10 @@ class FEConfig:
     def dpt(self) -> bool:
         return self.lookbehind > 0
 
+    # `model: fastenhancer.ln` (models/fastenhancer/ln/model.py): GroupNorm(1, C) after every conv and the reference's LayerNorm
+    # after the blocks' fc layers instead of BatchNorms; nothing folds into the convs
+    ln: bool = False
+
     @property
     def time_kernel(self) -> bool:
         return self.kernel_size_time > 1
@@ -174,6 +178,16 @@ def dprnn_config(channels: int = 64, kernel_size: Sequence[int] = (8, 3, 3), str
                                       normalize_final_conv=normalize_final_conv, pre_post_init=pre_post_init, resnet=False)
     import dataclasses
     return dataclasses.replace(base, channels_frnn=H, positional_embedding=None, final_scale_exp=(final_scale == "exp"))
+
+
+def ln_config(final_scale: Any = "exp", final_scale_init: str = "1/sqrt(fan_in)", **model_kwargs) -> FEConfig:
+    """yaml model_kwargs of `model: fastenhancer.ln` (configs/ablation/ln_b.yaml:2-31: the default model's keys + final_scale,
+    final_scale_init) -> FEConfig with ln set."""
+    if final_scale not in (True, False, "exp"):
+        raise AssertionError(f"final_scale={final_scale}")
+    base = FEConfig.from_model_kwargs(**model_kwargs)
+    import dataclasses
+    return dataclasses.replace(base, ln=True, final_scale_exp=(final_scale == "exp"))
 
 
 def dpt_config(channels: int = 64, kernel_size: Sequence[int] = (8, 3, 3), stride: int = 4, dpt_kwargs: Optional[Dict[str, Any]] = None,

@@ -50,6 +50,7 @@ struct Dims {
     int ks[FE_MAX_KERNELS];
     int KT = 1;                // kernel_size_time (time_kernel variant)
     int FR = 0;                // 1: dprnn variant (sub-band GRU of C2 / 2 hidden units per direction instead of the attention)
+    int LN = 0;                // 1: ln variant (GroupNorm after every conv, the reference's LayerNorm after the blocks' fc layers)
     int TA = 0;                // > 0: dptransformer variant (causal attention over the last TA frames instead of the time GRU)
     // model-state floats per stream: KB GRU states [F2][C2], or (dptransformer) 2 KB caches [F2][NH][TA][HD] + the ring head
     size_t hstate() const { return (size_t)KB * F2 * C2 * (TA ? 2 * TA : 1) + (TA ? 1 : 0); }
@@ -125,8 +126,51 @@ void add_section(fe_handle* h, const std::string& name, std::vector<int> shape) 
     h->blob_floats = off + n;
 }
 
+// the ln variant's fused state_dict (models/fastenhancer/ln/model.py:416-518 after remove_weight_reparameterizations; the final
+// conv as dec_post.2 with its scale folded in, like the default model's): convs with their own biases, every norm layer kept
+void build_sections_ln(fe_handle* h) {
+    const Dims& d = h->d;
+    char nm[128];
+    auto wb = [&](const std::string& p, std::vector<int> wshape, bool bias = true) {
+        add_section(h, p + ".weight", wshape);
+        if (bias) add_section(h, p + ".bias", {wshape[0]});
+    };
+    wb("enc_pre.0", {d.C1, 8, 2}); wb("enc_pre.1", {d.C1});
+    for (int i = 0; i < d.NL; ++i) {
+        snprintf(nm, sizeof nm, "encoder.%d.0", i); wb(nm, {d.C1, d.C1, 3});
+        snprintf(nm, sizeof nm, "encoder.%d.1", i); wb(nm, {d.C1});
+    }
+    add_section(h, "rf_pre.0.weight", {d.F2, d.F1});
+    wb("rf_pre.1", {d.C2, d.C1, 1}); wb("rf_pre.2", {d.C2});
+    for (int k = 0; k < d.KB; ++k) {
+        auto key = [&](const char* s) { snprintf(nm, sizeof nm, "rf_block.%d.%s", k, s); return std::string(nm); };
+        if (k == 0) add_section(h, key("pe"), {d.F2, d.C2});
+        add_section(h, key("rnn.weight_ih_l0"), {3 * d.C2, d.C2});
+        add_section(h, key("rnn.weight_hh_l0"), {3 * d.C2, d.C2});
+        add_section(h, key("rnn.bias_ih_l0"), {3 * d.C2});
+        add_section(h, key("rnn.bias_hh_l0"), {3 * d.C2});
+        add_section(h, key("rnn_fc.weight"), {d.C2, d.C2});
+        wb(key("rnn_post_norm"), {d.C2});
+        add_section(h, key("attn.qkv.weight"), {3 * d.C2, d.C2});
+        add_section(h, key("attn_fc.weight"), {d.C2, d.C2});
+        wb(key("attn_post_norm"), {d.C2});
+    }
+    add_section(h, "rf_post.0.weight", {d.F1, d.F2});
+    wb("rf_post.1", {d.C1, d.C2, 1}); wb("rf_post.2", {d.C1});
+    for (int i = 0; i < d.NL; ++i) {
+        snprintf(nm, sizeof nm, "decoder.%d.0", i); wb(nm, {d.C1, 2 * d.C1, 1});
+        snprintf(nm, sizeof nm, "decoder.%d.1", i); wb(nm, {d.C1});
+        snprintf(nm, sizeof nm, "decoder.%d.3", i); wb(nm, {d.C1, d.C1, 3}, false);
+        snprintf(nm, sizeof nm, "decoder.%d.4", i); wb(nm, {d.C1});
+    }
+    wb("dec_post.0", {d.C1, 2 * d.C1, 1}, false); wb("dec_post.1", {d.C1});
+    add_section(h, "dec_post.2.weight", {d.C1, 2, 8});
+    add_section(h, "dec_post.2.bias", {2});
+}
+
 void build_sections(fe_handle* h) {
     const Dims& d = h->d;
+    if (d.LN) { build_sections_ln(h); return; }
     char nm[128];
     add_section(h, "enc_pre.0.weight", {d.C1, 8, 2});
     add_section(h, "enc_pre.0.bias", {d.C1});
@@ -310,7 +354,7 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
             }
         }
         pack_1x1(o.blk_fc1_w[k], S(key("rnn_fc.weight")), C2, C2);
-        p.raw(o.blk_fc1_b[k], C2, S(key("rnn_fc.bias")));
+        if (!d.LN) p.raw(o.blk_fc1_b[k], C2, S(key("rnn_fc.bias")));      // (ln variant: the fc layers have no bias, their LayerNorm's is in the ln tables)
         if (d.FR) {
             // sub-band GRU: the input weights of both directions as one (3 C2)-column matrix [direction][r|z|n][unit] in the qkv
             // slot, its bias = b_ih + (r, z only) b_hh; hidden weights [direction][j][gate][unit]; b_hn.  (The block has no
@@ -340,16 +384,21 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
         if (k == 0) p.raw(o.blk_pe, (size_t)F2 * C2, S(key("pe")));
         pack_1x1(o.blk_qkv[k], S(key("attn.qkv.weight")), C2, 3 * C2);
         pack_1x1(o.blk_fc2_w[k], S(key("attn_fc.weight")), C2, C2);
-        p.raw(o.blk_fc2_b[k], C2, S(key("attn_fc.bias")));
+        if (!d.LN) p.raw(o.blk_fc2_b[k], C2, S(key("attn_fc.bias")));
     }
     {
         const float* w = S("rf_post.0.weight");   // (F1, F2)
         p.pack_a(o.rfpost_lin, F1, F2, [&](int m, int k) { return w[m * F2 + k]; });
         p.raw(o.rfpost_w, (size_t)C1 * C2, S("rf_post.1.weight"));      // plain copies: the debug dump of the rf_post stage
         p.raw(o.rfpost_b, C1, S("rf_post.1.bias"));
+        if (d.LN) {     // its own staged unit: a GroupNorm sits between it and decoder layer 0
+            pack_1x1(o.rfpost1_w, S("rf_post.1.weight"), C2, C1);
+            p.rep4(o.rfpost1_b, C1, S("rf_post.1.bias"));
+        }
     }
+    const std::vector<float> zeros_c1((size_t)C1, 0.0f);
     for (int i = 0; i < d.NL; ++i) {
-        if (i == 0) {
+        if (i == 0 && !d.LN) {
             // rf_post's 1x1 conv (C2 -> C1, affine, no activation) feeds only this layer's x half: folded in.
             //   v = Wd_x (Wrp y + brp) + Wd_s skip + bd  =  (Wd_x Wrp) y + Wd_s skip + (bd + Wd_x brp)
             // K = C2 (filterbank output, true scale: weights carry kSiluScale) + C1 (skip, already scaled)
@@ -374,18 +423,44 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
         snprintf(nm, sizeof nm, "decoder.%d.0.weight", i); pack_1x1(o.dec1_w[i], S(nm), 2 * C1, C1);
         snprintf(nm, sizeof nm, "decoder.%d.0.bias", i); p.rep4(o.dec1_b[i], C1, S(nm));
         }
+        if (d.LN) {     // (the k = 3 conv is module 3 there and has no bias)
+            snprintf(nm, sizeof nm, "decoder.%d.3.weight", i); pack_k3(&o.dec3_w[i * KT], S(nm));
+            p.rep4(o.dec3_b[i], C1, zeros_c1.data());
+            continue;
+        }
         snprintf(nm, sizeof nm, "decoder.%d.2.weight", i); pack_k3(&o.dec3_w[i * KT], S(nm));
         snprintf(nm, sizeof nm, "decoder.%d.2.bias", i); p.rep4(o.dec3_b[i], C1, S(nm));
     }
     pack_1x1(o.post1_w, S("dec_post.0.weight"), 2 * C1, C1);
-    p.rep4(o.post1_b, C1, S("dec_post.0.bias"));
+    p.rep4(o.post1_b, C1, d.LN ? zeros_c1.data() : S("dec_post.0.bias"));
+    if (d.LN) {     // gain / bias of the norm sites, Shape::LN_SITES order
+        int q = 0;
+        auto site = [&](const std::string& prefix, int C) {
+            p.raw(o.ln_g[q], C, S(prefix + ".weight"));
+            p.raw(o.ln_b[q], C, S(prefix + ".bias"));
+            ++q;
+        };
+        site("enc_pre.1", C1);
+        for (int i = 0; i < d.NL; ++i) { snprintf(nm, sizeof nm, "encoder.%d.1", i); site(nm, C1); }
+        site("rf_pre.2", C2);
+        for (int k = 0; k < d.KB; ++k) {
+            snprintf(nm, sizeof nm, "rf_block.%d.rnn_post_norm", k); site(nm, C2);
+            snprintf(nm, sizeof nm, "rf_block.%d.attn_post_norm", k); site(nm, C2);
+        }
+        site("rf_post.2", C1);
+        for (int i = 0; i < d.NL; ++i) {
+            snprintf(nm, sizeof nm, "decoder.%d.1", i); site(nm, C1);
+            snprintf(nm, sizeof nm, "decoder.%d.4", i); site(nm, C1);
+        }
+        site("dec_post.1", C1);
+    }
     {   // transposed conv weight (C1, 2, 8): B[k = ci][n = co*8 + j]
         const float* w = S("dec_post.2.weight");
         p.pack_b(o.post_t_w, C1, 16, [&](int k, int n) { return w[k * 16 + n]; });
         p.raw(o.post_t_b, 2, S("dec_post.2.bias"));
     }
     {   // scaled conv trunk (fe_kernels.hip.h, kSiluScale): biases of the SiLU layers, entry weights, exit weights
-        const float c = fe::kSiluScale;
+        const float c = d.LN ? 1.0f : fe::kSiluScale;      // (ln variant: no scaling - a norm layer follows every conv)
         auto szB = [](int K, int N) { return (size_t)fe::ceil_div(N, 16) * (K / 4) * 64; };
         auto scale = [&](int off, size_t n, float f) { for (size_t i = 0; i < n; ++i) p.buf[(size_t)off + i] *= f; };
         scale(o.enc_pre_w, szB(16, C1), c); scale(o.enc_pre_b, 4 * C1, c);       // (biases: 4x replicated tables)
@@ -1126,6 +1201,7 @@ fe::FrameArgs base_args(fe_handle* h, int B, int T) {
     a.B = B;
     a.T = T;
     a.compression = h->cfg.input_compression;
+    a.rf_eps = h->cfg.rf_eps > 0.0f ? h->cfg.rf_eps : 1.0e-5f;
     a.skip = h->skip_dev;
     return a;
 }
@@ -1164,24 +1240,26 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
     if (fr && 2 * cfg->channels_frnn != cfg->rf_channels)
         return fail(FE_ERR_UNSUPPORTED_CONFIG, "channels_frnn=%d with channels=%d (the dprnn kernels are built for channels_frnn = channels / 2, every shipped yaml)",
                     cfg->channels_frnn, cfg->rf_channels);
+    const int ln = cfg->ln ? 1 : 0;
+    if (ln && (fr || cfg->lookbehind > 0 || kt > 1)) return fail(FE_ERR_INVALID_ARG, "ln excludes channels_frnn / lookbehind / kernel_size_time");
     const int ta = cfg->lookbehind > 0 ? cfg->lookbehind : 0;
     if (ta && ta != 31) return fail(FE_ERR_UNSUPPORTED_CONFIG, "lookbehind=%d (the dptransformer kernels are built for 31, every shipped yaml)", ta);
     if (ta && fr) return fail(FE_ERR_INVALID_ARG, "channels_frnn and lookbehind are exclusive");
     for (const fe::Impl* im : impls())
         if (im->C1 == cfg->channels && im->NL == cfg->n_kernels - 1 && im->C2 == cfg->rf_channels && im->F2 == cfg->rf_freq &&
-            im->KB == cfg->rf_blocks && im->NFFT == cfg->n_fft && im->HOP == cfg->hop_size && im->KT == kt && im->LOW == 0 && im->FR == fr && im->TA == ta)
+            im->KB == cfg->rf_blocks && im->NFFT == cfg->n_fft && im->HOP == cfg->hop_size && im->KT == kt && im->LOW == 0 && im->FR == fr && im->TA == ta && im->LN == ln)
             impl = im;
     const fe::Impl* impl_many = nullptr;
     for (const fe::Impl* im : impls())
         if (impl && im->LOW >= 1 && im->occ >= 2 && im->C1 == impl->C1 && im->NL == impl->NL && im->C2 == impl->C2 && im->F2 == impl->F2 &&
-            im->KB == impl->KB && im->NFFT == impl->NFFT && im->HOP == impl->HOP && im->KT == impl->KT && im->FR == impl->FR && im->TA == impl->TA)
+            im->KB == impl->KB && im->NFFT == impl->NFFT && im->HOP == impl->HOP && im->KT == impl->KT && im->FR == impl->FR && im->TA == impl->TA && im->LN == impl->LN)
             impl_many = im;
     if (!impl)
         return fail(FE_ERR_UNSUPPORTED_CONFIG,
                     "no kernel compiled for channels=%d layers=%d rf_channels=%d rf_freq=%d rf_blocks=%d n_fft=%d hop=%d kernel_size_time=%d%s "
                     "(build it: python -m fastenhancer_amd.build --add-shape %d,%d,%d,%d,%d,%d,%d,%d%s)",
-                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, kt, fr ? " dprnn" : (ta ? " dptransformer" : ""),
-                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, kt, fr ? ",0,1" : (ta ? ",0,0,31" : ""));
+                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, kt, fr ? " dprnn" : (ta ? " dptransformer" : (ln ? " ln" : "")),
+                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, kt, fr ? ",0,1" : (ta ? ",0,0,31" : (ln ? ",0,0,0,1" : "")));
     if (impl->lds_bytes > 160 * 1024)
         return fail(FE_ERR_UNSUPPORTED_CONFIG, "shape needs %zu bytes of LDS (> 160 KiB per CU)", impl->lds_bytes);
     fe_handle* h = new fe_handle();
@@ -1192,6 +1270,7 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
     h->d.KT = impl->KT;
     h->d.FR = impl->FR;
     h->d.TA = impl->TA;
+    h->d.LN = impl->LN;
     for (int i = 0; i < cfg->n_kernels; ++i) h->d.ks[i] = cfg->kernel_size[i];
     if (hipGetDevice(&h->device) != hipSuccess) h->device = -1;   // no GPU: sections/tables still usable
     else {
@@ -1355,6 +1434,7 @@ static int pipe_width(const fe_handle* h, int B, int T) {
     if (!h->impl || h->pipe_frames == 0 || h->pipe_frames == 1 || T < 4 || 2 * B > h->max_wgs) return 0;
     if (h->d.KT > 1) return 0;     // (the time_kernel convs carry whole input frames from frame to frame: one workgroup walks them)
     if (h->d.TA) return 0;         // (so do the dptransformer variant's K / V caches)
+    if (h->d.LN) return 0;         // (ln variant: no time-pipelined instantiation)
     // automatic width: a hand-off (counter round trip + state fetch + the h half of the GRU + gates + publish) takes
     // ~2.6 us whatever the model; a frame takes ~4 us per MFLOP/frame at the measured kernel efficiency: that many frames
     // are worth having in flight (measured optimum: T 8-12, B 16, 48 kHz B 24, L > 24), more only adds pollers

@@ -12,7 +12,7 @@ namespace fe {
 constexpr int kMaxDevices = 64;
 
 struct Impl {
-    int C1, NL, C2, F2, KB, NFFT, HOP, KT, LOW, FR, TA;
+    int C1, NL, C2, F2, KB, NFFT, HOP, KT, LOW, FR, TA, LN;
     size_t lds_bytes;
     int occ;              // resident workgroups per CU
     bool many_persist;    // companion: also used beyond occ x #CUs streams (persistent workgroups)
@@ -67,7 +67,7 @@ void launch_impl(const FrameArgs& a, int max_wgs, hipStream_t st, hipError_t* er
 // that the runtime guarantees (or refuses) their co-residency instead of a spin-wait deadlock.
 template <class S>
 void launch_pipe_impl(const FrameArgs& a, hipStream_t st, hipError_t* err) {
-    if constexpr (S::TATT) { *err = hipErrorNotSupported; return; } else {     // (the K / V caches are handed from frame to frame: one workgroup walks them)
+    if constexpr (S::TATT || S::LN) { *err = hipErrorNotSupported; return; } else {     // (the K / V caches are handed from frame to frame: one workgroup walks them)
     auto* fn = &fe_frame_kernel<S, false, -1, false, true, true>;
     static std::atomic<bool> attr_set[kMaxDevices];
     int dev = 0;
@@ -92,7 +92,7 @@ void dbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
 
 template <class S>
 Impl make_impl() {
-    return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, S::KT, S::LOW, S::FRNN ? 1 : 0, S::LB, Lds<S>::BYTES, Lds<S>::OCC, Lds<S>::MANY_PERSIST, S::NU, Pack<S>::umax(), Lds<S>::STAGED,
+    return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, S::KT, S::LOW, S::FRNN ? 1 : 0, S::LB, S::LN ? 1 : 0, Lds<S>::BYTES, Lds<S>::OCC, Lds<S>::MANY_PERSIST, S::NU, Pack<S>::umax(), Lds<S>::STAGED,
                 Lds<S>::SKIPS_LDS ? (size_t)0 : (size_t)(S::NL + 1) * S::F1 * S::C1,
                 DebugLayout<S>::total(), DebugLayout<S>::n_stages, &Pack<S>::v, &launch_impl<S>, &launch_pipe_impl<S>, &dbg_stage_impl<S>};
 }

@@ -54,8 +54,12 @@ __host__ __device__ constexpr int round_up(int a, int b) { return ceil_div(a, b)
 // TA = L > 0: the `fastenhancer.dptransformer` variant (models/fastenhancer/dptransformer/model.py:175-236): the block's time GRU is
 // a causal attention over the last L frames (K / V caches [F2][NH][L][HD] per block and stream in the state) with a learned
 // positional bias [NH][L + 1].
-template <int C1_, int NL_, int C2_, int F2_, int KB_, int NFFT_, int HOP_, int KT_ = 1, int LOW_ = 0, int FR_ = 0, int TA_ = 0>
+// LN = 1: the `fastenhancer.ln` variant (models/fastenhancer/ln/model.py): GroupNorm(1, C) after every conv (statistics over the
+// channels and sub-bands of the frame), the reference's LayerNorm over (F2, C2) after the blocks' fc layers; nothing folds.
+template <int C1_, int NL_, int C2_, int F2_, int KB_, int NFFT_, int HOP_, int KT_ = 1, int LOW_ = 0, int FR_ = 0, int TA_ = 0, int LN_ = 0>
 struct Shape {
+    static constexpr bool LN = LN_ != 0;
+    static constexpr int LN_SITES = 4 + 3 * NL_ + 2 * KB_;      // enc_pre, encoder.i, rf_pre, (rnn, attn) per block, rf_post, (1x1, k3) per decoder layer, dec_post
     static constexpr int C1 = C1_, NL = NL_, C2 = C2_, F2 = F2_, KB = KB_, NFFT = NFFT_, HOP = HOP_, KT = KT_, LOW = LOW_;
     static constexpr bool FRNN = FR_ != 0;
     static constexpr bool TATT = TA_ != 0;
@@ -88,13 +92,13 @@ struct Shape {
     // packed-weight sizes (floats)
     static constexpr int KS_C = C1 / 4;           // k-steps over C1
     static constexpr int KS_2 = C2 / 4;           // k-steps over C2
-    static constexpr int NU = 6 + NL * (2 * KT + 1);   // LDS-staged weight units (Pack<S>): a k = 3 conv is one unit per time tap
+    static constexpr int NU = 6 + NL * (2 * KT + 1) + (LN ? 1 : 0);   // LDS-staged weight units (Pack<S>): a k = 3 conv is one unit per time tap; ln: + rf_post's 1x1
     // unit indices in consumption order
     static constexpr int U_ENC = 1;                                  // + l * KT + tap
     static constexpr int U_RFPRE = 1 + NL * KT;                      // filterbank, then the 1x1
     static constexpr int U_RFPOST = 3 + NL * KT;
-    static constexpr int U_DEC = 4 + NL * KT;                        // + l * (KT + 1): the 1x1, then + 1 + tap: the k = 3 conv
-    static constexpr int U_POST = 4 + NL * (2 * KT + 1);             // dec_post 1x1, then the transposed conv
+    static constexpr int U_DEC = 4 + NL * KT + (LN ? 1 : 0);         // + l * (KT + 1): the 1x1, then + 1 + tap: the k = 3 conv  (ln: rf_post's 1x1 is unit U_RFPOST + 1)
+    static constexpr int U_POST = 4 + NL * (2 * KT + 1) + (LN ? 1 : 0);   // dec_post 1x1, then the transposed conv
     static constexpr int TKQ = (KT - 1) * (F0 / 4) * C1;             // floats of one conv's frame cache per stream: [KT-1][F1][C1]
     // RNNFormer-block weight fragments held in registers per wave (this wave's column tiles)
     static constexpr int NTPW2 = ceil_div(NT2, kWaves), NTPW3 = ceil_div(NT3, kWaves);
@@ -126,6 +130,8 @@ struct PackedOffsets {
     int blk_qkv_b[8], blk_fhh[8], blk_fbhn[8];
     // dptransformer variant: the time attention's qkv weights per block, the model's positional bias [NH][32] (slot L = current frame)
     int blk_tqkv[8], tpe;
+    // ln variant: rf_post's 1x1 conv as a staged unit (B fragments + bias), gain / bias of every norm site ([channel])
+    int rfpost1_w, rfpost1_b, ln_g[48], ln_b[48];
     int rfpost_lin, rfpost_w, rfpost_b;
     int dec1_w[8], dec1_b[8], dec3_w[16], dec3_b[8];
     int post1_w, post1_b, post_t_w, post_t_b;
@@ -163,6 +169,7 @@ struct Pack {
         ubegin(); o.rfpre_lin = alloc(szA(F2, F1)); uend();
         ubegin(); o.rfpre_w = alloc(szB(C1, C2)); o.rfpre_b = alloc(4 * szBias(C2)); uend();
         ubegin(); o.rfpost_lin = alloc(szA(F1, F2)); uend();
+        if (S::LN) { ubegin(); o.rfpost1_w = alloc(szB(C2, C1)); o.rfpost1_b = alloc(4 * szBias(C1)); uend(); }
         // (rf_post's 1x1 conv has no unit: the host folds it into decoder layer 0's 1x1, whose first K-segment is the
         //  filterbank output - dec1_w[0] holds (C2 + C1) x C1; the plain copy below only serves the debug dump)
         for (int l = 0; l < S::NL; ++l) {
@@ -194,6 +201,8 @@ struct Pack {
             if (S::TATT) o.blk_tqkv[k] = alloc(szB(C2, 3 * C2));
         }
         if (S::TATT) o.tpe = alloc(S::NH * 32);
+        if (S::LN)
+            for (int q = 0; q < S::LN_SITES; ++q) { o.ln_g[q] = alloc(szBias(C1 > C2 ? C1 : C2)); o.ln_b[q] = alloc(szBias(C1 > C2 ? C1 : C2)); }
         o.blk_stride = S::KB > 1 ? o.blk_wih[1] - o.blk_wih[0] : 0;
         o.gru_flat = S::GFLAT ? 1 : 0;
         o.window = alloc(S::NFFT); o.window_istft = alloc(S::NFFT); o.twiddle = alloc(S::NFFT);
@@ -227,6 +236,7 @@ struct FrameArgs {
     int mode;                 // FE_MODE_*
     int Tw;                   // offline: samples per stream
     float compression;
+    float rf_eps;             // ln variant: eps of the blocks' LayerNorms (rnnformer_kwargs.eps)
     // time-pipelined launches (PIPE instantiation): P workgroups per stream, workgroup p runs frames p, p + P, ...
     unsigned int* pipe_flags; // [B][KB]: number of frames whose block-k GRU state has been published (zeroed before the launch)
     float* frames;            // offline: [B][T][N] windowed output frames (overlap-added by istft_ola_kernel afterwards)
@@ -527,6 +537,48 @@ __device__ __forceinline__ float row16_allreduce(float x, OP op) {
     return x;
 }
 
+// ln variant: one norm site.  buf holds the [ROWS x COLS] pre-norm values of the frame (leading dimension LD); the statistics are
+// over ALL of them (nn.GroupNorm(1, C) on [C, F] / the reference's LayerNorm over (F, C)): per-thread partial sums, DPP / row-swap
+// wave sums, four partials through LDS, one barrier.  FC = false: buf <- act(xhat * g[c] + b[c]).  FC = true (the blocks'
+// LayerNorm AS WRITTEN in models/fastenhancer/ln/model.py:31-34 - `diff.addcmul(inv_std * weight, bias)`, i.e. the centred value
+// plus inv_std * weight * bias): xres[r][c] += (v - mean) + inv_std * g[c] * b[c] (+ pe[r][c]).  The caller barriers afterwards.
+template <int ROWS, int COLS, int LD, bool ACT, bool FC>
+__device__ __forceinline__ void ln_pass(float* buf, float* red, const float* g, const float* bt, float eps, float* xres = nullptr, int ldx = 0,
+                                        const float* pe = nullptr) {
+    constexpr int N = ROWS * COLS, PER = ceil_div(N, kThreads);
+    const int tid = threadIdx.x;
+    float v[PER], s = 0.0f, q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = tid + kThreads * i, ec = e < N ? e : N - 1, r = ec / COLS, c = ec - r * COLS;
+        v[i] = buf[r * LD + c];
+        const float m = e < N ? v[i] : 0.0f;
+        s += m; q = fmaf(m, m, q);
+    }
+    auto add = [](float x, float y) { return x + y; };
+    s = rows_allreduce(row16_allreduce(s, add), add);
+    q = rows_allreduce(row16_allreduce(q, add), add);
+    if ((tid & 63) == 0) { red[tid >> 6] = s; red[4 + (tid >> 6)] = q; }
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) * (1.0f / N);
+    const float var = fmaxf((red[4] + red[5] + red[6] + red[7]) * (1.0f / N) - mean * mean, 0.0f);
+    const float inv = __builtin_amdgcn_rsqf(var + eps);
+    // (threads past the end of the last round redo element N - 1 and store to a dummy slot: no partially executed region)
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = tid + kThreads * i, ec = e < N ? e : N - 1, r = ec / COLS, c = ec - r * COLS;
+        if constexpr (FC) {
+            float x = xres[r * ldx + c] + (v[i] - mean) + inv * g[c] * bt[c];
+            if (pe != nullptr) x += pe[r * COLS + c];
+            (e < N ? xres + r * ldx + c : red + 8)[0] = x;
+        } else {
+            float y = fmaf((v[i] - mean) * inv, g[c], bt[c]);
+            if (ACT) y = silu_f(y);
+            (e < N ? buf + r * LD + c : red + 8)[0] = y;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Debug stage table (shared by host and device).
 template <class S>
@@ -565,7 +617,7 @@ __device__ __forceinline__ void dbg_dump(const FrameArgs& a, int b, int stage, c
     float* dst = a.dbg + (size_t)b * a.dbg_stride + D::offset(stage);
     // conv-trunk stages (enc_pre, encoder.i, rf_post, decoder.i) live scaled by kSiluScale
     const bool trunk = (stage >= 2 && stage < 3 + S::NL) || (stage >= 4 + S::NL + 2 * S::KB && stage < 5 + 2 * S::NL + 2 * S::KB);
-    const float sc = trunk ? 1.0f / kSiluScale : 1.0f;
+    const float sc = (trunk && !S::LN) ? 1.0f / kSiluScale : 1.0f;      // (the ln variant's trunk is not scaled)
     for (int i = threadIdx.x; i < rows * cols; i += kThreads) {
         int r = i / cols, c = i - r * cols;
         dst[i] = src[r * ld + c] * sc;
@@ -637,7 +689,8 @@ struct Lds {
     static constexpr int TOTAL_KT1 = STAGED ? NOSTAGE_TOTAL + 2 * Pack<S>::umax() : NOSTAGE_TOTAL;
     // time_kernel variant: the previous KT-1 input frames of the conv being computed, activation layout with halo rows
     static constexpr int CA = TOTAL_KT1;
-    static constexpr int TOTAL = TOTAL_KT1 + (S::KT - 1) * S::ACT;
+    static constexpr int LNS = TOTAL_KT1 + (S::KT - 1) * S::ACT;      // ln variant: 16 floats for the block-wide sums
+    static constexpr int TOTAL = LNS + (S::LN ? 16 : 0);
     static_assert(S::KT == 1 || (STAGED && SKIPS_LDS), "the time_kernel variant is built for shapes with staged weights and LDS-resident skips");
     static_assert((size_t)TOTAL * 4 <= 160 * 1024, "LDS plan exceeds 160 KiB");
     // software-pipeline depth of the fine-grained MFMA panels: with staged conv weights (and then register-resident
@@ -1215,6 +1268,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
         if constexpr (!SG) return Ebuf + l * S::ACT;
         else return ((l + (S::NL & 1)) & 1) ? W1 : W0;
     };
+    // ln variant: norm site `site` (Shape::LN_SITES order) over a [ROWS x COLS] LDS tile, GroupNorm form
+    float* const lnred = smem + L::LNS;
+#define FE_LN_SITE(ROWS, COLS, LD, ACT, buf, site) ln_pass<ROWS, COLS, LD, ACT, false>(buf, lnred, wp + lz + o.ln_g[site], wp + lz + o.ln_b[site], 1.0e-5f)   /* (+ lz: not hoisted out of the frame loop) */
+    static_assert(!S::LN || (L::STAGED && L::SKIPS_LDS && S::KT == 1 && !S::FRNN && !S::TATT && !PIPE), "ln variant: built for the B-type plan (staged weights, LDS skips)");
     // weight units: unit U of frame t is consumed from LDS buffer ((U + t*NU) & 1) while the next streams in
     constexpr int NPW = L::STAGED ? ceil_div(ceil_div(Pack<S>::umax(), 256), kWaves) : 1;
     DmaJobT<NPW> job;
@@ -1432,9 +1489,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     ((q & 2) ? W1 : W0)[((q & 1) ? F1 + 1 : 0) * LDC + c] = 0.0f;
                 }
             }
-            conv_store<S, S::NTC, C1, LDC, true>(acc, encbuf(0), 1, wave, lane, SG ? skipg : nullptr);
+            conv_store<S, S::NTC, C1, LDC, !S::LN>(acc, encbuf(0), 1, wave, lane, SG ? skipg : nullptr);
         }
         __syncthreads();
+        if constexpr (S::LN) { FE_LN_SITE(F1, C1, LDC, true, encbuf(0) + LDC, 0); __syncthreads(); }
         dbg_dump<S>(a, b, 2, encbuf(0) + LDC, LDC);
 
         // ---- time_kernel variant (CausalConv2d, models/fastenhancer/time_kernel/model.py:119-148): a k = 3 conv over frequency
@@ -1518,12 +1576,13 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
             __builtin_amdgcn_sched_barrier(0);
             if (l == 0) FE_CLK(41);
             stage.commit();
-            conv_store<S, S::NTC, C1, LDC, true>(acc, out, 1, wave, lane, SG ? skipg + (l + 1) * SKIP_FLOATS : nullptr);
+            conv_store<S, S::NTC, C1, LDC, !S::LN>(acc, out, 1, wave, lane, SG ? skipg + (l + 1) * SKIP_FLOATS : nullptr);
             }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (l == 0) FE_CLK(42);
             __syncthreads();
+            if constexpr (S::LN) { FE_LN_SITE(F1, C1, LDC, true, out + LDC, 1 + l); __syncthreads(); }
             if (l == 0) FE_CLK(43);
             dbg_dump<S>(a, b, 3 + l, out + LDC, LDC);
         });
@@ -1633,6 +1692,22 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
             }
         }
         __syncthreads();
+        // reload of the residual registers from the token buffer (ln variant: the norm passes update x in LDS)
+        auto xr_reload = [&]() {
+#pragma unroll
+            for (int i = 0; i < S::MT2; ++i)
+#pragma unroll
+                for (int j = 0; j < NTPW2; ++j) {
+                    const float* xd = tok_dst(Xb, j);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xr[i][j][r] = xd[(16 * i + r) * LDX];
+                }
+        };
+        if constexpr (S::LN) {
+            FE_LN_SITE(F2, C2, LDX, false, Xb, 1 + S::NL);
+            __syncthreads();
+            xr_reload();
+        }
         dbg_dump<S>(a, b, 3 + S::NL, Xb, LDX);
 
         FE_CLK(6);
@@ -1999,6 +2074,18 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     Wq.bind(wb, (o.blk_qkv[0] + kb), (S::FRNN ? o.blk_qkv_b[0] + kb : -1), S::NT3, wave);      // for the next phase, fetched inside the GEMM
                     tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf1, FetchSide<decltype(Wq)>{&Wq});
                 }
+                if constexpr (S::LN) {
+                    // raw fc output -> the (free) Gi buffer; the LayerNorm pass adds its result (and the positional embedding) to x
+                    float* td = Gi + (4 * lg) * LDG + 16 * wave + li;
+#pragma unroll
+                    for (int i = 0; i < S::MT2; ++i)
+#pragma unroll
+                        for (int j = 0; j < NTPW; ++j)
+                            if (wave + 4 * j < S::NT2) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) td[(16 * i + r) * LDG + 64 * j] = acc[i][j][r];
+                            }
+                } else {
 #pragma unroll
                 for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -2012,8 +2099,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                             xd[(16 * i + r) * LDX] = v;
                         }
                     }
+                }
             }
             __syncthreads();
+            if constexpr (S::LN) {
+                ln_pass<F2, C2, LDG, false, true>(Gi, lnred, wp + lz + o.ln_g[2 + S::NL + 2 * k], wp + lz + o.ln_b[2 + S::NL + 2 * k], a.rf_eps, Xb, LDX,
+                                                  k == 0 ? wp + lz + o.blk_pe : nullptr);
+                __syncthreads();
+                xr_reload();
+            }
             dbg_dump<S>(a, b, 4 + S::NL + 2 * k, Xb, LDX);
             if (k == 0) FE_CLK(23);
             {
@@ -2155,6 +2249,17 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                         if constexpr (GFLAT) hkeep[q] = hpre[q];
                     }
                 }
+                if constexpr (S::LN) {
+                    float* td = Gi + (4 * lg) * LDG + 16 * wave + li;      // (qkv is dead: the attention has consumed it)
+#pragma unroll
+                    for (int i = 0; i < S::MT2; ++i)
+#pragma unroll
+                        for (int j = 0; j < NTPW; ++j)
+                            if (wave + 4 * j < S::NT2) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) td[(16 * i + r) * LDG + 64 * j] = acc[i][j][r];
+                            }
+                } else {
 #pragma unroll
                 for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -2167,8 +2272,14 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                             xd[(16 * i + r) * LDX] = v;
                         }
                     }
+                }
             }
             __syncthreads();
+            if constexpr (S::LN) {
+                ln_pass<F2, C2, LDG, false, true>(Gi, lnred, wp + lz + o.ln_g[3 + S::NL + 2 * k], wp + lz + o.ln_b[3 + S::NL + 2 * k], a.rf_eps, Xb, LDX);
+                __syncthreads();
+                xr_reload();
+            }
             if (k == 0) FE_CLK(26);
             dbg_dump<S>(a, b, 5 + S::NL + 2 * k, Xb, LDX);
         }
@@ -2199,6 +2310,27 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
             int r = i / LDC, c = i - r * LDC;
             Wy[(r ? F1 + 1 : 0) * LDC + c] = 0.0f;
         }
+        if constexpr (S::LN) {
+            // ln variant: rf_post's 1x1 conv (C2 -> C1) is a phase of its own again - a GroupNorm sits between it and decoder
+            // layer 0: Z = GN(conv(Y2) + b) -> Wy (rows 1 .. F1), which layer 0's 1x1 then reads as its x segment (in place:
+            // a wave reads and writes its own rows only)
+            __syncthreads();                                      // (Wy's halo rows above)
+            {
+                FE_BEGIN_UNIT(S::U_RFPOST + 1);
+                f32x4 acc[S::MTPW][S::NTC];
+                acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.rfpost1_b, 0, 1, S::NTC);
+                const float* xa = Y2 + (16 * wave + li) * LDX + lg;
+                mma_panel<S::MTPW, S::NTC, S::KS_2, Lds<S>::PDK>(
+                    acc, [&](int i, int ks) { return xa[(64 * i) * LDX + 4 * ks]; },
+                    [&](int j, int ks) { return wb.at(o.rfpost1_w + (j * S::KS_2 + ks) * 64); }, stage);
+                stage.commit();
+                conv_store<S, S::NTC, C1, LDC, false>(acc, Wy, 1, wave, lane);
+            }
+            __syncthreads();
+            FE_LN_SITE(F1, C1, LDC, false, Wy + LDC, 2 + S::NL + 2 * S::KB);
+            __syncthreads();
+            dbg_dump<S>(a, b, 4 + S::NL + 2 * S::KB, Wy + LDC, LDC);
+        } else
         if (a.dbg != nullptr) {                                  // the rf_post stage no longer exists: recompute it for the dump
             float* dst = a.dbg + (size_t)b * a.dbg_stride + DebugLayout<S>::offset(4 + S::NL + 2 * S::KB);
             for (int i = tid; i < F1 * C1; i += kThreads) {
@@ -2218,8 +2350,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 // 1x1 conv on cat([x, skip]): two K-segments, never materialised.  Layer 0: x = rf_post's filterbank
                 // output Y2 [F1][C2] with rf_post's 1x1 folded into this layer's weights; later layers: x = Wx [F1][C1].
                 FE_BEGIN_UNIT(S::U_DEC + l * (S::KT + 1));
-                constexpr int K0 = (l == 0) ? S::KS_2 : S::KS_C;       // k-steps of the x segment
-                constexpr int LD0 = (l == 0) ? LDX : LDC;
+                constexpr bool FOLD0 = (l == 0) && !S::LN;             // (ln variant: layer 0 is a layer like the others, x = Z in Wy)
+                constexpr int K0 = FOLD0 ? S::KS_2 : S::KS_C;          // k-steps of the x segment
+                constexpr int LD0 = FOLD0 ? LDX : LDC;
                 if constexpr (NSPLIT) {
                     const float* xa0 = (l == 0) ? Y2 + li * LDX + lg : Wx + (li + 1) * LDC + lg;
                     const float* sk0 = skip + (li + 1) * LDC + lg;
@@ -2232,7 +2365,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 } else {
                     f32x4 acc[S::MTPW][S::NTC];
                     acc_init_bias<S::MTPW, S::NTC>(acc, wb, o.dec1_b[l], 0, 1, S::NTC);
-                    const float* xa = (l == 0) ? Y2 + (16 * wave + li) * LDX + lg : Wx + (16 * wave + li + 1) * LDC + lg;
+                    const float* xa = FOLD0 ? Y2 + (16 * wave + li) * LDX + lg : ((l == 0 ? Wy : Wx) + (16 * wave + li + 1) * LDC + lg);
                     const float* sk = skip + (16 * wave + li + 1) * LDC + lg;
                     // (SG: the skip comes back from the global scratch as A fragments, 8 k-steps ahead)
                     mma_panel<S::MTPW, S::NTC, K0 + S::KS_C, SG ? 8 : Lds<S>::PDK>(
@@ -2244,10 +2377,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                         },
                         [&](int j, int ks) { return wb.at(o.dec1_w[l] + (j * (K0 + S::KS_C) + ks) * 64); }, stage);
                     stage.commit();
-                    conv_store<S, S::NTC, C1, LDC, true>(acc, Wy, 1, wave, lane);
+                    conv_store<S, S::NTC, C1, LDC, !S::LN>(acc, Wy, 1, wave, lane);
                 }
             }
             __syncthreads();
+            if constexpr (S::LN) { FE_LN_SITE(F1, C1, LDC, true, Wy + LDC, 3 + S::NL + 2 * S::KB + 2 * l); __syncthreads(); }
             if constexpr (S::KT > 1) {
                 k3_time(std::integral_constant<int, S::U_DEC + l * (S::KT + 1) + 1>{}, Wy, Wx, S::NL + l, &o.dec3_w[l * S::KT], o.dec3_b[l]);
             } else {
@@ -2264,10 +2398,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                                               Wy + (16 * wave + li + 2) * LDC + lg};
                 conv_multi<S, S::NTC, 3, S::KS_C, LDC>(acc, taps, wb, o.dec3_w[l], stage);
                 stage.commit();
-                conv_store<S, S::NTC, C1, LDC, true>(acc, Wx, 1, wave, lane);   // Wx (and Y2 under it) was fully consumed before the barrier above
+                conv_store<S, S::NTC, C1, LDC, !S::LN>(acc, Wx, 1, wave, lane);   // Wx (and Y2 under it) was fully consumed before the barrier above
                 }
             }
             __syncthreads();
+            if constexpr (S::LN) { FE_LN_SITE(F1, C1, LDC, true, Wx + LDC, 4 + S::NL + 2 * S::KB + 2 * l); __syncthreads(); }
             dbg_dump<S>(a, b, 5 + S::NL + 2 * S::KB + l, Wx + LDC, LDC);
         });
 
@@ -2301,10 +2436,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     [&](int j, int ks) { return wb.at(o.post1_w + (j * (2 * S::KS_C) + ks) * 64); }, stage);
             }
             stage.commit();
-            conv_store<S, S::NTC, C1, LDC, true>(acc, Wy, 1, wave, lane);
+            conv_store<S, S::NTC, C1, LDC, !S::LN>(acc, Wy, 1, wave, lane);
             }
         }
         __syncthreads();
+        if constexpr (S::LN) { FE_LN_SITE(F1, C1, LDC, true, Wy + LDC, 3 + 3 * S::NL + 2 * S::KB); __syncthreads(); }
         {
             // transposed conv as GEMM: P[i][co*8+j] = sum_ci x[i][ci] w[ci][co][j]
             FE_BEGIN_UNIT(S::U_POST + 1);

@@ -66,6 +66,8 @@ class Engine:
             c.kernel_size_time = cfg.kernel_size_time
             c.channels_frnn = cfg.channels_frnn
             c.lookbehind = cfg.lookbehind
+            c.ln = 1 if cfg.ln else 0
+            c.rf_eps = cfg.rf_eps
         self._h = c_void_p()
         if self.device is not None and self.device.type == "cuda":
             with torch.cuda.device(self.device):

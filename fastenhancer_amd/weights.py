@@ -67,6 +67,8 @@ def fold_state_dict(sd: Mapping[str, Tensor], cfg: FEConfig) -> Dict[str, Tensor
         sd = {dprnn_canonical_key(k): v for k, v in sd.items()}
     if cfg.dpt:
         sd = {dpt_canonical_key(k): v for k, v in sd.items()}
+    if cfg.ln:
+        return _fold_state_dict_ln(sd, cfg)
     if is_fused(sd):
         sd = dict(sd)
         sd.pop("dec_post.2.scale", None)     # (the time_kernel variant's fused state_dict still lists the folded-in scale)
@@ -139,7 +141,71 @@ def fold_state_dict(sd: Mapping[str, Tensor], cfg: FEConfig) -> Dict[str, Tensor
     return out
 
 
+def _fold_state_dict_ln(sd: Dict[str, Tensor], cfg: FEConfig) -> Dict[str, Tensor]:
+    """The ln variant's deployment transform (models/fastenhancer/ln/model.py:524-533, 239-245, 116-135): the weight norms of the
+    GRU / qkv matrices and the final conv's normalisation + scale go away, every norm layer stays.  Fused keys = the training
+    keys, except the final conv: dec_post.3.{weight,scale,bias} -> dec_post.2.{weight,bias}."""
+    if "dec_post.2.weight" in sd:
+        return dict(sd)
+    out: Dict[str, Tensor] = {k: v for k, v in sd.items() if ".parametrizations." not in k and not k.startswith("dec_post.3.")}
+    for k in range(cfg.rf_blocks):
+        p = f"rf_block.{k}."
+        for mod, name in (("rnn", "weight_ih_l0"), ("rnn", "weight_hh_l0"), ("attn.qkv", "weight")):
+            g = p + f"{mod}.parametrizations.{name}.original0"
+            if g in sd:
+                out[p + f"{mod}.{name}"] = _weight_norm(sd[g], sd[p + f"{mod}.parametrizations.{name}.original1"])
+    w = sd["dec_post.3.weight"]
+    scale = sd.get("dec_post.3.scale", torch.ones(1))
+    if cfg.final_scale_exp:
+        scale = scale.exp()
+    if cfg.normalize_final_conv:
+        w = w / w.norm().clamp_min(1e-12)
+    out["dec_post.2.weight"] = w * scale
+    out["dec_post.2.bias"] = sd["dec_post.3.bias"]
+    return out
+
+
+def _expected_fused_shapes_ln(cfg: FEConfig) -> Dict[str, tuple]:
+    C1, C2, F1, F2 = cfg.channels, cfg.rf_channels, cfg.F1, cfg.rf_freq
+    s: Dict[str, tuple] = {}
+
+    def wb(prefix, wshape, bias=True):
+        s[prefix + ".weight"] = wshape
+        if bias:
+            s[prefix + ".bias"] = (wshape[0],)
+
+    wb("enc_pre.0", (C1, 2 * cfg.stride, cfg.kernel_size[0] // cfg.stride)); wb("enc_pre.1", (C1,))
+    for i in range(cfg.n_layers):
+        wb(f"encoder.{i}.0", (C1, C1, cfg.kernel_size[i + 1])); wb(f"encoder.{i}.1", (C1,))
+    s["rf_pre.0.weight"] = (F2, F1)
+    wb("rf_pre.1", (C2, C1, 1)); wb("rf_pre.2", (C2,))
+    for k in range(cfg.rf_blocks):
+        p = f"rf_block.{k}."
+        if k == 0:
+            s[p + "pe"] = (F2, C2)
+        s[p + "rnn.weight_ih_l0"] = (3 * C2, C2)
+        s[p + "rnn.weight_hh_l0"] = (3 * C2, C2)
+        s[p + "rnn.bias_ih_l0"] = (3 * C2,)
+        s[p + "rnn.bias_hh_l0"] = (3 * C2,)
+        s[p + "rnn_fc.weight"] = (C2, C2)
+        wb(p + "rnn_post_norm", (C2,))
+        s[p + "attn.qkv.weight"] = (3 * C2, C2)
+        s[p + "attn_fc.weight"] = (C2, C2)
+        wb(p + "attn_post_norm", (C2,))
+    s["rf_post.0.weight"] = (F1, F2)
+    wb("rf_post.1", (C1, C2, 1)); wb("rf_post.2", (C1,))
+    for i in range(cfg.n_layers):
+        wb(f"decoder.{i}.0", (C1, 2 * C1, 1)); wb(f"decoder.{i}.1", (C1,))
+        wb(f"decoder.{i}.3", (C1, C1, cfg.kernel_size[cfg.n_layers - i]), bias=False); wb(f"decoder.{i}.4", (C1,))
+    wb("dec_post.0", (C1, 2 * C1, 1), bias=False); wb("dec_post.1", (C1,))
+    s["dec_post.2.weight"] = (C1, 2, cfg.kernel_size[0])
+    s["dec_post.2.bias"] = (2,)
+    return s
+
+
 def expected_fused_shapes(cfg: FEConfig) -> Dict[str, tuple]:
+    if cfg.ln:
+        return _expected_fused_shapes_ln(cfg)
     C1, C2, F1, F2 = cfg.channels, cfg.rf_channels, cfg.F1, cfg.rf_freq
     tk, kt = cfg.time_kernel, cfg.kernel_size_time
     one = (1, 1) if tk else (1,)       # the time_kernel variant's 1x1 convs are Conv2d
@@ -262,7 +328,7 @@ def default_state_dict(cfg: FEConfig, generator: Optional[torch.Generator] = Non
     g = generator
     shapes = expected_fused_shapes(cfg)
     sd: Dict[str, Tensor] = {}
-    fb = linear_filterbank_time_kernel if cfg.time_kernel or cfg.dprnn or cfg.dpt else linear_filterbank
+    fb = linear_filterbank_time_kernel if cfg.time_kernel or cfg.dprnn or cfg.dpt or cfg.ln else linear_filterbank
     pre, post = (fb(cfg.F1, cfg.rf_freq) if (cfg.pre_post_init or "").startswith("linear") else (None, None))
     for k, shp in shapes.items():
         fan_in = 1
@@ -277,6 +343,8 @@ def default_state_dict(cfg: FEConfig, generator: Optional[torch.Generator] = Non
             sd[k] = positional_embedding(cfg.rf_heads, cfg.lookbehind + 1).t().contiguous()
         elif k.endswith(".pe"):
             sd[k] = positional_embedding(cfg.rf_channels, cfg.rf_freq)
+        elif cfg.ln and len(shp) == 1 and k.endswith(".weight"):       # GroupNorm / LayerNorm gains
+            sd[k] = torch.ones(shp)
         elif k.endswith("bias") and ".rnn." not in k and ".frnn." not in k:
             sd[k] = torch.zeros(shp)
         elif ".rnn." in k or ".frnn." in k:

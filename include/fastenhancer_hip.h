@@ -77,6 +77,12 @@ typedef struct fe_config {
                                       * that order rotate each [.., L, ..] axis left by head.  A cache slot whose first K element is +inf
                                       * does not take part (how a run "without caches", :216-218, marks the frames before the start; zero
                                       * caches do take part) */
+    int ln;                          /* `model: fastenhancer.ln` (models/fastenhancer/ln/model.py; configs/ablation/ln_b.yaml): 1 = GroupNorm(1, C)
+                                      * after every conv and the reference's LayerNorm over (F2, C2) after the blocks' fc layers instead of
+                                      * (folded) BatchNorms.  Weight sections = that model's state_dict after remove_weight_reparameterizations
+                                      * (convs with their own biases, <conv>.1 / .2 / .4 and rnn_post_norm / attn_post_norm weight + bias),
+                                      * the final conv as dec_post.2 with its scale folded in.  State as the default model */
+    float rf_eps;                    /* ln: eps of the blocks' LayerNorms (rnnformer_kwargs.eps; 0 -> 1e-5) */
 } fe_config;
 
 typedef struct fe_handle fe_handle;

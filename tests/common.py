@@ -142,6 +142,9 @@ def product_config(name):
         return dprnn_config(**kw)
     if MODEL_MODULE[name] == "fastenhancer.dptransformer":
         return dpt_config(**kw)
+    if MODEL_MODULE[name] == "fastenhancer.ln":
+        from fastenhancer_amd.config import ln_config
+        return ln_config(**kw)
     return time_kernel_config(**kw) if MODEL_MODULE[name] == "fastenhancer.time_kernel" else PCfg.from_model_kwargs(**kw)
 
 

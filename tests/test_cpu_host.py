@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 
 @pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m", "fe48_l", "fe48_b_h480", "fe_tk_b",
-                                  "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_s", "fe_dprnn_m", "fe_dprnn_l", "fe_dpt_t", "fe_dpt_b", "fe_dpt_s", "fe_dpt_m"])
+                                  "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_s", "fe_dprnn_m", "fe_dprnn_l", "fe_dpt_t", "fe_dpt_b", "fe_dpt_s", "fe_dpt_m", "fe_ln_b"])
 def test_section_table_matches_fused_schema(name):
     cfg = product_config(name)
     eng = Engine(cfg, None)
@@ -73,7 +73,7 @@ def test_config_rejects_what_the_reference_rejects():
         FEConfig.from_model_kwargs(**{**kw, "mask": "softmax"})
 
 
-@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_l", "fe48_b", "fe_tk_b", "fe_dprnn_b", "fe_dpt_b"])
+@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_l", "fe48_b", "fe_tk_b", "fe_dprnn_b", "fe_dpt_b", "fe_ln_b"])
 def test_host_fold_matches_oracle_fold(name):
     cfg_o, sd, fused_o, _ = build_oracle(name)
     cfg = product_config(name)

@@ -18,9 +18,9 @@ pytestmark = pytest.mark.gpu
 ABS_TOL = 1e-4
 REL_TOL = 1e-4
 GPU_SHAPES = ["fe_t", "fe_b", "fe_m", "fe_l", "fe48_b", "fe48_l", "fe48_b_h480", "fe_tk_b", "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_l",
-              "fe_dpt_t", "fe_dpt_b", "fe_dpt_m"]          # shapes with reference goldens
+              "fe_dpt_t", "fe_dpt_b", "fe_dpt_m", "fe_ln_b"]          # shapes with reference goldens
 ALL_SHAPES = ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m", "fe48_l", "fe48_b_h480", "fe_tk_b",
-              "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_s", "fe_dprnn_m", "fe_dprnn_l", "fe_dpt_t", "fe_dpt_b", "fe_dpt_s", "fe_dpt_m"]
+              "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_s", "fe_dprnn_m", "fe_dprnn_l", "fe_dpt_t", "fe_dpt_b", "fe_dpt_s", "fe_dpt_m", "fe_ln_b"]
 
 
 def _dev():
@@ -93,7 +93,7 @@ def test_spec_step_matches_reference_golden(name):
     _assert_close(h[-1].cpu().numpy(), g["chunk_h_last"], "h_last")
 
 
-@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_dprnn_b", "fe_dpt_b"])
+@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_dprnn_b", "fe_dpt_b", "fe_ln_b"])
 def test_driver_loop_matches_reference_golden(name):
     from fastenhancer_amd.streaming import enhance_stream
     g = load_golden(name)
@@ -338,7 +338,7 @@ def test_dptransformer_cacheless_chunk_longer_than_the_lookbehind():
     _assert_close(y2.cpu().numpy(), y2_ref, "continuation with the returned caches")
 
 
-@pytest.mark.parametrize("name,B,hops", [("fe_dprnn_b", 256, 3), ("fe_dprnn_l", 300, 2), ("fe_dpt_b", 256, 35), ("fe_dpt_t", 700, 4), ("fe_dpt_m", 260, 2)])
+@pytest.mark.parametrize("name,B,hops", [("fe_ln_b", 300, 3), ("fe_dprnn_b", 256, 3), ("fe_dprnn_l", 300, 2), ("fe_dpt_b", 256, 35), ("fe_dpt_t", 700, 4), ("fe_dpt_m", 260, 2)])
 def test_full_size_block_variants(name, B, hops):
     """the dprnn / dptransformer variants at full batch sizes (one workgroup per stream, and persistent workgroups above #CUs):
     oracle parity on sample streams, bitwise position independence on all; 35 hops of dpt_b take its K / V rings (31 slots)
