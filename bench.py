@@ -75,6 +75,8 @@ WORKLOADS = {
     "fe_dpt_b": dict(C1=48, ks=(8, 3, 3), dpt=31, C2=36, F2=24, K=3, N=512, H=256, sr=16000, init="linear_fixed", desc="FastEnhancer_B, dual-path transformer blocks"),
     "fe_dpt_s": dict(C1=64, ks=(8, 3, 3, 3), dpt=31, C2=48, F2=36, K=3, N=512, H=256, sr=16000, init="linear_fixed", desc="FastEnhancer_S, dual-path transformer blocks"),
     "fe_dpt_m": dict(C1=96, ks=(8, 3, 3, 3), dpt=31, C2=72, F2=48, K=4, N=512, H=160, sr=16000, init="linear_fixed", desc="FastEnhancer_M, dual-path transformer blocks"),
+    "fe_ln_b": dict(C1=48, ks=(8, 3, 3), ln=True, C2=36, F2=24, K=3, N=512, H=256, sr=16000, init="linear_fixed",
+                    desc="FastEnhancer_B with GroupNorm / LayerNorm (configs/ablation/ln_b.yaml)"),
     "fe_dprnn_s": dict(C1=64, ks=(8, 3, 3, 3), frnn=24, C2=48, F2=36, K=3, N=512, H=256, sr=16000, init="linear_fixed", desc="FastEnhancer_S, dprnn blocks"),
     "fe_dprnn_m": dict(C1=96, ks=(8, 3, 3, 3), frnn=36, C2=72, F2=48, K=4, N=512, H=160, sr=16000, init="linear_fixed", desc="FastEnhancer_M, dprnn blocks"),
     "fe_dprnn_l": dict(C1=128, ks=(8, 3, 3, 3, 3), frnn=48, C2=96, F2=64, K=5, N=512, H=100, sr=16000, init="linear_fixed",
@@ -92,6 +94,10 @@ def model_kwargs(w):
     if w.get("bsrnn"):
         return dict(num_channels=w["C"], num_layers=w["L"], bias=True, affine=True, n_fft=w["N"], hop_size=w["H"], win_size=w["N"],
                     window="hann", input_compression=0.3)
+    if w.get("ln"):
+        kw = model_kwargs({k: v for k, v in w.items() if k != "ln"})
+        kw.update(final_scale=True, final_scale_init="one")
+        return kw
     if w.get("dpt"):
         kw = model_kwargs({k: v for k, v in w.items() if k != "dpt"})
         rk = kw.pop("rnnformer_kwargs")
@@ -177,12 +183,12 @@ def host_cpus():
     return avail, quota
 
 
-def cpu_baseline_variant(kw: dict, sr: int, B: int, budget_s: float):
+def cpu_baseline_variant(kw: dict, sr: int, B: int, budget_s: float, variant=None):
     """The time_kernel / dprnn / dptransformer variants: the numpy oracle (oracle/fe_oracle.py, pinned on the reference's golden
     vectors of each variant; the C/OpenMP oracle restates the default model only) on ONE host core."""
     from oracle.fe_oracle import FEConfig as OCfg, FEOracle, fold_state_dict
     from oracle.weightgen import make_input, make_training_state_dict
-    cfg = OCfg.from_model_kwargs(kw)
+    cfg = OCfg.from_model_kwargs(kw, variant=variant)
     orc = FEOracle(cfg, fold_state_dict(make_training_state_dict(cfg, 2), cfg), np.float32)
     Bs = min(B, 16)
     H = cfg.hop_size
@@ -358,6 +364,9 @@ def main():
     elif w.get("dpt"):
         from fastenhancer_amd.config import dpt_config
         cfg = dpt_config(**kw)
+    elif w.get("ln"):
+        from fastenhancer_amd.config import ln_config
+        cfg = ln_config(**kw)
     else:
         cfg = FEConfig.from_model_kwargs(**kw)
     eng = Engine(cfg, dev)
@@ -508,8 +517,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline_fspen(kw, w["sr"], B, args.cpu_budget_s, lisennet=bool(w.get("lisennet")))
         elif world == 1 and not args.no_cpu_baseline and w.get("bsrnn"):
             res["cpu_baseline"] = cpu_baseline_bsrnn(args.workload, kw, w["sr"], B, args.cpu_budget_s)
-        elif world == 1 and not args.no_cpu_baseline and (w.get("kt") or w.get("frnn") or w.get("dpt")):
-            res["cpu_baseline"] = cpu_baseline_variant(kw, w["sr"], B, min(args.cpu_budget_s, 10.0))
+        elif world == 1 and not args.no_cpu_baseline and (w.get("kt") or w.get("frnn") or w.get("dpt") or w.get("ln")):
+            res["cpu_baseline"] = cpu_baseline_variant(kw, w["sr"], B, min(args.cpu_budget_s, 10.0), "ln" if w.get("ln") else None)
         elif world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.workload, kw, w["sr"], B, args.cpu_budget_s)
         print(json.dumps(res), flush=True)
