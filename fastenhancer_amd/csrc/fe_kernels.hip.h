@@ -547,11 +547,12 @@ __device__ __forceinline__ void ln_pass(float* buf, float* red, const float* g, 
                                         const float* pe = nullptr) {
     constexpr int N = ROWS * COLS, PER = ceil_div(N, kThreads);
     const int tid = threadIdx.x;
-    float v[PER], s = 0.0f, q = 0.0f;
+    float v[PER], gc[PER], bc[PER], s = 0.0f, q = 0.0f;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int e = tid + kThreads * i, ec = e < N ? e : N - 1, r = ec / COLS, c = ec - r * COLS;
         v[i] = buf[r * LD + c];
+        gc[i] = g[c]; bc[i] = bt[c];          // (L2 loads: in flight under the reduction and its barrier)
         const float m = e < N ? v[i] : 0.0f;
         s += m; q = fmaf(m, m, q);
     }
@@ -568,11 +569,11 @@ __device__ __forceinline__ void ln_pass(float* buf, float* red, const float* g, 
     for (int i = 0; i < PER; ++i) {
         const int e = tid + kThreads * i, ec = e < N ? e : N - 1, r = ec / COLS, c = ec - r * COLS;
         if constexpr (FC) {
-            float x = xres[r * ldx + c] + (v[i] - mean) + inv * g[c] * bt[c];
+            float x = xres[r * ldx + c] + (v[i] - mean) + inv * gc[i] * bc[i];
             if (pe != nullptr) x += pe[r * COLS + c];
             (e < N ? xres + r * ldx + c : red + 8)[0] = x;
         } else {
-            float y = fmaf((v[i] - mean) * inv, g[c], bt[c]);
+            float y = fmaf((v[i] - mean) * inv, gc[i], bc[i]);
             if (ACT) y = silu_f(y);
             (e < N ? buf + r * LD + c : red + 8)[0] = y;
         }
