@@ -1612,6 +1612,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
         float hkeep[GFLAT ? HPT : 1];                   // GFLAT: previous hidden state of this thread's gate elements
         TokW<NTPW2, S::KS_2, 1, REGW, WS> Wf1, Wf2;     // rnn_fc, attn_fc
         TokW<NTPW3, S::KS_2, 1, REGW, WS> Wq;           // qkv
+        TokW<NTPW3, S::KS_2, 1, REGW, WS> Wtq;          // dptransformer: the time attention's qkv (prefetched like the GRU weights it replaces)
         float pe_r[S::MT2][NTPW2][4];                                                  // positional embedding (block 0)
         // Unpredicated epilogue stores into the [F2P][C2 + 2] token buffers: pad rows are real rows, and lanes whose
         // column lies beyond C2 (the last channel tile; the wave without a tile) aim at the pad column - one select
@@ -1672,6 +1673,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
             }
             f32x4 acc[S::MT2][NTPW];
             acc_init_bias<S::MT2, NTPW>(acc, wb, o.rfpre_b, wave, 4, S::NT2);
+            if constexpr (S::TATT) {
+                Wtq.bind(wb, o.blk_tqkv[0], -1, S::NT3, wave);               // block 0's time-attention weights ride in this GEMM
+                tok_gemm<S, NTPW, S::KS_C, LDC>(acc, Y1 + li * LDC + lg, wb, o.rfpre_w, S::NT2, wave, side2(stage, FetchSide<decltype(Wtq)>{&Wtq}));
+            } else
             tok_gemm<S, NTPW, S::KS_C, LDC>(acc, Y1 + li * LDC + lg, wb, o.rfpre_w, S::NT2, wave, side2(stage, FetchSide<decltype(Wgh)>{&Wgh}));
             stage.commit();
 #pragma unroll
@@ -1724,8 +1729,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 // dptransformer variant (models/fastenhancer/dptransformer/model.py:200-236, 378-389): causal attention over time per
                 // sub-band and head.  Phase A: q | k | v of the frame = x W^T -> Gi (the layout of the sub-band attention's qkv).
                 static_assert(!L::PERHEAD && !PIPE && S::LB == 31, "dptransformer: full qkv buffer, one workgroup per stream, lookbehind 31");
-                TokW<NTPW3, S::KS_2, 1, REGW, WS> Wtq;
-                Wtq.fetch(wb, (o.blk_tqkv[0] + kb), -1, S::NT3, wave);
+                // (Wtq was fetched inside the previous phase's GEMM: rf_pre's for block 0, the previous block's attn_fc after that;
+                //  shapes that stream their block weights re-bind here)
+                if constexpr (!REGW) Wtq.bind(wb, (o.blk_tqkv[0] + kb), -1, S::NT3, wave);
                 Wf1.bind(wb, (o.blk_fc1_w[0] + kb), (o.blk_fc1_b[0] + kb), S::NT2, wave);   // fetched inside the GEMM below
                 if constexpr (GFLAT) Wq.bind(wb, (o.blk_qkv[0] + kb), -1, S::NT3, wave);
                 if (k == 0) {
@@ -1775,6 +1781,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     sl0 = sl0 >= LBK ? sl0 - LBK : sl0;
                     sl1 = sl1 >= LBK ? sl1 - LBK : sl1;
                     constexpr int NIT = ceil_div(PAIRS, 16);
+                    // the positional bias of this lane's two window positions: the head of pair grp + 16 it is grp mod 4 in every round
+                    static_assert(S::NH == 4, "head of a pair = its index mod 4");
+                    const float tpe0 = wb.gather_g(o.tpe + (grp & 3) * 32 + l16), tpe1 = wb.gather_g(o.tpe + (grp & 3) * 32 + j1);
 #pragma unroll 1
                     for (int it = 0; it < NIT; ++it) {
                         int p = grp + 16 * it;
@@ -1801,8 +1810,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
 #pragma unroll
                         for (int d = 0; d < HD; ++d) { const float qd = qk[d]; s0 = fmaf(qd, k0[d], s0); s1 = fmaf(qd, k1[d], s1); }
                         const float ninf = -__builtin_inff();
-                        s0 = (l16 < mask_lo || k0[0] == __builtin_inff()) ? ninf : fmaf(sc, s0, wb.gather_g(o.tpe + hh * 32 + l16));
-                        s1 = (j1 < mask_lo || (j1 < LBK && k1[0] == __builtin_inff())) ? ninf : fmaf(sc, s1, wb.gather_g(o.tpe + hh * 32 + j1));
+                        s0 = (l16 < mask_lo || k0[0] == __builtin_inff()) ? ninf : fmaf(sc, s0, tpe0);
+                        s1 = (j1 < mask_lo || (j1 < LBK && k1[0] == __builtin_inff())) ? ninf : fmaf(sc, s1, tpe1);
                         const float mx = row16_allreduce(fmaxf(s0, s1), [](float x, float y) { return fmaxf(x, y); });
                         const float e0 = __expf(s0 - mx), e1 = __expf(s1 - mx);
                         const float inv = __builtin_amdgcn_rcpf(row16_allreduce(e0 + e1, [](float x, float y) { return x + y; }));
@@ -2242,6 +2251,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = hgn[i < F2 * C2 ? i : F2 * C2 - 1]; }
                 }
                 f32x4 acc[S::MT2][NTPW];
+                if constexpr (S::TATT) {
+                    Wtq.bind(wb, (o.blk_tqkv[0] + kb + o.blk_stride), -1, S::NT3, wave, k + 1 < S::KB);      // the next block's
+                    tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf2, FetchSide<decltype(Wtq)>{&Wtq});
+                } else
                 tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf2, FetchSide<decltype(Wgh)>{&Wgh});
                 if (!PIPE && !S::TATT && k + 1 < S::KB) {
 #pragma unroll
