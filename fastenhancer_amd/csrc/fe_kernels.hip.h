@@ -2157,15 +2157,24 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 // the row the next step reads back as broadcasts (LDS operations of one wave execute in order) and frnn_fc's input.
                 static_assert(!L::PERHEAD && L::HL % 2 == 0 && S::LDX % 2 == 0 && S::HF % 2 == 0 && S::HF <= 64, "dprnn: sub-band GRU layout");
                 constexpr int H = S::HF;
-                const int u = lane < H ? lane : H - 1;           // lanes >= H shadow unit H - 1 (same loads, same stores: no partial-exec region)
+                // 16 <= H <= 32: the two 32-lane halves of the wave split the sum over j (half 0: j < HA, half 1: the rest, zero-padded
+                // to HA), one v_permlane32_swap joins the partial sums; both halves then do the same gate math and store the same h
+                // (256 streams: dprnn B 49.2 -> 47.5 us, S 98.9 -> 89.9; T, H = 10, loses 1 % and keeps the one-unit-per-lane form)
+                constexpr bool SPLIT = H <= 32 && H >= 16;
+                constexpr int HA = SPLIT ? round_up(H / 2, 2) : H;
+                const int half = SPLIT ? (lane >> 5) : 0;
+                const int ul = SPLIT ? (lane & 31) : lane;
+                const int u = ul < H ? ul : H - 1;               // lanes past H shadow unit H - 1 (same loads, same stores: no partial-exec region)
                 const int dirw = wave & 1;
-                float fw[3][H], fbn;
+                const int j0 = half * HA;
+                float fw[3][HA], fbn;
                 {
                     const int base = o.blk_fhh[0] + kb + dirw * (H * 3 * H);
 #pragma unroll
-                    for (int j = 0; j < H; ++j)
+                    for (int j = 0; j < HA; ++j)
 #pragma unroll
-                        for (int g = 0; g < 3; ++g) fw[g][j] = wb.at_gv(base + (j * 3 + g) * H, u * 4);
+                        for (int g = 0; g < 3; ++g)           // (j0 + j >= H: an out-of-range offset reads 0)
+                            fw[g][j] = wb.at_gv(base + (j * 3 + g) * H, (j0 + j < H ? (j0 * 3 * H + u) * 4 : 0x40000000));
                     fbn = wb.at_gv(o.blk_fbhn[0] + kb + dirw * H, u * 4);
                 }
                 __syncthreads();
@@ -2181,16 +2190,21 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     for (int st = 0; st < F2; ++st) {
                         const int fn = st + 1 < F2 ? f + df : f;
                         const float gr1 = gcol[fn * LDG], gz1 = gcol[fn * LDG + H], gn1 = gcol[fn * LDG + 2 * H];
-                        float ar = gr, az = gz, an = fbn;
+                        float ar = half ? 0.0f : gr, az = half ? 0.0f : gz, an = half ? 0.0f : fbn;
                         if (st > 0) {
                             // (plain FMAs: the packed form, two j per v_pk_fma_f32, measured 4 % / 11 % slower on dprnn B / L)
-                            const float* hp = hrow + (f - df) * LDX;
+                            const float* hp = hrow + (f - df) * LDX + j0;
 #pragma unroll
-                            for (int j = 0; j < H; j += 2) {
-                                const float2 hv = *reinterpret_cast<const float2*>(hp + j);
+                            for (int j = 0; j < HA; j += 2) {
+                                // (the padded tail of half 1 re-reads the row's last pair: its weights are zero)
+                                const float2 hv = *reinterpret_cast<const float2*>(j0 + j < H ? hp + j : hp + (H - 2 - j0));
                                 ar = fmaf(fw[0][j], hv.x, ar); az = fmaf(fw[1][j], hv.x, az); an = fmaf(fw[2][j], hv.x, an);
                                 ar = fmaf(fw[0][j + 1], hv.y, ar); az = fmaf(fw[1][j + 1], hv.y, az); an = fmaf(fw[2][j + 1], hv.y, an);
                             }
+                        }
+                        if constexpr (SPLIT) {
+                            auto join = [](float x) { float p = x, q = x; asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(p), "+v"(q)); return p + q; };
+                            ar = join(ar); az = join(az); an = join(an);
                         }
                         const float r = sigmoid_f(ar), z = sigmoid_f(az);
                         const float nn = tanh_f(gn + r * an);
