@@ -513,6 +513,12 @@ def main():
                          "flops_per_frame": eng.flops_per_frame,
                          "hbm_frac": alg_bytes / (kernel_ms * 1e-3) / 8e12},
         }
+        # the dominant bound: a workload whose algorithmic HBM traffic uses a larger fraction of the HBM peak than its FLOPs do of
+        # the fp32 matrix peak (the dptransformer variant: K / V caches of 31 frames read every hop) is priced against HBM
+        rf = res["roofline"]
+        if rf["hbm_frac"] > rf["frac"]:
+            rf.update({"bound": "hbm", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": rf["hbm_frac"],
+                       "mfma_frac": achieved / PEAK_FP32_TFLOPS})
         if world == 1 and not args.no_cpu_baseline and (w.get("fspen") or w.get("lisennet")):
             res["cpu_baseline"] = cpu_baseline_fspen(kw, w["sr"], B, args.cpu_budget_s, lisennet=bool(w.get("lisennet")))
         elif world == 1 and not args.no_cpu_baseline and w.get("bsrnn"):
