@@ -32,6 +32,9 @@ class Engine:
         self.lib = _lib.load()
         self.cfg = cfg
         self.device = torch.device(device) if device is not None else None
+        if self.device is not None and self.device.type == "cuda" and self.device.index is None and torch.cuda.is_available():
+            # torch.device('cuda') != torch.device('cuda:0'): keep one spelling, the indexed one tensors report
+            self.device = torch.device("cuda", torch.cuda.current_device())
         c = _lib.fe_config()
         self.is_bsrnn = isinstance(cfg, BSRNNConfig)
         self.is_fspen = isinstance(cfg, FSPENConfig)
@@ -141,7 +144,7 @@ class Engine:
         self._require_gpu()
         return torch.zeros(self.state_floats(B), dtype=torch.float32, device=self.device)
 
-    def split_state(self, state: Tensor, B: int) -> List[Tensor]:
+    def split_state(self, state: Tensor, B: int, head0: bool = False) -> List[Tensor]:
         """Views of the opaque state as the reference cache list
         [cache_stft [B,N-H], cache_istft [B,N-H], K x h [1,B*F2,C2]] (scripts/export_onnx.py:43-46)."""
         c = self.cfg
@@ -171,11 +174,12 @@ class Engine:
         if c.dpt:     # K and V caches per block, [B*F2, NH, L, hd] (models/fastenhancer/dptransformer/model.py:194-198)
             # In the state every cache is a ring over its L slots with one head per stream (include/fastenhancer_hip.h,
             # fe_config.lookbehind): the reference's tensors (oldest frame first) are the rings rotated left by head - copies,
-            # unless every head is 0 (a fresh or freshly packed state), when they are views
+            # (gathered on the device without looking at the heads: no device-to-host sync on the per-hop path), or views
+            # when the caller knows every head is 0 (head0: a fresh state)
             n = B * c.rf_freq * c.rf_channels * c.lookbehind
             L, hd = c.lookbehind, c.rf_channels // c.rf_heads
             heads = state[o + 2 * c.rf_blocks * n:o + 2 * c.rf_blocks * n + B]
-            rot = bool((heads != 0).any())
+            rot = not head0
             if rot:
                 idx = (heads.long()[:, None] + torch.arange(L, device=state.device)[None, :]) % L            # [B, L]
                 idx = idx[:, None, None, :, None].expand(B, c.rf_freq, c.rf_heads, L, hd)

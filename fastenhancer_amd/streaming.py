@@ -33,19 +33,32 @@ class StreamingModel:
     def engine(self) -> Engine:
         return self.model.engine
 
-    def _ensure(self, B: int, device):
-        if self._buf[0] is None or self._B != B or self._buf[0].device != device:
+    @staticmethod
+    def _same_device(a: torch.device, b) -> bool:
+        """torch.device('cuda') != torch.device('cuda:0'): compare type and index with None -> the current device"""
+        b = torch.device(b)
+        if a.type != b.type:
+            return False
+        if a.type != "cuda":
+            return True
+        cur = torch.cuda.current_device()
+        return (cur if a.index is None else a.index) == (cur if b.index is None else b.index)
+
+    def _ensure(self, B: int, device, fresh: bool = False):
+        if fresh or self._buf[0] is None or self._B != B or not self._same_device(self._buf[0].device, device):
             eng = self.engine
             self._buf = [eng.new_state(B), eng.new_state(B)]
-            self._views = [eng.split_state(self._buf[0], B), eng.split_state(self._buf[1], B)]
+            self._views = [eng.split_state(self._buf[0], B, head0=True), eng.split_state(self._buf[1], B, head0=True)]      # (fresh zero states)
             self._B = B
+            self._handed = (-1, [])          # the rotated copies of the previous buffers no longer name a buffer
 
     def initialize_cache(self, x: Tensor) -> tp.List[Tensor]:
         """scripts/export_onnx.py:43-46: [cache_stft, cache_istft] ++ model caches (zeros).  On the model's GPU the
-        tensors are views of ONE state buffer of the C ABI, so forward() need not re-pack them."""
+        tensors are views of ONE state buffer of the C ABI, so forward() need not re-pack them.  Every call allocates
+        fresh buffers (like the reference, which returns new tensors): the caches of a session still in progress on
+        this object keep their memory and simply stop being recognised as views (they are packed like foreign tensors)."""
         if x.is_cuda:
-            self._ensure(x.size(0), x.device)
-            self._buf[0].zero_()
+            self._ensure(x.size(0), x.device, fresh=True)
             return list(self._views[0])
         cache_list = self.model.stft.initialize_cache(x)
         cache_list.extend(self.model.initialize_cache(x))
@@ -64,7 +77,11 @@ class StreamingModel:
         return -1
 
     def forward(self, wav_in: Tensor, cache_stft: Tensor, cache_istft: Tensor, *cache_model: Tensor):
-        """wav_in [B, H]; functional like the reference: returns new cache tensors, the ones passed in are untouched.
+        """wav_in [B, H]; the caches passed in are never written (like the reference).  ALIASING CONTRACT, unlike the
+        reference: the caches returned are views of one of TWO internal state buffers used alternately, so the tensors
+        returned by call n are overwritten by call n + 2 - a caller that keeps a snapshot for roll-back must .clone() it
+        (INTEGRATION.md).  (dptransformer models return rotated copies of their K / V rings: in-place edits of those
+        are not seen by the next call; pass the edited tensors back in, which packs them like foreign tensors.)
         Caches that are the views handed out by initialize_cache() / the previous call (the driver loop of
         scripts/test_onnx.py) cost one device copy into the other state buffer; foreign tensors are packed first."""
         eng = self.engine

@@ -77,6 +77,10 @@ class FEConfig:
     # channels and sub-bands of a frame) and LayerNorm over (F2, C2) after the blocks' fc layers instead of the BatchNorms -
     # nothing folds into the convs, which carry their own biases
     ln: bool = False
+    # models/fastenhancer/noncausal/model.py (configs/fastenhancer_dns/huge_noncausal*.yaml, configs/fastenhancer_48khz/huge_noncausal.yaml):
+    # the blocks' time GRU is bidirectional (nn.GRU(C2, C2, bidirectional=True), :186) and rnn_fc maps 2 C2 -> C2 (:187); the
+    # module has the offline `Model` only (:348, :628-635) - no caches, no streaming step
+    noncausal: bool = False
 
     @property
     def time_kernel(self) -> bool:
@@ -102,6 +106,7 @@ class FEConfig:
             kernel_size_time=int(kw.get("kernel_size_time", 3)) if "kernel_size_freq" in kw else 1,
             final_scale_exp=(("kernel_size_freq" in kw or dp or dt or variant == "ln") and kw.get("final_scale", "exp") == "exp"),
             ln=(variant == "ln"),
+            noncausal=(variant == "noncausal"),
             lookbehind=int(rk.get("lookbehind", 16)) if dt else 0,
             channels_frnn=int(rk.get("channels_frnn", 16)) if dp else 0,
             stride=kw.get("stride", 4),
@@ -149,6 +154,8 @@ class FEConfig:
         elif self.dprnn:    # time GRU + fc, then the BiGRU over the F2 sub-bands (input and hidden products of both directions) + fc
             H = self.channels_frnn
             m += K * (C2 * C2 * 6 * F2 + C2 * C2 * F2 + 2 * 3 * H * (C2 + H) * F2 + 2 * H * C2 * F2)
+        elif self.noncausal:   # (no macs.py in the reference for this variant: the default model's count with both GRU directions and rnn_fc over 2 C2)
+            m += K * (2 * C2 * C2 * 6 * F2 + 2 * C2 * C2 * F2 + C2 * C2 * 3 * F2 + 2 * F2 * C2 * F2 + C2 * C2 * F2)
         else:
             m += K * (C2 * C2 * 6 * F2 + C2 * C2 * F2 + C2 * C2 * 3 * F2 + 2 * F2 * C2 * F2 + C2 * C2 * F2)
         m += F2 * F1 * C2 + C2 * C1 * F1
@@ -481,14 +488,15 @@ def fold_state_dict(sd: Dict[str, Array], cfg: FEConfig) -> Dict[str, Array]:
             else:
                 out[p + "time_attn.qkv.weight"] = sd[p + "time_attn.qkv.weight"].astype(np.float32)
         else:
-            for name in ("weight_ih_l0", "weight_hh_l0"):
-                key0 = p + f"rnn.parametrizations.{name}.original0"
-                if key0 in sd:
-                    out[p + "rnn." + name] = _weight_norm(sd[key0], sd[p + f"rnn.parametrizations.{name}.original1"])
-                else:
-                    out[p + "rnn." + name] = sd[p + "rnn." + name].astype(np.float32)
-            out[p + "rnn.bias_ih_l0"] = sd[p + "rnn.bias_ih_l0"].astype(np.float32)
-            out[p + "rnn.bias_hh_l0"] = sd[p + "rnn.bias_hh_l0"].astype(np.float32)
+            for sfx in ("", "_reverse") if cfg.noncausal else ("",):      # noncausal/model.py:215-222
+                for name in ("weight_ih_l0" + sfx, "weight_hh_l0" + sfx):
+                    key0 = p + f"rnn.parametrizations.{name}.original0"
+                    if key0 in sd:
+                        out[p + "rnn." + name] = _weight_norm(sd[key0], sd[p + f"rnn.parametrizations.{name}.original1"])
+                    else:
+                        out[p + "rnn." + name] = sd[p + "rnn." + name].astype(np.float32)
+                out[p + "rnn.bias_ih_l0" + sfx] = sd[p + "rnn.bias_ih_l0" + sfx].astype(np.float32)
+                out[p + "rnn.bias_hh_l0" + sfx] = sd[p + "rnn.bias_hh_l0" + sfx].astype(np.float32)
         if cfg.dprnn:      # DPRNN.remove_weight_reparameterizations, dprnn/model.py:172-192
             for name in ("weight_ih_l0", "weight_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse"):
                 key0 = p + f"frnn.parametrizations.{name}.original0"
@@ -641,17 +649,20 @@ def training_state_dict_spec(cfg: FEConfig) -> Dict[str, Tuple[int, ...]]:
             else:
                 spec[p + "time_attn.qkv.weight"] = (3 * C2, C2)
         else:
-            spec[p + "rnn.bias_ih_l0"] = (3 * C2,)
-            spec[p + "rnn.bias_hh_l0"] = (3 * C2,)
-            if cfg.weight_norm:
-                spec[p + "rnn.parametrizations.weight_ih_l0.original0"] = (3 * C2, 1)
-                spec[p + "rnn.parametrizations.weight_ih_l0.original1"] = (3 * C2, C2)
-                spec[p + "rnn.parametrizations.weight_hh_l0.original0"] = (3 * C2, 1)
-                spec[p + "rnn.parametrizations.weight_hh_l0.original1"] = (3 * C2, C2)
-            else:
-                spec[p + "rnn.weight_ih_l0"] = (3 * C2, C2)
-                spec[p + "rnn.weight_hh_l0"] = (3 * C2, C2)
-        spec[p + "rnn_fc.weight"] = (C2, C2)
+            sfxs = ("", "_reverse") if cfg.noncausal else ("",)       # nn.GRU registers the biases first, then the (parametrized) weights
+            for sfx in sfxs:
+                spec[p + "rnn.bias_ih_l0" + sfx] = (3 * C2,)
+                spec[p + "rnn.bias_hh_l0" + sfx] = (3 * C2,)
+            for sfx in sfxs:
+                if cfg.weight_norm:
+                    spec[p + f"rnn.parametrizations.weight_ih_l0{sfx}.original0"] = (3 * C2, 1)
+                    spec[p + f"rnn.parametrizations.weight_ih_l0{sfx}.original1"] = (3 * C2, C2)
+                    spec[p + f"rnn.parametrizations.weight_hh_l0{sfx}.original0"] = (3 * C2, 1)
+                    spec[p + f"rnn.parametrizations.weight_hh_l0{sfx}.original1"] = (3 * C2, C2)
+                else:
+                    spec[p + "rnn.weight_ih_l0" + sfx] = (3 * C2, C2)
+                    spec[p + "rnn.weight_hh_l0" + sfx] = (3 * C2, C2)
+        spec[p + "rnn_fc.weight"] = (C2, 2 * C2 if cfg.noncausal else C2)
         bn(p + "rnn_post_norm", C2)
         if cfg.dprnn:      # nn.GRU(bidirectional) registers biases first, then the (parametrized) weights, like the time GRU
             H = cfg.channels_frnn
@@ -858,6 +869,17 @@ class FEOracle:
                 ys, hk, hv = causal_time_attention(xs, w[p + "time_attn.qkv.weight"], w["time_pe"], c.rf_heads, c.lookbehind, hk, hv)
                 ys = ys.reshape(B, F2, T, C2).transpose(2, 0, 1, 3).reshape(T, B * F2, C2)
                 h_out += [hk, hv]
+            elif c.noncausal:
+                # bidirectional GRU over time, zero initial states (noncausal/model.py:186, 266-272): output = cat(forward, reverse)
+                assert h_list is None, "the noncausal model has no caches"
+                xs = x.reshape(T, B * F2, C2)
+                ys = np.empty((T, B * F2, 2 * C2), self.dtype)
+                for d, sfx in enumerate(("", "_reverse")):
+                    h = np.zeros((B * F2, C2), self.dtype)
+                    for t in (range(T) if d == 0 else range(T - 1, -1, -1)):
+                        h = gru_step(xs[t], h, w[p + "rnn.weight_ih_l0" + sfx], w[p + "rnn.weight_hh_l0" + sfx],
+                                     w[p + "rnn.bias_ih_l0" + sfx], w[p + "rnn.bias_hh_l0" + sfx])
+                        ys[t, :, d * C2:(d + 1) * C2] = h
             else:
                 h = np.zeros((B * F2, C2), self.dtype) if h_list is None else h_list[k][0].astype(self.dtype).copy()
                 # GRU over time (model.py:266-277), batch index b*F2+f

@@ -26,7 +26,7 @@ def make_training_state_dict(cfg: FEConfig, seed: int) -> Dict[str, np.ndarray]:
     """Training-form state_dict with seeded values."""
     rng = np.random.Generator(np.random.PCG64(seed))
     spec = training_state_dict_spec(cfg)
-    pre, post = (linear_filterbank_tk if cfg.time_kernel or cfg.dprnn or cfg.dpt or cfg.ln else linear_filterbank)(cfg.F1, cfg.rf_freq)
+    pre, post = (linear_filterbank_tk if cfg.time_kernel or cfg.dprnn or cfg.dpt or cfg.ln or cfg.noncausal else linear_filterbank)(cfg.F1, cfg.rf_freq)
     pe = positional_embedding(cfg.rf_channels, cfg.rf_freq)
     sd: Dict[str, np.ndarray] = {}
     for key, shape in spec.items():

@@ -90,7 +90,23 @@ CONFIGS = {
     "fe_dpt_m": ("configs/ablation/dpt_m.yaml", 142, 1, 36, 0),
     # the ln ablation (models/fastenhancer/ln): GroupNorm / LayerNorm instead of the (folded) BatchNorms
     "fe_ln_b": ("configs/ablation/ln_b.yaml", 150, 2, 10, 120),
+    # r3: the shipped shapes that were pinned on the oracle only (B = 1, 6 hops keeps each fixture small)
+    "fe_s": ("configs/fastenhancer/s.yaml", 105, 1, 6, 0),
+    "fe48_t": ("configs/fastenhancer_48khz/t.yaml", 107, 1, 6, 0),
+    "fe48_s": ("configs/fastenhancer_48khz/s.yaml", 108, 1, 6, 0),
+    "fe48_m": ("configs/fastenhancer_48khz/m.yaml", 109, 1, 6, 0),
+    "fe_dprnn_s": ("configs/ablation/dprnn_s.yaml", 133, 1, 6, 0),
+    "fe_dprnn_m": ("configs/ablation/dprnn_m.yaml", 134, 1, 6, 0),
+    "fe_dpt_s": ("configs/ablation/dpt_s.yaml", 143, 1, 6, 0),
 }
+
+
+def cache_checksum(a) -> np.ndarray:
+    """three float64 sums of a (large) cache tensor: plain, squared, and against a fixed position-dependent ramp - what the
+    goldens hold for the K / V caches whose full tensors are not stored"""
+    v = np.asarray(a, np.float64).reshape(-1)
+    ramp = np.cos(0.37 * np.arange(v.size, dtype=np.float64) + 0.11)
+    return np.array([v.sum(), (v * v).sum(), (v * ramp).sum()], np.float64)
 
 
 def to_t(sd):
@@ -185,7 +201,8 @@ def gen_fastenhancer(ref: str, name: str, out_dir: str):
     out["stream_cache_istft"] = cache_istft.numpy().copy()
     for k, hk in enumerate(h):
         if cfg.dpt and name != "fe_dpt_t" and 2 <= k < len(h) - 2:
-            continue          # (K / V caches are large: all blocks for dpt_t, the first and the last block's for the bigger shapes)
+            out[f"stream_h{k}_chk"] = cache_checksum(hk.numpy())
+            continue          # (K / V caches are large: all blocks for dpt_t; the first and the last block's + checksums of the others for the bigger shapes)
         out[f"stream_h{k}"] = hk.numpy().copy()
     out["stream_spec_in_last"] = specs_in[-1]
     out["stream_spec_out_last"] = specs_out[-1]
@@ -238,6 +255,69 @@ def gen_fastenhancer(ref: str, name: str, out_dir: str):
     rms_out = float(np.sqrt((out["stream_wav_out"][4:] ** 2).mean()))
     print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB) fold_worst={worst:.2e} "
           f"in_rms={rms_in:.3f} out_rms={rms_out:.3f}")
+
+
+NONCAUSAL_CONFIGS = {
+    # name: (yaml, seed, B, hops) - model: fastenhancer.noncausal (offline Model only)
+    "fe_nc": ("configs/fastenhancer_dns/huge_noncausal.yaml", 160, 2, 14),
+    "fe_nc24": ("configs/fastenhancer_dns/huge_noncausal_24khz.yaml", 161, 2, 9),
+    "fe48_nc": ("configs/fastenhancer_48khz/huge_noncausal.yaml", 162, 2, 10),
+}
+
+
+def gen_noncausal(ref: str, name: str, out_dir: str):
+    """models/fastenhancer/noncausal/model.py: bidirectional GRU over time; `Model.forward` (:628-635) is the whole surface."""
+    rel_yaml, seed, B, hops = NONCAUSAL_CONFIGS[name]
+    hps = yaml.safe_load(open(os.path.join(ref, rel_yaml)))
+    kw = hps["model_kwargs"]
+    sr = hps["data"]["sampling_rate"]
+    assert hps["model"] == "fastenhancer.noncausal"
+    cfg = FEConfig.from_model_kwargs(kw, variant="noncausal")
+    mod = import_reference_model(ref, "models/fastenhancer/noncausal/model.py", "ref_fe_model_noncausal")
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    model = mod.Model(**kw).eval()
+    ref_sd = model.state_dict()
+    spec = training_state_dict_spec(cfg)
+    assert list(ref_sd.keys()) == list(spec.keys()), (
+        "state_dict schema drifted", [k for k in ref_sd if k not in spec], [k for k in spec if k not in ref_sd])
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(spec[k]), (k, v.shape, spec[k])
+    if kw.get("pre_post_init", None) == "linear_fixed":       # the variant's own rf_pre_post_lin (:306-345, Hz axes with sr = 16 kHz)
+        pre, post = linear_filterbank_tk(cfg.F1, cfg.rf_freq)
+        assert np.abs(pre - model.rf_pre[0].weight.numpy()).max() < 1e-5
+        assert np.abs(post - model.rf_post[0].weight.numpy()).max() < 1e-5
+    sd = make_training_state_dict(cfg, seed)
+    model.load_state_dict(to_t(sd), strict=True)
+    H = cfg.hop_size
+    xo = torch.from_numpy(make_input(B, hops * H + 37, seed + 2000, sr))
+    with torch.no_grad():
+        wav_hat, spec_hat = model(xo)                    # training form (weight norm, BatchNorm in eval mode)
+        fused_model = mod.Model(**kw).eval()
+        fused_model.load_state_dict(to_t(sd), strict=True)
+        fused_model.remove_weight_reparameterizations()
+        wav_f, spec_f = fused_model(xo)                  # deployment form
+    fused_ref = {k: v.detach().numpy().copy() for k, v in fused_model.state_dict().items()}
+    fused_ref = {k.replace("dec_post.2.scale", "dec_post.3.scale"): v for k, v in fused_ref.items()}
+    fused_mine = fold_state_dict(sd, cfg)
+    # (the reference keeps the final conv's `scale` and un-normalised weight in its state_dict and applies them in forward:
+    #  the product of the two is what the fold emits)
+    w = fused_ref.pop("dec_post.2.weight")
+    scale = fused_ref.pop("dec_post.3.scale", None)
+    if scale is not None:
+        w = w / max(float(np.sqrt((w.astype(np.float32) ** 2).sum())), 1e-12) * scale if kw.get("normalize_final_conv", True) else w * scale
+    fused_ref["dec_post.2.weight"] = w.astype(np.float32)
+    assert set(fused_mine) == set(fused_ref), (set(fused_mine) ^ set(fused_ref))
+    worst = max(np.abs(fused_mine[k] - fused_ref[k]).max() / (np.abs(fused_ref[k]).max() + 1e-12) for k in fused_ref)
+    assert worst < 2e-6, worst
+    out = {"seed": np.int64(seed), "B": np.int64(B), "hops": np.int64(hops), "sr": np.int64(sr), "fold_worst_rel": np.float64(worst),
+           "offline_wav": wav_hat.numpy().copy(), "offline_spec": spec_hat.numpy().copy(),
+           "offline_fused_vs_training_max": np.float64(np.abs(wav_f.numpy() - wav_hat.numpy()).max())}
+    path = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB) fold_worst={worst:.2e} "
+          f"in_rms={float(np.sqrt((xo.numpy() ** 2).mean())):.3f} out_rms={float(np.sqrt((out['offline_wav'] ** 2).mean())):.3f} "
+          f"fused-vs-training {out['offline_fused_vs_training_max']:.2e}")
 
 
 BSRNN_CONFIGS = {
@@ -465,6 +545,10 @@ def main():
         if args.only and name not in args.only:
             continue
         gen_fastenhancer(args.ref, name, args.out)
+    for name in NONCAUSAL_CONFIGS:
+        if args.only and name not in args.only:
+            continue
+        gen_noncausal(args.ref, name, args.out)
     for name in BSRNN_CONFIGS:
         if args.only and name not in args.only:
             continue
