@@ -15,6 +15,7 @@ FE_ARCH_FASTENHANCER = 0
 FE_ARCH_BSRNN = 1
 FE_ARCH_FSPEN = 2
 FE_ARCH_LISENNET = 3
+FE_OFFLINE_AUTO, FE_OFFLINE_FRAME_WALK, FE_OFFLINE_TIME_BATCHED = 0, 1, 2
 
 
 class fe_config(ctypes.Structure):
@@ -23,6 +24,7 @@ class fe_config(ctypes.Structure):
         ("channels", c_int), ("n_kernels", c_int), ("kernel_size", c_int * FE_MAX_KERNELS),
         ("stride", c_int), ("rf_channels", c_int), ("rf_freq", c_int), ("rf_blocks", c_int),
         ("rf_heads", c_int), ("input_compression", c_float), ("kernel_size_time", c_int), ("channels_frnn", c_int), ("lookbehind", c_int), ("ln", c_int), ("rf_eps", c_float),
+        ("bidirectional", c_int),
     ]
 
 
@@ -39,6 +41,7 @@ SYMBOLS = {
     "fe_step": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "fe_spec_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fe_set_time_pipeline": (c_int, [c_void_p, c_int]),
+    "fe_set_offline_engine": (c_int, [c_void_p, c_int]),
     "fe_offline_work_floats": (c_size_t, [c_void_p, c_int, c_int]),
     "fe_offline": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fe_stft_step": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

@@ -19,11 +19,11 @@ CSRC = os.path.join(HERE, "csrc")
 _TAG = os.environ.get("FE_BUILD_TAG", "")
 OBJ = os.path.join(CSRC, "_obj" + ("_" + _TAG if _TAG else ""))
 LIB = os.path.join(HERE, "libfastenhancer_hip.so") if not _TAG else os.path.join(os.path.dirname(HERE), "ab", f"lib_{_TAG}.so")
-FE_DEPS = ["fe_kernels.hip.h", "fe_impl.h"]
+FE_DEPS = ["fe_kernels.hip.h", "fe_impl.h", "tb_kernels.hip.h"]
 BSRNN_DEPS = ["fe_kernels.hip.h", "bsrnn_kernels.hip.h"]
 FSPEN_DEPS = ["fe_kernels.hip.h", "fspen_kernels.hip.h"]
 LISENNET_DEPS = ["fe_kernels.hip.h", "fspen_kernels.hip.h", "lisennet_kernels.hip.h"]
-API_DEPS = ["fe_kernels.hip.h", "fe_impl.h", "fe_shapes.def", "bsrnn_kernels.hip.h", "fe_bsrnn_shapes.def", "stft_kernels.hip.h", "fspen_kernels.hip.h", "lisennet_kernels.hip.h",
+API_DEPS = ["fe_kernels.hip.h", "fe_impl.h", "tb_kernels.hip.h", "fe_shapes.def", "bsrnn_kernels.hip.h", "fe_bsrnn_shapes.def", "stft_kernels.hip.h", "fspen_kernels.hip.h", "lisennet_kernels.hip.h",
             os.path.join("..", "..", "include", "fastenhancer_hip.h")]
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in VGPRs instead of AGPRs - every epilogue read of an AGPR accumulator is a
 # v_accvgpr_read, a VALU instruction that the fp32 matrix path cannot overlap (~600 of them per wave and frame on
@@ -62,8 +62,9 @@ def add_shape(spec: str) -> str:
     kernel_size_time) -> a line in the local shape list.  The kernel template's constraints are checked here with a
     readable message (hipcc would report them as failed static_asserts): stride 4 and kernel_size [8, 3, ...] are fixed."""
     v = [int(x) for x in spec.replace(" ", "").split(",")]
-    if len(v) not in (7, 8, 10, 11, 12):
-        raise SystemExit("--add-shape wants C1,NL,C2,F2,KB,NFFT,HOP[,KT[,0,FR[,TA]]]  (FR = 1: the dprnn variant, TA = 31: the dptransformer variant)")
+    if len(v) not in (7, 8, 10, 11, 12, 13):
+        raise SystemExit("--add-shape wants C1,NL,C2,F2,KB,NFFT,HOP[,KT[,0,FR[,TA[,LN[,BD]]]]]  (FR = 1: the dprnn variant, TA = 31: the dptransformer variant, "
+                         "LN = 1: the ln variant, BD = 1: the noncausal variant)")
     C1, NL, C2, F2, KB, NFFT, HOP = v[:7]
     KT = v[7] if len(v) >= 8 else 1
     errs = []

@@ -49,6 +49,9 @@ class FEConfig:
     # `model: fastenhancer.ln` (models/fastenhancer/ln/model.py): GroupNorm(1, C) after every conv and the reference's LayerNorm
     # after the blocks' fc layers instead of BatchNorms; nothing folds into the convs
     ln: bool = False
+    # `model: fastenhancer.noncausal` (models/fastenhancer/noncausal/model.py:186-187): the blocks' time GRU is bidirectional and
+    # rnn_fc maps 2 C2 -> C2; the reference module has the offline `Model` only (no caches, no streaming step)
+    noncausal: bool = False
 
     @property
     def time_kernel(self) -> bool:
@@ -152,6 +155,14 @@ def time_kernel_config(channels: int = 64, kernel_size_freq: Sequence[int] = (8,
                                       normalize_final_conv=normalize_final_conv, pre_post_init=pre_post_init, resnet=False)
     import dataclasses
     return dataclasses.replace(base, kernel_size_time=int(kernel_size_time), final_scale_exp=(final_scale == "exp"))
+
+
+def noncausal_config(normalize_final_conv: bool = True, **model_kwargs) -> FEConfig:
+    """yaml model_kwargs of `model: fastenhancer.noncausal` (configs/fastenhancer_dns/huge_noncausal.yaml:2-30: the default model's keys;
+    defaults of models/fastenhancer/noncausal/model.py:349-368 - normalize_final_conv defaults to True there) -> FEConfig with noncausal set."""
+    base = FEConfig.from_model_kwargs(normalize_final_conv=normalize_final_conv, **model_kwargs)
+    import dataclasses
+    return dataclasses.replace(base, noncausal=True)
 
 
 def dprnn_config(channels: int = 64, kernel_size: Sequence[int] = (8, 3, 3), stride: int = 4, dprnn_kwargs: Optional[Dict[str, Any]] = None,

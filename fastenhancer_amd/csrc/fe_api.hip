@@ -52,8 +52,9 @@ struct Dims {
     int FR = 0;                // 1: dprnn variant (sub-band GRU of C2 / 2 hidden units per direction instead of the attention)
     int LN = 0;                // 1: ln variant (GroupNorm after every conv, the reference's LayerNorm after the blocks' fc layers)
     int TA = 0;                // > 0: dptransformer variant (causal attention over the last TA frames instead of the time GRU)
+    int BD = 0;                // 1: noncausal variant (bidirectional time GRU, rnn_fc over 2 C2; offline only, no caches)
     // model-state floats per stream: KB GRU states [F2][C2], or (dptransformer) 2 KB caches [F2][NH][TA][HD] + the ring head
-    size_t hstate() const { return (size_t)KB * F2 * C2 * (TA ? 2 * TA : 1) + (TA ? 1 : 0); }
+    size_t hstate() const { return BD ? 0 : (size_t)KB * F2 * C2 * (TA ? 2 * TA : 1) + (TA ? 1 : 0); }
 };
 
 // ---------------------------------------------------------------------------- dispatch table
@@ -105,6 +106,7 @@ struct fe_handle {
     int device = 0;
     int max_wgs = 256;             // CUs of the device: one resident workgroup per CU (persistent grid above that)
     int pipe_frames = -1;          // fe_set_time_pipeline (-1: chosen from the model size)
+    int offline_engine = FE_OFFLINE_AUTO;     // fe_set_offline_engine
     unsigned int* pipe_flags_dev = nullptr;   // fe_spec_step's frame counters [max_wgs][KB] (fe_offline keeps its own in the work buffer)
     std::vector<Section> sections;
     size_t blob_floats = 0;
@@ -188,12 +190,15 @@ void build_sections(fe_handle* h) {
         if (k == 0 && !d.FR) add_section(h, key("pe"), {d.F2, d.C2});
         if (d.TA) add_section(h, key("time_attn.qkv.weight"), {3 * d.C2, d.C2});
         else {
-        add_section(h, key("rnn.weight_ih_l0"), {3 * d.C2, d.C2});
-        add_section(h, key("rnn.weight_hh_l0"), {3 * d.C2, d.C2});
-        add_section(h, key("rnn.bias_ih_l0"), {3 * d.C2});
-        add_section(h, key("rnn.bias_hh_l0"), {3 * d.C2});
+        for (const char* sfx : {"", "_reverse"}) {
+            if (sfx[0] && !d.BD) break;
+            add_section(h, key((std::string("rnn.weight_ih_l0") + sfx).c_str()), {3 * d.C2, d.C2});
+            add_section(h, key((std::string("rnn.weight_hh_l0") + sfx).c_str()), {3 * d.C2, d.C2});
+            add_section(h, key((std::string("rnn.bias_ih_l0") + sfx).c_str()), {3 * d.C2});
+            add_section(h, key((std::string("rnn.bias_hh_l0") + sfx).c_str()), {3 * d.C2});
         }
-        add_section(h, key("rnn_fc.weight"), {d.C2, d.C2});
+        }
+        add_section(h, key("rnn_fc.weight"), {d.C2, d.BD ? 2 * d.C2 : d.C2});
         add_section(h, key("rnn_fc.bias"), {d.C2});
         if (d.FR) {     // DPRNN's fused state_dict (models/fastenhancer/dprnn/model.py:159-161), module names as the default model's
             const int H = d.C2 / 2;
@@ -333,7 +338,7 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
     for (int k = 0; k < d.KB; ++k) {
         auto key = [&](const char* s) { snprintf(nm, sizeof nm, "rf_block.%d.%s", k, s); return std::string(nm); };
         if (d.TA) pack_1x1(o.blk_tqkv[k], S(key("time_attn.qkv.weight")), C2, 3 * C2);
-        else
+        else if (!d.BD)
         {   // GRU (3*C2, C2), gate order r,z,n: one padded column block per gate
             const int gsz = fe::ceil_div(C2, 16) * (C2 / 4) * 64, bsz = fe::round_up(C2, 16);
             const float* wih = S(key("rnn.weight_ih_l0"));
@@ -353,7 +358,24 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
                 p.raw(o.blk_bhh[k] + g * bsz, C2, bhh + g * C2);
             }
         }
-        pack_1x1(o.blk_fc1_w[k], S(key("rnn_fc.weight")), C2, C2);
+        if (h->impl->tb && !d.TA) {
+            // time-batched engine (tb_kernels.hip.h): per direction the input weights as ONE flat (3 C2)-column matrix (rows r | z | n as
+            // stored by nn.GRU) with the bias b_ih + (r, z) b_hh, the hidden weights per gate, b_hn
+            const int gsz = fe::ceil_div(C2, 16) * (C2 / 4) * 64;
+            for (int dir = 0; dir < (d.BD ? 2 : 1); ++dir) {
+                const char* sfx = dir ? "_reverse" : "";
+                const float* wih = S(key((std::string("rnn.weight_ih_l0") + sfx).c_str()));
+                const float* whh = S(key((std::string("rnn.weight_hh_l0") + sfx).c_str()));
+                const float* bih = S(key((std::string("rnn.bias_ih_l0") + sfx).c_str()));
+                const float* bhh = S(key((std::string("rnn.bias_hh_l0") + sfx).c_str()));
+                pack_1x1(o.tb_wih[k][dir], wih, C2, 3 * C2);
+                for (int c = 0; c < 3 * C2; ++c) p.buf[(size_t)o.tb_bx[k][dir] + c] = bih[c] + (c < 2 * C2 ? bhh[c] : 0.0f);
+                for (int g = 0; g < 3; ++g) pack_1x1(o.tb_whh[k][dir] + g * gsz, whh + (size_t)g * C2 * C2, C2, C2);
+                p.raw(o.tb_bhn[k][dir], C2, bhh + 2 * C2);
+            }
+            if (d.BD) pack_1x1(o.tb_fc1_w[k], S(key("rnn_fc.weight")), 2 * C2, C2);
+        }
+        if (!d.BD) pack_1x1(o.blk_fc1_w[k], S(key("rnn_fc.weight")), C2, C2);
         if (!d.LN) p.raw(o.blk_fc1_b[k], C2, S(key("rnn_fc.bias")));      // (ln variant: the fc layers have no bias, their LayerNorm's is in the ln tables)
         if (d.FR) {
             // sub-band GRU: the input weights of both directions as one (3 C2)-column matrix [direction][r|z|n][unit] in the qkv
@@ -1242,24 +1264,26 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
                     cfg->channels_frnn, cfg->rf_channels);
     const int ln = cfg->ln ? 1 : 0;
     if (ln && (fr || cfg->lookbehind > 0 || kt > 1)) return fail(FE_ERR_INVALID_ARG, "ln excludes channels_frnn / lookbehind / kernel_size_time");
+    const int bd = cfg->bidirectional ? 1 : 0;
+    if (bd && (fr || cfg->lookbehind > 0 || kt > 1 || ln)) return fail(FE_ERR_INVALID_ARG, "bidirectional excludes channels_frnn / lookbehind / kernel_size_time / ln");
     const int ta = cfg->lookbehind > 0 ? cfg->lookbehind : 0;
     if (ta && ta != 31) return fail(FE_ERR_UNSUPPORTED_CONFIG, "lookbehind=%d (the dptransformer kernels are built for 31, every shipped yaml)", ta);
     if (ta && fr) return fail(FE_ERR_INVALID_ARG, "channels_frnn and lookbehind are exclusive");
     for (const fe::Impl* im : impls())
         if (im->C1 == cfg->channels && im->NL == cfg->n_kernels - 1 && im->C2 == cfg->rf_channels && im->F2 == cfg->rf_freq &&
-            im->KB == cfg->rf_blocks && im->NFFT == cfg->n_fft && im->HOP == cfg->hop_size && im->KT == kt && im->LOW == 0 && im->FR == fr && im->TA == ta && im->LN == ln)
+            im->KB == cfg->rf_blocks && im->NFFT == cfg->n_fft && im->HOP == cfg->hop_size && im->KT == kt && im->LOW == 0 && im->FR == fr && im->TA == ta && im->LN == ln && im->BD == bd)
             impl = im;
     const fe::Impl* impl_many = nullptr;
     for (const fe::Impl* im : impls())
         if (impl && im->LOW >= 1 && im->occ >= 2 && im->C1 == impl->C1 && im->NL == impl->NL && im->C2 == impl->C2 && im->F2 == impl->F2 &&
-            im->KB == impl->KB && im->NFFT == impl->NFFT && im->HOP == impl->HOP && im->KT == impl->KT && im->FR == impl->FR && im->TA == impl->TA && im->LN == impl->LN)
+            im->KB == impl->KB && im->NFFT == impl->NFFT && im->HOP == impl->HOP && im->KT == impl->KT && im->FR == impl->FR && im->TA == impl->TA && im->LN == impl->LN && !impl->BD)
             impl_many = im;
     if (!impl)
         return fail(FE_ERR_UNSUPPORTED_CONFIG,
                     "no kernel compiled for channels=%d layers=%d rf_channels=%d rf_freq=%d rf_blocks=%d n_fft=%d hop=%d kernel_size_time=%d%s "
                     "(build it: python -m fastenhancer_amd.build --add-shape %d,%d,%d,%d,%d,%d,%d,%d%s)",
-                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, kt, fr ? " dprnn" : (ta ? " dptransformer" : (ln ? " ln" : "")),
-                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, kt, fr ? ",0,1" : (ta ? ",0,0,31" : (ln ? ",0,0,0,1" : "")));
+                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, kt, fr ? " dprnn" : (ta ? " dptransformer" : (ln ? " ln" : (bd ? " noncausal" : ""))),
+                    cfg->channels, cfg->n_kernels - 1, cfg->rf_channels, cfg->rf_freq, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, kt, fr ? ",0,1" : (ta ? ",0,0,31" : (ln ? ",0,0,0,1" : (bd ? ",0,0,0,0,1" : ""))));
     if (impl->lds_bytes > 160 * 1024)
         return fail(FE_ERR_UNSUPPORTED_CONFIG, "shape needs %zu bytes of LDS (> 160 KiB per CU)", impl->lds_bytes);
     fe_handle* h = new fe_handle();
@@ -1271,6 +1295,7 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
     h->d.FR = impl->FR;
     h->d.TA = impl->TA;
     h->d.LN = impl->LN;
+    h->d.BD = impl->BD;
     for (int i = 0; i < cfg->n_kernels; ++i) h->d.ks[i] = cfg->kernel_size[i];
     if (hipGetDevice(&h->device) != hipSuccess) h->device = -1;   // no GPU: sections/tables still usable
     else {
@@ -1385,6 +1410,7 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
         ba.cache_stft = state; ba.cache_istft = state + (size_t)B * ovl_b; ba.lstm = state + 2 * (size_t)B * ovl_b;
         return launch_bsrnn(h, ba, stream);
     }
+    if (d.BD) return fail(FE_ERR_UNSUPPORTED_CONFIG, "the noncausal model has no streaming step (models/fastenhancer/noncausal/model.py has the offline Model only): use fe_offline");
     rc = ensure_scratch(h, B);
     if (rc != FE_OK) return rc;
     fe::FrameArgs a = base_args(h, B, T);
@@ -1476,6 +1502,7 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
         ba.spec_in = spec_in_dev; ba.spec_out = spec_out_dev; ba.lstm = h_dev;
         return launch_bsrnn(h, ba, stream);
     }
+    if (h->d.BD) return fail(FE_ERR_UNSUPPORTED_CONFIG, "the noncausal model has no spec -> spec step with caches (models/fastenhancer/noncausal/model.py has the offline Model only): use fe_offline");
     rc = ensure_scratch(h, B);
     if (rc != FE_OK) return rc;
     fe::FrameArgs a = base_args(h, B, T);
@@ -1504,9 +1531,41 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
     return FE_OK;
 }
 
+// floats of the time-batched engine's work buffer: xc | skip | x | gx | hs | frames, each a multiple of 4 floats
+static size_t tb_work_floats(const fe_handle* h, int B, int T, size_t* off /*[6] or nullptr*/) {
+    const Dims& d = h->d;
+    const size_t NF = (size_t)B * T, nd = d.BD ? 2 : 1;
+    const size_t sz[6] = {NF * 2 * d.F0, NF * (d.NL + 1) * d.F1 * d.C1, NF * d.F2 * d.C2, nd * NF * d.F2 * 3 * d.C2, NF * d.F2 * nd * d.C2, NF * d.NFFT};
+    size_t cur = 0;
+    for (int i = 0; i < 6; ++i) {
+        if (off) off[i] = cur;
+        cur += (sz[i] + 3) & ~(size_t)3;
+    }
+    return cur;
+}
+
+static bool use_tb_offline(const fe_handle* h) {
+    if (!h->impl || !h->impl->tb) return false;
+    if (h->d.BD) return true;
+    return h->offline_engine != FE_OFFLINE_FRAME_WALK;
+}
+
+int fe_set_offline_engine(fe_handle* h, int engine) {
+    if (!h || engine < FE_OFFLINE_AUTO || engine > FE_OFFLINE_TIME_BATCHED) return fail(FE_ERR_INVALID_ARG, "bad argument");
+    if (engine == FE_OFFLINE_TIME_BATCHED && !(h->impl && h->impl->tb)) return fail(FE_ERR_UNSUPPORTED_CONFIG, "no time-batched engine is compiled for this model");
+    if (engine == FE_OFFLINE_FRAME_WALK && h->d.BD) return fail(FE_ERR_UNSUPPORTED_CONFIG, "the noncausal model runs on the time-batched engine only");
+    h->offline_engine = engine;
+    return FE_OK;
+}
+
 size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw) {
     if (!h || B <= 0 || Tw <= 0) return 0;
     const Dims& d = h->d;
+    if (h->impl && h->impl->tb) {     // the larger of the two engines' needs, whatever the settings at call time (fe_set_time_pipeline / fe_set_offline_engine)
+        const int T = 1 + Tw / d.HOP;
+        size_t walk = d.BD ? 0 : (size_t)B * ((size_t)(d.NFFT - d.HOP) + d.hstate() + tk_floats(h)) + (((size_t)B * d.KB + 3) & ~(size_t)3) + (size_t)B * T * d.NFFT;
+        return std::max(walk, tb_work_floats(h, B, T, nullptr));
+    }
     if (h->limpl) return (size_t)B * ((size_t)(d.NFFT - d.HOP) + h->limpl->cache_floats);
     if (h->fimpl) return (size_t)B * (size_t)(d.NFFT - d.HOP) + fspen_gru_floats(B);
     if (h->bimpl) return (size_t)B * (size_t)(d.NFFT - d.HOP) + bsrnn_lstm_floats(h, B);
@@ -1528,6 +1587,41 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
         return fail(FE_ERR_INVALID_ARG, "Tw=%d: reflect padding of n_fft/2=%d needs a longer input", Tw, d.NFFT / 2);
     hipStream_t st = (hipStream_t)stream;
     const int T = 1 + Tw / d.HOP;
+    if (use_tb_offline(h)) {
+        // the time-batched engine: encoder pass, per block (scan over time, attention pass), decoder pass, overlap-add
+        rc = ensure_tables(h, st);
+        if (rc != FE_OK) return rc;
+        size_t off[6];
+        tb_work_floats(h, B, T, off);
+        fe::tb::TbArgs a{};
+        a.wp = h->packed_dev;
+        a.wav_in = noisy_dev; a.in_stride = (size_t)Tw; a.Tw = Tw;
+        a.spec_out = spec_hat_dev;
+        a.xc = work_dev + off[0]; a.skip = work_dev + off[1]; a.x = work_dev + off[2]; a.gx = work_dev + off[3]; a.hs = work_dev + off[4];
+        a.frames = work_dev + off[5];
+        a.hstate = nullptr;                      // zero initial state (model.py:626-627)
+        a.B = B; a.T = T; a.NF = B * T; a.mode = fe::FE_MODE_OFFLINE;
+        a.compression = h->cfg.input_compression;
+        hipError_t e = hipSuccess;
+        const fe::tb::TbImpl* tbi = h->impl->tb;
+        // (FE_TB_STAGES=n: stop after n launches - tools/gpu_tb_check.py reads the intermediate buffers out of work_dev)
+        const char* lim_s = std::getenv("FE_TB_STAGES");
+        int lim = lim_s ? std::atoi(lim_s) : 1 << 30;
+        if (lim-- > 0) tbi->launch(fe::tb::TB_ENC, a, h->max_wgs, st, &e);
+        for (int k = 0; k < d.KB && e == hipSuccess; ++k) {
+            a.k = k;
+            if (lim-- > 0) tbi->launch(fe::tb::TB_SCAN, a, h->max_wgs, st, &e);
+            if (e == hipSuccess && lim-- > 0) tbi->launch(fe::tb::TB_BLK, a, h->max_wgs, st, &e);
+        }
+        if (e == hipSuccess && lim-- > 0) tbi->launch(fe::tb::TB_DEC, a, h->max_wgs, st, &e);
+        if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+        const int n_out = d.HOP * (T - 1);
+        hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
+                           a.frames, h->tables_dev, wav_hat_dev, (size_t)n_out, d.NFFT, d.HOP, T);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+        return FE_OK;
+    }
     {   // zero the state, the tail and the frame counters (not the frames: every element is written)
         size_t nz = (size_t)B * ((size_t)(d.NFFT - d.HOP) + d.hstate() + tk_floats(h));
         if (h->bimpl || h->fimpl || h->limpl) nz = fe_offline_work_floats(h, B, Tw);
@@ -1759,7 +1853,9 @@ double fe_flops_per_frame(const fe_handle* h) {
     else if (d.FR) {  // time GRU + fc, then the sub-band GRU (input and hidden products of both directions) + fc
         const double H = C2 / 2;
         m += K * (C2 * C2 * 6 * F2 + C2 * C2 * F2 + 2 * 3 * H * (C2 + H) * F2 + 2 * H * C2 * F2);
-    } else
+    } else if (d.BD)  // both GRU directions, rnn_fc over 2 C2
+    m += K * (2 * C2 * C2 * 6 * F2 + 2 * C2 * C2 * F2 + C2 * C2 * 3 * F2 + 2 * F2 * C2 * F2 + C2 * C2 * F2);
+    else
     m += K * (C2 * C2 * 6 * F2 + C2 * C2 * F2 + C2 * C2 * 3 * F2 + 2 * F2 * C2 * F2 + C2 * C2 * F2);
     m += F2 * F1 * C2 + C2 * C1 * F1;
     for (int i = 1; i <= d.NL; ++i) m += 2 * C1 * C1 * F1 + C1 * C1 * 3 * KT * F1;

@@ -6,13 +6,13 @@
 #include <atomic>
 
 #include "fe_kernels.hip.h"
+#include "tb_kernels.hip.h"
 
 namespace fe {
 
-constexpr int kMaxDevices = 64;
-
 struct Impl {
-    int C1, NL, C2, F2, KB, NFFT, HOP, KT, LOW, FR, TA, LN;
+    int C1, NL, C2, F2, KB, NFFT, HOP, KT, LOW, FR, TA, LN, BD;
+    const tb::TbImpl* tb;   // time-batched engine (tb_kernels.hip.h) or nullptr
     size_t lds_bytes;
     int occ;              // resident workgroups per CU
     bool many_persist;    // companion: also used beyond occ x #CUs streams (persistent workgroups)
@@ -92,9 +92,19 @@ void dbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
 
 template <class S>
 Impl make_impl() {
-    return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, S::KT, S::LOW, S::FRNN ? 1 : 0, S::LB, S::LN ? 1 : 0, Lds<S>::BYTES, Lds<S>::OCC, Lds<S>::MANY_PERSIST, S::NU, Pack<S>::umax(), Lds<S>::STAGED,
+    const tb::TbImpl* tbp = nullptr;
+    if constexpr (S::TB) {
+        static const tb::TbImpl tbi = tb::make_tb_impl<S>();
+        tbp = &tbi;
+    }
+    if constexpr (S::BIDIR) {       // noncausal: no frame-by-frame kernel (the reverse-time scan needs all frames): time-batched engine only
+        return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, S::KT, S::LOW, 0, 0, 0, 1, tbp, (size_t)0, 1, false, S::NU, Pack<S>::umax(), false,
+                    (size_t)0, DebugLayout<S>::total(), DebugLayout<S>::n_stages, &Pack<S>::v, nullptr, nullptr, &dbg_stage_impl<S>};
+    } else {
+    return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, S::KT, S::LOW, S::FRNN ? 1 : 0, S::LB, S::LN ? 1 : 0, 0, tbp, Lds<S>::BYTES, Lds<S>::OCC, Lds<S>::MANY_PERSIST, S::NU, Pack<S>::umax(), Lds<S>::STAGED,
                 Lds<S>::SKIPS_LDS ? (size_t)0 : (size_t)(S::NL + 1) * S::F1 * S::C1,
                 DebugLayout<S>::total(), DebugLayout<S>::n_stages, &Pack<S>::v, &launch_impl<S>, &launch_pipe_impl<S>, &dbg_stage_impl<S>};
+    }
 }
 
 

@@ -56,9 +56,15 @@ __host__ __device__ constexpr int round_up(int a, int b) { return ceil_div(a, b)
 // positional bias [NH][L + 1].
 // LN = 1: the `fastenhancer.ln` variant (models/fastenhancer/ln/model.py): GroupNorm(1, C) after every conv (statistics over the
 // channels and sub-bands of the frame), the reference's LayerNorm over (F2, C2) after the blocks' fc layers; nothing folds.
-template <int C1_, int NL_, int C2_, int F2_, int KB_, int NFFT_, int HOP_, int KT_ = 1, int LOW_ = 0, int FR_ = 0, int TA_ = 0, int LN_ = 0>
+// BD = 1: the `fastenhancer.noncausal` variant (models/fastenhancer/noncausal/model.py:186-187): the blocks' time GRU is
+// bidirectional and rnn_fc maps 2 C2 -> C2; offline only, run by the time-batched engine (tb_kernels.hip.h) alone.
+template <int C1_, int NL_, int C2_, int F2_, int KB_, int NFFT_, int HOP_, int KT_ = 1, int LOW_ = 0, int FR_ = 0, int TA_ = 0, int LN_ = 0, int BD_ = 0>
 struct Shape {
     static constexpr bool LN = LN_ != 0;
+    static constexpr bool BIDIR = BD_ != 0;
+    static constexpr int ND = BD_ != 0 ? 2 : 1;      // GRU directions over time
+    // shapes the time-batched (layer-by-layer) engine runs: the default model and the noncausal variant
+    static constexpr bool TB = KT_ == 1 && LOW_ == 0 && FR_ == 0 && TA_ == 0 && LN_ == 0;
     static constexpr int LN_SITES = 4 + 3 * NL_ + 2 * KB_;      // enc_pre, encoder.i, rf_pre, (rnn, attn) per block, rf_post, (1x1, k3) per decoder layer, dec_post
     static constexpr int C1 = C1_, NL = NL_, C2 = C2_, F2 = F2_, KB = KB_, NFFT = NFFT_, HOP = HOP_, KT = KT_, LOW = LOW_;
     static constexpr bool FRNN = FR_ != 0;
@@ -138,6 +144,11 @@ struct PackedOffsets {
     int window, window_istft, twiddle;  // [N], [N], [N/2] float2
     int dft1, dft2, dft3, dft4;         // constant operands of the matrix-core DFT (see Dft<S>)
     int gru_flat;                       // 1: GRU weights / biases packed as one (3 C2)-column matrix (Shape::GFLAT)
+    // time-batched engine (tb_kernels.hip.h; Shape::TB), per block and direction: the GRU input weights as ONE flat (3 C2)-column B
+    // operand (rows r | z | n as stored by nn.GRU) with the bias b_ih (+ b_hh for r, z) [3 C2]; the hidden weights per gate
+    // (tile = gate * NT2 + channel tile, so that r, z, n of a (row, channel) meet in one lane) and b_hn [NT2 * 16];
+    // noncausal: rnn_fc over 2 C2 input channels
+    int tb_wih[8][2], tb_bx[8][2], tb_whh[8][2], tb_bhn[8][2], tb_fc1_w[8];
     int total;
     // LDS-staged weight "units" in consumption order (one per conv-type GEMM phase): [weights | bias],
     // 256-float aligned and padded, so that a unit is staged by whole 1-KiB global_load_lds pieces.
@@ -210,6 +221,14 @@ struct Pack {
             constexpr int N1 = S::NFFT / 32, KC = N1 / 2, MT = N1 / 16;
             o.dft1 = alloc(2 * 2 * 8 * 64); o.dft2 = alloc(2 * KC * 64); o.dft3 = alloc(2 * MT * KC * 64); o.dft4 = alloc(2 * 2 * 8 * 64);
         }
+        if (S::TB)
+            for (int k = 0; k < S::KB; ++k) {
+                for (int d = 0; d < S::ND; ++d) {
+                    o.tb_wih[k][d] = alloc(szB(C2, 3 * C2)); o.tb_bx[k][d] = alloc(szBias(3 * C2));
+                    o.tb_whh[k][d] = alloc(3 * szB(C2, C2)); o.tb_bhn[k][d] = alloc(szBias(C2));
+                }
+                if (S::BIDIR) o.tb_fc1_w[k] = alloc(szB(2 * C2, C2));
+            }
         o.total = round_up(cur, 64);
         return o;
     }
@@ -1083,7 +1102,7 @@ __device__ __forceinline__ void tok_gemm_w(f32x4 (&acc)[S::MT2][NTPW], const flo
 // Attention of one head for the query tiles q0, q0 + qstride, ... (NQ of them; tiles >= MT2 are skipped):
 //   S^T[key][query] = K Q^T, softmax over keys in registers, O^T = V^T P^T with the C/D row map as the k-permutation.
 // G holds q | k | v of the head at columns hoff, hoff + HD, hoff + 2 HD (row stride LDG); O -> Hl[query][head * HD + d].
-template <class S, int NQ, int LDG>
+template <class S, int NQ, int LDG, int PDK = Lds<S>::PDK>
 __device__ __forceinline__ void attention_head(const float* G, float* Hl, int hoff, int head, int q0, int qstride, int lane) {
     constexpr int HD = S::HD, F2 = S::F2, LDX = S::LDX;
     constexpr int KSD = ceil_div(HD, 4);
@@ -1094,7 +1113,7 @@ __device__ __forceinline__ void attention_head(const float* G, float* Hl, int ho
     for (int j = 0; j < NQ; ++j) { qt[j] = q0 + qstride * j; qt[j] = qt[j] < S::MT2 ? qt[j] : S::MT2 - 1; }
     f32x4 sacc[S::MT2][NQ];
     acc_init_zero<S::MT2, NQ>(sacc);
-    mma_panel<S::MT2, NQ, KSD, Lds<S>::PDK>(
+    mma_panel<S::MT2, NQ, KSD, PDK>(
         sacc,
         [&](int i, int ks) {
             // (K side unmasked: for d >= HD it reads the head's first v columns - finite values that meet the Q side's zeros)

@@ -1,0 +1,973 @@
+// tb_kernels.hip.h — the TIME-BATCHED (layer-by-layer) engine of the FastEnhancer forward path for gfx950 (MI355X).
+//
+// The reference's offline / chunk forward runs all T frames of an utterance as ONE batch
+// (models/fastenhancer/default/model.py:620-675, 728-735; noncausal/model.py:578-635): every layer but the blocks' time GRU
+// is independent from frame to frame.  The per-hop kernel (fe_kernels.hip.h) walks the frames of a stream one after the
+// other; here the network is cut at the GRUs instead and every piece runs over ALL frames of ALL utterances:
+//
+//   tb_enc_kernel   per tile of FT frames: STFT, compress, enc_pre, encoder, rf_pre, and the x half of block 0's GRU gates
+//                   (W_ih x + b: it does not depend on the previous frame)                      model.py:628-650, 266-271
+//   tb_scan_kernel  per block: the recurrence itself, h_t = GRU(gx_t, h_{t-1}), 16 (utterance, sub-band) rows per
+//                   workgroup, only W_hh h serial; forward and - noncausal - reverse in time     model.py:271 / noncausal :186,271
+//   tb_blk_kernel   per tile of frames: rnn_fc + residual (+ pe), qkv, attention, attn_fc + residual, and the x half of the
+//                   NEXT block's gates                                                          model.py:273-290
+//   tb_dec_kernel   per tile of frames: rf_post, decoder, dec_post, mask, un-compress, inverse DFT, synthesis window
+//                   (the overlap-add is istft_ola_kernel's)                                     model.py:654-674, 694-709
+//
+// Between the launches the activations that cross a GRU live in HBM (288 GB: the whole batch fits): the compressed
+// spectrum, the encoder outputs (skips, in MFMA A-fragment order so that the decoder reads them back as coalesced 256-byte
+// fragments), the token stream x [frame][F2][C2], the gate pre-activations gx and the GRU outputs hs.  Inside a launch a tile of
+// FT consecutive frames is ONE GEMM problem per layer: M = FT * F1 conv rows / FT * F2 token rows (no 24 -> 32 padding of the token
+// rows at FT = 2 for FastEnhancer_B), one barrier-bounded phase per layer and TILE instead of per layer and frame.
+// All contractions run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32) through the same software-pipelined panels as
+// the per-hop kernel; weights are read from the same packed buffer (fe::Pack<S>, fragment order, L2-resident).
+#pragma once
+#include <atomic>
+
+#include "fe_kernels.hip.h"
+
+namespace fe {
+constexpr int kMaxDevices = 64;
+namespace tb {
+
+constexpr int kPD = 8;          // software-pipeline depth of the MFMA panels: weight fragments stream from L2
+
+struct TbArgs {
+    const float* wp;            // packed weights + tables (Pack<S>::v)
+    const float* wav_in;        // offline: [b * in_stride + n], n < Tw
+    size_t in_stride;
+    const float* spec_in;       // spec mode: [B][F0+1][T][2]
+    float* spec_out;            // spec mode: [B][F0+1][T][2]; offline: spec_hat [B][F0][T][2] (compressed domain)
+    float* frames;              // offline: [B][T][N] windowed output frames (summed by istft_ola_kernel)
+    float* xc;                  // [NF][2][F0]  compressed spectrum (Re plane, Im plane)
+    float* skip;                // [NF][NL+1][F1*C1]  encoder outputs, A-fragment order
+    float* x;                   // [NF][F2][C2]  token stream between the blocks
+    float* gx;                  // [ND][NF][F2][3 C2]  W_ih x + b_ih (+ b_hh for r, z)
+    float* hs;                  // [NF][F2][ND*C2]  GRU outputs
+    float* hstate;              // [KB][B*F2][C2] carried GRU state (spec -> spec with caches), or nullptr: zero initial state
+    int B, T, NF;               // utterances, frames per utterance, B * T
+    int Tw;                     // offline: samples per utterance
+    int mode;                   // FE_MODE_OFFLINE / FE_MODE_SPEC
+    int k;                      // block index (tb_scan_kernel, tb_blk_kernel)
+    float compression;
+};
+
+template <class S>
+__device__ __forceinline__ WSrc<false> make_wsrc(const float* wp, int lane) {
+    WSrc<false> wb;
+    wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, Pack<S>::v.total * 4, 0x00020000);
+    wb.lane4 = lane * 4;
+    wb.li4 = (lane & 15) * 4;
+    wb.lds = nullptr;
+    wb.base = 0;
+    return wb;
+}
+
+// ------------------------------------------------------------------------------------------ conv-layout GEMMs over FT frames
+// Wave tiling: NS column groups x MS = 4 / NS row groups.  A wave's B fragments (weights, from L2) are private when NS = 4
+// (column split: every weight fragment is fetched once per workgroup); with channel-tile counts that do not divide by 4
+// (T, B: 3 tiles; M: 6) the rows are split instead and the waves re-read the (few) weight fragments.
+// Row tile rt of the tile of frames = (frame rt / MTC, m-tile rt % MTC); wave (wm, wn) owns rt = wm + MS * i, i < MT.
+template <class S, int FT>
+struct ConvTiling {
+    static constexpr int NS = (S::NTC % 4 == 0) ? 4 : ((S::NTC % 2 == 0) ? 2 : 1);
+    static constexpr int MS = kWaves / NS;
+    static constexpr int MT = FT * S::MTC / MS;          // row tiles per wave
+    static constexpr int NTW = S::NTC / NS;              // column tiles per wave
+    static_assert(S::MTC % MS == 0, "row groups must divide the m-tiles of a frame");
+    __host__ __device__ static constexpr int frame(int i) { return (MS * i) / S::MTC; }
+    __host__ __device__ static constexpr int mtile0(int i) { return (MS * i) % S::MTC; }      // + wm
+};
+
+// acc[i][j] = bias[column tile j of this wave]; A(i, ks) from `af`, B from the packed weights at w_off (KS k-steps per tile);
+// epilogue: optional SiLU (scaled trunk), store to the activation buffers out[f] (row 1 + m: row 0 is the halo) and - gskip -
+// to the frames' global skip slots in A-fragment order (one 16-byte store per lane and tile).
+template <class S, int FT, int KS, bool ACT, int NCOLS, int LDO, int OSTR, int ROW0, class AF>
+__device__ __forceinline__ void conv_gemm(AF&& af, const WSrc<false>& wb, int w_off, int b_off, float* out, float* gskip, size_t gskip_fstride,
+                                          int nvalid, int wave, int lane) {
+    using CT = ConvTiling<S, FT>;
+    constexpr int MT = CT::MT, NTW = CT::NTW, NTALL = (NCOLS + 15) / 16;
+    const int li = lane & 15, lg = lane >> 4;
+    const int wn = CT::NS == 1 ? 0 : wave % CT::NS, wm = CT::NS == kWaves ? 0 : wave / CT::NS;
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        int nt = wn * NTW + j;
+        nt = nt < NTALL ? nt : NTALL - 1;
+        const f32x4 bj = b_off >= 0 ? wb.at16x4(b_off + nt * 64) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i][j] = bj;
+    }
+    const int wbase = w_off + wn * NTW * KS * 64;
+    mma_panel<MT, NTW, KS, kPD>(acc, af, [&](int j, int ks) {
+        int nt = j;                                                        // (clamped for the 16-column transposed-conv GEMM: NTALL = 1)
+        if (NTALL < CT::NS * NTW) nt = (wn * NTW + j < NTALL) ? j : NTALL - 1 - wn * NTW;
+        return wb.at_g(wbase + (nt * KS + ks) * 64);
+    }, NoSide{});
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int f = CT::frame(i), mt = CT::mtile0(i) + wm;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int ntg = wn * NTW + j, col = 16 * ntg + li;
+            if (ntg < NTALL && col < NCOLS) {
+                f32x4 v = acc[i][j];
+                if (ACT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = silu_scaled_f(v[r]);
+                }
+                float* od = out + f * OSTR + (ROW0 + 16 * mt + 4 * lg) * LDO + col;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) od[r * LDO] = v[r];
+                if (gskip != nullptr && f < nvalid)
+                    *reinterpret_cast<f32x4*>(gskip + (size_t)f * gskip_fstride + (mt * S::KS_C + (col >> 2)) * 64 + (col & 3) * 16 + 4 * lg) = v;
+            }
+        }
+    }
+}
+
+// A-fragment source of a k = 3 conv over the activation buffers `in` (halo rows 0 and F1 + 1): k-step ks = tap * KS_C + c4
+template <class S, int FT>
+struct K3Src {
+    const float* base;          // in + (16 wm + li) * LDC + lg
+    __device__ __forceinline__ float operator()(int i, int ks) const {
+        using CT = ConvTiling<S, FT>;
+        return base[CT::frame(i) * S::ACT + (16 * CT::mtile0(i) + ks / S::KS_C) * S::LDC + 4 * (ks % S::KS_C)];
+    }
+};
+
+// ------------------------------------------------------------------------------------------ token-layout GEMMs over FT frames
+// Rows = the FT * F2 tokens of the tile, dense (frame f, sub-band r -> row f * F2 + r): MTT = ceil(FT F2 / 16) row tiles, no
+// per-frame padding.  Columns split over the waves (tile wave + 4 j): private weight fragments.
+template <class S, int FT>
+struct TokTiling {
+    static constexpr int ROWS = FT * S::F2;
+    static constexpr int MTT = (ROWS + 15) / 16;
+    static constexpr int ROWS_P = MTT * 16 + 16;        // allocated rows: whole tiles + one tile of slack for the attention's padded key reads
+};
+
+// acc[i][j] += A (LDS rows, leading dimension LDA) x W[:, tile wave + 4 j]   (tiles beyond NT read a clamped tile: discarded)
+template <int MTT, int NTPW, int KS, int LDA>
+__device__ __forceinline__ void tok_panel(f32x4 (&acc)[MTT][NTPW], const float* a_lane, const WSrc<false>& wb, int w_off, int NT, int wave) {
+    mma_panel<MTT, NTPW, KS, kPD>(
+        acc, [&](int i, int ks) { return a_lane[(16 * i) * LDA + 4 * ks]; },
+        [&](int j, int ks) {
+            int nt = wave + 4 * j;
+            nt = nt < NT ? nt : NT - 1;
+            return wb.at_g(w_off + (nt * KS + ks) * 64);
+        }, NoSide{});
+}
+
+// gx = x W_ih^T + b for one block and direction -> global [rows][3 C2]; X: the tile's tokens in LDS
+template <class S, int FT>
+__device__ __forceinline__ void gx_gemm(const float* Xb, const WSrc<false>& wb, int w_off, int b_off, float* gx_tile, int rows_valid, int wave, int lane) {
+    using TT = TokTiling<S, FT>;
+    constexpr int MTT = TT::MTT, NT3 = S::NT3, N3 = S::N3;
+    constexpr int NTPW = ceil_div(NT3, kWaves);
+    // column tiles in chunks so that the accumulators stay within ~32 tiles per wave
+    constexpr int CH = (MTT * NTPW <= 32) ? NTPW : (32 / MTT > 0 ? 32 / MTT : 1);
+    const int li = lane & 15, lg = lane >> 4;
+#pragma unroll 1
+    for (int j0 = 0; j0 < NTPW; j0 += CH) {
+        f32x4 acc[MTT][CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            int nt = wave + 4 * (j0 + j);
+            nt = nt < NT3 ? nt : NT3 - 1;
+            const float bj = wb.at16_g(b_off + nt * 16);
+#pragma unroll
+            for (int i = 0; i < MTT; ++i) acc[i][j] = f32x4{bj, bj, bj, bj};
+        }
+        mma_panel<MTT, CH, S::KS_2, kPD>(
+            acc, [&](int i, int ks) { return Xb[(16 * i + li) * S::LDX + lg + 4 * ks]; },
+            [&](int j, int ks) {
+                int nt = wave + 4 * (j0 + j);
+                nt = nt < NT3 ? nt : NT3 - 1;
+                return wb.at_g(w_off + (nt * S::KS_2 + ks) * 64);
+            }, NoSide{});
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int nt = wave + 4 * (j0 + j), col = 16 * nt + li;
+            if (nt < NT3 && col < N3) {
+#pragma unroll
+                for (int i = 0; i < MTT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * i + 4 * lg + r;
+                        if (row < rows_valid) gx_tile[(size_t)row * N3 + col] = acc[i][j][r];
+                    }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ encoder segment
+template <class S, int FT>
+struct EncLds {
+    using TT = TokTiling<S, FT>;
+    static constexpr int TW = 0;                                   // twiddles float2[N/2]
+    static constexpr int SC = TW + S::NFFT;                        // compressed spectrum [FT][2][LDS_S]
+    static constexpr int A0 = SC + FT * 2 * S::LDS_S;              // activation ping-pong [FT][ACT] x 2
+    static constexpr int A1 = A0 + FT * S::ACT;
+    static constexpr int TOTAL = A1 + FT * S::ACT;
+    // aliases: the FFT scratch (windowed frame | spectrum, 2 N floats) lies in A1 (not live before encoder layer 0); the rf_pre
+    // intermediate Y1 [FT F2][LDC] in the ping-pong buffer the last encoder layer did NOT write, the tokens X [16 MTT][LDX] in the other
+    // one (its content - the last encoder output - is dead once the filterbank has run)
+    static constexpr size_t BYTES = (size_t)TOTAL * 4;
+    static constexpr bool OK = 2 * S::NFFT <= FT * S::ACT && TT::MTT * 16 * S::LDX <= FT * S::ACT && TT::MTT * 16 * S::LDC <= FT * S::ACT && BYTES <= 160 * 1024;
+};
+
+template <class S, int FT>
+__global__ void __launch_bounds__(kThreads) tb_enc_kernel(TbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using L = EncLds<S, FT>;
+    using CT = ConvTiling<S, FT>;
+    using TT = TokTiling<S, FT>;
+    using D = Dft<S, kPD>;
+    constexpr int N = S::NFFT, H = S::HOP, F0 = S::F0, F1 = S::F1, C1 = S::C1, C2 = S::C2, F2 = S::F2;
+    constexpr int LDC = S::LDC, LDX = S::LDX;
+    constexpr PackedOffsets o = Pack<S>::v;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const WSrc<false> wb = make_wsrc<S>(a.wp, lane);
+    const int wm = CT::NS == kWaves ? 0 : wave / CT::NS;
+
+    float2* tw = reinterpret_cast<float2*>(smem + L::TW);
+    for (int i = tid; i < N / 2; i += kThreads) tw[i] = reinterpret_cast<const float2*>(a.wp + o.twiddle)[i];
+    for (int i = tid; i < FT * 2 * S::LDS_S; i += kThreads) smem[L::SC + i] = 0.0f;       // (the 2-bin halos stay zero)
+    float* const A0 = smem + L::A0;
+    float* const A1 = smem + L::A1;
+    float* const q0 = A1;             // windowed frame
+    float* const q3 = A1 + N;         // spectrum {Re[N/2], Im[N/2]}
+    typename D::FwdConst dc;
+    D::load(dc, wb, o, wave);
+    const int ntiles = (a.NF + FT - 1) / FT;
+    __syncthreads();
+
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int g0 = tile * FT;
+        const int nvalid = a.NF - g0 < FT ? a.NF - g0 : FT;
+        // ---- STFT (functional/audio_modules.py:78-80: center = True, reflect padding) + compress (model.py:684-690), frame by frame
+#pragma unroll 1
+        for (int f = 0; f < FT; ++f) {
+            const int g = g0 + f < a.NF ? g0 + f : a.NF - 1;
+            const int b = g / a.T, t = g - b * a.T;
+            float* sc = smem + L::SC + f * 2 * S::LDS_S;
+            float* xcg = a.xc + (size_t)g * (2 * F0);
+            if (a.mode != FE_MODE_SPEC) {
+                const float* xin = a.wav_in + (size_t)b * a.in_stride;
+                const float* win = a.wp + o.window;
+                constexpr int NPT = N / kThreads;
+                float fv[NPT], fw[NPT];
+#pragma unroll
+                for (int q = 0; q < NPT; ++q) {
+                    const int n = tid + q * kThreads;
+                    int idx = t * H + n - N / 2;
+                    idx = idx < 0 ? -idx : idx;
+                    idx = idx >= a.Tw ? 2 * (a.Tw - 1) - idx : idx;
+                    fv[q] = xin[idx];
+                    fw[q] = win[n];
+                }
+#pragma unroll
+                for (int q = 0; q < NPT; ++q) q0[tid + q * kThreads] = fv[q] * fw[q];
+                __syncthreads();
+                D::forward(q0, q3, tw, dc, wave, lane, nullptr);          // (ends with a barrier)
+                for (int fb = tid; fb < F0; fb += kThreads) {
+                    const float re = q3[fb], im = q3[N / 2 + fb];
+                    const float mag = fmaxf(sqrtf(re * re + im * im), 1.0e-5f);
+                    const float gn = pow_f(mag, a.compression - 1.0f);
+                    sc[2 + fb] = re * gn;
+                    sc[S::LDS_S + 2 + fb] = im * gn;
+                    if (f < nvalid) { xcg[fb] = re * gn; xcg[F0 + fb] = im * gn; }
+                }
+                __syncthreads();                                           // (q0 / q3 are re-used by the next frame)
+            } else {
+                const float* sp = a.spec_in + (size_t)b * (F0 + 1) * a.T * 2;
+                for (int fb = tid; fb < F0; fb += kThreads) {
+                    const float re = sp[((size_t)fb * a.T + t) * 2], im = sp[((size_t)fb * a.T + t) * 2 + 1];
+                    const float mag = fmaxf(sqrtf(re * re + im * im), 1.0e-5f);
+                    const float gn = pow_f(mag, a.compression - 1.0f);
+                    sc[2 + fb] = re * gn;
+                    sc[S::LDS_S + 2 + fb] = im * gn;
+                    if (f < nvalid) { xcg[fb] = re * gn; xcg[F0 + fb] = im * gn; }
+                }
+            }
+        }
+        // zero halo rows of both ping-pong buffers (A1 held the FFT scratch, A0 the previous tile's tokens)
+        for (int i = tid; i < FT * 4 * LDC; i += kThreads) {
+            const int f = i / (4 * LDC), q = (i / LDC) & 3, c = i % LDC;
+            ((q & 2) ? A1 : A0)[f * S::ACT + ((q & 1) ? F1 + 1 : 0) * LDC + c] = 0.0f;
+        }
+        __syncthreads();
+        float* const skip_tile = a.skip + (size_t)g0 * ((S::NL + 1) * F1 * C1);
+        constexpr size_t SKF = (size_t)(S::NL + 1) * F1 * C1;
+        // ---- enc_pre (model.py:436-443): strided conv as a K = 16 GEMM over the 2-bin-haloed spectrum
+        {
+            const float* scb = smem + L::SC;
+            conv_gemm<S, FT, 4, true, C1, LDC, S::ACT, 1>(
+                [&](int i, int ks) {
+                    const int kk = 4 * ks + lg, c = kk & 1, s = (kk >> 1) & 3, tp = kk >> 3;
+                    const int m = 16 * (CT::mtile0(i) + wm) + li;
+                    return scb[CT::frame(i) * 2 * S::LDS_S + c * S::LDS_S + 4 * (m + tp) + s];
+                }, wb, o.enc_pre_w, o.enc_pre_b, A0, skip_tile, SKF, nvalid, wave, lane);
+        }
+        __syncthreads();
+        // ---- encoder (model.py:446-456): k = 3 convs, ping-pong A0 <-> A1
+        static_for<S::NL>([&](auto l_) {
+            constexpr int l = decltype(l_)::value;
+            const float* in = (l & 1) ? A1 : A0;
+            float* out = (l & 1) ? A0 : A1;
+            conv_gemm<S, FT, 3 * S::KS_C, true, C1, LDC, S::ACT, 1>(K3Src<S, FT>{in + (16 * wm + li) * LDC + lg}, wb, o.enc_w[l], o.enc_b[l], out,
+                                                                     skip_tile + (size_t)(l + 1) * F1 * C1, SKF, nvalid, wave, lane);
+            __syncthreads();
+        });
+        float* const Elast = (S::NL & 1) ? A1 : A0;      // last encoder output
+        float* const Y1 = (S::NL & 1) ? A0 : A1;         // rf_pre intermediate [FT F2][LDC] (dense rows)
+        float* const Xb = Elast;                         // tokens [ROWS_P][LDX] (after the filterbank)
+        // ---- rf_pre (model.py:458-465): Linear over the frequency axis - A = the packed filterbank [F2][F1], B = the frames' last
+        // encoder outputs, the frames of the tile side by side along N - then the 1x1 conv over the dense token rows
+        {
+            constexpr int NTPW = ceil_div(S::NTC, kWaves), KS = F1 / 4;
+            f32x4 acc[S::MT2][FT * NTPW];
+            acc_init_zero<S::MT2, FT * NTPW>(acc);
+            const float* Ein = Elast + LDC;                  // row 0 = bin 0
+            mma_panel<S::MT2, FT * NTPW, KS, kPD>(
+                acc, [&](int i, int ks) { return wb.at_g(o.rfpre_lin + (i * KS + ks) * 64); },
+                [&](int j, int ks) {
+                    int nt = wave + 4 * (j % NTPW);
+                    nt = nt < S::NTC ? nt : S::NTC - 1;
+                    return Ein[(j / NTPW) * S::ACT + (4 * ks + lg) * LDC + 16 * nt + li];
+                }, NoSide{});
+#pragma unroll
+            for (int i = 0; i < S::MT2; ++i)
+#pragma unroll
+                for (int j = 0; j < FT * NTPW; ++j) {
+                    const int nt = wave + 4 * (j % NTPW), col = 16 * nt + li, f = j / NTPW;
+                    if (nt < S::NTC && col < C1 && 16 * i + 4 * lg < F2) {        // (F2 % 4 == 0: a lane's four rows are valid together)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Y1[(f * F2 + 16 * i + 4 * lg + r) * LDC + col] = acc[i][j][r];
+                    }
+                }
+        }
+        __syncthreads();
+        {
+            constexpr int NTPW = ceil_div(S::NT2, kWaves);
+            f32x4 acc[TT::MTT][NTPW];
+            acc_init_bias<TT::MTT, NTPW>(acc, wb, o.rfpre_b, wave, 4, S::NT2);
+            tok_panel<TT::MTT, NTPW, S::KS_C, LDC>(acc, Y1 + li * LDC + lg, wb, o.rfpre_w, S::NT2, wave);
+            float* xg = a.x + (size_t)g0 * (F2 * C2);
+            const int rows_valid = nvalid * F2;
+#pragma unroll
+            for (int i = 0; i < TT::MTT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTPW; ++j) {
+                    const int nt = wave + 4 * j, col = 16 * nt + li;
+                    if (nt < S::NT2 && col < C2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * i + 4 * lg + r;
+                            Xb[row * LDX + col] = acc[i][j][r];
+                            if (row < rows_valid) xg[(size_t)row * C2 + col] = acc[i][j][r];
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+        // ---- the x half of block 0's GRU gates, every direction
+#pragma unroll 1
+        for (int d = 0; d < S::ND; ++d)
+            gx_gemm<S, FT>(Xb, wb, o.tb_wih[0][0] + d * (o.tb_wih[0][S::ND - 1] - o.tb_wih[0][0]), o.tb_bx[0][0] + d * (o.tb_bx[0][S::ND - 1] - o.tb_bx[0][0]),
+                           a.gx + ((size_t)d * a.NF + g0) * (F2 * S::N3), nvalid * F2, wave, lane);
+        __syncthreads();                                     // (the next tile's FFT overwrites A1, its encoder A0)
+    }
+}
+
+// ------------------------------------------------------------------------------------------ GRU scan over time
+// One workgroup = 16 (utterance, sub-band) rows of one direction; wave w owns the channel tiles w, w + 4, ... with the three
+// gates' hidden weights of those channels in registers for the whole scan.  Per step only h W_hh^T is computed (the x half,
+// gx, was batched over all frames): A = h_{t-1} from LDS (double-buffered: one barrier per step), r / z / n of a (row, channel)
+// land in the same lane, the gate math runs in the epilogue, h_t goes to LDS (next step's A operand), to the registers (next
+// step's z h term) and to hs in global memory.  gx of step t + 1 is fetched while step t computes.
+template <class S>
+__global__ void __launch_bounds__(kThreads) tb_scan_kernel(TbArgs a) {
+    constexpr int C2 = S::C2, F2 = S::F2, KS = S::KS_2, NT2 = S::NT2, LDX = S::LDX, N3 = S::N3;
+    constexpr int NTPW = ceil_div(NT2, kWaves);
+    constexpr int HW = S::ND * C2;                           // hs row width
+    constexpr PackedOffsets o = Pack<S>::v;
+    __shared__ float hbuf[2][16 * LDX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const WSrc<false> wb = make_wsrc<S>(a.wp, lane);
+    const int dir = blockIdx.y, k = a.k;
+    const int R = a.B * F2, r0 = blockIdx.x * 16;
+    const int w_off = o.tb_whh[0][0] + k * (S::KB > 1 ? o.tb_whh[1][0] - o.tb_whh[0][0] : 0) + dir * (o.tb_whh[0][S::ND - 1] - o.tb_whh[0][0]);
+    const int bn_off = o.tb_bhn[0][0] + k * (S::KB > 1 ? o.tb_bhn[1][0] - o.tb_bhn[0][0] : 0) + dir * (o.tb_bhn[0][S::ND - 1] - o.tb_bhn[0][0]);
+    // hidden weights: tile (gate g, channel tile ct) at (g * NT2 + ct) * KS fragments
+    float whh[NTPW][3][KS], bhn[NTPW];
+    bool live[NTPW];
+#pragma unroll
+    for (int j = 0; j < NTPW; ++j) {
+        const int ct = wave + 4 * j;
+        live[j] = ct < NT2;
+        const int ctc = live[j] ? ct : NT2 - 1;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) whh[j][g][ks] = wb.at_g(w_off + ((g * NT2 + ctc) * KS + ks) * 64);
+        bhn[j] = wb.at16_g(bn_off + ctc * 16);
+    }
+    // this lane's four rows (C/D layout: rows 4 lg + r) and columns 16 ct + li
+    size_t grow[4], hrow[4];       // element offsets of (row, t = 0) in gx / hs
+    bool rok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int row = r0 + 4 * lg + r;
+        rok[r] = row < R;
+        row = rok[r] ? row : R - 1;
+        const int b = row / F2, f = row - b * F2;
+        grow[r] = ((size_t)b * a.T * F2 + f) * N3;
+        hrow[r] = ((size_t)b * a.T * F2 + f) * HW + dir * C2;
+    }
+    const float* gxd = a.gx + (size_t)dir * a.NF * F2 * N3;
+    float* hst = a.hstate ? a.hstate + ((size_t)k * R) * C2 : nullptr;
+    float hprev[NTPW][4];
+#pragma unroll
+    for (int j = 0; j < NTPW; ++j) {
+        const int col = 16 * (wave + 4 * j) + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + 4 * lg + r;
+            float v = 0.0f;
+            if (hst != nullptr && live[j] && col < C2 && rok[r]) v = hst[(size_t)row * C2 + col];
+            hprev[j][r] = v;
+            if (live[j] && col < C2) hbuf[0][(4 * lg + r) * LDX + col] = v;
+        }
+    }
+    float gxv[NTPW][3][4];
+    auto load_gx = [&](int t) {
+        const size_t toff = (size_t)t * F2 * N3;
+#pragma unroll
+        for (int j = 0; j < NTPW; ++j) {
+            int col = 16 * (wave + 4 * j) + li;
+            col = (live[j] && col < C2) ? col : 0;
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gxv[j][g][r] = gxd[grow[r] + toff + g * C2 + col];
+        }
+    };
+    const int t_first = dir ? a.T - 1 : 0, dt = dir ? -1 : 1;
+    load_gx(t_first);
+    __syncthreads();
+    int cur = 0;
+#pragma unroll 1
+    for (int st = 0; st < a.T; ++st) {
+        const int t = t_first + st * dt;
+        const float* hc = hbuf[cur] + li * LDX + lg;
+        float av[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) av[ks] = hc[4 * ks];
+        float gcur[NTPW][3][4];
+#pragma unroll
+        for (int j = 0; j < NTPW; ++j)
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gcur[j][g][r] = gxv[j][g][r];
+        if (st + 1 < a.T) load_gx(t + dt);                   // next step's x half: in flight under this step's MFMAs
+        f32x4 acc[NTPW][3];
+#pragma unroll
+        for (int j = 0; j < NTPW; ++j) {
+            acc[j][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            acc[j][1] = acc[j][0];
+            acc[j][2] = f32x4{bhn[j], bhn[j], bhn[j], bhn[j]};
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < NTPW; ++j)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[j][g] = FE_MFMA(av[ks], whh[j][g][ks], acc[j][g]);
+        float* hn = hbuf[cur ^ 1];
+        const size_t toff = (size_t)t * F2 * HW;
+#pragma unroll
+        for (int j = 0; j < NTPW; ++j) {
+            const int col = 16 * (wave + 4 * j) + li;
+            const bool cok = live[j] && col < C2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float rr = sigmoid_f(gcur[j][0][r] + acc[j][0][r]);
+                const float zz = sigmoid_f(gcur[j][1][r] + acc[j][1][r]);
+                const float nn = tanh_f(gcur[j][2][r] + rr * acc[j][2][r]);
+                const float hv = (1.0f - zz) * nn + zz * hprev[j][r];
+                hprev[j][r] = hv;
+                if (cok) {
+                    hn[(4 * lg + r) * LDX + col] = hv;
+                    if (rok[r]) a.hs[hrow[r] + toff + col] = hv;
+                }
+            }
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (hst != nullptr) {
+#pragma unroll
+        for (int j = 0; j < NTPW; ++j) {
+            const int col = 16 * (wave + 4 * j) + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (live[j] && col < C2 && rok[r]) hst[(size_t)(r0 + 4 * lg + r) * C2 + col] = hprev[j][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ RNNFormer block segment
+template <class S, int FT>
+struct BlkLds {
+    using TT = TokTiling<S, FT>;
+    static constexpr int LDH = S::ND * S::C2 + 2;                  // GRU-output rows
+    static constexpr int X = 0;                                    // tokens [ROWS_P][LDX]
+    static constexpr int U = X + TT::ROWS_P * S::LDX;              // union: { HS [ROWS_P][LDH] }  |  { HL [ROWS_P][LDX], GI [ROWS_P][LDG] }
+    static constexpr int HS = U;
+    static constexpr int HL = U;
+    static constexpr int GI = HL + TT::ROWS_P * S::LDX;
+    static constexpr int cmax(int p, int q) { return p > q ? p : q; }
+    static constexpr int FULL = U + cmax(TT::ROWS_P * LDH, TT::ROWS_P * (S::LDX + S::LDG));
+    // per-head qkv (C2 = 128, 48 kHz L): the full [rows][3 C2] buffer does not fit; q | k | v of ONE head at a time ([rows][3 hd + 2])
+    static constexpr bool PERHEAD = (size_t)FULL * 4 > 160 * 1024;
+    static constexpr int LDGX = PERHEAD ? 3 * S::HD + 2 : S::LDG;
+    static constexpr int TOTAL = U + cmax(TT::ROWS_P * LDH, TT::ROWS_P * (S::LDX + LDGX));
+    static constexpr size_t BYTES = (size_t)TOTAL * 4;
+    static constexpr bool OK = BYTES <= 160 * 1024;
+};
+
+template <class S, int FT>
+__global__ void __launch_bounds__(kThreads) tb_blk_kernel(TbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using L = BlkLds<S, FT>;
+    using TT = TokTiling<S, FT>;
+    constexpr int C2 = S::C2, F2 = S::F2, LDX = S::LDX, LDH = L::LDH, LDG = L::LDGX, HD = S::HD, HW = S::ND * C2;
+    constexpr int MTT = TT::MTT, NTPW2 = ceil_div(S::NT2, kWaves), NTPW3 = ceil_div(S::NT3, kWaves);
+    constexpr PackedOffsets o = Pack<S>::v;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const WSrc<false> wb = make_wsrc<S>(a.wp, lane);
+    const int k = a.k, kb = k * o.blk_stride;
+    float* const Xb = smem + L::X;
+    float* const Hs = smem + L::HS;
+    float* const Hl = smem + L::HL;
+    float* const Gi = smem + L::GI;
+    const int ntiles = (a.NF + FT - 1) / FT;
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int g0 = tile * FT;
+        const int nvalid = a.NF - g0 < FT ? a.NF - g0 : FT;
+        const int rows_valid = nvalid * F2;
+        // ---- the tile's tokens and GRU outputs: contiguous rows in global memory, 16-byte loads (rows past the batch: clamped)
+        {
+            const float* xg = a.x + (size_t)g0 * (F2 * C2);
+            const float* hg = a.hs + (size_t)g0 * (F2 * HW);
+            constexpr int XQ = C2 / 4, HQ = HW / 4;
+            for (int i = tid; i < TT::ROWS * XQ; i += kThreads) {
+                const int row = i / XQ, c4 = i - row * XQ, rs = row < rows_valid ? row : rows_valid - 1;
+                const float4 v = *reinterpret_cast<const float4*>(xg + (size_t)rs * C2 + 4 * c4);
+                float2* d = reinterpret_cast<float2*>(Xb + row * LDX + 4 * c4);
+                d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
+            }
+            for (int i = tid; i < TT::ROWS * HQ; i += kThreads) {
+                const int row = i / HQ, c4 = i - row * HQ, rs = row < rows_valid ? row : rows_valid - 1;
+                const float4 v = *reinterpret_cast<const float4*>(hg + (size_t)rs * HW + 4 * c4);
+                float2* d = reinterpret_cast<float2*>(Hs + row * LDH + 4 * c4);
+                d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
+            }
+        }
+        __syncthreads();
+        // ---- x += rnn_fc(h) (+ pe in block 0)   (model.py:273-280; noncausal: K = 2 C2)
+        {
+            f32x4 acc[MTT][NTPW2];
+#pragma unroll
+            for (int j = 0; j < NTPW2; ++j) {
+                int nt = wave + 4 * j;
+                nt = nt < S::NT2 ? nt : S::NT2 - 1;
+                const float bj = wb.at16_g(o.blk_fc1_b[0] + kb + nt * 16);
+#pragma unroll
+                for (int i = 0; i < MTT; ++i) acc[i][j] = f32x4{bj, bj, bj, bj};
+            }
+            const int w_off = S::BIDIR ? o.tb_fc1_w[0] + k * (S::KB > 1 ? o.tb_fc1_w[1] - o.tb_fc1_w[0] : 0) : o.blk_fc1_w[0] + kb;
+            tok_panel<MTT, NTPW2, S::ND * S::KS_2, LDH>(acc, Hs + li * LDH + lg, wb, w_off, S::NT2, wave);
+#pragma unroll
+            for (int i = 0; i < MTT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTPW2; ++j) {
+                    const int nt = wave + 4 * j, col = 16 * nt + li;
+                    if (nt < S::NT2 && col < C2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * i + 4 * lg + r;
+                            float v = acc[i][j][r] + Xb[row * LDX + col];
+                            if (k == 0) v += wb.gather_g(o.blk_pe + (row % F2) * C2 + col);
+                            Xb[row * LDX + col] = v;
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+        // ---- qkv = x W_qkv^T (rows per head interleaved [h][q|k|v][hd], model.py:142-146) and the attention over the F2 tokens of
+        // each frame; O -> Hl[token][head * hd + d]
+        if constexpr (!L::PERHEAD) {
+            constexpr int CH = (MTT * NTPW3 <= 32) ? NTPW3 : (32 / MTT > 0 ? 32 / MTT : 1);
+#pragma unroll 1
+            for (int j0 = 0; j0 < NTPW3; j0 += CH) {
+                f32x4 acc[MTT][CH];
+                acc_init_zero<MTT, CH>(acc);
+                mma_panel<MTT, CH, S::KS_2, kPD>(
+                    acc, [&](int i, int ks) { return Xb[(16 * i + li) * LDX + lg + 4 * ks]; },
+                    [&](int j, int ks) {
+                        int nt = wave + 4 * (j0 + j);
+                        nt = nt < S::NT3 ? nt : S::NT3 - 1;
+                        return wb.at_g(o.blk_qkv[0] + kb + (nt * S::KS_2 + ks) * 64);
+                    }, NoSide{});
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int nt = wave + 4 * (j0 + j);
+                    if (nt < S::NT3) {
+#pragma unroll
+                        for (int i = 0; i < MTT; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) Gi[(16 * i + 4 * lg + r) * LDG + 16 * nt + li] = acc[i][j][r];
+                    }
+                }
+            }
+            __syncthreads();
+            // wave = head, frame after frame
+#pragma unroll 1
+            for (int f = 0; f < FT; ++f)
+                attention_head<S, S::MT2, LDG, kPD>(Gi + f * F2 * LDG, Hl + f * F2 * LDX, wave * 3 * HD, wave, 0, 1, lane);
+        } else {
+            // one head at a time, all four waves on it: its 3 hd qkv columns as (column tile, row tile) jobs -> Gi[row][3 hd + 2],
+            // then its attention with the (frame, query tile) pairs split over the waves
+#pragma unroll 1
+            for (int hh = 0; hh < S::NH; ++hh) {
+                // the head's 3 hd columns [c_lo, c_lo + 3 hd) of the packed qkv weight lie in column tiles t0 .. t0 + nth - 1
+                const int c_lo = 3 * HD * hh, t0 = c_lo / 16, nth = (c_lo + 3 * HD - 1) / 16 - t0 + 1;
+#pragma unroll 1
+                for (int q = wave; q < nth * MTT; q += kWaves) {
+                    const int ct = t0 + q % nth, m0 = q / nth;
+                    f32x4 acc[1][1];
+                    acc_init_zero<1, 1>(acc);
+                    const int wq = o.blk_qkv[0] + kb + (ct * S::KS_2) * 64;
+                    mma_panel<1, 1, S::KS_2, kPD>(
+                        acc, [&](int, int ks) { return Xb[(16 * m0 + li) * LDX + lg + 4 * ks]; },
+                        [&](int, int ks) { return wb.at_g(wq + ks * 64); }, NoSide{});
+                    const int cl = 16 * ct + li - c_lo;
+                    if (cl >= 0 && cl < 3 * HD) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Gi[(16 * m0 + 4 * lg + r) * LDG + cl] = acc[0][0][r];
+                    }
+                }
+                __syncthreads();
+                constexpr int NQW = ceil_div(S::MT2, kWaves);
+#pragma unroll 1
+                for (int f = 0; f < FT; ++f)
+                    attention_head<S, NQW, LDG, kPD>(Gi + f * F2 * LDG, Hl + f * F2 * LDX, 0, hh, wave, kWaves, lane);
+                __syncthreads();                             // (the next head overwrites Gi)
+            }
+        }
+        if constexpr (!L::PERHEAD) __syncthreads();
+        // ---- x += attn_fc(o)   (model.py:282-290) -> LDS and the token stream in global memory
+        {
+            f32x4 acc[MTT][NTPW2];
+#pragma unroll
+            for (int j = 0; j < NTPW2; ++j) {
+                int nt = wave + 4 * j;
+                nt = nt < S::NT2 ? nt : S::NT2 - 1;
+                const float bj = wb.at16_g(o.blk_fc2_b[0] + kb + nt * 16);
+#pragma unroll
+                for (int i = 0; i < MTT; ++i) acc[i][j] = f32x4{bj, bj, bj, bj};
+            }
+            tok_panel<MTT, NTPW2, S::KS_2, LDX>(acc, Hl + li * LDX + lg, wb, o.blk_fc2_w[0] + kb, S::NT2, wave);
+            float* xg = a.x + (size_t)g0 * (F2 * C2);
+#pragma unroll
+            for (int i = 0; i < MTT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTPW2; ++j) {
+                    const int nt = wave + 4 * j, col = 16 * nt + li;
+                    if (nt < S::NT2 && col < C2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * i + 4 * lg + r;
+                            const float v = acc[i][j][r] + Xb[row * LDX + col];
+                            Xb[row * LDX + col] = v;
+                            if (row < rows_valid) xg[(size_t)row * C2 + col] = v;
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+        // ---- the x half of the next block's GRU gates
+        if (k + 1 < S::KB) {
+            const int dw = o.tb_wih[0][S::ND - 1] - o.tb_wih[0][0], db = o.tb_bx[0][S::ND - 1] - o.tb_bx[0][0];
+            const int kw = (k + 1) * (S::KB > 1 ? o.tb_wih[1][0] - o.tb_wih[0][0] : 0), kbx = (k + 1) * (S::KB > 1 ? o.tb_bx[1][0] - o.tb_bx[0][0] : 0);
+#pragma unroll 1
+            for (int d = 0; d < S::ND; ++d)
+                gx_gemm<S, FT>(Xb, wb, o.tb_wih[0][0] + kw + d * dw, o.tb_bx[0][0] + kbx + d * db, a.gx + ((size_t)d * a.NF + g0) * (F2 * S::N3), rows_valid, wave, lane);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------ decoder segment
+template <class S, int FT>
+struct DecLds {
+    static constexpr int TW = 0;                                   // twiddles
+    static constexpr int WY = TW + S::NFFT;                        // [FT][ACT]: 1x1 outputs (its first rows hold the tokens X until the filterbank has run)
+    static constexpr int WX = WY + FT * S::ACT;                    // [FT][ACT]: k = 3 outputs (first Y2 = the filterbank output [FT][F1][LDX]; at the end the iDFT scratch)
+    static constexpr int PT = WX + FT * S::ACT;                    // transposed-conv partials [FT][F1][LDP]
+    static constexpr int TOTAL = PT + FT * S::F1 * S::LDP;
+    static constexpr size_t BYTES = (size_t)TOTAL * 4;
+    static constexpr bool OK = S::F2 * S::LDX <= S::ACT && S::F1 * S::LDX <= S::ACT && 4 * S::NFFT <= FT * S::ACT && BYTES <= 160 * 1024;
+};
+
+template <class S, int FT>
+__global__ void __launch_bounds__(kThreads) tb_dec_kernel(TbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using L = DecLds<S, FT>;
+    using CT = ConvTiling<S, FT>;
+    using D = Dft<S, kPD>;
+    constexpr int N = S::NFFT, F0 = S::F0, F1 = S::F1, C1 = S::C1, C2 = S::C2, F2 = S::F2;
+    constexpr int LDC = S::LDC, LDX = S::LDX;
+    constexpr PackedOffsets o = Pack<S>::v;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const WSrc<false> wb = make_wsrc<S>(a.wp, lane);
+    const int wm = CT::NS == kWaves ? 0 : wave / CT::NS;
+    float2* tw = reinterpret_cast<float2*>(smem + L::TW);
+    for (int i = tid; i < N / 2; i += kThreads) tw[i] = reinterpret_cast<const float2*>(a.wp + o.twiddle)[i];
+    float* const Wy = smem + L::WY;
+    float* const Wx = smem + L::WX;
+    float* const PT = smem + L::PT;
+    float* const Xb = Wy;             // tokens [FT F2][LDX], dense rows
+    float* const Y2 = Wx;             // filterbank output [FT][F1][LDX]
+    typename D::InvConst idc;
+    D::load(idc, wb, o, wave);
+    const int ntiles = (a.NF + FT - 1) / FT;
+    constexpr size_t SKF = (size_t)(S::NL + 1) * F1 * C1;
+    __syncthreads();
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int g0 = tile * FT;
+        const int nvalid = a.NF - g0 < FT ? a.NF - g0 : FT;
+        const int rows_valid = nvalid * F2;
+        {
+            const float* xg = a.x + (size_t)g0 * (F2 * C2);
+            constexpr int XQ = C2 / 4;
+            for (int i = tid; i < FT * F2 * XQ; i += kThreads) {
+                const int row = i / XQ, c4 = i - row * XQ, rs = row < rows_valid ? row : rows_valid - 1;
+                const float4 v = *reinterpret_cast<const float4*>(xg + (size_t)rs * C2 + 4 * c4);
+                float2* d = reinterpret_cast<float2*>(Xb + row * LDX + 4 * c4);
+                d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
+            }
+        }
+        __syncthreads();
+        // the tile's encoder outputs as a buffer resource (coalesced A-fragment reads)
+        WSrc<false> skb;
+        {
+            const int gl = g0 + FT <= a.NF ? FT : a.NF - g0;
+            skb.rsrc = __builtin_amdgcn_make_buffer_rsrc(a.skip + (size_t)g0 * SKF, 0, (int)(gl * SKF * 4), 0x00020000);
+            skb.lane4 = lane * 4; skb.li4 = (lane & 15) * 4; skb.lds = nullptr; skb.base = 0;
+        }
+        // ---- rf_post (model.py:485-490): Linear over the sub-band axis, A = packed [F1][F2], B = the frames' tokens side by side
+        {
+            constexpr int KS = F2 / 4;
+            f32x4 acc[S::MTPW][FT * S::NT2];
+            acc_init_zero<S::MTPW, FT * S::NT2>(acc);
+            mma_panel<S::MTPW, FT * S::NT2, KS, kPD>(
+                acc, [&](int i, int ks) { return wb.at_g(o.rfpost_lin + ((wave + 4 * i) * KS + ks) * 64); },
+                [&](int j, int ks) { return Xb[((j / S::NT2) * F2 + 4 * ks + lg) * LDX + 16 * (j % S::NT2) + li]; }, NoSide{});
+            __syncthreads();                                 // (Y2 does not overlap X, but Wy's halo rows - zeroed below - do)
+#pragma unroll
+            for (int i = 0; i < S::MTPW; ++i)
+#pragma unroll
+                for (int j = 0; j < FT * S::NT2; ++j) {
+                    const int col = 16 * (j % S::NT2) + li;
+                    if (col < C2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Y2[(j / S::NT2) * (F1 * LDX) + (16 * (wave + 4 * i) + 4 * lg + r) * LDX + col] = acc[i][j][r];
+                    }
+                }
+            for (int i = tid; i < FT * 2 * LDC; i += kThreads) {
+                const int f = i / (2 * LDC), q = i - f * (2 * LDC);
+                Wy[f * S::ACT + (q >= LDC ? (F1 + 1) * LDC + (q - LDC) : q)] = 0.0f;
+            }
+        }
+        __syncthreads();
+        // ---- decoder (model.py:492-506): 1x1 on cat([x, skip]) as two K segments (layer 0: x = Y2 with rf_post's 1x1 folded into
+        // the weights on the host, fe_api.hip), then the k = 3 conv
+        static_for<S::NL>([&](auto l_) {
+            constexpr int l = decltype(l_)::value;
+            constexpr int K0 = (l == 0) ? S::KS_2 : S::KS_C;
+            {
+                const float* x0 = (l == 0) ? Y2 + (16 * wm + li) * LDX + lg : Wx + (16 * wm + li + 1) * LDC + lg;
+                const int sk_off = (S::NL - l) * F1 * C1;
+                conv_gemm<S, FT, K0 + S::KS_C, true, C1, LDC, S::ACT, 1>(
+                    [&](int i, int ks) {
+                        const int f = CT::frame(i), mt0 = CT::mtile0(i);
+                        if (ks < K0) return (l == 0) ? x0[f * (F1 * LDX) + (16 * mt0) * LDX + 4 * ks] : x0[f * S::ACT + (16 * mt0) * LDC + 4 * ks];
+                        return skb.at_g(f * (int)SKF + sk_off + ((mt0 + wm) * S::KS_C + (ks - K0)) * 64);
+                    }, wb, o.dec1_w[l], o.dec1_b[l], Wy, nullptr, 0, nvalid, wave, lane);
+            }
+            __syncthreads();
+            conv_gemm<S, FT, 3 * S::KS_C, true, C1, LDC, S::ACT, 1>(K3Src<S, FT>{Wy + (16 * wm + li) * LDC + lg}, wb, o.dec3_w[l], o.dec3_b[l], Wx,
+                                                                     nullptr, 0, nvalid, wave, lane);
+            __syncthreads();
+        });
+        // ---- dec_post (model.py:508-521): 1x1 on cat([x, enc_pre output]), then the transposed conv as a [F1 x C1].[C1 x 16] GEMM
+        {
+            const float* x0 = Wx + (16 * wm + li + 1) * LDC + lg;
+            conv_gemm<S, FT, 2 * S::KS_C, true, C1, LDC, S::ACT, 1>(
+                [&](int i, int ks) {
+                    const int f = CT::frame(i), mt0 = CT::mtile0(i);
+                    if (ks < S::KS_C) return x0[f * S::ACT + (16 * mt0) * LDC + 4 * ks];
+                    return skb.at_g(f * (int)SKF + ((mt0 + wm) * S::KS_C + (ks - S::KS_C)) * 64);
+                }, wb, o.post1_w, o.post1_b, Wy, nullptr, 0, nvalid, wave, lane);
+        }
+        __syncthreads();
+        {
+            const float* x0 = Wy + (16 * wm + li + 1) * LDC + lg;
+            conv_gemm<S, FT, S::KS_C, false, 16, S::LDP, F1 * S::LDP, 0>(
+                [&](int i, int ks) { return x0[CT::frame(i) * S::ACT + (16 * CT::mtile0(i)) * LDC + 4 * ks]; }, wb, o.post_t_w, -1, PT, nullptr, 0, nvalid, wave, lane);
+        }
+        __syncthreads();
+        // ---- mask, un-compress (model.py:694-709), inverse DFT + synthesis window (functional/audio_modules.py:117-119), frame by frame
+        float* const q0 = Wx;
+        float* const q1 = Wx + N;
+        float* const q3 = Wx + 3 * N;
+        const float b0 = wb.scalar(o.post_t_b), b1 = wb.scalar(o.post_t_b + 1);
+#pragma unroll 1
+        for (int f = 0; f < nvalid; ++f) {
+            const int g = g0 + f, b = g / a.T, t = g - b * a.T;
+            const float* xcg = a.xc + (size_t)g * (2 * F0);
+            const float* PTf = PT + f * (F1 * S::LDP);
+            float* spo = a.mode == FE_MODE_SPEC ? a.spec_out + (size_t)b * (F0 + 1) * a.T * 2 : nullptr;
+            float* sph = a.mode == FE_MODE_OFFLINE ? a.spec_out + (size_t)b * F0 * a.T * 2 : nullptr;
+            for (int fb = tid; fb < F0; fb += kThreads) {
+                const int q = fb + 2, j1 = q & 3, i1 = q >> 2;
+                float m0 = b0, m1 = b1;
+                if (i1 < F1) { m0 += PTf[i1 * S::LDP + j1]; m1 += PTf[i1 * S::LDP + 8 + j1]; }
+                if (i1 >= 1) { m0 += PTf[(i1 - 1) * S::LDP + j1 + 4]; m1 += PTf[(i1 - 1) * S::LDP + 8 + j1 + 4]; }
+                const float xr = xcg[fb], xi = xcg[F0 + fb];
+                float yr = xr * m0 - xi * m1, yi = xr * m1 + xi * m0;
+                if (sph != nullptr) { sph[((size_t)fb * a.T + t) * 2] = yr; sph[((size_t)fb * a.T + t) * 2 + 1] = yi; }
+                const float mag = sqrtf(yr * yr + yi * yi);
+                const float gn = pow_f(mag, 1.0f / a.compression - 1.0f);
+                yr *= gn; yi *= gn;
+                if (spo != nullptr) {
+                    spo[((size_t)fb * a.T + t) * 2] = yr;
+                    spo[((size_t)fb * a.T + t) * 2 + 1] = yi;
+                    if (fb == 0) { spo[((size_t)F0 * a.T + t) * 2] = 0.0f; spo[((size_t)F0 * a.T + t) * 2 + 1] = 0.0f; }
+                } else {
+                    q3[fb] = yr;
+                    q3[N / 2 + fb] = yi;
+                }
+            }
+            if (a.mode != FE_MODE_SPEC) {
+                __syncthreads();
+                const float* wi = a.wp + o.window;
+                constexpr int NPT = N / kThreads;
+                float ow[NPT];
+#pragma unroll
+                for (int q = 0; q < NPT; ++q) ow[q] = wi[tid + q * kThreads];
+                D::inverse(q3, q0, q1, tw, idc, wb, o, wave, lane);       // (ends with a barrier)
+                float* fr = a.frames + (size_t)g * N;
+#pragma unroll
+                for (int q = 0; q < NPT; ++q) {
+                    const int n = tid + q * kThreads;
+                    const int pi = D::pidx(n & (D::N1 - 1), n / D::N1);
+                    fr[n] = (q0[pi] + q1[pi]) * ow[q];
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------ launch glue
+// frames per tile of a segment: 2 where the plan fits and the shape is small enough for the tile's accumulators
+template <template <class, int> class P, class S>
+constexpr int pick_ft() {
+    if constexpr (S::C1 <= 64 && P<S, 2>::OK) return 2;
+    else return 1;
+}
+
+template <class S>
+struct TbCfg {
+    static constexpr int FT_E = pick_ft<EncLds, S>(), FT_B = pick_ft<BlkLds, S>(), FT_D = pick_ft<DecLds, S>();
+    static_assert(EncLds<S, FT_E>::OK && BlkLds<S, FT_B>::OK && DecLds<S, FT_D>::OK, "time-batched engine: an LDS plan does not fit");
+};
+
+enum { TB_ENC = 0, TB_SCAN = 1, TB_BLK = 2, TB_DEC = 3 };
+
+struct TbImpl {
+    int ft[4];                  // frames per tile of the stage (scan: 0)
+    size_t lds[4];              // dynamic LDS bytes
+    void (*launch)(int stage, const TbArgs&, int max_wgs, hipStream_t, hipError_t*);
+};
+
+template <class K>
+inline void set_lds(K* kern, size_t bytes, hipError_t* err) {
+    static std::atomic<bool> done[kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    if (!done[dev].load(std::memory_order_relaxed)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) { *err = e; return; }
+        done[dev].store(true, std::memory_order_relaxed);
+    }
+}
+
+// persistent grids: as many workgroups as fit on the chip at once (LDS-limited), each walking tiles blockIdx.x, + gridDim.x, ...
+template <class S>
+void tb_launch(int stage, const TbArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
+    using C = TbCfg<S>;
+    *err = hipSuccess;
+    auto grid_for = [&](int ft, size_t lds) {
+        const int ntiles = (a.NF + ft - 1) / ft;
+        int per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
+        per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+        const int slots = max_wgs * per_cu;
+        return ntiles < slots ? ntiles : slots;
+    };
+    if (stage == TB_ENC) {
+        auto* k = &tb_enc_kernel<S, C::FT_E>;
+        constexpr size_t lds = EncLds<S, C::FT_E>::BYTES;
+        set_lds(k, lds, err);
+        if (*err != hipSuccess) return;
+        hipLaunchKernelGGL(k, dim3(grid_for(C::FT_E, lds)), dim3(kThreads), lds, st, a);
+    } else if (stage == TB_SCAN) {
+        hipLaunchKernelGGL((tb_scan_kernel<S>), dim3((a.B * S::F2 + 15) / 16, S::ND), dim3(kThreads), 0, st, a);
+    } else if (stage == TB_BLK) {
+        auto* k = &tb_blk_kernel<S, C::FT_B>;
+        constexpr size_t lds = BlkLds<S, C::FT_B>::BYTES;
+        set_lds(k, lds, err);
+        if (*err != hipSuccess) return;
+        hipLaunchKernelGGL(k, dim3(grid_for(C::FT_B, lds)), dim3(kThreads), lds, st, a);
+    } else {
+        auto* k = &tb_dec_kernel<S, C::FT_D>;
+        constexpr size_t lds = DecLds<S, C::FT_D>::BYTES;
+        set_lds(k, lds, err);
+        if (*err != hipSuccess) return;
+        hipLaunchKernelGGL(k, dim3(grid_for(C::FT_D, lds)), dim3(kThreads), lds, st, a);
+    }
+    *err = hipGetLastError();
+}
+
+template <class S>
+TbImpl make_tb_impl() {
+    using C = TbCfg<S>;
+    return TbImpl{{C::FT_E, 0, C::FT_B, C::FT_D}, {EncLds<S, C::FT_E>::BYTES, 0, BlkLds<S, C::FT_B>::BYTES, DecLds<S, C::FT_D>::BYTES}, &tb_launch<S>};
+}
+
+}  // namespace tb
+}  // namespace fe

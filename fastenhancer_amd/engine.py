@@ -71,6 +71,7 @@ class Engine:
             c.lookbehind = cfg.lookbehind
             c.ln = 1 if cfg.ln else 0
             c.rf_eps = cfg.rf_eps
+            c.bidirectional = 1 if getattr(cfg, "noncausal", False) else 0
         self._h = c_void_p()
         if self.device is not None and self.device.type == "cuda":
             with torch.cuda.device(self.device):
@@ -239,6 +240,11 @@ class Engine:
                                         wav_out.stride(0) if B > 1 else T * H, B, T, _stream(self.device)), "fe_step")
         return wav_out
 
+    def set_offline_engine(self, engine: str):
+        """fe_set_offline_engine: "auto" | "frame_walk" | "time_batched" (the layer-by-layer engine of csrc/tb_kernels.hip.h)"""
+        code = {"auto": _lib.FE_OFFLINE_AUTO, "frame_walk": _lib.FE_OFFLINE_FRAME_WALK, "time_batched": _lib.FE_OFFLINE_TIME_BATCHED}[engine]
+        _lib.check(self.lib.fe_set_offline_engine(self._h, code), "fe_set_offline_engine")
+
     def set_time_pipeline(self, frames_in_flight: int):
         """fe_set_time_pipeline: workgroups per stream in offline / spec launches with T >= 4 (0 = one workgroup per stream)."""
         _lib.check(self.lib.fe_set_time_pipeline(self._h, int(frames_in_flight)), "fe_set_time_pipeline")
@@ -271,6 +277,7 @@ class Engine:
         wav = torch.empty(B, cfg.hop_size * (T - 1), dtype=torch.float32, device=noisy.device)
         spec = torch.empty(B, cfg.F0 + (1 if (self.is_bsrnn or self.is_fspen or self.is_lisennet) else 0), T, 2, dtype=torch.float32, device=noisy.device)
         work = torch.empty(int(self.lib.fe_offline_work_floats(self._h, B, Tw)), dtype=torch.float32, device=noisy.device)
+        self._last_work = work          # (tools/gpu_tb_check.py looks at the time-batched engine's intermediate buffers)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.fe_offline(self._h, _ptr(noisy), B, Tw, _ptr(wav), _ptr(spec), _ptr(work), _stream(self.device)),
                        "fe_offline")

@@ -98,14 +98,15 @@ def fold_state_dict(sd: Mapping[str, Tensor], cfg: FEConfig) -> Dict[str, Tensor
             out[p + "time_attn.qkv.weight"] = (_weight_norm(sd[g], sd[p + "time_attn.qkv.parametrizations.weight.original1"]) if g in sd
                                                else sd[p + "time_attn.qkv.weight"])
         else:
-            for name in ("weight_ih_l0", "weight_hh_l0"):
-                g = p + f"rnn.parametrizations.{name}.original0"
-                if g in sd:
-                    out[p + "rnn." + name] = _weight_norm(sd[g], sd[p + f"rnn.parametrizations.{name}.original1"])
-                else:
-                    out[p + "rnn." + name] = sd[p + "rnn." + name]
-            out[p + "rnn.bias_ih_l0"] = sd[p + "rnn.bias_ih_l0"]
-            out[p + "rnn.bias_hh_l0"] = sd[p + "rnn.bias_hh_l0"]
+            for sfx in ("", "_reverse") if cfg.noncausal else ("",):      # noncausal/model.py:215-222: both directions
+                for name in ("weight_ih_l0" + sfx, "weight_hh_l0" + sfx):
+                    g = p + f"rnn.parametrizations.{name}.original0"
+                    if g in sd:
+                        out[p + "rnn." + name] = _weight_norm(sd[g], sd[p + f"rnn.parametrizations.{name}.original1"])
+                    else:
+                        out[p + "rnn." + name] = sd[p + "rnn." + name]
+                out[p + "rnn.bias_ih_l0" + sfx] = sd[p + "rnn.bias_ih_l0" + sfx]
+                out[p + "rnn.bias_hh_l0" + sfx] = sd[p + "rnn.bias_hh_l0" + sfx]
         if cfg.dprnn:      # DPRNN.remove_weight_reparameterizations, dprnn/model.py:172-192
             for name in ("weight_ih_l0", "weight_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse"):
                 g = p + f"frnn.parametrizations.{name}.original0"
@@ -225,11 +226,12 @@ def expected_fused_shapes(cfg: FEConfig) -> Dict[str, tuple]:
         if cfg.dpt:
             s[p + "time_attn.qkv.weight"] = (3 * C2, C2)
         else:
-            s[p + "rnn.weight_ih_l0"] = (3 * C2, C2)
-            s[p + "rnn.weight_hh_l0"] = (3 * C2, C2)
-            s[p + "rnn.bias_ih_l0"] = (3 * C2,)
-            s[p + "rnn.bias_hh_l0"] = (3 * C2,)
-        s[p + "rnn_fc.weight"] = (C2, C2)
+            for sfx in ("", "_reverse") if cfg.noncausal else ("",):
+                s[p + "rnn.weight_ih_l0" + sfx] = (3 * C2, C2)
+                s[p + "rnn.weight_hh_l0" + sfx] = (3 * C2, C2)
+                s[p + "rnn.bias_ih_l0" + sfx] = (3 * C2,)
+                s[p + "rnn.bias_hh_l0" + sfx] = (3 * C2,)
+        s[p + "rnn_fc.weight"] = (C2, 2 * C2 if cfg.noncausal else C2)
         s[p + "rnn_fc.bias"] = (C2,)
         if cfg.dprnn:
             H = cfg.channels_frnn
@@ -328,7 +330,7 @@ def default_state_dict(cfg: FEConfig, generator: Optional[torch.Generator] = Non
     g = generator
     shapes = expected_fused_shapes(cfg)
     sd: Dict[str, Tensor] = {}
-    fb = linear_filterbank_time_kernel if cfg.time_kernel or cfg.dprnn or cfg.dpt or cfg.ln else linear_filterbank
+    fb = linear_filterbank_time_kernel if cfg.time_kernel or cfg.dprnn or cfg.dpt or cfg.ln or cfg.noncausal else linear_filterbank
     pre, post = (fb(cfg.F1, cfg.rf_freq) if (cfg.pre_post_init or "").startswith("linear") else (None, None))
     for k, shp in shapes.items():
         fan_in = 1

@@ -15,7 +15,9 @@
  * Ownership: the caller allocates and frees every device buffer.  The handle owns only its packed
  * copy of the weights and constant tables.  All compute entry points are asynchronous on the given
  * stream and return FE_OK or a negative code; fe_last_error() gives the text (thread-local).
- * A handle is bound to the device that was current at fe_create(); it is not thread-safe.
+ * A handle is bound to the device that was current at fe_create(); it is not thread-safe, and its launches must be
+ * stream-ordered: the handle owns per-workgroup scratch and frame counters, so two compute calls on the same handle may
+ * not run concurrently on different HIP streams (use one handle per stream).
  */
 #ifndef FASTENHANCER_HIP_H
 #define FASTENHANCER_HIP_H
@@ -83,6 +85,11 @@ typedef struct fe_config {
                                       * (convs with their own biases, <conv>.1 / .2 / .4 and rnn_post_norm / attn_post_norm weight + bias),
                                       * the final conv as dec_post.2 with its scale folded in.  State as the default model */
     float rf_eps;                    /* ln: eps of the blocks' LayerNorms (rnnformer_kwargs.eps; 0 -> 1e-5) */
+    int bidirectional;               /* `model: fastenhancer.noncausal` (models/fastenhancer/noncausal/model.py:186-187; configs/fastenhancer_dns/huge_noncausal*.yaml,
+                                      * configs/fastenhancer_48khz/huge_noncausal.yaml): 1 = the blocks' time GRU is bidirectional and rnn_fc maps
+                                      * 2 C2 -> C2.  Weight sections: + rf_block.k.rnn.{weight,bias}_{ih,hh}_l0_reverse, rnn_fc.weight [C2, 2 C2].
+                                      * The reference module has the offline `Model` only (:348, :628-635): fe_offline is the one compute entry
+                                      * point (no caches: fe_state_floats = the two STFT caches, fe_step / fe_spec_step return FE_ERR_UNSUPPORTED_CONFIG) */
 } fe_config;
 
 typedef struct fe_handle fe_handle;
@@ -133,6 +140,19 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
  * frames).  Negative (the default) = a width chosen from the model size (8 .. 64); 0 or 1 = off (one workgroup walks the
  * T frames of a stream).  Results agree to fp32 rounding. */
 int fe_set_time_pipeline(fe_handle* h, int frames_in_flight);
+
+/* Engine of fe_offline for the default and noncausal FastEnhancer models:
+ *   FE_OFFLINE_TIME_BATCHED (the default where compiled; the only engine of the noncausal model): the network is cut at the
+ *     blocks' time GRUs and every piece runs over ALL frames of ALL utterances, layer by layer, as the reference's own offline
+ *     forward does (model.py:620-675): encoder pass (tiles of frames as one GEMM per layer), per block a scan over time in
+ *     which only W_hh h is serial (the x half of the gates is batched) + a batched attention pass, decoder pass, overlap-add
+ *     (csrc/tb_kernels.hip.h).  Activations that cross a GRU live in work_dev.
+ *   FE_OFFLINE_FRAME_WALK: the per-hop kernel walking (or, fe_set_time_pipeline, pipelining) the frames of each utterance.
+ * Results agree to fp32 rounding.  The other architectures / variants always walk. */
+#define FE_OFFLINE_AUTO 0
+#define FE_OFFLINE_FRAME_WALK 1
+#define FE_OFFLINE_TIME_BATCHED 2
+int fe_set_offline_engine(fe_handle* h, int engine);
 
 /* Offline wav->wav, Model.forward (model.py:728-735) with CompressedSTFT
  * (functional/audio_modules.py:70-164): noisy [B, Tw] -> wav_hat [B, H*(Tw/H)], spec_hat [B, N/2, T, 2],

@@ -124,6 +124,9 @@ def product_config(name):
     if MODEL_MODULE[name] == "fastenhancer.ln":
         from fastenhancer_amd.config import ln_config
         return ln_config(**kw)
+    if MODEL_MODULE[name] == "fastenhancer.noncausal":
+        from fastenhancer_amd.config import noncausal_config
+        return noncausal_config(**kw)
     return time_kernel_config(**kw) if MODEL_MODULE[name] == "fastenhancer.time_kernel" else PCfg.from_model_kwargs(**kw)
 
 

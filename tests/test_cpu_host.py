@@ -28,7 +28,8 @@ def test_library_exports_every_declared_symbol():
 
 
 @pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m", "fe48_l", "fe48_b_h480", "fe_tk_b",
-                                  "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_s", "fe_dprnn_m", "fe_dprnn_l", "fe_dpt_t", "fe_dpt_b", "fe_dpt_s", "fe_dpt_m", "fe_ln_b"])
+                                  "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_s", "fe_dprnn_m", "fe_dprnn_l", "fe_dpt_t", "fe_dpt_b", "fe_dpt_s", "fe_dpt_m", "fe_ln_b",
+                                  "fe_nc", "fe_nc24", "fe48_nc"])
 def test_section_table_matches_fused_schema(name):
     cfg = product_config(name)
     eng = Engine(cfg, None)
@@ -63,6 +64,50 @@ def test_unsupported_shapes_are_rejected_with_a_message():
     assert b"even" in lib.fe_last_error()
 
 
+def test_every_shipped_yaml_constructs_a_mirror_and_a_kernel():
+    """all 41 configs/**/*.yaml of the reference (tests/golden/yaml_kwargs.json, dumped by tools/dump_yaml_kwargs.py): the module named by
+    the yaml's `model:` key exists under fastenhancer_amd.models, its class takes the yaml's model_kwargs verbatim, and fe_create
+    finds a compiled kernel for the shape (the reject list is empty)."""
+    import importlib
+    from common import YAML_KWARGS
+    assert len(YAML_KWARGS) == 41
+    rejected = []
+    for path, y in sorted(YAML_KWARGS.items()):
+        mod = importlib.import_module(f"fastenhancer_amd.models.{y['model']}.model")
+        for cls in ("Model", "ONNXModel"):
+            if y["model"] == "fastenhancer.noncausal" and cls == "ONNXModel":
+                assert not hasattr(mod, cls)            # the reference module defines the offline Model only
+                continue
+            m = getattr(mod, cls)(**y["model_kwargs"])
+            try:
+                Engine(m.cfg, None)                     # fe_create: a kernel is compiled for this shape (no GPU needed)
+            except _lib.FEError as e:
+                rejected.append((path, cls, str(e)))
+    assert rejected == []
+
+
+def test_noncausal_host_side_without_gpu():
+    """model: fastenhancer.noncausal - sections (both GRU directions, rnn_fc over 2 C2), no model caches, FLOPs, loud failure without a GPU"""
+    import importlib
+    from common import MODEL_MODULE
+    kw = MODEL_KWARGS["fe_nc"][0]
+    mod = importlib.import_module(f"fastenhancer_amd.models.{MODEL_MODULE['fe_nc']}.model")
+    m = mod.Model(**kw)
+    cfg = m.cfg
+    assert cfg.noncausal and cfg.rf_channels == 128 and cfg.rf_blocks == 6
+    eng = Engine(cfg, None)
+    names = [s[0] for s in eng.sections]
+    assert "rf_block.5.rnn.weight_hh_l0_reverse" in names and "rf_block.0.rnn.bias_ih_l0_reverse" in names
+    assert dict((s[0], s[2]) for s in eng.sections)["rf_block.0.rnn_fc.weight"] == 128 * 256
+    assert eng.state_floats(3) == 3 * 2 * cfg.cache_len            # the two STFT caches only: the model has none
+    cfg_o = build_oracle("fe_nc")[0]
+    assert eng.flops_per_frame == pytest.approx(cfg_o.flops_per_frame())
+    _, sd, _, _ = build_oracle("fe_nc")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    with pytest.raises(_lib.FEError, match="GPU"):
+        m(torch.zeros(1, 4000))
+
+
 def test_config_rejects_what_the_reference_rejects():
     kw = dict(MODEL_KWARGS["fe_b"][0])
     with pytest.raises(AssertionError):
@@ -73,7 +118,7 @@ def test_config_rejects_what_the_reference_rejects():
         FEConfig.from_model_kwargs(**{**kw, "mask": "softmax"})
 
 
-@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_l", "fe48_b", "fe_tk_b", "fe_dprnn_b", "fe_dpt_b", "fe_ln_b"])
+@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_l", "fe48_b", "fe_tk_b", "fe_dprnn_b", "fe_dpt_b", "fe_ln_b", "fe_nc", "fe48_nc"])
 def test_host_fold_matches_oracle_fold(name):
     cfg_o, sd, fused_o, _ = build_oracle(name)
     cfg = product_config(name)

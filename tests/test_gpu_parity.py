@@ -18,7 +18,10 @@ pytestmark = pytest.mark.gpu
 ABS_TOL = 1e-4
 REL_TOL = 1e-4
 GPU_SHAPES = ["fe_t", "fe_b", "fe_m", "fe_l", "fe48_b", "fe48_l", "fe48_b_h480", "fe_tk_b", "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_l",
-              "fe_dpt_t", "fe_dpt_b", "fe_dpt_m", "fe_ln_b"]          # shapes with reference goldens
+              "fe_dpt_t", "fe_dpt_b", "fe_dpt_m", "fe_ln_b",
+              "fe_s", "fe48_t", "fe48_s", "fe48_m", "fe_dprnn_s", "fe_dprnn_m", "fe_dpt_s"]          # shapes with reference goldens (r3: every shipped shape)
+NONCAUSAL = ["fe_nc", "fe_nc24", "fe48_nc"]           # model: fastenhancer.noncausal (offline Model only; time-batched engine)
+TB_SHAPES = ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m", "fe48_l", "fe48_b_h480"]      # default model: both offline engines
 ALL_SHAPES = ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m", "fe48_l", "fe48_b_h480", "fe_tk_b",
               "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_s", "fe_dprnn_m", "fe_dprnn_l", "fe_dpt_t", "fe_dpt_b", "fe_dpt_s", "fe_dpt_m", "fe_ln_b"]
 
@@ -482,6 +485,8 @@ def test_time_pipelined_offline_and_spec_agree_with_the_serial_walk(name):
     both must match the oracle on a long utterance (many state hand-offs, every workgroup several frames)."""
     m, orc, cfg, sr, seed = _model(name, "Model")
     eng = m.engine
+    if name in TB_SHAPES:
+        eng.set_offline_engine("frame_walk")          # (the default offline engine of these shapes is the time-batched one)
     H = cfg.hop_size
     x = make_input(2, 150 * H + 29, 606, sr)
     xd = torch.from_numpy(x).to(_dev())
@@ -522,7 +527,117 @@ def test_time_pipelined_offline_and_spec_agree_with_the_serial_walk(name):
             _assert_close(a_.cpu().numpy(), b_, f"spec chunk caches, pipeline {width}")
 
 
-@pytest.mark.parametrize("name", ["fe_s", "fe48_t", "fe48_s", "fe48_m", "fe_dprnn_s", "fe_dprnn_m", "fe_dpt_s"])
+@pytest.mark.parametrize("name", TB_SHAPES)
+def test_time_batched_offline_matches_oracle_and_the_frame_walk(name):
+    """fe_offline's two engines on the default model: the time-batched (layer-by-layer) one - encoder pass over all frames, per
+    block a scan over time + an attention pass, decoder pass - and the per-hop kernel walking the frames.  Both against the oracle
+    on utterances long enough for many scan steps, with a frame count (B * T = 3 * 62) that leaves a partial tile of frames."""
+    m, orc, cfg, sr, seed = _model(name, "Model")
+    eng = m.engine
+    H = cfg.hop_size
+    big = cfg.channels >= 96
+    B, T1 = (2, 23) if big else (3, 61)
+    x = make_input(B, T1 * H + 17, 707, sr)
+    xd = torch.from_numpy(x).to(_dev())
+    wav_ref, spec_ref = orc.offline_forward(x)
+    eng.set_offline_engine("time_batched")
+    wav_tb, spec_tb = m(xd)
+    wav_tb2, spec_tb2 = m(xd)
+    assert torch.equal(wav_tb, wav_tb2) and torch.equal(spec_tb, spec_tb2), "time-batched launch is not deterministic"
+    eng.set_offline_engine("frame_walk")
+    wav_fw, spec_fw = m(xd)
+    eng.set_offline_engine("auto")
+    _assert_close(wav_tb.cpu().numpy(), wav_ref, "time-batched offline wav")
+    _assert_close(spec_tb.cpu().numpy(), spec_ref, "time-batched offline spec")
+    _assert_close(wav_fw.cpu().numpy(), wav_ref, "frame-walk offline wav")
+    assert float((wav_tb - wav_fw).abs().max()) <= 3e-5 * max(1.0, float(wav_fw.abs().max()))
+    # one utterance alone == the same utterance inside the batch (frames of different utterances share tiles and scan workgroups)
+    w1, s1 = m(xd[1:2].contiguous())
+    assert float((w1 - wav_tb[1:2]).abs().max()) == 0.0 and float((s1 - spec_tb[1:2]).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", NONCAUSAL)
+def test_noncausal_model_forward_matches_reference_golden(name):
+    """SURVEY.md §8(f) rank 4, models/fastenhancer/noncausal/model.py:628-635: Model.forward(noisy) of the three huge_noncausal yamls
+    (bidirectional GRU over time) vs the reference's own output."""
+    g = load_golden(name)
+    m, orc, cfg, sr, seed = _model(name, "Model")
+    B, H = int(g["B"]), cfg.hop_size
+    x = torch.from_numpy(make_input(B, int(g["hops"]) * H + 37, seed + 2000, sr)).to(_dev())
+    wav_hat, spec_hat = m(x)
+    assert tuple(wav_hat.shape) == g["offline_wav"].shape and tuple(spec_hat.shape) == g["offline_spec"].shape
+    _assert_close(wav_hat.cpu().numpy(), g["offline_wav"], "offline wav")
+    _assert_close(spec_hat.cpu().numpy(), g["offline_spec"], "offline spec")
+    wav3, _ = m(x.unsqueeze(1))                       # [B, 1, Tw] input form
+    assert torch.equal(wav3, wav_hat)
+
+
+@pytest.mark.parametrize("name", ["fe_nc", "fe48_nc"])
+def test_noncausal_longer_batch_matches_oracle(name):
+    """more frames than any tile or scan chunk, three utterances (rows of different utterances share scan workgroups), and the
+    reverse direction really matters: truncating the input changes the EARLIER output"""
+    m, orc, cfg, sr, seed = _model(name, "Model")
+    H = cfg.hop_size
+    x = make_input(3, 45 * H + 5, 808, sr)
+    wav_ref, spec_ref = orc.offline_forward(x)
+    xd = torch.from_numpy(x).to(_dev())
+    wav_hat, spec_hat = m(xd)
+    _assert_close(wav_hat.cpu().numpy(), wav_ref, "noncausal offline wav")
+    _assert_close(spec_hat.cpu().numpy(), spec_ref, "noncausal offline spec")
+    w1, s1 = m(xd[2:3].contiguous())
+    assert float((w1 - wav_hat[2:3]).abs().max()) == 0.0
+    w_short, _ = m(xd[:, :30 * H + 5].contiguous())
+    assert float((w_short[:, :10 * H] - wav_hat[:, :10 * H]).abs().max()) > 1e-4, "the future does not reach the past: not bidirectional"
+
+
+def test_noncausal_surface_and_errors():
+    """the reference module has the offline Model only: no ONNXModel, no caches, no streaming / spec step"""
+    import importlib
+    from fastenhancer_amd import _lib
+    mod = importlib.import_module("fastenhancer_amd.models.fastenhancer.noncausal.model")
+    assert hasattr(mod, "Model") and not hasattr(mod, "ONNXModel")
+    m, orc, cfg, sr, seed = _model("fe_nc", "Model")
+    eng = m.engine
+    with pytest.raises(AttributeError):
+        m.initialize_cache(torch.zeros(1, 100))
+    with pytest.raises(_lib.FEError, match="noncausal"):
+        eng.step(torch.zeros(1, cfg.hop_size, device=_dev()), eng.new_state(1))
+    with pytest.raises(_lib.FEError, match="time-batched engine only"):
+        eng.set_offline_engine("frame_walk")
+    with pytest.raises(_lib.FEError, match="reflect padding"):
+        m(torch.zeros(1, 100, device=_dev()))
+
+
+def test_streaming_model_on_an_index_less_cuda_device():
+    """`.cuda()` / 'cuda' store torch.device('cuda') (no index) while tensors report cuda:0 - the state buffers must
+    not be re-allocated (and, dptransformer, the K / V rings not be lost) on every call"""
+    from fastenhancer_amd.streaming import StreamingModel
+    for name in ("fe_b", "fe_dpt_t"):
+        kw, sr, seed = MODEL_KWARGS[name]
+        cfg, sd, fused, orc = build_oracle(name)
+        mod = importlib.import_module(f"fastenhancer_amd.models.{MODEL_MODULE[name]}.model")
+        m = mod.ONNXModel(**kw).cuda().eval()
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        M = StreamingModel(m)
+        B, hops, H = 2, 8, cfg.hop_size
+        x = make_input(B, hops * H, 909, sr)
+        xd = torch.from_numpy(x).to("cuda")
+        caches = M.initialize_cache(xd)
+        buf0 = M._buf[0]
+        ref_c = orc.initialize_cache(B)
+        for t in range(hops):
+            wav_out, *caches = M(xd[:, t * H:(t + 1) * H], *caches)
+            ref_o, *ref_c = orc.step(x[:, t * H:(t + 1) * H], *ref_c)
+            _assert_close(wav_out.cpu().numpy(), ref_o, f"{name} hop {t}")
+        assert M._buf[0] is buf0, "the state buffers were re-allocated between calls"
+        # a second initialize_cache hands out FRESH buffers: the first session's caches keep their values
+        snap = [c.clone() for c in caches]
+        caches2 = M.initialize_cache(xd)
+        assert all(float(c.abs().max()) == 0.0 for c in caches2)
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(snap, caches))
+
+
+@pytest.mark.parametrize("name", ["fe_dprnn_s", "fe_dprnn_m", "fe_dpt_s"])
 def test_offline_matches_oracle(name):
     m, orc, cfg, sr, seed = _model(name, "Model")
     H = cfg.hop_size
