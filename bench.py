@@ -75,6 +75,12 @@ WORKLOADS = {
     "fe_dpt_b": dict(C1=48, ks=(8, 3, 3), dpt=31, C2=36, F2=24, K=3, N=512, H=256, sr=16000, init="linear_fixed", desc="FastEnhancer_B, dual-path transformer blocks"),
     "fe_dpt_s": dict(C1=64, ks=(8, 3, 3, 3), dpt=31, C2=48, F2=36, K=3, N=512, H=256, sr=16000, init="linear_fixed", desc="FastEnhancer_S, dual-path transformer blocks"),
     "fe_dpt_m": dict(C1=96, ks=(8, 3, 3, 3), dpt=31, C2=72, F2=48, K=4, N=512, H=160, sr=16000, init="linear_fixed", desc="FastEnhancer_M, dual-path transformer blocks"),
+    # model: fastenhancer.noncausal (configs/fastenhancer_dns/huge_noncausal.yaml, configs/fastenhancer_48khz/huge_noncausal.yaml): bidirectional
+    # GRU over time, offline Model.forward only (--offline-seconds is implied), time-batched engine
+    "fe_nc": dict(C1=128, ks=(8, 3, 3, 3, 3, 3), nc=True, C2=128, F2=64, K=6, N=512, H=100, sr=16000, init="linear_fixed",
+                  desc="FastEnhancer huge noncausal 16kHz"),
+    "fe48_nc": dict(C1=128, ks=(8, 3, 3, 3, 3, 3), nc=True, C2=128, F2=64, K=6, N=1024, H=200, sr=48000, init="linear",
+                    desc="FastEnhancer huge noncausal 48kHz"),
     "fe_ln_b": dict(C1=48, ks=(8, 3, 3), ln=True, C2=36, F2=24, K=3, N=512, H=256, sr=16000, init="linear_fixed",
                     desc="FastEnhancer_B with GroupNorm / LayerNorm (configs/ablation/ln_b.yaml)"),
     "fe_dprnn_s": dict(C1=64, ks=(8, 3, 3, 3), frnn=24, C2=48, F2=36, K=3, N=512, H=256, sr=16000, init="linear_fixed", desc="FastEnhancer_S, dprnn blocks"),
@@ -98,6 +104,8 @@ def model_kwargs(w):
         kw = model_kwargs({k: v for k, v in w.items() if k != "ln"})
         kw.update(final_scale=True, final_scale_init="one")
         return kw
+    if w.get("nc"):
+        return model_kwargs({k: v for k, v in w.items() if k != "nc"})
     if w.get("dpt"):
         kw = model_kwargs({k: v for k, v in w.items() if k != "dpt"})
         rk = kw.pop("rnnformer_kwargs")
@@ -268,6 +276,28 @@ def cpu_baseline_bsrnn(workload: str, kw: dict, sr: int, B: int, budget_s: float
                       f"core (BLAS limited to 1 thread{'' if threadpool_limits else ' - threadpoolctl missing, not enforced'})"}
 
 
+def cpu_baseline_offline_numpy(kw: dict, sr: int, budget_s: float):
+    """The numpy oracle's offline Model.forward (oracle/fe_oracle.py, pinned on the reference's golden vectors) of the noncausal model,
+    on the host cores numpy's BLAS uses, on a bounded sample: one utterance whose length is doubled until a call takes a few seconds."""
+    from oracle.fe_oracle import FEConfig as OCfg, FEOracle, fold_state_dict
+    from oracle.weightgen import make_input, make_training_state_dict
+    cfg = OCfg.from_model_kwargs(kw, variant="noncausal")
+    orc = FEOracle(cfg, fold_state_dict(make_training_state_dict(cfg, 2), cfg))
+    secs, best = 0.25, None
+    t_all = time.perf_counter()
+    while True:
+        x = make_input(1, int(secs * sr), 1236, sr)
+        t0 = time.perf_counter()
+        orc.offline_forward(x)
+        dt = time.perf_counter() - t0
+        best = ((1 + x.shape[1] // cfg.hop_size) / dt, secs, dt)
+        if dt > budget_s / 4 or time.perf_counter() - t_all > budget_s / 2:
+            break
+        secs *= 2
+    return {"value": best[0], "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"numpy oracle (oracle/fe_oracle.py::offline_forward, BLAS threads as configured), one utterance of {best[1]:g} s in {best[2]:.2f} s"}
+
+
 def measured_traffic(workload: str, B: int, T: int):
     """HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE), if one
     exists for exactly this configuration; None otherwise."""
@@ -290,6 +320,8 @@ def spawn_ranks(n: int) -> int:
     import socket
     import subprocess
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if "--cpu-dry-run" in sys.argv:
+        have = n                                      # (no devices involved)
     if have < n:
         print(f"bench.py: --gpus {n} needs {n} visible MI355X devices, this box has {have}; refusing to measure fewer ranks "
               f"under an n_gpus={n} label", file=sys.stderr, flush=True)
@@ -305,6 +337,56 @@ def spawn_ranks(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def dry_run(args, launched: bool, world: int, rank: int):
+    """--cpu-dry-run: everything around the kernels, on CPU tensors over gloo - so that the first real N-GPU run is not also the first
+    run of this code.  Same steps as main(): process group, rank 0 builds the blob, broadcast, every rank checks the checksums agree,
+    R blocks of K (empty) steps each bracketed by barriers with a MAX reduction, per-rank gather, rank 0 prints ONE JSON line."""
+    if launched:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = WORKLOADS[args.workload]
+    kw = model_kwargs(w)
+    cfg = FEConfig.from_model_kwargs(**kw)
+    eng = Engine(cfg, None)
+    from fastenhancer_amd.weights import default_state_dict
+    blob = torch.zeros(eng.weight_floats, dtype=torch.float32)
+    if rank == 0:
+        blob.copy_(eng.make_blob(default_state_dict(cfg, torch.Generator().manual_seed(2))))
+    broadcast_blob(blob, src=0)
+    chk = torch.stack([blob.double().sum(), blob.double().abs().sum()])
+    assert float(chk[1]) > 0.0
+    if launched:
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi), "weight broadcast: ranks disagree"
+    b0, b1 = shard_range(args.streams * world, world, rank)
+    times = []
+    for _ in range(max(1, min(args.blocks, 3))):
+        if launched:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pass
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if launched:
+            dist.barrier()
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        times.append(float(tt[0]))
+    per_rank = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    if launched:
+        dist.all_gather(per_rank, torch.tensor([float(b1 - b0)], dtype=torch.float64))
+    else:
+        per_rank = [torch.tensor([float(b1 - b0)])]
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "metric": "none (launch path only: no kernels ran)", "value": None, "n_gpus": world, "world_size": world,
+                          "backend": "gloo", "steps": args.steps, "warmup": args.warmup, "blocks": len(times),
+                          "streams_per_rank": [int(v) for v in per_rank], "weight_blob_floats": int(blob.numel()),
+                          "weight_checksum": float(chk[0])}), flush=True)
+    if launched:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,6 +395,18 @@ def main():
     ap.add_argument("--workload", default="fe_b", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=256, help="concurrent streams per GPU")
     ap.add_argument("--frames-per-step", type=int, default=1, help="hops per stream per launch (1 = per-hop streaming)")
+    ap.add_argument("--offline-seconds", type=float, default=0.0,
+                    help="> 0: a step is ONE offline Model.forward (fe_offline) over `--streams` utterances of this many seconds each "
+                         "(centered STFT, all frames, overlap-add) instead of one streaming hop per stream")
+    ap.add_argument("--offline-engine", default="auto", choices=["auto", "frame_walk", "time_batched"],
+                    help="fe_set_offline_engine: the time-batched (layer-by-layer) engine or the per-hop kernel walking the frames")
+    ap.add_argument("--blocks", type=int, default=25,
+                    help="consecutive timed blocks of --steps steps each; value / ms_per_step are the MEDIAN block (min / max / blocks reported), "
+                         "fewer when a block takes long (--block-budget-s)")
+    ap.add_argument("--block-budget-s", type=float, default=20.0)
+    ap.add_argument("--cpu-dry-run", action="store_true",
+                    help="no kernels, no GPU: the launch path alone - bench -> torch.distributed.run -> N ranks (gloo) -> weight-blob broadcast and its "
+                         "checksum agreement -> the block loop's barriers / reductions around empty steps -> ONE JSON line with world_size and dry_run: true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--graph", action="store_true",
@@ -333,6 +427,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.cpu_dry_run:
+        return dry_run(args, launched, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the FastEnhancer HIP path has no CPU fallback")
     if torch.cuda.device_count() <= local_rank:
@@ -367,9 +463,16 @@ def main():
     elif w.get("ln"):
         from fastenhancer_amd.config import ln_config
         cfg = ln_config(**kw)
+    elif w.get("nc"):
+        from fastenhancer_amd.config import noncausal_config
+        cfg = noncausal_config(**kw)
+        if args.offline_seconds <= 0:
+            args.offline_seconds = 4.0             # the noncausal model has the offline forward only
     else:
         cfg = FEConfig.from_model_kwargs(**kw)
     eng = Engine(cfg, dev)
+    if args.offline_engine != "auto":
+        eng.set_offline_engine(args.offline_engine)
 
     # ---- weights: rank 0 builds the seeded checkpoint, folds it, and broadcasts the blob (RCCL)
     blob = torch.empty(eng.weight_floats, dtype=torch.float32, device=dev)
@@ -403,26 +506,43 @@ def main():
 
     # ---- synthetic streams of this rank, step-major [steps, B, T*H], resident in HBM
     B, T, H = args.streams, args.frames_per_step, cfg.hop_size
+    offline = args.offline_seconds > 0
     total_steps = args.warmup + args.steps
     b0, b1 = shard_range(B * world, world, rank)
-    pool = min(total_steps, 64)                       # distinct steps of input; reused cyclically
-    x = synthetic_streams(b0, b1, pool * T * H, w["sr"], seed=1234 + 2).to(dev)         # [B, pool*T*H]
-    x = x.view(B, pool, T * H).permute(1, 0, 2).contiguous()                             # [pool, B, T*H]
-    out = torch.empty(B, T * H, dtype=torch.float32, device=dev)
-    state = eng.new_state(B)
-
     lib = eng.lib
     stream = torch.cuda.current_stream(dev)
     sptr = ctypes.c_void_p(stream.cuda_stream)
-    xptr, optr, stptr = x.data_ptr(), ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(state.data_ptr())
-    step_bytes = B * T * H * 4
+    if offline:
+        # one step = Model.forward over B utterances of offline_seconds each: T frames per utterance
+        Tw = int(args.offline_seconds * w["sr"])
+        T = 1 + Tw // H
+        x = synthetic_streams(b0, b1, Tw, w["sr"], seed=1234 + 2).to(dev).contiguous()   # [B, Tw]
+        out = torch.empty(B, H * (T - 1), dtype=torch.float32, device=dev)
+        spec_hat = torch.empty(B, cfg.F0 + (1 if (w.get("bsrnn") or w.get("fspen") or w.get("lisennet")) else 0), T, 2, dtype=torch.float32, device=dev)
+        work = torch.empty(int(lib.fe_offline_work_floats(eng._h, B, Tw)), dtype=torch.float32, device=dev)
+        state = torch.zeros(1, device=dev)
+        xp, op_, sp_, wp_ = (ctypes.c_void_p(t_.data_ptr()) for t_ in (x, out, spec_hat, work))
 
-    def run(n, first):
-        for i in range(n):
-            s = (first + i) % pool
-            rc = lib.fe_step(eng._h, ctypes.c_void_p(xptr + s * step_bytes), T * H, stptr, optr, T * H, B, T, sptr)
-            if rc != 0:
-                _lib.check(rc, "fe_step")
+        def run(n, first):
+            for _ in range(n):
+                rc = lib.fe_offline(eng._h, xp, B, Tw, op_, sp_, wp_, sptr)
+                if rc != 0:
+                    _lib.check(rc, "fe_offline")
+    else:
+        pool = min(total_steps, 64)                       # distinct steps of input; reused cyclically
+        x = synthetic_streams(b0, b1, pool * T * H, w["sr"], seed=1234 + 2).to(dev)         # [B, pool*T*H]
+        x = x.view(B, pool, T * H).permute(1, 0, 2).contiguous()                             # [pool, B, T*H]
+        out = torch.empty(B, T * H, dtype=torch.float32, device=dev)
+        state = eng.new_state(B)
+        xptr, optr, stptr = x.data_ptr(), ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(state.data_ptr())
+        step_bytes = B * T * H * 4
+
+        def run(n, first):
+            for i in range(n):
+                s = (first + i) % pool
+                rc = lib.fe_step(eng._h, ctypes.c_void_p(xptr + s * step_bytes), T * H, stptr, optr, T * H, B, T, sptr)
+                if rc != 0:
+                    _lib.check(rc, "fe_step")
 
     # untimed clock ramp: a 20-step run is otherwise measured on a GPU that is still raising its shader clock and
     # filling its instruction / TLB caches (r1: 39.3 us per step in the driver's 20-step run, 34.5 us in steady state)
@@ -430,9 +550,10 @@ def main():
     if args.clock_ramp_ms > 0:
         r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         r0.record(stream)
+        chunk = 2 if offline else 50
         while True:
-            run(50, 0)
-            ramp_steps += 50
+            run(chunk, 0)
+            ramp_steps += chunk
             r1.record(stream)
             r1.synchronize()
             if r0.elapsed_time(r1) >= args.clock_ramp_ms or ramp_steps >= 100000:
@@ -440,12 +561,8 @@ def main():
         state.zero_()
     run(args.warmup, 0)
     torch.cuda.synchronize(dev)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     graph = None
-    if args.graph:
+    if args.graph and not offline:
         cap = torch.cuda.Stream(dev)
         graph = torch.cuda.CUDAGraph()
         keep = state.clone()
@@ -458,26 +575,52 @@ def main():
                     _lib.check(rc, "fe_step")
         state.copy_(keep)
         torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    if graph is not None:
-        graph.replay()
-    else:
-        run(args.steps, args.warmup)
-    ev1.record(stream)
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0                     # this rank's K steps, device-complete; the MAX over ranks is taken below
+
+    # ---- timed region: R consecutive blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both sides and
+    # reduced with MAX over the ranks; the MEDIAN block is reported (a single 20-step block is a 0.7 ms sample)
+    def timed_block(first):
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        if graph is not None:
+            graph.replay()
+        else:
+            run(args.steps, first)
+        ev1.record(stream)
+        torch.cuda.synchronize(dev)
+        dt_ = time.perf_counter() - t0                # this rank's K steps, device-complete
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        km = ev0.elapsed_time(ev1) / args.steps       # HIP events on the launch stream: avg per launch
+        own = dt_
+        if use_dist:
+            tt = torch.tensor([dt_, km], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_, km = float(tt[0]), float(tt[1])
+        return dt_, km, own
+
+    blocks = [timed_block(args.warmup)]
+    n_blocks = max(1, args.blocks)
+    if blocks[0][0] > 0:
+        n_blocks = max(1, min(n_blocks, int(args.block_budget_s / blocks[0][0])))
+    if use_dist:                                      # every rank must run the same number of blocks
+        nb = torch.tensor([n_blocks], dtype=torch.int64, device=dev)
+        dist.all_reduce(nb, op=dist.ReduceOp.MIN)
+        n_blocks = int(nb[0])
+    for r_ in range(1, n_blocks):
+        blocks.append(timed_block(args.warmup + r_ * args.steps))
+    order = sorted(range(len(blocks)), key=lambda i_: blocks[i_][0])
+    med = order[(len(order) - 1) // 2]                # lower median: an actually measured block
+    dt, kernel_ms = blocks[med][0], blocks[med][1]
     if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps    # HIP events on the launch stream: avg per launch
-    if use_dist:
-        tt = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=dev)
+        mine = torch.tensor([blocks[med][2] / args.steps * 1e3], dtype=torch.float64, device=dev)
         per_rank = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
-        dist.all_gather(per_rank, tt[:1].clone() / args.steps * 1e3)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_gather(per_rank, mine)
         per_rank_ms = [float(v) for v in per_rank]
-        dt, kernel_ms = float(tt[0]), float(tt[1])
     else:
         per_rank_ms = [dt / args.steps * 1e3]
     assert torch.isfinite(out).all()
@@ -490,6 +633,8 @@ def main():
         # are rings - all read, one slot of 31 written per frame)
         state_bytes = 4 * eng.state_floats(B)
         alg_bytes = B * T * (2 * H * 4) + 2 * state_bytes
+        if offline:          # the utterances in and out, spec_hat out (the state is born and dies inside the call)
+            alg_bytes = B * (Tw * 4 + H * (T - 1) * 4) + spec_hat.numel() * 4
         if w.get("dpt"):
             cache_bytes = 4 * B * 2 * w["K"] * w["F2"] * w["C2"] * w["dpt"]
             alg_bytes = B * T * (2 * H * 4) + state_bytes + (state_bytes - cache_bytes) + T * cache_bytes // w["dpt"]
@@ -498,24 +643,33 @@ def main():
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "clock_ramp_steps": ramp_steps, "rccl_world_size": rccl_world, "weight_broadcast_ms": bcast_ms,
             "per_rank_ms_per_step": per_rank_ms,
+            "blocks": len(blocks), "statistic": "median of `blocks` consecutive blocks of `steps` steps (max over ranks per block)",
+            "min_ms_per_step": min(b_[0] for b_ in blocks) / args.steps * 1e3, "max_ms_per_step": max(b_[0] for b_ in blocks) / args.steps * 1e3,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{w['desc']} (N={w['N']}, H={w['H']}), {B} concurrent streams per GPU, "
-                                   f"{T} hop(s) per stream per step, wav->wav streaming step with STFT/iSTFT and GRU caches",
+            "config": {"workload": (f"{w['desc']} (N={w['N']}, H={w['H']}), offline Model.forward (centered STFT, all frames, overlap-add) over {B} utterances of "
+                                    f"{args.offline_seconds:g} s per GPU and step = {T} frames each, engine {args.offline_engine}") if offline else
+                                   (f"{w['desc']} (N={w['N']}, H={w['H']}), {B} concurrent streams per GPU, "
+                                    f"{T} hop(s) per stream per step, wav->wav streaming step with STFT/iSTFT and GRU caches"),
                        "streams_per_gpu": B, "frames_per_step": T, "parallelism": f"streams sharded dp{world}, RCCL weight broadcast",
                        "weights": "seeded random checkpoint (no trained weights offline), BN/weight-norm folded"},
-            "rtf_per_stream": dt * w["sr"] / (args.steps * T * H * B * world),   # amortised: wall time / audio time / streams
+            "rtf_per_stream": dt * w["sr"] / (args.steps * (Tw if offline else T * H) * B * world),   # amortised: wall time / audio time / streams
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": measured_traffic(args.workload, B, T),
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None if offline else measured_traffic(args.workload, B, T),
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "algorithmic_hbm_bytes_per_launch": alg_bytes,
-                         "kernel": "lisennet_frame_kernel" if w.get("lisennet") else "fspen_frame_kernel" if w.get("fspen") else ("bsrnn_frame_kernel" if w.get("bsrnn") else "fe_frame_kernel"), "kernel_ms": kernel_ms,
+                         "kernel": ("fe_offline = tb_enc_kernel + K x (tb_scan_kernel + tb_blk_kernel) + tb_dec_kernel + istft_ola_kernel (kernel_ms: the whole call)"
+                                    if offline and args.offline_engine != "frame_walk" and not (w.get("bsrnn") or w.get("fspen") or w.get("lisennet") or w.get("kt") or w.get("frnn") or w.get("dpt") or w.get("ln")) else
+                                    "lisennet_frame_kernel" if w.get("lisennet") else "fspen_frame_kernel" if w.get("fspen") else ("bsrnn_frame_kernel" if w.get("bsrnn") else "fe_frame_kernel")), "kernel_ms": kernel_ms,
                          "flops_per_frame": eng.flops_per_frame,
                          "hbm_frac": alg_bytes / (kernel_ms * 1e-3) / 8e12},
         }
         # the dominant bound: a workload whose algorithmic HBM traffic uses a larger fraction of the HBM peak than its FLOPs do of
         # the fp32 matrix peak (the dptransformer variant: K / V caches of 31 frames read every hop) is priced against HBM
         rf = res["roofline"]
+        # where `traffic` comes from: a PMC pass (FETCH_SIZE / WRITE_SIZE, rocprofv3 --pmc) of exactly this configuration committed under
+        # profiles/pmc_*.json - a constant read back, not a measurement of this run; null when no such pass exists
+        rf["traffic_source"] = "profiles/pmc_*.json (rocprofv3 --pmc FETCH_SIZE WRITE_SIZE pass of this configuration; counters as reported, no correction)" if rf["traffic"] is not None else None
         if rf["hbm_frac"] > rf["frac"]:
             rf.update({"bound": "hbm", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": rf["hbm_frac"],
                        "mfma_frac": achieved / PEAK_FP32_TFLOPS})
@@ -525,6 +679,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline_bsrnn(args.workload, kw, w["sr"], B, args.cpu_budget_s)
         elif world == 1 and not args.no_cpu_baseline and (w.get("kt") or w.get("frnn") or w.get("dpt") or w.get("ln")):
             res["cpu_baseline"] = cpu_baseline_variant(kw, w["sr"], B, min(args.cpu_budget_s, 10.0), "ln" if w.get("ln") else None)
+        elif world == 1 and not args.no_cpu_baseline and w.get("nc"):
+            res["cpu_baseline"] = cpu_baseline_offline_numpy(kw, w["sr"], min(args.cpu_budget_s, 15.0))
         elif world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.workload, kw, w["sr"], B, args.cpu_budget_s)
         print(json.dumps(res), flush=True)

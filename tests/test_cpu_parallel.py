@@ -82,3 +82,18 @@ def test_bench_refuses_to_measure_fewer_ranks_than_asked():
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_bench_launch_path_runs_end_to_end_on_two_gloo_ranks():
+    """`bench.py --gpus 2 --cpu-dry-run`: the SUCCESS path of spawn_ranks - bench -> torch.distributed.run -> 2 ranks -> blob broadcast ->
+    barrier-bracketed blocks -> exactly one JSON line from rank 0 - without kernels (the refusal branches are tested above)."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--cpu-dry-run", "--steps", "3", "--warmup", "1", "--workload", "fe_t",
+                        "--streams", "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["world_size"] == 2 and d["n_gpus"] == 2 and d["value"] is None
+    assert d["streams_per_rank"] == [5, 5] and d["weight_blob_floats"] > 0 and d["blocks"] >= 1
