@@ -42,12 +42,19 @@ def _hipcc() -> str:
 # Shapes beyond the shipped yamls: `python -m fastenhancer_amd.build --add-shape C1,NL,C2,F2,KB,NFFT,HOP[,KT]` appends a line
 # to this (git-ignored, optional) file and rebuilds; fe_api.hip includes it after fe_shapes.def.  FE_LOCAL_DEF overrides the path.
 LOCAL_DEF = os.environ.get("FE_LOCAL_DEF") or os.path.join(CSRC, "fe_shapes_local.def")
+# FE_SHAPES_DEF=<file>: a side build (FE_BUILD_TAG) with a SHORT shape list instead of csrc/fe_shapes.def - seconds instead of
+# minutes while a kernel is being worked on (tools/dev_shapes.def: B, T, L, NC); the library then knows those shapes only
+SHAPES_DEF = os.environ.get("FE_SHAPES_DEF", "")
+if SHAPES_DEF and not _TAG:
+    raise SystemExit("FE_SHAPES_DEF is for side builds: set FE_BUILD_TAG too")
 
 
 def shapes(fname="fe_shapes.def", macro="X"):
     out = []
     files = [os.path.join(CSRC, fname)]
-    if fname == "fe_shapes.def" and os.path.exists(LOCAL_DEF):
+    if fname == "fe_shapes.def" and SHAPES_DEF:
+        files = [os.path.abspath(SHAPES_DEF)]
+    elif fname == "fe_shapes.def" and os.path.exists(LOCAL_DEF):
         files.append(LOCAL_DEF)
     for f in files:
         for line in open(f):
@@ -122,6 +129,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     jobs = []
     api = os.path.join(CSRC, "fe_api.hip")
     api_defs = [f'-DFE_LOCAL_DEF="{LOCAL_DEF}"'] if os.path.exists(LOCAL_DEF) else []
+    if SHAPES_DEF:
+        api_defs = [f'-DFE_SHAPES_DEF="{os.path.abspath(SHAPES_DEF)}"']
+        common_api.append(os.path.abspath(SHAPES_DEF))
     jobs.append((api, os.path.join(OBJ, "fe_api.o"), api_defs, os.path.join(OBJ, "fe_api.stamp"), _digest(common_api + [api], " ".join(FLAGS + api_defs))))
     tmpl = os.path.join(CSRC, "fe_shape.hip.in")
     for name, args in shapes():

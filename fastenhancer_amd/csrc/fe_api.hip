@@ -59,9 +59,13 @@ struct Dims {
 
 // ---------------------------------------------------------------------------- dispatch table
 #define X(name, ...) extern "C" const fe::Impl* fe_impl_##name();
+#ifdef FE_SHAPES_DEF         // a side build with a short shape list (build.py)
+#include FE_SHAPES_DEF
+#else
 #include "fe_shapes.def"
 #ifdef FE_LOCAL_DEF          // shapes added with `python -m fastenhancer_amd.build --add-shape ...`
 #include FE_LOCAL_DEF
+#endif
 #endif
 #undef X
 
@@ -83,9 +87,13 @@ const std::vector<const fe::BImpl*>& bimpls() {
 const std::vector<const fe::Impl*>& impls() {
     static const std::vector<const fe::Impl*> v = {
 #define X(name, ...) fe_impl_##name(),
+#ifdef FE_SHAPES_DEF
+#include FE_SHAPES_DEF
+#else
 #include "fe_shapes.def"
 #ifdef FE_LOCAL_DEF
 #include FE_LOCAL_DEF
+#endif
 #endif
 #undef X
     };
@@ -108,6 +116,9 @@ struct fe_handle {
     int pipe_frames = -1;          // fe_set_time_pipeline (-1: chosen from the model size)
     int offline_engine = FE_OFFLINE_AUTO;     // fe_set_offline_engine
     unsigned int* pipe_flags_dev = nullptr;   // fe_spec_step's frame counters [max_wgs][KB] (fe_offline keeps its own in the work buffer)
+    std::vector<hipStream_t> tb_streams;      // time-batched engine: the streams its nodes are spread over (lazy; tb_run)
+    std::vector<hipEvent_t> tb_events;        // ... and its event pool
+    unsigned long long* tb_probe_dev = nullptr;   // FE_TB_PROBE builds: phase clocks [4][kProbeSlots]
     std::vector<Section> sections;
     size_t blob_floats = 0;
     float* packed_dev = nullptr;
@@ -1314,8 +1325,22 @@ void fe_destroy(fe_handle* h) {
     if (h->skip_dev) (void)hipFree(h->skip_dev);
     if (h->tables_dev) (void)hipFree(h->tables_dev);
     if (h->pipe_flags_dev) (void)hipFree(h->pipe_flags_dev);
+    for (hipStream_t s : h->tb_streams) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : h->tb_events) (void)hipEventDestroy(e);
+    if (h->tb_probe_dev) (void)hipFree(h->tb_probe_dev);
     delete h;
 }
+
+#ifdef FE_TB_PROBE
+// probe builds only (not part of the ABI): read and clear the time-batched engine's phase clocks, out[4 * kProbeSlots]
+extern "C" int fe_tb_probe_read(fe_handle* h, unsigned long long* out) {
+    if (!h || !h->tb_probe_dev) return FE_ERR_INVALID_ARG;
+    FE_HIP_CHECK(hipDeviceSynchronize());
+    FE_HIP_CHECK(hipMemcpy(out, h->tb_probe_dev, 4 * fe::tb::kProbeSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    FE_HIP_CHECK(hipMemset(h->tb_probe_dev, 0, 4 * fe::tb::kProbeSlots * sizeof(unsigned long long)));
+    return FE_OK;
+}
+#endif
 
 size_t fe_weight_floats(const fe_handle* h) { return h ? h->blob_floats : 0; }
 int fe_weight_sections(const fe_handle* h) { return h ? (int)h->sections.size() : 0; }
@@ -1531,22 +1556,135 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
     return FE_OK;
 }
 
-// floats of the time-batched engine's work buffer: xc | skip | x | gx | hs | frames, each a multiple of 4 floats
-static size_t tb_work_floats(const fe_handle* h, int B, int T, size_t* off /*[6] or nullptr*/) {
+// floats of the time-batched engine's work buffer: xc | skip | x | gx | hs | frames | carried GRU state, each a multiple of 4 floats
+static size_t tb_work_floats(const fe_handle* h, int B, int T, size_t* off /*[7] or nullptr*/) {
     const Dims& d = h->d;
     const size_t NF = (size_t)B * T, nd = d.BD ? 2 : 1;
-    const size_t sz[6] = {NF * 2 * d.F0, NF * (d.NL + 1) * d.F1 * d.C1, NF * d.F2 * d.C2, nd * NF * d.F2 * 3 * d.C2, NF * d.F2 * nd * d.C2, NF * d.NFFT};
+    const size_t sz[7] = {NF * 2 * d.F0, NF * (d.NL + 1) * d.F1 * d.C1, NF * d.F2 * d.C2, nd * NF * d.F2 * 3 * d.C2, NF * d.F2 * nd * d.C2, NF * d.NFFT,
+                          (size_t)d.KB * nd * B * d.F2 * d.C2};
     size_t cur = 0;
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 7; ++i) {
         if (off) off[i] = cur;
         cur += (sz[i] + 3) & ~(size_t)3;
     }
     return cur;
 }
 
-static bool use_tb_offline(const fe_handle* h) {
+// The time-batched engine's schedule.  The call's B x T frames are cut into NODES - G groups of utterances x NC chunks of
+// consecutive frames - and every node runs the chain  enc -> (scan k -> blk k) x KB -> dec  on its own slice of the work buffers.
+// Only the scans are serial in time: scan k of chunk c starts from the state scan k of chunk c - 1 left (an event), everything
+// else of a node depends on the node alone.  The nodes are spread round-robin over a few HIP streams of the handle, so that
+// the latency-bound scans of one node (16 rows per workgroup, one recurrence step after the other) run UNDER the GEMM passes
+// of the others instead of leaving the chip idle between them, and - a single utterance - the scans of consecutive blocks
+// pipeline through the chunks.  The noncausal model's reverse scan needs all frames of an utterance: utterance groups only.
+struct TbPlan { int G, NC, NS, stagger; };
+
+static TbPlan tb_plan(const fe_handle* h, int B, int T) {
+    auto env = [](const char* n, int dflt) { const char* v = std::getenv(n); return v ? std::atoi(v) : dflt; };
+    TbPlan p;
+    // Measured (profiles/r3d_tb_node_plans.txt): on this runtime the streams of one process share 3-4 hardware queues and kernels that
+    // overlap slow each other down by what the overlap hides - every multi-node plan came out slower than ONE node.  The default is
+    // therefore one node; FE_TB_NC / FE_TB_G / FE_TB_STREAMS keep the cut available (results are bit-identical by construction).
+    p.NC = std::max(1, std::min(T, env("FE_TB_NC", 1)));
+    if (h->d.BD) p.NC = 1;
+    p.G = std::max(1, std::min(B, env("FE_TB_G", 1)));
+    p.NS = std::max(1, std::min(8, env("FE_TB_STREAMS", 4)));
+    p.NS = std::min(p.NS, p.G * p.NC);
+    p.stagger = env("FE_TB_STAGGER", 1);
+    if (std::getenv("FE_TB_STAGES")) { p.G = p.NC = p.NS = 1; }
+    return p;
+}
+
+static int tb_run(fe_handle* h, fe::tb::TbArgs a0, float* work_dev, int B, int T, hipStream_t st) {
+    const Dims& d = h->d;
+    const fe::tb::TbImpl* tbi = h->impl->tb;
+    const TbPlan p = tb_plan(h, B, T);
+    const int nodes = p.G * p.NC;
+    size_t off[7];
+    tb_work_floats(h, B, T, off);
+    const size_t nd = d.BD ? 2 : 1;
+    a0.Bfull = B; a0.Tfull = T;
+#ifdef FE_TB_PROBE
+    if (!h->tb_probe_dev) {
+        FE_HIP_CHECK(hipMalloc(&h->tb_probe_dev, 4 * fe::tb::kProbeSlots * sizeof(unsigned long long)));
+        FE_HIP_CHECK(hipMemset(h->tb_probe_dev, 0, 4 * fe::tb::kProbeSlots * sizeof(unsigned long long)));
+    }
+    a0.probe = h->tb_probe_dev;
+#endif
+    const bool caller_state = a0.hstate != nullptr;     // caches handed in: read by the first chunk (h_init), left updated by the last
+    if (!caller_state && p.NC > 1) a0.hstate = work_dev + off[6];
+    a0.frames = work_dev + off[5];
+    hipError_t e = hipSuccess;
+    // (FE_TB_STAGES=n: stop after n launches - tools/gpu_tb_check.py reads the intermediate buffers out of work_dev)
+    const char* lim_s = std::getenv("FE_TB_STAGES");
+    int lim = lim_s ? std::atoi(lim_s) : 1 << 30;
+    const bool multi = p.NS > 1;
+    if (multi) {
+        while ((int)h->tb_streams.size() < p.NS) {
+            hipStream_t s;
+            FE_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            h->tb_streams.push_back(s);
+        }
+        const size_t nev = 1 + (size_t)p.NS + (size_t)nodes * (d.KB + 1);
+        while (h->tb_events.size() < nev) {
+            hipEvent_t ev;
+            FE_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            h->tb_events.push_back(ev);
+        }
+        FE_HIP_CHECK(hipEventRecord(h->tb_events[0], st));
+        for (int s = 0; s < p.NS; ++s) FE_HIP_CHECK(hipStreamWaitEvent(h->tb_streams[s], h->tb_events[0], 0));
+    }
+    auto scan_event = [&](int node, int k) { return h->tb_events[1 + p.NS + (size_t)node * (d.KB + 1) + k]; };
+    auto enc_event = [&](int node) { return h->tb_events[1 + p.NS + (size_t)node * (d.KB + 1) + d.KB]; };
+    size_t fbase = 0;                            // frames of the nodes before this one: its offset into the work buffers
+    for (int g = 0; g < p.G && e == hipSuccess; ++g) {
+        const int b0 = (int)((long)B * g / p.G), b1 = (int)((long)B * (g + 1) / p.G);
+        for (int c = 0; c < p.NC && e == hipSuccess; ++c) {
+            const int t0 = (int)((long)T * c / p.NC), t1 = (int)((long)T * (c + 1) / p.NC);
+            const int node = g * p.NC + c, sidx = node % p.NS;
+            hipStream_t ns = multi ? h->tb_streams[sidx] : st;
+            fe::tb::TbArgs a = a0;
+            a.B = b1 - b0; a.T = t1 - t0; a.NF = a.B * a.T; a.b0 = b0; a.t0 = t0;
+            a.h_init = (c > 0 || (caller_state && a0.h_init)) ? 1 : 0;
+            a.xc = work_dev + off[0] + fbase * 2 * d.F0;
+            a.skip = work_dev + off[1] + fbase * (size_t)(d.NL + 1) * d.F1 * d.C1;
+            a.x = work_dev + off[2] + fbase * (size_t)d.F2 * d.C2;
+            a.gx = work_dev + off[3] + nd * fbase * (size_t)d.F2 * 3 * d.C2;
+            a.hs = work_dev + off[4] + fbase * (size_t)d.F2 * nd * d.C2;
+            fbase += (size_t)a.NF;
+            if (a.NF == 0) continue;
+            // stagger: a node's encoder pass starts when the previous node's has finished - nodes that start together run in lockstep
+            // (GEMM passes together, then all of them in their scans with the chip idle)
+            if (multi && p.stagger && node > 0 && (node - 1) % p.NS != sidx) FE_HIP_CHECK(hipStreamWaitEvent(ns, enc_event(node - 1), 0));
+            if (lim-- > 0) tbi->launch(fe::tb::TB_ENC, a, h->max_wgs, ns, &e);
+            if (multi && p.stagger && node + 1 < nodes) FE_HIP_CHECK(hipEventRecord(enc_event(node), ns));
+            for (int k = 0; k < d.KB && e == hipSuccess; ++k) {
+                a.k = k;
+                if (multi && c > 0 && (node - 1) % p.NS != sidx) FE_HIP_CHECK(hipStreamWaitEvent(ns, scan_event(node - 1, k), 0));
+                if (lim-- > 0) tbi->launch(fe::tb::TB_SCAN, a, h->max_wgs, ns, &e);
+                if (multi && c + 1 < p.NC) FE_HIP_CHECK(hipEventRecord(scan_event(node, k), ns));
+                if (e == hipSuccess && lim-- > 0) tbi->launch(fe::tb::TB_BLK, a, h->max_wgs, ns, &e);
+            }
+            if (e == hipSuccess && lim-- > 0) tbi->launch(fe::tb::TB_DEC, a, h->max_wgs, ns, &e);
+        }
+    }
+    if (multi) {
+        for (int s = 0; s < p.NS; ++s) {
+            FE_HIP_CHECK(hipEventRecord(h->tb_events[1 + s], h->tb_streams[s]));
+            FE_HIP_CHECK(hipStreamWaitEvent(st, h->tb_events[1 + s], 0));
+        }
+    }
+    if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return FE_OK;
+}
+
+// FE_OFFLINE_AUTO: the time-batched engine, except for the big shapes (M, L and their 48 kHz forms: block weights streamed from L2,
+// one frame per tile) once there are enough utterances for the time-pipelined frame walk to fill the chip on its own - measured on
+// FastEnhancer_L, 4 s: 1 utterance 5.2 ms time-batched / 14.2 ms walk, 16 utterances 20.6 / 16.8 ms (profiles/r3d_tb_timing.txt)
+static bool use_tb_offline(const fe_handle* h, int B) {
     if (!h->impl || !h->impl->tb) return false;
     if (h->d.BD) return true;
+    if (h->offline_engine == FE_OFFLINE_AUTO) return !(h->d.C2 >= 72 && B >= 8);
     return h->offline_engine != FE_OFFLINE_FRAME_WALK;
 }
 
@@ -1587,34 +1725,23 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
         return fail(FE_ERR_INVALID_ARG, "Tw=%d: reflect padding of n_fft/2=%d needs a longer input", Tw, d.NFFT / 2);
     hipStream_t st = (hipStream_t)stream;
     const int T = 1 + Tw / d.HOP;
-    if (use_tb_offline(h)) {
+    if (use_tb_offline(h, B)) {
         // the time-batched engine: encoder pass, per block (scan over time, attention pass), decoder pass, overlap-add
         rc = ensure_tables(h, st);
         if (rc != FE_OK) return rc;
-        size_t off[6];
-        tb_work_floats(h, B, T, off);
         fe::tb::TbArgs a{};
         a.wp = h->packed_dev;
         a.wav_in = noisy_dev; a.in_stride = (size_t)Tw; a.Tw = Tw;
         a.spec_out = spec_hat_dev;
-        a.xc = work_dev + off[0]; a.skip = work_dev + off[1]; a.x = work_dev + off[2]; a.gx = work_dev + off[3]; a.hs = work_dev + off[4];
-        a.frames = work_dev + off[5];
         a.hstate = nullptr;                      // zero initial state (model.py:626-627)
-        a.B = B; a.T = T; a.NF = B * T; a.mode = fe::FE_MODE_OFFLINE;
+        a.mode = fe::FE_MODE_OFFLINE;
         a.compression = h->cfg.input_compression;
+        rc = tb_run(h, a, work_dev, B, T, st);
+        if (rc != FE_OK) return rc;
+        size_t off[7];
+        tb_work_floats(h, B, T, off);
+        a.frames = work_dev + off[5];
         hipError_t e = hipSuccess;
-        const fe::tb::TbImpl* tbi = h->impl->tb;
-        // (FE_TB_STAGES=n: stop after n launches - tools/gpu_tb_check.py reads the intermediate buffers out of work_dev)
-        const char* lim_s = std::getenv("FE_TB_STAGES");
-        int lim = lim_s ? std::atoi(lim_s) : 1 << 30;
-        if (lim-- > 0) tbi->launch(fe::tb::TB_ENC, a, h->max_wgs, st, &e);
-        for (int k = 0; k < d.KB && e == hipSuccess; ++k) {
-            a.k = k;
-            if (lim-- > 0) tbi->launch(fe::tb::TB_SCAN, a, h->max_wgs, st, &e);
-            if (e == hipSuccess && lim-- > 0) tbi->launch(fe::tb::TB_BLK, a, h->max_wgs, st, &e);
-        }
-        if (e == hipSuccess && lim-- > 0) tbi->launch(fe::tb::TB_DEC, a, h->max_wgs, st, &e);
-        if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
         const int n_out = d.HOP * (T - 1);
         hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
                            a.frames, h->tables_dev, wav_hat_dev, (size_t)n_out, d.NFFT, d.HOP, T);

@@ -23,6 +23,7 @@
 // the per-hop kernel; weights are read from the same packed buffer (fe::Pack<S>, fragment order, L2-resident).
 #pragma once
 #include <atomic>
+#include <cstdlib>
 
 #include "fe_kernels.hip.h"
 
@@ -41,16 +42,64 @@ struct TbArgs {
     float* frames;              // offline: [B][T][N] windowed output frames (summed by istft_ola_kernel)
     float* xc;                  // [NF][2][F0]  compressed spectrum (Re plane, Im plane)
     float* skip;                // [NF][NL+1][F1*C1]  encoder outputs, A-fragment order
-    float* x;                   // [NF][F2][C2]  token stream between the blocks
-    float* gx;                  // [ND][NF][F2][3 C2]  W_ih x + b_ih (+ b_hh for r, z)
-    float* hs;                  // [NF][F2][ND*C2]  GRU outputs
+    // token-layout buffers are CHANNEL-MAJOR per frame, [frame][channel][sub-band]: the four rows an accumulator lane holds (C/D layout:
+    // rows 4 lg .. 4 lg + 3 of a 16-row tile = four consecutive sub-bands, F2 % 4 == 0) are ONE 16-byte access, in the GEMM epilogues
+    // that write them and in the scan that reads gx / writes hs per (row, channel)
+    float* x;                   // [NF][C2][F2]  token stream between the blocks
+    float* gx;                  // [ND][NF][3 C2][F2]  W_ih x + b_ih (+ b_hh for r, z)
+    float* hs;                  // [NF][ND*C2][F2]  GRU outputs
     float* hstate;              // [KB][B*F2][C2] carried GRU state (spec -> spec with caches), or nullptr: zero initial state
-    int B, T, NF;               // utterances, frames per utterance, B * T
+    int B, T, NF;               // the NODE's utterances, frames per utterance and B * T: the work buffers are indexed by the node-local frame b * T + t
+    int b0, t0;                 // the node's first utterance / first frame within the whole call (input / output addressing, carried state)
+    int Bfull, Tfull;           // utterances and frames per utterance of the whole call
+    int h_init;                 // tb_scan_kernel: 1 = start from hstate (a later time chunk, or caches handed in), 0 = zero initial state
     int Tw;                     // offline: samples per utterance
     int mode;                   // FE_MODE_OFFLINE / FE_MODE_SPEC
     int k;                      // block index (tb_scan_kernel, tb_blk_kernel)
     float compression;
+    unsigned long long* probe;  // FE_TB_PROBE builds (tools/gpu_tb_phases.py): cycles per phase of workgroup 0, [stage][kProbeSlots]; else nullptr
 };
+
+constexpr int kProbeSlots = 32;
+enum { TB_ENC = 0, TB_SCAN = 1, TB_BLK = 2, TB_DEC = 3 };
+#ifdef FE_TB_PROBE
+// phase clocks: workgroup 0's thread 0 adds the cycles since the previous mark to slot i (s_memtime, after the phase's barrier)
+#define TB_PROBE_INIT(stage) unsigned long long* const tb_pr_ = (a.probe != nullptr && blockIdx.x == 0 && threadIdx.x == 0) ? a.probe + (stage) * kProbeSlots : nullptr; \
+                             unsigned long long tb_pt_ = __builtin_amdgcn_s_memtime()
+#define TB_MARK(i) do { if (tb_pr_ != nullptr) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tb_pr_[i] += n_ - tb_pt_; tb_pt_ = n_; } } while (0)
+#else
+#define TB_PROBE_INIT(stage) do {} while (0)
+#define TB_MARK(i) do {} while (0)
+#endif
+
+// A buffer resource over [p, p + bytes): stores / loads beyond the range are dropped / return 0 in hardware - the last, partial tile of a
+// launch needs no per-element predicate (hipcc turns those into one divergent block per store)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t range_rsrc(const float* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)(bytes < 0x7fffffffu ? bytes : 0x7fffffffu), 0x00020000);
+}
+__device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, const f32x4& v, int voff_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), r, voff_bytes, 0, 0);
+}
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, int voff_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, 0, 0));
+}
+// float offset, within a tile's [frame][NCH][F2] region, of the four sub-bands that are tile rows row0 .. row0 + 3 (row0 % 4 == 0) of channel col
+template <class S>
+__device__ __forceinline__ int cm_off(int row0, int col, int nch) {
+    const int fr = row0 / S::F2, f0 = row0 - fr * S::F2;
+    return (fr * nch + col) * S::F2 + f0;
+}
+// a tile's tokens [frame][NCH][F2] (global, frames g0 .. g0 + nv - 1 valid: later frames repeat the last) -> LDS rows [frame * F2 + f][LD], 16-byte loads
+template <class S, int FRAMES, int NCH, int LD>
+__device__ __forceinline__ void load_tokens(const float* src, int nv, float* dst, int tid) {
+    constexpr int F4 = S::F2 / 4, PER = NCH * F4;
+    for (int i = tid; i < FRAMES * PER; i += kThreads) {
+        const int fr = i / PER, q = i - fr * PER, c = q / F4, f4 = q - c * F4, fs = fr < nv ? fr : nv - 1;
+        const float4 v = *reinterpret_cast<const float4*>(src + ((size_t)fs * NCH + c) * S::F2 + 4 * f4);
+        float* d = dst + (fr * S::F2 + 4 * f4) * LD + c;
+        d[0] = v.x; d[LD] = v.y; d[2 * LD] = v.z; d[3 * LD] = v.w;
+    }
+}
 
 template <class S>
 __device__ __forceinline__ WSrc<false> make_wsrc(const float* wp, int lane) {
@@ -158,9 +207,48 @@ __device__ __forceinline__ void tok_panel(f32x4 (&acc)[MTT][NTPW], const float* 
         }, NoSide{});
 }
 
-// gx = x W_ih^T + b for one block and direction -> global [rows][3 C2]; X: the tile's tokens in LDS
+// The same panel with the B operand (weights) REGISTER-RESIDENT - w[j][ks], loaded once per launch: nothing but the A fragments
+// moves during the GEMM (LDS reads, ring of 3 k-steps), no L2 round trip at the head of the phase.
+template <int MTP, int NTP, int KS, int LDA, typename WF>
+__device__ __forceinline__ void tok_panel_rb(f32x4 (&acc)[MTP][NTP], const float* a_lane, WF&& wf) {
+    constexpr int PD = KS < 3 ? KS : 3;
+    float a[PD][MTP];
+#pragma unroll
+    for (int ks = 0; ks < PD; ++ks)
+#pragma unroll
+        for (int i = 0; i < MTP; ++i) a[ks][i] = a_lane[(16 * i) * LDA + 4 * ks];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        float av[MTP];
+#pragma unroll
+        for (int i = 0; i < MTP; ++i) av[i] = a[ks % PD][i];
+        if (ks + PD < KS) {
+#pragma unroll
+            for (int i = 0; i < MTP; ++i) a[ks % PD][i] = a_lane[(16 * i) * LDA + 4 * (ks + PD)];
+        }
+#pragma unroll
+        for (int i = 0; i < MTP; ++i)
+#pragma unroll
+            for (int j = 0; j < NTP; ++j) acc[i][j] = FE_MFMA(av[i], wf(j, ks), acc[i][j]);
+    }
+    constexpr int NM = MTP * NTP;
+    __builtin_amdgcn_sched_group_barrier(0x100, PD * MTP, 0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (ks + PD < KS) {
+#pragma unroll
+                for (int q = (m * MTP) / NM; q < ((m + 1) * MTP) / NM; ++q) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+}
+
+// gx = x W_ih^T + b for one block and direction -> global [frame][3 C2][F2]; X: the tile's tokens in LDS
 template <class S, int FT>
 __device__ __forceinline__ void gx_gemm(const float* Xb, const WSrc<false>& wb, int w_off, int b_off, float* gx_tile, int rows_valid, int wave, int lane) {
+    const __amdgpu_buffer_rsrc_t gr = range_rsrc(gx_tile, (size_t)rows_valid * S::N3 * 4);
     using TT = TokTiling<S, FT>;
     constexpr int MTT = TT::MTT, NT3 = S::NT3, N3 = S::N3;
     constexpr int NTPW = ceil_div(NT3, kWaves);
@@ -190,12 +278,7 @@ __device__ __forceinline__ void gx_gemm(const float* Xb, const WSrc<false>& wb, 
             const int nt = wave + 4 * (j0 + j), col = 16 * nt + li;
             if (nt < NT3 && col < N3) {
 #pragma unroll
-                for (int i = 0; i < MTT; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * i + 4 * lg + r;
-                        if (row < rows_valid) gx_tile[(size_t)row * N3 + col] = acc[i][j][r];
-                    }
+                for (int i = 0; i < MTT; ++i) bstore4(gr, acc[i][j], cm_off<S>(16 * i + 4 * lg, col, N3) * 4);
             }
         }
     }
@@ -242,50 +325,108 @@ __global__ void __launch_bounds__(kThreads) tb_enc_kernel(TbArgs a) {
     typename D::FwdConst dc;
     D::load(dc, wb, o, wave);
     const int ntiles = (a.NF + FT - 1) / FT;
+    // analysis window in registers; the samples of the tile's frames are fetched one tile ahead (fetch_frames)
+    constexpr int NPT = N / kThreads;
+    constexpr bool PARF = FT * 2 * N <= FT * S::ACT;          // every frame of the tile has its own transform scratch in A1
+    float fw[NPT], fv[FT][NPT];
+#pragma unroll
+    for (int q = 0; q < NPT; ++q) fw[q] = (a.wp + o.window)[tid + q * kThreads];
+    auto fetch_frames = [&](int tl) {
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+            int g = tl * FT + f;
+            g = g < a.NF ? g : a.NF - 1;
+            const int bl = g / a.T, t = a.t0 + (g - bl * a.T), b = a.b0 + bl;
+            const float* xin = a.wav_in + (size_t)b * a.in_stride;
+#pragma unroll
+            for (int q = 0; q < NPT; ++q) {
+                const int n = tid + q * kThreads;
+                int idx = t * H + n - N / 2;
+                idx = idx < 0 ? -idx : idx;
+                idx = idx >= a.Tw ? 2 * (a.Tw - 1) - idx : idx;
+                fv[f][q] = xin[idx];
+            }
+        }
+    };
+    if (PARF && a.mode != FE_MODE_SPEC && (int)blockIdx.x < ntiles) fetch_frames(blockIdx.x);
     __syncthreads();
+    TB_PROBE_INIT(TB_ENC);
+    TB_MARK(0);                     // prologue
 
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int g0 = tile * FT;
         const int nvalid = a.NF - g0 < FT ? a.NF - g0 : FT;
-        // ---- STFT (functional/audio_modules.py:78-80: center = True, reflect padding) + compress (model.py:684-690), frame by frame
-#pragma unroll 1
-        for (int f = 0; f < FT; ++f) {
-            const int g = g0 + f < a.NF ? g0 + f : a.NF - 1;
-            const int b = g / a.T, t = g - b * a.T;
-            float* sc = smem + L::SC + f * 2 * S::LDS_S;
-            float* xcg = a.xc + (size_t)g * (2 * F0);
-            if (a.mode != FE_MODE_SPEC) {
-                const float* xin = a.wav_in + (size_t)b * a.in_stride;
-                const float* win = a.wp + o.window;
-                constexpr int NPT = N / kThreads;
-                float fv[NPT], fw[NPT];
+        // ---- STFT (functional/audio_modules.py:78-80: center = True, reflect padding) + compress (model.py:684-690).  The tile's samples
+        // were fetched while the previous tile computed (fv), the window sits in registers; the frames' transforms run back to back,
+        // each in its own scratch (windowed frame | spectrum, 2 N floats per frame in A1)
+        if (a.mode != FE_MODE_SPEC) {
+            if constexpr (PARF) {
 #pragma unroll
-                for (int q = 0; q < NPT; ++q) {
-                    const int n = tid + q * kThreads;
-                    int idx = t * H + n - N / 2;
-                    idx = idx < 0 ? -idx : idx;
-                    idx = idx >= a.Tw ? 2 * (a.Tw - 1) - idx : idx;
-                    fv[q] = xin[idx];
-                    fw[q] = win[n];
-                }
+                for (int f = 0; f < FT; ++f)
 #pragma unroll
-                for (int q = 0; q < NPT; ++q) q0[tid + q * kThreads] = fv[q] * fw[q];
+                    for (int q = 0; q < NPT; ++q) A1[f * 2 * N + tid + q * kThreads] = fv[f][q] * fw[q];
                 __syncthreads();
-                D::forward(q0, q3, tw, dc, wave, lane, nullptr);          // (ends with a barrier)
-                for (int fb = tid; fb < F0; fb += kThreads) {
+                if (tile + (int)gridDim.x < ntiles) fetch_frames(tile + gridDim.x);       // in flight under this tile's GEMMs
+#pragma unroll 1
+                for (int f = 0; f < FT; ++f) D::forward(A1 + f * 2 * N, A1 + f * 2 * N + N, tw, dc, wave, lane, nullptr);          // (each ends with a barrier)
+                for (int i = tid; i < FT * F0; i += kThreads) {
+                    const int f = i / F0, fb = i - f * F0;
+                    const float* q3 = A1 + f * 2 * N + N;
+                    float* sc = smem + L::SC + f * 2 * S::LDS_S;
                     const float re = q3[fb], im = q3[N / 2 + fb];
                     const float mag = fmaxf(sqrtf(re * re + im * im), 1.0e-5f);
                     const float gn = pow_f(mag, a.compression - 1.0f);
                     sc[2 + fb] = re * gn;
                     sc[S::LDS_S + 2 + fb] = im * gn;
-                    if (f < nvalid) { xcg[fb] = re * gn; xcg[F0 + fb] = im * gn; }
+                    if (f < nvalid) {
+                        float* xcg = a.xc + (size_t)(g0 + f) * (2 * F0);
+                        xcg[fb] = re * gn; xcg[F0 + fb] = im * gn;
+                    }
                 }
-                __syncthreads();                                           // (q0 / q3 are re-used by the next frame)
+                __syncthreads();                                               // (encoder layer 0 writes A1)
             } else {
-                const float* sp = a.spec_in + (size_t)b * (F0 + 1) * a.T * 2;
+#pragma unroll 1
+                for (int f = 0; f < FT; ++f) {
+                    const int g = g0 + f < a.NF ? g0 + f : a.NF - 1;
+                    const int bl = g / a.T, t = a.t0 + (g - bl * a.T), b = a.b0 + bl;
+                    float* sc = smem + L::SC + f * 2 * S::LDS_S;
+                    float* xcg = a.xc + (size_t)g * (2 * F0);
+                    const float* xin = a.wav_in + (size_t)b * a.in_stride;
+                    float fr[NPT];
+#pragma unroll
+                    for (int q = 0; q < NPT; ++q) {
+                        const int n = tid + q * kThreads;
+                        int idx = t * H + n - N / 2;
+                        idx = idx < 0 ? -idx : idx;
+                        idx = idx >= a.Tw ? 2 * (a.Tw - 1) - idx : idx;
+                        fr[q] = xin[idx];
+                    }
+#pragma unroll
+                    for (int q = 0; q < NPT; ++q) q0[tid + q * kThreads] = fr[q] * fw[q];
+                    __syncthreads();
+                    D::forward(q0, q3, tw, dc, wave, lane, nullptr);          // (ends with a barrier)
+                    for (int fb = tid; fb < F0; fb += kThreads) {
+                        const float re = q3[fb], im = q3[N / 2 + fb];
+                        const float mag = fmaxf(sqrtf(re * re + im * im), 1.0e-5f);
+                        const float gn = pow_f(mag, a.compression - 1.0f);
+                        sc[2 + fb] = re * gn;
+                        sc[S::LDS_S + 2 + fb] = im * gn;
+                        if (f < nvalid) { xcg[fb] = re * gn; xcg[F0 + fb] = im * gn; }
+                    }
+                    __syncthreads();                                           // (q0 / q3 are re-used by the next frame)
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int f = 0; f < FT; ++f) {
+                const int g = g0 + f < a.NF ? g0 + f : a.NF - 1;
+                const int bl = g / a.T, t = a.t0 + (g - bl * a.T), b = a.b0 + bl;
+                float* sc = smem + L::SC + f * 2 * S::LDS_S;
+                float* xcg = a.xc + (size_t)g * (2 * F0);
+                const float* sp = a.spec_in + (size_t)b * (F0 + 1) * a.Tfull * 2;
                 for (int fb = tid; fb < F0; fb += kThreads) {
-                    const float re = sp[((size_t)fb * a.T + t) * 2], im = sp[((size_t)fb * a.T + t) * 2 + 1];
+                    const float re = sp[((size_t)fb * a.Tfull + t) * 2], im = sp[((size_t)fb * a.Tfull + t) * 2 + 1];
                     const float mag = fmaxf(sqrtf(re * re + im * im), 1.0e-5f);
                     const float gn = pow_f(mag, a.compression - 1.0f);
                     sc[2 + fb] = re * gn;
@@ -300,6 +441,7 @@ __global__ void __launch_bounds__(kThreads) tb_enc_kernel(TbArgs a) {
             ((q & 2) ? A1 : A0)[f * S::ACT + ((q & 1) ? F1 + 1 : 0) * LDC + c] = 0.0f;
         }
         __syncthreads();
+        TB_MARK(1);                 // STFT + compress
         float* const skip_tile = a.skip + (size_t)g0 * ((S::NL + 1) * F1 * C1);
         constexpr size_t SKF = (size_t)(S::NL + 1) * F1 * C1;
         // ---- enc_pre (model.py:436-443): strided conv as a K = 16 GEMM over the 2-bin-haloed spectrum
@@ -313,6 +455,7 @@ __global__ void __launch_bounds__(kThreads) tb_enc_kernel(TbArgs a) {
                 }, wb, o.enc_pre_w, o.enc_pre_b, A0, skip_tile, SKF, nvalid, wave, lane);
         }
         __syncthreads();
+        TB_MARK(2);                 // enc_pre
         // ---- encoder (model.py:446-456): k = 3 convs, ping-pong A0 <-> A1
         static_for<S::NL>([&](auto l_) {
             constexpr int l = decltype(l_)::value;
@@ -321,6 +464,7 @@ __global__ void __launch_bounds__(kThreads) tb_enc_kernel(TbArgs a) {
             conv_gemm<S, FT, 3 * S::KS_C, true, C1, LDC, S::ACT, 1>(K3Src<S, FT>{in + (16 * wm + li) * LDC + lg}, wb, o.enc_w[l], o.enc_b[l], out,
                                                                      skip_tile + (size_t)(l + 1) * F1 * C1, SKF, nvalid, wave, lane);
             __syncthreads();
+            TB_MARK(3 + l);         // encoder layer l
         });
         float* const Elast = (S::NL & 1) ? A1 : A0;      // last encoder output
         float* const Y1 = (S::NL & 1) ? A0 : A1;         // rf_pre intermediate [FT F2][LDC] (dense rows)
@@ -351,13 +495,13 @@ __global__ void __launch_bounds__(kThreads) tb_enc_kernel(TbArgs a) {
                 }
         }
         __syncthreads();
+        TB_MARK(12);                // rf_pre filterbank
         {
             constexpr int NTPW = ceil_div(S::NT2, kWaves);
             f32x4 acc[TT::MTT][NTPW];
             acc_init_bias<TT::MTT, NTPW>(acc, wb, o.rfpre_b, wave, 4, S::NT2);
             tok_panel<TT::MTT, NTPW, S::KS_C, LDC>(acc, Y1 + li * LDC + lg, wb, o.rfpre_w, S::NT2, wave);
-            float* xg = a.x + (size_t)g0 * (F2 * C2);
-            const int rows_valid = nvalid * F2;
+            const __amdgpu_buffer_rsrc_t xr = range_rsrc(a.x + (size_t)g0 * (F2 * C2), (size_t)nvalid * F2 * C2 * 4);
 #pragma unroll
             for (int i = 0; i < TT::MTT; ++i)
 #pragma unroll
@@ -365,21 +509,20 @@ __global__ void __launch_bounds__(kThreads) tb_enc_kernel(TbArgs a) {
                     const int nt = wave + 4 * j, col = 16 * nt + li;
                     if (nt < S::NT2 && col < C2) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = 16 * i + 4 * lg + r;
-                            Xb[row * LDX + col] = acc[i][j][r];
-                            if (row < rows_valid) xg[(size_t)row * C2 + col] = acc[i][j][r];
-                        }
+                        for (int r = 0; r < 4; ++r) Xb[(16 * i + 4 * lg + r) * LDX + col] = acc[i][j][r];
+                        bstore4(xr, acc[i][j], cm_off<S>(16 * i + 4 * lg, col, C2) * 4);
                     }
                 }
         }
         __syncthreads();
+        TB_MARK(13);                // rf_pre 1x1
         // ---- the x half of block 0's GRU gates, every direction
 #pragma unroll 1
         for (int d = 0; d < S::ND; ++d)
             gx_gemm<S, FT>(Xb, wb, o.tb_wih[0][0] + d * (o.tb_wih[0][S::ND - 1] - o.tb_wih[0][0]), o.tb_bx[0][0] + d * (o.tb_bx[0][S::ND - 1] - o.tb_bx[0][0]),
                            a.gx + ((size_t)d * a.NF + g0) * (F2 * S::N3), nvalid * F2, wave, lane);
         __syncthreads();                                     // (the next tile's FFT overwrites A1, its encoder A0)
+        TB_MARK(14);                // gx of block 0
     }
 }
 
@@ -396,6 +539,7 @@ __global__ void __launch_bounds__(kThreads) tb_scan_kernel(TbArgs a) {
     constexpr int HW = S::ND * C2;                           // hs row width
     constexpr PackedOffsets o = Pack<S>::v;
     __shared__ float hbuf[2][16 * LDX];
+    __builtin_amdgcn_s_setprio(3);      // a latency chain next to the GEMM passes of other nodes: its few instructions go first
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     const WSrc<false> wb = make_wsrc<S>(a.wp, lane);
@@ -417,20 +561,23 @@ __global__ void __launch_bounds__(kThreads) tb_scan_kernel(TbArgs a) {
             for (int ks = 0; ks < KS; ++ks) whh[j][g][ks] = wb.at_g(w_off + ((g * NT2 + ctc) * KS + ks) * 64);
         bhn[j] = wb.at16_g(bn_off + ctc * 16);
     }
-    // this lane's four rows (C/D layout: rows 4 lg + r) and columns 16 ct + li
-    size_t grow[4], hrow[4];       // element offsets of (row, t = 0) in gx / hs
+    // this lane's four rows (C/D layout: rows 4 lg + r - four consecutive sub-bands of one utterance: R % 4 == 0) and columns 16 ct + li
     bool rok[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        int row = r0 + 4 * lg + r;
-        rok[r] = row < R;
-        row = rok[r] ? row : R - 1;
+    size_t grow, hrow;             // element offsets of (the four rows, t = 0, channel 0) in gx / hs
+    {
+        int row = r0 + 4 * lg;
+        const bool ok = row < R;
+        row = ok ? row : R - 4;
         const int b = row / F2, f = row - b * F2;
-        grow[r] = ((size_t)b * a.T * F2 + f) * N3;
-        hrow[r] = ((size_t)b * a.T * F2 + f) * HW + dir * C2;
+        grow = (size_t)b * a.T * N3 * F2 + f;
+        hrow = ((size_t)b * a.T * HW + dir * C2) * F2 + f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rok[r] = ok;
     }
     const float* gxd = a.gx + (size_t)dir * a.NF * F2 * N3;
-    float* hst = a.hstate ? a.hstate + ((size_t)k * R) * C2 : nullptr;
+    // carried state [KB][ND][Bfull * F2][C2]: this node's rows start at utterance b0
+    float* hst = a.hstate ? a.hstate + (((size_t)(k * S::ND + dir) * a.Bfull + a.b0) * F2) * C2 : nullptr;
+    const bool hinit = a.h_init != 0;
     float hprev[NTPW][4];
 #pragma unroll
     for (int j = 0; j < NTPW; ++j) {
@@ -439,7 +586,7 @@ __global__ void __launch_bounds__(kThreads) tb_scan_kernel(TbArgs a) {
         for (int r = 0; r < 4; ++r) {
             const int row = r0 + 4 * lg + r;
             float v = 0.0f;
-            if (hst != nullptr && live[j] && col < C2 && rok[r]) v = hst[(size_t)row * C2 + col];
+            if (hst != nullptr && hinit && live[j] && col < C2 && rok[r]) v = hst[(size_t)row * C2 + col];
             hprev[j][r] = v;
             if (live[j] && col < C2) hbuf[0][(4 * lg + r) * LDX + col] = v;
         }
@@ -452,9 +599,10 @@ __global__ void __launch_bounds__(kThreads) tb_scan_kernel(TbArgs a) {
             int col = 16 * (wave + 4 * j) + li;
             col = (live[j] && col < C2) ? col : 0;
 #pragma unroll
-            for (int g = 0; g < 3; ++g)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gxv[j][g][r] = gxd[grow[r] + toff + g * C2 + col];
+            for (int g = 0; g < 3; ++g) {
+                const float4 v = *reinterpret_cast<const float4*>(gxd + grow + toff + (size_t)(g * C2 + col) * F2);
+                gxv[j][g][0] = v.x; gxv[j][g][1] = v.y; gxv[j][g][2] = v.z; gxv[j][g][3] = v.w;
+            }
         }
     };
     const int t_first = dir ? a.T - 1 : 0, dt = dir ? -1 : 1;
@@ -502,11 +650,9 @@ __global__ void __launch_bounds__(kThreads) tb_scan_kernel(TbArgs a) {
                 const float nn = tanh_f(gcur[j][2][r] + rr * acc[j][2][r]);
                 const float hv = (1.0f - zz) * nn + zz * hprev[j][r];
                 hprev[j][r] = hv;
-                if (cok) {
-                    hn[(4 * lg + r) * LDX + col] = hv;
-                    if (rok[r]) a.hs[hrow[r] + toff + col] = hv;
-                }
+                if (cok) hn[(4 * lg + r) * LDX + col] = hv;
             }
+            if (cok && rok[0]) *reinterpret_cast<float4*>(a.hs + hrow + toff + (size_t)col * F2) = make_float4(hprev[j][0], hprev[j][1], hprev[j][2], hprev[j][3]);
         }
         cur ^= 1;
         __syncthreads();
@@ -519,6 +665,146 @@ __global__ void __launch_bounds__(kThreads) tb_scan_kernel(TbArgs a) {
             for (int r = 0; r < 4; ++r)
                 if (live[j] && col < C2 && rok[r]) hst[(size_t)(r0 + 4 * lg + r) * C2 + col] = hprev[j][r];
         }
+    }
+}
+
+// The same recurrence for FEW rows (a handful of utterances: 16 rows per workgroup leave most of the chip idle and each step is a
+// chain of 27+ dependent 32-cycle MFMAs): FOUR (utterance, sub-band) rows per workgroup on v_mfma_f32_4x4x1_16B_f32 - sixteen
+// independent 4 x 4 outer products per instruction, 8 cycles.  A wave owns C2 / 4 channels of all three gates; its 16 blocks are
+// (channel block cb) x (K quarter q): lane = 16 cb + 4 q + j supplies h[row j][k] as A and W_g[k][channel 4 cb + j] as B for the k
+// of quarter q, so a gate is C2 / 4 instructions deep instead of C2 / 4 x 4 MFMA tiles wide.  The four quarter sums of a (row,
+// channel) sit in the four lanes q of a DPP row: two rotate-adds leave every lane with all four rows' totals, lane q keeps row q -
+// the gate math then runs on ONE (row, channel) per lane instead of four.  4x the workgroups, ~2.3x shorter steps.
+template <class S>
+__global__ void __launch_bounds__(kThreads) tb_scan4_kernel(TbArgs a) {
+    constexpr int C2 = S::C2, F2 = S::F2, KS = S::KS_2, NT2 = S::NT2, N3 = S::N3;
+    constexpr int HW = S::ND * C2;
+    constexpr int KQ = C2 / 4;                               // instructions per gate: k of one quarter
+    constexpr int KP = (KQ + 3) & ~3;                        // LDS stride of a quarter (16-byte reads)
+    constexpr int LDR = 4 * KP + 4;                          // LDS row stride
+    constexpr int CW = C2 / kWaves;                          // channels per wave
+    constexpr int NCB = ceil_div(CW, 4), NSET = ceil_div(NCB, 4);
+    static_assert(C2 % kWaves == 0, "tb_scan4_kernel: rnnformer channels must be a multiple of 4");
+    constexpr PackedOffsets o = Pack<S>::v;
+    __shared__ __attribute__((aligned(16))) float hbuf[2][4 * LDR];
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = lane >> 4, q = (lane >> 2) & 3, j = lane & 3;
+    const WSrc<false> wb = make_wsrc<S>(a.wp, lane);
+    const int dir = blockIdx.y, k = a.k;
+    const int gsz = NT2 * KS * 64;
+    const int w_off = o.tb_whh[0][0] + k * (S::KB > 1 ? o.tb_whh[1][0] - o.tb_whh[0][0] : 0) + dir * (o.tb_whh[0][S::ND - 1] - o.tb_whh[0][0]);
+    const int bn_off = o.tb_bhn[0][0] + k * (S::KB > 1 ? o.tb_bhn[1][0] - o.tb_bhn[0][0] : 0) + dir * (o.tb_bhn[0][S::ND - 1] - o.tb_bhn[0][0]);
+    // this lane's channel per set, its hidden weights of the quarter's k (gathered out of the 16x16x4 fragment order, once) and b_hn
+    int ch[NSET];
+    bool ok[NSET];
+    float w[NSET][3][KQ], bhn[NSET];
+#pragma unroll
+    for (int s = 0; s < NSET; ++s) {
+        const int cl = 4 * (4 * s + cb) + j;
+        ok[s] = cl < CW;
+        ch[s] = wave * CW + (ok[s] ? cl : 0);
+        const int c = ch[s];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk) {
+                const int kx = q * KQ + kk;
+                w[s][g][kk] = wb.gather_g(w_off + g * gsz + ((c >> 4) * KS + (kx >> 2)) * 64 + (kx & 3) * 16 + (c & 15));
+            }
+        bhn[s] = wb.gather_g(bn_off + c);
+    }
+    // this lane's (row, channel): row = 4 blockIdx.x + q
+    const int row = blockIdx.x * 4 + q;
+    const int b = row / F2, f = row - b * F2;
+    const size_t grow = (size_t)b * a.T * N3 * F2 + f;                          // gx / hs element offsets of (row, t = 0, channel 0)
+    const size_t hrow = ((size_t)b * a.T * HW + dir * C2) * F2 + f;
+    const float* gxd = a.gx + (size_t)dir * a.NF * F2 * N3;
+    float* hst = a.hstate ? a.hstate + (((size_t)(k * S::ND + dir) * a.Bfull + a.b0) * F2) * C2 : nullptr;
+    float hprev[NSET];
+#pragma unroll
+    for (int s = 0; s < NSET; ++s) {
+        float v = 0.0f;
+        if (hst != nullptr && a.h_init != 0 && ok[s]) v = hst[(size_t)row * C2 + ch[s]];
+        hprev[s] = v;
+        if (ok[s]) hbuf[0][q * LDR + (ch[s] / KQ) * KP + ch[s] % KQ] = v;
+    }
+    float gxv[NSET][3];
+    auto load_gx = [&](int t) {
+        const size_t toff = (size_t)t * F2 * N3;
+#pragma unroll
+        for (int s = 0; s < NSET; ++s)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gxv[s][g] = gxd[grow + toff + (size_t)(g * C2 + ch[s]) * F2];
+    };
+    const int t_first = dir ? a.T - 1 : 0, dt = dir ? -1 : 1;
+    load_gx(t_first);
+    __syncthreads();
+    int cur = 0;
+#pragma unroll 1
+    for (int st = 0; st < a.T; ++st) {
+        const int t = t_first + st * dt;
+        // A fragments: h[row j][quarter q]
+        float ha[KP];
+        {
+            const float* hc = hbuf[cur] + j * LDR + q * KP;
+#pragma unroll
+            for (int i = 0; i < KP / 4; ++i) {
+                const float4 v = *reinterpret_cast<const float4*>(hc + 4 * i);
+                ha[4 * i] = v.x; ha[4 * i + 1] = v.y; ha[4 * i + 2] = v.z; ha[4 * i + 3] = v.w;
+            }
+        }
+        float gcur[NSET][3];
+#pragma unroll
+        for (int s = 0; s < NSET; ++s)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gcur[s][g] = gxv[s][g];
+        if (st + 1 < a.T) load_gx(t + dt);                   // next step's x half: in flight under this step
+        f32x4 acc[NSET][3];
+#pragma unroll
+        for (int s = 0; s < NSET; ++s)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[s][g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk)
+#pragma unroll
+            for (int s = 0; s < NSET; ++s)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[s][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(ha[kk], w[s][g][kk], acc[s][g], 0, 0, 0);
+        float* hn = hbuf[cur ^ 1];
+        const size_t toff = (size_t)t * F2 * HW;
+#pragma unroll
+        for (int s = 0; s < NSET; ++s) {
+            float tot[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                float u[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float x = acc[s][g][i];
+                    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));   // row_ror:8
+                    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));   // row_ror:4
+                    u[i] = x;
+                }
+                tot[g] = q == 0 ? u[0] : (q == 1 ? u[1] : (q == 2 ? u[2] : u[3]));
+            }
+            const float rr = sigmoid_f(gcur[s][0] + tot[0]);
+            const float zz = sigmoid_f(gcur[s][1] + tot[1]);
+            const float nn = tanh_f(gcur[s][2] + rr * (tot[2] + bhn[s]));
+            const float hv = (1.0f - zz) * nn + zz * hprev[s];
+            hprev[s] = hv;
+            if (ok[s]) {
+                hn[q * LDR + (ch[s] / KQ) * KP + ch[s] % KQ] = hv;
+                a.hs[hrow + toff + (size_t)ch[s] * F2] = hv;
+            }
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (hst != nullptr) {
+#pragma unroll
+        for (int s = 0; s < NSET; ++s)
+            if (ok[s]) hst[(size_t)row * C2 + ch[s]] = hprev[s];
     }
 }
 
@@ -540,10 +826,11 @@ struct BlkLds {
     static constexpr int TOTAL = U + cmax(TT::ROWS_P * LDH, TT::ROWS_P * (S::LDX + LDGX));
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
     static constexpr bool OK = BYTES <= 160 * 1024;
+    static constexpr int OCC = 2 * BYTES <= 160 * 1024 ? 2 : 1;   // workgroups per CU the plan allows: the register budget follows it
 };
 
 template <class S, int FT>
-__global__ void __launch_bounds__(kThreads) tb_blk_kernel(TbArgs a) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(BlkLds<S, FT>::OCC, BlkLds<S, FT>::OCC))) tb_blk_kernel(TbArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = BlkLds<S, FT>;
     using TT = TokTiling<S, FT>;
@@ -559,30 +846,225 @@ __global__ void __launch_bounds__(kThreads) tb_blk_kernel(TbArgs a) {
     float* const Hl = smem + L::HL;
     float* const Gi = smem + L::GI;
     const int ntiles = (a.NF + FT - 1) / FT;
+    TB_PROBE_INIT(TB_BLK);
+    // Small blocks (T, B, S): this wave's column tiles of EVERY weight matrix of the block stay in registers for the whole launch,
+    // with the biases and - block 0 - the positional embedding of the lane's elements (the rows of a tile always start at
+    // sub-band 0, so a lane meets the same pe entries in every tile).  A token GEMM then moves nothing but its A fragments
+    // (LDS), the residual is the accumulators' initial value (read with the first A fragments instead of after the GEMM), and
+    // the NEXT tile's tokens / GRU outputs are in flight from HBM while this tile computes.
+    constexpr int KSF = S::ND * S::KS_2;
+    constexpr int WREGS = NTPW2 * KSF + NTPW3 * S::KS_2 + NTPW2 * S::KS_2 + S::ND * NTPW3 * S::KS_2;
+    constexpr bool REGW = !L::PERHEAD && WREGS <= 100 && MTT * NTPW3 <= 8;
+    if constexpr (REGW) {
+        float w1[NTPW2][KSF], wq[NTPW3][S::KS_2], w2[NTPW2][S::KS_2], wg[S::ND][NTPW3][S::KS_2];
+        float b1[NTPW2], b2[NTPW2], bg[S::ND][NTPW3], pe[MTT][NTPW2][4];
+        const bool more = k + 1 < S::KB;
+        {
+            const int w1o = S::BIDIR ? o.tb_fc1_w[0] + k * (S::KB > 1 ? o.tb_fc1_w[1] - o.tb_fc1_w[0] : 0) : o.blk_fc1_w[0] + kb;
+#pragma unroll
+            for (int j = 0; j < NTPW2; ++j) {
+                int nt = wave + 4 * j;
+                nt = nt < S::NT2 ? nt : S::NT2 - 1;
+#pragma unroll
+                for (int ks = 0; ks < KSF; ++ks) w1[j][ks] = wb.at_g(w1o + (nt * KSF + ks) * 64);
+#pragma unroll
+                for (int ks = 0; ks < S::KS_2; ++ks) w2[j][ks] = wb.at_g(o.blk_fc2_w[0] + kb + (nt * S::KS_2 + ks) * 64);
+                b1[j] = wb.at16_g(o.blk_fc1_b[0] + kb + nt * 16);
+                b2[j] = wb.at16_g(o.blk_fc2_b[0] + kb + nt * 16);
+                const int col = 16 * nt + li;
+#pragma unroll
+                for (int i = 0; i < MTT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * i + 4 * lg + r;
+                        pe[i][j][r] = (k == 0 && col < C2) ? wb.gather_g(o.blk_pe + (row % F2) * C2 + col) : 0.0f;
+                    }
+            }
+            const int dw = o.tb_wih[0][S::ND - 1] - o.tb_wih[0][0], db = o.tb_bx[0][S::ND - 1] - o.tb_bx[0][0];
+            const int kw = (k + 1) * (S::KB > 1 ? o.tb_wih[1][0] - o.tb_wih[0][0] : 0), kbx = (k + 1) * (S::KB > 1 ? o.tb_bx[1][0] - o.tb_bx[0][0] : 0);
+#pragma unroll
+            for (int j = 0; j < NTPW3; ++j) {
+                int nt = wave + 4 * j;
+                nt = nt < S::NT3 ? nt : S::NT3 - 1;
+#pragma unroll
+                for (int ks = 0; ks < S::KS_2; ++ks) wq[j][ks] = wb.at_g(o.blk_qkv[0] + kb + (nt * S::KS_2 + ks) * 64);
+#pragma unroll
+                for (int d = 0; d < S::ND; ++d) {
+#pragma unroll
+                    for (int ks = 0; ks < S::KS_2; ++ks) wg[d][j][ks] = more ? wb.at_g(o.tb_wih[0][0] + kw + d * dw + (nt * S::KS_2 + ks) * 64) : 0.0f;
+                    bg[d][j] = more ? wb.at16_g(o.tb_bx[0][0] + kbx + d * db + nt * 16) : 0.0f;
+                }
+            }
+        }
+        // the next tile's tokens / GRU outputs: [frame][channel][F2] in global memory, one 16-byte load = four sub-bands of a channel
+        constexpr int F4 = F2 / 4, XQ = FT * C2 * F4, HQ = FT * HW * F4;
+        constexpr int NX = ceil_div(XQ, kThreads), NH = ceil_div(HQ, kThreads);
+        float4 px[NX], ph[NH];
+        auto fetch_tile = [&](int tl) {
+            const int g0 = tl * FT;
+            const int nv = a.NF - g0 < FT ? a.NF - g0 : FT;
+            const float* xg = a.x + (size_t)g0 * (F2 * C2);
+            const float* hg = a.hs + (size_t)g0 * (F2 * HW);
+#pragma unroll
+            for (int q = 0; q < NX; ++q) {
+                int i = tid + q * kThreads;
+                i = i < XQ ? i : XQ - 1;
+                const int fr = i / (C2 * F4), fs = fr < nv ? fr : nv - 1;
+                px[q] = *reinterpret_cast<const float4*>(xg + (size_t)(i - fr * (C2 * F4) + fs * (C2 * F4)) * 4);
+            }
+#pragma unroll
+            for (int q = 0; q < NH; ++q) {
+                int i = tid + q * kThreads;
+                i = i < HQ ? i : HQ - 1;
+                const int fr = i / (HW * F4), fs = fr < nv ? fr : nv - 1;
+                ph[q] = *reinterpret_cast<const float4*>(hg + (size_t)(i - fr * (HW * F4) + fs * (HW * F4)) * 4);
+            }
+        };
+        auto park_tile = [&]() {
+#pragma unroll
+            for (int q = 0; q < NX; ++q) {
+                int i = tid + q * kThreads;
+                i = i < XQ ? i : XQ - 1;                                  // (the threads past the end store the last element again)
+                const int fr = i / (C2 * F4), qq = i - fr * (C2 * F4), c = qq / F4, f4 = qq - c * F4;
+                float* d = Xb + (fr * F2 + 4 * f4) * LDX + c;
+                d[0] = px[q].x; d[LDX] = px[q].y; d[2 * LDX] = px[q].z; d[3 * LDX] = px[q].w;
+            }
+#pragma unroll
+            for (int q = 0; q < NH; ++q) {
+                int i = tid + q * kThreads;
+                i = i < HQ ? i : HQ - 1;
+                const int fr = i / (HW * F4), qq = i - fr * (HW * F4), c = qq / F4, f4 = qq - c * F4;
+                float* d = Hs + (fr * F2 + 4 * f4) * LDH + c;
+                d[0] = ph[q].x; d[LDH] = ph[q].y; d[2 * LDH] = ph[q].z; d[3 * LDH] = ph[q].w;
+            }
+        };
+        if ((int)blockIdx.x < ntiles) { fetch_tile(blockIdx.x); park_tile(); }
+        __syncthreads();
+        TB_MARK(0);
+#pragma unroll 1
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const int g0 = tile * FT;
+            const int nvalid = a.NF - g0 < FT ? a.NF - g0 : FT;
+            const int rows_valid = nvalid * F2;
+            const int nxt = tile + gridDim.x;
+            if (nxt < ntiles) fetch_tile(nxt);
+            // ---- x += rnn_fc(h) (+ pe in block 0)   (model.py:273-280; noncausal: K = 2 C2)
+            {
+                f32x4 acc[MTT][NTPW2];
+#pragma unroll
+                for (int i = 0; i < MTT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTPW2; ++j) {
+                        int nt = wave + 4 * j;
+                        nt = nt < S::NT2 ? nt : S::NT2 - 1;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][j][r] = Xb[(16 * i + 4 * lg + r) * LDX + 16 * nt + li] + (b1[j] + pe[i][j][r]);
+                    }
+                tok_panel_rb<MTT, NTPW2, KSF, LDH>(acc, Hs + li * LDH + lg, [&](int j, int ks) { return w1[j][ks]; });
+#pragma unroll
+                for (int i = 0; i < MTT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTPW2; ++j) {
+                        const int nt = wave + 4 * j, col = 16 * nt + li;
+                        if (nt < S::NT2 && col < C2) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) Xb[(16 * i + 4 * lg + r) * LDX + col] = acc[i][j][r];
+                        }
+                    }
+            }
+            __syncthreads();
+            TB_MARK(1);
+            // ---- qkv = x W_qkv^T  (rows per head interleaved [h][q|k|v][hd], model.py:142-146)
+            {
+                f32x4 acc[MTT][NTPW3];
+                acc_init_zero<MTT, NTPW3>(acc);
+                tok_panel_rb<MTT, NTPW3, S::KS_2, LDX>(acc, Xb + li * LDX + lg, [&](int j, int ks) { return wq[j][ks]; });
+#pragma unroll
+                for (int j = 0; j < NTPW3; ++j) {
+                    const int nt = wave + 4 * j;
+                    if (nt < S::NT3) {
+#pragma unroll
+                        for (int i = 0; i < MTT; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) Gi[(16 * i + 4 * lg + r) * LDG + 16 * nt + li] = acc[i][j][r];
+                    }
+                }
+            }
+            __syncthreads();
+            TB_MARK(2);
+            // ---- attention over the F2 tokens of each frame, wave = head; O -> Hl[token][head * hd + d]
+#pragma unroll
+            for (int f = 0; f < FT; ++f)
+                attention_head<S, S::MT2, LDG, 3>(Gi + f * F2 * LDG, Hl + f * F2 * LDX, wave * 3 * HD, wave, 0, 1, lane);
+            __syncthreads();
+            TB_MARK(3);
+            // ---- x += attn_fc(o)   (model.py:282-290) -> LDS and the token stream in global memory
+            {
+                f32x4 acc[MTT][NTPW2];
+#pragma unroll
+                for (int i = 0; i < MTT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTPW2; ++j) {
+                        int nt = wave + 4 * j;
+                        nt = nt < S::NT2 ? nt : S::NT2 - 1;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][j][r] = Xb[(16 * i + 4 * lg + r) * LDX + 16 * nt + li] + b2[j];
+                    }
+                tok_panel_rb<MTT, NTPW2, S::KS_2, LDX>(acc, Hl + li * LDX + lg, [&](int j, int ks) { return w2[j][ks]; });
+                const __amdgpu_buffer_rsrc_t xr = range_rsrc(a.x + (size_t)g0 * (F2 * C2), (size_t)rows_valid * C2 * 4);
+#pragma unroll
+                for (int i = 0; i < MTT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTPW2; ++j) {
+                        const int nt = wave + 4 * j, col = 16 * nt + li;
+                        if (nt < S::NT2 && col < C2) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) Xb[(16 * i + 4 * lg + r) * LDX + col] = acc[i][j][r];
+                            bstore4(xr, acc[i][j], cm_off<S>(16 * i + 4 * lg, col, C2) * 4);
+                        }
+                    }
+            }
+            __syncthreads();
+            TB_MARK(4);
+            // ---- the x half of the next block's GRU gates
+            if (more) {
+#pragma unroll
+                for (int d = 0; d < S::ND; ++d) {
+                    f32x4 acc[MTT][NTPW3];
+#pragma unroll
+                    for (int j = 0; j < NTPW3; ++j)
+#pragma unroll
+                        for (int i = 0; i < MTT; ++i) acc[i][j] = f32x4{bg[d][j], bg[d][j], bg[d][j], bg[d][j]};
+                    tok_panel_rb<MTT, NTPW3, S::KS_2, LDX>(acc, Xb + li * LDX + lg, [&](int j, int ks) { return wg[d][j][ks]; });
+                    const __amdgpu_buffer_rsrc_t gr = range_rsrc(a.gx + ((size_t)d * a.NF + g0) * (F2 * S::N3), (size_t)rows_valid * S::N3 * 4);
+#pragma unroll
+                    for (int j = 0; j < NTPW3; ++j) {
+                        const int nt = wave + 4 * j, col = 16 * nt + li;
+                        if (nt < S::NT3 && col < S::N3) {
+#pragma unroll
+                            for (int i = 0; i < MTT; ++i) bstore4(gr, acc[i][j], cm_off<S>(16 * i + 4 * lg, col, S::N3) * 4);
+                        }
+                    }
+                }
+            }
+            __syncthreads();                                     // (every wave is done with Xb / Hl / Gi)
+            TB_MARK(5);
+            if (nxt < ntiles) park_tile();
+            __syncthreads();
+            TB_MARK(0);
+        }
+        return;
+    }
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int g0 = tile * FT;
         const int nvalid = a.NF - g0 < FT ? a.NF - g0 : FT;
         const int rows_valid = nvalid * F2;
-        // ---- the tile's tokens and GRU outputs: contiguous rows in global memory, 16-byte loads (rows past the batch: clamped)
-        {
-            const float* xg = a.x + (size_t)g0 * (F2 * C2);
-            const float* hg = a.hs + (size_t)g0 * (F2 * HW);
-            constexpr int XQ = C2 / 4, HQ = HW / 4;
-            for (int i = tid; i < TT::ROWS * XQ; i += kThreads) {
-                const int row = i / XQ, c4 = i - row * XQ, rs = row < rows_valid ? row : rows_valid - 1;
-                const float4 v = *reinterpret_cast<const float4*>(xg + (size_t)rs * C2 + 4 * c4);
-                float2* d = reinterpret_cast<float2*>(Xb + row * LDX + 4 * c4);
-                d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
-            }
-            for (int i = tid; i < TT::ROWS * HQ; i += kThreads) {
-                const int row = i / HQ, c4 = i - row * HQ, rs = row < rows_valid ? row : rows_valid - 1;
-                const float4 v = *reinterpret_cast<const float4*>(hg + (size_t)rs * HW + 4 * c4);
-                float2* d = reinterpret_cast<float2*>(Hs + row * LDH + 4 * c4);
-                d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
-            }
-        }
+        // ---- the tile's tokens and GRU outputs: [frame][channel][F2] in global memory, 16-byte loads (frames past the batch: clamped)
+        load_tokens<S, FT, C2, LDX>(a.x + (size_t)g0 * (F2 * C2), nvalid, Xb, tid);
+        load_tokens<S, FT, HW, LDH>(a.hs + (size_t)g0 * (F2 * HW), nvalid, Hs, tid);
         __syncthreads();
+        TB_MARK(0);                 // loads of x, hs
         // ---- x += rnn_fc(h) (+ pe in block 0)   (model.py:273-280; noncausal: K = 2 C2)
         {
             f32x4 acc[MTT][NTPW2];
@@ -613,6 +1095,7 @@ __global__ void __launch_bounds__(kThreads) tb_blk_kernel(TbArgs a) {
                 }
         }
         __syncthreads();
+        TB_MARK(1);                 // rnn_fc
         // ---- qkv = x W_qkv^T (rows per head interleaved [h][q|k|v][hd], model.py:142-146) and the attention over the F2 tokens of
         // each frame; O -> Hl[token][head * hd + d]
         if constexpr (!L::PERHEAD) {
@@ -640,6 +1123,7 @@ __global__ void __launch_bounds__(kThreads) tb_blk_kernel(TbArgs a) {
                 }
             }
             __syncthreads();
+            TB_MARK(2);             // qkv
             // wave = head, frame after frame
 #pragma unroll 1
             for (int f = 0; f < FT; ++f)
@@ -675,6 +1159,7 @@ __global__ void __launch_bounds__(kThreads) tb_blk_kernel(TbArgs a) {
             }
         }
         if constexpr (!L::PERHEAD) __syncthreads();
+        TB_MARK(3);                 // attention (per-head shapes: qkv + attention)
         // ---- x += attn_fc(o)   (model.py:282-290) -> LDS and the token stream in global memory
         {
             f32x4 acc[MTT][NTPW2];
@@ -687,24 +1172,26 @@ __global__ void __launch_bounds__(kThreads) tb_blk_kernel(TbArgs a) {
                 for (int i = 0; i < MTT; ++i) acc[i][j] = f32x4{bj, bj, bj, bj};
             }
             tok_panel<MTT, NTPW2, S::KS_2, LDX>(acc, Hl + li * LDX + lg, wb, o.blk_fc2_w[0] + kb, S::NT2, wave);
-            float* xg = a.x + (size_t)g0 * (F2 * C2);
+            const __amdgpu_buffer_rsrc_t xr = range_rsrc(a.x + (size_t)g0 * (F2 * C2), (size_t)rows_valid * C2 * 4);
 #pragma unroll
             for (int i = 0; i < MTT; ++i)
 #pragma unroll
                 for (int j = 0; j < NTPW2; ++j) {
                     const int nt = wave + 4 * j, col = 16 * nt + li;
                     if (nt < S::NT2 && col < C2) {
+                        f32x4 v;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int row = 16 * i + 4 * lg + r;
-                            const float v = acc[i][j][r] + Xb[row * LDX + col];
-                            Xb[row * LDX + col] = v;
-                            if (row < rows_valid) xg[(size_t)row * C2 + col] = v;
+                            v[r] = acc[i][j][r] + Xb[row * LDX + col];
+                            Xb[row * LDX + col] = v[r];
                         }
+                        bstore4(xr, v, cm_off<S>(16 * i + 4 * lg, col, C2) * 4);
                     }
                 }
         }
         __syncthreads();
+        TB_MARK(4);                 // attn_fc
         // ---- the x half of the next block's GRU gates
         if (k + 1 < S::KB) {
             const int dw = o.tb_wih[0][S::ND - 1] - o.tb_wih[0][0], db = o.tb_bx[0][S::ND - 1] - o.tb_bx[0][0];
@@ -714,6 +1201,7 @@ __global__ void __launch_bounds__(kThreads) tb_blk_kernel(TbArgs a) {
                 gx_gemm<S, FT>(Xb, wb, o.tb_wih[0][0] + kw + d * dw, o.tb_bx[0][0] + kbx + d * db, a.gx + ((size_t)d * a.NF + g0) * (F2 * S::N3), rows_valid, wave, lane);
         }
         __syncthreads();
+        TB_MARK(5);                 // gx of the next block
     }
 }
 
@@ -753,23 +1241,30 @@ __global__ void __launch_bounds__(kThreads) tb_dec_kernel(TbArgs a) {
     D::load(idc, wb, o, wave);
     const int ntiles = (a.NF + FT - 1) / FT;
     constexpr size_t SKF = (size_t)(S::NL + 1) * F1 * C1;
+    constexpr int NPT = N / kThreads, NB = FT * F0 / kThreads;
+    constexpr bool PARD = FT * 3 * N <= FT * S::ACT && F0 % kThreads == 0;       // every frame of the tile has its own inverse-transform scratch in Wx
+    float ow[NPT], xcr[NB][2];
+#pragma unroll
+    for (int q = 0; q < NPT; ++q) ow[q] = (a.wp + o.window)[tid + q * kThreads];
     __syncthreads();
+    TB_PROBE_INIT(TB_DEC);
+    TB_MARK(0);                     // prologue
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int g0 = tile * FT;
         const int nvalid = a.NF - g0 < FT ? a.NF - g0 : FT;
         const int rows_valid = nvalid * F2;
-        {
-            const float* xg = a.x + (size_t)g0 * (F2 * C2);
-            constexpr int XQ = C2 / 4;
-            for (int i = tid; i < FT * F2 * XQ; i += kThreads) {
-                const int row = i / XQ, c4 = i - row * XQ, rs = row < rows_valid ? row : rows_valid - 1;
-                const float4 v = *reinterpret_cast<const float4*>(xg + (size_t)rs * C2 + 4 * c4);
-                float2* d = reinterpret_cast<float2*>(Xb + row * LDX + 4 * c4);
-                d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
+        load_tokens<S, FT, C2, LDX>(a.x + (size_t)g0 * (F2 * C2), nvalid, Xb, tid);
+        if constexpr (PARD) {       // the frames' compressed input spectra (the mask multiplies them at the end of the tile): in flight under the GEMMs
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int i = tid + q * kThreads, f = i / F0, fb = i - f * F0;
+                const float* xcg = a.xc + (size_t)(g0 + (f < nvalid ? f : nvalid - 1)) * (2 * F0);
+                xcr[q][0] = xcg[fb]; xcr[q][1] = xcg[F0 + fb];
             }
         }
         __syncthreads();
+        TB_MARK(1);                 // load of x
         // the tile's encoder outputs as a buffer resource (coalesced A-fragment reads)
         WSrc<false> skb;
         {
@@ -802,6 +1297,7 @@ __global__ void __launch_bounds__(kThreads) tb_dec_kernel(TbArgs a) {
             }
         }
         __syncthreads();
+        TB_MARK(2);                 // rf_post filterbank
         // ---- decoder (model.py:492-506): 1x1 on cat([x, skip]) as two K segments (layer 0: x = Y2 with rf_post's 1x1 folded into
         // the weights on the host, fe_api.hip), then the k = 3 conv
         static_for<S::NL>([&](auto l_) {
@@ -818,9 +1314,11 @@ __global__ void __launch_bounds__(kThreads) tb_dec_kernel(TbArgs a) {
                     }, wb, o.dec1_w[l], o.dec1_b[l], Wy, nullptr, 0, nvalid, wave, lane);
             }
             __syncthreads();
+            TB_MARK(3 + 2 * l);     // decoder layer l, 1x1
             conv_gemm<S, FT, 3 * S::KS_C, true, C1, LDC, S::ACT, 1>(K3Src<S, FT>{Wy + (16 * wm + li) * LDC + lg}, wb, o.dec3_w[l], o.dec3_b[l], Wx,
                                                                      nullptr, 0, nvalid, wave, lane);
             __syncthreads();
+            TB_MARK(4 + 2 * l);     // decoder layer l, k = 3
         });
         // ---- dec_post (model.py:508-521): 1x1 on cat([x, enc_pre output]), then the transposed conv as a [F1 x C1].[C1 x 16] GEMM
         {
@@ -833,24 +1331,78 @@ __global__ void __launch_bounds__(kThreads) tb_dec_kernel(TbArgs a) {
                 }, wb, o.post1_w, o.post1_b, Wy, nullptr, 0, nvalid, wave, lane);
         }
         __syncthreads();
+        TB_MARK(20);                // dec_post 1x1
         {
             const float* x0 = Wy + (16 * wm + li + 1) * LDC + lg;
             conv_gemm<S, FT, S::KS_C, false, 16, S::LDP, F1 * S::LDP, 0>(
                 [&](int i, int ks) { return x0[CT::frame(i) * S::ACT + (16 * CT::mtile0(i)) * LDC + 4 * ks]; }, wb, o.post_t_w, -1, PT, nullptr, 0, nvalid, wave, lane);
         }
         __syncthreads();
-        // ---- mask, un-compress (model.py:694-709), inverse DFT + synthesis window (functional/audio_modules.py:117-119), frame by frame
+        TB_MARK(21);                // transposed conv
+        // ---- mask, un-compress (model.py:694-709), inverse DFT + synthesis window (functional/audio_modules.py:117-119)
+        const float b0 = wb.scalar(o.post_t_b), b1 = wb.scalar(o.post_t_b + 1);
+        if constexpr (PARD) {
+            // all frames of the tile at once: the compressed input spectrum was fetched at the top of the tile (xcr), every frame has its own
+            // transform scratch (spectrum | two partial outputs, 3 N floats in Wx), the transforms run back to back
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int i = tid + q * kThreads, f = i / F0, fb = i - f * F0;
+                const int g = g0 + (f < nvalid ? f : nvalid - 1), bl = g / a.T, t = a.t0 + (g - bl * a.T), b = a.b0 + bl, TF = a.Tfull;
+                const float* PTf = PT + f * (F1 * S::LDP);
+                const int qq = fb + 2, j1 = qq & 3, i1 = qq >> 2;
+                float m0 = b0, m1 = b1;
+                if (i1 < F1) { m0 += PTf[i1 * S::LDP + j1]; m1 += PTf[i1 * S::LDP + 8 + j1]; }
+                if (i1 >= 1) { m0 += PTf[(i1 - 1) * S::LDP + j1 + 4]; m1 += PTf[(i1 - 1) * S::LDP + 8 + j1 + 4]; }
+                const float xr = xcr[q][0], xi = xcr[q][1];
+                float yr = xr * m0 - xi * m1, yi = xr * m1 + xi * m0;
+                if (a.mode == FE_MODE_OFFLINE && f < nvalid) {
+                    float* sph = a.spec_out + (size_t)b * F0 * TF * 2;
+                    *reinterpret_cast<float2*>(sph + ((size_t)fb * TF + t) * 2) = make_float2(yr, yi);
+                }
+                const float mag = sqrtf(yr * yr + yi * yi);
+                const float gn = pow_f(mag, 1.0f / a.compression - 1.0f);
+                yr *= gn; yi *= gn;
+                if (a.mode == FE_MODE_SPEC) {
+                    if (f < nvalid) {
+                        float* spo = a.spec_out + (size_t)b * (F0 + 1) * TF * 2;
+                        *reinterpret_cast<float2*>(spo + ((size_t)fb * TF + t) * 2) = make_float2(yr, yi);
+                        if (fb == 0) *reinterpret_cast<float2*>(spo + ((size_t)F0 * TF + t) * 2) = make_float2(0.0f, 0.0f);
+                    }
+                } else {
+                    float* q3 = Wx + f * 3 * N + 2 * N;
+                    q3[fb] = yr;
+                    q3[N / 2 + fb] = yi;
+                }
+            }
+            if (a.mode != FE_MODE_SPEC) {
+                __syncthreads();
+#pragma unroll 1
+                for (int f = 0; f < FT; ++f) D::inverse(Wx + f * 3 * N + 2 * N, Wx + f * 3 * N, Wx + f * 3 * N + N, tw, idc, wb, o, wave, lane);       // (each ends with a barrier)
+#pragma unroll 1
+                for (int f = 0; f < nvalid; ++f) {
+                    const int g = g0 + f, bl = g / a.T, t = a.t0 + (g - bl * a.T), b = a.b0 + bl;
+                    float* fr = a.frames + ((size_t)b * a.Tfull + t) * N;
+                    const float* q0 = Wx + f * 3 * N;
+#pragma unroll
+                    for (int q = 0; q < NPT; ++q) {
+                        const int n = tid + q * kThreads;
+                        const int pi = D::pidx(n & (D::N1 - 1), n / D::N1);
+                        fr[n] = (q0[pi] + q0[N + pi]) * ow[q];
+                    }
+                }
+            }
+        } else {
         float* const q0 = Wx;
         float* const q1 = Wx + N;
         float* const q3 = Wx + 3 * N;
-        const float b0 = wb.scalar(o.post_t_b), b1 = wb.scalar(o.post_t_b + 1);
 #pragma unroll 1
         for (int f = 0; f < nvalid; ++f) {
-            const int g = g0 + f, b = g / a.T, t = g - b * a.T;
+            const int g = g0 + f, bl = g / a.T, t = a.t0 + (g - bl * a.T), b = a.b0 + bl;
+            const int TF = a.Tfull;
             const float* xcg = a.xc + (size_t)g * (2 * F0);
             const float* PTf = PT + f * (F1 * S::LDP);
-            float* spo = a.mode == FE_MODE_SPEC ? a.spec_out + (size_t)b * (F0 + 1) * a.T * 2 : nullptr;
-            float* sph = a.mode == FE_MODE_OFFLINE ? a.spec_out + (size_t)b * F0 * a.T * 2 : nullptr;
+            float* spo = a.mode == FE_MODE_SPEC ? a.spec_out + (size_t)b * (F0 + 1) * TF * 2 : nullptr;
+            float* sph = a.mode == FE_MODE_OFFLINE ? a.spec_out + (size_t)b * F0 * TF * 2 : nullptr;
             for (int fb = tid; fb < F0; fb += kThreads) {
                 const int q = fb + 2, j1 = q & 3, i1 = q >> 2;
                 float m0 = b0, m1 = b1;
@@ -858,14 +1410,14 @@ __global__ void __launch_bounds__(kThreads) tb_dec_kernel(TbArgs a) {
                 if (i1 >= 1) { m0 += PTf[(i1 - 1) * S::LDP + j1 + 4]; m1 += PTf[(i1 - 1) * S::LDP + 8 + j1 + 4]; }
                 const float xr = xcg[fb], xi = xcg[F0 + fb];
                 float yr = xr * m0 - xi * m1, yi = xr * m1 + xi * m0;
-                if (sph != nullptr) { sph[((size_t)fb * a.T + t) * 2] = yr; sph[((size_t)fb * a.T + t) * 2 + 1] = yi; }
+                if (sph != nullptr) { sph[((size_t)fb * TF + t) * 2] = yr; sph[((size_t)fb * TF + t) * 2 + 1] = yi; }
                 const float mag = sqrtf(yr * yr + yi * yi);
                 const float gn = pow_f(mag, 1.0f / a.compression - 1.0f);
                 yr *= gn; yi *= gn;
                 if (spo != nullptr) {
-                    spo[((size_t)fb * a.T + t) * 2] = yr;
-                    spo[((size_t)fb * a.T + t) * 2 + 1] = yi;
-                    if (fb == 0) { spo[((size_t)F0 * a.T + t) * 2] = 0.0f; spo[((size_t)F0 * a.T + t) * 2 + 1] = 0.0f; }
+                    spo[((size_t)fb * TF + t) * 2] = yr;
+                    spo[((size_t)fb * TF + t) * 2 + 1] = yi;
+                    if (fb == 0) { spo[((size_t)F0 * TF + t) * 2] = 0.0f; spo[((size_t)F0 * TF + t) * 2 + 1] = 0.0f; }
                 } else {
                     q3[fb] = yr;
                     q3[N / 2 + fb] = yi;
@@ -873,13 +1425,8 @@ __global__ void __launch_bounds__(kThreads) tb_dec_kernel(TbArgs a) {
             }
             if (a.mode != FE_MODE_SPEC) {
                 __syncthreads();
-                const float* wi = a.wp + o.window;
-                constexpr int NPT = N / kThreads;
-                float ow[NPT];
-#pragma unroll
-                for (int q = 0; q < NPT; ++q) ow[q] = wi[tid + q * kThreads];
                 D::inverse(q3, q0, q1, tw, idc, wb, o, wave, lane);       // (ends with a barrier)
-                float* fr = a.frames + (size_t)g * N;
+                float* fr = a.frames + ((size_t)b * TF + t) * N;
 #pragma unroll
                 for (int q = 0; q < NPT; ++q) {
                     const int n = tid + q * kThreads;
@@ -889,7 +1436,9 @@ __global__ void __launch_bounds__(kThreads) tb_dec_kernel(TbArgs a) {
                 __syncthreads();
             }
         }
+        }
         __syncthreads();
+        TB_MARK(22);                // mask, un-compress, inverse DFT, window
     }
 }
 
@@ -906,8 +1455,6 @@ struct TbCfg {
     static constexpr int FT_E = pick_ft<EncLds, S>(), FT_B = pick_ft<BlkLds, S>(), FT_D = pick_ft<DecLds, S>();
     static_assert(EncLds<S, FT_E>::OK && BlkLds<S, FT_B>::OK && DecLds<S, FT_D>::OK, "time-batched engine: an LDS plan does not fit");
 };
-
-enum { TB_ENC = 0, TB_SCAN = 1, TB_BLK = 2, TB_DEC = 3 };
 
 struct TbImpl {
     int ft[4];                  // frames per tile of the stage (scan: 0)
@@ -946,7 +1493,15 @@ void tb_launch(int stage, const TbArgs& a, int max_wgs, hipStream_t st, hipError
         if (*err != hipSuccess) return;
         hipLaunchKernelGGL(k, dim3(grid_for(C::FT_E, lds)), dim3(kThreads), lds, st, a);
     } else if (stage == TB_SCAN) {
-        hipLaunchKernelGGL((tb_scan_kernel<S>), dim3((a.B * S::F2 + 15) / 16, S::ND), dim3(kThreads), 0, st, a);
+        // 16 rows per workgroup when that fills the chip (the MFMA throughput of the 16x16x4 tiles is what counts then), else 4
+        static const int force = [] { const char* v = std::getenv("FE_TB_SCAN_ROWS"); return v ? std::atoi(v) : 0; }();
+        const int wg16 = ((a.B * S::F2 + 15) / 16) * S::ND;
+        const int wg4 = (a.B * S::F2 / 4) * S::ND;
+        (void)wg16;
+        if (force == 16 || (force != 4 && 4 * wg4 > 5 * max_wgs))        // (two 4-row workgroups on a CU take turns on its SIMDs: no gain beyond ~1 per CU)
+            hipLaunchKernelGGL((tb_scan_kernel<S>), dim3((a.B * S::F2 + 15) / 16, S::ND), dim3(kThreads), 0, st, a);
+        else
+            hipLaunchKernelGGL((tb_scan4_kernel<S>), dim3(a.B * S::F2 / 4, S::ND), dim3(kThreads), 0, st, a);
     } else if (stage == TB_BLK) {
         auto* k = &tb_blk_kernel<S, C::FT_B>;
         constexpr size_t lds = BlkLds<S, C::FT_B>::BYTES;

@@ -68,14 +68,14 @@ def main():
     print("after the encoder segment")
     xc = bufs[0].reshape(NF, 2, cfg.F0)
     rep("compressed spectrum", xc, spec.transpose(0, 2, 3, 1).reshape(NF, 2, cfg.F0))
-    rep("x = rf_pre", bufs[2].reshape(NF, F2, C2), tok(taps["rf_pre"]))
+    rep("x = rf_pre", bufs[2].reshape(NF, C2, F2).transpose(0, 2, 1), tok(taps["rf_pre"]))      # (work buffers: [frame][channel][sub-band])
     w = orc.w
     for d, sfx in enumerate(("", "_reverse")[:nd]):
         p = "rf_block.0.rnn."
         xs = tok(taps["rf_pre"])
         gxr = xs @ w[p + "weight_ih_l0" + sfx].T + w[p + "bias_ih_l0" + sfx]
         gxr[..., :2 * C2] += w[p + "bias_hh_l0" + sfx][:2 * C2]
-        rep(f"gx block 0 dir {d}", bufs[3].reshape(nd, NF, F2, 3 * C2)[d], gxr)
+        rep(f"gx block 0 dir {d}", bufs[3].reshape(nd, NF, 3 * C2, F2)[d].transpose(0, 2, 1), gxr)
     stage = 1
     xin = taps["rf_pre"]
     for k in range(KB):
@@ -90,11 +90,11 @@ def main():
             for t in (range(T) if d == 0 else range(T - 1, -1, -1)):
                 h = gru_step(xs[t], h, w[p + "weight_ih_l0" + sfx], w[p + "weight_hh_l0" + sfx], w[p + "bias_ih_l0" + sfx], w[p + "bias_hh_l0" + sfx])
                 ys[t, :, d * C2:(d + 1) * C2] = h
-        rep("hs", bufs[4].reshape(NF, F2, nd * C2), tok(ys.reshape(T, B, F2, nd * C2)))
+        rep("hs", bufs[4].reshape(NF, nd * C2, F2).transpose(0, 2, 1), tok(ys.reshape(T, B, F2, nd * C2)))
         stage += 1
         _, _, bufs = run(stage)
         print(f"after the attention pass of block {k}")
-        rep("x", bufs[2].reshape(NF, F2, C2), tok(taps[f"rf_block.{k}"]))
+        rep("x", bufs[2].reshape(NF, C2, F2).transpose(0, 2, 1), tok(taps[f"rf_block.{k}"]))
         xin = taps[f"rf_block.{k}"]
     os.environ.pop("FE_TB_STAGES")
     wav, sp, _ = run(1 << 20)
