@@ -173,6 +173,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     float* X = smem + L::X;
     float* Hs = smem + L::HS;
     float* Hn = smem + L::HN;
+    float* Cn = smem + L::YF;         // the time-LSTM's new cell state on its way to the state buffer (Yf is not live yet in that phase)
     float* Yf = smem + L::YF;
     float* Hb = smem + L::HB;
     float* XPl = smem + L::XP;
@@ -245,6 +246,13 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     int b = blockIdx.x;
 #pragma unroll 1
     do {
+    // An opaque zero per stream: the per-thread weight addresses of the phases far down the frame (band split, mask MLPs) do not depend on the
+    // stream, so hipcc computed them above this loop and kept them alive through the whole frame - 29 to 35 spilled registers whose scratch
+    // stores, made once per workgroup, were 40 % of the kernel's HBM writes (profiles/pmc_r2_bsrnn_xt.json).  Made loop-variant they are
+    // computed where they are used.
+    int oz = 0;
+    asm volatile("" : "+v"(oz));
+    const int tidv = tid + oz;
     float* cst = a.cache_stft + (size_t)b * OVL;
     float* cis = a.cache_istft + (size_t)b * OVL;
     float* dbg = DBG ? a.dbg + (size_t)b * a.dbg_stride : nullptr;
@@ -378,9 +386,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                         const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[0][3][r]));
                         const float cn = fg * cprev[r] + ig * gg;
                         const float hn = og * tanh_f(cn);
-                        if (row < kBands) {
-                            cg[row * HH + j] = cn;
-                            hg[row * HH + j] = hn;
+                        if (row < kBands) {        // (the state goes out after the barrier, coalesced: an accumulator lane's four rows are 4-byte
+                            Cn[row * LDH + j] = cn;    //  pieces of four different 128-byte lines - written from here, WRITE_SIZE was 1.7x the state)
                             Hn[row * LDH + j] = hn;
                         }
                     }
@@ -398,6 +405,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 }
             }
             __syncthreads();
+            {
+                // the layer's new (h, c) -> the state, consecutive threads = consecutive floats of the [31][HH] tensors
+#pragma unroll
+                for (int q = 0; q < HPT; ++q) {
+                    const int i = tid + q * kThreads, ic = i < kBands * HH ? i : kBands * HH - 1, r = ic / HH, c = ic - r * HH;
+                    const float hv = Hn[r * LDH + c], cv = Cn[r * LDH + c];
+                    if (i < kBands * HH) { hg[i] = hv; cg[i] = cv; }
+                }
+            }
             if (l == 0) BE_CLK(3);
             {
                 // fc_time + residual (:382-384): X += Hn W^T + b
@@ -665,7 +681,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             constexpr int NOUT = 2 * kBands * 4 * C, ROUNDS = (NOUT + kThreads - 1) / kThreads, R4 = C / 4;
             constexpr int D = OCC2 ? 2 : (R4 <= 4 ? 8 : (R4 <= 8 ? 4 : 2));      // rows in flight: under load the L2 round trip is ~1 us, the ring holds 32 KB per wave
             const int rot = (int)(blockIdx.x >> 3) % ROUNDS;
-            auto out_of = [&](int r) { int rr = r + rot; rr = rr >= ROUNDS ? rr - ROUNDS : rr; return tid + rr * kThreads; };
+            auto out_of = [&](int r) { int rr = r + rot; rr = rr >= ROUNDS ? rr - ROUNDS : rr; return tidv + rr * kThreads; };
             auto load_row = [&](int r, float4 (&wv)[R4], float& bias) {
                 if (r < ROUNDS) {
                     const int i = out_of(r), ii = i < NOUT ? i : NOUT - 1;
@@ -714,7 +730,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             constexpr int NROW = 2 * kMlpRows, ROUNDS = (NROW + kThreads - 1) / kThreads, NIT = ROUNDS * NCH, D = OCC2 ? 1 : 3;
             const int* row_band = reinterpret_cast<const int*>(wp + o.row_band);
             const int rot = (int)(blockIdx.x >> 3) % ROUNDS;
-            auto out_of = [&](int r) { int rr = r + rot; rr = rr >= ROUNDS ? rr - ROUNDS : rr; return tid + rr * kThreads; };
+            auto out_of = [&](int r) { int rr = r + rot; rr = rr >= ROUNDS ? rr - ROUNDS : rr; return tidv + rr * kThreads; };
             // the bins' row tables for the GLU below: fetched now (a dependent load there would be exposed)
             constexpr int FPT = (kBins + kThreads - 1) / kThreads;
             int bra[FPT], brg[FPT];
