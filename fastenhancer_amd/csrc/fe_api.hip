@@ -119,6 +119,7 @@ struct fe_handle {
     std::vector<hipStream_t> tb_streams;      // time-batched engine: the streams its nodes are spread over (lazy; tb_run)
     std::vector<hipEvent_t> tb_events;        // ... and its event pool
     unsigned long long* tb_probe_dev = nullptr;   // FE_TB_PROBE builds: phase clocks [4][kProbeSlots]
+    unsigned int* tb_prog_dev = nullptr;      // fused stages: the scan workgroups' frame counters [KB][2 * max_wgs]
     std::vector<Section> sections;
     size_t blob_floats = 0;
     float* packed_dev = nullptr;
@@ -1328,6 +1329,7 @@ void fe_destroy(fe_handle* h) {
     for (hipStream_t s : h->tb_streams) (void)hipStreamDestroy(s);
     for (hipEvent_t e : h->tb_events) (void)hipEventDestroy(e);
     if (h->tb_probe_dev) (void)hipFree(h->tb_probe_dev);
+    if (h->tb_prog_dev) (void)hipFree(h->tb_prog_dev);
     delete h;
 }
 
@@ -1577,7 +1579,7 @@ static size_t tb_work_floats(const fe_handle* h, int B, int T, size_t* off /*[7]
 // the latency-bound scans of one node (16 rows per workgroup, one recurrence step after the other) run UNDER the GEMM passes
 // of the others instead of leaving the chip idle between them, and - a single utterance - the scans of consecutive blocks
 // pipeline through the chunks.  The noncausal model's reverse scan needs all frames of an utterance: utterance groups only.
-struct TbPlan { int G, NC, NS, stagger; };
+struct TbPlan { int G, NC, NS, stagger, fuse; };
 
 static TbPlan tb_plan(const fe_handle* h, int B, int T) {
     auto env = [](const char* n, int dflt) { const char* v = std::getenv(n); return v ? std::atoi(v) : dflt; };
@@ -1591,7 +1593,12 @@ static TbPlan tb_plan(const fe_handle* h, int B, int T) {
     p.NS = std::max(1, std::min(8, env("FE_TB_STREAMS", 4)));
     p.NS = std::min(p.NS, p.G * p.NC);
     p.stagger = env("FE_TB_STAGGER", 1);
-    if (std::getenv("FE_TB_STAGES")) { p.G = p.NC = p.NS = 1; }
+    // FE_TB_FUSE=1: scan + block tiles of a block in ONE cooperative launch (tb_stage_kernel: the tiles follow the scan frame by frame
+    // behind its progress counters) where tb_launch accepts it.  Parity-green, but measured slower than the two launches it replaces
+    // (profiles/r3g_tb_fused_stage.txt): off by default.
+    p.fuse = env("FE_TB_FUSE", 0);
+    if (p.G * p.NC > 1) p.fuse = 0;
+    if (std::getenv("FE_TB_STAGES")) { p.G = p.NC = p.NS = 1; p.fuse = 0; }
     return p;
 }
 
@@ -1615,6 +1622,11 @@ static int tb_run(fe_handle* h, fe::tb::TbArgs a0, float* work_dev, int B, int T
     if (!caller_state && p.NC > 1) a0.hstate = work_dev + off[6];
     a0.frames = work_dev + off[5];
     hipError_t e = hipSuccess;
+    if (p.fuse) {
+        const size_t nprog = (size_t)d.KB * h->max_wgs * fe::tb::kProgStride;        // (a 128-byte line per scan workgroup)
+        if (!h->tb_prog_dev) FE_HIP_CHECK(hipMalloc(&h->tb_prog_dev, nprog * sizeof(unsigned int)));
+        FE_HIP_CHECK(hipMemsetAsync(h->tb_prog_dev, 0, nprog * sizeof(unsigned int), st));
+    }
     // (FE_TB_STAGES=n: stop after n launches - tools/gpu_tb_check.py reads the intermediate buffers out of work_dev)
     const char* lim_s = std::getenv("FE_TB_STAGES");
     int lim = lim_s ? std::atoi(lim_s) : 1 << 30;
@@ -1660,6 +1672,12 @@ static int tb_run(fe_handle* h, fe::tb::TbArgs a0, float* work_dev, int B, int T
             if (multi && p.stagger && node + 1 < nodes) FE_HIP_CHECK(hipEventRecord(enc_event(node), ns));
             for (int k = 0; k < d.KB && e == hipSuccess; ++k) {
                 a.k = k;
+                if (p.fuse) {
+                    a.prog = h->tb_prog_dev + (size_t)k * h->max_wgs * fe::tb::kProgStride;
+                    hipError_t ef = hipSuccess;
+                    tbi->launch(fe::tb::TB_STAGE, a, h->max_wgs, ns, &ef);
+                    if (ef == hipSuccess) continue;             // (refused: not a fusable shape / batch, or no co-residency - two launches)
+                }
                 if (multi && c > 0 && (node - 1) % p.NS != sidx) FE_HIP_CHECK(hipStreamWaitEvent(ns, scan_event(node - 1, k), 0));
                 if (lim-- > 0) tbi->launch(fe::tb::TB_SCAN, a, h->max_wgs, ns, &e);
                 if (multi && c + 1 < p.NC) FE_HIP_CHECK(hipEventRecord(scan_event(node, k), ns));

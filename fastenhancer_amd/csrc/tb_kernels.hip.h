@@ -57,11 +57,13 @@ struct TbArgs {
     int mode;                   // FE_MODE_OFFLINE / FE_MODE_SPEC
     int k;                      // block index (tb_scan_kernel, tb_blk_kernel)
     float compression;
+    unsigned int* prog;         // fused stage (tb_stage_kernel): frames finished by each 16-row scan workgroup of this block [n scan workgroups]
+    int nscan;                  // fused stage: workgroups 0 .. nscan - 1 of the launch run the scan, the others the block's tiles
     unsigned long long* probe;  // FE_TB_PROBE builds (tools/gpu_tb_phases.py): cycles per phase of workgroup 0, [stage][kProbeSlots]; else nullptr
 };
 
 constexpr int kProbeSlots = 32;
-enum { TB_ENC = 0, TB_SCAN = 1, TB_BLK = 2, TB_DEC = 3 };
+enum { TB_ENC = 0, TB_SCAN = 1, TB_BLK = 2, TB_DEC = 3, TB_STAGE = 4 };     // (TB_STAGE: scan + block tiles of one block in one launch)
 #ifdef FE_TB_PROBE
 // phase clocks: workgroup 0's thread 0 adds the cycles since the previous mark to slot i (s_memtime, after the phase's barrier)
 #define TB_PROBE_INIT(stage) unsigned long long* const tb_pr_ = (a.probe != nullptr && blockIdx.x == 0 && threadIdx.x == 0) ? a.probe + (stage) * kProbeSlots : nullptr; \
@@ -532,19 +534,25 @@ __global__ void __launch_bounds__(kThreads) tb_enc_kernel(TbArgs a) {
 // gx, was batched over all frames): A = h_{t-1} from LDS (double-buffered: one barrier per step), r / z / n of a (row, channel)
 // land in the same lane, the gate math runs in the epilogue, h_t goes to LDS (next step's A operand), to the registers (next
 // step's z h term) and to hs in global memory.  gx of step t + 1 is fetched while step t computes.
-template <class S>
-__global__ void __launch_bounds__(kThreads) tb_scan_kernel(TbArgs a) {
+// PUB > 0 (the fused stage): every PUB steps - and after the last one - the workgroup publishes how many frames of its 16 rows are in hs.
+// hs is written with agent-scope stores (they go to the coherence point, not into this XCD's L2); every wave drains its stores
+// (vmcnt(0)), the step's barrier, then one agent-scope store of the counter.  The consumer polls the counter and reads hs with
+// agent-scope loads as well.  No release / acquire FENCE on either side: measured, one L2 write-back per publish and one cache
+// invalidate per tile made the fused stage 3x slower than the two launches it replaces (profiles/r3g_tb_fused_stage.txt).
+constexpr int kScanPub = 32;
+constexpr int kProgStride = 32;      // ints between two scan workgroups' counters: a 128-byte line each (pollers and publisher meet on one line only)
+template <class S, int PUB>
+__device__ __forceinline__ void scan_role(const TbArgs& a, int rg, int dir, float (*hbuf)[16 * S::LDX]) {
     constexpr int C2 = S::C2, F2 = S::F2, KS = S::KS_2, NT2 = S::NT2, LDX = S::LDX, N3 = S::N3;
     constexpr int NTPW = ceil_div(NT2, kWaves);
     constexpr int HW = S::ND * C2;                           // hs row width
     constexpr PackedOffsets o = Pack<S>::v;
-    __shared__ float hbuf[2][16 * LDX];
-    __builtin_amdgcn_s_setprio(3);      // a latency chain next to the GEMM passes of other nodes: its few instructions go first
+    __builtin_amdgcn_s_setprio(3);      // a latency chain next to GEMM passes: its few instructions go first
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     const WSrc<false> wb = make_wsrc<S>(a.wp, lane);
-    const int dir = blockIdx.y, k = a.k;
-    const int R = a.B * F2, r0 = blockIdx.x * 16;
+    const int k = a.k;
+    const int R = a.B * F2, r0 = rg * 16;
     const int w_off = o.tb_whh[0][0] + k * (S::KB > 1 ? o.tb_whh[1][0] - o.tb_whh[0][0] : 0) + dir * (o.tb_whh[0][S::ND - 1] - o.tb_whh[0][0]);
     const int bn_off = o.tb_bhn[0][0] + k * (S::KB > 1 ? o.tb_bhn[1][0] - o.tb_bhn[0][0] : 0) + dir * (o.tb_bhn[0][S::ND - 1] - o.tb_bhn[0][0]);
     // hidden weights: tile (gate g, channel tile ct) at (g * NT2 + ct) * KS fragments
@@ -652,9 +660,23 @@ __global__ void __launch_bounds__(kThreads) tb_scan_kernel(TbArgs a) {
                 hprev[j][r] = hv;
                 if (cok) hn[(4 * lg + r) * LDX + col] = hv;
             }
-            if (cok && rok[0]) *reinterpret_cast<float4*>(a.hs + hrow + toff + (size_t)col * F2) = make_float4(hprev[j][0], hprev[j][1], hprev[j][2], hprev[j][3]);
+            if (cok && rok[0]) {
+                float* hd = a.hs + hrow + toff + (size_t)col * F2;
+                if constexpr (PUB > 0) {            // (read by other workgroups of the SAME launch: agent-scope accesses on both sides, no cache in between)
+                    // one 16-byte store with the system-coherent bits (what a relaxed agent-scope atomic store of each float would set)
+                    const f32x4 hv4 = {hprev[j][0], hprev[j][1], hprev[j][2], hprev[j][3]};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(hd), "v"(hv4) : "memory");
+                } else
+                *reinterpret_cast<float4*>(hd) = make_float4(hprev[j][0], hprev[j][1], hprev[j][2], hprev[j][3]);
+            }
         }
         cur ^= 1;
+        if constexpr (PUB > 0) {
+            const bool pub = ((st + 1) % PUB == 0) || st + 1 == a.T;
+            if (pub) __builtin_amdgcn_s_waitcnt(0x0f70);         // vmcnt(0): this wave's hs stores have left the CU
+            __syncthreads();
+            if (pub && tid == 0) __hip_atomic_store(a.prog + rg * kProgStride, (unsigned int)(st + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else
         __syncthreads();
     }
     if (hst != nullptr) {
@@ -666,6 +688,13 @@ __global__ void __launch_bounds__(kThreads) tb_scan_kernel(TbArgs a) {
                 if (live[j] && col < C2 && rok[r]) hst[(size_t)(r0 + 4 * lg + r) * C2 + col] = hprev[j][r];
         }
     }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+template <class S>
+__global__ void __launch_bounds__(kThreads) tb_scan_kernel(TbArgs a) {
+    __shared__ float hbuf[2][16 * S::LDX];
+    scan_role<S, 0>(a, blockIdx.x, blockIdx.y, hbuf);
 }
 
 // The same recurrence for FEW rows (a handful of utterances: 16 rows per workgroup leave most of the chip idle and each step is a
@@ -824,14 +853,17 @@ struct BlkLds {
     static constexpr bool PERHEAD = (size_t)FULL * 4 > 160 * 1024;
     static constexpr int LDGX = PERHEAD ? 3 * S::HD + 2 : S::LDG;
     static constexpr int TOTAL = U + cmax(TT::ROWS_P * LDH, TT::ROWS_P * (S::LDX + LDGX));
-    static constexpr size_t BYTES = (size_t)TOTAL * 4;
+    static constexpr size_t BYTES = (size_t)TOTAL * 4 + 16;      // (+ one word: the fused stage's "next tile is ready" flag)
     static constexpr bool OK = BYTES <= 160 * 1024;
     static constexpr int OCC = 2 * BYTES <= 160 * 1024 ? 2 : 1;   // workgroups per CU the plan allows: the register budget follows it
 };
 
-template <class S, int FT>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(BlkLds<S, FT>::OCC, BlkLds<S, FT>::OCC))) tb_blk_kernel(TbArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// FUSED (tb_stage_kernel): the tiles are walked TIME-major (tile n = frames tt FT .. of utterance n % B, tt = n / B) and a tile
+// waits until the scan workgroups of its utterance's rows have published its frames (a.prog; one lane polls with agent-scope loads,
+// the barrier hands the result to the workgroup; the tile's hs then comes in with agent-scope loads, x - written by the previous
+// launch - with plain ones).
+template <class S, int FT, bool FUSED>
+__device__ __forceinline__ void blk_body(const TbArgs& a, float* smem, const int wgid, const int nwg) {
     using L = BlkLds<S, FT>;
     using TT = TokTiling<S, FT>;
     constexpr int C2 = S::C2, F2 = S::F2, LDX = S::LDX, LDH = L::LDH, LDG = L::LDGX, HD = S::HD, HW = S::ND * C2;
@@ -845,7 +877,41 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(B
     float* const Hs = smem + L::HS;
     float* const Hl = smem + L::HL;
     float* const Gi = smem + L::GI;
-    const int ntiles = (a.NF + FT - 1) / FT;
+    const int TPU = (a.T + FT - 1) / FT;                      // FUSED: tiles per utterance
+    const int ntiles = FUSED ? a.B * TPU : (a.NF + FT - 1) / FT;
+    // tile -> its first frame (node-local index b * T + t) and the number of valid frames
+    auto tile_frames = [&](int tl, int& nv) -> int {
+        if constexpr (FUSED) {
+            const int tt = tl / a.B, b = tl - tt * a.B, t0 = tt * FT;
+            nv = a.T - t0 < FT ? a.T - t0 : FT;
+            return b * a.T + t0;
+        } else {
+            const int g0 = tl * FT;
+            nv = a.NF - g0 < FT ? a.NF - g0 : FT;
+            return g0;
+        }
+    };
+    // FUSED: has the scan published the tile's frames for every row of its utterance?  (thread 0; wait = poll until it has)
+    auto tile_ready = [&](int tl, bool wait) -> bool {
+        const int tt = tl / a.B, b = tl - tt * a.B;
+        const unsigned int need = (unsigned int)((tt + 1) * FT < a.T ? (tt + 1) * FT : a.T);
+        const int rg0 = (b * S::F2) / 16, rg1 = (b * S::F2 + S::F2 - 1) / 16;
+        bool ok = true;
+        for (int rg = rg0; rg <= rg1; ++rg) {
+            int spins = 0;
+            while (__hip_atomic_load(a.prog + rg * kProgStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                if (!wait || ++spins > (1 << 20)) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(16);
+            }
+        }
+        return ok;
+    };
+    auto wait_tile = [&](int tl) {
+        if constexpr (FUSED) {
+            if (threadIdx.x == 0) (void)tile_ready(tl, true);
+            __syncthreads();
+        }
+    };
     TB_PROBE_INIT(TB_BLK);
     // Small blocks (T, B, S): this wave's column tiles of EVERY weight matrix of the block stay in registers for the whole launch,
     // with the biases and - block 0 - the positional embedding of the lane's elements (the rows of a tile always start at
@@ -901,8 +967,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(B
         constexpr int NX = ceil_div(XQ, kThreads), NH = ceil_div(HQ, kThreads);
         float4 px[NX], ph[NH];
         auto fetch_tile = [&](int tl) {
-            const int g0 = tl * FT;
-            const int nv = a.NF - g0 < FT ? a.NF - g0 : FT;
+            int nv;
+            const int g0 = tile_frames(tl, nv);
             const float* xg = a.x + (size_t)g0 * (F2 * C2);
             const float* hg = a.hs + (size_t)g0 * (F2 * HW);
 #pragma unroll
@@ -917,7 +983,14 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(B
                 int i = tid + q * kThreads;
                 i = i < HQ ? i : HQ - 1;
                 const int fr = i / (HW * F4), fs = fr < nv ? fr : nv - 1;
-                ph[q] = *reinterpret_cast<const float4*>(hg + (size_t)(i - fr * (HW * F4) + fs * (HW * F4)) * 4);
+                const float* hp = hg + (size_t)(i - fr * (HW * F4) + fs * (HW * F4)) * 4;
+                if constexpr (FUSED) {       // (written by the scan workgroups of this launch: agent-scope loads)
+                    ph[q].x = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ph[q].y = __hip_atomic_load(hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ph[q].z = __hip_atomic_load(hp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ph[q].w = __hip_atomic_load(hp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else
+                ph[q] = *reinterpret_cast<const float4*>(hp);
             }
         };
         auto park_tile = [&]() {
@@ -938,16 +1011,21 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(B
                 d[0] = ph[q].x; d[LDH] = ph[q].y; d[2 * LDH] = ph[q].z; d[3 * LDH] = ph[q].w;
             }
         };
-        if ((int)blockIdx.x < ntiles) { fetch_tile(blockIdx.x); park_tile(); }
+        if (wgid < ntiles) { wait_tile(wgid); fetch_tile(wgid); park_tile(); }
         __syncthreads();
         TB_MARK(0);
 #pragma unroll 1
-        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-            const int g0 = tile * FT;
-            const int nvalid = a.NF - g0 < FT ? a.NF - g0 : FT;
+        for (int tile = wgid; tile < ntiles; tile += nwg) {
+            int nvalid;
+            const int g0 = tile_frames(tile, nvalid);
             const int rows_valid = nvalid * F2;
-            const int nxt = tile + gridDim.x;
-            if (nxt < ntiles) fetch_tile(nxt);
+            const int nxt = tile + nwg;
+            // the next tile rides under this one's phases - FUSED: if the scan is already past it (asked once, by thread 0; the answer
+            // crosses the first phase's barrier in LDS), else it is fetched after this tile
+            bool pre = !FUSED;
+            if constexpr (FUSED) {
+                if (nxt < ntiles && threadIdx.x == 0) smem[L::TOTAL] = tile_ready(nxt, false) ? 1.0f : 0.0f;
+            } else if (nxt < ntiles) fetch_tile(nxt);
             // ---- x += rnn_fc(h) (+ pe in block 0)   (model.py:273-280; noncausal: K = 2 C2)
             {
                 f32x4 acc[MTT][NTPW2];
@@ -974,6 +1052,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(B
             }
             __syncthreads();
             TB_MARK(1);
+            if constexpr (FUSED) {
+                if (nxt < ntiles) { pre = smem[L::TOTAL] != 0.0f; if (pre) fetch_tile(nxt); }
+            }
             // ---- qkv = x W_qkv^T  (rows per head interleaved [h][q|k|v][hd], model.py:142-146)
             {
                 f32x4 acc[MTT][NTPW3];
@@ -1049,14 +1130,19 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(B
             }
             __syncthreads();                                     // (every wave is done with Xb / Hl / Gi)
             TB_MARK(5);
-            if (nxt < ntiles) park_tile();
+            if (nxt < ntiles) {
+                if (!pre) { wait_tile(nxt); fetch_tile(nxt); }
+                park_tile();
+            }
             __syncthreads();
             TB_MARK(0);
         }
         return;
     }
+    static_assert(!FUSED || REGW, "the fused stage is built on the register-resident block path");
+    if constexpr (!FUSED) {
 #pragma unroll 1
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int tile = wgid; tile < ntiles; tile += nwg) {
         const int g0 = tile * FT;
         const int nvalid = a.NF - g0 < FT ? a.NF - g0 : FT;
         const int rows_valid = nvalid * F2;
@@ -1202,6 +1288,34 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(B
         }
         __syncthreads();
         TB_MARK(5);                 // gx of the next block
+    }
+    }
+}
+
+template <class S, int FT>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(BlkLds<S, FT>::OCC, BlkLds<S, FT>::OCC))) tb_blk_kernel(TbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    blk_body<S, FT, false>(a, smem, blockIdx.x, gridDim.x);
+}
+
+// One block stage in ONE launch: workgroups 0 .. nscan - 1 run the time scan of block k (16 rows each), the others the block's tiles
+// behind it.  The scan is a latency chain that leaves most of the chip idle and the tile pass cannot start before it - unless the
+// tiles follow the scan frame by frame: a stage then takes about as long as its scan alone.  All workgroups must be co-resident (the
+// tile workgroups spin on the scan's counters): a cooperative launch, sized by tb_launch.
+template <class S, int FT>
+constexpr bool stage_fusable() {
+    constexpr int NTPW2 = ceil_div(S::NT2, kWaves), NTPW3 = ceil_div(S::NT3, kWaves);
+    constexpr int WREGS = NTPW2 * S::ND * S::KS_2 + NTPW3 * S::KS_2 + NTPW2 * S::KS_2 + S::ND * NTPW3 * S::KS_2;
+    return !S::BIDIR && !BlkLds<S, FT>::PERHEAD && WREGS <= 100 && TokTiling<S, FT>::MTT * NTPW3 <= 8 && BlkLds<S, FT>::OCC == 2;
+}
+
+template <class S, int FT>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) tb_stage_kernel(TbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if constexpr (stage_fusable<S, FT>()) {
+        __shared__ float hbuf[2][16 * S::LDX];
+        if ((int)blockIdx.x < a.nscan) scan_role<S, kScanPub>(a, blockIdx.x, 0, hbuf);
+        else blk_body<S, FT, true>(a, smem, (int)blockIdx.x - a.nscan, (int)gridDim.x - a.nscan);
     }
 }
 
@@ -1502,6 +1616,28 @@ void tb_launch(int stage, const TbArgs& a, int max_wgs, hipStream_t st, hipError
             hipLaunchKernelGGL((tb_scan_kernel<S>), dim3((a.B * S::F2 + 15) / 16, S::ND), dim3(kThreads), 0, st, a);
         else
             hipLaunchKernelGGL((tb_scan4_kernel<S>), dim3(a.B * S::F2 / 4, S::ND), dim3(kThreads), 0, st, a);
+    } else if (stage == TB_STAGE) {
+        // the fused stage: only where the 16-row scan is the one in use, its workgroups leave room for tile workgroups on every CU, and the
+        // block runs on the register-resident path; anything else is refused (the caller launches scan and tiles one after the other)
+        if constexpr (!stage_fusable<S, C::FT_B>()) { *err = hipErrorNotSupported; return; } else {
+            const int nscan = (a.B * S::F2 + 15) / 16, wg4 = a.B * S::F2 / 4;
+            const int TPU = (a.T + C::FT_B - 1) / C::FT_B, ntiles = a.B * TPU;
+            const int room = 2 * max_wgs - nscan - 16;           // (a margin: the co-residency the runtime grants is sized by its own occupancy estimate)
+            if (!(4 * wg4 > 5 * max_wgs) || nscan > max_wgs || room < max_wgs / 2 || a.prog == nullptr) { *err = hipErrorNotSupported; return; }
+            auto* k = &tb_stage_kernel<S, C::FT_B>;
+            constexpr size_t lds = BlkLds<S, C::FT_B>::BYTES;
+            set_lds(k, lds, err);
+            if (*err != hipSuccess) return;
+            TbArgs args = a;
+            args.nscan = nscan;
+            void* kargs[] = {&args};
+            int grid = nscan + (ntiles < room ? ntiles : room);
+            static const int dbg = [] { const char* v = std::getenv("FE_TB_FUSE_DEBUG"); return v ? std::atoi(v) : 0; }();
+            if (dbg == 1) grid = nscan;          // (timing experiment: the scan role alone, with its agent-scope stores and publishes; results are garbage)
+            *err = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k), dim3(grid), dim3(kThreads), kargs, (unsigned int)lds, st);
+            if (*err != hipSuccess) (void)hipGetLastError();
+            return;
+        }
     } else if (stage == TB_BLK) {
         auto* k = &tb_blk_kernel<S, C::FT_B>;
         constexpr size_t lds = BlkLds<S, C::FT_B>::BYTES;
