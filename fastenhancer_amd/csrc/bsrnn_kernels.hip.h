@@ -99,6 +99,10 @@ struct BArgs {
     int B, T, mode, Tw;
     float compression;
     unsigned long long* clk;  // fe_profile_step: cycle probes of workgroup 0 (PROF instantiation only)
+    // time-pipelined offline launch (PIPE instantiation): pipe_p workgroups per utterance, workgroup p runs frames p, p + pipe_p, ...
+    unsigned int* pipe_flags; // [B][NLAY]: frames whose layer-l time-LSTM state (h, c) is in `lstm`
+    float* frames;            // [B][T][N] windowed output frames (summed / envelope-normalised by istft_ola_kernel)
+    int pipe_p;
 };
 
 // debug stage table: spec_in, compressed, band_split, (layer.l.time, layer.l.freq)..., mask_mlp, spec_out
@@ -145,8 +149,16 @@ struct BLds {
 // xxt).  A frame is a latency chain (186 barrier-separated recurrence steps); a second workgroup on the CU runs its own
 // chain in the gaps.  It has to live in 256 registers per wave: no register-resident layer weights (streamed inside the
 // GEMM pipelines like the larger shapes), shorter MLP weight rings - the other workgroup covers those latencies.
-template <class S, bool HOT, bool PROF, bool DBG, bool OCC2 = false>
+// PIPE: time pipelining of an offline launch (the per-hop kernel's scheme, fe_kernels.hip.h): everything in a frame but the time-LSTM's
+// (h, c) per layer is independent of the other frames, so the frames of an utterance are spread over pipe_p CO-RESIDENT workgroups
+// (cooperative launch) and the state is handed from frame t - 1 to frame t through `lstm` - agent-scope stores, drained, then an
+// agent-scope store of a per-(utterance, layer) frame counter; the consumer polls the counter and fetches the state with agent-scope
+// loads right before the layer's gate GEMM (state AND counter through agent-scope accesses: no release / acquire fence, which on this
+// part writes back / invalidates whole caches).  The serial chain per frame and layer is wait -> fetch -> gates -> publish; the band
+// recurrence, the fc layers and the mask MLPs - 9/10 of a frame - run in parallel across the frames in flight.
+template <class S, bool HOT, bool PROF, bool DBG, bool OCC2 = false, bool PIPE = false>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, OCC2 ? 2 : 1))) bsrnn_frame_kernel(BArgs a) {
+    static_assert(!PIPE || (!HOT && !PROF && !DBG), "the time-pipelined instantiation is the plain offline kernel");
     const int aT = HOT ? 1 : a.T;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = BLds<S>;
@@ -243,7 +255,16 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
 
-    int b = blockIdx.x;
+    int b = PIPE ? (int)blockIdx.x / a.pipe_p : (int)blockIdx.x;
+    const int t_first = PIPE ? (int)blockIdx.x - b * a.pipe_p : 0, t_step = PIPE ? a.pipe_p : 1;
+    auto ld_state = [](const float* p) -> float {
+        if constexpr (PIPE) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return *p;
+    };
+    auto st_state = [](float* p, float v) {
+        if constexpr (PIPE) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *p = v;
+    };
 #pragma unroll 1
     do {
     // An opaque zero per stream: the per-thread weight addresses of the phases far down the frame (band split, mask MLPs) do not depend on the
@@ -265,8 +286,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         }
     };
 
+    unsigned int* pflag = PIPE ? a.pipe_flags + (size_t)b * S::NLAY : nullptr;
 #pragma unroll 1
-    for (int t = 0; t < aT; ++t) {
+    for (int t = t_first; t < aT; t += t_step) {
         BE_CLK(0);
         // ============================ STFT + compress (all 257 bins; models/bsrnn/model.py:430-436) ============================
         if (mode != FE_MODE_SPEC) {
@@ -341,7 +363,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         // time-LSTM state of layer 0 (the later layers' is fetched under the previous layer's recurrence)
         constexpr int HPT = (kBands * HH + kThreads - 1) / kThreads;
         float hpre[HPT];
-        {
+        if constexpr (!PIPE) {
             const float* hg0 = a.lstm + (size_t)b * (kBands * HH);
 #pragma unroll
             for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = hg0[i < kBands * HH ? i : kBands * HH - 1]; }
@@ -359,6 +381,24 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             float* hg = a.lstm + ((size_t)(2 * l) * a.B + b) * (kBands * HH);
             float* cg = a.lstm + ((size_t)(2 * l + 1) * a.B + b) * (kBands * HH);
             if (l == 0) BE_CLK(2);
+            if constexpr (PIPE) {
+                // frame t - 1's state of this layer: wait for it, fetch h into the GEMM's A operand buffer (c is fetched in the epilogue's place)
+                if (t > 0) {
+                    if (tid == 0) {
+                        int spins = 0;
+                        while (__hip_atomic_load(pflag + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)t && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
+                    }
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = ld_state(hg + (i < kBands * HH ? i : kBands * HH - 1)); }
+#pragma unroll
+                for (int q = 0; q < HPT; ++q) {
+                    const int i = tid + q * kThreads, r = i / HH;
+                    if (i < kBands * HH) Hs[r * LDH + (i - r * HH)] = hpre[q];
+                }
+                __syncthreads();
+            }
             // ---------------- time LSTM (LSTMCell over the 31 bands; :371-381)
             // items (m-tile, hidden tile): 4 gate accumulators each; gates fused into the epilogue (order i,f,g,o);
             // gate rows are packed pre-scaled, so sigma(v) = rcp(1 + exp2(pre)) and tanh(v) = 2 rcp(1 + exp2(pre)) - 1
@@ -369,7 +409,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     float cprev[4];
                     const int j = 16 * ct + li;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { const int row = 16 * mt + 4 * lg + r; cprev[r] = cg[(row < kBands ? row : kBands - 1) * HH + j]; }
+                    for (int r = 0; r < 4; ++r) { const int row = 16 * mt + 4 * lg + r; cprev[r] = ld_state(cg + (row < kBands ? row : kBands - 1) * HH + j); }
                     f32x4 acc[1][4];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) { const float bv = wtbf(g); acc[0][g] = f32x4{bv, bv, bv, bv}; }
@@ -411,7 +451,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 for (int q = 0; q < HPT; ++q) {
                     const int i = tid + q * kThreads, ic = i < kBands * HH ? i : kBands * HH - 1, r = ic / HH, c = ic - r * HH;
                     const float hv = Hn[r * LDH + c], cv = Cn[r * LDH + c];
-                    if (i < kBands * HH) { hg[i] = hv; cg[i] = cv; }
+                    if (i < kBands * HH) { st_state(hg + i, hv); st_state(cg + i, cv); }
+                }
+                if constexpr (PIPE) {      // publish: every thread's state stores have left the CU, then one store of the counter
+                    __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_store(pflag + l, (unsigned int)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             if (l == 0) BE_CLK(3);
@@ -488,7 +533,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             __syncthreads();
             if (l == 0) BE_CLK(5);
             // next layer's time-LSTM hidden state: fetched now, parked in Hs after the recurrence
-            if (l + 1 < S::NLAY) {
+            if (!PIPE && l + 1 < S::NLAY) {
                 const float* hgn = a.lstm + ((size_t)(2 * l + 2) * a.B + b) * (kBands * HH);
 #pragma unroll
                 for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = hgn[i < kBands * HH ? i : kBands * HH - 1]; }
@@ -652,10 +697,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             }
             if (l + 1 < S::NLAY) {
                 // park the next layer's hidden state / hand the prefetched W_hh and fc_freq sets over
+                if constexpr (!PIPE) {
 #pragma unroll
                 for (int q = 0; q < HPT; ++q) {
                     const int i = tid + q * kThreads, r = i / HH;
                     if (i < kBands * HH) Hs[r * LDH + (i - r * HH)] = hpre[q];
+                }
                 }
                 if constexpr (REGW) {
 #pragma unroll
@@ -837,6 +884,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             const float* wi = wp + (mode == FE_MODE_STREAM ? o.window_istft : o.window);
             float* xo = reinterpret_cast<float*>(spare);
             const float invN = 1.0f / (float)N;
+            if constexpr (PIPE) {
+                float* fr = a.frames + ((size_t)b * aT + t) * N;
+                for (int n = tid; n < N; n += kThreads) fr[n] = y[n].x * invN * wi[n];
+                __syncthreads();               // (the next frame's FFT re-uses the buffers)
+            } else {
             for (int n = tid; n < N; n += kThreads) {
                 float v = y[n].x * invN * wi[n];
                 if (n < OVL) v += cis[n];
@@ -866,9 +918,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             }
             for (int m = tid; m < OVL; m += kThreads) cis[m] = xo[m + H];
             __syncthreads();
+            }
         }
         BE_CLK(11);
     }
+    if constexpr (PIPE) break;
     b += gridDim.x;
     } while (b < a.B);
 }
@@ -884,6 +938,8 @@ struct BImpl {
     int rec_threads;          // threads of one direction of the band recurrence (BShape::NTD)
     void (*launch)(const BArgs&, int max_wgs, hipStream_t, hipError_t*);
     void (*dbg_stage)(int, int*, int*, size_t*);
+    void (*launch_pipe)(const BArgs&, hipStream_t, hipError_t*);       // time-pipelined offline launch (cooperative: B * pipe_p workgroups)
+    int occ;                  // workgroups per CU the LDS plan allows
 };
 
 template <class S, bool HOT, bool PROF, bool DBG, bool OCC2 = false>
@@ -921,6 +977,22 @@ void blaunch_impl(const BArgs& a, int max_wgs, hipStream_t st, hipError_t* err) 
 }
 
 template <class S>
+void blaunch_pipe_impl(const BArgs& a, hipStream_t st, hipError_t* err) {
+    auto* fn = &bsrnn_frame_kernel<S, false, false, false, false, true>;
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev].load(std::memory_order_relaxed)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BLds<S>::BYTES);
+        if (e != hipSuccess) { *err = e; return; }
+        attr_set[dev].store(true, std::memory_order_relaxed);
+    }
+    BArgs args = a;
+    void* kargs[] = {&args};
+    *err = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(a.B * a.pipe_p), dim3(kThreads), kargs, (unsigned int)BLds<S>::BYTES, st);
+}
+
+template <class S>
 void bdbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
     *rows = BDebugLayout<S>::rows(s);
     *cols = BDebugLayout<S>::cols(s);
@@ -930,7 +1002,8 @@ void bdbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
 template <class S>
 BImpl make_bimpl() {
     return BImpl{S::C, S::NLAY, S::HOP, BLds<S>::BYTES, S::XPG ? (size_t)2 * 32 * S::G4 : (size_t)0,
-                 BDebugLayout<S>::total(), BDebugLayout<S>::n_stages, S::WREG, S::KSPLIT, S::NTD, &blaunch_impl<S>, &bdbg_stage_impl<S>};
+                 BDebugLayout<S>::total(), BDebugLayout<S>::n_stages, S::WREG, S::KSPLIT, S::NTD, &blaunch_impl<S>, &bdbg_stage_impl<S>,
+                 &blaunch_pipe_impl<S>, 1};      // (the PIPE instantiation is compiled for one workgroup per CU: waves_per_eu(1, 1))
 }
 
 }  // namespace fe

@@ -1501,6 +1501,17 @@ static int pipe_width(const fe_handle* h, int B, int T) {
     return p < T ? p : T;
 }
 
+// BSRNN: frames in flight per utterance of a time-pipelined offline launch (0: one workgroup walks the frames).  A hand-off chain
+// (wait, fetch, gate GEMM, publish) is ~1/40 of a frame, so every co-resident workgroup the batch leaves free is worth having.
+static int bsrnn_pipe_width(const fe_handle* h, int B, int T) {
+    if (!h->bimpl || !h->bimpl->launch_pipe || h->pipe_frames == 0 || h->pipe_frames == 1 || T < 4) return 0;
+    int p = (h->max_wgs * h->bimpl->occ) / B;
+    const int want = h->pipe_frames < 0 ? 64 : h->pipe_frames;
+    p = p < want ? p : want;
+    p = p < T ? p : T;
+    return p >= 2 ? p : 0;
+}
+
 int fe_set_time_pipeline(fe_handle* h, int frames_in_flight) {
     if (!h) return fail(FE_ERR_INVALID_ARG, "bad argument");
     h->pipe_frames = frames_in_flight;
@@ -1724,7 +1735,10 @@ size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw) {
     }
     if (h->limpl) return (size_t)B * ((size_t)(d.NFFT - d.HOP) + h->limpl->cache_floats);
     if (h->fimpl) return (size_t)B * (size_t)(d.NFFT - d.HOP) + fspen_gru_floats(B);
-    if (h->bimpl) return (size_t)B * (size_t)(d.NFFT - d.HOP) + bsrnn_lstm_floats(h, B);
+    if (h->bimpl) {     // overlap-add tail + LSTM states, and - whatever fe_set_time_pipeline says at call time - the frame counters and the windowed frames
+        const int T = 1 + Tw / d.HOP;
+        return (size_t)B * (size_t)(d.NFFT - d.HOP) + ((bsrnn_lstm_floats(h, B) + 3) & ~(size_t)3) + (((size_t)B * h->cfg.rf_blocks + 3) & ~(size_t)3) + (size_t)B * T * d.NFFT;
+    }
     // GRU state (zero initial state, model.py:626-627) + overlap-add tail, both zeroed by fe_offline; time-pipelined
     // launches: + the frame counters [B][KB] and the windowed output frames [B][T][N]
     size_t n = (size_t)B * ((size_t)(d.NFFT - d.HOP) + d.hstate() + tk_floats(h));
@@ -1769,7 +1783,8 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
     }
     {   // zero the state, the tail and the frame counters (not the frames: every element is written)
         size_t nz = (size_t)B * ((size_t)(d.NFFT - d.HOP) + d.hstate() + tk_floats(h));
-        if (h->bimpl || h->fimpl || h->limpl) nz = fe_offline_work_floats(h, B, Tw);
+        if (h->bimpl) nz = (size_t)B * (size_t)(d.NFFT - d.HOP) + ((bsrnn_lstm_floats(h, B) + 3) & ~(size_t)3) + (((size_t)B * h->cfg.rf_blocks + 3) & ~(size_t)3);
+        else if (h->fimpl || h->limpl) nz = fe_offline_work_floats(h, B, Tw);
         else if (pipe_width(h, B, T)) nz += ((size_t)B * d.KB + 3) & ~(size_t)3;
         FE_HIP_CHECK(hipMemsetAsync(work_dev, 0, nz * sizeof(float), st));
     }
@@ -1804,6 +1819,27 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
         ba.spec_out = spec_hat_dev;
         ba.cache_istft = work_dev; ba.cache_stft = work_dev;
         ba.lstm = work_dev + (size_t)B * (d.NFFT - d.HOP);
+        if (const int P = bsrnn_pipe_width(h, B, T)) {
+            // the frames of an utterance over P co-resident workgroups (bsrnn_kernels.hip.h, PIPE); refused co-residency: the serial walk
+            rc = ensure_tables(h, st);
+            if (rc != FE_OK) return rc;
+            float* flags = ba.lstm + ((bsrnn_lstm_floats(h, B) + 3) & ~(size_t)3);
+            ba.pipe_flags = reinterpret_cast<unsigned int*>(flags);
+            ba.frames = flags + (((size_t)B * h->cfg.rf_blocks + 3) & ~(size_t)3);
+            ba.pipe_p = P;
+            hipError_t e = hipSuccess;
+            h->bimpl->launch_pipe(ba, st, &e);
+            if (e == hipSuccess) {
+                const int n_out = d.HOP * (T - 1);
+                hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
+                                   ba.frames, h->tables_dev, wav_hat_dev, (size_t)n_out, d.NFFT, d.HOP, T);
+                e = hipGetLastError();
+                if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+                return FE_OK;
+            }
+            (void)hipGetLastError();
+            ba.pipe_flags = nullptr; ba.frames = nullptr; ba.pipe_p = 0;
+        }
         return launch_bsrnn(h, ba, stream);
     }
     rc = ensure_scratch(h, B);

@@ -742,6 +742,29 @@ def test_bsrnn_offline_matches_reference_golden(name):
     _assert_close(spec_hat.cpu().numpy(), g["offline_spec"], "offline spec")
 
 
+@pytest.mark.parametrize("name,B", [("bsrnn_xt", 1), ("bsrnn_xt", 3), ("bsrnn_t", 2), ("bsrnn_s", 1)])
+def test_bsrnn_time_pipelined_offline_agrees_with_the_serial_walk(name, B):
+    """fe_offline of BSRNN with the frames of an utterance spread over co-resident workgroups (the time-LSTM state handed from frame
+    to frame through per-layer counters) against one workgroup walking the frames, and against the oracle."""
+    m, orc, cfg, sr, seed = _bsrnn(name, "Model")
+    eng = m.engine
+    x = make_input(B, 41 * cfg.hop_size + 19, seed + 31, sr)
+    xd = torch.from_numpy(x).to(_dev())
+    eng.set_time_pipeline(0)
+    w_ser, s_ser = [t.clone() for t in eng.offline(xd)]
+    for width in (-1, 5, 16):
+        eng.set_time_pipeline(width)
+        for rep in range(2):          # (twice: the counters live in the work buffer and are zeroed by every call)
+            w, s = eng.offline(xd)
+            assert float((w - w_ser).abs().max()) <= 2e-5 * max(1.0, float(w_ser.abs().max())), (width, rep, float((w - w_ser).abs().max()))
+            assert float((s - s_ser).abs().max()) <= 2e-5 * max(1.0, float(s_ser.abs().max())), (width, rep)
+    eng.set_time_pipeline(-1)
+    wav_ref, spec_ref = orc.offline_forward(x)
+    w, s = eng.offline(xd)
+    _assert_close(w.cpu().numpy(), wav_ref, "pipelined offline wav vs oracle")
+    _assert_close(s.cpu().numpy(), spec_ref, "pipelined offline spec vs oracle")
+
+
 @pytest.mark.parametrize("name", ["bsrnn_xt", "bsrnn_t", "bsrnn_s"])
 def test_bsrnn_batch_and_chunk_vs_oracle(name):
     m, orc, cfg, sr, seed = _bsrnn(name)

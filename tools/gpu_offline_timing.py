@@ -20,17 +20,32 @@ def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "fe_b"
     secs = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
     B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-    kw, sr, _ = MODEL_KWARGS[name]
     dev = torch.device("cuda:0")
-    cfg = FEConfig.from_model_kwargs(**kw)
-    eng = Engine(cfg, dev)
-    eng.load_state_dict(default_state_dict(cfg, torch.Generator().manual_seed(1)))
+    if name.startswith("bsrnn"):       # (BSRNN: the mirror with the oracle's seeded checkpoint, as the tests build it)
+        import importlib
+        import numpy as np
+        from common import BSRNN_KWARGS, build_bsrnn_oracle
+        kw, sr, _ = BSRNN_KWARGS[name]
+        cfg, sd, _, _ = build_bsrnn_oracle(name)
+        m = importlib.import_module("fastenhancer_amd.models.bsrnn.model").Model(**kw).to(dev).eval()
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        eng = m.engine
+    else:
+        kw, sr, _ = MODEL_KWARGS[name]
+        cfg = FEConfig.from_model_kwargs(**kw)
+        eng = Engine(cfg, dev)
+        eng.load_state_dict(default_state_dict(cfg, torch.Generator().manual_seed(1)))
     x = 0.1 * torch.randn(B, int(secs * sr), device=dev)
     T = 1 + x.shape[1] // cfg.hop_size
     res = {}
+    ref = None
     for width in (0, 4, 8, 12, 16, 24, 32, 48, 64, -1):
         eng.set_time_pipeline(width)
-        for _ in range(3):
+        w0 = eng.offline(x)[0]
+        if ref is None:
+            ref = w0.clone()
+        err = float((w0 - ref).abs().max())
+        for _ in range(2):
             eng.offline(x)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -41,7 +56,7 @@ def main():
         dt = (time.perf_counter() - t0) / n
         res[width] = dt
         print(f"{name} B={B} {secs:.1f} s ({T} frames): frames in flight {width:2d}: {dt * 1e3:8.3f} ms  "
-              f"({B * T / dt / 1e3:8.1f} k frames/s, RTF {dt / secs / B:.5f}, x{res[0] / dt:5.2f} vs serial)")
+              f"({B * T / dt / 1e3:8.1f} k frames/s, RTF {dt / secs / B:.5f}, x{res[0] / dt:5.2f} vs serial, max |diff| to serial {err:.1e})")
 
 
 if __name__ == "__main__":
