@@ -1487,7 +1487,6 @@ static int pipe_width(const fe_handle* h, int B, int T) {
     if (!h->impl || h->pipe_frames == 0 || h->pipe_frames == 1 || T < 4 || 2 * B > h->max_wgs) return 0;
     if (h->d.KT > 1) return 0;     // (the time_kernel convs carry whole input frames from frame to frame: one workgroup walks them)
     if (h->d.TA) return 0;         // (so do the dptransformer variant's K / V caches)
-    if (h->d.LN) return 0;         // (ln variant: no time-pipelined instantiation)
     // automatic width: a hand-off (counter round trip + state fetch + the h half of the GRU + gates + publish) takes
     // ~2.6 us whatever the model; a frame takes ~4 us per MFLOP/frame at the measured kernel efficiency: that many frames
     // are worth having in flight (measured optimum: T 8-12, B 16, 48 kHz B 24, L > 24), more only adds pollers

@@ -1291,7 +1291,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
     // ln variant: norm site `site` (Shape::LN_SITES order) over a [ROWS x COLS] LDS tile, GroupNorm form
     float* const lnred = smem + L::LNS;
 #define FE_LN_SITE(ROWS, COLS, LD, ACT, buf, site) ln_pass<ROWS, COLS, LD, ACT, false>(buf, lnred, wp + lz + o.ln_g[site], wp + lz + o.ln_b[site], 1.0e-5f)   /* (+ lz: not hoisted out of the frame loop) */
-    static_assert(!S::LN || (L::STAGED && L::SKIPS_LDS && S::KT == 1 && !S::FRNN && !S::TATT && !PIPE), "ln variant: built for the B-type plan (staged weights, LDS skips)");
+    static_assert(!S::LN || (L::STAGED && L::SKIPS_LDS && S::KT == 1 && !S::FRNN && !S::TATT), "ln variant: built for the B-type plan (staged weights, LDS skips)");
     // weight units: unit U of frame t is consumed from LDS buffer ((U + t*NU) & 1) while the next streams in
     constexpr int NPW = L::STAGED ? ceil_div(ceil_div(Pack<S>::umax(), 256), kWaves) : 1;
     DmaJobT<NPW> job;
@@ -1331,7 +1331,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
         if constexpr (PIPE) {
             if (t > 0) {
                 if (tid == 0) {
-                    while (__hip_atomic_load(pflag + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)t) __builtin_amdgcn_s_sleep(1);
+                    while (__hip_atomic_load(pflag + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)t) __builtin_amdgcn_s_sleep(1);
                 }
                 __syncthreads();
             }
@@ -1342,7 +1342,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
         if constexpr (PIPE) {
             __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0) (gfx9 encoding: lgkmcnt / expcnt left alone)
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(pflag + k, (unsigned int)(t + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(pflag + k, (unsigned int)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
 

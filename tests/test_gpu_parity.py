@@ -478,7 +478,7 @@ def test_offline_model_forward_matches_reference_golden(name):
     assert torch.equal(wav3, wav_hat)
 
 
-@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_m", "fe48_b", "fe_dprnn_b"])
+@pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_m", "fe48_b", "fe_dprnn_b", "fe_ln_b"])
 def test_time_pipelined_offline_and_spec_agree_with_the_serial_walk(name):
     """fe_offline / fe_spec_step with T >= 4 spread a stream's frames over co-resident workgroups that hand the GRU state
     from frame to frame (fe_set_time_pipeline); one workgroup walking the frames serially must give the same result, and

@@ -10,7 +10,7 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
-from common import MODEL_KWARGS  # noqa: E402
+from common import MODEL_KWARGS, product_config  # noqa: E402
 from fastenhancer_amd.config import FEConfig  # noqa: E402
 from fastenhancer_amd.engine import Engine  # noqa: E402
 from fastenhancer_amd.weights import default_state_dict  # noqa: E402
@@ -32,8 +32,10 @@ def main():
         eng = m.engine
     else:
         kw, sr, _ = MODEL_KWARGS[name]
-        cfg = FEConfig.from_model_kwargs(**kw)
+        cfg = product_config(name)
         eng = Engine(cfg, dev)
+        if not cfg.noncausal:
+            eng.set_offline_engine("frame_walk")       # (this tool times the frame walk and its time pipeline; tools/gpu_tb_timing.py the time-batched engine)
         eng.load_state_dict(default_state_dict(cfg, torch.Generator().manual_seed(1)))
     x = 0.1 * torch.randn(B, int(secs * sr), device=dev)
     T = 1 + x.shape[1] // cfg.hop_size
