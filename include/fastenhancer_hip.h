@@ -138,7 +138,9 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
  * frames of a stream are spread over up to `frames_in_flight` co-resident workgroups that hand the GRU state of each
  * RNNFormer block from frame to frame through global memory (everything else in a frame is independent of the other
  * frames).  Negative (the default) = a width chosen from the model size (8 .. 64); 0 or 1 = off (one workgroup walks the
- * T frames of a stream).  Results agree to fp32 rounding. */
+ * T frames of a stream).  Results agree to fp32 rounding.  BSRNN's fe_offline is pipelined the same way (the time-LSTM (h, c) of
+ * each layer is the hand-off; up to 64 frames in flight), and so is the ln variant's; the time_kernel and dptransformer variants
+ * (whole frames / K-V caches carried from frame to frame), FSPEN and LiSenNet walk. */
 int fe_set_time_pipeline(fe_handle* h, int frames_in_flight);
 
 /* Engine of fe_offline for the default and noncausal FastEnhancer models:
@@ -147,8 +149,12 @@ int fe_set_time_pipeline(fe_handle* h, int frames_in_flight);
  *     forward does (model.py:620-675): encoder pass (tiles of frames as one GEMM per layer), per block a scan over time in
  *     which only W_hh h is serial (the x half of the gates is batched) + a batched attention pass, decoder pass, overlap-add
  *     (csrc/tb_kernels.hip.h).  Activations that cross a GRU live in work_dev.
+ *     With few utterances the scan runs four rows per workgroup on v_mfma_f32_4x4x1 instead of sixteen on 16x16x4.
  *   FE_OFFLINE_FRAME_WALK: the per-hop kernel walking (or, fe_set_time_pipeline, pipelining) the frames of each utterance.
- * Results agree to fp32 rounding.  The other architectures / variants always walk. */
+ *   FE_OFFLINE_AUTO: time-batched, except for the big shapes (rf_channels >= 72) with 8 or more utterances, where the pipelined
+ *     walk of the per-hop kernel is the faster one.
+ * Results agree to fp32 rounding.  The other architectures / variants always walk.  A handle's compute calls must be stream-ordered
+ * (one stream, or event-ordered streams): the engines keep per-handle scratch, counters and helper streams. */
 #define FE_OFFLINE_AUTO 0
 #define FE_OFFLINE_FRAME_WALK 1
 #define FE_OFFLINE_TIME_BATCHED 2
