@@ -547,6 +547,18 @@ def main():
     # untimed clock ramp: a 20-step run is otherwise measured on a GPU that is still raising its shader clock and
     # filling its instruction / TLB caches (r1: 39.3 us per step in the driver's 20-step run, 34.5 us in steady state)
     ramp_steps = 0
+    cold_ms = None
+    if args.clock_ramp_ms > 0 and not use_dist and not args.graph:
+        # the figure WITHOUT the ramp, for comparison with r1's numbers and with baselines measured cold: W warm-up steps, then K steps
+        # timed on the host clock, before anything else has run on the device (reported as cold_ms_per_step, never as `value`)
+        run(args.warmup, 0)
+        torch.cuda.synchronize(dev)
+        c0 = time.perf_counter()
+        run(args.steps, args.warmup)
+        torch.cuda.synchronize(dev)
+        cold_ms = (time.perf_counter() - c0) / args.steps * 1e3
+        if not offline:
+            state.zero_()
     if args.clock_ramp_ms > 0:
         r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         r0.record(stream)
@@ -641,7 +653,7 @@ def main():
         res = {
             "metric": "audio frames/sec (hop=256, 16kHz) FastEnhancer_B" if args.workload == "fe_b" else f"audio frames/sec {w['desc']}",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "clock_ramp_steps": ramp_steps, "rccl_world_size": rccl_world, "weight_broadcast_ms": bcast_ms,
+            "clock_ramp_steps": ramp_steps, "cold_ms_per_step": cold_ms, "rccl_world_size": rccl_world, "weight_broadcast_ms": bcast_ms,
             "per_rank_ms_per_step": per_rank_ms,
             "blocks": len(blocks), "statistic": "median of `blocks` consecutive blocks of `steps` steps (max over ranks per block)",
             "min_ms_per_step": min(b_[0] for b_ in blocks) / args.steps * 1e3, "max_ms_per_step": max(b_[0] for b_ in blocks) / args.steps * 1e3,

@@ -1742,7 +1742,8 @@ size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw) {
     // launches: + the frame counters [B][KB] and the windowed output frames [B][T][N]
     size_t n = (size_t)B * ((size_t)(d.NFFT - d.HOP) + d.hstate() + tk_floats(h));
     const int T = 1 + Tw / d.HOP;
-    if (pipe_width(h, B, T)) n += (((size_t)B * d.KB + 3) & ~(size_t)3) + (size_t)B * T * d.NFFT;
+    // (whatever fe_set_time_pipeline says at the time of THIS call: a buffer sized with the pipeline off must still do when it is on)
+    if (h->impl && T >= 4 && d.KT == 1 && !d.TA) n += (((size_t)B * d.KB + 3) & ~(size_t)3) + (size_t)B * T * d.NFFT;
     return n;
 }
 
