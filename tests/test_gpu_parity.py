@@ -556,6 +556,44 @@ def test_time_batched_offline_matches_oracle_and_the_frame_walk(name):
     assert float((w1 - wav_tb[1:2]).abs().max()) == 0.0 and float((s1 - spec_tb[1:2]).abs().max()) == 0.0
 
 
+def test_time_batched_optional_schedules_agree_with_the_default():
+    """The time-batched engine's opt-in schedules (measured slower, DESIGN 3c - but they must stay correct): the call cut into nodes
+    (time chunks / utterance groups over the handle's streams, FE_TB_NC / FE_TB_G / FE_TB_STREAMS) and the fused block stage (scan and
+    tile pass of a block in one cooperative launch behind progress counters, FE_TB_FUSE=1), on a batch large enough for the 16-row
+    scan (the fused stage's regime)."""
+    import os
+    m, orc, cfg, sr, seed = _model("fe_b", "Model")
+    eng = m.engine
+    eng.set_offline_engine("time_batched")
+    B, T1 = 56, 37
+    xd = torch.from_numpy(make_input(B, T1 * cfg.hop_size + 5, 909, sr)).to(_dev())
+    keys = ("FE_TB_NC", "FE_TB_G", "FE_TB_STREAMS", "FE_TB_FUSE")
+    saved = {k: os.environ.pop(k, None) for k in keys}
+    try:
+        w0, s0 = [t.clone() for t in m(xd)]
+        os.environ.update(FE_TB_NC="3", FE_TB_G="1", FE_TB_STREAMS="2")          # time chunks: the same kernels on the same rows
+        w1, s1 = [t.clone() for t in m(xd)]
+        assert torch.equal(w1, w0) and torch.equal(s1, s0), "time-chunked nodes changed the result"
+        os.environ.update(FE_TB_NC="2", FE_TB_G="2", FE_TB_STREAMS="3")          # utterance groups: a group of 28 scans four rows per workgroup
+        w2, s2 = [t.clone() for t in m(xd)]
+        assert float((w2 - w0).abs().max()) <= 2e-5 * max(1.0, float(w0.abs().max()))
+        assert float((s2 - s0).abs().max()) <= 2e-5 * max(1.0, float(s0.abs().max()))
+        for k in keys[:3]:
+            os.environ.pop(k, None)
+        os.environ["FE_TB_FUSE"] = "1"
+        w3, s3 = [t.clone() for t in m(xd)]
+        w3b, _ = m(xd)
+        assert torch.equal(w3, w3b), "fused stage is not deterministic"
+        assert float((w3 - w0).abs().max()) <= 2e-5 * max(1.0, float(w0.abs().max()))
+        assert float((s3 - s0).abs().max()) <= 2e-5 * max(1.0, float(s0.abs().max()))
+    finally:
+        for k in keys:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+    eng.set_offline_engine("auto")
+
+
 @pytest.mark.parametrize("name", NONCAUSAL)
 def test_noncausal_model_forward_matches_reference_golden(name):
     """SURVEY.md §8(f) rank 4, models/fastenhancer/noncausal/model.py:628-635: Model.forward(noisy) of the three huge_noncausal yamls
