@@ -39,6 +39,7 @@ SYMBOLS = {
     "fe_state_floats": (c_size_t, [c_void_p, c_int]),
     "fe_state_init": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "fe_step": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "fe_step_host": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p, c_void_p]),
     "fe_spec_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fe_set_time_pipeline": (c_int, [c_void_p, c_int]),
     "fe_set_offline_engine": (c_int, [c_void_p, c_int]),

@@ -119,6 +119,8 @@ struct fe_handle {
     std::vector<hipStream_t> tb_streams;      // time-batched engine: the streams its nodes are spread over (lazy; tb_run)
     std::vector<hipEvent_t> tb_events;        // ... and its event pool
     unsigned long long* tb_probe_dev = nullptr;   // FE_TB_PROBE builds: phase clocks [4][kProbeSlots]
+    hipStream_t host_streams[2] = {nullptr, nullptr};     // fe_step_host: copy-in / copy-out streams (lazy)
+    hipEvent_t host_events[7] = {};                       // ... and its events
     unsigned int* tb_prog_dev = nullptr;      // fused stages: the scan workgroups' frame counters [KB][2 * max_wgs]
     std::vector<Section> sections;
     size_t blob_floats = 0;
@@ -1330,6 +1332,8 @@ void fe_destroy(fe_handle* h) {
     for (hipEvent_t e : h->tb_events) (void)hipEventDestroy(e);
     if (h->tb_probe_dev) (void)hipFree(h->tb_probe_dev);
     if (h->tb_prog_dev) (void)hipFree(h->tb_prog_dev);
+    for (hipStream_t s : h->host_streams) if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : h->host_events) if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -1468,6 +1472,48 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
 int fe_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, float* state_dev, float* wav_out_dev, size_t out_stride,
             int B, int T, void* stream) {
     return run_step(h, wav_in_dev, in_stride, state_dev, wav_out_dev, out_stride, B, T, nullptr, nullptr, stream);
+}
+
+int fe_step_host(fe_handle* h, const float* wav_in_host, size_t in_stride, float* state_dev, float* wav_out_host, size_t out_stride,
+                 int B, int T, int n_calls, float* work_dev, void* stream) {
+    int rc = check_ready(h);
+    if (rc != FE_OK) return rc;
+    if (!wav_in_host || !wav_out_host || !state_dev || !work_dev || B <= 0 || T <= 0 || n_calls <= 0) return fail(FE_ERR_INVALID_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    for (hipStream_t& s : h->host_streams)
+        if (!s) FE_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    for (hipEvent_t& e : h->host_events)
+        if (!e) FE_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipStream_t s_in = h->host_streams[0], s_out = h->host_streams[1];
+    // events: [0] start, [1 + buf] block copied in, [3 + buf] block computed, [5 + buf] block copied out
+    hipEvent_t* ev = h->host_events;
+    const size_t row = (size_t)T * h->d.HOP, blk = (size_t)B * row;
+    float* xd[2] = {work_dev, work_dev + blk};
+    float* yd[2] = {work_dev + 2 * blk, work_dev + 3 * blk};
+    FE_HIP_CHECK(hipEventRecord(ev[0], st));
+    FE_HIP_CHECK(hipStreamWaitEvent(s_in, ev[0], 0));
+    FE_HIP_CHECK(hipStreamWaitEvent(s_out, ev[0], 0));
+    for (int c = 0; c < n_calls; ++c) {
+        const int buf = c & 1;
+        // copy-in of block c: its staging buffer was last read by the kernel of block c - 2
+        if (c >= 2) FE_HIP_CHECK(hipStreamWaitEvent(s_in, ev[3 + buf], 0));
+        FE_HIP_CHECK(hipMemcpy2DAsync(xd[buf], row * sizeof(float), wav_in_host + (size_t)c * row, in_stride * sizeof(float), row * sizeof(float), (size_t)B,
+                                      hipMemcpyHostToDevice, s_in));
+        FE_HIP_CHECK(hipEventRecord(ev[1 + buf], s_in));
+        // kernel of block c: input landed, and the output staging buffer has been copied out (block c - 2)
+        FE_HIP_CHECK(hipStreamWaitEvent(st, ev[1 + buf], 0));
+        if (c >= 2) FE_HIP_CHECK(hipStreamWaitEvent(st, ev[5 + buf], 0));
+        rc = run_step(h, xd[buf], row, state_dev, yd[buf], row, B, T, nullptr, nullptr, stream);
+        if (rc != FE_OK) return rc;
+        FE_HIP_CHECK(hipEventRecord(ev[3 + buf], st));
+        // copy-out of block c
+        FE_HIP_CHECK(hipStreamWaitEvent(s_out, ev[3 + buf], 0));
+        FE_HIP_CHECK(hipMemcpy2DAsync(wav_out_host + (size_t)c * row, out_stride * sizeof(float), yd[buf], row * sizeof(float), row * sizeof(float), (size_t)B,
+                                      hipMemcpyDeviceToHost, s_out));
+        FE_HIP_CHECK(hipEventRecord(ev[5 + buf], s_out));
+    }
+    for (int buf = 0; buf < (n_calls < 2 ? n_calls : 2); ++buf) FE_HIP_CHECK(hipStreamWaitEvent(st, ev[5 + buf], 0));
+    return FE_OK;
 }
 
 int fe_debug_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, float* state_dev, float* wav_out_dev,

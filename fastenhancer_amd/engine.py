@@ -240,6 +240,26 @@ class Engine:
                                         wav_out.stride(0) if B > 1 else T * H, B, T, _stream(self.device)), "fe_step")
         return wav_out
 
+    def step_host(self, wav_in: Tensor, state: Tensor, wav_out: Optional[Tensor] = None, T: int = 1) -> Tensor:
+        """fe_step_host: wav_in [B, n*T*H] in HOST memory (pinned for full speed) -> wav_out [B, n*T*H] in host memory, n calls of T hops
+        each with the copies of the neighbouring calls under each kernel; state (device) updated in place.  Asynchronous on the current
+        stream: synchronise it before reading wav_out."""
+        self._require_gpu()
+        B, H = wav_in.shape[0], self.cfg.hop_size
+        assert not wav_in.is_cuda and wav_in.dtype == torch.float32 and wav_in.stride(1) == 1 and wav_in.shape[1] % (T * H) == 0
+        assert state.numel() == self.state_floats(B) and state.is_contiguous() and state.is_cuda
+        n = wav_in.shape[1] // (T * H)
+        if wav_out is None:
+            wav_out = torch.empty(B, n * T * H, dtype=torch.float32).pin_memory()
+        assert not wav_out.is_cuda and wav_out.stride(1) == 1 and wav_out.shape == wav_in.shape
+        work = torch.empty(4 * B * T * H, dtype=torch.float32, device=self.device)
+        self._host_work = work          # (kept until the next call: the launches are asynchronous)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fe_step_host(self._h, ctypes.c_void_p(wav_in.data_ptr()), wav_in.stride(0) if B > 1 else n * T * H, _ptr(state),
+                                             ctypes.c_void_p(wav_out.data_ptr()), wav_out.stride(0) if B > 1 else n * T * H, B, T, n, _ptr(work),
+                                             _stream(self.device)), "fe_step_host")
+        return wav_out
+
     def set_offline_engine(self, engine: str):
         """fe_set_offline_engine: "auto" | "frame_walk" | "time_batched" (the layer-by-layer engine of csrc/tb_kernels.hip.h)"""
         code = {"auto": _lib.FE_OFFLINE_AUTO, "frame_walk": _lib.FE_OFFLINE_FRAME_WALK, "time_batched": _lib.FE_OFFLINE_TIME_BATCHED}[engine]

@@ -112,6 +112,22 @@ def enhance_stream(model, wav: Tensor, frames_per_call: int = 1) -> Tensor:
     cfg: FEConfig = model.cfg
     eng: Engine = model.engine
     N, H = cfg.n_fft, cfg.hop_size
+    if not wav.is_cuda:
+        # audio in host memory (how scripts/test_onnx.py holds it): hop blocks go over PCIe under the kernels of their neighbours
+        # (fe_step_host); the result comes back in pinned host memory
+        wav = wav.to(torch.float32).clamp(-1, 1)
+        B, length = wav.shape
+        n_hops = len(range(0, length + N - H, H))
+        T = max(1, int(frames_per_call))
+        n_calls = -(-n_hops // T)
+        padded = torch.zeros(B, max(n_calls * T * H, length + N), dtype=torch.float32).pin_memory()
+        padded[:, :length] = wav
+        out = torch.empty(B, n_calls * T * H, dtype=torch.float32).pin_memory()
+        state = eng.new_state(B)
+        eng.step_host(padded[:, :n_calls * T * H], state, out, T=T)
+        torch.cuda.current_stream(eng.device).synchronize()
+        s = N - H
+        return out[:, s:s + length].clamp(-1.0, 1.0)
     wav = wav.to(eng.device, torch.float32).clamp(-1, 1)
     B, length = wav.shape
     n_hops = len(range(0, length + N - H, H))

@@ -129,6 +129,15 @@ int fe_state_init(fe_handle* h, float* state_dev, int B, void* stream);
 int fe_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, float* state_dev,
             float* wav_out_dev, size_t out_stride, int B, int T, void* stream);
 
+/* The same step for callers whose audio lives in HOST memory (the reference's scripts/test_onnx.py feeds numpy arrays hop by hop):
+ * n_calls consecutive fe_step calls of T hops each, hop block c = hops c*T .. c*T+T-1 of
+ *   wav_in_host [b*in_stride + t*H + n], wav_out_host [b*out_stride + t*H + n]   (page-locked for asynchronous copies; pageable works, slower)
+ * The copy-in of block c + 1 and the copy-out of block c - 1 run under the kernel of block c: two copy streams of the handle next
+ * to `stream`, double-buffered device staging in work_dev (4*B*T*H floats).  Asynchronous: `stream` is complete when the last block
+ * is back in host memory.  (bench.py's `value` is the device-resident rate; this is the PCIe-inclusive one - DESIGN.md 1.) */
+int fe_step_host(fe_handle* h, const float* wav_in_host, size_t in_stride, float* state_dev, float* wav_out_host,
+                 size_t out_stride, int B, int T, int n_calls, float* work_dev, void* stream);
+
 /* The spec->spec step, ONNXModel.forward (model.py:677-710): spec [B, N/2+1, T, 2] in and out,
  * h_dev = the K GRU caches [K][B*F2][C2] (updated in place).  Any T >= 1. */
 int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* spec_out_dev,

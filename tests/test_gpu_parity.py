@@ -556,6 +556,33 @@ def test_time_batched_offline_matches_oracle_and_the_frame_walk(name):
     assert float((w1 - wav_tb[1:2]).abs().max()) == 0.0 and float((s1 - spec_tb[1:2]).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("name,T", [("fe_b", 1), ("fe_b", 3), ("bsrnn_xt", 1)])
+def test_step_with_host_buffers_matches_device_stepping(name, T):
+    """fe_step_host (audio in host memory, the copies of neighbouring hop blocks under each kernel) against fe_step on device
+    buffers: the same kernel on the same data - bit for bit, pinned or pageable host memory, strided rows; and enhance_stream on a
+    CPU tensor against enhance_stream on the device."""
+    from fastenhancer_amd.streaming import enhance_stream
+    m, orc, cfg, sr, seed = (_bsrnn(name) if name.startswith("bsrnn") else _model(name))
+    eng = m.engine
+    B, H, n = 5, cfg.hop_size, 7
+    x = torch.from_numpy(make_input(B, n * T * H + 40, 515, sr))
+    state_d, state_h, state_p = eng.new_state(B), eng.new_state(B), eng.new_state(B)
+    xd = x.to(_dev())
+    ref = torch.cat([eng.step(xd[:, c * T * H:(c + 1) * T * H], state_d, T=T).clone() for c in range(n)], dim=1)
+    xh = x.pin_memory()
+    yh = eng.step_host(xh[:, :n * T * H], state_h, T=T)           # (a strided view: row stride n*T*H + 40)
+    yp = torch.empty(B, n * T * H)
+    eng.step_host(x[:, :n * T * H], state_p, yp, T=T)               # pageable memory on both sides
+    torch.cuda.synchronize()
+    assert torch.equal(yh, ref.cpu()) and torch.equal(yp, ref.cpu())
+    assert torch.equal(state_h, state_d) and torch.equal(state_p, state_d)
+    if not name.startswith("bsrnn"):
+        w = torch.from_numpy(make_input(2, 9 * H + 11, 516, sr))
+        a = enhance_stream(m, w, frames_per_call=T)
+        b = enhance_stream(m, w.to(_dev()), frames_per_call=T)
+        assert not a.is_cuda and torch.equal(a, b.cpu())
+
+
 def test_time_batched_optional_schedules_agree_with_the_default():
     """The time-batched engine's opt-in schedules (measured slower, DESIGN 3c - but they must stay correct): the call cut into nodes
     (time chunks / utterance groups over the handle's streams, FE_TB_NC / FE_TB_G / FE_TB_STREAMS) and the fused block stage (scan and

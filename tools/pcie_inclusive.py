@@ -2,6 +2,7 @@
 audio in host memory pays): pinned host input -> device, fe_step, device -> pinned host output, per step.
    serial:    copy in, step, copy out, synchronise - every step (a caller that needs hop t's output before hop t + 1 arrives)
    pipelined: the same three operations queued on one stream for all steps, one synchronise at the end
+   overlapped: fe_step_host - the copies of the neighbouring hops under each kernel (three streams, events; enqueued in C++)
 Prints frames/s next to the device-resident rate bench.py reports.  tools/pcie_inclusive.py [workload] [streams]"""
 import json
 import sys
@@ -49,6 +50,20 @@ def run(mode):
     return B * steps / (time.perf_counter() - t0)
 
 
+def run_overlapped(T):
+    # fe_step_host: copy-in / kernel / copy-out of neighbouring hop blocks (T hops each) on three streams, enqueued by the library
+    xh = x_host.permute(1, 0, 2).reshape(B, steps * H).contiguous().pin_memory()
+    yh = torch.empty(B, steps * H).pin_memory()
+    eng.step_host(xh[:, :8 * T * H], state, yh[:, :8 * T * H], T=T)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.step_host(xh, state, yh, T=T)
+    torch.cuda.synchronize()
+    return B * steps / (time.perf_counter() - t0)
+
+
 res = {m: run(m) for m in ("resident", "pipelined", "serial")}
+res["overlapped"] = run_overlapped(1)
+res["overlapped_4_hops_per_call"] = run_overlapped(4)
 print(json.dumps({"workload": wl, "streams": B, "frames_per_s": {k: round(v) for k, v in res.items()},
                   "bytes_over_pcie_per_step": 2 * B * H * 4}))
