@@ -599,8 +599,11 @@ __device__ __forceinline__ void scan_role(const TbArgs& a, int rg, int dir, floa
             if (live[j] && col < C2) hbuf[0][(4 * lg + r) * LDX + col] = v;
         }
     }
-    float gxv[NTPW][3][4];
-    auto load_gx = [&](int t) {
+    // gx of the steps ahead: a ring of GD steps in registers.  gx does not fit in L2 for a real batch (10 KB per frame): with ONE step of
+    // prefetch every step waited for an HBM round trip - all scan variants ran at the same ~0.9 us per step whatever their arithmetic.
+    constexpr int GD = (NTPW * 12 <= 24) ? 4 : 2;
+    float gxv[GD][NTPW][3][4];
+    auto load_gx = [&](int slot, int t) {
         const size_t toff = (size_t)t * F2 * N3;
 #pragma unroll
         for (int j = 0; j < NTPW; ++j) {
@@ -609,16 +612,22 @@ __device__ __forceinline__ void scan_role(const TbArgs& a, int rg, int dir, floa
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 const float4 v = *reinterpret_cast<const float4*>(gxd + grow + toff + (size_t)(g * C2 + col) * F2);
-                gxv[j][g][0] = v.x; gxv[j][g][1] = v.y; gxv[j][g][2] = v.z; gxv[j][g][3] = v.w;
+                gxv[slot][j][g][0] = v.x; gxv[slot][j][g][1] = v.y; gxv[slot][j][g][2] = v.z; gxv[slot][j][g][3] = v.w;
             }
         }
     };
     const int t_first = dir ? a.T - 1 : 0, dt = dir ? -1 : 1;
-    load_gx(t_first);
+#pragma unroll
+    for (int d = 0; d < GD; ++d)
+        if (d < a.T) load_gx(d, t_first + d * dt);
     __syncthreads();
     int cur = 0;
 #pragma unroll 1
-    for (int st = 0; st < a.T; ++st) {
+    for (int st0 = 0; st0 < a.T; st0 += GD) {
+#pragma unroll
+    for (int d = 0; d < GD; ++d) {
+        const int st = st0 + d;
+        if (st >= a.T) break;
         const int t = t_first + st * dt;
         const float* hc = hbuf[cur] + li * LDX + lg;
         float av[KS];
@@ -630,8 +639,8 @@ __device__ __forceinline__ void scan_role(const TbArgs& a, int rg, int dir, floa
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gcur[j][g][r] = gxv[j][g][r];
-        if (st + 1 < a.T) load_gx(t + dt);                   // next step's x half: in flight under this step's MFMAs
+                for (int r = 0; r < 4; ++r) gcur[j][g][r] = gxv[d][j][g][r];
+        if (st + GD < a.T) load_gx(d, t + GD * dt);          // the x half GD steps ahead: in flight under the next GD - 1 steps
         f32x4 acc[NTPW][3];
 #pragma unroll
         for (int j = 0; j < NTPW; ++j) {
@@ -678,6 +687,7 @@ __device__ __forceinline__ void scan_role(const TbArgs& a, int rg, int dir, floa
             if (pub && tid == 0) __hip_atomic_store(a.prog + rg * kProgStride, (unsigned int)(st + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else
         __syncthreads();
+    }
     }
     if (hst != nullptr) {
 #pragma unroll
