@@ -121,6 +121,8 @@ struct fe_handle {
     unsigned long long* tb_probe_dev = nullptr;   // FE_TB_PROBE builds: phase clocks [4][kProbeSlots]
     hipStream_t host_streams[2] = {nullptr, nullptr};     // fe_step_host: copy-in / copy-out streams (lazy)
     hipEvent_t host_events[7] = {};                       // ... and its events
+    float* tb_work_dev = nullptr;             // fe_spec_step on the time-batched engine: grow-only work buffer
+    size_t tb_work_floats = 0;
     unsigned int* tb_prog_dev = nullptr;      // fused stages: the scan workgroups' frame counters [KB][2 * max_wgs]
     std::vector<Section> sections;
     size_t blob_floats = 0;
@@ -1332,6 +1334,7 @@ void fe_destroy(fe_handle* h) {
     for (hipEvent_t e : h->tb_events) (void)hipEventDestroy(e);
     if (h->tb_probe_dev) (void)hipFree(h->tb_probe_dev);
     if (h->tb_prog_dev) (void)hipFree(h->tb_prog_dev);
+    if (h->tb_work_dev) (void)hipFree(h->tb_work_dev);
     for (hipStream_t s : h->host_streams) if (s) (void)hipStreamDestroy(s);
     for (hipEvent_t e : h->host_events) if (e) (void)hipEventDestroy(e);
     delete h;
@@ -1563,6 +1566,19 @@ int fe_set_time_pipeline(fe_handle* h, int frames_in_flight) {
     return FE_OK;
 }
 
+static size_t tb_work_floats(const fe_handle* h, int B, int T, size_t* off);
+static int tb_run(fe_handle* h, fe::tb::TbArgs a0, float* work_dev, int B, int T, hipStream_t st);
+static int pipe_width(const fe_handle* h, int B, int T);
+
+// spec -> spec chunks on the time-batched engine: when asked for (FE_OFFLINE_TIME_BATCHED), or - AUTO - for long chunks of batches that
+// the time pipeline cannot take (more than #CUs / 2 streams: each workgroup would walk its T frames alone) or that are simply large
+static bool use_tb_spec(const fe_handle* h, int B, int T) {
+    if (!h->impl || !h->impl->tb || h->d.BD || h->offline_engine == FE_OFFLINE_FRAME_WALK || T < 2) return false;
+    if (h->offline_engine == FE_OFFLINE_TIME_BATCHED) return true;
+    if (h->d.C2 >= 72) return false;
+    return T >= 16 && (pipe_width(h, B, T) == 0 || (long)B * T >= 2048);
+}
+
 int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* spec_out_dev, int B, int T, void* stream) {
     int rc = check_ready(h);
     if (rc != FE_OK) return rc;
@@ -1586,6 +1602,23 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
         return launch_bsrnn(h, ba, stream);
     }
     if (h->d.BD) return fail(FE_ERR_UNSUPPORTED_CONFIG, "the noncausal model has no spec -> spec step with caches (models/fastenhancer/noncausal/model.py has the offline Model only): use fe_offline");
+    if (use_tb_spec(h, B, T)) {
+        // the chunk as one encoder pass, per block a scan that starts from the caller's GRU state and leaves the new one + a tile pass,
+        // one decoder pass (fe_spec_step has no work buffer argument: the handle keeps a grow-only one - a first / larger call allocates)
+        const size_t need = tb_work_floats(h, B, T, nullptr);
+        if (need > h->tb_work_floats) {
+            if (h->tb_work_dev) { FE_HIP_CHECK(hipFree(h->tb_work_dev)); h->tb_work_dev = nullptr; h->tb_work_floats = 0; }
+            FE_HIP_CHECK(hipMalloc(&h->tb_work_dev, need * sizeof(float)));
+            h->tb_work_floats = need;
+        }
+        fe::tb::TbArgs ta{};
+        ta.wp = h->packed_dev;
+        ta.spec_in = spec_in_dev; ta.spec_out = spec_out_dev;
+        ta.hstate = h_dev; ta.h_init = 1;
+        ta.mode = fe::FE_MODE_SPEC;
+        ta.compression = h->cfg.input_compression;
+        return tb_run(h, ta, h->tb_work_dev, B, T, (hipStream_t)stream);
+    }
     rc = ensure_scratch(h, B);
     if (rc != FE_OK) return rc;
     fe::FrameArgs a = base_args(h, B, T);

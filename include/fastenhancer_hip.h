@@ -162,6 +162,9 @@ int fe_set_time_pipeline(fe_handle* h, int frames_in_flight);
  *   FE_OFFLINE_FRAME_WALK: the per-hop kernel walking (or, fe_set_time_pipeline, pipelining) the frames of each utterance.
  *   FE_OFFLINE_AUTO: time-batched, except for the big shapes (rf_channels >= 72) with 8 or more utterances, where the pipelined
  *     walk of the per-hop kernel is the faster one.
+ * fe_spec_step follows the same setting: FE_OFFLINE_TIME_BATCHED runs every chunk of T >= 2 frames on the time-batched engine (the
+ * scans start from the caller's GRU caches and leave the new ones), AUTO the chunks of 16+ frames of batches too large for the time
+ * pipeline (or of 2048+ frames in all); the handle then keeps a grow-only work buffer (a first / larger call allocates).
  * Results agree to fp32 rounding.  The other architectures / variants always walk.  A handle's compute calls must be stream-ordered
  * (one stream, or event-ordered streams): the engines keep per-handle scratch, counters and helper streams. */
 #define FE_OFFLINE_AUTO 0

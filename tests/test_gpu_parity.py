@@ -583,6 +583,40 @@ def test_step_with_host_buffers_matches_device_stepping(name, T):
         assert not a.is_cuda and torch.equal(a, b.cpu())
 
 
+@pytest.mark.parametrize("name", ["fe_t", "fe_b"])
+def test_spec_chunks_on_the_time_batched_engine_carry_the_caches(name):
+    """fe_spec_step (ONNXModel.forward(spec, *caches), model.py:677-710) on the time-batched engine: two consecutive chunks with the GRU
+    caches carried from one to the next, against the frame walk (same kernels as the per-hop step) and against the oracle; the scan
+    starts from the caller's state and leaves the new one in its place."""
+    mo, orc, cfg, sr, seed = _model(name)
+    eng = mo.engine
+    B, H, T1, T2 = 3, cfg.hop_size, 21, 34
+    x = make_input(B, (T1 + T2) * H, 4242, sr)
+    cache = orc.initialize_cache(B)[0]
+    specs = []
+    for t in range(T1 + T2):
+        s_, cache = orc.stft_step(x[:, t * H:(t + 1) * H], cache)
+        specs.append(s_)
+    spec = np.concatenate(specs, axis=2).astype(np.float32)             # [B, F, T, 2]
+    sd = torch.from_numpy(spec).to(_dev())
+    outs = {}
+    for engine in ("frame_walk", "time_batched"):
+        eng.set_offline_engine(engine)
+        caches = mo.initialize_cache(sd[:, :, :1])
+        y1, *caches = mo(sd[:, :, :T1].contiguous(), *caches)
+        y2, *caches = mo(sd[:, :, T1:].contiguous(), *caches)
+        outs[engine] = (torch.cat([y1, y2], dim=2), [c.clone() for c in caches])
+    eng.set_offline_engine("auto")
+    (ya, ca), (yb, cb) = outs["frame_walk"], outs["time_batched"]
+    assert float((ya - yb).abs().max()) <= 3e-5 * max(1.0, float(ya.abs().max())), float((ya - yb).abs().max())
+    for p_, q_ in zip(ca, cb):
+        assert float((p_ - q_).abs().max()) <= 3e-5 * max(1.0, float(p_.abs().max()))
+    y_ref, co = orc.spec_forward(spec, orc.initialize_cache(B)[2:])
+    _assert_close(yb.cpu().numpy(), y_ref, "time-batched spec chunks vs oracle")
+    for got, want in zip(cb, co):
+        _assert_close(got.cpu().numpy(), want, "GRU cache after the chunks")
+
+
 def test_time_batched_optional_schedules_agree_with_the_default():
     """The time-batched engine's opt-in schedules (measured slower, DESIGN 3c - but they must stay correct): the call cut into nodes
     (time chunks / utterance groups over the handle's streams, FE_TB_NC / FE_TB_G / FE_TB_STREAMS) and the fused block stage (scan and
