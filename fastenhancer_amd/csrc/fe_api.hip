@@ -1532,9 +1532,11 @@ int fe_profile_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, flo
 }
 
 // workgroups per stream of a time-pipelined launch (0: one workgroup walks the frames of a stream)
-static int pipe_width(const fe_handle* h, int B, int T) {
+static int pipe_width(const fe_handle* h, int B, int T, bool offline = false) {
     if (!h->impl || h->pipe_frames == 0 || h->pipe_frames == 1 || T < 4 || 2 * B > h->max_wgs) return 0;
-    if (h->d.KT > 1) return 0;     // (the time_kernel convs carry whole input frames from frame to frame: one workgroup walks them)
+    // (time_kernel variant: its convs' inputs are handed from frame to frame through rings in the work buffer - fe_offline only; a
+    //  spec -> spec step with caches walks)
+    if (h->d.KT > 1 && !offline) return 0;
     if (h->d.TA) return 0;         // (so do the dptransformer variant's K / V caches)
     // automatic width: a hand-off (counter round trip + state fetch + the h half of the GRU + gates + publish) takes
     // ~2.6 us whatever the model; a frame takes ~4 us per MFLOP/frame at the measured kernel efficiency: that many frames
@@ -1568,7 +1570,7 @@ int fe_set_time_pipeline(fe_handle* h, int frames_in_flight) {
 
 static size_t tb_work_floats(const fe_handle* h, int B, int T, size_t* off);
 static int tb_run(fe_handle* h, fe::tb::TbArgs a0, float* work_dev, int B, int T, hipStream_t st);
-static int pipe_width(const fe_handle* h, int B, int T);
+static int pipe_width(const fe_handle* h, int B, int T, bool offline);
 
 // spec -> spec chunks on the time-batched engine: when asked for (FE_OFFLINE_TIME_BATCHED), or - AUTO - for long chunks of batches that
 // the time pipeline cannot take (more than #CUs / 2 streams: each workgroup would walk its T frames alone) or that are simply large
@@ -1576,7 +1578,7 @@ static bool use_tb_spec(const fe_handle* h, int B, int T) {
     if (!h->impl || !h->impl->tb || h->d.BD || h->offline_engine == FE_OFFLINE_FRAME_WALK || T < 2) return false;
     if (h->offline_engine == FE_OFFLINE_TIME_BATCHED) return true;
     if (h->d.C2 >= 72) return false;
-    return T >= 16 && (pipe_width(h, B, T) == 0 || (long)B * T >= 2048);
+    return T >= 16 && (pipe_width(h, B, T, false) == 0 || (long)B * T >= 2048);
 }
 
 int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* spec_out_dev, int B, int T, void* stream) {
@@ -1822,7 +1824,10 @@ size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw) {
     size_t n = (size_t)B * ((size_t)(d.NFFT - d.HOP) + d.hstate() + tk_floats(h));
     const int T = 1 + Tw / d.HOP;
     // (whatever fe_set_time_pipeline says at the time of THIS call: a buffer sized with the pipeline off must still do when it is on)
-    if (h->impl && T >= 4 && d.KT == 1 && !d.TA) n += (((size_t)B * d.KB + 3) & ~(size_t)3) + (size_t)B * T * d.NFFT;
+    if (h->impl && T >= 4 && !d.TA) {
+        n += (((size_t)B * (d.KB + (d.KT > 1 ? 2 * d.NL : 0)) + 3) & ~(size_t)3) + (size_t)B * T * d.NFFT;
+        if (d.KT > 1) n += (size_t)B * 2 * d.NL * (64 + d.KT - 1) * d.F1 * d.C1;      // the time convs' input rings at the widest pipeline
+    }
     return n;
 }
 
@@ -1864,7 +1869,7 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
         size_t nz = (size_t)B * ((size_t)(d.NFFT - d.HOP) + d.hstate() + tk_floats(h));
         if (h->bimpl) nz = (size_t)B * (size_t)(d.NFFT - d.HOP) + ((bsrnn_lstm_floats(h, B) + 3) & ~(size_t)3) + (((size_t)B * h->cfg.rf_blocks + 3) & ~(size_t)3);
         else if (h->fimpl || h->limpl) nz = fe_offline_work_floats(h, B, Tw);
-        else if (pipe_width(h, B, T)) nz += ((size_t)B * d.KB + 3) & ~(size_t)3;
+        else if (pipe_width(h, B, T, true)) nz += ((size_t)B * (d.KB + (d.KT > 1 ? 2 * d.NL : 0)) + 3) & ~(size_t)3;
         FE_HIP_CHECK(hipMemsetAsync(work_dev, 0, nz * sizeof(float), st));
     }
     if (h->limpl) {
@@ -1936,12 +1941,15 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
     a.h = work_dev + (size_t)B * (d.NFFT - d.HOP);
     a.tk = a.h + (size_t)B * d.hstate();
     hipError_t e = hipSuccess;
-    if (const int P = pipe_width(h, B, T)) {
+    if (const int P = pipe_width(h, B, T, true)) {
         rc = ensure_tables(h, st);
         if (rc != FE_OK) return rc;
-        float* flags = a.h + (size_t)B * d.hstate();
+        // work buffer: tail | GRU states | time-conv caches (serial walk) | frame counters | windowed frames | time-conv input rings
+        float* const tk_serial = a.tk;
+        float* flags = a.tk + (size_t)B * tk_floats(h);
         a.pipe_flags = reinterpret_cast<unsigned int*>(flags);
-        a.frames = flags + (((size_t)B * d.KB + 3) & ~(size_t)3);
+        a.frames = flags + (((size_t)B * (d.KB + (d.KT > 1 ? 2 * d.NL : 0)) + 3) & ~(size_t)3);
+        if (d.KT > 1) a.tk = a.frames + (size_t)B * T * d.NFFT;      // (PIPE: rings of P + KT - 1 slots per conv and stream)
         a.pipe_p = P;
         h->impl->launch_pipe(a, st, &e);
         if (e != hipSuccess) {     // the runtime refused co-residency (GPU shared with other work): walk the frames serially
@@ -1949,6 +1957,7 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
             a.pipe_p = 0;
             a.pipe_flags = nullptr;
             a.frames = nullptr;
+            a.tk = tk_serial;
             h->impl->launch(a, h->max_wgs, st, &e);
             if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
             return FE_OK;

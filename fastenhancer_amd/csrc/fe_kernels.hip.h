@@ -257,7 +257,8 @@ struct FrameArgs {
     float compression;
     float rf_eps;             // ln variant: eps of the blocks' LayerNorms (rnnformer_kwargs.eps)
     // time-pipelined launches (PIPE instantiation): P workgroups per stream, workgroup p runs frames p, p + P, ...
-    unsigned int* pipe_flags; // [B][KB]: number of frames whose block-k GRU state has been published (zeroed before the launch)
+    unsigned int* pipe_flags; // [B][KB (+ 2 NL, time_kernel variant)]: number of frames whose block-k GRU state (whose input of time conv
+                              // j) has been published (zeroed before the launch)
     float* frames;            // offline: [B][T][N] windowed output frames (overlap-added by istft_ola_kernel afterwards)
     int pipe_p;
 };
@@ -1325,7 +1326,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
     do {
     float* cst = a.cache_stft + (size_t)b * OVL;
     float* cis = a.cache_istft + (size_t)b * OVL;
-    unsigned int* pflag = PIPE ? a.pipe_flags + (size_t)b * S::KB : nullptr;
+    constexpr int NFLAG = S::KB + (S::KT > 1 ? 2 * S::NL : 0);       // counters per stream
+    unsigned int* pflag = PIPE ? a.pipe_flags + (size_t)b * NFLAG : nullptr;
     // wait until the block-k state of frame t-1 is published (all threads call; thread 0 polls)
     auto pipe_wait = [&](int k, int t) {
         if constexpr (PIPE) {
@@ -1529,6 +1531,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
             static_assert(Q4 % kThreads == 0, "cache slots are moved by whole float4 rounds");
             float* CAb = smem + L::CA;
             float4* tkg = reinterpret_cast<float4*>(a.tk + ((size_t)lidx * a.B + b) * S::TKQ);
+            // PIPE (time-pipelined offline launch): the conv's input of every frame goes through a RING of pipe_p + KT - 1 slots per
+            // (conv, stream) in a.tk instead of the two-slot cache - frame t publishes its input in slot t mod RS and counts it in
+            // pflag[KB + conv]; frames t + 1 .. t + KT - 1 wait for that count and fetch the slot (agent-scope accesses on both sides).
+            // Slot t mod RS is overwritten by frame t + RS, run by the workgroup of frame t + KT - 1 after that frame: every reader is done.
+            const int RS = PIPE ? a.pipe_p + KT - 1 : 1;
+            float* ringb = a.tk + (((size_t)lidx * a.B + b) * RS) * (size_t)(F1 * C1);
             f32x4 acc[S::MTPW][S::NTC];
             float4 creg[CPT];
             static_for<KT>([&](auto s_) {
@@ -1536,8 +1544,26 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 FE_BEGIN_UNIT(U0 + sub);
                 if constexpr (sub == 0) {
                     acc_init_bias<S::MTPW, S::NTC>(acc, wb, b_off, 0, 1, S::NTC);
+                    if constexpr (PIPE) {
+                        if (t > 0) {
+                            if (tid == 0) {
+                                while (__hip_atomic_load(pflag + S::KB + lidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)t) __builtin_amdgcn_s_sleep(1);
+                            }
+                            __syncthreads();
+                        }
+#pragma unroll
+                        for (int q = 0; q < CPT; ++q) {
+                            const int e4 = tid + q * kThreads, slot = e4 / Q4, r = e4 - slot * Q4;
+                            const int fr = t - (KT - 1) + slot;                    // slot 0 = the oldest frame of the window
+                            const float* src = ringb + (size_t)((fr < 0 ? 0 : fr) % RS) * (F1 * C1) + 4 * r;
+                            float4 v;
+                            v.x = ld_state(src); v.y = ld_state(src + 1); v.z = ld_state(src + 2); v.w = ld_state(src + 3);
+                            creg[q] = fr < 0 ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : v;      // (before the utterance: the zero cache of Model.forward)
+                        }
+                    } else {
 #pragma unroll
                     for (int q = 0; q < CPT; ++q) creg[q] = tkg[tid + q * kThreads];
+                    }
                 }
                 const float* src = sub == 0 ? in : CAb + (KT - 1 - sub) * S::ACT;     // tap 1 <-> frame t-1 = the newest slot
                 const float* const taps[3] = {src + (16 * wave + li + 0) * LDC + lg, src + (16 * wave + li + 1) * LDC + lg,
@@ -1553,7 +1579,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                         // (the state holds the reference's activations; the conv trunk works on them scaled by kSiluScale)
                         d2[0] = make_float2(creg[q].x * kSiluScale, creg[q].y * kSiluScale);
                         d2[1] = make_float2(creg[q].z * kSiluScale, creg[q].w * kSiluScale);
-                        if (slot >= 1) tkg[e4 - Q4] = creg[q];                     // shift: slot j <- old slot j + 1
+                        if constexpr (!PIPE) { if (slot >= 1) tkg[e4 - Q4] = creg[q]; }      // shift: slot j <- old slot j + 1
                     }
 #pragma unroll
                     for (int q = 0; q < NPT; ++q) {                                 // newest slot <- this frame's input
@@ -1561,10 +1587,18 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                         const float2* s2 = reinterpret_cast<const float2*>(in + (f + 1) * LDC + c);
                         const float2 v0 = s2[0], v1 = s2[1];
                         constexpr float un = 1.0f / kSiluScale;
+                        if constexpr (PIPE) {
+                            float* dst = ringb + (size_t)(t % RS) * (F1 * C1) + 4 * r;
+                            st_state(dst, v0.x * un); st_state(dst + 1, v0.y * un); st_state(dst + 2, v1.x * un); st_state(dst + 3, v1.y * un);
+                        } else
                         tkg[(KT - 2) * Q4 + r] = make_float4(v0.x * un, v0.y * un, v1.x * un, v1.y * un);
                     }
+                    if constexpr (PIPE) __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this thread's slot stores have left the CU
                 }
                 if constexpr (sub + 1 < KT) __syncthreads();
+                if constexpr (PIPE && sub == 0) {
+                    if (tid == 0) __hip_atomic_store(pflag + S::KB + lidx, (unsigned int)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             });
             conv_store<S, S::NTC, C1, LDC, true>(acc, out, 1, wave, lane);
             }

@@ -478,6 +478,28 @@ def test_offline_model_forward_matches_reference_golden(name):
     assert torch.equal(wav3, wav_hat)
 
 
+def test_time_kernel_time_pipelined_offline_agrees_with_the_serial_walk():
+    """The time_kernel variant's offline Model.forward with the frames of an utterance over co-resident workgroups: besides the GRU
+    states, every causal time conv hands its INPUT of frame t to frames t + 1, t + 2 through a ring of slots and a counter per
+    (conv, stream).  Against the serial walk and the oracle, at several widths (the ring has pipe + 2 slots), twice each."""
+    m, orc, cfg, sr, seed = _model("fe_tk_b", "Model")
+    eng = m.engine
+    x = make_input(2, 70 * cfg.hop_size + 3, 777, sr)
+    xd = torch.from_numpy(x).to(_dev())
+    eng.set_time_pipeline(0)
+    w_ser, s_ser = [t.clone() for t in m(xd)]
+    for width in (16, 3, -1):
+        eng.set_time_pipeline(width)
+        for rep in range(2):
+            w, s_ = m(xd)
+            assert float((w - w_ser).abs().max()) <= 2e-5 * max(1.0, float(w_ser.abs().max())), (width, rep, float((w - w_ser).abs().max()))
+            assert float((s_ - s_ser).abs().max()) <= 2e-5 * max(1.0, float(s_ser.abs().max())), (width, rep)
+    wav_ref, spec_ref = orc.offline_forward(x)
+    _assert_close(w.cpu().numpy(), wav_ref, "time_kernel pipelined offline wav vs oracle")
+    _assert_close(s_.cpu().numpy(), spec_ref, "time_kernel pipelined offline spec vs oracle")
+    eng.set_time_pipeline(-1)
+
+
 @pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_m", "fe48_b", "fe_dprnn_b", "fe_ln_b"])
 def test_time_pipelined_offline_and_spec_agree_with_the_serial_walk(name):
     """fe_offline / fe_spec_step with T >= 4 spread a stream's frames over co-resident workgroups that hand the GRU state
