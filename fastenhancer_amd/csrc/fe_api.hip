@@ -1537,13 +1537,14 @@ static int pipe_width(const fe_handle* h, int B, int T, bool offline = false) {
     // (time_kernel variant: its convs' inputs are handed from frame to frame through rings in the work buffer - fe_offline only; a
     //  spec -> spec step with caches walks)
     if (h->d.KT > 1 && !offline) return 0;
-    if (h->d.TA) return 0;         // (so do the dptransformer variant's K / V caches)
+    if (h->d.TA && !offline) return 0;   // (dptransformer: per-frame K / V rings in the work buffer - fe_offline only)
     // automatic width: a hand-off (counter round trip + state fetch + the h half of the GRU + gates + publish) takes
     // ~2.6 us whatever the model; a frame takes ~4 us per MFLOP/frame at the measured kernel efficiency: that many frames
     // are worth having in flight (measured optimum: T 8-12, B 16, 48 kHz B 24, L > 24), more only adds pollers
     int want = h->pipe_frames;
     if (want < 0) {
         want = (int)(fe_flops_per_frame(h) / 6.0e5) + 2;
+        if (h->d.TA) want *= 2;     // (dptransformer: a frame spends half its time streaming its K / V window - measured 16 -> 32 in flight: 1.37 -> 0.73 ms)
         want = want < 8 ? 8 : (want > 64 ? 64 : want);
     }
     int p = h->max_wgs / B;
@@ -1824,9 +1825,10 @@ size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw) {
     size_t n = (size_t)B * ((size_t)(d.NFFT - d.HOP) + d.hstate() + tk_floats(h));
     const int T = 1 + Tw / d.HOP;
     // (whatever fe_set_time_pipeline says at the time of THIS call: a buffer sized with the pipeline off must still do when it is on)
-    if (h->impl && T >= 4 && !d.TA) {
+    if (h->impl && T >= 4) {
         n += (((size_t)B * (d.KB + (d.KT > 1 ? 2 * d.NL : 0)) + 3) & ~(size_t)3) + (size_t)B * T * d.NFFT;
         if (d.KT > 1) n += (size_t)B * 2 * d.NL * (64 + d.KT - 1) * d.F1 * d.C1;      // the time convs' input rings at the widest pipeline
+        if (d.TA) n += (size_t)B * 2 * d.KB * d.F2 * d.C2 * (d.TA + 64);                // the K / V rings at the widest pipeline
     }
     return n;
 }
@@ -1950,6 +1952,8 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
         a.pipe_flags = reinterpret_cast<unsigned int*>(flags);
         a.frames = flags + (((size_t)B * (d.KB + (d.KT > 1 ? 2 * d.NL : 0)) + 3) & ~(size_t)3);
         if (d.KT > 1) a.tk = a.frames + (size_t)B * T * d.NFFT;      // (PIPE: rings of P + KT - 1 slots per conv and stream)
+        float* const h_serial = a.h;
+        if (d.TA) a.h = a.frames + (size_t)B * T * d.NFFT;           // (PIPE: K / V rings of L + P slots per pair)
         a.pipe_p = P;
         h->impl->launch_pipe(a, st, &e);
         if (e != hipSuccess) {     // the runtime refused co-residency (GPU shared with other work): walk the frames serially
@@ -1958,6 +1962,7 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
             a.pipe_flags = nullptr;
             a.frames = nullptr;
             a.tk = tk_serial;
+            a.h = h_serial;
             h->impl->launch(a, h->max_wgs, st, &e);
             if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
             return FE_OK;

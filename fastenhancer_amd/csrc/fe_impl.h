@@ -67,7 +67,7 @@ void launch_impl(const FrameArgs& a, int max_wgs, hipStream_t st, hipError_t* er
 // that the runtime guarantees (or refuses) their co-residency instead of a spin-wait deadlock.
 template <class S>
 void launch_pipe_impl(const FrameArgs& a, hipStream_t st, hipError_t* err) {
-    if constexpr (S::TATT) { *err = hipErrorNotSupported; return; } else {     // (the K / V caches are handed from frame to frame: one workgroup walks them)
+    {
     auto* fn = &fe_frame_kernel<S, false, -1, false, true, true>;
     static std::atomic<bool> attr_set[kMaxDevices];
     int dev = 0;

@@ -1349,7 +1349,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
     };
 
     int ring_head0 = 0;                              // dptransformer: slot of the oldest cached frame when this launch starts
-    if constexpr (S::TATT) ring_head0 = (int)a.h[(size_t)a.B * S::KB * S::HSTATE + b];
+    if constexpr (S::TATT && !PIPE) ring_head0 = (int)a.h[(size_t)a.B * S::KB * S::HSTATE + b];
 #pragma unroll 1
     for (int t = t_first; t < a.T; t += t_step, ++fc) {
         // A loop-variant zero keeps the (many) wave-uniform offsets of a frame from being hoisted out of the frame
@@ -1781,7 +1781,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
             if constexpr (S::TATT) {
                 // dptransformer variant (models/fastenhancer/dptransformer/model.py:200-236, 378-389): causal attention over time per
                 // sub-band and head.  Phase A: q | k | v of the frame = x W^T -> Gi (the layout of the sub-band attention's qkv).
-                static_assert(!L::PERHEAD && !PIPE && S::LB == 31, "dptransformer: full qkv buffer, one workgroup per stream, lookbehind 31");
+                static_assert(!L::PERHEAD && S::LB == 31, "dptransformer: full qkv buffer, lookbehind 31");
                 // (Wtq was fetched inside the previous phase's GEMM: rf_pre's for block 0, the previous block's attn_fc after that;
                 //  shapes that stream their block weights re-bind here)
                 if constexpr (!REGW) Wtq.bind(wb, (o.blk_tqkv[0] + kb), -1, S::NT3, wave);
@@ -1821,6 +1821,88 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     // instead of the reference's shift of all 31 (k[:, :, -L:]), which would double the HBM traffic of this HBM-bound
                     // step.  With head = 0 the ring IS the reference's cache tensor.  A slot whose first K element is +inf is masked
                     // (how a cache-less run marks frames before the start), as are, in offline mode, the slots older than the utterance.
+                    if constexpr (PIPE) {
+                    // time-pipelined offline launch: the K / V "caches" are per-frame rings of L + pipe_p slots per pair in the work buffer
+                    // ([pair][RS][hd]; frame fr lives in slot fr mod RS).  The frame's own k / v go out FIRST and are counted in pflag[k] as
+                    // soon as frame t - 1 has counted its own - the next frame waits for that, not for this frame's attention -, then the
+                    // window t - 31 .. t - 1 is fetched
+                    // (agent-scope accesses on both sides; slots older than the utterance are masked by frame index and read as zero).
+                    constexpr int LBK = S::LB, PAIRS = F2 * S::NH;
+                    const int RS = LBK + a.pipe_p;
+                    const size_t cstride = (size_t)F2 * C2 * RS;
+                    float* kc = a.h + ((size_t)(2 * k) * a.B + b) * cstride;
+                    float* vc = a.h + ((size_t)(2 * k + 1) * a.B + b) * cstride;
+                    {
+                        const int slot = t % RS;
+                        for (int e = tid; e < PAIRS * HD; e += kThreads) {
+                            const int p = e / HD, d = e - p * HD, f = p / S::NH, hh = p - f * S::NH;
+                            const float* qk = Gi + f * LDG + hh * 3 * HD;
+                            st_state(kc + ((size_t)p * RS + slot) * HD + d, qk[HD + d]);
+                            st_state(vc + ((size_t)p * RS + slot) * HD + d, qk[2 * HD + d]);
+                        }
+                    }
+                    // (wait first, then count: the counter must never step back - frame t + 1 may get here before frame t)
+                    pipe_wait(k, t);
+                    pipe_publish(k, t);
+                    const int grp = tid >> 4, l16 = tid & 15;
+                    const int mask_lo = LBK - t > 0 ? LBK - t : 0;
+                    const float sc = __builtin_amdgcn_rsqf((float)HD);
+                    const int j1 = l16 + 16;                                        // position 31 = the current frame
+                    const bool m0 = l16 < mask_lo, m1 = j1 < LBK && j1 < mask_lo;
+                    int fr0 = t - LBK + l16, fr1 = t - LBK + (j1 < LBK ? j1 : 0);
+                    fr0 = fr0 < 0 ? 0 : fr0; fr1 = fr1 < 0 ? 0 : fr1;
+                    const int sl0 = fr0 % RS, sl1 = fr1 % RS;
+                    constexpr int NIT = ceil_div(PAIRS, 16);
+                    static_assert(S::NH == 4, "head of a pair = its index mod 4");
+                    const float tpe0 = wb.gather_g(o.tpe + (grp & 3) * 32 + l16), tpe1 = wb.gather_g(o.tpe + (grp & 3) * 32 + j1);
+#pragma unroll 1
+                    for (int it = 0; it < NIT; ++it) {
+                        int p = grp + 16 * it;
+                        const bool live = p < PAIRS;
+                        p = live ? p : PAIRS - 1;
+                        const int f = p / S::NH, hh = p - f * S::NH;
+                        const float* qk = Gi + f * LDG + hh * 3 * HD;
+                        const float* kp = kc + (size_t)p * (RS * HD);
+                        const float* vp = vc + (size_t)p * (RS * HD);
+                        float k0[HD], k1[HD], v0[HD], v1[HD];
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) k0[d] = ld_state(kp + sl0 * HD + d);
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) k1[d] = ld_state(kp + sl1 * HD + d);
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) v0[d] = ld_state(vp + sl0 * HD + d);
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) v1[d] = ld_state(vp + sl1 * HD + d);
+                        if (j1 == LBK) {
+#pragma unroll
+                            for (int d = 0; d < HD; ++d) { k1[d] = qk[HD + d]; v1[d] = qk[2 * HD + d]; }
+                        }
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) {          // (slots before the utterance hold whatever the buffer held: keep it out of the sums)
+                            v0[d] = m0 ? 0.0f : v0[d];
+                            v1[d] = m1 ? 0.0f : v1[d];
+                        }
+                        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) { const float qd = qk[d]; s0 = fmaf(qd, k0[d], s0); s1 = fmaf(qd, k1[d], s1); }
+                        const float ninf = -__builtin_inff();
+                        s0 = m0 ? ninf : fmaf(sc, s0, tpe0);
+                        s1 = m1 ? ninf : fmaf(sc, s1, tpe1);
+                        const float mx = row16_allreduce(fmaxf(s0, s1), [](float x, float y) { return fmaxf(x, y); });
+                        const float e0 = __expf(s0 - mx), e1 = __expf(s1 - mx);
+                        const float inv = __builtin_amdgcn_rcpf(row16_allreduce(e0 + e1, [](float x, float y) { return x + y; }));
+                        float od = 0.0f, od2 = 0.0f;
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) {
+                            const float sum = row16_allreduce(e0 * v0[d] + e1 * v1[d], [](float x, float y) { return x + y; });
+                            if (d < 16) od = (l16 == d) ? sum : od; else od2 = (l16 == d - 16) ? sum : od2;
+                        }
+                        if (live) {
+                            if (l16 < HD) Hl[f * LDX + hh * HD + l16] = od * inv;
+                            if (HD > 16 && l16 + 16 < HD) Hl[f * LDX + hh * HD + l16 + 16] = od2 * inv;
+                        }
+                    }
+                    } else {
                     constexpr int LBK = S::LB, PAIRS = F2 * S::NH;
                     const size_t cstride = (size_t)F2 * C2 * LBK;                    // one cache tensor of one stream: [F2][NH][L][HD]
                     float* kc = a.h + ((size_t)(2 * k) * a.B + b) * cstride;
@@ -1886,6 +1968,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                         }
                     }
                     if (k == S::KB - 1 && tid == 0) a.h[(size_t)a.B * S::KB * S::HSTATE + b] = (float)((head + 1) % LBK);
+                    }
                 }
             } else
             {
@@ -2122,7 +2205,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 }
             }
             if (k == 0) FE_CLK(47);
-            if constexpr (PIPE) pipe_publish(k, t);      // (its barrier is this phase's barrier)
+            if constexpr (PIPE && !S::TATT) pipe_publish(k, t);      // (its barrier is this phase's barrier; dptransformer: published above)
             else __syncthreads();
             if (k == 0) FE_CLK(21);
             if (k == 0) FE_CLK(22);

@@ -148,9 +148,9 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
  * RNNFormer block from frame to frame through global memory (everything else in a frame is independent of the other
  * frames).  Negative (the default) = a width chosen from the model size (8 .. 64); 0 or 1 = off (one workgroup walks the
  * T frames of a stream).  Results agree to fp32 rounding.  BSRNN's fe_offline is pipelined the same way (the time-LSTM (h, c) of
- * each layer is the hand-off; up to 64 frames in flight), and so are the ln variant's and the time_kernel variant's (fe_offline
- * only: its time convs hand their input frames on through rings in work_dev); the dptransformer variant (K / V caches carried
- * from frame to frame), FSPEN and LiSenNet walk. */
+ * each layer is the hand-off; up to 64 frames in flight), and so are the ln variant's, the time_kernel variant's and the
+ * dptransformer variant's (the last two fe_offline only: the time convs' input frames / the K-V caches go through per-frame rings in
+ * work_dev); FSPEN and LiSenNet walk. */
 int fe_set_time_pipeline(fe_handle* h, int frames_in_flight);
 
 /* Engine of fe_offline for the default and noncausal FastEnhancer models:

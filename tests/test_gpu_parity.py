@@ -478,6 +478,29 @@ def test_offline_model_forward_matches_reference_golden(name):
     assert torch.equal(wav3, wav_hat)
 
 
+@pytest.mark.parametrize("name", ["fe_dpt_t", "fe_dpt_b"])
+def test_dptransformer_time_pipelined_offline_agrees_with_the_serial_walk(name):
+    """The dptransformer variant's offline Model.forward over co-resident workgroups: the K / V caches become per-frame rings of
+    L + pipe slots in the work buffer, a frame publishes its k / v of a block before it attends.  Utterances longer than the lookbehind
+    (the window slides over ring wrap-arounds), several widths, twice each; against the serial walk and the oracle."""
+    m, orc, cfg, sr, seed = _model(name, "Model")
+    eng = m.engine
+    x = make_input(2, 83 * cfg.hop_size + 9, 778, sr)
+    xd = torch.from_numpy(x).to(_dev())
+    eng.set_time_pipeline(0)
+    w_ser, s_ser = [t.clone() for t in m(xd)]
+    for width in (16, 5, -1):
+        eng.set_time_pipeline(width)
+        for rep in range(2):
+            w, s_ = m(xd)
+            assert float((w - w_ser).abs().max()) <= 2e-5 * max(1.0, float(w_ser.abs().max())), (width, rep, float((w - w_ser).abs().max()))
+            assert float((s_ - s_ser).abs().max()) <= 2e-5 * max(1.0, float(s_ser.abs().max())), (width, rep)
+    wav_ref, spec_ref = orc.offline_forward(x)
+    _assert_close(w.cpu().numpy(), wav_ref, "dptransformer pipelined offline wav vs oracle")
+    _assert_close(s_.cpu().numpy(), spec_ref, "dptransformer pipelined offline spec vs oracle")
+    eng.set_time_pipeline(-1)
+
+
 def test_time_kernel_time_pipelined_offline_agrees_with_the_serial_walk():
     """The time_kernel variant's offline Model.forward with the frames of an utterance over co-resident workgroups: besides the GRU
     states, every causal time conv hands its INPUT of frame t to frames t + 1, t + 2 through a ring of slots and a counter per
