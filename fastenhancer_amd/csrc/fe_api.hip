@@ -1815,7 +1815,10 @@ size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw) {
         return std::max(walk, tb_work_floats(h, B, T, nullptr));
     }
     if (h->limpl) return (size_t)B * ((size_t)(d.NFFT - d.HOP) + h->limpl->cache_floats);
-    if (h->fimpl) return (size_t)B * (size_t)(d.NFFT - d.HOP) + fspen_gru_floats(B);
+    if (h->fimpl) {     // tail + inter-GRU states, and the time pipeline's frame counters + windowed frames
+        const int T = 1 + Tw / d.HOP;
+        return (size_t)B * (size_t)(d.NFFT - d.HOP) + ((fspen_gru_floats(B) + 3) & ~(size_t)3) + (((size_t)B * h->fimpl->num_blocks + 3) & ~(size_t)3) + (size_t)B * T * d.NFFT;
+    }
     if (h->bimpl) {     // overlap-add tail + LSTM states, and - whatever fe_set_time_pipeline says at call time - the frame counters and the windowed frames
         const int T = 1 + Tw / d.HOP;
         return (size_t)B * (size_t)(d.NFFT - d.HOP) + ((bsrnn_lstm_floats(h, B) + 3) & ~(size_t)3) + (((size_t)B * h->cfg.rf_blocks + 3) & ~(size_t)3) + (size_t)B * T * d.NFFT;
@@ -1870,7 +1873,8 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
     {   // zero the state, the tail and the frame counters (not the frames: every element is written)
         size_t nz = (size_t)B * ((size_t)(d.NFFT - d.HOP) + d.hstate() + tk_floats(h));
         if (h->bimpl) nz = (size_t)B * (size_t)(d.NFFT - d.HOP) + ((bsrnn_lstm_floats(h, B) + 3) & ~(size_t)3) + (((size_t)B * h->cfg.rf_blocks + 3) & ~(size_t)3);
-        else if (h->fimpl || h->limpl) nz = fe_offline_work_floats(h, B, Tw);
+        else if (h->fimpl) nz = (size_t)B * (size_t)(d.NFFT - d.HOP) + ((fspen_gru_floats(B) + 3) & ~(size_t)3) + (((size_t)B * h->fimpl->num_blocks + 3) & ~(size_t)3);
+        else if (h->limpl) nz = fe_offline_work_floats(h, B, Tw);
         else if (pipe_width(h, B, T, true)) nz += ((size_t)B * (d.KB + (d.KT > 1 ? 2 * d.NL : 0)) + 3) & ~(size_t)3;
         FE_HIP_CHECK(hipMemsetAsync(work_dev, 0, nz * sizeof(float), st));
     }
@@ -1894,6 +1898,33 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
         fa.spec_out = spec_hat_dev;
         fa.cache_istft = work_dev; fa.cache_stft = work_dev;
         fa.gru = work_dev + (size_t)B * (d.NFFT - d.HOP);
+        if (h->fimpl->launch_pipe && h->pipe_frames != 0 && h->pipe_frames != 1 && T >= 4) {
+            // the frames of an utterance over co-resident workgroups (fspen_kernels.hip.h, PIPE); refused co-residency: the serial walk
+            int P = (h->max_wgs * h->fimpl->occ) / B;
+            const int want = h->pipe_frames < 0 ? 32 : h->pipe_frames;
+            P = P < want ? P : want;
+            P = P < T ? P : T;
+            if (P >= 2) {
+                rc = ensure_tables(h, st);
+                if (rc != FE_OK) return rc;
+                float* flags = fa.gru + ((fspen_gru_floats(B) + 3) & ~(size_t)3);
+                fa.pipe_flags = reinterpret_cast<unsigned int*>(flags);
+                fa.frames = flags + (((size_t)B * h->fimpl->num_blocks + 3) & ~(size_t)3);
+                fa.pipe_p = P;
+                hipError_t e = hipSuccess;
+                h->fimpl->launch_pipe(fa, st, &e);
+                if (e == hipSuccess) {
+                    const int n_out = d.HOP * (T - 1);
+                    hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
+                                       fa.frames, h->tables_dev, wav_hat_dev, (size_t)n_out, d.NFFT, d.HOP, T);
+                    e = hipGetLastError();
+                    if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+                    return FE_OK;
+                }
+                (void)hipGetLastError();
+                fa.pipe_flags = nullptr; fa.frames = nullptr; fa.pipe_p = 0;
+            }
+        }
         return launch_fspen(h, fa, stream);
     }
     if (h->bimpl) {

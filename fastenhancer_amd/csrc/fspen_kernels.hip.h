@@ -83,6 +83,10 @@ struct FArgs {
     int B, T, mode, Tw;
     float compression;
     unsigned long long* clk;
+    // time-pipelined offline launch (PIPE instantiation): pipe_p workgroups per utterance, workgroup p runs frames p, p + pipe_p, ...
+    unsigned int* pipe_flags; // [B][num_blocks]: frames whose inter-GRU states of block k are in `gru`
+    float* frames;            // [B][T][N] windowed output frames (summed / envelope-normalised by istft_ola_kernel)
+    int pipe_p;
 };
 
 // debug stages (fe_debug_step): name, rows, cols as dumped (row-major)
@@ -209,8 +213,12 @@ __device__ __forceinline__ float row_bcast(float v) {
 
 #define FS_CLK(i) do { if constexpr (PROF) { if (blockIdx.x == 0 && threadIdx.x == 0) a.clk[(i)] = __builtin_readcyclecounter(); } } while (0)
 
-template <class S, bool PROF, bool DBG>
+// PIPE: time pipelining of an offline launch (as for FastEnhancer / BSRNN): the only thing a frame needs from the previous one are the
+// inter-GRU states (24 x [4][16] per stream), handed over per DPE block through `gru` - agent-scope stores, drained, a counter per
+// (utterance, block); the consumer polls the counter and fetches the states right before the block's inter GRUs.
+template <class S, bool PROF, bool DBG, bool PIPE = false>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(FS_WPE, FS_WPE))) fspen_frame_kernel(FArgs a) {
+    static_assert(!PIPE || (!PROF && !DBG), "the time-pipelined instantiation is the plain offline kernel");
     __shared__ __attribute__((aligned(16))) float smem[FLds::TOTAL];
     using L = FLds;
     using P = FPk;
@@ -236,7 +244,16 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
     for (int i = tid; i < 16 * 68; i += kThreads) e1[i] = 0.0f;
     __syncthreads();
 
-    int b = blockIdx.x;
+    int b = PIPE ? (int)blockIdx.x / a.pipe_p : (int)blockIdx.x;
+    const int t_first = PIPE ? (int)blockIdx.x - b * a.pipe_p : 0, t_step = PIPE ? a.pipe_p : 1;
+    auto ld_state = [](const float* p) -> float {
+        if constexpr (PIPE) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return *p;
+    };
+    auto st_state = [](float* p, float v) {
+        if constexpr (PIPE) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *p = v;
+    };
 #pragma unroll 1
     do {
     // (per-stream pointers are derived from the kernel arguments where they are used, not kept live through the frame)
@@ -257,7 +274,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
     };
 
 #pragma unroll 1
-    for (int t = 0; t < aT; ++t) {
+    for (int t = t_first; t < aT; t += t_step) {
         // a loop-variant zero on the weight pointer: the weights sit at compile-time offsets, and hoisted out of the frame /
         // stream loops their loads would stay live for the whole kernel (512 VGPRs, 229 spilled SGPRs without it)
         // (the same for the thread index: ~250 hoisted LDS addresses otherwise)
@@ -503,7 +520,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int f = (tid >> 4) + 16 * q, g = f >> 2;
-                hp[q] = a.gru[(((size_t)(blk * S::G + g) * a.B + b) * S::FG + (f & 3)) * S::C + (tid & 15)];
+                hp[q] = PIPE ? 0.0f : a.gru[(((size_t)(blk * S::G + g) * a.B + b) * S::FG + (f & 3)) * S::C + (tid & 15)];
             }
             // ---- intra GRU input projections: gi[d][f][g48] = x[f] . W_ih^T + bias
             if (tid < 192) {
@@ -611,6 +628,22 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
             __syncthreads();
             dump(5 + 2 * blk, [&](int r, int c) { return xn[r * 16 + c]; });
             if (blk == 0) FS_CLK(10);
+            if constexpr (PIPE) {
+                // frame t - 1's inter-GRU states of this block: wait for them, fetch them into hprev
+                if (t > 0) {
+                    if (tid == 0) {
+                        int spins = 0;
+                        while (__hip_atomic_load(a.pipe_flags + (size_t)b * S::NB + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)t && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
+                    }
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int f = (tid >> 4) + 16 * q, g = f >> 2;
+                    hprev[f * 16 + (tid & 15)] = ld_state(a.gru + (((size_t)(blk * S::G + g) * a.B + b) * S::FG + (f & 3)) * S::C + (tid & 15));
+                }
+                __syncthreads();
+            }
             // ---- inter path (InterRNNPathExtension.forward, :122-138): group g = f / 4 has its own GRU (one step per frame) and fc
             if (tid < 128) {
                 const int c = tid & 15;
@@ -633,7 +666,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
                     const float n = tanh_f(in_ + r * hnn);
                     const float hnew = (1.0f - z) * n + z * hprev[f * 16 + c];
                     hn[f * 16 + c] = hnew;
-                    a.gru[(((size_t)(blk * S::G + ig_) * a.B + b) * S::FG + fl) * S::C + c] = hnew;
+                    st_state(a.gru + (((size_t)(blk * S::G + ig_) * a.B + b) * S::FG + fl) * S::C + c, hnew);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -645,7 +678,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
                 for (int k = 0; k < 16; ++k) ifc_w[q][k] = wg[P::G_FC_W + k * 16 + (tid & 15)];
                 ifc_b[q] = wg[P::G_FC_B + (tid & 15)];
             }
+            if constexpr (PIPE) __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this thread's state stores have left the CU
             __syncthreads();
+            if constexpr (PIPE) {
+                if (tid == 0) __hip_atomic_store(a.pipe_flags + (size_t)b * S::NB + blk, (unsigned int)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int f = (tid >> 4) + 16 * q, c = tid & 15;
@@ -955,6 +992,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
             const WView wi = wp + (mode == FE_MODE_STREAM ? P::WINDOW_I : P::WINDOW);
             float* xo = reinterpret_cast<float*>(spare);
             const float invN = 1.0f / (float)N;
+            if constexpr (PIPE) {
+                float* fr = a.frames + ((size_t)b * aT + t) * N;
+                for (int n = tid; n < N; n += kThreads) fr[n] = yv[n].x * invN * wi[n];
+                __syncthreads();
+            } else {
             for (int n = tid; n < N; n += kThreads) {
                 float v = yv[n].x * invN * wi[n];
                 if (n < OVL) v += cis[n];
@@ -984,9 +1026,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
             }
             for (int m = tid; m < OVL; m += kThreads) cis[m] = xo[m + H];
             __syncthreads();
+            }
         }
         FS_CLK(7);
     }
+    if constexpr (PIPE) break;
     b += gridDim.x;
     } while (b < a.B);
 }
@@ -1001,7 +1045,17 @@ struct FImpl {
     size_t packed_floats;
     void (*launch)(const FArgs&, int max_wgs, hipStream_t, hipError_t*);
     void (*dbg_stage)(int, int*, int*, size_t*);
+    void (*launch_pipe)(const FArgs&, hipStream_t, hipError_t*);       // time-pipelined offline launch (cooperative: B * pipe_p workgroups)
+    int occ;                  // workgroups per CU
+    int num_blocks;
 };
+
+template <class S>
+void flaunch_pipe_impl(const FArgs& a, hipStream_t st, hipError_t* err) {
+    FArgs args = a;
+    void* kargs[] = {&args};
+    *err = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&fspen_frame_kernel<S, false, false, true>), dim3(a.B * a.pipe_p), dim3(kThreads), kargs, 0, st);
+}
 
 template <class S>
 void flaunch_impl(const FArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
@@ -1023,7 +1077,9 @@ inline void fdbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
 
 template <class S>
 FImpl make_fimpl() {
-    return FImpl{S::HOP, (size_t)FLds::TOTAL * 4, FDebugLayout::total(), FDebugLayout::n_stages, (size_t)FPk::TOTAL, &flaunch_impl<S>, &fdbg_stage_impl};
+    constexpr int OCC_LDS = (160 * 1024) / (FLds::TOTAL * 4);
+    return FImpl{S::HOP, (size_t)FLds::TOTAL * 4, FDebugLayout::total(), FDebugLayout::n_stages, (size_t)FPk::TOTAL, &flaunch_impl<S>, &fdbg_stage_impl,
+                 &flaunch_pipe_impl<S>, OCC_LDS < FS_WPE ? OCC_LDS : FS_WPE, S::NB};
 }
 
 }  // namespace fe

@@ -1123,6 +1123,28 @@ def test_fspen_offline_matches_reference_golden():
     _assert_close(spec_hat.cpu().numpy(), g["offline_spec"], "offline spec")
 
 
+@pytest.mark.parametrize("B", [1, 4])
+def test_fspen_time_pipelined_offline_agrees_with_the_serial_walk(B):
+    """FSPEN's offline Model.forward with the frames of an utterance over co-resident workgroups (the inter-GRU states of each DPE
+    block handed from frame to frame) against one workgroup walking the frames, and against the oracle."""
+    m, orc, cfg, sr, seed = _fspen("Model")
+    eng = m.engine
+    x = make_input(B, 57 * cfg.hop_size + 21, seed + 77, sr)
+    xd = torch.from_numpy(x).to(_dev())
+    eng.set_time_pipeline(0)
+    w_ser, s_ser = [t.clone() for t in m(xd)]
+    for width in (-1, 5):
+        eng.set_time_pipeline(width)
+        for rep in range(2):
+            w, s_ = m(xd)
+            assert float((w - w_ser).abs().max()) <= 2e-5 * max(1.0, float(w_ser.abs().max())), (width, rep, float((w - w_ser).abs().max()))
+            assert float((s_ - s_ser).abs().max()) <= 2e-5 * max(1.0, float(s_ser.abs().max())), (width, rep)
+    eng.set_time_pipeline(-1)
+    wav_ref, spec_ref = orc.offline_forward(x)
+    _assert_close(w.cpu().numpy(), wav_ref, "fspen pipelined offline wav vs oracle")
+    _assert_close(s_.cpu().numpy(), spec_ref, "fspen pipelined offline spec vs oracle")
+
+
 @pytest.mark.parametrize("B", [256, 600, 1000])
 def test_fspen_full_size(B):
     """256 streams (one workgroup per CU), 600 (three per CU) and 1000 (persistent): oracle parity on a sample, bitwise

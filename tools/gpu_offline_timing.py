@@ -30,6 +30,15 @@ def main():
         m = importlib.import_module("fastenhancer_amd.models.bsrnn.model").Model(**kw).to(dev).eval()
         m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
         eng = m.engine
+    elif name == "fspen":
+        import importlib
+        import numpy as np
+        from common import FSPEN_KWARGS, build_fspen_oracle
+        kw, sr, _ = FSPEN_KWARGS
+        cfg, sd, _, _ = build_fspen_oracle()
+        m = importlib.import_module("fastenhancer_amd.models.fspen.model").Model(**kw).to(dev).eval()
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        eng = m.engine
     else:
         kw, sr, _ = MODEL_KWARGS[name]
         cfg = product_config(name)
