@@ -1607,6 +1607,8 @@ void tb_launch(int stage, const TbArgs& a, int max_wgs, hipStream_t st, hipError
         const int ntiles = (a.NF + ft - 1) / ft;
         int per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
         per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+        static const int cap = [] { const char* v = std::getenv("FE_TB_PER_CU"); return v ? std::atoi(v) : 0; }();      // (measurement: one workgroup per CU)
+        if (cap > 0 && per_cu > cap) per_cu = cap;
         const int slots = max_wgs * per_cu;
         return ntiles < slots ? ntiles : slots;
     };
