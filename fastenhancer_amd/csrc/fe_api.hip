@@ -1814,7 +1814,11 @@ size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw) {
         size_t walk = d.BD ? 0 : (size_t)B * ((size_t)(d.NFFT - d.HOP) + d.hstate() + tk_floats(h)) + (((size_t)B * d.KB + 3) & ~(size_t)3) + (size_t)B * T * d.NFFT;
         return std::max(walk, tb_work_floats(h, B, T, nullptr));
     }
-    if (h->limpl) return (size_t)B * ((size_t)(d.NFFT - d.HOP) + h->limpl->cache_floats);
+    if (h->limpl) {     // tail + caches, and the time pipeline's counters, windowed frames and cache ring (widest pipeline: 64 + 2 slots)
+        const int T = 1 + Tw / d.HOP;
+        const size_t cf = (size_t)B * h->limpl->cache_floats;
+        return (size_t)B * (size_t)(d.NFFT - d.HOP) + ((cf + 3) & ~(size_t)3) + (((size_t)B * h->limpl->nsite + 3) & ~(size_t)3) + (size_t)B * T * d.NFFT + (size_t)B * 66 * h->limpl->cache_floats;
+    }
     if (h->fimpl) {     // tail + inter-GRU states, and the time pipeline's frame counters + windowed frames
         const int T = 1 + Tw / d.HOP;
         return (size_t)B * (size_t)(d.NFFT - d.HOP) + ((fspen_gru_floats(B) + 3) & ~(size_t)3) + (((size_t)B * h->fimpl->num_blocks + 3) & ~(size_t)3) + (size_t)B * T * d.NFFT;
@@ -1874,7 +1878,7 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
         size_t nz = (size_t)B * ((size_t)(d.NFFT - d.HOP) + d.hstate() + tk_floats(h));
         if (h->bimpl) nz = (size_t)B * (size_t)(d.NFFT - d.HOP) + ((bsrnn_lstm_floats(h, B) + 3) & ~(size_t)3) + (((size_t)B * h->cfg.rf_blocks + 3) & ~(size_t)3);
         else if (h->fimpl) nz = (size_t)B * (size_t)(d.NFFT - d.HOP) + ((fspen_gru_floats(B) + 3) & ~(size_t)3) + (((size_t)B * h->fimpl->num_blocks + 3) & ~(size_t)3);
-        else if (h->limpl) nz = fe_offline_work_floats(h, B, Tw);
+        else if (h->limpl) nz = (size_t)B * (size_t)(d.NFFT - d.HOP) + (((size_t)B * h->limpl->cache_floats + 3) & ~(size_t)3) + (((size_t)B * h->limpl->nsite + 3) & ~(size_t)3);
         else if (pipe_width(h, B, T, true)) nz += ((size_t)B * (d.KB + (d.KT > 1 ? 2 * d.NL : 0)) + 3) & ~(size_t)3;
         FE_HIP_CHECK(hipMemsetAsync(work_dev, 0, nz * sizeof(float), st));
     }
@@ -1887,6 +1891,35 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
         la.spec_out = spec_hat_dev;
         la.cache_istft = work_dev; la.cache_stft = work_dev;
         la.cache = work_dev + (size_t)B * (d.NFFT - d.HOP);
+        if (h->limpl->launch_pipe && h->pipe_frames != 0 && h->pipe_frames != 1 && T >= 4) {
+            // the frames of an utterance over co-resident workgroups (lisennet_kernels.hip.h, PIPE); refused co-residency: the serial walk
+            int P = (h->max_wgs * h->limpl->occ) / B;
+            const int want = h->pipe_frames < 0 ? 32 : h->pipe_frames;
+            P = P < want ? P : want;
+            P = P < T ? P : T;
+            if (P >= 2) {
+                rc = ensure_tables(h, st);
+                if (rc != FE_OK) return rc;
+                const size_t cf = (size_t)B * h->limpl->cache_floats;
+                float* flags = la.cache + ((cf + 3) & ~(size_t)3);
+                la.pipe_flags = reinterpret_cast<unsigned int*>(flags);
+                la.frames = flags + (((size_t)B * h->limpl->nsite + 3) & ~(size_t)3);
+                la.ring = la.frames + (size_t)B * T * d.NFFT;
+                la.pipe_p = P;
+                hipError_t e = hipSuccess;
+                h->limpl->launch_pipe(la, st, &e);
+                if (e == hipSuccess) {
+                    const int n_out = d.HOP * (T - 1);
+                    hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
+                                       la.frames, h->tables_dev, wav_hat_dev, (size_t)n_out, d.NFFT, d.HOP, T);
+                    e = hipGetLastError();
+                    if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+                    return FE_OK;
+                }
+                (void)hipGetLastError();
+                la.pipe_flags = nullptr; la.frames = nullptr; la.ring = nullptr; la.pipe_p = 0;
+            }
+        }
         return launch_lisennet(h, la, stream);
     }
     if (h->fimpl) {

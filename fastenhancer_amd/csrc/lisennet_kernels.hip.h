@@ -82,6 +82,11 @@ struct LArgs {
     int B, T, mode, Tw;
     float compression;
     unsigned long long* clk;
+    // time-pipelined offline launch (PIPE instantiation): pipe_p workgroups per utterance, workgroup p runs frames p, p + pipe_p, ...
+    unsigned int* pipe_flags; // [B][5 + 2 n_blocks]: per cache, the number of frames that have published it
+    float* ring;              // [B][pipe_p + 2][CACHE_FLOATS]: the caches of the frames in flight (one slot per frame, cache layout)
+    float* frames;            // [B][T][N] windowed output frames (summed / envelope-normalised by istft_ola_kernel)
+    int pipe_p;
 };
 
 // debug stages: 0 spec_in [257][2], 1 compressed [257][2], 2 features [3][257], 3 encoder.conv_1 [4][257], 4 encoder.conv_2 [8][128],
@@ -151,8 +156,14 @@ __device__ __forceinline__ float mish_f(float x) {
 
 #define LS_CLK(i) do { if constexpr (PROF) { if (blockIdx.x == 0 && threadIdx.x == 0) a.clk[(i)] = __builtin_readcyclecounter(); } } while (0)
 
-template <class S, bool PROF, bool DBG>
+// PIPE: time pipelining of an offline launch.  A frame needs the previous frame's value of NINE caches (the phase, three encoder frames,
+// per block the GRU state and the ConvGLU's two frames, the decoder frame) - each is read and replaced at ONE place of the frame.  The
+// frames in flight keep their caches in a ring of pipe_p + 2 slots per utterance (slot = frame mod RS, cache layout); a site waits for
+// the previous frame's count of that cache, reads slot t - 1 (the ConvGLU: t - 2 and t - 1), writes slot t and counts it - agent-scope
+// accesses on both sides, one counter per (utterance, cache).
+template <class S, bool PROF, bool DBG, bool PIPE = false>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) lisennet_frame_kernel(LArgs a) {
+    static_assert(!PIPE || (!PROF && !DBG), "the time-pipelined instantiation is the plain offline kernel");
     __shared__ __attribute__((aligned(16))) float smem[LLds::TOTAL];
     using L = LLds;
     using P = LPk;
@@ -172,7 +183,17 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
     for (int i = tid0; i < N / 2; i += kThreads) tw[i] = reinterpret_cast<const float2*>(wp0 + P::TW)[i];
     __syncthreads();
 
-    int b = blockIdx.x;
+    int b = PIPE ? (int)blockIdx.x / a.pipe_p : (int)blockIdx.x;
+    const int t_first = PIPE ? (int)blockIdx.x - b * a.pipe_p : 0, t_step = PIPE ? a.pipe_p : 1;
+    constexpr int NSITE = 5 + 2 * S::NB;
+    auto ld_state = [](const float* p) -> float {
+        if constexpr (PIPE) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return *p;
+    };
+    auto st_state = [](float* p, float v) {
+        if constexpr (PIPE) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *p = v;
+    };
 #pragma unroll 1
     do {
     float* dbg = DBG ? a.dbg + (size_t)b * a.dbg_stride : nullptr;
@@ -195,7 +216,31 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
     };
 
 #pragma unroll 1
-    for (int t = 0; t < aT; ++t) {
+    for (int t = t_first; t < aT; t += t_step) {
+        // PIPE: the ring slots of this utterance; cprev(off, back) = cache `off` as frame t - back left it, ccur(off) = where frame t leaves it
+        const int RS = PIPE ? a.pipe_p + 2 : 1;
+        float* const ringb = PIPE ? a.ring + (size_t)b * RS * S::CACHE_FLOATS : nullptr;
+        auto cprev = [&](int off, int back) -> const float* { return ringb + (size_t)((t - back < 0 ? 0 : t - back) % RS) * S::CACHE_FLOATS + off; };
+        auto ccur = [&](int off) -> float* { return ringb + (size_t)(t % RS) * S::CACHE_FLOATS + off; };
+        unsigned int* const pflag = PIPE ? a.pipe_flags + (size_t)b * NSITE : nullptr;
+        auto cwait = [&](int site) {          // frame t - 1 has left cache `site` (all threads call)
+            if constexpr (PIPE) {
+                if (t > 0) {
+                    if (threadIdx.x == 0) {
+                        int spins = 0;
+                        while (__hip_atomic_load(pflag + site, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)t && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
+                    }
+                    __syncthreads();
+                }
+            }
+        };
+        auto cpub = [&](int site) {           // this frame's value of cache `site` is in its slot (includes a barrier)
+            if constexpr (PIPE) {
+                __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
+                __syncthreads();
+                if (threadIdx.x == 0) __hip_atomic_store(pflag + site, (unsigned int)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        };
         // loop-variant zeros on the weight pointer and the thread index (see fspen_kernels.hip.h)
         int lz = 0, lzv = 0;
         asm volatile("" : "+s"(lz));
@@ -286,16 +331,20 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
             __syncthreads();
             const float sgn = mode == FE_MODE_OFFLINE ? 1.0f : -1.0f;        // Model: current - previous (torch.diff); ONNXModel: previous - current
             constexpr float kInvPi = 0.31830988618379067f;
+            cwait(0);
             for (int f = tid; f < BINS; f += kThreads) {
                 const float re = sp[2 * f], im = sp[2 * f + 1], ph = phs[f];
                 const float dgd = sgn * (ph - (f > 0 ? phs[f - 1] : 0.0f));
-                const float dif = sgn * (ph - cpha[f]) - 6.283185307179586f * ((float)H / (float)N) * (float)f;
+                float pprev;
+                if constexpr (PIPE) pprev = t > 0 ? ld_state(cprev(0, 1) + f) : 0.0f; else pprev = cpha[f];
+                const float dif = sgn * (ph - pprev) - 6.283185307179586f * ((float)H / (float)N) * (float)f;
                 feat[f] = sqrtf(re * re + im * im);
                 feat[260 + f] = atan2f(sinf(dgd), cosf(dgd)) * kInvPi;
                 feat[520 + f] = atan2f(sinf(dif), cosf(dif)) * kInvPi;
-                cpha[f] = ph;
+                if constexpr (PIPE) st_state(ccur(0) + f, ph); else cpha[f] = ph;
             }
         }
+        if constexpr (PIPE) cpub(0); else
         __syncthreads();
         dump(2, [&](int r, int c) { return feat[r * 260 + c]; });
 
@@ -317,21 +366,28 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
             ln_stats(v, cnt, 1.0f / (4.0f * BINS), mean, rstd);
             float* c2 = cache_ptr(S::K_PHA, S::K_E2);
             cnt = 0;
+            cwait(1);
             for (int i = tid; i < 4 * BINS; i += kThreads, ++cnt) {
                 const int o = i / BINS, f = i - o * BINS;
                 float y = (v[cnt] - mean) * rstd * wp[P::C1_G + f] + wp[P::C1_BE + f];
                 y = y >= 0.0f ? y : y * wp[P::C1_P + o];
+                if constexpr (PIPE) {
+                    x1p[o * 260 + f] = t > 0 ? ld_state(cprev(S::K_PHA, 1) + i) : 0.0f;
+                    st_state(ccur(S::K_PHA) + i, y);
+                } else {
                 x1p[o * 260 + f] = c2[i];           // previous frame (the cache) in, this frame out
                 c2[i] = y;
+                }
                 x1[o * 260 + f] = y;
             }
         }
+        if constexpr (PIPE) cpub(1); else
         __syncthreads();
         dump(3, [&](int r, int c) { return x1[r * 260 + c]; });
         // DSConv (:190-208): causal two-frame conv, the bins split into a low quarter (k 3, stride 1) and the rest (k 5, stride 3), both
         // zero padded by one bin AFTER the split; LayerNorm over (channel, freq), per-frequency affine, PReLU
         auto dsconv = [&](auto CIN_, auto COUT_, auto FIN_, const float* cur, const float* prev, int ld_in, float* out, float* cache_io, float* prev_out,
-                          int w_lo, int w_hi, int b_lo, int b_hi, int g_, int be_, int p_) {
+                          int w_lo, int w_hi, int b_lo, int b_hi, int g_, int be_, int p_, int site = -1, int site_off = 0) {
             constexpr int CIN = decltype(CIN_)::value, COUT = decltype(COUT_)::value, FIN = decltype(FIN_)::value;
             constexpr int LOWF = FIN / 4, HALF = LOWF, FO = 2 * HALF, NOUT = COUT * FO, PER = (NOUT + kThreads - 1) / kThreads;
             stage(w_lo, p_ + COUT - w_lo);                      // [low | high | biases | gamma | beta | PReLU] of this layer
@@ -381,6 +437,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
                 const float var = 1.0f / (rstd * rstd) - 1.0e-5f - (float)PADN / (float)NOUT * mean * mean;
                 rstd = 1.0f / sqrtf(var + 1.0e-5f);
             }
+            if (cache_io) cwait(site);
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
                 const int i = tid + q * kThreads;
@@ -389,9 +446,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
                     float y = (v[q] - mean) * rstd * ws[g_ + f] + ws[be_ + f];
                     y = y >= 0.0f ? y : y * ws[p_ + o];
                     out[o * FO + f] = y;
-                    if (cache_io) { prev_out[o * FO + f] = cache_io[o * FO + f]; cache_io[o * FO + f] = y; }
+                    if (cache_io) {
+                        if constexpr (PIPE) {
+                            prev_out[o * FO + f] = t > 0 ? ld_state(cprev(site_off, 1) + o * FO + f) : 0.0f;
+                            st_state(ccur(site_off) + o * FO + f, y);
+                        } else { prev_out[o * FO + f] = cache_io[o * FO + f]; cache_io[o * FO + f] = y; }
+                    }
                 }
             }
+            if (PIPE && cache_io) cpub(site); else
             __syncthreads();
         };
         using I4 = std::integral_constant<int, 4>;
@@ -402,11 +465,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
         using I128 = std::integral_constant<int, 128>;
         using I257 = std::integral_constant<int, 257>;
         float* xp = smem + L::XP;
-        dsconv(I4{}, I8{}, I257{}, x1, x1p, 260, x2, cache_ptr(S::K_PHA + S::K_E2, S::K_E3), xp, P::D2_LO, P::D2_HI, P::D2_BL, P::D2_BH, P::D2_G, P::D2_BE, P::D2_P);
+        dsconv(I4{}, I8{}, I257{}, x1, x1p, 260, x2, cache_ptr(S::K_PHA + S::K_E2, S::K_E3), xp, P::D2_LO, P::D2_HI, P::D2_BL, P::D2_BH, P::D2_G, P::D2_BE, P::D2_P, 2, S::K_PHA + S::K_E2);
         dump(4, [&](int r, int c) { return x2[r * 128 + c]; });
         {
             float* xq = smem + L::Y;       // previous frame of x3's input is in xp (x2's cache); x3's own cache lands in xq
-            dsconv(I8{}, I12{}, I128{}, x2, xp, 128, x3, cache_ptr(S::K_PHA + S::K_E2 + S::K_E3, S::K_E4), xq, P::D3_LO, P::D3_HI, P::D3_BL, P::D3_BH, P::D3_G, P::D3_BE, P::D3_P);
+            dsconv(I8{}, I12{}, I128{}, x2, xp, 128, x3, cache_ptr(S::K_PHA + S::K_E2 + S::K_E3, S::K_E4), xq, P::D3_LO, P::D3_HI, P::D3_BL, P::D3_BH, P::D3_G, P::D3_BE, P::D3_P, 3, S::K_PHA + S::K_E2 + S::K_E3);
             dump(5, [&](int r, int c) { return x3[r * 64 + c]; });
             dsconv(I12{}, I16{}, I64{}, x3, xq, 64, x4, nullptr, nullptr, P::D4_LO, P::D4_HI, P::D4_BL, P::D4_BH, P::D4_G, P::D4_BE, P::D4_P);
             dump(6, [&](int r, int c) { return x4[r * 32 + c]; });
@@ -433,7 +496,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
             // inter GRU state -> LDS (in flight across the intra path)
             float hpre[3];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) hpre[q] = ch[tid + 256 * q];
+            for (int q = 0; q < 3; ++q) hpre[q] = PIPE ? 0.0f : ch[tid + 256 * q];
             // ---- intra_norm: nn.LayerNorm((32, 16)) over the whole token matrix
             {
                 float v[2] = {xt[tid], xt[tid + 256]};
@@ -520,6 +583,13 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
                 for (int q = 0; q < 2; ++q) { const int i = tid + 256 * q; yn[i] = (v[q] - mean) * rstd * wd[P::B_N2W + i] + wd[P::B_N2B + i]; }
             }
             __syncthreads();
+            if constexpr (PIPE) {       // frame t - 1's GRU state of this block -> hp
+                cwait(4 + 2 * blk);
+                const int hoff = OFF_BLK + blk * (S::K_H + S::K_GLU);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) hp[tid + 256 * q] = t > 0 ? ld_state(cprev(hoff, 1) + tid + 256 * q) : 0.0f;
+                __syncthreads();
+            }
             {   // ONE GRU for all sub-bands: thread (hidden unit c, row group fg) keeps the unit's three gate rows (3 x (16 + 24) weights)
                 // in registers and walks the rows f = fg, fg + 10, ...
                 const int c = tid % 24, fg = tid / 24;                  // 240 threads, fg < 10
@@ -553,9 +623,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
                     const float n = tanh_f(in_ + rg * hnn);
                     const float hnew = (1.0f - z) * n + z * hp[f * 24 + c];
                     hn[f * 24 + c] = hnew;
+                    if constexpr (PIPE) st_state(ccur(OFF_BLK + blk * (S::K_H + S::K_GLU)) + f * 24 + c, hnew); else
                     ch[f * 24 + c] = hnew;
                 }
             }
+            if constexpr (PIPE) cpub(4 + 2 * blk); else
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -579,8 +651,19 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
                 ln_stats(v, 2, 1.0f / 512.0f, mean, rstd);
                 // the previous two frames of fc1's first half (the cache) -> xx[0], xx[1]; in flight across fc1
                 float cpre[8];
+                if constexpr (PIPE) {       // the ConvGLU's frames t - 2 and t - 1: each frame leaves ITS frame in the first half of its slot's cache
+                    cwait(5 + 2 * blk);
+                    const int goff = OFF_BLK + blk * (S::K_H + S::K_GLU) + S::K_H;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int i = tid + 256 * q, chn = i >> 6, dt = (i >> 5) & 1, f = i & 31;
+                        const int back = 2 - dt;                                    // dt = 0: frame t - 2, dt = 1: frame t - 1
+                        cpre[q] = t - back >= 0 ? ld_state(cprev(goff, back) + chn * 32 + f) : 0.0f;
+                    }
+                } else {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) cpre[q] = cg[tid + 256 * q];
+                }
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int i = tid + 256 * q, f = i >> 4, d = i & 15;
@@ -616,9 +699,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
                         acc = fmaf(wd[P::B_DW + (dt * 3 + df) * 32 + chn], ok ? xv : 0.0f, acc);
                     }
                 gg[i] = mish_f(acc) * vv[i];
+                if constexpr (PIPE) st_state(ccur(OFF_BLK + blk * (S::K_H + S::K_GLU) + S::K_H) + chn * 32 + f, xx[(64 + chn) * 32 + f]); else {
                 cg[(chn * 2 + 0) * 32 + f] = xx[(32 + chn) * 32 + f];
                 cg[(chn * 2 + 1) * 32 + f] = xx[(64 + chn) * 32 + f];
+                }
             }
+            if constexpr (PIPE) cpub(5 + 2 * blk); else
             __syncthreads();
             // fc2: 1x1 (32 -> 16) + residual -> block output (b, d, t, f) and the next block's tokens
 #pragma unroll
@@ -682,8 +768,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
         float* mk = smem + L::MK;
         {
             float* cd = cache_ptr(OFF_BLK + S::NB * (S::K_H + S::K_GLU), S::K_DEC);
+            if constexpr (PIPE) {
+                cwait(4 + 2 * S::NB);
+                const int doff = OFF_BLK + S::NB * (S::K_H + S::K_GLU);
+                for (int i = tid; i < 4 * 256; i += kThreads) { u3p[i] = t > 0 ? ld_state(cprev(doff, 1) + i) : 0.0f; st_state(ccur(doff) + i, u3[i]); }
+                cpub(4 + 2 * S::NB);
+            } else {
             for (int i = tid; i < 4 * 256; i += kThreads) { u3p[i] = cd[i]; cd[i] = u3[i]; }
             __syncthreads();
+            }
             // mask_conv.0: Conv2d(4 -> 2, (2, 2), padding (0, 1)) over (previous, current) frame: 257 output bins
             float v[3];
             int cnt = 0;
@@ -755,6 +848,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
             const float* wi = wp + (mode == FE_MODE_STREAM ? P::WINDOW_I : P::WINDOW);
             float* xo = reinterpret_cast<float*>(spare);
             const float invN = 1.0f / (float)N;
+            if constexpr (PIPE) {
+                float* fr = a.frames + ((size_t)b * aT + t) * N;
+                for (int n = tid; n < N; n += kThreads) fr[n] = yv[n].x * invN * wi[n];
+                __syncthreads();
+            } else {
             for (int n = tid; n < N; n += kThreads) {
                 float v = yv[n].x * invN * wi[n];
                 if (n < OVL) v += cis[n];
@@ -784,9 +882,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
             }
             for (int m = tid; m < OVL; m += kThreads) cis[m] = xo[m + H];
             __syncthreads();
+            }
         }
         LS_CLK(5);
     }
+    if constexpr (PIPE) break;
     b += gridDim.x;
     } while (b < a.B);
 }
@@ -800,7 +900,17 @@ struct LImpl {
     size_t cache_floats;      // model caches per stream
     void (*launch)(const LArgs&, int max_wgs, hipStream_t, hipError_t*);
     void (*dbg_stage)(int, int*, int*, size_t*);
+    void (*launch_pipe)(const LArgs&, hipStream_t, hipError_t*);       // time-pipelined offline launch (cooperative: B * pipe_p workgroups)
+    int occ;                  // workgroups per CU
+    int nsite;                // caches handed from frame to frame (counters per stream)
 };
+
+template <class S>
+void llaunch_pipe_impl(const LArgs& a, hipStream_t st, hipError_t* err) {
+    LArgs args = a;
+    void* kargs[] = {&args};
+    *err = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&lisennet_frame_kernel<S, false, false, true>), dim3(a.B * a.pipe_p), dim3(kThreads), kargs, 0, st);
+}
 
 template <class S>
 void llaunch_impl(const LArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
@@ -822,8 +932,9 @@ inline void ldbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
 
 template <class S>
 LImpl make_limpl() {
+    constexpr int OCC_LDS = (160 * 1024) / (LLds::TOTAL * 4);
     return LImpl{S::HOP, (size_t)LLds::TOTAL * 4, LDebugLayout::total(), LDebugLayout::n_stages, (size_t)LPk::TOTAL, (size_t)S::CACHE_FLOATS,
-                 &llaunch_impl<S>, &ldbg_stage_impl};
+                 &llaunch_impl<S>, &ldbg_stage_impl, &llaunch_pipe_impl<S>, OCC_LDS < 2 ? OCC_LDS : 2, 5 + 2 * S::NB};
 }
 
 }  // namespace fe

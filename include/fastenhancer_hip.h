@@ -150,7 +150,7 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
  * T frames of a stream).  Results agree to fp32 rounding.  BSRNN's fe_offline is pipelined the same way (the time-LSTM (h, c) of
  * each layer is the hand-off; up to 64 frames in flight), and so are the ln variant's, the time_kernel variant's and the
  * dptransformer variant's (the last two fe_offline only: the time convs' input frames / the K-V caches go through per-frame rings in
- * work_dev), and FSPEN's (its inter-GRU states per DPE block); LiSenNet walks. */
+ * work_dev), FSPEN's (its inter-GRU states per DPE block) and LiSenNet's (its nine caches through a ring of per-frame slots). */
 int fe_set_time_pipeline(fe_handle* h, int frames_in_flight);
 
 /* Engine of fe_offline for the default and noncausal FastEnhancer models:

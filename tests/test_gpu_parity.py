@@ -1245,6 +1245,31 @@ def test_lisennet_offline_matches_oracle():
     _assert_close(spec_hat.cpu().numpy(), spec_ref, "offline spec")
 
 
+@pytest.mark.parametrize("B", [1, 3])
+def test_lisennet_time_pipelined_offline_agrees_with_the_serial_walk(B):
+    """LiSenNet's offline Model.forward with the frames of an utterance over co-resident workgroups: its nine caches (previous phase,
+    encoder frames, per block GRU state + ConvGLU frames, decoder frame) go through a ring of per-frame slots with a counter per cache.
+    Against the serial walk and the oracle (leading silence: frame 0 of the offline path is ill-conditioned, see the test above)."""
+    g = load_golden("lisennet")
+    m, orc, cfg, sr, seed = _lisennet("Model")
+    eng = m.engine
+    x = make_input(B, 61 * cfg.hop_size + 9, seed + 88, sr)
+    x[:, :int(g["offline_leading_zeros"])] = 0.0
+    xd = torch.from_numpy(x).to(_dev())
+    eng.set_time_pipeline(0)
+    w_ser, s_ser = [t.clone() for t in m(xd)]
+    for width in (-1, 5):
+        eng.set_time_pipeline(width)
+        for rep in range(2):
+            w, s_ = m(xd)
+            assert float((w - w_ser).abs().max()) <= 3e-5 * max(1.0, float(w_ser.abs().max())), (width, rep, float((w - w_ser).abs().max()))
+            assert float((s_ - s_ser).abs().max()) <= 3e-5 * max(1.0, float(s_ser.abs().max())), (width, rep)
+    eng.set_time_pipeline(-1)
+    wav_ref, spec_ref = orc.offline_forward(x)
+    _assert_close(w.cpu().numpy(), wav_ref, "lisennet pipelined offline wav vs oracle")
+    _assert_close(s_.cpu().numpy(), spec_ref, "lisennet pipelined offline spec vs oracle")
+
+
 @pytest.mark.parametrize("B", [256, 700])
 def test_lisennet_full_size(B):
     """256 streams (one workgroup per CU) and 700 (two per CU, then persistent): oracle parity on a sample, bitwise position

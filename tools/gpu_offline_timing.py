@@ -30,6 +30,15 @@ def main():
         m = importlib.import_module("fastenhancer_amd.models.bsrnn.model").Model(**kw).to(dev).eval()
         m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
         eng = m.engine
+    elif name == "lisennet":
+        import importlib
+        import numpy as np
+        from common import LISENNET_KWARGS, build_lisennet_oracle
+        kw, sr, _ = LISENNET_KWARGS
+        cfg, sd, _, _ = build_lisennet_oracle()
+        m = importlib.import_module("fastenhancer_amd.models.lisennet.model").Model(**kw).to(dev).eval()
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        eng = m.engine
     elif name == "fspen":
         import importlib
         import numpy as np
