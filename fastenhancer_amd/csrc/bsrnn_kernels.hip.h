@@ -538,25 +538,44 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll
                 for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = hgn[i < kBands * HH ? i : kBands * HH - 1]; }
             }
-            auto xp_at = [&](int s, int rr) -> float {
-                const int band = rd == 0 ? s : kBands - 1 - s;
-                const int col = rgate * HH + (rq >> 2) + S::UPP * rr;
-                if constexpr (S::XPG) return XPg[(rd * 32 + band) * G4 + col];
-                else return XPl[(rd * 32 + band) * LDP + col];
+            // The walk of a direction (band = s forward, kBands - 1 - s backward) as RUNNING offsets - one add per step for the
+            // projections and one for the outputs instead of a select and two multiplies - and the h double buffer's parity as a
+            // compile-time fact (steps come in pairs): a lone wave per SIMD issues an instruction every ~5.5 cycles whatever its
+            // kind, and the step's ~22 scalar bookkeeping instructions were a seventh of it.
+            constexpr int XS = S::XPG ? G4 : LDP;
+            int xo = 0, xd = 0, yob = 0, ydb = 0;           // (yob, ydb: bytes)
+            const float act_m = rgate == 2 ? 2.0f : 1.0f, act_a = rgate == 2 ? -1.0f : 0.0f;
+            auto walk_init = [&]() {
+                const int band0 = rd == 0 ? 0 : kBands - 1;
+                xo = (rd * 32 + band0) * XS + rgate * HH + (rq >> 2);
+                yob = 4 * (band0 * LDY + rd * HH + (rq >> 2));
+                xd = rd == 0 ? XS : -XS;
+                ydb = rd == 0 ? 4 * LDY : -4 * LDY;
+                asm volatile("" : "+v"(yob), "+v"(ydb));          // (per-lane values: the running output address is ONE vector add per step)
+            };
+            auto xp_ld = [&](int rr) -> float {
+                if constexpr (S::XPG) return XPg[xo + S::UPP * rr];
+                else return XPl[xo + S::UPP * rr];
             };
             float xp_next[S::RPT];
             // One step of both scans (work split: see BShape::KSPLIT).  With KSPLIT a lane reads HH/4 floats of h from LDS
             // instead of all HH; the quarters are summed across the quad with two DPP adds per gate; lane rgate then finishes
             // gate rgate.  Either way the four activations of a unit are exchanged with DPP quad broadcasts, ALL four lanes
             // compute the (identical) cell / hidden update and store it - no exec-masked block, no branch.
-            auto rec_step = [&](int s) {
-                const int band = rd == 0 ? s : kBands - 1 - s;
+            // PAR: parity of the step (which half of the h double buffer is read); LAST: no projection fetch for a next step.
+            auto rec_step = [&](auto PAR, auto LAST) {
+                constexpr int par = decltype(PAR)::value;
                 constexpr int Q = S::KSPLIT ? HH / 4 : HH;   // floats of h per lane
-                const float4* hp4 = reinterpret_cast<const float4*>(Hb + (rd * 2 + (s & 1)) * HH + (S::KSPLIT ? rgate * Q : 0));
-                float* hnext = Hb + (rd * 2 + ((s + 1) & 1)) * HH;
+                const float4* hp4 = reinterpret_cast<const float4*>(Hb + (rd * 2 + par) * HH + (S::KSPLIT ? rgate * Q : 0));
+                float* hnext = Hb + (rd * 2 + (par ^ 1)) * HH;
                 float xp_cur[S::RPT];
 #pragma unroll
-                for (int rr = 0; rr < S::RPT; ++rr) { xp_cur[rr] = xp_next[rr]; xp_next[rr] = xp_at(s + 1 < kBands ? s + 1 : s, rr); }
+                for (int rr = 0; rr < S::RPT; ++rr) xp_cur[rr] = xp_next[rr];
+                if constexpr (!decltype(LAST)::value) {
+                    xo += xd;
+#pragma unroll
+                    for (int rr = 0; rr < S::RPT; ++rr) xp_next[rr] = xp_ld(rr);
+                }
                 float4 hq[Q / 4];
 #pragma unroll
                 for (int k = 0; k < Q / 4; ++k) hq[k] = hp4[k];
@@ -634,7 +653,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     }
                     const float pre = mine + xp_cur[rr];
                     const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre));
-                    const float act = rgate == 2 ? 2.0f * sg - 1.0f : sg;
+                    const float act = __builtin_fmaf(sg, act_m, act_a);          // g: tanh = 2 s - 1, the others: s
                     const int ai = __builtin_bit_cast(int, act);
                     const float ig = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, ai, 0x00, 0xf, 0xf, true));
                     const float fg = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, ai, 0x55, 0xf, 0xf, true));
@@ -644,32 +663,40 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     cstate[rr] = cn;
                     const float hn = og * (2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * cn)) - 1.0f);
                     hnext[j] = hn;                                  // (the four lanes of the quad store the same value)
-                    Yf[band * LDY + rd * HH + j] = hn;
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(Yf) + yob + 4 * S::UPP * rr) = hn;
                 }
+                yob += ydb;
                 __syncthreads();
+            };
+            using P0 = std::integral_constant<int, 0>;
+            using P1 = std::integral_constant<int, 1>;
+            auto rec_pairs = [&](int n) {          // 2 n steps, starting on an even one
+#pragma unroll 1
+                for (int s = 0; s < n; ++s) { rec_step(P0{}, std::false_type{}); rec_step(P1{}, std::false_type{}); }
             };
 #pragma unroll 1
             for (int dd = 0; dd < (S::SEQD ? 2 : 1); ++dd) {
             if constexpr (S::SEQD) { rd = dd; load_whh(dd); }      // (the previous direction's last step ended with a barrier)
 #pragma unroll
-            for (int rr = 0; rr < S::RPT; ++rr) { cstate[rr] = 0.0f; xp_next[rr] = xp_at(0, rr); }
+            for (int rr = 0; rr < S::RPT; ++rr) cstate[rr] = 0.0f;
+            walk_init();
+#pragma unroll
+            for (int rr = 0; rr < S::RPT; ++rr) xp_next[rr] = xp_ld(rr);
+            static_assert(kBands == 31, "the recurrence is walked as 15 pairs of steps and a last one");
             if constexpr (REGW) {
                 // the next layer's weights ride under this latency chain, in three bursts (a wave keeps at most 63 loads in flight)
                 const bool more = l + 1 < S::NLAY;
                 const int ln = more ? l + 1 : l;
                 if (more) fetch_part(I0{}, I3{}, ln, std::false_type{});
-#pragma unroll 1
-                for (int s = 0; s < 10; ++s) rec_step(s);
+                rec_pairs(5);
                 if (more) fetch_part(I1{}, I3{}, ln, std::false_type{});
-#pragma unroll 1
-                for (int s = 10; s < 20; ++s) rec_step(s);
+                rec_pairs(5);
                 if (more) fetch_part(I2{}, I3{}, ln, std::false_type{});
-#pragma unroll 1
-                for (int s = 20; s < kBands; ++s) rec_step(s);
+                rec_pairs(5);
             } else {
-#pragma unroll 1
-                for (int s = 0; s < kBands; ++s) rec_step(s);
+                rec_pairs(15);
             }
+            rec_step(P0{}, std::true_type{});
             }
             if (l == 0) BE_CLK(6);
             {
