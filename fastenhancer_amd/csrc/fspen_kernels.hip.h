@@ -207,6 +207,38 @@ __device__ __forceinline__ float row_bcast(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + K, 0xf, 0xf, true));
 }
 
+// acc + sum_k w[k] * (lane k of the caller's 16-lane row of h): K `v_fmac_f32_dpp` with the row broadcast on the multiplicand, in two
+// chains.  Written out because hipcc does not fold row_bcast<k>() into the consuming fmac here: it emitted v_mov_b32_dpp + v_fmac_f32 +
+// a hazard nop per term - 48 instructions for 16 products on the latency chain of a GRU step (a lone wave issues one every ~6 cycles).
+// (`s_nop 1`: a DPP operand needs two wait states after the VALU write of its register - the recogniser does not look into the asm.)
+#define FS_DF(acc, w, k) "v_fmac_f32_dpp %" #acc ", %2, %" #w " row_newbcast:" #k " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ float row_dot(const float (&w)[16], float h, float acc) {
+    float a1 = 0.0f;
+    asm("s_nop 1\n\t"
+        FS_DF(0, 3, 0) FS_DF(1, 4, 1) FS_DF(0, 5, 2) FS_DF(1, 6, 3) FS_DF(0, 7, 4) FS_DF(1, 8, 5) FS_DF(0, 9, 6) FS_DF(1, 10, 7)
+        FS_DF(0, 11, 8) FS_DF(1, 12, 9) FS_DF(0, 13, 10) FS_DF(1, 14, 11) FS_DF(0, 15, 12) FS_DF(1, 16, 13) FS_DF(0, 17, 14) FS_DF(1, 18, 15)
+        : "+v"(acc), "+v"(a1)
+        : "v"(h), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]),
+          "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
+    return acc + a1;
+}
+__device__ __forceinline__ float row_dot(const float (&w)[12], float h, float acc) {
+    float a1 = 0.0f;
+    asm("s_nop 1\n\t"
+        FS_DF(0, 3, 0) FS_DF(1, 4, 1) FS_DF(0, 5, 2) FS_DF(1, 6, 3) FS_DF(0, 7, 4) FS_DF(1, 8, 5) FS_DF(0, 9, 6) FS_DF(1, 10, 7)
+        FS_DF(0, 11, 8) FS_DF(1, 12, 9) FS_DF(0, 13, 10) FS_DF(1, 14, 11)
+        : "+v"(acc), "+v"(a1)
+        : "v"(h), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]),
+          "v"(w[11]));
+    return acc + a1;
+}
+#undef FS_DF
+// gate pre-activations carried SCALED (r, z by -log2 e; the n parts by 2 log2 e - the scale sits in the weights / at the place the x side
+// is produced): sigmoid and tanh are then exp2 + rcp with no multiply on the step's chain
+constexpr float kGateRZ = -1.4426950408889634f, kGateN = 2.8853900817779268f;
+__device__ __forceinline__ float sigmoid_pre(float u) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u)); }          // u = -log2e x
+__device__ __forceinline__ float tanh_pre(float u) { return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u)), 1.0f); }   // u = 2 log2e x
+
 #ifndef FS_WPE
 #define FS_WPE 3          // waves per SIMD = workgroups per CU of the register budget (168 VGPRs: what the 54 KB LDS plan allows too)
 #endif
@@ -529,14 +561,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
 #pragma unroll
                 for (int k = 0; k < 32; ++k) w[k] = wd[P::D_IH + k * 48 + g48];
                 const float bias0 = wd[P::D_GB + g48], bias1 = wd[P::D_GB + 48 + g48];
+                const float gsc = g48 < 32 ? kGateRZ : kGateN;        // (the recurrence works on scaled pre-activations: row_dot's note)
 #pragma unroll 2
                 for (int r = 0; r < 8; ++r) {
                     const int f = fq + 4 * r;
                     float a0 = bias0, a1 = bias1;
 #pragma unroll
                     for (int k = 0; k < 16; ++k) { const float xv = x[f * 16 + k]; a0 = fmaf(w[k], xv, a0); a1 = fmaf(w[16 + k], xv, a1); }
-                    gi[f * 48 + g48] = a0;
-                    gi[(32 + f) * 48 + g48] = a1;
+                    gi[f * 48 + g48] = a0 * gsc;
+                    gi[(32 + f) * 48 + g48] = a1 * gsc;
                 }
             }
 #pragma unroll
@@ -551,9 +584,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
             {
                 const int c = lane & 15, dsel = wave & 1;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) wg_[k] = wd[P::D_HH + ((dsel * 3 + g_row) * 16 + k) * 16 + c];
+                for (int k = 0; k < 16; ++k) wg_[k] = wd[P::D_HH + ((dsel * 3 + g_row) * 16 + k) * 16 + c] * (g_row == 2 ? kGateN : kGateRZ);
             }
-            const float bhn = (lane >> 4) == 2 ? wd[P::D_HN + (wave & 1) * 16 + (lane & 15)] : 0.0f;
+            const float bhn = (lane >> 4) == 2 ? wd[P::D_HN + (wave & 1) * 16 + (lane & 15)] * kGateN : 0.0f;
             FS_LDW(fc_w, 32, (P::DPE + blk * P::D_SIZE) + P::D_FC_W + (tid & 15), 16);
             const float fc_b = wd[P::D_FC_B + (tid & 15)];
             float ln_w[2], ln_b[2];
@@ -573,22 +606,25 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
                 const int d = wave, c = lane & 15;
                 const bool is_n = (lane >> 4) == 2;
                 float h = 0.0f;
-                const float* gd = gi + d * 32 * 48;
-                int f = d ? 31 : 0;
-                float g_own = gd[f * 48 + g_row * 16 + c], g_n = gd[f * 48 + 32 + c];
+                // running LDS offsets of the walk (sub-band 0 -> 31 forward, 31 -> 0 backward): one add each per step
+                const int f0 = d ? 31 : 0;
+                int go = (d * 32 + f0) * 48 + g_row * 16 + c, gn = (d * 32 + f0) * 48 + 32 + c, ho = f0 * 32 + d * 16 + c;
+                const int gstep = d ? -48 : 48, hstep = d ? -32 : 32;
+                float g_own = gi[go], g_n = gi[gn];
 #pragma unroll 1
                 for (int s_ = 0; s_ < 32; ++s_) {
-                    const int fnx = d ? (s_ < 31 ? f - 1 : f) : (s_ < 31 ? f + 1 : f);
-                    const float n_own = gd[fnx * 48 + g_row * 16 + c], n_n = gd[fnx * 48 + 32 + c];      // next step's x side
-                    float acc = bhn;
-                    static_for<16>([&](auto k_) { constexpr int k = decltype(k_)::value; acc = fmaf(wg_[k], row_bcast<k>(h), acc); });
-                    const float x_ = is_n ? acc : sigmoid_f(g_own + acc);
+                    go += gstep; gn += gstep;
+                    // next step's x side (the read after the last step lands in the other direction's rows: unused)
+                    const float n_own = gi[go], n_n = gi[gn];
+                    const float acc = row_dot(wg_, h, bhn);
+                    const float x_ = is_n ? acc : sigmoid_pre(g_own + acc);
                     float r, z, pn;
                     rows_gather3(x_, r, z, pn);
-                    const float n = tanh_f(g_n + r * pn);
-                    h = (1.0f - z) * n + z * h;
-                    if (lane < 16) hseq[f * 32 + d * 16 + c] = h;
-                    f = fnx; g_own = n_own; g_n = n_n;
+                    const float n = tanh_pre(__builtin_fmaf(r, pn, g_n));
+                    h = __builtin_fmaf(z, h - n, n);                      // (1 - z) n + z h
+                    hseq[ho] = h;                                        // (the four rows hold the same h: same value to the same address)
+                    ho += hstep;
+                    g_own = n_own; g_n = n_n;
                 }
             }
             __syncthreads();

@@ -515,6 +515,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
                 for (int k = 0; k < 32; ++k) wq[k] = wd[P::B_IH + k * 36 + g36];
                 const float bq0 = wd[P::B_GB + g36], bq1 = wd[P::B_GB + 36 + g36];
+                const float gsc = g36 < 24 ? kGateRZ : kGateN;          // (scaled pre-activations: fspen_kernels.hip.h, row_dot)
                 // all 256 threads run all five rows: a row index past the end is clamped to row 31 and threads 252.. repeat rows of group 0
                 // (identical values stored twice) - no partially-executed region around register-heavy code (a VGPR spilled and
                 // reloaded inside one loses its inactive lanes: see DESIGN.md)
@@ -524,8 +525,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
                     float a0 = bq0, a1 = bq1;
 #pragma unroll
                     for (int k = 0; k < 16; ++k) { const float xv = yn[f * 16 + k]; a0 = fmaf(wq[k], xv, a0); a1 = fmaf(wq[16 + k], xv, a1); }
-                    gi[f * 36 + g36] = a0;
-                    gi[(32 + f) * 36 + g36] = a1;
+                    gi[f * 36 + g36] = a0 * gsc;
+                    gi[(32 + f) * 36 + g36] = a1 * gsc;
                 }
             }
             // lane = (gate row = lane / 16: r, z, n, (r again), hidden unit c = lane % 16, 12 used): one gate row of 12 weights per lane
@@ -535,29 +536,33 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
             {
                 const int dsel = wave & 1;
 #pragma unroll
-                for (int k = 0; k < 12; ++k) wg_[k] = wd[P::B_HH + ((dsel * 3 + g_row) * 12 + k) * 12 + c12];
+                for (int k = 0; k < 12; ++k) wg_[k] = wd[P::B_HH + ((dsel * 3 + g_row) * 12 + k) * 12 + c12] * (g_row == 2 ? kGateN : kGateRZ);
             }
-            const float bhn = (lane >> 4) == 2 ? wd[P::B_HN + (wave & 1) * 12 + c12] : 0.0f;
+            const float bhn = (lane >> 4) == 2 ? wd[P::B_HN + (wave & 1) * 12 + c12] * kGateN : 0.0f;
             __syncthreads();
             if (blk == 0) LS_CLK(6);
             if (wave < 2) {      // (gates one per lane, DPP row broadcasts of h, row-swap gather: see fspen_kernels.hip.h)
                 const int d = wave;
                 const bool is_n = (lane >> 4) == 2;
                 float h = 0.0f;
-                const float* gd = gi + d * 32 * 36;
-                int f = d ? 31 : 0;
+                // running LDS offsets of the walk, the next step's x side fetched a step ahead (fspen_kernels.hip.h)
+                const int f0 = d ? 31 : 0;
+                int go = (d * 32 + f0) * 36 + g_row * 12 + c12, gn = (d * 32 + f0) * 36 + 24 + c12, ho = f0 * 24 + d * 12 + c12;
+                const int gstep = d ? -36 : 36, hstep = d ? -24 : 24;
+                float g_own = gi[go], g_n = gi[gn];
 #pragma unroll 1
                 for (int s_ = 0; s_ < 32; ++s_) {
-                    const float g_own = gd[f * 36 + g_row * 12 + c12], g_n = gd[f * 36 + 24 + c12];
-                    float acc = bhn;
-                    static_for<12>([&](auto k_) { constexpr int k = decltype(k_)::value; acc = fmaf(wg_[k], row_bcast<k>(h), acc); });
-                    const float x_ = is_n ? acc : sigmoid_f(g_own + acc);
+                    go += gstep; gn += gstep;
+                    const float n_own = gi[go], n_n = gi[gn];       // (after the last step: the other direction's rows, unused)
+                    const float acc = row_dot(wg_, h, bhn);
+                    const float x_ = is_n ? acc : sigmoid_pre(g_own + acc);
                     float r, z, pn;
                     rows_gather3(x_, r, z, pn);
-                    const float n = tanh_f(g_n + r * pn);
-                    h = (1.0f - z) * n + z * h;
-                    if (lane < 12) hseq[f * 24 + d * 12 + lane] = h;
-                    f += d ? -1 : 1;
+                    const float n = tanh_pre(__builtin_fmaf(r, pn, g_n));
+                    h = __builtin_fmaf(z, h - n, n);
+                    hseq[ho] = h;                                   // (lanes 12..15 of a row shadow unit 0; the four rows hold the same h)
+                    ho += hstep;
+                    g_own = n_own; g_n = n_n;
                 }
             }
             __syncthreads();
