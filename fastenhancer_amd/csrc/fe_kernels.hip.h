@@ -281,6 +281,12 @@ __device__ __forceinline__ float silu_scaled_f(float u) { return u * __builtin_a
 // x^p for x > 0 through the 1-ulp hardware log2 / exp2 (v_log_f32, v_exp_f32); pow_f(0, p > 0) = 0
 __device__ __forceinline__ float pow_f(float x, float p) { return x > 0.0f ? __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x)) : 0.0f; }
 __device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+// GRU gate pre-activations carried SCALED on the latency chains (the time-batched scans, the FSPEN / LiSenNet recurrences): r, z by
+// -log2 e, the n parts by 2 log2 e - the scale sits in the weights / at the place the x side is produced -, so that sigmoid and tanh are
+// exp2 + rcp with no multiply on the step's chain (a lone wave issues one instruction every ~6 cycles whatever its kind)
+constexpr float kGateRZ = -1.4426950408889634f, kGateN = 2.8853900817779268f;
+__device__ __forceinline__ float sigmoid_pre(float u) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u)); }          // u = -log2e x
+__device__ __forceinline__ float tanh_pre(float u) { return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u)), 1.0f); }   // u = 2 log2e x
 
 // Weights / tables are read through ONE buffer resource: the per-lane part of every address is the
 // single VGPR `lane*4`; the section / tile / k-step part is a scalar (SGPR or immediate) offset.

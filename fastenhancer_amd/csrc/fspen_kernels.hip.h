@@ -233,12 +233,6 @@ __device__ __forceinline__ float row_dot(const float (&w)[12], float h, float ac
     return acc + a1;
 }
 #undef FS_DF
-// gate pre-activations carried SCALED (r, z by -log2 e; the n parts by 2 log2 e - the scale sits in the weights / at the place the x side
-// is produced): sigmoid and tanh are then exp2 + rcp with no multiply on the step's chain
-constexpr float kGateRZ = -1.4426950408889634f, kGateN = 2.8853900817779268f;
-__device__ __forceinline__ float sigmoid_pre(float u) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u)); }          // u = -log2e x
-__device__ __forceinline__ float tanh_pre(float u) { return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u)), 1.0f); }   // u = 2 log2e x
-
 #ifndef FS_WPE
 #define FS_WPE 3          // waves per SIMD = workgroups per CU of the register budget (168 VGPRs: what the 54 KB LDS plan allows too)
 #endif

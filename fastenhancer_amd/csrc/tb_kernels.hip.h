@@ -247,7 +247,11 @@ __device__ __forceinline__ void tok_panel_rb(f32x4 (&acc)[MTP][NTP], const float
         }
 }
 
-// gx = x W_ih^T + b for one block and direction -> global [frame][3 C2][F2]; X: the tile's tokens in LDS
+// gx is stored SCALED for the scans (fe_kernels.hip.h, kGateRZ / kGateN): the r and z columns by -log2 e, the n columns by 2 log2 e
+template <class S>
+__device__ __forceinline__ float gx_scale(int col) { return col < 2 * S::C2 ? kGateRZ : kGateN; }
+
+// gx = (x W_ih^T + b) * gx_scale for one block and direction -> global [frame][3 C2][F2]; X: the tile's tokens in LDS
 template <class S, int FT>
 __device__ __forceinline__ void gx_gemm(const float* Xb, const WSrc<false>& wb, int w_off, int b_off, float* gx_tile, int rows_valid, int wave, int lane) {
     const __amdgpu_buffer_rsrc_t gr = range_rsrc(gx_tile, (size_t)rows_valid * S::N3 * 4);
@@ -279,8 +283,9 @@ __device__ __forceinline__ void gx_gemm(const float* Xb, const WSrc<false>& wb, 
         for (int j = 0; j < CH; ++j) {
             const int nt = wave + 4 * (j0 + j), col = 16 * nt + li;
             if (nt < NT3 && col < N3) {
+                const float gsc = gx_scale<S>(col);
 #pragma unroll
-                for (int i = 0; i < MTT; ++i) bstore4(gr, acc[i][j], cm_off<S>(16 * i + 4 * lg, col, N3) * 4);
+                for (int i = 0; i < MTT; ++i) bstore4(gr, acc[i][j] * gsc, cm_off<S>(16 * i + 4 * lg, col, N3) * 4);
             }
         }
     }
@@ -566,8 +571,8 @@ __device__ __forceinline__ void scan_role(const TbArgs& a, int rg, int dir, floa
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) whh[j][g][ks] = wb.at_g(w_off + ((g * NT2 + ctc) * KS + ks) * 64);
-        bhn[j] = wb.at16_g(bn_off + ctc * 16);
+            for (int ks = 0; ks < KS; ++ks) whh[j][g][ks] = wb.at_g(w_off + ((g * NT2 + ctc) * KS + ks) * 64) * (g < 2 ? kGateRZ : kGateN);
+        bhn[j] = wb.at16_g(bn_off + ctc * 16) * kGateN;          // (scaled pre-activations, like gx: see gx_scale)
     }
     // this lane's four rows (C/D layout: rows 4 lg + r - four consecutive sub-bands of one utterance: R % 4 == 0) and columns 16 ct + li
     bool rok[4];
@@ -601,25 +606,36 @@ __device__ __forceinline__ void scan_role(const TbArgs& a, int rg, int dir, floa
     }
     // gx of the steps ahead: a ring of GD steps in registers.  gx does not fit in L2 for a real batch (10 KB per frame): with ONE step of
     // prefetch every step waited for an HBM round trip - all scan variants ran at the same ~0.9 us per step whatever their arithmetic.
+    // The step is a latency chain on a lone wave per SIMD - it costs its instruction count - so: the r / z parts of gx are the MFMA
+    // accumulators' initial values (no add), everything is pre-scaled for exp2 (no multiply), a slot is refilled AFTER its step has
+    // used it (no register copies), gx / hs are walked with running pointers, h goes to LDS unpredicated (idle lanes aim at the pad column).
     constexpr int GD = (NTPW * 12 <= 24) ? 4 : 2;
-    float gxv[GD][NTPW][3][4];
-    auto load_gx = [&](int slot, int t) {
-        const size_t toff = (size_t)t * F2 * N3;
+    const int t_first = dir ? a.T - 1 : 0, dt = dir ? -1 : 1;
+    f32x4 gxv[GD][NTPW][3];
+    const float* gxp[NTPW];
+    float* hsp[NTPW];
+    int hcol[NTPW];
+    bool cokj[NTPW];
+#pragma unroll
+    for (int j = 0; j < NTPW; ++j) {
+        const int col = 16 * (wave + 4 * j) + li;
+        cokj[j] = live[j] && col < C2;
+        hcol[j] = cokj[j] ? col : C2;                                           // LDS column (C2 = the pad column of the h tile)
+        gxp[j] = gxd + grow + (size_t)t_first * F2 * N3 + (size_t)(cokj[j] ? col : 0) * F2;
+        hsp[j] = a.hs + hrow + (size_t)t_first * F2 * HW + (size_t)(cokj[j] ? col : 0) * F2;
+    }
+    const ptrdiff_t gstep = (ptrdiff_t)dt * F2 * N3, hstep = (ptrdiff_t)dt * F2 * HW;
+    auto load_gx = [&](int slot) {             // the next unfetched step of every column tile; the pointers move on
 #pragma unroll
         for (int j = 0; j < NTPW; ++j) {
-            int col = 16 * (wave + 4 * j) + li;
-            col = (live[j] && col < C2) ? col : 0;
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                const float4 v = *reinterpret_cast<const float4*>(gxd + grow + toff + (size_t)(g * C2 + col) * F2);
-                gxv[slot][j][g][0] = v.x; gxv[slot][j][g][1] = v.y; gxv[slot][j][g][2] = v.z; gxv[slot][j][g][3] = v.w;
-            }
+            for (int g = 0; g < 3; ++g) gxv[slot][j][g] = *reinterpret_cast<const f32x4*>(gxp[j] + (size_t)g * C2 * F2);
+            gxp[j] += gstep;
         }
     };
-    const int t_first = dir ? a.T - 1 : 0, dt = dir ? -1 : 1;
 #pragma unroll
     for (int d = 0; d < GD; ++d)
-        if (d < a.T) load_gx(d, t_first + d * dt);
+        if (d < a.T) load_gx(d);
     __syncthreads();
     int cur = 0;
 #pragma unroll 1
@@ -628,24 +644,15 @@ __device__ __forceinline__ void scan_role(const TbArgs& a, int rg, int dir, floa
     for (int d = 0; d < GD; ++d) {
         const int st = st0 + d;
         if (st >= a.T) break;
-        const int t = t_first + st * dt;
         const float* hc = hbuf[cur] + li * LDX + lg;
         float av[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) av[ks] = hc[4 * ks];
-        float gcur[NTPW][3][4];
-#pragma unroll
-        for (int j = 0; j < NTPW; ++j)
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gcur[j][g][r] = gxv[d][j][g][r];
-        if (st + GD < a.T) load_gx(d, t + GD * dt);          // the x half GD steps ahead: in flight under the next GD - 1 steps
         f32x4 acc[NTPW][3];
 #pragma unroll
         for (int j = 0; j < NTPW; ++j) {
-            acc[j][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            acc[j][1] = acc[j][0];
+            acc[j][0] = gxv[d][j][0];
+            acc[j][1] = gxv[d][j][1];
             acc[j][2] = f32x4{bhn[j], bhn[j], bhn[j], bhn[j]};
         }
 #pragma unroll
@@ -655,22 +662,19 @@ __device__ __forceinline__ void scan_role(const TbArgs& a, int rg, int dir, floa
 #pragma unroll
                 for (int g = 0; g < 3; ++g) acc[j][g] = FE_MFMA(av[ks], whh[j][g][ks], acc[j][g]);
         float* hn = hbuf[cur ^ 1];
-        const size_t toff = (size_t)t * F2 * HW;
 #pragma unroll
         for (int j = 0; j < NTPW; ++j) {
-            const int col = 16 * (wave + 4 * j) + li;
-            const bool cok = live[j] && col < C2;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float rr = sigmoid_f(gcur[j][0][r] + acc[j][0][r]);
-                const float zz = sigmoid_f(gcur[j][1][r] + acc[j][1][r]);
-                const float nn = tanh_f(gcur[j][2][r] + rr * acc[j][2][r]);
-                const float hv = (1.0f - zz) * nn + zz * hprev[j][r];
+                const float rr = sigmoid_pre(acc[j][0][r]);
+                const float zz = sigmoid_pre(acc[j][1][r]);
+                const float nn = tanh_pre(__builtin_fmaf(rr, acc[j][2][r], gxv[d][j][2][r]));
+                const float hv = __builtin_fmaf(zz, hprev[j][r] - nn, nn);          // (1 - z) n + z h
                 hprev[j][r] = hv;
-                if (cok) hn[(4 * lg + r) * LDX + col] = hv;
+                hn[(4 * lg + r) * LDX + hcol[j]] = hv;
             }
-            if (cok && rok[0]) {
-                float* hd = a.hs + hrow + toff + (size_t)col * F2;
+            if (cokj[j] && rok[0]) {
+                float* hd = hsp[j];
                 if constexpr (PUB > 0) {            // (read by other workgroups of the SAME launch: agent-scope accesses on both sides, no cache in between)
                     // one 16-byte store with the system-coherent bits (what a relaxed agent-scope atomic store of each float would set)
                     const f32x4 hv4 = {hprev[j][0], hprev[j][1], hprev[j][2], hprev[j][3]};
@@ -678,7 +682,9 @@ __device__ __forceinline__ void scan_role(const TbArgs& a, int rg, int dir, floa
                 } else
                 *reinterpret_cast<float4*>(hd) = make_float4(hprev[j][0], hprev[j][1], hprev[j][2], hprev[j][3]);
             }
+            hsp[j] += hstep;
         }
+        if (st + GD < a.T) load_gx(d);          // the x half GD steps ahead, into the slot this step has just used up
         cur ^= 1;
         if constexpr (PUB > 0) {
             const bool pub = ((st + 1) % PUB == 0) || st + 1 == a.T;
@@ -749,9 +755,9 @@ __global__ void __launch_bounds__(kThreads) tb_scan4_kernel(TbArgs a) {
 #pragma unroll
             for (int kk = 0; kk < KQ; ++kk) {
                 const int kx = q * KQ + kk;
-                w[s][g][kk] = wb.gather_g(w_off + g * gsz + ((c >> 4) * KS + (kx >> 2)) * 64 + (kx & 3) * 16 + (c & 15));
+                w[s][g][kk] = wb.gather_g(w_off + g * gsz + ((c >> 4) * KS + (kx >> 2)) * 64 + (kx & 3) * 16 + (c & 15)) * (g < 2 ? kGateRZ : kGateN);
             }
-        bhn[s] = wb.gather_g(bn_off + c);
+        bhn[s] = wb.gather_g(bn_off + c) * kGateN;               // (scaled pre-activations, like gx: see gx_scale)
     }
     // this lane's (row, channel): row = 4 blockIdx.x + q
     const int row = blockIdx.x * 4 + q;
@@ -768,21 +774,32 @@ __global__ void __launch_bounds__(kThreads) tb_scan4_kernel(TbArgs a) {
         hprev[s] = v;
         if (ok[s]) hbuf[0][q * LDR + (ch[s] / KQ) * KP + ch[s] % KQ] = v;
     }
-    float gxv[NSET][3];
-    auto load_gx = [&](int t) {
-        const size_t toff = (size_t)t * F2 * N3;
-#pragma unroll
-        for (int s = 0; s < NSET; ++s)
-#pragma unroll
-            for (int g = 0; g < 3; ++g) gxv[s][g] = gxd[grow + toff + (size_t)(g * C2 + ch[s]) * F2];
-    };
+    // (the step costs its instruction count - see scan_role: running pointers, scaled pre-activations, the slot refilled after its use)
     const int t_first = dir ? a.T - 1 : 0, dt = dir ? -1 : 1;
-    load_gx(t_first);
+    float gxv[NSET][3];
+    const float* gxp[NSET];
+    float* hsp[NSET];
+    int hoff[NSET];
+#pragma unroll
+    for (int s = 0; s < NSET; ++s) {
+        gxp[s] = gxd + grow + (size_t)t_first * F2 * N3 + (size_t)ch[s] * F2;
+        hsp[s] = a.hs + hrow + (size_t)t_first * F2 * HW + (size_t)ch[s] * F2;
+        hoff[s] = q * LDR + (ch[s] / KQ) * KP + ch[s] % KQ;
+    }
+    const ptrdiff_t gstep = (ptrdiff_t)dt * F2 * N3, hstep = (ptrdiff_t)dt * F2 * HW;
+    auto load_gx = [&]() {
+#pragma unroll
+        for (int s = 0; s < NSET; ++s) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gxv[s][g] = gxp[s][(size_t)g * C2 * F2];
+            gxp[s] += gstep;
+        }
+    };
+    load_gx();
     __syncthreads();
     int cur = 0;
 #pragma unroll 1
     for (int st = 0; st < a.T; ++st) {
-        const int t = t_first + st * dt;
         // A fragments: h[row j][quarter q]
         float ha[KP];
         {
@@ -793,12 +810,6 @@ __global__ void __launch_bounds__(kThreads) tb_scan4_kernel(TbArgs a) {
                 ha[4 * i] = v.x; ha[4 * i + 1] = v.y; ha[4 * i + 2] = v.z; ha[4 * i + 3] = v.w;
             }
         }
-        float gcur[NSET][3];
-#pragma unroll
-        for (int s = 0; s < NSET; ++s)
-#pragma unroll
-            for (int g = 0; g < 3; ++g) gcur[s][g] = gxv[s][g];
-        if (st + 1 < a.T) load_gx(t + dt);                   // next step's x half: in flight under this step
         f32x4 acc[NSET][3];
 #pragma unroll
         for (int s = 0; s < NSET; ++s)
@@ -811,7 +822,6 @@ __global__ void __launch_bounds__(kThreads) tb_scan4_kernel(TbArgs a) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) acc[s][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(ha[kk], w[s][g][kk], acc[s][g], 0, 0, 0);
         float* hn = hbuf[cur ^ 1];
-        const size_t toff = (size_t)t * F2 * HW;
 #pragma unroll
         for (int s = 0; s < NSET; ++s) {
             float tot[3];
@@ -827,16 +837,15 @@ __global__ void __launch_bounds__(kThreads) tb_scan4_kernel(TbArgs a) {
                 }
                 tot[g] = q == 0 ? u[0] : (q == 1 ? u[1] : (q == 2 ? u[2] : u[3]));
             }
-            const float rr = sigmoid_f(gcur[s][0] + tot[0]);
-            const float zz = sigmoid_f(gcur[s][1] + tot[1]);
-            const float nn = tanh_f(gcur[s][2] + rr * (tot[2] + bhn[s]));
-            const float hv = (1.0f - zz) * nn + zz * hprev[s];
+            const float rr = sigmoid_pre(gxv[s][0] + tot[0]);
+            const float zz = sigmoid_pre(gxv[s][1] + tot[1]);
+            const float nn = tanh_pre(__builtin_fmaf(rr, tot[2] + bhn[s], gxv[s][2]));
+            const float hv = __builtin_fmaf(zz, hprev[s] - nn, nn);
             hprev[s] = hv;
-            if (ok[s]) {
-                hn[q * LDR + (ch[s] / KQ) * KP + ch[s] % KQ] = hv;
-                a.hs[hrow + toff + (size_t)ch[s] * F2] = hv;
-            }
+            if (ok[s]) { hn[hoff[s]] = hv; *hsp[s] = hv; }
+            hsp[s] += hstep;
         }
+        if (st + 1 < a.T) load_gx();                         // next step's x half: in flight under the next step's MFMAs
         cur ^= 1;
         __syncthreads();
     }
@@ -964,11 +973,12 @@ __device__ __forceinline__ void blk_body(const TbArgs& a, float* smem, const int
                 nt = nt < S::NT3 ? nt : S::NT3 - 1;
 #pragma unroll
                 for (int ks = 0; ks < S::KS_2; ++ks) wq[j][ks] = wb.at_g(o.blk_qkv[0] + kb + (nt * S::KS_2 + ks) * 64);
+                const float gsc = gx_scale<S>(16 * nt + li);        // gx is stored SCALED (gx_scale): free here, the weights are loaded once
 #pragma unroll
                 for (int d = 0; d < S::ND; ++d) {
 #pragma unroll
-                    for (int ks = 0; ks < S::KS_2; ++ks) wg[d][j][ks] = more ? wb.at_g(o.tb_wih[0][0] + kw + d * dw + (nt * S::KS_2 + ks) * 64) : 0.0f;
-                    bg[d][j] = more ? wb.at16_g(o.tb_bx[0][0] + kbx + d * db + nt * 16) : 0.0f;
+                    for (int ks = 0; ks < S::KS_2; ++ks) wg[d][j][ks] = more ? wb.at_g(o.tb_wih[0][0] + kw + d * dw + (nt * S::KS_2 + ks) * 64) * gsc : 0.0f;
+                    bg[d][j] = more ? wb.at16_g(o.tb_bx[0][0] + kbx + d * db + nt * 16) * gsc : 0.0f;
                 }
             }
         }
