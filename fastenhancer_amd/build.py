@@ -143,12 +143,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
         defs = [f"-DFE_SHAPE_NAME={name}", f"-DFE_SHAPE_ARGS={args}"]
         jobs.append((tmpl_b, os.path.join(OBJ, f"fe_bsrnn_{name}.o"), defs, os.path.join(OBJ, f"fe_bsrnn_{name}.stamp"),
                      _digest(common_b + [tmpl_b], " ".join(FLAGS + defs))))
+    # The two VALU-only models are compiled without the SLP vectoriser: it pairs the FMAs of two outputs into v_pk_fma_f32 whose packed
+    # operand it then has to assemble with one or two v_mov_b32 each (811 moves in FSPEN's hot kernel): FSPEN +7 % at 4096 streams,
+    # +2 % at 256, LiSenNet +1 % (profiles/r3z_no_slp_ab.txt; the MFMA kernels and BSRNN lose 0.2-1.3 % without it and keep it).
+    valu_defs = ["-fno-slp-vectorize"]
     fsp = os.path.join(CSRC, "fe_fspen.hip")
-    jobs.append((fsp, os.path.join(OBJ, "fe_fspen.o"), [], os.path.join(OBJ, "fe_fspen.stamp"),
-                 _digest([os.path.join(CSRC, d) for d in FSPEN_DEPS] + [fsp], " ".join(FLAGS))))
+    jobs.append((fsp, os.path.join(OBJ, "fe_fspen.o"), valu_defs, os.path.join(OBJ, "fe_fspen.stamp"),
+                 _digest([os.path.join(CSRC, d) for d in FSPEN_DEPS] + [fsp], " ".join(FLAGS + valu_defs))))
     lsn = os.path.join(CSRC, "fe_lisennet.hip")
-    jobs.append((lsn, os.path.join(OBJ, "fe_lisennet.o"), [], os.path.join(OBJ, "fe_lisennet.stamp"),
-                 _digest([os.path.join(CSRC, d) for d in LISENNET_DEPS] + [lsn], " ".join(FLAGS))))
+    jobs.append((lsn, os.path.join(OBJ, "fe_lisennet.o"), valu_defs, os.path.join(OBJ, "fe_lisennet.stamp"),
+                 _digest([os.path.join(CSRC, d) for d in LISENNET_DEPS] + [lsn], " ".join(FLAGS + valu_defs))))
     if force:
         for j in jobs:
             if os.path.exists(j[3]):
