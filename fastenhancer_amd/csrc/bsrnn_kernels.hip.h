@@ -103,6 +103,11 @@ struct BArgs {
     unsigned int* pipe_flags; // [B][NLAY]: frames whose layer-l time-LSTM state (h, c) is in `lstm`
     float* frames;            // [B][T][N] windowed output frames (summed / envelope-normalised by istft_ola_kernel)
     int pipe_p;
+    // the split per-hop step (PART 1 -> bsrnn_mlp_kernel -> PART 2): band features after the last layer [B][31][C], the compressed
+    // spectrum [B][257][2], the mask decoder's layer-2 pre-activations [B][2][1028]
+    float* mlp_x;
+    float* mlp_sp;
+    float* mlp_pre;
 };
 
 // debug stage table: spec_in, compressed, band_split, (layer.l.time, layer.l.freq)..., mask_mlp, spec_out
@@ -156,9 +161,15 @@ struct BLds {
 // loads right before the layer's gate GEMM (state AND counter through agent-scope accesses: no release / acquire fence, which on this
 // part writes back / invalidates whole caches).  The serial chain per frame and layer is wait -> fetch -> gates -> publish; the band
 // recurrence, the fc layers and the mask MLPs - 9/10 of a frame - run in parallel across the frames in flight.
-template <class S, bool HOT, bool PROF, bool DBG, bool OCC2 = false, bool PIPE = false>
+// PART (the per-hop step split in three launches, blaunch_split): every workgroup of the fused kernel streams the mask decoder's 780 KB
+// (xt) of weights from L2 once per frame - each weight is used ONCE per stream (M = 1) - and that is 40 k of a frame's 240 k cycles at
+// ~20 B/clk per CU.  Batched over the streams the same products are a small MFMA GEMM whose weights are read once per 64 streams:
+// PART = 1 runs the frame up to the last layer and leaves the band features and the compressed spectrum in global memory,
+// bsrnn_mlp_kernel computes the two MLP layers for all streams, PART = 2 applies GLU / mask / residual and runs the iSTFT.
+template <class S, bool HOT, bool PROF, bool DBG, bool OCC2 = false, bool PIPE = false, int PART = 0>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, OCC2 ? 2 : 1))) bsrnn_frame_kernel(BArgs a) {
     static_assert(!PIPE || (!HOT && !PROF && !DBG), "the time-pipelined instantiation is the plain offline kernel");
+    static_assert(PART == 0 || (HOT && !PROF && !DBG && !PIPE), "the split step is the per-hop streaming step");
     const int aT = HOT ? 1 : a.T;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = BLds<S>;
@@ -290,6 +301,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll 1
     for (int t = t_first; t < aT; t += t_step) {
         BE_CLK(0);
+        if constexpr (PART != 2) {
         // ============================ STFT + compress (all 257 bins; models/bsrnn/model.py:430-436) ============================
         if (mode != FE_MODE_SPEC) {
             const float* win = wp + o.window;
@@ -744,14 +756,23 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             if (l == 0) BE_CLK(7);
         }
 
+        }      // (PART != 2)
         BE_CLK(8);
+        if constexpr (PART == 1) {
+            // hand-over to bsrnn_mlp_kernel / the PART 2 launch
+            float* xg = a.mlp_x + (size_t)b * (kBands * C);
+            for (int i = tid; i < kBands * C; i += kThreads) { const int bb = i / C; xg[i] = X[bb * LDX + (i - bb * C)]; }
+            float* sg = a.mlp_sp + (size_t)b * (2 * kBins);
+            for (int i = tid; i < 2 * kBins; i += kThreads) sg[i] = sp[i];
+            __syncthreads();          // (a persistent workgroup's next stream overwrites X / sp)
+        } else {
         // ============================ mask decoder (MaskDecoder.forward, :225-246) ============================
         // Every workgroup streams the same 780 KB (xt) of MLP weights once per frame.  Started together, the workgroups of
         // an XCD would all ask its L2 for the same lines at the same time (one channel busy, fifteen idle): each workgroup
         // therefore walks the rows in its own rotation.  Rows are software-pipelined D rows ahead of the FMAs (register ring).
         // layer 1: thread <-> output (kind, band, o): a wave covers 64 consecutive outputs of ONE band (4C >= 64), so the
         // X reads are LDS broadcasts
-        {
+        if constexpr (PART == 0) {
             constexpr int NOUT = 2 * kBands * 4 * C, ROUNDS = (NOUT + kThreads - 1) / kThreads, R4 = C / 4;
             constexpr int D = OCC2 ? 2 : (R4 <= 4 ? 8 : (R4 <= 8 ? 4 : 2));      // rows in flight: under load the L2 round trip is ~1 us, the ring holds 32 KB per wave
             const int rot = (int)(blockIdx.x >> 3) % ROUNDS;
@@ -818,6 +839,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     brg[q] = bin_2sub[f];
                 }
             }
+            if constexpr (PART == 2) {
+                const float* pg = a.mlp_pre + (size_t)b * (2 * kMlpRows);
+                for (int i = tid; i < 2 * kMlpRows; i += kThreads) PRE[i] = pg[i];
+                const float* sg = a.mlp_sp + (size_t)b * (2 * kBins);
+                for (int i = tid; i < 2 * kBins; i += kThreads) sp[i] = sg[i];
+            } else {
             auto load_item = [&](int it, float4 (&wv)[CH], int& band, float& bias) {
                 if (it < NIT) {
                     const int r = it / NCH, ch = it - r * NCH;
@@ -858,6 +885,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     load_item(it + D, ring[jj], rbnd[jj], rbias[jj]);
                 }
             }
+            }      // (PART != 2)
             __syncthreads();
             // GLU(dim=1) per band: rows [0, 2 sub) are values, rows [2 sub, 4 sub) their gates; then spec * mask + residual (:393-401)
             float* spo = mode == FE_MODE_SPEC ? a.spec_out + (size_t)b * kBins * aT * 2 : nullptr;
@@ -947,11 +975,131 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             __syncthreads();
             }
         }
+        }      // (PART != 1)
         BE_CLK(11);
     }
     if constexpr (PIPE) break;
     b += gridDim.x;
     } while (b < a.B);
+}
+
+// The mask decoder's two MLP layers (MaskDecoder.forward, models/bsrnn/model.py:225-246) batched over the streams: a wave = 16 streams x one
+// (kind, band); its four waves give a workgroup 64 streams of the same (kind, band), so the band's weights are read from L2 once per 64 streams
+// (the fused kernel: once per stream).  Layer 1 [16 x C] x [C x 4C] + tanh -> a wave-private LDS tile (C/D layout -> A operand) -> layer 2
+// [16 x 4C] x [4C x 4 sub] for the band's rows -> PRE[stream][kind][row] in global memory (GLU / mask in the PART 2 launch).  The B
+// fragments come straight out of the VALU path's k-major float4 layouts ([band][k/4][o] / [k/4][row]): lane (n = li, k = 4 ks + lg) is
+// element lg of float4 (ks, n).  No barrier: nothing is shared between the waves.
+__host__ __device__ constexpr int bsrnn_band_sub(int b) { return b == 0 ? 2 : (b <= 10 ? 3 : (b <= 22 ? 8 : (b <= 29 ? 16 : 17))); }
+__host__ __device__ constexpr int bsrnn_band_bin0(int b) { return b == 0 ? 0 : (b <= 10 ? 2 + 3 * (b - 1) : (b <= 22 ? 32 + 8 * (b - 11) : (b <= 29 ? 128 + 16 * (b - 23) : 240))); }
+static_assert(bsrnn_band_bin0(30) + bsrnn_band_sub(30) == kBins, "band table");
+template <class S>
+struct BMlpLds {
+    static constexpr int LDH = 4 * S::C + 2;                   // hidden rows: 2 x odd floats (conflict-free A-fragment reads)
+    static constexpr size_t BYTES = (size_t)kWaves * 16 * LDH * 4;
+};
+template <class S>
+__global__ void __launch_bounds__(kThreads) bsrnn_mlp_kernel(BArgs a) {
+    constexpr int C = S::C, O1 = 4 * C, R4 = C / 4, NT1 = O1 / 16, KS2 = O1 / 4, LDH = BMlpLds<S>::LDH;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int kb = (int)blockIdx.x % (2 * kBands), tg = (int)blockIdx.x / (2 * kBands);
+    const int kind = kb / kBands, band = kb - kind * kBands;
+    const int s0 = (tg * kWaves + wave) * 16;
+    if (s0 >= a.B) return;                                    // (wave-uniform; the kernel has no barrier)
+    const float* __restrict__ wp = a.wp;
+    const BOffsets& o = a.off;
+    float* h1 = smem + wave * (16 * LDH);
+    // layer 2's work list: items = (column tile of the band's rows, burst of KB k-steps); their weights ride D items ahead of the MFMAs in a
+    // register ring, and the first D are requested before layer 1 (a wave per SIMD: nothing else hides the L2 round trips)
+    const int n2 = 4 * bsrnn_band_sub(band), row0 = 4 * bsrnn_band_bin0(band);
+    const int nt2 = (n2 + 15) >> 4;
+    constexpr int KB = KS2 < 16 ? KS2 : 16, NB = KS2 / KB, D = NB == 1 ? 5 : 8;   // (C = 16: a band has at most five items - all in flight at once)
+    const int nit = nt2 * NB;
+    auto row_of = [&](int nt) { const int c = 16 * nt + li; return row0 + (c < n2 ? c : n2 - 1); };
+    auto load_item = [&](int it, float (&wv)[KB], float& bias) {
+        if (it < nit) {
+            const int nt = it / NB, kbi = it - nt * NB, row = row_of(nt);
+            const float* w2 = wp + o.m_w2[kind] + (size_t)row * 4 + lg + (size_t)(kbi * KB) * kMlpRows * 4;
+#pragma unroll
+            for (int ks = 0; ks < KB; ++ks) wv[ks] = w2[(size_t)ks * kMlpRows * 4];
+            bias = wp[o.m_b2[kind] + row];
+        }
+    };
+    float ring[D][KB], rbias[D];
+#pragma unroll
+    for (int jj = 0; jj < D; ++jj) { rbias[jj] = 0.0f; load_item(jj, ring[jj], rbias[jj]); }
+    // ---- layer 1
+    {
+        const int srow = s0 + li < a.B ? s0 + li : a.B - 1;   // (rows past the batch shadow its last stream; their results are not stored)
+        const float* xa = a.mlp_x + ((size_t)srow * kBands + band) * C + lg;
+        float av[R4];
+#pragma unroll
+        for (int ks = 0; ks < R4; ++ks) av[ks] = xa[4 * ks];
+        const float* w1 = wp + o.m_w1[kind] + (size_t)band * R4 * O1 * 4 + li * 4 + lg;
+        const float* b1 = wp + o.m_b1[kind] + band * O1 + li;
+#pragma unroll
+        for (int nt0 = 0; nt0 < NT1; nt0 += 4) {              // four column tiles at a time (C = 64: 16 tiles)
+            f32x4 acc[4];
+            float wv[4][R4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float bj = b1[16 * (nt0 + j)];
+                acc[j] = f32x4{bj, bj, bj, bj};
+#pragma unroll
+                for (int ks = 0; ks < R4; ++ks) wv[j][ks] = w1[((size_t)ks * O1 + 16 * (nt0 + j)) * 4];
+            }
+#pragma unroll
+            for (int ks = 0; ks < R4; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = FE_MFMA(av[ks], wv[j][ks], acc[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h1[(4 * lg + r) * LDH + 16 * (nt0 + j) + li] = tanh_f(acc[j][r]);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- layer 2: the band's 4 sub rows (value rows, then gate rows)
+    {
+        float av[KS2];
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) av[ks] = h1[li * LDH + 4 * ks + lg];
+        float* pre = a.mlp_pre + (size_t)kind * kMlpRows;
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+        for (int g = 0; g * D < nit; ++g) {
+#pragma unroll
+            for (int jj = 0; jj < D; ++jj) {
+                const int it = g * D + jj;
+                if (it < nit) {
+                    const int nt = it / NB, kbi = it - nt * NB;
+                    if (kbi == 0) acc = f32x4{rbias[jj], rbias[jj], rbias[jj], rbias[jj]};
+                    // (av is indexed by compile-time k-steps: one unrolled body per burst position)
+                    static_for<NB>([&](auto kb_) {
+                        constexpr int kbc = decltype(kb_)::value;
+                        if (NB == 1 || kbi == kbc) {
+#pragma unroll
+                            for (int ks = 0; ks < KB; ++ks) acc = FE_MFMA(av[kbc * KB + ks], ring[jj][ks], acc);
+                        }
+                    });
+                    if (kbi == NB - 1) {
+                        const bool cok = 16 * nt + li < n2;
+                        const int row = row_of(nt);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int st = s0 + 4 * lg + r;
+                            if (cok && st < a.B) pre[(size_t)st * (2 * kMlpRows) + row] = acc[r];
+                        }
+                    }
+                }
+                load_item(it + D, ring[jj], rbias[jj]);
+            }
+        }
+    }
 }
 
 struct BImpl {
@@ -967,6 +1115,7 @@ struct BImpl {
     void (*dbg_stage)(int, int*, int*, size_t*);
     void (*launch_pipe)(const BArgs&, hipStream_t, hipError_t*);       // time-pipelined offline launch (cooperative: B * pipe_p workgroups)
     int occ;                  // workgroups per CU the LDS plan allows
+    void (*launch_split)(const BArgs&, int max_wgs, hipStream_t, hipError_t*);   // the per-hop step as three launches (mlp_x / mlp_sp / mlp_pre set)
 };
 
 template <class S, bool HOT, bool PROF, bool DBG, bool OCC2 = false>
@@ -1003,6 +1152,47 @@ void blaunch_impl(const BArgs& a, int max_wgs, hipStream_t st, hipError_t* err) 
     else blaunch_one<S, false, false, false>(a, grid, st, err);
 }
 
+template <class S, bool OCC2, int PART>
+void blaunch_part(const BArgs& a, int grid, hipStream_t st, hipError_t* err) {
+    auto* fn = &bsrnn_frame_kernel<S, true, false, false, OCC2, false, PART>;
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev].load(std::memory_order_relaxed)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BLds<S>::BYTES);
+        if (e != hipSuccess) { *err = e; return; }
+        attr_set[dev].store(true, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), BLds<S>::BYTES, st, a);
+    *err = hipGetLastError();
+}
+
+// the per-hop streaming step (mode = stream, T = 1) as head -> batched mask-decoder MLP -> tail
+template <class S>
+void blaunch_split_impl(const BArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
+    constexpr bool FITS2 = 2 * BLds<S>::BYTES <= 160 * 1024 && !S::XPG;
+    if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 1>(a, a.B < 2 * max_wgs ? a.B : 2 * max_wgs, st, err);
+    else blaunch_part<S, false, 1>(a, a.B < max_wgs ? a.B : max_wgs, st, err);
+    if (*err != hipSuccess) return;
+    {
+        auto* fn = &bsrnn_mlp_kernel<S>;
+        static std::atomic<bool> attr_set[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!attr_set[dev].load(std::memory_order_relaxed)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BMlpLds<S>::BYTES);
+            if (e != hipSuccess) { *err = e; return; }
+            attr_set[dev].store(true, std::memory_order_relaxed);
+        }
+        const int groups = (a.B + 16 * kWaves - 1) / (16 * kWaves);
+        hipLaunchKernelGGL(fn, dim3(2 * kBands * groups), dim3(kThreads), BMlpLds<S>::BYTES, st, a);
+        *err = hipGetLastError();
+        if (*err != hipSuccess) return;
+    }
+    if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 2>(a, a.B < 2 * max_wgs ? a.B : 2 * max_wgs, st, err);
+    else blaunch_part<S, false, 2>(a, a.B < max_wgs ? a.B : max_wgs, st, err);
+}
+
 template <class S>
 void blaunch_pipe_impl(const BArgs& a, hipStream_t st, hipError_t* err) {
     auto* fn = &bsrnn_frame_kernel<S, false, false, false, false, true>;
@@ -1030,7 +1220,8 @@ template <class S>
 BImpl make_bimpl() {
     return BImpl{S::C, S::NLAY, S::HOP, BLds<S>::BYTES, S::XPG ? (size_t)2 * 32 * S::G4 : (size_t)0,
                  BDebugLayout<S>::total(), BDebugLayout<S>::n_stages, S::WREG, S::KSPLIT, S::NTD, &blaunch_impl<S>, &bdbg_stage_impl<S>,
-                 &blaunch_pipe_impl<S>, 1};      // (the PIPE instantiation is compiled for one workgroup per CU: waves_per_eu(1, 1))
+                 &blaunch_pipe_impl<S>, 1,       // (the PIPE instantiation is compiled for one workgroup per CU: waves_per_eu(1, 1))
+                 &blaunch_split_impl<S>};
 }
 
 }  // namespace fe

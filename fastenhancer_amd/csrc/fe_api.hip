@@ -122,6 +122,8 @@ struct fe_handle {
     hipStream_t host_streams[2] = {nullptr, nullptr};     // fe_step_host: copy-in / copy-out streams (lazy)
     hipEvent_t host_events[7] = {};                       // ... and its events
     float* tb_work_dev = nullptr;             // fe_spec_step on the time-batched engine: grow-only work buffer
+    float* bsplit_dev = nullptr;              // BSRNN per-hop step in three launches: band features | compressed spectrum | MLP pre-activations
+    int bsplit_streams = 0;                   // (grow-only, sized by fe_state_init / the first step of a larger batch)
     size_t tb_work_floats = 0;
     unsigned int* tb_prog_dev = nullptr;      // fused stages: the scan workgroups' frame counters [KB][2 * max_wgs]
     std::vector<Section> sections;
@@ -1199,8 +1201,35 @@ fe::BArgs bsrnn_args(fe_handle* h, int B, int T) {
     return a;
 }
 
-int launch_bsrnn(fe_handle* h, const fe::BArgs& a, void* stream) {
+// The per-hop BSRNN step runs as three launches (bsrnn_kernels.hip.h, PART): per stream 31 C floats of band features, 514 of compressed
+// spectrum and 2056 of MLP pre-activations pass through this scratch.  Grow-only; fe_state_init sizes it for its batch, so that a
+// steady-state step allocates nothing (FE_BSRNN_SPLIT=0: the fused kernel, for A/B measurements).
+size_t bsplit_floats_per_stream(const fe_handle* h) { return (size_t)31 * h->cfg.channels + 2 * 257 + 2 * 1028; }
+int ensure_bsplit(fe_handle* h, int B) {
+    if (!h->bimpl || B <= h->bsplit_streams) return FE_OK;
+    static const bool off = [] { const char* e = getenv("FE_BSRNN_SPLIT"); return e && e[0] == '0'; }();
+    if (off) return FE_OK;
+    if (h->bsplit_dev) { FE_HIP_CHECK(hipFree(h->bsplit_dev)); h->bsplit_dev = nullptr; h->bsplit_streams = 0; }
+    FE_HIP_CHECK(hipMalloc(&h->bsplit_dev, (size_t)B * bsplit_floats_per_stream(h) * sizeof(float)));
+    h->bsplit_streams = B;
+    return FE_OK;
+}
+
+int launch_bsrnn(fe_handle* h, const fe::BArgs& a_in, void* stream) {
     hipError_t e = hipSuccess;
+    fe::BArgs a = a_in;
+    if (a.mode == fe::FE_MODE_STREAM && a.T == 1 && a.dbg == nullptr && a.clk == nullptr) {
+        const int rc = ensure_bsplit(h, a.B);
+        if (rc != FE_OK) return rc;
+        if (h->bsplit_dev && a.B <= h->bsplit_streams) {
+            a.mlp_x = h->bsplit_dev;
+            a.mlp_sp = a.mlp_x + (size_t)a.B * 31 * h->cfg.channels;
+            a.mlp_pre = a.mlp_sp + (size_t)a.B * 2 * 257;
+            h->bimpl->launch_split(a, h->max_wgs, (hipStream_t)stream, &e);
+            if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+            return FE_OK;
+        }
+    }
     h->bimpl->launch(a, h->max_wgs, (hipStream_t)stream, &e);
     if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return FE_OK;
@@ -1335,6 +1364,7 @@ void fe_destroy(fe_handle* h) {
     if (h->tb_probe_dev) (void)hipFree(h->tb_probe_dev);
     if (h->tb_prog_dev) (void)hipFree(h->tb_prog_dev);
     if (h->tb_work_dev) (void)hipFree(h->tb_work_dev);
+    if (h->bsplit_dev) (void)hipFree(h->bsplit_dev);
     for (hipStream_t s : h->host_streams) if (s) (void)hipStreamDestroy(s);
     for (hipEvent_t e : h->host_events) if (e) (void)hipEventDestroy(e);
     delete h;
@@ -1400,6 +1430,10 @@ size_t fe_state_floats(const fe_handle* h, int B) {
 int fe_state_init(fe_handle* h, float* state_dev, int B, void* stream) {
     if (!h || !state_dev || B <= 0) return fail(FE_ERR_INVALID_ARG, "bad argument");
     FE_HIP_CHECK(hipMemsetAsync(state_dev, 0, fe_state_floats(h, B) * sizeof(float), (hipStream_t)stream));
+    if (h->bimpl) {                // (the scratch of the three-launch per-hop step: sized here, so that the steps of this batch allocate nothing)
+        const int rc = ensure_bsplit(h, B);
+        if (rc != FE_OK) return rc;
+    }
     return FE_OK;
 }
 
