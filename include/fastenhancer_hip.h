@@ -118,7 +118,10 @@ int fe_load_weights(fe_handle* h, const float* blob_dev, size_t nfloats, void* s
  *   FE_ARCH_BSRNN         2 * num_layers x [B*31, 2C]: h0, c0, h1, c1, ...              (models/bsrnn/model.py:409-416)
  *   FE_ARCH_FSPEN         num_blocks * groups x [1, B*freq/groups, C] inter-GRU states  (models/fspen/model.py:293-297)
  *   FE_ARCH_LISENNET      [B,1,257] phase | [B,4,1,257] [B,8,1,128] [B,12,1,64] encoder frames | n_blocks x ([1,B*32,24] GRU,
- *                         [B,32,2,32] ConvGLU frames) | [B,4,1,256] decoder frame     (models/lisennet/model.py:380-396) */
+ *                         [B,32,2,32] ConvGLU frames) | [B,4,1,256] decoder frame     (models/lisennet/model.py:380-396)
+ * FE_ARCH_BSRNN: fe_state_init also sizes the handle's scratch for the per-hop step of B streams (that step runs as three launches with
+ * 10.6 KB per stream between them); a step of a larger batch than any fe_state_init has seen grows it on its first call (a device
+ * allocation: not inside a stream capture). */
 size_t fe_state_floats(const fe_handle* h, int B);
 int fe_state_init(fe_handle* h, float* state_dev, int B, void* stream);
 
