@@ -1014,6 +1014,15 @@ def test_bsrnn_more_streams_than_cus():
     _full_size_check(m, orc, cfg, sr, 300, 3, [0, 1, 43, 44, 255, 256, 257, 299], "bsrnn_xxt B=300")
 
 
+def test_bsrnn_split_step_with_ragged_stream_tiles():
+    """the per-hop step in three launches (frame kernel head, mask-decoder MLPs batched over the streams, tail): 1030 streams = two
+    persistent workgroups per CU in the head / tail and a last MLP stream tile of 6 rows (16-stream tiles, 64-stream workgroups);
+    7 streams = one partial tile.  Oracle parity on a sample and position independence (_full_size_check)."""
+    m, orc, cfg, sr, seed = _bsrnn("bsrnn_xt")
+    _full_size_check(m, orc, cfg, sr, 1030, 2, [0, 15, 16, 63, 64, 511, 512, 1023, 1024, 1029], "bsrnn_xt B=1030")
+    _full_size_check(m, orc, cfg, sr, 7, 3, [0, 3, 6], "bsrnn_xt B=7")
+
+
 def test_steps_can_be_captured_into_a_hip_graph():
     """no allocation, free or synchronisation inside fe_step: a burst of per-hop launches captured into a HIP graph
     (torch.cuda.CUDAGraph on the capture stream) replays to the same bits as the eager launches, for the LDS-skip (B),
