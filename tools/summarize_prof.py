@@ -25,16 +25,26 @@ def main():
                   f"ms_per_step={d['ms_per_step']:.5f} kernel_ms={d['roofline']['kernel_ms']:.5f} frac={d['roofline']['frac']:.4f}")
         except Exception as e:  # noqa
             pass
-    print("\n## PMC counters, fe_frame_kernel dispatches only: per-dispatch mean (sum over XCDs/SEs as reported)")
+    print("\n## PMC counters of the step's kernels (fe:: namespace): per-dispatch mean (sum over XCDs/SEs as reported); a step that runs as"
+          "\n## several launches (BSRNN: frame kernel PART 1, bsrnn_mlp_kernel, PART 2) also gets the per-step sum")
     for f in sorted(glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
-        acc = defaultdict(list)
+        acc = defaultdict(lambda: defaultdict(list))
         for row in csv.DictReader(open(f)):
-            if "frame_kernel" not in row.get("Kernel_Name", ""):
+            kn = row.get("Kernel_Name", "")
+            if "fe::" not in kn or "ola" in kn:
                 continue
-            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
-        for k, v in sorted(acc.items()):
-            v = v[len(v) // 10:]  # drop warm-up dispatches
-            print(f"{k:36s} n={len(v):4d} mean={sum(v) / max(len(v), 1):.4g}")
+            short = kn.split("(")[0].replace("void ", "")
+            short = short[:40] + ".." + short[-24:] if len(short) > 70 else short
+            acc[row["Counter_Name"]][short].append(float(row["Counter_Value"]))
+        for k, per in sorted(acc.items()):
+            tot = 0.0
+            for kn, v in sorted(per.items()):
+                v = v[len(v) // 10:]  # drop warm-up dispatches
+                m = sum(v) / max(len(v), 1)
+                tot += m
+                if len(per) > 1:
+                    print(f"{k:36s} {kn:70s} n={len(v):4d} mean={m:.4g}")
+            print(f"{k:36s} {'per step' if len(per) > 1 else '':70s} mean={tot:.4g}")
     print("\nnotes: FETCH_SIZE/WRITE_SIZE are in KiB-equivalents as rocprofv3 reports them (x1024 = bytes; on gfx950 a wide"
           " coalesced read stream is under-reported 2x, MI355X_MICROARCH.md §HBM).")
 
