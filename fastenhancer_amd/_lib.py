@@ -16,6 +16,7 @@ FE_ARCH_BSRNN = 1
 FE_ARCH_FSPEN = 2
 FE_ARCH_LISENNET = 3
 FE_OFFLINE_AUTO, FE_OFFLINE_FRAME_WALK, FE_OFFLINE_TIME_BATCHED = 0, 1, 2
+FE_STEP_KERNEL_WAVES4, FE_STEP_KERNEL_WG8, FE_STEP_KERNEL_WG8_PERSIST = 0, 1, 2
 
 
 class fe_config(ctypes.Structure):
@@ -43,6 +44,7 @@ SYMBOLS = {
     "fe_spec_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fe_set_time_pipeline": (c_int, [c_void_p, c_int]),
     "fe_set_offline_engine": (c_int, [c_void_p, c_int]),
+    "fe_set_step_kernel": (c_int, [c_void_p, c_int]),
     "fe_offline_work_floats": (c_size_t, [c_void_p, c_int, c_int]),
     "fe_offline": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fe_stft_step": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

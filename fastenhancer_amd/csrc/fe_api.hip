@@ -115,6 +115,7 @@ struct fe_handle {
     int max_wgs = 256;             // CUs of the device: one resident workgroup per CU (persistent grid above that)
     int pipe_frames = -1;          // fe_set_time_pipeline (-1: chosen from the model size)
     int offline_engine = FE_OFFLINE_AUTO;     // fe_set_offline_engine
+    int step_kernel = [] { const char* e = std::getenv("FE_WG8"); return e ? std::atoi(e) : FE_STEP_KERNEL_WG8; }();      // fe_set_step_kernel
     unsigned int* pipe_flags_dev = nullptr;   // fe_spec_step's frame counters [max_wgs][KB] (fe_offline keeps its own in the work buffer)
     std::vector<hipStream_t> tb_streams;      // time-batched engine: the streams its nodes are spread over (lazy; tb_run)
     std::vector<hipEvent_t> tb_events;        // ... and its event pool
@@ -375,6 +376,42 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
                 p.raw(o.blk_bih[k] + g * bsz, C2, bih + g * C2);
                 p.raw(o.blk_bhh[k] + g * bsz, C2, bhh + g * C2);
             }
+        }
+        if (o.k4_g8x[k] != 0) {
+            // 512-thread per-hop kernel (fe_frame8.hip.h, Shape::G8P): the block weights in "k4" fragment order (PackedOffsets::k4_*).
+            const float* wih = S(key("rnn.weight_ih_l0"));
+            const float* whh = S(key("rnn.weight_hh_l0"));
+            const float* bih = S(key("rnn.bias_ih_l0"));
+            const float* bhh = S(key("rnn.bias_hh_l0"));
+            const int NG = C2 / 16, R = C2 % 16, NT = 3 * NG + 1, KS = C2 / 4, NF = KS / 4, REM = KS % 4 + 1, T4 = NF * 256 + 64 * REM;
+            // tile t, column c -> row of the (rows, C2) weight matrix (-1: padding); bias(t, c)
+            auto pack_k4 = [&](int off, int ntiles, const float* w, const std::function<int(int, int)>& wrow, const std::function<float(int, int)>& bias) {
+                for (int t = 0; t < ntiles; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int ks = 0; ks <= KS; ++ks) {
+                            const int row = wrow(t, lane % 16);
+                            float v = 0.0f;
+                            if (ks < KS) v = row >= 0 ? w[(size_t)row * C2 + 4 * ks + lane / 16] : 0.0f;
+                            else v = row >= 0 ? bias(t, lane % 16) : 0.0f;
+                            const size_t at = ks < 4 * NF ? (size_t)(ks / 4) * 256 + lane * 4 + ks % 4 : (size_t)NF * 256 + lane * REM + (ks - 4 * NF);
+                            p.buf[(size_t)off + (size_t)t * T4 + at] = v;
+                        }
+            };
+            // channel-grouped gate tiles: tile 3 G + gate: column c <-> channel 16 G + c of that gate; the last tile: columns [0, R) r,
+            // [R, 2 R) z, [2 R, 3 R) n of the R = C2 % 16 left-over channels
+            auto grow = [&](int t, int c) -> int {
+                if (t < 3 * NG) return (t % 3) * C2 + 16 * (t / 3) + c;
+                return c < 3 * R ? (c / R) * C2 + 16 * NG + c % R : -1;
+            };
+            auto shared = [&](int t) { return t < 3 * NG && t % 3 < 2; };      // pure r / z tile: x and h halves in one accumulator
+            pack_k4(o.k4_g8x[k], NT, wih, grow, [&](int t, int c) { const int r = grow(t, c); return bih[r] + (shared(t) ? bhh[r] : 0.0f); });
+            pack_k4(o.k4_g8h[k], NT, whh, grow, [&](int t, int c) { const int r = grow(t, c); return shared(t) ? 0.0f : bhh[r]; });
+            auto plain = [&](int ncols) { return [ncols](int t, int c) { return 16 * t + c < ncols ? 16 * t + c : -1; }; };
+            const float* f1b = S(key("rnn_fc.bias"));
+            const float* f2b = S(key("attn_fc.bias"));
+            pack_k4(o.k4_f1[k], fe::ceil_div(C2, 16), S(key("rnn_fc.weight")), plain(C2), [&](int t, int c) { return f1b[16 * t + c]; });
+            pack_k4(o.k4_q[k], fe::ceil_div(3 * C2, 16), S(key("attn.qkv.weight")), plain(3 * C2), [&](int, int) { return 0.0f; });
+            pack_k4(o.k4_f2[k], fe::ceil_div(C2, 16), S(key("attn_fc.weight")), plain(C2), [&](int t, int c) { return f2b[16 * t + c]; });
         }
         if (h->impl->tb && !d.TA) {
             // time-batched engine (tb_kernels.hip.h): per direction the input weights as ONE flat (3 C2)-column matrix (rows r | z | n as
@@ -1270,6 +1307,7 @@ fe::FrameArgs base_args(fe_handle* h, int B, int T) {
     a.compression = h->cfg.input_compression;
     a.rf_eps = h->cfg.rf_eps > 0.0f ? h->cfg.rf_eps : 1.0e-5f;
     a.skip = h->skip_dev;
+    a.step_kernel = h->step_kernel;
     return a;
 }
 
@@ -1499,7 +1537,8 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
     // per-hop launches above #CUs streams: the low-LDS companion (two workgroups per CU; same packed weights - Pack<S> does
     // not depend on LOW), where one is compiled and measured faster
     const fe::Impl* im = h->impl;
-    if (h->impl_many && T == 1 && B > h->max_wgs && (h->impl_many->many_persist || B <= h->max_wgs * h->impl_many->occ) && !dbg && !clk)
+    if (h->impl_many && T == 1 && B > h->max_wgs && (h->impl_many->many_persist || B <= h->max_wgs * h->impl_many->occ) && !dbg && !clk &&
+        !(h->step_kernel == FE_STEP_KERNEL_WG8_PERSIST && h->impl->wg8))
         im = h->impl_many;
     im->launch(a, h->max_wgs, (hipStream_t)stream, &e);
     if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
@@ -1830,6 +1869,12 @@ static bool use_tb_offline(const fe_handle* h, int B) {
     if (h->d.BD) return true;
     if (h->offline_engine == FE_OFFLINE_AUTO) return !(h->d.C2 >= 72 && B >= 8);
     return h->offline_engine != FE_OFFLINE_FRAME_WALK;
+}
+
+int fe_set_step_kernel(fe_handle* h, int kernel) {
+    if (!h || kernel < FE_STEP_KERNEL_WAVES4 || kernel > FE_STEP_KERNEL_WG8_PERSIST) return fail(FE_ERR_INVALID_ARG, "bad argument");
+    h->step_kernel = kernel;
+    return FE_OK;
 }
 
 int fe_set_offline_engine(fe_handle* h, int engine) {

@@ -1,0 +1,749 @@
+// fe_frame8.hip.h — the per-hop streaming step (scripts/export_onnx.py:48-58, one hop per launch) on a 512-THREAD workgroup:
+// eight wavefronts per stream, TWO per SIMD of the CU.
+//
+// fe_frame_kernel (fe_kernels.hip.h) runs a stream on four waves, one per SIMD: a frame is a chain of ~38 barrier-bounded
+// phases, and with a lone wave per SIMD nothing hides a wave's own latencies - the pipeline fill after each barrier, the LDS
+// write -> read turn-around, the dependent transcendental chains of the epilogues (52 % MFMA-busy, 42 % of the wave cycles
+// waiting, profiles/r3k_*).  Here every phase's tiles are split once more so that each SIMD holds two waves (w and w + 4)
+// that issue into each other's stalls:
+//   conv-type GEMMs  [F1 x C1] (M = 4 row tiles, N = NTC channel tiles): wave (ws, wh) = row tile ws, channel tiles
+//                    [0, NTA) for wh = 0 and [NTA, NTC) for wh = 1 - unequal halves (2 : 1 for FastEnhancer_B) on purpose:
+//                    the lighter wave reaches its epilogue while the heavier one still feeds the matrix pipe
+//   token GEMMs      [F2P x C2] (M = 2 row tiles): wave (ws, wh) = row tile wh x the column tiles ws, ws + 4 - the
+//                    register-resident weight fragments are fetched by both waves of a pair (L1 / L2 hits)
+//   attention        wave (ws, wh) = head ws, query tile wh
+//   element-wise     512 threads
+//   DFT / iDFT       the four-wave transform of Dft<S> on waves 0-3 (one per SIMD), the other four run the
+//                    element-wise work next to it (cache shift, constant prefetch)
+// Same LDS plan (Lds<S>), same packed weights (Pack<S>), same state and the same arithmetic per output element as
+// fe_frame_kernel: the two kernels agree to fp32 rounding (the order of the additions inside a GEMM is the same; tests
+// compare both with the oracle and with each other).
+// Reference: models/fastenhancer/default/model.py:266-290 (RNNFormer block), 620-675 (model_forward), 677-710 (ONNXModel.forward),
+// functional/audio_modules.py:243-303 (ONNXSTFT).
+#pragma once
+#include "fe_kernels.hip.h"
+
+namespace fe {
+
+constexpr int kThreads8 = 512;
+constexpr int kWaves8 = 8;
+
+template <class S>
+struct Wg8 {
+    using L = Lds<S>;
+    static constexpr bool MDFT = (S::NFFT == 512) || (S::C1 < 128);
+    // built for the B-type plan: staged conv weights, LDS-resident skips, register-resident block weights with flat GRU gates
+    static constexpr bool OK = L::STAGED && L::SKIPS_LDS && S::GFLAT && S::KT == 1 && S::LOW == 0 && !S::FRNN && !S::TATT && !S::LN && !S::BIDIR &&
+                               S::G8P && S::MTC == 4 && S::MT2 == 2 && MDFT && !L::PERHEAD && S::NFFT == kThreads8;
+    static constexpr int NTA = (S::NTC + 1) / 2, NTB = S::NTC - NTA;        // conv channel tiles of the wh = 0 / wh = 1 wave
+    static constexpr int N2A = (S::NT2 + 1) / 2, N2B = S::NT2 - N2A;        // rf_post's token-channel tiles likewise
+    static constexpr int NPW = ceil_div(ceil_div(Pack<S>::umax(), 256), kWaves8);
+    static constexpr int HPT = ceil_div(S::F2 * S::C2, kThreads8);          // hidden-state elements per thread
+};
+
+// Register-resident block weights of a wave in "k4" fragment order (PackedOffsets::k4_*; packed by fe_api.hip::pack_weights):
+// tiles t0, t0 + tstride, ... (NTW of them; tiles >= tend load zeros through an out-of-range buffer offset: no traffic), each
+// KG buffer_load_dwordx4 of four k-steps; slot KS of a lane holds the bias of its column.  Same side-job interface as TokW.
+template <int NTW, int KS, int TS, class WS>      // TS: tile stride (4: column tiles ws, ws + 4, ...; 1: consecutive gate tiles)
+struct K4W {
+    static constexpr int NF = KS / 4, REM = KS % 4 + 1, TILE = NF * 256 + 64 * REM, KG = NF + 1;
+    static_assert(REM == 2, "k4 tail: two floats per lane (KS % 4 == 1)");      // (1 and 4 would be a dword / dwordx4 tail; 3 has no load of its size)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x4 w[NTW][NF];
+    f32x2 tail[NTW];
+    __amdgpu_buffer_rsrc_t rsrc;
+    int soff0;            // byte offset of tile t0 (wave-uniform)
+    int voff[NTW];        // lane * 16 (the tail: half of it), or an out-of-range offset for a tile this wave does not have
+    __device__ __forceinline__ void bind(const WS& s, int off_floats, int t0, int tend, bool live = true) {
+        rsrc = s.rsrc;
+        soff0 = (off_floats + t0 * TILE) * 4;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) voff[j] = s.lane4 * 4 + ((live && t0 + j * TS < tend) ? 0 : 0x40000000);
+    }
+    static constexpr int TOT = NTW * KG;
+    __device__ __forceinline__ void fetch_elem(int e) {
+        const int j = e / KG, kg = e - j * KG;
+        if (kg < NF) w[j][kg] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], soff0 + (j * TS * TILE + kg * 256) * 4, 0));
+        else tail[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff[j] >> 1, soff0 + (j * TS * TILE + NF * 256) * 4, 0));
+    }
+    static constexpr int part_count(int part, int parts) {
+        const int per = (TOT + parts - 1) / parts;
+        int lo = part * per, hi = (part + 1) * per;
+        lo = lo < TOT ? lo : TOT;
+        hi = hi < TOT ? hi : TOT;
+        return hi - lo;
+    }
+    __device__ __forceinline__ void fetch_part(int part, int parts) {
+        const int per = (TOT + parts - 1) / parts;
+#pragma unroll
+        for (int q = 0; q < TOT; ++q)
+            if (q >= part * per && q < (part + 1) * per) fetch_elem(q);
+    }
+    __device__ __forceinline__ float get(int j, int ks) const { return ks < 4 * NF ? w[j][ks / 4][ks % 4] : tail[j][ks - 4 * NF]; }
+    __device__ __forceinline__ float bias(int j) const { return tail[j][REM - 1]; }
+    // an (empty) read of every register of the set: a wave that has no use for some tiles must still keep their registers out of the
+    // allocator's hands until the loads have landed
+    __device__ __forceinline__ void touch() const {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+#pragma unroll
+            for (int g = 0; g < NF; ++g) asm volatile("" ::"v"(w[j][g]));
+            asm volatile("" ::"v"(tail[j]));
+        }
+    }
+};
+
+// One conv-layout GEMM job of a wave: row tile mt x the NT channel tiles J0 .. J0 + NT - 1, K = 4 KS.
+//   af(ks) -> A fragment element, bf(j, ks) -> B fragment element of ABSOLUTE tile j, bias(j) -> accumulator start.
+// Epilogue: optional SiLU (scaled trunk), store to out[(row0 + m)][col] for col < NCOLS.
+template <class S, int NT, int J0, int KS, int NCOLS, int LDO, bool ACT, class AF, class BF, class BI, class SIDE>
+__device__ __forceinline__ void conv8(AF&& af, BF&& bf, BI&& bias, const SIDE& side, float* out, int row0, int mt, int lane) {
+    if constexpr (NT > 0) {
+        const int li = lane & 15, lg = lane >> 4;
+        f32x4 acc[1][NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[0][j] = bias(J0 + j);
+        mma_panel<1, NT, KS, Lds<S>::PDK>(acc, [&](int, int ks) { return af(ks); }, [&](int j, int ks) { return bf(J0 + j, ks); }, side);
+        side.commit();
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = 16 * (J0 + j) + li;
+            if (col < NCOLS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * mt + 4 * lg + r;
+                    float v = acc[0][j][r];
+                    if (ACT) v = silu_scaled_f(v);
+                    out[(row0 + m) * LDO + col] = v;
+                }
+            }
+        }
+    } else {
+        // a wave without a tile still moves its share of the next weight unit
+        constexpr int NSG = (KS + 3) / 4;
+#pragma unroll
+        for (int g = 0; g < NSG; ++g) side(g, NSG);
+        side.commit();
+    }
+}
+// the pair split: wh = 0 takes the tiles [0, NA), wh = 1 the tiles [NA, NA + NB)
+template <class S, int NA, int NB, int KS, int NCOLS, int LDO, bool ACT, class AF, class BF, class BI, class SIDE>
+__device__ __forceinline__ void conv8_pair(int wh, AF&& af, BF&& bf, BI&& bias, const SIDE& side, float* out, int row0, int mt, int lane) {
+    if (wh == 0) conv8<S, NA, 0, KS, NCOLS, LDO, ACT>(af, bf, bias, side, out, row0, mt, lane);
+    else conv8<S, NB, NA, KS, NCOLS, LDO, ACT>(af, bf, bias, side, out, row0, mt, lane);
+}
+
+// DBG: per-stage dumps (fe_debug_step) and the phase cycle probes (fe_profile_step).  PERSIST: more streams than CUs,
+// each workgroup walks the streams blockIdx.x, blockIdx.x + gridDim.x, ...
+template <class S, bool DBG, bool PERSIST>
+__global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(2, 2))) fe_frame8_kernel(FrameArgs a_in) {
+    static_assert(Wg8<S>::OK, "fe_frame8_kernel: shape outside the 512-thread kernel's plan");
+    FrameArgs a = a_in;
+#ifdef FE_PROBE_HOT
+    if constexpr (!DBG) a.dbg = nullptr;
+#else
+    if constexpr (!DBG) { a.dbg = nullptr; a.clk = nullptr; }
+#endif
+    FE_CLK(62);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using L = Lds<S>;
+    using W8 = Wg8<S>;
+    constexpr int N = S::NFFT, H = S::HOP, OVL = S::OVL, F0 = S::F0, F1 = S::F1;
+    constexpr int C1 = S::C1, C2 = S::C2, F2 = S::F2, HD = S::HD;
+    constexpr int LDC = S::LDC, LDX = S::LDX, LDG = L::LDGX;
+    constexpr int NTH = kThreads8;
+    constexpr int PDK = L::PDK;
+
+    const int tid0 = threadIdx.x;
+    const int tid = tid0;
+    const int lane = tid & 63;
+    const int wave0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave0;
+#ifdef FE_WG8_PRIO
+    if (wave0 >= 4) __builtin_amdgcn_s_setprio(FE_WG8_PRIO);      // experiment: the second wave of a SIMD runs ahead of the first
+#endif
+    const float* __restrict__ wp = a.wp;
+    WSrc<true> wb;
+    constexpr PackedOffsets o = Pack<S>::v;
+    wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, o.total * 4, 0x00020000);
+    wb.lane4 = lane * 4;
+    wb.li4 = (lane & 15) * 4;
+    wb.lds = nullptr;
+    wb.base = 0;
+
+    // ---- one-time: the zero halos (compressed spectrum, skip buffers), twiddles, weight unit 0.
+    // !PERSIST (one stream per workgroup): everything the front of the frame waits for is requested HERE, in one memory round trip
+    // with the prologue's own loads - the frame and its window, the DFT constants, and weight unit 1 as well (both staging
+    // buffers are free at this point), so that enc_pre, a 12-MFMA phase, does not wait for 28 KiB of the next layer's weights.
+    float* sc = smem + L::SC;
+    float* Ebuf = smem + L::E;
+    float* W0 = smem + L::W0;
+    float* W1 = smem + L::W1;
+    float2* tw = reinterpret_cast<float2*>(smem + L::TW);
+    constexpr int NPW = W8::NPW;
+    DmaJobT<NPW> job;
+    job.l = smem + L::WB0;
+    job.rsrc = wb.rsrc;
+    job.soff = (o.u_off[0] + wave * 256) * 4;
+    job.wave = wave;
+    job.lane = lane;
+    typename Dft<S>::FwdConst dc;
+    float fv = 0.0f, fw = 0.0f;
+    {
+        const StageSide<NPW, o.u_size[0] / 256, kWaves8> st0{&job};
+        st0(0, 1);
+        float2 twv = make_float2(0.0f, 0.0f);
+        if (tid < N / 2) twv = reinterpret_cast<const float2*>(wp + o.twiddle)[tid];
+        DmaJobT<NPW> job1 = job;
+        job1.l = smem + L::WB1;
+        job1.soff = (o.u_off[1] + wave * 256) * 4;
+        const StageSide<NPW, PERSIST ? 0 : o.u_size[1] / 256, kWaves8> st1{&job1};
+        if constexpr (!PERSIST) {
+            const int b0 = (int)blockIdx.x;
+            fv = (tid < OVL) ? a.cache_stft[(size_t)b0 * OVL + tid] : a.wav_in[(size_t)b0 * a.in_stride + tid - OVL];
+            fw = wp[o.window + tid];
+            if (wave < 4) Dft<S>::load(dc, wb, o, wave);
+            st1(0, 1);
+        }
+        for (int i = tid; i < 2 * S::LDS_S; i += NTH) smem[L::SC + i] = 0.0f;
+        for (int i = tid; i < (S::NL + 1) * 2 * LDC; i += NTH) {
+            const int e = i / (2 * LDC), q = i - e * (2 * LDC);
+            smem[L::E + e * S::ACT + (q >= LDC ? (F1 + 1) * LDC + (q - LDC) : q)] = 0.0f;
+        }
+        if (tid < N / 2) tw[tid] = twv;
+        st0.commit();
+        if constexpr (!PERSIST) {
+            st1.commit();
+            smem[L::FFT_A + tid] = fv * fw;
+        }
+    }
+    __syncthreads();
+
+    int b = (int)blockIdx.x;
+    int fc = 0;
+#pragma unroll 1
+    do {
+        // PERSIST: a loop-variant zero keeps the wave-uniform / per-lane offsets of a frame from being hoisted out of the stream loop
+        // (hoisted, they stay live through the whole frame and spill - see fe_frame_kernel)
+        int lz = 0, lzv = 0;
+        if constexpr (PERSIST) { asm volatile("" : "+s"(lz)); asm volatile("" : "+v"(lzv)); }
+        const int wave = wave0 + lz;
+        const int tid = tid0 + lzv;
+        const int lane = tid & 63;
+        const int ws = wave & 3, wh = wave >> 2;          // SIMD slot, half
+        const int li = lane & 15, lg = lane >> 4;
+        float* cst = a.cache_stft + (size_t)b * OVL;
+        float* cis = a.cache_istft + (size_t)b * OVL;
+        const int fpar = (S::NU & 1) ? (fc & 1) : 0;
+#define FE8_BEGIN_UNIT(U)                                                                          \
+        constexpr int fe_un_ = ((U) + 1 == S::NU) ? 0 : (U) + 1;                                   \
+        {                                                                                          \
+            const int slot_ = ((U) & 1) ^ fpar;                                                    \
+            job.l = smem + (slot_ ? L::WB0 : L::WB1);                                              \
+            job.soff = (o.u_off[fe_un_] + wave * 256) * 4;                                         \
+            wb.lds = smem + (slot_ ? L::WB1 : L::WB0);                                             \
+            wb.base = o.u_off[(U)];                                                                \
+        }                                                                                          \
+        const StageSide<NPW, (!PERSIST && ((U) + 1 == S::NU || (U) == 0)) ? 0 : o.u_size[fe_un_] / 256, kWaves8> stage{&job}
+        FE_CLK(0);
+        // =========================== STFT (a1-a3) ===========================
+        // LDS quarters of the FFT arena: q0 windowed frame / iSTFT partial sums, q1 iSTFT partial sums, q3 spectrum {Re[N/2], Im[N/2]}
+        float* q0 = smem + L::FFT_A;
+        float* q1 = q0 + N;
+        float* q3 = smem + L::FFT_B + N;
+        {
+            if constexpr (PERSIST) {
+                if (wave < 4) Dft<S>::load(dc, wb, o, wave);             // in flight while the frame is fetched
+                const float* xin = a.wav_in + (size_t)b * a.in_stride;
+                fv = (tid < OVL) ? cst[tid] : xin[tid - OVL];            // one sample per thread
+                fw = wp[o.window + tid];
+                q0[tid] = fv * fw;
+                __syncthreads();
+            }
+            // cache' = frame[H:], straight from the registers (every load of the old cache has landed: its value went to LDS above)
+            if (tid >= H) cst[tid - H] = fv;
+            FE_CLK(1);
+            float* nyq = a.dbg ? a.dbg + (size_t)b * a.dbg_stride + DebugLayout<S>::offset(0) + 2 * F0 : nullptr;
+            if (wave < 4) Dft<S>::template forward<false>(q0, q3, tw, dc, wave, lane, nyq);
+            __syncthreads();
+            FE_CLK(2);
+            const float* Xr = q3;
+            const float* Xi = q3 + N / 2;
+            if (a.dbg) {
+                float* dst = a.dbg + (size_t)b * a.dbg_stride + DebugLayout<S>::offset(0);
+                for (int f = tid; f < F0; f += NTH) { dst[2 * f] = Xr[f]; dst[2 * f + 1] = Xi[f]; }
+            }
+            // =========================== compress (a4) ===========================
+            for (int f = tid; f < F0; f += NTH) {
+                const float re = Xr[f], im = Xi[f];
+                const float mag = fmaxf(sqrtf(re * re + im * im), 1.0e-5f);
+                const float g = pow_f(mag, a.compression - 1.0f);
+                sc[2 + f] = re * g;
+                sc[S::LDS_S + 2 + f] = im * g;
+            }
+        }
+        __syncthreads();
+        if (a.dbg) {
+            float* dst = a.dbg + (size_t)b * a.dbg_stride + DebugLayout<S>::offset(1);
+            for (int f = tid; f < F0; f += NTH) { dst[2 * f] = sc[2 + f]; dst[2 * f + 1] = sc[S::LDS_S + 2 + f]; }
+        }
+
+        FE_CLK(3);
+        // =========================== enc_pre (a5): strided conv as a K = 16 GEMM ===========================
+        {
+            FE8_BEGIN_UNIT(0);
+            conv8_pair<S, W8::NTA, W8::NTB, 4, C1, LDC, true>(
+                wh,
+                [&](int ks) {
+                    const int kk = 4 * ks + lg;
+                    const int c = kk & 1, s = (kk >> 1) & 3, tp = kk >> 3;
+                    return sc[c * S::LDS_S + 4 * (16 * ws + li + tp) + s];
+                },
+                [&](int j, int ks) { return wb.at(o.enc_pre_w + (j * 4 + ks) * 64); },
+                [&](int j) { return wb.at16x4(o.enc_pre_b + j * 64); }, stage, Ebuf, 1, ws, lane);
+        }
+        __syncthreads();
+        dbg_dump<S, NTH>(a, b, 2, Ebuf + LDC, LDC);
+
+        FE_CLK(4);
+        // =========================== encoder (a6): k = 3 convs ===========================
+        static_for<S::NL>([&](auto l_) {
+            constexpr int l = decltype(l_)::value;
+            const float* in = Ebuf + l * S::ACT;
+            float* out = Ebuf + (l + 1) * S::ACT;
+            if (l == 0) FE_CLK(40);
+            {
+                FE8_BEGIN_UNIT(S::U_ENC + l);
+                const float* const t0 = in + (16 * ws + li) * LDC + lg;
+                conv8_pair<S, W8::NTA, W8::NTB, 3 * S::KS_C, C1, LDC, true>(
+                    wh, [&](int ks) { return t0[(ks / S::KS_C) * LDC + 4 * (ks % S::KS_C)]; },
+                    [&](int j, int ks) { return wb.at(o.enc_w[l] + (j * (3 * S::KS_C) + ks) * 64); },
+                    [&](int j) { return wb.at16x4(o.enc_b[l] + j * 64); }, stage, out, 1, ws, lane);
+            }
+            if (l == 0) FE_CLK(42);
+            __syncthreads();
+            if (l == 0) FE_CLK(43);
+            dbg_dump<S, NTH>(a, b, 3 + l, out + LDC, LDC);
+        });
+
+        float* Xb = smem + L::X;
+        float* Hl = smem + L::HL;
+        float* Hs = smem + L::HS;
+        float* Gi = smem + L::GI;
+        float* Y1 = smem + L::Y1;
+        float* Y2 = smem + L::Y2;
+
+        FE_CLK(5);
+        // =========================== rf_pre (a7) ===========================
+        constexpr int NTPW2 = S::NTPW2, NTPW3 = S::NTPW3;
+        constexpr int HPT = W8::HPT;
+        static_assert(NTPW2 == 1, "token GEMMs: one channel tile per SIMD slot");
+        f32x4 xr[NTPW2];                               // residual stream x: row tile wh, this wave's channel tiles
+        using WS = WSrc<true>;
+        // GRU: (channel group, row tile) jobs - waves 0-3 a 16-channel group x a row tile (three gate tiles: 54 MFMAs), waves 4 and 5
+        // (SIMDs 0 and 1) the mixed tile of the left-over channels x a row tile (18 MFMAs), waves 6 and 7 none: 72 / 72 / 54 / 54
+        // MFMAs per SIMD, and the three gates of a (row, channel) meet in one lane
+        K4W<3, S::KS_2, 1, WS> Gx, Gh;
+        const int g_rt = wave & 1;                                         // row tile of this wave's GRU job
+        const int g_t0 = wave < 4 ? 3 * (wave >> 1) : 3 * S::G8_NG;        // its first gate tile
+        const int g_nt = wave < 4 ? 3 : (wave < 6 ? 1 : 0);
+        constexpr int k4_stride = S::KB > 1 ? o.k4_g8x[1] - o.k4_g8x[0] : 0;
+        K4W<NTPW2, S::KS_2, 4, WS> Wf1, Wf2;              // rnn_fc, attn_fc: channel tile ws
+        K4W<NTPW3, S::KS_2, 4, WS> Wq;                   // qkv: column tiles ws, ws + 4
+        float pe_r[NTPW2][4];
+        // unpredicated epilogue stores into the [F2P][C2 + 2] token buffers (pad rows are real rows, lanes past C2 aim at the pad column)
+        auto tok_dst = [&](float* base, int j) {
+            const int col = 16 * (ws + 4 * j) + li;
+            return base + (16 * wh + 4 * lg) * LDX + (col < C2 ? col : C2);
+        };
+        int hs_off[HPT];
+#pragma unroll
+        for (int q = 0; q < HPT; ++q) {
+            const int i = tid + q * NTH, f = i / C2;
+            hs_off[q] = i < F2 * C2 ? f * LDX + (i - f * C2) : C2;
+        }
+        {
+            // Y1[f2][c1] = sum_f1 Wf[f2][f1] E[f1][c1]      (A = packed filterbank rows of tile wh, B = LDS, channel tile ws)
+            constexpr int KS = F1 / 4;
+            const float* Ein = Ebuf + S::NL * S::ACT + LDC;   // row 0 = bin 0
+            FE8_BEGIN_UNIT(S::U_RFPRE);
+            Gx.bind(wb, o.k4_g8x[0], g_t0, g_t0 + g_nt);                // block 0's GRU input weights ride in this GEMM
+            f32x4 acc[1][1];
+            acc_init_zero<1, 1>(acc);
+            const int nt = ws < S::NTC ? ws : S::NTC - 1;
+            mma_panel<1, 1, KS, PDK>(
+                acc, [&](int, int ks) { return wb.at(o.rfpre_lin + (wh * KS + ks) * 64); },
+                [&](int, int ks) { return Ein[(4 * ks + lg) * LDC + 16 * nt + li]; }, side2(stage, FetchSide<decltype(Gx)>{&Gx}));
+            stage.commit();
+            const int col = 16 * ws + li;
+            if (ws < S::NTC && col < C1 && 16 * wh + 4 * lg < F2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Y1[(16 * wh + 4 * lg + r) * LDC + col] = acc[0][0][r];
+            }
+        }
+        __syncthreads();
+        {
+            // X[f2][c2] = Y1[f2][:] . Wc[c2][:] + b
+            FE8_BEGIN_UNIT(S::U_RFPRE + 1);
+            Gh.bind(wb, o.k4_g8h[0], g_t0, g_t0 + g_nt);                // ... and the hidden weights in this one
+            float hpre[HPT];
+            const float* hg0 = a.h + (size_t)b * (F2 * C2);
+#pragma unroll
+            for (int q = 0; q < HPT; ++q) { const int i = tid + q * NTH; hpre[q] = hg0[i < F2 * C2 ? i : F2 * C2 - 1]; }
+            f32x4 acc[1][1];
+            const int nt = ws < S::NT2 ? ws : S::NT2 - 1;
+            acc[0][0] = wb.at16x4(o.rfpre_b + nt * 64);
+            const float* ya = Y1 + (16 * wh + li) * LDC + lg;
+            mma_panel<1, 1, S::KS_C, PDK>(
+                acc, [&](int, int ks) { return ya[4 * ks]; },
+                [&](int, int ks) { return wb.at(o.rfpre_w + (nt * S::KS_C + ks) * 64); }, side2(stage, FetchSide<decltype(Gh)>{&Gh}));
+            stage.commit();
+            xr[0] = acc[0][0];
+            float* xd = tok_dst(Xb, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xd[r * LDX] = acc[0][0][r];
+#pragma unroll
+            for (int q = 0; q < HPT; ++q) Hs[hs_off[q]] = hpre[q];
+        }
+        __syncthreads();
+        dbg_dump<S, NTH>(a, b, 3 + S::NL, Xb, LDX);
+
+        FE_CLK(6);
+        // =========================== RNNFormer blocks (a9-a11) ===========================
+#pragma unroll
+        for (int k = 0; k < S::KB; ++k) {
+            float* hg = a.h + ((size_t)k * a.B + b) * (F2 * C2);
+            const int kb = k * o.blk_stride;
+            if (k == 0) FE_CLK(20);
+            {
+                // GRU (nn.GRU gate order r, z, n; model.py:187, 271) over (channel group, row tile) jobs, the gate math in the GEMM
+                // epilogue - r, z, n of a (row, channel) sit in one lane: no exchange through LDS, one barrier for the phase
+                // weight fetch schedule (side jobs of the GEMMs): rnn_fc's and qkv's here, attn_fc's in rnn_fc, the next block's GRU input
+                // weights in qkv and its hidden weights in attn_fc.  (Measured and dropped: every set two phases ahead - the GRU phase
+                // gains what rf_pre and rnn_fc lose: a wave-level buffer load costs the CU's vector-memory path ~16 cycles whatever
+                // its width, and 8 waves x 9 loads do not fit under a 9-MFMA GEMM wherever they are put.)
+                Wf1.bind(wb, o.k4_f1[0] + k * k4_stride, ws, S::NT2);
+                Wq.bind(wb, o.k4_q[0] + k * k4_stride, ws, S::NT3);
+                if (k == 0) {
+#pragma unroll
+                    for (int j = 0; j < NTPW2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * wh + 4 * lg + r, col = 16 * (ws + 4 * j) + li;
+                            pe_r[j][r] = wb.gather_g(o.blk_pe + (row < F2 ? row : F2 - 1) * C2 + (col < C2 ? col : C2 - 1));
+                        }
+                }
+                constexpr int K2 = S::KS_2;
+                using SideG = FetchSide2<decltype(Wf1), decltype(Wq)>;
+                const SideG sideg{&Wf1, &Wq};
+                const float* xa = Xb + (16 * g_rt + li) * LDX + lg;
+                const float* ha = Hs + (16 * g_rt + li) * LDX + lg;
+                __builtin_amdgcn_sched_barrier(0);
+                if (k == 0) FE_CLK(45);
+                if (wave < 4) {
+                    // a 16-channel group: tiles r, z (x and h halves in one accumulator), n (separate halves)
+                    const int ch = 16 * (wave >> 1) + li;
+                    float hprev[4];                      // previous state of this lane's outputs: in flight under the GEMM
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hprev[r] = Hs[(16 * g_rt + 4 * lg + r) * LDX + ch];
+                    f32x4 ar = f32x4{Gx.bias(0), Gx.bias(0), Gx.bias(0), Gx.bias(0)}, az = f32x4{Gx.bias(1), Gx.bias(1), Gx.bias(1), Gx.bias(1)};
+                    f32x4 anx = f32x4{Gx.bias(2), Gx.bias(2), Gx.bias(2), Gx.bias(2)}, anh = f32x4{Gh.bias(2), Gh.bias(2), Gh.bias(2), Gh.bias(2)};
+                    mma_panel_sel<1, 3, 2 * K2, PDK>(
+                        [&](int, int j, int ks) -> f32x4& { return j == 0 ? ar : (j == 1 ? az : (ks < K2 ? anx : anh)); },
+                        [&](int, int ks) { return ks < K2 ? xa[4 * ks] : ha[4 * (ks - K2)]; },
+                        [&](int j, int ks) { return ks < K2 ? Gx.get(j, ks) : Gh.get(j, ks - K2); }, sideg);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k == 0) FE_CLK(46);
+                    float hn[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float rr = sigmoid_f(ar[r]);
+                        const float zz = sigmoid_f(az[r]);
+                        const float nn = tanh_f(anx[r] + rr * anh[r]);
+                        hn[r] = (1.0f - zz) * nn + zz * hprev[r];
+                    }
+                    if (16 * g_rt + 4 * lg < F2) {       // (F2 % 4 == 0: the four rows of a lane are valid together)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * g_rt + 4 * lg + r;
+                            Hl[row * LDX + ch] = hn[r];
+                            hg[row * C2 + ch] = hn[r];
+                        }
+                    }
+                } else if (wave < 6) {
+                    // the mixed tile: lanes li < R hold r, R .. 2 R - 1 z, 2 R .. 3 R - 1 n of channel 16 NG + li % R; the z and n values
+                    // move down to the r lanes (DPP row shifts), which finish the R channels
+                    constexpr int R = S::G8_R;
+                    const int ch = 16 * S::G8_NG + (li < R ? li : 0);
+                    float hprev[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hprev[r] = Hs[(16 * g_rt + 4 * lg + r) * LDX + ch];
+                    // (18 dependent MFMAs next to the 54 independent ones of this SIMD's big job: two chains per half, and a raised
+                    //  priority - arbitrated oldest-first, this wave got a matrix-pipe slot only when the other one stalled and the
+                    //  whole workgroup waited for it: 3.5 k cycles for 18 MFMAs)
+                    f32x4 ax = f32x4{Gx.bias(0), Gx.bias(0), Gx.bias(0), Gx.bias(0)}, ah = f32x4{Gh.bias(0), Gh.bias(0), Gh.bias(0), Gh.bias(0)};
+                    f32x4 ax1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, ah1 = ax1;
+                    __builtin_amdgcn_s_setprio(3);
+                    mma_panel_sel<1, 1, 2 * K2, PDK>(
+                        [&](int, int, int ks) -> f32x4& { return ks < K2 ? ((ks & 1) ? ax1 : ax) : ((ks & 1) ? ah1 : ah); },
+                        [&](int, int ks) { return ks < K2 ? xa[4 * ks] : ha[4 * (ks - K2)]; },
+                        [&](int, int ks) { return ks < K2 ? Gx.get(0, ks) : Gh.get(0, ks - K2); }, sideg);
+                    __builtin_amdgcn_s_setprio(0);
+                    ax += ax1;
+                    ah += ah1;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k == 0) FE_CLK(46);
+                    auto shl = [](float v, auto n_) {      // lane i <- lane i + n of its 16-lane row
+                        constexpr int n = decltype(n_)::value;
+                        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + n, 0xf, 0xf, true));
+                    };
+                    float hn[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sx = ax[r], sh = ah[r], sm = sx + sh;
+                        const float rr = sigmoid_f(sm);
+                        const float zz = sigmoid_f(shl(sm, std::integral_constant<int, R>{}));
+                        const float nn = tanh_f(shl(sx, std::integral_constant<int, 2 * R>{}) + rr * shl(sh, std::integral_constant<int, 2 * R>{}));
+                        hn[r] = (1.0f - zz) * nn + zz * hprev[r];
+                    }
+                    if (li < R && 16 * g_rt + 4 * lg < F2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * g_rt + 4 * lg + r;
+                            Hl[row * LDX + ch] = hn[r];
+                            hg[row * C2 + ch] = hn[r];
+                        }
+                    }
+                } else {
+                    constexpr int NSG = (2 * K2 + 3) / 4;      // no GRU job: this wave's side loads only
+#pragma unroll
+                    for (int g = 0; g < NSG; ++g) sideg(g, NSG);
+                }
+            }
+            if (k == 0) FE_CLK(47);
+            __syncthreads();
+            if (k == 0) FE_CLK(21);
+            if (k == 0) FE_CLK(22);
+            {
+                // x += rnn_fc(h') (+ pe in block 0)
+                Wf2.bind(wb, o.k4_f2[0] + k * k4_stride, ws, S::NT2);
+                f32x4 acc[1][NTPW2];
+                const float bj = Wf1.bias(0);
+                acc[0][0] = f32x4{bj, bj, bj, bj};
+                const float* hla = Hl + (16 * wh + li) * LDX + lg;
+                mma_panel<1, NTPW2, S::KS_2, PDK>(acc, [&](int, int ks) { return hla[4 * ks]; }, [&](int j, int ks) { return Wf1.get(j, ks); },
+                                                  FetchSide<decltype(Wf2)>{&Wf2});
+                float* xd = tok_dst(Xb, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[0][0][r] + xr[0][r];
+                    if (k == 0) v += pe_r[0][r];
+                    xr[0][r] = v;
+                    xd[r * LDX] = v;
+                }
+            }
+            __syncthreads();
+            dbg_dump<S, NTH>(a, b, 4 + S::NL + 2 * k, Xb, LDX);
+            if (k == 0) FE_CLK(23);
+            {
+                // qkv = x W_qkv^T -> Gi (columns per head interleaved [h][q|k|v][hd]); the next block's GRU input weights ride along
+                Gx.bind(wb, o.k4_g8x[0] + (k + 1) * k4_stride, g_t0, g_t0 + g_nt, k + 1 < S::KB);
+                f32x4 acc[1][NTPW3];
+#pragma unroll
+                for (int j = 0; j < NTPW3; ++j) { const float bj = Wq.bias(j); acc[0][j] = f32x4{bj, bj, bj, bj}; }      // (zero; read so that no loaded register is dead)
+                __builtin_amdgcn_sched_barrier(0);
+                if (k == 0) FE_CLK(50);
+                const float* xa = Xb + (16 * wh + li) * LDX + lg;
+                mma_panel<1, NTPW3, S::KS_2, PDK>(acc, [&](int, int ks) { return xa[4 * ks]; }, [&](int j, int ks) { return Wq.get(j, ks); },
+                                                  FetchSide<decltype(Gx)>{&Gx});
+                __builtin_amdgcn_sched_barrier(0);
+                if (k == 0) FE_CLK(51);
+                float* gdst = Gi + (16 * wh + 4 * lg) * LDG + 16 * ws + li;
+#pragma unroll
+                for (int j = 0; j < NTPW3; ++j)
+                    if (ws + 4 * j < S::NT3) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) gdst[r * LDG + 64 * j] = acc[0][j][r];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                if (k == 0) FE_CLK(52);
+            }
+            __syncthreads();
+            if (k == 0) FE_CLK(24);
+            // attention: wave (ws, wh) = head ws, query tile wh
+            attention_head<S, 1, LDG>(Gi, Hl, ws * 3 * HD, ws, wh, 1, lane);
+            __syncthreads();
+            if (k == 0) FE_CLK(25);
+            {
+                // x += attn_fc(o); the next block's GRU hidden weights ride along, its hidden state is fetched now and parked after the GEMM
+                float hpre[HPT];
+                Gh.bind(wb, o.k4_g8h[0] + (k + 1) * k4_stride, g_t0, g_t0 + g_nt, k + 1 < S::KB);
+                if (k + 1 < S::KB) {
+                    const float* hgn = hg + (size_t)a.B * (F2 * C2);
+#pragma unroll
+                    for (int q = 0; q < HPT; ++q) { const int i = tid + q * NTH; hpre[q] = hgn[i < F2 * C2 ? i : F2 * C2 - 1]; }
+                }
+                f32x4 acc[1][NTPW2];
+                const float bj = Wf2.bias(0);
+                acc[0][0] = f32x4{bj, bj, bj, bj};
+                const float* hla = Hl + (16 * wh + li) * LDX + lg;
+                mma_panel<1, NTPW2, S::KS_2, PDK>(acc, [&](int, int ks) { return hla[4 * ks]; }, [&](int j, int ks) { return Wf2.get(j, ks); },
+                                                  FetchSide<decltype(Gh)>{&Gh});
+                if (k + 1 < S::KB) {
+#pragma unroll
+                    for (int q = 0; q < HPT; ++q) Hs[hs_off[q]] = hpre[q];
+                }
+                float* xd = tok_dst(Xb, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[0][0][r] + xr[0][r];
+                    xr[0][r] = v;
+                    xd[r * LDX] = v;
+                }
+            }
+            __syncthreads();
+            if (k == 0) FE_CLK(26);
+            dbg_dump<S, NTH>(a, b, 5 + S::NL + 2 * k, Xb, LDX);
+        }
+
+        FE_CLK(7);
+        // =========================== rf_post (a13) ===========================
+        {
+            // Y2[f1][c2] = sum_f2 Wp[f1][f2] X[f2][c2]      (A = packed filterbank rows of tile ws, B = LDS tokens)
+            constexpr int KS = F2 / 4;
+            FE8_BEGIN_UNIT(S::U_RFPOST);
+            conv8_pair<S, W8::N2A, W8::N2B, KS, C2, LDX, false>(
+                wh, [&](int ks) { return wb.at(o.rfpost_lin + (ws * KS + ks) * 64); },
+                [&](int j, int ks) { return Xb[(4 * ks + lg) * LDX + 16 * j + li]; },
+                [&](int) { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }, stage, Y2, 0, ws, lane);
+        }
+        __syncthreads();
+        // rf_post's 1x1 conv is folded into decoder layer 0's 1x1 on the host (fe_api.hip::pack_weights): that layer reads Y2 as its
+        // first K-segment.  Wy (= W0) takes the 1x1 outputs, Wx (= W1, whose first rows Y2 occupies until layer 0 has consumed it)
+        // the k = 3 outputs.
+        float* const Wx = W1;
+        float* const Wy = W0;
+        for (int i = tid; i < 2 * LDC; i += NTH) {                // Wy lay under the token arena: zero its halo rows 0 and F1 + 1
+            const int r = i / LDC, c = i - r * LDC;
+            Wy[(r ? F1 + 1 : 0) * LDC + c] = 0.0f;
+        }
+        if (a.dbg != nullptr) {                                   // the rf_post stage no longer exists: recompute it for the dump
+            float* dst = a.dbg + (size_t)b * a.dbg_stride + DebugLayout<S>::offset(4 + S::NL + 2 * S::KB);
+            for (int i = tid; i < F1 * C1; i += NTH) {
+                const int f = i / C1, n = i - f * C1;
+                float v = wp[o.rfpost_b + n];
+                for (int kk = 0; kk < C2; ++kk) v += Y2[f * LDX + kk] * wp[o.rfpost_w + n * C2 + kk];
+                dst[i] = v;
+            }
+        }
+
+        FE_CLK(8);
+        // =========================== decoder (a14) ===========================
+        static_for<S::NL>([&](auto l_) {
+            constexpr int l = decltype(l_)::value;
+            const float* skip = Ebuf + (S::NL - l) * S::ACT;
+            {
+                // 1x1 conv on cat([x, skip]): two K-segments, never materialised
+                FE8_BEGIN_UNIT(S::U_DEC + l * 2);
+                constexpr bool FOLD0 = (l == 0);
+                constexpr int K0 = FOLD0 ? S::KS_2 : S::KS_C;
+                const float* xa = FOLD0 ? Y2 + (16 * ws + li) * LDX + lg : Wx + (16 * ws + li + 1) * LDC + lg;
+                const float* sk = skip + (16 * ws + li + 1) * LDC + lg;
+                conv8_pair<S, W8::NTA, W8::NTB, K0 + S::KS_C, C1, LDC, true>(
+                    wh, [&](int ks) { return ks < K0 ? xa[4 * ks] : sk[4 * (ks - K0)]; },
+                    [&](int j, int ks) { return wb.at(o.dec1_w[l] + (j * (K0 + S::KS_C) + ks) * 64); },
+                    [&](int j) { return wb.at16x4(o.dec1_b[l] + j * 64); }, stage, Wy, 1, ws, lane);
+            }
+            __syncthreads();
+            {
+                FE8_BEGIN_UNIT(S::U_DEC + l * 2 + 1);
+                const float* const t0 = Wy + (16 * ws + li) * LDC + lg;
+                conv8_pair<S, W8::NTA, W8::NTB, 3 * S::KS_C, C1, LDC, true>(
+                    wh, [&](int ks) { return t0[(ks / S::KS_C) * LDC + 4 * (ks % S::KS_C)]; },
+                    [&](int j, int ks) { return wb.at(o.dec3_w[l] + (j * (3 * S::KS_C) + ks) * 64); },
+                    [&](int j) { return wb.at16x4(o.dec3_b[l] + j * 64); }, stage, Wx, 1, ws, lane);
+            }
+            __syncthreads();
+            dbg_dump<S, NTH>(a, b, 5 + S::NL + 2 * S::KB + l, Wx + LDC, LDC);
+        });
+
+        FE_CLK(9);
+        // =========================== dec_post (a15) ===========================
+        float* PT = smem + L::PT;
+        {
+            FE8_BEGIN_UNIT(S::U_POST);
+            const float* xa = Wx + (16 * ws + li + 1) * LDC + lg;
+            const float* sk = Ebuf + (16 * ws + li + 1) * LDC + lg;
+            conv8_pair<S, W8::NTA, W8::NTB, 2 * S::KS_C, C1, LDC, true>(
+                wh, [&](int ks) { return ks < S::KS_C ? xa[4 * ks] : sk[4 * (ks - S::KS_C)]; },
+                [&](int j, int ks) { return wb.at(o.post1_w + (j * (2 * S::KS_C) + ks) * 64); },
+                [&](int j) { return wb.at16x4(o.post1_b + j * 64); }, stage, Wy, 1, ws, lane);
+        }
+        __syncthreads();
+        typename Dft<S>::InvConst idc;
+        {
+            // transposed conv as a GEMM: P[i][co * 8 + j] = sum_ci x[i][ci] w[ci][co][j]   (one channel tile: the wh = 0 waves)
+            FE8_BEGIN_UNIT(S::U_POST + 1);
+            const float* xa = Wy + (16 * ws + li + 1) * LDC + lg;
+            conv8_pair<S, 1, 0, S::KS_C, 16, S::LDP, false>(
+                wh, [&](int ks) { return xa[4 * ks]; }, [&](int j, int ks) { return wb.at(o.post_t_w + (j * S::KS_C + ks) * 64); },
+                [&](int) { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }, stage, PT, 0, ws, lane);
+            if (wave < 4) Dft<S>::load(idc, wb, o, wave);         // iSTFT constants, in flight during the mask phase
+        }
+        __syncthreads();
+
+        FE_CLK(10);
+        // =========================== mask, un-compress (a16, a17) ===========================
+        {
+            const float b0 = wb.scalar(o.post_t_b), b1 = wb.scalar(o.post_t_b + 1);
+            for (int f = tid; f < F0; f += NTH) {
+                const int q = f + 2, j1 = q & 3, i1 = q >> 2;
+                float m0 = b0, m1 = b1;
+                if (i1 < F1) { m0 += PT[i1 * S::LDP + j1]; m1 += PT[i1 * S::LDP + 8 + j1]; }
+                if (i1 >= 1) { m0 += PT[(i1 - 1) * S::LDP + j1 + 4]; m1 += PT[(i1 - 1) * S::LDP + 8 + j1 + 4]; }
+                const float xr_ = sc[2 + f], xi_ = sc[S::LDS_S + 2 + f];
+                float yr = xr_ * m0 - xi_ * m1;
+                float yi = xr_ * m1 + xi_ * m0;
+                if (a.dbg) {
+                    float* dst = a.dbg + (size_t)b * a.dbg_stride + DebugLayout<S>::offset(5 + 2 * S::NL + 2 * S::KB);
+                    dst[2 * f] = m0; dst[2 * f + 1] = m1;
+                }
+                const float mag = sqrtf(yr * yr + yi * yi);
+                const float g = pow_f(mag, 1.0f / a.compression - 1.0f);
+                yr *= g; yi *= g;
+                if (a.dbg) {
+                    float* dst = a.dbg + (size_t)b * a.dbg_stride + DebugLayout<S>::offset(6 + 2 * S::NL + 2 * S::KB);
+                    dst[2 * f] = yr; dst[2 * f + 1] = yi;
+                    if (f == 0) { dst[2 * F0] = 0.0f; dst[2 * F0 + 1] = 0.0f; }
+                }
+                q3[f] = yr;
+                q3[N / 2 + f] = yi;
+            }
+        }
+        __syncthreads();
+
+        FE_CLK(11);
+        // =========================== iSTFT (a18) ===========================
+        {
+            // synthesis window w / sum_k w^2 and the overlap tail: fetched across the inverse DFT
+            const float ow = wp[o.window_istft + tid];
+            const float oc = tid < OVL ? cis[tid] : 0.0f;
+            if (wave < 4) Dft<S>::template inverse<WSrc<true>, false>(q3, q0, q1, tw, idc, wb, o, wave, lane);
+            __syncthreads();
+            FE_CLK(12);
+            const int pi = Dft<S>::pidx(tid & (Dft<S>::N1 - 1), tid / Dft<S>::N1);
+            const float xo = (q0[pi] + q1[pi]) * ow + oc;
+            // one sample per thread: the first H go out, the rest is the new overlap tail (the old tail was read before the barrier)
+            if (tid < H) a.wav_out[(size_t)b * a.out_stride + tid] = xo;
+            else cis[tid - H] = xo;
+            if constexpr (PERSIST) __syncthreads();               // (the next stream's frame load reuses q0)
+        }
+        FE_CLK(13);
+        b += (int)gridDim.x;
+        ++fc;
+    } while (PERSIST && b < a.B);
+#undef FE8_BEGIN_UNIT
+    FE_CLK(63);
+}
+
+}  // namespace fe

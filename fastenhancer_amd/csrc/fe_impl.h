@@ -5,7 +5,10 @@
 
 #include <atomic>
 
+#include <cstdlib>
+
 #include "fe_kernels.hip.h"
+#include "fe_frame8.hip.h"
 #include "tb_kernels.hip.h"
 
 namespace fe {
@@ -16,6 +19,7 @@ struct Impl {
     size_t lds_bytes;
     int occ;              // resident workgroups per CU
     bool many_persist;    // companion: also used beyond occ x #CUs streams (persistent workgroups)
+    bool wg8;             // the 512-thread per-hop kernel (fe_frame8.hip.h) is built for this shape
     int n_units, u_max;
     bool staged;
     size_t skip_floats;   // per stream, 0 when the skips stay in LDS
@@ -45,12 +49,47 @@ void launch_one(const FrameArgs& a, int grid_x, hipStream_t st, hipError_t* err)
     *err = hipGetLastError();
 }
 
+// a.step_kernel (fe_set_step_kernel; the handle's default comes from the environment variable FE_WG8, else 1):
+//   0 = the four-wave kernel everywhere; 1 = the 512-thread kernel (fe_frame8.hip.h: two waves per SIMD, channel-grouped GRU gates)
+//   for the per-hop step of the shapes it is built for, up to one stream per CU; 2 = also above that (persistent workgroups)
+template <class S, bool DBG, bool PERSIST>
+void launch_one8(const FrameArgs& a, int grid_x, hipStream_t st, hipError_t* err) {
+    static std::atomic<bool> attr_set[kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    if (!attr_set[dev].load(std::memory_order_relaxed)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fe_frame8_kernel<S, DBG, PERSIST>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds<S>::BYTES);
+        if (e != hipSuccess) { *err = e; return; }
+        attr_set[dev].store(true, std::memory_order_relaxed);
+    }
+    dim3 grid(grid_x), block(kThreads8);
+    hipLaunchKernelGGL((fe_frame8_kernel<S, DBG, PERSIST>), grid, block, Lds<S>::BYTES, st, a);
+    *err = hipGetLastError();
+}
+
 // max_wgs: workgroups that are resident at once (one per CU: 129+ KiB of LDS and waves_per_eu(1,1)); a batch with more
 // streams runs on a grid of max_wgs PERSISTENT workgroups, each walking its streams b, b + grid, ...
 template <class S>
 void launch_impl(const FrameArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
     const int slots = max_wgs * Lds<S>::OCC;         // resident workgroups
     const int grid = a.B < slots ? a.B : slots;
+    if constexpr (Wg8<S>::OK) {
+        if (a.step_kernel > 0 && a.mode == FE_MODE_STREAM && a.T == 1) {
+            const int grid8 = a.B < max_wgs ? a.B : max_wgs;       // (one 512-thread workgroup per CU)
+#ifdef FE_PROBE_HOT
+            const bool dbg8 = a.dbg != nullptr;
+#else
+            const bool dbg8 = a.dbg != nullptr || a.clk != nullptr;
+#endif
+            if (grid8 == a.B) {
+                if (dbg8) launch_one8<S, true, false>(a, grid8, st, err);
+                else launch_one8<S, false, false>(a, grid8, st, err);
+                return;
+            }
+            if (a.step_kernel > 1 && !dbg8) { launch_one8<S, false, true>(a, grid8, st, err); return; }
+        }
+    }
 #ifdef FE_PROBE_HOT
     if (a.dbg != nullptr) launch_one<S, true, -1, false, true>(a, grid, st, err);
 #else
@@ -98,10 +137,10 @@ Impl make_impl() {
         tbp = &tbi;
     }
     if constexpr (S::BIDIR) {       // noncausal: no frame-by-frame kernel (the reverse-time scan needs all frames): time-batched engine only
-        return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, S::KT, S::LOW, 0, 0, 0, 1, tbp, (size_t)0, 1, false, S::NU, Pack<S>::umax(), false,
+        return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, S::KT, S::LOW, 0, 0, 0, 1, tbp, (size_t)0, 1, false, false, S::NU, Pack<S>::umax(), false,
                     (size_t)0, DebugLayout<S>::total(), DebugLayout<S>::n_stages, &Pack<S>::v, nullptr, nullptr, &dbg_stage_impl<S>};
     } else {
-    return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, S::KT, S::LOW, S::FRNN ? 1 : 0, S::LB, S::LN ? 1 : 0, 0, tbp, Lds<S>::BYTES, Lds<S>::OCC, Lds<S>::MANY_PERSIST, S::NU, Pack<S>::umax(), Lds<S>::STAGED,
+    return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, S::KT, S::LOW, S::FRNN ? 1 : 0, S::LB, S::LN ? 1 : 0, 0, tbp, Lds<S>::BYTES, Lds<S>::OCC, Lds<S>::MANY_PERSIST, Wg8<S>::OK, S::NU, Pack<S>::umax(), Lds<S>::STAGED,
                 Lds<S>::SKIPS_LDS ? (size_t)0 : (size_t)(S::NL + 1) * S::F1 * S::C1,
                 DebugLayout<S>::total(), DebugLayout<S>::n_stages, &Pack<S>::v, &launch_impl<S>, &launch_pipe_impl<S>, &dbg_stage_impl<S>};
     }

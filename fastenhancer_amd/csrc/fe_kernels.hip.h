@@ -113,6 +113,15 @@ struct Shape {
     // like the qkv GEMM.  r, z, n of a channel then sit in different lanes: the pre-activations cross through LDS
     // and the gate math runs element-per-thread over all 256 threads.  (Register-resident weights only.)
     static constexpr bool GFLAT = (C2 % 16 != 0) && (3 * NTPW3 + 2 * NTPW2) * KS_2 <= 160;
+    // "channel-grouped" GRU gate packing of the 512-thread per-hop kernel (fe_frame8.hip.h): the r, z, n columns of 16 channels as
+    // three tiles of ONE wave (the gates of a (row, channel) meet in a lane: gate math in the GEMM epilogue, no exchange through
+    // LDS), the C2 % 16 left-over channels' r | z | n in one mixed tile.  A packing predicate only: it must not depend on LOW
+    // (a low-LDS companion shares the packed buffer of its shape).
+    static constexpr int G8_NG = C2 / 16, G8_R = C2 % 16;
+    static constexpr bool G8P = GFLAT && MT2 == 2 && G8_NG == 2 && G8_R > 0 && 3 * G8_R <= 16 && KT_ == 1 && FR_ == 0 && TA_ == 0 && LN_ == 0 && BD_ == 0;
+    static constexpr int G8_NT = 3 * G8_NG + 1;      // tiles: (group, gate) ..., the mixed tile
+    // "k4" fragment order: K4_NF groups of four k-steps per tile, then a tail of K4_REM floats per lane (the left-over k-steps + the bias)
+    static constexpr int K4_NF = (C2 / 4) / 4, K4_REM = (C2 / 4) % 4 + 1, K4_TILE = K4_NF * 256 + 64 * K4_REM;
     static_assert(C1 % 4 == 0 && C2 % 4 == 0 && F2 % 4 == 0, "channel counts must be multiples of 4");
     static_assert(C2 % NH == 0, "C2 must be divisible by the 4 heads");
     static_assert(F1 % 64 == 0, "F1 must be a multiple of 64");
@@ -149,6 +158,15 @@ struct PackedOffsets {
     // (tile = gate * NT2 + channel tile, so that r, z, n of a (row, channel) meet in one lane) and b_hn [NT2 * 16];
     // noncausal: rnn_fc over 2 C2 input channels
     int tb_wih[8][2], tb_bx[8][2], tb_whh[8][2], tb_bhn[8][2], tb_fc1_w[8];
+    // 512-thread per-hop kernel (Shape::G8P), per block: the register-resident block weights in "k4" fragment order - a lane's
+    // k-steps 4 kg .. 4 kg + 3 of a tile are 16 contiguous bytes, tile * K4_TILE + [kg][lane][4], so that a wave fetches four
+    // k-steps with ONE fully coalesced buffer_load_dwordx4 (a buffer_load_dword costs the CU's vector-memory path as much as a
+    // dwordx4: ~16 cycles per wave instruction, tools/micro/vmem_issue_rate.hip); the tail [lane][K4_REM] holds the left-over
+    // k-steps and, last, the bias of the lane's column - no padding: a loaded register that nothing reads is re-used by the
+    // register allocator while the load is still in flight, and the write-after-write wait stalls the GEMM it rides in.  g8x / g8h: input / hidden weights of the channel-grouped GRU gate tiles (bias: b_ih, plus b_hh on pure
+    // r / z tiles whose x and h halves share an accumulator / b_hh on the n tiles and the mixed tile, else 0); f1, q, f2: rnn_fc,
+    // qkv, attn_fc in their plain column order.
+    int k4_g8x[8], k4_g8h[8], k4_f1[8], k4_q[8], k4_f2[8];
     int total;
     // LDS-staged weight "units" in consumption order (one per conv-type GEMM phase): [weights | bias],
     // 256-float aligned and padded, so that a unit is staged by whole 1-KiB global_load_lds pieces.
@@ -229,6 +247,12 @@ struct Pack {
                 }
                 if (S::BIDIR) o.tb_fc1_w[k] = alloc(szB(2 * C2, C2));
             }
+        if (S::G8P)      // (allocated last: every other offset is the same with and without it)
+            for (int k = 0; k < S::KB; ++k) {
+                constexpr int T4 = S::K4_TILE;        // floats per tile
+                o.k4_g8x[k] = alloc(S::G8_NT * T4); o.k4_g8h[k] = alloc(S::G8_NT * T4);
+                o.k4_f1[k] = alloc(S::NT2 * T4); o.k4_q[k] = alloc(S::NT3 * T4); o.k4_f2[k] = alloc(S::NT2 * T4);
+            }
         o.total = round_up(cur, 64);
         return o;
     }
@@ -261,10 +285,14 @@ struct FrameArgs {
                               // j) has been published (zeroed before the launch)
     float* frames;            // offline: [B][T][N] windowed output frames (overlap-added by istft_ola_kernel afterwards)
     int pipe_p;
+    int step_kernel;          // host side only (fe_impl.h::launch_impl): FE_STEP_KERNEL_* of the handle (fe_set_step_kernel)
 };
 
 // ------------------------------------------------------------------------------------------
-#define FE_CLK(i) do { if (a.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.clk[(i)] = __builtin_readcyclecounter(); } while (0)
+#ifndef FE_PROBE_TID
+#define FE_PROBE_TID 0      // the thread whose clock the phase probes record (measurement builds: -DFE_PROBE_TID=256 = wave 4 of the 512-thread kernel)
+#endif
+#define FE_CLK(i) do { if (a.clk != nullptr && blockIdx.x == 0 && threadIdx.x == FE_PROBE_TID) a.clk[(i)] = __builtin_readcyclecounter(); } while (0)
 
 // v_exp_f32 / v_rcp_f32 are 1-ulp hardware ops; the resulting activations are accurate to a few
 // 1e-7 (measured against the oracle per stage), far inside the 1e-4 waveform budget.
@@ -350,10 +378,10 @@ struct DmaJobT {
 // The loads of a unit of NP pieces ride in the software pipeline of the phase's GEMM as its side job, spread
 // over the k-groups (issued back to back they stall the wave: the vector-memory path takes 64 B/clk per CU, i.e.
 // 64 cycles per round of four 1-KiB pieces); commit() writes them to LDS after the GEMM.
-template <int NPW, int NP>
+template <int NPW, int NP, int NWV = kWaves>      // NWV: waves of the workgroup (8 in the 512-thread per-hop kernel, fe_frame8.hip.h)
 struct StageSide {
     DmaJobT<NPW>* j;
-    static constexpr int NPI = (NP + kWaves - 1) / kWaves;     // pieces per wave
+    static constexpr int NPI = (NP + NWV - 1) / NWV;     // pieces per wave
     // piece i rides in k-group slot(i, ng): spread over the first 2/3 of the GEMM so that the last one has landed by commit()
     static constexpr int slot(int i, int ng) { const int span = (2 * ng + 2) / 3 > 0 ? (2 * ng + 2) / 3 : 1; return i * span / NPI; }
     static constexpr int loads(int g, int ng) {
@@ -363,8 +391,8 @@ struct StageSide {
     }
     __device__ __forceinline__ void load(int i) const {
         int voff = j->lane * 16;
-        if (4 * i + 3 >= NP) voff = (j->wave + kWaves * i < NP) ? voff : 0x40000000;     // out of range: reads 0, no traffic
-        j->r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(j->rsrc, voff, j->soff + i * (kWaves * 1024), 0));
+        if (NWV * i + NWV - 1 >= NP) voff = (j->wave + NWV * i < NP) ? voff : 0x40000000;     // out of range: reads 0, no traffic
+        j->r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(j->rsrc, voff, j->soff + i * (NWV * 1024), 0));
     }
     __device__ __forceinline__ void operator()(int g, int ng) const {
 #pragma unroll
@@ -374,8 +402,8 @@ struct StageSide {
     __device__ __forceinline__ void commit() const {
 #pragma unroll
         for (int i = 0; i < NPI; ++i) {
-            const int p = j->wave + kWaves * i;
-            if (4 * i + 3 < NP || p < NP) *reinterpret_cast<f32x4*>(j->l + p * 256 + j->lane * 4) = j->r[i];
+            const int p = j->wave + NWV * i;
+            if (NWV * i + NWV - 1 < NP || p < NP) *reinterpret_cast<f32x4*>(j->l + p * 256 + j->lane * 4) = j->r[i];
         }
     }
 };
@@ -636,7 +664,7 @@ struct DebugLayout {
     __host__ __device__ static constexpr size_t total() { return offset(n_stages); }
 };
 
-template <class S>
+template <class S, int NTH = kThreads>
 __device__ __forceinline__ void dbg_dump(const FrameArgs& a, int b, int stage, const float* src, int ld) {
     if (a.dbg == nullptr) return;
     using D = DebugLayout<S>;
@@ -645,7 +673,7 @@ __device__ __forceinline__ void dbg_dump(const FrameArgs& a, int b, int stage, c
     // conv-trunk stages (enc_pre, encoder.i, rf_post, decoder.i) live scaled by kSiluScale
     const bool trunk = (stage >= 2 && stage < 3 + S::NL) || (stage >= 4 + S::NL + 2 * S::KB && stage < 5 + 2 * S::NL + 2 * S::KB);
     const float sc = (trunk && !S::LN) ? 1.0f / kSiluScale : 1.0f;      // (the ln variant's trunk is not scaled)
-    for (int i = threadIdx.x; i < rows * cols; i += kThreads) {
+    for (int i = threadIdx.x; i < rows * cols; i += NTH) {
         int r = i / cols, c = i - r * cols;
         dst[i] = src[r * ld + c] * sc;
     }
@@ -821,6 +849,7 @@ struct Dft {
 
     // xw[N] (windowed frame) -> X = {Re[N/2], Im[N/2]} (bins 0 .. N/2-1), followed by a barrier.
     // nyq != nullptr: also store bin N/2 there (debug dump only; for N1 = 32 it costs an extra reduction).
+    template <bool BAR = true>      // BAR = false: the caller barriers (the 512-thread kernel runs the transform on four of its eight waves)
     __device__ static __forceinline__ void forward(const float* xw, float* X, const float2* tw, const FwdConst& c,
                                                    int wave, int lane, float* nyq) {
         const int li = lane & 15, lg = lane >> 4, p = wave >> 1, jt = wave & 1, k2 = 16 * jt + li;
@@ -865,12 +894,12 @@ struct Dft {
                 if (lane == 0) { nyq[0] = sgn; nyq[1] = 0.0f; }
             }
         }
-        __syncthreads();
+        if constexpr (BAR) __syncthreads();
     }
 
     // Y = {Re[N/2], Im[N/2]} (bins 0 .. N/2-1, bin N/2 = 0, Im Y[0] ignored) -> y[n] = P0[pidx] + P1[pidx]
     // (P_jt = the partial sum over this wave pair's k2 tile), followed by a barrier.
-    template <class WS>
+    template <class WS, bool BAR = true>
     __device__ static __forceinline__ void inverse(const float* Y, float* P0, float* P1, const float2* tw, const InvConst& c,
                                                    const WS& wb, const PackedOffsets& o, int wave, int lane) {
         const int li = lane & 15, lg = lane >> 4, p = wave >> 1, jt = wave & 1, k2 = 16 * jt + li;
@@ -923,7 +952,7 @@ struct Dft {
 #pragma unroll
             for (int r = 0; r < 4; ++r) P[pidx(16 * i + 4 * lg + r, 16 * p + li)] = e0[r] + e1[r];
         }
-        __syncthreads();
+        if constexpr (BAR) __syncthreads();
     }
 };
 

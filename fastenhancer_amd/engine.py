@@ -260,6 +260,11 @@ class Engine:
                                              _stream(self.device)), "fe_step_host")
         return wav_out
 
+    def set_step_kernel(self, kernel: str):
+        """fe_set_step_kernel: "waves4" (the 256-thread kernel) | "wg8" (default: the 512-thread per-hop kernel where built) | "wg8_persist"."""
+        code = {"waves4": _lib.FE_STEP_KERNEL_WAVES4, "wg8": _lib.FE_STEP_KERNEL_WG8, "wg8_persist": _lib.FE_STEP_KERNEL_WG8_PERSIST}[kernel]
+        _lib.check(self.lib.fe_set_step_kernel(self._h, code), "fe_set_step_kernel")
+
     def set_offline_engine(self, engine: str):
         """fe_set_offline_engine: "auto" | "frame_walk" | "time_batched" (the layer-by-layer engine of csrc/tb_kernels.hip.h)"""
         code = {"auto": _lib.FE_OFFLINE_AUTO, "frame_walk": _lib.FE_OFFLINE_FRAME_WALK, "time_batched": _lib.FE_OFFLINE_TIME_BATCHED}[engine]

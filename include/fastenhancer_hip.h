@@ -171,6 +171,19 @@ int fe_set_time_pipeline(fe_handle* h, int frames_in_flight);
  * pipeline (or of 2048+ frames in all); the handle then keeps a grow-only work buffer (a first / larger call allocates).
  * Results agree to fp32 rounding.  The other architectures / variants always walk.  A handle's compute calls must be stream-ordered
  * (one stream, or event-ordered streams): the engines keep per-handle scratch, counters and helper streams. */
+/* Which kernel runs the per-hop streaming step (fe_step / fe_step_host with T = 1) of the default FastEnhancer model:
+ *   FE_STEP_KERNEL_WAVES4: one 256-thread workgroup per stream (fe_kernels.hip.h), the kernel every other entry point uses too;
+ *   FE_STEP_KERNEL_WG8 (default): where built for the shape (FastEnhancer_B), one 512-thread workgroup per stream - two waves per
+ *     SIMD, GRU gates grouped by channel (fe_frame8.hip.h) - for batches of up to one stream per CU;
+ *   FE_STEP_KERNEL_WG8_PERSIST: the same also above that (persistent workgroups instead of the low-LDS companion kernel).
+ * The two kernels agree to fp32 rounding (a few 1e-8 on the waveform), not bit for bit: a caller that needs a chunked launch
+ * (T > 1) to be bit-identical to T per-hop launches selects FE_STEP_KERNEL_WAVES4.  The environment variable FE_WG8 = 0 | 1 | 2
+ * sets the default of new handles.  The reference has one forward only (models/fastenhancer/default/model.py:677-710). */
+#define FE_STEP_KERNEL_WAVES4 0
+#define FE_STEP_KERNEL_WG8 1
+#define FE_STEP_KERNEL_WG8_PERSIST 2
+int fe_set_step_kernel(fe_handle* h, int kernel);
+
 #define FE_OFFLINE_AUTO 0
 #define FE_OFFLINE_FRAME_WALK 1
 #define FE_OFFLINE_TIME_BATCHED 2

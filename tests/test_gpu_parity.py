@@ -103,11 +103,16 @@ def test_driver_loop_matches_reference_golden(name):
     m, orc, cfg, sr, seed = _model(name)
     length = int(g["long_length"])
     x = torch.from_numpy(make_input(1, length, seed + 3000, sr))
-    y1 = enhance_stream(m, x, frames_per_call=1).cpu().numpy()
-    y16 = enhance_stream(m, x, frames_per_call=16).cpu().numpy()
+    y1 = enhance_stream(m, x, frames_per_call=1).cpu().numpy()         # (default per-hop kernel: the 512-thread one where built)
     assert y1.shape == (1, length)
     _assert_close(y1[0], g["long_wav_out"], "long run T=1")
-    assert np.array_equal(y1, y16), "chunked launches must be bit-identical to per-hop launches"
+    # chunked launches run the 256-thread kernel: bit-identical to per-hop launches of the SAME kernel
+    m.engine.set_step_kernel("waves4")
+    y1w = enhance_stream(m, x, frames_per_call=1).cpu().numpy()
+    y16 = enhance_stream(m, x, frames_per_call=16).cpu().numpy()
+    _assert_close(y1w[0], g["long_wav_out"], "long run T=1, 256-thread kernel")
+    assert np.array_equal(y1w, y16), "chunked launches must be bit-identical to per-hop launches"
+    assert np.abs(y1 - y1w).max() <= 2e-6 * max(1.0, np.abs(y1w).max()), "the two per-hop kernels agree to fp32 rounding"
 
 
 @pytest.mark.parametrize("name", ALL_SHAPES)
@@ -143,6 +148,7 @@ def test_chunked_launch_is_bit_identical_to_per_hop_launches(name):
     eng = m.engine
     B, T, H = 4, 6, cfg.hop_size
     x = torch.from_numpy(make_input(B, T * H, 31, sr)).to(_dev())
+    eng.set_step_kernel("waves4")       # (the 512-thread per-hop kernel agrees with it to fp32 rounding only: test_wg8_*)
     s1, s2 = eng.new_state(B), eng.new_state(B)
     y1 = eng.step(x, s1, T=T)
     y2 = torch.cat([eng.step(x[:, t * H:(t + 1) * H], s2, T=1) for t in range(T)], dim=1)
@@ -154,6 +160,38 @@ def test_chunked_launch_is_bit_identical_to_per_hop_launches(name):
         o, *caches = orc.step(x.cpu().numpy()[:, t * H:(t + 1) * H], *caches)
         refs.append(o)
     _assert_close(y1.cpu().numpy(), np.concatenate(refs, 1), "chunk vs oracle")
+
+
+@pytest.mark.parametrize("B", [1, 5, 256, 300])
+def test_wg8_per_hop_kernel_matches_oracle_and_the_four_wave_kernel(B):
+    """The 512-thread per-hop kernel (fe_frame8.hip.h; FastEnhancer_B): every output and every cache against the oracle and against the
+    256-thread kernel on the same input; B = 300 runs it with persistent workgroups (more streams than CUs)."""
+    m, orc, cfg, sr, seed = _model("fe_b")
+    eng = m.engine
+    hops, H = 6, cfg.hop_size
+    x = make_input(B, hops * H, 777 + B, sr)
+    xd = torch.from_numpy(x).to(_dev())
+    outs, states = {}, {}
+    for kern in ("waves4", "wg8_persist" if B > 256 else "wg8"):
+        eng.set_step_kernel(kern)
+        st = eng.new_state(B)
+        outs[kern] = torch.cat([eng.step(xd[:, t * H:(t + 1) * H], st, T=1) for t in range(hops)], dim=1).cpu().numpy()
+        states[kern] = st.cpu().numpy()
+    k8 = "wg8_persist" if B > 256 else "wg8"
+    assert np.abs(outs[k8] - outs["waves4"]).max() <= 2e-6 * max(1.0, np.abs(outs["waves4"]).max())
+    assert np.abs(states[k8] - states["waves4"]).max() <= 2e-6 * max(1.0, np.abs(states["waves4"]).max())
+    assert not np.array_equal(outs[k8], outs["waves4"]) or B == 0, "both switch positions ran the same kernel?"
+    sel = list(range(B)) if B <= 5 else [0, 1, B // 2, B - 2, B - 1]
+    caches = orc.initialize_cache(len(sel))
+    refs = []
+    for t in range(hops):
+        o, *caches = orc.step(x[sel][:, t * H:(t + 1) * H], *caches)
+        refs.append(o)
+    _assert_close(outs[k8][sel], np.concatenate(refs, 1), f"wg8 kernel vs oracle, B = {B}")
+    # the GRU states it leaves (the tail of the state buffer: [KB][B * F2][C2]) against the oracle's caches
+    hs = states[k8][2 * B * (cfg.n_fft - cfg.hop_size):].reshape(len(caches) - 2, B, -1)
+    for kb, c in enumerate(caches[2:]):
+        _assert_close(hs[kb][sel].reshape(-1), np.asarray(c).reshape(-1), f"h[{kb}]")
 
 
 @pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_l", "fe48_b_h480"])
