@@ -313,6 +313,38 @@ def measured_traffic(workload: str, B: int, T: int):
     return best
 
 
+def pin_rank(local_rank: int, world: int) -> None:
+    """One contiguous slice of the allowed logical cores per rank (its launch thread stops migrating between the other ranks' cores);
+    the cores of the GPU's own NUMA node when the driver exposes it.  Best effort: any failure leaves the affinity alone."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        if len(allowed) < 2 * world or os.environ.get("FE_BENCH_NO_PIN"):
+            return
+        local = None
+        try:      # /sys/class/drm/card*/device/numa_node + /sys/devices/system/node/nodeK/cpulist
+            cards = sorted(c for c in os.listdir("/sys/class/drm") if c.startswith("card") and c[4:].isdigit()
+                           and os.path.exists(f"/sys/class/drm/{c}/device/numa_node"))
+            if local_rank < len(cards):
+                node = int(open(f"/sys/class/drm/{cards[local_rank]}/device/numa_node").read())
+                if node >= 0:
+                    cpus = set()
+                    for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+                        lo, _, hi = part.partition("-")
+                        cpus.update(range(int(lo), int(hi or lo) + 1))
+                    local = sorted(cpus & set(allowed))
+        except Exception:
+            local = None
+        per = len(allowed) // world
+        mine = allowed[local_rank * per:(local_rank + 1) * per]
+        if local and len(local) >= per:      # the slice of the GPU's node that this rank's position among the node's ranks selects
+            k = (local_rank * per) % max(1, len(local) - per + 1)
+            mine = local[k:k + per]
+        if mine:
+            os.sched_setaffinity(0, mine)
+    except Exception:
+        pass
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` (no launcher): start N ranks of this script, one per GPU, under torch.distributed.run
     (the command line the driver itself uses), rendezvous on 127.0.0.1; rank 0 prints the JSON line.  Never falls
@@ -331,7 +363,12 @@ def spawn_ranks(n: int) -> int:
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
-    env.setdefault("OMP_NUM_THREADS", "4")
+    # host threads per rank: the container's CPU quota (cgroup cpu.max: 16 CPUs on the r2 / r3 boxes, whatever the host shows) shared by
+    # the N ranks - 8 ranks x 4 OpenMP threads on a 16-CPU quota would throttle the launch threads themselves
+    avail, quota = host_cpus()
+    cap = avail if quota is None else max(1, min(avail, int(quota + 0.5)))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(4, cap // n))))
+    env.setdefault("MKL_NUM_THREADS", env["OMP_NUM_THREADS"])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
@@ -427,6 +464,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        pin_rank(local_rank, world)
     if args.cpu_dry_run:
         return dry_run(args, launched, world, rank)
     if not torch.cuda.is_available():
@@ -655,6 +693,9 @@ def main():
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "clock_ramp_steps": ramp_steps, "cold_ms_per_step": cold_ms, "rccl_world_size": rccl_world, "weight_broadcast_ms": bcast_ms,
             "per_rank_ms_per_step": per_rank_ms,
+            # host side of a step on the slowest rank: wall time per step minus the HIP-event time of its launches - tells a launch-jitter-bound
+            # N-GPU number from a kernel-bound one
+            "host_launch_overhead_ms_per_step": dt / args.steps * 1e3 - kernel_ms,
             "blocks": len(blocks), "statistic": "median of `blocks` consecutive blocks of `steps` steps (max over ranks per block)",
             "min_ms_per_step": min(b_[0] for b_ in blocks) / args.steps * 1e3, "max_ms_per_step": max(b_[0] for b_ in blocks) / args.steps * 1e3,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -672,7 +713,9 @@ def main():
                          "algorithmic_hbm_bytes_per_launch": alg_bytes,
                          "kernel": ("fe_offline = tb_enc_kernel + K x (tb_scan_kernel + tb_blk_kernel) + tb_dec_kernel + istft_ola_kernel (kernel_ms: the whole call)"
                                     if offline and args.offline_engine != "frame_walk" and not (w.get("bsrnn") or w.get("fspen") or w.get("lisennet") or w.get("kt") or w.get("frnn") or w.get("dpt") or w.get("ln")) else
-                                    "lisennet_frame_kernel" if w.get("lisennet") else "fspen_frame_kernel" if w.get("fspen") else ("bsrnn_frame_kernel<PART 1> + bsrnn_mlp_kernel + bsrnn_frame_kernel<PART 2> (kernel_ms: the step's three launches)" if w.get("bsrnn") and args.frames_per_step == 1 else "bsrnn_frame_kernel" if w.get("bsrnn") else "fe_frame_kernel")), "kernel_ms": kernel_ms,
+                                    "lisennet_frame_kernel" if w.get("lisennet") else "fspen_frame_kernel" if w.get("fspen") else ("bsrnn_frame_kernel<PART 1> + bsrnn_mlp_kernel + bsrnn_frame_kernel<PART 2> (kernel_ms: the step's three launches)" if w.get("bsrnn") and args.frames_per_step == 1 else "bsrnn_frame_kernel" if w.get("bsrnn") else
+                                    ("fe_frame8_kernel (512-thread per-hop kernel, fe_frame8.hip.h)" if args.workload == "fe_b" and not offline and T == 1 and B <= torch.cuda.get_device_properties(dev).multi_processor_count
+                                     and os.environ.get("FE_WG8", "1") != "0" else "fe_frame_kernel"))), "kernel_ms": kernel_ms,
                          "flops_per_frame": eng.flops_per_frame,
                          "hbm_frac": alg_bytes / (kernel_ms * 1e-3) / 8e12},
         }

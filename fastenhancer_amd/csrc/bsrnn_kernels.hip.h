@@ -399,6 +399,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     if (tid == 0) {
                         int spins = 0;
                         while (__hip_atomic_load(pflag + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)t && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(1);
+                        if (spins >= (1 << 24)) __builtin_trap();      // (a producer that never shows up: fail the launch loudly, never run on stale state)
                     }
                     __syncthreads();
                 }

@@ -1604,6 +1604,8 @@ int fe_profile_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, flo
     return run_step(h, wav_in_dev, in_stride, state_dev, wav_out_dev, out_stride, B, T, nullptr, clk_dev, stream);
 }
 
+constexpr int kMaxPipeFrames = 64;      // frames in flight per stream the work-buffer rings are sized for
+
 // workgroups per stream of a time-pipelined launch (0: one workgroup walks the frames of a stream)
 static int pipe_width(const fe_handle* h, int B, int T, bool offline = false) {
     if (!h->impl || h->pipe_frames == 0 || h->pipe_frames == 1 || T < 4 || 2 * B > h->max_wgs) return 0;
@@ -1638,7 +1640,9 @@ static int bsrnn_pipe_width(const fe_handle* h, int B, int T) {
 
 int fe_set_time_pipeline(fe_handle* h, int frames_in_flight) {
     if (!h) return fail(FE_ERR_INVALID_ARG, "bad argument");
-    h->pipe_frames = frames_in_flight;
+    // The per-frame rings in work_dev (time_kernel inputs, dptransformer K / V, LiSenNet caches) are sized for at most kMaxPipeFrames
+    // frames in flight (fe_offline_work_floats), and more never paid on any model: larger requests are clamped, not refused.
+    h->pipe_frames = frames_in_flight > kMaxPipeFrames ? kMaxPipeFrames : frames_in_flight;
     return FE_OK;
 }
 
@@ -1652,7 +1656,9 @@ static bool use_tb_spec(const fe_handle* h, int B, int T) {
     if (!h->impl || !h->impl->tb || h->d.BD || h->offline_engine == FE_OFFLINE_FRAME_WALK || T < 2) return false;
     if (h->offline_engine == FE_OFFLINE_TIME_BATCHED) return true;
     if (h->d.C2 >= 72) return false;
-    return T >= 16 && (pipe_width(h, B, T, false) == 0 || (long)B * T >= 2048);
+    // ("cannot take" = too many streams - NOT a caller's fe_set_time_pipeline(0 / 1), which asks for the serial walk and gets it)
+    if (h->pipe_frames == 0 || h->pipe_frames == 1) return false;
+    return T >= 16 && (2 * B > h->max_wgs || (long)B * T >= 2048);
 }
 
 int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* spec_out_dev, int B, int T, void* stream) {
@@ -1891,6 +1897,9 @@ size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw) {
     if (h->impl && h->impl->tb) {     // the larger of the two engines' needs, whatever the settings at call time (fe_set_time_pipeline / fe_set_offline_engine)
         const int T = 1 + Tw / d.HOP;
         size_t walk = d.BD ? 0 : (size_t)B * ((size_t)(d.NFFT - d.HOP) + d.hstate() + tk_floats(h)) + (((size_t)B * d.KB + 3) & ~(size_t)3) + (size_t)B * T * d.NFFT;
+        // (sized for the engine the CURRENT setting selects for this batch - for FastEnhancer_L x 16 x 4 s the time-batched buffers are
+        //  3 GB against the walk's 25 MB; a caller that changes fe_set_offline_engine afterwards queries again)
+        if (!d.BD && !use_tb_offline(h, B)) return walk;
         return std::max(walk, tb_work_floats(h, B, T, nullptr));
     }
     if (h->limpl) {     // tail + caches, and the time pipeline's counters, windowed frames and cache ring (widest pipeline: 64 + 2 slots)

@@ -1245,8 +1245,11 @@ __device__ __forceinline__ void attention_head(const float* G, float* Hl, int ho
 // PIPE (offline / spec -> spec with T >> 1): the frames of ONE stream are spread over P co-resident workgroups (one per
 // CU), workgroup p running frames p, p + P, ...  Everything in a frame but the GRU state is independent of the other
 // frames, so the workgroups run their frames concurrently, staggered by the one true dependency: frame t's GRU in block
-// k needs h_k(t-1).  The producer publishes it through global memory (agent-scope stores, then a release on a per-(stream,
-// block) frame counter), the consumer spins on the counter (acquire) before it fetches the state.  The serial chain is
+// k needs h_k(t-1).  The producer publishes it through global memory: agent-scope (sc1) stores of the state, drained with
+// s_waitcnt vmcnt(0) + the phase barrier, then a RELAXED agent-scope store of a per-(stream, block) frame counter; the consumer polls
+// the counter (relaxed, agent scope) and then fetches the state with agent-scope loads.  INVARIANT: every datum handed from one
+// workgroup to another goes through st_state / ld_state - a plain load or store added to a ring or state would be a silent stale read
+// (no release / acquire fence covers it).  The serial chain is
 // T x (state round trip + one GRU phase) instead of T x (whole frame): ~12 frames in flight for FastEnhancer_B.
 template <class S, bool DBG, int MODE, bool T1, bool PERSIST, bool PIPE = false>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(Lds<S>::OCC, Lds<S>::OCC))) fe_frame_kernel(FrameArgs a_in) {
@@ -1817,6 +1820,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 // dptransformer variant (models/fastenhancer/dptransformer/model.py:200-236, 378-389): causal attention over time per
                 // sub-band and head.  Phase A: q | k | v of the frame = x W^T -> Gi (the layout of the sub-band attention's qkv).
                 static_assert(!L::PERHEAD && S::LB == 31, "dptransformer: full qkv buffer, lookbehind 31");
+                // (PIPE: a frame writes its K / V slot before any wait; re-use of that slot is ordered through the block-0 wait of the
+                //  same frame one block later - which needs a second block)
+                static_assert(!PIPE || S::KB >= 2, "dptransformer time pipeline: slot re-use is ordered through the next block's wait");
                 // (Wtq was fetched inside the previous phase's GEMM: rf_pre's for block 0, the previous block's attn_fc after that;
                 //  shapes that stream their block weights re-bind here)
                 if constexpr (!REGW) Wtq.bind(wb, (o.blk_tqkv[0] + kb), -1, S::NT3, wave);

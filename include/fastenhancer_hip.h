@@ -150,7 +150,7 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
  * frames of a stream are spread over up to `frames_in_flight` co-resident workgroups that hand the GRU state of each
  * RNNFormer block from frame to frame through global memory (everything else in a frame is independent of the other
  * frames).  Negative (the default) = a width chosen from the model size (8 .. 64); 0 or 1 = off (one workgroup walks the
- * T frames of a stream).  Results agree to fp32 rounding.  BSRNN's fe_offline is pipelined the same way (the time-LSTM (h, c) of
+ * T frames of a stream); values above 64 are clamped to 64 (the per-frame rings in work_dev are sized for that).  Results agree to fp32 rounding.  BSRNN's fe_offline is pipelined the same way (the time-LSTM (h, c) of
  * each layer is the hand-off; up to 64 frames in flight), and so are the ln variant's, the time_kernel variant's and the
  * dptransformer variant's (the last two fe_offline only: the time convs' input frames / the K-V caches go through per-frame rings in
  * work_dev), FSPEN's (its inter-GRU states per DPE block) and LiSenNet's (its nine caches through a ring of per-frame slots). */

@@ -97,3 +97,19 @@ def test_bench_launch_path_runs_end_to_end_on_two_gloo_ranks():
     d = json.loads(lines[0])
     assert d["dry_run"] is True and d["world_size"] == 2 and d["n_gpus"] == 2 and d["value"] is None
     assert d["streams_per_rank"] == [5, 5] and d["weight_blob_floats"] > 0 and d["blocks"] >= 1
+
+
+def test_bench_config3_command_line_dry_run_on_eight_gloo_ranks():
+    """BASELINE config 3's exact command line - `bench.py --workload fe_l --gpus 8` (FastEnhancer_L, 256 streams per GPU = 2048 over the
+    node) - through the launch path on eight gloo ranks: the host-thread budget is split over the ranks, every rank gets its shard,
+    one JSON line comes back."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", "fe_l", "--gpus", "8", "--cpu-dry-run", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["world_size"] == 8 and d["n_gpus"] == 8
+    assert d["streams_per_rank"] == [256] * 8 and sum(d["streams_per_rank"]) == 2048

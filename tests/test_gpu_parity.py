@@ -1317,6 +1317,32 @@ def test_lisennet_time_pipelined_offline_agrees_with_the_serial_walk(B):
     _assert_close(s_.cpu().numpy(), spec_ref, "lisennet pipelined offline spec vs oracle")
 
 
+@pytest.mark.parametrize("which", ["fe_tk_b", "fe_dpt_b", "lisennet"])
+def test_time_pipeline_width_above_the_ring_size_is_clamped(which):
+    """fe_set_time_pipeline(128) with one long utterance: the per-frame rings in work_dev (time_kernel inputs, dptransformer K / V,
+    LiSenNet caches) hold 64 frames in flight - a wider request is clamped (it used to index past the rings); results equal the serial walk."""
+    if which == "lisennet":
+        g = load_golden("lisennet")
+        m, orc, cfg, sr, seed = _lisennet("Model")
+    else:
+        m, orc, cfg, sr, seed = _model(which, "Model")
+    eng = m.engine
+    x = make_input(1, 150 * cfg.hop_size + 5, 4711, sr)
+    if which == "lisennet":
+        x[:, :int(g["offline_leading_zeros"])] = 0.0
+    xd = torch.from_numpy(x).to(_dev())
+    guard = torch.full((1 << 20,), 7.0, device=_dev())          # (allocated right after the work buffers of the calls below)
+    eng.set_time_pipeline(0)
+    w_ser, s_ser = [t.clone() for t in m(xd)]
+    eng.set_time_pipeline(128)
+    for rep in range(2):
+        w, s_ = m(xd)
+        assert float((w - w_ser).abs().max()) <= 3e-5 * max(1.0, float(w_ser.abs().max())), (rep, float((w - w_ser).abs().max()))
+        assert float((s_ - s_ser).abs().max()) <= 3e-5 * max(1.0, float(s_ser.abs().max())), rep
+    assert bool((guard == 7.0).all())
+    eng.set_time_pipeline(-1)
+
+
 @pytest.mark.parametrize("B", [256, 700])
 def test_lisennet_full_size(B):
     """256 streams (one workgroup per CU) and 700 (two per CU, then persistent): oracle parity on a sample, bitwise position
@@ -1374,3 +1400,37 @@ def test_baseline_models_long_run_has_no_state_drift(which):
     _assert_close(np.concatenate(got[-20:], axis=1), np.concatenate(ref[-20:], axis=1), f"{which} hops 40..59")
     for a_, b_ in zip(eng.split_state(state, B), caches):
         _assert_close(a_.cpu().numpy(), b_, f"{which} cache after 60 hops")
+
+
+@pytest.mark.parametrize("name,B", [("fe_b", 7), ("fe_tk_b", 3), ("fe_dpt_b", 1), ("fe_ln_b", 3), ("bsrnn_xt", 7), ("fspen", 7), ("lisennet", 3)])
+def test_time_pipeline_stress_is_bit_reproducible_and_equals_the_serial_walk(name, B):
+    """A reduced tools/gpu_pipeline_stress.py in the suite, so that EVERY box the tests run on exercises the hand-rolled hand-off ordering
+    of the time-pipelined launches (relaxed agent-scope counters + s_waitcnt vmcnt(0) + barrier, fe_kernels.hip.h): per family one batch
+    size the other tests do not use (7 streams: ragged against every pipeline width), 10 repetitions that must reproduce the first bit for
+    bit - the hand-off order does not change the arithmetic - and agree with one workgroup walking the frames serially."""
+    if name == "fspen":
+        m, orc, cfg, sr, seed = _fspen("Model")
+    elif name == "lisennet":
+        m, orc, cfg, sr, seed = _lisennet("Model")
+    elif name.startswith("bsrnn"):
+        m, orc, cfg, sr, seed = _bsrnn(name, "Model")
+    else:
+        m, orc, cfg, sr, seed = _model(name, "Model")
+    eng = m.engine
+    if name in TB_SHAPES:
+        eng.set_offline_engine("frame_walk")
+    xn = make_input(B, 97 * cfg.hop_size + 13, 31 + B, sr)
+    if name == "lisennet":
+        xn[:, :1024] = 0.0           # (frame 0 of its offline path is ill-conditioned on a non-silent start, see test_lisennet_offline_matches_oracle)
+    x = torch.from_numpy(xn).to(_dev())
+    eng.set_time_pipeline(0)
+    w_ser = m(x)[0].clone()
+    tol = (6e-5 if name == "fspen" else 2e-5) * max(1.0, float(w_ser.abs().max()))      # (FSPEN at 7 streams: 4.4e-5 absolute, profiles/r3t_pipeline_stress.txt)
+    for width in (-1, 6):
+        eng.set_time_pipeline(width)
+        w0 = m(x)[0].clone()
+        assert bool(torch.isfinite(w0).all())
+        assert float((w0 - w_ser).abs().max()) <= tol, (width, float((w0 - w_ser).abs().max()))
+        for rep in range(10):
+            assert torch.equal(m(x)[0], w0), (width, rep)
+    eng.set_time_pipeline(-1)
