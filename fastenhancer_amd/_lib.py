@@ -47,6 +47,8 @@ SYMBOLS = {
     "fe_set_step_kernel": (c_int, [c_void_p, c_int]),
     "fe_offline_work_floats": (c_size_t, [c_void_p, c_int, c_int]),
     "fe_offline": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fe_offline_ragged_work_floats": (c_size_t, [c_void_p, c_int, c_int]),
+    "fe_offline_ragged": (c_int, [c_void_p, c_void_p, c_size_t, POINTER(c_int), c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "fe_stft_step": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "fe_istft_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "fe_stft_offline": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -1891,6 +1891,34 @@ int fe_set_offline_engine(fe_handle* h, int engine) {
     return FE_OK;
 }
 
+// fe_offline on the time-batched engine: encoder pass, per block (scan over time, attention pass), decoder pass, overlap-add.
+// Tw_b_dev != nullptr: a ragged batch laid out for Tw (= the longest utterance), utterance b has Tw_b_dev[b] samples.
+static int offline_tb(fe_handle* h, const float* noisy_dev, size_t in_stride, const int* Tw_b_dev, int Tw, int B, float* wav_hat_dev, size_t out_stride,
+                      float* spec_hat_dev, float* work_dev, hipStream_t st) {
+    const Dims& d = h->d;
+    const int T = 1 + Tw / d.HOP;
+    int rc = ensure_tables(h, st);
+    if (rc != FE_OK) return rc;
+    fe::tb::TbArgs a{};
+    a.wp = h->packed_dev;
+    a.wav_in = noisy_dev; a.in_stride = in_stride; a.Tw = Tw; a.Tw_b = Tw_b_dev;
+    a.spec_out = spec_hat_dev;
+    a.hstate = nullptr;                      // zero initial state (model.py:626-627)
+    a.mode = fe::FE_MODE_OFFLINE;
+    a.compression = h->cfg.input_compression;
+    rc = tb_run(h, a, work_dev, B, T, st);
+    if (rc != FE_OK) return rc;
+    size_t off[7];
+    tb_work_floats(h, B, T, off);
+    a.frames = work_dev + off[5];
+    const int n_out = d.HOP * (T - 1);
+    hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
+                       a.frames, h->tables_dev, wav_hat_dev, out_stride, d.NFFT, d.HOP, T, Tw_b_dev);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return FE_OK;
+}
+
 size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw) {
     if (!h || B <= 0 || Tw <= 0) return 0;
     const Dims& d = h->d;
@@ -1938,30 +1966,7 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
         return fail(FE_ERR_INVALID_ARG, "Tw=%d: reflect padding of n_fft/2=%d needs a longer input", Tw, d.NFFT / 2);
     hipStream_t st = (hipStream_t)stream;
     const int T = 1 + Tw / d.HOP;
-    if (use_tb_offline(h, B)) {
-        // the time-batched engine: encoder pass, per block (scan over time, attention pass), decoder pass, overlap-add
-        rc = ensure_tables(h, st);
-        if (rc != FE_OK) return rc;
-        fe::tb::TbArgs a{};
-        a.wp = h->packed_dev;
-        a.wav_in = noisy_dev; a.in_stride = (size_t)Tw; a.Tw = Tw;
-        a.spec_out = spec_hat_dev;
-        a.hstate = nullptr;                      // zero initial state (model.py:626-627)
-        a.mode = fe::FE_MODE_OFFLINE;
-        a.compression = h->cfg.input_compression;
-        rc = tb_run(h, a, work_dev, B, T, st);
-        if (rc != FE_OK) return rc;
-        size_t off[7];
-        tb_work_floats(h, B, T, off);
-        a.frames = work_dev + off[5];
-        hipError_t e = hipSuccess;
-        const int n_out = d.HOP * (T - 1);
-        hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
-                           a.frames, h->tables_dev, wav_hat_dev, (size_t)n_out, d.NFFT, d.HOP, T);
-        e = hipGetLastError();
-        if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
-        return FE_OK;
-    }
+    if (use_tb_offline(h, B)) return offline_tb(h, noisy_dev, (size_t)Tw, nullptr, Tw, B, wav_hat_dev, (size_t)d.HOP * (T - 1), spec_hat_dev, work_dev, st);
     {   // zero the state, the tail and the frame counters (not the frames: every element is written)
         size_t nz = (size_t)B * ((size_t)(d.NFFT - d.HOP) + d.hstate() + tk_floats(h));
         if (h->bimpl) nz = (size_t)B * (size_t)(d.NFFT - d.HOP) + ((bsrnn_lstm_floats(h, B) + 3) & ~(size_t)3) + (((size_t)B * h->cfg.rf_blocks + 3) & ~(size_t)3);
@@ -2163,6 +2168,54 @@ static fe::StftArgs stft_args(const fe_handle* h, int B) {
     a.compression = 1.0f;
     a.eps = 1.0e-5f;
     return a;
+}
+
+// spec_hat rows of an offline call: N/2 (FastEnhancer: the model drops the Nyquist bin) or N/2 + 1 (BSRNN / FSPEN / LiSenNet)
+static int offline_spec_rows(const fe_handle* h) { return h->d.NFFT / 2 + ((h->bimpl || h->fimpl || h->limpl) ? 1 : 0); }
+
+size_t fe_offline_ragged_work_floats(const fe_handle* h, int B, int Tw_max) {
+    if (!h || B <= 0 || Tw_max <= 0) return 0;
+    const int Tmax = 1 + Tw_max / h->d.HOP;
+    // the batched call's scratch (>= one utterance's), the per-utterance lengths, one utterance's spec_hat (the one-by-one fallback)
+    return fe_offline_work_floats(h, B, Tw_max) + (((size_t)B + 3) & ~(size_t)3) + (size_t)offline_spec_rows(h) * Tmax * 2;
+}
+
+int fe_offline_ragged(fe_handle* h, const float* noisy_dev, size_t in_stride, const int* Tw_host, int B, float* wav_hat_dev, size_t out_stride,
+                      float* spec_hat_dev, float* work_dev, void* stream) {
+    int rc = check_ready(h);
+    if (rc != FE_OK) return rc;
+    if (!noisy_dev || !Tw_host || !wav_hat_dev || !spec_hat_dev || !work_dev || B <= 0) return fail(FE_ERR_INVALID_ARG, "bad argument");
+    const Dims& d = h->d;
+    int Tw_max = 0;
+    for (int b = 0; b < B; ++b) {
+        if (Tw_host[b] <= d.NFFT / 2) return fail(FE_ERR_INVALID_ARG, "Tw[%d]=%d: reflect padding of n_fft/2=%d needs a longer input", b, Tw_host[b], d.NFFT / 2);
+        if ((size_t)Tw_host[b] > in_stride && B > 1) return fail(FE_ERR_INVALID_ARG, "Tw[%d]=%d > in_stride %zu", b, Tw_host[b], in_stride);
+        Tw_max = std::max(Tw_max, Tw_host[b]);
+    }
+    const int Tmax = 1 + Tw_max / d.HOP;
+    if (out_stride < (size_t)d.HOP * (Tmax - 1) && B > 1) return fail(FE_ERR_INVALID_ARG, "out_stride %zu < H*(Tmax-1)", out_stride);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t base = fe_offline_work_floats(h, B, Tw_max);
+    if (use_tb_offline(h, B)) {
+        // ONE batched call laid out for the longest utterance; every utterance's frames past its own end are computed on clamped input and
+        // stay out of its output (causal in time; the noncausal model's reverse scans start at each utterance's own last frame)
+        int* Tw_dev = reinterpret_cast<int*>(work_dev + base);
+        FE_HIP_CHECK(hipMemcpyAsync(Tw_dev, Tw_host, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+        return offline_tb(h, noisy_dev, in_stride, Tw_dev, Tw_max, B, wav_hat_dev, out_stride, spec_hat_dev, work_dev, st);
+    }
+    // no batched form for this model / engine setting (the frame walk and its time pipeline take ONE length per launch): one by one
+    const int F = offline_spec_rows(h);
+    float* spec_tmp = work_dev + base + (((size_t)B + 3) & ~(size_t)3);
+    for (int b = 0; b < B; ++b) {
+        const int Tb = 1 + Tw_host[b] / d.HOP;
+        float* dst = spec_hat_dev + (size_t)b * F * Tmax * 2;
+        rc = fe_offline(h, noisy_dev + (size_t)b * in_stride, 1, Tw_host[b], wav_hat_dev + (size_t)b * out_stride, Tb == Tmax ? dst : spec_tmp, work_dev, stream);
+        if (rc != FE_OK) return rc;
+        if (Tb != Tmax)
+            FE_HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)Tmax * 2 * sizeof(float), spec_tmp, (size_t)Tb * 2 * sizeof(float), (size_t)Tb * 2 * sizeof(float), (size_t)F,
+                                          hipMemcpyDeviceToDevice, st));
+    }
+    return FE_OK;
 }
 
 int fe_stft_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, const float* cache_in_dev, float* cache_out_dev,

@@ -153,17 +153,21 @@ __global__ void __launch_bounds__(kThreads) istft_frames_kernel(StftArgs a) {
 
 // torch.istft(center=True) tail (functional/audio_modules.py:117-119): y[pos] = sum_t frames[t][n - tH] / sum_t w^2[n - tH],
 // n = pos + N/2, for pos < H (T-1).  One thread per output sample; frames stay L2-resident between the two launches.
+// Tw_b != nullptr (ragged batch, fe_offline_ragged): utterance b has Tw_b[b] samples = Tb = 1 + Tw_b[b] / H frames of the T the batch is
+// laid out for; its output is H (Tb - 1) samples from its own frames only (the rest of its row is left untouched).
 __global__ void __launch_bounds__(kThreads) istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ win,
-                                                            float* __restrict__ wav_out, size_t out_stride, int N, int H, int T) {
+                                                            float* __restrict__ wav_out, size_t out_stride, int N, int H, int T,
+                                                            const int* __restrict__ Tw_b = nullptr) {
     const int b = blockIdx.y;
     const int pos = blockIdx.x * kThreads + threadIdx.x;
-    const int n_out = H * (T - 1);
+    const int Tb = Tw_b != nullptr ? 1 + Tw_b[b] / H : T;
+    const int n_out = H * (Tb - 1);
     if (pos >= n_out) return;
     const int n = pos + N / 2;
     int t_lo = (n - N + H) / H;            // ceil((n - N + 1) / H)
     t_lo = t_lo < 0 ? 0 : t_lo;
     int t_hi = n / H;
-    t_hi = t_hi > T - 1 ? T - 1 : t_hi;
+    t_hi = t_hi > Tb - 1 ? Tb - 1 : t_hi;
     const float* fr = frames + (size_t)b * T * N;
     float acc = 0.0f, env = 0.0f;
     for (int tt = t_lo; tt <= t_hi; ++tt) {

@@ -54,6 +54,8 @@ struct TbArgs {
     int Bfull, Tfull;           // utterances and frames per utterance of the whole call
     int h_init;                 // tb_scan_kernel: 1 = start from hstate (a later time chunk, or caches handed in), 0 = zero initial state
     int Tw;                     // offline: samples per utterance
+    const int* Tw_b;            // offline, ragged batch (fe_offline_ragged): samples of utterance b, [Bfull], every one <= Tw (the batch is laid out for
+                                // Tw: frames past an utterance's own 1 + Tw_b / H are computed on clamped input and never reach its output); nullptr: all Tw
     int mode;                   // FE_MODE_OFFLINE / FE_MODE_SPEC
     int k;                      // block index (tb_scan_kernel, tb_blk_kernel)
     float compression;
@@ -345,12 +347,14 @@ __global__ void __launch_bounds__(kThreads) tb_enc_kernel(TbArgs a) {
             g = g < a.NF ? g : a.NF - 1;
             const int bl = g / a.T, t = a.t0 + (g - bl * a.T), b = a.b0 + bl;
             const float* xin = a.wav_in + (size_t)b * a.in_stride;
+            const int Twb = a.Tw_b != nullptr ? a.Tw_b[b] : a.Tw;
 #pragma unroll
             for (int q = 0; q < NPT; ++q) {
                 const int n = tid + q * kThreads;
                 int idx = t * H + n - N / 2;
                 idx = idx < 0 ? -idx : idx;
-                idx = idx >= a.Tw ? 2 * (a.Tw - 1) - idx : idx;
+                idx = idx >= Twb ? 2 * (Twb - 1) - idx : idx;
+                idx = idx < 0 ? 0 : idx;             // (ragged batch: a frame past the utterance's end)
                 fv[f][q] = xin[idx];
             }
         }
@@ -400,13 +404,15 @@ __global__ void __launch_bounds__(kThreads) tb_enc_kernel(TbArgs a) {
                     float* sc = smem + L::SC + f * 2 * S::LDS_S;
                     float* xcg = a.xc + (size_t)g * (2 * F0);
                     const float* xin = a.wav_in + (size_t)b * a.in_stride;
+                    const int Twb = a.Tw_b != nullptr ? a.Tw_b[b] : a.Tw;
                     float fr[NPT];
 #pragma unroll
                     for (int q = 0; q < NPT; ++q) {
                         const int n = tid + q * kThreads;
                         int idx = t * H + n - N / 2;
                         idx = idx < 0 ? -idx : idx;
-                        idx = idx >= a.Tw ? 2 * (a.Tw - 1) - idx : idx;
+                        idx = idx >= Twb ? 2 * (Twb - 1) - idx : idx;
+                        idx = idx < 0 ? 0 : idx;
                         fr[q] = xin[idx];
                     }
 #pragma unroll
@@ -576,6 +582,7 @@ __device__ __forceinline__ void scan_role(const TbArgs& a, int rg, int dir, floa
     }
     // this lane's four rows (C/D layout: rows 4 lg + r - four consecutive sub-bands of one utterance: R % 4 == 0) and columns 16 ct + li
     bool rok[4];
+    int tb_last = 0x7fffffff;      // (noncausal, ragged batch) last frame of this lane's utterance
     size_t grow, hrow;             // element offsets of (the four rows, t = 0, channel 0) in gx / hs
     {
         int row = r0 + 4 * lg;
@@ -586,6 +593,9 @@ __device__ __forceinline__ void scan_role(const TbArgs& a, int rg, int dir, floa
         hrow = ((size_t)b * a.T * HW + dir * C2) * F2 + f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) rok[r] = ok;
+        // ragged batch, reverse direction: the utterance of this lane's rows ends at frame tb_last - the steps before it (t > tb_last)
+        // leave h at its zero initial state
+        if constexpr (S::BIDIR) { if (a.Tw_b != nullptr) tb_last = a.Tw_b[a.b0 + b] / S::HOP; }
     }
     const float* gxd = a.gx + (size_t)dir * a.NF * F2 * N3;
     // carried state [KB][ND][Bfull * F2][C2]: this node's rows start at utterance b0
@@ -669,7 +679,8 @@ __device__ __forceinline__ void scan_role(const TbArgs& a, int rg, int dir, floa
                 const float rr = sigmoid_pre(acc[j][0][r]);
                 const float zz = sigmoid_pre(acc[j][1][r]);
                 const float nn = tanh_pre(__builtin_fmaf(rr, acc[j][2][r], gxv[d][j][2][r]));
-                const float hv = __builtin_fmaf(zz, hprev[j][r] - nn, nn);          // (1 - z) n + z h
+                float hv = __builtin_fmaf(zz, hprev[j][r] - nn, nn);                // (1 - z) n + z h
+                if constexpr (S::BIDIR) { if (dir && t_first - st > tb_last) hv = 0.0f; }
                 hprev[j][r] = hv;
                 hn[(4 * lg + r) * LDX + hcol[j]] = hv;
             }
@@ -766,6 +777,8 @@ __global__ void __launch_bounds__(kThreads) tb_scan4_kernel(TbArgs a) {
     const size_t hrow = ((size_t)b * a.T * HW + dir * C2) * F2 + f;
     const float* gxd = a.gx + (size_t)dir * a.NF * F2 * N3;
     float* hst = a.hstate ? a.hstate + (((size_t)(k * S::ND + dir) * a.Bfull + a.b0) * F2) * C2 : nullptr;
+    int tb_last = 0x7fffffff;      // (noncausal, ragged batch) last frame of this row's utterance: see tb_scan_kernel
+    if constexpr (S::BIDIR) { if (a.Tw_b != nullptr) tb_last = a.Tw_b[a.b0 + b] / S::HOP; }
     float hprev[NSET];
 #pragma unroll
     for (int s = 0; s < NSET; ++s) {
@@ -840,7 +853,8 @@ __global__ void __launch_bounds__(kThreads) tb_scan4_kernel(TbArgs a) {
             const float rr = sigmoid_pre(gxv[s][0] + tot[0]);
             const float zz = sigmoid_pre(gxv[s][1] + tot[1]);
             const float nn = tanh_pre(__builtin_fmaf(rr, tot[2] + bhn[s], gxv[s][2]));
-            const float hv = __builtin_fmaf(zz, hprev[s] - nn, nn);
+            float hv = __builtin_fmaf(zz, hprev[s] - nn, nn);
+            if constexpr (S::BIDIR) { if (dir && t_first - st > tb_last) hv = 0.0f; }
             hprev[s] = hv;
             if (ok[s]) { hn[hoff[s]] = hv; *hsp[s] = hv; }
             hsp[s] += hstep;

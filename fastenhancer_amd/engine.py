@@ -308,6 +308,32 @@ class Engine:
                        "fe_offline")
         return wav, spec
 
+    def offline_ragged(self, noisy: List[Tensor]) -> Tuple[List[Tensor], List[Tensor]]:
+        """Model.forward over utterances of different lengths in ONE call (fe_offline_ragged; the reference enhances a directory file by
+        file, scripts/test_pytorch.py:28-37): noisy = B tensors [Tw_b] (or [1, Tw_b]) -> (B wavs [H * (Tw_b // H)], B specs [F, T_b, 2])."""
+        self._require_gpu()
+        cfg, dev = self.cfg, self.device
+        xs = [t.reshape(-1).to(dev, torch.float32) for t in noisy]
+        B = len(xs)
+        lens = [int(t.numel()) for t in xs]
+        Tw = max(lens)
+        Tmax = 1 + Tw // cfg.hop_size
+        F = cfg.F0 + (1 if (self.is_bsrnn or self.is_fspen or self.is_lisennet) else 0)
+        batch = torch.zeros(B, Tw, dtype=torch.float32, device=dev)
+        for b, t in enumerate(xs):
+            batch[b, :lens[b]] = t
+        n_out = cfg.hop_size * (Tmax - 1)
+        wav = torch.zeros(B, n_out, dtype=torch.float32, device=dev)
+        spec = torch.empty(B, F, Tmax, 2, dtype=torch.float32, device=dev)
+        work = torch.empty(int(self.lib.fe_offline_ragged_work_floats(self._h, B, Tw)), dtype=torch.float32, device=dev)
+        self._last_work = work
+        lens_c = (ctypes.c_int * B)(*lens)
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.fe_offline_ragged(self._h, _ptr(batch), Tw, lens_c, B, _ptr(wav), n_out, _ptr(spec), _ptr(work), _stream(dev)),
+                       "fe_offline_ragged")
+        Tb = [1 + n // cfg.hop_size for n in lens]
+        return [wav[b, :cfg.hop_size * (Tb[b] - 1)] for b in range(B)], [spec[b, :, :Tb[b]] for b in range(B)]
+
     # ------------------------------------------------------------------ stand-alone STFT / iSTFT (the `.stft` modules)
     def stft_step(self, wav_in: Tensor, cache: Tensor) -> Tuple[Tensor, Tensor]:
         """ONNXSTFT.forward: wav_in [B, H], cache [B, N-H] -> (spec [B, N/2+1, 1, 2], cache'); inputs untouched."""

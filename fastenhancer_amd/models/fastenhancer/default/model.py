@@ -139,6 +139,8 @@ class Model(ONNXModel):
         """One fused launch sequence (fe_offline): centered STFT, all T frames, envelope-normalised overlap-add;
         returns (wav_hat [B, H*(Tw//H)], spec_hat [B, F0, T, 2]).  ``self.stft`` / ``self.stft.inverse`` give the
         front / back end alone."""
+        if isinstance(noisy, (list, tuple)):      # utterances of different lengths, one batched call: (list of wavs, list of specs)
+            return self.engine.offline_ragged(list(noisy))
         return self.engine.offline(noisy.to(self.engine.device))
 
     __call__ = forward

@@ -30,6 +30,8 @@ class Model(_default.ONNXModel):
 
     def forward(self, noisy: Tensor):
         """noncausal/model.py:628-635: noisy [B, T_wav] -> (wav_hat [B, H*(Tw//H)], spec_hat [B, F0, T, 2])"""
+        if isinstance(noisy, (list, tuple)):      # utterances of different lengths, one batched call: (list of wavs, list of specs)
+            return self.engine.offline_ragged(list(noisy))
         return self.engine.offline(noisy.to(self.engine.device))
 
     __call__ = forward

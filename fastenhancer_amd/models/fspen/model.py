@@ -98,6 +98,8 @@ class Model(ONNXModel):
         return CompressedSTFT(self, self.cfg, discard_last_freq_bin=False)
 
     def forward(self, noisy: Tensor):
+        if isinstance(noisy, (list, tuple)):      # utterances of different lengths, one batched call: (list of wavs, list of specs)
+            return self.engine.offline_ragged(list(noisy))
         return self.engine.offline(noisy.to(self.engine.device))
 
     __call__ = forward

@@ -24,6 +24,9 @@ def main(argv=None):
     p.add_argument("-i", "--input-dir", type=str, required=True)
     p.add_argument("-o", "--output-dir", type=str, default="enhanced/dns")
     p.add_argument("--device", type=str, default="cuda:0")
+    p.add_argument("--batch", type=int, default=64,
+                   help="files per Model.forward call: the directory is sorted by length and pushed through in ragged batches of this many "
+                        "(fe_offline_ragged; every file's result is what its own call would give); 1 = file by file like the reference")
     args = p.parse_args(argv)
 
     out_dir = Path(args.output_dir)
@@ -35,11 +38,21 @@ def main(argv=None):
         raise FileNotFoundError(f"no checkpoint [0-9]{{5,}}.pth under logs/{args.name}")
     model = build_model(hps, args.device, offline=True, checkpoint=ckpt)
     files = sorted(Path(args.input_dir).glob("*.wav"))
-    for path in files:
-        noisy = torch.from_numpy(read_wav(str(path), sr)).float().to(args.device).unsqueeze(0)
-        with torch.no_grad():
-            enhanced, _ = model(noisy)                                      # return: wav, spec
-        write_wav(str(out_dir / path.name), sr, enhanced.squeeze().cpu().numpy())
+    if args.batch <= 1:
+        for path in files:
+            noisy = torch.from_numpy(read_wav(str(path), sr)).float().to(args.device).unsqueeze(0)
+            with torch.no_grad():
+                enhanced, _ = model(noisy)                                      # return: wav, spec
+            write_wav(str(out_dir / path.name), sr, enhanced.squeeze().cpu().numpy())
+    else:
+        # sorted by length, so that a batch is laid out for little more than its own frames
+        wavs = sorted(((read_wav(str(path), sr), path) for path in files), key=lambda wp: len(wp[0]))
+        for i in range(0, len(wavs), args.batch):
+            chunk = wavs[i:i + args.batch]
+            with torch.no_grad():
+                enhanced, _ = model([torch.from_numpy(w).float() for w, _ in chunk])
+            for (_, path), e in zip(chunk, enhanced):
+                write_wav(str(out_dir / path.name), sr, e.cpu().numpy())
     print(f"enhanced {len(files)} file(s) -> {out_dir}")
 
 

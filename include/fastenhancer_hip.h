@@ -196,6 +196,20 @@ size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw);
 int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_hat_dev,
                float* spec_hat_dev, float* work_dev, void* stream);
 
+/* The same for a batch of utterances of DIFFERENT lengths - what the reference's offline caller does file by file
+ * (scripts/test_pytorch.py:28-37: one Model.forward per file of the directory): utterance b = noisy_dev[b * in_stride + n],
+ * n < Tw_host[b] (a HOST array, read before the call returns); wav_hat_dev[b * out_stride + n], n < H * (Tw[b] / H), the rest of a row is
+ * left untouched; spec_hat_dev [B, F, Tmax, 2] with Tmax = 1 + max(Tw) / H (F = N/2 for FastEnhancer), the frames of an utterance past
+ * its own 1 + Tw[b] / H unspecified.  On the time-batched engine (the default FastEnhancer model and the noncausal one) this is ONE
+ * batched pass laid out for the longest utterance - every utterance's result is bit-identical to its own fe_offline call on that engine
+ * (frames are rows of the layer GEMMs, scans are per row; the reflect padding, the reverse scans of the noncausal model and the
+ * overlap-add use each utterance's own length); sort a directory by length to keep the padding small.  The other models / variants
+ * and FE_OFFLINE_FRAME_WALK have no batched form (one length per launch): the call runs them one utterance after the other.
+ * work_dev: fe_offline_ragged_work_floats(B, max(Tw)) floats. */
+size_t fe_offline_ragged_work_floats(const fe_handle* h, int B, int Tw_max);
+int fe_offline_ragged(fe_handle* h, const float* noisy_dev, size_t in_stride, const int* Tw_host, int B, float* wav_hat_dev, size_t out_stride,
+                      float* spec_hat_dev, float* work_dev, void* stream);
+
 /* The STFT front / back ends as launches of their own - the modules the reference exposes as `model.stft` and that
  * scripts/export_onnx.py:55-57 composes line by line (inside fe_step / fe_offline they are fused into the frame kernel).
  * No weights needed.  Streaming, one hop (ONNXSTFT.forward / .inverse, functional/audio_modules.py:243-303):

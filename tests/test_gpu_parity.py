@@ -858,6 +858,69 @@ def test_command_line_callers(tmp_path, monkeypatch):
     _assert_close(ys, orc.enhance_stream(x[None])[0], "test_streaming CLI")
 
 
+@pytest.mark.parametrize("name,n_files", [("fe_b", 40), ("fe_t", 9), ("fe_nc", 6), ("fe_tk_b", 3), ("bsrnn_xt", 3)])
+def test_ragged_offline_batch_is_bit_identical_to_one_call_per_utterance(name, n_files):
+    """fe_offline_ragged (Model.forward on a LIST of utterances - what scripts/test_pytorch.py:28-37 does file by file): n files of
+    different lengths in one batched call give, bit for bit, what each file's own call gives.  fe_b / fe_t / fe_nc run ONE batched pass of
+    the time-batched engine (per-utterance reflect padding, reverse-scan start and overlap-add); fe_tk_b / bsrnn_xt have no batched form
+    and are walked one after the other inside the call.  A sample of the files is also checked against the oracle."""
+    if name.startswith("bsrnn"):
+        m, orc, cfg, sr, seed = _bsrnn(name, "Model")
+    else:
+        m, orc, cfg, sr, seed = _model(name, "Model")
+    eng = m.engine
+    if name in TB_SHAPES:
+        eng.set_offline_engine("time_batched")
+    rng = np.random.default_rng(5)
+    H = cfg.hop_size
+    lens = [int(v) for v in rng.integers(cfg.n_fft // 2 + 1 + 3 * H, 60 * H, size=n_files)]
+    lens[0] = 23 * H                       # a whole number of hops
+    lens[1] = max(lens) + 5                # the longest
+    lens[2] = cfg.n_fft // 2 + 1           # the shortest a centered STFT takes
+    xs = [make_input(1, n, 100 + i, sr)[0] for i, n in enumerate(lens)]
+    wavs, specs = m([torch.from_numpy(x) for x in xs])
+    assert len(wavs) == len(specs) == n_files
+    for i, x in enumerate(xs):
+        w1, s1 = m(torch.from_numpy(x)[None].to(_dev()))
+        assert wavs[i].shape == w1[0].shape and specs[i].shape == s1[0].shape, (i, wavs[i].shape, w1.shape)
+        assert torch.equal(wavs[i], w1[0]), (i, lens[i], float((wavs[i] - w1[0]).abs().max()))
+        assert torch.equal(specs[i], s1[0]), (i, lens[i])
+    for i in (0, 1, n_files - 1):
+        wav_ref, spec_ref = orc.offline_forward(xs[i][None])
+        _assert_close(wavs[i].cpu().numpy(), wav_ref[0], f"ragged batch, file {i} vs oracle")
+        _assert_close(specs[i].cpu().numpy(), spec_ref[0], f"ragged batch, file {i} spec vs oracle")
+    if name in TB_SHAPES:
+        eng.set_offline_engine("auto")
+
+
+def test_offline_cli_pushes_a_directory_through_in_ragged_batches(tmp_path, monkeypatch):
+    """scripts/test_offline.py --batch: a directory of files of different lengths, sorted by length and enhanced in ragged batches, writes
+    the same samples as file-by-file calls (--batch 1, the reference's loop)."""
+    import yaml
+    from scipy.io import wavfile
+    from fastenhancer_amd.scripts import test_offline
+    name = "fe_b"
+    kw, sr, seed = MODEL_KWARGS[name]
+    cfg, sd, fused, orc = build_oracle(name)
+    logs = tmp_path / "logs" / "run"
+    logs.mkdir(parents=True)
+    (logs / "config.yaml").write_text(yaml.safe_dump({"model": "fastenhancer.default", "model_kwargs": kw, "data": {"sampling_rate": sr}}))
+    torch.save({"model": {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, "epoch": 3}, str(logs / "00003.pth"))
+    noisy_dir = tmp_path / "noisy"
+    noisy_dir.mkdir()
+    rng = np.random.default_rng(11)
+    for i, n in enumerate(rng.integers(2000, 30000, size=11)):
+        wavfile.write(str(noisy_dir / f"f{i:02d}.wav"), sr, make_input(1, int(n), 300 + i, sr)[0])
+    monkeypatch.chdir(tmp_path)
+    test_offline.main(["-n", "run", "-i", str(noisy_dir), "-o", str(tmp_path / "batched"), "--batch", "4"])
+    test_offline.main(["-n", "run", "-i", str(noisy_dir), "-o", str(tmp_path / "single"), "--batch", "1"])
+    for i in range(11):
+        ra, ya = wavfile.read(str(tmp_path / "batched" / f"f{i:02d}.wav"))
+        rb, yb = wavfile.read(str(tmp_path / "single" / f"f{i:02d}.wav"))
+        assert ra == rb == sr and ya.shape == yb.shape
+        assert np.abs(ya - yb).max() <= 2e-6 * max(1.0, np.abs(yb).max()), i      # (file by file the engine is chosen per call: AUTO)
+
+
 # ------------------------------------------------------------------------------------------------ BSRNN (a22-a25)
 def _bsrnn(name, cls="ONNXModel"):
     from common import BSRNN_KWARGS, build_bsrnn_oracle
