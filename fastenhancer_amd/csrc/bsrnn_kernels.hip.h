@@ -108,6 +108,7 @@ struct BArgs {
     float* mlp_x;
     float* mlp_sp;
     float* mlp_pre;
+    float* sb_y;              // stream-batched layers (bsrnn_sb_kernels.hip.h): the band LSTM's outputs of the running layer [B][2][31][HH]
 };
 
 // debug stage table: spec_in, compressed, band_split, (layer.l.time, layer.l.freq)..., mask_mlp, spec_out
@@ -170,13 +171,15 @@ template <class S, bool HOT, bool PROF, bool DBG, bool OCC2 = false, bool PIPE =
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, OCC2 ? 2 : 1))) bsrnn_frame_kernel(BArgs a) {
     static_assert(!PIPE || (!HOT && !PROF && !DBG), "the time-pipelined instantiation is the plain offline kernel");
     static_assert(PART == 0 || (HOT && !PROF && !DBG && !PIPE), "the split step is the per-hop streaming step");
+    // PART = 3: the front of the frame alone (STFT, compress, band split -> mlp_x / mlp_sp): the stream-batched step
+    // (bsrnn_sb_kernels.hip.h) runs the layers for sixteen streams per workgroup on the matrix cores
     const int aT = HOT ? 1 : a.T;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = BLds<S>;
     constexpr int N = S::NFFT, H = S::HOP, OVL = S::OVL, C = S::C, HH = S::HH, G4 = S::G4;
     constexpr int LDX = S::LDX, LDH = S::LDH, LDY = S::LDY, LDP = S::LDP, LDH1 = S::LDH1;
     constexpr int KSC = S::KSC, KSH = S::KSH, KS1 = S::KS1;
-    constexpr bool REGW = S::REGW && !OCC2;
+    constexpr bool REGW = S::REGW && !OCC2 && PART != 3;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
@@ -375,7 +378,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         // time-LSTM state of layer 0 (the later layers' is fetched under the previous layer's recurrence)
         constexpr int HPT = (kBands * HH + kThreads - 1) / kThreads;
         float hpre[HPT];
-        if constexpr (!PIPE) {
+        if constexpr (!PIPE && PART != 3) {
             const float* hg0 = a.lstm + (size_t)b * (kBands * HH);
 #pragma unroll
             for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = hg0[i < kBands * HH ? i : kBands * HH - 1]; }
@@ -389,7 +392,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         dump(2, X, LDX);
 
 #pragma unroll 1
-        for (int l = 0; l < S::NLAY; ++l) {
+        for (int l = 0; l < (PART == 3 ? 0 : S::NLAY); ++l) {
             float* hg = a.lstm + ((size_t)(2 * l) * a.B + b) * (kBands * HH);
             float* cg = a.lstm + ((size_t)(2 * l + 1) * a.B + b) * (kBands * HH);
             if (l == 0) BE_CLK(2);
@@ -759,8 +762,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 
         }      // (PART != 2)
         BE_CLK(8);
-        if constexpr (PART == 1) {
-            // hand-over to bsrnn_mlp_kernel / the PART 2 launch
+        if constexpr (PART == 1 || PART == 3) {
+            // hand-over to bsrnn_mlp_kernel / the PART 2 launch (PART 3: to bsrnn_sb_layers_kernel first)
             float* xg = a.mlp_x + (size_t)b * (kBands * C);
             for (int i = tid; i < kBands * C; i += kThreads) { const int bb = i / C; xg[i] = X[bb * LDX + (i - bb * C)]; }
             float* sg = a.mlp_sp + (size_t)b * (2 * kBins);
@@ -1103,6 +1106,7 @@ __global__ void __launch_bounds__(kThreads) bsrnn_mlp_kernel(BArgs a) {
     }
 }
 
+struct SbOffsets;
 struct BImpl {
     int C, NLAY, HOP;
     size_t lds_bytes;
@@ -1117,6 +1121,9 @@ struct BImpl {
     void (*launch_pipe)(const BArgs&, hipStream_t, hipError_t*);       // time-pipelined offline launch (cooperative: B * pipe_p workgroups)
     int occ;                  // workgroups per CU the LDS plan allows
     void (*launch_split)(const BArgs&, int max_wgs, hipStream_t, hipError_t*);   // the per-hop step as three launches (mlp_x / mlp_sp / mlp_pre set)
+    // the per-hop step with the layers batched over the streams (bsrnn_sb_kernels.hip.h): front (PART 3) -> layers -> mask-decoder MLP -> tail
+    // (PART 2); nullptr where the stream-batched layers are not built (num_channels > 16)
+    void (*launch_sb)(const BArgs&, const SbOffsets&, int total_floats, int max_wgs, hipStream_t, hipError_t*);
 };
 
 template <class S, bool HOT, bool PROF, bool DBG, bool OCC2 = false>
@@ -1168,6 +1175,10 @@ void blaunch_part(const BArgs& a, int grid, hipStream_t st, hipError_t* err) {
     *err = hipGetLastError();
 }
 
+}  // namespace fe
+#include "bsrnn_sb_kernels.hip.h"
+namespace fe {
+
 // the per-hop streaming step (mode = stream, T = 1) as head -> batched mask-decoder MLP -> tail
 template <class S>
 void blaunch_split_impl(const BArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
@@ -1190,6 +1201,40 @@ void blaunch_split_impl(const BArgs& a, int max_wgs, hipStream_t st, hipError_t*
         *err = hipGetLastError();
         if (*err != hipSuccess) return;
     }
+    if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 2>(a, a.B < 2 * max_wgs ? a.B : 2 * max_wgs, st, err);
+    else blaunch_part<S, false, 2>(a, a.B < max_wgs ? a.B : max_wgs, st, err);
+}
+
+template <class S>
+void blaunch_mlp(const BArgs& a, hipStream_t st, hipError_t* err) {
+    auto* fn = &bsrnn_mlp_kernel<S>;
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev].load(std::memory_order_relaxed)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BMlpLds<S>::BYTES);
+        if (e != hipSuccess) { *err = e; return; }
+        attr_set[dev].store(true, std::memory_order_relaxed);
+    }
+    const int groups = (a.B + 16 * kWaves - 1) / (16 * kWaves);
+    hipLaunchKernelGGL(fn, dim3(2 * kBands * groups), dim3(kThreads), BMlpLds<S>::BYTES, st, a);
+    *err = hipGetLastError();
+}
+
+// the per-hop step of a LARGE batch: front per stream (PART 3), the LSTM layers for sixteen streams per workgroup on the matrix
+// cores (bsrnn_sb_layers_kernel), the batched mask-decoder MLP, the tail per stream (PART 2)
+template <class S>
+void blaunch_sb_impl(const BArgs& a, const SbOffsets& so, int total_floats, int max_wgs, hipStream_t st, hipError_t* err) {
+    constexpr bool FITS2 = 2 * BLds<S>::BYTES <= 160 * 1024 && !S::XPG;
+    if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 3>(a, a.B < 2 * max_wgs ? a.B : 2 * max_wgs, st, err);
+    else blaunch_part<S, false, 3>(a, a.B < max_wgs ? a.B : max_wgs, st, err);
+    if (*err != hipSuccess) return;
+    SbArgs sa{};
+    sa.wp = a.wp; sa.off = so; sa.x = a.mlp_x; sa.lstm = a.lstm; sa.y = a.sb_y; sa.B = a.B; sa.total = total_floats;
+    sb_launch_layers<S>(sa, st, err);
+    if (*err != hipSuccess) return;
+    blaunch_mlp<S>(a, st, err);
+    if (*err != hipSuccess) return;
     if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 2>(a, a.B < 2 * max_wgs ? a.B : 2 * max_wgs, st, err);
     else blaunch_part<S, false, 2>(a, a.B < max_wgs ? a.B : max_wgs, st, err);
 }
@@ -1222,7 +1267,7 @@ BImpl make_bimpl() {
     return BImpl{S::C, S::NLAY, S::HOP, BLds<S>::BYTES, S::XPG ? (size_t)2 * 32 * S::G4 : (size_t)0,
                  BDebugLayout<S>::total(), BDebugLayout<S>::n_stages, S::WREG, S::KSPLIT, S::NTD, &blaunch_impl<S>, &bdbg_stage_impl<S>,
                  &blaunch_pipe_impl<S>, 1,       // (the PIPE instantiation is compiled for one workgroup per CU: waves_per_eu(1, 1))
-                 &blaunch_split_impl<S>};
+                 &blaunch_split_impl<S>, SbLds<S>::FITS ? &blaunch_sb_impl<S> : nullptr};
 }
 
 }  // namespace fe

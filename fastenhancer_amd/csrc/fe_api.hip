@@ -111,6 +111,8 @@ struct fe_handle {
     const fe::FImpl* fimpl = nullptr;     // arch == FE_ARCH_FSPEN
     const fe::LImpl* limpl = nullptr;     // arch == FE_ARCH_LISENNET
     fe::BOffsets boff{};
+    fe::SbOffsets sboff{};                    // stream-batched BSRNN layers (bsrnn_sb_kernels.hip.h), where built
+    int packed_floats = 0;                    // floats of packed_dev (BSRNN)
     int device = 0;
     int max_wgs = 256;             // CUs of the device: one resident workgroup per CU (persistent grid above that)
     int pipe_frames = -1;          // fe_set_time_pipeline (-1: chosen from the model size)
@@ -738,6 +740,58 @@ int pack_weights_bsrnn(fe_handle* h, const std::vector<float>& blob, std::vector
             memcpy(&buf[o.ffc_b[l]], S(key("fc_freq.%d.bias")), C * sizeof(float));
         }
     }
+    if (h->bimpl->launch_sb) {
+        // stream-batched layers (bsrnn_sb_kernels.hip.h): the weights as A fragments of the TRANSPOSED products.  Feature permutations:
+        // k-step ks, lane group lg carries channel KSC lg + ks / hidden unit KSH lg + ks; row 4 lg' + r of gate tile t = (unit KSH lg' + t,
+        // gate r); row 4 lg' + r of fc output tile `to` = channel KSC lg' + 4 to + r.
+        fe::SbOffsets& so = h->sboff;
+        const int KSC = C / 4, KSH = HH / 4, KS1 = KSC + KSH, NTO = C / 16;
+        auto pack_lstm = [&](const float* wih, const float* whh, const float* bi, const float* bh, int* w_off, int* b_off) {
+            *w_off = alloc((size_t)KSH * KS1 * 64);
+            *b_off = alloc((size_t)KSH * 16);
+            for (int t = 0; t < KSH; ++t) {
+                for (int ks = 0; ks < KS1; ++ks)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int rho = lane % 16, lgk = lane / 16, row = (rho % 4) * HH + KSH * (rho / 4) + t;
+                        const float v = ks < KSC ? wih[(size_t)row * C + KSC * lgk + ks] : whh[(size_t)row * HH + KSH * lgk + (ks - KSC)];
+                        buf[*w_off + ((size_t)t * KS1 + ks) * 64 + lane] = gscale(row) * v;
+                    }
+                for (int lg = 0; lg < 4; ++lg)
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = r * HH + KSH * lg + t;
+                        buf[*b_off + t * 16 + lg * 4 + r] = gscale(row) * (bi[row] + bh[row]);
+                    }
+            }
+        };
+        auto pack_fc = [&](const float* w, int ld, int col0, int* w_off) {       // rows = channels, columns col0 .. col0 + HH - 1 of a (C, ld) matrix
+            *w_off = alloc((size_t)NTO * KSH * 64);
+            for (int to = 0; to < NTO; ++to)
+                for (int ks = 0; ks < KSH; ++ks)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int rho = lane % 16, lgk = lane / 16, ch = KSC * (rho / 4) + 4 * to + rho % 4;
+                        buf[*w_off + ((size_t)to * KSH + ks) * 64 + lane] = w[(size_t)ch * ld + col0 + KSH * lgk + ks];
+                    }
+        };
+        auto pack_fc_bias = [&](const float* b, int* b_off) {
+            *b_off = alloc((size_t)NTO * 16);
+            for (int to = 0; to < NTO; ++to)
+                for (int lg = 0; lg < 4; ++lg)
+                    for (int r = 0; r < 4; ++r) buf[*b_off + to * 16 + lg * 4 + r] = b[KSC * lg + 4 * to + r];
+        };
+        for (int l = 0; l < L; ++l) {
+            auto key = [&](const char* fmt) { snprintf(nm, sizeof nm, fmt, l); return std::string(nm); };
+            pack_lstm(S(key("rnn_time.%d.weight_ih")), S(key("rnn_time.%d.weight_hh")), S(key("rnn_time.%d.bias_ih")), S(key("rnn_time.%d.bias_hh")), &so.t_w[l], &so.t_b[l]);
+            pack_fc(S(key("fc_time.%d.weight")), HH, 0, &so.tfc_w[l]);
+            pack_fc_bias(S(key("fc_time.%d.bias")), &so.tfc_b[l]);
+            for (int d = 0; d < 2; ++d) {
+                const char* sfx = d ? "_reverse" : "";
+                auto keyd = [&](const char* stem) { snprintf(nm, sizeof nm, "rnn_freq.%d.%s_l0%s", l, stem, sfx); return std::string(nm); };
+                pack_lstm(S(keyd("weight_ih")), S(keyd("weight_hh")), S(keyd("bias_ih")), S(keyd("bias_hh")), &so.f_w[l][d], &so.f_b[l][d]);
+                pack_fc(S(key("fc_freq.%d.weight")), 2 * HH, d * HH, &so.ffc_w[l][d]);
+            }
+            pack_fc_bias(S(key("fc_freq.%d.bias")), &so.ffc_b[l]);
+        }
+    }
     const char* kinds[2] = {"mlp_mask", "mlp_residual"};
     for (int kind = 0; kind < 2; ++kind) {
         o.m_w1[kind] = alloc((size_t)31 * 4 * C * C);      // [band][k/4][o] float4
@@ -788,6 +842,7 @@ int pack_weights_bsrnn(fe_handle* h, const std::vector<float>& blob, std::vector
     o.window_istft = alloc(h->window_istft.size()); memcpy(&buf[o.window_istft], h->window_istft.data(), h->window_istft.size() * sizeof(float));
     o.twiddle = alloc(h->twiddle.size()); memcpy(&buf[o.twiddle], h->twiddle.data(), h->twiddle.size() * sizeof(float));
     o.total = (int)((buf.size() + 63) & ~(size_t)63);
+    h->packed_floats = o.total;
     buf.resize(o.total, 0.0f);
     *out = std::move(buf);
     return FE_OK;
@@ -1241,7 +1296,9 @@ fe::BArgs bsrnn_args(fe_handle* h, int B, int T) {
 // The per-hop BSRNN step runs as three launches (bsrnn_kernels.hip.h, PART): per stream 31 C floats of band features, 514 of compressed
 // spectrum and 2056 of MLP pre-activations pass through this scratch.  Grow-only; fe_state_init sizes it for its batch, so that a
 // steady-state step allocates nothing (FE_BSRNN_SPLIT=0: the fused kernel, for A/B measurements).
-size_t bsplit_floats_per_stream(const fe_handle* h) { return (size_t)31 * h->cfg.channels + 2 * 257 + 2 * 1028; }
+size_t bsplit_floats_per_stream(const fe_handle* h) {
+    return (size_t)31 * h->cfg.channels + 2 * 257 + 2 * 1028 + (h->bimpl->launch_sb ? (size_t)2 * 31 * 2 * h->cfg.channels : 0);      // (+ the stream-batched layers' y scratch)
+}
 int ensure_bsplit(fe_handle* h, int B) {
     if (!h->bimpl || B <= h->bsplit_streams) return FE_OK;
     static const bool off = [] { const char* e = getenv("FE_BSRNN_SPLIT"); return e && e[0] == '0'; }();
@@ -1262,6 +1319,12 @@ int launch_bsrnn(fe_handle* h, const fe::BArgs& a_in, void* stream) {
             a.mlp_x = h->bsplit_dev;
             a.mlp_sp = a.mlp_x + (size_t)a.B * 31 * h->cfg.channels;
             a.mlp_pre = a.mlp_sp + (size_t)a.B * 2 * 257;
+            a.sb_y = a.mlp_pre + (size_t)a.B * 2 * 1028;
+            // large batches: the LSTM layers batched over the streams on the matrix cores (sixteen streams per workgroup) - from the batch
+            // size where sixteen-stream workgroups fill the chip better than one stream per workgroup (FE_BSRNN_SB: that threshold; 0 = never)
+            static const int sb_min = [] { const char* v = getenv("FE_BSRNN_SB"); return v ? atoi(v) : 2560; }();      // (measured crossover on 256 CUs: 0.55 ms per step up to 4096 streams against 0.22 us per stream)
+            if (h->bimpl->launch_sb && sb_min > 0 && a.B >= sb_min) h->bimpl->launch_sb(a, h->sboff, h->packed_floats, h->max_wgs, (hipStream_t)stream, &e);
+            else
             h->bimpl->launch_split(a, h->max_wgs, (hipStream_t)stream, &e);
             if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
             return FE_OK;

@@ -1115,6 +1115,17 @@ def test_bsrnn_more_streams_than_cus():
     _full_size_check(m, orc, cfg, sr, 300, 3, [0, 1, 43, 44, 255, 256, 257, 299], "bsrnn_xxt B=300")
 
 
+@pytest.mark.parametrize("name,B", [("bsrnn_xt", 2605), ("bsrnn_xxt", 4096)])
+def test_bsrnn_stream_batched_layers_above_2560_streams(name, B):
+    """From 2560 streams the per-hop step runs its LSTM layers batched over the streams on the matrix cores (bsrnn_sb_kernels.hip.h:
+    front per stream, sixteen streams per workgroup through the layers, batched mask-decoder MLP, tail per stream).  2605 streams = a
+    last tile of 13.  Oracle parity (outputs and every time-LSTM cache) on a sample that covers first / last tiles and columns, and
+    bitwise position independence on all streams (_full_size_check runs the batch again in reversed order: every stream then sits
+    in another tile and another column)."""
+    m, orc, cfg, sr, seed = _bsrnn(name)
+    _full_size_check(m, orc, cfg, sr, B, 3, [0, 1, 15, 16, 17, 1000, 2047, B - 14, B - 13, B - 2, B - 1], f"{name} B={B}")
+
+
 def test_bsrnn_split_step_with_ragged_stream_tiles():
     """the per-hop step in three launches (frame kernel head, mask-decoder MLPs batched over the streams, tail): 1030 streams = two
     persistent workgroups per CU in the head / tail and a last MLP stream tile of 6 rows (16-stream tiles, 64-stream workgroups);
