@@ -1395,14 +1395,21 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
         // (Measured on the kernels with a frame loop: FastEnhancer_B 46.0 -> 44.1 us per frame, T 21.2 -> 20.5 us,
         //  S +29 %, M +1 %; L - whose frames re-derive far more offsets than it has SGPRs to save - loses 7 %.)
         int lz = 0;
-        if constexpr (S::C1 <= 96) asm volatile("" : "+s"(lz));
+        // r4: the big shapes (C1 > 96: L, 48 kHz L, dprnn L) get it too in the instantiations that HAVE a frame / stream loop (persistent,
+        // generic, time-pipelined) - r1's "L loses 7 %" was measured when one instantiation served everything.  FastEnhancer_L:
+        // SGPR spills 2322 / 2371 / 2380 -> 37 / 93 / 119, VGPR spills 114 / 205 / 75 -> 0 (with the per-lane zero below);
+        // 512 / 1024 streams 60.2 / 60.8 % -> 65.3 / 65.4 % of the fp32 peak, 16 x 4 s offline (frame walk) 16.1 -> 15.5 ms.
+#ifndef FE_LZ_BIG
+#define FE_LZ_BIG 1      // (0: r3's behaviour, for A/B builds)
+#endif
+        if constexpr (S::C1 <= 96 || (FE_LZ_BIG && (PERSIST || PIPE || !T1))) asm volatile("" : "+s"(lz));
         const int wave = wave0 + lz;
         // LOW = 2 companions (256 VGPRs, operands streamed from L2): the same for the per-lane offsets - hoisted out of the
         // stream loop they stay live through the whole frame and the persistent instantiation spills (S: 167 -> 92 VGPRs,
         // 48 kHz B: 73 -> 14; +12 % / +15 % at 1024 streams).  Kernels that fit anyway pay for the re-derived offsets
         // (B companion -3 %, T -7 %): not applied there.
         int lzv = 0;
-        if constexpr (PERSIST && S::LOW == 2) asm volatile("" : "+v"(lzv));
+        if constexpr ((PERSIST && S::LOW == 2) || (FE_LZ_BIG && S::C1 > 96 && (PERSIST || PIPE || !T1))) asm volatile("" : "+v"(lzv));
         const int tid = tid0 + lzv;
         const int lane = lane0 + lzv;
         const int li = lane & 15, lg = lane >> 4;

@@ -319,10 +319,10 @@ __global__ void __launch_bounds__(kThreads) tb_enc_kernel(TbArgs a) {
     constexpr int N = S::NFFT, H = S::HOP, F0 = S::F0, F1 = S::F1, C1 = S::C1, C2 = S::C2, F2 = S::F2;
     constexpr int LDC = S::LDC, LDX = S::LDX;
     constexpr PackedOffsets o = Pack<S>::v;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wave_k = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     const WSrc<false> wb = make_wsrc<S>(a.wp, lane);
-    const int wm = CT::NS == kWaves ? 0 : wave / CT::NS;
+    const int wave = wave_k, wm = CT::NS == kWaves ? 0 : wave / CT::NS;
 
     float2* tw = reinterpret_cast<float2*>(smem + L::TW);
     for (int i = tid; i < N / 2; i += kThreads) tw[i] = reinterpret_cast<const float2*>(a.wp + o.twiddle)[i];
@@ -366,6 +366,12 @@ __global__ void __launch_bounds__(kThreads) tb_enc_kernel(TbArgs a) {
 
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // big shapes (C1 > 96): a loop-variant zero in the wave index keeps the (hundreds of) wave-uniform weight offsets of a tile from
+        // being hoisted out of the tile loop, where they sat in SGPRs for the whole kernel and spilled to VGPR lanes (tb_enc_kernel<L>:
+        // 961 SGPR spills - v_writelane / v_readlane traffic on the datapath the fp32 MFMAs share with the vector ALUs)
+        int lz = 0;
+        if constexpr (S::C1 > 96) asm volatile("" : "+s"(lz));
+        const int wave = wave_k + lz, wm = CT::NS == kWaves ? 0 : wave / CT::NS;
         const int g0 = tile * FT;
         const int nvalid = a.NF - g0 < FT ? a.NF - g0 : FT;
         // ---- STFT (functional/audio_modules.py:78-80: center = True, reflect padding) + compress (model.py:684-690).  The tile's samples
@@ -1374,10 +1380,10 @@ __global__ void __launch_bounds__(kThreads) tb_dec_kernel(TbArgs a) {
     constexpr int N = S::NFFT, F0 = S::F0, F1 = S::F1, C1 = S::C1, C2 = S::C2, F2 = S::F2;
     constexpr int LDC = S::LDC, LDX = S::LDX;
     constexpr PackedOffsets o = Pack<S>::v;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wave_k = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     const WSrc<false> wb = make_wsrc<S>(a.wp, lane);
-    const int wm = CT::NS == kWaves ? 0 : wave / CT::NS;
+    const int wave = wave_k, wm = CT::NS == kWaves ? 0 : wave / CT::NS;
     float2* tw = reinterpret_cast<float2*>(smem + L::TW);
     for (int i = tid; i < N / 2; i += kThreads) tw[i] = reinterpret_cast<const float2*>(a.wp + o.twiddle)[i];
     float* const Wy = smem + L::WY;
@@ -1399,6 +1405,9 @@ __global__ void __launch_bounds__(kThreads) tb_dec_kernel(TbArgs a) {
     TB_MARK(0);                     // prologue
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int lz = 0;                       // (big shapes: weight offsets not hoisted out of the tile loop - see tb_enc_kernel; tb_dec_kernel<L>: 1395 SGPR spills)
+        if constexpr (S::C1 > 96) asm volatile("" : "+s"(lz));
+        const int wave = wave_k + lz, wm = CT::NS == kWaves ? 0 : wave / CT::NS;
         const int g0 = tile * FT;
         const int nvalid = a.NF - g0 < FT ? a.NF - g0 : FT;
         const int rows_valid = nvalid * F2;
