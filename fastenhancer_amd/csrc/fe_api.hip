@@ -379,25 +379,24 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
                 p.raw(o.blk_bhh[k] + g * bsz, C2, bhh + g * C2);
             }
         }
-        if (o.k4_g8x[k] != 0) {
-            // 512-thread per-hop kernel (fe_frame8.hip.h, Shape::G8P): the block weights in "k4" fragment order (PackedOffsets::k4_*).
+        if (o.u8_gx[k] != 0) {
+            // 512-thread per-hop kernel (fe_frame8.hip.h, Shape::G8P): the block weights as LDS-staged units (PackedOffsets::u8_*):
+            // B fragments [tile][k-step][64] followed by the tiles' start values [tile][16].
             const float* wih = S(key("rnn.weight_ih_l0"));
             const float* whh = S(key("rnn.weight_hh_l0"));
             const float* bih = S(key("rnn.bias_ih_l0"));
             const float* bhh = S(key("rnn.bias_hh_l0"));
-            const int NG = C2 / 16, R = C2 % 16, NT = 3 * NG + 1, KS = C2 / 4, NF = KS / 4, REM = KS % 4 + 1, T4 = NF * 256 + 64 * REM;
+            const int NG = C2 / 16, R = C2 % 16, NT = 3 * NG + 1, KS = C2 / 4;
             // tile t, column c -> row of the (rows, C2) weight matrix (-1: padding); bias(t, c)
-            auto pack_k4 = [&](int off, int ntiles, const float* w, const std::function<int(int, int)>& wrow, const std::function<float(int, int)>& bias) {
-                for (int t = 0; t < ntiles; ++t)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int ks = 0; ks <= KS; ++ks) {
+            auto pack_u8 = [&](int off, int ntiles, const float* w, const std::function<int(int, int)>& wrow, const std::function<float(int, int)>& bias) {
+                for (int t = 0; t < ntiles; ++t) {
+                    for (int ks = 0; ks < KS; ++ks)
+                        for (int lane = 0; lane < 64; ++lane) {
                             const int row = wrow(t, lane % 16);
-                            float v = 0.0f;
-                            if (ks < KS) v = row >= 0 ? w[(size_t)row * C2 + 4 * ks + lane / 16] : 0.0f;
-                            else v = row >= 0 ? bias(t, lane % 16) : 0.0f;
-                            const size_t at = ks < 4 * NF ? (size_t)(ks / 4) * 256 + lane * 4 + ks % 4 : (size_t)NF * 256 + lane * REM + (ks - 4 * NF);
-                            p.buf[(size_t)off + (size_t)t * T4 + at] = v;
+                            p.buf[(size_t)off + ((size_t)t * KS + ks) * 64 + lane] = row >= 0 ? w[(size_t)row * C2 + 4 * ks + lane / 16] : 0.0f;
                         }
+                    for (int c = 0; c < 16; ++c) p.buf[(size_t)off + (size_t)ntiles * KS * 64 + t * 16 + c] = wrow(t, c) >= 0 ? bias(t, c) : 0.0f;
+                }
             };
             // channel-grouped gate tiles: tile 3 G + gate: column c <-> channel 16 G + c of that gate; the last tile: columns [0, R) r,
             // [R, 2 R) z, [2 R, 3 R) n of the R = C2 % 16 left-over channels
@@ -406,14 +405,23 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
                 return c < 3 * R ? (c / R) * C2 + 16 * NG + c % R : -1;
             };
             auto shared = [&](int t) { return t < 3 * NG && t % 3 < 2; };      // pure r / z tile: x and h halves in one accumulator
-            pack_k4(o.k4_g8x[k], NT, wih, grow, [&](int t, int c) { const int r = grow(t, c); return bih[r] + (shared(t) ? bhh[r] : 0.0f); });
-            pack_k4(o.k4_g8h[k], NT, whh, grow, [&](int t, int c) { const int r = grow(t, c); return shared(t) ? 0.0f : bhh[r]; });
+            pack_u8(o.u8_gx[k], NT, wih, grow, [&](int t, int c) { const int r = grow(t, c); return bih[r] + (shared(t) ? bhh[r] : 0.0f); });
+            pack_u8(o.u8_gh[k], NT, whh, grow, [&](int t, int c) { const int r = grow(t, c); return shared(t) ? 0.0f : bhh[r]; });
             auto plain = [&](int ncols) { return [ncols](int t, int c) { return 16 * t + c < ncols ? 16 * t + c : -1; }; };
             const float* f1b = S(key("rnn_fc.bias"));
             const float* f2b = S(key("attn_fc.bias"));
-            pack_k4(o.k4_f1[k], fe::ceil_div(C2, 16), S(key("rnn_fc.weight")), plain(C2), [&](int t, int c) { return f1b[16 * t + c]; });
-            pack_k4(o.k4_q[k], fe::ceil_div(3 * C2, 16), S(key("attn.qkv.weight")), plain(3 * C2), [&](int, int) { return 0.0f; });
-            pack_k4(o.k4_f2[k], fe::ceil_div(C2, 16), S(key("attn_fc.weight")), plain(C2), [&](int t, int c) { return f2b[16 * t + c]; });
+            pack_u8(o.u8_f1[k], fe::ceil_div(C2, 16), S(key("rnn_fc.weight")), plain(C2), [&](int t, int c) { return f1b[16 * t + c]; });
+            {   // qkv: fragments only (the unit has no start values)
+                const float* wq = S(key("attn.qkv.weight"));
+                const int ntq = fe::ceil_div(3 * C2, 16);
+                for (int t = 0; t < ntq; ++t)
+                    for (int ks = 0; ks < KS; ++ks)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int row = 16 * t + lane % 16;
+                            p.buf[(size_t)o.u8_q[k] + ((size_t)t * KS + ks) * 64 + lane] = row < 3 * C2 ? wq[(size_t)row * C2 + 4 * ks + lane / 16] : 0.0f;
+                        }
+            }
+            pack_u8(o.u8_f2[k], fe::ceil_div(C2, 16), S(key("attn_fc.weight")), plain(C2), [&](int t, int c) { return f2b[16 * t + c]; });
         }
         if (h->impl->tb && !d.TA) {
             // time-batched engine (tb_kernels.hip.h): per direction the input weights as ONE flat (3 C2)-column matrix (rows r | z | n as

@@ -33,64 +33,24 @@ struct Wg8 {
     using L = Lds<S>;
     static constexpr bool MDFT = (S::NFFT == 512) || (S::C1 < 128);
     // built for the B-type plan: staged conv weights, LDS-resident skips, register-resident block weights with flat GRU gates
-    static constexpr bool OK = L::STAGED && L::SKIPS_LDS && S::GFLAT && S::KT == 1 && S::LOW == 0 && !S::FRNN && !S::TATT && !S::LN && !S::BIDIR &&
-                               S::G8P && S::MTC == 4 && S::MT2 == 2 && MDFT && !L::PERHEAD && S::NFFT == kThreads8;
+    static constexpr bool OK0 = L::STAGED && L::SKIPS_LDS && S::GFLAT && S::KT == 1 && S::LOW == 0 && !S::FRNN && !S::TATT && !S::LN && !S::BIDIR &&
+                               S::G8P && S::MTC == 4 && S::MT2 == 2 && MDFT && !L::PERHEAD && S::NFFT == kThreads8 && S::NTPW2 == 1;
     static constexpr int NTA = (S::NTC + 1) / 2, NTB = S::NTC - NTA;        // conv channel tiles of the wh = 0 / wh = 1 wave
     static constexpr int N2A = (S::NT2 + 1) / 2, N2B = S::NT2 - N2A;        // rf_post's token-channel tiles likewise
     static constexpr int NPW = ceil_div(ceil_div(Pack<S>::umax(), 256), kWaves8);
     static constexpr int HPT = ceil_div(S::F2 * S::C2, kThreads8);          // hidden-state elements per thread
-};
-
-// Register-resident block weights of a wave in "k4" fragment order (PackedOffsets::k4_*; packed by fe_api.hip::pack_weights):
-// tiles t0, t0 + tstride, ... (NTW of them; tiles >= tend load zeros through an out-of-range buffer offset: no traffic), each
-// KG buffer_load_dwordx4 of four k-steps; slot KS of a lane holds the bias of its column.  Same side-job interface as TokW.
-template <int NTW, int KS, int TS, class WS>      // TS: tile stride (4: column tiles ws, ws + 4, ...; 1: consecutive gate tiles)
-struct K4W {
-    static constexpr int NF = KS / 4, REM = KS % 4 + 1, TILE = NF * 256 + 64 * REM, KG = NF + 1;
-    static_assert(REM == 2, "k4 tail: two floats per lane (KS % 4 == 1)");      // (1 and 4 would be a dword / dwordx4 tail; 3 has no load of its size)
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x4 w[NTW][NF];
-    f32x2 tail[NTW];
-    __amdgpu_buffer_rsrc_t rsrc;
-    int soff0;            // byte offset of tile t0 (wave-uniform)
-    int voff[NTW];        // lane * 16 (the tail: half of it), or an out-of-range offset for a tile this wave does not have
-    __device__ __forceinline__ void bind(const WS& s, int off_floats, int t0, int tend, bool live = true) {
-        rsrc = s.rsrc;
-        soff0 = (off_floats + t0 * TILE) * 4;
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) voff[j] = s.lane4 * 4 + ((live && t0 + j * TS < tend) ? 0 : 0x40000000);
-    }
-    static constexpr int TOT = NTW * KG;
-    __device__ __forceinline__ void fetch_elem(int e) {
-        const int j = e / KG, kg = e - j * KG;
-        if (kg < NF) w[j][kg] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], soff0 + (j * TS * TILE + kg * 256) * 4, 0));
-        else tail[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff[j] >> 1, soff0 + (j * TS * TILE + NF * 256) * 4, 0));
-    }
-    static constexpr int part_count(int part, int parts) {
-        const int per = (TOT + parts - 1) / parts;
-        int lo = part * per, hi = (part + 1) * per;
-        lo = lo < TOT ? lo : TOT;
-        hi = hi < TOT ? hi : TOT;
-        return hi - lo;
-    }
-    __device__ __forceinline__ void fetch_part(int part, int parts) {
-        const int per = (TOT + parts - 1) / parts;
-#pragma unroll
-        for (int q = 0; q < TOT; ++q)
-            if (q >= part * per && q < (part + 1) * per) fetch_elem(q);
-    }
-    __device__ __forceinline__ float get(int j, int ks) const { return ks < 4 * NF ? w[j][ks / 4][ks % 4] : tail[j][ks - 4 * NF]; }
-    __device__ __forceinline__ float bias(int j) const { return tail[j][REM - 1]; }
-    // an (empty) read of every register of the set: a wave that has no use for some tiles must still keep their registers out of the
-    // allocator's hands until the loads have landed
-    __device__ __forceinline__ void touch() const {
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-#pragma unroll
-            for (int g = 0; g < NF; ++g) asm volatile("" ::"v"(w[j][g]));
-            asm volatile("" ::"v"(tail[j]));
-        }
-    }
+    // Weight staging region: FOUR slots of U8_SLOT floats.  The conv units use them as the two buffers of fe_frame_kernel (WB0 = slots
+    // 0-1, WB1 = slots 2-3); during the RNNFormer blocks - where fe_frame_kernel's staging buffers sit idle and its waves fetch their
+    // private weight fragments from L2 - the BLOCK weights go through the four slots as well: eight waves would fetch every fragment
+    // twice (the two waves of a SIMD work on the same columns), 240 wave-level loads per block at ~16 cycles of the CU's vector-memory
+    // path each (measured: 3.5 us of the 32.7 us frame, profiles/r4a_wg8_steps.txt); staged, a block is 64 one-KiB pieces.
+    //   slot 1: GRU input weights   slot 3: GRU hidden weights   slot 0: rnn_fc, then attn_fc   slot 2: qkv
+    static constexpr int SLOT = S::U8_SLOT;
+    static constexpr int WB0 = L::NOSTAGE_TOTAL, WB1 = WB0 + 2 * SLOT;
+    static constexpr size_t BYTES = (size_t)(L::NOSTAGE_TOTAL + 4 * SLOT) * 4;
+    static constexpr int NPWB = ceil_div(ceil_div(SLOT, 256), kWaves8);      // pieces per wave of a block unit
+    static constexpr bool PLAN_OK = 2 * SLOT >= Pack<S>::umax() && BYTES <= 160 * 1024 && (S::NU & 1) == 0;
+    static constexpr bool OK = OK0 && PLAN_OK;
 };
 
 // One conv-layout GEMM job of a wave: row tile mt x the NT channel tiles J0 .. J0 + NT - 1, K = 4 KS.
@@ -152,7 +112,10 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
     constexpr int C1 = S::C1, C2 = S::C2, F2 = S::F2, HD = S::HD;
     constexpr int LDC = S::LDC, LDX = S::LDX, LDG = L::LDGX;
     constexpr int NTH = kThreads8;
-    constexpr int PDK = L::PDK;
+#ifndef FE_WG8_PDK
+#define FE_WG8_PDK 3      // software-pipeline depth of the token GEMMs (A and B both from LDS)
+#endif
+    constexpr int PDK = FE_WG8_PDK;
 
     const int tid0 = threadIdx.x;
     const int tid = tid0;
@@ -182,7 +145,7 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
     float2* tw = reinterpret_cast<float2*>(smem + L::TW);
     constexpr int NPW = W8::NPW;
     DmaJobT<NPW> job;
-    job.l = smem + L::WB0;
+    job.l = smem + W8::WB0;
     job.rsrc = wb.rsrc;
     job.soff = (o.u_off[0] + wave * 256) * 4;
     job.wave = wave;
@@ -195,7 +158,7 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
         float2 twv = make_float2(0.0f, 0.0f);
         if (tid < N / 2) twv = reinterpret_cast<const float2*>(wp + o.twiddle)[tid];
         DmaJobT<NPW> job1 = job;
-        job1.l = smem + L::WB1;
+        job1.l = smem + W8::WB1;
         job1.soff = (o.u_off[1] + wave * 256) * 4;
         const StageSide<NPW, PERSIST ? 0 : o.u_size[1] / 256, kWaves8> st1{&job1};
         if constexpr (!PERSIST) {
@@ -239,12 +202,12 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
         constexpr int fe_un_ = ((U) + 1 == S::NU) ? 0 : (U) + 1;                                   \
         {                                                                                          \
             const int slot_ = ((U) & 1) ^ fpar;                                                    \
-            job.l = smem + (slot_ ? L::WB0 : L::WB1);                                              \
+            job.l = smem + (slot_ ? W8::WB0 : W8::WB1);                                            \
             job.soff = (o.u_off[fe_un_] + wave * 256) * 4;                                         \
-            wb.lds = smem + (slot_ ? L::WB1 : L::WB0);                                             \
+            wb.lds = smem + (slot_ ? W8::WB1 : W8::WB0);                                           \
             wb.base = o.u_off[(U)];                                                                \
         }                                                                                          \
-        const StageSide<NPW, (!PERSIST && ((U) + 1 == S::NU || (U) == 0)) ? 0 : o.u_size[fe_un_] / 256, kWaves8> stage{&job}
+        const StageSide<NPW, ((!PERSIST && ((U) + 1 == S::NU || (U) == 0)) || (U) == S::U_RFPRE + 1) ? 0 : o.u_size[fe_un_] / 256, kWaves8> stage{&job}
         FE_CLK(0);
         // =========================== STFT (a1-a3) ===========================
         // LDS quarters of the FFT arena: q0 windowed frame / iSTFT partial sums, q1 iSTFT partial sums, q3 spectrum {Re[N/2], Im[N/2]}
@@ -335,25 +298,34 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
 
         FE_CLK(5);
         // =========================== rf_pre (a7) ===========================
-        constexpr int NTPW2 = S::NTPW2, NTPW3 = S::NTPW3;
+        constexpr int NTPW3 = S::NTPW3;
         constexpr int HPT = W8::HPT;
-        static_assert(NTPW2 == 1, "token GEMMs: one channel tile per SIMD slot");
-        f32x4 xr[NTPW2];                               // residual stream x: row tile wh, this wave's channel tiles
-        using WS = WSrc<true>;
+        constexpr int K2 = S::KS_2;
+        f32x4 xr;                                      // residual stream x: row tile wh, channel tile ws
         // GRU: (channel group, row tile) jobs - waves 0-3 a 16-channel group x a row tile (three gate tiles: 54 MFMAs), waves 4 and 5
         // (SIMDs 0 and 1) the mixed tile of the left-over channels x a row tile (18 MFMAs), waves 6 and 7 none: 72 / 72 / 54 / 54
         // MFMAs per SIMD, and the three gates of a (row, channel) meet in one lane
-        K4W<3, S::KS_2, 1, WS> Gx, Gh;
         const int g_rt = wave & 1;                                         // row tile of this wave's GRU job
         const int g_t0 = wave < 4 ? 3 * (wave >> 1) : 3 * S::G8_NG;        // its first gate tile
-        const int g_nt = wave < 4 ? 3 : (wave < 6 ? 1 : 0);
-        constexpr int k4_stride = S::KB > 1 ? o.k4_g8x[1] - o.k4_g8x[0] : 0;
-        K4W<NTPW2, S::KS_2, 4, WS> Wf1, Wf2;              // rnn_fc, attn_fc: channel tile ws
-        K4W<NTPW3, S::KS_2, 4, WS> Wq;                   // qkv: column tiles ws, ws + 4
-        float pe_r[NTPW2][4];
+        // block weights in LDS (W8 slots): B fragment (tile, k-step) of a unit at u[(tile * K2 + ks) * 64 + lane], start value of a tile's
+        // column at u[NT * K2 * 64 + tile * 16 + li]
+        const float* const sGx = smem + W8::WB0 + 1 * W8::SLOT;
+        const float* const sGh = smem + W8::WB0 + 3 * W8::SLOT;
+        const float* const sF = smem + W8::WB0 + 0 * W8::SLOT;
+        const float* const sQ = smem + W8::WB0 + 2 * W8::SLOT;
+        constexpr int NPWB = W8::NPWB;
+        DmaJobT<NPWB> jb1, jb2;                        // staging jobs of the block units (two may ride in one GEMM)
+        jb1.rsrc = wb.rsrc; jb1.wave = wave; jb1.lane = lane; jb1.l = smem; jb1.soff = 0;
+        jb2 = jb1;
+        auto stage_to = [&](DmaJobT<NPWB>& j, int src_floats, int dst_floats) { j.l = smem + dst_floats; j.soff = (src_floats + wave * 256) * 4; };
+        constexpr int u8_stride = S::KB > 1 ? o.u8_gx[1] - o.u8_gx[0] : 0;
+        using StG = StageSide<NPWB, S::U8_G / 256, kWaves8>;
+        using StF = StageSide<NPWB, S::U8_F / 256, kWaves8>;
+        using StQ = StageSide<NPWB, S::U8_Q / 256, kWaves8>;
+        float pe_r[4];
         // unpredicated epilogue stores into the [F2P][C2 + 2] token buffers (pad rows are real rows, lanes past C2 aim at the pad column)
-        auto tok_dst = [&](float* base, int j) {
-            const int col = 16 * (ws + 4 * j) + li;
+        auto tok_dst = [&](float* base) {
+            const int col = 16 * ws + li;
             return base + (16 * wh + 4 * lg) * LDX + (col < C2 ? col : C2);
         };
         int hs_off[HPT];
@@ -367,14 +339,16 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
             constexpr int KS = F1 / 4;
             const float* Ein = Ebuf + S::NL * S::ACT + LDC;   // row 0 = bin 0
             FE8_BEGIN_UNIT(S::U_RFPRE);
-            Gx.bind(wb, o.k4_g8x[0], g_t0, g_t0 + g_nt);                // block 0's GRU input weights ride in this GEMM
+            stage_to(jb1, o.u8_gx[0], W8::WB0 + 1 * W8::SLOT);          // block 0's GRU input weights -> slot 1
+            const StG stg{&jb1};
             f32x4 acc[1][1];
             acc_init_zero<1, 1>(acc);
             const int nt = ws < S::NTC ? ws : S::NTC - 1;
             mma_panel<1, 1, KS, PDK>(
                 acc, [&](int, int ks) { return wb.at(o.rfpre_lin + (wh * KS + ks) * 64); },
-                [&](int, int ks) { return Ein[(4 * ks + lg) * LDC + 16 * nt + li]; }, side2(stage, FetchSide<decltype(Gx)>{&Gx}));
+                [&](int, int ks) { return Ein[(4 * ks + lg) * LDC + 16 * nt + li]; }, side2(stage, stg));
             stage.commit();
+            stg.commit();
             const int col = 16 * ws + li;
             if (ws < S::NTC && col < C1 && 16 * wh + 4 * lg < F2) {
 #pragma unroll
@@ -385,7 +359,8 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
         {
             // X[f2][c2] = Y1[f2][:] . Wc[c2][:] + b
             FE8_BEGIN_UNIT(S::U_RFPRE + 1);
-            Gh.bind(wb, o.k4_g8h[0], g_t0, g_t0 + g_nt);                // ... and the hidden weights in this one
+            stage_to(jb1, o.u8_gh[0], W8::WB0 + 3 * W8::SLOT);          // ... and the hidden weights -> slot 3
+            const StG stg{&jb1};
             float hpre[HPT];
             const float* hg0 = a.h + (size_t)b * (F2 * C2);
 #pragma unroll
@@ -396,10 +371,11 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
             const float* ya = Y1 + (16 * wh + li) * LDC + lg;
             mma_panel<1, 1, S::KS_C, PDK>(
                 acc, [&](int, int ks) { return ya[4 * ks]; },
-                [&](int, int ks) { return wb.at(o.rfpre_w + (nt * S::KS_C + ks) * 64); }, side2(stage, FetchSide<decltype(Gh)>{&Gh}));
-            stage.commit();
-            xr[0] = acc[0][0];
-            float* xd = tok_dst(Xb, 0);
+                [&](int, int ks) { return wb.at(o.rfpre_w + (nt * S::KS_C + ks) * 64); }, stg);
+            (void)stage;
+            stg.commit();
+            xr = acc[0][0];
+            float* xd = tok_dst(Xb);
 #pragma unroll
             for (int r = 0; r < 4; ++r) xd[r * LDX] = acc[0][0][r];
 #pragma unroll
@@ -413,31 +389,30 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int k = 0; k < S::KB; ++k) {
             float* hg = a.h + ((size_t)k * a.B + b) * (F2 * C2);
-            const int kb = k * o.blk_stride;
+            const int ub = k * u8_stride;
             if (k == 0) FE_CLK(20);
             {
                 // GRU (nn.GRU gate order r, z, n; model.py:187, 271) over (channel group, row tile) jobs, the gate math in the GEMM
-                // epilogue - r, z, n of a (row, channel) sit in one lane: no exchange through LDS, one barrier for the phase
-                // weight fetch schedule (side jobs of the GEMMs): rnn_fc's and qkv's here, attn_fc's in rnn_fc, the next block's GRU input
-                // weights in qkv and its hidden weights in attn_fc.  (Measured and dropped: every set two phases ahead - the GRU phase
-                // gains what rf_pre and rnn_fc lose: a wave-level buffer load costs the CU's vector-memory path ~16 cycles whatever
-                // its width, and 8 waves x 9 loads do not fit under a 9-MFMA GEMM wherever they are put.)
-                Wf1.bind(wb, o.k4_f1[0] + k * k4_stride, ws, S::NT2);
-                Wq.bind(wb, o.k4_q[0] + k * k4_stride, ws, S::NT3);
+                // epilogue - r, z, n of a (row, channel) sit in one lane: no exchange through LDS, one barrier for the phase.
+                // Staged meanwhile: this block's rnn_fc -> slot 0 and qkv -> slot 2.
+                stage_to(jb1, o.u8_f1[0] + ub, W8::WB0 + 0 * W8::SLOT);
+                stage_to(jb2, o.u8_q[0] + ub, W8::WB0 + 2 * W8::SLOT);
+                const StF st1{&jb1};
+                const StQ st2{&jb2};
+                const auto sideg = side2(st1, st2);
                 if (k == 0) {
 #pragma unroll
-                    for (int j = 0; j < NTPW2; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = 16 * wh + 4 * lg + r, col = 16 * (ws + 4 * j) + li;
-                            pe_r[j][r] = wb.gather_g(o.blk_pe + (row < F2 ? row : F2 - 1) * C2 + (col < C2 ? col : C2 - 1));
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * wh + 4 * lg + r, col = 16 * ws + li;
+                        pe_r[r] = wb.gather_g(o.blk_pe + (row < F2 ? row : F2 - 1) * C2 + (col < C2 ? col : C2 - 1));
+                    }
                 }
-                constexpr int K2 = S::KS_2;
-                using SideG = FetchSide2<decltype(Wf1), decltype(Wq)>;
-                const SideG sideg{&Wf1, &Wq};
                 const float* xa = Xb + (16 * g_rt + li) * LDX + lg;
                 const float* ha = Hs + (16 * g_rt + li) * LDX + lg;
+                const float* wx = sGx + g_t0 * (K2 * 64) + lane;
+                const float* wh_ = sGh + g_t0 * (K2 * 64) + lane;
+                const float* bx = sGx + S::G8_NT * K2 * 64 + g_t0 * 16 + li;
+                const float* bh = sGh + S::G8_NT * K2 * 64 + g_t0 * 16 + li;
                 __builtin_amdgcn_sched_barrier(0);
                 if (k == 0) FE_CLK(45);
                 if (wave < 4) {
@@ -446,12 +421,13 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
                     float hprev[4];                      // previous state of this lane's outputs: in flight under the GEMM
 #pragma unroll
                     for (int r = 0; r < 4; ++r) hprev[r] = Hs[(16 * g_rt + 4 * lg + r) * LDX + ch];
-                    f32x4 ar = f32x4{Gx.bias(0), Gx.bias(0), Gx.bias(0), Gx.bias(0)}, az = f32x4{Gx.bias(1), Gx.bias(1), Gx.bias(1), Gx.bias(1)};
-                    f32x4 anx = f32x4{Gx.bias(2), Gx.bias(2), Gx.bias(2), Gx.bias(2)}, anh = f32x4{Gh.bias(2), Gh.bias(2), Gh.bias(2), Gh.bias(2)};
+                    const float b0 = bx[0], b1 = bx[16], b2 = bx[32], b3 = bh[32];
+                    f32x4 ar = f32x4{b0, b0, b0, b0}, az = f32x4{b1, b1, b1, b1};
+                    f32x4 anx = f32x4{b2, b2, b2, b2}, anh = f32x4{b3, b3, b3, b3};
                     mma_panel_sel<1, 3, 2 * K2, PDK>(
                         [&](int, int j, int ks) -> f32x4& { return j == 0 ? ar : (j == 1 ? az : (ks < K2 ? anx : anh)); },
                         [&](int, int ks) { return ks < K2 ? xa[4 * ks] : ha[4 * (ks - K2)]; },
-                        [&](int j, int ks) { return ks < K2 ? Gx.get(j, ks) : Gh.get(j, ks - K2); }, sideg);
+                        [&](int j, int ks) { return ks < K2 ? wx[(j * K2 + ks) * 64] : wh_[(j * K2 + (ks - K2)) * 64]; }, sideg);
                     __builtin_amdgcn_sched_barrier(0);
                     if (k == 0) FE_CLK(46);
                     float hn[4];
@@ -472,22 +448,22 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
                     }
                 } else if (wave < 6) {
                     // the mixed tile: lanes li < R hold r, R .. 2 R - 1 z, 2 R .. 3 R - 1 n of channel 16 NG + li % R; the z and n values
-                    // move down to the r lanes (DPP row shifts), which finish the R channels
+                    // move down to the r lanes (DPP row shifts), which finish the R channels.  (18 dependent MFMAs next to the 54
+                    // independent ones of this SIMD's big job: two chains per half, and a raised priority - arbitrated oldest-first,
+                    // this wave got a matrix-pipe slot only when the other one stalled and the whole workgroup waited for it)
                     constexpr int R = S::G8_R;
                     const int ch = 16 * S::G8_NG + (li < R ? li : 0);
                     float hprev[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) hprev[r] = Hs[(16 * g_rt + 4 * lg + r) * LDX + ch];
-                    // (18 dependent MFMAs next to the 54 independent ones of this SIMD's big job: two chains per half, and a raised
-                    //  priority - arbitrated oldest-first, this wave got a matrix-pipe slot only when the other one stalled and the
-                    //  whole workgroup waited for it: 3.5 k cycles for 18 MFMAs)
-                    f32x4 ax = f32x4{Gx.bias(0), Gx.bias(0), Gx.bias(0), Gx.bias(0)}, ah = f32x4{Gh.bias(0), Gh.bias(0), Gh.bias(0), Gh.bias(0)};
+                    const float b0 = bx[0], b1 = bh[0];
+                    f32x4 ax = f32x4{b0, b0, b0, b0}, ah = f32x4{b1, b1, b1, b1};
                     f32x4 ax1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, ah1 = ax1;
                     __builtin_amdgcn_s_setprio(3);
                     mma_panel_sel<1, 1, 2 * K2, PDK>(
                         [&](int, int, int ks) -> f32x4& { return ks < K2 ? ((ks & 1) ? ax1 : ax) : ((ks & 1) ? ah1 : ah); },
                         [&](int, int ks) { return ks < K2 ? xa[4 * ks] : ha[4 * (ks - K2)]; },
-                        [&](int, int ks) { return ks < K2 ? Gx.get(0, ks) : Gh.get(0, ks - K2); }, sideg);
+                        [&](int, int ks) { return ks < K2 ? wx[ks * 64] : wh_[(ks - K2) * 64]; }, sideg);
                     __builtin_amdgcn_s_setprio(0);
                     ax += ax1;
                     ah += ah1;
@@ -515,30 +491,38 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
                         }
                     }
                 } else {
-                    constexpr int NSG = (2 * K2 + 3) / 4;      // no GRU job: this wave's side loads only
+                    constexpr int NSG = (2 * K2 + 3) / 4;      // no GRU job: this wave's share of the staging only
 #pragma unroll
                     for (int g = 0; g < NSG; ++g) sideg(g, NSG);
                 }
+                st1.commit();
+                st2.commit();
             }
             if (k == 0) FE_CLK(47);
             __syncthreads();
             if (k == 0) FE_CLK(21);
             if (k == 0) FE_CLK(22);
+            const int ntf = ws < S::NT2 ? ws : S::NT2 - 1;           // this wave's channel tile of the fc layers (ws = 3: a shadow of the last)
             {
-                // x += rnn_fc(h') (+ pe in block 0)
-                Wf2.bind(wb, o.k4_f2[0] + k * k4_stride, ws, S::NT2);
-                f32x4 acc[1][NTPW2];
-                const float bj = Wf1.bias(0);
+                // x += rnn_fc(h') (+ pe in block 0); staged meanwhile: the next block's GRU input weights -> slot 1
+                stage_to(jb1, o.u8_gx[0] + ub + u8_stride, W8::WB0 + 1 * W8::SLOT);
+                const StageSide<NPWB, (S::U8_G / 256), kWaves8> stn{&jb1};
+                f32x4 acc[1][1];
+                const float bj = sF[S::NT2 * K2 * 64 + ntf * 16 + li];
                 acc[0][0] = f32x4{bj, bj, bj, bj};
                 const float* hla = Hl + (16 * wh + li) * LDX + lg;
-                mma_panel<1, NTPW2, S::KS_2, PDK>(acc, [&](int, int ks) { return hla[4 * ks]; }, [&](int j, int ks) { return Wf1.get(j, ks); },
-                                                  FetchSide<decltype(Wf2)>{&Wf2});
-                float* xd = tok_dst(Xb, 0);
+                const float* wf = sF + ntf * (K2 * 64) + lane;
+                if (k + 1 < S::KB) {
+                    mma_panel<1, 1, K2, PDK>(acc, [&](int, int ks) { return hla[4 * ks]; }, [&](int, int ks) { return wf[ks * 64]; }, stn);
+                    stn.commit();
+                } else
+                    mma_panel<1, 1, K2, PDK>(acc, [&](int, int ks) { return hla[4 * ks]; }, [&](int, int ks) { return wf[ks * 64]; }, NoSide{});
+                float* xd = tok_dst(Xb);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = acc[0][0][r] + xr[0][r];
-                    if (k == 0) v += pe_r[0][r];
-                    xr[0][r] = v;
+                    float v = acc[0][0][r] + xr[r];
+                    if (k == 0) v += pe_r[r];
+                    xr[r] = v;
                     xd[r * LDX] = v;
                 }
             }
@@ -546,16 +530,21 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
             dbg_dump<S, NTH>(a, b, 4 + S::NL + 2 * k, Xb, LDX);
             if (k == 0) FE_CLK(23);
             {
-                // qkv = x W_qkv^T -> Gi (columns per head interleaved [h][q|k|v][hd]); the next block's GRU input weights ride along
-                Gx.bind(wb, o.k4_g8x[0] + (k + 1) * k4_stride, g_t0, g_t0 + g_nt, k + 1 < S::KB);
+                // qkv = x W_qkv^T -> Gi (columns per head interleaved [h][q|k|v][hd]); staged meanwhile: attn_fc -> slot 0
+                stage_to(jb1, o.u8_f2[0] + ub, W8::WB0 + 0 * W8::SLOT);
+                const StF st1{&jb1};
                 f32x4 acc[1][NTPW3];
-#pragma unroll
-                for (int j = 0; j < NTPW3; ++j) { const float bj = Wq.bias(j); acc[0][j] = f32x4{bj, bj, bj, bj}; }      // (zero; read so that no loaded register is dead)
+                acc_init_zero<1, NTPW3>(acc);
                 __builtin_amdgcn_sched_barrier(0);
                 if (k == 0) FE_CLK(50);
                 const float* xa = Xb + (16 * wh + li) * LDX + lg;
-                mma_panel<1, NTPW3, S::KS_2, PDK>(acc, [&](int, int ks) { return xa[4 * ks]; }, [&](int j, int ks) { return Wq.get(j, ks); },
-                                                  FetchSide<decltype(Gx)>{&Gx});
+                mma_panel<1, NTPW3, K2, PDK>(acc, [&](int, int ks) { return xa[4 * ks]; },
+                                             [&](int j, int ks) {
+                                                 int nt = ws + 4 * j;
+                                                 nt = nt < S::NT3 ? nt : S::NT3 - 1;
+                                                 return sQ[(nt * K2 + ks) * 64 + lane];
+                                             }, st1);
+                st1.commit();
                 __builtin_amdgcn_sched_barrier(0);
                 if (k == 0) FE_CLK(51);
                 float* gdst = Gi + (16 * wh + 4 * lg) * LDG + 16 * ws + li;
@@ -575,29 +564,39 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
             __syncthreads();
             if (k == 0) FE_CLK(25);
             {
-                // x += attn_fc(o); the next block's GRU hidden weights ride along, its hidden state is fetched now and parked after the GEMM
+                // x += attn_fc(o); staged meanwhile: the next block's GRU hidden weights -> slot 3 (last block: rf_post's filterbank -> WB1);
+                // the next block's hidden state is fetched now and parked after the GEMM
                 float hpre[HPT];
-                Gh.bind(wb, o.k4_g8h[0] + (k + 1) * k4_stride, g_t0, g_t0 + g_nt, k + 1 < S::KB);
                 if (k + 1 < S::KB) {
                     const float* hgn = hg + (size_t)a.B * (F2 * C2);
 #pragma unroll
                     for (int q = 0; q < HPT; ++q) { const int i = tid + q * NTH; hpre[q] = hgn[i < F2 * C2 ? i : F2 * C2 - 1]; }
                 }
-                f32x4 acc[1][NTPW2];
-                const float bj = Wf2.bias(0);
+                f32x4 acc[1][1];
+                const float bj = sF[S::NT2 * K2 * 64 + ntf * 16 + li];
                 acc[0][0] = f32x4{bj, bj, bj, bj};
                 const float* hla = Hl + (16 * wh + li) * LDX + lg;
-                mma_panel<1, NTPW2, S::KS_2, PDK>(acc, [&](int, int ks) { return hla[4 * ks]; }, [&](int j, int ks) { return Wf2.get(j, ks); },
-                                                  FetchSide<decltype(Gh)>{&Gh});
+                const float* wf = sF + ntf * (K2 * 64) + lane;
+                if (k + 1 < S::KB) {
+                    stage_to(jb1, o.u8_gh[0] + ub + u8_stride, W8::WB0 + 3 * W8::SLOT);
+                    const StG stn{&jb1};
+                    mma_panel<1, 1, K2, PDK>(acc, [&](int, int ks) { return hla[4 * ks]; }, [&](int, int ks) { return wf[ks * 64]; }, stn);
+                    stn.commit();
+                } else {
+                    stage_to(jb1, o.u_off[S::U_RFPOST], W8::WB1);
+                    const StageSide<NPWB, o.u_size[S::U_RFPOST] / 256, kWaves8> stn{&jb1};
+                    mma_panel<1, 1, K2, PDK>(acc, [&](int, int ks) { return hla[4 * ks]; }, [&](int, int ks) { return wf[ks * 64]; }, stn);
+                    stn.commit();
+                }
                 if (k + 1 < S::KB) {
 #pragma unroll
                     for (int q = 0; q < HPT; ++q) Hs[hs_off[q]] = hpre[q];
                 }
-                float* xd = tok_dst(Xb, 0);
+                float* xd = tok_dst(Xb);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = acc[0][0][r] + xr[0][r];
-                    xr[0][r] = v;
+                    const float v = acc[0][0][r] + xr[r];
+                    xr[r] = v;
                     xd[r * LDX] = v;
                 }
             }

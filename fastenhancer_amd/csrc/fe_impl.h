@@ -59,12 +59,12 @@ void launch_one8(const FrameArgs& a, int grid_x, hipStream_t st, hipError_t* err
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
     if (!attr_set[dev].load(std::memory_order_relaxed)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fe_frame8_kernel<S, DBG, PERSIST>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds<S>::BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wg8<S>::BYTES);
         if (e != hipSuccess) { *err = e; return; }
         attr_set[dev].store(true, std::memory_order_relaxed);
     }
     dim3 grid(grid_x), block(kThreads8);
-    hipLaunchKernelGGL((fe_frame8_kernel<S, DBG, PERSIST>), grid, block, Lds<S>::BYTES, st, a);
+    hipLaunchKernelGGL((fe_frame8_kernel<S, DBG, PERSIST>), grid, block, Wg8<S>::BYTES, st, a);
     *err = hipGetLastError();
 }
 

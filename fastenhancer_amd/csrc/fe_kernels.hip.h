@@ -120,8 +120,12 @@ struct Shape {
     static constexpr int G8_NG = C2 / 16, G8_R = C2 % 16;
     static constexpr bool G8P = GFLAT && MT2 == 2 && G8_NG == 2 && G8_R > 0 && 3 * G8_R <= 16 && KT_ == 1 && FR_ == 0 && TA_ == 0 && LN_ == 0 && BD_ == 0;
     static constexpr int G8_NT = 3 * G8_NG + 1;      // tiles: (group, gate) ..., the mixed tile
-    // "k4" fragment order: K4_NF groups of four k-steps per tile, then a tail of K4_REM floats per lane (the left-over k-steps + the bias)
-    static constexpr int K4_NF = (C2 / 4) / 4, K4_REM = (C2 / 4) % 4 + 1, K4_TILE = K4_NF * 256 + 64 * K4_REM;
+    // 512-thread per-hop kernel: its block weights are staged through LDS like the conv weights, as units of whole 1-KiB pieces:
+    // B fragments [tile][k-step][64] followed by the tiles' start values [tile][16] (a token GEMM's bias)
+    static constexpr int U8_G = round_up(G8_NT * (C2 / 4) * 64 + G8_NT * 16, 256);                     // GRU input / hidden weights: the channel-grouped gate tiles
+    static constexpr int U8_F = round_up(ceil_div(C2, 16) * (C2 / 4) * 64 + ceil_div(C2, 16) * 16, 256);   // rnn_fc / attn_fc
+    static constexpr int U8_Q = round_up(ceil_div(3 * C2, 16) * (C2 / 4) * 64, 256);                   // qkv (no bias)
+    static constexpr int U8_SLOT = U8_G > U8_Q ? U8_G : U8_Q;                                        // one of the four staging slots
     static_assert(C1 % 4 == 0 && C2 % 4 == 0 && F2 % 4 == 0, "channel counts must be multiples of 4");
     static_assert(C2 % NH == 0, "C2 must be divisible by the 4 heads");
     static_assert(F1 % 64 == 0, "F1 must be a multiple of 64");
@@ -158,15 +162,11 @@ struct PackedOffsets {
     // (tile = gate * NT2 + channel tile, so that r, z, n of a (row, channel) meet in one lane) and b_hn [NT2 * 16];
     // noncausal: rnn_fc over 2 C2 input channels
     int tb_wih[8][2], tb_bx[8][2], tb_whh[8][2], tb_bhn[8][2], tb_fc1_w[8];
-    // 512-thread per-hop kernel (Shape::G8P), per block: the register-resident block weights in "k4" fragment order - a lane's
-    // k-steps 4 kg .. 4 kg + 3 of a tile are 16 contiguous bytes, tile * K4_TILE + [kg][lane][4], so that a wave fetches four
-    // k-steps with ONE fully coalesced buffer_load_dwordx4 (a buffer_load_dword costs the CU's vector-memory path as much as a
-    // dwordx4: ~16 cycles per wave instruction, tools/micro/vmem_issue_rate.hip); the tail [lane][K4_REM] holds the left-over
-    // k-steps and, last, the bias of the lane's column - no padding: a loaded register that nothing reads is re-used by the
-    // register allocator while the load is still in flight, and the write-after-write wait stalls the GEMM it rides in.  g8x / g8h: input / hidden weights of the channel-grouped GRU gate tiles (bias: b_ih, plus b_hh on pure
-    // r / z tiles whose x and h halves share an accumulator / b_hh on the n tiles and the mixed tile, else 0); f1, q, f2: rnn_fc,
-    // qkv, attn_fc in their plain column order.
-    int k4_g8x[8], k4_g8h[8], k4_f1[8], k4_q[8], k4_f2[8];
+    // 512-thread per-hop kernel (Shape::G8P), per block: the block weights as LDS-staged units (Shape::U8_*): B fragments
+    // [tile][k-step][64], then the start values [tile][16].  gx / gh: input / hidden weights of the channel-grouped GRU gate tiles
+    // (start values: b_ih, plus b_hh on pure r / z tiles whose x and h halves share an accumulator / b_hh on the n tiles and the mixed
+    // tile, else 0); f1, q, f2: rnn_fc, qkv, attn_fc in their plain column order.
+    int u8_gx[8], u8_gh[8], u8_f1[8], u8_q[8], u8_f2[8];
     int total;
     // LDS-staged weight "units" in consumption order (one per conv-type GEMM phase): [weights | bias],
     // 256-float aligned and padded, so that a unit is staged by whole 1-KiB global_load_lds pieces.
@@ -249,9 +249,11 @@ struct Pack {
             }
         if (S::G8P)      // (allocated last: every other offset is the same with and without it)
             for (int k = 0; k < S::KB; ++k) {
-                constexpr int T4 = S::K4_TILE;        // floats per tile
-                o.k4_g8x[k] = alloc(S::G8_NT * T4); o.k4_g8h[k] = alloc(S::G8_NT * T4);
-                o.k4_f1[k] = alloc(S::NT2 * T4); o.k4_q[k] = alloc(S::NT3 * T4); o.k4_f2[k] = alloc(S::NT2 * T4);
+                cur = round_up(cur, 256); o.u8_gx[k] = cur; cur += S::U8_G;
+                o.u8_gh[k] = cur; cur += S::U8_G;
+                o.u8_f1[k] = cur; cur += S::U8_F;
+                o.u8_q[k] = cur; cur += S::U8_Q;
+                o.u8_f2[k] = cur; cur += S::U8_F;
             }
         o.total = round_up(cur, 64);
         return o;
