@@ -191,6 +191,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     wb.li4 = li * 4;
     wb.lds = nullptr;
     wb.base = 0;
+    wb.k4d = 0;
 
     float* sp = smem + L::SP;
     float2* tw = reinterpret_cast<float2*>(smem + L::TW);

@@ -83,6 +83,7 @@ __global__ void __launch_bounds__(kSbThreads) __attribute__((amdgpu_waves_per_eu
     wb.li4 = li * 4;
     wb.lds = nullptr;
     wb.base = 0;
+    wb.k4d = 0;
     float* xs = smem + L::XS;
     const int b0 = (int)blockIdx.x * NS;
     const int bs = b0 + li < a.B ? b0 + li : a.B - 1;          // this lane's stream (the last tile's idle columns shadow the last stream)

@@ -593,6 +593,27 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
                 });
         }
     }
+    if (o.k4_delta != 0) {
+        // Register-resident block weights (fe::Shape::REGW): a second copy of the block-weight region whose B-operand tiles are
+        // regrouped four k-steps per lane ([ks / 4][lane][4], the ks % 4 remainder plain) for 16-byte fetches - fe::TokW
+        const int KS = C2 / 4, NF4 = KS / 4, tile_floats = KS * 64;
+        std::copy(p.buf.begin() + o.blk_wih[0], p.buf.begin() + o.blk_end, p.buf.begin() + o.blk_wih[0] + o.k4_delta);
+        std::vector<float> t((size_t)tile_floats);
+        auto regroup = [&](int off, int floats) {
+            for (int tl = 0; tl < floats / tile_floats; ++tl) {
+                float* dst = &p.buf[(size_t)off + o.k4_delta + (size_t)tl * tile_floats];
+                std::copy(dst, dst + tile_floats, t.begin());
+                for (int ks = 0; ks < 4 * NF4; ++ks)
+                    for (int ln = 0; ln < 64; ++ln) dst[(ks / 4) * 256 + ln * 4 + (ks % 4)] = t[(size_t)ks * 64 + ln];
+            }
+        };
+        const int szCC = fe::ceil_div(C2, 16) * tile_floats, szC3 = fe::ceil_div(3 * C2, 16) * tile_floats;
+        for (int k = 0; k < d.KB; ++k) {
+            regroup(o.blk_wih[k], 3 * szCC); regroup(o.blk_whh[k], 3 * szCC);
+            regroup(o.blk_fc1_w[k], szCC); regroup(o.blk_qkv[k], szC3); regroup(o.blk_fc2_w[k], szCC);
+            if (d.TA) regroup(o.blk_tqkv[k], szC3);
+        }
+    }
     *out = std::move(p.buf);
     return FE_OK;
 }

@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
     wb.li4 = (lane & 15) * 4;
     wb.lds = nullptr;
     wb.base = 0;
+    wb.k4d = 0;
 
     // ---- one-time: the zero halos (compressed spectrum, skip buffers), twiddles, weight unit 0.
     // !PERSIST (one stream per workgroup): everything the front of the frame waits for is requested HERE, in one memory round trip

@@ -113,6 +113,10 @@ struct Shape {
     // like the qkv GEMM.  r, z, n of a channel then sit in different lanes: the pre-activations cross through LDS
     // and the gate math runs element-per-thread over all 256 threads.  (Register-resident weights only.)
     static constexpr bool GFLAT = (C2 % 16 != 0) && (3 * NTPW3 + 2 * NTPW2) * KS_2 <= 160;
+    // block weights register-resident in the 256-thread per-hop kernel (fetched one phase ahead).  Those shapes read a second
+    // copy of the block-weight region (PackedOffsets::k4_delta) whose tiles are regrouped four k-steps per lane: one 16-byte
+    // load per four fragments (a wave-level load costs the CU's vector-memory path 12 - 17 cycles whatever its width)
+    static constexpr bool REGW = GFLAT || (NTPW2 * 6 + NTPW3 + 2 * NTPW2) * KS_2 <= 160;
     // "channel-grouped" GRU gate packing of the 512-thread per-hop kernel (fe_frame8.hip.h): the r, z, n columns of 16 channels as
     // three tiles of ONE wave (the gates of a (row, channel) meet in a lane: gate math in the GEMM epilogue, no exchange through
     // LDS), the C2 % 16 left-over channels' r | z | n in one mixed tile.  A packing predicate only: it must not depend on LOW
@@ -149,6 +153,7 @@ struct PackedOffsets {
     int blk_qkv_b[8], blk_fhh[8], blk_fbhn[8];
     // dptransformer variant: the time attention's qkv weights per block, the model's positional bias [NH][32] (slot L = current frame)
     int blk_tqkv[8], tpe;
+    int blk_end, k4_delta;      // end of the block-weight region; distance to its k4-regrouped copy (Shape::REGW, else 0)
     // ln variant: rf_post's 1x1 conv as a staged unit (B fragments + bias), gain / bias of every norm site ([channel])
     int rfpost1_w, rfpost1_b, ln_g[48], ln_b[48];
     int rfpost_lin, rfpost_w, rfpost_b;
@@ -229,11 +234,17 @@ struct Pack {
             }
             if (S::TATT) o.blk_tqkv[k] = alloc(szB(C2, 3 * C2));
         }
+        o.blk_end = round_up(cur, 64);
         if (S::TATT) o.tpe = alloc(S::NH * 32);
         if (S::LN)
             for (int q = 0; q < S::LN_SITES; ++q) { o.ln_g[q] = alloc(szBias(C1 > C2 ? C1 : C2)); o.ln_b[q] = alloc(szBias(C1 > C2 ? C1 : C2)); }
         o.blk_stride = S::KB > 1 ? o.blk_wih[1] - o.blk_wih[0] : 0;
         o.gru_flat = S::GFLAT ? 1 : 0;
+        o.k4_delta = 0;
+        if (S::REGW) {      // k4-regrouped copy of [blk_wih[0], blk_end) for the register-resident fetches (TokW)
+            const int n = o.blk_end - o.blk_wih[0];
+            o.k4_delta = alloc(n) - o.blk_wih[0];
+        }
         o.window = alloc(S::NFFT); o.window_istft = alloc(S::NFFT); o.twiddle = alloc(S::NFFT);
         {
             constexpr int N1 = S::NFFT / 32, KC = N1 / 2, MT = N1 / 16;
@@ -327,6 +338,7 @@ struct WSrc {
     int li4;            // (lane & 15) * 4 bytes
     const float* lds;   // STAGED: LDS copy of the current weight unit
     int base;           // STAGED: absolute offset (floats) of the current unit in the packed buffer
+    int k4d;            // distance (floats) from the block-weight region to its k4-regrouped copy (Shape::REGW), else 0
     __device__ __forceinline__ float at(int off_floats) const {          // + lane
         if constexpr (STAGED) return lds[off_floats - base + (lane4 >> 2)];
         else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane4, off_floats * 4, 0));
@@ -349,6 +361,9 @@ struct WSrc {
     // explicit per-lane byte offset (an offset beyond the buffer reads 0 without touching memory)
     __device__ __forceinline__ float at_gv(int off_floats, int voff_bytes) const {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_bytes, off_floats * 4, 0));
+    }
+    __device__ __forceinline__ f32x4 at_gv4(int off_floats, int voff_bytes) const {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_bytes, off_floats * 4, 0));
     }
     __device__ __forceinline__ float gather_g(int off_floats_per_lane) const {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off_floats_per_lane * 4, 0, 0));
@@ -1082,19 +1097,30 @@ struct TokW {
         return g * NT + ct;
     }
     __device__ __forceinline__ void bind(const WS& s, int w_off_, int b_off_, int NT_, int wave_, bool live = true) {
-        src = &s; w_off = w_off_; b_off = b_off_; NT = NT_; wave = wave_; kill = live ? 0 : 0x40000000;
+        src = &s; w_off = w_off_ + (REG ? s.k4d : 0); b_off = b_off_; NT = NT_; wave = wave_; kill = live ? 0 : 0x40000000;
     }
-    // element e of the flattened register set [NTPW][NG][KS + 1] (the +1 is the bias)
+    // Register-resident sets read the k4-regrouped copy of the weights: per tile [KS / 4][lane][4] (four consecutive k-steps of
+    // a lane in 16 bytes) then the KS % 4 left-over k-steps as plain [ks][lane].  One fetch element = one load:
+    // per (tile, gate) NF 16-byte loads, REM dword loads and the bias dword.
+    static constexpr int NF = KS / 4, REM = KS % 4, EPT = NF + REM + 1;
     __device__ __forceinline__ void fetch_elem(int e) {
-        const int j = e / (NG * (KS + 1)), r = e - j * (NG * (KS + 1));
-        const int g = r / (KS + 1), ks = r - g * (KS + 1);
-        if (ks == KS) bv[j][g] = b_off >= 0 ? src->at_gv(b_off + tile(j, g) * 16, src->li4 + oob(j)) : 0.0f;
-        else w[j][g][ks] = src->at_gv(w_off + (tile(j, g) * KS + ks) * 64, src->lane4 + oob(j));
+        const int j = e / (NG * EPT), r = e - j * (NG * EPT);
+        const int g = r / EPT, q = r - g * EPT;
+        const int t0 = w_off + tile(j, g) * (KS * 64);
+        if (q < NF) {
+            const f32x4 v = src->at_gv4(t0 + q * 256, src->lane4 * 4 + oob(j));
+            w[j][g][4 * q] = v[0]; w[j][g][4 * q + 1] = v[1]; w[j][g][4 * q + 2] = v[2]; w[j][g][4 * q + 3] = v[3];
+        } else if (q < NF + REM) {
+            const int ks = 4 * NF + (q - NF);
+            w[j][g][ks] = src->at_gv(t0 + ks * 64, src->lane4 + oob(j));
+        } else {
+            bv[j][g] = b_off >= 0 ? src->at_gv(b_off + tile(j, g) * 16, src->li4 + oob(j)) : 0.0f;
+        }
     }
     // number of loads fetch_part(part, parts) issues
     static constexpr int part_count(int part, int parts) {
         if (!REG) return 0;
-        const int TOT = NTPW * NG * (KS + 1), per = (TOT + parts - 1) / parts;
+        const int TOT = NTPW * NG * EPT, per = (TOT + parts - 1) / parts;
         int lo = part * per, hi = (part + 1) * per;
         lo = lo < TOT ? lo : TOT;
         hi = hi < TOT ? hi : TOT;
@@ -1103,7 +1129,7 @@ struct TokW {
     // slice `part` of `parts` (all indices are compile-time constants once the caller's loops are unrolled)
     __device__ __forceinline__ void fetch_part(int part, int parts) {
         if constexpr (REG) {
-            constexpr int TOT = NTPW * NG * (KS + 1);
+            constexpr int TOT = NTPW * NG * EPT;
             const int per = (TOT + parts - 1) / parts;
 #pragma unroll
             for (int q = 0; q < TOT; ++q)
@@ -1288,6 +1314,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
     wb.li4 = (lane & 15) * 4;
     wb.lds = nullptr;
     wb.base = 0;
+    wb.k4d = o.k4_delta;
 
     // ---- one-time: zero what must be zero - the 2-bin halo of the compressed spectrum and the halo rows of the
     // LDS-resident skip buffers (the work buffers' halos are re-zeroed per frame).  Everything else in LDS is either
@@ -1704,7 +1731,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
         // one phase ahead when they fit (REGW), else streamed from L2 inside the GEMM pipeline
         constexpr int NTPW3 = ceil_div(S::NT3, kWaves);
         constexpr bool GFLAT = S::GFLAT;
-        constexpr bool REGW = GFLAT || (NTPW2 * 6 + NTPW3 + 2 * NTPW2) * S::KS_2 <= 160;
+        constexpr bool REGW = S::REGW;
         using WS = WSrc<Lds<S>::STAGED>;
         // GRU gates (r,z,n), input and hidden matrices: three column blocks per channel tile, or (GFLAT) one flat matrix
         constexpr int GNT = GFLAT ? S::NT3 : S::NT2;

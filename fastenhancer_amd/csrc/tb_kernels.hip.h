@@ -113,6 +113,7 @@ __device__ __forceinline__ WSrc<false> make_wsrc(const float* wp, int lane) {
     wb.li4 = (lane & 15) * 4;
     wb.lds = nullptr;
     wb.base = 0;
+    wb.k4d = 0;
     return wb;
 }
 
