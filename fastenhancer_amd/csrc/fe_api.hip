@@ -1035,6 +1035,83 @@ int pack_weights_fspen(fe_handle* h, const std::vector<float>& blob, std::vector
             for (int c = 0; c < 16; ++c) { for (int k = 0; k < 16; ++k) buf[Gb + P::G_FC_W + k * 16 + c] = fw[c * 16 + k]; buf[Gb + P::G_FC_B + c] = fb[c]; }
         }
     }
+    {   // stream-batched DPE (fspen_sb_kernels.hip.h): A-operand fragments - lane (li = row, lg) of k-step ks holds W[row][4 (ks % 4) + lg];
+        // the r / z rows and biases carry -log2 e, the n rows 2 log2 e (sigma / tanh as one exp2 + rcp of the pre-scaled value)
+        using Q = fe::FSbPk;
+        const float kRZ = -1.4426950408889634f, kN = 2.8853900817779268f;
+        for (int b = 0; b < 3; ++b) {
+            const int D = P::SB + b * Q::D_SIZE;
+            snprintf(nm, sizeof nm, "dpe_blocks.%d.", b);
+            const std::string p = nm;
+            for (int d = 0; d < 2; ++d) {
+                const char* sfx = d ? "_reverse" : "";
+                const float* wi = S(p + "intra_rnn.weight_ih_l0" + sfx);      // (48, 16), gate order r, z, n
+                const float* wh = S(p + "intra_rnn.weight_hh_l0" + sfx);
+                const float* bi = S(p + "intra_rnn.bias_ih_l0" + sfx);
+                const float* bh = S(p + "intra_rnn.bias_hh_l0" + sfx);
+                for (int q = 0; q < 4; ++q) {
+                    const int wave = d * 4 + q;
+                    for (int ks = 0; ks < 8; ++ks)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int li = lane & 15, lg = lane >> 4, j = li >> 2, g = li & 3, u = 4 * q + j, k = 4 * (ks & 3) + lg;
+                            float v = 0.0f;      // row (unit u, gate g of r, z, n_x, n_h): the x half of n_x, the h half of n_h
+                            if (ks < 4) { if (g == 0) v = wi[u * 16 + k] * kRZ; else if (g == 1) v = wi[(16 + u) * 16 + k] * kRZ; else if (g == 2) v = wi[(32 + u) * 16 + k] * kN; }
+                            else { if (g == 0) v = wh[u * 16 + k] * kRZ; else if (g == 1) v = wh[(16 + u) * 16 + k] * kRZ; else if (g == 3) v = wh[(32 + u) * 16 + k] * kN; }
+                            buf[D + Q::I_W + (wave * 8 + ks) * 64 + lane] = v;
+                        }
+                    for (int lg = 0; lg < 4; ++lg) {
+                        const int u = 4 * q + lg;
+                        float* dst = &buf[D + Q::I_B + (wave * 4 + lg) * 4];
+                        dst[0] = (bi[u] + bh[u]) * kRZ; dst[1] = (bi[16 + u] + bh[16 + u]) * kRZ; dst[2] = bi[32 + u] * kN; dst[3] = bh[32 + u] * kN;
+                    }
+                }
+            }
+            auto feat = [](int li) { return 4 * (li & 3) + (li >> 2); };        // output row li = 4 lg + r  <->  feature 4 r + lg
+            {
+                const float* w = S(p + "intra_fc.weight");                      // (16, 32)
+                const float* bb = S(p + "intra_fc.bias");
+                const float* lw = S(p + "intra_ln.weight");
+                const float* lb = S(p + "intra_ln.bias");
+                for (int ks = 0; ks < 8; ++ks)
+                    for (int lane = 0; lane < 64; ++lane) buf[D + Q::FC_W + ks * 64 + lane] = w[feat(lane & 15) * 32 + 16 * (ks >> 2) + 4 * (ks & 3) + (lane >> 4)];
+                for (int lg = 0; lg < 4; ++lg)
+                    for (int r = 0; r < 4; ++r) {
+                        buf[D + Q::FC_B + lg * 4 + r] = bb[4 * r + lg];
+                        for (int f = 0; f < 32; ++f) {
+                            buf[D + Q::LN_W + f * 16 + lg * 4 + r] = lw[f * 16 + 4 * r + lg];
+                            buf[D + Q::LN_B + f * 16 + lg * 4 + r] = lb[f * 16 + 4 * r + lg];
+                        }
+                    }
+            }
+            for (int g = 0; g < 8; ++g) {
+                const int Gb = D + Q::GRP + g * Q::G_SIZE;
+                const std::string q = p + "inter_rnn.inter_rnn." + std::to_string(g);
+                const float* wi = S(q + ".weight_ih_l0");
+                const float* wh = S(q + ".weight_hh_l0");
+                const float* bi = S(q + ".bias_ih_l0");
+                const float* bh = S(q + ".bias_hh_l0");
+                const float* fw = S(p + "inter_rnn.inter_fc." + std::to_string(g) + ".weight");
+                const float* fb = S(p + "inter_rnn.inter_fc." + std::to_string(g) + ".bias");
+                for (int i = 0; i < 24; ++i) {
+                    const int gate = i < 8 ? 0 : (i < 16 ? 1 : 2), ksl = i < 16 ? (i & 7) : i - 16;      // ksl < 4: x half, else h half
+                    const float* src = ksl < 4 ? wi : wh;
+                    for (int lane = 0; lane < 64; ++lane)
+                        buf[Gb + Q::G_W + i * 64 + lane] = src[(gate * 16 + feat(lane & 15)) * 16 + 4 * (ksl & 3) + (lane >> 4)] * (gate < 2 ? kRZ : kN);
+                }
+                for (int lg = 0; lg < 4; ++lg)
+                    for (int r = 0; r < 4; ++r) {
+                        const int u = 4 * r + lg;
+                        buf[Gb + Q::G_B + 0 + lg * 4 + r] = (bi[u] + bh[u]) * kRZ;
+                        buf[Gb + Q::G_B + 16 + lg * 4 + r] = (bi[16 + u] + bh[16 + u]) * kRZ;
+                        buf[Gb + Q::G_B + 32 + lg * 4 + r] = bi[32 + u] * kN;
+                        buf[Gb + Q::G_B + 48 + lg * 4 + r] = bh[32 + u] * kN;
+                        buf[Gb + Q::G_FCB + lg * 4 + r] = fb[u];
+                    }
+                for (int ks = 0; ks < 4; ++ks)
+                    for (int lane = 0; lane < 64; ++lane) buf[Gb + Q::G_FCW + ks * 64 + lane] = fw[feat(lane & 15) * 16 + 4 * ks + (lane >> 4)];
+            }
+        }
+    }
     conv("feature_split.0", 32, 16, 1, P::SP1_W, P::SP1_B);
     {   // feature_split.1 Linear (64 out j, 32 in f) -> [f][j]
         const float* w = S("feature_split.1.weight");
@@ -1084,8 +1161,32 @@ fe::FArgs fspen_args(fe_handle* h, int B, int T) {
     return a;
 }
 
-int launch_fspen(fe_handle* h, const fe::FArgs& a, void* stream) {
+// FSPEN per-hop step of large batches: the DPE blocks batched over the streams (fspen_sb_kernels.hip.h) from FE_FSPEN_SB streams
+// (0 = never; measured crossover on 256 CUs between 1536 and 2048 streams - a sixteen-stream workgroup per CU needs 4096 to fill the chip)
+int fspen_sb_min() {
+    static const int v = [] { const char* e = getenv("FE_FSPEN_SB"); return e ? atoi(e) : 2048; }();
+    return v;
+}
+int ensure_fsplit(fe_handle* h, int B) {
+    if (!h->fimpl || fspen_sb_min() <= 0 || B < fspen_sb_min() || B <= h->bsplit_streams) return FE_OK;
+    if (h->bsplit_dev) { FE_HIP_CHECK(hipFree(h->bsplit_dev)); h->bsplit_dev = nullptr; h->bsplit_streams = 0; }
+    FE_HIP_CHECK(hipMalloc(&h->bsplit_dev, (size_t)B * h->fimpl->split_floats_per_stream * sizeof(float)));
+    h->bsplit_streams = B;
+    return FE_OK;
+}
+
+int launch_fspen(fe_handle* h, const fe::FArgs& a_in, void* stream) {
     hipError_t e = hipSuccess;
+    fe::FArgs a = a_in;
+    if (a.mode == fe::FE_MODE_STREAM && a.T == 1 && a.dbg == nullptr && fspen_sb_min() > 0 && a.B >= fspen_sb_min()) {      // (fe_profile_step: the DPE kernel's counters only)
+        const int rc = ensure_fsplit(h, a.B);
+        if (rc != FE_OK) return rc;
+        a.tok = h->bsplit_dev;
+        a.carry = a.tok + (size_t)a.B * 512;
+        h->fimpl->launch_sb(a, h->max_wgs, (hipStream_t)stream, &e);
+        if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+        return FE_OK;
+    }
     h->fimpl->launch(a, h->max_wgs, (hipStream_t)stream, &e);
     if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return FE_OK;
@@ -1562,6 +1663,10 @@ int fe_state_init(fe_handle* h, float* state_dev, int B, void* stream) {
     FE_HIP_CHECK(hipMemsetAsync(state_dev, 0, fe_state_floats(h, B) * sizeof(float), (hipStream_t)stream));
     if (h->bimpl) {                // (the scratch of the three-launch per-hop step: sized here, so that the steps of this batch allocate nothing)
         const int rc = ensure_bsplit(h, B);
+        if (rc != FE_OK) return rc;
+    }
+    if (h->fimpl) {
+        const int rc = ensure_fsplit(h, B);
         if (rc != FE_OK) return rc;
     }
     return FE_OK;

@@ -23,6 +23,20 @@ struct FShape {
     static constexpr int CACHE_FLOATS = NCACHE * FG * C;                  // per stream
 };
 
+// ---- the stream-batched DPE kernel's region of the packed weights (fspen_sb_kernels.hip.h; per DPE block, offsets in floats)
+struct FSbPk {
+    static constexpr int I_W = 0;                       // intra GRU: A fragments [wave = 4 d + q][k-step < 8 (x | h)][64], rows (unit 4 q + j, gate r z n_x n_h)
+    static constexpr int I_B = I_W + 8 * 8 * 64;        // [wave][lg = unit 4 q + lg][gate]: b_ih + b_hh (r, z), b_in, b_hn - pre-scaled like the rows
+    static constexpr int FC_W = I_B + 128;              // intra_fc: A fragments [k-step < 8 (fwd | bwd)][64], row 4 lg + r <-> channel 4 r + lg
+    static constexpr int FC_B = FC_W + 512;             // [lg][r]
+    static constexpr int LN_W = FC_B + 16;              // [f][lg][r]
+    static constexpr int LN_B = LN_W + 512;
+    static constexpr int GRP = LN_B + 512;              // 8 groups x { gate fragments [24][64]: r (x | h), z (x | h), n_x, n_h; biases [gate][lg][r]; inter_fc [4][64]; its bias [lg][r] }
+    static constexpr int G_W = 0, G_B = 24 * 64, G_FCW = G_B + 64, G_FCB = G_FCW + 256, G_SIZE = G_FCB + 16;
+    static constexpr int D_SIZE = GRP + 8 * G_SIZE;
+    static constexpr int TOTAL = 3 * D_SIZE;
+};
+
 // ---- packed weights (floats), filled by the host packer; all matrices k-major: [k][outputs]
 struct FPk {
     static constexpr int WINDOW = 0, WINDOW_I = 512, TW = 1024;           // twiddles float2[256]
@@ -65,7 +79,8 @@ struct FPk {
     static constexpr int FD2_W = FD1_B + 4;                               // [c < 8][4]
     static constexpr int FD2_T = FD2_W + 32;                              // [(c*6 + k)][2]    c < 4
     static constexpr int FD2_B = FD2_T + 48;
-    static constexpr int TOTAL = (FD2_B + 2 + 3) / 4 * 4;
+    static constexpr int SB = (FD2_B + 2 + 3) / 4 * 4;                    // stream-batched DPE region (FSbPk)
+    static constexpr int TOTAL = SB + FSbPk::TOTAL;
 };
 
 struct FArgs {
@@ -87,6 +102,9 @@ struct FArgs {
     unsigned int* pipe_flags; // [B][num_blocks]: frames whose inter-GRU states of block k are in `gru`
     float* frames;            // [B][T][N] windowed output frames (summed / envelope-normalised by istft_ola_kernel)
     int pipe_p;
+    // split step of large batches (PART 1 -> fspen_sb_dpe_kernel -> PART 2)
+    float* tok;               // [B][32][16] DPE tokens
+    float* carry;             // [B][FCarry::FLOATS] what the tail needs of the front's LDS: compressed spectrum, encoder outputs, sub-band features
 };
 
 // debug stages (fe_debug_step): name, rows, cols as dumped (row-major)
@@ -134,8 +152,16 @@ struct FLds {
     static constexpr int T1 = SB + 5632, D1 = SB + 6656, T0 = SB + 7168;
     static constexpr int MF = SB + 2048;           // full-band mask [2][258]
     static constexpr int TOTAL = SB + 7696;
+    static constexpr int FRONT_TOTAL = EIN + 2 * 264;      // what PART 1 (STFT .. feature merge) touches: 34 KB, four workgroups per CU
     static_assert(SB % 2 == 0 && TW % 2 == 0, "float2 alignment");
     static_assert((size_t)TOTAL * 4 <= 64 * 1024, "static LDS");
+};
+
+// the front's LDS regions that the tail reads: [SP, TW) and [E0, SB)
+struct FCarry {
+    static constexpr int A0 = FLds::SP, AN = FLds::TW - FLds::SP, B0 = FLds::E0, BN = FLds::SB - FLds::E0;
+    static constexpr int FLOATS = (AN + BN + 3) / 4 * 4;
+    static_assert(AN % 4 == 0 && BN % 4 == 0 && A0 % 4 == 0 && B0 % 4 == 0, "16-byte copies");
 };
 
 // Read-only view of the packed weights through ONE buffer resource with 32-bit indices.  With plain pointers every far constant
@@ -242,10 +268,16 @@ __device__ __forceinline__ float row_dot(const float (&w)[12], float h, float ac
 // PIPE: time pipelining of an offline launch (as for FastEnhancer / BSRNN): the only thing a frame needs from the previous one are the
 // inter-GRU states (24 x [4][16] per stream), handed over per DPE block through `gru` - agent-scope stores, drained, a counter per
 // (utterance, block); the consumer polls the counter and fetches the states right before the block's inter GRUs.
-template <class S, bool PROF, bool DBG, bool PIPE = false>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(FS_WPE, FS_WPE))) fspen_frame_kernel(FArgs a) {
+// PART: 0 the whole frame; 1 the front (STFT .. feature merge: tokens and the tail's inputs to global memory); 2 the tail (feature
+// split .. iSTFT) - the per-hop step of large batches runs 1 -> fspen_sb_dpe_kernel (fspen_sb_kernels.hip.h) -> 2
+#ifndef FS_WPE_FRONT
+#define FS_WPE_FRONT 4
+#endif
+template <class S, bool PROF, bool DBG, bool PIPE = false, int PART = 0>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PART == 1 ? FS_WPE_FRONT : FS_WPE, PART == 1 ? FS_WPE_FRONT : FS_WPE))) fspen_frame_kernel(FArgs a) {
     static_assert(!PIPE || (!PROF && !DBG), "the time-pipelined instantiation is the plain offline kernel");
-    __shared__ __attribute__((aligned(16))) float smem[FLds::TOTAL];
+    static_assert(PART == 0 || (!PROF && !DBG && !PIPE), "the split step is the plain per-hop kernel");
+    __shared__ __attribute__((aligned(16))) float smem[PART == 1 ? FLds::FRONT_TOTAL : FLds::TOTAL];
     using L = FLds;
     using P = FPk;
     constexpr int N = S::NFFT, H = S::HOP, OVL = S::OVL, BINS = S::BINS;
@@ -311,6 +343,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
         const int tid = tid0 + lzv;
         const int lane = tid & 63;
         FS_CLK(0);
+        float* x = smem + L::XA;          // tokens [f][c]
+        float* xn = smem + L::XB;
+        if constexpr (PART != 2) {
         // ============================ STFT + compress (models/fspen/model.py:409-417) ============================
         float* magp = smem + L::MAGP;
         float* ein = smem + L::EIN;
@@ -516,8 +551,6 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
         FS_LDW(mg2_w, 32, P::MG2_W + (tid & 15), 16);
         const float mg2_b = wp[P::MG2_B + (tid & 15)];
         __syncthreads();
-        float* x = smem + L::XA;          // tokens [f][c]
-        float* xn = smem + L::XB;
         {
             const int c = tid & 15;
             float acc[2] = {mg2_b, mg2_b};
@@ -530,8 +563,26 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
         }
         __syncthreads();
         dump(4, [&](int r, int c) { return x[c * 16 + r]; });
+        if constexpr (PART == 1) {
+            f32x4* tk = reinterpret_cast<f32x4*>(a.tok + (size_t)b * 512);
+            f32x4* cr = reinterpret_cast<f32x4*>(a.carry + (size_t)b * FCarry::FLOATS);
+            for (int i = tid; i < 128; i += kThreads) tk[i] = reinterpret_cast<const f32x4*>(x)[i];
+            for (int i = tid; i < FCarry::AN / 4; i += kThreads) cr[i] = reinterpret_cast<const f32x4*>(smem + FCarry::A0)[i];
+            for (int i = tid; i < FCarry::BN / 4; i += kThreads) cr[FCarry::AN / 4 + i] = reinterpret_cast<const f32x4*>(smem + FCarry::B0)[i];
+            __syncthreads();
+            continue;
+        }
+        } else {
+            const f32x4* tk = reinterpret_cast<const f32x4*>(a.tok + (size_t)b * 512);
+            const f32x4* cr = reinterpret_cast<const f32x4*>(a.carry + (size_t)b * FCarry::FLOATS);
+            for (int i = tid; i < 128; i += kThreads) reinterpret_cast<f32x4*>(x)[i] = tk[i];
+            for (int i = tid; i < FCarry::AN / 4; i += kThreads) reinterpret_cast<f32x4*>(smem + FCarry::A0)[i] = cr[i];
+            for (int i = tid; i < FCarry::BN / 4; i += kThreads) reinterpret_cast<f32x4*>(smem + FCarry::B0)[i] = cr[FCarry::AN / 4 + i];
+            __syncthreads();
+        }
 
         FS_CLK(3);
+        if constexpr (PART == 0) {
         // ============================ 3 x DPE (DPE.forward, :172-189) ============================
         float* gi = smem + L::GI;
         float* hseq = smem + L::HSEQ;
@@ -725,6 +776,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
             __syncthreads();
             dump(6 + 2 * blk, [&](int r, int c) { return x[r * 16 + c]; });
             if (blk == 0) FS_CLK(11);
+        }
         }
 
         FS_CLK(4);
@@ -1068,6 +1120,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(F
 
 #undef FS_LDW
 
+}  // namespace fe
+#include "fspen_sb_kernels.hip.h"
+namespace fe {
+
 struct FImpl {
     int HOP;
     size_t lds_bytes;
@@ -1079,6 +1135,9 @@ struct FImpl {
     void (*launch_pipe)(const FArgs&, hipStream_t, hipError_t*);       // time-pipelined offline launch (cooperative: B * pipe_p workgroups)
     int occ;                  // workgroups per CU
     int num_blocks;
+    // per-hop step of large batches: front -> DPE blocks batched over the streams (fspen_sb_kernels.hip.h) -> tail; a.tok / a.carry set
+    void (*launch_sb)(const FArgs&, int max_wgs, hipStream_t, hipError_t*);
+    size_t split_floats_per_stream;      // tok + carry
 };
 
 template <class S>
@@ -1100,6 +1159,22 @@ void flaunch_impl(const FArgs& a, int max_wgs, hipStream_t st, hipError_t* err) 
     *err = hipGetLastError();
 }
 
+template <class S>
+void flaunch_sb_impl(const FArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
+    constexpr int OCC_LDS = (160 * 1024) / (FLds::TOTAL * 4);
+    constexpr int OCC = OCC_LDS < FS_WPE ? OCC_LDS : FS_WPE;
+    const int slots = max_wgs * OCC;
+    const int grid = a.B < slots ? a.B : slots;
+    constexpr int OCC_F_LDS = (160 * 1024) / (FLds::FRONT_TOTAL * 4);
+    const int slots_f = max_wgs * (OCC_F_LDS < FS_WPE_FRONT ? OCC_F_LDS : FS_WPE_FRONT);
+    hipLaunchKernelGGL((fspen_frame_kernel<S, false, false, false, 1>), dim3(a.B < slots_f ? a.B : slots_f), dim3(kThreads), 0, st, a);
+    FSbArgs sa{a.wp, a.tok, a.gru, a.B, a.clk};
+    *err = fspen_sb_launch<S>(sa, st);
+    if (*err != hipSuccess) return;
+    hipLaunchKernelGGL((fspen_frame_kernel<S, false, false, false, 2>), dim3(grid), dim3(kThreads), 0, st, a);
+    *err = hipGetLastError();
+}
+
 inline void fdbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
     *rows = FDebugLayout::rows(s);
     *cols = FDebugLayout::cols(s);
@@ -1110,7 +1185,7 @@ template <class S>
 FImpl make_fimpl() {
     constexpr int OCC_LDS = (160 * 1024) / (FLds::TOTAL * 4);
     return FImpl{S::HOP, (size_t)FLds::TOTAL * 4, FDebugLayout::total(), FDebugLayout::n_stages, (size_t)FPk::TOTAL, &flaunch_impl<S>, &fdbg_stage_impl,
-                 &flaunch_pipe_impl<S>, OCC_LDS < FS_WPE ? OCC_LDS : FS_WPE, S::NB};
+                 &flaunch_pipe_impl<S>, OCC_LDS < FS_WPE ? OCC_LDS : FS_WPE, S::NB, &flaunch_sb_impl<S>, (size_t)512 + FCarry::FLOATS};
 }
 
 }  // namespace fe

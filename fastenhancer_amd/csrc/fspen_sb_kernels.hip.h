@@ -1,0 +1,308 @@
+// fspen_sb_kernels.hip.h — FSPEN's three DPE blocks BATCHED OVER THE STREAMS on the fp32 matrix cores (gfx950), for the per-hop step
+// of large batches (models/fspen/model.py:122-189: per block an intra bidirectional GRU over the 32 sub-bands + intra_fc + LayerNorm
+// + residual, then eight grouped inter GRUs over time + inter_fc + residuals).
+//
+// fspen_frame_kernel gives a stream a workgroup: every product of the DPE is then M = 1 (vector FMAs), and the intra GRU is a chain
+// of 96 dependent steps per frame on two of its four waves.  Here a workgroup takes SIXTEEN streams and every product is a matrix-core
+// GEMM with the streams as the N dimension, computed TRANSPOSED (as in bsrnn_sb_kernels.hip.h):
+//     out^T [rows x 16 streams] = W [rows x K] . in^T [K x 16 streams]
+// A = weights (fragments in registers), B = activations: lane (li, lg) holds feature 4 ks + lg of stream li for k-step ks,
+// C/D = lane (li, lg) holds rows 4 lg + r of stream li.  The ROW ORDER of every A operand is chosen by the host packer:
+//   * intra GRU step: all eight waves take part - wave (direction d = wave / 4, quarter q = wave % 4) owns hidden units 4 q .. 4 q + 3 of
+//     its direction; its ONE 16-row tile is (unit 4 q + j, gate g) at row 4 j + g with the gates r, z, n_x, n_h: K = 32 (the x half of
+//     n_x and the h half of n_h only - zero fragments elsewhere).  The four gate values of a (stream, unit) are the four accumulator
+//     registers of one lane: one gate evaluation per lane and step (6 transcendentals), the new h goes to the h sequence in LDS -
+//     [direction][sub-band][unit][16 streams] - which is at once the exchange buffer of the next step (ONE barrier per step for both
+//     directions) and the input of intra_fc.  The x half of the next step is issued before the barrier.
+//   * intra_fc, the inter GRUs' gate tiles and inter_fc: row 4 lg + r <-> feature 4 r + lg.  A lane's accumulator register r is then
+//     feature 4 r + lg = what the B operand of k-step r carries: LayerNorm output, new inter state and block output feed the next product
+//     from registers, and their LDS stores ([feature][16 streams], 64 consecutive floats per register) are conflict-free.
+// Wave w owns sub-bands 4 w .. 4 w + 3 = inter group w for intra_fc / LayerNorm / inter GRU / inter_fc: no barrier between those
+// phases but the two of the LayerNorm statistics (sums over a stream's 512 values: lanes li, li + 16, .. of eight waves).
+// LDS: tokens [32][16][16] (32 KiB) + h sequences [2][32][16][16] (64 KiB) + reductions: one workgroup per CU, 4096 streams fill the chip.
+// (included by fspen_kernels.hip.h, after FShape / FPk)
+#pragma once
+
+namespace fe {
+
+constexpr int kFsbStreams = 16;
+constexpr int kFsbThreads = 512;
+
+struct FSbLds {
+    static constexpr int X = 0;                       // [32 f][16 c][16 n]
+    static constexpr int HS = X + 32 * 16 * 16;       // [2 d][32 f][16 u][16 n]
+    static constexpr int RED = HS + 2 * 32 * 16 * 16; // [2][8 waves][16 n]
+    static constexpr int TOTAL = RED + 2 * 8 * 16;
+    static constexpr size_t BYTES = (size_t)TOTAL * 4;
+};
+
+struct FSbArgs {
+    const float* wp;          // the packed buffer of fspen_frame_kernel; the stream-batched region starts at FPk::SB
+    float* tok;               // [B][32][16] DPE tokens, in place (fspen_frame_kernel PART 1 -> this kernel -> PART 2)
+    float* gru;               // [24][B * 4][16] inter-GRU states
+    int B;
+    unsigned long long* clk;  // fe_profile_step: cycle counters of workgroup 0 (slots 32 ..), else null
+};
+
+__device__ __forceinline__ float fsb_sig(float pre) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre)); }                            // pre = -log2e x
+__device__ __forceinline__ float fsb_tanh(float pre) { return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre)), 1.0f); }   // pre = 2 log2e x
+
+// sum over the four lane groups (lanes li, li + 16, li + 32, li + 48)
+__device__ __forceinline__ float fsb_sum_lg(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <class S>      // (S = FShape<HOP>: the DPE does not depend on it - a template so that the kernel is emitted by the translation unit that launches it)
+__global__ void __launch_bounds__(kFsbThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) fspen_sb_dpe_kernel(FSbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using L = FSbLds;
+    using Q = FSbPk;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, FPk::TOTAL * 4, 0x00020000);
+    auto ldw = [&](int off_floats, int voff_bytes) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_bytes, off_floats * 4, 0));
+    };
+    auto ldw4 = [&](int off_floats, int voff_bytes) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_bytes, off_floats * 4, 0));
+    };
+#define FSB_CLK(i) do { if (a.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.clk[32 + (i)] = __builtin_readcyclecounter(); } while (0)
+    FSB_CLK(0);
+    float* X = smem + L::X;
+    float* HS = smem + L::HS;
+    float* red = smem + L::RED;
+    const int b0 = blockIdx.x * kFsbStreams;
+    const bool live = b0 + li < a.B;
+    const int bn = live ? b0 + li : a.B - 1;                     // this lane's stream (tiles past the batch repeat the last stream; stores predicated)
+    // tokens -> LDS [f][c][n]: thread (stream n = tid % 16, sub-band f = tid / 16) reads its 64 contiguous bytes
+    {
+        const int n = tid & 15, f = tid >> 4;
+        const int bs = b0 + n < a.B ? b0 + n : a.B - 1;
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.tok + (size_t)bs * 512 + f * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v = src[i];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[(f * 16 + 4 * i + r) * 16 + n] = v[r];
+        }
+    }
+    __syncthreads();
+    // the wave's own sub-bands (4 wave + fl): residual stream in registers, xr[fl][r] = channel 4 r + lg of stream li
+    float xr[4][4];
+#pragma unroll
+    for (int fl = 0; fl < 4; ++fl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xr[fl][r] = X[((4 * wave + fl) * 16 + 4 * r + lg) * 16 + li];
+
+    FSB_CLK(1);
+    const int d = wave >> 2, q = wave & 3;
+#pragma unroll 1
+    for (int blk = 0; blk < 3; ++blk) {
+        int lz = 0;
+        asm volatile("" : "+s"(lz));
+        const int D = FPk::SB + blk * Q::D_SIZE + lz;
+        // every weight of the block and the inter-GRU states are requested here: they land under the first recurrence steps
+        float aw[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) aw[ks] = ldw(D + Q::I_W + (wave * 8 + ks) * 64, lane * 4);
+        const f32x4 bias = ldw4(D + Q::I_B + (wave * 4) * 4, lg * 16);
+        float fw[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) fw[ks] = ldw(D + Q::FC_W + ks * 64, lane * 4);
+        const f32x4 fb = ldw4(D + Q::FC_B, lg * 16);
+        f32x4 lw[4], lb[4];
+#pragma unroll
+        for (int fl = 0; fl < 4; ++fl) {
+            lw[fl] = ldw4(D + Q::LN_W + (4 * wave + fl) * 16, lg * 16);
+            lb[fl] = ldw4(D + Q::LN_B + (4 * wave + fl) * 16, lg * 16);
+        }
+        const int G = D + Q::GRP + wave * Q::G_SIZE;
+        float gw[24];                                       // r: 8 k-steps (x | h), z: 8, n_x: 4, n_h: 4
+#pragma unroll
+        for (int i = 0; i < 24; ++i) gw[i] = ldw(G + Q::G_W + i * 64, lane * 4);
+        float cw[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) cw[ks] = ldw(G + Q::G_FCW + ks * 64, lane * 4);
+        const f32x4 b_r = ldw4(G + Q::G_B, lg * 16), b_z = ldw4(G + Q::G_B + 16, lg * 16), b_nx = ldw4(G + Q::G_B + 32, lg * 16),
+                    b_nh = ldw4(G + Q::G_B + 48, lg * 16), b_fc = ldw4(G + Q::G_FCB, lg * 16);
+        float* const st0 = a.gru + (((size_t)(blk * 8 + wave) * a.B + bn) * 4) * 16;
+        float hp[4][4];
+#pragma unroll
+        for (int fl = 0; fl < 4; ++fl)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) hp[fl][ks] = st0[fl * 16 + 4 * ks + lg];
+        // ---------------- intra GRU: 32 steps, both directions, one barrier per step ----------------
+        FSB_CLK(2 + 4 * blk);
+        {
+            const int f0 = d ? 31 : 0, fstep = d ? -1 : 1;
+            auto xload = [&](float (&xb)[4], int f) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) xb[ks] = X[(f * 16 + 4 * ks + lg) * 16 + li];
+            };
+            // the x half of a step - always issued one step ahead, off the h chain
+            auto xpart = [&](const float (&xb)[4]) {
+                f32x4 p = bias;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) p = FE_MFMA(aw[ks], xb[ks], p);
+                return p;
+            };
+            auto gates = [&](const f32x4& acc, float h) {
+                const float rg = fsb_sig(acc[0]), zg = fsb_sig(acc[1]);
+                const float ng = fsb_tanh(__builtin_fmaf(rg, acc[3], acc[2]));
+                return __builtin_fmaf(zg, h - ng, ng);                      // (1 - z) n + z h
+            };
+            // One workgroup barrier per step for both directions.  On gfx950 the fp32 MFMAs and the vector ALU share a SIMD's datapath:
+            // a step costs its 16 MFMAs (two waves x 8, 512 cycles) PLUS its vector instructions (timing experiments, cycles per step of
+            // 1.19 k: no x MFMAs -325, no h MFMAs -272, no barrier -210, no transcendentals -160) - no ordering of the two overlaps
+            // them (x half before / after / interleaved with the gate math: 36.0 / 38.2 / 38.2 k cycles per block), and neither does
+            // decoupling the directions (each direction's four waves on their own LDS counter, release add / acquire poll: 40.5 k).
+            float xb[4];
+            xload(xb, f0);
+            f32x4 accx = xpart(xb);
+            xload(xb, f0 + fstep);
+            // step 0: h = 0
+            f32x4 accn = xpart(xb);                                         // step 1's x half
+            float h = gates(accx, 0.0f);
+            HS[((d * 32 + f0) * 16 + 4 * q + lg) * 16 + li] = h;
+            accx = accn;
+            xload(xb, f0 + 2 * fstep);
+            __syncthreads();
+            int f = f0 + fstep;
+#pragma unroll 1
+            for (int s = 1; s < 32; ++s) {
+                float hb[4];
+                const float* hq = HS + ((d * 32 + (f - fstep)) * 16) * 16;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) hb[ks] = hq[(4 * ks + lg) * 16 + li];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) accx = FE_MFMA(aw[4 + ks], hb[ks], accx);
+                accn = xpart(xb);                 // the next step's x half
+                h = gates(accx, h);
+                HS[((d * 32 + f) * 16 + 4 * q + lg) * 16 + li] = h;
+                accx = accn;
+                f += fstep;
+                const int fn = f + fstep;
+                xload(xb, fn & 31);               // (the load after the last step is not used)
+                __syncthreads();
+            }
+        }
+        // the h half of the inter GRUs' gates does not wait for the LayerNorm: issued here, under the statistics' barriers
+        f32x4 ar[4], az[4], anx[4], anh[4];
+#pragma unroll
+        for (int fl = 0; fl < 4; ++fl) { ar[fl] = b_r; az[fl] = b_z; anx[fl] = b_nx; anh[fl] = b_nh; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int fl = 0; fl < 4; ++fl) {
+                ar[fl] = FE_MFMA(gw[4 + ks], hp[fl][ks], ar[fl]);
+                az[fl] = FE_MFMA(gw[12 + ks], hp[fl][ks], az[fl]);
+                anh[fl] = FE_MFMA(gw[20 + ks], hp[fl][ks], anh[fl]);
+            }
+        // ---------------- intra_fc + LayerNorm([F, C]) + residual: wave w owns sub-bands 4 w .. 4 w + 3 ----------------
+        FSB_CLK(3 + 4 * blk);
+        float xn[4][4];
+        {
+            f32x4 y[4];
+#pragma unroll
+            for (int fl = 0; fl < 4; ++fl) y[fl] = fb;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int fl = 0; fl < 4; ++fl) {
+                    const float hb = HS[(((ks >> 2) * 32 + 4 * wave + fl) * 16 + 4 * (ks & 3) + lg) * 16 + li];
+                    y[fl] = FE_MFMA(fw[ks], hb, y[fl]);
+                }
+            float s0 = 0.0f;
+#pragma unroll
+            for (int fl = 0; fl < 4; ++fl) s0 += (y[fl][0] + y[fl][1]) + (y[fl][2] + y[fl][3]);
+            s0 = fsb_sum_lg(s0);
+            if (lg == 0) red[wave * 16 + li] = s0;
+            __syncthreads();
+            float mean = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) mean += red[w * 16 + li];
+            mean *= (1.0f / 512.0f);
+            float s1 = 0.0f;
+#pragma unroll
+            for (int fl = 0; fl < 4; ++fl)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { y[fl][r] -= mean; s1 = __builtin_fmaf(y[fl][r], y[fl][r], s1); }
+            s1 = fsb_sum_lg(s1);
+            if (lg == 0) red[128 + wave * 16 + li] = s1;
+            __syncthreads();
+            float var = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) var += red[128 + w * 16 + li];
+            const float inv_std = __builtin_amdgcn_rsqf(var * (1.0f / 512.0f) + 1.0e-5f);
+#pragma unroll
+            for (int fl = 0; fl < 4; ++fl)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xn[fl][r] = __builtin_fmaf(y[fl][r] * inv_std, lw[fl][r], lb[fl][r]) + xr[fl][r];
+        }
+        // ---------------- inter path: group g = wave, one GRU step per sub-band row, inter_fc, residuals ----------------
+        FSB_CLK(4 + 4 * blk);
+        {
+            // the four rows' gate products interleaved: four independent chains per gate
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int fl = 0; fl < 4; ++fl) {
+                    ar[fl] = FE_MFMA(gw[ks], xn[fl][ks], ar[fl]);
+                    az[fl] = FE_MFMA(gw[8 + ks], xn[fl][ks], az[fl]);
+                    anx[fl] = FE_MFMA(gw[16 + ks], xn[fl][ks], anx[fl]);
+                }
+            float hn[4][4];
+#pragma unroll
+            for (int fl = 0; fl < 4; ++fl)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float rg = fsb_sig(ar[fl][r]), zg = fsb_sig(az[fl][r]);
+                    const float ng = fsb_tanh(__builtin_fmaf(rg, anh[fl][r], anx[fl][r]));
+                    hn[fl][r] = __builtin_fmaf(zg, hp[fl][r] - ng, ng);
+                    if (live) st0[fl * 16 + 4 * r + lg] = hn[fl][r];
+                }
+            f32x4 o[4];
+#pragma unroll
+            for (int fl = 0; fl < 4; ++fl) o[fl] = b_fc;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int fl = 0; fl < 4; ++fl) o[fl] = FE_MFMA(cw[ks], hn[fl][ks], o[fl]);
+#pragma unroll
+            for (int fl = 0; fl < 4; ++fl)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    xr[fl][r] = __builtin_fmaf(2.0f, xn[fl][r], o[fl][r]);     // + x_in inside the path extension, + x_in again in DPE.forward
+                    X[((4 * wave + fl) * 16 + 4 * r + lg) * 16 + li] = xr[fl][r];
+                }
+        }
+        __syncthreads();
+        FSB_CLK(5 + 4 * blk);
+    }
+    if (live) {
+#pragma unroll
+        for (int fl = 0; fl < 4; ++fl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.tok[(size_t)bn * 512 + (4 * wave + fl) * 16 + 4 * r + lg] = xr[fl][r];
+    }
+    FSB_CLK(14);
+#undef FSB_CLK
+}
+
+template <class S>
+hipError_t fspen_sb_launch(const FSbArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fspen_sb_dpe_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FSbLds::BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int grid = (a.B + kFsbStreams - 1) / kFsbStreams;
+    hipLaunchKernelGGL(fspen_sb_dpe_kernel<S>, dim3(grid), dim3(kFsbThreads), FSbLds::BYTES, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace fe
