@@ -388,16 +388,19 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
             const float* bhh = S(key("rnn.bias_hh_l0"));
             const int NG = C2 / 16, R = C2 % 16, NT = 3 * NG + 1, KS = C2 / 4;
             // tile t, column c -> row of the (rows, C2) weight matrix (-1: padding); bias(t, c)
-            auto pack_u8 = [&](int off, int ntiles, const float* w, const std::function<int(int, int)>& wrow, const std::function<float(int, int)>& bias) {
+            // (rscale(row): the gate rows carry -log2 e (r, z) / 2 log2 e (n) so that sigma / tanh are one exp2 + rcp of the accumulator)
+            auto pack_u8 = [&](int off, int ntiles, const float* w, const std::function<int(int, int)>& wrow, const std::function<float(int, int)>& bias,
+                               const std::function<float(int)>& rscale = [](int) { return 1.0f; }) {
                 for (int t = 0; t < ntiles; ++t) {
                     for (int ks = 0; ks < KS; ++ks)
                         for (int lane = 0; lane < 64; ++lane) {
                             const int row = wrow(t, lane % 16);
-                            p.buf[(size_t)off + ((size_t)t * KS + ks) * 64 + lane] = row >= 0 ? w[(size_t)row * C2 + 4 * ks + lane / 16] : 0.0f;
+                            p.buf[(size_t)off + ((size_t)t * KS + ks) * 64 + lane] = row >= 0 ? w[(size_t)row * C2 + 4 * ks + lane / 16] * rscale(row) : 0.0f;
                         }
-                    for (int c = 0; c < 16; ++c) p.buf[(size_t)off + (size_t)ntiles * KS * 64 + t * 16 + c] = wrow(t, c) >= 0 ? bias(t, c) : 0.0f;
+                    for (int c = 0; c < 16; ++c) p.buf[(size_t)off + (size_t)ntiles * KS * 64 + t * 16 + c] = wrow(t, c) >= 0 ? bias(t, c) * rscale(wrow(t, c)) : 0.0f;
                 }
             };
+            auto gscale = [&](int row) { return row < 2 * C2 ? fe::kGateRZ : fe::kGateN; };
             // channel-grouped gate tiles: tile 3 G + gate: column c <-> channel 16 G + c of that gate; the last tile: columns [0, R) r,
             // [R, 2 R) z, [2 R, 3 R) n of the R = C2 % 16 left-over channels
             auto grow = [&](int t, int c) -> int {
@@ -405,8 +408,8 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
                 return c < 3 * R ? (c / R) * C2 + 16 * NG + c % R : -1;
             };
             auto shared = [&](int t) { return t < 3 * NG && t % 3 < 2; };      // pure r / z tile: x and h halves in one accumulator
-            pack_u8(o.u8_gx[k], NT, wih, grow, [&](int t, int c) { const int r = grow(t, c); return bih[r] + (shared(t) ? bhh[r] : 0.0f); });
-            pack_u8(o.u8_gh[k], NT, whh, grow, [&](int t, int c) { const int r = grow(t, c); return shared(t) ? 0.0f : bhh[r]; });
+            pack_u8(o.u8_gx[k], NT, wih, grow, [&](int t, int c) { const int r = grow(t, c); return bih[r] + (shared(t) ? bhh[r] : 0.0f); }, gscale);
+            pack_u8(o.u8_gh[k], NT, whh, grow, [&](int t, int c) { const int r = grow(t, c); return shared(t) ? 0.0f : bhh[r]; }, gscale);
             auto plain = [&](int ncols) { return [ncols](int t, int c) { return 16 * t + c < ncols ? 16 * t + c : -1; }; };
             const float* f1b = S(key("rnn_fc.bias"));
             const float* f2b = S(key("attn_fc.bias"));

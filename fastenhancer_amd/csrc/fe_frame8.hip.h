@@ -434,10 +434,10 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
                     float hn[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float rr = sigmoid_f(ar[r]);
-                        const float zz = sigmoid_f(az[r]);
-                        const float nn = tanh_f(anx[r] + rr * anh[r]);
-                        hn[r] = (1.0f - zz) * nn + zz * hprev[r];
+                        const float rr = sigmoid_pre(ar[r]);        // (the packer scales the gate rows: -log2 e / 2 log2 e)
+                        const float zz = sigmoid_pre(az[r]);
+                        const float nn = tanh_pre(__builtin_fmaf(rr, anh[r], anx[r]));
+                        hn[r] = __builtin_fmaf(zz, hprev[r] - nn, nn);          // (1 - z) n + z h
                     }
                     if (16 * g_rt + 4 * lg < F2) {       // (F2 % 4 == 0: the four rows of a lane are valid together)
 #pragma unroll
@@ -478,10 +478,10 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float sx = ax[r], sh = ah[r], sm = sx + sh;
-                        const float rr = sigmoid_f(sm);
-                        const float zz = sigmoid_f(shl(sm, std::integral_constant<int, R>{}));
-                        const float nn = tanh_f(shl(sx, std::integral_constant<int, 2 * R>{}) + rr * shl(sh, std::integral_constant<int, 2 * R>{}));
-                        hn[r] = (1.0f - zz) * nn + zz * hprev[r];
+                        const float rr = sigmoid_pre(sm);
+                        const float zz = sigmoid_pre(shl(sm, std::integral_constant<int, R>{}));
+                        const float nn = tanh_pre(__builtin_fmaf(rr, shl(sh, std::integral_constant<int, 2 * R>{}), shl(sx, std::integral_constant<int, 2 * R>{})));
+                        hn[r] = __builtin_fmaf(zz, hprev[r] - nn, nn);          // (1 - z) n + z h
                     }
                     if (li < R && 16 * g_rt + 4 * lg < F2) {
 #pragma unroll

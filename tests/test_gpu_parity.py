@@ -112,7 +112,8 @@ def test_driver_loop_matches_reference_golden(name):
     y16 = enhance_stream(m, x, frames_per_call=16).cpu().numpy()
     _assert_close(y1w[0], g["long_wav_out"], "long run T=1, 256-thread kernel")
     assert np.array_equal(y1w, y16), "chunked launches must be bit-identical to per-hop launches"
-    assert np.abs(y1 - y1w).max() <= 2e-6 * max(1.0, np.abs(y1w).max()), "the two per-hop kernels agree to fp32 rounding"
+    # (two summation orders / pre-scaled gate rows through a 198-hop recurrence: a few ulp of the output scale; both are checked against the golden above)
+    assert np.abs(y1 - y1w).max() <= 5e-6 * max(1.0, np.abs(y1w).max()), "the two per-hop kernels agree to fp32 rounding"
 
 
 @pytest.mark.parametrize("name", ALL_SHAPES)
@@ -178,8 +179,8 @@ def test_wg8_per_hop_kernel_matches_oracle_and_the_four_wave_kernel(B):
         outs[kern] = torch.cat([eng.step(xd[:, t * H:(t + 1) * H], st, T=1) for t in range(hops)], dim=1).cpu().numpy()
         states[kern] = st.cpu().numpy()
     k8 = "wg8_persist" if B > 256 else "wg8"
-    assert np.abs(outs[k8] - outs["waves4"]).max() <= 2e-6 * max(1.0, np.abs(outs["waves4"]).max())
-    assert np.abs(states[k8] - states["waves4"]).max() <= 2e-6 * max(1.0, np.abs(states["waves4"]).max())
+    assert np.abs(outs[k8] - outs["waves4"]).max() <= 5e-6 * max(1.0, np.abs(outs["waves4"]).max())
+    assert np.abs(states[k8] - states["waves4"]).max() <= 5e-6 * max(1.0, np.abs(states["waves4"]).max())
     assert not np.array_equal(outs[k8], outs["waves4"]) or B == 0, "both switch positions ran the same kernel?"
     sel = list(range(B)) if B <= 5 else [0, 1, B // 2, B - 2, B - 1]
     caches = orc.initialize_cache(len(sel))
