@@ -1115,6 +1115,46 @@ int pack_weights_fspen(fe_handle* h, const std::vector<float>& blob, std::vector
             }
         }
     }
+    {   // stream-batched fullband_encoder_post, feature merge / split, fullband_decoder.0's 1x1 (fspen_sb_kernels.hip.h)
+        using Q = fe::FSbPk;
+        auto feat = [](int li) { return 4 * (li & 3) + (li >> 2); };
+        const float* wpo = S("fullband_encoder_post.weight");  // (32, 32, 1)
+        const float* w1 = S("feature_merge.0.weight");        // (32, 64)
+        const float* w2 = S("feature_merge.2.weight");        // (16, 32, 1)
+        const float* b2 = S("feature_merge.2.bias");
+        const float* s1 = S("feature_split.0.weight");        // (32, 16, 1)
+        const float* sb1 = S("feature_split.0.bias");
+        const float* s2 = S("feature_split.1.weight");        // (64, 32)
+        const float* wd0 = S("fullband_decoder.0.0.weight");  // (32, 64, 1)
+        const float* wdt = S("fullband_decoder.0.1.weight");  // ConvTranspose1d (32 in, 16 out, 6)
+        const float* bdt = S("fullband_decoder.0.1.bias");
+        for (int o = 0; o < 16; ++o) buf[P::SB + Q::FD0T_B + o] = bdt[o];
+        for (int lane = 0; lane < 64; ++lane) {
+            const int li = lane & 15, lg = lane >> 4;
+            for (int ot = 0; ot < 2; ++ot)
+                for (int ks = 0; ks < 8; ++ks) buf[P::SB + Q::POST_W + (ot * 8 + ks) * 64 + lane] = wpo[(16 * ot + feat(li)) * 32 + 4 * ks + lg];
+            for (int jt = 0; jt < 2; ++jt)
+                for (int ks = 0; ks < 16; ++ks) {
+                    const int i = ks < 8 ? 4 * ks + lg : 32 + 16 * ((ks - 8) >> 2) + 4 * lg + ((ks - 8) & 3);
+                    buf[P::SB + Q::MG1_W + (jt * 16 + ks) * 64 + lane] = w1[(16 * jt + feat(li)) * 64 + i];
+                }
+            for (int ks = 0; ks < 8; ++ks) buf[P::SB + Q::MG2_W + ks * 64 + lane] = w2[feat(li) * 32 + 4 * ks + lg];
+            for (int ct = 0; ct < 2; ++ct)
+                for (int ks = 0; ks < 4; ++ks) buf[P::SB + Q::SP1_W + (ct * 4 + ks) * 64 + lane] = s1[(16 * ct + feat(li)) * 16 + 4 * ks + lg];
+            for (int jt = 0; jt < 4; ++jt)
+                for (int ks = 0; ks < 8; ++ks) buf[P::SB + Q::SP2_W + (jt * 8 + ks) * 64 + lane] = s2[(16 * jt + (jt < 2 ? feat(li) : li)) * 32 + 4 * ks + lg];
+            for (int ot = 0; ot < 2; ++ot)      // (rows 4 lg + r <-> output 4 r + lg: its output is the next product's B operand, stored to LDS)
+                for (int ks = 0; ks < 16; ++ks) buf[P::SB + Q::FD0_W + (ot * 16 + ks) * 64 + lane] = wd0[(16 * ot + feat(li)) * 64 + (ks < 8 ? 4 * ks + lg : 32 + 4 * (ks - 8) + lg)];
+            for (int par = 0; par < 2; ++par)
+                for (int t = 0; t < 3; ++t)
+                    for (int ks = 0; ks < 8; ++ks) buf[P::SB + Q::FD0T_W + ((par * 3 + t) * 8 + ks) * 64 + lane] = wdt[((4 * ks + lg) * 16 + li) * 6 + par + 2 * t];
+        }
+        for (int lg = 0; lg < 4; ++lg)
+            for (int r = 0; r < 4; ++r) {
+                buf[P::SB + Q::MG2_B + lg * 4 + r] = b2[4 * r + lg];
+                for (int ct = 0; ct < 2; ++ct) buf[P::SB + Q::SP1_B + ct * 16 + lg * 4 + r] = sb1[16 * ct + 4 * r + lg];
+            }
+    }
     conv("feature_split.0", 32, 16, 1, P::SP1_W, P::SP1_B);
     {   // feature_split.1 Linear (64 out j, 32 in f) -> [f][j]
         const float* w = S("feature_split.1.weight");
@@ -1164,10 +1204,10 @@ fe::FArgs fspen_args(fe_handle* h, int B, int T) {
     return a;
 }
 
-// FSPEN per-hop step of large batches: the DPE blocks batched over the streams (fspen_sb_kernels.hip.h) from FE_FSPEN_SB streams
-// (0 = never; measured crossover on 256 CUs between 1536 and 2048 streams - a sixteen-stream workgroup per CU needs 4096 to fill the chip)
+// FSPEN per-hop step of large batches: the middle of the network batched over the streams (fspen_sb_kernels.hip.h) from FE_FSPEN_SB streams
+// (0 = never; measured crossover on 256 CUs at ~1500 streams - a sixteen-stream workgroup per CU needs 4096 to fill the chip)
 int fspen_sb_min() {
-    static const int v = [] { const char* e = getenv("FE_FSPEN_SB"); return e ? atoi(e) : 2048; }();
+    static const int v = [] { const char* e = getenv("FE_FSPEN_SB"); return e ? atoi(e) : 1536; }();
     return v;
 }
 int ensure_fsplit(fe_handle* h, int B) {
@@ -1185,7 +1225,7 @@ int launch_fspen(fe_handle* h, const fe::FArgs& a_in, void* stream) {
         const int rc = ensure_fsplit(h, a.B);
         if (rc != FE_OK) return rc;
         a.tok = h->bsplit_dev;
-        a.carry = a.tok + (size_t)a.B * 512;
+        a.carry = a.tok + (size_t)a.B * 2048;
         h->fimpl->launch_sb(a, h->max_wgs, (hipStream_t)stream, &e);
         if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
         return FE_OK;

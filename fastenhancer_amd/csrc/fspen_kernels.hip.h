@@ -34,7 +34,19 @@ struct FSbPk {
     static constexpr int GRP = LN_B + 512;              // 8 groups x { gate fragments [24][64]: r (x | h), z (x | h), n_x, n_h; biases [gate][lg][r]; inter_fc [4][64]; its bias [lg][r] }
     static constexpr int G_W = 0, G_B = 24 * 64, G_FCW = G_B + 64, G_FCB = G_FCW + 256, G_SIZE = G_FCB + 16;
     static constexpr int D_SIZE = GRP + 8 * G_SIZE;
-    static constexpr int TOTAL = 3 * D_SIZE;
+    // after the three blocks: feature merge / split (row 4 lg + r <-> output 4 r + lg unless noted)
+    static constexpr int POST_W = 3 * D_SIZE;            // fullband_encoder_post: A fragments [o tile < 2][k-step < 8][64]
+    static constexpr int MG1_W = POST_W + 16 * 64;       // feature_merge.0: [j tile < 2][k-step < 16][64]; k-steps 0-7 natural (input 4 ks + lg), 8 + 4 q + e <-> input 32 + 16 q + 4 lg + e
+    static constexpr int MG2_W = MG1_W + 32 * 64;        // feature_merge.2: [k-step < 8][64]; bias [lg][r]
+    static constexpr int MG2_B = MG2_W + 8 * 64;
+    static constexpr int SP1_W = MG2_B + 16;             // feature_split.0: [ch tile < 2][k-step < 4][64]; bias [tile][lg][r]
+    static constexpr int SP1_B = SP1_W + 8 * 64;
+    static constexpr int SP2_W = SP1_B + 32;             // feature_split.1: [j tile < 4][k-step < 8][64]; tiles 2, 3 (sub-band half): rows in natural order
+    static constexpr int FD0_W = SP2_W + 32 * 64;        // fullband_decoder.0.0 (1x1, 64 -> 32): [o tile < 2][k-step < 16][64]; k-steps 0-7 x_full, 8-15 enc_out[2]
+    static constexpr int FD0T_W = FD0_W + 32 * 64;       // fullband_decoder.0.1 (ConvTranspose1d 32 -> 16, k 6, s 2): [parity < 2][tap < 3][k-step < 8][64], rows in natural order,
+                                                         // tap i of parity q = kernel index q + 2 i <-> input position m + 1 - i of output positions 2 m + q
+    static constexpr int FD0T_B = FD0T_W + 48 * 64;      // [16]
+    static constexpr int TOTAL = FD0T_B + 16;
 };
 
 // ---- packed weights (floats), filled by the host packer; all matrices k-major: [k][outputs]
@@ -103,8 +115,8 @@ struct FArgs {
     float* frames;            // [B][T][N] windowed output frames (summed / envelope-normalised by istft_ola_kernel)
     int pipe_p;
     // split step of large batches (PART 1 -> fspen_sb_dpe_kernel -> PART 2)
-    float* tok;               // [B][32][16] DPE tokens
-    float* carry;             // [B][FCarry::FLOATS] what the tail needs of the front's LDS: compressed spectrum, encoder outputs, sub-band features
+    float* tok;               // [B][2][1024] written by fspen_sb_dpe_kernel, read by PART 2: feature_split output, sub-band half [32][32] | fullband_decoder.0 output [16][64]
+    float* carry;             // [B][FCarry::FLOATS] the front's LDS regions that the DPE kernel (cat) and the tail read: compressed spectrum, encoder outputs, sub-band / full-band features
 };
 
 // debug stages (fe_debug_step): name, rows, cols as dumped (row-major)
@@ -268,8 +280,9 @@ __device__ __forceinline__ float row_dot(const float (&w)[12], float h, float ac
 // PIPE: time pipelining of an offline launch (as for FastEnhancer / BSRNN): the only thing a frame needs from the previous one are the
 // inter-GRU states (24 x [4][16] per stream), handed over per DPE block through `gru` - agent-scope stores, drained, a counter per
 // (utterance, block); the consumer polls the counter and fetches the states right before the block's inter GRUs.
-// PART: 0 the whole frame; 1 the front (STFT .. feature merge: tokens and the tail's inputs to global memory); 2 the tail (feature
-// split .. iSTFT) - the per-hop step of large batches runs 1 -> fspen_sb_dpe_kernel (fspen_sb_kernels.hip.h) -> 2
+// PART: 0 the whole frame; 1 the front (STFT .. encoders: its LDS regions to global memory); 2 the tail (sub-band decoder,
+// fullband_decoder.1 .. iSTFT) - the per-hop step of large batches runs 1 -> fspen_sb_dpe_kernel (fullband_encoder_post, feature
+// merge, 3 x DPE, feature split, fullband_decoder.0 - batched over the streams, fspen_sb_kernels.hip.h) -> 2
 #ifndef FS_WPE_FRONT
 #define FS_WPE_FRONT 4
 #endif
@@ -520,6 +533,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(P
         FS_LDW(post_w, 32, P::POST_W + (tid & 31), 32);
         __syncthreads();
         dump(3, [&](int r, int c) { return e2[r * 32 + c]; });
+        if constexpr (PART != 1)
         {   // fullband_encoder_post: 1x1 (32 -> 32), no bias -> cat[o][f], f < 32
             const int o = tid & 31;
             float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -537,6 +551,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(P
         FS_CLK(2);
         // ============================ feature merge (:246-250): Linear(64 -> 32) over the band axis, ELU, 1x1 (32 -> 16) ============================
         float* m1 = smem + L::M1;
+        if constexpr (PART != 1) {
         {
             const int j = tid & 31;
             float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -563,19 +578,20 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(P
         }
         __syncthreads();
         dump(4, [&](int r, int c) { return x[c * 16 + r]; });
+        }
         if constexpr (PART == 1) {
-            f32x4* tk = reinterpret_cast<f32x4*>(a.tok + (size_t)b * 512);
             f32x4* cr = reinterpret_cast<f32x4*>(a.carry + (size_t)b * FCarry::FLOATS);
-            for (int i = tid; i < 128; i += kThreads) tk[i] = reinterpret_cast<const f32x4*>(x)[i];
             for (int i = tid; i < FCarry::AN / 4; i += kThreads) cr[i] = reinterpret_cast<const f32x4*>(smem + FCarry::A0)[i];
             for (int i = tid; i < FCarry::BN / 4; i += kThreads) cr[FCarry::AN / 4 + i] = reinterpret_cast<const f32x4*>(smem + FCarry::B0)[i];
             __syncthreads();
             continue;
         }
         } else {
-            const f32x4* tk = reinterpret_cast<const f32x4*>(a.tok + (size_t)b * 512);
+            const f32x4* tk = reinterpret_cast<const f32x4*>(a.tok + (size_t)b * 2048);
             const f32x4* cr = reinterpret_cast<const f32x4*>(a.carry + (size_t)b * FCarry::FLOATS);
-            for (int i = tid; i < 128; i += kThreads) reinterpret_cast<f32x4*>(x)[i] = tk[i];
+            // feature_split output, sub-band half -> s2[ch][32 ..]; fullband_decoder.0's output -> d2 [16][64]
+            for (int i = tid; i < 256; i += kThreads) reinterpret_cast<f32x4*>(smem + L::S2 + (i >> 3) * 64 + 32)[i & 7] = tk[i];
+            for (int i = tid; i < 256; i += kThreads) reinterpret_cast<f32x4*>(smem + L::D2)[i] = tk[256 + i];
             for (int i = tid; i < FCarry::AN / 4; i += kThreads) reinterpret_cast<f32x4*>(smem + FCarry::A0)[i] = cr[i];
             for (int i = tid; i < FCarry::BN / 4; i += kThreads) reinterpret_cast<f32x4*>(smem + FCarry::B0)[i] = cr[FCarry::AN / 4 + i];
             __syncthreads();
@@ -783,6 +799,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(P
         // ============================ feature split (:256-260): 1x1 (16 -> 32), Linear(32 -> 64) over the band axis, ELU ============================
         float* s1 = smem + L::S1;
         float* s2 = smem + L::S2;
+        if constexpr (PART != 2) {
         {
             const int ch = tid & 31;
             FS_LDW(w, 16, P::SP1_W + ch, 32);
@@ -811,6 +828,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(P
                 for (int q = 0; q < 8; ++q) acc[q] = fmaf(sp2_w[f], s1[((tid >> 6) + 4 * q) * 32 + f], acc[q]);
 #pragma unroll
             for (int q = 0; q < 8; ++q) s2[((tid >> 6) + 4 * q) * 64 + j] = elu_f(acc[q]);
+        }
         }
         __builtin_amdgcn_sched_barrier(0);      // (keeps the next phase's weight burst from being hoisted above this phase's arithmetic)
         FS_LDW(sd_w, 16, P::SD_W + tid, 260);                  // sub-band decoder column of bin = tid, chunk 0 of 4
@@ -844,6 +862,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(P
         __builtin_amdgcn_sched_barrier(0);
         // ============================ full-band decoder (:262-277, :397-400) ============================
         float* t2 = smem + L::T2;
+        if constexpr (PART != 2)
         {   // decoder 0: 1x1 over cat(x_full, enc_out[2]) (64 -> 32): chunks 0, 1 from s2[c][f] (row stride 64), 2, 3 from e2[c][f] (32)
             const int o = tid & 31;
             FS_LDW(w0, 16, P::FD0_W + o, 32);
@@ -860,6 +879,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(P
         __builtin_amdgcn_sched_barrier(0);
         // transposed convs: output p takes the taps k = k0, k0 + 2, ... (k0 = parity of p + padding), input f = (p + pad - k) / 2; all
         // of a thread's outputs share the parity, hence the taps' weights; out-of-range inputs are clamped and multiplied by 0
+        float* d2 = smem + L::D2;
+        if constexpr (PART != 2) {
         float fd0_t[12];                                         // chunk 0 of 8: 4 channels x 3 taps
         {
             const int k0 = (tid >> 4) & 1;
@@ -868,7 +889,6 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(P
         }
         const float fd0_b = wp[P::FD0_B + (tid & 15)];
         __syncthreads();
-        float* d2 = smem + L::D2;
         {   // ConvTranspose1d(32 -> 16, k 6, s 2, p 2) + folded BN + ELU: y[o][p] += x[c][f] w[c][o][k], p = 2 f + k - 2
             const int o = tid & 15, k0 = (tid >> 4) & 1;
             // per (output q, tap i): clamped input column and its 0 / 1 mask
@@ -913,6 +933,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(P
                 for (int i = 0; i < 3; ++i) acc = fmaf(fm[q][i], acc3[q * 3 + i], acc);
                 d2[o * 64 + (tid >> 4) + 16 * q] = elu_f(acc);
             }
+        }
         }
         __builtin_amdgcn_sched_barrier(0);      // (keeps the next phase's weight burst from being hoisted above this phase's arithmetic)
         FS_LDW(fd1_w, 32, P::FD1_W + (tid & 15), 16);
@@ -1168,7 +1189,7 @@ void flaunch_sb_impl(const FArgs& a, int max_wgs, hipStream_t st, hipError_t* er
     constexpr int OCC_F_LDS = (160 * 1024) / (FLds::FRONT_TOTAL * 4);
     const int slots_f = max_wgs * (OCC_F_LDS < FS_WPE_FRONT ? OCC_F_LDS : FS_WPE_FRONT);
     hipLaunchKernelGGL((fspen_frame_kernel<S, false, false, false, 1>), dim3(a.B < slots_f ? a.B : slots_f), dim3(kThreads), 0, st, a);
-    FSbArgs sa{a.wp, a.tok, a.gru, a.B, a.clk};
+    FSbArgs sa{a.wp, a.carry, a.tok, a.gru, a.B, a.clk};
     *err = fspen_sb_launch<S>(sa, st);
     if (*err != hipSuccess) return;
     hipLaunchKernelGGL((fspen_frame_kernel<S, false, false, false, 2>), dim3(grid), dim3(kThreads), 0, st, a);
@@ -1185,7 +1206,7 @@ template <class S>
 FImpl make_fimpl() {
     constexpr int OCC_LDS = (160 * 1024) / (FLds::TOTAL * 4);
     return FImpl{S::HOP, (size_t)FLds::TOTAL * 4, FDebugLayout::total(), FDebugLayout::n_stages, (size_t)FPk::TOTAL, &flaunch_impl<S>, &fdbg_stage_impl,
-                 &flaunch_pipe_impl<S>, OCC_LDS < FS_WPE ? OCC_LDS : FS_WPE, S::NB, &flaunch_sb_impl<S>, (size_t)512 + FCarry::FLOATS};
+                 &flaunch_pipe_impl<S>, OCC_LDS < FS_WPE ? OCC_LDS : FS_WPE, S::NB, &flaunch_sb_impl<S>, (size_t)2048 + FCarry::FLOATS};
 }
 
 }  // namespace fe

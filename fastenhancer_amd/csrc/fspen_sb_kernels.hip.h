@@ -1,9 +1,10 @@
-// fspen_sb_kernels.hip.h — FSPEN's three DPE blocks BATCHED OVER THE STREAMS on the fp32 matrix cores (gfx950), for the per-hop step
-// of large batches (models/fspen/model.py:122-189: per block an intra bidirectional GRU over the 32 sub-bands + intra_fc + LayerNorm
-// + residual, then eight grouped inter GRUs over time + inter_fc + residuals).
+// fspen_sb_kernels.hip.h — the MIDDLE of FSPEN BATCHED OVER THE STREAMS on the fp32 matrix cores (gfx950), for the per-hop step of large
+// batches: fullband_encoder_post, feature merge, the three DPE blocks, feature split and fullband_decoder.0 (models/fspen/model.py:
+// 244-264 around 122-189: per block an intra bidirectional GRU over the 32 sub-bands + intra_fc + LayerNorm + residual, then eight
+// grouped inter GRUs over time + inter_fc + residuals) - 0.86 of the model's 0.99 MMAC per frame.
 //
-// fspen_frame_kernel gives a stream a workgroup: every product of the DPE is then M = 1 (vector FMAs), and the intra GRU is a chain
-// of 96 dependent steps per frame on two of its four waves.  Here a workgroup takes SIXTEEN streams and every product is a matrix-core
+// fspen_frame_kernel gives a stream a workgroup: every product is then M = 1 (vector FMAs), and the intra GRU is a chain of 96
+// dependent steps per frame on two of its four waves.  Here a workgroup takes SIXTEEN streams and every product is a matrix-core
 // GEMM with the streams as the N dimension, computed TRANSPOSED (as in bsrnn_sb_kernels.hip.h):
 //     out^T [rows x 16 streams] = W [rows x K] . in^T [K x 16 streams]
 // A = weights (fragments in registers), B = activations: lane (li, lg) holds feature 4 ks + lg of stream li for k-step ks,
@@ -13,14 +14,19 @@
 //     n_x and the h half of n_h only - zero fragments elsewhere).  The four gate values of a (stream, unit) are the four accumulator
 //     registers of one lane: one gate evaluation per lane and step (6 transcendentals), the new h goes to the h sequence in LDS -
 //     [direction][sub-band][unit][16 streams] - which is at once the exchange buffer of the next step (ONE barrier per step for both
-//     directions) and the input of intra_fc.  The x half of the next step is issued before the barrier.
+//     directions) and the input of intra_fc.  The x half of the next step is issued one step ahead.
 //   * intra_fc, the inter GRUs' gate tiles and inter_fc: row 4 lg + r <-> feature 4 r + lg.  A lane's accumulator register r is then
 //     feature 4 r + lg = what the B operand of k-step r carries: LayerNorm output, new inter state and block output feed the next product
 //     from registers, and their LDS stores ([feature][16 streams], 64 consecutive floats per register) are conflict-free.
 // Wave w owns sub-bands 4 w .. 4 w + 3 = inter group w for intra_fc / LayerNorm / inter GRU / inter_fc: no barrier between those
 // phases but the two of the LayerNorm statistics (sums over a stream's 512 values: lanes li, li + 16, .. of eight waves).
-// LDS: tokens [32][16][16] (32 KiB) + h sequences [2][32][16][16] (64 KiB) + reductions: one workgroup per CU, 4096 streams fill the chip.
-// (included by fspen_kernels.hip.h, after FShape / FPk)
+// The layers around the blocks contract alternately over channels and over positions: a product stores its C/D tile TRANSPOSED into one
+// of two [32 rows][32 + 1 pad][16 streams] LDS matrices (R0 / R1, aliasing the tokens / h sequences of the DPE) and the next product reads
+// its B operands from there; operands that the front left in global memory (enc_out[2], the sub-band features) are read straight from
+// there, 16 bytes (four positions or four k-steps) per lane; fullband_decoder.0's transposed convolution is, per pair of output
+// positions 2 m / 2 m + 1, two 16-row tiles over K = 3 taps x 32 channels of the positions m + 1, m, m - 1.
+// LDS: 136 KB: one workgroup per CU, 4096 streams fill the chip.
+// (included by fspen_kernels.hip.h, after FShape / FPk / FLds / FCarry)
 #pragma once
 
 namespace fe {
@@ -31,14 +37,19 @@ constexpr int kFsbThreads = 512;
 struct FSbLds {
     static constexpr int X = 0;                       // [32 f][16 c][16 n]
     static constexpr int HS = X + 32 * 16 * 16;       // [2 d][32 f][16 u][16 n]
-    static constexpr int RED = HS + 2 * 32 * 16 * 16; // [2][8 waves][16 n]
+    // before / after the DPE blocks the same space holds two [32 rows][32 + 1 pad][16 n] matrices (R0 over X and the head of HS, R1 behind it)
+    static constexpr int MS = 33 * 16;                // their row stride: 528 = 16 mod 64 - the C/D-layout stores of four lane groups hit four bank quarters
+    static constexpr int R0 = 0, R1 = 32 * MS;
+    static constexpr int RED = R1 + 32 * MS;          // [2][8 waves][16 n]
+    static_assert(RED >= HS + 2 * 32 * 16 * 16, "the h sequences end before the reduction slots");
     static constexpr int TOTAL = RED + 2 * 8 * 16;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
 };
 
 struct FSbArgs {
     const float* wp;          // the packed buffer of fspen_frame_kernel; the stream-batched region starts at FPk::SB
-    float* tok;               // [B][32][16] DPE tokens, in place (fspen_frame_kernel PART 1 -> this kernel -> PART 2)
+    const float* carry;       // [B][FCarry::FLOATS] the front's LDS regions (fspen_frame_kernel PART 1): cat = sub-band | full-band features [32][64] is read here
+    float* s2;                // [B][2][1024] for the tail (fspen_frame_kernel PART 2): feature_split output, sub-band half [32][32] | fullband_decoder.0 output [16][64]
     float* gru;               // [24][B * 4][16] inter-GRU states
     int B;
     unsigned long long* clk;  // fe_profile_step: cycle counters of workgroup 0 (slots 32 ..), else null
@@ -77,26 +88,87 @@ __global__ void __launch_bounds__(kFsbThreads) __attribute__((amdgpu_waves_per_e
     const int b0 = blockIdx.x * kFsbStreams;
     const bool live = b0 + li < a.B;
     const int bn = live ? b0 + li : a.B - 1;                     // this lane's stream (tiles past the batch repeat the last stream; stores predicated)
-    // tokens -> LDS [f][c][n]: thread (stream n = tid % 16, sub-band f = tid / 16) reads its 64 contiguous bytes
-    {
-        const int n = tid & 15, f = tid >> 4;
-        const int bs = b0 + n < a.B ? b0 + n : a.B - 1;
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.tok + (size_t)bs * 512 + f * 16);
+    // ---------------- fullband_encoder_post (1x1, 32 -> 32, :244) + feature merge (:246-250): Linear(64 -> 32) over the band axis, ELU, 1x1 (32 -> 16) ----
+    const float* cr = a.carry + (size_t)bn * FCarry::FLOATS + FCarry::AN;          // the front's LDS region [E0, SB) of this lane's stream
+    const float* e2g = cr + (FLds::E2 - FLds::E0);                                 // fullband_encoder.2 output [32 c][32 f]
+    float* P = smem + L::R0;             // post output [32 o][32 f + pad][16 n]
+    float* M1 = smem + L::R1;            // merge Linear output [32 j][32 ch + pad][16 n]
+    // (every weight fragment and global operand of the three products is requested up front: one memory round trip, not three)
+    float w1[2][16];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 v = src[i];
+    for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) X[(f * 16 + 4 * i + r) * 16 + n] = v[r];
+        for (int ks = 0; ks < 16; ++ks) w1[jt][ks] = ldw(FPk::SB + Q::MG1_W + (jt * 16 + ks) * 64, lane * 4);
+    float w2m[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) w2m[ks] = ldw(FPk::SB + Q::MG2_W + ks * 64, lane * 4);
+    const f32x4 b2 = ldw4(FPk::SB + Q::MG2_B, lg * 16);
+    f32x4 cv[4][2];
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+        for (int q4 = 0; q4 < 2; ++q4) cv[c4][q4] = *reinterpret_cast<const f32x4*>(cr + (FLds::CAT - FLds::E0) + (4 * wave + c4) * 64 + 32 + 16 * q4 + 4 * lg);
+    {   // wave w takes positions f = 4 w .. 4 w + 3: post^T [32 o x 16 n] = Wp [32 x 32] . e2[:, f]^T, B straight from global memory (16 bytes = four positions)
+        float wp_[2][8];
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) wp_[ot][ks] = ldw(FPk::SB + Q::POST_W + (ot * 8 + ks) * 64, lane * 4);
+        f32x4 ev[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) ev[ks] = *reinterpret_cast<const f32x4*>(e2g + (4 * ks + lg) * 32 + 4 * wave);
+#pragma unroll
+        for (int fl = 0; fl < 4; ++fl) {
+            f32x4 acc[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) acc[ot] = FE_MFMA(wp_[ot][ks], ev[ks][fl], acc[ot]);
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) P[(16 * ot + 4 * r + lg) * L::MS + (4 * wave + fl) * 16 + li] = acc[ot][r];
         }
     }
     __syncthreads();
-    // the wave's own sub-bands (4 wave + fl): residual stream in registers, xr[fl][r] = channel 4 r + lg of stream li
+    {   // wave w takes channels 4 w .. 4 w + 3 of cat = post | sub-band features [32 ch][64]: m1^T [32 j x 16 n] = W1 [32 x 64] . cat[ch]^T; the
+        // full-band half from LDS, the sub-band half straight from global memory (k-step 8 + 4 q + e <-> input 32 + 16 q + 4 lg + e)
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            f32x4 acc[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const float pb = P[(4 * wave + c4) * L::MS + (4 * ks + lg) * 16 + li];
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) acc[jt] = FE_MFMA(w1[jt][ks], pb, acc[jt]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) acc[jt] = FE_MFMA(w1[jt][8 + ks], cv[c4][ks >> 2][ks & 3], acc[jt]);
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) M1[(16 * jt + 4 * r + lg) * L::MS + (4 * wave + c4) * 16 + li] = elu_f(acc[jt][r]);
+        }
+    }
+    __syncthreads();
+    // 1x1 (32 -> 16): wave w owns sub-bands 4 w .. 4 w + 3 from here on - the residual stream in registers, xr[fl][r] = channel 4 r + lg of stream li
     float xr[4][4];
+    {
 #pragma unroll
-    for (int fl = 0; fl < 4; ++fl)
+        for (int fl = 0; fl < 4; ++fl) {
+            f32x4 acc = b2;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xr[fl][r] = X[((4 * wave + fl) * 16 + 4 * r + lg) * 16 + li];
-
+            for (int ks = 0; ks < 8; ++ks) acc = FE_MFMA(w2m[ks], M1[(4 * wave + fl) * L::MS + (4 * ks + lg) * 16 + li], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xr[fl][r] = acc[r];
+                X[((4 * wave + fl) * 16 + 4 * r + lg) * 16 + li] = acc[r];
+            }
+        }
+    }
+    __syncthreads();
     FSB_CLK(1);
     const int d = wave >> 2, q = wave & 3;
 #pragma unroll 1
@@ -282,11 +354,128 @@ __global__ void __launch_bounds__(kFsbThreads) __attribute__((amdgpu_waves_per_e
         __syncthreads();
         FSB_CLK(5 + 4 * blk);
     }
-    if (live) {
+    // ---------------- feature split (:256-260): 1x1 (16 -> 32), Linear(32 -> 64) over the band axis, ELU; fullband_decoder.0's 1x1 (:262-264) ----------------
+    {
+        float* S1 = smem + L::R1;            // [32 ch][32 f + pad][16 n]
+        float* S2T = smem + L::R0;           // full-band half of the split output, transposed: [32 f][32 ch + pad][16 n]
+        float ws[2][4];
 #pragma unroll
-        for (int fl = 0; fl < 4; ++fl)
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a.tok[(size_t)bn * 512 + (4 * wave + fl) * 16 + 4 * r + lg] = xr[fl][r];
+            for (int ks = 0; ks < 4; ++ks) ws[ct][ks] = ldw(FPk::SB + Q::SP1_W + (ct * 4 + ks) * 64, lane * 4);
+        const f32x4 bs[2] = {ldw4(FPk::SB + Q::SP1_B, lg * 16), ldw4(FPk::SB + Q::SP1_B + 16, lg * 16)};
+        float w2[4][8];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) w2[jt][ks] = ldw(FPk::SB + Q::SP2_W + (jt * 8 + ks) * 64, lane * 4);
+        float wd[2][16];
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) wd[ot][ks] = ldw(FPk::SB + Q::FD0_W + (ot * 16 + ks) * 64, lane * 4);
+        f32x4 ev[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) ev[ks] = *reinterpret_cast<const f32x4*>(e2g + (4 * ks + lg) * 32 + 4 * wave);
+#pragma unroll
+        for (int fl = 0; fl < 4; ++fl) {
+            f32x4 acc[2] = {bs[0], bs[1]};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[ct] = FE_MFMA(ws[ct][ks], xr[fl][ks], acc[ct]);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S1[(16 * ct + 4 * r + lg) * L::MS + (4 * wave + fl) * 16 + li] = acc[ct][r];
+        }
+        __syncthreads();
+        // wave w takes channels 4 w .. 4 w + 3: s2^T [64 j x 16 n] = W2 [64 x 32] . s1[ch]^T.  Full-band half (j < 32, rows 4 lg + r <-> j 4 r + lg):
+        // to LDS, transposed, for the decoder's 1x1; sub-band half (rows in natural order: a lane's four rows = 16 bytes): to the tail
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const int ch = 4 * wave + c4;
+            f32x4 acc[4];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) acc[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const float sb = S1[ch * L::MS + (4 * ks + lg) * 16 + li];
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) acc[jt] = FE_MFMA(w2[jt][ks], sb, acc[jt]);
+            }
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S2T[(16 * jt + 4 * r + lg) * L::MS + ch * 16 + li] = elu_f(acc[jt][r]);
+            if (live) {
+#pragma unroll
+                for (int jt = 2; jt < 4; ++jt) {
+                    const f32x4 o = {elu_f(acc[jt][0]), elu_f(acc[jt][1]), elu_f(acc[jt][2]), elu_f(acc[jt][3])};
+                    *reinterpret_cast<f32x4*>(a.s2 + (size_t)bn * 2048 + ch * 32 + 16 * (jt - 2) + 4 * lg) = o;
+                }
+            }
+        }
+        // fullband_decoder.0, 1x1 over cat(x_full, enc_out[2]) (64 -> 32, no bias): wave w takes positions f = 4 w .. 4 w + 3
+        __syncthreads();
+        float* T2L = smem + L::R1;           // the 1x1's output, position-major: [32 f][32 c + pad][16 n] (S1 is dead)
+#pragma unroll
+        for (int fl = 0; fl < 4; ++fl) {
+            f32x4 t2v[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const float sb = S2T[(4 * wave + fl) * L::MS + (4 * ks + lg) * 16 + li];
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) t2v[ot] = FE_MFMA(wd[ot][ks], sb, t2v[ot]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) t2v[ot] = FE_MFMA(wd[ot][8 + ks], ev[ks][fl], t2v[ot]);
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T2L[(4 * wave + fl) * L::MS + (16 * ot + 4 * r + lg) * 16 + li] = t2v[ot][r];
+        }
+        // fullband_decoder.0's ConvTranspose1d(32 -> 16, k 6, s 2, p 2) + folded BN + ELU: output positions 2 m + q (q = 0, 1) take kernel
+        // indices q + 2 i from input positions m + 1 - i (i = 0, 1, 2).  Wave w takes m = 4 w .. 4 w + 3: per m and parity one 16-row tile, K = 3 x 32
+        float wt[2][3][8];
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) wt[par][t][ks] = ldw(FPk::SB + Q::FD0T_W + ((par * 3 + t) * 8 + ks) * 64, lane * 4);
+        const f32x4 bt = ldw4(FPk::SB + Q::FD0T_B, lg * 16);
+        __syncthreads();
+        f32x4 dv[4][2];
+#pragma unroll
+        for (int ml = 0; ml < 4; ++ml) {
+            const int m = 4 * wave + ml;
+            dv[ml][0] = bt; dv[ml][1] = bt;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int f = m + 1 - t;
+                if (f >= 0 && f < 32) {          // (wave-uniform)
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        const float tb = T2L[f * L::MS + (4 * ks + lg) * 16 + li];
+                        dv[ml][0] = FE_MFMA(wt[0][t][ks], tb, dv[ml][0]);
+                        dv[ml][1] = FE_MFMA(wt[1][t][ks], tb, dv[ml][1]);
+                    }
+                }
+            }
+        }
+        if (live) {      // d2 [16 o][64 p]: a lane's eight positions 8 w .. 8 w + 7 of output o = 4 lg + r are 32 bytes
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x4 o0 = {elu_f(dv[0][0][r]), elu_f(dv[0][1][r]), elu_f(dv[1][0][r]), elu_f(dv[1][1][r])};
+                const f32x4 o1 = {elu_f(dv[2][0][r]), elu_f(dv[2][1][r]), elu_f(dv[3][0][r]), elu_f(dv[3][1][r])};
+                float* dst = a.s2 + (size_t)bn * 2048 + 1024 + (4 * lg + r) * 64 + 8 * wave;
+                *reinterpret_cast<f32x4*>(dst) = o0;
+                *reinterpret_cast<f32x4*>(dst + 4) = o1;
+            }
+        }
     }
     FSB_CLK(14);
 #undef FSB_CLK

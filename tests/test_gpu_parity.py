@@ -1283,10 +1283,10 @@ def test_fspen_full_size(B):
 
 
 @pytest.mark.parametrize("B", [2057, 4096])
-def test_fspen_stream_batched_dpe_above_2048_streams(B):
-    """From 2048 streams the per-hop step runs the three DPE blocks batched over the streams on the matrix cores
-    (fspen_sb_kernels.hip.h: front per stream, sixteen streams per workgroup through the DPE, tail per stream).  2057 streams = a last
-    tile of 9.  Oracle parity (outputs and all 24 inter-GRU caches) on a sample that covers first / last tiles and columns, bitwise
+def test_fspen_stream_batched_middle_above_1536_streams(B):
+    """From 1536 streams the per-hop step runs the middle of the network - fullband_encoder_post, feature merge, the three DPE blocks,
+    feature split, fullband_decoder.0 - batched over the streams on the matrix cores (fspen_sb_kernels.hip.h: front per stream, sixteen
+    streams per workgroup, tail per stream).  2057 streams = a last tile of 9.  Oracle parity (outputs and all 24 inter-GRU caches) on a sample that covers first / last tiles and columns, bitwise
     position independence on all streams (_full_size_check runs the batch again in reversed order)."""
     m, orc, cfg, sr, seed = _fspen()
     _full_size_check(m, orc, cfg, sr, B, 3, [0, 1, 15, 16, 17, 511, 1000, B - 10, B - 9, B - 2, B - 1], f"fspen B={B}")

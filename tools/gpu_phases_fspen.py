@@ -32,12 +32,12 @@ def main():
     c = clk.cpu().numpy()
     if c[32] != 0:      # the stream-batched DPE kernel ran (fspen_sb_kernels.hip.h): its counters
         q = c[32:]
-        print(f"fspen B={B}: stream-batched DPE kernel = {q[14] - q[0]} cycles; token load {q[1] - q[0]}")
+        print(f"fspen B={B}: stream-batched kernel = {q[14] - q[0]} cycles; post + feature merge {q[1] - q[0]}")
         for b in range(3):
             o = 2 + 4 * b
             print(f"  block {b}: weight / state requests {q[o] - (q[1] if b == 0 else q[o - 1])}, recurrence {q[o + 1] - q[o]}, "
                   f"intra_fc + LayerNorm {q[o + 2] - q[o + 1]}, inter GRUs + fc {q[o + 3] - q[o + 2]}")
-        print(f"  token store {q[14] - q[13]}")
+        print(f"  feature split + decoder 1x1 {q[14] - q[13]}")
         return
     tot = c[7] - c[0]
     print(f"fspen B={B}: frame = {tot} cycles")
