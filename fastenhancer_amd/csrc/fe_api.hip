@@ -1119,6 +1119,8 @@ int pack_weights_fspen(fe_handle* h, const std::vector<float>& blob, std::vector
         using Q = fe::FSbPk;
         auto feat = [](int li) { return 4 * (li & 3) + (li >> 2); };
         const float* wpo = S("fullband_encoder_post.weight");  // (32, 32, 1)
+        const float* wf2 = S("fullband_encoder.2.0.weight");   // Conv1d (32, 16, 6)
+        const float* bf2 = S("fullband_encoder.2.0.bias");
         const float* w1 = S("feature_merge.0.weight");        // (32, 64)
         const float* w2 = S("feature_merge.2.weight");        // (16, 32, 1)
         const float* b2 = S("feature_merge.2.bias");
@@ -1131,6 +1133,8 @@ int pack_weights_fspen(fe_handle* h, const std::vector<float>& blob, std::vector
         for (int o = 0; o < 16; ++o) buf[P::SB + Q::FD0T_B + o] = bdt[o];
         for (int lane = 0; lane < 64; ++lane) {
             const int li = lane & 15, lg = lane >> 4;
+            for (int ot = 0; ot < 2; ++ot)
+                for (int ks = 0; ks < 24; ++ks) buf[P::SB + Q::FE2_W + (ot * 24 + ks) * 64 + lane] = wf2[((16 * ot + feat(li)) * 16 + 4 * (ks & 3) + lg) * 6 + (ks >> 2)];
             for (int ot = 0; ot < 2; ++ot)
                 for (int ks = 0; ks < 8; ++ks) buf[P::SB + Q::POST_W + (ot * 8 + ks) * 64 + lane] = wpo[(16 * ot + feat(li)) * 32 + 4 * ks + lg];
             for (int jt = 0; jt < 2; ++jt)
@@ -1152,6 +1156,7 @@ int pack_weights_fspen(fe_handle* h, const std::vector<float>& blob, std::vector
         for (int lg = 0; lg < 4; ++lg)
             for (int r = 0; r < 4; ++r) {
                 buf[P::SB + Q::MG2_B + lg * 4 + r] = b2[4 * r + lg];
+                for (int ot = 0; ot < 2; ++ot) buf[P::SB + Q::FE2_B + ot * 16 + lg * 4 + r] = bf2[16 * ot + 4 * r + lg];
                 for (int ct = 0; ct < 2; ++ct) buf[P::SB + Q::SP1_B + ct * 16 + lg * 4 + r] = sb1[16 * ct + 4 * r + lg];
             }
     }
@@ -1213,7 +1218,7 @@ int fspen_sb_min() {
 int ensure_fsplit(fe_handle* h, int B) {
     if (!h->fimpl || fspen_sb_min() <= 0 || B < fspen_sb_min() || B <= h->bsplit_streams) return FE_OK;
     if (h->bsplit_dev) { FE_HIP_CHECK(hipFree(h->bsplit_dev)); h->bsplit_dev = nullptr; h->bsplit_streams = 0; }
-    FE_HIP_CHECK(hipMalloc(&h->bsplit_dev, (size_t)B * h->fimpl->split_floats_per_stream * sizeof(float)));
+    FE_HIP_CHECK(hipMalloc(&h->bsplit_dev, ((size_t)B + 16) * h->fimpl->split_floats_per_stream * sizeof(float)));      // (+ 16: the last stream tile's lane-private scratch is whole)
     h->bsplit_streams = B;
     return FE_OK;
 }

@@ -35,7 +35,9 @@ struct FSbPk {
     static constexpr int G_W = 0, G_B = 24 * 64, G_FCW = G_B + 64, G_FCB = G_FCW + 256, G_SIZE = G_FCB + 16;
     static constexpr int D_SIZE = GRP + 8 * G_SIZE;
     // after the three blocks: feature merge / split (row 4 lg + r <-> output 4 r + lg unless noted)
-    static constexpr int POST_W = 3 * D_SIZE;            // fullband_encoder_post: A fragments [o tile < 2][k-step < 8][64]
+    static constexpr int FE2_W = 3 * D_SIZE;             // fullband_encoder.2: A fragments [o tile < 2][k-step < 24 = 4 tap + cq][64]; bias [tile][lg][r]
+    static constexpr int FE2_B = FE2_W + 48 * 64;
+    static constexpr int POST_W = FE2_B + 32;            // fullband_encoder_post: A fragments [o tile < 2][k-step < 8][64]
     static constexpr int MG1_W = POST_W + 16 * 64;       // feature_merge.0: [j tile < 2][k-step < 16][64]; k-steps 0-7 natural (input 4 ks + lg), 8 + 4 q + e <-> input 32 + 16 q + 4 lg + e
     static constexpr int MG2_W = MG1_W + 32 * 64;        // feature_merge.2: [k-step < 8][64]; bias [lg][r]
     static constexpr int MG2_B = MG2_W + 8 * 64;
@@ -280,9 +282,9 @@ __device__ __forceinline__ float row_dot(const float (&w)[12], float h, float ac
 // PIPE: time pipelining of an offline launch (as for FastEnhancer / BSRNN): the only thing a frame needs from the previous one are the
 // inter-GRU states (24 x [4][16] per stream), handed over per DPE block through `gru` - agent-scope stores, drained, a counter per
 // (utterance, block); the consumer polls the counter and fetches the states right before the block's inter GRUs.
-// PART: 0 the whole frame; 1 the front (STFT .. encoders: its LDS regions to global memory); 2 the tail (sub-band decoder,
-// fullband_decoder.1 .. iSTFT) - the per-hop step of large batches runs 1 -> fspen_sb_dpe_kernel (fullband_encoder_post, feature
-// merge, 3 x DPE, feature split, fullband_decoder.0 - batched over the streams, fspen_sb_kernels.hip.h) -> 2
+// PART: 0 the whole frame; 1 the front (STFT, sub-band encoder, fullband_encoder.0-1: its LDS regions to global memory); 2 the tail
+// (sub-band decoder, fullband_decoder.1 .. iSTFT) - the per-hop step of large batches runs 1 -> fspen_sb_dpe_kernel (fullband_encoder.2,
+// fullband_encoder_post, feature merge, 3 x DPE, feature split, fullband_decoder.0 - batched over the streams, fspen_sb_kernels.hip.h) -> 2
 #ifndef FS_WPE_FRONT
 #define FS_WPE_FRONT 4
 #endif
@@ -519,6 +521,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(P
         FS_LDW(fe2_w, 12, P::FE2_W + (tid & 31), 32);          // chunk 0 of 8 (2 channels x 6 taps each)
         const float fe2_b = wp[P::FE2_B + (tid & 31)];
         __syncthreads();
+        if constexpr (PART != 1)
         {   // fullband_encoder.2: Conv1d(16 -> 32, k 6, s 2, p 2) -> e2[o][j], j < 32
             const int o = tid & 31;
             float acc[4] = {fe2_b, fe2_b, fe2_b, fe2_b};
@@ -1189,7 +1192,7 @@ void flaunch_sb_impl(const FArgs& a, int max_wgs, hipStream_t st, hipError_t* er
     constexpr int OCC_F_LDS = (160 * 1024) / (FLds::FRONT_TOTAL * 4);
     const int slots_f = max_wgs * (OCC_F_LDS < FS_WPE_FRONT ? OCC_F_LDS : FS_WPE_FRONT);
     hipLaunchKernelGGL((fspen_frame_kernel<S, false, false, false, 1>), dim3(a.B < slots_f ? a.B : slots_f), dim3(kThreads), 0, st, a);
-    FSbArgs sa{a.wp, a.carry, a.tok, a.gru, a.B, a.clk};
+    FSbArgs sa{a.wp, a.carry, a.tok, a.carry + (size_t)a.B * FCarry::FLOATS, a.gru, a.B, a.clk};
     *err = fspen_sb_launch<S>(sa, st);
     if (*err != hipSuccess) return;
     hipLaunchKernelGGL((fspen_frame_kernel<S, false, false, false, 2>), dim3(grid), dim3(kThreads), 0, st, a);
@@ -1206,7 +1209,7 @@ template <class S>
 FImpl make_fimpl() {
     constexpr int OCC_LDS = (160 * 1024) / (FLds::TOTAL * 4);
     return FImpl{S::HOP, (size_t)FLds::TOTAL * 4, FDebugLayout::total(), FDebugLayout::n_stages, (size_t)FPk::TOTAL, &flaunch_impl<S>, &fdbg_stage_impl,
-                 &flaunch_pipe_impl<S>, OCC_LDS < FS_WPE ? OCC_LDS : FS_WPE, S::NB, &flaunch_sb_impl<S>, (size_t)2048 + FCarry::FLOATS};
+                 &flaunch_pipe_impl<S>, OCC_LDS < FS_WPE ? OCC_LDS : FS_WPE, S::NB, &flaunch_sb_impl<S>, (size_t)2048 + FCarry::FLOATS + 1024};
 }
 
 }  // namespace fe

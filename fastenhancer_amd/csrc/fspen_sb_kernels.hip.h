@@ -1,7 +1,7 @@
 // fspen_sb_kernels.hip.h — the MIDDLE of FSPEN BATCHED OVER THE STREAMS on the fp32 matrix cores (gfx950), for the per-hop step of large
-// batches: fullband_encoder_post, feature merge, the three DPE blocks, feature split and fullband_decoder.0 (models/fspen/model.py:
+// batches: fullband_encoder.2, fullband_encoder_post, feature merge, the three DPE blocks, feature split and fullband_decoder.0 (models/fspen/model.py:
 // 244-264 around 122-189: per block an intra bidirectional GRU over the 32 sub-bands + intra_fc + LayerNorm + residual, then eight
-// grouped inter GRUs over time + inter_fc + residuals) - 0.86 of the model's 0.99 MMAC per frame.
+// grouped inter GRUs over time + inter_fc + residuals) - 0.97 of the model's 0.99 MMAC per frame.
 //
 // fspen_frame_kernel gives a stream a workgroup: every product is then M = 1 (vector FMAs), and the intra GRU is a chain of 96
 // dependent steps per frame on two of its four waves.  Here a workgroup takes SIXTEEN streams and every product is a matrix-core
@@ -40,7 +40,9 @@ struct FSbLds {
     // before / after the DPE blocks the same space holds two [32 rows][32 + 1 pad][16 n] matrices (R0 over X and the head of HS, R1 behind it)
     static constexpr int MS = 33 * 16;                // their row stride: 528 = 16 mod 64 - the C/D-layout stores of four lane groups hit four bank quarters
     static constexpr int R0 = 0, R1 = 32 * MS;
-    static constexpr int RED = R1 + 32 * MS;          // [2][8 waves][16 n]
+    static constexpr int E1S = 69;                    // fullband_encoder.1's output in R1: [16 c][68 + 1 pad positions][16 n] (channel stride 69 x 16 = 16 mod 64)
+    static constexpr int RED = R1 + 16 * E1S * 16;    // [2][8 waves][16 n]
+    static_assert(16 * E1S * 16 >= 32 * MS, "R1 holds either");
     static_assert(RED >= HS + 2 * 32 * 16 * 16, "the h sequences end before the reduction slots");
     static constexpr int TOTAL = RED + 2 * 8 * 16;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
@@ -48,8 +50,10 @@ struct FSbLds {
 
 struct FSbArgs {
     const float* wp;          // the packed buffer of fspen_frame_kernel; the stream-batched region starts at FPk::SB
-    const float* carry;       // [B][FCarry::FLOATS] the front's LDS regions (fspen_frame_kernel PART 1): cat = sub-band | full-band features [32][64] is read here
+    float* carry;             // [B][FCarry::FLOATS] the front's LDS regions (fspen_frame_kernel PART 1): enc_out[1] and the sub-band features are read here,
+                              // enc_out[2] is written (and read back by fullband_decoder.0 at the end)
     float* s2;                // [B][2][1024] for the tail (fspen_frame_kernel PART 2): feature_split output, sub-band half [32][32] | fullband_decoder.0 output [16][64]
+    float* e2x;               // [ceil(B / 16)][8 waves][8][64 lanes][4] enc_out[2] of the step, lane-private: written after fullband_encoder.2, read back by fullband_decoder.0
     float* gru;               // [24][B * 4][16] inter-GRU states
     int B;
     unsigned long long* clk;  // fe_profile_step: cycle counters of workgroup 0 (slots 32 ..), else null
@@ -89,41 +93,102 @@ __global__ void __launch_bounds__(kFsbThreads) __attribute__((amdgpu_waves_per_e
     const bool live = b0 + li < a.B;
     const int bn = live ? b0 + li : a.B - 1;                     // this lane's stream (tiles past the batch repeat the last stream; stores predicated)
     // ---------------- fullband_encoder_post (1x1, 32 -> 32, :244) + feature merge (:246-250): Linear(64 -> 32) over the band axis, ELU, 1x1 (32 -> 16) ----
-    const float* cr = a.carry + (size_t)bn * FCarry::FLOATS + FCarry::AN;          // the front's LDS region [E0, SB) of this lane's stream
-    const float* e2g = cr + (FLds::E2 - FLds::E0);                                 // fullband_encoder.2 output [32 c][32 f]
-    float* P = smem + L::R0;             // post output [32 o][32 f + pad][16 n]
-    float* M1 = smem + L::R1;            // merge Linear output [32 j][32 ch + pad][16 n]
-    // (every weight fragment and global operand of the three products is requested up front: one memory round trip, not three)
-    float w1[2][16];
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) w1[jt][ks] = ldw(FPk::SB + Q::MG1_W + (jt * 16 + ks) * 64, lane * 4);
-    float w2m[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) w2m[ks] = ldw(FPk::SB + Q::MG2_W + ks * 64, lane * 4);
-    const f32x4 b2 = ldw4(FPk::SB + Q::MG2_B, lg * 16);
+    float* cr = a.carry + (size_t)bn * FCarry::FLOATS + FCarry::AN;                // the front's LDS region [E0, SB) of this lane's stream
+    // enc_out[2] between fullband_encoder.2 and fullband_decoder.0: the lane that produces (channel 16 ot + 4 r + lg, positions 4 w .. 4 w + 3) of
+    // stream li is the lane that consumes it - 16 bytes per (ot, r), whole 1-KB lines per wave instruction (as [32 o][32 f] rows per stream the
+    // same stores were 64 partial lines per instruction and took ~12 k cycles to drain)
+    f32x4* e2x = reinterpret_cast<f32x4*>(a.e2x) + ((size_t)blockIdx.x * 8 + wave) * 8 * 64 + lane;
+    // ---------------- fullband_encoder.2 (Conv1d 16 -> 32, k 6, s 2, p 2, + folded BN + ELU, :238-242) ----------------
+    // enc_out[1] [16 c][68 positions, zero padded] of the sixteen streams -> LDS, stream-minor; then per output position j one product
+    // e2^T [32 o x 16 n] = W [32 x (6 taps x 16 c)] . patch_j^T, k-step 4 tap + cq <-> (tap, channel 4 cq + lg) at position 2 j + tap
+    // The weight fragments of these layers are the same for all eight waves: fetched by every wave they are 1.3 k wave-level loads per CU at
+    // ~16 cycles of its vector-memory path each (20 k cycles measured).  The workgroup copies them ONCE into LDS (R0 is free until the post
+    // layer writes there) with 16-byte loads, and every wave picks its register copy from there.
+    constexpr int WS0 = Q::FE2_W, WS0_N = Q::MG2_B + 16 - Q::FE2_W;        // fullband_encoder.2 .. feature_merge.2, contiguous in the packed buffer
+    static_assert(WS0_N % 4 == 0 && WS0_N <= 32 * L::MS, "start weights fit R0");
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.wp + FPk::SB + WS0);
+        f32x4* dst = reinterpret_cast<f32x4*>(smem + L::R0);
+        for (int i = tid; i < WS0_N / 4; i += kFsbThreads) dst[i] = src[i];
+    }
     f32x4 cv[4][2];
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4)
 #pragma unroll
         for (int q4 = 0; q4 < 2; ++q4) cv[c4][q4] = *reinterpret_cast<const f32x4*>(cr + (FLds::CAT - FLds::E0) + (4 * wave + c4) * 64 + 32 + 16 * q4 + 4 * lg);
-    {   // wave w takes positions f = 4 w .. 4 w + 3: post^T [32 o x 16 n] = Wp [32 x 32] . e2[:, f]^T, B straight from global memory (16 bytes = four positions)
-        float wp_[2][8];
+    auto lw0 = [&](int off) { return smem[L::R0 + (off - WS0) + lane]; };                                                 // fragment at packed offset `off`
+    auto lw0_4 = [&](int off) { return *reinterpret_cast<const f32x4*>(smem + L::R0 + (off - WS0) + 4 * lg); };            // bias [lg][r]
+    float w1[2][16], w2m[8], wp_[2][8], wf[2][24];
+    f32x4 b2, bf[2];
+    float e2r[4][2][4];                  // this wave's positions 4 w .. 4 w + 3: e2r[fl][ot][r] = channel 16 ot + 4 r + lg = the B operand of k-step 4 ot + r below
+    {
+        float* E1L = smem + L::R1;
+        {
+            // thread (stream n = tid % 16, j = tid / 16) takes the 16-byte pieces j, j + 32, .. of its stream's [16][68] rows (17 pieces per row):
+            // four consecutive lanes read 64 contiguous bytes
+            const int n = tid & 15, j = tid >> 4;
+            const int bs = b0 + n < a.B ? b0 + n : a.B - 1;
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.carry + (size_t)bs * FCarry::FLOATS + FCarry::AN + (FLds::E1 - FLds::E0));
+            f32x4 v[9];
+#pragma unroll
+            for (int q9 = 0; q9 < 9; ++q9) { const int i4 = j + 32 * q9; v[q9] = src[i4 < 272 ? i4 : 271]; }
+#pragma unroll
+            for (int q9 = 0; q9 < 9; ++q9) {
+                const int i4 = j + 32 * q9, c = i4 / 17, p0 = (i4 - 17 * c) * 4;
+                if (i4 < 272) {
+                    float* dst = E1L + (c * L::E1S + p0) * 16 + n;
+                    dst[0] = v[q9][0]; dst[16] = v[q9][1]; dst[32] = v[q9][2]; dst[48] = v[q9][3];
+                }
+            }
+        }
+        __syncthreads();
 #pragma unroll
         for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) wp_[ot][ks] = ldw(FPk::SB + Q::POST_W + (ot * 8 + ks) * 64, lane * 4);
-        f32x4 ev[8];
+            for (int ks = 0; ks < 24; ++ks) wf[ot][ks] = lw0(Q::FE2_W + (ot * 24 + ks) * 64);
+        bf[0] = lw0_4(Q::FE2_B); bf[1] = lw0_4(Q::FE2_B + 16);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) ev[ks] = *reinterpret_cast<const f32x4*>(e2g + (4 * ks + lg) * 32 + 4 * wave);
+        for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) wp_[ot][ks] = lw0(Q::POST_W + (ot * 8 + ks) * 64);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) w1[jt][ks] = lw0(Q::MG1_W + (jt * 16 + ks) * 64);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) w2m[ks] = lw0(Q::MG2_W + ks * 64);
+        b2 = lw0_4(Q::MG2_B);
+        __syncthreads();                 // (every wave has its copy: R0 may be overwritten)
+        FSB_CLK(15);
+#pragma unroll
+        for (int fl = 0; fl < 4; ++fl) {
+            f32x4 acc[2] = {bf[0], bf[1]};
+            const float* xp = E1L + (lg * L::E1S + 2 * (4 * wave + fl)) * 16 + li;
+            float xb[24];        // (all B operands of the position first: left alone, hipcc sinks each LDS read next to its MFMA and the loop runs at LDS latency)
+#pragma unroll
+            for (int ks = 0; ks < 24; ++ks) xb[ks] = xp[(4 * (ks & 3) * L::E1S + (ks >> 2)) * 16];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 24; ++ks)
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) acc[ot] = FE_MFMA(wf[ot][ks], xb[ks], acc[ot]);
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e2r[fl][ot][r] = elu_f(acc[ot][r]);
+        }
+    }
+    float* P = smem + L::R0;             // post output [32 o][32 f + pad][16 n]
+    float* M1 = smem + L::R1;            // merge Linear output [32 j][32 ch + pad][16 n]
+    FSB_CLK(16);
+    {   // wave w takes positions f = 4 w .. 4 w + 3: post^T [32 o x 16 n] = Wp [32 x 32] . e2[:, f]^T, B = the accumulators above
 #pragma unroll
         for (int fl = 0; fl < 4; ++fl) {
             f32x4 acc[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-                for (int ot = 0; ot < 2; ++ot) acc[ot] = FE_MFMA(wp_[ot][ks], ev[ks][fl], acc[ot]);
+                for (int ot = 0; ot < 2; ++ot) acc[ot] = FE_MFMA(wp_[ot][ks], e2r[fl][ks >> 2][ks & 3], acc[ot]);
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -131,17 +196,20 @@ __global__ void __launch_bounds__(kFsbThreads) __attribute__((amdgpu_waves_per_e
         }
     }
     __syncthreads();
+    FSB_CLK(17);
     {   // wave w takes channels 4 w .. 4 w + 3 of cat = post | sub-band features [32 ch][64]: m1^T [32 j x 16 n] = W1 [32 x 64] . cat[ch]^T; the
         // full-band half from LDS, the sub-band half straight from global memory (k-step 8 + 4 q + e <-> input 32 + 16 q + 4 lg + e)
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
             f32x4 acc[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+            float pb[8];
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const float pb = P[(4 * wave + c4) * L::MS + (4 * ks + lg) * 16 + li];
+            for (int ks = 0; ks < 8; ++ks) pb[ks] = P[(4 * wave + c4) * L::MS + (4 * ks + lg) * 16 + li];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int jt = 0; jt < 2; ++jt) acc[jt] = FE_MFMA(w1[jt][ks], pb, acc[jt]);
-            }
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) acc[jt] = FE_MFMA(w1[jt][ks], pb[ks], acc[jt]);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
@@ -153,14 +221,19 @@ __global__ void __launch_bounds__(kFsbThreads) __attribute__((amdgpu_waves_per_e
         }
     }
     __syncthreads();
+    FSB_CLK(18);
     // 1x1 (32 -> 16): wave w owns sub-bands 4 w .. 4 w + 3 from here on - the residual stream in registers, xr[fl][r] = channel 4 r + lg of stream li
     float xr[4][4];
     {
 #pragma unroll
         for (int fl = 0; fl < 4; ++fl) {
             f32x4 acc = b2;
+            float mb[8];
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) acc = FE_MFMA(w2m[ks], M1[(4 * wave + fl) * L::MS + (4 * ks + lg) * 16 + li], acc);
+            for (int ks = 0; ks < 8; ++ks) mb[ks] = M1[(4 * wave + fl) * L::MS + (4 * ks + lg) * 16 + li];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) acc = FE_MFMA(w2m[ks], mb[ks], acc);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 xr[fl][r] = acc[r];
@@ -168,6 +241,10 @@ __global__ void __launch_bounds__(kFsbThreads) __attribute__((amdgpu_waves_per_e
             }
         }
     }
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e2x[(4 * ot + r) * 64] = f32x4{e2r[0][ot][r], e2r[1][ot][r], e2r[2][ot][r], e2r[3][ot][r]};
     __syncthreads();
     FSB_CLK(1);
     const int d = wave >> 2, q = wave & 3;
@@ -358,25 +435,45 @@ __global__ void __launch_bounds__(kFsbThreads) __attribute__((amdgpu_waves_per_e
     {
         float* S1 = smem + L::R1;            // [32 ch][32 f + pad][16 n]
         float* S2T = smem + L::R0;           // full-band half of the split output, transposed: [32 f][32 ch + pad][16 n]
+        // the section's weight fragments through LDS, like the start section's (R0: the tokens and h sequences are dead)
+        constexpr int WS1 = Q::SP1_W, WS1_N = Q::FD0T_B + 16 - Q::SP1_W;
+        static_assert(WS1_N % 4 == 0 && WS1_N <= 32 * L::MS, "end weights fit R0");
+        {
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.wp + FPk::SB + WS1);
+            f32x4* dst = reinterpret_cast<f32x4*>(smem + L::R0);
+            for (int i = tid; i < WS1_N / 4; i += kFsbThreads) dst[i] = src[i];
+        }
+        auto lw1 = [&](int off) { return smem[L::R0 + (off - WS1) + lane]; };
+        auto lw1_4 = [&](int off) { return *reinterpret_cast<const f32x4*>(smem + L::R0 + (off - WS1) + 4 * lg); };
+        __syncthreads();
         float ws[2][4];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) ws[ct][ks] = ldw(FPk::SB + Q::SP1_W + (ct * 4 + ks) * 64, lane * 4);
-        const f32x4 bs[2] = {ldw4(FPk::SB + Q::SP1_B, lg * 16), ldw4(FPk::SB + Q::SP1_B + 16, lg * 16)};
+            for (int ks = 0; ks < 4; ++ks) ws[ct][ks] = lw1(Q::SP1_W + (ct * 4 + ks) * 64);
+        const f32x4 bs[2] = {lw1_4(Q::SP1_B), lw1_4(Q::SP1_B + 16)};
         float w2[4][8];
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) w2[jt][ks] = ldw(FPk::SB + Q::SP2_W + (jt * 8 + ks) * 64, lane * 4);
+            for (int ks = 0; ks < 8; ++ks) w2[jt][ks] = lw1(Q::SP2_W + (jt * 8 + ks) * 64);
         float wd[2][16];
 #pragma unroll
         for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) wd[ot][ks] = ldw(FPk::SB + Q::FD0_W + (ot * 16 + ks) * 64, lane * 4);
+            for (int ks = 0; ks < 16; ++ks) wd[ot][ks] = lw1(Q::FD0_W + (ot * 16 + ks) * 64);
         f32x4 ev[8];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) ev[ks] = *reinterpret_cast<const f32x4*>(e2g + (4 * ks + lg) * 32 + 4 * wave);
+        for (int ks = 0; ks < 8; ++ks) ev[ks] = e2x[ks * 64];
+        // (all of the section's loads before its first global store: see the note at the enc_out[2] stores)
+        float wt[2][3][8];
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) wt[par][t][ks] = lw1(Q::FD0T_W + ((par * 3 + t) * 8 + ks) * 64);
+        const f32x4 bt = lw1_4(Q::FD0T_B);
 #pragma unroll
         for (int fl = 0; fl < 4; ++fl) {
             f32x4 acc[2] = {bs[0], bs[1]};
@@ -398,12 +495,14 @@ __global__ void __launch_bounds__(kFsbThreads) __attribute__((amdgpu_waves_per_e
             f32x4 acc[4];
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) acc[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            float sb[8];
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const float sb = S1[ch * L::MS + (4 * ks + lg) * 16 + li];
+            for (int ks = 0; ks < 8; ++ks) sb[ks] = S1[ch * L::MS + (4 * ks + lg) * 16 + li];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt) acc[jt] = FE_MFMA(w2[jt][ks], sb, acc[jt]);
-            }
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) acc[jt] = FE_MFMA(w2[jt][ks], sb[ks], acc[jt]);
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
@@ -422,12 +521,14 @@ __global__ void __launch_bounds__(kFsbThreads) __attribute__((amdgpu_waves_per_e
 #pragma unroll
         for (int fl = 0; fl < 4; ++fl) {
             f32x4 t2v[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+            float sb[8];
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const float sb = S2T[(4 * wave + fl) * L::MS + (4 * ks + lg) * 16 + li];
+            for (int ks = 0; ks < 8; ++ks) sb[ks] = S2T[(4 * wave + fl) * L::MS + (4 * ks + lg) * 16 + li];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ot = 0; ot < 2; ++ot) t2v[ot] = FE_MFMA(wd[ot][ks], sb, t2v[ot]);
-            }
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) t2v[ot] = FE_MFMA(wd[ot][ks], sb[ks], t2v[ot]);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
@@ -439,14 +540,6 @@ __global__ void __launch_bounds__(kFsbThreads) __attribute__((amdgpu_waves_per_e
         }
         // fullband_decoder.0's ConvTranspose1d(32 -> 16, k 6, s 2, p 2) + folded BN + ELU: output positions 2 m + q (q = 0, 1) take kernel
         // indices q + 2 i from input positions m + 1 - i (i = 0, 1, 2).  Wave w takes m = 4 w .. 4 w + 3: per m and parity one 16-row tile, K = 3 x 32
-        float wt[2][3][8];
-#pragma unroll
-        for (int par = 0; par < 2; ++par)
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) wt[par][t][ks] = ldw(FPk::SB + Q::FD0T_W + ((par * 3 + t) * 8 + ks) * 64, lane * 4);
-        const f32x4 bt = ldw4(FPk::SB + Q::FD0T_B, lg * 16);
         __syncthreads();
         f32x4 dv[4][2];
 #pragma unroll
@@ -457,11 +550,14 @@ __global__ void __launch_bounds__(kFsbThreads) __attribute__((amdgpu_waves_per_e
             for (int t = 0; t < 3; ++t) {
                 const int f = m + 1 - t;
                 if (f >= 0 && f < 32) {          // (wave-uniform)
+                    float tb[8];
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) tb[ks] = T2L[f * L::MS + (4 * ks + lg) * 16 + li];
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int ks = 0; ks < 8; ++ks) {
-                        const float tb = T2L[f * L::MS + (4 * ks + lg) * 16 + li];
-                        dv[ml][0] = FE_MFMA(wt[0][t][ks], tb, dv[ml][0]);
-                        dv[ml][1] = FE_MFMA(wt[1][t][ks], tb, dv[ml][1]);
+                        dv[ml][0] = FE_MFMA(wt[0][t][ks], tb[ks], dv[ml][0]);
+                        dv[ml][1] = FE_MFMA(wt[1][t][ks], tb[ks], dv[ml][1]);
                     }
                 }
             }

@@ -33,6 +33,7 @@ def main():
     if c[32] != 0:      # the stream-batched DPE kernel ran (fspen_sb_kernels.hip.h): its counters
         q = c[32:]
         print(f"fspen B={B}: stream-batched kernel = {q[14] - q[0]} cycles; post + feature merge {q[1] - q[0]}")
+        print(f"  enc_out[1] -> LDS {q[15] - q[0]}, fullband_encoder.2 {q[16] - q[15]}, post {q[17] - q[16]}, merge Linear {q[18] - q[17]}, merge 1x1 {q[1] - q[18]}")
         for b in range(3):
             o = 2 + 4 * b
             print(f"  block {b}: weight / state requests {q[o] - (q[1] if b == 0 else q[o - 1])}, recurrence {q[o + 1] - q[o]}, "
