@@ -1,7 +1,7 @@
 // fspen_sb_kernels.hip.h — the MIDDLE of FSPEN BATCHED OVER THE STREAMS on the fp32 matrix cores (gfx950), for the per-hop step of large
 // batches: fullband_encoder.2, fullband_encoder_post, feature merge, the three DPE blocks, feature split and fullband_decoder.0 (models/fspen/model.py:
 // 244-264 around 122-189: per block an intra bidirectional GRU over the 32 sub-bands + intra_fc + LayerNorm + residual, then eight
-// grouped inter GRUs over time + inter_fc + residuals) - 0.97 of the model's 0.99 MMAC per frame.
+// grouped inter GRUs over time + inter_fc + residuals) - 0.97 of the model's 1.04 MMAC per frame.
 //
 // fspen_frame_kernel gives a stream a workgroup: every product is then M = 1 (vector FMAs), and the intra GRU is a chain of 96
 // dependent steps per frame on two of its four waves.  Here a workgroup takes SIXTEEN streams and every product is a matrix-core
