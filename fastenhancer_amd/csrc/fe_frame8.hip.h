@@ -47,7 +47,12 @@ struct Wg8 {
     //   slot 1: GRU input weights   slot 3: GRU hidden weights   slot 0: rnn_fc, then attn_fc   slot 2: qkv
     static constexpr int SLOT = S::U8_SLOT;
     static constexpr int WB0 = L::NOSTAGE_TOTAL, WB1 = WB0 + 2 * SLOT;
-    static constexpr size_t BYTES = (size_t)(L::NOSTAGE_TOTAL + 4 * SLOT) * 4;
+    // The new GRU states of the KB blocks wait in LDS for the end of the frame and leave as whole lines (HST, when it fits): stored from the GRU
+    // epilogues - 64-byte pieces of [F2][C2] rows - their acknowledgements were charged to the next vmcnt wait of the weight staging
+    // (vmcnt counts loads and stores in order): 0.6 us of the 31.6 us frame (same-box timing experiment, profiles/r4a_wg8_steps.txt)
+    static constexpr int HST = L::NOSTAGE_TOTAL + 4 * SLOT;
+    static constexpr bool HSTASH = (size_t)(HST + S::KB * S::F2 * S::C2) * 4 <= 160 * 1024;
+    static constexpr size_t BYTES = (size_t)(HST + (HSTASH ? S::KB * S::F2 * S::C2 : 0)) * 4;
     static constexpr int NPWB = ceil_div(ceil_div(SLOT, 256), kWaves8);      // pieces per wave of a block unit
     static constexpr bool PLAN_OK = 2 * SLOT >= Pack<S>::umax() && BYTES <= 160 * 1024 && (S::NU & 1) == 0;
     static constexpr bool OK = OK0 && PLAN_OK;
@@ -444,7 +449,8 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
                         for (int r = 0; r < 4; ++r) {
                             const int row = 16 * g_rt + 4 * lg + r;
                             Hl[row * LDX + ch] = hn[r];
-                            hg[row * C2 + ch] = hn[r];
+                            if constexpr (W8::HSTASH) smem[W8::HST + k * (F2 * C2) + row * C2 + ch] = hn[r];
+                            else hg[row * C2 + ch] = hn[r];
                         }
                     }
                 } else if (wave < 6) {
@@ -488,7 +494,8 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
                         for (int r = 0; r < 4; ++r) {
                             const int row = 16 * g_rt + 4 * lg + r;
                             Hl[row * LDX + ch] = hn[r];
-                            hg[row * C2 + ch] = hn[r];
+                            if constexpr (W8::HSTASH) smem[W8::HST + k * (F2 * C2) + row * C2 + ch] = hn[r];
+                            else hg[row * C2 + ch] = hn[r];
                         }
                     }
                 } else {
@@ -736,6 +743,16 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
             // one sample per thread: the first H go out, the rest is the new overlap tail (the old tail was read before the barrier)
             if (tid < H) a.wav_out[(size_t)b * a.out_stride + tid] = xo;
             else cis[tid - H] = xo;
+            if constexpr (W8::HSTASH) {       // the frame's new GRU states: [KB][B][F2 * C2], 16 bytes per thread and store
+                constexpr int N4 = F2 * C2 / 4;
+                static_assert((F2 * C2) % 4 == 0 && W8::HST % 4 == 0, "16-byte state rows");
+                const f32x4* hst = reinterpret_cast<const f32x4*>(smem + W8::HST);
+#pragma unroll
+                for (int k = 0; k < S::KB; ++k) {
+                    f32x4* dst = reinterpret_cast<f32x4*>(a.h + ((size_t)k * a.B + b) * (F2 * C2));
+                    for (int e = tid; e < N4; e += NTH) dst[e] = hst[k * N4 + e];
+                }
+            }
             if constexpr (PERSIST) __syncthreads();               // (the next stream's frame load reuses q0)
         }
         FE_CLK(13);
