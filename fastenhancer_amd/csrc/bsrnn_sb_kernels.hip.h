@@ -37,7 +37,12 @@ template <class S>
 struct SbLds {
     static constexpr int XS = 0;                                         // [31][C][16]   band features, position p = 4 ks + lg <-> channel KSC lg + ks
     static constexpr int HB = XS + kBands * S::C * kSbStreams;            // [2 directions][2][HH][16]   h of the running step (double buffer)
-    static constexpr int TOTAL = HB + 4 * S::HH * kSbStreams;
+    // the time LSTM's and fc_time's fragments + start values of the running layer - the same for all eight waves: copied once per workgroup
+    // (each wave fetching its own copy: 1.1 k wave-level loads per workgroup and layer on the CU's vector-memory path)
+    static constexpr int WT = HB + 4 * S::HH * kSbStreams;
+    static constexpr int WT_W = 0, WT_FC = WT_W + (S::HH / 4) * (S::C / 4 + S::HH / 4) * 64, WT_B = WT_FC + (S::C / 16) * (S::HH / 4) * 64,
+                         WT_FCB = WT_B + (S::HH / 4) * 16, WT_N = WT_FCB + (S::C / 16) * 16;
+    static constexpr int TOTAL = WT + WT_N;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
     static constexpr bool FITS = S::C == 16;      // (the register plan - a layer's gate fragments per wave - is for num_channels = 16)
 };
@@ -114,17 +119,29 @@ __global__ void __launch_bounds__(kSbThreads) __attribute__((amdgpu_waves_per_eu
     for (int l = 0; l < S::NLAY; ++l) {
         // ======================================= time LSTM + fc_time: bands over the waves, no barrier =======================================
         {
+            float* wtl = smem + L::WT;
+            {
+                auto copy4 = [&](int dst, int off, int n) {
+                    const f32x4* src = reinterpret_cast<const f32x4*>(a.wp + off);
+                    for (int i = tid; i < n / 4; i += kSbThreads) reinterpret_cast<f32x4*>(wtl + dst)[i] = src[i];
+                };
+                copy4(L::WT_W, o.t_w[l], KSH * KS1 * 64);
+                copy4(L::WT_FC, o.tfc_w[l], NTO * KSH * 64);
+                copy4(L::WT_B, o.t_b[l], KSH * 16);
+                copy4(L::WT_FCB, o.tfc_b[l], NTO * 16);
+            }
+            __syncthreads();
             float Wt[KSH][KS1], Wf1[NTO][KSH];
             f32x4 Wf1b[NTO];
 #pragma unroll
             for (int t = 0; t < KSH; ++t)
 #pragma unroll
-                for (int ks = 0; ks < KS1; ++ks) Wt[t][ks] = afrag(o.t_w[l], t, KS1, ks);
+                for (int ks = 0; ks < KS1; ++ks) Wt[t][ks] = wtl[L::WT_W + (t * KS1 + ks) * 64 + lane];
 #pragma unroll
             for (int to = 0; to < NTO; ++to) {
 #pragma unroll
-                for (int ks = 0; ks < KSH; ++ks) Wf1[to][ks] = afrag(o.tfc_w[l], to, KSH, ks);
-                Wf1b[to] = bias4(o.tfc_b[l], to);
+                for (int ks = 0; ks < KSH; ++ks) Wf1[to][ks] = wtl[L::WT_FC + (to * KSH + ks) * 64 + lane];
+                Wf1b[to] = *reinterpret_cast<const f32x4*>(wtl + L::WT_FCB + to * 16 + 4 * lg);
             }
             float* hg = a.lstm + (size_t)(2 * l) * a.B * (kBands * HH);
             float* cg = a.lstm + (size_t)(2 * l + 1) * a.B * (kBands * HH);
@@ -147,7 +164,7 @@ __global__ void __launch_bounds__(kSbThreads) __attribute__((amdgpu_waves_per_eu
                 for (int ks = 0; ks < KSC; ++ks) xb[ks] = xs[(j * C + 4 * ks + lg) * NS + li];
                 f32x4 acc[KSH];
 #pragma unroll
-                for (int t = 0; t < KSH; ++t) acc[t] = bias4(o.t_b[l], t);     // (L2-hot 16-byte loads; held in registers they would not fit next to the fragments)
+                for (int t = 0; t < KSH; ++t) acc[t] = *reinterpret_cast<const f32x4*>(wtl + L::WT_B + t * 16 + 4 * lg);     // (held in registers they would not fit next to the fragments)
 #pragma unroll
                 for (int ks = 0; ks < KSC; ++ks)
 #pragma unroll
@@ -298,6 +315,12 @@ template <class S>
 void sb_launch_layers(const SbArgs& a, hipStream_t st, hipError_t* err) {
     if constexpr (SbLds<S>::FITS) {
         auto* fn = &bsrnn_sb_layers_kernel<S>;
+        static bool attr_set = false;
+        if (!attr_set) {      // (more than 64 KB of dynamic LDS)
+            *err = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SbLds<S>::BYTES);
+            if (*err != hipSuccess) return;
+            attr_set = true;
+        }
         hipLaunchKernelGGL(fn, dim3((a.B + kSbStreams - 1) / kSbStreams), dim3(kSbThreads), SbLds<S>::BYTES, st, a);
         *err = hipGetLastError();
     } else {
