@@ -1174,7 +1174,7 @@ int pack_weights_fspen(fe_handle* h, const std::vector<float>& blob, std::vector
             const float* bb = S(nm);
             for (int q = 0; q < keep[i]; ++q) {
                 const int bin = base[i] + q, o = (k0[i] + q) % kSdN[i];
-                for (int k = 0; k < 64; ++k) buf[P::SD_W + k * 260 + bin] = w[o * 64 + k];
+                for (int k = 0; k < 64; ++k) buf[P::SD_W + ((k / 4) * 260 + bin) * 4 + k % 4] = w[o * 64 + k];
                 buf[P::SD_B + bin] = bb[o];
             }
         }

@@ -82,7 +82,7 @@ struct FPk {
     static constexpr int SP1_W = DPE + 3 * D_SIZE;                        // feature_split.0^T [c < 16][ch < 32]
     static constexpr int SP1_B = SP1_W + 512;
     static constexpr int SP2_W = SP1_B + 32;                              // feature_split.1^T [f < 32][j < 64]
-    static constexpr int SD_W = SP2_W + 2048;                             // sub-band decoder, one column per bin: [k < 64][260]
+    static constexpr int SD_W = SP2_W + 2048;                             // sub-band decoder, one column per bin: [k / 4 < 16][260][4] (16-byte loads: four k per load)
     static constexpr int SD_B = SD_W + 64 * 260;                          // [260]
     static constexpr int FD0_W = SD_B + 260;                              // decoder 1x1 ^T: [c < 64][32]
     static constexpr int FD0_T = FD0_W + 2048;                            // transposed conv [(c*6 + k)][16]   c < 32
@@ -187,6 +187,9 @@ struct WView {
                                // made every vector offset loop-invariant, hoisted and kept live - measured slower)
     __device__ __forceinline__ float operator[](int i) const {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (base + i) * 4, 0, 0));
+    }
+    __device__ __forceinline__ f32x4 ld4(int i) const {         // 16 bytes at float index i (a multiple of 4)
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (base + i) * 4, 0, 0));
     }
     __device__ __forceinline__ WView operator+(int off) const { return WView{rsrc, base + off}; }
 };
@@ -834,7 +837,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(P
         }
         }
         __builtin_amdgcn_sched_barrier(0);      // (keeps the next phase's weight burst from being hoisted above this phase's arithmetic)
-        FS_LDW(sd_w, 16, P::SD_W + tid, 260);                  // sub-band decoder column of bin = tid, chunk 0 of 4
+        // sub-band decoder column of bin = tid: 64 weights as sixteen 16-byte loads, the first eight before the barrier.  (The wave-level load
+        // is the unit the CU's vector-memory path charges for - with three / four of these workgroups per CU that path, not the ALU, bounds the tail.)
+        f32x4 sd_w[8];
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) sd_w[k4] = wp.ld4(P::SD_W + (k4 * 260 + tid) * 4);
         const float sd_b = wp[P::SD_B + tid];
         __syncthreads();
         dump(11, [&](int r, int c) { return s2[r * 64 + c]; });
@@ -854,12 +861,20 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(P
             const int row = sd_row(tid);
             const bool zero_row = row >= 32;                      // lin5's F.pad row: ReLU(bias)
             const int rc = zero_row ? 0 : row;
-            float acc[1] = {0.0f};
-            const WView wcol = wp + P::SD_W + tid;
-            // k < 32: x_sub1 (cat[k][32 + row]); k >= 32: x_sub2 (s2[k - 32][32 + row]); both are [32][64] arrays, chunks 0, 1 | 2, 3
-            fs_pipe<4, 16, 1>(acc, sd_w, [&](int ch, int j) { return wcol[(ch * 16 + j) * 260]; },
-                              [&](int ch, int j, int) { const float* src = ch < 2 ? cat : s2 - 32 * 64; return src[(ch * 16 + j) * 64 + 32 + rc]; });
-            msub[tid] = fmaxf(sd_b + (zero_row ? 0.0f : acc[0]), 0.0f);
+            // k < 32: x_sub1 (cat[k][32 + row]); k >= 32: x_sub2 (s2[k - 32][32 + row]); both are [32][64] arrays
+            f32x4 sd_w2[8];
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4) sd_w2[k4] = wp.ld4(P::SD_W + ((8 + k4) * 260 + tid) * 4);
+            float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc0 = fmaf(sd_w[k4][e], cat[(4 * k4 + e) * 64 + 32 + rc], acc0);
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc1 = fmaf(sd_w2[k4][e], s2[(4 * k4 + e) * 64 + 32 + rc], acc1);
+            msub[tid] = fmaxf(sd_b + (zero_row ? 0.0f : acc0 + acc1), 0.0f);
             if (tid == 0) msub[256] = fmaxf(wp[P::SD_B + 256], 0.0f);          // bin 256 reads the zero row too
         }
         __builtin_amdgcn_sched_barrier(0);
