@@ -108,6 +108,7 @@ struct BArgs {
     float* mlp_x;
     float* mlp_sp;
     float* mlp_pre;
+    int mlp_tpw;              // bsrnn_mlp_kernel: sixteen-stream tiles per wave (> 1 only where a band's layer-2 weights all sit in the register ring: C = 16)
     float* sb_y;              // stream-batched layers (bsrnn_sb_kernels.hip.h): the band LSTM's outputs of the running layer [B][2][31][HH]
 };
 
@@ -1011,8 +1012,11 @@ __global__ void __launch_bounds__(kThreads) bsrnn_mlp_kernel(BArgs a) {
     const int li = lane & 15, lg = lane >> 4;
     const int kb = (int)blockIdx.x % (2 * kBands), tg = (int)blockIdx.x / (2 * kBands);
     const int kind = kb / kBands, band = kb - kind * kBands;
-    const int s0 = (tg * kWaves + wave) * 16;
-    if (s0 >= a.B) return;                                    // (wave-uniform; the kernel has no barrier)
+    // a wave takes `tpw` sixteen-stream tiles of its band, one after the other (large batches of the C = 16 shapes: the band's weights - all of
+    // them in registers there - are fetched once per wave instead of once per tile: the kernel ran at a third of its MFMA time, on weight loads)
+    const int tpw = a.mlp_tpw > 1 ? a.mlp_tpw : 1;
+    const int tile0 = (tg * kWaves + wave) * tpw;
+    if (tile0 * 16 >= a.B) return;                            // (wave-uniform; the kernel has no barrier)
     const float* __restrict__ wp = a.wp;
     const BOffsets& o = a.off;
     float* h1 = smem + wave * (16 * LDH);
@@ -1035,6 +1039,10 @@ __global__ void __launch_bounds__(kThreads) bsrnn_mlp_kernel(BArgs a) {
     float ring[D][KB], rbias[D];
 #pragma unroll
     for (int jj = 0; jj < D; ++jj) { rbias[jj] = 0.0f; load_item(jj, ring[jj], rbias[jj]); }
+#pragma unroll 1
+    for (int tl = 0; tl < tpw; ++tl) {
+    const int s0 = (tile0 + tl) * 16;
+    if (s0 >= a.B) break;
     // ---- layer 1
     {
         const int srow = s0 + li < a.B ? s0 + li : a.B - 1;   // (rows past the batch shadow its last stream; their results are not stored)
@@ -1104,6 +1112,7 @@ __global__ void __launch_bounds__(kThreads) bsrnn_mlp_kernel(BArgs a) {
                 load_item(it + D, ring[jj], rbias[jj]);
             }
         }
+    }
     }
 }
 
@@ -1217,8 +1226,10 @@ void blaunch_mlp(const BArgs& a, hipStream_t st, hipError_t* err) {
         if (e != hipSuccess) { *err = e; return; }
         attr_set[dev].store(true, std::memory_order_relaxed);
     }
-    const int groups = (a.B + 16 * kWaves - 1) / (16 * kWaves);
-    hipLaunchKernelGGL(fn, dim3(2 * kBands * groups), dim3(kThreads), BMlpLds<S>::BYTES, st, a);
+    BArgs am = a;
+    am.mlp_tpw = (S::C == 16 && a.B >= 2048) ? 4 : 1;       // (C = 16: KS2 = 16 k-steps = one burst per item, at most five items = the ring)
+    const int groups = (a.B + 16 * kWaves * am.mlp_tpw - 1) / (16 * kWaves * am.mlp_tpw);
+    hipLaunchKernelGGL(fn, dim3(2 * kBands * groups), dim3(kThreads), BMlpLds<S>::BYTES, st, am);
     *err = hipGetLastError();
 }
 
