@@ -1128,6 +1128,10 @@ int pack_weights_fspen(fe_handle* h, const std::vector<float>& blob, std::vector
         const float* sb1 = S("feature_split.0.bias");
         const float* s2 = S("feature_split.1.weight");        // (64, 32)
         const float* wd0 = S("fullband_decoder.0.0.weight");  // (32, 64, 1)
+        const float* wd1 = S("fullband_decoder.1.0.weight");  // (16, 32, 1)
+        const float* wd1t = S("fullband_decoder.1.1.weight"); // ConvTranspose1d (16 in, 4 out, 8)
+        const float* bd1t = S("fullband_decoder.1.1.bias");
+        for (int row = 0; row < 16; ++row) buf[P::SB + Q::FD1T_B + row] = row < 8 ? bd1t[row & 3] : 0.0f;
         const float* wdt = S("fullband_decoder.0.1.weight");  // ConvTranspose1d (32 in, 16 out, 6)
         const float* bdt = S("fullband_decoder.0.1.bias");
         for (int o = 0; o < 16; ++o) buf[P::SB + Q::FD0T_B + o] = bdt[o];
@@ -1152,6 +1156,12 @@ int pack_weights_fspen(fe_handle* h, const std::vector<float>& blob, std::vector
             for (int par = 0; par < 2; ++par)
                 for (int t = 0; t < 3; ++t)
                     for (int ks = 0; ks < 8; ++ks) buf[P::SB + Q::FD0T_W + ((par * 3 + t) * 8 + ks) * 64 + lane] = wdt[((4 * ks + lg) * 16 + li) * 6 + par + 2 * t];
+            for (int ks = 0; ks < 8; ++ks) buf[P::SB + Q::FD1_W + ks * 64 + lane] = wd1[feat(li) * 32 + (ks < 4 ? 4 * lg + ks : 16 + 4 * (ks - 4) + lg)];
+            for (int j = 0; j < 5; ++j)
+                for (int cq = 0; cq < 4; ++cq) {
+                    const int par = li >> 2, o = li & 3, k = (par ? 8 : 7) - 2 * j;      // output positions 2 m + par <- input position m - 2 + j
+                    buf[P::SB + Q::FD1T_W + (j * 4 + cq) * 64 + lane] = (li < 8 && k >= 0 && k < 8) ? wd1t[((4 * cq + lg) * 4 + o) * 8 + k] : 0.0f;
+                }
         }
         for (int lg = 0; lg < 4; ++lg)
             for (int r = 0; r < 4; ++r) {

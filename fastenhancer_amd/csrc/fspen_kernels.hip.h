@@ -48,7 +48,10 @@ struct FSbPk {
     static constexpr int FD0T_W = FD0_W + 32 * 64;       // fullband_decoder.0.1 (ConvTranspose1d 32 -> 16, k 6, s 2): [parity < 2][tap < 3][k-step < 8][64], rows in natural order,
                                                          // tap i of parity q = kernel index q + 2 i <-> input position m + 1 - i of output positions 2 m + q
     static constexpr int FD0T_B = FD0T_W + 48 * 64;      // [16]
-    static constexpr int TOTAL = FD0T_B + 16;
+    static constexpr int FD1_W = FD0T_B + 16;            // fullband_decoder.1.0 (1x1, 32 -> 16): [k-step < 8][64]; k-steps 0-3: d2 channel 4 lg + ks, 4-7: enc_out[1] channel 4 (ks - 4) + lg
+    static constexpr int FD1T_W = FD1_W + 8 * 64;        // fullband_decoder.1.1 (ConvTranspose1d 16 -> 4, k 8, s 2): [input position j < 5][cq < 4][64], rows 4 q + o (parity q, output o), rows 8-15 zero
+    static constexpr int FD1T_B = FD1T_W + 20 * 64;      // [16] (rows 4 q + o: bias[o]; rows 8-15: 0)
+    static constexpr int TOTAL = FD1T_B + 16;
 };
 
 // ---- packed weights (floats), filled by the host packer; all matrices k-major: [k][outputs]
@@ -117,7 +120,7 @@ struct FArgs {
     float* frames;            // [B][T][N] windowed output frames (summed / envelope-normalised by istft_ola_kernel)
     int pipe_p;
     // split step of large batches (PART 1 -> fspen_sb_dpe_kernel -> PART 2)
-    float* tok;               // [B][2][1024] written by fspen_sb_dpe_kernel, read by PART 2: feature_split output, sub-band half [32][32] | fullband_decoder.0 output [16][64]
+    float* tok;               // [B][2][1024] written by fspen_sb_dpe_kernel, read by PART 2: feature_split output, sub-band half [32][32] | fullband_decoder.1 output [4][128]
     float* carry;             // [B][FCarry::FLOATS] the front's LDS regions that the DPE kernel (cat) and the tail read: compressed spectrum, encoder outputs, sub-band / full-band features
 };
 
@@ -286,8 +289,8 @@ __device__ __forceinline__ float row_dot(const float (&w)[12], float h, float ac
 // inter-GRU states (24 x [4][16] per stream), handed over per DPE block through `gru` - agent-scope stores, drained, a counter per
 // (utterance, block); the consumer polls the counter and fetches the states right before the block's inter GRUs.
 // PART: 0 the whole frame; 1 the front (STFT, sub-band encoder, fullband_encoder.0-1: its LDS regions to global memory); 2 the tail
-// (sub-band decoder, fullband_decoder.1 .. iSTFT) - the per-hop step of large batches runs 1 -> fspen_sb_dpe_kernel (fullband_encoder.2,
-// fullband_encoder_post, feature merge, 3 x DPE, feature split, fullband_decoder.0 - batched over the streams, fspen_sb_kernels.hip.h) -> 2
+// (sub-band decoder, fullband_decoder.2, masks, iSTFT) - the per-hop step of large batches runs 1 -> fspen_sb_dpe_kernel (fullband_encoder.2,
+// fullband_encoder_post, feature merge, 3 x DPE, feature split, fullband_decoder.0-1 - batched over the streams, fspen_sb_kernels.hip.h) -> 2
 #ifndef FS_WPE_FRONT
 #define FS_WPE_FRONT 4
 #endif
@@ -595,9 +598,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(P
         } else {
             const f32x4* tk = reinterpret_cast<const f32x4*>(a.tok + (size_t)b * 2048);
             const f32x4* cr = reinterpret_cast<const f32x4*>(a.carry + (size_t)b * FCarry::FLOATS);
-            // feature_split output, sub-band half -> s2[ch][32 ..]; fullband_decoder.0's output -> d2 [16][64]
+            // feature_split output, sub-band half -> s2[ch][32 ..]; fullband_decoder.1's output -> d1 [4][128]
             for (int i = tid; i < 256; i += kThreads) reinterpret_cast<f32x4*>(smem + L::S2 + (i >> 3) * 64 + 32)[i & 7] = tk[i];
-            for (int i = tid; i < 256; i += kThreads) reinterpret_cast<f32x4*>(smem + L::D2)[i] = tk[256 + i];
+            for (int i = tid; i < 128; i += kThreads) reinterpret_cast<f32x4*>(smem + L::D1)[i] = tk[256 + i];
             for (int i = tid; i < FCarry::AN / 4; i += kThreads) reinterpret_cast<f32x4*>(smem + FCarry::A0)[i] = cr[i];
             for (int i = tid; i < FCarry::BN / 4; i += kThreads) reinterpret_cast<f32x4*>(smem + FCarry::B0)[i] = cr[FCarry::AN / 4 + i];
             __syncthreads();
@@ -958,6 +961,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(P
         __syncthreads();
         dump(12, [&](int r, int c) { return d2[r * 64 + c]; });
         float* t1 = smem + L::T1;
+        float* d1 = smem + L::D1;
+        if constexpr (PART != 2) {
         {   // decoder 1: 1x1 over cat(d2, enc_out[1]) (32 -> 16)
             const int o = tid & 15;
             float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -981,7 +986,6 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(P
         }
         const float fd1_b = wp[P::FD1_B + (tid & 3)];
         __syncthreads();
-        float* d1 = smem + L::D1;
         {   // ConvTranspose1d(16 -> 4, k 8, s 2, p 3) + folded BN + ELU: p = 2 f + k - 3
             const int o = tid & 3, k0 = ((tid >> 2) + 1) & 1;
             int fcol[2][4];
@@ -1024,6 +1028,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(P
                 for (int i = 0; i < 4; ++i) acc = fmaf(fm[q][i], acc4[q * 4 + i], acc);
                 d1[o * 128 + (tid >> 2) + 64 * q] = elu_f(acc);
             }
+        }
         }
         __builtin_amdgcn_sched_barrier(0);      // (keeps the next phase's weight burst from being hoisted above this phase's arithmetic)
         FS_LDW(fd2_w, 8, P::FD2_W + (tid & 3), 4);

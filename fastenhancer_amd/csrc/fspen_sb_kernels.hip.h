@@ -1,5 +1,5 @@
 // fspen_sb_kernels.hip.h — the MIDDLE of FSPEN BATCHED OVER THE STREAMS on the fp32 matrix cores (gfx950), for the per-hop step of large
-// batches: fullband_encoder.2, fullband_encoder_post, feature merge, the three DPE blocks, feature split and fullband_decoder.0 (models/fspen/model.py:
+// batches: fullband_encoder.2, fullband_encoder_post, feature merge, the three DPE blocks, feature split and fullband_decoder.0-1 (models/fspen/model.py:
 // 244-264 around 122-189: per block an intra bidirectional GRU over the 32 sub-bands + intra_fc + LayerNorm + residual, then eight
 // grouped inter GRUs over time + inter_fc + residuals) - 0.97 of the model's 1.04 MMAC per frame.
 //
@@ -44,7 +44,8 @@ struct FSbLds {
     static constexpr int RED = R1 + 16 * E1S * 16;    // [2][8 waves][16 n]
     static_assert(16 * E1S * 16 >= 32 * MS, "R1 holds either");
     static_assert(RED >= HS + 2 * 32 * 16 * 16, "the h sequences end before the reduction slots");
-    static constexpr int TOTAL = RED + 2 * 8 * 16;
+    static constexpr int WX = RED + 2 * 8 * 16;       // fullband_decoder.1's fragments and bias (FSbPk::FD1_W ..): a region of their own - R0 / R1 are busy by then
+    static constexpr int TOTAL = WX + (FSbPk::FD1T_B + 16 - FSbPk::FD1_W);
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
 };
 
@@ -443,6 +444,14 @@ __global__ void __launch_bounds__(kFsbThreads) __attribute__((amdgpu_waves_per_e
             f32x4* dst = reinterpret_cast<f32x4*>(smem + L::R0);
             for (int i = tid; i < WS1_N / 4; i += kFsbThreads) dst[i] = src[i];
         }
+        {
+            constexpr int WX_N = Q::FD1T_B + 16 - Q::FD1_W;
+            static_assert(WX_N % 4 == 0, "16-byte copy");
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.wp + FPk::SB + Q::FD1_W);
+            f32x4* dst = reinterpret_cast<f32x4*>(smem + L::WX);
+            for (int i = tid; i < WX_N / 4; i += kFsbThreads) dst[i] = src[i];
+        }
+        auto lwx = [&](int off) { return smem[L::WX + (off - Q::FD1_W) + lane]; };
         auto lw1 = [&](int off) { return smem[L::R0 + (off - WS1) + lane]; };
         auto lw1_4 = [&](int off) { return *reinterpret_cast<const f32x4*>(smem + L::R0 + (off - WS1) + 4 * lg); };
         __syncthreads();
@@ -562,14 +571,73 @@ __global__ void __launch_bounds__(kFsbThreads) __attribute__((amdgpu_waves_per_e
                 }
             }
         }
-        if (live) {      // d2 [16 o][64 p]: a lane's eight positions 8 w .. 8 w + 7 of output o = 4 lg + r are 32 bytes
+        // ---------------- fullband_decoder.1 (:266-270): 1x1 over cat(d2, enc_out[1]) (32 -> 16, no bias), ConvTranspose1d(16 -> 4, k 8, s 2, p 3) + folded BN + ELU ----------------
+        // the 1x1 per output position p = 8 w .. 8 w + 7 of this wave: the d2 half of K straight from the accumulators above (register r of a lane =
+        // channel 4 lg + r = k-step r of the "4 lg + ks" k-order), the enc_out[1] half from global memory (8 bytes = two positions per load)
+        float* T1L = smem + L::R0;           // its output, position-major: [64 p][16 c][16 n] (the split output there is dead)
+        {
+            float wa[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) wa[ks] = lwx(Q::FD1_W + ks * 64);
+            float2 e1v[4][4];
+            const float* e1g = cr + (FLds::E1 - FLds::E0) + 2 + 8 * wave;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int q2 = 0; q2 < 4; ++q2) e1v[ks][q2] = *reinterpret_cast<const float2*>(e1g + (4 * ks + lg) * 68 + 2 * q2);
+#pragma unroll
+            for (int ml = 0; ml < 4; ++ml)
+#pragma unroll
+                for (int par = 0; par < 2; ++par) {
+                    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) acc = FE_MFMA(wa[ks], elu_f(dv[ml][par][ks]), acc);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) acc = FE_MFMA(wa[4 + ks], par ? e1v[ks][ml].y : e1v[ks][ml].x, acc);
+                    const int p = 8 * wave + 2 * ml + par;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T1L[(p * 16 + 4 * r + lg) * 16 + li] = acc[r];
+                }
+        }
+        float wq[5][4];
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq) wq[j][cq] = lwx(Q::FD1T_W + (j * 4 + cq) * 64);
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(smem + L::WX + (Q::FD1T_B - Q::FD1_W) + 4 * lg);
+        __syncthreads();
+        // the transposed convolution: output positions 2 m + q take kernel indices 7 - 2 j (q = 0) / 8 - 2 j (q = 1) from input positions m - 2 + j, j < 5.
+        // Per m ONE 16-row tile (rows 4 q + o, q < 2, o < 4; rows 8 .. 15 idle) over K = 5 positions x 16 channels; wave w takes m = 8 w .. 8 w + 7
+        {
+            f32x4 d1v[8];
+#pragma unroll
+            for (int ml = 0; ml < 8; ++ml) {
+                const int m = 8 * wave + ml;
+                d1v[ml] = bq;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const int f = m - 2 + j;
+                    if (f >= 0 && f < 64) {          // (wave-uniform)
+                        float tb[4];
+#pragma unroll
+                        for (int cq = 0; cq < 4; ++cq) tb[cq] = T1L[(f * 16 + 4 * cq + lg) * 16 + li];
+#pragma unroll
+                        for (int cq = 0; cq < 4; ++cq) d1v[ml] = FE_MFMA(wq[j][cq], tb[cq], d1v[ml]);
+                    }
+                }
+            }
+            // d1 [4 o][128 p] for the tail: lane group lg < 2 holds parity lg of output o = r; the parities of a position pair meet in the lg = 0 lanes
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const f32x4 o0 = {elu_f(dv[0][0][r]), elu_f(dv[0][1][r]), elu_f(dv[1][0][r]), elu_f(dv[1][1][r])};
-                const f32x4 o1 = {elu_f(dv[2][0][r]), elu_f(dv[2][1][r]), elu_f(dv[3][0][r]), elu_f(dv[3][1][r])};
-                float* dst = a.s2 + (size_t)bn * 2048 + 1024 + (4 * lg + r) * 64 + 8 * wave;
-                *reinterpret_cast<f32x4*>(dst) = o0;
-                *reinterpret_cast<f32x4*>(dst + 4) = o1;
+                float own[8], oth[8];
+#pragma unroll
+                for (int ml = 0; ml < 8; ++ml) { own[ml] = elu_f(d1v[ml][r]); oth[ml] = __shfl_xor(own[ml], 16, 64); }
+                if (live && lg == 0) {
+                    float* dst = a.s2 + (size_t)bn * 2048 + 1024 + r * 128 + 16 * wave;
+#pragma unroll
+                    for (int h4 = 0; h4 < 4; ++h4)
+                        *reinterpret_cast<f32x4*>(dst + 4 * h4) = f32x4{own[2 * h4], oth[2 * h4], own[2 * h4 + 1], oth[2 * h4 + 1]};
+                }
             }
         }
     }
