@@ -178,7 +178,7 @@ struct FLds {
 struct FCarry {
     static constexpr int A0 = FLds::SP, AN = FLds::TW - FLds::SP, B0 = FLds::E0, BN = FLds::SB - FLds::E0;
     static constexpr int FLOATS = (AN + BN + 3) / 4 * 4;
-    static_assert(AN % 4 == 0 && BN % 4 == 0 && A0 % 4 == 0 && B0 % 4 == 0, "16-byte copies");
+    static_assert(AN % 4 == 0 && BN % 4 == 0 && A0 % 4 == 0 && B0 % 4 == 0 && FLds::E1 % 4 == 0 && FLds::E2 % 4 == 0 && FLds::CAT % 4 == 0, "16-byte copies");
 };
 
 // Read-only view of the packed weights through ONE buffer resource with 32-bit indices.  With plain pointers every far constant
@@ -589,9 +589,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(P
         dump(4, [&](int r, int c) { return x[c * 16 + r]; });
         }
         if constexpr (PART == 1) {
+            // what the later kernels read, at its LDS offsets: the compressed spectrum and enc_out[0] (tail), enc_out[1] and the sub-band half of
+            // cat (middle kernel; the tail's sub-band decoder reads that half too) - 12.7 KB per stream (the whole region: 20.8 KB)
             f32x4* cr = reinterpret_cast<f32x4*>(a.carry + (size_t)b * FCarry::FLOATS);
             for (int i = tid; i < FCarry::AN / 4; i += kThreads) cr[i] = reinterpret_cast<const f32x4*>(smem + FCarry::A0)[i];
-            for (int i = tid; i < FCarry::BN / 4; i += kThreads) cr[FCarry::AN / 4 + i] = reinterpret_cast<const f32x4*>(smem + FCarry::B0)[i];
+            for (int i = tid; i < (L::E2 - L::E0) / 4; i += kThreads) cr[FCarry::AN / 4 + i] = reinterpret_cast<const f32x4*>(smem + FCarry::B0)[i];
+            for (int i = tid; i < 256; i += kThreads) {
+                const int o = (L::CAT - L::E0) / 4 + (i >> 3) * 16 + 8 + (i & 7);
+                cr[FCarry::AN / 4 + o] = reinterpret_cast<const f32x4*>(smem + FCarry::B0)[o];
+            }
             __syncthreads();
             continue;
         }
@@ -601,8 +607,13 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(P
             // feature_split output, sub-band half -> s2[ch][32 ..]; fullband_decoder.1's output -> d1 [4][128]
             for (int i = tid; i < 256; i += kThreads) reinterpret_cast<f32x4*>(smem + L::S2 + (i >> 3) * 64 + 32)[i & 7] = tk[i];
             for (int i = tid; i < 128; i += kThreads) reinterpret_cast<f32x4*>(smem + L::D1)[i] = tk[256 + i];
+            // of the front's regions the tail reads the compressed spectrum, enc_out[0] and the sub-band half of cat
             for (int i = tid; i < FCarry::AN / 4; i += kThreads) reinterpret_cast<f32x4*>(smem + FCarry::A0)[i] = cr[i];
-            for (int i = tid; i < FCarry::BN / 4; i += kThreads) reinterpret_cast<f32x4*>(smem + FCarry::B0)[i] = cr[FCarry::AN / 4 + i];
+            for (int i = tid; i < (L::E1 - L::E0) / 4; i += kThreads) reinterpret_cast<f32x4*>(smem + FCarry::B0)[i] = cr[FCarry::AN / 4 + i];
+            for (int i = tid; i < 256; i += kThreads) {
+                const int o = (L::CAT - L::E0) / 4 + (i >> 3) * 16 + 8 + (i & 7);
+                reinterpret_cast<f32x4*>(smem + FCarry::B0)[o] = cr[FCarry::AN / 4 + o];
+            }
             __syncthreads();
         }
 
