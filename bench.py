@@ -715,7 +715,7 @@ def main():
                                     if offline and args.offline_engine != "frame_walk" and not (w.get("bsrnn") or w.get("fspen") or w.get("lisennet") or w.get("kt") or w.get("frnn") or w.get("dpt") or w.get("ln")) else
                                     "lisennet_frame_kernel" if w.get("lisennet") else ("fspen_frame_kernel<PART 1> + fspen_sb_dpe_kernel (16 streams per workgroup) + fspen_frame_kernel<PART 2> (kernel_ms: the step's three launches)"
                                      if args.frames_per_step == 1 and 0 < int(os.environ.get("FE_FSPEN_SB", "1536")) <= B else "fspen_frame_kernel") if w.get("fspen") else ("bsrnn_frame_kernel<PART 3> + bsrnn_sb_layers_kernel (16 streams per workgroup) + bsrnn_mlp_kernel + bsrnn_frame_kernel<PART 2> (kernel_ms: the step's four launches)"
-                                     if w.get("bsrnn") and args.frames_per_step == 1 and w.get("C") == 16 and 0 < int(os.environ.get("FE_BSRNN_SB", "2560")) <= B else
+                                     if w.get("bsrnn") and args.frames_per_step == 1 and w.get("C") == 16 and 0 < int(os.environ.get("FE_BSRNN_SB", "2048")) <= B else
                                      "bsrnn_frame_kernel<PART 1> + bsrnn_mlp_kernel + bsrnn_frame_kernel<PART 2> (kernel_ms: the step's three launches)" if w.get("bsrnn") and args.frames_per_step == 1 else "bsrnn_frame_kernel" if w.get("bsrnn") else
                                     ("fe_frame8_kernel (512-thread per-hop kernel, fe_frame8.hip.h)" if args.workload == "fe_b" and not offline and T == 1 and B <= torch.cuda.get_device_properties(dev).multi_processor_count
                                      and os.environ.get("FE_WG8", "1") != "0" else "fe_frame_kernel"))), "kernel_ms": kernel_ms,

@@ -1510,7 +1510,7 @@ int launch_bsrnn(fe_handle* h, const fe::BArgs& a_in, void* stream) {
             a.sb_y = a.mlp_pre + (size_t)a.B * 2 * 1028;
             // large batches: the LSTM layers batched over the streams on the matrix cores (sixteen streams per workgroup) - from the batch
             // size where sixteen-stream workgroups fill the chip better than one stream per workgroup (FE_BSRNN_SB: that threshold; 0 = never)
-            static const int sb_min = [] { const char* v = getenv("FE_BSRNN_SB"); return v ? atoi(v) : 2560; }();      // (measured crossover on 256 CUs: 0.55 ms per step up to 4096 streams against 0.22 us per stream)
+            static const int sb_min = [] { const char* v = getenv("FE_BSRNN_SB"); return v ? atoi(v) : 2048; }();      // (measured crossover on 256 CUs: ~1900 streams, profiles/r4c_bsrnn_stream_batched.txt)
             if (h->bimpl->launch_sb && sb_min > 0 && a.B >= sb_min) h->bimpl->launch_sb(a, h->sboff, h->packed_floats, h->max_wgs, (hipStream_t)stream, &e);
             else
             h->bimpl->launch_split(a, h->max_wgs, (hipStream_t)stream, &e);
