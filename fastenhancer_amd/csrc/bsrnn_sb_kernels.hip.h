@@ -315,11 +315,13 @@ template <class S>
 void sb_launch_layers(const SbArgs& a, hipStream_t st, hipError_t* err) {
     if constexpr (SbLds<S>::FITS) {
         auto* fn = &bsrnn_sb_layers_kernel<S>;
-        static bool attr_set = false;
-        if (!attr_set) {      // (more than 64 KB of dynamic LDS)
+        static std::atomic<bool> attr_set[64];      // (more than 64 KB of dynamic LDS; per device: a process may drive several)
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!attr_set[dev].load(std::memory_order_relaxed)) {
             *err = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SbLds<S>::BYTES);
             if (*err != hipSuccess) return;
-            attr_set = true;
+            attr_set[dev].store(true, std::memory_order_relaxed);
         }
         hipLaunchKernelGGL(fn, dim3((a.B + kSbStreams - 1) / kSbStreams), dim3(kSbThreads), SbLds<S>::BYTES, st, a);
         *err = hipGetLastError();

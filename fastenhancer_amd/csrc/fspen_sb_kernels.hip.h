@@ -28,6 +28,7 @@
 // LDS: 136 KB: one workgroup per CU, 4096 streams fill the chip.
 // (included by fspen_kernels.hip.h, after FShape / FPk / FLds / FCarry)
 #pragma once
+#include <atomic>
 
 namespace fe {
 
@@ -647,11 +648,13 @@ __global__ void __launch_bounds__(kFsbThreads) __attribute__((amdgpu_waves_per_e
 
 template <class S>
 hipError_t fspen_sb_launch(const FSbArgs& a, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<bool> attr_set[64];          // (per device: a process may drive several)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev].load(std::memory_order_relaxed)) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fspen_sb_dpe_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FSbLds::BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev].store(true, std::memory_order_relaxed);
     }
     const int grid = (a.B + kFsbStreams - 1) / kFsbStreams;
     hipLaunchKernelGGL(fspen_sb_dpe_kernel<S>, dim3(grid), dim3(kFsbThreads), FSbLds::BYTES, st, a);
