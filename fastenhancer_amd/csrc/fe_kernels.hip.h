@@ -1417,6 +1417,30 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
 
     int ring_head0 = 0;                              // dptransformer: slot of the oldest cached frame when this launch starts
     if constexpr (S::TATT && !PIPE) ring_head0 = (int)a.h[(size_t)a.B * S::KB * S::HSTATE + b];
+    // dptransformer, per-hop launch with one stream per workgroup (r4): the K / V window of a block - 31 cached frames x [F2][C2] x 2,
+    // 214 KB per stream and block for B, the whole HBM traffic of this HBM-bound step - is fetched into REGISTERS (4 HD floats per lane
+    // and round of sixteen (sub-band, head) pairs: 216 of the 342 the lone wave per SIMD has left) in pieces issued at the END of the
+    // phases that precede its use: block 0's under STFT / encoder / rf_pre, block k + 1's under block k's fc / qkv / attention phases,
+    // piece by piece so that a phase's own weight fetches (older in the in-order vmcnt queue) never wait for more than one piece.
+    // The time attention itself then runs from registers; what stays exposed is the part of the stream that does not fit under the
+    // compute in between (kvw_issue / FE_KVW below, phase B of the blocks).
+#ifndef FE_KVW_PREFETCH
+#define FE_KVW_PREFETCH 1
+#endif
+    constexpr int W_PAIRS = F2 * S::NH;
+    constexpr bool WPF = FE_KVW_PREFETCH && S::TATT && !PIPE && !DBG && T1 && !PERSIST && W_PAIRS % 16 == 0 && (W_PAIRS / 16) * 4 * HD <= 224;
+    constexpr int W_NIT = WPF ? W_PAIRS / 16 : 1;
+#ifndef FE_KVW_NB
+#define FE_KVW_NB 2
+#endif
+#ifndef FE_KVW_FRONT
+#define FE_KVW_FRONT 0
+#endif
+    constexpr int W_NB = FE_KVW_NB;                  // pieces of the next block's window issued inside phase B itself
+    // front schedule of block 0's window: piece issued after {frame load, DFT, compress, enc_pre}, the encoder layers take the next NL
+    constexpr int W_F0 = 0, W_F1 = FE_KVW_FRONT == 0 ? 1 : -1, W_F2 = FE_KVW_FRONT == 0 ? 2 : 1, W_F3 = FE_KVW_FRONT == 0 ? 3 : 2;
+    constexpr int W_FE = W_F3 + 1;
+    float kvw[W_NIT][WPF ? 4 * HD : 1];
 #pragma unroll 1
     for (int t = t_first; t < a.T; t += t_step, ++fc) {
         // A loop-variant zero keeps the (many) wave-uniform offsets of a frame from being hoisted out of the frame
@@ -1442,6 +1466,45 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
         const int tid = tid0 + lzv;
         const int lane = lane0 + lzv;
         const int li = lane & 15, lg = lane >> 4;
+        // (WPF) this lane's two window slots - positions l16 and l16 + 16 of the ring, oldest first - as float offsets into the
+        // [pair][LB][HD] cache of a block; kvw_issue(block, piece): k0 | k1 | v0 | v1 of the pairs 16 piece + (tid >> 4)
+        int w_off0 = 0, w_off1 = 0;
+        if constexpr (WPF) {
+            const int head = (ring_head0 + t) % S::LB;
+            const int l16 = tid & 15, j1 = l16 + 16;
+            int sl0 = head + l16, sl1 = head + (j1 < S::LB ? j1 : S::LB - 1);
+            sl0 = sl0 >= S::LB ? sl0 - S::LB : sl0;
+            sl1 = sl1 >= S::LB ? sl1 - S::LB : sl1;
+            w_off0 = ((tid >> 4) * S::LB + sl0) * HD;
+            w_off1 = ((tid >> 4) * S::LB + sl1) * HD;
+        }
+        auto kvw_issue = [&](int kblk, auto it_) {
+            constexpr int it = decltype(it_)::value;
+            if constexpr (WPF && it < W_NIT) {
+                if (kblk < S::KB) {
+                    const size_t cstride = (size_t)F2 * C2 * S::LB;
+                    const float* kc = a.h + ((size_t)(2 * kblk) * a.B + b) * cstride + (size_t)(16 * it) * (S::LB * HD);
+                    const float* vc = kc + (size_t)a.B * cstride;
+                    // (plain loads: the rings of 256 streams - 164 MB for B - live in the 256 MiB Infinity Cache from launch to launch; non-temporal
+                    //  loads measured 52.5 -> 76.6 us, profiles/r4u_*)
+#pragma unroll
+                    for (int d = 0; d < HD; ++d) kvw[it][d] = kc[w_off0 + d];
+#pragma unroll
+                    for (int d = 0; d < HD; ++d) kvw[it][HD + d] = kc[w_off1 + d];
+#pragma unroll
+                    for (int d = 0; d < HD; ++d) kvw[it][2 * HD + d] = vc[w_off0 + d];
+#pragma unroll
+                    for (int d = 0; d < HD; ++d) kvw[it][3 * HD + d] = vc[w_off1 + d];
+                }
+            }
+        };
+#define FE_KVW(KBLK, IT) kvw_issue((KBLK), std::integral_constant<int, (IT)>{})
+        // pieces FROM .. W_NIT - 1 (the last issue point before a window is used takes whatever is left)
+        auto kvw_issue_rest = [&](int kblk, auto from_) {
+            static_for<W_NIT>([&](auto c_) {
+                if constexpr (decltype(c_)::value >= decltype(from_)::value) kvw_issue(kblk, c_);
+            });
+        };
         // begin_unit(U): called right after the barrier that precedes the GEMM phase of staged unit U:
         // selects the LDS copy of this phase's weights and sets up the DMA job of the next unit.
         const int fpar = (S::NU & 1) ? (((PERSIST || PIPE) ? fc : t) & 1) : 0;
@@ -1517,6 +1580,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 }
             }
             __syncthreads();
+            FE_KVW(0, W_F0);
             if (mode == FE_MODE_STREAM) {
                 for (int m = tid; m < OVL; m += kThreads) cst[m] = MDFT ? q1[m + H] : fb[m + H].x;   // cache' = frame[H:]
                 if constexpr (!MDFT) __syncthreads();       // (the FFT's first stage overwrites fb)
@@ -1533,6 +1597,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 Xi = &X[0].y;
             }
             FE_CLK(2);
+            if constexpr (W_F1 >= 0) FE_KVW(0, W_F1);
             // spectrum bins 0..F0 (F0 = Nyquist, dropped by the model)
             if (a.dbg) {
                 float* dst = a.dbg + (size_t)b * a.dbg_stride + DebugLayout<S>::offset(0);
@@ -1548,6 +1613,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
             }
         } else {
             const float* sp = a.spec_in + (size_t)b * (F0 + 1) * a.T * 2;
+            FE_KVW(0, W_F0);
+            if constexpr (W_F1 >= 0) FE_KVW(0, W_F1);
             for (int f = tid; f < F0; f += kThreads) {
                 float re = sp[((size_t)f * a.T + t) * 2], im = sp[((size_t)f * a.T + t) * 2 + 1];
                 float mag = fmaxf(sqrtf(re * re + im * im), 1.0e-5f);
@@ -1556,6 +1623,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 sc[S::LDS_S + 2 + f] = im * g;
             }
         }
+        FE_KVW(0, W_F2);
         __syncthreads();
         if (a.dbg) {
             float* dst = a.dbg + (size_t)b * a.dbg_stride + DebugLayout<S>::offset(1);
@@ -1587,6 +1655,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
             }
             conv_store<S, S::NTC, C1, LDC, !S::LN>(acc, encbuf(0), 1, wave, lane, SG ? skipg : nullptr);
         }
+        FE_KVW(0, W_F3);
         __syncthreads();
         if constexpr (S::LN) { FE_LN_SITE(F1, C1, LDC, true, encbuf(0) + LDC, 0); __syncthreads(); }
         dbg_dump<S>(a, b, 2, encbuf(0) + LDC, LDC);
@@ -1709,6 +1778,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
             }
             __builtin_amdgcn_sched_barrier(0);
             if (l == 0) FE_CLK(42);
+            FE_KVW(0, W_FE + l);
             __syncthreads();
             if constexpr (S::LN) { FE_LN_SITE(F1, C1, LDC, true, out + LDC, 1 + l); __syncthreads(); }
             if (l == 0) FE_CLK(43);
@@ -1785,6 +1855,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     }
                 }
         }
+        kvw_issue_rest(0, std::integral_constant<int, W_FE + S::NL>{});
         __syncthreads();
         {
             // X[f2][c2] = Y1[f2][:] . Wc[c2][:] + b
@@ -1979,6 +2050,65 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                             if (HD > 16 && l16 + 16 < HD) Hl[f * LDX + hh * HD + l16 + 16] = od2 * inv;
                         }
                     }
+                    } else if constexpr (WPF) {
+                    // per-hop launch: the window is in registers (kvw, fetched piece by piece since the previous use - see the top of the
+                    // kernel); the same arithmetic per pair as the branch below.  After round `it` the registers of piece `it` are free:
+                    // the first W_NB pieces of the NEXT block's window are requested right here, the others at the end of the block's
+                    // later phases.
+                    constexpr int LBK = S::LB;
+                    const size_t cstride = (size_t)F2 * C2 * LBK;
+                    float* kc = a.h + ((size_t)(2 * k) * a.B + b) * cstride;
+                    float* vc = a.h + ((size_t)(2 * k + 1) * a.B + b) * cstride;
+                    const int grp = tid >> 4, l16 = tid & 15;
+                    const int mask_lo = (a.mode == FE_MODE_OFFLINE) ? (LBK - t > 0 ? LBK - t : 0) : 0;
+                    const float sc = __builtin_amdgcn_rsqf((float)HD);
+                    const int head = (ring_head0 + t) % LBK;
+                    const int j1 = l16 + 16;
+                    static_assert(S::NH == 4, "head of a pair = its index mod 4");
+                    const float tpe0 = wb.gather_g(o.tpe + (grp & 3) * 32 + l16), tpe1 = wb.gather_g(o.tpe + (grp & 3) * 32 + j1);
+                    static_for<W_NIT>([&](auto it_) {
+                        constexpr int it = decltype(it_)::value;
+                        const int p = grp + 16 * it;
+                        const int f = p / S::NH, hh = p - f * S::NH;
+                        const float* qk = Gi + f * LDG + hh * 3 * HD;
+                        float* kp = kc + (size_t)p * (LBK * HD);
+                        float* vp = vc + (size_t)p * (LBK * HD);
+                        float k0[HD], k1[HD], v0[HD], v1[HD];
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) { k0[d] = kvw[it][d]; k1[d] = kvw[it][HD + d]; v0[d] = kvw[it][2 * HD + d]; v1[d] = kvw[it][3 * HD + d]; }
+                        // (opaque copies: with the conditional overwrite below the optimiser would otherwise select between the ADDRESSES -
+                        //  LDS or the register array - and load once, which pins the whole array in scratch memory)
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) { asm("" : "+v"(k1[d])); asm("" : "+v"(v1[d])); }
+                        if (j1 == LBK) {
+#pragma unroll
+                            for (int d = 0; d < HD; ++d) { k1[d] = qk[HD + d]; v1[d] = qk[2 * HD + d]; }
+                        }
+                        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) { const float qd = qk[d]; s0 = fmaf(qd, k0[d], s0); s1 = fmaf(qd, k1[d], s1); }
+                        const float ninf = -__builtin_inff();
+                        s0 = (l16 < mask_lo || k0[0] == __builtin_inff()) ? ninf : fmaf(sc, s0, tpe0);
+                        s1 = (j1 < mask_lo || (j1 < LBK && k1[0] == __builtin_inff())) ? ninf : fmaf(sc, s1, tpe1);
+                        const float mx = row16_allreduce(fmaxf(s0, s1), [](float x, float y) { return fmaxf(x, y); });
+                        const float e0 = __expf(s0 - mx), e1 = __expf(s1 - mx);
+                        const float inv = __builtin_amdgcn_rcpf(row16_allreduce(e0 + e1, [](float x, float y) { return x + y; }));
+                        float od = 0.0f;
+                        float od2 = 0.0f;
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) {
+                            const float sum = row16_allreduce(e0 * v0[d] + e1 * v1[d], [](float x, float y) { return x + y; });
+                            if (d < 16) od = (l16 == d) ? sum : od; else od2 = (l16 == d - 16) ? sum : od2;
+                        }
+                        if (l16 < HD) Hl[f * LDX + hh * HD + l16] = od * inv;
+                        if (HD > 16 && l16 + 16 < HD) Hl[f * LDX + hh * HD + l16 + 16] = od2 * inv;
+                        if (j1 == LBK) {                                  // the lane that holds the frame's k / v: over the oldest slot
+#pragma unroll
+                            for (int d = 0; d < HD; ++d) { kp[head * HD + d] = k1[d]; vp[head * HD + d] = v1[d]; }
+                        }
+                        if constexpr (it < W_NB) kvw_issue(k + 1, it_);
+                    });
+                    if (k == S::KB - 1 && tid == 0) a.h[(size_t)a.B * S::KB * S::HSTATE + b] = (float)((head + 1) % LBK);
                     } else {
                     constexpr int LBK = S::LB, PAIRS = F2 * S::NH;
                     const size_t cstride = (size_t)F2 * C2 * LBK;                    // one cache tensor of one stream: [F2][NH][L][HD]
@@ -2324,6 +2454,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     }
                 }
             }
+            FE_KVW(k + 1, W_NB);
             __syncthreads();
             if constexpr (S::LN) {
                 ln_pass<F2, C2, LDG, false, true>(Gi, lnred, wp + lz + o.ln_g[2 + S::NL + 2 * k], wp + lz + o.ln_b[2 + S::NL + 2 * k], a.rf_eps, Xb, LDX,
@@ -2363,6 +2494,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 if (k == 0) FE_CLK(52);
                 }
             }
+            FE_KVW(k + 1, W_NB + 1);
             if constexpr (S::FRNN) {
                 // dprnn variant (models/fastenhancer/dprnn/model.py:239-241): bidirectional GRU over the F2 sub-bands, zero initial
                 // state.  Gi holds the input pre-activations [f][direction][r|z|n][unit] (+ b_ih, + b_hh for r, z); wave = direction,
@@ -2464,6 +2596,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     if (hh + 1 < S::NH) __syncthreads();           // (the next head overwrites Gi)
                 }
             }
+            FE_KVW(k + 1, W_NB + 2);
             __syncthreads();
             if (k == 0) FE_CLK(25);
             {
@@ -2515,6 +2648,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     }
                 }
             }
+            kvw_issue_rest(k + 1, std::integral_constant<int, W_NB + 3>{});
             __syncthreads();
             if constexpr (S::LN) {
                 ln_pass<F2, C2, LDG, false, true>(Gi, lnred, wp + lz + o.ln_g[3 + S::NL + 2 * k], wp + lz + o.ln_b[3 + S::NL + 2 * k], a.rf_eps, Xb, LDX);

@@ -9,7 +9,7 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
-from common import MODEL_KWARGS  # noqa: E402
+from common import MODEL_KWARGS, product_config  # noqa: E402
 from fastenhancer_amd.config import FEConfig  # noqa: E402
 from fastenhancer_amd.engine import Engine  # noqa: E402
 from fastenhancer_amd.weights import default_state_dict  # noqa: E402
@@ -24,7 +24,7 @@ def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "fe_b"
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     dev = torch.device("cuda:0")
-    cfg = FEConfig.from_model_kwargs(**MODEL_KWARGS[name][0])
+    cfg = product_config(name)     # (the variants' yamls have their own keys)
     eng = Engine(cfg, dev)
     eng.load_state_dict(default_state_dict(cfg, torch.Generator().manual_seed(1)))
     H = cfg.hop_size
