@@ -125,6 +125,8 @@ struct fe_handle {
     hipStream_t host_streams[2] = {nullptr, nullptr};     // fe_step_host: copy-in / copy-out streams (lazy)
     hipEvent_t host_events[7] = {};                       // ... and its events
     float* tb_work_dev = nullptr;             // fe_spec_step on the time-batched engine: grow-only work buffer
+    float* spec_ring_dev = nullptr;           // fe_spec_step, dptransformer, time-pipelined: the K / V rings of TA + P slots per pair (grow-only)
+    size_t spec_ring_floats = 0;
     float* bsplit_dev = nullptr;              // BSRNN per-hop step in three launches: band features | compressed spectrum | MLP pre-activations
     int bsplit_streams = 0;                   // (grow-only, sized by fe_state_init / the first step of a larger batch)
     size_t tb_work_floats = 0;
@@ -1566,6 +1568,39 @@ fe::FrameArgs base_args(fe_handle* h, int B, int T) {
 
 static int ensure_tables(fe_handle* h, hipStream_t st);
 
+// fe_spec_step on the time pipeline for the variants whose frames exchange more than the GRU state (r4v).  dptransformer: the caller's K / V
+// caches - per (cache, stream, pair) a ring of L slots whose oldest frame sits in slot `head` of the stream - are laid out as the pipeline's
+// rings of RS = L + P slots (ring index j = window position j, oldest first; frame t of the chunk lives at index L + t), and after the
+// launch the chunk's last L frames (ring indices T .. T + L - 1) go back to the caller's caches in the reference's order (head = 0): what
+// ONNXModel.forward returns (dptransformer/model.py:231-232).  time_kernel: the same for the causal convs' input caches (L = KT - 1 slots of
+// [F1][C1] per (conv, stream), no head; time_kernel/model.py:119-148).
+// caches [ROWS][L][SZ], rings [ROWS][RS][SZ], ROWS = caches x streams x PAIRS; heads [B] (floats) or nullptr; one thread per float.
+__global__ void ring_in_kernel(const float* __restrict__ cache, const float* __restrict__ heads, float* __restrict__ ring, size_t n, int B, int PAIRS,
+                               int SZ, int L, int RS) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int dd = (int)(i % SZ);
+    const int j = (int)((i / SZ) % L);                // window position, oldest first
+    const size_t row = i / ((size_t)SZ * L);
+    int slot = j;
+    if (heads != nullptr) {
+        slot += (int)heads[(row / PAIRS) % B];
+        slot = slot >= L ? slot - L : slot;
+    }
+    ring[(row * RS + j) * SZ + dd] = cache[(row * L + slot) * SZ + dd];
+}
+
+__global__ void ring_out_kernel(const float* __restrict__ ring, float* __restrict__ cache, float* __restrict__ heads, size_t n, int B, int SZ, int L, int RS,
+                                int T) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (heads != nullptr && i < (size_t)B) heads[i] = 0.0f;
+    if (i >= n) return;
+    const int dd = (int)(i % SZ);
+    const int j = (int)((i / SZ) % L);
+    const size_t row = i / ((size_t)SZ * L);
+    cache[(row * L + j) * SZ + dd] = ring[(row * RS + (size_t)((T + j) % RS)) * SZ + dd];
+}
+
 extern "C" {
 
 const char* fe_last_error(void) { return g_err.c_str(); }
@@ -1653,6 +1688,7 @@ void fe_destroy(fe_handle* h) {
     if (h->tb_probe_dev) (void)hipFree(h->tb_probe_dev);
     if (h->tb_prog_dev) (void)hipFree(h->tb_prog_dev);
     if (h->tb_work_dev) (void)hipFree(h->tb_work_dev);
+    if (h->spec_ring_dev) (void)hipFree(h->spec_ring_dev);
     if (h->bsplit_dev) (void)hipFree(h->bsplit_dev);
     for (hipStream_t s : h->host_streams) if (s) (void)hipStreamDestroy(s);
     for (hipEvent_t e : h->host_events) if (e) (void)hipEventDestroy(e);
@@ -1862,12 +1898,12 @@ int fe_profile_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, flo
 constexpr int kMaxPipeFrames = 64;      // frames in flight per stream the work-buffer rings are sized for
 
 // workgroups per stream of a time-pipelined launch (0: one workgroup walks the frames of a stream)
-static int pipe_width(const fe_handle* h, int B, int T, bool offline = false) {
+static int pipe_width(const fe_handle* h, int B, int T, bool offline = false, bool spec_rings = false) {
     if (!h->impl || h->pipe_frames == 0 || h->pipe_frames == 1 || T < 4 || 2 * B > h->max_wgs) return 0;
-    // (time_kernel variant: its convs' inputs are handed from frame to frame through rings in the work buffer - fe_offline only; a
-    //  spec -> spec step with caches walks)
-    if (h->d.KT > 1 && !offline) return 0;
-    if (h->d.TA && !offline) return 0;   // (dptransformer: per-frame K / V rings in the work buffer - fe_offline only)
+    // (time_kernel variant: its convs' inputs are handed from frame to frame through rings - in fe_offline's work buffer, or (r4v) the handle's
+    //  for a spec -> spec step with caches)
+    if (h->d.KT > 1 && !offline && !spec_rings) return 0;
+    if (h->d.TA && !offline && !spec_rings) return 0;   // (dptransformer: per-frame K / V rings - fe_offline's work buffer, or the handle's for fe_spec_step, r4v)
     // automatic width: a hand-off (counter round trip + state fetch + the h half of the GRU + gates + publish) takes
     // ~2.6 us whatever the model; a frame takes ~4 us per MFLOP/frame at the measured kernel efficiency: that many frames
     // are worth having in flight (measured optimum: T 8-12, B 16, 48 kHz B 24, L > 24), more only adds pollers
@@ -1903,7 +1939,7 @@ int fe_set_time_pipeline(fe_handle* h, int frames_in_flight) {
 
 static size_t tb_work_floats(const fe_handle* h, int B, int T, size_t* off);
 static int tb_run(fe_handle* h, fe::tb::TbArgs a0, float* work_dev, int B, int T, hipStream_t st);
-static int pipe_width(const fe_handle* h, int B, int T, bool offline);
+static int pipe_width(const fe_handle* h, int B, int T, bool offline, bool spec_rings);
 
 // spec -> spec chunks on the time-batched engine: when asked for (FE_OFFLINE_TIME_BATCHED), or - AUTO - for long chunks of batches that
 // the time pipeline cannot take (more than #CUs / 2 streams: each workgroup would walk its T frames alone) or that are simply large
@@ -1965,18 +2001,49 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
     a.tk = h_dev + (size_t)B * h->d.hstate();
     hipError_t e = hipSuccess;
     a.mode = fe::FE_MODE_SPEC;
-    if (const int P = pipe_width(h, B, T)) {
-        const size_t nflags = (size_t)h->max_wgs * h->d.KB;
+    if (const int P = pipe_width(h, B, T, false, true)) {
+        hipStream_t st = (hipStream_t)stream;
+        const size_t per = (size_t)h->d.KB + (h->d.KT > 1 ? 2 * h->d.NL : 0);      // counters per stream (fe_kernels.hip.h: NFLAG)
+        const size_t nflags = (size_t)h->max_wgs * per;
         if (!h->pipe_flags_dev) FE_HIP_CHECK(hipMalloc(&h->pipe_flags_dev, nflags * sizeof(unsigned int)));
-        FE_HIP_CHECK(hipMemsetAsync(h->pipe_flags_dev, 0, (size_t)B * h->d.KB * sizeof(unsigned int), (hipStream_t)stream));
+        FE_HIP_CHECK(hipMemsetAsync(h->pipe_flags_dev, 0, (size_t)B * per * sizeof(unsigned int), st));
         a.pipe_flags = h->pipe_flags_dev;
         a.pipe_p = P;
-        h->impl->launch_pipe(a, (hipStream_t)stream, &e);
+        // dptransformer / time_kernel (r4v): the frames of a chunk in flight exchange their k / v (their convs' inputs) through rings of
+        // L + P slots; the caller's caches go in before the launch and the chunk's last L frames come back after it (the handle keeps the
+        // rings: grow-only, a first / wider call allocates)
+        const Dims& d = h->d;
+        const bool rings = d.TA != 0 || d.KT > 1;
+        const int L = d.TA ? d.TA : d.KT - 1, RS = L + P;
+        const int PAIRS = d.TA ? d.F2 * 4 : 1, SZ = d.TA ? d.C2 / 4 : d.F1 * d.C1;
+        const size_t rows = (size_t)(d.TA ? 2 * d.KB : 2 * d.NL) * B * PAIRS, nfl = rows * L * SZ;
+        float* caches = d.TA ? h_dev : h_dev + (size_t)B * d.hstate();
+        float* heads = d.TA ? h_dev + (size_t)B * (d.hstate() - 1) : nullptr;     // (the ring heads sit behind the K / V caches: fe_kernels.hip.h, ring_head0)
+        const unsigned cgrid = (unsigned)((nfl + 255) / 256);
+        if (rings) {
+            const size_t need = rows * RS * SZ;
+            if (need > h->spec_ring_floats) {
+                if (h->spec_ring_dev) { FE_HIP_CHECK(hipFree(h->spec_ring_dev)); h->spec_ring_dev = nullptr; h->spec_ring_floats = 0; }
+                FE_HIP_CHECK(hipMalloc(&h->spec_ring_dev, need * sizeof(float)));
+                h->spec_ring_floats = need;
+            }
+            hipLaunchKernelGGL(ring_in_kernel, dim3(cgrid), dim3(256), 0, st, caches, heads, h->spec_ring_dev, nfl, B, PAIRS, SZ, L, RS);
+            if (d.TA) { a.h = h->spec_ring_dev; a.tatt_base = d.TA; }
+            else { a.tk = h->spec_ring_dev; a.tk_base = d.KT - 1; }
+        }
+        h->impl->launch_pipe(a, st, &e);
         if (e != hipSuccess) {     // the runtime refused co-residency (GPU shared with other work): walk the frames serially
             (void)hipGetLastError();
             a.pipe_p = 0;
             a.pipe_flags = nullptr;
-            h->impl->launch(a, h->max_wgs, (hipStream_t)stream, &e);
+            a.h = h_dev;
+            a.tk = h_dev + (size_t)B * d.hstate();
+            a.tatt_base = 0;
+            a.tk_base = 0;
+            h->impl->launch(a, h->max_wgs, st, &e);
+        } else if (rings) {
+            hipLaunchKernelGGL(ring_out_kernel, dim3(cgrid), dim3(256), 0, st, h->spec_ring_dev, caches, heads, nfl, B, SZ, L, RS, T);
+            e = hipGetLastError();
         }
     } else
     h->impl->launch(a, h->max_wgs, (hipStream_t)stream, &e);

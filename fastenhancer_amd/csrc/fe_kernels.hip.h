@@ -298,6 +298,11 @@ struct FrameArgs {
                               // j) has been published (zeroed before the launch)
     float* frames;            // offline: [B][T][N] windowed output frames (overlap-added by istft_ola_kernel afterwards)
     int pipe_p;
+    int tatt_base;            // dptransformer, time-pipelined launch: 0 = offline (frame t lives in ring slot t mod RS, frames before the utterance are
+                              // masked); LB = spec -> spec step with carried caches (r4v): ring indices 0 .. LB - 1 hold the caller's caches, oldest
+                              // first, frame t lives at index LB + t, and only slots marked +inf (a cache-less start) are masked
+    int tk_base;              // time_kernel variant, time-pipelined launch: 0 = offline (frames before the utterance read as zero); KT - 1 = spec -> spec
+                              // step with carried caches (r4v): ring indices 0 .. KT - 2 hold the caller's cache slots, frame t lives at index KT - 1 + t
     int step_kernel;          // host side only (fe_impl.h::launch_impl): FE_STEP_KERNEL_* of the handle (fe_set_step_kernel)
 };
 
@@ -1697,7 +1702,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
 #pragma unroll
                         for (int q = 0; q < CPT; ++q) {
                             const int e4 = tid + q * kThreads, slot = e4 / Q4, r = e4 - slot * Q4;
-                            const int fr = t - (KT - 1) + slot;                    // slot 0 = the oldest frame of the window
+                            const int fr = t + a.tk_base - (KT - 1) + slot;        // slot 0 = the oldest frame of the window (ring index)
                             const float* src = ringb + (size_t)((fr < 0 ? 0 : fr) % RS) * (F1 * C1) + 4 * r;
                             float4 v;
                             v.x = ld_state(src); v.y = ld_state(src + 1); v.z = ld_state(src + 2); v.w = ld_state(src + 3);
@@ -1731,7 +1736,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                         const float2 v0 = s2[0], v1 = s2[1];
                         constexpr float un = 1.0f / kSiluScale;
                         if constexpr (PIPE) {
-                            float* dst = ringb + (size_t)(t % RS) * (F1 * C1) + 4 * r;
+                            float* dst = ringb + (size_t)((t + a.tk_base) % RS) * (F1 * C1) + 4 * r;
                             st_state(dst, v0.x * un); st_state(dst + 1, v0.y * un); st_state(dst + 2, v1.x * un); st_state(dst + 3, v1.y * un);
                         } else
                         tkg[(KT - 2) * Q4 + r] = make_float4(v0.x * un, v0.y * un, v1.x * un, v1.y * un);
@@ -1980,8 +1985,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     const size_t cstride = (size_t)F2 * C2 * RS;
                     float* kc = a.h + ((size_t)(2 * k) * a.B + b) * cstride;
                     float* vc = a.h + ((size_t)(2 * k + 1) * a.B + b) * cstride;
+                    const int wbase = a.tatt_base;
                     {
-                        const int slot = t % RS;
+                        const int slot = (t + wbase) % RS;
                         for (int e = tid; e < PAIRS * HD; e += kThreads) {
                             const int p = e / HD, d = e - p * HD, f = p / S::NH, hh = p - f * S::NH;
                             const float* qk = Gi + f * LDG + hh * 3 * HD;
@@ -1993,11 +1999,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     pipe_wait(k, t);
                     pipe_publish(k, t);
                     const int grp = tid >> 4, l16 = tid & 15;
-                    const int mask_lo = LBK - t > 0 ? LBK - t : 0;
+                    const int mask_lo = wbase ? 0 : (LBK - t > 0 ? LBK - t : 0);
                     const float sc = __builtin_amdgcn_rsqf((float)HD);
                     const int j1 = l16 + 16;                                        // position 31 = the current frame
-                    const bool m0 = l16 < mask_lo, m1 = j1 < LBK && j1 < mask_lo;
-                    int fr0 = t - LBK + l16, fr1 = t - LBK + (j1 < LBK ? j1 : 0);
+                    const bool mf0 = l16 < mask_lo, mf1 = j1 < LBK && j1 < mask_lo;
+                    int fr0 = t + wbase - LBK + l16, fr1 = t + wbase - LBK + (j1 < LBK ? j1 : 0);
                     fr0 = fr0 < 0 ? 0 : fr0; fr1 = fr1 < 0 ? 0 : fr1;
                     const int sl0 = fr0 % RS, sl1 = fr1 % RS;
                     constexpr int NIT = ceil_div(PAIRS, 16);
@@ -2021,6 +2027,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                         for (int d = 0; d < HD; ++d) v0[d] = ld_state(vp + sl0 * HD + d);
 #pragma unroll
                         for (int d = 0; d < HD; ++d) v1[d] = ld_state(vp + sl1 * HD + d);
+                        // (carried caches: a slot whose first K element is +inf marks a frame before a cache-less start)
+                        const bool m0 = mf0 || (wbase != 0 && k0[0] == __builtin_inff());
+                        const bool m1 = mf1 || (wbase != 0 && j1 < LBK && k1[0] == __builtin_inff());
                         if (j1 == LBK) {
 #pragma unroll
                             for (int d = 0; d < HD; ++d) { k1[d] = qk[HD + d]; v1[d] = qk[2 * HD + d]; }

@@ -152,8 +152,11 @@ int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* sp
  * frames).  Negative (the default) = a width chosen from the model size (8 .. 64); 0 or 1 = off (one workgroup walks the
  * T frames of a stream); values above 64 are clamped to 64 (the per-frame rings in work_dev are sized for that).  Results agree to fp32 rounding.  BSRNN's fe_offline is pipelined the same way (the time-LSTM (h, c) of
  * each layer is the hand-off; up to 64 frames in flight), and so are the ln variant's, the time_kernel variant's and the
- * dptransformer variant's (the last two fe_offline only: the time convs' input frames / the K-V caches go through per-frame rings in
- * work_dev), FSPEN's (its inter-GRU states per DPE block) and LiSenNet's (its nine caches through a ring of per-frame slots). */
+ * dptransformer variant's (the time convs' input frames / the K-V caches go through per-frame rings: in work_dev for fe_offline;
+ * for fe_spec_step - ONNXModel.forward(spec, *caches) with T >> 1, time_kernel/model.py:746-806, dptransformer/model.py:194-236 - in a
+ * grow-only buffer of the handle, filled from the caller's caches before the launch and read back after it: a first or wider call
+ * allocates, so not inside a stream capture), FSPEN's (its inter-GRU states per DPE block) and LiSenNet's (its nine caches through
+ * a ring of per-frame slots). */
 int fe_set_time_pipeline(fe_handle* h, int frames_in_flight);
 
 /* Engine of fe_offline for the default and noncausal FastEnhancer models:

@@ -380,6 +380,116 @@ def test_dptransformer_cacheless_chunk_longer_than_the_lookbehind():
     _assert_close(y2.cpu().numpy(), y2_ref, "continuation with the returned caches")
 
 
+@pytest.mark.parametrize("name,B,T", [("fe_dpt_t", 2, 40), ("fe_dpt_b", 3, 70), ("fe_dpt_t", 5, 33)])
+def test_dptransformer_spec_chunks_run_on_the_time_pipeline(name, B, T):
+    """fe_spec_step with T >> 1 for the dptransformer variant (r4v): the frames of a chunk run on co-resident workgroups and hand their
+    k / v on through rings of lookbehind + P slots in the handle; the caller's caches go in before the launch (whatever their ring head)
+    and come back in the reference's order.  Checked: (1) a cache-less chunk, (2) a chunk WITH caches whose rings have a non-zero head
+    (left by per-hop launches), (3) a third chunk that continues from the returned caches - each against the oracle AND against the
+    serial walk of the same call (fe_set_time_pipeline(0)), outputs and caches."""
+    m, orc, cfg, sr, seed = _model(name)
+    eng = m.engine
+    H = cfg.hop_size
+    hops1 = 5                                   # per-hop launches first: the rings' heads advance to 5
+    n_frames = hops1 + 3 * T
+    x = make_input(B, n_frames * H, 4242, sr)
+    cache = orc.initialize_cache(B)[0]
+    specs = []
+    for t in range(n_frames):
+        s_, cache = orc.stft_step(x[:, t * H:(t + 1) * H], cache)
+        specs.append(s_)
+    spec = np.concatenate(specs, axis=2)
+    spec_d = torch.from_numpy(spec).to(_dev())
+
+    def run(width):
+        eng.set_time_pipeline(width)
+        outs = []
+        y, *h = m(spec_d[:, :, :T].contiguous())                       # (1) cache-less chunk
+        outs.append((y, h))
+        for t in range(T, T + hops1):                                   # per-hop launches: ring heads move
+            y, *h = m(spec_d[:, :, t:t + 1].contiguous(), *h)
+        y, *h = m(spec_d[:, :, T + hops1:2 * T + hops1].contiguous(), *h)            # (2) chunk with caches, head != 0
+        outs.append((y, h))
+        y, *h = m(spec_d[:, :, 2 * T + hops1:3 * T + hops1].contiguous(), *h)        # (3) continuation
+        outs.append((y, h))
+        eng.set_time_pipeline(-1)
+        return outs
+
+    piped, serial = run(-1), run(0)
+    # oracle
+    y_ref, h_ref = orc.spec_forward(spec[:, :, :T], None)
+    refs = [(y_ref, h_ref)]
+    for t in range(T, T + hops1):
+        _, h_ref = orc.spec_forward(spec[:, :, t:t + 1], h_ref)
+    y_ref, h_ref = orc.spec_forward(spec[:, :, T + hops1:2 * T + hops1], h_ref)
+    refs.append((y_ref, h_ref))
+    y_ref, h_ref = orc.spec_forward(spec[:, :, 2 * T + hops1:3 * T + hops1], h_ref)
+    refs.append((y_ref, h_ref))
+    for i, ((yp, hp), (ys, hs), (yr, hr)) in enumerate(zip(piped, serial, refs)):
+        _assert_close(yp.cpu().numpy(), yr, f"pipelined chunk {i} vs oracle")
+        _assert_close(ys.cpu().numpy(), yr, f"serial chunk {i} vs oracle")
+        scale = float(np.abs(yr).max())
+        assert float((yp - ys).abs().max()) <= 3e-5 * scale, f"pipelined vs serial chunk {i}"
+        if (i + 1) * T + (hops1 if i else 0) >= 31:      # (before 31 frames have been seen the slots not yet filled carry the +inf marks; the reference returns fewer slots)
+            for a_, b_, c_ in zip(hp, hs, hr):
+                _assert_close(a_.cpu().numpy(), c_, f"caches after pipelined chunk {i}")
+                _assert_close(b_.cpu().numpy(), c_, f"caches after serial chunk {i}")
+
+
+@pytest.mark.parametrize("B,T", [(1, 40), (3, 17)])
+def test_time_kernel_spec_chunks_run_on_the_time_pipeline(B, T):
+    """fe_spec_step with T >> 1 for the time_kernel variant (r4v): the frames of a chunk run on co-resident workgroups; every causal conv's
+    input goes from frame to frame through a ring of P + kt - 1 slots in the handle, filled from the caller's caches before the launch and
+    read back (the chunk's last kt - 1 frames) after it; the GRU states travel as in the default model.  Three chunks with per-hop launches
+    in between, against the oracle and against the serial walk of the same calls - outputs and all caches."""
+    m, orc, cfg, sr, seed = _model("fe_tk_b")
+    eng = m.engine
+    H = cfg.hop_size
+    hops1 = 3
+    n_frames = hops1 + 3 * T
+    x = make_input(B, n_frames * H, 777, sr)
+    cache = orc.initialize_cache(B)[0]
+    specs = []
+    for t in range(n_frames):
+        s_, cache = orc.stft_step(x[:, t * H:(t + 1) * H], cache)
+        specs.append(s_)
+    spec = np.concatenate(specs, axis=2)
+    spec_d = torch.from_numpy(spec).to(_dev())
+    cuts = [(0, T), (T + hops1, 2 * T + hops1), (2 * T + hops1, 3 * T + hops1)]
+
+    def run(width):
+        eng.set_time_pipeline(width)
+        outs = []
+        y, *h = m(spec_d[:, :, :T].contiguous(), *m.initialize_cache(spec_d))
+        outs.append((y, h))
+        for t in range(T, T + hops1):
+            y, *h = m(spec_d[:, :, t:t + 1].contiguous(), *h)
+        for lo, hi in cuts[1:]:
+            y, *h = m(spec_d[:, :, lo:hi].contiguous(), *h)
+            outs.append((y, h))
+        eng.set_time_pipeline(-1)
+        return outs
+
+    piped, serial = run(-1), run(0)
+    h_ref = orc.initialize_cache(B)[2:]
+    refs = []
+    y_ref, h_ref = orc.spec_forward(spec[:, :, :T], h_ref)
+    refs.append((y_ref, h_ref))
+    for t in range(T, T + hops1):
+        _, h_ref = orc.spec_forward(spec[:, :, t:t + 1], h_ref)
+    for lo, hi in cuts[1:]:
+        y_ref, h_ref = orc.spec_forward(spec[:, :, lo:hi], h_ref)
+        refs.append((y_ref, h_ref))
+    for i, ((yp, hp), (ys, hs), (yr, hr)) in enumerate(zip(piped, serial, refs)):
+        _assert_close(yp.cpu().numpy(), yr, f"pipelined chunk {i} vs oracle")
+        _assert_close(ys.cpu().numpy(), yr, f"serial chunk {i} vs oracle")
+        scale = float(np.abs(yr).max())
+        assert float((yp - ys).abs().max()) <= 3e-5 * scale, f"pipelined vs serial chunk {i}"
+        for a_, b_, c_ in zip(hp, hs, hr):
+            _assert_close(a_.cpu().numpy(), c_, f"caches after pipelined chunk {i}")
+            _assert_close(b_.cpu().numpy(), c_, f"caches after serial chunk {i}")
+
+
 @pytest.mark.parametrize("name,B,hops", [("fe_ln_b", 300, 3), ("fe_dprnn_b", 256, 3), ("fe_dprnn_l", 300, 2), ("fe_dpt_b", 256, 35), ("fe_dpt_t", 700, 4), ("fe_dpt_m", 260, 2)])
 def test_full_size_block_variants(name, B, hops):
     """the dprnn / dptransformer variants at full batch sizes (one workgroup per stream, and persistent workgroups above #CUs):
