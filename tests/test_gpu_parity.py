@@ -1597,6 +1597,37 @@ def test_baseline_models_long_run_has_no_state_drift(which):
         _assert_close(a_.cpu().numpy(), b_, f"{which} cache after 60 hops")
 
 
+@pytest.mark.parametrize("name,B,T", [("fe_dpt_b", 5, 97), ("fe_tk_b", 7, 61)])
+def test_pipelined_spec_chunks_with_ring_caches_are_bit_reproducible(name, B, T):
+    """the ring hand-over of fe_spec_step's pipelined chunks (r4v: K / V caches, conv input caches) under the same stress as the offline launches: ten
+    repetitions of one chunk from the same caches must reproduce the first bit for bit - outputs and returned caches - and agree with the
+    serial walk; the caches that go in have been through per-hop launches (non-zero ring heads)."""
+    m, orc, cfg, sr, seed = _model(name)
+    eng = m.engine
+    spec = torch.from_numpy(make_input(B * 257 * (T + 4) * 2, 1, 55, sr).reshape(B, 257, T + 4, 2).astype(np.float32) * 0.3).to(_dev())
+    h = m.initialize_cache(spec)
+    for t in range(4):
+        _, *h = m(spec[:, :, t:t + 1].contiguous(), *h)
+    h = [t.clone() for t in h]
+    chunk = spec[:, :, 4:].contiguous()
+    eng.set_time_pipeline(0)
+    y0, *h0 = m(chunk, *[t.clone() for t in h])
+    eng.set_time_pipeline(-1)
+    first = None
+    for rep in range(10):
+        y, *hn = m(chunk, *[t.clone() for t in h])
+        if first is None:
+            first = (y.clone(), [t.clone() for t in hn])
+            scale = float(y0.abs().max())
+            assert float((y - y0).abs().max()) <= 3e-5 * scale, "pipelined vs serial"
+            for a_, b_ in zip(hn, h0):
+                assert float((a_ - b_).abs().max()) <= 3e-5 * max(float(b_.abs().max()), 1e-3), "caches: pipelined vs serial"
+        else:
+            assert torch.equal(y, first[0]), f"repetition {rep} differs"
+            for a_, b_ in zip(hn, first[1]):
+                assert torch.equal(a_, b_), f"caches of repetition {rep} differ"
+
+
 @pytest.mark.parametrize("name,B", [("fe_b", 7), ("fe_tk_b", 3), ("fe_dpt_b", 1), ("fe_ln_b", 3), ("bsrnn_xt", 7), ("fspen", 7), ("lisennet", 3)])
 def test_time_pipeline_stress_is_bit_reproducible_and_equals_the_serial_walk(name, B):
     """A reduced tools/gpu_pipeline_stress.py in the suite, so that EVERY box the tests run on exercises the hand-rolled hand-off ordering
