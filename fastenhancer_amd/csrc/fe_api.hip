@@ -619,6 +619,32 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
             if (d.TA) regroup(o.blk_tqkv[k], szC3);
         }
     }
+    if (o.conv_k4_delta != 0) {
+        // Time-batched engine (r4w): a copy of the conv units whose weight tiles are regrouped four k-steps per lane for 16-byte fetches
+        // (tb_kernels.hip.h::conv_gemm; the biases and the filterbanks in the copy stay as they are).  Must run AFTER every conv weight is packed.
+        const int ubeg = o.u_off[0], uend = o.u_off[o.n_units - 1] + o.u_size[o.n_units - 1];
+        std::copy(p.buf.begin() + ubeg, p.buf.begin() + uend, p.buf.begin() + ubeg + o.conv_k4_delta);
+        std::vector<float> t;
+        auto regroup_c = [&](int off, int tiles, int KS) {
+            const int tile_floats = KS * 64, NF4 = KS / 4;
+            t.resize((size_t)tile_floats);
+            for (int tl = 0; tl < tiles; ++tl) {
+                float* dst = &p.buf[(size_t)off + o.conv_k4_delta + (size_t)tl * tile_floats];
+                std::copy(dst, dst + tile_floats, t.begin());
+                for (int ks = 0; ks < 4 * NF4; ++ks)
+                    for (int ln = 0; ln < 64; ++ln) dst[(ks / 4) * 256 + ln * 4 + (ks % 4)] = t[(size_t)ks * 64 + ln];
+            }
+        };
+        const int NTC = fe::ceil_div(C1, 16), KSC = C1 / 4, KS2 = C2 / 4;
+        regroup_c(o.enc_pre_w, NTC, 4);
+        for (int l = 0; l < d.NL; ++l) {
+            regroup_c(o.enc_w[l], NTC, 3 * KSC);
+            regroup_c(o.dec1_w[l], NTC, ((l == 0 && !d.LN) ? KS2 : KSC) + KSC);
+            regroup_c(o.dec3_w[l], NTC, 3 * KSC);
+        }
+        regroup_c(o.post1_w, NTC, 2 * KSC);
+        regroup_c(o.post_t_w, 1, KSC);
+    }
     *out = std::move(p.buf);
     return FE_OK;
 }

@@ -154,6 +154,7 @@ struct PackedOffsets {
     // dptransformer variant: the time attention's qkv weights per block, the model's positional bias [NH][32] (slot L = current frame)
     int blk_tqkv[8], tpe;
     int blk_end, k4_delta;      // end of the block-weight region; distance to its k4-regrouped copy (Shape::REGW, else 0)
+    int conv_k4_delta;          // time-batched engine (Shape::TB): distance from the conv units to their k4-regrouped copy (r4w), else 0
     // ln variant: rf_post's 1x1 conv as a staged unit (B fragments + bias), gain / bias of every norm site ([channel])
     int rfpost1_w, rfpost1_b, ln_g[48], ln_b[48];
     int rfpost_lin, rfpost_w, rfpost_b;
@@ -266,6 +267,15 @@ struct Pack {
                 o.u8_q[k] = cur; cur += S::U8_Q;
                 o.u8_f2[k] = cur; cur += S::U8_F;
             }
+        o.conv_k4_delta = 0;
+        if (S::TB) {     // (allocated after everything else: every other offset is the same with and without it)
+            // r4w: the time-batched engine's conv GEMMs stream their weight fragments from L2 - one wave-level load per (tile, k-step) kept the
+            // CU's vector-memory path as busy as its matrix pipes (539 loads for 930 MFMAs per tile of tb_dec<B>).  A copy of the conv units
+            // [u_off[0], end of the last unit) whose weight tiles are regrouped four k-steps per lane ([ks / 4][lane][4], the ks % 4 remainder
+            // plain; the host packer does the shuffle) lets conv_gemm fetch four fragments per 16-byte load.
+            const int ubeg = o.u_off[0], uend_ = o.u_off[o.n_units - 1] + o.u_size[o.n_units - 1];
+            o.conv_k4_delta = alloc(uend_ - ubeg) - ubeg;
+        }
         o.total = round_up(cur, 64);
         return o;
     }
