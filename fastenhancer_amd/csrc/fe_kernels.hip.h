@@ -1470,7 +1470,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
 #ifndef FE_LZ_BIG
 #define FE_LZ_BIG 1      // (0: r3's behaviour, for A/B builds)
 #endif
-        if constexpr (S::C1 <= 96 || (FE_LZ_BIG && (PERSIST || PIPE || !T1))) asm volatile("" : "+s"(lz));
+#ifndef FE_LZ_T1
+#define FE_LZ_T1 1      // r4w: the big shapes' per-hop instantiation too - it has no loop, but its offsets were all derived at kernel entry and
+#endif                  // parked in spilled SGPRs (FastEnhancer_L: 1022 SGPR spills -> 0; 256 streams 377 -> 364 us, 0.645 -> 0.669).  0: r4d's behaviour
+        if constexpr (S::C1 <= 96 || (FE_LZ_BIG && (PERSIST || PIPE || !T1 || FE_LZ_T1))) asm volatile("" : "+s"(lz));
         const int wave = wave0 + lz;
         // LOW = 2 companions (256 VGPRs, operands streamed from L2): the same for the per-lane offsets - hoisted out of the
         // stream loop they stay live through the whole frame and the persistent instantiation spills (S: 167 -> 92 VGPRs,
