@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(kThreads) tb_enc_kernel(TbArgs a) {
         // being hoisted out of the tile loop, where they sat in SGPRs for the whole kernel and spilled to VGPR lanes (tb_enc_kernel<L>:
         // 961 SGPR spills - v_writelane / v_readlane traffic on the datapath the fp32 MFMAs share with the vector ALUs)
         int lz = 0;
-        if constexpr (S::C1 > 96) asm volatile("" : "+s"(lz));
+        if constexpr (S::C1 >= 96) asm volatile("" : "+s"(lz));
         const int wave = wave_k + lz, wm = CT::NS == kWaves ? 0 : wave / CT::NS;
         const int g0 = tile * FT;
         const int nvalid = a.NF - g0 < FT ? a.NF - g0 : FT;
@@ -1195,8 +1195,14 @@ __device__ __forceinline__ void blk_body(const TbArgs& a, float* smem, const int
     }
     static_assert(!FUSED || REGW, "the fused stage is built on the register-resident block path");
     if constexpr (!FUSED) {
+    const int wave_outer = wave;
 #pragma unroll 1
     for (int tile = wgid; tile < ntiles; tile += nwg) {
+        // (streamed block weights - M, L, the noncausal model: the loop-variant zero of tb_enc / tb_dec keeps the tile's wave-uniform weight
+        //  offsets out of the loop pre-header - tb_blk_kernel<L>: 299 SGPR spills, <M>: 184)
+        int lz = 0;
+        asm volatile("" : "+s"(lz));
+        const int wave = wave_outer + lz;
         const int g0 = tile * FT;
         const int nvalid = a.NF - g0 < FT ? a.NF - g0 : FT;
         const int rows_valid = nvalid * F2;
@@ -1420,7 +1426,7 @@ __global__ void __launch_bounds__(kThreads) tb_dec_kernel(TbArgs a) {
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int lz = 0;                       // (big shapes: weight offsets not hoisted out of the tile loop - see tb_enc_kernel; tb_dec_kernel<L>: 1395 SGPR spills)
-        if constexpr (S::C1 > 96) asm volatile("" : "+s"(lz));
+        if constexpr (S::C1 >= 96) asm volatile("" : "+s"(lz));
         const int wave = wave_k + lz, wm = CT::NS == kWaves ? 0 : wave / CT::NS;
         const int g0 = tile * FT;
         const int nvalid = a.NF - g0 < FT ? a.NF - g0 : FT;
