@@ -139,6 +139,9 @@ struct Shape {
 // Offsets (floats) of the packed weights inside the handle's device buffer.  The layout is a pure
 // function of the shape, evaluated at compile time and shared by the host packer (fe_api.hip) and the
 // kernel, where every offset folds into an instruction immediate / one SGPR add.
+#ifndef FE_K4_STREAM
+#define FE_K4_STREAM 1      // r4x: shapes that stream their block weights from L2 inside the GEMMs (M, L, their 48 kHz / variant shapes) fetch four k-steps per 16-byte load too
+#endif
 struct PackedOffsets {
     int enc_pre_w, enc_pre_b;
     int enc_w[16], enc_b[8];            // enc_w / dec3_w: [layer * KT + tap], taps in consumption order (tap 0 = the current frame)
@@ -242,7 +245,7 @@ struct Pack {
         o.blk_stride = S::KB > 1 ? o.blk_wih[1] - o.blk_wih[0] : 0;
         o.gru_flat = S::GFLAT ? 1 : 0;
         o.k4_delta = 0;
-        if (S::REGW) {      // k4-regrouped copy of [blk_wih[0], blk_end) for the register-resident fetches (TokW)
+        if (S::REGW || FE_K4_STREAM) {      // k4-regrouped copy of [blk_wih[0], blk_end): the register-resident fetches (TokW) and, r4x, the STREAMED block weights of the big shapes
             const int n = o.blk_end - o.blk_wih[0];
             o.k4_delta = alloc(n) - o.blk_wih[0];
         }
@@ -1056,6 +1059,19 @@ __device__ __forceinline__ void conv_nsplit(AF&& af, const WS& w, int w_off, int
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[i][j] = bj;
     }
+    constexpr int CK4 = Pack<S>::v.conv_k4_delta;
+    if constexpr (FE_K4_STREAM && CK4 != 0 && KS >= 4 && !std::is_same_v<std::remove_cv_t<WS>, WSrc<true>>) {
+        // r4x: the streamed conv weights four k-steps per 16-byte load, from the k4-regrouped copy of the conv units (the one the time-batched
+        // engine reads; its KS % 4 left-over k-steps are plain)
+        f32x4 cur[NTW];
+        mma_panel<MT, NTW, KS, Lds<S>::PDK>(acc, [&](int i, int ks) { return af(m0 + i, ks); },
+                               [&](int j, int ks) {
+                                   const int base = w_off + CK4 + (wn * NTW + j) * (KS * 64);
+                                   if (ks >= 4 * (KS / 4)) return w.at_g(base + ks * 64);
+                                   if ((ks & 3) == 0) cur[j] = w.at_gv4(base + (ks >> 2) * 256, w.lane4 * 4);
+                                   return cur[j][ks & 3];
+                               }, side);
+    } else
     mma_panel<MT, NTW, KS, Lds<S>::PDK>(acc, [&](int i, int ks) { return af(m0 + i, ks); },
                            [&](int j, int ks) { return w.at(w_off + ((wn * NTW + j) * KS + ks) * 64); }, side);
     side.commit();
@@ -1155,9 +1171,17 @@ struct TokW {
         bind(s, w_off_, b_off_, NT_, wave_);
         fetch_part(0, 1);
     }
+    // streamed (REG = false): four k-steps of a tile per 16-byte load from the k4 copy - the GEMM pipelines ask for (j, ks) in rising ks per tile, the load
+    // rides on the first k-step of every group of four (r4x: a wave-level load costs the vector-memory path the same whatever its width, and the big
+    // shapes' block GEMMs issued one per two to four MFMAs)
+    mutable f32x4 cur[REG ? 1 : NTPW][REG ? 1 : NG];
     __device__ __forceinline__ float get(int j, int g, int ks) const {
         if constexpr (REG) return w[j][g][ks];
-        else return src->at_gv(w_off + (tile(j, g) * KS + ks) * 64, src->lane4 + oob(j));
+        else if constexpr (FE_K4_STREAM) {
+            if (ks >= 4 * (KS / 4)) return src->at_gv(w_off + src->k4d + (tile(j, g) * KS + ks) * 64, src->lane4 + oob(j));
+            if ((ks & 3) == 0) cur[j][g] = src->at_gv4(w_off + src->k4d + tile(j, g) * (KS * 64) + (ks >> 2) * 256, src->lane4 * 4 + oob(j));
+            return cur[j][g][ks & 3];
+        } else return src->at_gv(w_off + (tile(j, g) * KS + ks) * 64, src->lane4 + oob(j));
     }
     __device__ __forceinline__ float bias(int j, int g) const {
         if constexpr (REG) return bv[j][g];
@@ -2354,13 +2378,20 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                         }
                         // x half then h half in ONE software pipeline (k-steps KS_2 .. 2 KS_2 - 1 accumulate into ah)
                         constexpr int K2 = S::KS_2;
+                        f32x4 gcur[3];
                         mma_panel_sel<MG, 3, 2 * K2, Lds<S>::PDK>(
                             [&](int i, int g, int ks) -> f32x4& { return ks < K2 ? ax[i][g] : ah[i][g]; },
                             [&](int i, int ks) {
                                 return ks < K2 ? Xb[(16 * (m0 + i) + li) * LDX + lg + 4 * ks] : Hs[(16 * (m0 + i) + li) * LDX + lg + 4 * (ks - K2)];
                             },
                             [&](int g, int ks) {
-                                return ks < K2 ? wb.at_g(wih + ((g * S::NT2 + ct) * K2 + ks) * 64) : wb.at_g(whh + ((g * S::NT2 + ct) * K2 + ks - K2) * 64);
+                                const int k = ks < K2 ? ks : ks - K2;
+                                const int base = (ks < K2 ? wih : whh) + (g * S::NT2 + ct) * (K2 * 64);
+                                if constexpr (FE_K4_STREAM) {       // four k-steps per 16-byte load (the k4 copy; its K2 % 4 left-over k-steps are plain)
+                                    if (k >= 4 * (K2 / 4)) return wb.at_g(base + wb.k4d + k * 64);
+                                    if ((k & 3) == 0) gcur[g] = wb.at_gv4(base + wb.k4d + (k >> 2) * 256, wb.lane4 * 4);
+                                    return gcur[g][k & 3];
+                                } else return wb.at_g(base + k * 64);
                             }, NoSide{});
                         const int c = 16 * ct + li;
                         if (c < C2) {
