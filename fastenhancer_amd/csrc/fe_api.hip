@@ -1673,6 +1673,11 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
         if (impl && im->LOW >= 1 && im->occ >= 2 && im->C1 == impl->C1 && im->NL == impl->NL && im->C2 == impl->C2 && im->F2 == impl->F2 &&
             im->KB == impl->KB && im->NFFT == impl->NFFT && im->HOP == impl->HOP && im->KT == impl->KT && im->FR == impl->FR && im->TA == impl->TA && im->LN == impl->LN && !impl->BD)
             impl_many = im;
+    // a companion reads its shape's packed buffer: every offset it uses must be the same function of the shape (fe::Pack does not depend on LOW; r4x: the
+    // k4 copies sit behind the time-batched engine's and the 512-thread kernel's sections - checked here rather than trusted)
+    if (impl && impl_many && (impl_many->off->k4_delta != impl->off->k4_delta || impl_many->off->conv_k4_delta != impl->off->conv_k4_delta ||
+                              impl_many->off->window != impl->off->window || impl_many->off->blk_wih[0] != impl->off->blk_wih[0]))
+        impl_many = nullptr;
     if (!impl)
         return fail(FE_ERR_UNSUPPORTED_CONFIG,
                     "no kernel compiled for channels=%d layers=%d rf_channels=%d rf_freq=%d rf_blocks=%d n_fft=%d hop=%d kernel_size_time=%d%s "

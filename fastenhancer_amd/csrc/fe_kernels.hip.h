@@ -254,7 +254,8 @@ struct Pack {
             constexpr int N1 = S::NFFT / 32, KC = N1 / 2, MT = N1 / 16;
             o.dft1 = alloc(2 * 2 * 8 * 64); o.dft2 = alloc(2 * KC * 64); o.dft3 = alloc(2 * MT * KC * 64); o.dft4 = alloc(2 * 2 * 8 * 64);
         }
-        if (S::TB)
+        // (allocated for the low-LDS companions too - S::TB without its LOW term: a companion shares its shape's buffer and reads the conv k4 copy behind this)
+        if (S::KT == 1 && !S::FRNN && !S::TATT && !S::LN)
             for (int k = 0; k < S::KB; ++k) {
                 for (int d = 0; d < S::ND; ++d) {
                     o.tb_wih[k][d] = alloc(szB(C2, 3 * C2)); o.tb_bx[k][d] = alloc(szBias(3 * C2));
@@ -271,7 +272,7 @@ struct Pack {
                 o.u8_f2[k] = cur; cur += S::U8_F;
             }
         o.conv_k4_delta = 0;
-        if (S::TB) {     // (allocated after everything else: every other offset is the same with and without it)
+        if (S::KT == 1 && !S::LN) {     // (allocated after everything else: every other offset is the same with and without it; NOT a function of LOW: a companion shares its shape's buffer)
             // r4w: the time-batched engine's conv GEMMs stream their weight fragments from L2 - one wave-level load per (tile, k-step) kept the
             // CU's vector-memory path as busy as its matrix pipes (539 loads for 930 MFMAs per tile of tb_dec<B>).  A copy of the conv units
             // [u_off[0], end of the last unit) whose weight tiles are regrouped four k-steps per lane ([ks / 4][lane][4], the ks % 4 remainder
@@ -992,6 +993,27 @@ struct Dft {
 };
 
 // ------------------------------------------------------------------------------------------
+// B fragment (tile j, k-step ks) of a conv unit's weights at w_off (KS_TOT k-steps per tile).  Staged shapes read the LDS copy.  Shapes that
+// STREAM their conv weights from L2 (the low-LDS companions, the variants' big shapes) fetch four k-steps per 16-byte load from the k4-regrouped
+// copy of the conv units (r4x: a wave-level load costs the vector-memory path the same whatever its width; the GEMM pipelines ask for (j, ks)
+// in rising ks per tile, so the load rides on the first k-step of every group of four; the KS_TOT % 4 left-over k-steps are plain in the copy).
+template <class S, int NT, int KS_TOT, class WS>
+struct ConvB {
+    const WS& w;
+    int w_off;
+    mutable f32x4 cur[NT];
+    static constexpr bool K4 = FE_K4_STREAM && !std::is_same_v<std::remove_cv_t<WS>, WSrc<true>> && KS_TOT >= 4;
+    __device__ __forceinline__ float operator()(int j, int ks) const {
+        constexpr int CK4 = Pack<S>::v.conv_k4_delta;
+        if constexpr (K4 && CK4 != 0) {
+            const int base = w_off + CK4 + j * (KS_TOT * 64);
+            if (ks >= 4 * (KS_TOT / 4)) return w.at_g(base + ks * 64);
+            if ((ks & 3) == 0) cur[j] = w.at_gv4(base + (ks >> 2) * 256, w.lane4 * 4);
+            return cur[j][ks & 3];
+        } else return w.at(w_off + (j * KS_TOT + ks) * 64);
+    }
+};
+
 // conv-layout GEMM segment: this wave's m-tiles (wave + 4*i) x all NT n-tiles, K = 4*KS.
 //   a_lane : LDS pointer to A[(16*wave + (lane&15)) rows][(lane>>4) col] of the segment
 //   w_lane : packed weights + lane, at k-step 0 of this segment;  KS_TOT = k-steps per n-tile
@@ -1000,7 +1022,7 @@ __device__ __forceinline__ void conv_seg(f32x4 (&acc)[S::MTPW][NT], const float*
     mma_panel<S::MTPW, NT, KS, Lds<S>::PDK>(
         acc,
         [&](int i, int ks) { return a_lane[(64 * i) * LDA + 4 * ks]; },
-        [&](int j, int ks) { return w.at(w_off + (j * KS_TOT + ks) * 64); }, side);
+        ConvB<S, NT, KS_TOT, WS>{w, w_off}, side);
 }
 
 // Several K-segments (conv taps / concatenated inputs) accumulated in ONE software pipeline:
@@ -1011,7 +1033,7 @@ __device__ __forceinline__ void conv_multi(f32x4 (&acc)[S::MTPW][NT], const floa
     mma_panel<S::MTPW, NT, NSEG * KS_SEG, Lds<S>::PDK>(
         acc,
         [&](int i, int ks) { return a_lane[ks / KS_SEG][(64 * i) * LDA + 4 * (ks % KS_SEG)]; },
-        [&](int j, int ks) { return w.at(w_off + (j * (NSEG * KS_SEG) + ks) * 64); }, side);
+        ConvB<S, NT, NSEG * KS_SEG, WS>{w, w_off}, side);
 }
 
 // Epilogue of a conv-layout GEMM: optional SiLU, store to out[(row0 + m)][col] for col < NCOLS.
@@ -1687,7 +1709,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     const int m = 16 * (wave + 4 * i) + li;
                     return sc[c * S::LDS_S + 4 * (m + tp) + s];
                 },
-                [&](int j, int ks) { return wb.at(o.enc_pre_w + (j * 4 + ks) * 64); }, stage);
+                ConvB<S, S::NTC, 4, decltype(wb)>{wb, o.enc_pre_w}, stage);
             stage.commit();
             if constexpr (SG) {   // the arena was used by the FFT: restore the zero halo rows of both ping-pong buffers
                 for (int i = tid; i < 4 * LDC; i += kThreads) {
@@ -2803,7 +2825,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                             if constexpr (SG) return skb.at_g((S::NL - l) * SKIP_FLOATS + ((wave + 4 * i) * S::KS_C + (ks - K0)) * 64);
                             else return sk[(64 * i) * LDC + 4 * (ks - K0)];
                         },
-                        [&](int j, int ks) { return wb.at(o.dec1_w[l] + (j * (K0 + S::KS_C) + ks) * 64); }, stage);
+                        ConvB<S, S::NTC, K0 + S::KS_C, decltype(wb)>{wb, o.dec1_w[l]}, stage);
                     stage.commit();
                     conv_store<S, S::NTC, C1, LDC, !S::LN>(acc, Wy, 1, wave, lane);
                 }
@@ -2861,7 +2883,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     [&](int i, int ks) {
                         return ks < S::KS_C ? xa[(64 * i) * LDC + 4 * ks] : skb.at_g(((wave + 4 * i) * S::KS_C + (ks - S::KS_C)) * 64);
                     },
-                    [&](int j, int ks) { return wb.at(o.post1_w + (j * (2 * S::KS_C) + ks) * 64); }, stage);
+                    ConvB<S, S::NTC, 2 * S::KS_C, decltype(wb)>{wb, o.post1_w}, stage);
             }
             stage.commit();
             conv_store<S, S::NTC, C1, LDC, !S::LN>(acc, Wy, 1, wave, lane);
