@@ -214,14 +214,21 @@ struct TokTiling {
 };
 
 // acc[i][j] += A (LDS rows, leading dimension LDA) x W[:, tile wave + 4 j]   (tiles beyond NT read a clamped tile: discarded)
-template <int MTT, int NTPW, int KS, int LDA>
+// K4D != 0 (r4x; w_off inside the block-weight region, whose k4-regrouped copy sits K4D = PackedOffsets::k4_delta floats behind it): four k-steps per 16-byte load
+template <int MTT, int NTPW, int KS, int LDA, int K4D = 0>
 __device__ __forceinline__ void tok_panel(f32x4 (&acc)[MTT][NTPW], const float* a_lane, const WSrc<false>& wb, int w_off, int NT, int wave) {
+    f32x4 cur[NTPW];
     mma_panel<MTT, NTPW, KS, kPD>(
         acc, [&](int i, int ks) { return a_lane[(16 * i) * LDA + 4 * ks]; },
         [&](int j, int ks) {
             int nt = wave + 4 * j;
             nt = nt < NT ? nt : NT - 1;
-            return wb.at_g(w_off + (nt * KS + ks) * 64);
+            if constexpr (K4D != 0 && FE_K4_STREAM && KS >= 4) {
+                const int base = w_off + K4D + nt * (KS * 64);
+                if (ks >= 4 * (KS / 4)) return wb.at_g(base + ks * 64);
+                if ((ks & 3) == 0) cur[j] = wb.at_gv4(base + (ks >> 2) * 256, wb.lane4 * 4);
+                return cur[j][ks & 3];
+            } else return wb.at_g(w_off + (nt * KS + ks) * 64);
         }, NoSide{});
 }
 
@@ -1223,7 +1230,7 @@ __device__ __forceinline__ void blk_body(const TbArgs& a, float* smem, const int
                 for (int i = 0; i < MTT; ++i) acc[i][j] = f32x4{bj, bj, bj, bj};
             }
             const int w_off = S::BIDIR ? o.tb_fc1_w[0] + k * (S::KB > 1 ? o.tb_fc1_w[1] - o.tb_fc1_w[0] : 0) : o.blk_fc1_w[0] + kb;
-            tok_panel<MTT, NTPW2, S::ND * S::KS_2, LDH>(acc, Hs + li * LDH + lg, wb, w_off, S::NT2, wave);
+            tok_panel<MTT, NTPW2, S::ND * S::KS_2, LDH, S::BIDIR ? 0 : o.k4_delta>(acc, Hs + li * LDH + lg, wb, w_off, S::NT2, wave);
 #pragma unroll
             for (int i = 0; i < MTT; ++i)
 #pragma unroll
@@ -1250,12 +1257,18 @@ __device__ __forceinline__ void blk_body(const TbArgs& a, float* smem, const int
             for (int j0 = 0; j0 < NTPW3; j0 += CH) {
                 f32x4 acc[MTT][CH];
                 acc_init_zero<MTT, CH>(acc);
+                f32x4 qcur[CH];
                 mma_panel<MTT, CH, S::KS_2, kPD>(
                     acc, [&](int i, int ks) { return Xb[(16 * i + li) * LDX + lg + 4 * ks]; },
                     [&](int j, int ks) {
                         int nt = wave + 4 * (j0 + j);
                         nt = nt < S::NT3 ? nt : S::NT3 - 1;
-                        return wb.at_g(o.blk_qkv[0] + kb + (nt * S::KS_2 + ks) * 64);
+                        if constexpr (FE_K4_STREAM && S::KS_2 >= 4 && o.k4_delta != 0) {       // (r4x: four k-steps per 16-byte load from the k4 copy)
+                            const int base = o.blk_qkv[0] + kb + o.k4_delta + nt * (S::KS_2 * 64);
+                            if (ks >= 4 * (S::KS_2 / 4)) return wb.at_g(base + ks * 64);
+                            if ((ks & 3) == 0) qcur[j] = wb.at_gv4(base + (ks >> 2) * 256, wb.lane4 * 4);
+                            return qcur[j][ks & 3];
+                        } else return wb.at_g(o.blk_qkv[0] + kb + (nt * S::KS_2 + ks) * 64);
                     }, NoSide{});
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
@@ -1317,7 +1330,7 @@ __device__ __forceinline__ void blk_body(const TbArgs& a, float* smem, const int
 #pragma unroll
                 for (int i = 0; i < MTT; ++i) acc[i][j] = f32x4{bj, bj, bj, bj};
             }
-            tok_panel<MTT, NTPW2, S::KS_2, LDX>(acc, Hl + li * LDX + lg, wb, o.blk_fc2_w[0] + kb, S::NT2, wave);
+            tok_panel<MTT, NTPW2, S::KS_2, LDX, o.k4_delta>(acc, Hl + li * LDX + lg, wb, o.blk_fc2_w[0] + kb, S::NT2, wave);
             const __amdgpu_buffer_rsrc_t xr = range_rsrc(a.x + (size_t)g0 * (F2 * C2), (size_t)rows_valid * C2 * 4);
 #pragma unroll
             for (int i = 0; i < MTT; ++i)
