@@ -1677,7 +1677,7 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
     // k4 copies sit behind the time-batched engine's and the 512-thread kernel's sections - checked here rather than trusted)
     if (impl && impl_many && (impl_many->off->k4_delta != impl->off->k4_delta || impl_many->off->conv_k4_delta != impl->off->conv_k4_delta ||
                               impl_many->off->window != impl->off->window || impl_many->off->blk_wih[0] != impl->off->blk_wih[0]))
-        impl_many = nullptr;
+        return fail(FE_ERR_UNSUPPORTED_CONFIG, "build error: the low-LDS companion of this shape was compiled with a different packed-weight layout (fe::Pack must not depend on LOW)");
     if (!impl)
         return fail(FE_ERR_UNSUPPORTED_CONFIG,
                     "no kernel compiled for channels=%d layers=%d rf_channels=%d rf_freq=%d rf_blocks=%d n_fft=%d hop=%d kernel_size_time=%d%s "
