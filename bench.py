@@ -298,6 +298,49 @@ def cpu_baseline_offline_numpy(kw: dict, sr: int, budget_s: float):
             "sample": f"numpy oracle (oracle/fe_oracle.py::offline_forward, BLAS threads as configured), one utterance of {best[1]:g} s in {best[2]:.2f} s"}
 
 
+def parity_after_timed_region(workload: str, w: dict, kw: dict, sd: dict, eng, B: int, x_hop: np.ndarray, caches_in, out_gpu: np.ndarray, caches_out):
+    """Outside the timed blocks: the launch the bench times (same handle, same kernel, same B, per-hop) is issued ONCE more from the state the
+    timed run left behind; the oracle steps ALL B streams from that same state on the same input hop.  Returns the relative rms error of the
+    enhanced hop and the largest one over the returned caches.  The oracle (oracle/: test infrastructure) is the checker here, nothing else."""
+    def rms(a):
+        return float(np.sqrt(np.mean(np.square(np.asarray(a, np.float64)))))
+    caches_in = [np.ascontiguousarray(c, dtype=np.float32) for c in caches_in]
+    if w.get("bsrnn"):
+        from oracle import bsrnn_oracle as bo
+        orc = bo.BSRNNOracle(bo.BSRNNConfig.from_model_kwargs(kw), {k: v.numpy() for k, v in sd.items()}, np.float32)
+        what = "oracle/bsrnn_oracle.py"
+    elif w.get("fspen"):
+        from oracle import fspen_oracle as fo
+        orc = fo.FSPENOracle(fo.FSPENConfig.from_model_kwargs(kw), {k: v.numpy() for k, v in sd.items()}, np.float32)
+        what = "oracle/fspen_oracle.py"
+    elif w.get("lisennet"):
+        from oracle import lisennet_oracle as lo
+        orc = lo.LiSenNetOracle(lo.LiSenNetConfig.from_model_kwargs(kw), {k: v.numpy() for k, v in sd.items()}, np.float32)
+        what = "oracle/lisennet_oracle.py"
+    else:
+        from oracle.fe_oracle import FEConfig as OCfg, FEOracle
+        variant = "time_kernel" if w.get("kt") else "dprnn" if w.get("frnn") else "dptransformer" if w.get("dpt") else "ln" if w.get("ln") else None
+        ocfg = OCfg.from_model_kwargs(kw, variant=variant)
+        fused = {k: v.numpy() for k, v in sd.items()}
+        if variant is None:
+            from oracle.c_oracle import COracle
+            co = COracle(ocfg, fused, threads=max(1, min(8, host_cpus()[0])))
+            cs, ci = caches_in[0].copy(), caches_in[1].copy()
+            h = np.ascontiguousarray(np.concatenate(caches_in[2:], axis=0))          # K x [1, B*F2, C2] -> [K, B*F2, C2]
+            ref_out = co.step(x_hop, cs, ci, h)                                       # (in place on the caches)
+            ref_caches = [cs, ci] + [h[k:k + 1] for k in range(h.shape[0])]
+            what = "oracle/fe_oracle.c"
+            orc = None
+        else:
+            orc = FEOracle(ocfg, fused, np.float32)
+            what = "oracle/fe_oracle.py"
+    if orc is not None:
+        ref_out, *ref_caches = orc.step(x_hop, *caches_in)
+    r_out = rms(out_gpu - ref_out) / max(rms(ref_out), 1e-12)
+    r_cache = max(rms(np.asarray(a).reshape(-1) - np.asarray(b).reshape(-1)) / max(rms(b), 1e-3) for a, b in zip(caches_out, ref_caches))
+    return r_out, r_cache, what
+
+
 def measured_traffic(workload: str, B: int, T: int):
     """HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE), if one
     exists for exactly this configuration; None otherwise."""
@@ -352,8 +395,8 @@ def spawn_ranks(n: int) -> int:
     import socket
     import subprocess
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if "--cpu-dry-run" in sys.argv:
-        have = n                                      # (no devices involved)
+    if "--cpu-dry-run" in sys.argv or (have >= 1 and ("--share-gpu" in sys.argv or os.environ.get("FE_BENCH_SHARE_GPU") == "1")):
+        have = n                                      # (no devices involved / the contention probe: every rank on cuda:0)
     if have < n:
         print(f"bench.py: --gpus {n} needs {n} visible MI355X devices, this box has {have}; refusing to measure fewer ranks "
               f"under an n_gpus={n} label", file=sys.stderr, flush=True)
@@ -445,6 +488,11 @@ def main():
                     help="no kernels, no GPU: the launch path alone - bench -> torch.distributed.run -> N ranks (gloo) -> weight-blob broadcast and its "
                          "checksum agreement -> the block loop's barriers / reductions around empty steps -> ONE JSON line with world_size and dry_run: true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the post-run parity check against the oracle (parity_rms_rel: null)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="HOST-CONTENTION PROBE, not a scaling number: all N ranks launch on cuda:0 (gloo for the control traffic; RCCL cannot put two ranks on "
+                         "one device) - what N launch threads cost each other under the container's CPU quota (host_enqueue_us_per_step); "
+                         "the JSON line carries contention_probe: true and no roofline claim")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--graph", action="store_true",
                     help="capture the K timed steps (K launches, each on its own input hop) into ONE HIP graph and time its replay")
@@ -461,6 +509,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    share = args.share_gpu or os.environ.get("FE_BENCH_SHARE_GPU") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -469,13 +518,18 @@ def main():
         return dry_run(args, launched, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the FastEnhancer HIP path has no CPU fallback")
-    if torch.cuda.device_count() <= local_rank:
+    if torch.cuda.device_count() <= local_rank and not share:
         raise SystemExit(f"bench.py: rank {rank} has no GPU (local_rank {local_rank}, {torch.cuda.device_count()} visible)")
-    dev = torch.device(f"cuda:{local_rank}")
+    dev = torch.device("cuda:0" if share else f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     use_dist = launched
-    if use_dist:
+    cdev = dev                                        # where the control tensors of the collectives live
+    if use_dist and share:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        cdev = torch.device("cpu")
+    elif use_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if use_dist:
         assert dist.get_world_size() == world
 
     w = WORKLOADS[args.workload]
@@ -530,12 +584,17 @@ def main():
         blob.copy_(eng.make_blob(sd))
     torch.cuda.synchronize(dev)
     tb0 = time.perf_counter()
-    broadcast_blob(blob, src=0)                       # the path's only collective: one ncclBroadcast over xGMI
+    if share and use_dist:                            # (probe: gloo on a host copy)
+        hb = blob.cpu()
+        broadcast_blob(hb, src=0)
+        blob.copy_(hb)
+    else:
+        broadcast_blob(blob, src=0)                   # the path's only collective: one ncclBroadcast over xGMI
     torch.cuda.synchronize(dev)
     bcast_ms = (time.perf_counter() - tb0) * 1e3      # (first collective of the communicator: includes RCCL's lazy init)
     rccl_world = dist.get_world_size() if use_dist else 1
     if use_dist:                                      # every rank must now hold rank 0's bytes
-        chk = torch.stack([blob.double().sum(), blob.double().abs().sum()])
+        chk = torch.stack([blob.double().sum(), blob.double().abs().sum()]).to(cdev)
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -639,6 +698,7 @@ def main():
             graph.replay()
         else:
             run(args.steps, first)
+        enq = time.perf_counter() - t0                # the launch thread's own time: K launches enqueued (not complete)
         ev1.record(stream)
         torch.cuda.synchronize(dev)
         dt_ = time.perf_counter() - t0                # this rank's K steps, device-complete
@@ -648,17 +708,17 @@ def main():
         km = ev0.elapsed_time(ev1) / args.steps       # HIP events on the launch stream: avg per launch
         own = dt_
         if use_dist:
-            tt = torch.tensor([dt_, km], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt_, km, enq], dtype=torch.float64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt_, km = float(tt[0]), float(tt[1])
-        return dt_, km, own
+            dt_, km, enq = float(tt[0]), float(tt[1]), float(tt[2])
+        return dt_, km, own, enq
 
     blocks = [timed_block(args.warmup)]
     n_blocks = max(1, args.blocks)
     if blocks[0][0] > 0:
         n_blocks = max(1, min(n_blocks, int(args.block_budget_s / blocks[0][0])))
     if use_dist:                                      # every rank must run the same number of blocks
-        nb = torch.tensor([n_blocks], dtype=torch.int64, device=dev)
+        nb = torch.tensor([n_blocks], dtype=torch.int64, device=cdev)
         dist.all_reduce(nb, op=dist.ReduceOp.MIN)
         n_blocks = int(nb[0])
     for r_ in range(1, n_blocks):
@@ -667,13 +727,23 @@ def main():
     med = order[(len(order) - 1) // 2]                # lower median: an actually measured block
     dt, kernel_ms = blocks[med][0], blocks[med][1]
     if use_dist:
-        mine = torch.tensor([blocks[med][2] / args.steps * 1e3], dtype=torch.float64, device=dev)
-        per_rank = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        mine = torch.tensor([blocks[med][2] / args.steps * 1e3], dtype=torch.float64, device=cdev)
+        per_rank = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
         dist.all_gather(per_rank, mine)
         per_rank_ms = [float(v) for v in per_rank]
     else:
         per_rank_ms = [dt / args.steps * 1e3]
     assert torch.isfinite(out).all()
+
+    # ---- parity of exactly what was timed, outside the timed blocks: one more launch from the state the run left, against the oracle
+    parity = None
+    if rank == 0 and not offline and T == 1 and not args.no_parity:
+        nxt = (args.warmup + len(blocks) * args.steps) % pool
+        snap = state.clone()
+        run(1, nxt)
+        torch.cuda.synchronize(dev)
+        parity = parity_after_timed_region(args.workload, w, kw, sd, eng, B, x[nxt].cpu().numpy(), [c.cpu().numpy() for c in eng.split_state(snap, B)],
+                                           out.cpu().numpy(), [c.cpu().numpy() for c in eng.split_state(state, B)])
 
     if rank == 0:
         frames = B * world * T * args.steps
@@ -692,10 +762,17 @@ def main():
             "metric": "audio frames/sec (hop=256, 16kHz) FastEnhancer_B" if args.workload == "fe_b" else f"audio frames/sec {w['desc']}",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "clock_ramp_steps": ramp_steps, "cold_ms_per_step": cold_ms, "rccl_world_size": rccl_world, "weight_broadcast_ms": bcast_ms,
+            "collective_backend": (dist.get_backend() if use_dist else "none (no launcher: no process group)"),
             "per_rank_ms_per_step": per_rank_ms,
             # host side of a step on the slowest rank: wall time per step minus the HIP-event time of its launches - tells a launch-jitter-bound
             # N-GPU number from a kernel-bound one
-            "host_launch_overhead_ms_per_step": dt / args.steps * 1e3 - kernel_ms,
+            "host_launch_overhead_ms_per_step": dt / args.steps * 1e3 - kernel_ms, "kernel_ms_hip_events": kernel_ms,
+            # the launch thread alone: wall time for K fe_step calls to RETURN (enqueued, not complete), slowest rank of the median block
+            "host_enqueue_us_per_step": blocks[med][3] / args.steps * 1e6,
+            # parity of what was timed (outside the timed blocks): one more launch of the same configuration from the state the run left vs the
+            # oracle stepping all B streams from that state - relative rms error of the enhanced hop / the worst returned cache
+            "parity_rms_rel": None if parity is None else parity[0], "parity_cache_rms_rel": None if parity is None else parity[1],
+            "parity_checker": None if parity is None else f"{parity[2]}, all {B} streams of rank 0, after the timed region",
             "blocks": len(blocks), "statistic": "median of `blocks` consecutive blocks of `steps` steps (max over ranks per block)",
             "min_ms_per_step": min(b_[0] for b_ in blocks) / args.steps * 1e3, "max_ms_per_step": max(b_[0] for b_ in blocks) / args.steps * 1e3,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -741,6 +818,10 @@ def main():
             res["cpu_baseline"] = cpu_baseline_offline_numpy(kw, w["sr"], min(args.cpu_budget_s, 15.0))
         elif world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.workload, kw, w["sr"], B, args.cpu_budget_s)
+        if share:
+            res.update({"contention_probe": True, "metric": f"HOST-CONTENTION PROBE (NOT a scaling number): {world} ranks launching on ONE GPU",
+                        "n_gpus_really_used": 1, "backend": "gloo"})
+            res["roofline"] = None
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()

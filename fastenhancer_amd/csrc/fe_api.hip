@@ -117,7 +117,9 @@ struct fe_handle {
     int max_wgs = 256;             // CUs of the device: one resident workgroup per CU (persistent grid above that)
     int pipe_frames = -1;          // fe_set_time_pipeline (-1: chosen from the model size)
     int offline_engine = FE_OFFLINE_AUTO;     // fe_set_offline_engine
-    int step_kernel = [] { const char* e = std::getenv("FE_WG8"); return e ? std::atoi(e) : FE_STEP_KERNEL_WG8; }();      // fe_set_step_kernel
+    // fe_set_step_kernel; FE_WG8=0|1|2 overrides the default for A/B runs (anything else, garbage included, is ignored)
+    int step_kernel = [] { const char* e = std::getenv("FE_WG8");
+                           return (e && e[0] >= '0' && e[0] <= '0' + FE_STEP_KERNEL_WG8_PERSIST && !e[1]) ? e[0] - '0' : FE_STEP_KERNEL_WG8; }();
     unsigned int* pipe_flags_dev = nullptr;   // fe_spec_step's frame counters [max_wgs][KB] (fe_offline keeps its own in the work buffer)
     std::vector<hipStream_t> tb_streams;      // time-batched engine: the streams its nodes are spread over (lazy; tb_run)
     std::vector<hipEvent_t> tb_events;        // ... and its event pool
@@ -2223,10 +2225,11 @@ static int tb_run(fe_handle* h, fe::tb::TbArgs a0, float* work_dev, int B, int T
 // FE_OFFLINE_AUTO: the time-batched engine, except for the big shapes (M, L and their 48 kHz forms: block weights streamed from L2,
 // one frame per tile) once there are enough utterances for the time-pipelined frame walk to fill the chip on its own - measured on
 // FastEnhancer_L, 4 s: 1 utterance 5.2 ms time-batched / 14.2 ms walk, 16 utterances 20.6 / 16.8 ms (profiles/r3d_tb_timing.txt)
+constexpr int kAutoWalkFrom = 8;
 static bool use_tb_offline(const fe_handle* h, int B) {
     if (!h->impl || !h->impl->tb) return false;
     if (h->d.BD) return true;
-    if (h->offline_engine == FE_OFFLINE_AUTO) return !(h->d.C2 >= 72 && B >= 8);
+    if (h->offline_engine == FE_OFFLINE_AUTO) return !(h->d.C2 >= 72 && B >= kAutoWalkFrom);
     return h->offline_engine != FE_OFFLINE_FRAME_WALK;
 }
 
@@ -2275,13 +2278,16 @@ static int offline_tb(fe_handle* h, const float* noisy_dev, size_t in_stride, co
 size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw) {
     if (!h || B <= 0 || Tw <= 0) return 0;
     const Dims& d = h->d;
-    if (h->impl && h->impl->tb) {     // the larger of the two engines' needs, whatever the settings at call time (fe_set_time_pipeline / fe_set_offline_engine)
+    if (h->impl && h->impl->tb) {
+        // Sized for the engine the CURRENT fe_set_offline_engine setting selects (FastEnhancer_L x 16 x 4 s: the time-batched buffers are
+        // 3 GB against the frame walk's 25 MB), and MONOTONE in B under that setting: a buffer sized for B serves every batch of at most B
+        // utterances of at most Tw samples.  Under AUTO the big shapes walk from 8 utterances on but take the time-batched engine below
+        // that, so their size covers the time-batched need of min(B, 7) as well.  After fe_set_offline_engine: query again (header).
         const int T = 1 + Tw / d.HOP;
-        size_t walk = d.BD ? 0 : (size_t)B * ((size_t)(d.NFFT - d.HOP) + d.hstate() + tk_floats(h)) + (((size_t)B * d.KB + 3) & ~(size_t)3) + (size_t)B * T * d.NFFT;
-        // (sized for the engine the CURRENT setting selects for this batch - for FastEnhancer_L x 16 x 4 s the time-batched buffers are
-        //  3 GB against the walk's 25 MB; a caller that changes fe_set_offline_engine afterwards queries again)
-        if (!d.BD && !use_tb_offline(h, B)) return walk;
-        return std::max(walk, tb_work_floats(h, B, T, nullptr));
+        const size_t walk = d.BD ? 0 : (size_t)B * ((size_t)(d.NFFT - d.HOP) + d.hstate() + tk_floats(h)) + (((size_t)B * d.KB + 3) & ~(size_t)3) + (size_t)B * T * d.NFFT;
+        if (d.BD || use_tb_offline(h, B)) return std::max(walk, tb_work_floats(h, B, T, nullptr));
+        if (h->offline_engine == FE_OFFLINE_AUTO) return std::max(walk, tb_work_floats(h, std::min(B, kAutoWalkFrom - 1), T, nullptr));
+        return walk;
     }
     if (h->limpl) {     // tail + caches, and the time pipeline's counters, windowed frames and cache ring (widest pipeline: 64 + 2 slots)
         const int T = 1 + Tw / d.HOP;
@@ -2526,11 +2532,24 @@ static fe::StftArgs stft_args(const fe_handle* h, int B) {
 // spec_hat rows of an offline call: N/2 (FastEnhancer: the model drops the Nyquist bin) or N/2 + 1 (BSRNN / FSPEN / LiSenNet)
 static int offline_spec_rows(const fe_handle* h) { return h->d.NFFT / 2 + ((h->bimpl || h->fimpl || h->limpl) ? 1 : 0); }
 
+// A ragged batch has ONE batched form: the time-batched engine (the frame walk and its time pipeline take one length per launch).  It is
+// taken whenever the model has that engine and the caller has not asked for the frame walk - also for the big shapes at 8+ utterances,
+// where AUTO would walk an equal-length batch: sixteen 4 s files of FastEnhancer_L are 20.6 ms in one time-batched pass, 16 x 5.2 ms one by one.
+static bool ragged_uses_tb(const fe_handle* h) {
+    return h->impl && h->impl->tb && (h->d.BD || h->offline_engine != FE_OFFLINE_FRAME_WALK);
+}
+
+// scratch of the call's engine: the batched pass, or the one-by-one fallback's largest single call (fe_offline_work_floats is monotone in B)
+static size_t ragged_base_floats(const fe_handle* h, int B, int Tw_max) {
+    if (ragged_uses_tb(h)) return tb_work_floats(h, B, 1 + Tw_max / h->d.HOP, nullptr);
+    return std::max(fe_offline_work_floats(h, B, Tw_max), fe_offline_work_floats(h, 1, Tw_max));
+}
+
 size_t fe_offline_ragged_work_floats(const fe_handle* h, int B, int Tw_max) {
     if (!h || B <= 0 || Tw_max <= 0) return 0;
     const int Tmax = 1 + Tw_max / h->d.HOP;
-    // the batched call's scratch (>= one utterance's), the per-utterance lengths, one utterance's spec_hat (the one-by-one fallback)
-    return fe_offline_work_floats(h, B, Tw_max) + (((size_t)B + 3) & ~(size_t)3) + (size_t)offline_spec_rows(h) * Tmax * 2;
+    // the call's scratch, the per-utterance lengths, one utterance's spec_hat (the one-by-one fallback)
+    return ragged_base_floats(h, B, Tw_max) + (((size_t)B + 3) & ~(size_t)3) + (size_t)offline_spec_rows(h) * Tmax * 2;
 }
 
 int fe_offline_ragged(fe_handle* h, const float* noisy_dev, size_t in_stride, const int* Tw_host, int B, float* wav_hat_dev, size_t out_stride,
@@ -2548,8 +2567,8 @@ int fe_offline_ragged(fe_handle* h, const float* noisy_dev, size_t in_stride, co
     const int Tmax = 1 + Tw_max / d.HOP;
     if (out_stride < (size_t)d.HOP * (Tmax - 1) && B > 1) return fail(FE_ERR_INVALID_ARG, "out_stride %zu < H*(Tmax-1)", out_stride);
     hipStream_t st = (hipStream_t)stream;
-    const size_t base = fe_offline_work_floats(h, B, Tw_max);
-    if (use_tb_offline(h, B)) {
+    const size_t base = ragged_base_floats(h, B, Tw_max);
+    if (ragged_uses_tb(h)) {
         // ONE batched call laid out for the longest utterance; every utterance's frames past its own end are computed on clamped input and
         // stay out of its output (causal in time; the noncausal model's reverse scans start at each utterance's own last frame)
         int* Tw_dev = reinterpret_cast<int*>(work_dev + base);

@@ -26,7 +26,8 @@ def main(argv=None):
     p.add_argument("--device", type=str, default="cuda:0")
     p.add_argument("--batch", type=int, default=64,
                    help="files per Model.forward call: the directory is sorted by length and pushed through in ragged batches of this many "
-                        "(fe_offline_ragged; every file's result is what its own call would give); 1 = file by file like the reference")
+                        "(fe_offline_ragged; on the default / noncausal FastEnhancer models every file's samples are bit-identical to its own call's); "
+                        "1 = file by file like the reference")
     args = p.parse_args(argv)
 
     out_dir = Path(args.output_dir)
@@ -45,13 +46,14 @@ def main(argv=None):
                 enhanced, _ = model(noisy)                                      # return: wav, spec
             write_wav(str(out_dir / path.name), sr, enhanced.squeeze().cpu().numpy())
     else:
-        # sorted by length, so that a batch is laid out for little more than its own frames
-        wavs = sorted(((read_wav(str(path), sr), path) for path in files), key=lambda wp: len(wp[0]))
-        for i in range(0, len(wavs), args.batch):
-            chunk = wavs[i:i + args.batch]
+        # sorted by file size (a proxy for the length that needs no decoding), so that a batch is laid out for little more than its own
+        # frames; a batch's files are read when its turn comes - host memory holds one batch, not the directory
+        files_by_size = sorted(files, key=lambda path: (path.stat().st_size, path.name))
+        for i in range(0, len(files_by_size), args.batch):
+            chunk = files_by_size[i:i + args.batch]
             with torch.no_grad():
-                enhanced, _ = model([torch.from_numpy(w).float() for w, _ in chunk])
-            for (_, path), e in zip(chunk, enhanced):
+                enhanced, _ = model([torch.from_numpy(read_wav(str(path), sr)).float() for path in chunk])
+            for path, e in zip(chunk, enhanced):
                 write_wav(str(out_dir / path.name), sr, e.cpu().numpy())
     print(f"enhanced {len(files)} file(s) -> {out_dir}")
 

@@ -22,84 +22,76 @@ class StreamingModel:
         """model: a fastenhancer_amd ONNXModel (weights already loaded)."""
         self.model = model
         self.cfg: FEConfig = model.cfg
-        self._buf: tp.List[tp.Optional[Tensor]] = [None, None]     # two state buffers of the C ABI, used alternately
-        self._views: tp.List[tp.Optional[tp.List[Tensor]]] = [None, None]
-        self._B = 0
-        # dptransformer variant: its K / V caches are rings in the state, the tensors handed out are rotated copies - the
-        # tensors of the last call are recognised by identity instead of by address
-        self._handed: tp.Tuple[int, tp.List[Tensor]] = (-1, [])
+        # per batch size: the geometry of the reference's cache list inside one state buffer of the C ABI, as
+        # (offset in floats, shape, stride) per tensor - what split_state() returns for a fresh state
+        self._geom: tp.Dict[int, tp.List[tp.Tuple[int, torch.Size, tp.Tuple[int, ...]]]] = {}
+        # dptransformer variant: its K / V caches are rings in the state, the tensors handed out are rotated COPIES - the
+        # tensors of the last call are recognised by identity and name the state buffer they were gathered from
+        self._handed: tp.Tuple[tp.Optional[Tensor], tp.List[Tensor]] = (None, [])
 
     @property
     def engine(self) -> Engine:
         return self.model.engine
 
-    @staticmethod
-    def _same_device(a: torch.device, b) -> bool:
-        """torch.device('cuda') != torch.device('cuda:0'): compare type and index with None -> the current device"""
-        b = torch.device(b)
-        if a.type != b.type:
-            return False
-        if a.type != "cuda":
-            return True
-        cur = torch.cuda.current_device()
-        return (cur if a.index is None else a.index) == (cur if b.index is None else b.index)
+    def _geometry(self, B: int, state: Tensor):
+        g = self._geom.get(B)
+        if g is None:
+            p0 = state.data_ptr()
+            g = [((v.data_ptr() - p0) // 4, v.shape, v.stride()) for v in self.engine.split_state(state, B, head0=True)]
+            self._geom[B] = g
+        return g
 
-    def _ensure(self, B: int, device, fresh: bool = False):
-        if fresh or self._buf[0] is None or self._B != B or not self._same_device(self._buf[0].device, device):
-            eng = self.engine
-            self._buf = [eng.new_state(B), eng.new_state(B)]
-            self._views = [eng.split_state(self._buf[0], B, head0=True), eng.split_state(self._buf[1], B, head0=True)]      # (fresh zero states)
-            self._B = B
-            self._handed = (-1, [])          # the rotated copies of the previous buffers no longer name a buffer
+    def _views(self, state: Tensor, B: int) -> tp.List[Tensor]:
+        return [state.as_strided(shape, stride, off) for off, shape, stride in self._geometry(B, state)]
 
     def initialize_cache(self, x: Tensor) -> tp.List[Tensor]:
         """scripts/export_onnx.py:43-46: [cache_stft, cache_istft] ++ model caches (zeros).  On the model's GPU the
-        tensors are views of ONE state buffer of the C ABI, so forward() need not re-pack them.  Every call allocates
-        fresh buffers (like the reference, which returns new tensors): the caches of a session still in progress on
-        this object keep their memory and simply stop being recognised as views (they are packed like foreign tensors)."""
+        tensors are views of ONE freshly allocated state buffer of the C ABI, so forward() need not re-pack them."""
         if x.is_cuda:
-            self._ensure(x.size(0), x.device, fresh=True)
-            return list(self._views[0])
+            B = x.size(0)
+            return self._views(self.engine.new_state(B), B)
         cache_list = self.model.stft.initialize_cache(x)
         cache_list.extend(self.model.initialize_cache(x))
         return cache_list
 
-    def _which(self, caches) -> int:
-        """index of the state buffer the given cache tensors are exactly the views of, else -1"""
-        if self._handed[0] >= 0 and len(caches) == len(self._handed[1]) and all(c is w for c, w in zip(caches, self._handed[1])):
+    def _source(self, caches: tp.List[Tensor], B: int, n: int) -> tp.Optional[Tensor]:
+        """the state buffer the given cache tensors are exactly the views of (same memory, same layout), else None"""
+        if self._handed[0] is not None and len(caches) == len(self._handed[1]) and all(c is w for c, w in zip(caches, self._handed[1])):
             return self._handed[0]
-        for i in (0, 1):
-            v = self._views[i]
-            if v is not None and len(v) == len(caches) and all(
-                    c.data_ptr() == w.data_ptr() and c.shape == w.shape and c.dtype == w.dtype and c.stride() == w.stride()
-                    for c, w in zip(caches, v)):
-                return i
-        return -1
+        base = caches[0]._base
+        g = self._geom.get(B)
+        if base is None or g is None or len(g) != len(caches) or base.numel() != n or base.dtype != torch.float32 or not base.is_cuda \
+                or base.dim() != 1 or base.stride(0) != 1:
+            return None
+        p0 = base.data_ptr()
+        for c, (off, shape, stride) in zip(caches, g):
+            if c.data_ptr() != p0 + 4 * off or c.shape != shape or c.stride() != stride or c.dtype != torch.float32:
+                return None
+        return base
 
     def forward(self, wav_in: Tensor, cache_stft: Tensor, cache_istft: Tensor, *cache_model: Tensor):
-        """wav_in [B, H]; the caches passed in are never written (like the reference).  ALIASING CONTRACT, unlike the
-        reference: the caches returned are views of one of TWO internal state buffers used alternately, so the tensors
-        returned by call n are overwritten by call n + 2 - a caller that keeps a snapshot for roll-back must .clone() it
-        (INTEGRATION.md).  (dptransformer models return rotated copies of their K / V rings: in-place edits of those
-        are not seen by the next call; pass the edited tensors back in, which packs them like foreign tensors.)
-        Caches that are the views handed out by initialize_cache() / the previous call (the driver loop of
-        scripts/test_onnx.py) cost one device copy into the other state buffer; foreign tensors are packed first."""
+        """wav_in [B, H].  VALUE SEMANTICS, like the reference's Model.forward (scripts/export_onnx.py:48-58): the caches passed
+        in are never written, the caches returned are views of a state buffer allocated for THIS call (the caching allocator's
+        job) and are never written again - a caller may keep them for roll-back, look-ahead or A/B runs and feed them back in at
+        any later time.  Caches that are the views handed out by initialize_cache() / an earlier call (the driver loop of
+        scripts/test_onnx.py) cost one device copy into the new buffer; any other tensors (clones, CPU tensors, tensors of the
+        reference) are packed into the state layout first.  (dptransformer models return rotated copies of their K / V rings.)"""
         eng = self.engine
         B = wav_in.size(0)
         caches = [cache_stft, cache_istft, *cache_model]
-        self._ensure(B, eng.device)
-        src = self._which(caches)
-        dst = 1 - src if src >= 0 else 0
-        if src >= 0:
-            self._buf[dst].copy_(self._buf[src])
+        n = eng.state_floats(B)
+        src = self._source(caches, B, n)
+        if src is not None and src.device == eng.device:
+            state = torch.empty_like(src)
+            state.copy_(src)
         else:
-            self._buf[dst].copy_(eng.pack_state([t.to(eng.device) for t in caches], B))
-        wav_out = eng.step(wav_in.to(eng.device, torch.float32), self._buf[dst], T=1)
+            state = eng.pack_state([t.to(eng.device) for t in caches], B)        # (torch.cat: a fresh buffer)
+        wav_out = eng.step(wav_in.to(eng.device, torch.float32), state, T=1)
         if getattr(self.cfg, "dpt", False):
-            out = eng.split_state(self._buf[dst], B)
-            self._handed = (dst, out)
+            out = eng.split_state(state, B)
+            self._handed = (state, out)
             return (wav_out, *out)
-        return (wav_out, *self._views[dst])
+        return (wav_out, *self._views(state, B))
 
     __call__ = forward
 

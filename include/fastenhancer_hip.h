@@ -181,7 +181,7 @@ int fe_set_time_pipeline(fe_handle* h, int frames_in_flight);
  *   FE_STEP_KERNEL_WG8_PERSIST: the same also above that (persistent workgroups instead of the low-LDS companion kernel).
  * The two kernels agree to fp32 rounding (a few 1e-8 on the waveform), not bit for bit: a caller that needs a chunked launch
  * (T > 1) to be bit-identical to T per-hop launches selects FE_STEP_KERNEL_WAVES4.  The environment variable FE_WG8 = 0 | 1 | 2
- * sets the default of new handles.  The reference has one forward only (models/fastenhancer/default/model.py:677-710). */
+ * sets the default of new handles (any other value is ignored).  The reference has one forward only (models/fastenhancer/default/model.py:677-710). */
 #define FE_STEP_KERNEL_WAVES4 0
 #define FE_STEP_KERNEL_WG8 1
 #define FE_STEP_KERNEL_WG8_PERSIST 2
@@ -194,7 +194,11 @@ int fe_set_offline_engine(fe_handle* h, int engine);
 
 /* Offline wav->wav, Model.forward (model.py:728-735) with CompressedSTFT
  * (functional/audio_modules.py:70-164): noisy [B, Tw] -> wav_hat [B, H*(Tw/H)], spec_hat [B, N/2, T, 2],
- * T = 1 + Tw/H.  work_dev: scratch of fe_offline_work_floats(B, Tw) floats. */
+ * T = 1 + Tw/H.  work_dev: scratch of fe_offline_work_floats(B, Tw) floats.
+ * The size is that of the engine the CURRENT fe_set_offline_engine / fe_set_time_pipeline setting selects and is monotone in B and Tw
+ * under that setting: a buffer sized once for the largest batch serves every smaller one (AUTO on the big shapes covers both the frame
+ * walk of 8+ utterances and the time-batched pass of fewer).  After fe_set_offline_engine the size must be queried again - the
+ * time-batched engine of FastEnhancer_L needs ~100x the frame walk's scratch, and fe_offline cannot see the size of work_dev. */
 size_t fe_offline_work_floats(const fe_handle* h, int B, int Tw);
 int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_hat_dev,
                float* spec_hat_dev, float* work_dev, void* stream);
@@ -206,9 +210,12 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
  * its own 1 + Tw[b] / H unspecified.  On the time-batched engine (the default FastEnhancer model and the noncausal one) this is ONE
  * batched pass laid out for the longest utterance - every utterance's result is bit-identical to its own fe_offline call on that engine
  * (frames are rows of the layer GEMMs, scans are per row; the reflect padding, the reverse scans of the noncausal model and the
- * overlap-add use each utterance's own length); sort a directory by length to keep the padding small.  The other models / variants
- * and FE_OFFLINE_FRAME_WALK have no batched form (one length per launch): the call runs them one utterance after the other.
- * work_dev: fe_offline_ragged_work_floats(B, max(Tw)) floats. */
+ * overlap-add use each utterance's own length); sort a directory by length to keep the padding small.  A ragged batch takes that pass
+ * under FE_OFFLINE_AUTO too, whatever the shape and B (the frame walk AUTO prefers for 8+ equal-length utterances of the big shapes has
+ * no ragged form).  The other models / variants and FE_OFFLINE_FRAME_WALK have no batched form (one length per launch): the call runs
+ * them one utterance after the other, each on the engine fe_offline would take for a single utterance.
+ * work_dev: fe_offline_ragged_work_floats(B, max(Tw)) floats (same contract as fe_offline_work_floats: query again after
+ * fe_set_offline_engine). */
 size_t fe_offline_ragged_work_floats(const fe_handle* h, int B, int Tw_max);
 int fe_offline_ragged(fe_handle* h, const float* noisy_dev, size_t in_stride, const int* Tw_host, int B, float* wav_hat_dev, size_t out_stride,
                       float* spec_hat_dev, float* work_dev, void* stream);

@@ -5,6 +5,7 @@ Tolerance (BASELINE.json north_star): enhanced-waveform RMS error < 1e-4 absolut
 synthetic checkpoints emit audio of RMS 0.1-0.5 we ALSO require 1e-4 relative to the reference
 RMS, which is the tighter of the two.  Observed: ~1e-6 relative."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -17,6 +18,8 @@ pytestmark = pytest.mark.gpu
 
 ABS_TOL = 1e-4
 REL_TOL = 1e-4
+# regression bounds, relative rms (floor 1e-3 on the reference rms): ~5x the largest error a full run of the suite records per family
+TIGHT_REL = {"fastenhancer": 1e-4, "bsrnn": 1e-4, "fspen": 1e-4, "lisennet": 1e-4}      # (set from profiles/r5_parity_observed.json)
 GPU_SHAPES = ["fe_t", "fe_b", "fe_m", "fe_l", "fe48_b", "fe48_l", "fe48_b_h480", "fe_tk_b", "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_l",
               "fe_dpt_t", "fe_dpt_b", "fe_dpt_m", "fe_ln_b",
               "fe_s", "fe48_t", "fe48_s", "fe48_m", "fe_dprnn_s", "fe_dprnn_m", "fe_dpt_s"]          # shapes with reference goldens (r3: every shipped shape)
@@ -31,14 +34,34 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _assert_close(got, ref, what):
+# test id -> largest relative rms error any of its comparisons saw; FE_RECORD_PARITY=<file> writes the table at session end
+# (tests/conftest.py) - the per-family tight bounds below are ~5x what a full run of this table shows
+OBSERVED = {}
+
+
+def _family():
+    tid = os.environ.get("PYTEST_CURRENT_TEST", "")
+    for fam in ("bsrnn", "fspen", "lisennet"):
+        if fam in tid:
+            return fam
+    return "fastenhancer"
+
+
+def _assert_close(got, ref, what, tight=None):
     got = np.asarray(got, np.float64)
     ref = np.asarray(ref, np.float64)
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     assert np.isfinite(got).all(), what
     err, r = rms(got - ref), rms(ref)
-    # absolute 1e-4 for audio-level signals (rms <= 1), relative 1e-4 always
-    assert err < ABS_TOL * max(1.0, r) and err <= REL_TOL * max(r, 1e-3), f"{what}: rms err {err:.3e}, ref rms {r:.3e}"
+    rel = err / max(r, 1e-3)
+    tid = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    if rel > OBSERVED.get(tid, (0.0, ""))[0]:
+        OBSERVED[tid] = (rel, what)
+    # (1) the north_star bound: absolute 1e-4 for audio-level signals (rms <= 1), relative 1e-4 always
+    assert err < ABS_TOL * max(1.0, r) and err <= REL_TOL * max(r, 1e-3), f"{what}: rms err {err:.3e}, ref rms {r:.3e} (north_star bound 1e-4)"
+    # (2) the regression bound: what the kernels deliver (exact fp32 arithmetic, fp32 oracle), per family
+    bound = TIGHT_REL[_family()] if tight is None else tight
+    assert rel <= bound, f"{what}: relative rms err {rel:.3e} > {bound:.1e} (the kernels deliver ~{bound / 5:.0e}: a precision regression)"
     return err / max(r, 1e-12)
 
 
@@ -266,7 +289,7 @@ def test_standalone_stft_modules_match_oracle(name):
     assert ref.shape == tuple(back.shape)
 
 
-def test_streaming_model_reuses_its_state_buffer_and_stays_functional():
+def test_streaming_model_steps_without_repacking_and_stays_functional():
     """the driver-loop form `wav_out, *caches = M(wav_in, *caches)` must not re-pack the caches, must not modify the
     tensors it was given, and must equal the packed path bit for bit"""
     from fastenhancer_amd.streaming import StreamingModel
@@ -276,14 +299,43 @@ def test_streaming_model_reuses_its_state_buffer_and_stays_functional():
     x = torch.from_numpy(make_input(B, hops * H, 12, sr)).to(_dev())
     c1 = M1.initialize_cache(x)
     c2 = [t.clone() for t in M2.initialize_cache(x)]            # foreign tensors: the packing path
+    n_state = m.engine.state_floats(B)
     for t in range(hops):
         before = [t_.clone() for t_ in c1]
+        assert M1._source(c1, B, n_state) is not None, "the caches handed out are not recognised as views of a state buffer"
         o1, *n1 = M1(x[:, t * H:(t + 1) * H], *c1)
         assert all(torch.equal(a_, b_) for a_, b_ in zip(c1, before)), "input caches were modified"
-        assert M1._which(n1) >= 0, "returned caches are not views of the state buffer"
+        assert M2._source(c2, B, n_state) is None
         o2, *n2 = M2(x[:, t * H:(t + 1) * H], *c2)
         assert torch.equal(o1, o2) and all(torch.equal(a_, b_) for a_, b_ in zip(n1, n2))
         c1, c2 = n1, [t_.clone() for t_ in n2]
+
+
+@pytest.mark.parametrize("name", ["fe_b", "fe_tk_b", "fe_dpt_t", "bsrnn_xt"])
+def test_streaming_model_has_the_reference_value_semantics(name):
+    """scripts/export_onnx.py:48-58: caches are passed in and returned, never mutated in place, and the caller owns them.  The caches
+    returned by call n stay what they were through five more calls and are still valid input: resuming from them reproduces, bit for bit,
+    what the uninterrupted run produced."""
+    from fastenhancer_amd.streaming import StreamingModel
+    m, orc, cfg, sr, seed = _bsrnn(name) if name.startswith("bsrnn") else _model(name)
+    M = StreamingModel(m)
+    B, hops, H, keep = 3, 9, cfg.hop_size, 2
+    x = torch.from_numpy(make_input(B, hops * H, 31, sr)).to(_dev())
+    caches = M.initialize_cache(x)
+    init = caches
+    outs, kept, kept_snap = [], None, None
+    for t in range(hops):
+        o, *caches = M(x[:, t * H:(t + 1) * H], *caches)
+        outs.append(o)
+        if t == keep:
+            kept, kept_snap = caches, [c.clone() for c in caches]
+    assert all(float(c.abs().max()) == 0.0 for c in init), "the initial caches were written"
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(kept, kept_snap)), "caches returned by call n changed during the later calls"
+    caches = kept                       # roll back to after hop `keep` and run on
+    for t in range(keep + 1, hops):
+        o, *caches = M(x[:, t * H:(t + 1) * H], *caches)
+        assert torch.equal(o, outs[t]), f"resumed run differs at hop {t}"
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(kept, kept_snap))
 
 
 def test_full_size_batch_256_matches_oracle_and_is_stream_independent():
@@ -903,7 +955,7 @@ def test_noncausal_surface_and_errors():
 
 def test_streaming_model_on_an_index_less_cuda_device():
     """`.cuda()` / 'cuda' store torch.device('cuda') (no index) while tensors report cuda:0 - the state buffers must
-    not be re-allocated (and, dptransformer, the K / V rings not be lost) on every call"""
+    not be taken for foreign tensors (and, dptransformer, the K / V rings not be lost) on every call"""
     from fastenhancer_amd.streaming import StreamingModel
     for name in ("fe_b", "fe_dpt_t"):
         kw, sr, seed = MODEL_KWARGS[name]
@@ -916,13 +968,13 @@ def test_streaming_model_on_an_index_less_cuda_device():
         x = make_input(B, hops * H, 909, sr)
         xd = torch.from_numpy(x).to("cuda")
         caches = M.initialize_cache(xd)
-        buf0 = M._buf[0]
         ref_c = orc.initialize_cache(B)
+        n_state = m.engine.state_floats(B)
         for t in range(hops):
+            assert M._source(caches, B, n_state) is not None, "caches on 'cuda' are packed like foreign tensors on every call"
             wav_out, *caches = M(xd[:, t * H:(t + 1) * H], *caches)
             ref_o, *ref_c = orc.step(x[:, t * H:(t + 1) * H], *ref_c)
             _assert_close(wav_out.cpu().numpy(), ref_o, f"{name} hop {t}")
-        assert M._buf[0] is buf0, "the state buffers were re-allocated between calls"
         # a second initialize_cache hands out FRESH buffers: the first session's caches keep their values
         snap = [c.clone() for c in caches]
         caches2 = M.initialize_cache(xd)
@@ -969,19 +1021,22 @@ def test_command_line_callers(tmp_path, monkeypatch):
     _assert_close(ys, orc.enhance_stream(x[None])[0], "test_streaming CLI")
 
 
-@pytest.mark.parametrize("name,n_files", [("fe_b", 40), ("fe_t", 9), ("fe_nc", 6), ("fe_tk_b", 3), ("bsrnn_xt", 3)])
-def test_ragged_offline_batch_is_bit_identical_to_one_call_per_utterance(name, n_files):
+@pytest.mark.parametrize("name,n_files,engine", [("fe_b", 40, "time_batched"), ("fe_t", 9, "time_batched"), ("fe_nc", 6, None), ("fe_tk_b", 3, None), ("bsrnn_xt", 3, None),
+                                                 ("fe_l", 9, "auto"), ("fe_m", 8, "auto"), ("fe_l", 9, "frame_walk"), ("fe_b", 5, "frame_walk")])
+def test_ragged_offline_batch_is_bit_identical_to_one_call_per_utterance(name, n_files, engine):
     """fe_offline_ragged (Model.forward on a LIST of utterances - what scripts/test_pytorch.py:28-37 does file by file): n files of
     different lengths in one batched call give, bit for bit, what each file's own call gives.  fe_b / fe_t / fe_nc run ONE batched pass of
     the time-batched engine (per-utterance reflect padding, reverse-scan start and overlap-add); fe_tk_b / bsrnn_xt have no batched form
-    and are walked one after the other inside the call.  A sample of the files is also checked against the oracle."""
+    and are walked one after the other inside the call.  A sample of the files is also checked against the oracle.
+    r5: the big shapes under AUTO with 8+ files (AUTO walks an equal-length batch of that size; a ragged one takes the batched pass) and the
+    explicit frame walk (one by one inside the call, scratch sized for it)."""
     if name.startswith("bsrnn"):
         m, orc, cfg, sr, seed = _bsrnn(name, "Model")
     else:
         m, orc, cfg, sr, seed = _model(name, "Model")
     eng = m.engine
-    if name in TB_SHAPES:
-        eng.set_offline_engine("time_batched")
+    if engine:
+        eng.set_offline_engine(engine)
     rng = np.random.default_rng(5)
     H = cfg.hop_size
     lens = [int(v) for v in rng.integers(cfg.n_fft // 2 + 1 + 3 * H, 60 * H, size=n_files)]
@@ -1000,7 +1055,7 @@ def test_ragged_offline_batch_is_bit_identical_to_one_call_per_utterance(name, n
         wav_ref, spec_ref = orc.offline_forward(xs[i][None])
         _assert_close(wavs[i].cpu().numpy(), wav_ref[0], f"ragged batch, file {i} vs oracle")
         _assert_close(specs[i].cpu().numpy(), spec_ref[0], f"ragged batch, file {i} spec vs oracle")
-    if name in TB_SHAPES:
+    if engine:
         eng.set_offline_engine("auto")
 
 
@@ -1029,7 +1084,7 @@ def test_offline_cli_pushes_a_directory_through_in_ragged_batches(tmp_path, monk
         ra, ya = wavfile.read(str(tmp_path / "batched" / f"f{i:02d}.wav"))
         rb, yb = wavfile.read(str(tmp_path / "single" / f"f{i:02d}.wav"))
         assert ra == rb == sr and ya.shape == yb.shape
-        assert np.abs(ya - yb).max() <= 2e-6 * max(1.0, np.abs(yb).max()), i      # (file by file the engine is chosen per call: AUTO)
+        assert np.array_equal(ya, yb), i      # (both run the time-batched engine: a ragged batch's rows are bit-identical to single calls)
 
 
 # ------------------------------------------------------------------------------------------------ BSRNN (a22-a25)
