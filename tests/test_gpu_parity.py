@@ -5,6 +5,7 @@ Tolerance (BASELINE.json north_star): enhanced-waveform RMS error < 1e-4 absolut
 synthetic checkpoints emit audio of RMS 0.1-0.5 we ALSO require 1e-4 relative to the reference
 RMS, which is the tighter of the two.  Observed: ~1e-6 relative."""
 import importlib
+import json
 import os
 
 import numpy as np
@@ -18,8 +19,16 @@ pytestmark = pytest.mark.gpu
 
 ABS_TOL = 1e-4
 REL_TOL = 1e-4
-# regression bounds, relative rms (floor 1e-3 on the reference rms): ~5x the largest error a full run of the suite records per family
-TIGHT_REL = {"fastenhancer": 1e-4, "bsrnn": 1e-4, "fspen": 1e-4, "lisennet": 1e-4}      # (set from profiles/r5_parity_observed.json)
+# Regression bounds, relative rms (floor 1e-3 on the reference rms), next to the north_star bound above: what exact-fp32 kernels against an
+# fp32 oracle deliver, so that a fast-math exp, a dropped summation order or a bf16 staging slip - two lost digits - turns the suite red.
+# Per family: ~5x the LARGEST error a full run of the suite recorded (tests/golden/parity_observed_r5.json = profiles/r5_parity_observed.json,
+# written by FE_RECORD_PARITY on the MI355X: fastenhancer 3.8e-6 (a dprnn_s stage), bsrnn 1.8e-6, fspen 1.9e-6, lisennet 9.6e-7);
+# per test: 5x what THAT test recorded (floor 2e-6), whichever is smaller.
+TIGHT_REL = {"fastenhancer": 2e-5, "bsrnn": 1e-5, "fspen": 1e-5, "lisennet": 5e-6}
+try:
+    _OBSERVED_R5 = {k: v["rel_rms"] for k, v in json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parity_observed_r5.json"))).items()}
+except FileNotFoundError:
+    _OBSERVED_R5 = {}
 GPU_SHAPES = ["fe_t", "fe_b", "fe_m", "fe_l", "fe48_b", "fe48_l", "fe48_b_h480", "fe_tk_b", "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_l",
               "fe_dpt_t", "fe_dpt_b", "fe_dpt_m", "fe_ln_b",
               "fe_s", "fe48_t", "fe48_s", "fe48_m", "fe_dprnn_s", "fe_dprnn_m", "fe_dpt_s"]          # shapes with reference goldens (r3: every shipped shape)
@@ -60,7 +69,7 @@ def _assert_close(got, ref, what, tight=None):
     # (1) the north_star bound: absolute 1e-4 for audio-level signals (rms <= 1), relative 1e-4 always
     assert err < ABS_TOL * max(1.0, r) and err <= REL_TOL * max(r, 1e-3), f"{what}: rms err {err:.3e}, ref rms {r:.3e} (north_star bound 1e-4)"
     # (2) the regression bound: what the kernels deliver (exact fp32 arithmetic, fp32 oracle), per family
-    bound = TIGHT_REL[_family()] if tight is None else tight
+    bound = min(TIGHT_REL[_family()], max(5.0 * _OBSERVED_R5.get(tid, 1.0), 2e-6)) if tight is None else tight
     assert rel <= bound, f"{what}: relative rms err {rel:.3e} > {bound:.1e} (the kernels deliver ~{bound / 5:.0e}: a precision regression)"
     return err / max(r, 1e-12)
 
@@ -637,7 +646,10 @@ def test_edge_inputs():
     for t in range(8):
         o, *caches = orc.step(sq.cpu().numpy()[:, t * H:(t + 1) * H], *caches)
         refs.append(o)
-    _assert_close(out.cpu().numpy(), np.concatenate(refs, 1), "full-scale input")
+    # A +-1 wave of period 3 is exactly periodic: most bins of its spectrum are rounding noise (~1e-5) around an exact zero, and the
+    # compression gain max(|X|, 1e-5)^(c - 1) is ~3000 there - the reference's own output moves in the fifth digit with the FFT's summation
+    # order (observed 8.1e-5 between the matrix-core DFT and numpy's FFT).  This input keeps the north_star bound only.
+    _assert_close(out.cpu().numpy(), np.concatenate(refs, 1), "full-scale input", tight=REL_TOL)
 
 
 def test_error_behaviour():
