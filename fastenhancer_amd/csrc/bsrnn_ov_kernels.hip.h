@@ -1,0 +1,433 @@
+// bsrnn_ov_kernels.hip.h — PART 1 of BSRNN's per-hop step (STFT -> compress -> band split -> L x [time LSTM, band LSTM]) for
+// num_channels = 16 (xt / xxt) at ONE stream per CU, with the layers' matrix-core work taken off the recurrence's critical path.
+//
+// bsrnn_frame_kernel runs a layer as five barrier-separated phases on all four waves: time-LSTM gates, fc_time, the band LSTM's input
+// projections, the band recurrence (31 dependent steps per direction), fc_freq - 7.9 k + 21.1 k cycles per layer
+// (profiles/r5a_phases_bsrnn_xt.txt).  What the next layer needs of band j - x[j] after fc_freq - exists as soon as BOTH scans have passed
+// band j, i.e. after step max(j, 30 - j): the middle bands long before the recurrence ends.  Here the waves have ROLES:
+//   waves 0, 1   the forward / backward scan, one wave per direction (two gate rows per lane, W_hh rows in registers, h through LDS with
+//                no barrier: a wave's LDS operations execute in order; tools/micro/lstm_step.hip S1: 569 cycles per step against 585-680
+//                with a workgroup barrier per step) - nothing else
+//   waves 2, 3   everything on the matrix cores, for two row tiles of bands that are cut by readiness, not by index:
+//                tile A = bands 8..22 (ready after step 22), tile B = bands 0..7 and 23..30 (ready after step 30).  Per tile the chain
+//                fc_freq (layer l) -> x -> time-LSTM gates (layer l + 1) -> fc_time -> input projections of layer l + 1; tile A's chain
+//                runs under steps 23..30 of layer l's scans, only tile B's is serial with them.  The h half of the time-LSTM gates
+//                (W_hh h_{t-1}: known since the last frame) is accumulated under the early steps.
+// Synchronisation is by monotonic counters in LDS (scan progress per direction, a two-wave rendezvous inside a chain, "projections of
+// layer l complete"), polled; the input projections are double-buffered by layer parity.  The two helper waves split the gate GEMM by
+// hidden tile and the projections by direction, and compute the narrow fc layers (N = 16) redundantly - identical values written to the
+// same LDS words - so that a chain needs ONE rendezvous (the new time-LSTM h, whose two column halves meet in fc_time).
+// Reference: models/bsrnn/model.py:367-390 (the layer loop), :249-257 (ONNXLSTM), :136-153 (BandSplit).
+#pragma once
+
+namespace fe {
+
+template <class S>
+struct BOvLds {
+    static constexpr int SP = 0;                              // compressed spectrum [257][2]
+    static constexpr int TW = SP + 2 * kBins + 2;             // twiddles
+    static constexpr int FA = TW + S::NFFT;                   // FFT ping-pong
+    static constexpr int FB = FA + 2 * S::NFFT;
+    static constexpr int XB = FB + 2 * S::NFFT;               // [32][LDX] band features before a layer's time LSTM (after fc_freq)
+    static constexpr int XA = XB + 32 * S::LDX;               // [32][LDX] ... after fc_time (input of the projections and of fc_freq's residual)
+    static constexpr int HN = XA + 32 * S::LDX;               // [32][LDH] the time LSTM's new h (A operand of fc_time)
+    static constexpr int YF = HN + 32 * S::LDH;               // [32][LDY] band-LSTM outputs (fwd | bwd)
+    static constexpr int HB = (YF + 32 * S::LDY + 3) / 4 * 4; // [2 dirs][2 buffers][HH] + [HH] dump slots of the low lanes
+    static constexpr int FLG = HB + 5 * S::HH;                // counters (ints): scan progress fwd / bwd, helper rendezvous x 2, projections ready
+    static constexpr int XP = FLG + 16;                       // [2 layer parities][2 dirs][32 bands][64 lanes][2]: gate rows in the scan's lane order
+    static constexpr int XPBUF = 2 * 32 * 128;
+    static constexpr int TOTAL = XP + 2 * XPBUF;
+    static constexpr size_t BYTES = (size_t)TOTAL * 4;
+    static_assert(XP % 2 == 0 && HB % 4 == 0, "aligned f32x2 / float4 LDS reads");
+    static_assert(BYTES <= 160 * 1024, "BSRNN role-split LDS plan exceeds 160 KiB");
+};
+
+// monotonic LDS counters: the writer's earlier LDS writes are complete before the counter moves (lgkmcnt(0), and a wave's LDS
+// operations execute in issue order); the reader polls, then reads the data
+__device__ __forceinline__ void ov_signal(int* flag, int v) {
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+    __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+__device__ __forceinline__ void ov_wait(int* flag, int v) {
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    int spins = 0;
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < v) {
+        if (++spins > (1 << 22)) __builtin_trap();        // (a partner that never arrives: fail the launch loudly)
+    }
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+
+// band of row i of a tile: tile 0 (A) = bands 8..22 (+ one pad row), tile 1 (B) = bands 0..7, 23..30
+template <int T>
+__device__ __forceinline__ int ov_band(int i) {
+    if constexpr (T == 0) return 8 + (i < 15 ? i : 14);
+    else return i < 8 ? i : i + 15;
+}
+
+template <class S>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) bsrnn_ov_kernel(BArgs a) {
+    static_assert(S::C == 16 && S::HH == 32 && S::NFFT == 512, "the role-split kernel is built for num_channels = 16");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using L = BOvLds<S>;
+    constexpr int N = S::NFFT, H = S::HOP, OVL = S::OVL, C = S::C, HH = S::HH;
+    constexpr int LDX = S::LDX, LDH = S::LDH, LDY = S::LDY;
+    constexpr int KSC = S::KSC, KSH = S::KSH, KS1 = S::KS1;      // 4, 8, 12
+    constexpr float K2 = -2.8853900817779268f;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const float* __restrict__ wp = a.wp;
+    const BOffsets& o = a.off;
+    WSrc<false> wb;
+    wb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, o.total * 4, 0x00020000);
+    wb.lane4 = lane * 4;
+    wb.li4 = li * 4;
+    wb.lds = nullptr;
+    wb.base = 0;
+    wb.k4d = 0;
+
+    float* sp = smem + L::SP;
+    float2* tw = reinterpret_cast<float2*>(smem + L::TW);
+    float2* fa = reinterpret_cast<float2*>(smem + L::FA);
+    float2* fb = reinterpret_cast<float2*>(smem + L::FB);
+    float* XB = smem + L::XB;
+    float* XA = smem + L::XA;
+    float* Hn = smem + L::HN;
+    float* Yf = smem + L::YF;
+    float* Hb = smem + L::HB;
+    int* flg = reinterpret_cast<int*>(smem + L::FLG);
+    float* XPs = smem + L::XP;
+    const int b = (int)blockIdx.x;
+    float* cst = a.cache_stft + (size_t)b * OVL;
+    const size_t lsz = (size_t)kBands * HH;                      // one (h or c) tensor of a layer and stream
+
+    for (int i = tid; i < N / 2; i += kThreads) tw[i] = reinterpret_cast<const float2*>(wp + o.twiddle)[i];
+    if (tid < 16) flg[tid] = 0;
+
+    // ---------------- the roles' register sets
+    // scans (waves 0, 1): lane = (half, unit): half 0 holds gate rows (i, g), half 1 (f, o) of unit u over the whole K
+    const int d = wave & 1, u = lane & 31, half = lane >> 5;
+    float W0[HH], W1[HH];
+    auto load_whh = [&](int l) {
+        const float* wr = wp + o.f_whh[l][d] + 4 * u + half;       // packed [k][4 u + gate] per direction (gate order i, f, g, o)
+#pragma unroll
+        for (int k = 0; k < HH; ++k) { W0[k] = wr[k * 128]; W1[k] = wr[k * 128 + 2]; }
+    };
+    // helpers (waves 2, 3): hidden tile ct of the time-LSTM gates, direction ct of the projections
+    const int ct = wave & 1;
+    float Wt[4][KS1], Wtb[4], Wf1[KSH], Wf1b = 0.0f, Wf2[2 * KSH], Wf2b = 0.0f, Wip[8][KSC], Wipb[8];
+    f32x4 hh[2][4];             // the gates' h half (+ bias) per tile
+    float cprev[2][4];          // previous cell state of this lane's outputs per tile
+    f32x4 xr[2];                // the tiles' band features in accumulator layout
+    auto load_time = [&](int l) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) Wt[g][ks] = wb.at_g(o.t_w[l] + ((g * S::NCT + ct) * KS1 + ks) * 64);
+            Wtb[g] = wb.at16_g(o.t_b[l] + g * HH + ct * 16);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSH; ++ks) Wf1[ks] = wb.at_g(o.tfc_w[l] + ks * 64);
+        Wf1b = wb.at16_g(o.tfc_b[l]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int ks = 0; ks < KSC; ++ks) Wip[j][ks] = wb.at_g(o.f_wih[l][ct] + (j * KSC + ks) * 64);
+            Wipb[j] = wb.at16_g(o.f_b[l][ct] + j * 16);
+        }
+    };
+    auto load_ffc = [&](int l) {
+#pragma unroll
+        for (int ks = 0; ks < 2 * KSH; ++ks) Wf2[ks] = wb.at_g(o.ffc_w[l] + ks * 64);
+        Wf2b = wb.at16_g(o.ffc_b[l]);
+    };
+    // the h half of layer l's time-LSTM gates for both tiles: state fragments straight from the state tensors
+    auto pre_gates = [&](int l) {
+        const float* hg = a.lstm + ((size_t)(2 * l) * a.B + b) * lsz;
+        const float* cg = hg + (size_t)a.B * lsz;
+        static_for<2>([&](auto T_) {
+            constexpr int T = decltype(T_)::value;
+            float af[KSH];
+            const float* hr = hg + ov_band<T>(li) * HH + lg;
+#pragma unroll
+            for (int ks = 0; ks < KSH; ++ks) af[ks] = hr[4 * ks];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cprev[T][r] = cg[ov_band<T>(4 * lg + r) * HH + 16 * ct + li];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) hh[T][g] = f32x4{Wtb[g], Wtb[g], Wtb[g], Wtb[g]};
+#pragma unroll
+            for (int ks = 0; ks < KSH; ++ks)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) hh[T][g] = FE_MFMA(af[ks], Wt[g][KSC + ks], hh[T][g]);
+        });
+    };
+    if (wave < 2) load_whh(0);
+    else load_time(0);
+    __syncthreads();
+
+    // ============================ STFT + compress (all 257 bins; models/bsrnn/model.py:430-436) ============================
+    {
+        const float* win = wp + o.window;
+        const float* xin = a.wav_in + (size_t)b * a.in_stride;
+        for (int n = tid; n < N; n += kThreads) {
+            const float v = (n < OVL) ? cst[n] : xin[n - OVL];
+            fb[n] = make_float2(v, 0.0f);
+            fa[n] = make_float2(v * win[n], 0.0f);
+        }
+        __syncthreads();
+        for (int m = tid; m < OVL; m += kThreads) cst[m] = fb[m + H].x;
+        __syncthreads();
+        float2* Xf = fft_lds<S, false>(fa, fb, tw);
+        for (int f = tid; f < kBins; f += kThreads) {
+            const float re = Xf[f].x, im = Xf[f].y;
+            const float g = pow_f(fmaxf(sqrtf(re * re + im * im), 1.0e-5f), a.compression - 1.0f);
+            sp[2 * f] = re * g;
+            sp[2 * f + 1] = im * g;
+        }
+    }
+    __syncthreads();
+    // ============================ band split (BandSplit.forward, :136-153; BN folded) ============================
+    for (int i = tid; i < kBands * C; i += kThreads) {
+        const int bb = i / C;
+        const float4* w4 = reinterpret_cast<const float4*>(wp + o.bs_w) + i;      // [k/4][band * C + c] float4: coalesced over the threads
+        float4 wv[kBsKP / 4];
+#pragma unroll
+        for (int k = 0; k < kBsKP / 4; ++k) wv[k] = w4[k * (kBands * C)];
+        const int s0 = bb == 0 ? 0 : (bb <= 10 ? 3 * bb - 1 : (bb <= 22 ? 8 * bb - 56 : 16 * bb - 240));
+        const float* s = sp + 2 * s0;
+        float a0 = wp[o.bs_b + i], a1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kBsKP / 4; ++k) {
+            a0 += wv[k].x * s[4 * k] + wv[k].z * s[4 * k + 2];
+            a1 += wv[k].y * s[4 * k + 1] + wv[k].w * s[4 * k + 3];
+        }
+        XB[bb * LDX + (i - bb * C)] = a0 + a1;
+    }
+    if (wave >= 2) pre_gates(0);
+    __syncthreads();
+
+    int* const f_prog = flg;            // [2]: 32 l + steps done, per direction
+    int* const f_hs = flg + 2;          // [2]: chains passed, per helper
+    int* const f_xp = flg + 4;          // layers whose input projections are complete
+
+    if (wave < 2) {
+        // ================================================ the scans ================================================
+        float* hb = Hb + d * (2 * HH);                                   // [2 buffers][HH]
+        float* ydump = Hb + 4 * HH + u;                                  // where the low lanes' (unused) h goes: no exec-masked region
+        const float act_m = half == 0 ? 2.0f : 1.0f, act_a = half == 0 ? -1.0f : 0.0f;      // second row: g (tanh) in the low half, o in the high half
+        const int band0 = d == 0 ? 0 : kBands - 1;
+        const int xd = d == 0 ? 128 : -128, yd = d == 0 ? LDY : -LDY;
+#pragma unroll 1
+        for (int l = 0; l < S::NLAY; ++l) {
+            ov_wait(f_xp, l + 1);
+            const float* xp = XPs + (l & 1) * L::XPBUF;
+            hb[lane] = 0.0f;                                             // h = 0, both buffers
+            float cs = 0.0f;
+            int xo = ((d * 32 + band0) * 64 + lane) * 2, yo = band0 * LDY + d * HH + u;
+            f32x2 xp_next = *reinterpret_cast<const f32x2*>(xp + xo);
+            auto steps = [&](int s0, int s1) {
+#pragma unroll 1
+                for (int s = s0; s < s1; ++s) {
+                    const int par = s & 1;
+                    const f32x2 xp_cur = xp_next;
+                    if (s + 1 < kBands) { xo += xd; xp_next = *reinterpret_cast<const f32x2*>(xp + xo); }
+                    const float4* hp4 = reinterpret_cast<const float4*>(hb + par * HH);
+                    float4 hq[HH / 4];
+#pragma unroll
+                    for (int k = 0; k < HH / 4; ++k) hq[k] = hp4[k];
+                    f32x2 p0 = {xp_cur.x, 0.0f}, p1 = {xp_cur.y, 0.0f};
+#pragma unroll
+                    for (int k = 0; k < HH / 4; ++k) {
+                        p0 += f32x2{W0[4 * k], W0[4 * k + 1]} * f32x2{hq[k].x, hq[k].y};
+                        p1 += f32x2{W1[4 * k], W1[4 * k + 1]} * f32x2{hq[k].x, hq[k].y};
+                        p0 += f32x2{W0[4 * k + 2], W0[4 * k + 3]} * f32x2{hq[k].z, hq[k].w};
+                        p1 += f32x2{W1[4 * k + 2], W1[4 * k + 3]} * f32x2{hq[k].z, hq[k].w};
+                    }
+                    const float a0 = p0.x + p0.y, a1 = p1.x + p1.y;
+                    const float s0v = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a0));                                   // low: i, high: f
+                    const float s1v = __builtin_fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a1)), act_m, act_a);      // low: g, high: o
+                    float x = s0v, y = s0v * s1v;                                    // low y: i * g
+                    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));       // x.hi <- y.lo: the high lanes hold i * g in x
+                    const float cn = __builtin_fmaf(s0v, cs, x);                     // high: f * c + i * g   (low lanes: bounded garbage)
+                    cs = cn;
+                    const float hn = s1v * (2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(K2 * cn)) - 1.0f);     // high: o * tanh(c)
+                    *(half ? hb + (par ^ 1) * HH + u : ydump) = hn;
+                    *(half ? Yf + yo : ydump) = hn;
+                    yo += yd;
+                }
+            };
+            steps(0, 23);
+            if (lane == 0) ov_signal(f_prog + d, 32 * l + 23);
+            steps(23, kBands);
+            if (lane == 0) ov_signal(f_prog + d, 32 * l + 31);
+            if (l + 1 < S::NLAY) load_whh(l + 1);                        // lands while the helpers finish tile B
+        }
+    } else {
+        // ================================================ the matrix-core work ================================================
+        const int me = wave - 2;
+        int nsync = 0;
+        // one tile's chain.  FREQ: starts with fc_freq of the finished layer; TIME: continues with the next layer's time part
+        auto chain = [&](auto T_, auto FREQ_, auto TIME_, int l, float* xpn) {
+            constexpr int T = decltype(T_)::value;
+            constexpr bool FREQ = decltype(FREQ_)::value, TIME = decltype(TIME_)::value;
+            const int arow = ov_band<T>(li);
+            int crow[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) crow[r] = ov_band<T>(4 * lg + r);
+            const bool cok3 = T == 1 || 4 * lg + 3 < 15;                  // (tile A: its last row is a pad row)
+            f32x4 x = xr[T];
+            if constexpr (FREQ) {
+                // fc_freq + residual (:389-390): x += Yf W^T + b
+                const float* ya = Yf + arow * LDY + lg;
+                f32x4 c0 = x + f32x4{Wf2b, Wf2b, Wf2b, Wf2b}, c1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                float af[2 * KSH];
+#pragma unroll
+                for (int ks = 0; ks < 2 * KSH; ++ks) af[ks] = ya[4 * ks];
+#pragma unroll
+                for (int ks = 0; ks < 2 * KSH; ks += 2) { c0 = FE_MFMA(af[ks], Wf2[ks], c0); c1 = FE_MFMA(af[ks + 1], Wf2[ks + 1], c1); }
+                x = c0 + c1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < 3 || cok3) XB[crow[r] * LDX + li] = x[r];
+            }
+            if constexpr (!TIME) { xr[T] = x; return; }
+            else {
+            // time-LSTM gates (LSTMCell over the bands; :371-381): the x half on top of the accumulated h half, gate math in the epilogue
+            f32x4 acc[4];
+            {
+                const float* xa = XB + arow * LDX + lg;
+                float af[KSC];
+#pragma unroll
+                for (int ks = 0; ks < KSC; ++ks) af[ks] = xa[4 * ks];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = hh[T][g];
+#pragma unroll
+                for (int ks = 0; ks < KSC; ++ks)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = FE_MFMA(af[ks], Wt[g][ks], acc[g]);
+            }
+            float hn[4], cn[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[0][r]));
+                const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[1][r]));
+                const float gg = 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[2][r])) - 1.0f;
+                const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[3][r]));
+                cn[r] = fg * cprev[T][r] + ig * gg;
+                hn[r] = og * tanh_f(cn[r]);
+                if (r < 3 || cok3) Hn[crow[r] * LDH + 16 * ct + li] = hn[r];
+            }
+            // rendezvous: both column halves of the new h are in LDS (and the partner has consumed its fragments of the old state)
+            ++nsync;
+            if (lane == 0) ov_signal(f_hs + me, nsync);
+            ov_wait(f_hs + (me ^ 1), nsync);
+            {
+                float* hg = a.lstm + ((size_t)(2 * l) * a.B + b) * lsz;
+                float* cg = hg + (size_t)a.B * lsz;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < 3 || cok3) { hg[crow[r] * HH + 16 * ct + li] = hn[r]; cg[crow[r] * HH + 16 * ct + li] = cn[r]; }
+            }
+            // fc_time + residual (:382-384): x += h' W^T + b
+            {
+                const float* ha = Hn + arow * LDH + lg;
+                float af[KSH];
+#pragma unroll
+                for (int ks = 0; ks < KSH; ++ks) af[ks] = ha[4 * ks];
+                f32x4 c0 = x + f32x4{Wf1b, Wf1b, Wf1b, Wf1b}, c1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int ks = 0; ks < KSH; ks += 2) { c0 = FE_MFMA(af[ks], Wf1[ks], c0); c1 = FE_MFMA(af[ks + 1], Wf1[ks + 1], c1); }
+                x = c0 + c1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < 3 || cok3) XA[crow[r] * LDX + li] = x[r];
+                xr[T] = x;
+            }
+            // band-LSTM input projections (:386-388) of direction ct: eight 16-row tiles of gate rows, stored in the scan's lane order
+            // [band][half * 32 + unit][slot]: gates (i, g) / (f, o) of a unit are the two slots of one lane
+            {
+                const float* xa = XA + arow * LDX + lg;
+                float af[KSC];
+#pragma unroll
+                for (int ks = 0; ks < KSC; ++ks) af[ks] = xa[4 * ks];
+                f32x4 pa[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pa[j] = f32x4{Wipb[j], Wipb[j], Wipb[j], Wipb[j]};
+#pragma unroll
+                for (int ks = 0; ks < KSC; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pa[j] = FE_MFMA(af[ks], Wip[j][ks], pa[j]);
+                // column tile j = 2 gate + unit half; gates g and g + 2 (tiles j and j + 4) share a lane
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int g = j >> 1, uh = j & 1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r < 3 || cok3)
+                            *reinterpret_cast<f32x2*>(xpn + ((ct * 32 + crow[r]) * 64 + g * 32 + 16 * uh + li) * 2) = f32x2{pa[j][r], pa[j + 4][r]};
+                }
+            }
+            }
+        };
+        using TA = std::integral_constant<int, 0>;
+        using TB = std::integral_constant<int, 1>;
+        // the tiles' band features after the band split
+        static_for<2>([&](auto T_) {
+            constexpr int T = decltype(T_)::value;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xr[T][r] = XB[ov_band<T>(4 * lg + r) * LDX + li];
+        });
+        // layer 0's time part: nothing to overlap it with
+        chain(TA{}, std::false_type{}, std::true_type{}, 0, XPs);
+        chain(TB{}, std::false_type{}, std::true_type{}, 0, XPs);
+        if (lane == 0) ov_signal(f_xp, 1);
+#pragma unroll 1
+        for (int l = 0; l < S::NLAY; ++l) {
+            const bool more = l + 1 < S::NLAY;
+            float* xpn = XPs + ((l + 1) & 1) * L::XPBUF;
+            // under the early steps of layer l's scans: this layer's fc_freq, the next layer's time part and the h half of its gates
+            load_ffc(l);
+            if (more) { load_time(l + 1); pre_gates(l + 1); }
+            ov_wait(f_prog, 32 * l + 23);
+            ov_wait(f_prog + 1, 32 * l + 23);
+            if (more) chain(TA{}, std::true_type{}, std::true_type{}, l + 1, xpn);
+            else chain(TA{}, std::true_type{}, std::false_type{}, l + 1, xpn);
+            ov_wait(f_prog, 32 * l + 31);
+            ov_wait(f_prog + 1, 32 * l + 31);
+            if (more) chain(TB{}, std::true_type{}, std::true_type{}, l + 1, xpn);
+            else chain(TB{}, std::true_type{}, std::false_type{}, l + 1, xpn);
+            if (more && lane == 0) ov_signal(f_xp, l + 2);
+        }
+    }
+    __syncthreads();
+    // hand-over to bsrnn_mlp_kernel / the PART 2 launch: band features after the last layer, the compressed spectrum
+    {
+        float* xg = a.mlp_x + (size_t)b * (kBands * C);
+        for (int i = tid; i < kBands * C; i += kThreads) { const int bb = i / C; xg[i] = XB[bb * LDX + (i - bb * C)]; }
+        float* sg = a.mlp_sp + (size_t)b * (2 * kBins);
+        for (int i = tid; i < 2 * kBins; i += kThreads) sg[i] = sp[i];
+    }
+}
+
+template <class S>
+void blaunch_ov(const BArgs& a, int grid, hipStream_t st, hipError_t* err) {
+    if constexpr (S::C == 16) {
+        auto* fn = &bsrnn_ov_kernel<S>;
+        static std::atomic<bool> attr_set[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!attr_set[dev].load(std::memory_order_relaxed)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BOvLds<S>::BYTES);
+            if (e != hipSuccess) { *err = e; return; }
+            attr_set[dev].store(true, std::memory_order_relaxed);
+        }
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), BOvLds<S>::BYTES, st, a);
+        *err = hipGetLastError();
+    } else {
+        *err = hipErrorInvalidValue;
+    }
+}
+
+}  // namespace fe
