@@ -1197,7 +1197,8 @@ void blaunch_split_impl(const BArgs& a, int max_wgs, hipStream_t st, hipError_t*
     // r5: at most one stream per CU and num_channels = 16 - the role-split PART 1 (bsrnn_ov_kernels.hip.h: the scans alone on two
     // waves, the layers' matrix-core work under them on the other two).  FE_BSRNN_OV=0: the phase-by-phase kernel, for A/B runs.
     static const bool ov_on = [] { const char* e = getenv("FE_BSRNN_OV"); return !(e && e[0] == '0'); }();
-    if (S::C == 16 && ov_on && a.B <= max_wgs) blaunch_ov<S>(a, a.B, st, err);
+    if (S::C == 16 && ov_on && a.B <= max_wgs && a.clk != nullptr) blaunch_ov<S, true>(a, a.B, st, err);      // (fe_profile_step with FE_BSRNN_OV_PROF=1)
+    else if (S::C == 16 && ov_on && a.B <= max_wgs) blaunch_ov<S>(a, a.B, st, err);
     else if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 1>(a, a.B < 2 * max_wgs ? a.B : 2 * max_wgs, st, err);
     else blaunch_part<S, false, 1>(a, a.B < max_wgs ? a.B : max_wgs, st, err);
     if (*err != hipSuccess) return;

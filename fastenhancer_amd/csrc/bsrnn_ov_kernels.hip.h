@@ -66,7 +66,9 @@ __device__ __forceinline__ int ov_band(int i) {
     else return i < 8 ? i : i + 15;
 }
 
-template <class S>
+// PROF: cycle probes of workgroup 0, sixteen per wave (clk[16 wave + i]; tools/gpu_phases_bsrnn_ov.py)
+#define OV_CLK(i) do { if constexpr (PROF) { if (blockIdx.x == 0 && lane == 0) a.clk[16 * wave + (i)] = __builtin_readcyclecounter(); } } while (0)
+template <class S, bool PROF = false>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) bsrnn_ov_kernel(BArgs a) {
     static_assert(S::C == 16 && S::HH == 32 && S::NFFT == 512, "the role-split kernel is built for num_channels = 16");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -103,6 +105,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     float* cst = a.cache_stft + (size_t)b * OVL;
     const size_t lsz = (size_t)kBands * HH;                      // one (h or c) tensor of a layer and stream
 
+    OV_CLK(0);
     for (int i = tid; i < N / 2; i += kThreads) tw[i] = reinterpret_cast<const float2*>(wp + o.twiddle)[i];
     if (tid < 16) flg[tid] = 0;
 
@@ -207,6 +210,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     }
     if (wave >= 2) pre_gates(0);
     __syncthreads();
+    OV_CLK(1);
 
     int* const f_prog = flg;            // [2]: 32 l + steps done, per direction
     int* const f_hs = flg + 2;          // [2]: chains passed, per helper
@@ -222,6 +226,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll 1
         for (int l = 0; l < S::NLAY; ++l) {
             ov_wait(f_xp, l + 1);
+            if (l == 0) OV_CLK(2);
+            if (l == 1) OV_CLK(5);
+            if (l == S::NLAY - 1) OV_CLK(7);
             const float* xp = XPs + (l & 1) * L::XPBUF;
             hb[lane] = 0.0f;                                             // h = 0, both buffers
             float cs = 0.0f;
@@ -260,8 +267,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             };
             steps(0, 23);
             if (lane == 0) ov_signal(f_prog + d, 32 * l + 23);
+            if (l == 0) OV_CLK(3);
             steps(23, kBands);
             if (lane == 0) ov_signal(f_prog + d, 32 * l + 31);
+            if (l == 0) OV_CLK(4);
+            if (l == 1) OV_CLK(6);
+            if (l == S::NLAY - 1) OV_CLK(8);
             if (l + 1 < S::NLAY) load_whh(l + 1);                        // lands while the helpers finish tile B
         }
     } else {
@@ -272,6 +283,13 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         auto chain = [&](auto T_, auto FREQ_, auto TIME_, int l, float* xpn) {
             constexpr int T = decltype(T_)::value;
             constexpr bool FREQ = decltype(FREQ_)::value, TIME = decltype(TIME_)::value;
+            // (PROF: the inside of tile B's chain under layer 0's scans, wave 2: slots 44-47, 60-63)
+            auto cclk = [&](int j) {
+                if constexpr (PROF && T == 1 && FREQ && TIME) {
+                    if (blockIdx.x == 0 && lane == 0 && wave == 2 && l == 1) a.clk[(j < 4 ? 44 : 56) + j] = __builtin_readcyclecounter();
+                }
+            };
+            cclk(0);
             const int arow = ov_band<T>(li);
             int crow[4];
 #pragma unroll
@@ -292,6 +310,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 for (int r = 0; r < 4; ++r)
                     if (r < 3 || cok3) XB[crow[r] * LDX + li] = x[r];
             }
+            cclk(1);
             if constexpr (!TIME) { xr[T] = x; return; }
             else {
             // time-LSTM gates (LSTMCell over the bands; :371-381): the x half on top of the accumulated h half, gate math in the epilogue
@@ -308,6 +327,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll
                     for (int g = 0; g < 4; ++g) acc[g] = FE_MFMA(af[ks], Wt[g][ks], acc[g]);
             }
+            cclk(2);
             float hn[4], cn[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -320,9 +340,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 if (r < 3 || cok3) Hn[crow[r] * LDH + 16 * ct + li] = hn[r];
             }
             // rendezvous: both column halves of the new h are in LDS (and the partner has consumed its fragments of the old state)
+            cclk(3);
             ++nsync;
             if (lane == 0) ov_signal(f_hs + me, nsync);
             ov_wait(f_hs + (me ^ 1), nsync);
+            cclk(4);
             {
                 float* hg = a.lstm + ((size_t)(2 * l) * a.B + b) * lsz;
                 float* cg = hg + (size_t)a.B * lsz;
@@ -345,6 +367,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     if (r < 3 || cok3) XA[crow[r] * LDX + li] = x[r];
                 xr[T] = x;
             }
+            cclk(5);
             // band-LSTM input projections (:386-388) of direction ct: eight 16-row tiles of gate rows, stored in the scan's lane order
             // [band][half * 32 + unit][slot]: gates (i, g) / (f, o) of a unit are the two slots of one lane
             {
@@ -359,6 +382,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 for (int ks = 0; ks < KSC; ++ks)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pa[j] = FE_MFMA(af[ks], Wip[j][ks], pa[j]);
+                cclk(6);
                 // column tile j = 2 gate + unit half; gates g and g + 2 (tiles j and j + 4) share a lane
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -369,6 +393,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                             *reinterpret_cast<f32x2*>(xpn + ((ct * 32 + crow[r]) * 64 + g * 32 + 16 * uh + li) * 2) = f32x2{pa[j][r], pa[j + 4][r]};
                 }
             }
+            cclk(7);
             }
         };
         using TA = std::integral_constant<int, 0>;
@@ -383,6 +408,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         chain(TA{}, std::false_type{}, std::true_type{}, 0, XPs);
         chain(TB{}, std::false_type{}, std::true_type{}, 0, XPs);
         if (lane == 0) ov_signal(f_xp, 1);
+        OV_CLK(2);
 #pragma unroll 1
         for (int l = 0; l < S::NLAY; ++l) {
             const bool more = l + 1 < S::NLAY;
@@ -390,18 +416,26 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             // under the early steps of layer l's scans: this layer's fc_freq, the next layer's time part and the h half of its gates
             load_ffc(l);
             if (more) { load_time(l + 1); pre_gates(l + 1); }
+            if (l == 0) OV_CLK(3);
             ov_wait(f_prog, 32 * l + 23);
             ov_wait(f_prog + 1, 32 * l + 23);
+            if (l == 0) OV_CLK(4);
             if (more) chain(TA{}, std::true_type{}, std::true_type{}, l + 1, xpn);
             else chain(TA{}, std::true_type{}, std::false_type{}, l + 1, xpn);
+            if (l == 0) OV_CLK(5);
             ov_wait(f_prog, 32 * l + 31);
             ov_wait(f_prog + 1, 32 * l + 31);
+            if (l == 0) OV_CLK(6);
+            if (l == S::NLAY - 1) OV_CLK(8);
             if (more) chain(TB{}, std::true_type{}, std::true_type{}, l + 1, xpn);
             else chain(TB{}, std::true_type{}, std::false_type{}, l + 1, xpn);
             if (more && lane == 0) ov_signal(f_xp, l + 2);
+            if (l == 0) OV_CLK(7);
+            if (l == S::NLAY - 1) OV_CLK(9);
         }
     }
     __syncthreads();
+    OV_CLK(10);
     // hand-over to bsrnn_mlp_kernel / the PART 2 launch: band features after the last layer, the compressed spectrum
     {
         float* xg = a.mlp_x + (size_t)b * (kBands * C);
@@ -409,12 +443,14 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         float* sg = a.mlp_sp + (size_t)b * (2 * kBins);
         for (int i = tid; i < 2 * kBins; i += kThreads) sg[i] = sp[i];
     }
+    OV_CLK(11);
 }
+#undef OV_CLK
 
-template <class S>
+template <class S, bool PROF = false>
 void blaunch_ov(const BArgs& a, int grid, hipStream_t st, hipError_t* err) {
     if constexpr (S::C == 16) {
-        auto* fn = &bsrnn_ov_kernel<S>;
+        auto* fn = &bsrnn_ov_kernel<S, PROF>;
         static std::atomic<bool> attr_set[64];
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
