@@ -79,6 +79,16 @@ struct BOffsets {
     int row_band;              // int[1028]: band of each layer-2 row
     int bin_row, bin_2sub;     // int[257]: first "a" row of a bin (its (re, im) pair), 2 * sub of its band (distance to the gate rows)
     int window, window_istft, twiddle;
+    int dft1, dft2, dft3, dft4;   // constant operands of the matrix-core DFT (fe::Dft, N = 512; r5: the role-split PART 1's STFT)
+    // r5, num_channels = 16: a layer's fragments regrouped for 16-byte fetches by the role-split PART 1 (bsrnn_ov_kernels.hip.h) - a
+    // wave-level load costs the vector-memory path ~16 cycles whatever its width, and a layer is 182 dword fragments per wave
+    int ov_t[8];               // time LSTM: [ct][gate][k-step / 4][lane][4]
+    int ov_tb[8];              // its bias: [ct][lane & 15][gate]
+    int ov_f1[8];              // fc_time: [k-step / 4][lane][4]
+    int ov_ip[8][2];           // input projections per direction: [column tile][lane][4 k-steps]
+    int ov_ipb[8][2];          // their bias: [lane & 15][column tile (8)]
+    int ov_f2[8];              // fc_freq: [k-step / 4][lane][4]
+    int ov_hh[8][2];           // W_hh in the scan's lane order: [row set (2)][k / 4][lane = half * 32 + unit][4]
     int total;
 };
 

@@ -28,7 +28,7 @@ struct BOvLds {
     static constexpr int TW = SP + 2 * kBins + 2;             // twiddles
     static constexpr int FA = TW + S::NFFT;                   // FFT ping-pong
     static constexpr int FB = FA + 2 * S::NFFT;
-    static constexpr int XB = FB + 2 * S::NFFT;               // [32][LDX] band features before a layer's time LSTM (after fc_freq)
+    static constexpr int XB = FB + 2 * S::NFFT;               // (FA: windowed frame, FB: spectrum {Re, Im} + Nyquist)   [32][LDX] band features before a layer's time LSTM (after fc_freq)
     static constexpr int XA = XB + 32 * S::LDX;               // [32][LDX] ... after fc_time (input of the projections and of fc_freq's residual)
     static constexpr int HN = XA + 32 * S::LDX;               // [32][LDH] the time LSTM's new h (A operand of fc_time)
     static constexpr int YF = HN + 32 * S::LDH;               // [32][LDY] band-LSTM outputs (fwd | bwd)
@@ -113,84 +113,130 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     // scans (waves 0, 1): lane = (half, unit): half 0 holds gate rows (i, g), half 1 (f, o) of unit u over the whole K
     const int d = wave & 1, u = lane & 31, half = lane >> 5;
     float W0[HH], W1[HH];
-    auto load_whh = [&](int l) {
-        const float* wr = wp + o.f_whh[l][d] + 4 * u + half;       // packed [k][4 u + gate] per direction (gate order i, f, g, o)
+    const int lane16 = lane * 16;                                   // bytes: this lane's 16-byte piece of a regrouped fragment set
+    auto ld4 = [&](int off_floats) { return wb.at_gv4(off_floats, lane16); };
+    auto load_whh = [&](int l) {                                    // BOffsets::ov_hh: [row set][k / 4][lane][4]
 #pragma unroll
-        for (int k = 0; k < HH; ++k) { W0[k] = wr[k * 128]; W1[k] = wr[k * 128 + 2]; }
+        for (int q = 0; q < HH / 4; ++q) {
+            const f32x4 v0 = ld4(o.ov_hh[l][d] + q * 256), v1 = ld4(o.ov_hh[l][d] + (HH / 4 + q) * 256);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { W0[4 * q + j] = v0[j]; W1[4 * q + j] = v1[j]; }
+        }
     };
-    // helpers (waves 2, 3): hidden tile ct of the time-LSTM gates, direction ct of the projections
+    // matrix-core work: hidden tile ct of the time-LSTM gates, direction ct of the projections (a pair of waves = ct 0, 1)
     const int ct = wave & 1;
     float Wt[4][KS1], Wtb[4], Wf1[KSH], Wf1b = 0.0f, Wf2[2 * KSH], Wf2b = 0.0f, Wip[8][KSC], Wipb[8];
     f32x4 hh[2][4];             // the gates' h half (+ bias) per tile
     float cprev[2][4];          // previous cell state of this lane's outputs per tile
     f32x4 xr[2];                // the tiles' band features in accumulator layout
+    auto load_proj = [&](int l, auto J0_, auto NJ_) {               // projection column-tile pairs (j, j + 4), j = J0 .. J0 + NJ - 1
+        constexpr int J0 = decltype(J0_)::value, NJ = decltype(NJ_)::value;
+        static_assert(KSC == 4, "one 16-byte fetch per column tile");
+#pragma unroll
+        for (int jj = 0; jj < 2 * NJ; ++jj) {
+            const int j = J0 + (jj < NJ ? jj : jj - NJ + 4);
+            const f32x4 v = ld4(o.ov_ip[l][ct] + j * 256);
+#pragma unroll
+            for (int ks = 0; ks < KSC; ++ks) Wip[j][ks] = v[ks];
+        }
+        const f32x4 b0 = wb.at_gv4(o.ov_ipb[l][ct], li * 32), b1 = wb.at_gv4(o.ov_ipb[l][ct] + 4, li * 32);
+#pragma unroll
+        for (int jj = 0; jj < 2 * NJ; ++jj) {
+            const int j = J0 + (jj < NJ ? jj : jj - NJ + 4);
+            Wipb[j] = j < 4 ? b0[j & 3] : b1[j & 3];
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I2 = std::integral_constant<int, 2>;
+    using I4 = std::integral_constant<int, 4>;
     auto load_time = [&](int l) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) Wt[g][ks] = wb.at_g(o.t_w[l] + ((g * S::NCT + ct) * KS1 + ks) * 64);
-            Wtb[g] = wb.at16_g(o.t_b[l] + g * HH + ct * 16);
+            for (int q = 0; q < KS1 / 4; ++q) {
+                const f32x4 v = ld4(o.ov_t[l] + ((ct * 4 + g) * (KS1 / 4) + q) * 256);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Wt[g][4 * q + j] = v[j];
+            }
+        {
+            const f32x4 v = wb.at_gv4(o.ov_tb[l] + ct * 64, li * 16);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) Wtb[g] = v[g];
         }
 #pragma unroll
-        for (int ks = 0; ks < KSH; ++ks) Wf1[ks] = wb.at_g(o.tfc_w[l] + ks * 64);
+        for (int q = 0; q < KSH / 4; ++q) {
+            const f32x4 v = ld4(o.ov_f1[l] + q * 256);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Wf1[4 * q + j] = v[j];
+        }
         Wf1b = wb.at16_g(o.tfc_b[l]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#pragma unroll
-            for (int ks = 0; ks < KSC; ++ks) Wip[j][ks] = wb.at_g(o.f_wih[l][ct] + (j * KSC + ks) * 64);
-            Wipb[j] = wb.at16_g(o.f_b[l][ct] + j * 16);
-        }
+        load_proj(l, I0{}, I4{});
     };
     auto load_ffc = [&](int l) {
 #pragma unroll
-        for (int ks = 0; ks < 2 * KSH; ++ks) Wf2[ks] = wb.at_g(o.ffc_w[l] + ks * 64);
+        for (int q = 0; q < 2 * KSH / 4; ++q) {
+            const f32x4 v = ld4(o.ov_f2[l] + q * 256);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Wf2[4 * q + j] = v[j];
+        }
         Wf2b = wb.at16_g(o.ffc_b[l]);
     };
-    // the h half of layer l's time-LSTM gates for both tiles: state fragments straight from the state tensors
-    auto pre_gates = [&](int l) {
+    // the h half of layer l's time-LSTM gates for tile T: state fragments straight from the state tensors
+    auto pre_gates = [&](int l, auto T_) {
+        constexpr int T = decltype(T_)::value;
         const float* hg = a.lstm + ((size_t)(2 * l) * a.B + b) * lsz;
         const float* cg = hg + (size_t)a.B * lsz;
-        static_for<2>([&](auto T_) {
-            constexpr int T = decltype(T_)::value;
-            float af[KSH];
-            const float* hr = hg + ov_band<T>(li) * HH + lg;
+        float af[KSH];
+        const float* hr = hg + ov_band<T>(li) * HH + lg;
 #pragma unroll
-            for (int ks = 0; ks < KSH; ++ks) af[ks] = hr[4 * ks];
+        for (int ks = 0; ks < KSH; ++ks) af[ks] = hr[4 * ks];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) cprev[T][r] = cg[ov_band<T>(4 * lg + r) * HH + 16 * ct + li];
+        for (int r = 0; r < 4; ++r) cprev[T][r] = cg[ov_band<T>(4 * lg + r) * HH + 16 * ct + li];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) hh[T][g] = f32x4{Wtb[g], Wtb[g], Wtb[g], Wtb[g]};
+        for (int g = 0; g < 4; ++g) hh[T][g] = f32x4{Wtb[g], Wtb[g], Wtb[g], Wtb[g]};
 #pragma unroll
-            for (int ks = 0; ks < KSH; ++ks)
+        for (int ks = 0; ks < KSH; ++ks)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) hh[T][g] = FE_MFMA(af[ks], Wt[g][KSC + ks], hh[T][g]);
-        });
+            for (int g = 0; g < 4; ++g) hh[T][g] = FE_MFMA(af[ks], Wt[g][KSC + ks], hh[T][g]);
     };
-    if (wave < 2) load_whh(0);
-    else load_time(0);
+    using TA = std::integral_constant<int, 0>;
+    using TB = std::integral_constant<int, 1>;
     __syncthreads();
 
     // ============================ STFT + compress (all 257 bins; models/bsrnn/model.py:430-436) ============================
+    // The transform runs on the matrix cores (fe::Dft: two chained GEMM stages per wave, one barrier) instead of nine radix-2 passes
     {
+        using D = Dft<S, 3>;
+        float* xw = smem + L::FA;                  // windowed frame [N]
+        float* Xs = smem + L::FB;                  // {Re[N/2], Im[N/2]}, then the Nyquist bin {Re, Im}
         const float* win = wp + o.window;
         const float* xin = a.wav_in + (size_t)b * a.in_stride;
-        for (int n = tid; n < N; n += kThreads) {
-            const float v = (n < OVL) ? cst[n] : xin[n - OVL];
-            fb[n] = make_float2(v, 0.0f);
-            fa[n] = make_float2(v * win[n], 0.0f);
-        }
-        __syncthreads();
-        for (int m = tid; m < OVL; m += kThreads) cst[m] = fb[m + H].x;
-        __syncthreads();
-        float2* Xf = fft_lds<S, false>(fa, fb, tw);
+        constexpr int NPT = N / kThreads;
+        float fv[NPT];
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) { const int n = tid + q * kThreads; fv[q] = (n < OVL) ? cst[n] : xin[n - OVL]; }
+        typename D::FwdConst dc;
+        D::load(dc, wb, o, wave);
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) { const int n = tid + q * kThreads; xw[n] = fv[q] * win[n]; }
+        __syncthreads();                           // (every read of the old cache has landed)
+        if (wave == 0) OV_CLK(12);
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) { const int n = tid + q * kThreads; if (n >= H) cst[n - H] = fv[q]; }      // cache' = frame[H:]
+        // layer 0's weights: requested behind the frame, in flight across the transform and the band split
+        if (wave < 2) load_whh(0);
+        load_time(0);
+        D::template forward<true>(xw, Xs, tw, dc, wave, lane, Xs + N);
+        if (wave == 0) OV_CLK(13);
         for (int f = tid; f < kBins; f += kThreads) {
-            const float re = Xf[f].x, im = Xf[f].y;
+            const float re = f < N / 2 ? Xs[f] : Xs[N], im = f < N / 2 ? Xs[N / 2 + f] : Xs[N + 1];
             const float g = pow_f(fmaxf(sqrtf(re * re + im * im), 1.0e-5f), a.compression - 1.0f);
             sp[2 * f] = re * g;
             sp[2 * f + 1] = im * g;
         }
     }
     __syncthreads();
+    if (wave == 0) OV_CLK(14);
     // ============================ band split (BandSplit.forward, :136-153; BN folded) ============================
     for (int i = tid; i < kBands * C; i += kThreads) {
         const int bb = i / C;
@@ -208,13 +254,146 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         }
         XB[bb * LDX + (i - bb * C)] = a0 + a1;
     }
-    if (wave >= 2) pre_gates(0);
+    if (wave == 0) OV_CLK(15);
+    // layer 0's time part has nothing to hide under: tile A on waves 0, 1, tile B on waves 2, 3
+    if (wave < 2) pre_gates(0, TA{});
+    else pre_gates(0, TB{});
     __syncthreads();
     OV_CLK(1);
 
     int* const f_prog = flg;            // [2]: 32 l + steps done, per direction
-    int* const f_hs = flg + 2;          // [2]: chains passed, per helper
-    int* const f_xp = flg + 4;          // layers whose input projections are complete
+    int* const f_hs = flg + 2;          // [2 pairs][2]: chains passed, per wave of a pair
+    int* const f_xa = flg + 6;          // [2]: helper ct has stored tile B's x of layer f_xa (input of the scans' share of the projections)
+    int* const f_xpd = flg + 8;         // [2]: layers whose tile-B projections helper ct has completed (its share)
+    int* const f_xpa = flg + 10;        // [2]: layers whose tile-A projections helper ct has completed
+
+    // projection column-tile pairs (j, j + 4), j = J0 .. J0 + NJ - 1, of direction ct for tile T: 16-row tiles of gate rows, stored in the
+    // scan's lane order [band][half * 32 + unit][slot] - gates (i, g) / (f, o) of a unit are the two slots of one lane (:386-388)
+    auto proj = [&](auto T_, auto J0_, auto NJ_, float* xpn) {
+        constexpr int T = decltype(T_)::value, J0 = decltype(J0_)::value, NJ = decltype(NJ_)::value;
+        const float* xa = XA + ov_band<T>(li) * LDX + lg;
+        float af[KSC];
+#pragma unroll
+        for (int ks = 0; ks < KSC; ++ks) af[ks] = xa[4 * ks];
+        f32x4 pa[2 * NJ];
+#pragma unroll
+        for (int jj = 0; jj < 2 * NJ; ++jj) { const float bv = Wipb[J0 + (jj < NJ ? jj : jj - NJ + 4)]; pa[jj] = f32x4{bv, bv, bv, bv}; }
+#pragma unroll
+        for (int ks = 0; ks < KSC; ++ks)
+#pragma unroll
+            for (int jj = 0; jj < 2 * NJ; ++jj) pa[jj] = FE_MFMA(af[ks], Wip[J0 + (jj < NJ ? jj : jj - NJ + 4)][ks], pa[jj]);
+        float* dst = xpn + ((ct * 32) * 64 + li) * 2;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int j = J0 + jj, g = j >> 1, uh = j & 1;           // column tile j = 2 gate + unit half
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (T == 1 || r < 3 || 4 * lg + 3 < 15)
+                    *reinterpret_cast<f32x2*>(dst + (ov_band<T>(4 * lg + r) * 64 + g * 32 + 16 * uh) * 2) = f32x2{pa[jj][r], pa[jj + NJ][r]};
+        }
+    };
+
+    int nsync = 0;
+    // One tile's chain on a pair of waves.  FREQ: starts with fc_freq of the finished layer; TIME: continues with layer l's time part;
+    // PSPLIT: the scans take half of the tile's projections (tile B in the steady state: the scans have ended, their waves are free)
+    auto chain = [&](auto T_, auto FREQ_, auto TIME_, auto PSPLIT_, auto DOPROJ_, int l, float* xpn, int pair) {
+        constexpr int T = decltype(T_)::value;
+        constexpr bool FREQ = decltype(FREQ_)::value, TIME = decltype(TIME_)::value, PSPLIT = decltype(PSPLIT_)::value, DOPROJ = decltype(DOPROJ_)::value;
+        // (PROF: the inside of tile B's chain under layer 0's scans, wave 2: slots 44-47, 60-63)
+        auto cclk = [&](int j) {
+            if constexpr (PROF && T == 1 && FREQ && TIME) {
+                if (blockIdx.x == 0 && lane == 0 && wave == 2 && l == 1) a.clk[(j < 4 ? 44 : 56) + j] = __builtin_readcyclecounter();
+            }
+        };
+        cclk(0);
+        const int arow = ov_band<T>(li);
+        int crow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) crow[r] = ov_band<T>(4 * lg + r);
+        const bool cok3 = T == 1 || 4 * lg + 3 < 15;                  // (tile A: its last row is a pad row)
+        f32x4 x = xr[T];
+        if constexpr (FREQ) {
+            // fc_freq + residual (:389-390): x += Yf W^T + b
+            const float* ya = Yf + arow * LDY + lg;
+            f32x4 c0 = x + f32x4{Wf2b, Wf2b, Wf2b, Wf2b}, c1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            float af[2 * KSH];
+#pragma unroll
+            for (int ks = 0; ks < 2 * KSH; ++ks) af[ks] = ya[4 * ks];
+#pragma unroll
+            for (int ks = 0; ks < 2 * KSH; ks += 2) { c0 = FE_MFMA(af[ks], Wf2[ks], c0); c1 = FE_MFMA(af[ks + 1], Wf2[ks + 1], c1); }
+            x = c0 + c1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < 3 || cok3) XB[crow[r] * LDX + li] = x[r];
+        }
+        cclk(1);
+        if constexpr (!TIME) { xr[T] = x; return; }
+        else {
+        // time-LSTM gates (LSTMCell over the bands; :371-381): the x half on top of the accumulated h half, gate math in the epilogue
+        f32x4 acc[4];
+        {
+            const float* xa = XB + arow * LDX + lg;
+            float af[KSC];
+#pragma unroll
+            for (int ks = 0; ks < KSC; ++ks) af[ks] = xa[4 * ks];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = hh[T][g];
+#pragma unroll
+            for (int ks = 0; ks < KSC; ++ks)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = FE_MFMA(af[ks], Wt[g][ks], acc[g]);
+        }
+        cclk(2);
+        float hn[4], cn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[0][r]));
+            const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[1][r]));
+            const float gg = 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[2][r])) - 1.0f;
+            const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[3][r]));
+            cn[r] = fg * cprev[T][r] + ig * gg;
+            hn[r] = og * (2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(K2 * cn[r])) - 1.0f);
+            if (r < 3 || cok3) Hn[crow[r] * LDH + 16 * ct + li] = hn[r];
+        }
+        cclk(3);
+        // rendezvous: both column halves of the new h are in LDS (and the partner has consumed its fragments of the old state)
+        ++nsync;
+        if (lane == 0) ov_signal(f_hs + 2 * pair + ct, nsync);
+        ov_wait(f_hs + 2 * pair + (ct ^ 1), nsync);
+        cclk(4);
+        {
+            // the layer's new (h, c) -> the state tensors (after the rendezvous: the partner's fragments of the old state are consumed)
+            float* hg = a.lstm + ((size_t)(2 * l) * a.B + b) * lsz;
+            float* cg = hg + (size_t)a.B * lsz;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < 3 || cok3) { hg[crow[r] * HH + 16 * ct + li] = hn[r]; cg[crow[r] * HH + 16 * ct + li] = cn[r]; }
+        }
+        // fc_time + residual (:382-384): x += h' W^T + b
+        {
+            const float* ha = Hn + arow * LDH + lg;
+            float af[KSH];
+#pragma unroll
+            for (int ks = 0; ks < KSH; ++ks) af[ks] = ha[4 * ks];
+            f32x4 c0 = x + f32x4{Wf1b, Wf1b, Wf1b, Wf1b}, c1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int ks = 0; ks < KSH; ks += 2) { c0 = FE_MFMA(af[ks], Wf1[ks], c0); c1 = FE_MFMA(af[ks + 1], Wf1[ks + 1], c1); }
+            x = c0 + c1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < 3 || cok3) XA[crow[r] * LDX + li] = x[r];
+            xr[T] = x;
+        }
+        if constexpr (PSPLIT) { if (lane == 0) ov_signal(f_xa + ct, l); }
+        cclk(5);
+        if constexpr (DOPROJ) {
+            if constexpr (PSPLIT) proj(T_, I2{}, I2{}, xpn);
+            else proj(T_, I0{}, I4{}, xpn);
+        }
+        cclk(6);
+        cclk(7);
+        }
+    };
 
     if (wave < 2) {
         // ================================================ the scans ================================================
@@ -223,9 +402,13 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         const float act_m = half == 0 ? 2.0f : 1.0f, act_a = half == 0 ? -1.0f : 0.0f;      // second row: g (tanh) in the low half, o in the high half
         const int band0 = d == 0 ? 0 : kBands - 1;
         const int xd = d == 0 ? 128 : -128, yd = d == 0 ? LDY : -LDY;
+        // layer 0, tile A
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xr[0][r] = XB[ov_band<0>(4 * lg + r) * LDX + li];
+        chain(TA{}, std::false_type{}, std::true_type{}, std::false_type{}, std::true_type{}, 0, XPs, 1);
 #pragma unroll 1
         for (int l = 0; l < S::NLAY; ++l) {
-            ov_wait(f_xp, l + 1);
+            ov_wait(f_xpd + d, l + 1);
             if (l == 0) OV_CLK(2);
             if (l == 1) OV_CLK(5);
             if (l == S::NLAY - 1) OV_CLK(7);
@@ -265,7 +448,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     yo += yd;
                 }
             };
-            steps(0, 23);
+            steps(0, 8);
+            if (l > 0) ov_wait(f_xpa + d, l + 1);                       // bands 8..22 come next: tile A's projections (normally long there)
+            steps(8, 23);
             if (lane == 0) ov_signal(f_prog + d, 32 * l + 23);
             if (l == 0) OV_CLK(3);
             steps(23, kBands);
@@ -273,141 +458,21 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             if (l == 0) OV_CLK(4);
             if (l == 1) OV_CLK(6);
             if (l == S::NLAY - 1) OV_CLK(8);
-            if (l + 1 < S::NLAY) load_whh(l + 1);                        // lands while the helpers finish tile B
+            if (l + 1 < S::NLAY) {
+                // the helpers are on tile B's chain: fetch the next layer's W_hh and this wave's half of tile B's projections
+                // (column-tile pairs 0, 1 of its own direction), computed as soon as helper d has stored the tile's x
+                load_whh(l + 1);
+                load_proj(l + 1, I0{}, I2{});
+                ov_wait(f_xa + d, l + 1);
+                proj(TB{}, I0{}, I2{}, XPs + ((l + 1) & 1) * L::XPBUF);
+            }
         }
     } else {
         // ================================================ the matrix-core work ================================================
-        const int me = wave - 2;
-        int nsync = 0;
-        // one tile's chain.  FREQ: starts with fc_freq of the finished layer; TIME: continues with the next layer's time part
-        auto chain = [&](auto T_, auto FREQ_, auto TIME_, int l, float* xpn) {
-            constexpr int T = decltype(T_)::value;
-            constexpr bool FREQ = decltype(FREQ_)::value, TIME = decltype(TIME_)::value;
-            // (PROF: the inside of tile B's chain under layer 0's scans, wave 2: slots 44-47, 60-63)
-            auto cclk = [&](int j) {
-                if constexpr (PROF && T == 1 && FREQ && TIME) {
-                    if (blockIdx.x == 0 && lane == 0 && wave == 2 && l == 1) a.clk[(j < 4 ? 44 : 56) + j] = __builtin_readcyclecounter();
-                }
-            };
-            cclk(0);
-            const int arow = ov_band<T>(li);
-            int crow[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) crow[r] = ov_band<T>(4 * lg + r);
-            const bool cok3 = T == 1 || 4 * lg + 3 < 15;                  // (tile A: its last row is a pad row)
-            f32x4 x = xr[T];
-            if constexpr (FREQ) {
-                // fc_freq + residual (:389-390): x += Yf W^T + b
-                const float* ya = Yf + arow * LDY + lg;
-                f32x4 c0 = x + f32x4{Wf2b, Wf2b, Wf2b, Wf2b}, c1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                float af[2 * KSH];
-#pragma unroll
-                for (int ks = 0; ks < 2 * KSH; ++ks) af[ks] = ya[4 * ks];
-#pragma unroll
-                for (int ks = 0; ks < 2 * KSH; ks += 2) { c0 = FE_MFMA(af[ks], Wf2[ks], c0); c1 = FE_MFMA(af[ks + 1], Wf2[ks + 1], c1); }
-                x = c0 + c1;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < 3 || cok3) XB[crow[r] * LDX + li] = x[r];
-            }
-            cclk(1);
-            if constexpr (!TIME) { xr[T] = x; return; }
-            else {
-            // time-LSTM gates (LSTMCell over the bands; :371-381): the x half on top of the accumulated h half, gate math in the epilogue
-            f32x4 acc[4];
-            {
-                const float* xa = XB + arow * LDX + lg;
-                float af[KSC];
-#pragma unroll
-                for (int ks = 0; ks < KSC; ++ks) af[ks] = xa[4 * ks];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = hh[T][g];
-#pragma unroll
-                for (int ks = 0; ks < KSC; ++ks)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[g] = FE_MFMA(af[ks], Wt[g][ks], acc[g]);
-            }
-            cclk(2);
-            float hn[4], cn[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[0][r]));
-                const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[1][r]));
-                const float gg = 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[2][r])) - 1.0f;
-                const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[3][r]));
-                cn[r] = fg * cprev[T][r] + ig * gg;
-                hn[r] = og * tanh_f(cn[r]);
-                if (r < 3 || cok3) Hn[crow[r] * LDH + 16 * ct + li] = hn[r];
-            }
-            // rendezvous: both column halves of the new h are in LDS (and the partner has consumed its fragments of the old state)
-            cclk(3);
-            ++nsync;
-            if (lane == 0) ov_signal(f_hs + me, nsync);
-            ov_wait(f_hs + (me ^ 1), nsync);
-            cclk(4);
-            {
-                float* hg = a.lstm + ((size_t)(2 * l) * a.B + b) * lsz;
-                float* cg = hg + (size_t)a.B * lsz;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < 3 || cok3) { hg[crow[r] * HH + 16 * ct + li] = hn[r]; cg[crow[r] * HH + 16 * ct + li] = cn[r]; }
-            }
-            // fc_time + residual (:382-384): x += h' W^T + b
-            {
-                const float* ha = Hn + arow * LDH + lg;
-                float af[KSH];
-#pragma unroll
-                for (int ks = 0; ks < KSH; ++ks) af[ks] = ha[4 * ks];
-                f32x4 c0 = x + f32x4{Wf1b, Wf1b, Wf1b, Wf1b}, c1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int ks = 0; ks < KSH; ks += 2) { c0 = FE_MFMA(af[ks], Wf1[ks], c0); c1 = FE_MFMA(af[ks + 1], Wf1[ks + 1], c1); }
-                x = c0 + c1;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < 3 || cok3) XA[crow[r] * LDX + li] = x[r];
-                xr[T] = x;
-            }
-            cclk(5);
-            // band-LSTM input projections (:386-388) of direction ct: eight 16-row tiles of gate rows, stored in the scan's lane order
-            // [band][half * 32 + unit][slot]: gates (i, g) / (f, o) of a unit are the two slots of one lane
-            {
-                const float* xa = XA + arow * LDX + lg;
-                float af[KSC];
-#pragma unroll
-                for (int ks = 0; ks < KSC; ++ks) af[ks] = xa[4 * ks];
-                f32x4 pa[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pa[j] = f32x4{Wipb[j], Wipb[j], Wipb[j], Wipb[j]};
-#pragma unroll
-                for (int ks = 0; ks < KSC; ++ks)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pa[j] = FE_MFMA(af[ks], Wip[j][ks], pa[j]);
-                cclk(6);
-                // column tile j = 2 gate + unit half; gates g and g + 2 (tiles j and j + 4) share a lane
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int g = j >> 1, uh = j & 1;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (r < 3 || cok3)
-                            *reinterpret_cast<f32x2*>(xpn + ((ct * 32 + crow[r]) * 64 + g * 32 + 16 * uh + li) * 2) = f32x2{pa[j][r], pa[j + 4][r]};
-                }
-            }
-            cclk(7);
-            }
-        };
-        using TA = std::integral_constant<int, 0>;
-        using TB = std::integral_constant<int, 1>;
-        // the tiles' band features after the band split
-        static_for<2>([&](auto T_) {
-            constexpr int T = decltype(T_)::value;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) xr[T][r] = XB[ov_band<T>(4 * lg + r) * LDX + li];
-        });
-        // layer 0's time part: nothing to overlap it with
-        chain(TA{}, std::false_type{}, std::true_type{}, 0, XPs);
-        chain(TB{}, std::false_type{}, std::true_type{}, 0, XPs);
-        if (lane == 0) ov_signal(f_xp, 1);
+        for (int r = 0; r < 4; ++r) xr[1][r] = XB[ov_band<1>(4 * lg + r) * LDX + li];
+        chain(TB{}, std::false_type{}, std::true_type{}, std::false_type{}, std::true_type{}, 0, XPs, 0);
+        if (lane == 0) ov_signal(f_xpd + ct, 1);
         OV_CLK(2);
 #pragma unroll 1
         for (int l = 0; l < S::NLAY; ++l) {
@@ -415,21 +480,31 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             float* xpn = XPs + ((l + 1) & 1) * L::XPBUF;
             // under the early steps of layer l's scans: this layer's fc_freq, the next layer's time part and the h half of its gates
             load_ffc(l);
-            if (more) { load_time(l + 1); pre_gates(l + 1); }
+            if (more) { load_time(l + 1); pre_gates(l + 1, TA{}); pre_gates(l + 1, TB{}); }
             if (l == 0) OV_CLK(3);
             ov_wait(f_prog, 32 * l + 23);
             ov_wait(f_prog + 1, 32 * l + 23);
+            if (l == 0) {         // (tile A's x after layer 0's time part was computed by the scan waves)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xr[0][r] = XA[ov_band<0>(4 * lg + r) * LDX + li];
+            }
             if (l == 0) OV_CLK(4);
-            if (more) chain(TA{}, std::true_type{}, std::true_type{}, l + 1, xpn);
-            else chain(TA{}, std::true_type{}, std::false_type{}, l + 1, xpn);
+            // tile A up to its x after fc_time: its projections are not needed before step 8 of the next layer's scans and wait until
+            // tile B's chain - the only serial piece - is through
+            if (more) chain(TA{}, std::true_type{}, std::true_type{}, std::false_type{}, std::false_type{}, l + 1, xpn, 0);
+            else chain(TA{}, std::true_type{}, std::false_type{}, std::false_type{}, std::false_type{}, l + 1, xpn, 0);
             if (l == 0) OV_CLK(5);
             ov_wait(f_prog, 32 * l + 31);
             ov_wait(f_prog + 1, 32 * l + 31);
             if (l == 0) OV_CLK(6);
             if (l == S::NLAY - 1) OV_CLK(8);
-            if (more) chain(TB{}, std::true_type{}, std::true_type{}, l + 1, xpn);
-            else chain(TB{}, std::true_type{}, std::false_type{}, l + 1, xpn);
-            if (more && lane == 0) ov_signal(f_xp, l + 2);
+            if (more) chain(TB{}, std::true_type{}, std::true_type{}, std::true_type{}, std::true_type{}, l + 1, xpn, 0);
+            else chain(TB{}, std::true_type{}, std::false_type{}, std::false_type{}, std::false_type{}, l + 1, xpn, 0);
+            if (more && lane == 0) ov_signal(f_xpd + ct, l + 2);
+            if (more) {
+                proj(TA{}, I0{}, I4{}, xpn);                  // under steps 0..7 of layer l + 1's scans
+                if (lane == 0) ov_signal(f_xpa + ct, l + 2);
+            }
             if (l == 0) OV_CLK(7);
             if (l == S::NLAY - 1) OV_CLK(9);
         }

@@ -313,6 +313,43 @@ struct Packer {
     }
 };
 
+// constant operands of the matrix-core DFT (fe::Dft in fe_kernels.hip.h), N = N1 * 32, at the four given offsets of p.buf
+void pack_dft_constants(Packer& p, int N, int dft1, int dft2, int dft3, int dft4) {
+    {
+        const int N1 = N / 32, KC = N1 / 2, MT = N1 / 16;
+        auto c32 = [](int a, int b) { return std::cos(2.0 * M_PI * (double)((a * b) % 32) / 32.0); };
+        auto s32 = [](int a, int b) { return std::sin(2.0 * M_PI * (double)((a * b) % 32) / 32.0); };
+        auto c1 = [&](int a, int b) { return std::cos(2.0 * M_PI * (double)((a * b) % N1) / (double)N1); };
+        auto s1 = [&](int a, int b) { return std::sin(2.0 * M_PI * (double)((a * b) % N1) / (double)N1); };
+        for (int q = 0; q < 2; ++q) {
+            // forward, 32-point stage: B[k = n2][n = k2] = Re (q = 0) / Im (q = 1) of W_32^(n2 k2)
+            p.pack_b(dft1 + q * (2 * 8 * 64), 32, 32, [&](int k, int n) { return (float)(q == 0 ? c32(k, n) : -s32(k, n)); });
+            // forward, N1-point stage, output half q: A[m = k1][k-step a*4MT + 4i + r, lane group lg]  <->  half a of
+            // G', row n1 = 16 i + 4 lg + r:   Re X: [cos | sin],  Im X: [-sin | cos]
+            p.pack_a(dft2 + q * (KC * 64), 16, 2 * N1, [&](int m, int k) {
+                const int ks = k / 4, lg = k % 4, a = ks / (4 * MT), i = (ks % (4 * MT)) / 4, r = ks % 4;
+                const int n1 = 16 * i + 4 * lg + r;
+                if (q == 0) return (float)(a ? s1(m, n1) : c1(m, n1));
+                return (float)(a ? c1(m, n1) : -s1(m, n1));
+            });
+            // inverse, N1-point stage (transposed), half q of H: B[k = (b, k1)][n = n1]:  Re H: [cos | -sin],  Im H: [sin | cos]
+            p.pack_b(dft3 + q * (MT * KC * 64), 2 * N1, N1, [&](int k, int n) {
+                const int b = k / N1, k1 = k % N1;
+                if (q == 0) return (float)(b ? -s1(n, k1) : c1(n, k1));
+                return (float)(b ? c1(n, k1) : s1(n, k1));
+            });
+            // inverse, 32-point stage (with the 1/N of irfft), per wave (p = q, jt): B[k-step a*4 + r, lane group lg][n = li]
+            // <-> half a of H', k2 = 16 jt + 4 lg + r, output sample column n2 = 16 p + li:  cos / N (a = 0), -sin / N (a = 1)
+            for (int jt = 0; jt < 2; ++jt)
+                p.pack_b(dft4 + (q * 2 + jt) * (8 * 64), 32, 16, [&](int k, int n) {
+                    const int ks = k / 4, lg = k % 4, a = ks / 4, r = ks % 4;
+                    const int k2 = 16 * jt + 4 * lg + r, n2 = 16 * q + n;
+                    return (float)((a ? -s32(k2, n2) : c32(k2, n2)) / (double)N);
+                });
+        }
+    }
+}
+
 const float* sec(const fe_handle* h, const std::vector<float>& blob, const std::string& name) {
     for (const Section& s : h->sections)
         if (s.name == name) return blob.data() + s.offset;
@@ -567,39 +604,7 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
     p.raw(o.window, h->window.size(), h->window.data());
     p.raw(o.window_istft, h->window_istft.size(), h->window_istft.data());
     p.raw(o.twiddle, h->twiddle.size(), h->twiddle.data());
-    {   // constant operands of the matrix-core DFT (fe::Dft in fe_kernels.hip.h), N = N1 * 32
-        const int N = h->cfg.n_fft, N1 = N / 32, KC = N1 / 2, MT = N1 / 16;
-        auto c32 = [](int a, int b) { return std::cos(2.0 * M_PI * (double)((a * b) % 32) / 32.0); };
-        auto s32 = [](int a, int b) { return std::sin(2.0 * M_PI * (double)((a * b) % 32) / 32.0); };
-        auto c1 = [&](int a, int b) { return std::cos(2.0 * M_PI * (double)((a * b) % N1) / (double)N1); };
-        auto s1 = [&](int a, int b) { return std::sin(2.0 * M_PI * (double)((a * b) % N1) / (double)N1); };
-        for (int q = 0; q < 2; ++q) {
-            // forward, 32-point stage: B[k = n2][n = k2] = Re (q = 0) / Im (q = 1) of W_32^(n2 k2)
-            p.pack_b(o.dft1 + q * (2 * 8 * 64), 32, 32, [&](int k, int n) { return (float)(q == 0 ? c32(k, n) : -s32(k, n)); });
-            // forward, N1-point stage, output half q: A[m = k1][k-step a*4MT + 4i + r, lane group lg]  <->  half a of
-            // G', row n1 = 16 i + 4 lg + r:   Re X: [cos | sin],  Im X: [-sin | cos]
-            p.pack_a(o.dft2 + q * (KC * 64), 16, 2 * N1, [&](int m, int k) {
-                const int ks = k / 4, lg = k % 4, a = ks / (4 * MT), i = (ks % (4 * MT)) / 4, r = ks % 4;
-                const int n1 = 16 * i + 4 * lg + r;
-                if (q == 0) return (float)(a ? s1(m, n1) : c1(m, n1));
-                return (float)(a ? c1(m, n1) : -s1(m, n1));
-            });
-            // inverse, N1-point stage (transposed), half q of H: B[k = (b, k1)][n = n1]:  Re H: [cos | -sin],  Im H: [sin | cos]
-            p.pack_b(o.dft3 + q * (MT * KC * 64), 2 * N1, N1, [&](int k, int n) {
-                const int b = k / N1, k1 = k % N1;
-                if (q == 0) return (float)(b ? -s1(n, k1) : c1(n, k1));
-                return (float)(b ? c1(n, k1) : s1(n, k1));
-            });
-            // inverse, 32-point stage (with the 1/N of irfft), per wave (p = q, jt): B[k-step a*4 + r, lane group lg][n = li]
-            // <-> half a of H', k2 = 16 jt + 4 lg + r, output sample column n2 = 16 p + li:  cos / N (a = 0), -sin / N (a = 1)
-            for (int jt = 0; jt < 2; ++jt)
-                p.pack_b(o.dft4 + (q * 2 + jt) * (8 * 64), 32, 16, [&](int k, int n) {
-                    const int ks = k / 4, lg = k % 4, a = ks / 4, r = ks % 4;
-                    const int k2 = 16 * jt + 4 * lg + r, n2 = 16 * q + n;
-                    return (float)((a ? -s32(k2, n2) : c32(k2, n2)) / (double)N);
-                });
-        }
-    }
+    pack_dft_constants(p, h->cfg.n_fft, o.dft1, o.dft2, o.dft3, o.dft4);
     if (o.k4_delta != 0) {
         // Register-resident block weights (fe::Shape::REGW): a second copy of the block-weight region whose B-operand tiles are
         // regrouped four k-steps per lane ([ks / 4][lane][4], the ks % 4 remainder plain) for 16-byte fetches - fe::TokW
@@ -903,6 +908,58 @@ int pack_weights_bsrnn(fe_handle* h, const std::vector<float>& blob, std::vector
     o.window = alloc(h->window.size()); memcpy(&buf[o.window], h->window.data(), h->window.size() * sizeof(float));
     o.window_istft = alloc(h->window_istft.size()); memcpy(&buf[o.window_istft], h->window_istft.data(), h->window_istft.size() * sizeof(float));
     o.twiddle = alloc(h->twiddle.size()); memcpy(&buf[o.twiddle], h->twiddle.data(), h->twiddle.size() * sizeof(float));
+    if (C == 16) {
+        // r5: the role-split PART 1's copies, regrouped from the sections packed above for 16-byte fetches (see BOffsets)
+        const int KSC = C / 4, KSH = HH / 4, KS1 = KSC + KSH, NCT = HH / 16;
+        for (int l = 0; l < L; ++l) {
+            o.ov_t[l] = alloc((size_t)NCT * 4 * (KS1 / 4) * 256);
+            for (int ct = 0; ct < NCT; ++ct)
+                for (int g = 0; g < 4; ++g)
+                    for (int q = 0; q < KS1 / 4; ++q)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 4; ++j)
+                                buf[o.ov_t[l] + (((size_t)(ct * 4 + g) * (KS1 / 4) + q) * 64 + lane) * 4 + j] = buf[o.t_w[l] + ((size_t)(g * NCT + ct) * KS1 + 4 * q + j) * 64 + lane];
+            o.ov_tb[l] = alloc((size_t)NCT * 16 * 4);
+            for (int ct = 0; ct < NCT; ++ct)
+                for (int li = 0; li < 16; ++li)
+                    for (int g = 0; g < 4; ++g) buf[o.ov_tb[l] + (ct * 16 + li) * 4 + g] = buf[o.t_b[l] + g * HH + ct * 16 + li];
+            auto regroup = [&](int src, int ks_total) {          // one column tile's [ks][lane] -> [ks / 4][lane][4]
+                const int off = alloc((size_t)ks_total * 64);
+                for (int q = 0; q < ks_total / 4; ++q)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j) buf[off + ((size_t)q * 64 + lane) * 4 + j] = buf[src + (size_t)(4 * q + j) * 64 + lane];
+                return off;
+            };
+            o.ov_f1[l] = regroup(o.tfc_w[l], KSH);
+            o.ov_f2[l] = regroup(o.ffc_w[l], 2 * KSH);
+            for (int d = 0; d < 2; ++d) {
+                o.ov_ip[l][d] = alloc((size_t)8 * 256);
+                for (int j = 0; j < 8; ++j)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int ks = 0; ks < KSC; ++ks) buf[o.ov_ip[l][d] + ((size_t)j * 64 + lane) * 4 + ks] = buf[o.f_wih[l][d] + ((size_t)j * KSC + ks) * 64 + lane];
+                o.ov_ipb[l][d] = alloc(16 * 8);
+                for (int li = 0; li < 16; ++li)
+                    for (int j = 0; j < 8; ++j) buf[o.ov_ipb[l][d] + li * 8 + j] = buf[o.f_b[l][d] + j * 16 + li];
+                // W_hh: lane = half * 32 + unit holds gate rows (half, 2 + half) of its unit; source [k][4 u + gate] (register shapes, NTD = 128)
+                o.ov_hh[l][d] = alloc((size_t)2 * (HH / 4) * 256);
+                for (int rs = 0; rs < 2; ++rs)
+                    for (int q = 0; q < HH / 4; ++q)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 4; ++j) {
+                                const int half = lane >> 5, u = lane & 31, gate = 2 * rs + half, k = 4 * q + j;
+                                buf[o.ov_hh[l][d] + (((size_t)rs * (HH / 4) + q) * 64 + lane) * 4 + j] = buf[o.f_whh[l][d] + (size_t)k * 128 + 4 * u + gate];
+                            }
+            }
+        }
+    }
+    {   // the matrix-core DFT's constant operands (r5: the role-split PART 1 runs the STFT on them), N = 512: N1 = 16, KC = 8, MT = 1
+        const int N1 = h->cfg.n_fft / 32, KC = N1 / 2, MT = N1 / 16;
+        o.dft1 = alloc(2 * 2 * 8 * 64); o.dft2 = alloc((size_t)2 * KC * 64); o.dft3 = alloc((size_t)2 * MT * KC * 64); o.dft4 = alloc(2 * 2 * 8 * 64);
+        Packer p;
+        p.buf.swap(buf);
+        pack_dft_constants(p, h->cfg.n_fft, o.dft1, o.dft2, o.dft3, o.dft4);
+        p.buf.swap(buf);
+    }
     o.total = (int)((buf.size() + 63) & ~(size_t)63);
     h->packed_floats = o.total;
     buf.resize(o.total, 0.0f);

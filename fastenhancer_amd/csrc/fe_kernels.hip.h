@@ -862,8 +862,8 @@ struct Dft {
 
     struct FwdConst { float c1[2][8], c2[KC]; };
     struct InvConst { float c3[PRELOAD3 ? 2 * MT : 1][PRELOAD3 ? KC : 1], c4[8]; };
-    template <class WS>
-    __device__ static __forceinline__ void load(FwdConst& c, const WS& wb, const PackedOffsets& o, int wave) {
+    template <class WS, class OFF>      // (OFF: any offsets struct with dft1 .. dft4 - PackedOffsets, BSRNN's BOffsets)
+    __device__ static __forceinline__ void load(FwdConst& c, const WS& wb, const OFF& o, int wave) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -871,8 +871,8 @@ struct Dft {
 #pragma unroll
         for (int ks = 0; ks < KC; ++ks) c.c2[ks] = wb.at_g(o.dft2 + ((wave >> 1) * KC + ks) * 64);
     }
-    template <class WS>
-    __device__ static __forceinline__ void load(InvConst& c, const WS& wb, const PackedOffsets& o, int wave) {
+    template <class WS, class OFF>
+    __device__ static __forceinline__ void load(InvConst& c, const WS& wb, const OFF& o, int wave) {
         if constexpr (PRELOAD3) {
 #pragma unroll
             for (int j = 0; j < 2 * MT; ++j)
@@ -935,9 +935,9 @@ struct Dft {
 
     // Y = {Re[N/2], Im[N/2]} (bins 0 .. N/2-1, bin N/2 = 0, Im Y[0] ignored) -> y[n] = P0[pidx] + P1[pidx]
     // (P_jt = the partial sum over this wave pair's k2 tile), followed by a barrier.
-    template <class WS, bool BAR = true>
+    template <class WS, bool BAR = true, class OFF = PackedOffsets>
     __device__ static __forceinline__ void inverse(const float* Y, float* P0, float* P1, const float2* tw, const InvConst& c,
-                                                   const WS& wb, const PackedOffsets& o, int wave, int lane) {
+                                                   const WS& wb, const OFF& o, int wave, int lane) {
         const int li = lane & 15, lg = lane >> 4, p = wave >> 1, jt = wave & 1, k2 = 16 * jt + li;
         // first stage, transposed: H^T[k2][n1] = sum Y^T[k2][(b, k1)] C[(b, k1)][n1], both halves (columns j = q * MT + i)
         float yq[KC];

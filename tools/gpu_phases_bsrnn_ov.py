@@ -48,6 +48,12 @@ def main():
             t = int(c[16 * w + i]) - t0
             print(f"   {t:8d}  {'+' + str(t - prev) if prev is not None else '':>8s}  {nm}")
             prev = t
+    print(" front (wave 0)")
+    prev = 0
+    for i, nm in ((12, "frame loaded, windowed"), (13, "FFT done"), (14, "compressed"), (15, "band split done"), (1, "h half of layer 0's gates done, barrier")):
+        t = int(c[i]) - t0
+        print(f"   {t:8d}  {'+' + str(t - prev):>8s}  {nm}")
+        prev = t
     names = ["chain starts", "fc_freq done, x stored", "gate GEMM (x half) done", "gate math done, new h stored", "rendezvous passed", "state stored, fc_time done",
              "projection GEMM done", "projections stored"]
     print(" inside tile B's chain under layer 0's scans (wave 2)")
