@@ -341,19 +341,34 @@ def parity_after_timed_region(workload: str, w: dict, kw: dict, sd: dict, eng, B
     return r_out, r_cache, what
 
 
+# rocprofv3's FETCH_SIZE on gfx950 reports HALF of the bytes read, at every access width the kernels use and for cache-resident as
+# well as HBM-sourced data; WRITE_SIZE is exact, partial lines included (profiles/r5_hbm_counter_calib.txt: known byte counts in the
+# kernels' own access patterns, tools/micro/hbm_counter_calib.hip).  Traffic = 2 x FETCH_SIZE + WRITE_SIZE.
+FETCH_SIZE_FACTOR, WRITE_SIZE_FACTOR = 2.0, 1.0
+
+
 def measured_traffic(workload: str, B: int, T: int):
-    """HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE), if one
-    exists for exactly this configuration; None otherwise."""
+    """(HBM-side bytes per launch, source text) from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE) for exactly this
+    configuration - the newest round's file wins - with the calibrated counter factors applied; (None, None) if there is none."""
     best = None
-    for name in sorted(os.listdir(os.path.join(REPO, "profiles"))) if os.path.isdir(os.path.join(REPO, "profiles")) else []:
+    pdir = os.path.join(REPO, "profiles")
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
         if name.startswith("pmc_") and name.endswith(".json"):
             try:
-                d = json.load(open(os.path.join(REPO, "profiles", name)))
+                d = json.load(open(os.path.join(pdir, name)))
             except Exception:
                 continue
             if d.get("workload") == workload and d.get("streams_per_gpu") == B and d.get("frames_per_step") == T:
-                best = d.get("hbm_bytes_per_launch")
-    return best
+                if best is None or d.get("round", 0) >= best[1].get("round", 0):
+                    best = (name, d)
+    if best is None:
+        return None, None
+    name, d = best
+    if "FETCH_SIZE_KiB" in d and "WRITE_SIZE_KiB" in d:
+        t = int(round((FETCH_SIZE_FACTOR * d["FETCH_SIZE_KiB"] + WRITE_SIZE_FACTOR * d["WRITE_SIZE_KiB"]) * 1024))
+        return t, (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration, {FETCH_SIZE_FACTOR:g} x FETCH_SIZE + "
+                   f"{WRITE_SIZE_FACTOR:g} x WRITE_SIZE (factors calibrated on known byte counts: profiles/r5_hbm_counter_calib.txt)")
+    return d.get("hbm_bytes_per_launch"), f"profiles/{name}: counters as reported (no per-counter values kept: uncalibrated)"
 
 
 def pin_rank(local_rank: int, world: int) -> None:
@@ -785,7 +800,7 @@ def main():
                        "weights": "seeded random checkpoint (no trained weights offline), BN/weight-norm folded"},
             "rtf_per_stream": dt * w["sr"] / (args.steps * (Tw if offline else T * H) * B * world),   # amortised: wall time / audio time / streams
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None if offline else measured_traffic(args.workload, B, T),
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None if offline else measured_traffic(args.workload, B, T)[0],
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "algorithmic_hbm_bytes_per_launch": alg_bytes,
                          "kernel": ("fe_offline = tb_enc_kernel + K x (tb_scan_kernel + tb_blk_kernel) + tb_dec_kernel + istft_ola_kernel (kernel_ms: the whole call)"
@@ -793,6 +808,8 @@ def main():
                                     "lisennet_frame_kernel" if w.get("lisennet") else ("fspen_frame_kernel<PART 1> + fspen_sb_dpe_kernel (16 streams per workgroup) + fspen_frame_kernel<PART 2> (kernel_ms: the step's three launches)"
                                      if args.frames_per_step == 1 and 0 < int(os.environ.get("FE_FSPEN_SB", "1536")) <= B else "fspen_frame_kernel") if w.get("fspen") else ("bsrnn_frame_kernel<PART 3> + bsrnn_sb_layers_kernel (16 streams per workgroup) + bsrnn_mlp_kernel + bsrnn_frame_kernel<PART 2> (kernel_ms: the step's four launches)"
                                      if w.get("bsrnn") and args.frames_per_step == 1 and w.get("C") == 16 and 0 < int(os.environ.get("FE_BSRNN_SB", "2048")) <= B else
+                                     "bsrnn_ov_kernel (role-split PART 1, bsrnn_ov_kernels.hip.h) + bsrnn_mlp_kernel + bsrnn_frame_kernel<PART 2> (kernel_ms: the step's three launches)"
+                                     if w.get("bsrnn") and args.frames_per_step == 1 and w.get("C") == 16 and B <= torch.cuda.get_device_properties(dev).multi_processor_count and os.environ.get("FE_BSRNN_OV", "1") != "0" else
                                      "bsrnn_frame_kernel<PART 1> + bsrnn_mlp_kernel + bsrnn_frame_kernel<PART 2> (kernel_ms: the step's three launches)" if w.get("bsrnn") and args.frames_per_step == 1 else "bsrnn_frame_kernel" if w.get("bsrnn") else
                                     ("fe_frame8_kernel (512-thread per-hop kernel, fe_frame8.hip.h)" if args.workload == "fe_b" and not offline and T == 1 and B <= torch.cuda.get_device_properties(dev).multi_processor_count
                                      and os.environ.get("FE_WG8", "1") != "0" else "fe_frame_kernel"))), "kernel_ms": kernel_ms,
@@ -804,7 +821,7 @@ def main():
         rf = res["roofline"]
         # where `traffic` comes from: a PMC pass (FETCH_SIZE / WRITE_SIZE, rocprofv3 --pmc) of exactly this configuration committed under
         # profiles/pmc_*.json - a constant read back, not a measurement of this run; null when no such pass exists
-        rf["traffic_source"] = "profiles/pmc_*.json (rocprofv3 --pmc FETCH_SIZE WRITE_SIZE pass of this configuration; counters as reported, no correction)" if rf["traffic"] is not None else None
+        rf["traffic_source"] = None if offline else measured_traffic(args.workload, B, T)[1]
         if rf["hbm_frac"] > rf["frac"]:
             rf.update({"bound": "hbm", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": rf["hbm_frac"],
                        "mfma_frac": achieved / PEAK_FP32_TFLOPS})

@@ -181,17 +181,20 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         }
         Wf2b = wb.at16_g(o.ffc_b[l]);
     };
-    // the h half of layer l's time-LSTM gates for tile T: state fragments straight from the state tensors
-    auto pre_gates = [&](int l, auto T_) {
+    // the h half of layer l's time-LSTM gates for tile T: state fragments straight from the state tensors (pre_load), the products once
+    // the layer's weights are there (pre_mma)
+    auto pre_load = [&](int l, auto T_, float (&af)[KSH]) {
         constexpr int T = decltype(T_)::value;
         const float* hg = a.lstm + ((size_t)(2 * l) * a.B + b) * lsz;
         const float* cg = hg + (size_t)a.B * lsz;
-        float af[KSH];
         const float* hr = hg + ov_band<T>(li) * HH + lg;
 #pragma unroll
         for (int ks = 0; ks < KSH; ++ks) af[ks] = hr[4 * ks];
 #pragma unroll
         for (int r = 0; r < 4; ++r) cprev[T][r] = cg[ov_band<T>(4 * lg + r) * HH + 16 * ct + li];
+    };
+    auto pre_mma = [&](auto T_, const float (&af)[KSH]) {
+        constexpr int T = decltype(T_)::value;
 #pragma unroll
         for (int g = 0; g < 4; ++g) hh[T][g] = f32x4{Wtb[g], Wtb[g], Wtb[g], Wtb[g]};
 #pragma unroll
@@ -199,10 +202,19 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll
             for (int g = 0; g < 4; ++g) hh[T][g] = FE_MFMA(af[ks], Wt[g][KSC + ks], hh[T][g]);
     };
+    auto pre_gates = [&](int l, auto T_) {
+        float af[KSH];
+        pre_load(l, T_, af);
+        pre_mma(T_, af);
+    };
     using TA = std::integral_constant<int, 0>;
     using TB = std::integral_constant<int, 1>;
     __syncthreads();
 
+    constexpr int BSI = (kBands * C + kThreads - 1) / kThreads;      // band-split outputs per thread
+    float4 bsw[BSI][kBsKP / 4];
+    float bsb[BSI];
+    float af0[KSH];
     // ============================ STFT + compress (all 257 bins; models/bsrnn/model.py:430-436) ============================
     // The transform runs on the matrix cores (fe::Dft: two chained GEMM stages per wave, one barrier) instead of nine radix-2 passes
     {
@@ -212,13 +224,23 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         const float* win = wp + o.window;
         const float* xin = a.wav_in + (size_t)b * a.in_stride;
         constexpr int NPT = N / kThreads;
-        float fv[NPT];
+        float fv[NPT], fw[NPT];
 #pragma unroll
-        for (int q = 0; q < NPT; ++q) { const int n = tid + q * kThreads; fv[q] = (n < OVL) ? cst[n] : xin[n - OVL]; }
+        for (int q = 0; q < NPT; ++q) { const int n = tid + q * kThreads; fv[q] = (n < OVL) ? cst[n] : xin[n - OVL]; fw[q] = win[n]; }
         typename D::FwdConst dc;
         D::load(dc, wb, o, wave);
+        if (wave < 2) pre_load(0, TA{}, af0);      // layer 0's state fragments and the band split's weight rows: independent of the frame
+        else pre_load(0, TB{}, af0);
 #pragma unroll
-        for (int q = 0; q < NPT; ++q) { const int n = tid + q * kThreads; xw[n] = fv[q] * win[n]; }
+        for (int it = 0; it < BSI; ++it) {
+            const int i = tid + it * kThreads, ic = i < kBands * C ? i : kBands * C - 1;
+            const float4* w4 = reinterpret_cast<const float4*>(wp + o.bs_w) + ic;      // [k/4][band * C + c] float4: coalesced over the threads
+#pragma unroll
+            for (int k = 0; k < kBsKP / 4; ++k) bsw[it][k] = w4[k * (kBands * C)];
+            bsb[it] = wp[o.bs_b + ic];
+        }
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) { const int n = tid + q * kThreads; xw[n] = fv[q] * fw[q]; }
         __syncthreads();                           // (every read of the old cache has landed)
         if (wave == 0) OV_CLK(12);
 #pragma unroll
@@ -238,26 +260,27 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     __syncthreads();
     if (wave == 0) OV_CLK(14);
     // ============================ band split (BandSplit.forward, :136-153; BN folded) ============================
-    for (int i = tid; i < kBands * C; i += kThreads) {
-        const int bb = i / C;
-        const float4* w4 = reinterpret_cast<const float4*>(wp + o.bs_w) + i;      // [k/4][band * C + c] float4: coalesced over the threads
-        float4 wv[kBsKP / 4];
+    // thread <-> (band, channel): its zero-padded weight row of kBsKP floats was fetched at the top of the kernel
 #pragma unroll
-        for (int k = 0; k < kBsKP / 4; ++k) wv[k] = w4[k * (kBands * C)];
-        const int s0 = bb == 0 ? 0 : (bb <= 10 ? 3 * bb - 1 : (bb <= 22 ? 8 * bb - 56 : 16 * bb - 240));
-        const float* s = sp + 2 * s0;
-        float a0 = wp[o.bs_b + i], a1 = 0.0f;
+    for (int it = 0; it < BSI; ++it) {
+        const int i = tid + it * kThreads;
+        if (i < kBands * C) {
+            const int bb = i / C;
+            const int s0 = bb == 0 ? 0 : (bb <= 10 ? 3 * bb - 1 : (bb <= 22 ? 8 * bb - 56 : 16 * bb - 240));
+            const float* s = sp + 2 * s0;
+            float a0 = bsb[it], a1 = 0.0f;
 #pragma unroll
-        for (int k = 0; k < kBsKP / 4; ++k) {
-            a0 += wv[k].x * s[4 * k] + wv[k].z * s[4 * k + 2];
-            a1 += wv[k].y * s[4 * k + 1] + wv[k].w * s[4 * k + 3];
+            for (int k = 0; k < kBsKP / 4; ++k) {
+                a0 += bsw[it][k].x * s[4 * k] + bsw[it][k].z * s[4 * k + 2];
+                a1 += bsw[it][k].y * s[4 * k + 1] + bsw[it][k].w * s[4 * k + 3];
+            }
+            XB[bb * LDX + (i - bb * C)] = a0 + a1;
         }
-        XB[bb * LDX + (i - bb * C)] = a0 + a1;
     }
     if (wave == 0) OV_CLK(15);
     // layer 0's time part has nothing to hide under: tile A on waves 0, 1, tile B on waves 2, 3
-    if (wave < 2) pre_gates(0, TA{});
-    else pre_gates(0, TB{});
+    if (wave < 2) pre_mma(TA{}, af0);
+    else pre_mma(TB{}, af0);
     __syncthreads();
     OV_CLK(1);
 
