@@ -451,6 +451,17 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
             auto shared = [&](int t) { return t < 3 * NG && t % 3 < 2; };      // pure r / z tile: x and h halves in one accumulator
             pack_u8(o.u8_gx[k], NT, wih, grow, [&](int t, int c) { const int r = grow(t, c); return bih[r] + (shared(t) ? bhh[r] : 0.0f); }, gscale);
             pack_u8(o.u8_gh[k], NT, whh, grow, [&](int t, int c) { const int r = grow(t, c); return shared(t) ? 0.0f : bhh[r]; }, gscale);
+            {   // ... and regrouped four k-steps per lane for the front-of-frame W_hh h products (PackedOffsets::u8_gh4)
+                const int NQ = KS / 4, KR = KS % 4, TS = NQ * 256 + KR * 64;
+                for (int t = 0; t < NT; ++t)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        for (int q = 0; q < NQ; ++q)
+                            for (int j = 0; j < 4; ++j)
+                                p.buf[(size_t)o.u8_gh4[k] + (size_t)t * TS + q * 256 + lane * 4 + j] = p.buf[(size_t)o.u8_gh[k] + ((size_t)t * KS + 4 * q + j) * 64 + lane];
+                        for (int r = 0; r < KR; ++r)
+                            p.buf[(size_t)o.u8_gh4[k] + (size_t)t * TS + NQ * 256 + r * 64 + lane] = p.buf[(size_t)o.u8_gh[k] + ((size_t)t * KS + 4 * NQ + r) * 64 + lane];
+                    }
+            }
             auto plain = [&](int ncols) { return [ncols](int t, int c) { return 16 * t + c < ncols ? 16 * t + c : -1; }; };
             const float* f1b = S(key("rnn_fc.bias"));
             const float* f2b = S(key("attn_fc.bias"));

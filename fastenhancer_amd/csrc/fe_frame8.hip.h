@@ -25,6 +25,16 @@
 
 namespace fe {
 
+// FE_WG8_HPRE=1 (r5; MEASURED NEGATIVE, off by default - profiles/r5_headline_hpre.txt): the GRU's hidden halves
+// W_hh h_{t-1} of ALL blocks - h_{t-1} is known when the frame starts - accumulated by waves 4-7 in the front of the frame (next to the DFT of
+// waves 0-3 and in enc_pre), the GRU jobs moved to the waves that hold the sums (wave 4, 5: channel group 0 + the mixed tile of a row tile;
+// wave 6, 7: channel group 1).  The products removed altogether (wrong results) are worth 31.64 -> 30.09 us; moved, the frame is 33.5 us: the
+// front grows by 7.4 k cycles (operand fetches of three blocks: +4.9 k before the first phase, DFT phase +1.3 k, enc_pre +1.2 k) and a
+// block's GRU phase shrinks by 0.67 k instead of 1.15 k - its GEMM, now on ONE wave per SIMD, runs at 57 cycles per MFMA (LDS operand
+// latency that the second wave of a SIMD used to cover).
+#ifndef FE_WG8_HPRE
+#define FE_WG8_HPRE 0
+#endif
 constexpr int kThreads8 = 512;
 constexpr int kWaves8 = 8;
 
@@ -214,6 +224,62 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
             wb.base = o.u_off[(U)];                                                                \
         }                                                                                          \
         const StageSide<NPW, ((!PERSIST && ((U) + 1 == S::NU || (U) == 0)) || (U) == S::U_RFPRE + 1) ? 0 : o.u_size[fe_un_] / 256, kWaves8> stage{&job}
+#if FE_WG8_HPRE
+        // ---- W_hh h_{t-1} of every block, on waves 4-7: job = (channel group hcg, row tile hrt) [+ the mixed tile on waves 4, 5]
+        constexpr int HK2 = S::KS_2, HNQ = HK2 / 4, HKR = HK2 % 4, HTS = HNQ * 256 + HKR * 64;
+        static_assert(HKR <= 1, "one plain k-step after the 16-byte groups");
+        const int hcg = (wave - 4) >> 1, hrt = wave & 1;
+        f32x4 hp[S::KB][4];                     // [block]: r, z, n (with b_hn) of the group; [3]: the mixed tile (waves 4, 5)
+        float hpa[S::KB][HK2];                  // per block: A fragments (rows of h), B fragments of the job's tiles, start values - all requested
+        f32x4 hpb[S::KB][4][HNQ > 0 ? HNQ : 1];    // at the top of the frame (dead once the block's products are issued)
+        float hpr[S::KB][4], hpbn[S::KB], hpbm[S::KB];
+        auto hpre_load = [&](auto k_) {
+            constexpr int k = decltype(k_)::value;
+            if (wave >= 4) {
+                const int row = 16 * hrt + (lane & 15);
+                const float* hrow = a.h + ((size_t)k * a.B + b) * (S::F2 * S::C2) + (row < S::F2 ? row : S::F2 - 1) * S::C2 + (lane >> 4);
+#pragma unroll
+                for (int ks = 0; ks < HK2; ++ks) hpa[k][ks] = hrow[4 * ks];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = j < 3 ? 3 * hcg + j : 3 * S::G8_NG;              // (j = 3: the mixed tile; fetched by waves 6, 7 too - unused there)
+#pragma unroll
+                    for (int q = 0; q < HNQ; ++q) hpb[k][j][q] = wb.at_gv4(o.u8_gh4[k] + t * HTS + q * 256, wb.lane4 * 4);
+                    if constexpr (HKR == 1) hpr[k][j] = wb.at_g(o.u8_gh4[k] + t * HTS + HNQ * 256);
+                }
+                hpbn[k] = wb.at16_g(o.u8_gh[k] + S::G8_NT * HK2 * 64 + (3 * hcg + 2) * 16);      // b_hn of the group's n tile
+                hpbm[k] = wb.at16_g(o.u8_gh[k] + S::G8_NT * HK2 * 64 + (3 * S::G8_NG) * 16);      // the mixed tile's h-side start values
+            }
+        };
+        auto hpre_mma = [&](auto k_) {
+            constexpr int k = decltype(k_)::value;
+            if (wave >= 4) {
+                hp[k][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                hp[k][1] = hp[k][0];
+                hp[k][2] = f32x4{hpbn[k], hpbn[k], hpbn[k], hpbn[k]};
+                hp[k][3] = f32x4{hpbm[k], hpbm[k], hpbm[k], hpbm[k]};
+                auto bfr = [&](int j, int ks) { return ks < 4 * HNQ ? hpb[k][j][ks >> 2][ks & 3] : hpr[k][j]; };
+                if (wave < 6) {
+#pragma unroll
+                    for (int ks = 0; ks < HK2; ++ks)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) hp[k][j] = FE_MFMA(hpa[k][ks], bfr(j, ks), hp[k][j]);
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < HK2; ++ks)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) hp[k][j] = FE_MFMA(hpa[k][ks], bfr(j, ks), hp[k][j]);
+                }
+            }
+        };
+        using HK0 = std::integral_constant<int, 0>;
+        using HK1 = std::integral_constant<int, (S::KB > 1 ? 1 : 0)>;
+        using HK2_ = std::integral_constant<int, (S::KB > 2 ? 2 : 0)>;
+        static_assert(S::KB <= 3, "FE_WG8_HPRE schedules three blocks");
+        hpre_load(HK0{});
+        if constexpr (S::KB > 1) hpre_load(HK1{});
+        if constexpr (S::KB > 2) hpre_load(HK2_{});
+#endif
         FE_CLK(0);
         // =========================== STFT (a1-a3) ===========================
         // LDS quarters of the FFT arena: q0 windowed frame / iSTFT partial sums, q1 iSTFT partial sums, q3 spectrum {Re[N/2], Im[N/2]}
@@ -234,6 +300,12 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
             FE_CLK(1);
             float* nyq = a.dbg ? a.dbg + (size_t)b * a.dbg_stride + DebugLayout<S>::offset(0) + 2 * F0 : nullptr;
             if (wave < 4) Dft<S>::template forward<false>(q0, q3, tw, dc, wave, lane, nyq);
+#if FE_WG8_HPRE
+            else {
+                hpre_mma(HK0{});
+                if constexpr (S::KB > 1) hpre_mma(HK1{});
+            }
+#endif
             __syncthreads();
             FE_CLK(2);
             const float* Xr = q3;
@@ -270,6 +342,9 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
                 },
                 [&](int j, int ks) { return wb.at(o.enc_pre_w + (j * 4 + ks) * 64); },
                 [&](int j) { return wb.at16x4(o.enc_pre_b + j * 64); }, stage, Ebuf, 1, ws, lane);
+#if FE_WG8_HPRE
+            if constexpr (S::KB > 2) hpre_mma(HK2_{});        // (waves 4-7: the lighter half of this 12-MFMA phase)
+#endif
         }
         __syncthreads();
         dbg_dump<S, NTH>(a, b, 2, Ebuf + LDC, LDC);
@@ -365,8 +440,12 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
         {
             // X[f2][c2] = Y1[f2][:] . Wc[c2][:] + b
             FE8_BEGIN_UNIT(S::U_RFPRE + 1);
+#if FE_WG8_HPRE
+            const NoSide stg{};                                         // (the hidden weights never pass through LDS)
+#else
             stage_to(jb1, o.u8_gh[0], W8::WB0 + 3 * W8::SLOT);          // ... and the hidden weights -> slot 3
             const StG stg{&jb1};
+#endif
             float hpre[HPT];
             const float* hg0 = a.h + (size_t)b * (F2 * C2);
 #pragma unroll
@@ -379,7 +458,9 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
                 acc, [&](int, int ks) { return ya[4 * ks]; },
                 [&](int, int ks) { return wb.at(o.rfpre_w + (nt * S::KS_C + ks) * 64); }, stg);
             (void)stage;
+#if !FE_WG8_HPRE
             stg.commit();
+#endif
             xr = acc[0][0];
             float* xd = tok_dst(Xb);
 #pragma unroll
@@ -421,6 +502,91 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
                 const float* bh = sGh + S::G8_NT * K2 * 64 + g_t0 * 16 + li;
                 __builtin_amdgcn_sched_barrier(0);
                 if (k == 0) FE_CLK(45);
+#if FE_WG8_HPRE
+                if (wave >= 4) {
+                    // x halves on top of the hidden halves accumulated in the front: the group's tiles r, z, n (+ the mixed tile on waves 4, 5:
+                    // it shares the row tile's A fragments)
+                    const int ch = 16 * hcg + li;
+                    constexpr int R = S::G8_R;
+                    const int chm = 16 * S::G8_NG + (li < R ? li : 0);
+                    float hprev[4], hprevm[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        hprev[r] = Hs[(16 * hrt + 4 * lg + r) * LDX + ch];
+                        hprevm[r] = Hs[(16 * hrt + 4 * lg + r) * LDX + chm];
+                    }
+                    const float* xa8 = Xb + (16 * hrt + li) * LDX + lg;
+                    const float* wx8 = sGx + (3 * hcg) * (K2 * 64) + lane;
+                    const float* wxm = sGx + (3 * S::G8_NG) * (K2 * 64) + lane;
+                    const float* bx8 = sGx + S::G8_NT * K2 * 64 + (3 * hcg) * 16 + li;
+                    const float b0 = bx8[0], b1 = bx8[16], b2 = bx8[32], bm = sGx[S::G8_NT * K2 * 64 + (3 * S::G8_NG) * 16 + li];
+                    f32x4 ar, az, anx = f32x4{b2, b2, b2, b2}, anh, ax = f32x4{bm, bm, bm, bm}, ah;
+                    static_for<S::KB>([&](auto kk_) {         // (hp is indexed at compile time: the block loop is unrolled)
+                        constexpr int kk = decltype(kk_)::value;
+                        if (k == kk) { ar = hp[kk][0] + f32x4{b0, b0, b0, b0}; az = hp[kk][1] + f32x4{b1, b1, b1, b1}; anh = hp[kk][2]; ah = hp[kk][3]; }
+                    });
+                    if (wave < 6) {
+                        mma_panel_sel<1, 4, K2, PDK>(
+                            [&](int, int j, int) -> f32x4& { return j == 0 ? ar : (j == 1 ? az : (j == 2 ? anx : ax)); },
+                            [&](int, int ks) { return xa8[4 * ks]; },
+                            [&](int j, int ks) { return j < 3 ? wx8[(j * K2 + ks) * 64] : wxm[ks * 64]; }, sideg);
+                    } else {
+                        mma_panel_sel<1, 3, K2, PDK>(
+                            [&](int, int j, int) -> f32x4& { return j == 0 ? ar : (j == 1 ? az : anx); },
+                            [&](int, int ks) { return xa8[4 * ks]; },
+                            [&](int j, int ks) { return wx8[(j * K2 + ks) * 64]; }, sideg);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k == 0) FE_CLK(46);
+                    float hn[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float rr = sigmoid_pre(ar[r]);        // (the packer scales the gate rows: -log2 e / 2 log2 e)
+                        const float zz = sigmoid_pre(az[r]);
+                        const float nn = tanh_pre(__builtin_fmaf(rr, anh[r], anx[r]));
+                        hn[r] = __builtin_fmaf(zz, hprev[r] - nn, nn);          // (1 - z) n + z h
+                    }
+                    if (16 * hrt + 4 * lg < F2) {       // (F2 % 4 == 0: the four rows of a lane are valid together)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * hrt + 4 * lg + r;
+                            Hl[row * LDX + ch] = hn[r];
+                            if constexpr (W8::HSTASH) smem[W8::HST + k * (F2 * C2) + row * C2 + ch] = hn[r];
+                            else hg[row * C2 + ch] = hn[r];
+                        }
+                    }
+                    if (wave < 6) {
+                        // the mixed tile: lanes li < R hold r, R .. 2 R - 1 z, 2 R .. 3 R - 1 n of channel 16 NG + li % R; the z and n values
+                        // move down to the r lanes (DPP row shifts), which finish the R channels
+                        auto shl = [](float v, auto n_) {      // lane i <- lane i + n of its 16-lane row
+                            constexpr int n = decltype(n_)::value;
+                            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + n, 0xf, 0xf, true));
+                        };
+                        float hm[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float sx = ax[r], sh = ah[r], sm = sx + sh;
+                            const float rr = sigmoid_pre(sm);
+                            const float zz = sigmoid_pre(shl(sm, std::integral_constant<int, R>{}));
+                            const float nn = tanh_pre(__builtin_fmaf(rr, shl(sh, std::integral_constant<int, 2 * R>{}), shl(sx, std::integral_constant<int, 2 * R>{})));
+                            hm[r] = __builtin_fmaf(zz, hprevm[r] - nn, nn);
+                        }
+                        if (li < R && 16 * hrt + 4 * lg < F2) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = 16 * hrt + 4 * lg + r;
+                                Hl[row * LDX + chm] = hm[r];
+                                if constexpr (W8::HSTASH) smem[W8::HST + k * (F2 * C2) + row * C2 + chm] = hm[r];
+                                else hg[row * C2 + chm] = hm[r];
+                            }
+                        }
+                    }
+                } else {
+                    constexpr int NSG = (K2 + 3) / 4;      // waves 0-3: their share of the staging only
+#pragma unroll
+                    for (int g = 0; g < NSG; ++g) sideg(g, NSG);
+                }
+#else
                 if (wave < 4) {
                     // a 16-channel group: tiles r, z (x and h halves in one accumulator), n (separate halves)
                     const int ch = 16 * (wave >> 1) + li;
@@ -430,7 +596,12 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
                     const float b0 = bx[0], b1 = bx[16], b2 = bx[32], b3 = bh[32];
                     f32x4 ar = f32x4{b0, b0, b0, b0}, az = f32x4{b1, b1, b1, b1};
                     f32x4 anx = f32x4{b2, b2, b2, b2}, anh = f32x4{b3, b3, b3, b3};
-                    mma_panel_sel<1, 3, 2 * K2, PDK>(
+#ifdef FE_EXP_NOHH      // timing experiment (wrong results): the GRU phases without their W_hh h products
+                    constexpr int KSG = K2;
+#else
+                    constexpr int KSG = 2 * K2;
+#endif
+                    mma_panel_sel<1, 3, KSG, PDK>(
                         [&](int, int j, int ks) -> f32x4& { return j == 0 ? ar : (j == 1 ? az : (ks < K2 ? anx : anh)); },
                         [&](int, int ks) { return ks < K2 ? xa[4 * ks] : ha[4 * (ks - K2)]; },
                         [&](int j, int ks) { return ks < K2 ? wx[(j * K2 + ks) * 64] : wh_[(j * K2 + (ks - K2)) * 64]; }, sideg);
@@ -467,7 +638,12 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
                     f32x4 ax = f32x4{b0, b0, b0, b0}, ah = f32x4{b1, b1, b1, b1};
                     f32x4 ax1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, ah1 = ax1;
                     __builtin_amdgcn_s_setprio(3);
-                    mma_panel_sel<1, 1, 2 * K2, PDK>(
+#ifdef FE_EXP_NOHH
+                    constexpr int KSG = K2;
+#else
+                    constexpr int KSG = 2 * K2;
+#endif
+                    mma_panel_sel<1, 1, KSG, PDK>(
                         [&](int, int, int ks) -> f32x4& { return ks < K2 ? ((ks & 1) ? ax1 : ax) : ((ks & 1) ? ah1 : ah); },
                         [&](int, int ks) { return ks < K2 ? xa[4 * ks] : ha[4 * (ks - K2)]; },
                         [&](int, int ks) { return ks < K2 ? wx[ks * 64] : wh_[(ks - K2) * 64]; }, sideg);
@@ -503,6 +679,7 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
                     for (int g = 0; g < NSG; ++g) sideg(g, NSG);
                 }
+#endif
                 st1.commit();
                 st2.commit();
             }
@@ -586,10 +763,14 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
                 const float* hla = Hl + (16 * wh + li) * LDX + lg;
                 const float* wf = sF + ntf * (K2 * 64) + lane;
                 if (k + 1 < S::KB) {
+#if FE_WG8_HPRE
+                    mma_panel<1, 1, K2, PDK>(acc, [&](int, int ks) { return hla[4 * ks]; }, [&](int, int ks) { return wf[ks * 64]; }, NoSide{});
+#else
                     stage_to(jb1, o.u8_gh[0] + ub + u8_stride, W8::WB0 + 3 * W8::SLOT);
                     const StG stn{&jb1};
                     mma_panel<1, 1, K2, PDK>(acc, [&](int, int ks) { return hla[4 * ks]; }, [&](int, int ks) { return wf[ks * 64]; }, stn);
                     stn.commit();
+#endif
                 } else {
                     stage_to(jb1, o.u_off[S::U_RFPOST], W8::WB1);
                     const StageSide<NPWB, o.u_size[S::U_RFPOST] / 256, kWaves8> stn{&jb1};

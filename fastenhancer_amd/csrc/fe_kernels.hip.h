@@ -127,6 +127,7 @@ struct Shape {
     // 512-thread per-hop kernel: its block weights are staged through LDS like the conv weights, as units of whole 1-KiB pieces:
     // B fragments [tile][k-step][64] followed by the tiles' start values [tile][16] (a token GEMM's bias)
     static constexpr int U8_G = round_up(G8_NT * (C2 / 4) * 64 + G8_NT * 16, 256);                     // GRU input / hidden weights: the channel-grouped gate tiles
+    static constexpr int U8_GH4 = round_up(G8_NT * (((C2 / 4) / 4) * 256 + ((C2 / 4) % 4) * 64), 256);      // the hidden weights regrouped for 16-byte fetches (PackedOffsets::u8_gh4)
     static constexpr int U8_F = round_up(ceil_div(C2, 16) * (C2 / 4) * 64 + ceil_div(C2, 16) * 16, 256);   // rnn_fc / attn_fc
     static constexpr int U8_Q = round_up(ceil_div(3 * C2, 16) * (C2 / 4) * 64, 256);                   // qkv (no bias)
     static constexpr int U8_SLOT = U8_G > U8_Q ? U8_G : U8_Q;                                        // one of the four staging slots
@@ -176,6 +177,8 @@ struct PackedOffsets {
     // (start values: b_ih, plus b_hh on pure r / z tiles whose x and h halves share an accumulator / b_hh on the n tiles and the mixed
     // tile, else 0); f1, q, f2: rnn_fc, qkv, attn_fc in their plain column order.
     int u8_gx[8], u8_gh[8], u8_f1[8], u8_q[8], u8_f2[8];
+    int u8_gh4[8];                      // r5: the hidden-weight tiles once more, [tile][k-step / 4][lane][4] + the k-steps % 4 plain: fetched by the waves that
+                                        // accumulate W_hh h of all blocks in the front of the frame (fe_frame8.hip.h, FE_WG8_HPRE)
     int total;
     // LDS-staged weight "units" in consumption order (one per conv-type GEMM phase): [weights | bias],
     // 256-float aligned and padded, so that a unit is staged by whole 1-KiB global_load_lds pieces.
@@ -271,6 +274,8 @@ struct Pack {
                 o.u8_q[k] = cur; cur += S::U8_Q;
                 o.u8_f2[k] = cur; cur += S::U8_F;
             }
+        if (S::G8P)
+            for (int k = 0; k < S::KB; ++k) { cur = round_up(cur, 256); o.u8_gh4[k] = cur; cur += S::U8_GH4; }
         o.conv_k4_delta = 0;
         if (S::KT == 1 && !S::LN) {     // (allocated after everything else: every other offset is the same with and without it; NOT a function of LOW: a companion shares its shape's buffer)
             // r4w: the time-batched engine's conv GEMMs stream their weight fragments from L2 - one wave-level load per (tile, k-step) kept the
