@@ -316,6 +316,22 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll 1
     for (int t = t_first; t < aT; t += t_step) {
         BE_CLK(0);
+        // r5, PART 2 (the per-hop tail): the inverse transform on the matrix cores (fe::Dft: one barrier instead of nine radix-2 passes);
+        // its constants and the old overlap tail are requested here, ahead of the GLU
+        constexpr bool MIDFT = (PART == 2);
+        using DI = Dft<S, 3>;
+        typename DI::InvConst idc;
+        constexpr int OPT = (N + kThreads - 1) / kThreads;      // output samples per thread
+        float ocis[OPT], owin[OPT];
+        if constexpr (MIDFT) {
+            DI::load(idc, wb, o, wave);
+#pragma unroll
+            for (int q = 0; q < OPT; ++q) {
+                const int n = tid + q * kThreads;
+                ocis[q] = n < OVL ? cis[n] : 0.0f;
+                owin[q] = wp[o.window_istft + (n < N ? n : N - 1)];
+            }
+        }
         if constexpr (PART != 2) {
         // ============================ STFT + compress (all 257 bins; models/bsrnn/model.py:430-436) ============================
         if (mode != FE_MODE_SPEC) {
@@ -932,7 +948,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     float* dst = dbg + BDebugLayout<S>::offset(4 + 2 * S::NLAY) + 2 * f;
                     dst[0] = yr; dst[1] = yi;
                 }
-                if (mode == FE_MODE_SPEC) {
+                if constexpr (MIDFT) {
+                    float* Ys = reinterpret_cast<float*>(fa);            // {Re[N/2], Im[N/2]}, then Re of the Nyquist bin
+                    if (f < N / 2) { Ys[f] = yr; Ys[N / 2 + f] = yi; }
+                    else Ys[N] = yr;
+                } else if (mode == FE_MODE_SPEC) {
                     spo[((size_t)f * aT + t) * 2] = yr;
                     spo[((size_t)f * aT + t) * 2 + 1] = yi;
                 } else if (f == 0) {
@@ -949,6 +969,29 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 
         BE_CLK(10);
         // ============================ iSTFT (functional/audio_modules.py:259-303 / torch.istft) ============================
+        if constexpr (PART == 2) {
+            // irfft keeps Re X[N/2] only and ignores Im X[0]: the transform covers bins 0 .. N/2 - 1, the Nyquist bin is (-1)^n X[N/2] / N
+            const float* Ys = reinterpret_cast<const float*>(fa);
+            float* P0 = reinterpret_cast<float*>(fb);
+            float* P1 = P0 + N;
+            DI::template inverse<WSrc<false>, true>(Ys, P0, P1, tw, idc, wb, o, wave, lane);
+            const float nyq = Ys[N] * (1.0f / (float)N);
+            float* out = a.wav_out + (size_t)b * a.out_stride;
+            float vo[OPT];
+#pragma unroll
+            for (int q = 0; q < OPT; ++q) {
+                const int n = tid + q * kThreads, nc = n < N ? n : N - 1;
+                const int pi = DI::pidx(nc & (DI::N1 - 1), nc / DI::N1);
+                vo[q] = (P0[pi] + P1[pi] + ((nc & 1) ? -nyq : nyq)) * owin[q] + ocis[q];
+            }
+            // (every read of the old overlap tail landed before the GLU's barrier)
+#pragma unroll
+            for (int q = 0; q < OPT; ++q) {
+                const int n = tid + q * kThreads;
+                if (n < H) out[n] = vo[q];
+                else if (n < N) cis[n - H] = vo[q];
+            }
+        } else
         if (mode != FE_MODE_SPEC) {
             float2* y = fft_lds<S, true>(fa, fb, tw);
             float2* spare = (y == fa) ? fb : fa;
