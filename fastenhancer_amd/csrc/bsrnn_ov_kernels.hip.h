@@ -422,7 +422,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         // ================================================ the scans ================================================
         float* hb = Hb + d * (2 * HH);                                   // [2 buffers][HH]
         float* ydump = Hb + 4 * HH + u;                                  // where the low lanes' (unused) h goes: no exec-masked region
-        const float act_m = half == 0 ? 2.0f : 1.0f, act_a = half == 0 ? -1.0f : 0.0f;      // second row: g (tanh) in the low half, o in the high half
+        // second row: g in the low half - tanh scaled by K2 = -2 log2 e, so that the cell state is carried as K2 c and tanh(c) is one exp2 + rcp
+        // of it with no multiply on the step's chain -, o in the high half
+        const float act_m = half == 0 ? 2.0f * K2 : 1.0f, act_a = half == 0 ? -K2 : 0.0f;
         const int band0 = d == 0 ? 0 : kBands - 1;
         const int xd = d == 0 ? 128 : -128, yd = d == 0 ? LDY : -LDY;
         // layer 0, tile A
@@ -461,11 +463,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     const float a0 = p0.x + p0.y, a1 = p1.x + p1.y;
                     const float s0v = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a0));                                   // low: i, high: f
                     const float s1v = __builtin_fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a1)), act_m, act_a);      // low: g, high: o
-                    float x = s0v, y = s0v * s1v;                                    // low y: i * g
-                    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));       // x.hi <- y.lo: the high lanes hold i * g in x
-                    const float cn = __builtin_fmaf(s0v, cs, x);                     // high: f * c + i * g   (low lanes: bounded garbage)
+                    float x = s0v, y = s0v * s1v;                                    // low y: K2 i g
+                    const float o2 = 2.0f * s1v, on = -s1v;                          // (off the chain)
+                    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));       // x.hi <- y.lo: the high lanes hold K2 i g in x
+                    const float cn = __builtin_fmaf(s0v, cs, x);                     // high: K2 (f c + i g)   (low lanes: bounded garbage)
                     cs = cn;
-                    const float hn = s1v * (2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(K2 * cn)) - 1.0f);     // high: o * tanh(c)
+                    const float hn = __builtin_fmaf(o2, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cn)), on);       // high: o (2 r - 1) = o tanh(c)
                     *(half ? hb + (par ^ 1) * HH + u : ydump) = hn;
                     *(half ? Yf + yo : ydump) = hn;
                     yo += yd;
