@@ -120,6 +120,7 @@ struct BArgs {
     float* mlp_pre;
     int mlp_tpw;              // bsrnn_mlp_kernel: sixteen-stream tiles per wave (> 1 only where a band's layer-2 weights all sit in the register ring: C = 16)
     float* sb_y;              // stream-batched layers (bsrnn_sb_kernels.hip.h): the band LSTM's outputs of the running layer [B][2][31][HH]
+    int ov_off;               // fe_set_step_kernel(FE_STEP_KERNEL_WAVES4): PART 1 on the phase-by-phase kernel instead of the role-split one
 };
 
 // debug stage table: spec_in, compressed, band_split, (layer.l.time, layer.l.freq)..., mask_mlp, spec_out
@@ -1250,8 +1251,8 @@ void blaunch_split_impl(const BArgs& a, int max_wgs, hipStream_t st, hipError_t*
     // r5: at most one stream per CU and num_channels = 16 - the role-split PART 1 (bsrnn_ov_kernels.hip.h: the scans alone on two
     // waves, the layers' matrix-core work under them on the other two).  FE_BSRNN_OV=0: the phase-by-phase kernel, for A/B runs.
     static const bool ov_on = [] { const char* e = getenv("FE_BSRNN_OV"); return !(e && e[0] == '0'); }();
-    if (S::C == 16 && ov_on && a.B <= max_wgs && a.clk != nullptr) blaunch_ov<S, true>(a, a.B, st, err);      // (fe_profile_step with FE_BSRNN_OV_PROF=1)
-    else if (S::C == 16 && ov_on && a.B <= max_wgs) blaunch_ov<S>(a, a.B, st, err);
+    if (S::C == 16 && ov_on && !a.ov_off && a.B <= max_wgs && a.clk != nullptr) blaunch_ov<S, true>(a, a.B, st, err);      // (fe_profile_step with FE_BSRNN_OV_PROF=1)
+    else if (S::C == 16 && ov_on && !a.ov_off && a.B <= max_wgs) blaunch_ov<S>(a, a.B, st, err);
     else if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 1>(a, a.B < 2 * max_wgs ? a.B : 2 * max_wgs, st, err);
     else blaunch_part<S, false, 1>(a, a.B < max_wgs ? a.B : max_wgs, st, err);
     if (*err != hipSuccess) return;

@@ -1598,6 +1598,7 @@ int ensure_bsplit(fe_handle* h, int B) {
 int launch_bsrnn(fe_handle* h, const fe::BArgs& a_in, void* stream) {
     hipError_t e = hipSuccess;
     fe::BArgs a = a_in;
+    a.ov_off = h->step_kernel == FE_STEP_KERNEL_WAVES4 ? 1 : 0;
     // (FE_BSRNN_OV_PROF=1: fe_profile_step probes the role-split PART 1 of the three-launch step instead of the fused kernel's phases)
     static const bool ov_prof = [] { const char* e = getenv("FE_BSRNN_OV_PROF"); return e && e[0] == '1'; }();
     if (a.mode == fe::FE_MODE_STREAM && a.T == 1 && a.dbg == nullptr && (a.clk == nullptr || (ov_prof && h->cfg.channels == 16 && a.B <= h->max_wgs))) {

@@ -181,7 +181,10 @@ int fe_set_time_pipeline(fe_handle* h, int frames_in_flight);
  *   FE_STEP_KERNEL_WG8_PERSIST: the same also above that (persistent workgroups instead of the low-LDS companion kernel).
  * The two kernels agree to fp32 rounding (a few 1e-8 on the waveform), not bit for bit: a caller that needs a chunked launch
  * (T > 1) to be bit-identical to T per-hop launches selects FE_STEP_KERNEL_WAVES4.  The environment variable FE_WG8 = 0 | 1 | 2
- * sets the default of new handles (any other value is ignored).  The reference has one forward only (models/fastenhancer/default/model.py:677-710). */
+ * sets the default of new handles (any other value is ignored).  The reference has one forward only (models/fastenhancer/default/model.py:677-710).
+ * BSRNN with num_channels = 16 (r5): FE_STEP_KERNEL_WAVES4 runs the layers of the per-hop step phase by phase on all four waves
+ * (bsrnn_frame_kernel<PART 1>), any other value the role-split kernel (bsrnn_ov_kernels.hip.h) for batches of up to one stream per CU;
+ * the two agree to fp32 rounding.  (models/bsrnn/model.py:367-390) */
 #define FE_STEP_KERNEL_WAVES4 0
 #define FE_STEP_KERNEL_WG8 1
 #define FE_STEP_KERNEL_WG8_PERSIST 2

@@ -575,6 +575,43 @@ def test_full_size_bsrnn_xt_256_streams():
     _full_size_check(m, orc, cfg, sr, 256, 4, [0, 1, 17, 128, 254, 255], "bsrnn_xt B=256")
 
 
+@pytest.mark.parametrize("name,B", [("bsrnn_xt", 256), ("bsrnn_xt", 5), ("bsrnn_xxt", 64)])
+def test_bsrnn_role_split_part1_agrees_with_the_phase_by_phase_kernel(name, B):
+    """r5: the per-hop step's PART 1 for num_channels = 16 at up to one stream per CU runs on the role-split kernel (bsrnn_ov_kernels.hip.h:
+    the scans alone on two waves, the layers' matrix-core chains on the other two, LDS counters between them);
+    fe_set_step_kernel(FE_STEP_KERNEL_WAVES4) selects the phase-by-phase kernel.  Both against the oracle on sampled streams, and against
+    each other on every stream and every cache - twelve hops, so that the time-LSTM state both kernels write back is fed forward."""
+    m, orc, cfg, sr, seed = _bsrnn(name)
+    eng = m.engine
+    hops, H = 12, cfg.hop_size
+    x = make_input(B, hops * H, seed + 77, sr)
+    xd = torch.from_numpy(x).to(_dev())
+    res = {}
+    for kern in ("wg8", "waves4"):
+        eng.set_step_kernel(kern)
+        state = eng.new_state(B)
+        outs = [eng.step(xd[:, t * H:(t + 1) * H].contiguous(), state, T=1).cpu().numpy() for t in range(hops)]
+        res[kern] = (np.concatenate(outs, 1), [c.cpu().numpy() for c in eng.split_state(state, B)])
+    eng.set_step_kernel("wg8")
+    sel = sorted(set([0, 1, B // 2, B - 1]))
+    caches = orc.initialize_cache(len(sel))
+    refs = []
+    for t in range(hops):
+        o, *caches = orc.step(x[sel][:, t * H:(t + 1) * H], *caches)
+        refs.append(o)
+    ref = np.concatenate(refs, 1)
+    for kern in ("wg8", "waves4"):
+        _assert_close(res[kern][0][sel], ref, f"{name} B={B} {kern} wav_out")
+        for got, want in zip(res[kern][1], caches):
+            _assert_close(got[sel] if got.shape[0] == B else got.reshape(B, -1)[sel].reshape(want.shape), want, f"{name} B={B} {kern} cache")
+    scale = float(np.sqrt(np.mean(ref ** 2)))
+    d = float(np.sqrt(np.mean((res["wg8"][0] - res["waves4"][0]) ** 2))) / scale
+    assert d < 3e-6, d
+    for a_, b_ in zip(res["wg8"][1], res["waves4"][1]):
+        sc = float(np.sqrt(np.mean(b_ ** 2))) + 1e-12
+        assert float(np.sqrt(np.mean((a_ - b_) ** 2))) / sc < 3e-6
+
+
 def test_win_size_smaller_than_n_fft():
     """ONNXSTFT pads a shorter window to n_fft (functional/audio_modules.py:213-217); no shipped yaml uses it."""
     from oracle.fe_oracle import FEConfig as OCfg, FEOracle, fold_state_dict
