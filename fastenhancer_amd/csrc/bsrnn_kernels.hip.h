@@ -89,6 +89,11 @@ struct BOffsets {
     int ov_ipb[8][2];          // their bias: [lane & 15][column tile (8)]
     int ov_f2[8];              // fc_freq: [k-step / 4][lane][4]
     int ov_hh[8][2];           // W_hh in the scan's lane order: [row set (2)][k / 4][lane = half * 32 + unit][4]
+    // ... and row-major pieces for the TRANSPOSED chains (bands as the N of every product: an accumulator fragment - rows 4 lg + r of lane
+    // (li, lg) - is the next product's B operand as it stands, k-step r carrying row 4 lg + r; the A operand then is W[row li][4 lg + r]):
+    int ov_tx[8];              // time LSTM, x rows: [ct][gate][16 gate rows][C] (scaled like t_w)
+    int ov_f1t[8];             // fc_time: [C][HH]
+    int ov_ipt[8][2];          // input projections per direction: [4 HH][C] (scaled like f_wih)
     int total;
 };
 

@@ -28,17 +28,18 @@ struct BOvLds {
     static constexpr int TW = SP + 2 * kBins + 2;             // twiddles
     static constexpr int FA = TW + S::NFFT;                   // FFT ping-pong
     static constexpr int FB = FA + 2 * S::NFFT;
-    static constexpr int XB = FB + 2 * S::NFFT;               // (FA: windowed frame, FB: spectrum {Re, Im} + Nyquist)   [32][LDX] band features before a layer's time LSTM (after fc_freq)
-    static constexpr int XA = XB + 32 * S::LDX;               // [32][LDX] ... after fc_time (input of the projections and of fc_freq's residual)
-    static constexpr int HN = XA + 32 * S::LDX;               // [32][LDH] the time LSTM's new h (A operand of fc_time)
-    static constexpr int YF = HN + 32 * S::LDH;               // [32][LDY] band-LSTM outputs (fwd | bwd)
+    static constexpr int XB = FB + 2 * S::NFFT;               // (FA: windowed frame, FB: spectrum {Re, Im} + Nyquist)   [32][LDX] band features: the band split's output, the last layer's
+    static constexpr int XT = (XB + 32 * S::LDX + 3) / 4 * 4; // [2 tiles][64 lanes][4]: a tile's x after fc_time as accumulator fragments (for the waves that did not compute it)
+    static constexpr int HX = XT + 2 * 256;                   // [2 pairs][2 chain parities][2 ct][64 lanes][4]: the new time-LSTM h of a wave's hidden tile, for its partner
+    static constexpr int YF = HX + 2 * 2 * 2 * 256;           // [32][LDY] band-LSTM outputs (fwd | bwd)
     static constexpr int HB = (YF + 32 * S::LDY + 3) / 4 * 4; // [2 dirs][2 buffers][HH] + [HH] dump slots of the low lanes
-    static constexpr int FLG = HB + 5 * S::HH;                // counters (ints): scan progress fwd / bwd, helper rendezvous x 2, projections ready
-    static constexpr int XP = FLG + 16;                       // [2 layer parities][2 dirs][32 bands][64 lanes][2]: gate rows in the scan's lane order
-    static constexpr int XPBUF = 2 * 32 * 128;
+    static constexpr int FLG = HB + 5 * S::HH;                // counters (ints): scan progress fwd / bwd, helper rendezvous, projections ready
+    static constexpr int XP = FLG + 16;                       // [2 layer parities][2 dirs][32 bands][XPLD]: gate rows in the scan's lane order [64 lanes][2]
+    static constexpr int XPLD = 132;                          // (+ 4: the chains store a band's row from sixteen lanes = sixteen bands at once)
+    static constexpr int XPBUF = 2 * 32 * XPLD;
     static constexpr int TOTAL = XP + 2 * XPBUF;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
-    static_assert(XP % 2 == 0 && HB % 4 == 0, "aligned f32x2 / float4 LDS reads");
+    static_assert(XP % 4 == 0 && HB % 4 == 0 && XT % 4 == 0 && XPLD % 4 == 0, "aligned f32x2 / float4 LDS accesses");
     static_assert(BYTES <= 160 * 1024, "BSRNN role-split LDS plan exceeds 160 KiB");
 };
 
@@ -95,8 +96,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     float2* fa = reinterpret_cast<float2*>(smem + L::FA);
     float2* fb = reinterpret_cast<float2*>(smem + L::FB);
     float* XB = smem + L::XB;
-    float* XA = smem + L::XA;
-    float* Hn = smem + L::HN;
+    float* XT = smem + L::XT;
+    float* HX = smem + L::HX;
     float* Yf = smem + L::YF;
     float* Hb = smem + L::HB;
     int* flg = reinterpret_cast<int*>(smem + L::FLG);
@@ -106,7 +107,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     const size_t lsz = (size_t)kBands * HH;                      // one (h or c) tensor of a layer and stream
 
     OV_CLK(0);
-    for (int i = tid; i < N / 2; i += kThreads) tw[i] = reinterpret_cast<const float2*>(wp + o.twiddle)[i];
+    // (the twiddles are requested here and parked in LDS together with the windowed frame: ONE cold round trip to memory for both)
+    static_assert(N / 2 == kThreads, "one twiddle per thread");
+    const float2 twv = reinterpret_cast<const float2*>(wp + o.twiddle)[tid];
     if (tid < 16) flg[tid] = 0;
 
     // ---------------- the roles' register sets
@@ -123,27 +126,29 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             for (int j = 0; j < 4; ++j) { W0[4 * q + j] = v0[j]; W1[4 * q + j] = v1[j]; }
         }
     };
-    // matrix-core work: hidden tile ct of the time-LSTM gates, direction ct of the projections (a pair of waves = ct 0, 1)
+    // matrix-core work: hidden tile ct of the time-LSTM gates, direction ct of the projections (a pair of waves = ct 0, 1).
+    // Every product is computed TRANSPOSED, the sixteen bands of a tile as its N: out^T [rows x bands] = W [rows x K] . in^T [K x bands].  The
+    // accumulator fragment of one product - lane (li = band, lg) holds rows 4 lg + r - IS the B operand of the next one, k-step r carrying row
+    // 4 lg + r; the A operand then is the weight matrix row-major, W[row li][4 lg + r] (BOffsets::ov_tx / ov_f1t / ov_ipt).  A tile's chain
+    // touches LDS for the scans' outputs, the exchange of the new h between the two hidden tiles, and the projections it hands to the scans.
     const int ct = wave & 1;
-    float Wt[4][KS1], Wtb[4], Wf1[KSH], Wf1b = 0.0f, Wf2[2 * KSH], Wf2b = 0.0f, Wip[8][KSC], Wipb[8];
-    f32x4 hh[2][4];             // the gates' h half (+ bias) per tile
-    float cprev[2][4];          // previous cell state of this lane's outputs per tile
-    f32x4 xr[2];                // the tiles' band features in accumulator layout
+    auto g4 = [&](int off_floats) { return *reinterpret_cast<const f32x4*>(wp + off_floats); };
+    float Wf2[2 * KSH];                          // fc_freq [C x 2 HH]: A fragments (k = 4 ks + lg over the scans' outputs, read from LDS)
+    f32x4 Wf2b, Wf1b;                            // biases of this lane's rows 4 lg + r
+    f32x4 Wtx[4], Wtb[4];                        // time LSTM, x rows of gate g: W[16 ct + li][4 lg + r]; bias of units 16 ct + 4 lg + r
+    float Wth[4][KSH];                           // ... h rows: A fragments (k = 4 ks + lg over the state, read from the state tensor)
+    f32x4 Wf1lo, Wf1hi;                          // fc_time [C x HH]: W[li][4 lg + r] (units 0..15), W[li][16 + 4 lg + r] (units 16..31)
+    f32x4 Wip[8], Wipb[8];                       // projections of direction ct, column tile j: W[16 j + li][4 lg + r], bias of rows 16 j + 4 lg + r
+    f32x4 hh[2][4];                              // the gates' h half (+ bias) per tile
+    f32x4 cprev[2];                              // previous cell state of this lane's units per tile
+    f32x4 xr[2];                                 // the tiles' band features x^T: channels 4 lg + r of band li
     auto load_proj = [&](int l, auto J0_, auto NJ_) {               // projection column-tile pairs (j, j + 4), j = J0 .. J0 + NJ - 1
         constexpr int J0 = decltype(J0_)::value, NJ = decltype(NJ_)::value;
-        static_assert(KSC == 4, "one 16-byte fetch per column tile");
 #pragma unroll
         for (int jj = 0; jj < 2 * NJ; ++jj) {
             const int j = J0 + (jj < NJ ? jj : jj - NJ + 4);
-            const f32x4 v = ld4(o.ov_ip[l][ct] + j * 256);
-#pragma unroll
-            for (int ks = 0; ks < KSC; ++ks) Wip[j][ks] = v[ks];
-        }
-        const f32x4 b0 = wb.at_gv4(o.ov_ipb[l][ct], li * 32), b1 = wb.at_gv4(o.ov_ipb[l][ct] + 4, li * 32);
-#pragma unroll
-        for (int jj = 0; jj < 2 * NJ; ++jj) {
-            const int j = J0 + (jj < NJ ? jj : jj - NJ + 4);
-            Wipb[j] = j < 4 ? b0[j & 3] : b1[j & 3];
+            Wip[j] = g4(o.ov_ipt[l][ct] + (16 * j + li) * C + 4 * lg);
+            Wipb[j] = g4(o.f_b[l][ct] + 16 * j + 4 * lg);
         }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -151,25 +156,19 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     using I4 = std::integral_constant<int, 4>;
     auto load_time = [&](int l) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g) {
+            Wtx[g] = g4(o.ov_tx[l] + ((ct * 4 + g) * 16 + li) * C + 4 * lg);
+            Wtb[g] = g4(o.t_b[l] + g * HH + 16 * ct + 4 * lg);
 #pragma unroll
-            for (int q = 0; q < KS1 / 4; ++q) {
-                const f32x4 v = ld4(o.ov_t[l] + ((ct * 4 + g) * (KS1 / 4) + q) * 256);
+            for (int q = 0; q < KSH / 4; ++q) {
+                const f32x4 v = ld4(o.ov_t[l] + ((ct * 4 + g) * (KS1 / 4) + KSC / 4 + q) * 256);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) Wt[g][4 * q + j] = v[j];
+                for (int j = 0; j < 4; ++j) Wth[g][4 * q + j] = v[j];
             }
-        {
-            const f32x4 v = wb.at_gv4(o.ov_tb[l] + ct * 64, li * 16);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) Wtb[g] = v[g];
         }
-#pragma unroll
-        for (int q = 0; q < KSH / 4; ++q) {
-            const f32x4 v = ld4(o.ov_f1[l] + q * 256);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Wf1[4 * q + j] = v[j];
-        }
-        Wf1b = wb.at16_g(o.tfc_b[l]);
+        Wf1lo = g4(o.ov_f1t[l] + li * HH + 4 * lg);
+        Wf1hi = g4(o.ov_f1t[l] + li * HH + 16 + 4 * lg);
+        Wf1b = g4(o.tfc_b[l] + 4 * lg);
         load_proj(l, I0{}, I4{});
     };
     auto load_ffc = [&](int l) {
@@ -179,7 +178,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll
             for (int j = 0; j < 4; ++j) Wf2[4 * q + j] = v[j];
         }
-        Wf2b = wb.at16_g(o.ffc_b[l]);
+        Wf2b = g4(o.ffc_b[l] + 4 * lg);
     };
     // the h half of layer l's time-LSTM gates for tile T: state fragments straight from the state tensors (pre_load), the products once
     // the layer's weights are there (pre_mma)
@@ -190,17 +189,16 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         const float* hr = hg + ov_band<T>(li) * HH + lg;
 #pragma unroll
         for (int ks = 0; ks < KSH; ++ks) af[ks] = hr[4 * ks];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cprev[T][r] = cg[ov_band<T>(4 * lg + r) * HH + 16 * ct + li];
+        cprev[T] = *reinterpret_cast<const f32x4*>(cg + ov_band<T>(li) * HH + 16 * ct + 4 * lg);
     };
     auto pre_mma = [&](auto T_, const float (&af)[KSH]) {
         constexpr int T = decltype(T_)::value;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) hh[T][g] = f32x4{Wtb[g], Wtb[g], Wtb[g], Wtb[g]};
+        for (int g = 0; g < 4; ++g) hh[T][g] = Wtb[g];
 #pragma unroll
         for (int ks = 0; ks < KSH; ++ks)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) hh[T][g] = FE_MFMA(af[ks], Wt[g][KSC + ks], hh[T][g]);
+            for (int g = 0; g < 4; ++g) hh[T][g] = FE_MFMA(Wth[g][ks], af[ks], hh[T][g]);
     };
     auto pre_gates = [&](int l, auto T_) {
         float af[KSH];
@@ -209,7 +207,6 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     };
     using TA = std::integral_constant<int, 0>;
     using TB = std::integral_constant<int, 1>;
-    __syncthreads();
 
     constexpr int BSI = (kBands * C + kThreads - 1) / kThreads;      // band-split outputs per thread
     float4 bsw[BSI][kBsKP / 4];
@@ -239,6 +236,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             for (int k = 0; k < kBsKP / 4; ++k) bsw[it][k] = w4[k * (kBands * C)];
             bsb[it] = wp[o.bs_b + ic];
         }
+        tw[tid] = twv;
 #pragma unroll
         for (int q = 0; q < NPT; ++q) { const int n = tid + q * kThreads; xw[n] = fv[q] * fw[q]; }
         __syncthreads();                           // (every read of the old cache has landed)
@@ -290,35 +288,33 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     int* const f_xpd = flg + 8;         // [2]: layers whose tile-B projections helper ct has completed (its share)
     int* const f_xpa = flg + 10;        // [2]: layers whose tile-A projections helper ct has completed
 
-    // projection column-tile pairs (j, j + 4), j = J0 .. J0 + NJ - 1, of direction ct for tile T: 16-row tiles of gate rows, stored in the
-    // scan's lane order [band][half * 32 + unit][slot] - gates (i, g) / (f, o) of a unit are the two slots of one lane (:386-388)
-    auto proj = [&](auto T_, auto J0_, auto NJ_, float* xpn) {
+    // projection column-tile pairs (j, j + 4), j = J0 .. J0 + NJ - 1, of direction ct for tile T from its x^T fragment, stored in the scan's
+    // lane order [band][half * 32 + unit][slot] - gates (i, g) / (f, o) of a unit are the two slots of one lane (:386-388): a lane holds units
+    // 4 lg + r of column tile j = 2 gate + unit half, i.e. eight consecutive floats of its band's row per pair
+    auto proj = [&](auto T_, auto J0_, auto NJ_, float* xpn, const f32x4& x) {
         constexpr int T = decltype(T_)::value, J0 = decltype(J0_)::value, NJ = decltype(NJ_)::value;
-        const float* xa = XA + ov_band<T>(li) * LDX + lg;
-        float af[KSC];
-#pragma unroll
-        for (int ks = 0; ks < KSC; ++ks) af[ks] = xa[4 * ks];
         f32x4 pa[2 * NJ];
 #pragma unroll
-        for (int jj = 0; jj < 2 * NJ; ++jj) { const float bv = Wipb[J0 + (jj < NJ ? jj : jj - NJ + 4)]; pa[jj] = f32x4{bv, bv, bv, bv}; }
+        for (int jj = 0; jj < 2 * NJ; ++jj) pa[jj] = Wipb[J0 + (jj < NJ ? jj : jj - NJ + 4)];
 #pragma unroll
-        for (int ks = 0; ks < KSC; ++ks)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int jj = 0; jj < 2 * NJ; ++jj) pa[jj] = FE_MFMA(af[ks], Wip[J0 + (jj < NJ ? jj : jj - NJ + 4)][ks], pa[jj]);
-        float* dst = xpn + ((ct * 32) * 64 + li) * 2;
+            for (int jj = 0; jj < 2 * NJ; ++jj) pa[jj] = FE_MFMA(Wip[J0 + (jj < NJ ? jj : jj - NJ + 4)][r], x[r], pa[jj]);
+        if (T == 1 || li < 15) {
+            float* dst = xpn + (ct * 32 + ov_band<T>(li)) * L::XPLD + 8 * lg;
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) {
-            const int j = J0 + jj, g = j >> 1, uh = j & 1;           // column tile j = 2 gate + unit half
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (T == 1 || r < 3 || 4 * lg + 3 < 15)
-                    *reinterpret_cast<f32x2*>(dst + (ov_band<T>(4 * lg + r) * 64 + g * 32 + 16 * uh) * 2) = f32x2{pa[jj][r], pa[jj + NJ][r]};
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int j = J0 + jj, g = j >> 1, uh = j & 1;
+                *reinterpret_cast<f32x4*>(dst + (g * 32 + 16 * uh) * 2) = f32x4{pa[jj][0], pa[jj + NJ][0], pa[jj][1], pa[jj + NJ][1]};
+                *reinterpret_cast<f32x4*>(dst + (g * 32 + 16 * uh) * 2 + 4) = f32x4{pa[jj][2], pa[jj + NJ][2], pa[jj][3], pa[jj + NJ][3]};
+            }
         }
     };
 
     int nsync = 0;
     // One tile's chain on a pair of waves.  FREQ: starts with fc_freq of the finished layer; TIME: continues with layer l's time part;
-    // PSPLIT: the scans take half of the tile's projections (tile B in the steady state: the scans have ended, their waves are free)
+    // PSPLIT: the scans take half of the tile's projections (tile B in the steady state: the scans have ended, their waves are free);
+    // DOPROJ: the projections follow at once (tile A's wait until tile B's chain is through)
     auto chain = [&](auto T_, auto FREQ_, auto TIME_, auto PSPLIT_, auto DOPROJ_, int l, float* xpn, int pair) {
         constexpr int T = decltype(T_)::value;
         constexpr bool FREQ = decltype(FREQ_)::value, TIME = decltype(TIME_)::value, PSPLIT = decltype(PSPLIT_)::value, DOPROJ = decltype(DOPROJ_)::value;
@@ -329,45 +325,40 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             }
         };
         cclk(0);
-        const int arow = ov_band<T>(li);
-        int crow[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) crow[r] = ov_band<T>(4 * lg + r);
-        const bool cok3 = T == 1 || 4 * lg + 3 < 15;                  // (tile A: its last row is a pad row)
+        const int band = ov_band<T>(li);
+        const bool valid = T == 1 || li < 15;                             // (tile A: its last column is a pad band)
         f32x4 x = xr[T];
         if constexpr (FREQ) {
-            // fc_freq + residual (:389-390): x += Yf W^T + b
-            const float* ya = Yf + arow * LDY + lg;
-            f32x4 c0 = x + f32x4{Wf2b, Wf2b, Wf2b, Wf2b}, c1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            float af[2 * KSH];
+            // fc_freq + residual (:389-390): x^T += W Yf^T + b
+            const float* ya = Yf + band * LDY + lg;
+            float yf[2 * KSH];
 #pragma unroll
-            for (int ks = 0; ks < 2 * KSH; ++ks) af[ks] = ya[4 * ks];
+            for (int ks = 0; ks < 2 * KSH; ++ks) yf[ks] = ya[4 * ks];
+            f32x4 c0 = x + Wf2b, c1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int ks = 0; ks < 2 * KSH; ks += 2) { c0 = FE_MFMA(af[ks], Wf2[ks], c0); c1 = FE_MFMA(af[ks + 1], Wf2[ks + 1], c1); }
+            for (int ks = 0; ks < 2 * KSH; ks += 2) { c0 = FE_MFMA(Wf2[ks], yf[ks], c0); c1 = FE_MFMA(Wf2[ks + 1], yf[ks + 1], c1); }
             x = c0 + c1;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < 3 || cok3) XB[crow[r] * LDX + li] = x[r];
         }
         cclk(1);
-        if constexpr (!TIME) { xr[T] = x; return; }
+        if constexpr (!TIME) {
+            xr[T] = x;
+            if (valid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) XB[band * LDX + 4 * lg + r] = x[r];      // the last layer's features, for the hand-over
+            }
+            return;
+        }
         else {
         // time-LSTM gates (LSTMCell over the bands; :371-381): the x half on top of the accumulated h half, gate math in the epilogue
         f32x4 acc[4];
-        {
-            const float* xa = XB + arow * LDX + lg;
-            float af[KSC];
 #pragma unroll
-            for (int ks = 0; ks < KSC; ++ks) af[ks] = xa[4 * ks];
+        for (int g = 0; g < 4; ++g) acc[g] = hh[T][g];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = hh[T][g];
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int ks = 0; ks < KSC; ++ks)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = FE_MFMA(af[ks], Wt[g][ks], acc[g]);
-        }
+            for (int g = 0; g < 4; ++g) acc[g] = FE_MFMA(Wtx[g][r], x[r], acc[g]);
         cclk(2);
-        float hn[4], cn[4];
+        f32x4 hn, cn;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[0][r]));
@@ -376,42 +367,39 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[3][r]));
             cn[r] = fg * cprev[T][r] + ig * gg;
             hn[r] = og * (2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(K2 * cn[r])) - 1.0f);
-            if (r < 3 || cok3) Hn[crow[r] * LDH + 16 * ct + li] = hn[r];
         }
-        cclk(3);
-        // rendezvous: both column halves of the new h are in LDS (and the partner has consumed its fragments of the old state)
+        // the two hidden tiles meet in fc_time: this wave's new h goes to its partner as a fragment (the same lane reads it back), double-
+        // buffered by chain parity; the rendezvous also says that the partner has consumed its fragments of the old state
         ++nsync;
+        float* hx = HX + ((pair * 2 + (nsync & 1)) * 2) * 256 + lane * 4;
+        *reinterpret_cast<f32x4*>(hx + ct * 256) = hn;
+        cclk(3);
         if (lane == 0) ov_signal(f_hs + 2 * pair + ct, nsync);
         ov_wait(f_hs + 2 * pair + (ct ^ 1), nsync);
+        const f32x4 hp = *reinterpret_cast<const f32x4*>(hx + (ct ^ 1) * 256);
         cclk(4);
-        {
-            // the layer's new (h, c) -> the state tensors (after the rendezvous: the partner's fragments of the old state are consumed)
-            float* hg = a.lstm + ((size_t)(2 * l) * a.B + b) * lsz;
-            float* cg = hg + (size_t)a.B * lsz;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < 3 || cok3) { hg[crow[r] * HH + 16 * ct + li] = hn[r]; cg[crow[r] * HH + 16 * ct + li] = cn[r]; }
+        if (valid) {
+            // the layer's new (h, c) -> the state tensors: units 16 ct + 4 lg + r of band li, 16 bytes each
+            float* hg = a.lstm + ((size_t)(2 * l) * a.B + b) * lsz + band * HH + 16 * ct + 4 * lg;
+            *reinterpret_cast<f32x4*>(hg) = hn;
+            *reinterpret_cast<f32x4*>(hg + (size_t)a.B * lsz) = cn;
         }
-        // fc_time + residual (:382-384): x += h' W^T + b
+        // fc_time + residual (:382-384): x^T += W h'^T + b.  Both waves of the pair compute it, in the SAME order (units 0..15 into c0,
+        // 16..31 into c1, whoever produced them): their x must agree bit for bit - either one's copy is read by other waves
         {
-            const float* ha = Hn + arow * LDH + lg;
-            float af[KSH];
+            const f32x4 hlo = ct ? hp : hn, hhi = ct ? hn : hp;
+            f32x4 c0 = x + Wf1b, c1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int ks = 0; ks < KSH; ++ks) af[ks] = ha[4 * ks];
-            f32x4 c0 = x + f32x4{Wf1b, Wf1b, Wf1b, Wf1b}, c1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int ks = 0; ks < KSH; ks += 2) { c0 = FE_MFMA(af[ks], Wf1[ks], c0); c1 = FE_MFMA(af[ks + 1], Wf1[ks + 1], c1); }
+            for (int r = 0; r < 4; ++r) { c0 = FE_MFMA(Wf1lo[r], hlo[r], c0); c1 = FE_MFMA(Wf1hi[r], hhi[r], c1); }
             x = c0 + c1;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < 3 || cok3) XA[crow[r] * LDX + li] = x[r];
             xr[T] = x;
         }
+        *reinterpret_cast<f32x4*>(XT + (T * 64 + lane) * 4) = x;          // (for the waves that take part of this tile's work without having computed x)
         if constexpr (PSPLIT) { if (lane == 0) ov_signal(f_xa + ct, l); }
         cclk(5);
         if constexpr (DOPROJ) {
-            if constexpr (PSPLIT) proj(T_, I2{}, I2{}, xpn);
-            else proj(T_, I0{}, I4{}, xpn);
+            if constexpr (PSPLIT) proj(T_, I2{}, I2{}, xpn, x);
+            else proj(T_, I0{}, I4{}, xpn, x);
         }
         cclk(6);
         cclk(7);
@@ -426,10 +414,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         // of it with no multiply on the step's chain -, o in the high half
         const float act_m = half == 0 ? 2.0f * K2 : 1.0f, act_a = half == 0 ? -K2 : 0.0f;
         const int band0 = d == 0 ? 0 : kBands - 1;
-        const int xd = d == 0 ? 128 : -128, yd = d == 0 ? LDY : -LDY;
+        const int xd = d == 0 ? L::XPLD : -L::XPLD, yd = d == 0 ? LDY : -LDY;
         // layer 0, tile A
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xr[0][r] = XB[ov_band<0>(4 * lg + r) * LDX + li];
+        for (int r = 0; r < 4; ++r) xr[0][r] = XB[ov_band<0>(li) * LDX + 4 * lg + r];
         chain(TA{}, std::false_type{}, std::true_type{}, std::false_type{}, std::true_type{}, 0, XPs, 1);
 #pragma unroll 1
         for (int l = 0; l < S::NLAY; ++l) {
@@ -440,7 +428,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             const float* xp = XPs + (l & 1) * L::XPBUF;
             hb[lane] = 0.0f;                                             // h = 0, both buffers
             float cs = 0.0f;
-            int xo = ((d * 32 + band0) * 64 + lane) * 2, yo = band0 * LDY + d * HH + u;
+            int xo = (d * 32 + band0) * L::XPLD + lane * 2, yo = band0 * LDY + d * HH + u;
             f32x2 xp_next = *reinterpret_cast<const f32x2*>(xp + xo);
             auto steps = [&](int s0, int s1) {
 #pragma unroll 1
@@ -490,13 +478,13 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                 load_whh(l + 1);
                 load_proj(l + 1, I0{}, I2{});
                 ov_wait(f_xa + d, l + 1);
-                proj(TB{}, I0{}, I2{}, XPs + ((l + 1) & 1) * L::XPBUF);
+                proj(TB{}, I0{}, I2{}, XPs + ((l + 1) & 1) * L::XPBUF, *reinterpret_cast<const f32x4*>(XT + (64 + lane) * 4));
             }
         }
     } else {
         // ================================================ the matrix-core work ================================================
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xr[1][r] = XB[ov_band<1>(4 * lg + r) * LDX + li];
+        for (int r = 0; r < 4; ++r) xr[1][r] = XB[ov_band<1>(li) * LDX + 4 * lg + r];
         chain(TB{}, std::false_type{}, std::true_type{}, std::false_type{}, std::true_type{}, 0, XPs, 0);
         if (lane == 0) ov_signal(f_xpd + ct, 1);
         OV_CLK(2);
@@ -510,10 +498,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             if (l == 0) OV_CLK(3);
             ov_wait(f_prog, 32 * l + 23);
             ov_wait(f_prog + 1, 32 * l + 23);
-            if (l == 0) {         // (tile A's x after layer 0's time part was computed by the scan waves)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xr[0][r] = XA[ov_band<0>(4 * lg + r) * LDX + li];
-            }
+            if (l == 0) xr[0] = *reinterpret_cast<const f32x4*>(XT + lane * 4);      // (tile A's x after layer 0's time part was computed by the scan waves)
             if (l == 0) OV_CLK(4);
             // tile A up to its x after fc_time: its projections are not needed before step 8 of the next layer's scans and wait until
             // tile B's chain - the only serial piece - is through
@@ -528,7 +513,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             else chain(TB{}, std::true_type{}, std::false_type{}, std::false_type{}, std::false_type{}, l + 1, xpn, 0);
             if (more && lane == 0) ov_signal(f_xpd + ct, l + 2);
             if (more) {
-                proj(TA{}, I0{}, I4{}, xpn);                  // under steps 0..7 of layer l + 1's scans
+                proj(TA{}, I0{}, I4{}, xpn, xr[0]);            // under steps 0..7 of layer l + 1's scans
                 if (lane == 0) ov_signal(f_xpa + ct, l + 2);
             }
             if (l == 0) OV_CLK(7);

@@ -941,6 +941,15 @@ int pack_weights_bsrnn(fe_handle* h, const std::vector<float>& blob, std::vector
                         for (int j = 0; j < 4; ++j) buf[off + ((size_t)q * 64 + lane) * 4 + j] = buf[src + (size_t)(4 * q + j) * 64 + lane];
                 return off;
             };
+            o.ov_tx[l] = alloc((size_t)NCT * 4 * 16 * C);
+            for (int ct = 0; ct < NCT; ++ct)
+                for (int g = 0; g < 4; ++g)
+                    for (int r = 0; r < 16; ++r)
+                        for (int ch = 0; ch < C; ++ch)
+                            buf[o.ov_tx[l] + (((size_t)(ct * 4 + g) * 16 + r) * C) + ch] = buf[o.t_w[l] + ((size_t)(g * NCT + ct) * KS1 + ch / 4) * 64 + (ch % 4) * 16 + r];
+            o.ov_f1t[l] = alloc((size_t)C * HH);
+            for (int ch = 0; ch < C; ++ch)
+                for (int un = 0; un < HH; ++un) buf[o.ov_f1t[l] + (size_t)ch * HH + un] = buf[o.tfc_w[l] + (size_t)(un / 4) * 64 + (un % 4) * 16 + ch];
             o.ov_f1[l] = regroup(o.tfc_w[l], KSH);
             o.ov_f2[l] = regroup(o.ffc_w[l], 2 * KSH);
             for (int d = 0; d < 2; ++d) {
@@ -951,6 +960,11 @@ int pack_weights_bsrnn(fe_handle* h, const std::vector<float>& blob, std::vector
                 o.ov_ipb[l][d] = alloc(16 * 8);
                 for (int li = 0; li < 16; ++li)
                     for (int j = 0; j < 8; ++j) buf[o.ov_ipb[l][d] + li * 8 + j] = buf[o.f_b[l][d] + j * 16 + li];
+                // row-major for the transposed chains: W[n][ch] = fragment (tile n / 16, k-step ch / 4) lane (ch % 4) * 16 + n % 16
+                o.ov_ipt[l][d] = alloc((size_t)G4 * C);
+                for (int n = 0; n < G4; ++n)
+                    for (int ch = 0; ch < C; ++ch)
+                        buf[o.ov_ipt[l][d] + (size_t)n * C + ch] = buf[o.f_wih[l][d] + ((size_t)(n / 16) * KSC + ch / 4) * 64 + (ch % 4) * 16 + n % 16];
                 // W_hh: lane = half * 32 + unit holds gate rows (half, 2 + half) of its unit; source [k][4 u + gate] (register shapes, NTD = 128)
                 o.ov_hh[l][d] = alloc((size_t)2 * (HH / 4) * 256);
                 for (int rs = 0; rs < 2; ++rs)
