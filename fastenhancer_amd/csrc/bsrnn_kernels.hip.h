@@ -1073,8 +1073,12 @@ __global__ void __launch_bounds__(kThreads) bsrnn_mlp_kernel(BArgs a) {
     const int kind = kb / kBands, band = kb - kind * kBands;
     // a wave takes `tpw` sixteen-stream tiles of its band, one after the other (large batches of the C = 16 shapes: the band's weights - all of
     // them in registers there - are fetched once per wave instead of once per tile: the kernel ran at a third of its MFMA time, on weight loads)
+    // mlp_tpw = 0 (r5, small batches - fewer 64-stream groups than CUs): the four waves of a workgroup share ONE sixteen-stream tile and split
+    // the band's layer-2 column tiles between them (layer 1 - 16 MFMAs - is computed by each): a wide band's five dependent 16-MFMA items were
+    // the kernel's critical path
+    const bool split = a.mlp_tpw == 0;
     const int tpw = a.mlp_tpw > 1 ? a.mlp_tpw : 1;
-    const int tile0 = (tg * kWaves + wave) * tpw;
+    const int tile0 = split ? tg : (tg * kWaves + wave) * tpw;
     if (tile0 * 16 >= a.B) return;                            // (wave-uniform; the kernel has no barrier)
     const float* __restrict__ wp = a.wp;
     const BOffsets& o = a.off;
@@ -1084,10 +1088,14 @@ __global__ void __launch_bounds__(kThreads) bsrnn_mlp_kernel(BArgs a) {
     const int n2 = 4 * bsrnn_band_sub(band), row0 = 4 * bsrnn_band_bin0(band);
     const int nt2 = (n2 + 15) >> 4;
     constexpr int KB = KS2 < 16 ? KS2 : 16, NB = KS2 / KB, D = NB == 1 ? 5 : 8;   // (C = 16: a band has at most five items - all in flight at once)
-    const int nit = nt2 * NB;
+    const int nit_all = nt2 * NB;
+    // (split: this wave's items are wave, wave + 4, ... of the band's list - whole column tiles: NB = 1 there)
+    const int nit = (split && NB == 1) ? (nit_all - wave + kWaves - 1) / kWaves : nit_all;
+    if (split && NB == 1 && nit == 0) return;                 // (a narrow band: fewer column tiles than waves)
     auto row_of = [&](int nt) { const int c = 16 * nt + li; return row0 + (c < n2 ? c : n2 - 1); };
-    auto load_item = [&](int it, float (&wv)[KB], float& bias) {
-        if (it < nit) {
+    auto load_item = [&](int itl, float (&wv)[KB], float& bias) {
+        if (itl < nit) {
+            const int it = (split && NB == 1) ? wave + kWaves * itl : itl;
             const int nt = it / NB, kbi = it - nt * NB, row = row_of(nt);
             const float* w2 = wp + o.m_w2[kind] + (size_t)row * 4 + lg + (size_t)(kbi * KB) * kMlpRows * 4;
 #pragma unroll
@@ -1146,8 +1154,9 @@ __global__ void __launch_bounds__(kThreads) bsrnn_mlp_kernel(BArgs a) {
         for (int g = 0; g * D < nit; ++g) {
 #pragma unroll
             for (int jj = 0; jj < D; ++jj) {
-                const int it = g * D + jj;
-                if (it < nit) {
+                const int itl = g * D + jj;
+                if (itl < nit) {
+                    const int it = (split && NB == 1) ? wave + kWaves * itl : itl;
                     const int nt = it / NB, kbi = it - nt * NB;
                     if (kbi == 0) acc = f32x4{rbias[jj], rbias[jj], rbias[jj], rbias[jj]};
                     // (av is indexed by compile-time k-steps: one unrolled body per burst position)
@@ -1168,7 +1177,7 @@ __global__ void __launch_bounds__(kThreads) bsrnn_mlp_kernel(BArgs a) {
                         }
                     }
                 }
-                load_item(it + D, ring[jj], rbias[jj]);
+                load_item(itl + D, ring[jj], rbias[jj]);
             }
         }
     }
@@ -1271,8 +1280,11 @@ void blaunch_split_impl(const BArgs& a, int max_wgs, hipStream_t st, hipError_t*
             if (e != hipSuccess) { *err = e; return; }
             attr_set[dev].store(true, std::memory_order_relaxed);
         }
-        const int groups = (a.B + 16 * kWaves - 1) / (16 * kWaves);
-        hipLaunchKernelGGL(fn, dim3(2 * kBands * groups), dim3(kThreads), BMlpLds<S>::BYTES, st, a);
+        BArgs am = a;
+        const bool msplit = S::C == 16 && a.B <= max_wgs;      // (fewer 64-stream groups than CUs: one sixteen-stream tile per workgroup, column tiles over its waves)
+        am.mlp_tpw = msplit ? 0 : 1;
+        const int groups = msplit ? (a.B + 15) / 16 : (a.B + 16 * kWaves - 1) / (16 * kWaves);
+        hipLaunchKernelGGL(fn, dim3(2 * kBands * groups), dim3(kThreads), BMlpLds<S>::BYTES, st, am);
         *err = hipGetLastError();
         if (*err != hipSuccess) return;
     }
