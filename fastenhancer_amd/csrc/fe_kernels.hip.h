@@ -140,6 +140,9 @@ struct Shape {
 // Offsets (floats) of the packed weights inside the handle's device buffer.  The layout is a pure
 // function of the shape, evaluated at compile time and shared by the host packer (fe_api.hip) and the
 // kernel, where every offset folds into an instruction immediate / one SGPR add.
+#ifndef FE_FBAL
+#define FE_FBAL 1           // r5: rnn_fc / attn_fc of the shapes with more than four column tiles over balanced (column tile, row tile) jobs (fe_frame_kernel; 0: whole column tiles, for A/B runs)
+#endif
 #ifndef FE_K4_STREAM
 #define FE_K4_STREAM 1      // r4x: shapes that stream their block weights from L2 inside the GEMMs (M, L, their 48 kHz / variant shapes) fetch four k-steps per 16-byte load too
 #endif
@@ -1887,6 +1890,100 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
             const int col = 16 * (wave + 4 * j) + li;
             return base + (4 * lg) * LDX + (col < C2 ? col : C2);
         };
+        // r5, FBAL: shapes with more than four column tiles and streamed block weights (M: 5 tiles, L: 6) gave whole column tiles of rnn_fc / attn_fc
+        // to the waves - 2:1:1:1 / 2:2:1:1.  Now a wave owns column tile `wave` (all row tiles: slot 0 of xr / pe_r) and the extra tiles' (row tile,
+        // column tile) items q = wave + 4 x, x < NXI (slot 1, index x): L 6 + 6 + 6 + 6 tile-rows instead of 8 + 8 + 4 + 4, M 4 + 4 + 4 + 3 instead of
+        // 6 + 3 + 3 + 3.  (The GRU phase of these shapes has been running on such jobs since r2: GBAL.)
+        constexpr bool FBAL = FE_FBAL && !REGW && S::NT2 > 4 && S::NT2 <= 8 && !S::LN;
+        constexpr int NE = FBAL ? S::NT2 - 4 : 1, NXQ = NE * S::MT2, NXI = FBAL ? ceil_div(NXQ, kWaves) : 1;
+        static_assert(!FBAL || (NXI <= S::MT2 && NTPW2 == 2), "FBAL: the extra items live in slot 1 of the residual registers");
+        constexpr bool XSAME = (kWaves % S::MT2) == 0;      // every extra item of a wave lies in the same row tile: one A fragment serves them
+        auto x_ok = [&](int x) { return wave + kWaves * x < NXQ; };
+        auto x_ct = [&](int x) { int q = wave + kWaves * x; q = q < NXQ ? q : NXQ - 1; return 4 + q / S::MT2; };
+        auto x_rt = [&](int x) { int q = wave + kWaves * x; q = q < NXQ ? q : NXQ - 1; return q % S::MT2; };
+        auto x_dst = [&](float* base, int x) {               // like tok_dst: rows 4 lg + r of the item's row tile, its column (pad column past C2)
+            const int col = 16 * x_ct(x) + li;
+            return base + (16 * x_rt(x) + 4 * lg) * LDX + (col < C2 ? col : C2);
+        };
+        // acc = bias + A(LDS tokens) x W for the wave's FBAL jobs: accb = column tile `wave`, accx[x] = extra item x
+        auto fc_gemm_bal = [&](f32x4 (&accb)[S::MT2][1], f32x4 (&accx)[1][NXI], const float* abase, int w_off, int b_off) {
+            if constexpr (FBAL) {
+                const int wk4 = w_off + wb.k4d;
+                constexpr int KS = S::KS_2;
+                f32x4 cache[NXI + 1];
+                auto wget = [&](int slot, int t, int ks) -> float {      // TokW::get for an explicit column tile (streamed, k4 copy)
+                    if (ks >= 4 * (KS / 4)) return wb.at_gv(wk4 + (t * KS + ks) * 64, wb.lane4);
+                    if ((ks & 3) == 0) cache[slot] = wb.at_gv4(wk4 + t * (KS * 64) + (ks >> 2) * 256, wb.lane4 * 4);
+                    return cache[slot][ks & 3];
+                };
+                {
+                    const float bj = wb.at_gv(b_off + wave * 16, wb.li4);
+#pragma unroll
+                    for (int i = 0; i < S::MT2; ++i) accb[i][0] = f32x4{bj, bj, bj, bj};
+                    const float* a_lane = abase + li * LDX + lg;
+                    mma_panel<S::MT2, 1, KS, Lds<S>::PDK>(accb, [&](int i, int ks) { return a_lane[(16 * i) * LDX + 4 * ks]; },
+                                                          [&](int, int ks) { return wget(0, wave, ks); }, NoSide{});
+                }
+#pragma unroll
+                for (int x = 0; x < NXI; ++x) { const float bj = wb.at_gv(b_off + x_ct(x) * 16, wb.li4); accx[0][x] = f32x4{bj, bj, bj, bj}; }
+                if constexpr (XSAME) {
+                    const float* a_lane = abase + (16 * x_rt(0) + li) * LDX + lg;
+                    mma_panel<1, NXI, KS, Lds<S>::PDK>(accx, [&](int, int ks) { return a_lane[4 * ks]; },
+                                                       [&](int x, int ks) { return wget(1 + x, x_ct(x), ks); }, NoSide{});
+                } else {
+#pragma unroll
+                    for (int x = 0; x < NXI; ++x) {
+                        f32x4 a1[1][1];
+                        a1[0][0] = accx[0][x];
+                        const float* a_lane = abase + (16 * x_rt(x) + li) * LDX + lg;
+                        mma_panel<1, 1, KS, Lds<S>::PDK>(a1, [&](int, int ks) { return a_lane[4 * ks]; },
+                                                         [&](int, int ks) { return wget(1 + x, x_ct(x), ks); }, NoSide{});
+                        accx[0][x] = a1[0][0];
+                    }
+                }
+            }
+        };
+        // x += acc (+ pe) for the FBAL jobs, into the residual registers and the token buffer
+        auto fc_epi_bal = [&](const f32x4 (&accb)[S::MT2][1], const f32x4 (&accx)[1][NXI], bool add_pe) {
+            if constexpr (FBAL) {
+                float* xd = tok_dst(Xb, 0);
+#pragma unroll
+                for (int i = 0; i < S::MT2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = accb[i][0][r] + xr[i][0][r];
+                        if (add_pe) v += pe_r[i][0][r];
+                        xr[i][0][r] = v;
+                        xd[(16 * i + r) * LDX] = v;
+                    }
+#pragma unroll
+                for (int x = 0; x < NXI; ++x)
+                    if (x_ok(x)) {
+                        float* xe = x_dst(Xb, x);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = accx[0][x][r] + xr[x][1][r];
+                            if (add_pe) v += pe_r[x][1][r];
+                            xr[x][1][r] = v;
+                            xe[r * LDX] = v;
+                        }
+                    }
+            }
+        };
+        auto pe_load = [&]() {
+#pragma unroll
+            for (int i = 0; i < S::MT2; ++i)
+#pragma unroll
+                for (int j = 0; j < NTPW2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int row = 16 * i + 4 * lg + r, col = 16 * (wave + 4 * j) + li;
+                        if constexpr (FBAL) {
+                            if (j == 1) { row = 16 * x_rt(i < NXI ? i : 0) + 4 * lg + r; col = 16 * x_ct(i < NXI ? i : 0) + li; }
+                        }
+                        pe_r[i][j][r] = wb.gather_g(o.blk_pe + (row < F2 ? row : F2 - 1) * C2 + (col < C2 ? col : C2 - 1));   // (pad rows / columns are never stored)
+                    }
+        };
         // LDS slot of hidden-state element tid + q * 256 (elements past F2 * C2 park in row 0's pad column)
         int hs_off[HPT];
 #pragma unroll
@@ -1967,6 +2064,19 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
         __syncthreads();
         // reload of the residual registers from the token buffer (ln variant: the norm passes update x in LDS)
         auto xr_reload = [&]() {
+            if constexpr (FBAL) {
+                const float* xd = tok_dst(Xb, 0);
+#pragma unroll
+                for (int i = 0; i < S::MT2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xr[i][0][r] = xd[(16 * i + r) * LDX];
+#pragma unroll
+                for (int x = 0; x < NXI; ++x) {
+                    const float* xe = x_dst(Xb, x);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xr[x][1][r] = xe[r * LDX];
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -1975,12 +2085,13 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
 #pragma unroll
                     for (int r = 0; r < 4; ++r) xr[i][j][r] = xd[(16 * i + r) * LDX];
                 }
+            }
         };
         if constexpr (S::LN) {
             FE_LN_SITE(F2, C2, LDX, false, Xb, 1 + S::NL);
             __syncthreads();
             xr_reload();
-        }
+        } else if constexpr (FBAL) xr_reload();         // (rf_pre's GEMM hands out whole column tiles: pick the residual up under the fc layers' ownership)
         dbg_dump<S>(a, b, 3 + S::NL, Xb, LDX);
 
         FE_CLK(6);
@@ -2004,17 +2115,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 if constexpr (!REGW) Wtq.bind(wb, (o.blk_tqkv[0] + kb), -1, S::NT3, wave);
                 Wf1.bind(wb, (o.blk_fc1_w[0] + kb), (o.blk_fc1_b[0] + kb), S::NT2, wave);   // fetched inside the GEMM below
                 if constexpr (GFLAT) Wq.bind(wb, (o.blk_qkv[0] + kb), -1, S::NT3, wave);
-                if (k == 0) {
-#pragma unroll
-                    for (int i = 0; i < S::MT2; ++i)
-#pragma unroll
-                        for (int j = 0; j < NTPW2; ++j)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = 16 * i + 4 * lg + r, col = 16 * (wave + 4 * j) + li;
-                                pe_r[i][j][r] = wb.gather_g(o.blk_pe + (row < F2 ? row : F2 - 1) * C2 + (col < C2 ? col : C2 - 1));
-                            }
-                }
+                if (k == 0) pe_load();
                 {
                     f32x4 acc[S::MT2][NTPW3];
                     if constexpr (GFLAT) tok_gemm_w<S, NTPW3, S::KS_2, LDX>(acc, Xb + li * LDX + lg, Wtq, FetchSide2<decltype(Wf1), decltype(Wq)>{&Wf1, &Wq});
@@ -2260,17 +2361,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 // GFLAT: the qkv weights ride in this (long) GEMM too, attn_fc's in rnn_fc's - fetched one short phase
                 // ahead they were still in flight when their GEMM started
                 if constexpr (GFLAT) Wq.bind(wb, (o.blk_qkv[0] + kb), (S::FRNN ? o.blk_qkv_b[0] + kb : -1), S::NT3, wave);
-                if (k == 0) {
-#pragma unroll
-                    for (int i = 0; i < S::MT2; ++i)
-#pragma unroll
-                        for (int j = 0; j < NTPW2; ++j)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = 16 * i + 4 * lg + r, col = 16 * (wave + 4 * j) + li;
-                                pe_r[i][j][r] = wb.gather_g(o.blk_pe + (row < F2 ? row : F2 - 1) * C2 + (col < C2 ? col : C2 - 1));   // (pad rows / columns are never stored)
-                            }
-                }
+                if (k == 0) pe_load();
                 // Shapes with more than four column tiles and streamed weights (M: 5 tiles, L: 6): handing whole column
                 // tiles to the waves leaves them 2:1:1:1 / 2:2:1:1 loaded.  Their GRU phase - it writes only to LDS and
                 // the state, no register-resident residual - runs over (column tile, row-tile group) jobs instead,
@@ -2500,6 +2591,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 // x += rnn_fc(h') (+ pe in block 0)
                 constexpr int NTPW = NTPW2;
                 f32x4 acc[S::MT2][NTPW];
+                if constexpr (FBAL) {
+                    Wq.bind(wb, (o.blk_qkv[0] + kb), (S::FRNN ? o.blk_qkv_b[0] + kb : -1), S::NT3, wave);
+                    f32x4 accb[S::MT2][1], accx[1][NXI];
+                    fc_gemm_bal(accb, accx, Hl, (o.blk_fc1_w[0] + kb), (o.blk_fc1_b[0] + kb));
+                    fc_epi_bal(accb, accx, k == 0);
+                } else
                 if constexpr (GFLAT) {
                     Wf2.bind(wb, (o.blk_fc2_w[0] + kb), (o.blk_fc2_b[0] + kb), S::NT2, wave);
                     tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf1, FetchSide<decltype(Wf2)>{&Wf2});
@@ -2518,7 +2615,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) td[(16 * i + r) * LDG + 64 * j] = acc[i][j][r];
                             }
-                } else {
+                } else if constexpr (!FBAL) {
 #pragma unroll
                 for (int i = 0; i < S::MT2; ++i)
 #pragma unroll
@@ -2691,6 +2788,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     for (int q = 0; q < HPT; ++q) { const int i = tid + q * kThreads; hpre[q] = hgn[i < F2 * C2 ? i : F2 * C2 - 1]; }
                 }
                 f32x4 acc[S::MT2][NTPW];
+                f32x4 accb[S::MT2][1], accx[1][NXI];
+                if constexpr (FBAL) {
+                    if constexpr (S::TATT) Wtq.bind(wb, (o.blk_tqkv[0] + kb + o.blk_stride), -1, S::NT3, wave, k + 1 < S::KB);
+                    fc_gemm_bal(accb, accx, Hl, (o.blk_fc2_w[0] + kb), (o.blk_fc2_b[0] + kb));
+                } else
                 if constexpr (S::TATT) {
                     Wtq.bind(wb, (o.blk_tqkv[0] + kb + o.blk_stride), -1, S::NT3, wave, k + 1 < S::KB);      // the next block's
                     tok_gemm_w<S, NTPW, S::KS_2, LDX>(acc, Hl + li * LDX + lg, Wf2, FetchSide<decltype(Wtq)>{&Wtq});
@@ -2713,6 +2815,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) td[(16 * i + r) * LDG + 64 * j] = acc[i][j][r];
                             }
+                } else if constexpr (FBAL) {
+                    fc_epi_bal(accb, accx, false);
                 } else {
 #pragma unroll
                 for (int i = 0; i < S::MT2; ++i)
