@@ -1894,7 +1894,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
         // to the waves - 2:1:1:1 / 2:2:1:1.  Now a wave owns column tile `wave` (all row tiles: slot 0 of xr / pe_r) and the extra tiles' (row tile,
         // column tile) items q = wave + 4 x, x < NXI (slot 1, index x): L 6 + 6 + 6 + 6 tile-rows instead of 8 + 8 + 4 + 4, M 4 + 4 + 4 + 3 instead of
         // 6 + 3 + 3 + 3.  (The GRU phase of these shapes has been running on such jobs since r2: GBAL.)
-        constexpr bool FBAL = FE_FBAL && !REGW && S::NT2 > 4 && S::NT2 <= 8 && !S::LN;
+        // (three items per wave in three different row tiles - 48 kHz L, six row tiles - measured -0.3 %: no A fragment is shared any more; left as it was)
+        constexpr bool FBAL = FE_FBAL && !REGW && S::NT2 > 4 && S::NT2 <= 8 && !S::LN &&
+                              ((kWaves % S::MT2) == 0 || ceil_div((S::NT2 - 4) * S::MT2, kWaves) <= 2);
         constexpr int NE = FBAL ? S::NT2 - 4 : 1, NXQ = NE * S::MT2, NXI = FBAL ? ceil_div(NXQ, kWaves) : 1;
         static_assert(!FBAL || (NXI <= S::MT2 && NTPW2 == 2), "FBAL: the extra items live in slot 1 of the residual registers");
         constexpr bool XSAME = (kWaves % S::MT2) == 0;      // every extra item of a wave lies in the same row tile: one A fragment serves them
@@ -1931,14 +1933,27 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                     mma_panel<1, NXI, KS, Lds<S>::PDK>(accx, [&](int, int ks) { return a_lane[4 * ks]; },
                                                        [&](int x, int ks) { return wget(1 + x, x_ct(x), ks); }, NoSide{});
                 } else {
+                    // the items lie in different row tiles: NXI independent (A row tile, B column tile) chains through one software pipeline
+                    constexpr int PD = KS < Lds<S>::PDK ? KS : Lds<S>::PDK;
+                    const float* a_lane[NXI];
 #pragma unroll
-                    for (int x = 0; x < NXI; ++x) {
-                        f32x4 a1[1][1];
-                        a1[0][0] = accx[0][x];
-                        const float* a_lane = abase + (16 * x_rt(x) + li) * LDX + lg;
-                        mma_panel<1, 1, KS, Lds<S>::PDK>(a1, [&](int, int ks) { return a_lane[4 * ks]; },
-                                                         [&](int, int ks) { return wget(1 + x, x_ct(x), ks); }, NoSide{});
-                        accx[0][x] = a1[0][0];
+                    for (int x = 0; x < NXI; ++x) a_lane[x] = abase + (16 * x_rt(x) + li) * LDX + lg;
+                    float av[PD][NXI], bv[PD][NXI];
+#pragma unroll
+                    for (int ks = 0; ks < PD; ++ks)
+#pragma unroll
+                        for (int x = 0; x < NXI; ++x) { av[ks][x] = a_lane[x][4 * ks]; bv[ks][x] = wget(1 + x, x_ct(x), ks); }
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        float a1[NXI], b1[NXI];
+#pragma unroll
+                        for (int x = 0; x < NXI; ++x) { a1[x] = av[ks % PD][x]; b1[x] = bv[ks % PD][x]; }
+                        if (ks + PD < KS) {
+#pragma unroll
+                            for (int x = 0; x < NXI; ++x) { av[ks % PD][x] = a_lane[x][4 * (ks + PD)]; bv[ks % PD][x] = wget(1 + x, x_ct(x), ks + PD); }
+                        }
+#pragma unroll
+                        for (int x = 0; x < NXI; ++x) accx[0][x] = FE_MFMA(a1[x], b1[x], accx[0][x]);
                     }
                 }
             }
