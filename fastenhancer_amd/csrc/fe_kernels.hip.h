@@ -143,6 +143,9 @@ struct Shape {
 #ifndef FE_FBAL
 #define FE_FBAL 1           // r5: rnn_fc / attn_fc of the shapes with more than four column tiles over balanced (column tile, row tile) jobs (fe_frame_kernel; 0: whole column tiles, for A/B runs)
 #endif
+#ifndef FE_QBAL
+#define FE_QBAL 1           // r5: qkv's last two column tiles (NT3 % 4 == 2: L) split by row halves over the wave pairs (0: whole column tiles, for A/B runs)
+#endif
 #ifndef FE_K4_STREAM
 #define FE_K4_STREAM 1      // r4x: shapes that stream their block weights from L2 inside the GEMMs (M, L, their 48 kHz / variant shapes) fetch four k-steps per 16-byte load too
 #endif
@@ -2662,6 +2665,44 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
                 // fetched inside the GEMM: attn_fc weights and the next block's GRU input weights
                 if constexpr (!GFLAT) Wf2.bind(wb, (o.blk_fc2_w[0] + kb), (o.blk_fc2_b[0] + kb), S::NT2, wave);
                 Wgi.bind(wb, (o.blk_wih[0] + kb + o.blk_stride), (o.blk_bih[0] + kb + o.blk_stride), GNT, wave, k + 1 < S::KB && !S::TATT);
+                // r5, QBAL: eighteen column tiles (L) are 5 : 5 : 4 : 4 over the waves; the last two tiles' row tiles go half and half to the wave pairs
+                // (0, 2) / (1, 3) instead: 4.5 tiles each.  (Gi is LDS only: no register-resident ownership to move.)
+                constexpr bool QBAL = FE_QBAL && !REGW && !L::PERHEAD && (S::NT3 % 4) == 2 && (S::MT2 % 2) == 0 && NTPW3 >= 2;
+                if constexpr (QBAL) {
+                    constexpr int NQ = NTPW - 1, MH = S::MT2 / 2, KS = S::KS_2;
+                    f32x4 acc[S::MT2][NQ];
+                    tok_gemm_w<S, NQ, KS, LDX>(acc, Xb + li * LDX + lg, Wq, NoSide{});
+                    {
+                        float* gdst = Gi + (4 * lg) * LDG + 16 * wave + li;
+#pragma unroll
+                        for (int j = 0; j < NQ; ++j)
+#pragma unroll
+                            for (int i = 0; i < S::MT2; ++i)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) gdst[(16 * i + r) * LDG + 64 * j] = acc[i][j][r];
+                    }
+                    const int xt = S::NT3 - 2 + (wave & 1), xr0 = MH * (wave >> 1);
+                    const int wk4 = Wq.w_off + wb.k4d;
+                    f32x4 cache;
+                    f32x4 accx[MH][1];
+                    {
+                        const float bj = Wq.b_off >= 0 ? wb.at_gv(Wq.b_off + xt * 16, wb.li4) : 0.0f;
+#pragma unroll
+                        for (int i = 0; i < MH; ++i) accx[i][0] = f32x4{bj, bj, bj, bj};
+                    }
+                    const float* a_lane = Xb + (16 * xr0 + li) * LDX + lg;
+                    mma_panel<MH, 1, KS, Lds<S>::PDK>(accx, [&](int i, int ks) { return a_lane[(16 * i) * LDX + 4 * ks]; },
+                                                       [&](int, int ks) -> float {
+                                                           if (ks >= 4 * (KS / 4)) return wb.at_gv(wk4 + (xt * KS + ks) * 64, wb.lane4);
+                                                           if ((ks & 3) == 0) cache = wb.at_gv4(wk4 + xt * (KS * 64) + (ks >> 2) * 256, wb.lane4 * 4);
+                                                           return cache[ks & 3];
+                                                       }, NoSide{});
+                    float* gx = Gi + (16 * xr0 + 4 * lg) * LDG + 16 * xt + li;
+#pragma unroll
+                    for (int i = 0; i < MH; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) gx[(16 * i + r) * LDG] = accx[i][0][r];
+                } else
                 if constexpr (!L::PERHEAD) {
                 f32x4 acc[S::MT2][NTPW];
                 __builtin_amdgcn_sched_barrier(0);
