@@ -689,6 +689,35 @@ def test_edge_inputs():
     _assert_close(out.cpu().numpy(), np.concatenate(refs, 1), "full-scale input", tight=REL_TOL)
 
 
+@pytest.mark.parametrize("kern", ["wg8", "waves4"])
+def test_bsrnn_edge_inputs(kern):
+    """Silence (BSRNN's mask has a residual branch: the output is small, not zero) and a burst forty times full scale that drives the LSTM gates into
+    saturation (exp2 overflows to inf, rcp(inf) = 0: no NaN) - both PART 1 kernels of the per-hop step against the oracle, finite everywhere."""
+    m, orc, cfg, sr, seed = _bsrnn("bsrnn_xt")
+    eng = m.engine
+    eng.set_step_kernel(kern)
+    B, hops, H = 3, 6, cfg.hop_size
+    x = make_input(B, hops * H, seed + 5, sr)
+    x[0] = 0.0
+    x[1, 2 * H:3 * H] *= 40.0
+    xd = torch.from_numpy(x).to(_dev())
+    st = eng.new_state(B)
+    outs = [eng.step(xd[:, t * H:(t + 1) * H].contiguous(), st, T=1).cpu().numpy() for t in range(hops)]
+    eng.set_step_kernel("wg8")
+    caches = orc.initialize_cache(B)
+    refs = []
+    for t in range(hops):
+        o, *caches = orc.step(x[:, t * H:(t + 1) * H], *caches)
+        refs.append(o)
+    got, ref = np.concatenate(outs, 1), np.concatenate(refs, 1)
+    assert np.isfinite(got).all()
+    _assert_close(got[1:], ref[1:], f"bsrnn_xt edge inputs ({kern})")
+    assert float(np.abs(got[0] - ref[0]).max()) < 1e-6                      # (the silent stream: an absolute bound, its scale is ~0)
+    for a_, b_ in zip(eng.split_state(st, B), caches):
+        assert np.isfinite(a_.cpu().numpy()).all()
+        _assert_close(a_.cpu().numpy()[B - 1 if a_.shape[0] == B else slice((B - 1) * 31, B * 31)], np.asarray(b_)[B - 1 if a_.shape[0] == B else slice((B - 1) * 31, B * 31)], f"cache ({kern})")
+
+
 def test_error_behaviour():
     from fastenhancer_amd import _lib
     from fastenhancer_amd.config import FEConfig
