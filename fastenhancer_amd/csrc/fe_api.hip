@@ -668,917 +668,10 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
 }
 
 
-// ============================================================================ BSRNN (models/bsrnn/model.py)
-const int kSub[31] = {2, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 16, 16, 16, 16, 16, 16, 16, 17};
-
-void build_sections_bsrnn(fe_handle* h) {
-    const int C = h->cfg.channels, L = h->cfg.rf_blocks, HH = 2 * C;
-    char nm[160];
-    for (int b = 0; b < 31; ++b) {
-        snprintf(nm, sizeof nm, "band_split.fc.%d.weight", b); add_section(h, nm, {C, 2 * kSub[b], 1});
-        snprintf(nm, sizeof nm, "band_split.fc.%d.bias", b); add_section(h, nm, {C});
-    }
-    for (int l = 0; l < L; ++l) {
-        snprintf(nm, sizeof nm, "rnn_time.%d.weight_ih", l); add_section(h, nm, {4 * HH, C});
-        snprintf(nm, sizeof nm, "rnn_time.%d.weight_hh", l); add_section(h, nm, {4 * HH, HH});
-        snprintf(nm, sizeof nm, "rnn_time.%d.bias_ih", l); add_section(h, nm, {4 * HH});
-        snprintf(nm, sizeof nm, "rnn_time.%d.bias_hh", l); add_section(h, nm, {4 * HH});
-        snprintf(nm, sizeof nm, "fc_time.%d.weight", l); add_section(h, nm, {C, HH});
-        snprintf(nm, sizeof nm, "fc_time.%d.bias", l); add_section(h, nm, {C});
-        for (const char* sfx : {"", "_reverse"}) {
-            snprintf(nm, sizeof nm, "rnn_freq.%d.weight_ih_l0%s", l, sfx); add_section(h, nm, {4 * HH, C});
-            snprintf(nm, sizeof nm, "rnn_freq.%d.weight_hh_l0%s", l, sfx); add_section(h, nm, {4 * HH, HH});
-            snprintf(nm, sizeof nm, "rnn_freq.%d.bias_ih_l0%s", l, sfx); add_section(h, nm, {4 * HH});
-            snprintf(nm, sizeof nm, "rnn_freq.%d.bias_hh_l0%s", l, sfx); add_section(h, nm, {4 * HH});
-        }
-        snprintf(nm, sizeof nm, "fc_freq.%d.weight", l); add_section(h, nm, {C, 2 * HH});
-        snprintf(nm, sizeof nm, "fc_freq.%d.bias", l); add_section(h, nm, {C});
-    }
-    for (const char* kind : {"mlp_mask", "mlp_residual"})
-        for (int b = 0; b < 31; ++b) {
-            snprintf(nm, sizeof nm, "mask_decoder.%s.%d.0.weight", kind, b); add_section(h, nm, {4 * C, C, 1});
-            snprintf(nm, sizeof nm, "mask_decoder.%s.%d.0.bias", kind, b); add_section(h, nm, {4 * C});
-            snprintf(nm, sizeof nm, "mask_decoder.%s.%d.2.weight", kind, b); add_section(h, nm, {4 * kSub[b], 4 * C, 1});
-            snprintf(nm, sizeof nm, "mask_decoder.%s.%d.2.bias", kind, b); add_section(h, nm, {4 * kSub[b]});
-        }
-}
-
-int create_bsrnn(const fe_config* cfg, fe_handle** out) {
-    if (cfg->n_fft != 512) return fail(FE_ERR_INVALID_ARG, "Only n_fft=512 is supported, but given %d", cfg->n_fft);
-    if (cfg->win_size > cfg->n_fft) return fail(FE_ERR_INVALID_ARG, "n_fft(%d) must be bigger than win_size(%d)", cfg->n_fft, cfg->win_size);
-    if (cfg->hop_size <= 0 || cfg->hop_size > cfg->n_fft) return fail(FE_ERR_INVALID_ARG, "hop_size %d out of range", cfg->hop_size);
-    const fe::BImpl* bi = nullptr;
-    for (const fe::BImpl* im : bimpls())
-        if (im->C == cfg->channels && im->NLAY == cfg->rf_blocks && im->HOP == cfg->hop_size) bi = im;
-    if (!bi)
-        return fail(FE_ERR_UNSUPPORTED_CONFIG, "no BSRNN kernel compiled for num_channels=%d num_layers=%d hop=%d", cfg->channels,
-                    cfg->rf_blocks, cfg->hop_size);
-    fe_handle* h = new fe_handle();
-    h->cfg = *cfg;
-    h->bimpl = bi;
-    h->d = Dims{cfg->channels, 0, 0, 0, cfg->rf_blocks, cfg->n_fft, cfg->hop_size, cfg->n_fft / 2, 0, 0, {0}};
-    if (hipGetDevice(&h->device) != hipSuccess) h->device = -1;
-    else {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->max_wgs = cus;
-    }
-    build_sections_bsrnn(h);
-    build_tables(h);
-    *out = h;
-    return FE_OK;
-}
-
-int pack_weights_bsrnn(fe_handle* h, const std::vector<float>& blob, std::vector<float>* out) {
-    const int C = h->cfg.channels, L = h->cfg.rf_blocks, HH = 2 * C, G4 = 4 * HH, R = 4 * 257;
-    const bool whh_regs = h->bimpl->whh_regs;
-    fe::BOffsets& o = h->boff;
-    std::vector<float> buf;
-    auto alloc = [&](size_t n) { size_t off = (buf.size() + 63) & ~(size_t)63; buf.resize(off + n, 0.0f); return (int)off; };
-    auto S = [&](const std::string& n) { return sec(h, blob, n); };
-    auto pack_b = [&](int K, int Ncols, const std::function<float(int, int)>& Bkn) {
-        const int KS = K / 4, NT = (Ncols + 15) / 16;
-        int off = alloc((size_t)NT * KS * 64);
-        for (int nt = 0; nt < NT; ++nt)
-            for (int ks = 0; ks < KS; ++ks)
-                for (int lane = 0; lane < 64; ++lane) {
-                    int k = 4 * ks + lane / 16, n = 16 * nt + lane % 16;
-                    buf[off + ((size_t)nt * KS + ks) * 64 + lane] = n < Ncols ? Bkn(k, n) : 0.0f;
-                }
-        return off;
-    };
-    // LSTM gate rows (order i, f, g, o) are packed pre-scaled: with pre' = s_g * pre the kernel evaluates every gate as
-    // rcp(1 + exp2(pre')): sigma(v) for s = -log2(e), and tanh(v) = 2 rcp(1 + exp2(-2 log2(e) v)) - 1 for the cell gate g
-    const double kL2E = 1.4426950408889634;
-    auto gscale = [&](int row) { return (float)((row / HH) == 2 ? -2.0 * kL2E : -kL2E); };
-    char nm[160];
-    {   // band split: [k/4][band*C + c] float4 - thread (band, c) reads its zero-padded row as 16-byte loads coalesced over the threads
-        o.bs_w = alloc((size_t)31 * C * fe::kBsKP);
-        o.bs_b = alloc(31 * C);
-        for (int b = 0; b < 31; ++b) {
-            snprintf(nm, sizeof nm, "band_split.fc.%d.weight", b);
-            const float* w = S(nm);                                   // (C, 2sub)
-            const int k2 = 2 * kSub[b];
-            for (int c = 0; c < C; ++c)
-                for (int k = 0; k < k2; ++k) buf[o.bs_w + (((size_t)(k / 4) * 31 * C) + b * C + c) * 4 + (k & 3)] = w[c * k2 + k];
-            snprintf(nm, sizeof nm, "band_split.fc.%d.bias", b);
-            memcpy(&buf[o.bs_b + b * C], S(nm), C * sizeof(float));
-        }
-    }
-    for (int l = 0; l < L; ++l) {
-        auto key = [&](const char* fmt) { snprintf(nm, sizeof nm, fmt, l); return std::string(nm); };
-        {   // time LSTM: K = [x (C) | h (HH)], N = 4HH gate rows (i,f,g,o)
-            const float* wih = S(key("rnn_time.%d.weight_ih"));
-            const float* whh = S(key("rnn_time.%d.weight_hh"));
-            o.t_w[l] = pack_b(C + HH, G4, [&](int k, int n) { return gscale(n) * (k < C ? wih[n * C + k] : whh[n * HH + (k - C)]); });
-            const float* bi = S(key("rnn_time.%d.bias_ih"));
-            const float* bh = S(key("rnn_time.%d.bias_hh"));
-            o.t_b[l] = alloc(G4);
-            for (int i = 0; i < G4; ++i) buf[o.t_b[l] + i] = gscale(i) * (bi[i] + bh[i]);
-        }
-        {
-            const float* w = S(key("fc_time.%d.weight"));         // (C, HH)
-            o.tfc_w[l] = pack_b(HH, C, [&](int k, int n) { return w[n * HH + k]; });
-            o.tfc_b[l] = alloc(C);
-            memcpy(&buf[o.tfc_b[l]], S(key("fc_time.%d.bias")), C * sizeof(float));
-        }
-        for (int d = 0; d < 2; ++d) {
-            const char* sfx = d ? "_reverse" : "";
-            auto keyd = [&](const char* stem) { snprintf(nm, sizeof nm, "rnn_freq.%d.%s_l0%s", l, stem, sfx); return std::string(nm); };
-            const float* wih = S(keyd("weight_ih"));
-            o.f_wih[l][d] = pack_b(C, G4, [&](int k, int n) { return gscale(n) * wih[n * C + k]; });
-            const float* bi = S(keyd("bias_ih"));
-            const float* bh = S(keyd("bias_hh"));
-            o.f_b[l][d] = alloc(G4);
-            for (int i = 0; i < G4; ++i) buf[o.f_b[l][d] + i] = gscale(i) * (bi[i] + bh[i]);
-            {   // recurrence weights in thread order.  Thread t (0..NTD-1; NTD = 128, or 256 for C = 64) of a direction = 4 u + q, hidden unit u (+ NTD/4 rr).
-                // KSPLIT shapes: q = K-quarter; the thread holds, for all four gates g, W_hh[g*HH + u + 32 rr][q*HH/4 + kk] at
-                //   [rr][g*HH/4 + kk][t].  Otherwise q = gate: it holds row W_hh[q*HH + u + 32 rr][k] at [rr][k][t].
-                // (streamed shapes: the k index in float4 groups)
-                const float* whh = S(keyd("weight_hh"));      // (4HH, HH), gate-major rows
-                o.f_whh[l][d] = alloc((size_t)G4 * HH);
-                const int NTD = h->bimpl->rec_threads, UPP = NTD / 4;      // threads of a direction (256 for C = 64: SEQD), units per pass
-                const int RPT = HH / UPP, Q = HH / 4;
-                const bool ksplit = h->bimpl->ksplit;
-                for (int rr = 0; rr < RPT; ++rr)
-                    for (int kp = 0; kp < HH; ++kp)
-                        for (int t = 0; t < NTD; ++t) {
-                            const int u = (t >> 2) + UPP * rr, q = t & 3;
-                            const int row = ksplit ? (kp / Q) * HH + u : q * HH + u;
-                            const int k = ksplit ? q * Q + (kp % Q) : kp;
-                            const float v = gscale(row) * whh[(size_t)row * HH + k];
-                            if (whh_regs) buf[o.f_whh[l][d] + ((size_t)rr * HH + kp) * NTD + t] = v;
-                            else buf[o.f_whh[l][d] + ((((size_t)rr * (HH / 4)) + kp / 4) * NTD + t) * 4 + (kp & 3)] = v;
-                        }
-            }
-        }
-        {
-            const float* w = S(key("fc_freq.%d.weight"));         // (C, 2HH)
-            o.ffc_w[l] = pack_b(2 * HH, C, [&](int k, int n) { return w[n * 2 * HH + k]; });
-            o.ffc_b[l] = alloc(C);
-            memcpy(&buf[o.ffc_b[l]], S(key("fc_freq.%d.bias")), C * sizeof(float));
-        }
-    }
-    if (h->bimpl->launch_sb) {
-        // stream-batched layers (bsrnn_sb_kernels.hip.h): the weights as A fragments of the TRANSPOSED products.  Feature permutations:
-        // k-step ks, lane group lg carries channel KSC lg + ks / hidden unit KSH lg + ks; row 4 lg' + r of gate tile t = (unit KSH lg' + t,
-        // gate r); row 4 lg' + r of fc output tile `to` = channel KSC lg' + 4 to + r.
-        fe::SbOffsets& so = h->sboff;
-        const int KSC = C / 4, KSH = HH / 4, KS1 = KSC + KSH, NTO = C / 16;
-        auto pack_lstm = [&](const float* wih, const float* whh, const float* bi, const float* bh, int* w_off, int* b_off) {
-            *w_off = alloc((size_t)KSH * KS1 * 64);
-            *b_off = alloc((size_t)KSH * 16);
-            for (int t = 0; t < KSH; ++t) {
-                for (int ks = 0; ks < KS1; ++ks)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int rho = lane % 16, lgk = lane / 16, row = (rho % 4) * HH + KSH * (rho / 4) + t;
-                        const float v = ks < KSC ? wih[(size_t)row * C + KSC * lgk + ks] : whh[(size_t)row * HH + KSH * lgk + (ks - KSC)];
-                        buf[*w_off + ((size_t)t * KS1 + ks) * 64 + lane] = gscale(row) * v;
-                    }
-                for (int lg = 0; lg < 4; ++lg)
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = r * HH + KSH * lg + t;
-                        buf[*b_off + t * 16 + lg * 4 + r] = gscale(row) * (bi[row] + bh[row]);
-                    }
-            }
-        };
-        auto pack_fc = [&](const float* w, int ld, int col0, int* w_off) {       // rows = channels, columns col0 .. col0 + HH - 1 of a (C, ld) matrix
-            *w_off = alloc((size_t)NTO * KSH * 64);
-            for (int to = 0; to < NTO; ++to)
-                for (int ks = 0; ks < KSH; ++ks)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int rho = lane % 16, lgk = lane / 16, ch = KSC * (rho / 4) + 4 * to + rho % 4;
-                        buf[*w_off + ((size_t)to * KSH + ks) * 64 + lane] = w[(size_t)ch * ld + col0 + KSH * lgk + ks];
-                    }
-        };
-        auto pack_fc_bias = [&](const float* b, int* b_off) {
-            *b_off = alloc((size_t)NTO * 16);
-            for (int to = 0; to < NTO; ++to)
-                for (int lg = 0; lg < 4; ++lg)
-                    for (int r = 0; r < 4; ++r) buf[*b_off + to * 16 + lg * 4 + r] = b[KSC * lg + 4 * to + r];
-        };
-        for (int l = 0; l < L; ++l) {
-            auto key = [&](const char* fmt) { snprintf(nm, sizeof nm, fmt, l); return std::string(nm); };
-            pack_lstm(S(key("rnn_time.%d.weight_ih")), S(key("rnn_time.%d.weight_hh")), S(key("rnn_time.%d.bias_ih")), S(key("rnn_time.%d.bias_hh")), &so.t_w[l], &so.t_b[l]);
-            pack_fc(S(key("fc_time.%d.weight")), HH, 0, &so.tfc_w[l]);
-            pack_fc_bias(S(key("fc_time.%d.bias")), &so.tfc_b[l]);
-            for (int d = 0; d < 2; ++d) {
-                const char* sfx = d ? "_reverse" : "";
-                auto keyd = [&](const char* stem) { snprintf(nm, sizeof nm, "rnn_freq.%d.%s_l0%s", l, stem, sfx); return std::string(nm); };
-                pack_lstm(S(keyd("weight_ih")), S(keyd("weight_hh")), S(keyd("bias_ih")), S(keyd("bias_hh")), &so.f_w[l][d], &so.f_b[l][d]);
-                pack_fc(S(key("fc_freq.%d.weight")), 2 * HH, d * HH, &so.ffc_w[l][d]);
-            }
-            pack_fc_bias(S(key("fc_freq.%d.bias")), &so.ffc_b[l]);
-        }
-    }
-    const char* kinds[2] = {"mlp_mask", "mlp_residual"};
-    for (int kind = 0; kind < 2; ++kind) {
-        o.m_w1[kind] = alloc((size_t)31 * 4 * C * C);      // [band][k/4][o] float4
-        o.m_b1[kind] = alloc((size_t)31 * 4 * C);
-        o.m_w2[kind] = alloc((size_t)R * 4 * C);           // [k/4][global row] float4
-        o.m_b2[kind] = alloc(R);
-        int row0 = 0;
-        for (int b = 0; b < 31; ++b) {
-            snprintf(nm, sizeof nm, "mask_decoder.%s.%d.0.weight", kinds[kind], b);
-            {
-                const float* w1 = S(nm);                                  // (4C, C) -> [k/4][o] float4 per band
-                for (int oo = 0; oo < 4 * C; ++oo)
-                    for (int k = 0; k < C; ++k)
-                        buf[o.m_w1[kind] + (((size_t)b * (C / 4) + k / 4) * (4 * C) + oo) * 4 + (k & 3)] = w1[oo * C + k];
-            }
-            snprintf(nm, sizeof nm, "mask_decoder.%s.%d.0.bias", kinds[kind], b);
-            memcpy(&buf[o.m_b1[kind] + b * 4 * C], S(nm), 4 * C * sizeof(float));
-            snprintf(nm, sizeof nm, "mask_decoder.%s.%d.2.weight", kinds[kind], b);
-            const int rows = 4 * kSub[b];
-            {
-                const float* w2 = S(nm);                                  // (4sub, 4C) -> [k/4][global row] float4
-                for (int r = 0; r < rows; ++r)
-                    for (int k = 0; k < 4 * C; ++k)
-                        buf[o.m_w2[kind] + ((size_t)(k / 4) * R + row0 + r) * 4 + (k & 3)] = w2[r * 4 * C + k];
-            }
-            snprintf(nm, sizeof nm, "mask_decoder.%s.%d.2.bias", kinds[kind], b);
-            memcpy(&buf[o.m_b2[kind] + row0], S(nm), rows * sizeof(float));
-            row0 += rows;
-        }
-    }
-    {   // index tables (ints stored in the float buffer): band of a layer-2 row; a bin's first value row and 2*sub of its band
-        o.row_band = alloc(R);
-        o.bin_row = alloc(257);
-        o.bin_2sub = alloc(257);
-        int row0 = 0, f0 = 0;
-        for (int b = 0; b < 31; ++b) {
-            for (int r = 0; r < 4 * kSub[b]; ++r) { const int v = b; memcpy(&buf[o.row_band + row0 + r], &v, 4); }
-            for (int f = 0; f < kSub[b]; ++f) {
-                const int ra = 4 * f0 + 2 * f, s2 = 2 * kSub[b];
-                memcpy(&buf[o.bin_row + f0 + f], &ra, 4);
-                memcpy(&buf[o.bin_2sub + f0 + f], &s2, 4);
-            }
-            row0 += 4 * kSub[b];
-            f0 += kSub[b];
-        }
-    }
-    o.window = alloc(h->window.size()); memcpy(&buf[o.window], h->window.data(), h->window.size() * sizeof(float));
-    o.window_istft = alloc(h->window_istft.size()); memcpy(&buf[o.window_istft], h->window_istft.data(), h->window_istft.size() * sizeof(float));
-    o.twiddle = alloc(h->twiddle.size()); memcpy(&buf[o.twiddle], h->twiddle.data(), h->twiddle.size() * sizeof(float));
-    if (C == 16) {
-        // r5: the role-split PART 1's copies, regrouped from the sections packed above for 16-byte fetches (see BOffsets)
-        const int KSC = C / 4, KSH = HH / 4, KS1 = KSC + KSH, NCT = HH / 16;
-        for (int l = 0; l < L; ++l) {
-            o.ov_t[l] = alloc((size_t)NCT * 4 * (KS1 / 4) * 256);
-            for (int ct = 0; ct < NCT; ++ct)
-                for (int g = 0; g < 4; ++g)
-                    for (int q = 0; q < KS1 / 4; ++q)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int j = 0; j < 4; ++j)
-                                buf[o.ov_t[l] + (((size_t)(ct * 4 + g) * (KS1 / 4) + q) * 64 + lane) * 4 + j] = buf[o.t_w[l] + ((size_t)(g * NCT + ct) * KS1 + 4 * q + j) * 64 + lane];
-            o.ov_tb[l] = alloc((size_t)NCT * 16 * 4);
-            for (int ct = 0; ct < NCT; ++ct)
-                for (int li = 0; li < 16; ++li)
-                    for (int g = 0; g < 4; ++g) buf[o.ov_tb[l] + (ct * 16 + li) * 4 + g] = buf[o.t_b[l] + g * HH + ct * 16 + li];
-            auto regroup = [&](int src, int ks_total) {          // one column tile's [ks][lane] -> [ks / 4][lane][4]
-                const int off = alloc((size_t)ks_total * 64);
-                for (int q = 0; q < ks_total / 4; ++q)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 4; ++j) buf[off + ((size_t)q * 64 + lane) * 4 + j] = buf[src + (size_t)(4 * q + j) * 64 + lane];
-                return off;
-            };
-            o.ov_tx[l] = alloc((size_t)NCT * 4 * 16 * C);
-            for (int ct = 0; ct < NCT; ++ct)
-                for (int g = 0; g < 4; ++g)
-                    for (int r = 0; r < 16; ++r)
-                        for (int ch = 0; ch < C; ++ch)
-                            buf[o.ov_tx[l] + (((size_t)(ct * 4 + g) * 16 + r) * C) + ch] = buf[o.t_w[l] + ((size_t)(g * NCT + ct) * KS1 + ch / 4) * 64 + (ch % 4) * 16 + r];
-            o.ov_f1t[l] = alloc((size_t)C * HH);
-            for (int ch = 0; ch < C; ++ch)
-                for (int un = 0; un < HH; ++un) buf[o.ov_f1t[l] + (size_t)ch * HH + un] = buf[o.tfc_w[l] + (size_t)(un / 4) * 64 + (un % 4) * 16 + ch];
-            o.ov_f1[l] = regroup(o.tfc_w[l], KSH);
-            o.ov_f2[l] = regroup(o.ffc_w[l], 2 * KSH);
-            for (int d = 0; d < 2; ++d) {
-                o.ov_ip[l][d] = alloc((size_t)8 * 256);
-                for (int j = 0; j < 8; ++j)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int ks = 0; ks < KSC; ++ks) buf[o.ov_ip[l][d] + ((size_t)j * 64 + lane) * 4 + ks] = buf[o.f_wih[l][d] + ((size_t)j * KSC + ks) * 64 + lane];
-                o.ov_ipb[l][d] = alloc(16 * 8);
-                for (int li = 0; li < 16; ++li)
-                    for (int j = 0; j < 8; ++j) buf[o.ov_ipb[l][d] + li * 8 + j] = buf[o.f_b[l][d] + j * 16 + li];
-                // row-major for the transposed chains: W[n][ch] = fragment (tile n / 16, k-step ch / 4) lane (ch % 4) * 16 + n % 16
-                o.ov_ipt[l][d] = alloc((size_t)G4 * C);
-                for (int n = 0; n < G4; ++n)
-                    for (int ch = 0; ch < C; ++ch)
-                        buf[o.ov_ipt[l][d] + (size_t)n * C + ch] = buf[o.f_wih[l][d] + ((size_t)(n / 16) * KSC + ch / 4) * 64 + (ch % 4) * 16 + n % 16];
-                // W_hh: lane = half * 32 + unit holds gate rows (half, 2 + half) of its unit; source [k][4 u + gate] (register shapes, NTD = 128)
-                o.ov_hh[l][d] = alloc((size_t)2 * (HH / 4) * 256);
-                for (int rs = 0; rs < 2; ++rs)
-                    for (int q = 0; q < HH / 4; ++q)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int j = 0; j < 4; ++j) {
-                                const int half = lane >> 5, u = lane & 31, gate = 2 * rs + half, k = 4 * q + j;
-                                buf[o.ov_hh[l][d] + (((size_t)rs * (HH / 4) + q) * 64 + lane) * 4 + j] = buf[o.f_whh[l][d] + (size_t)k * 128 + 4 * u + gate];
-                            }
-            }
-        }
-    }
-    {   // the matrix-core DFT's constant operands (r5: the role-split PART 1 runs the STFT on them), N = 512: N1 = 16, KC = 8, MT = 1
-        const int N1 = h->cfg.n_fft / 32, KC = N1 / 2, MT = N1 / 16;
-        o.dft1 = alloc(2 * 2 * 8 * 64); o.dft2 = alloc((size_t)2 * KC * 64); o.dft3 = alloc((size_t)2 * MT * KC * 64); o.dft4 = alloc(2 * 2 * 8 * 64);
-        Packer p;
-        p.buf.swap(buf);
-        pack_dft_constants(p, h->cfg.n_fft, o.dft1, o.dft2, o.dft3, o.dft4);
-        p.buf.swap(buf);
-    }
-    o.total = (int)((buf.size() + 63) & ~(size_t)63);
-    h->packed_floats = o.total;
-    buf.resize(o.total, 0.0f);
-    *out = std::move(buf);
-    return FE_OK;
-}
-
-// ============================================================================ FSPEN (models/fspen/model.py)
-// fused state_dict of ONNXModel after remove_weight_reparameterizations (:299-340), reference layouts
-const int kSeK[5] = {4, 7, 11, 20, 40};                   // SubbandEncoder kernels (:41-44)
-const int kSdN[5] = {2, 3, 5, 10, 20};                    // SubbandDecoder outputs per row (:70)
-
-void build_sections_fspen(fe_handle* h) {
-    char nm[160];
-    for (int i = 0; i < 5; ++i) {
-        snprintf(nm, sizeof nm, "subband_encoder.conv%d.0.weight", i + 1); add_section(h, nm, {32, 1, kSeK[i]});
-        snprintf(nm, sizeof nm, "subband_encoder.conv%d.0.bias", i + 1); add_section(h, nm, {32});
-    }
-    for (int i = 0; i < 5; ++i) {
-        snprintf(nm, sizeof nm, "subband_decoder.lin%d.0.weight", i + 1); add_section(h, nm, {kSdN[i], 64});
-        snprintf(nm, sizeof nm, "subband_decoder.lin%d.0.bias", i + 1); add_section(h, nm, {kSdN[i]});
-    }
-    const int C1[3] = {4, 16, 32}, K[3] = {6, 8, 6};
-    for (int i = 0; i < 3; ++i) {
-        snprintf(nm, sizeof nm, "fullband_encoder.%d.0.weight", i); add_section(h, nm, {C1[i], i == 0 ? 2 : C1[i - 1], K[i]});
-        snprintf(nm, sizeof nm, "fullband_encoder.%d.0.bias", i); add_section(h, nm, {C1[i]});
-    }
-    add_section(h, "fullband_encoder_post.weight", {32, 32, 1});
-    add_section(h, "feature_merge.0.weight", {32, 64});
-    add_section(h, "feature_merge.2.weight", {16, 32, 1});
-    add_section(h, "feature_merge.2.bias", {16});
-    for (int b = 0; b < 3; ++b) {
-        auto gru = [&](const std::string& p, const char* sfx) {
-            add_section(h, p + ".weight_ih_l0" + sfx, {48, 16});
-            add_section(h, p + ".weight_hh_l0" + sfx, {48, 16});
-            add_section(h, p + ".bias_ih_l0" + sfx, {48});
-            add_section(h, p + ".bias_hh_l0" + sfx, {48});
-        };
-        snprintf(nm, sizeof nm, "dpe_blocks.%d.", b);
-        const std::string p = nm;
-        gru(p + "intra_rnn", "");
-        gru(p + "intra_rnn", "_reverse");
-        add_section(h, p + "intra_fc.weight", {16, 32});
-        add_section(h, p + "intra_fc.bias", {16});
-        add_section(h, p + "intra_ln.weight", {32, 16});
-        add_section(h, p + "intra_ln.bias", {32, 16});
-        for (int g = 0; g < 8; ++g) gru(p + "inter_rnn.inter_rnn." + std::to_string(g), "");
-        for (int g = 0; g < 8; ++g) {
-            add_section(h, p + "inter_rnn.inter_fc." + std::to_string(g) + ".weight", {16, 16});
-            add_section(h, p + "inter_rnn.inter_fc." + std::to_string(g) + ".bias", {16});
-        }
-    }
-    add_section(h, "feature_split.0.weight", {32, 16, 1});
-    add_section(h, "feature_split.0.bias", {32});
-    add_section(h, "feature_split.1.weight", {64, 32});
-    for (int j = 0; j < 3; ++j) {
-        const int i = 2 - j, cin = C1[i], cout = i == 0 ? 2 : C1[i - 1];
-        snprintf(nm, sizeof nm, "fullband_decoder.%d.0.weight", j); add_section(h, nm, {cin, 2 * cin, 1});
-        snprintf(nm, sizeof nm, "fullband_decoder.%d.1.weight", j); add_section(h, nm, {cin, cout, K[i]});
-        snprintf(nm, sizeof nm, "fullband_decoder.%d.1.bias", j); add_section(h, nm, {cout});
-    }
-}
-
-int create_fspen(const fe_config* cfg, fe_handle** out) {
-    if (cfg->n_fft != 512) return fail(FE_ERR_INVALID_ARG, "Only n_fft == 512 is allowed, but given %d", cfg->n_fft);
-    if (cfg->win_size > cfg->n_fft) return fail(FE_ERR_INVALID_ARG, "n_fft(%d) must be bigger than win_size(%d)", cfg->n_fft, cfg->win_size);
-    // the one architecture of configs/others/fspen.yaml: channels [4, 16, 32], kernel_size [6, 8, 6], stride 2, DPE 3 x (16 ch, 32 bands, 8 groups)
-    const bool ok = cfg->channels == 32 && cfg->n_kernels == 3 && cfg->kernel_size[0] == 6 && cfg->kernel_size[1] == 8 && cfg->kernel_size[2] == 6 &&
-                    cfg->stride == 2 && cfg->rf_channels == 16 && cfg->rf_freq == 32 && cfg->rf_blocks == 3 && cfg->rf_heads == 8;
-    const fe::FImpl* fi = (ok && cfg->hop_size == 256) ? fe_fimpl_h256() : nullptr;
-    if (!fi)
-        return fail(FE_ERR_UNSUPPORTED_CONFIG, "no FSPEN kernel compiled for channels[-1]=%d kernels=%d dpe=(%d blocks, %d ch, %d bands, %d groups) hop=%d "
-                    "(configs/others/fspen.yaml is the compiled architecture)", cfg->channels, cfg->n_kernels, cfg->rf_blocks, cfg->rf_channels,
-                    cfg->rf_freq, cfg->rf_heads, cfg->hop_size);
-    fe_handle* h = new fe_handle();
-    h->cfg = *cfg;
-    h->fimpl = fi;
-    h->d = Dims{32, 0, 16, 32, 3, cfg->n_fft, cfg->hop_size, cfg->n_fft / 2, 0, 0, {0}};
-    if (hipGetDevice(&h->device) != hipSuccess) h->device = -1;
-    else {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->max_wgs = cus;
-    }
-    build_sections_fspen(h);
-    build_tables(h);
-    *out = h;
-    return FE_OK;
-}
-
-// k-major repack of the fused weights at the compile-time offsets of fe::FPk (fspen_kernels.hip.h)
-int pack_weights_fspen(fe_handle* h, const std::vector<float>& blob, std::vector<float>* out) {
-    using P = fe::FPk;
-    std::vector<float> buf(P::TOTAL, 0.0f);
-    auto S = [&](const std::string& n) { return sec(h, blob, n); };
-    char nm[160];
-    for (int i = 0; i < 512; ++i) { buf[P::WINDOW + i] = h->window[i]; buf[P::WINDOW_I + i] = h->window_istft[i]; buf[P::TW + i] = h->twiddle[i]; }
-    for (int i = 0, row = 0; i < 5; row += kSeK[i], ++i) {
-        snprintf(nm, sizeof nm, "subband_encoder.conv%d.0.weight", i + 1);
-        const float* w = S(nm);                                       // (32, 1, K)
-        snprintf(nm, sizeof nm, "subband_encoder.conv%d.0.bias", i + 1);
-        const float* b = S(nm);
-        for (int ch = 0; ch < 32; ++ch) {
-            for (int k = 0; k < kSeK[i]; ++k) buf[P::SE_W + (row + k) * 32 + ch] = w[ch * kSeK[i] + k];
-            buf[P::SE_B + i * 32 + ch] = b[ch];
-        }
-    }
-    // Conv1d (Cout, Cin, K) -> [(c*K + k)][Cout]
-    auto conv = [&](const char* key, int cout, int cin, int K, int dst_w, int dst_b) {
-        const float* w = S(std::string(key) + ".weight");
-        for (int o = 0; o < cout; ++o)
-            for (int c = 0; c < cin; ++c)
-                for (int k = 0; k < K; ++k) buf[dst_w + (c * K + k) * cout + o] = w[(o * cin + c) * K + k];
-        if (dst_b >= 0) { const float* b = S(std::string(key) + ".bias"); for (int o = 0; o < cout; ++o) buf[dst_b + o] = b[o]; }
-    };
-    conv("fullband_encoder.0.0", 4, 2, 6, P::FE0_W, P::FE0_B);
-    conv("fullband_encoder.1.0", 16, 4, 8, P::FE1_W, P::FE1_B);
-    conv("fullband_encoder.2.0", 32, 16, 6, P::FE2_W, P::FE2_B);
-    conv("fullband_encoder_post", 32, 32, 1, P::POST_W, -1);
-    {   // feature_merge.0 Linear (32 out j, 64 in i) -> [i][j]
-        const float* w = S("feature_merge.0.weight");
-        for (int j = 0; j < 32; ++j) for (int i = 0; i < 64; ++i) buf[P::MG1_W + i * 32 + j] = w[j * 64 + i];
-    }
-    conv("feature_merge.2", 16, 32, 1, P::MG2_W, P::MG2_B);
-    // GRU (gate order r, z, n): W_ih^T [k][48]; bias = b_ih + (b_hh for r, z); b_hh of n kept apart (it sits inside r * (...))
-    auto gru_ih = [&](const std::string& p, const char* sfx, int dst_w, int dst_gb, int dst_hn) {
-        const float* wi = S(p + ".weight_ih_l0" + sfx);
-        const float* bi = S(p + ".bias_ih_l0" + sfx);
-        const float* bh = S(p + ".bias_hh_l0" + sfx);
-        for (int g = 0; g < 48; ++g) {
-            for (int k = 0; k < 16; ++k) buf[dst_w + k * 48 + g] = wi[g * 16 + k];
-            buf[dst_gb + g] = bi[g] + (g < 32 ? bh[g] : 0.0f);
-        }
-        for (int c = 0; c < 16; ++c) buf[dst_hn + c] = bh[32 + c];
-    };
-    for (int b = 0; b < 3; ++b) {
-        const int D = P::DPE + b * P::D_SIZE;
-        snprintf(nm, sizeof nm, "dpe_blocks.%d.", b);
-        const std::string p = nm;
-        for (int d = 0; d < 2; ++d) {
-            const char* sfx = d ? "_reverse" : "";
-            gru_ih(p + "intra_rnn", sfx, D + P::D_IH + d * 768, D + P::D_GB + d * 48, D + P::D_HN + d * 16);
-            const float* wh = S(p + "intra_rnn.weight_hh_l0" + sfx);       // (48, 16) -> [gate][k][unit]
-            for (int gate = 0; gate < 3; ++gate)
-                for (int k = 0; k < 16; ++k)
-                    for (int c = 0; c < 16; ++c) buf[D + P::D_HH + ((d * 3 + gate) * 16 + k) * 16 + c] = wh[(gate * 16 + c) * 16 + k];
-        }
-        {
-            const float* w = S(p + "intra_fc.weight");                      // (16, 32) -> [k][c]
-            const float* bb = S(p + "intra_fc.bias");
-            for (int c = 0; c < 16; ++c) { for (int k = 0; k < 32; ++k) buf[D + P::D_FC_W + k * 16 + c] = w[c * 32 + k]; buf[D + P::D_FC_B + c] = bb[c]; }
-            const float* lw = S(p + "intra_ln.weight");
-            const float* lb = S(p + "intra_ln.bias");
-            for (int i = 0; i < 512; ++i) { buf[D + P::D_LN_W + i] = lw[i]; buf[D + P::D_LN_B + i] = lb[i]; }
-        }
-        for (int g = 0; g < 8; ++g) {
-            const int Gb = D + P::D_G + g * P::G_SIZE;
-            const std::string q = p + "inter_rnn.inter_rnn." + std::to_string(g);
-            gru_ih(q, "", Gb + P::G_IH, Gb + P::G_GB, Gb + P::G_HN);
-            const float* wh = S(q + ".weight_hh_l0");
-            for (int gg = 0; gg < 48; ++gg) for (int k = 0; k < 16; ++k) buf[Gb + P::G_HH + k * 48 + gg] = wh[gg * 16 + k];
-            const float* fw = S(p + "inter_rnn.inter_fc." + std::to_string(g) + ".weight");
-            const float* fb = S(p + "inter_rnn.inter_fc." + std::to_string(g) + ".bias");
-            for (int c = 0; c < 16; ++c) { for (int k = 0; k < 16; ++k) buf[Gb + P::G_FC_W + k * 16 + c] = fw[c * 16 + k]; buf[Gb + P::G_FC_B + c] = fb[c]; }
-        }
-    }
-    {   // stream-batched DPE (fspen_sb_kernels.hip.h): A-operand fragments - lane (li = row, lg) of k-step ks holds W[row][4 (ks % 4) + lg];
-        // the r / z rows and biases carry -log2 e, the n rows 2 log2 e (sigma / tanh as one exp2 + rcp of the pre-scaled value)
-        using Q = fe::FSbPk;
-        const float kRZ = -1.4426950408889634f, kN = 2.8853900817779268f;
-        for (int b = 0; b < 3; ++b) {
-            const int D = P::SB + b * Q::D_SIZE;
-            snprintf(nm, sizeof nm, "dpe_blocks.%d.", b);
-            const std::string p = nm;
-            for (int d = 0; d < 2; ++d) {
-                const char* sfx = d ? "_reverse" : "";
-                const float* wi = S(p + "intra_rnn.weight_ih_l0" + sfx);      // (48, 16), gate order r, z, n
-                const float* wh = S(p + "intra_rnn.weight_hh_l0" + sfx);
-                const float* bi = S(p + "intra_rnn.bias_ih_l0" + sfx);
-                const float* bh = S(p + "intra_rnn.bias_hh_l0" + sfx);
-                for (int q = 0; q < 4; ++q) {
-                    const int wave = d * 4 + q;
-                    for (int ks = 0; ks < 8; ++ks)
-                        for (int lane = 0; lane < 64; ++lane) {
-                            const int li = lane & 15, lg = lane >> 4, j = li >> 2, g = li & 3, u = 4 * q + j, k = 4 * (ks & 3) + lg;
-                            float v = 0.0f;      // row (unit u, gate g of r, z, n_x, n_h): the x half of n_x, the h half of n_h
-                            if (ks < 4) { if (g == 0) v = wi[u * 16 + k] * kRZ; else if (g == 1) v = wi[(16 + u) * 16 + k] * kRZ; else if (g == 2) v = wi[(32 + u) * 16 + k] * kN; }
-                            else { if (g == 0) v = wh[u * 16 + k] * kRZ; else if (g == 1) v = wh[(16 + u) * 16 + k] * kRZ; else if (g == 3) v = wh[(32 + u) * 16 + k] * kN; }
-                            buf[D + Q::I_W + (wave * 8 + ks) * 64 + lane] = v;
-                        }
-                    for (int lg = 0; lg < 4; ++lg) {
-                        const int u = 4 * q + lg;
-                        float* dst = &buf[D + Q::I_B + (wave * 4 + lg) * 4];
-                        dst[0] = (bi[u] + bh[u]) * kRZ; dst[1] = (bi[16 + u] + bh[16 + u]) * kRZ; dst[2] = bi[32 + u] * kN; dst[3] = bh[32 + u] * kN;
-                    }
-                }
-            }
-            auto feat = [](int li) { return 4 * (li & 3) + (li >> 2); };        // output row li = 4 lg + r  <->  feature 4 r + lg
-            {
-                const float* w = S(p + "intra_fc.weight");                      // (16, 32)
-                const float* bb = S(p + "intra_fc.bias");
-                const float* lw = S(p + "intra_ln.weight");
-                const float* lb = S(p + "intra_ln.bias");
-                for (int ks = 0; ks < 8; ++ks)
-                    for (int lane = 0; lane < 64; ++lane) buf[D + Q::FC_W + ks * 64 + lane] = w[feat(lane & 15) * 32 + 16 * (ks >> 2) + 4 * (ks & 3) + (lane >> 4)];
-                for (int lg = 0; lg < 4; ++lg)
-                    for (int r = 0; r < 4; ++r) {
-                        buf[D + Q::FC_B + lg * 4 + r] = bb[4 * r + lg];
-                        for (int f = 0; f < 32; ++f) {
-                            buf[D + Q::LN_W + f * 16 + lg * 4 + r] = lw[f * 16 + 4 * r + lg];
-                            buf[D + Q::LN_B + f * 16 + lg * 4 + r] = lb[f * 16 + 4 * r + lg];
-                        }
-                    }
-            }
-            for (int g = 0; g < 8; ++g) {
-                const int Gb = D + Q::GRP + g * Q::G_SIZE;
-                const std::string q = p + "inter_rnn.inter_rnn." + std::to_string(g);
-                const float* wi = S(q + ".weight_ih_l0");
-                const float* wh = S(q + ".weight_hh_l0");
-                const float* bi = S(q + ".bias_ih_l0");
-                const float* bh = S(q + ".bias_hh_l0");
-                const float* fw = S(p + "inter_rnn.inter_fc." + std::to_string(g) + ".weight");
-                const float* fb = S(p + "inter_rnn.inter_fc." + std::to_string(g) + ".bias");
-                for (int i = 0; i < 24; ++i) {
-                    const int gate = i < 8 ? 0 : (i < 16 ? 1 : 2), ksl = i < 16 ? (i & 7) : i - 16;      // ksl < 4: x half, else h half
-                    const float* src = ksl < 4 ? wi : wh;
-                    for (int lane = 0; lane < 64; ++lane)
-                        buf[Gb + Q::G_W + i * 64 + lane] = src[(gate * 16 + feat(lane & 15)) * 16 + 4 * (ksl & 3) + (lane >> 4)] * (gate < 2 ? kRZ : kN);
-                }
-                for (int lg = 0; lg < 4; ++lg)
-                    for (int r = 0; r < 4; ++r) {
-                        const int u = 4 * r + lg;
-                        buf[Gb + Q::G_B + 0 + lg * 4 + r] = (bi[u] + bh[u]) * kRZ;
-                        buf[Gb + Q::G_B + 16 + lg * 4 + r] = (bi[16 + u] + bh[16 + u]) * kRZ;
-                        buf[Gb + Q::G_B + 32 + lg * 4 + r] = bi[32 + u] * kN;
-                        buf[Gb + Q::G_B + 48 + lg * 4 + r] = bh[32 + u] * kN;
-                        buf[Gb + Q::G_FCB + lg * 4 + r] = fb[u];
-                    }
-                for (int ks = 0; ks < 4; ++ks)
-                    for (int lane = 0; lane < 64; ++lane) buf[Gb + Q::G_FCW + ks * 64 + lane] = fw[feat(lane & 15) * 16 + 4 * ks + (lane >> 4)];
-            }
-        }
-    }
-    {   // stream-batched fullband_encoder_post, feature merge / split, fullband_decoder.0's 1x1 (fspen_sb_kernels.hip.h)
-        using Q = fe::FSbPk;
-        auto feat = [](int li) { return 4 * (li & 3) + (li >> 2); };
-        const float* wpo = S("fullband_encoder_post.weight");  // (32, 32, 1)
-        const float* wf2 = S("fullband_encoder.2.0.weight");   // Conv1d (32, 16, 6)
-        const float* bf2 = S("fullband_encoder.2.0.bias");
-        const float* w1 = S("feature_merge.0.weight");        // (32, 64)
-        const float* w2 = S("feature_merge.2.weight");        // (16, 32, 1)
-        const float* b2 = S("feature_merge.2.bias");
-        const float* s1 = S("feature_split.0.weight");        // (32, 16, 1)
-        const float* sb1 = S("feature_split.0.bias");
-        const float* s2 = S("feature_split.1.weight");        // (64, 32)
-        const float* wd0 = S("fullband_decoder.0.0.weight");  // (32, 64, 1)
-        const float* wd1 = S("fullband_decoder.1.0.weight");  // (16, 32, 1)
-        const float* wd1t = S("fullband_decoder.1.1.weight"); // ConvTranspose1d (16 in, 4 out, 8)
-        const float* bd1t = S("fullband_decoder.1.1.bias");
-        for (int row = 0; row < 16; ++row) buf[P::SB + Q::FD1T_B + row] = row < 8 ? bd1t[row & 3] : 0.0f;
-        const float* wdt = S("fullband_decoder.0.1.weight");  // ConvTranspose1d (32 in, 16 out, 6)
-        const float* bdt = S("fullband_decoder.0.1.bias");
-        for (int o = 0; o < 16; ++o) buf[P::SB + Q::FD0T_B + o] = bdt[o];
-        for (int lane = 0; lane < 64; ++lane) {
-            const int li = lane & 15, lg = lane >> 4;
-            for (int ot = 0; ot < 2; ++ot)
-                for (int ks = 0; ks < 24; ++ks) buf[P::SB + Q::FE2_W + (ot * 24 + ks) * 64 + lane] = wf2[((16 * ot + feat(li)) * 16 + 4 * (ks & 3) + lg) * 6 + (ks >> 2)];
-            for (int ot = 0; ot < 2; ++ot)
-                for (int ks = 0; ks < 8; ++ks) buf[P::SB + Q::POST_W + (ot * 8 + ks) * 64 + lane] = wpo[(16 * ot + feat(li)) * 32 + 4 * ks + lg];
-            for (int jt = 0; jt < 2; ++jt)
-                for (int ks = 0; ks < 16; ++ks) {
-                    const int i = ks < 8 ? 4 * ks + lg : 32 + 16 * ((ks - 8) >> 2) + 4 * lg + ((ks - 8) & 3);
-                    buf[P::SB + Q::MG1_W + (jt * 16 + ks) * 64 + lane] = w1[(16 * jt + feat(li)) * 64 + i];
-                }
-            for (int ks = 0; ks < 8; ++ks) buf[P::SB + Q::MG2_W + ks * 64 + lane] = w2[feat(li) * 32 + 4 * ks + lg];
-            for (int ct = 0; ct < 2; ++ct)
-                for (int ks = 0; ks < 4; ++ks) buf[P::SB + Q::SP1_W + (ct * 4 + ks) * 64 + lane] = s1[(16 * ct + feat(li)) * 16 + 4 * ks + lg];
-            for (int jt = 0; jt < 4; ++jt)
-                for (int ks = 0; ks < 8; ++ks) buf[P::SB + Q::SP2_W + (jt * 8 + ks) * 64 + lane] = s2[(16 * jt + (jt < 2 ? feat(li) : li)) * 32 + 4 * ks + lg];
-            for (int ot = 0; ot < 2; ++ot)      // (rows 4 lg + r <-> output 4 r + lg: its output is the next product's B operand, stored to LDS)
-                for (int ks = 0; ks < 16; ++ks) buf[P::SB + Q::FD0_W + (ot * 16 + ks) * 64 + lane] = wd0[(16 * ot + feat(li)) * 64 + (ks < 8 ? 4 * ks + lg : 32 + 4 * (ks - 8) + lg)];
-            for (int par = 0; par < 2; ++par)
-                for (int t = 0; t < 3; ++t)
-                    for (int ks = 0; ks < 8; ++ks) buf[P::SB + Q::FD0T_W + ((par * 3 + t) * 8 + ks) * 64 + lane] = wdt[((4 * ks + lg) * 16 + li) * 6 + par + 2 * t];
-            for (int ks = 0; ks < 8; ++ks) buf[P::SB + Q::FD1_W + ks * 64 + lane] = wd1[feat(li) * 32 + (ks < 4 ? 4 * lg + ks : 16 + 4 * (ks - 4) + lg)];
-            for (int j = 0; j < 5; ++j)
-                for (int cq = 0; cq < 4; ++cq) {
-                    const int par = li >> 2, o = li & 3, k = (par ? 8 : 7) - 2 * j;      // output positions 2 m + par <- input position m - 2 + j
-                    buf[P::SB + Q::FD1T_W + (j * 4 + cq) * 64 + lane] = (li < 8 && k >= 0 && k < 8) ? wd1t[((4 * cq + lg) * 4 + o) * 8 + k] : 0.0f;
-                }
-        }
-        for (int lg = 0; lg < 4; ++lg)
-            for (int r = 0; r < 4; ++r) {
-                buf[P::SB + Q::MG2_B + lg * 4 + r] = b2[4 * r + lg];
-                for (int ot = 0; ot < 2; ++ot) buf[P::SB + Q::FE2_B + ot * 16 + lg * 4 + r] = bf2[16 * ot + 4 * r + lg];
-                for (int ct = 0; ct < 2; ++ct) buf[P::SB + Q::SP1_B + ct * 16 + lg * 4 + r] = sb1[16 * ct + 4 * r + lg];
-            }
-    }
-    conv("feature_split.0", 32, 16, 1, P::SP1_W, P::SP1_B);
-    {   // feature_split.1 Linear (64 out j, 32 in f) -> [f][j]
-        const float* w = S("feature_split.1.weight");
-        for (int j = 0; j < 64; ++j) for (int f = 0; f < 32; ++f) buf[P::SP2_W + f * 64 + j] = w[j * 32 + f];
-    }
-    {   // sub-band decoder (SubbandDecoder.forward, :83-95): bin -> (layer, output o of its row): one weight column per bin
-        const int base[5] = {0, 16, 32, 64, 128}, k0[5] = {0, 1, 4, 8, 16}, keep[5] = {16, 16, 32, 64, 129};
-        for (int i = 0; i < 5; ++i) {
-            snprintf(nm, sizeof nm, "subband_decoder.lin%d.0.weight", i + 1);
-            const float* w = S(nm);                                   // (n, 64)
-            snprintf(nm, sizeof nm, "subband_decoder.lin%d.0.bias", i + 1);
-            const float* bb = S(nm);
-            for (int q = 0; q < keep[i]; ++q) {
-                const int bin = base[i] + q, o = (k0[i] + q) % kSdN[i];
-                for (int k = 0; k < 64; ++k) buf[P::SD_W + ((k / 4) * 260 + bin) * 4 + k % 4] = w[o * 64 + k];
-                buf[P::SD_B + bin] = bb[o];
-            }
-        }
-    }
-    // ConvTranspose1d (Cin, Cout, K) -> [(c*K + k)][Cout]
-    auto convt = [&](const char* key, int cin, int cout, int K, int dst_w, int dst_b) {
-        const float* w = S(std::string(key) + ".weight");
-        const float* b = S(std::string(key) + ".bias");
-        for (int c = 0; c < cin; ++c)
-            for (int o = 0; o < cout; ++o)
-                for (int k = 0; k < K; ++k) buf[dst_w + (c * K + k) * cout + o] = w[(c * cout + o) * K + k];
-        for (int o = 0; o < cout; ++o) buf[dst_b + o] = b[o];
-    };
-    conv("fullband_decoder.0.0", 32, 64, 1, P::FD0_W, -1);
-    convt("fullband_decoder.0.1", 32, 16, 6, P::FD0_T, P::FD0_B);
-    conv("fullband_decoder.1.0", 16, 32, 1, P::FD1_W, -1);
-    convt("fullband_decoder.1.1", 16, 4, 8, P::FD1_T, P::FD1_B);
-    conv("fullband_decoder.2.0", 4, 8, 1, P::FD2_W, -1);
-    convt("fullband_decoder.2.1", 4, 2, 6, P::FD2_T, P::FD2_B);
-    *out = std::move(buf);
-    return FE_OK;
-}
-
-size_t fspen_gru_floats(int B) { return (size_t)B * fe::FShape<256>::CACHE_FLOATS; }
-
-fe::FArgs fspen_args(fe_handle* h, int B, int T) {
-    fe::FArgs a{};
-    a.wp = h->packed_dev;
-    a.B = B;
-    a.T = T;
-    a.compression = h->cfg.input_compression;
-    return a;
-}
-
-// FSPEN per-hop step of large batches: the middle of the network batched over the streams (fspen_sb_kernels.hip.h) from FE_FSPEN_SB streams
-// (0 = never; measured crossover on 256 CUs at ~1500 streams - a sixteen-stream workgroup per CU needs 4096 to fill the chip)
-int fspen_sb_min() {
-    static const int v = [] { const char* e = getenv("FE_FSPEN_SB"); return e ? atoi(e) : 1536; }();
-    return v;
-}
-int ensure_fsplit(fe_handle* h, int B) {
-    if (!h->fimpl || fspen_sb_min() <= 0 || B < fspen_sb_min() || B <= h->bsplit_streams) return FE_OK;
-    if (h->bsplit_dev) { FE_HIP_CHECK(hipFree(h->bsplit_dev)); h->bsplit_dev = nullptr; h->bsplit_streams = 0; }
-    FE_HIP_CHECK(hipMalloc(&h->bsplit_dev, ((size_t)B + 16) * h->fimpl->split_floats_per_stream * sizeof(float)));      // (+ 16: the last stream tile's lane-private scratch is whole)
-    h->bsplit_streams = B;
-    return FE_OK;
-}
-
-int launch_fspen(fe_handle* h, const fe::FArgs& a_in, void* stream) {
-    hipError_t e = hipSuccess;
-    fe::FArgs a = a_in;
-    if (a.mode == fe::FE_MODE_STREAM && a.T == 1 && a.dbg == nullptr && fspen_sb_min() > 0 && a.B >= fspen_sb_min()) {      // (fe_profile_step: the DPE kernel's counters only)
-        const int rc = ensure_fsplit(h, a.B);
-        if (rc != FE_OK) return rc;
-        a.tok = h->bsplit_dev;
-        a.carry = a.tok + (size_t)a.B * 2048;
-        h->fimpl->launch_sb(a, h->max_wgs, (hipStream_t)stream, &e);
-        if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
-        return FE_OK;
-    }
-    h->fimpl->launch(a, h->max_wgs, (hipStream_t)stream, &e);
-    if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
-    return FE_OK;
-}
-
-// ============================================================================ LiSenNet (models/lisennet/model.py)
-// the checkpoint as it is (remove_weight_reparameterizations is a no-op, :476-477), reference layouts, module order
-void build_sections_lisennet(fe_handle* h) {
-    const int C = 16, c1 = 4, c2 = 8, c3 = 12, F = 257, Hd = 24, nf = 32;
-    auto dsconv = [&](const std::string& p, int cin, int cout, int nfq) {
-        add_section(h, p + ".low_conv.weight", {cout, cin, 2, 3});
-        add_section(h, p + ".low_conv.bias", {cout});
-        add_section(h, p + ".high_conv.weight", {cout, cin, 2, 5});
-        add_section(h, p + ".high_conv.bias", {cout});
-        add_section(h, p + ".norm.gamma", {1, 1, 1, nfq / 2});
-        add_section(h, p + ".norm.beta", {1, 1, 1, nfq / 2});
-        add_section(h, p + ".act.weight", {cout});
-    };
-    auto gru = [&](const std::string& p, int i, int hd, bool bi) {
-        for (const char* sfx : {"", "_reverse"}) {
-            if (!bi && sfx[0]) break;
-            add_section(h, p + ".weight_ih_l0" + sfx, {3 * hd, i});
-            add_section(h, p + ".weight_hh_l0" + sfx, {3 * hd, hd});
-            add_section(h, p + ".bias_ih_l0" + sfx, {3 * hd});
-            add_section(h, p + ".bias_hh_l0" + sfx, {3 * hd});
-        }
-    };
-    add_section(h, "encoder.conv_1.0.weight", {c1, 3, 1, 1});
-    add_section(h, "encoder.conv_1.0.bias", {c1});
-    add_section(h, "encoder.conv_1.1.gamma", {1, 1, 1, F});
-    add_section(h, "encoder.conv_1.1.beta", {1, 1, 1, F});
-    add_section(h, "encoder.conv_1.2.weight", {c1});
-    dsconv("encoder.conv_2", c1, c2, F);
-    dsconv("encoder.conv_3", c2, c3, F / 2);
-    dsconv("encoder.conv_4", c3, C, F / 4);
-    for (int b = 0; b < 2; ++b) {
-        const std::string p = "blocks." + std::to_string(b) + ".";
-        add_section(h, p + "dp_rnn_attn.intra_norm.weight", {nf, C});
-        add_section(h, p + "dp_rnn_attn.intra_norm.bias", {nf, C});
-        gru(p + "dp_rnn_attn.intra_rnn_attn.rnn", C, Hd / 2, true);
-        add_section(h, p + "dp_rnn_attn.intra_rnn_attn.dense.weight", {C, Hd});
-        add_section(h, p + "dp_rnn_attn.intra_rnn_attn.dense.bias", {C});
-        add_section(h, p + "dp_rnn_attn.inter_norm.weight", {nf, C});
-        add_section(h, p + "dp_rnn_attn.inter_norm.bias", {nf, C});
-        gru(p + "dp_rnn_attn.inter_rnn_attn.rnn", C, Hd, false);
-        add_section(h, p + "dp_rnn_attn.inter_rnn_attn.dense.weight", {C, Hd});
-        add_section(h, p + "dp_rnn_attn.inter_rnn_attn.dense.bias", {C});
-        add_section(h, p + "conv_glu.norm.gamma", {1, C, 1, nf});
-        add_section(h, p + "conv_glu.norm.beta", {1, C, 1, nf});
-        add_section(h, p + "conv_glu.fc1.weight", {4 * C, C, 1, 1});
-        add_section(h, p + "conv_glu.fc1.bias", {4 * C});
-        add_section(h, p + "conv_glu.dwconv.weight", {2 * C, 1, 3, 3});
-        add_section(h, p + "conv_glu.dwconv.bias", {2 * C});
-        add_section(h, p + "conv_glu.fc2.weight", {C, 2 * C, 1, 1});
-        add_section(h, p + "conv_glu.fc2.bias", {C});
-    }
-    const int ucin[3] = {2 * C, 2 * c3, 2 * c2}, ucout[3] = {c3, c2, c1};
-    for (int i = 0; i < 3; ++i) {
-        const std::string p = "decoder.up" + std::to_string(i + 1) + ".";
-        add_section(h, p + "low_conv.weight", {ucout[i], ucin[i], 1, 3});
-        add_section(h, p + "low_conv.bias", {ucout[i]});
-        add_section(h, p + "high_conv.conv.weight", {3 * ucout[i], ucin[i], 1, 3});
-        add_section(h, p + "high_conv.conv.bias", {3 * ucout[i]});
-    }
-    add_section(h, "decoder.mask_conv.0.weight", {2, c1, 2, 2});
-    add_section(h, "decoder.mask_conv.0.bias", {2});
-    add_section(h, "decoder.mask_conv.1.gamma", {1, 1, 1, F});
-    add_section(h, "decoder.mask_conv.1.beta", {1, 1, 1, F});
-    add_section(h, "decoder.mask_conv.2.weight", {2});
-    add_section(h, "decoder.mask_conv.3.weight", {2, 2, 1, 1});
-    add_section(h, "decoder.mask_conv.3.bias", {2});
-    add_section(h, "decoder.lsigmoid.slope", {F, 1, 1});
-}
-
-int create_lisennet(const fe_config* cfg, fe_handle** out) {
-    if (cfg->win_size > cfg->n_fft) return fail(FE_ERR_INVALID_ARG, "n_fft(%d) must be bigger than win_size(%d)", cfg->n_fft, cfg->win_size);
-    const fe::LImpl* li = (cfg->channels == 16 && cfg->rf_blocks == 2 && cfg->n_fft == 512 && cfg->hop_size == 256) ? fe_limpl_h256() : nullptr;
-    if (!li)
-        return fail(FE_ERR_UNSUPPORTED_CONFIG, "no LiSenNet kernel compiled for num_channels=%d n_blocks=%d n_fft=%d hop=%d "
-                    "(configs/others/lisennet.yaml is the compiled architecture)", cfg->channels, cfg->rf_blocks, cfg->n_fft, cfg->hop_size);
-    fe_handle* h = new fe_handle();
-    h->cfg = *cfg;
-    h->limpl = li;
-    h->d = Dims{16, 0, 16, 32, 2, cfg->n_fft, cfg->hop_size, cfg->n_fft / 2, 0, 0, {0}};
-    if (hipGetDevice(&h->device) != hipSuccess) h->device = -1;
-    else {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->max_wgs = cus;
-    }
-    build_sections_lisennet(h);
-    build_tables(h);
-    *out = h;
-    return FE_OK;
-}
-
-// k-major repack at the compile-time offsets of fe::LPk (lisennet_kernels.hip.h)
-int pack_weights_lisennet(fe_handle* h, const std::vector<float>& blob, std::vector<float>* out) {
-    using P = fe::LPk;
-    std::vector<float> buf(P::TOTAL, 0.0f);
-    auto S = [&](const std::string& n) { return sec(h, blob, n); };
-    auto copy = [&](const std::string& n, int dst, int cnt) { const float* w = S(n); for (int i = 0; i < cnt; ++i) buf[dst + i] = w[i]; };
-    for (int i = 0; i < 512; ++i) { buf[P::WINDOW + i] = h->window[i]; buf[P::WINDOW_I + i] = h->window_istft[i]; buf[P::TW + i] = h->twiddle[i]; }
-    {
-        const float* w = S("encoder.conv_1.0.weight");            // (4, 3, 1, 1) -> [c][o]
-        for (int o = 0; o < 4; ++o) for (int c = 0; c < 3; ++c) buf[P::C1_W + c * 4 + o] = w[o * 3 + c];
-        copy("encoder.conv_1.0.bias", P::C1_B, 4);
-        copy("encoder.conv_1.1.gamma", P::C1_G, 257);
-        copy("encoder.conv_1.1.beta", P::C1_BE, 257);
-        copy("encoder.conv_1.2.weight", P::C1_P, 4);
-    }
-    // Conv2d (O, Cin, KT, KF) -> [((c*KT + dt)*KF + df)][O]
-    auto conv = [&](const std::string& key, int O, int Cin, int KT, int KF, int dst_w, int dst_b) {
-        const float* w = S(key + ".weight");
-        for (int o = 0; o < O; ++o)
-            for (int c = 0; c < Cin; ++c)
-                for (int dt = 0; dt < KT; ++dt)
-                    for (int df = 0; df < KF; ++df) buf[dst_w + ((c * KT + dt) * KF + df) * O + o] = w[((o * Cin + c) * KT + dt) * KF + df];
-        if (dst_b >= 0) copy(key + ".bias", dst_b, O);
-    };
-    auto dsconv = [&](const std::string& p, int cin, int cout, int half, int lo, int hi, int bl, int bh, int g, int be, int pr) {
-        conv(p + ".low_conv", cout, cin, 2, 3, lo, bl);
-        conv(p + ".high_conv", cout, cin, 2, 5, hi, bh);
-        copy(p + ".norm.gamma", g, 2 * half);
-        copy(p + ".norm.beta", be, 2 * half);
-        copy(p + ".act.weight", pr, cout);
-    };
-    dsconv("encoder.conv_2", 4, 8, 64, P::D2_LO, P::D2_HI, P::D2_BL, P::D2_BH, P::D2_G, P::D2_BE, P::D2_P);
-    dsconv("encoder.conv_3", 8, 12, 32, P::D3_LO, P::D3_HI, P::D3_BL, P::D3_BH, P::D3_G, P::D3_BE, P::D3_P);
-    dsconv("encoder.conv_4", 12, 16, 16, P::D4_LO, P::D4_HI, P::D4_BL, P::D4_BH, P::D4_G, P::D4_BE, P::D4_P);
-    for (int b = 0; b < 2; ++b) {
-        const int D = P::BLK + b * P::B_SIZE;
-        const std::string p = "blocks." + std::to_string(b) + ".";
-        copy(p + "dp_rnn_attn.intra_norm.weight", D + P::B_N1W, 512);
-        copy(p + "dp_rnn_attn.intra_norm.bias", D + P::B_N1B, 512);
-        for (int d = 0; d < 2; ++d) {
-            const std::string sfx = d ? "_reverse" : "";
-            const std::string q = p + "dp_rnn_attn.intra_rnn_attn.rnn.";
-            const float* wi = S(q + "weight_ih_l0" + sfx);        // (36, 16)
-            const float* wh = S(q + "weight_hh_l0" + sfx);        // (36, 12)
-            const float* bi = S(q + "bias_ih_l0" + sfx);
-            const float* bh = S(q + "bias_hh_l0" + sfx);
-            for (int g = 0; g < 36; ++g) {
-                for (int k = 0; k < 16; ++k) buf[D + P::B_IH + (d * 16 + k) * 36 + g] = wi[g * 16 + k];
-                buf[D + P::B_GB + d * 36 + g] = bi[g] + (g < 24 ? bh[g] : 0.0f);
-            }
-            for (int gate = 0; gate < 3; ++gate)
-                for (int k = 0; k < 12; ++k)
-                    for (int c = 0; c < 12; ++c) buf[D + P::B_HH + ((d * 3 + gate) * 12 + k) * 12 + c] = wh[(gate * 12 + c) * 12 + k];
-            for (int c = 0; c < 12; ++c) buf[D + P::B_HN + d * 12 + c] = bh[24 + c];
-        }
-        {
-            const float* w = S(p + "dp_rnn_attn.intra_rnn_attn.dense.weight");     // (16, 24) -> [k][d]
-            for (int d = 0; d < 16; ++d) for (int k = 0; k < 24; ++k) buf[D + P::B_D1W + k * 16 + d] = w[d * 24 + k];
-            copy(p + "dp_rnn_attn.intra_rnn_attn.dense.bias", D + P::B_D1B, 16);
-        }
-        copy(p + "dp_rnn_attn.inter_norm.weight", D + P::B_N2W, 512);
-        copy(p + "dp_rnn_attn.inter_norm.bias", D + P::B_N2B, 512);
-        {
-            const std::string q = p + "dp_rnn_attn.inter_rnn_attn.rnn.";
-            const float* wi = S(q + "weight_ih_l0");              // (72, 16)
-            const float* wh = S(q + "weight_hh_l0");              // (72, 24)
-            const float* bi = S(q + "bias_ih_l0");
-            const float* bh = S(q + "bias_hh_l0");
-            for (int g = 0; g < 72; ++g) {
-                for (int k = 0; k < 16; ++k) buf[D + P::B_XIH + k * 72 + g] = wi[g * 16 + k];
-                for (int k = 0; k < 24; ++k) buf[D + P::B_XHH + k * 72 + g] = wh[g * 24 + k];
-                buf[D + P::B_XGB + g] = bi[g] + (g < 48 ? bh[g] : 0.0f);
-            }
-            for (int c = 0; c < 24; ++c) buf[D + P::B_XHN + c] = bh[48 + c];
-            const float* w = S(p + "dp_rnn_attn.inter_rnn_attn.dense.weight");
-            for (int d = 0; d < 16; ++d) for (int k = 0; k < 24; ++k) buf[D + P::B_D2W + k * 16 + d] = w[d * 24 + k];
-            copy(p + "dp_rnn_attn.inter_rnn_attn.dense.bias", D + P::B_D2B, 16);
-        }
-        copy(p + "conv_glu.norm.gamma", D + P::B_GG, 512);        // (1, 16, 1, 32) -> [d][f]
-        copy(p + "conv_glu.norm.beta", D + P::B_GBE, 512);
-        {
-            const float* w = S(p + "conv_glu.fc1.weight");        // (64, 16, 1, 1) -> [d][o]
-            for (int o = 0; o < 64; ++o) for (int d = 0; d < 16; ++d) buf[D + P::B_F1W + d * 64 + o] = w[o * 16 + d];
-            copy(p + "conv_glu.fc1.bias", D + P::B_F1B, 64);
-            const float* dw = S(p + "conv_glu.dwconv.weight");    // (32, 1, 3, 3) -> [(dt*3 + df)][ch]
-            for (int c = 0; c < 32; ++c) for (int j = 0; j < 9; ++j) buf[D + P::B_DW + j * 32 + c] = dw[c * 9 + j];
-            copy(p + "conv_glu.dwconv.bias", D + P::B_DWB, 32);
-            const float* w2 = S(p + "conv_glu.fc2.weight");       // (16, 32, 1, 1) -> [ch][d]
-            for (int d = 0; d < 16; ++d) for (int c = 0; c < 32; ++c) buf[D + P::B_F2W + c * 16 + d] = w2[d * 32 + c];
-            copy(p + "conv_glu.fc2.bias", D + P::B_F2B, 16);
-        }
-    }
-    conv("decoder.up1.low_conv", 12, 32, 1, 3, P::U1_LO, P::U1_BL);
-    conv("decoder.up1.high_conv.conv", 36, 32, 1, 3, P::U1_HI, P::U1_BH);
-    conv("decoder.up2.low_conv", 8, 24, 1, 3, P::U2_LO, P::U2_BL);
-    conv("decoder.up2.high_conv.conv", 24, 24, 1, 3, P::U2_HI, P::U2_BH);
-    conv("decoder.up3.low_conv", 4, 16, 1, 3, P::U3_LO, P::U3_BL);
-    conv("decoder.up3.high_conv.conv", 12, 16, 1, 3, P::U3_HI, P::U3_BH);
-    conv("decoder.mask_conv.0", 2, 4, 2, 2, P::M0_W, P::M0_B);
-    copy("decoder.mask_conv.1.gamma", P::M_G, 257);
-    copy("decoder.mask_conv.1.beta", P::M_BE, 257);
-    copy("decoder.mask_conv.2.weight", P::M_P, 2);
-    {
-        const float* w = S("decoder.mask_conv.3.weight");          // (2, 2, 1, 1) -> [c][o]
-        for (int o = 0; o < 2; ++o) for (int c = 0; c < 2; ++c) buf[P::M3_W + c * 2 + o] = w[o * 2 + c];
-        copy("decoder.mask_conv.3.bias", P::M3_B, 2);
-        copy("decoder.lsigmoid.slope", P::SLOPE, 257);
-    }
-    *out = std::move(buf);
-    return FE_OK;
-}
-
-fe::LArgs lisennet_args(fe_handle* h, int B, int T) {
-    fe::LArgs a{};
-    a.wp = h->packed_dev;
-    a.B = B;
-    a.T = T;
-    a.compression = h->cfg.input_compression;
-    return a;
-}
-
-int launch_lisennet(fe_handle* h, const fe::LArgs& a, void* stream) {
-    hipError_t e = hipSuccess;
-    h->limpl->launch(a, h->max_wgs, (hipStream_t)stream, &e);
-    if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
-    return FE_OK;
-}
+// the baseline families' host sides (weight sections, handle creation, packers): one file each
+#include "fe_api_bsrnn.inc"
+#include "fe_api_fspen.inc"
+#include "fe_api_lisennet.inc"
 
 size_t bsrnn_lstm_floats(const fe_handle* h, int B) { return (size_t)2 * h->cfg.rf_blocks * B * 31 * 2 * h->cfg.channels; }
 
