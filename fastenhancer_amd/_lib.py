@@ -59,6 +59,7 @@ SYMBOLS = {
     "fe_debug_floats": (c_size_t, [c_void_p]),
     "fe_debug_step": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p]),
     "fe_profile_step": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),
+    "fe_debug_poison_lds": (c_int, [c_void_p]),
     "fe_last_error": (c_char_p, []),
     "fe_version": (c_char_p, []),
 }

@@ -225,6 +225,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     float* PRE = smem + L::PRE;
     float* XPg = S::XPG ? a.xp_scratch + (size_t)blockIdx.x * (2 * 32 * G4) : nullptr;
     for (int i = tid; i < N / 2; i += kThreads) tw[i] = reinterpret_cast<const float2*>(wp + o.twiddle)[i];
+    if (tid < 2) sp[2 * kBins + tid] = 0.0f;      // (r5) the band split reads the last band's row zero-padded to kBsKP floats: the two words past the spectrum meet zero
+                                                  // weights - leftovers of another kernel there could be NaN / inf (seen once: a whole run non-finite right after process start)
     __syncthreads();
 
     const int mode = HOT ? FE_MODE_STREAM : a.mode;

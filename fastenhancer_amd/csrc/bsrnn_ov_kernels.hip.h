@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     static_assert(N / 2 == kThreads, "one twiddle per thread");
     const float2 twv = reinterpret_cast<const float2*>(wp + o.twiddle)[tid];
     if (tid < 16) flg[tid] = 0;
+    if (tid < 2) sp[2 * kBins + tid] = 0.0f;      // the band split reads the last band's row zero-padded to kBsKP floats: two words past the spectrum meet zero weights - they must not be NaN / inf leftovers
 
     // ---------------- the roles' register sets
     // scans (waves 0, 1): lane = (half, unit): half 0 holds gate rows (i, g), half 1 (f, o) of unit u over the whole K

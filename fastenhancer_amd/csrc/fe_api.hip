@@ -807,7 +807,26 @@ __global__ void ring_out_kernel(const float* __restrict__ ring, float* __restric
     cache[(row * L + j) * SZ + dd] = ring[(row * RS + (size_t)((T + j) % RS)) * SZ + dd];
 }
 
+// fe_debug_poison_lds: every workgroup fills 160 KiB of LDS (= one workgroup per CU at a time) with quiet-NaN patterns; 16 x #CUs workgroups so that every CU
+// gets at least one whatever the dispatch order
+__global__ void __launch_bounds__(256) poison_lds_kernel(unsigned int* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned int pl[];
+    for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) pl[i] = 0x7fc00000u | (unsigned int)i;
+    __syncthreads();
+    if (pl[(threadIdx.x * 97 + blockIdx.x) % (160 * 1024 / 4)] == 0x12345u && sink) sink[0] = 1u;      // (keeps the stores alive)
+}
+
 extern "C" {
+
+int fe_debug_poison_lds(void* stream) {
+    int dev = 0, cus = 0;
+    FE_HIP_CHECK(hipGetDevice(&dev));
+    FE_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    FE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(16 * (cus > 0 ? cus : 256)), dim3(256), 160 * 1024, (hipStream_t)stream, (unsigned int*)nullptr);
+    FE_HIP_CHECK(hipGetLastError());
+    return FE_OK;
+}
 
 const char* fe_last_error(void) { return g_err.c_str(); }
 const char* fe_version(void) { return "fastenhancer_hip 0.1 (gfx950)"; }

@@ -391,6 +391,12 @@ class Engine:
                                                  _stream(self.device)), "fe_istft_offline")
         return wav
 
+    def poison_lds(self) -> None:
+        """fe_debug_poison_lds: NaN into every CU's LDS (test support: what an earlier kernel leaves in LDS must not matter)."""
+        self._require_gpu()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fe_debug_poison_lds(_stream(self.device)), "fe_debug_poison_lds")
+
     def profile_step(self, wav_in: Tensor, state: Tensor, T: int = 1) -> Tensor:
         """Phase cycle counters (int64[64]) of workgroup 0 for the last frame of the launch."""
         self._require_gpu()

@@ -262,6 +262,12 @@ int fe_debug_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, float
 int fe_profile_step(fe_handle* h, const float* wav_in_dev, size_t in_stride, float* state_dev,
                     float* wav_out_dev, size_t out_stride, int B, int T, unsigned long long* clk_dev, void* stream);
 
+/* Test support (r5): fills the LDS of every CU of the current device with NaN bit patterns (a short launch on `stream`).  The kernels
+ * read padded operands in places - zero weights against words past the end of a tensor in LDS - and whatever an earlier kernel left
+ * there must not matter: the parity tests run a step after this call and require the bits of the un-poisoned run.
+ * (The reference has no counterpart: PyTorch pads explicitly, models/bsrnn/model.py:136-153.) */
+int fe_debug_poison_lds(void* stream);
+
 const char* fe_last_error(void);
 const char* fe_version(void);
 

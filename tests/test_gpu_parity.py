@@ -1793,3 +1793,85 @@ def test_time_pipeline_stress_is_bit_reproducible_and_equals_the_serial_walk(nam
         for rep in range(10):
             assert torch.equal(m(x)[0], w0), (width, rep)
     eng.set_time_pipeline(-1)
+
+
+_POISON_CASES = [("fe_t", 5, None), ("fe_b", 5, "wg8"), ("fe_b", 5, "waves4"), ("fe_b", 300, None), ("fe_s", 3, None), ("fe_m", 3, None), ("fe_l", 3, None),
+                 ("fe48_t", 3, None), ("fe48_b", 3, None), ("fe48_b_h480", 300, None), ("fe48_l", 2, None), ("fe_tk_b", 3, None), ("fe_dprnn_b", 3, None),
+                 ("fe_dpt_b", 3, None), ("fe_ln_b", 3, None), ("bsrnn_xt", 5, "wg8"), ("bsrnn_xt", 5, "waves4"), ("bsrnn_xt", 300, None), ("bsrnn_xxt", 3, None),
+                 ("bsrnn_t", 3, None), ("bsrnn_s", 2, None), ("fspen", 3, None), ("lisennet", 3, None)]
+
+
+@pytest.mark.parametrize("name,B,kern", _POISON_CASES)
+def test_lds_leftovers_of_other_kernels_do_not_matter(name, B, kern):
+    """r5: the kernels read padded operands in places - zero weights against words past the end of a tensor in LDS (BSRNN's band split reads the last
+    band's row padded to 36 floats: two words past the spectrum).  What an earlier kernel left there must not matter: with every CU's LDS filled with
+    NaN before each launch (fe_debug_poison_lds) a per-hop run gives the bits of the plain run.  (Found by a 400-hop run that came back non-finite
+    once, right after process start.)"""
+    if name.startswith("bsrnn"):
+        m, orc, cfg, sr, seed = _bsrnn(name)
+    elif name == "fspen":
+        m, orc, cfg, sr, seed = _fspen()
+    elif name == "lisennet":
+        m, orc, cfg, sr, seed = _lisennet()
+    else:
+        m, orc, cfg, sr, seed = _model(name)
+    eng = m.engine
+    if kern is not None:
+        eng.set_step_kernel(kern)
+    hops, H = 4, cfg.hop_size
+    x = torch.from_numpy(make_input(B, hops * H, seed + 99, sr)).to(_dev())
+    res = []
+    for poison in (False, True):
+        st = eng.new_state(B)
+        outs = []
+        for t in range(hops):
+            if poison:
+                eng.poison_lds()
+            outs.append(eng.step(x[:, t * H:(t + 1) * H].contiguous(), st, T=1).clone())
+        res.append((torch.cat(outs, 1), st.clone()))
+    if kern is not None:
+        eng.set_step_kernel("wg8")
+    assert bool(torch.isfinite(res[1][0]).all()) and bool(torch.isfinite(res[1][1]).all()), "non-finite output after NaN leftovers in LDS"
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), "the result depends on what was in LDS before the launch"
+
+
+@pytest.mark.parametrize("name,B", [("fe_b", 3), ("fe_t", 2), ("fe_l", 2), ("fe48_b", 2), ("fe_nc", 2), ("fe_tk_b", 2), ("fe_dpt_b", 2), ("bsrnn_xt", 3), ("bsrnn_t", 2),
+                                    ("fspen", 2), ("lisennet", 2), ("bsrnn_xt", 2100), ("fspen", 1600)])
+def test_lds_leftovers_do_not_matter_chunked_offline_and_stream_batched(name, B):
+    """The same for the other launch shapes: a chunked step (T = 3), offline Model.forward (time-batched engine / time-pipelined walk), and the
+    stream-batched steps of the large batches (BSRNN from 2048 streams, FSPEN from 1536)."""
+    cls = "Model" if name == "fe_nc" else "ONNXModel"
+    if name.startswith("bsrnn"):
+        m, orc, cfg, sr, seed = _bsrnn(name)
+        mo = _bsrnn(name, "Model")[0] if B < 100 else None
+    elif name == "fspen":
+        m, orc, cfg, sr, seed = _fspen()
+        mo = _fspen("Model")[0] if B < 100 else None
+    elif name == "lisennet":
+        m, orc, cfg, sr, seed = _lisennet()
+        mo = _lisennet("Model")[0]
+    else:
+        m, orc, cfg, sr, seed = _model(name, cls)
+        mo = m if cls == "Model" else _model(name, "Model")[0]
+    H = cfg.hop_size
+    if cls == "ONNXModel":
+        eng = m.engine
+        T = 1 if B > 100 else 3
+        x = torch.from_numpy(make_input(B, 2 * T * H, seed + 7, sr)).to(_dev())
+        res = []
+        for poison in (False, True):
+            st = eng.new_state(B)
+            outs = []
+            for c in range(2):
+                if poison:
+                    eng.poison_lds()
+                outs.append(eng.step(x[:, c * T * H:(c + 1) * T * H].contiguous(), st, T=T).clone())
+            res.append((torch.cat(outs, 1), st.clone()))
+        assert bool(torch.isfinite(res[1][0]).all())
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), "chunked / stream-batched step depends on LDS leftovers"
+    if mo is not None:
+        xo = torch.from_numpy(make_input(2, 9 * H + 11, seed + 8, sr)).to(_dev())
+        w0, s0 = [t.clone() for t in mo(xo)]
+        mo.engine.poison_lds()
+        w1, s1 = [t.clone() for t in mo(xo)]
+        assert bool(torch.isfinite(w1).all()) and torch.equal(w0, w1) and torch.equal(s0, s1), "offline forward depends on LDS leftovers"
