@@ -1875,3 +1875,42 @@ def test_lds_leftovers_do_not_matter_chunked_offline_and_stream_batched(name, B)
         mo.engine.poison_lds()
         w1, s1 = [t.clone() for t in mo(xo)]
         assert bool(torch.isfinite(w1).all()) and torch.equal(w0, w1) and torch.equal(s0, s1), "offline forward depends on LDS leftovers"
+
+
+@pytest.mark.parametrize("name", ["fe_b", "fe_t", "fe_l", "fe48_b", "fe_nc", "fe_tk_b", "fe_dpt_b", "fe_ln_b", "bsrnn_xt", "bsrnn_t", "fspen", "lisennet"])
+def test_uninitialised_work_buffers_do_not_matter(name, monkeypatch):
+    """The caller-owned work / output buffers of fe_offline (the mirror gets them from torch.empty): every word the engines read they must have written
+    first.  With torch.empty handing out NaN-filled buffers, Model.forward gives the bits of the plain run - on the time-batched engine and on the frame walk."""
+    if name.startswith("bsrnn"):
+        mo = _bsrnn(name, "Model")[0]
+        cfg, sr, seed = mo.engine.cfg, 16000, 11
+    elif name == "fspen":
+        mo = _fspen("Model")[0]
+        cfg, sr, seed = mo.engine.cfg, 16000, 12
+    elif name == "lisennet":
+        mo = _lisennet("Model")[0]
+        cfg, sr, seed = mo.engine.cfg, 16000, 13
+    else:
+        mo, orc, cfg, sr, seed = _model(name, "Model")
+    H = cfg.hop_size
+    xo = torch.from_numpy(make_input(3, 21 * H + 5, seed + 3, sr)).to(_dev())
+    engines = ["auto"] if name in ("fe_nc",) or name.startswith("bsrnn") or name in ("fspen", "lisennet") else ["auto", "frame_walk"]
+    real_empty = torch.empty
+
+    def nan_empty(*a, **k):
+        t = real_empty(*a, **k)
+        if t.is_floating_point():
+            t.fill_(float("nan"))
+        return t
+
+    for engname in engines:
+        if engname != "auto":
+            mo.engine.set_offline_engine(engname)
+        w0, s0 = [t.clone() for t in mo(xo)]
+        monkeypatch.setattr(torch, "empty", nan_empty)
+        w1, s1 = [t.clone() for t in mo(xo)]
+        monkeypatch.setattr(torch, "empty", real_empty)
+        assert bool(torch.isfinite(w1).all()) and bool(torch.isfinite(s1).all()), f"{name} {engname}: non-finite output from NaN-filled work buffers"
+        assert torch.equal(w0, w1) and torch.equal(s0, s1), f"{name} {engname}: the result depends on the work buffers' previous content"
+    if len(engines) > 1:
+        mo.engine.set_offline_engine("auto")
