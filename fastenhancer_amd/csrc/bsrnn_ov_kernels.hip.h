@@ -10,13 +10,18 @@
 //                with a workgroup barrier per step) - nothing else
 //   waves 2, 3   everything on the matrix cores, for two row tiles of bands that are cut by readiness, not by index:
 //                tile A = bands 8..22 (ready after step 22), tile B = bands 0..7 and 23..30 (ready after step 30).  Per tile the chain
-//                fc_freq (layer l) -> x -> time-LSTM gates (layer l + 1) -> fc_time -> input projections of layer l + 1; tile A's chain
-//                runs under steps 23..30 of layer l's scans, only tile B's is serial with them.  The h half of the time-LSTM gates
-//                (W_hh h_{t-1}: known since the last frame) is accumulated under the early steps.
-// Synchronisation is by monotonic counters in LDS (scan progress per direction, a two-wave rendezvous inside a chain, "projections of
-// layer l complete"), polled; the input projections are double-buffered by layer parity.  The two helper waves split the gate GEMM by
-// hidden tile and the projections by direction, and compute the narrow fc layers (N = 16) redundantly - identical values written to the
-// same LDS words - so that a chain needs ONE rendezvous (the new time-LSTM h, whose two column halves meet in fc_time).
+//                fc_freq (layer l) -> x -> time-LSTM gates (layer l + 1) -> fc_time -> input projections of layer l + 1.  Tile A's chain
+//                up to its x runs under steps 23..30 of layer l's scans and its projections under steps 0..7 of layer l + 1's (bands
+//                8..22 are not read before step 8); only tile B's chain is serial with the scans, and the scan waves - idle by then -
+//                take half of its projections.  The h half of the time-LSTM gates (W_hh h_{t-1}: known since the last frame) is
+//                accumulated under the early steps.  Layer 0's time part runs on all four waves (tile A on waves 0, 1).
+// Every product of a chain is computed TRANSPOSED, the sixteen bands of a tile as its N: the accumulator fragment of one product is the B
+// operand of the next (see the register sets below) - a chain touches LDS for the scans' outputs, the exchange of the new h between the two
+// hidden tiles and the projections it hands over.
+// Synchronisation is by monotonic counters in LDS, polled: scan progress per direction, a two-wave rendezvous inside a chain, "tile B's x
+// stored", "projections of layer l complete" per tile and direction; the projections are double-buffered by layer parity.  The two waves
+// of a pair split the gate GEMM by hidden tile and the projections by direction, and both compute the narrow fc layers (N = 16) - IN THE
+// SAME SUMMATION ORDER: either wave's copy of x is read by other waves, so the two must agree bit for bit (else a run is not reproducible).
 // Reference: models/bsrnn/model.py:367-390 (the layer loop), :249-257 (ONNXLSTM), :136-153 (BandSplit).
 #pragma once
 
@@ -26,9 +31,9 @@ template <class S>
 struct BOvLds {
     static constexpr int SP = 0;                              // compressed spectrum [257][2]
     static constexpr int TW = SP + 2 * kBins + 2;             // twiddles
-    static constexpr int FA = TW + S::NFFT;                   // FFT ping-pong
+    static constexpr int FA = TW + S::NFFT;                   // windowed frame [N] (the radix-2 kernels' ping-pong size is kept: 2 N floats each)
     static constexpr int FB = FA + 2 * S::NFFT;
-    static constexpr int XB = FB + 2 * S::NFFT;               // (FA: windowed frame, FB: spectrum {Re, Im} + Nyquist)   [32][LDX] band features: the band split's output, the last layer's
+    static constexpr int XB = FB + 2 * S::NFFT;               // (FB: spectrum {Re[N/2], Im[N/2]} + the Nyquist bin)   [32][LDX] band features: the band split's output, the last layer's
     static constexpr int XT = (XB + 32 * S::LDX + 3) / 4 * 4; // [2 tiles][64 lanes][4]: a tile's x after fc_time as accumulator fragments (for the waves that did not compute it)
     static constexpr int HX = XT + 2 * 256;                   // [2 pairs][2 chain parities][2 ct][64 lanes][4]: the new time-LSTM h of a wave's hidden tile, for its partner
     static constexpr int YF = HX + 2 * 2 * 2 * 256;           // [32][LDY] band-LSTM outputs (fwd | bwd)
