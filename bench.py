@@ -462,11 +462,12 @@ def dry_run(args, launched: bool, world: int, rank: int):
         t0 = time.perf_counter()
         for _ in range(args.steps):
             pass
-        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        own = time.perf_counter() - t0
+        tt = torch.tensor([own, -own], dtype=torch.float64)
         if launched:
             dist.barrier()
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        times.append(float(tt[0]))
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)      # (slowest rank, and - negated - the fastest: the spread main() reports)
+        times.append((float(tt[0]), -float(tt[1])))
     per_rank = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
     if launched:
         dist.all_gather(per_rank, torch.tensor([float(b1 - b0)], dtype=torch.float64))
@@ -475,6 +476,11 @@ def dry_run(args, launched: bool, world: int, rank: int):
     if rank == 0:
         print(json.dumps({"dry_run": True, "metric": "none (launch path only: no kernels ran)", "value": None, "n_gpus": world, "world_size": world,
                           "backend": "gloo", "steps": args.steps, "warmup": args.warmup, "blocks": len(times),
+                          # what main() would do with these flags: one HIP graph of the K steps at world > 1 unless --no-graph
+                          "launch_mode": "hip_graph" if ((args.graph or world > 1) and not args.no_graph and args.offline_seconds <= 0) else "eager",
+                          "eager_ms_per_step": None,
+                          "rank_spread_ms_per_step": {"min": min(t[1] for t in times) / max(args.steps, 1) * 1e3, "max": max(t[0] for t in times) / max(args.steps, 1) * 1e3,
+                                                      "widest_block_max_over_min": max(t[0] / max(t[1], 1e-12) for t in times)},
                           "streams_per_rank": [int(v) for v in per_rank], "weight_blob_floats": int(blob.numel()),
                           "weight_checksum": float(chk[0])}), flush=True)
     if launched:
@@ -510,7 +516,11 @@ def main():
                          "the JSON line carries contention_probe: true and no roofline claim")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--graph", action="store_true",
-                    help="capture the K timed steps (K launches, each on its own input hop) into ONE HIP graph and time its replay")
+                    help="capture the K timed steps (K launches, each on its own input hop) into ONE HIP graph and time its replay.  The DEFAULT when "
+                         "the world has more than one rank (r6): a 32-us step leaves an eager N-rank number to the launch threads' jitter on a shared CPU "
+                         "quota (enqueue 3.7 us per eager launch against 0.3-0.8 us per graph node, profiles/r5_host_contention.txt); the eager figure "
+                         "of the same run is reported beside it as eager_ms_per_step")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches also at world > 1")
     ap.add_argument("--clock-ramp-ms", type=float, default=250.0,
                     help="untimed launches of the same step BEFORE the counted warm-up, until this much GPU time has passed "
                          "(brings the shader clock and the caches to steady state; reported as clock_ramp_steps)")
@@ -525,6 +535,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     share = args.share_gpu or os.environ.get("FE_BENCH_SHARE_GPU") == "1"
+    use_graph = (args.graph or (world > 1 and not share)) and not args.no_graph and args.offline_seconds <= 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -660,7 +671,7 @@ def main():
     # filling its instruction / TLB caches (r1: 39.3 us per step in the driver's 20-step run, 34.5 us in steady state)
     ramp_steps = 0
     cold_ms = None
-    if args.clock_ramp_ms > 0 and not use_dist and not args.graph:
+    if args.clock_ramp_ms > 0 and not use_dist and not use_graph:
         # the figure WITHOUT the ramp, for comparison with r1's numbers and with baselines measured cold: W warm-up steps, then K steps
         # timed on the host clock, before anything else has run on the device (reported as cold_ms_per_step, never as `value`)
         run(args.warmup, 0)
@@ -685,31 +696,43 @@ def main():
         state.zero_()
     run(args.warmup, 0)
     torch.cuda.synchronize(dev)
+    kernel_name = eng.last_step_kernel()              # fe_last_step_kernel: what the library dispatched for this configuration (the timed launches are the same call)
     graph = None
-    if args.graph and not offline:
-        cap = torch.cuda.Stream(dev)
-        graph = torch.cuda.CUDAGraph()
+    graph_note = None
+    if use_graph and not offline:
         keep = state.clone()
-        with torch.cuda.graph(graph, stream=cap):
-            csptr = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            for i in range(args.steps):
-                s_ = (args.warmup + i) % pool
-                rc = lib.fe_step(eng._h, ctypes.c_void_p(xptr + s_ * step_bytes), T * H, stptr, optr, T * H, B, T, csptr)
-                if rc != 0:
-                    _lib.check(rc, "fe_step")
+        try:
+            cap = torch.cuda.Stream(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=cap):
+                csptr = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                for i in range(args.steps):
+                    s_ = (args.warmup + i) % pool
+                    rc = lib.fe_step(eng._h, ctypes.c_void_p(xptr + s_ * step_bytes), T * H, stptr, optr, T * H, B, T, csptr)
+                    if rc != 0:
+                        _lib.check(rc, "fe_step")
+        except Exception as exc:                          # (a capture the runtime refuses: measure eagerly and say so)
+            if args.graph:
+                raise
+            graph, graph_note = None, f"graph capture failed, eager launches timed: {type(exc).__name__}: {exc}"[:300]
         state.copy_(keep)
         torch.cuda.synchronize(dev)
+    if use_dist:                                      # every rank must time the same way
+        gflag = torch.tensor([1 if graph is not None else 0], dtype=torch.int64, device=cdev)
+        dist.all_reduce(gflag, op=dist.ReduceOp.MIN)
+        if int(gflag[0]) == 0 and graph is not None:
+            graph, graph_note = None, "another rank could not capture its graph: eager launches timed on every rank"
 
     # ---- timed region: R consecutive blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both sides and
     # reduced with MAX over the ranks; the MEDIAN block is reported (a single 20-step block is a 0.7 ms sample)
-    def timed_block(first):
+    def timed_block(first, eager=False):
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(stream)
-        if graph is not None:
+        if graph is not None and not eager:
             graph.replay()
         else:
             run(args.steps, first)
@@ -722,11 +745,22 @@ def main():
         torch.cuda.synchronize(dev)
         km = ev0.elapsed_time(ev1) / args.steps       # HIP events on the launch stream: avg per launch
         own = dt_
+        lo_ = dt_
         if use_dist:
-            tt = torch.tensor([dt_, km, enq], dtype=torch.float64, device=cdev)
+            tt = torch.tensor([dt_, km, enq, -dt_], dtype=torch.float64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt_, km, enq = float(tt[0]), float(tt[1]), float(tt[2])
-        return dt_, km, own, enq
+            dt_, km, enq, lo_ = float(tt[0]), float(tt[1]), float(tt[2]), -float(tt[3])
+        return dt_, km, own, enq, lo_                 # (lo_: the fastest rank's time for the block - the spread over the ranks)
+
+    # the eager figure of the same run beside a graph-timed value: one block of K plain launches (state restored afterwards)
+    eager_ms = None
+    if graph is not None:
+        keep = state.clone()
+        timed_block(args.warmup, eager=True)
+        eb = timed_block(args.warmup, eager=True)
+        eager_ms = eb[0] / args.steps * 1e3
+        state.copy_(keep)
+        torch.cuda.synchronize(dev)
 
     blocks = [timed_block(args.warmup)]
     n_blocks = max(1, args.blocks)
@@ -789,6 +823,12 @@ def main():
             "parity_rms_rel": None if parity is None else parity[0], "parity_cache_rms_rel": None if parity is None else parity[1],
             "parity_checker": None if parity is None else f"{parity[2]}, all {B} streams of rank 0, after the timed region",
             "blocks": len(blocks), "statistic": "median of `blocks` consecutive blocks of `steps` steps (max over ranks per block)",
+            # how the K timed steps were issued: one HIP graph of K fe_step launches (the default at world > 1) or K eager launches; with a graph the
+            # eager time of one block of the same run is reported beside it
+            "launch_mode": "hip_graph" if graph is not None else "eager", "graph_note": graph_note, "eager_ms_per_step": eager_ms,
+            # spread over the ranks (fastest / slowest rank's wall time per step): of the median block, and the widest of any block
+            "rank_spread_ms_per_step": {"min": blocks[med][4] / args.steps * 1e3, "max": blocks[med][0] / args.steps * 1e3,
+                                        "widest_block_max_over_min": max(b_[0] / max(b_[4], 1e-12) for b_ in blocks)},
             "min_ms_per_step": min(b_[0] for b_ in blocks) / args.steps * 1e3, "max_ms_per_step": max(b_[0] for b_ in blocks) / args.steps * 1e3,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -803,16 +843,8 @@ def main():
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None if offline else measured_traffic(args.workload, B, T)[0],
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "algorithmic_hbm_bytes_per_launch": alg_bytes,
-                         "kernel": ("fe_offline = tb_enc_kernel + K x (tb_scan_kernel + tb_blk_kernel) + tb_dec_kernel + istft_ola_kernel (kernel_ms: the whole call)"
-                                    if offline and args.offline_engine != "frame_walk" and not (w.get("bsrnn") or w.get("fspen") or w.get("lisennet") or w.get("kt") or w.get("frnn") or w.get("dpt") or w.get("ln")) else
-                                    "lisennet_frame_kernel" if w.get("lisennet") else ("fspen_frame_kernel<PART 1> + fspen_sb_dpe_kernel (16 streams per workgroup) + fspen_frame_kernel<PART 2> (kernel_ms: the step's three launches)"
-                                     if args.frames_per_step == 1 and 0 < int(os.environ.get("FE_FSPEN_SB", "1536")) <= B else "fspen_frame_kernel") if w.get("fspen") else ("bsrnn_frame_kernel<PART 3> + bsrnn_sb_layers_kernel (16 streams per workgroup) + bsrnn_mlp_kernel + bsrnn_frame_kernel<PART 2> (kernel_ms: the step's four launches)"
-                                     if w.get("bsrnn") and args.frames_per_step == 1 and w.get("C") == 16 and 0 < int(os.environ.get("FE_BSRNN_SB", "2048")) <= B else
-                                     "bsrnn_ov_kernel (role-split PART 1, bsrnn_ov_kernels.hip.h) + bsrnn_mlp_kernel + bsrnn_frame_kernel<PART 2> (kernel_ms: the step's three launches)"
-                                     if w.get("bsrnn") and args.frames_per_step == 1 and w.get("C") == 16 and B <= torch.cuda.get_device_properties(dev).multi_processor_count and os.environ.get("FE_BSRNN_OV", "1") != "0" else
-                                     "bsrnn_frame_kernel<PART 1> + bsrnn_mlp_kernel + bsrnn_frame_kernel<PART 2> (kernel_ms: the step's three launches)" if w.get("bsrnn") and args.frames_per_step == 1 else "bsrnn_frame_kernel" if w.get("bsrnn") else
-                                    ("fe_frame8_kernel (512-thread per-hop kernel, fe_frame8.hip.h)" if args.workload == "fe_b" and not offline and T == 1 and B <= torch.cuda.get_device_properties(dev).multi_processor_count
-                                     and os.environ.get("FE_WG8", "1") != "0" else "fe_frame_kernel"))), "kernel_ms": kernel_ms,
+                         # fe_last_step_kernel: the kernels the library dispatched for this call, in launch order (kernel_ms: all of them)
+                         "kernel": kernel_name, "kernel_ms": kernel_ms,
                          "flops_per_frame": eng.flops_per_frame,
                          "hbm_frac": alg_bytes / (kernel_ms * 1e-3) / 8e12},
         }

@@ -45,6 +45,11 @@ SYMBOLS = {
     "fe_set_time_pipeline": (c_int, [c_void_p, c_int]),
     "fe_set_offline_engine": (c_int, [c_void_p, c_int]),
     "fe_set_step_kernel": (c_int, [c_void_p, c_int]),
+    "fe_set_option": (c_int, [c_void_p, c_char_p, c_int]),
+    "fe_get_option": (c_int, [c_void_p, c_char_p, POINTER(c_int)]),
+    "fe_options": (c_int, []),
+    "fe_option_name": (c_char_p, [c_int]),
+    "fe_last_step_kernel": (c_char_p, [c_void_p]),
     "fe_offline_work_floats": (c_size_t, [c_void_p, c_int, c_int]),
     "fe_offline": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fe_offline_ragged_work_floats": (c_size_t, [c_void_p, c_int, c_int]),

@@ -83,10 +83,6 @@ struct BOffsets {
     // r5, num_channels = 16: a layer's fragments regrouped for 16-byte fetches by the role-split PART 1 (bsrnn_ov_kernels.hip.h) - a
     // wave-level load costs the vector-memory path ~16 cycles whatever its width, and a layer is 182 dword fragments per wave
     int ov_t[8];               // time LSTM: [ct][gate][k-step / 4][lane][4]
-    int ov_tb[8];              // its bias: [ct][lane & 15][gate]
-    int ov_f1[8];              // fc_time: [k-step / 4][lane][4]
-    int ov_ip[8][2];           // input projections per direction: [column tile][lane][4 k-steps]
-    int ov_ipb[8][2];          // their bias: [lane & 15][column tile (8)]
     int ov_f2[8];              // fc_freq: [k-step / 4][lane][4]
     int ov_hh[8][2];           // W_hh in the scan's lane order: [row set (2)][k / 4][lane = half * 32 + unit][4]
     // ... and row-major pieces for the TRANSPOSED chains (bands as the N of every product: an accumulator fragment - rows 4 lg + r of lane
@@ -1204,6 +1200,7 @@ struct BImpl {
     // the per-hop step with the layers batched over the streams (bsrnn_sb_kernels.hip.h): front (PART 3) -> layers -> mask-decoder MLP -> tail
     // (PART 2); nullptr where the stream-batched layers are not built (num_channels > 16)
     void (*launch_sb)(const BArgs&, const SbOffsets&, int total_floats, int max_wgs, hipStream_t, hipError_t*);
+    const char* name = nullptr;      // the line of fe_bsrnn_shapes.def (fe_bsrnn_shape.hip.in): part of fe_last_step_kernel's answer
 };
 
 template <class S, bool HOT, bool PROF, bool DBG, bool OCC2 = false>
@@ -1217,6 +1214,8 @@ void blaunch_one(const BArgs& a, int grid, hipStream_t st, hipError_t* err) {
         if (e != hipSuccess) { *err = e; return; }
         attr_set[dev].store(true, std::memory_order_relaxed);
     }
+    note_kernel(DBG ? "bsrnn_frame_kernel<debug>" : PROF ? "bsrnn_frame_kernel<profile>" : HOT ? (OCC2 ? "bsrnn_frame_kernel<per-hop, two workgroups per CU>" : "bsrnn_frame_kernel<per-hop>")
+                    : (OCC2 ? "bsrnn_frame_kernel<generic, two workgroups per CU>" : "bsrnn_frame_kernel<generic>"));
     hipLaunchKernelGGL((bsrnn_frame_kernel<S, HOT, PROF, DBG, OCC2>), dim3(grid), dim3(kThreads), BLds<S>::BYTES, st, a);
     *err = hipGetLastError();
 }
@@ -1251,6 +1250,9 @@ void blaunch_part(const BArgs& a, int grid, hipStream_t st, hipError_t* err) {
         if (e != hipSuccess) { *err = e; return; }
         attr_set[dev].store(true, std::memory_order_relaxed);
     }
+    note_kernel(PART == 1 ? (OCC2 ? "bsrnn_frame_kernel<PART 1, two workgroups per CU>" : "bsrnn_frame_kernel<PART 1>")
+                : PART == 2 ? (OCC2 ? "bsrnn_frame_kernel<PART 2, two workgroups per CU>" : "bsrnn_frame_kernel<PART 2>")
+                : (OCC2 ? "bsrnn_frame_kernel<PART 3, two workgroups per CU>" : "bsrnn_frame_kernel<PART 3>"));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), BLds<S>::BYTES, st, a);
     *err = hipGetLastError();
 }
@@ -1265,10 +1267,10 @@ template <class S>
 void blaunch_split_impl(const BArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
     constexpr bool FITS2 = 2 * BLds<S>::BYTES <= 160 * 1024 && !S::XPG;
     // r5: at most one stream per CU and num_channels = 16 - the role-split PART 1 (bsrnn_ov_kernels.hip.h: the scans alone on two
-    // waves, the layers' matrix-core work under them on the other two).  FE_BSRNN_OV=0: the phase-by-phase kernel, for A/B runs.
-    static const bool ov_on = [] { const char* e = getenv("FE_BSRNN_OV"); return !(e && e[0] == '0'); }();
-    if (S::C == 16 && ov_on && !a.ov_off && a.B <= max_wgs && a.clk != nullptr) blaunch_ov<S, true>(a, a.B, st, err);      // (fe_profile_step with FE_BSRNN_OV_PROF=1)
-    else if (S::C == 16 && ov_on && !a.ov_off && a.B <= max_wgs) blaunch_ov<S>(a, a.B, st, err);
+    // waves, the layers' matrix-core work under them on the other two).  a.ov_off (fe_set_step_kernel(WAVES4) / fe_set_option("bsrnn_role_split", 0)):
+    // the phase-by-phase kernel.
+    if (S::C == 16 && !a.ov_off && a.B <= max_wgs && a.clk != nullptr) blaunch_ov<S, true>(a, a.B, st, err);      // (fe_profile_step with fe_set_option("bsrnn_ov_profile", 1))
+    else if (S::C == 16 && !a.ov_off && a.B <= max_wgs) blaunch_ov<S>(a, a.B, st, err);
     else if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 1>(a, a.B < 2 * max_wgs ? a.B : 2 * max_wgs, st, err);
     else blaunch_part<S, false, 1>(a, a.B < max_wgs ? a.B : max_wgs, st, err);
     if (*err != hipSuccess) return;
@@ -1286,6 +1288,7 @@ void blaunch_split_impl(const BArgs& a, int max_wgs, hipStream_t st, hipError_t*
         const bool msplit = S::C == 16 && a.B <= max_wgs;      // (fewer 64-stream groups than CUs: one sixteen-stream tile per workgroup, column tiles over its waves)
         am.mlp_tpw = msplit ? 0 : 1;
         const int groups = msplit ? (a.B + 15) / 16 : (a.B + 16 * kWaves - 1) / (16 * kWaves);
+        note_kernel(msplit ? "bsrnn_mlp_kernel<one 16-stream tile per workgroup>" : "bsrnn_mlp_kernel");
         hipLaunchKernelGGL(fn, dim3(2 * kBands * groups), dim3(kThreads), BMlpLds<S>::BYTES, st, am);
         *err = hipGetLastError();
         if (*err != hipSuccess) return;
@@ -1308,6 +1311,7 @@ void blaunch_mlp(const BArgs& a, hipStream_t st, hipError_t* err) {
     BArgs am = a;
     am.mlp_tpw = (S::C == 16 && a.B >= 2048) ? 4 : 1;       // (C = 16: KS2 = 16 k-steps = one burst per item, at most five items = the ring)
     const int groups = (a.B + 16 * kWaves * am.mlp_tpw - 1) / (16 * kWaves * am.mlp_tpw);
+    note_kernel(am.mlp_tpw == 4 ? "bsrnn_mlp_kernel<four tiles per wave>" : "bsrnn_mlp_kernel");
     hipLaunchKernelGGL(fn, dim3(2 * kBands * groups), dim3(kThreads), BMlpLds<S>::BYTES, st, am);
     *err = hipGetLastError();
 }
@@ -1343,6 +1347,7 @@ void blaunch_pipe_impl(const BArgs& a, hipStream_t st, hipError_t* err) {
     }
     BArgs args = a;
     void* kargs[] = {&args};
+    note_kernel("bsrnn_frame_kernel<time-pipelined>");
     *err = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(a.B * a.pipe_p), dim3(kThreads), kargs, (unsigned int)BLds<S>::BYTES, st);
 }
 

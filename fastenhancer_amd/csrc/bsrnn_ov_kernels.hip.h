@@ -11,8 +11,8 @@
 //   waves 2, 3   everything on the matrix cores, for two row tiles of bands that are cut by readiness, not by index:
 //                tile A = bands 8..22 (ready after step 22), tile B = bands 0..7 and 23..30 (ready after step 30).  Per tile the chain
 //                fc_freq (layer l) -> x -> time-LSTM gates (layer l + 1) -> fc_time -> input projections of layer l + 1.  Tile A's chain
-//                up to its x runs under steps 23..30 of layer l's scans and its projections under steps 0..7 of layer l + 1's (bands
-//                8..22 are not read before step 8); only tile B's chain is serial with the scans, and the scan waves - idle by then -
+//                up to its x runs under steps 23..30 of layer l's scans and its projections under steps 0..6 of layer l + 1's (bands
+//                8..22 are not fetched before step 7: a step fetches the next step's projections); only tile B's chain is serial with the scans, and the scan waves - idle by then -
 //                take half of its projections.  The h half of the time-LSTM gates (W_hh h_{t-1}: known since the last frame) is
 //                accumulated under the early steps.  Layer 0's time part runs on all four waves (tile A on waves 0, 1).
 // Every product of a chain is computed TRANSPOSED, the sixteen bands of a tile as its N: the accumulator fragment of one product is the B
@@ -60,7 +60,9 @@ __device__ __forceinline__ void ov_wait(int* flag, int v) {
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
     int spins = 0;
     while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < v) {
-        if (++spins > (1 << 22)) __builtin_trap();        // (a partner that never arrives: fail the launch loudly)
+        // a partner that never arrives fails the launch instead of hanging the device - but only after ~2^30 polls (minutes): a debugger, a
+        // page-fault / XNACK stall on first touch of the weights or a preempted queue must not trip it (2^22 polls were 0.1-0.2 s)
+        if (++spins > (1 << 30)) __builtin_trap();
     }
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
 }
@@ -468,9 +470,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
                     yo += yd;
                 }
             };
-            steps(0, 8);
-            if (l > 0) ov_wait(f_xpa + d, l + 1);                       // bands 8..22 come next: tile A's projections (normally long there)
-            steps(8, 23);
+            // bands 8..22 belong to tile A, whose projections have a ready counter of their own.  A step FETCHES the next step's projections
+            // (xp_next), so the wait sits before step 7 - the first one that touches a tile A row - not before step 8 (with the wait
+            // after step 7 its fetch of band 8 / 22 was ordered before the wait and could read the buffer's contents of two layers ago)
+            steps(0, 7);
+            if (l > 0) ov_wait(f_xpa + d, l + 1);                       // (normally long there: the helpers compute them under steps 0..6)
+            steps(7, 23);
             if (lane == 0) ov_signal(f_prog + d, 32 * l + 23);
             if (l == 0) OV_CLK(3);
             steps(23, kBands);
@@ -506,7 +511,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             ov_wait(f_prog + 1, 32 * l + 23);
             if (l == 0) xr[0] = *reinterpret_cast<const f32x4*>(XT + lane * 4);      // (tile A's x after layer 0's time part was computed by the scan waves)
             if (l == 0) OV_CLK(4);
-            // tile A up to its x after fc_time: its projections are not needed before step 8 of the next layer's scans and wait until
+            // tile A up to its x after fc_time: its projections are not fetched before step 7 of the next layer's scans and wait until
             // tile B's chain - the only serial piece - is through
             if (more) chain(TA{}, std::true_type{}, std::true_type{}, std::false_type{}, std::false_type{}, l + 1, xpn, 0);
             else chain(TA{}, std::true_type{}, std::false_type{}, std::false_type{}, std::false_type{}, l + 1, xpn, 0);
@@ -519,7 +524,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             else chain(TB{}, std::true_type{}, std::false_type{}, std::false_type{}, std::false_type{}, l + 1, xpn, 0);
             if (more && lane == 0) ov_signal(f_xpd + ct, l + 2);
             if (more) {
-                proj(TA{}, I0{}, I4{}, xpn, xr[0]);            // under steps 0..7 of layer l + 1's scans
+                proj(TA{}, I0{}, I4{}, xpn, xr[0]);            // under steps 0..6 of layer l + 1's scans
                 if (lane == 0) ov_signal(f_xpa + ct, l + 2);
             }
             if (l == 0) OV_CLK(7);
@@ -551,6 +556,7 @@ void blaunch_ov(const BArgs& a, int grid, hipStream_t st, hipError_t* err) {
             if (e != hipSuccess) { *err = e; return; }
             attr_set[dev].store(true, std::memory_order_relaxed);
         }
+        note_kernel(PROF ? "bsrnn_ov_kernel<profile>" : "bsrnn_ov_kernel");
         hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), BOvLds<S>::BYTES, st, a);
         *err = hipGetLastError();
     } else {

@@ -323,6 +323,7 @@ void sb_launch_layers(const SbArgs& a, hipStream_t st, hipError_t* err) {
             if (*err != hipSuccess) return;
             attr_set[dev].store(true, std::memory_order_relaxed);
         }
+        note_kernel("bsrnn_sb_layers_kernel");
         hipLaunchKernelGGL(fn, dim3((a.B + kSbStreams - 1) / kSbStreams), dim3(kSbThreads), SbLds<S>::BYTES, st, a);
         *err = hipGetLastError();
     } else {

@@ -19,9 +19,42 @@
 #include "lisennet_kernels.hip.h"
 #include "stft_kernels.hip.h"
 
+// fe_last_step_kernel: the launchers (per-shape translation units included) name what they enqueue; a compute entry point
+// clears the log when it starts and leaves it in its handle when it returns (KernelLogScope)
+namespace fe {
+namespace {
+struct KernelLog { const char* name[16]; int n; };
+thread_local KernelLog g_klog{};
+}
+void note_kernel(const char* name) {
+    if (g_klog.n < 16) g_klog.name[g_klog.n] = name;
+    if (g_klog.n < 17) ++g_klog.n;           // (17: more than the log holds)
+}
+}  // namespace fe
+
 namespace {
 
 thread_local std::string g_err;
+
+// fe_set_option / fe_get_option.  `env`: the environment variable that sets the value NEW handles start with (A/B scripts under tools/);
+// out-of-range or non-numeric values are ignored.
+enum { OPT_BSRNN_ROLE_SPLIT = 0, OPT_BSRNN_SB_MIN, OPT_BSRNN_THREE_LAUNCH, OPT_BSRNN_OV_PROFILE, OPT_FSPEN_SB_MIN, OPT_LOW_LDS_COMPANION, OPT_COUNT };
+struct OptionDef { const char* name; const char* env; int dflt, lo, hi; };
+constexpr OptionDef kOptions[OPT_COUNT] = {
+    {"bsrnn_role_split", "FE_BSRNN_OV", 1, 0, 1},
+    {"bsrnn_stream_batch_min", "FE_BSRNN_SB", 2048, 0, 1 << 24},
+    {"bsrnn_three_launch_step", "FE_BSRNN_SPLIT", 1, 0, 1},
+    {"bsrnn_ov_profile", "FE_BSRNN_OV_PROF", 0, 0, 1},
+    {"fspen_stream_batch_min", "FE_FSPEN_SB", 1536, 0, 1 << 24},
+    {"low_lds_companion", "FE_LOWLDS", 1, 0, 1},
+};
+int env_int(const char* name, int dflt, int lo, int hi) {
+    const char* e = std::getenv(name);
+    if (!e || !*e) return dflt;
+    char* end = nullptr;
+    const long v = std::strtol(e, &end, 10);
+    return (end && *end == 0 && v >= lo && v <= hi) ? (int)v : dflt;
+}
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -117,9 +150,19 @@ struct fe_handle {
     int max_wgs = 256;             // CUs of the device: one resident workgroup per CU (persistent grid above that)
     int pipe_frames = -1;          // fe_set_time_pipeline (-1: chosen from the model size)
     int offline_engine = FE_OFFLINE_AUTO;     // fe_set_offline_engine
-    // fe_set_step_kernel; FE_WG8=0|1|2 overrides the default for A/B runs (anything else, garbage included, is ignored)
-    int step_kernel = [] { const char* e = std::getenv("FE_WG8");
-                           return (e && e[0] >= '0' && e[0] <= '0' + FE_STEP_KERNEL_WG8_PERSIST && !e[1]) ? e[0] - '0' : FE_STEP_KERNEL_WG8; }();
+    // fe_set_step_kernel / fe_set_option: which kernel a step dispatches.  The environment variables named in kOptions set the values NEW handles start
+    // with (A/B runs of tools/ab_*.sh; a value outside the option's range, garbage included, is ignored) - nothing else in the library reads them.
+    int step_kernel = FE_STEP_KERNEL_WG8;
+    int opt[8] = {};                          // kOptions order
+    const char* last_kernels[16] = {};        // fe_last_step_kernel: what the last compute call enqueued (string literals of the launchers)
+    int n_last_kernels = 0;
+    const char* last_shape = nullptr;         // ... and the compiled shape record that launched it
+    mutable std::string last_text;
+    fe_handle() {
+        for (int i = 0; i < OPT_COUNT; ++i) opt[i] = env_int(kOptions[i].env, kOptions[i].dflt, kOptions[i].lo, kOptions[i].hi);
+        if (std::getenv("FE_NO_LOWLDS")) opt[OPT_LOW_LDS_COMPANION] = 0;      // (the older spelling tools/ab_lowlds.sh uses)
+        step_kernel = env_int("FE_WG8", FE_STEP_KERNEL_WG8, FE_STEP_KERNEL_WAVES4, FE_STEP_KERNEL_WG8_PERSIST);
+    }
     unsigned int* pipe_flags_dev = nullptr;   // fe_spec_step's frame counters [max_wgs][KB] (fe_offline keeps its own in the work buffer)
     std::vector<hipStream_t> tb_streams;      // time-batched engine: the streams its nodes are spread over (lazy; tb_run)
     std::vector<hipEvent_t> tb_events;        // ... and its event pool
@@ -144,6 +187,20 @@ struct fe_handle {
 };
 
 namespace {
+
+// what a compute entry point enqueues ends up in its handle (fe_last_step_kernel)
+struct KernelLogScope {
+    fe_handle* h;
+    explicit KernelLogScope(fe_handle* h_) : h(h_) {
+        fe::g_klog.n = 0;
+        h->last_shape = h->impl ? h->impl->name : h->bimpl ? h->bimpl->name : h->fimpl ? "fspen" : h->limpl ? "lisennet" : nullptr;
+    }
+    ~KernelLogScope() {
+        if (!h) return;
+        h->n_last_kernels = fe::g_klog.n;
+        std::memcpy(h->last_kernels, fe::g_klog.name, sizeof(h->last_kernels));
+    }
+};
 
 void add_section(fe_handle* h, const std::string& name, std::vector<int> shape) {
     size_t n = 1;
@@ -451,6 +508,7 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
             auto shared = [&](int t) { return t < 3 * NG && t % 3 < 2; };      // pure r / z tile: x and h halves in one accumulator
             pack_u8(o.u8_gx[k], NT, wih, grow, [&](int t, int c) { const int r = grow(t, c); return bih[r] + (shared(t) ? bhh[r] : 0.0f); }, gscale);
             pack_u8(o.u8_gh[k], NT, whh, grow, [&](int t, int c) { const int r = grow(t, c); return shared(t) ? 0.0f : bhh[r]; }, gscale);
+#if FE_WG8_HPRE
             {   // ... and regrouped four k-steps per lane for the front-of-frame W_hh h products (PackedOffsets::u8_gh4)
                 const int NQ = KS / 4, KR = KS % 4, TS = NQ * 256 + KR * 64;
                 for (int t = 0; t < NT; ++t)
@@ -462,6 +520,7 @@ int pack_weights(fe_handle* h, const std::vector<float>& blob, std::vector<float
                             p.buf[(size_t)o.u8_gh4[k] + (size_t)t * TS + NQ * 256 + r * 64 + lane] = p.buf[(size_t)o.u8_gh[k] + ((size_t)t * KS + 4 * NQ + r) * 64 + lane];
                     }
             }
+#endif
             auto plain = [&](int ncols) { return [ncols](int t, int c) { return 16 * t + c < ncols ? 16 * t + c : -1; }; };
             const float* f1b = S(key("rnn_fc.bias"));
             const float* f2b = S(key("attn_fc.bias"));
@@ -694,8 +753,7 @@ size_t bsplit_floats_per_stream(const fe_handle* h) {
 }
 int ensure_bsplit(fe_handle* h, int B) {
     if (!h->bimpl || B <= h->bsplit_streams) return FE_OK;
-    static const bool off = [] { const char* e = getenv("FE_BSRNN_SPLIT"); return e && e[0] == '0'; }();
-    if (off) return FE_OK;
+    if (!h->opt[OPT_BSRNN_THREE_LAUNCH]) return FE_OK;
     if (h->bsplit_dev) { FE_HIP_CHECK(hipFree(h->bsplit_dev)); h->bsplit_dev = nullptr; h->bsplit_streams = 0; }
     FE_HIP_CHECK(hipMalloc(&h->bsplit_dev, (size_t)B * bsplit_floats_per_stream(h) * sizeof(float)));
     h->bsplit_streams = B;
@@ -705,9 +763,10 @@ int ensure_bsplit(fe_handle* h, int B) {
 int launch_bsrnn(fe_handle* h, const fe::BArgs& a_in, void* stream) {
     hipError_t e = hipSuccess;
     fe::BArgs a = a_in;
-    a.ov_off = h->step_kernel == FE_STEP_KERNEL_WAVES4 ? 1 : 0;
-    // (FE_BSRNN_OV_PROF=1: fe_profile_step probes the role-split PART 1 of the three-launch step instead of the fused kernel's phases)
-    static const bool ov_prof = [] { const char* e = getenv("FE_BSRNN_OV_PROF"); return e && e[0] == '1'; }();
+    a.ov_off = (h->step_kernel == FE_STEP_KERNEL_WAVES4 || !h->opt[OPT_BSRNN_ROLE_SPLIT]) ? 1 : 0;
+    // (fe_set_option("bsrnn_ov_profile", 1): fe_profile_step probes the role-split PART 1 of the three-launch step instead of the fused kernel's phases)
+    const bool ov_prof = h->opt[OPT_BSRNN_OV_PROFILE] != 0;
+    h->last_shape = h->bimpl->name;
     if (a.mode == fe::FE_MODE_STREAM && a.T == 1 && a.dbg == nullptr && (a.clk == nullptr || (ov_prof && h->cfg.channels == 16 && a.B <= h->max_wgs))) {
         const int rc = ensure_bsplit(h, a.B);
         if (rc != FE_OK) return rc;
@@ -718,7 +777,7 @@ int launch_bsrnn(fe_handle* h, const fe::BArgs& a_in, void* stream) {
             a.sb_y = a.mlp_pre + (size_t)a.B * 2 * 1028;
             // large batches: the LSTM layers batched over the streams on the matrix cores (sixteen streams per workgroup) - from the batch
             // size where sixteen-stream workgroups fill the chip better than one stream per workgroup (FE_BSRNN_SB: that threshold; 0 = never)
-            static const int sb_min = [] { const char* v = getenv("FE_BSRNN_SB"); return v ? atoi(v) : 2048; }();      // (measured crossover on 256 CUs: ~1900 streams, profiles/r4c_bsrnn_stream_batched.txt)
+            const int sb_min = h->opt[OPT_BSRNN_SB_MIN];      // (default 2048; measured crossover on 256 CUs: ~1900 streams, profiles/r4c_bsrnn_stream_batched.txt)
             if (h->bimpl->launch_sb && sb_min > 0 && a.B >= sb_min) h->bimpl->launch_sb(a, h->sboff, h->packed_floats, h->max_wgs, (hipStream_t)stream, &e);
             else
             h->bimpl->launch_split(a, h->max_wgs, (hipStream_t)stream, &e);
@@ -888,7 +947,7 @@ int fe_create(const fe_config* cfg, fe_handle** out) {
     fe_handle* h = new fe_handle();
     h->cfg = *cfg;
     h->impl = impl;
-    h->impl_many = std::getenv("FE_NO_LOWLDS") ? nullptr : impl_many;      // (FE_NO_LOWLDS: A/B switch of tools/ab_lowlds.sh)
+    h->impl_many = impl_many;              // (fe_set_option("low_lds_companion", 0) keeps run_step off it)
     h->d = Dims{impl->C1, impl->NL, impl->C2, impl->F2, impl->KB, impl->NFFT, impl->HOP, impl->NFFT / 2, impl->NFFT / 8, impl->C2 / 4, {0}};
     h->d.KT = impl->KT;
     h->d.FR = impl->FR;
@@ -1000,6 +1059,7 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
                     int B, int T, float* dbg, unsigned long long* clk, void* stream) {
     int rc = check_ready(h);
     if (rc != FE_OK) return rc;
+    KernelLogScope klog_(h);
     if (!wav_in || !state || !wav_out || B <= 0 || T <= 0) return fail(FE_ERR_INVALID_ARG, "bad argument");
     const Dims& d = h->d;
     if (in_stride < (size_t)T * d.HOP && B > 1) return fail(FE_ERR_INVALID_ARG, "in_stride %zu < T*H", in_stride);
@@ -1058,9 +1118,10 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
     // per-hop launches above #CUs streams: the low-LDS companion (two workgroups per CU; same packed weights - Pack<S> does
     // not depend on LOW), where one is compiled and measured faster
     const fe::Impl* im = h->impl;
-    if (h->impl_many && T == 1 && B > h->max_wgs && (h->impl_many->many_persist || B <= h->max_wgs * h->impl_many->occ) && !dbg && !clk &&
+    if (h->impl_many && h->opt[OPT_LOW_LDS_COMPANION] && T == 1 && B > h->max_wgs && (h->impl_many->many_persist || B <= h->max_wgs * h->impl_many->occ) && !dbg && !clk &&
         !(h->step_kernel == FE_STEP_KERNEL_WG8_PERSIST && h->impl->wg8))
         im = h->impl_many;
+    h->last_shape = im->name;
     im->launch(a, h->max_wgs, (hipStream_t)stream, &e);
     if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return FE_OK;
@@ -1185,6 +1246,7 @@ static bool use_tb_spec(const fe_handle* h, int B, int T) {
 int fe_spec_step(fe_handle* h, const float* spec_in_dev, float* h_dev, float* spec_out_dev, int B, int T, void* stream) {
     int rc = check_ready(h);
     if (rc != FE_OK) return rc;
+    KernelLogScope klog_(h);
     if (!spec_in_dev || !h_dev || !spec_out_dev || B <= 0 || T <= 0) return fail(FE_ERR_INVALID_ARG, "bad argument");
     if (h->limpl) {
         fe::LArgs la = lisennet_args(h, B, T);
@@ -1436,6 +1498,46 @@ int fe_set_step_kernel(fe_handle* h, int kernel) {
     return FE_OK;
 }
 
+int fe_set_option(fe_handle* h, const char* name, int value) {
+    if (!h || !name) return fail(FE_ERR_INVALID_ARG, "null argument");
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (std::strcmp(name, kOptions[i].name) == 0) {
+            if (value < kOptions[i].lo || value > kOptions[i].hi)
+                return fail(FE_ERR_INVALID_ARG, "fe_set_option(%s): %d is outside [%d, %d]", name, value, kOptions[i].lo, kOptions[i].hi);
+            h->opt[i] = value;
+            return FE_OK;
+        }
+    return fail(FE_ERR_INVALID_ARG, "fe_set_option: no option named '%s'", name);
+}
+
+int fe_get_option(const fe_handle* h, const char* name, int* value) {
+    if (!h || !name || !value) return fail(FE_ERR_INVALID_ARG, "null argument");
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (std::strcmp(name, kOptions[i].name) == 0) { *value = h->opt[i]; return FE_OK; }
+    return fail(FE_ERR_INVALID_ARG, "fe_get_option: no option named '%s'", name);
+}
+
+int fe_options(void) { return OPT_COUNT; }
+const char* fe_option_name(int idx) { return idx >= 0 && idx < OPT_COUNT ? kOptions[idx].name : nullptr; }
+
+const char* fe_last_step_kernel(const fe_handle* h) {
+    if (!h) return "";
+    std::string& s = h->last_text;
+    s.clear();
+    const int n = h->n_last_kernels < 16 ? h->n_last_kernels : 16;
+    for (int i = 0; i < n;) {
+        int j = i;
+        while (j < n && h->last_kernels[j] == h->last_kernels[i]) ++j;
+        if (!s.empty()) s += " + ";
+        if (j - i > 1) s += std::to_string(j - i) + " x ";
+        s += h->last_kernels[i];
+        i = j;
+    }
+    if (h->n_last_kernels > 16) s += " + ...";
+    if (!s.empty() && h->last_shape) s += std::string(" [shape ") + h->last_shape + "]";
+    return s.c_str();
+}
+
 int fe_set_offline_engine(fe_handle* h, int engine) {
     if (!h || engine < FE_OFFLINE_AUTO || engine > FE_OFFLINE_TIME_BATCHED) return fail(FE_ERR_INVALID_ARG, "bad argument");
     if (engine == FE_OFFLINE_TIME_BATCHED && !(h->impl && h->impl->tb)) return fail(FE_ERR_UNSUPPORTED_CONFIG, "no time-batched engine is compiled for this model");
@@ -1465,7 +1567,8 @@ static int offline_tb(fe_handle* h, const float* noisy_dev, size_t in_stride, co
     tb_work_floats(h, B, T, off);
     a.frames = work_dev + off[5];
     const int n_out = d.HOP * (T - 1);
-    hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
+    fe::note_kernel("istft_ola_kernel");
+        hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
                        a.frames, h->tables_dev, wav_hat_dev, out_stride, d.NFFT, d.HOP, T, Tw_b_dev);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
@@ -1516,6 +1619,7 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
                void* stream) {
     int rc = check_ready(h);
     if (rc != FE_OK) return rc;
+    KernelLogScope klog_(h);
     if (!noisy_dev || !wav_hat_dev || !spec_hat_dev || !work_dev || B <= 0) return fail(FE_ERR_INVALID_ARG, "bad argument");
     const Dims& d = h->d;
     if (Tw <= d.NFFT / 2)   // torch.stft reflect padding needs pad < length
@@ -1559,7 +1663,8 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
                 h->limpl->launch_pipe(la, st, &e);
                 if (e == hipSuccess) {
                     const int n_out = d.HOP * (T - 1);
-                    hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
+                    fe::note_kernel("istft_ola_kernel");
+        hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
                                        la.frames, h->tables_dev, wav_hat_dev, (size_t)n_out, d.NFFT, d.HOP, T);
                     e = hipGetLastError();
                     if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
@@ -1597,7 +1702,8 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
                 h->fimpl->launch_pipe(fa, st, &e);
                 if (e == hipSuccess) {
                     const int n_out = d.HOP * (T - 1);
-                    hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
+                    fe::note_kernel("istft_ola_kernel");
+        hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
                                        fa.frames, h->tables_dev, wav_hat_dev, (size_t)n_out, d.NFFT, d.HOP, T);
                     e = hipGetLastError();
                     if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
@@ -1630,7 +1736,8 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
             h->bimpl->launch_pipe(ba, st, &e);
             if (e == hipSuccess) {
                 const int n_out = d.HOP * (T - 1);
-                hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
+                fe::note_kernel("istft_ola_kernel");
+        hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
                                    ba.frames, h->tables_dev, wav_hat_dev, (size_t)n_out, d.NFFT, d.HOP, T);
                 e = hipGetLastError();
                 if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
@@ -1681,6 +1788,7 @@ int fe_offline(fe_handle* h, const float* noisy_dev, int B, int Tw, float* wav_h
             return FE_OK;
         }
         const int n_out = d.HOP * (T - 1);
+        fe::note_kernel("istft_ola_kernel");
         hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
                            a.frames, h->tables_dev, wav_hat_dev, (size_t)n_out, d.NFFT, d.HOP, T);
         e = hipGetLastError();
@@ -1753,6 +1861,7 @@ int fe_offline_ragged(fe_handle* h, const float* noisy_dev, size_t in_stride, co
                       float* spec_hat_dev, float* work_dev, void* stream) {
     int rc = check_ready(h);
     if (rc != FE_OK) return rc;
+    KernelLogScope klog_(h);
     if (!noisy_dev || !Tw_host || !wav_hat_dev || !spec_hat_dev || !work_dev || B <= 0) return fail(FE_ERR_INVALID_ARG, "bad argument");
     const Dims& d = h->d;
     int Tw_max = 0;
@@ -1842,7 +1951,8 @@ int fe_istft_offline(fe_handle* h, const float* spec_in_dev, int B, int T, int F
     a.compression = compress ? h->cfg.input_compression : 1.0f;
     FE_STFT_LAUNCH(istft_frames_kernel, a, dim3(T, B), st);
     const int n_out = H * (T - 1);
-    hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
+    fe::note_kernel("istft_ola_kernel");
+        hipLaunchKernelGGL(fe::istft_ola_kernel, dim3((n_out + fe::kThreads - 1) / fe::kThreads, B), dim3(fe::kThreads), 0, st,
                        frames_dev, h->tables_dev, wav_out_dev, (size_t)n_out, N, H, T);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FE_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));

@@ -32,9 +32,7 @@ namespace fe {
 // front grows by 7.4 k cycles (operand fetches of three blocks: +4.9 k before the first phase, DFT phase +1.3 k, enc_pre +1.2 k) and a
 // block's GRU phase shrinks by 0.67 k instead of 1.15 k - its GEMM, now on ONE wave per SIMD, runs at 57 cycles per MFMA (LDS operand
 // latency that the second wave of a SIMD used to cover).
-#ifndef FE_WG8_HPRE
-#define FE_WG8_HPRE 0
-#endif
+// (FE_WG8_HPRE defaults to 0 in fe_kernels.hip.h: the packed section u8_gh4 exists in such builds only)
 constexpr int kThreads8 = 512;
 constexpr int kWaves8 = 8;
 

@@ -29,7 +29,17 @@ struct Impl {
     void (*launch)(const FrameArgs&, int max_wgs, hipStream_t, hipError_t*);
     void (*launch_pipe)(const FrameArgs&, hipStream_t, hipError_t*);     // time-pipelined offline / spec launch (a.pipe_p workgroups per stream)
     void (*dbg_stage)(int, int*, int*, size_t*);
+    const char* name = nullptr;      // the line of fe_shapes.def this record was compiled from (fe_shape.hip.in): part of fe_last_step_kernel's answer
 };
+
+// the instantiation a launcher picked, as fe_last_step_kernel reports it
+template <class S>
+constexpr const char* frame_kernel_name(bool dbg, bool per_hop, bool persist) {
+    if (dbg) return S::LOW == 2 ? "fe_frame_kernel<LOW=2, debug>" : S::LOW == 1 ? "fe_frame_kernel<LOW=1, debug>" : "fe_frame_kernel<debug>";
+    if (per_hop && !persist) return S::LOW == 2 ? "fe_frame_kernel<LOW=2, per-hop>" : S::LOW == 1 ? "fe_frame_kernel<LOW=1, per-hop>" : "fe_frame_kernel<per-hop>";
+    if (per_hop) return S::LOW == 2 ? "fe_frame_kernel<LOW=2, per-hop, persistent>" : S::LOW == 1 ? "fe_frame_kernel<LOW=1, per-hop, persistent>" : "fe_frame_kernel<per-hop, persistent>";
+    return S::LOW == 2 ? "fe_frame_kernel<LOW=2, generic>" : S::LOW == 1 ? "fe_frame_kernel<LOW=1, generic>" : "fe_frame_kernel<generic>";
+}
 
 template <class S, bool DBG, int MODE, bool T1, bool PERSIST>
 void launch_one(const FrameArgs& a, int grid_x, hipStream_t st, hipError_t* err) {
@@ -45,6 +55,7 @@ void launch_one(const FrameArgs& a, int grid_x, hipStream_t st, hipError_t* err)
         attr_set[dev].store(true, std::memory_order_relaxed);
     }
     dim3 grid(grid_x), block(kThreads);
+    note_kernel(frame_kernel_name<S>(DBG, T1, PERSIST));
     hipLaunchKernelGGL((fe_frame_kernel<S, DBG, MODE, T1, PERSIST>), grid, block, Lds<S>::BYTES, st, a);
     *err = hipGetLastError();
 }
@@ -64,6 +75,7 @@ void launch_one8(const FrameArgs& a, int grid_x, hipStream_t st, hipError_t* err
         attr_set[dev].store(true, std::memory_order_relaxed);
     }
     dim3 grid(grid_x), block(kThreads8);
+    note_kernel(DBG ? "fe_frame8_kernel<debug>" : PERSIST ? "fe_frame8_kernel<persistent>" : "fe_frame8_kernel");
     hipLaunchKernelGGL((fe_frame8_kernel<S, DBG, PERSIST>), grid, block, Wg8<S>::BYTES, st, a);
     *err = hipGetLastError();
 }
@@ -118,6 +130,7 @@ void launch_pipe_impl(const FrameArgs& a, hipStream_t st, hipError_t* err) {
     }
     FrameArgs args = a;
     void* kargs[] = {&args};
+    note_kernel("fe_frame_kernel<time-pipelined>");
     *err = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(a.B * a.pipe_p), dim3(kThreads), kargs, (unsigned int)Lds<S>::BYTES, st);
     }
 }

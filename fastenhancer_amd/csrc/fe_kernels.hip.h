@@ -34,6 +34,16 @@ constexpr int FE_MODE_STREAM = 0, FE_MODE_SPEC = 1, FE_MODE_OFFLINE = 2;
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
 
+// FE_WG8_HPRE=1: a measured-negative variant of the 512-thread per-hop kernel (fe_frame8.hip.h, profiles/r5_headline_hpre.txt); its extra packed
+// section (PackedOffsets::u8_gh4) exists in such builds only
+#ifndef FE_WG8_HPRE
+#define FE_WG8_HPRE 0
+#endif
+
+// fe_last_step_kernel (C ABI, r6): every host-side launcher names the kernel it enqueues (a string literal: family + instantiation);
+// the compute entry points of fe_api.hip collect the names of one call in the handle.  Defined in fe_api.hip (thread-local log).
+void note_kernel(const char* name);
+
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{})
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
@@ -280,8 +290,10 @@ struct Pack {
                 o.u8_q[k] = cur; cur += S::U8_Q;
                 o.u8_f2[k] = cur; cur += S::U8_F;
             }
+#if FE_WG8_HPRE
         if (S::G8P)
             for (int k = 0; k < S::KB; ++k) { cur = round_up(cur, 256); o.u8_gh4[k] = cur; cur += S::U8_GH4; }
+#endif
         o.conv_k4_delta = 0;
         if (S::KT == 1 && !S::LN) {     // (allocated after everything else: every other offset is the same with and without it; NOT a function of LOW: a companion shares its shape's buffer)
             // r4w: the time-batched engine's conv GEMMs stream their weight fragments from L2 - one wave-level load per (tile, k-step) kept the

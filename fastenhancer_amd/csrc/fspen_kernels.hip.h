@@ -1199,6 +1199,7 @@ template <class S>
 void flaunch_pipe_impl(const FArgs& a, hipStream_t st, hipError_t* err) {
     FArgs args = a;
     void* kargs[] = {&args};
+    note_kernel("fspen_frame_kernel<time-pipelined>");
     *err = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&fspen_frame_kernel<S, false, false, true>), dim3(a.B * a.pipe_p), dim3(kThreads), kargs, 0, st);
 }
 
@@ -1208,6 +1209,7 @@ void flaunch_impl(const FArgs& a, int max_wgs, hipStream_t st, hipError_t* err) 
     constexpr int OCC = OCC_LDS < FS_WPE ? OCC_LDS : FS_WPE;
     const int slots = max_wgs * OCC;
     const int grid = a.B < slots ? a.B : slots;                    // more streams than slots: persistent workgroups walk b, b + grid, ...
+    note_kernel(a.dbg != nullptr ? "fspen_frame_kernel<debug>" : a.clk != nullptr ? "fspen_frame_kernel<profile>" : "fspen_frame_kernel");
     if (a.dbg != nullptr) hipLaunchKernelGGL((fspen_frame_kernel<S, false, true>), dim3(grid), dim3(kThreads), 0, st, a);
     else if (a.clk != nullptr) hipLaunchKernelGGL((fspen_frame_kernel<S, true, false>), dim3(grid), dim3(kThreads), 0, st, a);
     else hipLaunchKernelGGL((fspen_frame_kernel<S, false, false>), dim3(grid), dim3(kThreads), 0, st, a);
@@ -1222,10 +1224,12 @@ void flaunch_sb_impl(const FArgs& a, int max_wgs, hipStream_t st, hipError_t* er
     const int grid = a.B < slots ? a.B : slots;
     constexpr int OCC_F_LDS = (160 * 1024) / (FLds::FRONT_TOTAL * 4);
     const int slots_f = max_wgs * (OCC_F_LDS < FS_WPE_FRONT ? OCC_F_LDS : FS_WPE_FRONT);
+    note_kernel("fspen_frame_kernel<PART 1>");
     hipLaunchKernelGGL((fspen_frame_kernel<S, false, false, false, 1>), dim3(a.B < slots_f ? a.B : slots_f), dim3(kThreads), 0, st, a);
     FSbArgs sa{a.wp, a.carry, a.tok, a.carry + (size_t)a.B * FCarry::FLOATS, a.gru, a.B, a.clk};
     *err = fspen_sb_launch<S>(sa, st);
     if (*err != hipSuccess) return;
+    note_kernel("fspen_frame_kernel<PART 2>");
     hipLaunchKernelGGL((fspen_frame_kernel<S, false, false, false, 2>), dim3(grid), dim3(kThreads), 0, st, a);
     *err = hipGetLastError();
 }

@@ -657,6 +657,7 @@ hipError_t fspen_sb_launch(const FSbArgs& a, hipStream_t st) {
         attr_set[dev].store(true, std::memory_order_relaxed);
     }
     const int grid = (a.B + kFsbStreams - 1) / kFsbStreams;
+    note_kernel("fspen_sb_dpe_kernel");
     hipLaunchKernelGGL(fspen_sb_dpe_kernel<S>, dim3(grid), dim3(kFsbThreads), FSbLds::BYTES, st, a);
     return hipGetLastError();
 }

@@ -915,6 +915,7 @@ template <class S>
 void llaunch_pipe_impl(const LArgs& a, hipStream_t st, hipError_t* err) {
     LArgs args = a;
     void* kargs[] = {&args};
+    note_kernel("lisennet_frame_kernel<time-pipelined>");
     *err = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&lisennet_frame_kernel<S, false, false, true>), dim3(a.B * a.pipe_p), dim3(kThreads), kargs, 0, st);
 }
 
@@ -924,6 +925,7 @@ void llaunch_impl(const LArgs& a, int max_wgs, hipStream_t st, hipError_t* err) 
     constexpr int OCC = OCC_LDS < 2 ? OCC_LDS : 2;                 // (256 VGPRs per wave: two workgroups per CU)
     const int slots = max_wgs * OCC;
     const int grid = a.B < slots ? a.B : slots;
+    note_kernel(a.dbg != nullptr ? "lisennet_frame_kernel<debug>" : a.clk != nullptr ? "lisennet_frame_kernel<profile>" : "lisennet_frame_kernel");
     if (a.dbg != nullptr) hipLaunchKernelGGL((lisennet_frame_kernel<S, false, true>), dim3(grid), dim3(kThreads), 0, st, a);
     else if (a.clk != nullptr) hipLaunchKernelGGL((lisennet_frame_kernel<S, true, false>), dim3(grid), dim3(kThreads), 0, st, a);
     else hipLaunchKernelGGL((lisennet_frame_kernel<S, false, false>), dim3(grid), dim3(kThreads), 0, st, a);

@@ -1683,6 +1683,7 @@ void tb_launch(int stage, const TbArgs& a, int max_wgs, hipStream_t st, hipError
         constexpr size_t lds = EncLds<S, C::FT_E>::BYTES;
         set_lds(k, lds, err);
         if (*err != hipSuccess) return;
+        note_kernel("tb_enc_kernel");
         hipLaunchKernelGGL(k, dim3(grid_for(C::FT_E, lds)), dim3(kThreads), lds, st, a);
     } else if (stage == TB_SCAN) {
         // 16 rows per workgroup when that fills the chip (the MFMA throughput of the 16x16x4 tiles is what counts then), else 4
@@ -1690,7 +1691,9 @@ void tb_launch(int stage, const TbArgs& a, int max_wgs, hipStream_t st, hipError
         const int wg16 = ((a.B * S::F2 + 15) / 16) * S::ND;
         const int wg4 = (a.B * S::F2 / 4) * S::ND;
         (void)wg16;
-        if (force == 16 || (force != 4 && 4 * wg4 > 5 * max_wgs))        // (two 4-row workgroups on a CU take turns on its SIMDs: no gain beyond ~1 per CU)
+        const bool rows16 = force == 16 || (force != 4 && 4 * wg4 > 5 * max_wgs);      // (two 4-row workgroups on a CU take turns on its SIMDs: no gain beyond ~1 per CU)
+        note_kernel(rows16 ? "tb_scan_kernel" : "tb_scan4_kernel");
+        if (rows16)
             hipLaunchKernelGGL((tb_scan_kernel<S>), dim3((a.B * S::F2 + 15) / 16, S::ND), dim3(kThreads), 0, st, a);
         else
             hipLaunchKernelGGL((tb_scan4_kernel<S>), dim3(a.B * S::F2 / 4, S::ND), dim3(kThreads), 0, st, a);
@@ -1714,6 +1717,7 @@ void tb_launch(int stage, const TbArgs& a, int max_wgs, hipStream_t st, hipError
             if (dbg == 1) grid = nscan;          // (timing experiment: the scan role alone, with its agent-scope stores and publishes; results are garbage)
             *err = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k), dim3(grid), dim3(kThreads), kargs, (unsigned int)lds, st);
             if (*err != hipSuccess) (void)hipGetLastError();
+            else note_kernel("tb_stage_kernel");
             return;
         }
     } else if (stage == TB_BLK) {
@@ -1721,12 +1725,14 @@ void tb_launch(int stage, const TbArgs& a, int max_wgs, hipStream_t st, hipError
         constexpr size_t lds = BlkLds<S, C::FT_B>::BYTES;
         set_lds(k, lds, err);
         if (*err != hipSuccess) return;
+        note_kernel("tb_blk_kernel");
         hipLaunchKernelGGL(k, dim3(grid_for(C::FT_B, lds)), dim3(kThreads), lds, st, a);
     } else {
         auto* k = &tb_dec_kernel<S, C::FT_D>;
         constexpr size_t lds = DecLds<S, C::FT_D>::BYTES;
         set_lds(k, lds, err);
         if (*err != hipSuccess) return;
+        note_kernel("tb_dec_kernel");
         hipLaunchKernelGGL(k, dim3(grid_for(C::FT_D, lds)), dim3(kThreads), lds, st, a);
     }
     *err = hipGetLastError();

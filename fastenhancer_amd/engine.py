@@ -265,6 +265,23 @@ class Engine:
         code = {"waves4": _lib.FE_STEP_KERNEL_WAVES4, "wg8": _lib.FE_STEP_KERNEL_WG8, "wg8_persist": _lib.FE_STEP_KERNEL_WG8_PERSIST}[kernel]
         _lib.check(self.lib.fe_set_step_kernel(self._h, code), "fe_set_step_kernel")
 
+    def set_option(self, name: str, value: int):
+        """fe_set_option: the other kernel-selection switches of the handle by name ("bsrnn_role_split", "bsrnn_stream_batch_min",
+        "bsrnn_three_launch_step", "bsrnn_ov_profile", "fspen_stream_batch_min", "low_lds_companion"; include/fastenhancer_hip.h)."""
+        _lib.check(self.lib.fe_set_option(self._h, name.encode(), int(value)), "fe_set_option")
+
+    def get_option(self, name: str) -> int:
+        v = ctypes.c_int(0)
+        _lib.check(self.lib.fe_get_option(self._h, name.encode(), ctypes.byref(v)), "fe_get_option")
+        return v.value
+
+    def option_names(self):
+        return [self.lib.fe_option_name(i).decode() for i in range(self.lib.fe_options())]
+
+    def last_step_kernel(self) -> str:
+        """fe_last_step_kernel: what the last compute call of this handle enqueued (kernel families / instantiations + the compiled shape)."""
+        return self.lib.fe_last_step_kernel(self._h).decode()
+
     def set_offline_engine(self, engine: str):
         """fe_set_offline_engine: "auto" | "frame_walk" | "time_batched" (the layer-by-layer engine of csrc/tb_kernels.hip.h)"""
         code = {"auto": _lib.FE_OFFLINE_AUTO, "frame_walk": _lib.FE_OFFLINE_FRAME_WALK, "time_batched": _lib.FE_OFFLINE_TIME_BATCHED}[engine]

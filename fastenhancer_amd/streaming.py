@@ -27,7 +27,7 @@ class StreamingModel:
         self._geom: tp.Dict[int, tp.List[tp.Tuple[int, torch.Size, tp.Tuple[int, ...]]]] = {}
         # dptransformer variant: its K / V caches are rings in the state, the tensors handed out are rotated COPIES - the
         # tensors of the last call are recognised by identity and name the state buffer they were gathered from
-        self._handed: tp.Tuple[tp.Optional[Tensor], tp.List[Tensor]] = (None, [])
+        self._handed: tp.Tuple[tp.Optional[Tensor], tp.List[Tensor], tp.List[int]] = (None, [], [])
 
     @property
     def engine(self) -> Engine:
@@ -56,7 +56,11 @@ class StreamingModel:
 
     def _source(self, caches: tp.List[Tensor], B: int, n: int) -> tp.Optional[Tensor]:
         """the state buffer the given cache tensors are exactly the views of (same memory, same layout), else None"""
-        if self._handed[0] is not None and len(caches) == len(self._handed[1]) and all(c is w for c, w in zip(caches, self._handed[1])):
+        # dptransformer: the K / V tensors handed out are rotated COPIES of the rings, recognised by identity - and only while nobody has
+        # written to them (torch's version counters, recorded at hand-out): an edited copy (say, one stream's cache zeroed) is packed like
+        # any foreign tensor instead of being silently replaced by the internal buffer
+        if self._handed[0] is not None and len(caches) == len(self._handed[1]) and \
+                all(c is w and c._version == v for c, w, v in zip(caches, self._handed[1], self._handed[2])):
             return self._handed[0]
         base = caches[0]._base
         g = self._geom.get(B)
@@ -75,7 +79,9 @@ class StreamingModel:
         job) and are never written again - a caller may keep them for roll-back, look-ahead or A/B runs and feed them back in at
         any later time.  Caches that are the views handed out by initialize_cache() / an earlier call (the driver loop of
         scripts/test_onnx.py) cost one device copy into the new buffer; any other tensors (clones, CPU tensors, tensors of the
-        reference) are packed into the state layout first.  (dptransformer models return rotated copies of their K / V rings.)"""
+        reference) are packed into the state layout first.  dptransformer models return rotated copies of their K / V rings (the reference's
+        oldest-first order); fed back UNMODIFIED they are recognised and the rings themselves are used, edited in place they are packed
+        like any other tensor (their version counters tell).  The last handed-out set keeps its state buffer alive."""
         eng = self.engine
         B = wav_in.size(0)
         caches = [cache_stft, cache_istft, *cache_model]
@@ -89,7 +95,7 @@ class StreamingModel:
         wav_out = eng.step(wav_in.to(eng.device, torch.float32), state, T=1)
         if getattr(self.cfg, "dpt", False):
             out = eng.split_state(state, B)
-            self._handed = (state, out)
+            self._handed = (state, out, [t._version for t in out])
             return (wav_out, *out)
         return (wav_out, *self._views(state, B))
 

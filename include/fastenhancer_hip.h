@@ -181,7 +181,7 @@ int fe_set_time_pipeline(fe_handle* h, int frames_in_flight);
  *   FE_STEP_KERNEL_WG8_PERSIST: the same also above that (persistent workgroups instead of the low-LDS companion kernel).
  * The two kernels agree to fp32 rounding (a few 1e-8 on the waveform), not bit for bit: a caller that needs a chunked launch
  * (T > 1) to be bit-identical to T per-hop launches selects FE_STEP_KERNEL_WAVES4.  The environment variable FE_WG8 = 0 | 1 | 2
- * sets the default of new handles (any other value is ignored).  The reference has one forward only (models/fastenhancer/default/model.py:677-710).
+ * sets the value new handles start with (any other value is ignored).  The reference has one forward only (models/fastenhancer/default/model.py:677-710).
  * BSRNN with num_channels = 16 (r5): FE_STEP_KERNEL_WAVES4 runs the layers of the per-hop step phase by phase on all four waves
  * (bsrnn_frame_kernel<PART 1>), any other value the role-split kernel (bsrnn_ov_kernels.hip.h) for batches of up to one stream per CU;
  * the two agree to fp32 rounding.  (models/bsrnn/model.py:367-390) */
@@ -189,6 +189,34 @@ int fe_set_time_pipeline(fe_handle* h, int frames_in_flight);
 #define FE_STEP_KERNEL_WG8 1
 #define FE_STEP_KERNEL_WG8_PERSIST 2
 int fe_set_step_kernel(fe_handle* h, int kernel);
+
+/* The other kernel-selection switches of a handle, by name (r6; until r5 these were environment variables read in three files).
+ * FE_ERR_INVALID_ARG for an unknown name or a value outside the option's range; fe_options() / fe_option_name(i) enumerate them.
+ *   name                       range      default  meaning
+ *   "bsrnn_role_split"         0 | 1      1        BSRNN, num_channels 16, up to one stream per CU: PART 1 of the per-hop step on the role-split
+ *                                                  kernel (bsrnn_ov_kernels.hip.h); 0 = the phase-by-phase kernel (what fe_set_step_kernel(WAVES4) selects too)
+ *   "bsrnn_stream_batch_min"   0 .. 2^24  2048     BSRNN, num_channels 16: from this many streams the layers run batched over the streams
+ *                                                  (bsrnn_sb_kernels.hip.h); 0 = never
+ *   "bsrnn_three_launch_step"  0 | 1      1        BSRNN per-hop step as PART 1 -> batched mask decoder -> PART 2; 0 = one fused kernel per stream
+ *   "bsrnn_ov_profile"         0 | 1      0        fe_profile_step probes the role-split PART 1 instead of the fused kernel's phases
+ *   "fspen_stream_batch_min"   0 .. 2^24  1536     FSPEN: from this many streams the middle of the network runs batched over the streams; 0 = never
+ *   "low_lds_companion"        0 | 1      1        FastEnhancer per-hop step above one stream per CU: the low-LDS companion kernel (two workgroups
+ *                                                  per CU) where one is compiled; 0 = persistent workgroups of the shape's own kernel
+ * A/B scripts (tools/ab_*.sh) preset the values NEW handles start with through FE_BSRNN_OV, FE_BSRNN_SB, FE_BSRNN_SPLIT, FE_BSRNN_OV_PROF,
+ * FE_FSPEN_SB, FE_LOWLDS (FE_NO_LOWLDS) and FE_WG8 (the step kernel): read once, in fe_create, validated against the same ranges (anything else
+ * is ignored).  The reference has one forward per model and nothing to select (models/fastenhancer/default/model.py:677-710). */
+int fe_set_option(fe_handle* h, const char* name, int value);
+int fe_get_option(const fe_handle* h, const char* name, int* value);
+int fe_options(void);
+const char* fe_option_name(int idx);
+
+/* What the handle's last compute call (fe_step / fe_step_host / fe_spec_step / fe_offline / fe_offline_ragged / fe_debug_step / fe_profile_step)
+ * enqueued: the kernel family and instantiation of every launch in order, as the launchers name them, " + "-joined, repeats as "n x", then the
+ * compiled shape record - e.g. "fe_frame8_kernel [shape B]", "fe_frame_kernel<LOW=2, per-hop> [shape B48H480LOW]",
+ * "bsrnn_ov_kernel + bsrnn_mlp_kernel<one 16-stream tile per workgroup> + bsrnn_frame_kernel<PART 2> [shape xt]".  These are the names
+ * rocprofv3 --kernel-trace shows (bench.py's roofline.kernel is this string).  "" before the first call.  The pointer is valid until the
+ * next call of this function on the handle. */
+const char* fe_last_step_kernel(const fe_handle* h);
 
 #define FE_OFFLINE_AUTO 0
 #define FE_OFFLINE_FRAME_WALK 1

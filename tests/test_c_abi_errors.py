@@ -211,6 +211,64 @@ def test_fe_wg8_environment_default_is_validated(monkeypatch):
         _lib.load().fe_destroy(h)
 
 
+def test_options_are_enumerable_validated_and_preset_by_their_environment_variables(monkeypatch):
+    """r6: the kernel-selection switches are ONE documented fe_set_option surface; the environment variables only preset
+    the values new handles start with, validated against the option's range."""
+    import os
+    import re
+    lib = _lib.load()
+    names = [lib.fe_option_name(i).decode() for i in range(lib.fe_options())]
+    assert names == ["bsrnn_role_split", "bsrnn_stream_batch_min", "bsrnn_three_launch_step", "bsrnn_ov_profile", "fspen_stream_batch_min", "low_lds_companion"]
+    assert lib.fe_option_name(len(names)) is None and lib.fe_option_name(-1) is None
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fastenhancer_hip.h")).read()
+    integration = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    for n in names:                                         # header, library and INTEGRATION.md name the same options
+        assert f'"{n}"' in header, n
+        assert n in integration, n
+    assert "fe_last_step_kernel" in header and "fe_last_step_kernel" in integration
+    defaults = {"bsrnn_role_split": 1, "bsrnn_stream_batch_min": 2048, "bsrnn_three_launch_step": 1, "bsrnn_ov_profile": 0,
+                "fspen_stream_batch_min": 1536, "low_lds_companion": 1}
+    for v in ("FE_BSRNN_OV", "FE_BSRNN_SB", "FE_BSRNN_SPLIT", "FE_BSRNN_OV_PROF", "FE_FSPEN_SB", "FE_LOWLDS", "FE_NO_LOWLDS", "FE_WG8"):
+        monkeypatch.delenv(v, raising=False)
+    rc, h = _create(_cfg())
+    assert rc == 0
+    try:
+        val = c_int(-7)
+        for n in names:
+            assert lib.fe_get_option(h, n.encode(), byref(val)) == 0 and val.value == defaults[n], (n, val.value)
+        assert lib.fe_set_option(h, b"bsrnn_stream_batch_min", 4096) == 0
+        assert lib.fe_get_option(h, b"bsrnn_stream_batch_min", byref(val)) == 0 and val.value == 4096
+        _expect(lib.fe_set_option(h, b"bsrnn_role_split", 2), FE_ERR_INVALID_ARG, "outside [0, 1]")
+        _expect(lib.fe_set_option(h, b"fspen_stream_batch_min", -1), FE_ERR_INVALID_ARG, "outside [0,")
+        _expect(lib.fe_set_option(h, b"no_such_switch", 1), FE_ERR_INVALID_ARG, "no option named 'no_such_switch'")
+        _expect(lib.fe_get_option(h, b"no_such_switch", byref(val)), FE_ERR_INVALID_ARG, "no option named")
+        _expect(lib.fe_set_option(NULL, b"bsrnn_role_split", 1), FE_ERR_INVALID_ARG, "null argument")
+        _expect(lib.fe_set_option(h, None, 1), FE_ERR_INVALID_ARG, "null argument")
+        assert lib.fe_last_step_kernel(h) == b"" and lib.fe_last_step_kernel(NULL) == b""          # nothing has run
+    finally:
+        lib.fe_destroy(h)
+    # presets: a valid value is taken, garbage and out-of-range values are ignored
+    for env, opt, good, bad in (("FE_BSRNN_OV", "bsrnn_role_split", "0", ("2", "x", "-1", "")), ("FE_BSRNN_SB", "bsrnn_stream_batch_min", "512", ("-5", "1e3", "99999999999")),
+                                ("FE_FSPEN_SB", "fspen_stream_batch_min", "0", ("no",)), ("FE_LOWLDS", "low_lds_companion", "0", ("3",))):
+        for v in (good,) + bad:
+            monkeypatch.setenv(env, v)
+            rc, h = _create(_cfg())
+            assert rc == 0
+            val = c_int(-7)
+            assert lib.fe_get_option(h, opt.encode(), byref(val)) == 0
+            assert val.value == (int(good) if v == good else defaults[opt]), (env, v, val.value)
+            lib.fe_destroy(h)
+        monkeypatch.delenv(env)
+    # the library reads its selection switches from the environment in fe_create only (fe_handle's constructor): no getenv of them elsewhere
+    src = ""
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fastenhancer_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".h", ".hip", ".inc")):
+            src += open(os.path.join(csrc, f)).read()
+    for v in ("FE_BSRNN_OV", "FE_BSRNN_SB", "FE_BSRNN_SPLIT", "FE_FSPEN_SB", "FE_WG8"):
+        assert not re.search(r'getenv\("' + v + r'"\)', src), v
+
+
 # ------------------------------------------------------------------------------------------------ GPU: checks behind check_ready()
 def _loaded_engine(name):
     from common import build_oracle
@@ -302,3 +360,65 @@ def test_time_batched_engine_request_on_a_model_without_one():
     x = torch.zeros(1, 256, device="cuda:0")
     p = c_void_p(x.data_ptr())
     _expect(lib.fe_step(eng._h, p, 256, p, p, 256, 1, 1, NULL), FE_ERR_NO_WEIGHTS, "fe_load_weights has not been called")
+
+
+@pytest.mark.gpu
+def test_last_step_kernel_names_what_was_dispatched():
+    """r6: the library says which kernel family / instantiation its last compute call enqueued - bench.py's roofline.kernel
+    is this string, not a guess made from flags and environment variables.  It follows fe_set_step_kernel, the batch size relative to the CU
+    count, the entry point and fe_set_option."""
+    dev = torch.device("cuda:0")
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    eng = _loaded_engine("fe_b")
+    assert eng.last_step_kernel() == ""
+    H = eng.cfg.hop_size
+
+    def step(B, T=1):
+        st = eng.new_state(B)
+        eng.step(torch.zeros(B, T * H, device=dev), st, T=T)
+        torch.cuda.synchronize()
+        return eng.last_step_kernel()
+
+    assert step(4) == "fe_frame8_kernel [shape B]"
+    assert step(4, T=3) == "fe_frame_kernel<generic> [shape B]"                        # chunks run on the 256-thread kernel
+    many = step(cus + 8)
+    assert many == "fe_frame_kernel<LOW=1, per-hop> [shape BLOW]", many                 # above one stream per CU: the low-LDS companion
+    eng.set_option("low_lds_companion", 0)
+    assert step(cus + 8) == "fe_frame_kernel<per-hop, persistent> [shape B]"
+    eng.set_option("low_lds_companion", 1)
+    eng.set_step_kernel("wg8_persist")
+    assert step(cus + 8) == "fe_frame8_kernel<persistent> [shape B]"
+    eng.set_step_kernel("waves4")
+    assert step(4) == "fe_frame_kernel<per-hop> [shape B]"
+    eng.set_step_kernel("wg8")
+    assert step(4) == "fe_frame8_kernel [shape B]"
+    x = torch.zeros(2, 4 * 16000, device=dev)
+    eng.offline(x)
+    torch.cuda.synchronize()
+    off = eng.last_step_kernel()
+    assert off.startswith("tb_enc_kernel + ") and "tb_blk_kernel" in off and off.endswith("istft_ola_kernel [shape B]"), off
+    # BSRNN: the role-split PART 1 up to one stream per CU, the phase-by-phase kernel above or on request, the stream-batched layers from the threshold
+    import importlib
+    import numpy as np
+    from common import build_bsrnn_oracle
+    kw = BSRNN_KWARGS["bsrnn_xt"][0]
+    bsd = build_bsrnn_oracle("bsrnn_xt")[1]
+    m = importlib.import_module("fastenhancer_amd.models.bsrnn.model").ONNXModel(**kw).to(dev).eval()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in bsd.items()}, strict=True)
+    beng = m.engine
+
+    def bstep(B):
+        st = beng.new_state(B)
+        beng.step(torch.zeros(B, beng.cfg.hop_size, device=dev), st, T=1)
+        torch.cuda.synchronize()
+        return beng.last_step_kernel()
+
+    assert bstep(4) == "bsrnn_ov_kernel + bsrnn_mlp_kernel<one 16-stream tile per workgroup> + bsrnn_frame_kernel<PART 2> [shape xt]"
+    beng.set_option("bsrnn_role_split", 0)
+    assert bstep(4) == "bsrnn_frame_kernel<PART 1> + bsrnn_mlp_kernel<one 16-stream tile per workgroup> + bsrnn_frame_kernel<PART 2> [shape xt]"
+    beng.set_option("bsrnn_role_split", 1)
+    assert bstep(cus + 8).startswith("bsrnn_frame_kernel<PART 1, two workgroups per CU> + bsrnn_mlp_kernel + ")
+    beng.set_option("bsrnn_stream_batch_min", 32)
+    assert bstep(48) == "bsrnn_frame_kernel<PART 3> + bsrnn_sb_layers_kernel + bsrnn_mlp_kernel + bsrnn_frame_kernel<PART 2> [shape xt]"
+    beng.set_option("bsrnn_three_launch_step", 0)
+    beng.set_option("bsrnn_stream_batch_min", 2048)

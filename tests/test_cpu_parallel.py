@@ -97,6 +97,7 @@ def test_bench_launch_path_runs_end_to_end_on_two_gloo_ranks():
     d = json.loads(lines[0])
     assert d["dry_run"] is True and d["world_size"] == 2 and d["n_gpus"] == 2 and d["value"] is None
     assert d["streams_per_rank"] == [5, 5] and d["weight_blob_floats"] > 0 and d["blocks"] >= 1
+    assert d["launch_mode"] == "hip_graph"
 
 
 def test_bench_config3_command_line_dry_run_on_eight_gloo_ranks():
@@ -113,3 +114,8 @@ def test_bench_config3_command_line_dry_run_on_eight_gloo_ranks():
     d = json.loads(lines[0])
     assert d["dry_run"] is True and d["world_size"] == 8 and d["n_gpus"] == 8
     assert d["streams_per_rank"] == [256] * 8 and sum(d["streams_per_rank"]) == 2048
+    # r6: a world of more than one rank times ONE HIP graph of the K steps by default (the eager figure beside it), and the line carries the
+    # spread over the ranks
+    assert d["launch_mode"] == "hip_graph" and "eager_ms_per_step" in d
+    sp = d["rank_spread_ms_per_step"]
+    assert 0.0 <= sp["min"] <= sp["max"] and sp["widest_block_max_over_min"] >= 1.0

@@ -8,6 +8,7 @@ import os
 import socket
 import subprocess
 import sys
+import warnings
 
 import pytest
 
@@ -46,15 +47,69 @@ def test_bench_under_torchrun_walks_the_rccl_branch_and_matches_the_plain_run():
     assert math.isfinite(launched["weight_broadcast_ms"]) and launched["weight_broadcast_ms"] > 0.0
     assert len(launched["per_rank_ms_per_step"]) == 1 and math.isfinite(launched["per_rank_ms_per_step"][0])
     assert launched["steps"] == 50 and launched["warmup"] == 5 and launched["config"] == plain["config"]
-    # the kernel the two runs time is the same one: HIP-event time per launch within 3 %, whole-step wall rate within 5 % (a 1.6 ms block on the host clock)
+    # the kernel the two runs time is the same one - by name (fe_last_step_kernel), and by time as a SANITY bound only (a
+    # correctness test must not flake on a busy box or under clock ramp: a factor 1.5, not the 3 % / 5 % of r5; the measured agreement goes
+    # to the report as a warning)
+    assert launched["roofline"]["kernel"] == plain["roofline"]["kernel"] == "fe_frame8_kernel [shape B]"
     k0, k1 = plain["roofline"]["kernel_ms"], launched["roofline"]["kernel_ms"]
-    assert abs(k1 - k0) <= 0.03 * k0, (k0, k1)
-    assert abs(launched["value"] - plain["value"]) <= 0.05 * plain["value"], (plain["value"], launched["value"])
+    assert k1 < 1.5 * k0 and k0 < 1.5 * k1, (k0, k1)
+    if abs(k1 - k0) > 0.05 * k0:
+        warnings.warn(f"launched / plain kernel time differ by more than 5 %: {k0:.5f} vs {k1:.5f} ms")
+    # r6: a launched run times ONE HIP graph of the K steps only at world > 1; at world 1 both runs are eager
+    assert plain["launch_mode"] == launched["launch_mode"] == "eager" and launched["eager_ms_per_step"] is None
+    assert launched["rank_spread_ms_per_step"]["min"] <= launched["rank_spread_ms_per_step"]["max"]
     # parity of what was timed (bench.py, after the timed region): fp32 rounding, far inside north_star's 1e-4
     for line in (plain, launched):
         assert line["parity_rms_rel"] is not None and line["parity_rms_rel"] < 3e-6, line["parity_rms_rel"]
         assert line["parity_cache_rms_rel"] < 3e-6, line["parity_cache_rms_rel"]
-    assert launched["roofline"]["frac"] > 0.3
+    assert launched["roofline"]["frac"] > 0.2                                                 # (sanity: the right kernel at a plausible rate)
+
+
+def test_graph_launch_mode_under_torchrun_matches_the_eager_run():
+    """r6: at world > 1 bench.py times ONE HIP graph of the K steps (0.3-0.8 us of launch thread per step instead of
+    3.7 us: the N-rank number is then not a host-jitter measurement) and reports the eager figure of the same run beside it.  One GPU here:
+    `--graph` forces the mode under the launcher at world 1 - capture inside an RCCL process group, replay between the barriers, the eager
+    block, the post-run parity of the state the graph replays left."""
+    flags = ["--gpus", "1", "--steps", "50", "--warmup", "5", "--blocks", "5", "--no-cpu-baseline"]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    g = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+              "--master-port", str(_free_port()), "bench.py", "--graph"] + flags, env=env)
+    assert g["launch_mode"] == "hip_graph" and g["graph_note"] is None and g["collective_backend"] == "nccl"
+    assert g["eager_ms_per_step"] is not None and math.isfinite(g["eager_ms_per_step"]) and g["eager_ms_per_step"] > 0.0
+    assert g["roofline"]["kernel"] == "fe_frame8_kernel [shape B]"
+    assert g["ms_per_step"] < 1.5 * g["eager_ms_per_step"]                                     # (sanity; a graph node is cheaper than an eager launch)
+    assert g["parity_rms_rel"] is not None and g["parity_rms_rel"] < 3e-6 and g["parity_cache_rms_rel"] < 3e-6
+    assert g["host_enqueue_us_per_step"] < 3.0, g["host_enqueue_us_per_step"]                  # one replay call for 50 steps
+
+
+# BASELINE.json's four GPU configurations exactly as bench.py times them: (workload, streams, the kernels the library must report, parity
+# bound of the family, roofline fraction of the kept matrix - profiles/r5_bench_matrix.txt / r6)
+BASELINE_GPU = [
+    ("fe_b", 256, "fe_frame8_kernel [shape B]", 3e-6, 0.43),
+    ("fe_l", 256, "fe_frame_kernel<per-hop> [shape L]", 3e-6, 0.73),
+    ("fe48_b_h480", 512, "fe_frame_kernel<LOW=2, per-hop> [shape B48H480LOW]", 3e-6, 0.51),
+    ("bsrnn_xt", 256, "bsrnn_ov_kernel + bsrnn_mlp_kernel<one 16-stream tile per workgroup> + bsrnn_frame_kernel<PART 2> [shape xt]", 1e-5, 0.16),
+]
+
+
+@pytest.mark.parametrize("workload,streams,kernel,bound,frac", BASELINE_GPU, ids=[c[0] for c in BASELINE_GPU])
+def test_timed_configuration_of_every_gpu_baseline_config(workload, streams, kernel, bound, frac):
+    """r6: the parity of exactly what the bench times - ALL B streams of the launch shape bench.py measures,
+    one more launch from the state the timed run left, against the oracle - witnessed by the driver's `-m gpu` run for every GPU BASELINE
+    config, not for config 2 alone; and the kernel the library reports for it is the one the roofline line is about."""
+    line = _run([sys.executable, "bench.py", "--workload", workload, "--streams", str(streams), "--steps", "20", "--warmup", "5", "--blocks", "3",
+                 "--no-cpu-baseline"])
+    assert line["config"]["streams_per_gpu"] == streams and line["steps"] == 20
+    assert line["parity_rms_rel"] is not None and line["parity_rms_rel"] < bound, line["parity_rms_rel"]
+    assert line["parity_cache_rms_rel"] < bound, line["parity_cache_rms_rel"]
+    assert f"all {streams} streams" in line["parity_checker"]
+    assert line["roofline"]["kernel"] == kernel, line["roofline"]["kernel"]
+    # the rate: a regression guard with room for a busy box (ADVICE r5), the 5 % band of the kept matrix as a warning
+    got = line["roofline"]["frac"]
+    assert got > 0.75 * frac, (got, frac)
+    if abs(got - frac) > 0.05 * frac:
+        warnings.warn(f"{workload} x {streams}: roofline.frac {got:.4f} is outside 5 % of the kept matrix's {frac:.3f}")
 
 
 def test_host_contention_probe_is_labelled_as_such():

@@ -7,6 +7,7 @@ RMS, which is the tighter of the two.  Observed: ~1e-6 relative."""
 import importlib
 import json
 import os
+import warnings
 
 import numpy as np
 import pytest
@@ -68,9 +69,14 @@ def _assert_close(got, ref, what, tight=None):
         OBSERVED[tid] = (rel, what)
     # (1) the north_star bound: absolute 1e-4 for audio-level signals (rms <= 1), relative 1e-4 always
     assert err < ABS_TOL * max(1.0, r) and err <= REL_TOL * max(r, 1e-3), f"{what}: rms err {err:.3e}, ref rms {r:.3e} (north_star bound 1e-4)"
-    # (2) the regression bound: what the kernels deliver (exact fp32 arithmetic, fp32 oracle), per family
-    bound = min(TIGHT_REL[_family()], max(5.0 * _OBSERVED_R5.get(tid, 1.0), 2e-6)) if tight is None else tight
+    # (2) the regression bound: what the kernels deliver (exact fp32 arithmetic, fp32 oracle), per family - the hard assert; the per-test
+    # bound (5x what THIS test recorded in r5, keyed on the node id of one recorded run) is reported as a warning only (a benign
+    # compiler / ROCm update or another rootdir must not turn the suite red)
+    bound = TIGHT_REL[_family()] if tight is None else tight
     assert rel <= bound, f"{what}: relative rms err {rel:.3e} > {bound:.1e} (the kernels deliver ~{bound / 5:.0e}: a precision regression)"
+    per_test = max(5.0 * _OBSERVED_R5.get(tid, 1.0), 2e-6)
+    if tight is None and rel > per_test:
+        warnings.warn(f"{what}: relative rms err {rel:.3e} is above 5x this test's recorded r5 value ({per_test:.1e})")
     return err / max(r, 1e-12)
 
 
@@ -345,6 +351,31 @@ def test_streaming_model_has_the_reference_value_semantics(name):
         o, *caches = M(x[:, t * H:(t + 1) * H], *caches)
         assert torch.equal(o, outs[t]), f"resumed run differs at hop {t}"
     assert all(torch.equal(a_, b_) for a_, b_ in zip(kept, kept_snap))
+
+
+def test_dptransformer_caches_edited_in_place_are_honoured():
+    """the dptransformer mirror hands out rotated COPIES of its K / V rings and recognises them by identity on the way back; a
+    caller who edits such a tensor in place (zeroing one stream's cache - what resetting a stream between utterances looks like with the
+    reference's Model.forward, scripts/export_onnx.py:48-58) must get the edit, not the untouched internal buffer.  The edited tensors give the
+    bits that clones with the same edit give."""
+    from fastenhancer_amd.streaming import StreamingModel
+    m, orc, cfg, sr, seed = _model("fe_dpt_t")
+    M = StreamingModel(m)
+    B, H = 3, cfg.hop_size
+    x = torch.from_numpy(make_input(B, 4 * H, 57, sr)).to(_dev())
+    caches = M.initialize_cache(x)
+    for t in range(3):
+        o, *caches = M(x[:, t * H:(t + 1) * H], *caches)
+    clones = [c.clone() for c in caches]
+    o_plain, *_ = M(x[:, 3 * H:4 * H], *caches)               # unmodified: the fast path (identity + version counters)
+    for c in (caches, clones):                                # reset stream 1 in every model cache, in place
+        for tns in c[2:]:
+            n = tns.shape[0] // B                                # [B * F2, NH, L, hd]: stream b = rows b * F2 .. (b + 1) * F2 - 1
+            tns[n:2 * n].zero_()
+    o_edit, *_ = M(x[:, 3 * H:4 * H], *caches)
+    o_clone, *_ = M(x[:, 3 * H:4 * H], *clones)
+    assert torch.equal(o_edit, o_clone), "caches edited in place were replaced by the internal state"
+    assert not torch.equal(o_edit[1], o_plain[1]) and torch.equal(o_edit[0], o_plain[0]) and torch.equal(o_edit[2], o_plain[2])
 
 
 def test_full_size_batch_256_matches_oracle_and_is_stream_independent():
