@@ -388,6 +388,22 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
         const int g_t0 = wave < 4 ? 3 * (wave >> 1) : 3 * S::G8_NG;        // its first gate tile
         // block weights in LDS (W8 slots): B fragment (tile, k-step) of a unit at u[(tile * K2 + ks) * 64 + lane], start value of a tile's
         // column at u[NT * K2 * 64 + tile * 16 + li]
+#ifdef FE_EXP_BREG      // timing experiment (wrong results): the blocks' B operands as register values, no block-weight staging - the upper bound of register-resident block weights
+        float breg0 = 0.001f * (float)lane, breg1 = 0.002f, breg2 = -0.001f, breg3 = 0.0005f;
+        asm volatile("" : "+v"(breg0), "+v"(breg1), "+v"(breg2), "+v"(breg3));
+#define FE8_B(expr, ks) (((ks) & 3) == 0 ? breg0 : ((ks) & 3) == 1 ? breg1 : ((ks) & 3) == 2 ? breg2 : breg3)
+#define FE8_STAGE_ON 0
+#else
+#define FE8_B(expr, ks) (expr)
+#define FE8_STAGE_ON 1
+#endif
+#ifdef FE_EXP_AREG      // ... and their A operands too (no LDS operand reads in the blocks' GEMMs at all)
+        float areg0 = 0.003f * (float)(lane & 15), areg1 = 0.001f, areg2 = -0.002f;
+        asm volatile("" : "+v"(areg0), "+v"(areg1), "+v"(areg2));
+#define FE8_A(expr, ks) ((ks) % 3 == 0 ? areg0 : (ks) % 3 == 1 ? areg1 : areg2)
+#else
+#define FE8_A(expr, ks) (expr)
+#endif
         const float* const sGx = smem + W8::WB0 + 1 * W8::SLOT;
         const float* const sGh = smem + W8::WB0 + 3 * W8::SLOT;
         const float* const sF = smem + W8::WB0 + 0 * W8::SLOT;
@@ -398,9 +414,9 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
         jb2 = jb1;
         auto stage_to = [&](DmaJobT<NPWB>& j, int src_floats, int dst_floats) { j.l = smem + dst_floats; j.soff = (src_floats + wave * 256) * 4; };
         constexpr int u8_stride = S::KB > 1 ? o.u8_gx[1] - o.u8_gx[0] : 0;
-        using StG = StageSide<NPWB, S::U8_G / 256, kWaves8>;
-        using StF = StageSide<NPWB, S::U8_F / 256, kWaves8>;
-        using StQ = StageSide<NPWB, S::U8_Q / 256, kWaves8>;
+        using StG = StageSide<NPWB, FE8_STAGE_ON * (S::U8_G / 256), kWaves8>;
+        using StF = StageSide<NPWB, FE8_STAGE_ON * (S::U8_F / 256), kWaves8>;
+        using StQ = StageSide<NPWB, FE8_STAGE_ON * (S::U8_Q / 256), kWaves8>;
         float pe_r[4];
         // unpredicated epilogue stores into the [F2P][C2 + 2] token buffers (pad rows are real rows, lanes past C2 aim at the pad column)
         auto tok_dst = [&](float* base) {
@@ -601,8 +617,8 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
 #endif
                     mma_panel_sel<1, 3, KSG, PDK>(
                         [&](int, int j, int ks) -> f32x4& { return j == 0 ? ar : (j == 1 ? az : (ks < K2 ? anx : anh)); },
-                        [&](int, int ks) { return ks < K2 ? xa[4 * ks] : ha[4 * (ks - K2)]; },
-                        [&](int j, int ks) { return ks < K2 ? wx[(j * K2 + ks) * 64] : wh_[(j * K2 + (ks - K2)) * 64]; }, sideg);
+                        [&](int, int ks) { return FE8_A(ks < K2 ? xa[4 * ks] : ha[4 * (ks - K2)], ks); },
+                        [&](int j, int ks) { return FE8_B(ks < K2 ? wx[(j * K2 + ks) * 64] : wh_[(j * K2 + (ks - K2)) * 64], ks + j); }, sideg);
                     __builtin_amdgcn_sched_barrier(0);
                     if (k == 0) FE_CLK(46);
                     float hn[4];
@@ -643,8 +659,8 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
 #endif
                     mma_panel_sel<1, 1, KSG, PDK>(
                         [&](int, int, int ks) -> f32x4& { return ks < K2 ? ((ks & 1) ? ax1 : ax) : ((ks & 1) ? ah1 : ah); },
-                        [&](int, int ks) { return ks < K2 ? xa[4 * ks] : ha[4 * (ks - K2)]; },
-                        [&](int, int ks) { return ks < K2 ? wx[ks * 64] : wh_[(ks - K2) * 64]; }, sideg);
+                        [&](int, int ks) { return FE8_A(ks < K2 ? xa[4 * ks] : ha[4 * (ks - K2)], ks); },
+                        [&](int, int ks) { return FE8_B(ks < K2 ? wx[ks * 64] : wh_[(ks - K2) * 64], ks); }, sideg);
                     __builtin_amdgcn_s_setprio(0);
                     ax += ax1;
                     ah += ah1;
@@ -689,17 +705,17 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
             {
                 // x += rnn_fc(h') (+ pe in block 0); staged meanwhile: the next block's GRU input weights -> slot 1
                 stage_to(jb1, o.u8_gx[0] + ub + u8_stride, W8::WB0 + 1 * W8::SLOT);
-                const StageSide<NPWB, (S::U8_G / 256), kWaves8> stn{&jb1};
+                const StG stn{&jb1};
                 f32x4 acc[1][1];
                 const float bj = sF[S::NT2 * K2 * 64 + ntf * 16 + li];
                 acc[0][0] = f32x4{bj, bj, bj, bj};
                 const float* hla = Hl + (16 * wh + li) * LDX + lg;
                 const float* wf = sF + ntf * (K2 * 64) + lane;
                 if (k + 1 < S::KB) {
-                    mma_panel<1, 1, K2, PDK>(acc, [&](int, int ks) { return hla[4 * ks]; }, [&](int, int ks) { return wf[ks * 64]; }, stn);
+                    mma_panel<1, 1, K2, PDK>(acc, [&](int, int ks) { return FE8_A(hla[4 * ks], ks); }, [&](int, int ks) { return FE8_B(wf[ks * 64], ks); }, stn);
                     stn.commit();
                 } else
-                    mma_panel<1, 1, K2, PDK>(acc, [&](int, int ks) { return hla[4 * ks]; }, [&](int, int ks) { return wf[ks * 64]; }, NoSide{});
+                    mma_panel<1, 1, K2, PDK>(acc, [&](int, int ks) { return FE8_A(hla[4 * ks], ks); }, [&](int, int ks) { return FE8_B(wf[ks * 64], ks); }, NoSide{});
                 float* xd = tok_dst(Xb);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -721,11 +737,11 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
                 __builtin_amdgcn_sched_barrier(0);
                 if (k == 0) FE_CLK(50);
                 const float* xa = Xb + (16 * wh + li) * LDX + lg;
-                mma_panel<1, NTPW3, K2, PDK>(acc, [&](int, int ks) { return xa[4 * ks]; },
+                mma_panel<1, NTPW3, K2, PDK>(acc, [&](int, int ks) { return FE8_A(xa[4 * ks], ks); },
                                              [&](int j, int ks) {
                                                  int nt = ws + 4 * j;
                                                  nt = nt < S::NT3 ? nt : S::NT3 - 1;
-                                                 return sQ[(nt * K2 + ks) * 64 + lane];
+                                                 return FE8_B(sQ[(nt * K2 + ks) * 64 + lane], ks + j);
                                              }, st1);
                 st1.commit();
                 __builtin_amdgcn_sched_barrier(0);
@@ -762,17 +778,17 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
                 const float* wf = sF + ntf * (K2 * 64) + lane;
                 if (k + 1 < S::KB) {
 #if FE_WG8_HPRE
-                    mma_panel<1, 1, K2, PDK>(acc, [&](int, int ks) { return hla[4 * ks]; }, [&](int, int ks) { return wf[ks * 64]; }, NoSide{});
+                    mma_panel<1, 1, K2, PDK>(acc, [&](int, int ks) { return FE8_A(hla[4 * ks], ks); }, [&](int, int ks) { return FE8_B(wf[ks * 64], ks); }, NoSide{});
 #else
                     stage_to(jb1, o.u8_gh[0] + ub + u8_stride, W8::WB0 + 3 * W8::SLOT);
                     const StG stn{&jb1};
-                    mma_panel<1, 1, K2, PDK>(acc, [&](int, int ks) { return hla[4 * ks]; }, [&](int, int ks) { return wf[ks * 64]; }, stn);
+                    mma_panel<1, 1, K2, PDK>(acc, [&](int, int ks) { return FE8_A(hla[4 * ks], ks); }, [&](int, int ks) { return FE8_B(wf[ks * 64], ks); }, stn);
                     stn.commit();
 #endif
                 } else {
                     stage_to(jb1, o.u_off[S::U_RFPOST], W8::WB1);
                     const StageSide<NPWB, o.u_size[S::U_RFPOST] / 256, kWaves8> stn{&jb1};
-                    mma_panel<1, 1, K2, PDK>(acc, [&](int, int ks) { return hla[4 * ks]; }, [&](int, int ks) { return wf[ks * 64]; }, stn);
+                    mma_panel<1, 1, K2, PDK>(acc, [&](int, int ks) { return FE8_A(hla[4 * ks], ks); }, [&](int, int ks) { return FE8_B(wf[ks * 64], ks); }, stn);
                     stn.commit();
                 }
                 if (k + 1 < S::KB) {
@@ -939,6 +955,9 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
         ++fc;
     } while (PERSIST && b < a.B);
 #undef FE8_BEGIN_UNIT
+#undef FE8_B
+#undef FE8_A
+#undef FE8_STAGE_ON
     FE_CLK(63);
 }
 
