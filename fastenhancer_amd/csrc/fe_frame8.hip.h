@@ -651,6 +651,9 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
                     const float b0 = bx[0], b1 = bh[0];
                     f32x4 ax = f32x4{b0, b0, b0, b0}, ah = f32x4{b1, b1, b1, b1};
                     f32x4 ax1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, ah1 = ax1;
+#ifdef FE_WG8_MIX4      // four accumulator chains per half instead of two: the dependent chain of the small job ends earlier
+                    f32x4 ax2 = ax1, ax3 = ax1, ah2 = ax1, ah3 = ax1;
+#endif
                     __builtin_amdgcn_s_setprio(3);
 #ifdef FE_EXP_NOHH
                     constexpr int KSG = K2;
@@ -658,12 +661,22 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
                     constexpr int KSG = 2 * K2;
 #endif
                     mma_panel_sel<1, 1, KSG, PDK>(
+#ifdef FE_WG8_MIX4
+                        [&](int, int, int ks) -> f32x4& { return ks < K2 ? ((ks & 3) == 0 ? ax : (ks & 3) == 1 ? ax1 : (ks & 3) == 2 ? ax2 : ax3)
+                                                                         : ((ks & 3) == 0 ? ah : (ks & 3) == 1 ? ah1 : (ks & 3) == 2 ? ah2 : ah3); },
+#else
                         [&](int, int, int ks) -> f32x4& { return ks < K2 ? ((ks & 1) ? ax1 : ax) : ((ks & 1) ? ah1 : ah); },
+#endif
                         [&](int, int ks) { return FE8_A(ks < K2 ? xa[4 * ks] : ha[4 * (ks - K2)], ks); },
                         [&](int, int ks) { return FE8_B(ks < K2 ? wx[ks * 64] : wh_[(ks - K2) * 64], ks); }, sideg);
                     __builtin_amdgcn_s_setprio(0);
+#ifdef FE_WG8_MIX4
+                    ax = (ax + ax1) + (ax2 + ax3);
+                    ah = (ah + ah1) + (ah2 + ah3);
+#else
                     ax += ax1;
                     ah += ah1;
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                     if (k == 0) FE_CLK(46);
                     auto shl = [](float v, auto n_) {      // lane i <- lane i + n of its 16-lane row
