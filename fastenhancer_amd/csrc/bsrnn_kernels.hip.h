@@ -122,6 +122,9 @@ struct BArgs {
     int mlp_tpw;              // bsrnn_mlp_kernel: sixteen-stream tiles per wave (> 1 only where a band's layer-2 weights all sit in the register ring: C = 16)
     float* sb_y;              // stream-batched layers (bsrnn_sb_kernels.hip.h): the band LSTM's outputs of the running layer [B][2][31][HH]
     int ov_off;               // fe_set_step_kernel(FE_STEP_KERNEL_WAVES4): PART 1 on the phase-by-phase kernel instead of the role-split one
+    // r6, the fused per-hop step (bsrnn_ov_kernel<FUSED>): barrier counters of the sixteen-stream tiles [tiles][2] (handle-owned, zeroed once,
+    // monotonic), nullptr = the three-launch step
+    unsigned int* gsync;
 };
 
 // debug stage table: spec_in, compressed, band_split, (layer.l.time, layer.l.freq)..., mask_mlp, spec_out
@@ -1060,40 +1063,25 @@ struct BMlpLds {
     static constexpr int LDH = 4 * S::C + 2;                   // hidden rows: 2 x odd floats (conflict-free A-fragment reads)
     static constexpr size_t BYTES = (size_t)kWaves * 16 * LDH * 4;
 };
-template <class S>
-__global__ void __launch_bounds__(kThreads) bsrnn_mlp_kernel(BArgs a) {
+// One wave's share of the mask decoder for sixteen streams (s0 .. s0 + 15) of one (kind, band): layer 1, then the layer-2 items
+// it0, it0 + its, ... (nitw of them; an item = a column tile of the band's rows x a burst of KB k-steps) of `tpw` consecutive stream tiles.
+// AGENT (r6, the fused per-hop step: bsrnn_ov_kernels.hip.h): the band features were written, and the pre-activations will be read, by
+// OTHER workgroups of the same launch - agent-scope loads / stores (the hand-over protocol of the time-pipelined kernels: no fences).
+template <class S, bool AGENT>
+__device__ __forceinline__ void bsrnn_mlp_wave(const BArgs& a, float* h1, int kind, int band, int tile0, int tpw, int it0, int its, int nitw, int lane) {
     constexpr int C = S::C, O1 = 4 * C, R4 = C / 4, NT1 = O1 / 16, KS2 = O1 / 4, LDH = BMlpLds<S>::LDH;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
-    const int kb = (int)blockIdx.x % (2 * kBands), tg = (int)blockIdx.x / (2 * kBands);
-    const int kind = kb / kBands, band = kb - kind * kBands;
-    // a wave takes `tpw` sixteen-stream tiles of its band, one after the other (large batches of the C = 16 shapes: the band's weights - all of
-    // them in registers there - are fetched once per wave instead of once per tile: the kernel ran at a third of its MFMA time, on weight loads)
-    // mlp_tpw = 0 (r5, small batches - fewer 64-stream groups than CUs): the four waves of a workgroup share ONE sixteen-stream tile and split
-    // the band's layer-2 column tiles between them (layer 1 - 16 MFMAs - is computed by each): a wide band's five dependent 16-MFMA items were
-    // the kernel's critical path
-    const bool split = a.mlp_tpw == 0;
-    const int tpw = a.mlp_tpw > 1 ? a.mlp_tpw : 1;
-    const int tile0 = split ? tg : (tg * kWaves + wave) * tpw;
-    if (tile0 * 16 >= a.B) return;                            // (wave-uniform; the kernel has no barrier)
     const float* __restrict__ wp = a.wp;
     const BOffsets& o = a.off;
-    float* h1 = smem + wave * (16 * LDH);
-    // layer 2's work list: items = (column tile of the band's rows, burst of KB k-steps); their weights ride D items ahead of the MFMAs in a
-    // register ring, and the first D are requested before layer 1 (a wave per SIMD: nothing else hides the L2 round trips)
     const int n2 = 4 * bsrnn_band_sub(band), row0 = 4 * bsrnn_band_bin0(band);
-    const int nt2 = (n2 + 15) >> 4;
     constexpr int KB = KS2 < 16 ? KS2 : 16, NB = KS2 / KB, D = NB == 1 ? 5 : 8;   // (C = 16: a band has at most five items - all in flight at once)
-    const int nit_all = nt2 * NB;
-    // (split: this wave's items are wave, wave + 4, ... of the band's list - whole column tiles: NB = 1 there)
-    const int nit = (split && NB == 1) ? (nit_all - wave + kWaves - 1) / kWaves : nit_all;
-    if (split && NB == 1 && nit == 0) return;                 // (a narrow band: fewer column tiles than waves)
+    const int nit = nitw;
     auto row_of = [&](int nt) { const int c = 16 * nt + li; return row0 + (c < n2 ? c : n2 - 1); };
+    // layer 2's work list: the items' weights ride D items ahead of the MFMAs in a register ring, and the first D are requested before layer 1
+    // (a wave per SIMD: nothing else hides the L2 round trips)
     auto load_item = [&](int itl, float (&wv)[KB], float& bias) {
         if (itl < nit) {
-            const int it = (split && NB == 1) ? wave + kWaves * itl : itl;
+            const int it = it0 + its * itl;
             const int nt = it / NB, kbi = it - nt * NB, row = row_of(nt);
             const float* w2 = wp + o.m_w2[kind] + (size_t)row * 4 + lg + (size_t)(kbi * KB) * kMlpRows * 4;
 #pragma unroll
@@ -1114,7 +1102,10 @@ __global__ void __launch_bounds__(kThreads) bsrnn_mlp_kernel(BArgs a) {
         const float* xa = a.mlp_x + ((size_t)srow * kBands + band) * C + lg;
         float av[R4];
 #pragma unroll
-        for (int ks = 0; ks < R4; ++ks) av[ks] = xa[4 * ks];
+        for (int ks = 0; ks < R4; ++ks) {
+            if constexpr (AGENT) av[ks] = __hip_atomic_load(xa + 4 * ks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else av[ks] = xa[4 * ks];
+        }
         const float* w1 = wp + o.m_w1[kind] + (size_t)band * R4 * O1 * 4 + li * 4 + lg;
         const float* b1 = wp + o.m_b1[kind] + band * O1 + li;
 #pragma unroll
@@ -1154,7 +1145,7 @@ __global__ void __launch_bounds__(kThreads) bsrnn_mlp_kernel(BArgs a) {
             for (int jj = 0; jj < D; ++jj) {
                 const int itl = g * D + jj;
                 if (itl < nit) {
-                    const int it = (split && NB == 1) ? wave + kWaves * itl : itl;
+                    const int it = it0 + its * itl;
                     const int nt = it / NB, kbi = it - nt * NB;
                     if (kbi == 0) acc = f32x4{rbias[jj], rbias[jj], rbias[jj], rbias[jj]};
                     // (av is indexed by compile-time k-steps: one unrolled body per burst position)
@@ -1171,7 +1162,10 @@ __global__ void __launch_bounds__(kThreads) bsrnn_mlp_kernel(BArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int st = s0 + 4 * lg + r;
-                            if (cok && st < a.B) pre[(size_t)st * (2 * kMlpRows) + row] = acc[r];
+                            if (cok && st < a.B) {
+                                if constexpr (AGENT) __hip_atomic_store(pre + (size_t)st * (2 * kMlpRows) + row, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                else pre[(size_t)st * (2 * kMlpRows) + row] = acc[r];
+                            }
                         }
                     }
                 }
@@ -1180,6 +1174,33 @@ __global__ void __launch_bounds__(kThreads) bsrnn_mlp_kernel(BArgs a) {
         }
     }
     }
+}
+
+template <class S>
+__global__ void __launch_bounds__(kThreads) bsrnn_mlp_kernel(BArgs a) {
+    constexpr int O1 = 4 * S::C, KS2 = O1 / 4, LDH = BMlpLds<S>::LDH;
+    constexpr int KB = KS2 < 16 ? KS2 : 16, NB = KS2 / KB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kb = (int)blockIdx.x % (2 * kBands), tg = (int)blockIdx.x / (2 * kBands);
+    const int kind = kb / kBands, band = kb - kind * kBands;
+    // a wave takes `tpw` sixteen-stream tiles of its band, one after the other (large batches of the C = 16 shapes: the band's weights - all of
+    // them in registers there - are fetched once per wave instead of once per tile: the kernel ran at a third of its MFMA time, on weight loads)
+    // mlp_tpw = 0 (r5, small batches - fewer 64-stream groups than CUs): the four waves of a workgroup share ONE sixteen-stream tile and split
+    // the band's layer-2 column tiles between them (layer 1 - 16 MFMAs - is computed by each): a wide band's five dependent 16-MFMA items were
+    // the kernel's critical path
+    const bool split = a.mlp_tpw == 0;
+    const int tpw = a.mlp_tpw > 1 ? a.mlp_tpw : 1;
+    const int tile0 = split ? tg : (tg * kWaves + wave) * tpw;
+    if (tile0 * 16 >= a.B) return;                            // (wave-uniform; the kernel has no barrier)
+    const int n2 = 4 * bsrnn_band_sub(band);
+    const int nit_all = ((n2 + 15) >> 4) * NB;
+    // (split: this wave's items are wave, wave + 4, ... of the band's list - whole column tiles: NB = 1 there)
+    const bool wsplit = split && NB == 1;
+    const int nit = wsplit ? (nit_all - wave + kWaves - 1) / kWaves : nit_all;
+    if (wsplit && nit <= 0) return;                           // (a narrow band: fewer column tiles than waves)
+    bsrnn_mlp_wave<S, false>(a, smem + wave * (16 * LDH), kind, band, tile0, tpw, wsplit ? wave : 0, wsplit ? kWaves : 1, nit, lane);
 }
 
 struct SbOffsets;
@@ -1270,6 +1291,15 @@ void blaunch_split_impl(const BArgs& a, int max_wgs, hipStream_t st, hipError_t*
     // waves, the layers' matrix-core work under them on the other two).  a.ov_off (fe_set_step_kernel(WAVES4) / fe_set_option("bsrnn_role_split", 0)):
     // the phase-by-phase kernel.
     if (S::C == 16 && !a.ov_off && a.B <= max_wgs && a.clk != nullptr) blaunch_ov<S, true>(a, a.B, st, err);      // (fe_profile_step with fe_set_option("bsrnn_ov_profile", 1))
+    else if (S::C == 16 && !a.ov_off && a.B <= max_wgs && a.gsync != nullptr) {
+        // r6: the whole step in ONE cooperative launch (fe_set_option("bsrnn_fused_step", 1); MEASURED NEGATIVE - 81 us against 77, and the
+        // cooperative launch adds ~21 us on top: profiles/r6_bsrnn_fused_step.txt - hence off by default); a launch the runtime refuses
+        // (co-residency not guaranteed) falls through to the three launches
+        blaunch_ov<S, false, true>(a, a.B, st, err);
+        if (*err == hipSuccess) return;
+        *err = hipSuccess;
+        blaunch_ov<S>(a, a.B, st, err);
+    }
     else if (S::C == 16 && !a.ov_off && a.B <= max_wgs) blaunch_ov<S>(a, a.B, st, err);
     else if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 1>(a, a.B < 2 * max_wgs ? a.B : 2 * max_wgs, st, err);
     else blaunch_part<S, false, 1>(a, a.B < max_wgs ? a.B : max_wgs, st, err);

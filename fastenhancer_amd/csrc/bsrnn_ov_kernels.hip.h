@@ -76,7 +76,38 @@ __device__ __forceinline__ int ov_band(int i) {
 
 // PROF: cycle probes of workgroup 0, sixteen per wave (clk[16 wave + i]; tools/gpu_phases_bsrnn_ov.py)
 #define OV_CLK(i) do { if constexpr (PROF) { if (blockIdx.x == 0 && lane == 0) a.clk[16 * wave + (i)] = __builtin_readcyclecounter(); } } while (0)
-template <class S, bool PROF = false>
+// Arrival at / wait for a barrier over the (up to) sixteen workgroups of one sixteen-stream tile of a FUSED launch.  A monotonic counter in global
+// memory per tile and barrier: every barrier instance advances it by exactly 16 (the first workgroup of a short last tile arrives for the absent
+// ones), so the instance a workgroup takes part in is old / 16 and it is over at (old / 16 + 1) * 16 - no reset, no generation word, no epoch in the
+// kernel arguments (a captured HIP graph replays the same arguments), unsigned wrap-around included.  Data handed across the barrier goes through
+// agent-scope stores drained with s_waitcnt vmcnt(0) before the arrival, and agent-scope loads after it (the protocol of the time-pipelined
+// kernels: no release / acquire fences, which write back / invalidate whole caches on this part).  All workgroups of the launch are
+// co-resident: one per CU, at most #CUs of them, launched cooperatively.
+__device__ __forceinline__ void ov_group_barrier(unsigned int* cnt, unsigned int arrive) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): this thread's stores have left the CU
+    __syncthreads();
+#ifdef FE_EXP_FUS_NOBAR      // (timing experiment: no waiting for the other workgroups)
+    return;
+#endif
+    if (threadIdx.x == 0) {
+        const unsigned int old = __hip_atomic_fetch_add(cnt, arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int target = (old / 16u + 1u) * 16u;
+        unsigned int spins = 0;
+        while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 28)) __builtin_trap();        // (a workgroup of the tile that never arrives: fail the launch loudly)
+        }
+    }
+    __syncthreads();
+}
+
+// FUSED (r6): the whole per-hop step in ONE launch - after the layers the workgroups of a sixteen-stream tile meet at a barrier, run the mask
+// decoder's two MLP layers for their sixteen streams on the matrix cores (one (kind, band) job per WAVE: 62 jobs + the widest band split in two
+// = the tile's 64 waves), meet again, and every workgroup finishes its own stream (GLU, mask, un-compress, inverse transform, overlap-add).
+// The three-launch step pays ~4.8 us per kernel boundary (an empty bsrnn_mlp_kernel: profiles/r3zz_*) twice in a 77-us step - but a barrier
+// over sixteen workgroups on eight XCDs measured 5.9 us, and a cooperative launch ~21 us more than a plain one: NEGATIVE (81 / 102 us),
+// profiles/r6_bsrnn_fused_step.txt.  Kept behind fe_set_option("bsrnn_fused_step", 1), bit-identical to the three launches.
+template <class S, bool PROF = false, bool FUSED = false>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) bsrnn_ov_kernel(BArgs a) {
     static_assert(S::C == 16 && S::HH == 32 && S::NFFT == 512, "the role-split kernel is built for num_channels = 16");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -533,21 +564,131 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
     }
     __syncthreads();
     OV_CLK(10);
-    // hand-over to bsrnn_mlp_kernel / the PART 2 launch: band features after the last layer, the compressed spectrum
-    {
+    if constexpr (!FUSED) {
+        // hand-over to bsrnn_mlp_kernel / the PART 2 launch: band features after the last layer, the compressed spectrum
         float* xg = a.mlp_x + (size_t)b * (kBands * C);
         for (int i = tid; i < kBands * C; i += kThreads) { const int bb = i / C; xg[i] = XB[bb * LDX + (i - bb * C)]; }
         float* sg = a.mlp_sp + (size_t)b * (2 * kBins);
         for (int i = tid; i < 2 * kBins; i += kThreads) sg[i] = sp[i];
+        OV_CLK(11);
+    } else {
+        // ============================ mask decoder for the sixteen-stream tile (MaskDecoder.forward, :225-246) ============================
+        const int tile = b >> 4, r16 = b & 15;
+        const int members = a.B - 16 * tile < 16 ? a.B - 16 * tile : 16;       // workgroups of this tile (a short last tile)
+        unsigned int* gcnt = a.gsync + 2 * tile;
+        const unsigned int arrive = r16 == 0 ? (unsigned int)(16 - members + 1) : 1u;
+        {
+            float* xg = a.mlp_x + (size_t)b * (kBands * C);
+            for (int i = tid; i < kBands * C; i += kThreads) {
+                const int bb = i / C;
+                __hip_atomic_store(xg + i, XB[bb * LDX + (i - bb * C)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        ov_group_barrier(gcnt, arrive);
+        // the tail's constants, requested now: the inverse transform's operands, the synthesis window, the old overlap tail, the bins' row tables
+        using DI = Dft<S, 3>;
+        typename DI::InvConst idc;
+        DI::load(idc, wb, o, wave);
+        constexpr int OPT = (N + kThreads - 1) / kThreads, FPT = (kBins + kThreads - 1) / kThreads;
+        float* cis = a.cache_istft + (size_t)b * OVL;
+        float ocis[OPT], owin[OPT];
+        int bra[FPT], brg[FPT];
+#pragma unroll
+        for (int q = 0; q < OPT; ++q) {
+            const int n = tid + q * kThreads;
+            ocis[q] = n < OVL ? cis[n] : 0.0f;
+            owin[q] = wp[o.window_istft + (n < N ? n : N - 1)];
+        }
+        {
+            const int* bin_row = reinterpret_cast<const int*>(wp + o.bin_row);
+            const int* bin_2sub = reinterpret_cast<const int*>(wp + o.bin_2sub);
+#pragma unroll
+            for (int q = 0; q < FPT; ++q) {
+                const int f = tid + q * kThreads < kBins ? tid + q * kThreads : kBins - 1;
+                bra[q] = bin_row[f];
+                brg[q] = bin_2sub[f];
+            }
+        }
+        // unit u of the tile's 64: (kind, band) jobs in cost order - bands 30 (five layer-2 items, two waves: items 0-2 / 3-4), 29 .. 23 (four),
+        // 22 .. 11 (two), 10 .. 0 (one) - dealt round-robin over the workgroups (unit u on wave u / 16 of workgroup u % 16); a workgroup of a
+        // short tile also takes the units of the absent ones
+        {
+            float* h1 = smem + L::XP + wave * (16 * BMlpLds<S>::LDH);          // (the projection buffers are dead)
+            static_assert(kWaves * 16 * BMlpLds<S>::LDH + 2 * kMlpRows <= 2 * L::XPBUF, "MLP hidden tiles + pre-activations alias the projection buffers");
+#pragma unroll 1
+            for (int vr = r16; vr < 16; vr += members) {
+                const int u = 16 * wave + vr;
+                int kind, band, it0, nitw;
+                if (u < 4) { kind = u >> 1; band = 30; it0 = (u & 1) ? 3 : 0; nitw = (u & 1) ? 2 : 3; }
+                else {
+                    const int j = u - 4;                       // 60 single-wave jobs: bands 29 .. 0 of kind j & 1
+                    kind = j & 1; band = 29 - (j >> 1); it0 = 0;
+                    nitw = (4 * bsrnn_band_sub(band) + 15) >> 4;
+                }
+#ifndef FE_EXP_FUS_NOMLP      // (timing experiment: the fused step without its mask decoder)
+                bsrnn_mlp_wave<S, true>(a, h1, kind, band, tile, 1, it0, 1, nitw, lane);
+#endif
+            }
+        }
+        ov_group_barrier(gcnt + 1, arrive);
+        // ============================ GLU, mask, un-compress (:393-401), iSTFT (functional/audio_modules.py:259-303) ============================
+        float* PRE = smem + L::XP + kWaves * 16 * BMlpLds<S>::LDH;
+        {
+            const float* pg = a.mlp_pre + (size_t)b * (2 * kMlpRows);
+            for (int i = tid; i < 2 * kMlpRows; i += kThreads) PRE[i] = __hip_atomic_load(pg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        float* Ys = smem + L::FA;                  // {Re[N/2], Im[N/2]}, then Re of the Nyquist bin
+#pragma unroll
+        for (int q = 0; q < FPT; ++q) {
+            const int f = tid + q * kThreads;
+            if (f >= kBins) break;
+            const int ra = bra[q], rg = ra + brg[q];
+            float mr[4];
+#pragma unroll
+            for (int kind = 0; kind < 2; ++kind)
+#pragma unroll
+                for (int ri = 0; ri < 2; ++ri)
+                    mr[kind * 2 + ri] = PRE[kind * kMlpRows + ra + ri] * sigmoid_f(PRE[kind * kMlpRows + rg + ri]);
+            const float xr_ = sp[2 * f], xi_ = sp[2 * f + 1];
+            float yr = xr_ * mr[0] - xi_ * mr[1] + mr[2];
+            float yi = xr_ * mr[1] + xi_ * mr[0] + mr[3];
+            const float g = pow_f(sqrtf(yr * yr + yi * yi), 1.0f / a.compression - 1.0f);
+            yr *= g;
+            yi *= g;
+            if (f < N / 2) { Ys[f] = yr; Ys[N / 2 + f] = yi; }
+            else Ys[N] = yr;
+        }
+        __syncthreads();
+        {
+            // irfft keeps Re X[N/2] only and ignores Im X[0]: the transform covers bins 0 .. N/2 - 1, the Nyquist bin is (-1)^n X[N/2] / N
+            float* P0 = smem + L::FB;
+            float* P1 = P0 + N;
+            DI::template inverse<WSrc<false>, true>(Ys, P0, P1, tw, idc, wb, o, wave, lane);
+            const float nyq = Ys[N] * (1.0f / (float)N);
+            float* out = a.wav_out + (size_t)b * a.out_stride;
+            float vo[OPT];
+#pragma unroll
+            for (int q = 0; q < OPT; ++q) {
+                const int n = tid + q * kThreads, nc = n < N ? n : N - 1;
+                const int pi = DI::pidx(nc & (DI::N1 - 1), nc / DI::N1);
+                vo[q] = (P0[pi] + P1[pi] + ((nc & 1) ? -nyq : nyq)) * owin[q] + ocis[q];
+            }
+#pragma unroll
+            for (int q = 0; q < OPT; ++q) {
+                const int n = tid + q * kThreads;
+                if (n < H) out[n] = vo[q];
+                else if (n < N) cis[n - H] = vo[q];
+            }
+        }
     }
-    OV_CLK(11);
 }
 #undef OV_CLK
 
-template <class S, bool PROF = false>
+template <class S, bool PROF = false, bool FUSED = false>
 void blaunch_ov(const BArgs& a, int grid, hipStream_t st, hipError_t* err) {
     if constexpr (S::C == 16) {
-        auto* fn = &bsrnn_ov_kernel<S, PROF>;
+        auto* fn = &bsrnn_ov_kernel<S, PROF, FUSED>;
         static std::atomic<bool> attr_set[64];
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -555,6 +696,22 @@ void blaunch_ov(const BArgs& a, int grid, hipStream_t st, hipError_t* err) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BOvLds<S>::BYTES);
             if (e != hipSuccess) { *err = e; return; }
             attr_set[dev].store(true, std::memory_order_relaxed);
+        }
+        if constexpr (FUSED) {
+            // the workgroups of a sixteen-stream tile wait for each other: a cooperative launch (co-residency guaranteed, or refused)
+            static const bool plain = [] { const char* e = getenv("FE_EXP_FUSED_PLAIN"); return e && e[0] == '1'; }();      // (timing experiment)
+            if (plain) {
+                hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), BOvLds<S>::BYTES, st, a);
+                *err = hipGetLastError();
+                note_kernel("bsrnn_ov_kernel<fused step, plain launch>");
+                return;
+            }
+            BArgs args = a;
+            void* kargs[] = {&args};
+            *err = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(grid), dim3(kThreads), kargs, (unsigned int)BOvLds<S>::BYTES, st);
+            if (*err == hipSuccess) note_kernel("bsrnn_ov_kernel<fused step>");
+            else (void)hipGetLastError();
+            return;
         }
         note_kernel(PROF ? "bsrnn_ov_kernel<profile>" : "bsrnn_ov_kernel");
         hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), BOvLds<S>::BYTES, st, a);

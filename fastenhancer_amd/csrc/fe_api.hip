@@ -38,7 +38,7 @@ thread_local std::string g_err;
 
 // fe_set_option / fe_get_option.  `env`: the environment variable that sets the value NEW handles start with (A/B scripts under tools/);
 // out-of-range or non-numeric values are ignored.
-enum { OPT_BSRNN_ROLE_SPLIT = 0, OPT_BSRNN_SB_MIN, OPT_BSRNN_THREE_LAUNCH, OPT_BSRNN_OV_PROFILE, OPT_FSPEN_SB_MIN, OPT_LOW_LDS_COMPANION, OPT_COUNT };
+enum { OPT_BSRNN_ROLE_SPLIT = 0, OPT_BSRNN_SB_MIN, OPT_BSRNN_THREE_LAUNCH, OPT_BSRNN_OV_PROFILE, OPT_FSPEN_SB_MIN, OPT_LOW_LDS_COMPANION, OPT_BSRNN_FUSED, OPT_COUNT };
 struct OptionDef { const char* name; const char* env; int dflt, lo, hi; };
 constexpr OptionDef kOptions[OPT_COUNT] = {
     {"bsrnn_role_split", "FE_BSRNN_OV", 1, 0, 1},
@@ -47,6 +47,7 @@ constexpr OptionDef kOptions[OPT_COUNT] = {
     {"bsrnn_ov_profile", "FE_BSRNN_OV_PROF", 0, 0, 1},
     {"fspen_stream_batch_min", "FE_FSPEN_SB", 1536, 0, 1 << 24},
     {"low_lds_companion", "FE_LOWLDS", 1, 0, 1},
+    {"bsrnn_fused_step", "FE_BSRNN_FUSED", 0, 0, 1},      // (measured negative: profiles/r6_bsrnn_fused_step.txt)
 };
 int env_int(const char* name, int dflt, int lo, int hi) {
     const char* e = std::getenv(name);
@@ -172,6 +173,7 @@ struct fe_handle {
     float* tb_work_dev = nullptr;             // fe_spec_step on the time-batched engine: grow-only work buffer
     float* spec_ring_dev = nullptr;           // fe_spec_step, dptransformer, time-pipelined: the K / V rings of TA + P slots per pair (grow-only)
     size_t spec_ring_floats = 0;
+    unsigned int* bsync_dev = nullptr;        // BSRNN fused per-hop step: barrier counters of the sixteen-stream tiles [kSyncTiles][2] (zeroed once; monotonic)
     float* bsplit_dev = nullptr;              // BSRNN per-hop step in three launches: band features | compressed spectrum | MLP pre-activations
     int bsplit_streams = 0;                   // (grow-only, sized by fe_state_init / the first step of a larger batch)
     size_t tb_work_floats = 0;
@@ -748,6 +750,7 @@ fe::BArgs bsrnn_args(fe_handle* h, int B, int T) {
 // The per-hop BSRNN step runs as three launches (bsrnn_kernels.hip.h, PART): per stream 31 C floats of band features, 514 of compressed
 // spectrum and 2056 of MLP pre-activations pass through this scratch.  Grow-only; fe_state_init sizes it for its batch, so that a
 // steady-state step allocates nothing (FE_BSRNN_SPLIT=0: the fused kernel, for A/B measurements).
+constexpr int kSyncTiles = 64;       // sixteen-stream tiles of a fused BSRNN step (one workgroup per CU: 1024 CUs)
 size_t bsplit_floats_per_stream(const fe_handle* h) {
     return (size_t)31 * h->cfg.channels + 2 * 257 + 2 * 1028 + (h->bimpl->launch_sb ? (size_t)2 * 31 * 2 * h->cfg.channels : 0);      // (+ the stream-batched layers' y scratch)
 }
@@ -757,6 +760,10 @@ int ensure_bsplit(fe_handle* h, int B) {
     if (h->bsplit_dev) { FE_HIP_CHECK(hipFree(h->bsplit_dev)); h->bsplit_dev = nullptr; h->bsplit_streams = 0; }
     FE_HIP_CHECK(hipMalloc(&h->bsplit_dev, (size_t)B * bsplit_floats_per_stream(h) * sizeof(float)));
     h->bsplit_streams = B;
+    if (!h->bsync_dev) {
+        FE_HIP_CHECK(hipMalloc(&h->bsync_dev, kSyncTiles * 2 * sizeof(unsigned int)));
+        FE_HIP_CHECK(hipMemset(h->bsync_dev, 0, kSyncTiles * 2 * sizeof(unsigned int)));
+    }
     return FE_OK;
 }
 
@@ -775,6 +782,7 @@ int launch_bsrnn(fe_handle* h, const fe::BArgs& a_in, void* stream) {
             a.mlp_sp = a.mlp_x + (size_t)a.B * 31 * h->cfg.channels;
             a.mlp_pre = a.mlp_sp + (size_t)a.B * 2 * 257;
             a.sb_y = a.mlp_pre + (size_t)a.B * 2 * 1028;
+            a.gsync = (h->opt[OPT_BSRNN_FUSED] && a.clk == nullptr && (a.B + 15) / 16 <= kSyncTiles) ? h->bsync_dev : nullptr;
             // large batches: the LSTM layers batched over the streams on the matrix cores (sixteen streams per workgroup) - from the batch
             // size where sixteen-stream workgroups fill the chip better than one stream per workgroup (FE_BSRNN_SB: that threshold; 0 = never)
             const int sb_min = h->opt[OPT_BSRNN_SB_MIN];      // (default 2048; measured crossover on 256 CUs: ~1900 streams, profiles/r4c_bsrnn_stream_batched.txt)
@@ -979,6 +987,7 @@ void fe_destroy(fe_handle* h) {
     if (h->tb_work_dev) (void)hipFree(h->tb_work_dev);
     if (h->spec_ring_dev) (void)hipFree(h->spec_ring_dev);
     if (h->bsplit_dev) (void)hipFree(h->bsplit_dev);
+    if (h->bsync_dev) (void)hipFree(h->bsync_dev);
     for (hipStream_t s : h->host_streams) if (s) (void)hipStreamDestroy(s);
     for (hipEvent_t e : h->host_events) if (e) (void)hipEventDestroy(e);
     delete h;

@@ -33,6 +33,9 @@ namespace fe {
 // block's GRU phase shrinks by 0.67 k instead of 1.15 k - its GEMM, now on ONE wave per SIMD, runs at 57 cycles per MFMA (LDS operand
 // latency that the second wave of a SIMD used to cover).
 // (FE_WG8_HPRE defaults to 0 in fe_kernels.hip.h: the packed section u8_gh4 exists in such builds only)
+#ifndef FE_WG8_MIXSPLIT
+#define FE_WG8_MIXSPLIT 1
+#endif
 constexpr int kThreads8 = 512;
 constexpr int kWaves8 = 8;
 
@@ -58,7 +61,12 @@ struct Wg8 {
     // The new GRU states of the KB blocks wait in LDS for the end of the frame and leave as whole lines (HST, when it fits): stored from the GRU
     // epilogues - 64-byte pieces of [F2][C2] rows - their acknowledgements were charged to the next vmcnt wait of the weight staging
     // (vmcnt counts loads and stores in order): 0.6 us of the 31.6 us frame (same-box timing experiment, profiles/r4a_wg8_steps.txt)
-    static constexpr int HST = L::NOSTAGE_TOTAL + 4 * SLOT;
+    // r6 (FE_WG8_MIXSPLIT): the mixed gate tile's x half and h half are computed by different waves (4 / 5: x, 6 / 7: h - 63 MFMAs per SIMD instead
+    // of 72 / 72 / 54 / 54); both write their raw sums here, [half][row tile][16 rows][LDM], and the h-half wave finishes the tile's gate math
+    // one element per lane.  + 4 words: the x-half waves' "written" counters per row tile (monotonic: frame * KB + block + 1)
+    static constexpr int LDM = 13;
+    static constexpr int MXB = L::NOSTAGE_TOTAL + 4 * SLOT, MX_FLOATS = round_up(4 * 16 * LDM + 4, 4), MXF = MXB + 4 * 16 * LDM;
+    static constexpr int HST = MXB + MX_FLOATS;
     static constexpr bool HSTASH = (size_t)(HST + S::KB * S::F2 * S::C2) * 4 <= 160 * 1024;
     static constexpr size_t BYTES = (size_t)(HST + (HSTASH ? S::KB * S::F2 * S::C2 : 0)) * 4;
     static constexpr int NPWB = ceil_div(ceil_div(SLOT, 256), kWaves8);      // pieces per wave of a block unit
@@ -171,6 +179,7 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
         st0(0, 1);
         float2 twv = make_float2(0.0f, 0.0f);
         if (tid < N / 2) twv = reinterpret_cast<const float2*>(wp + o.twiddle)[tid];
+        // (r6: committing unit 1 after the forward DFT instead of here - vmcnt completes in order, the first barrier waits for its 28 KiB - measured neutral: 30.76 / 30.76 us)
         DmaJobT<NPW> job1 = job;
         job1.l = smem + W8::WB1;
         job1.soff = (o.u_off[1] + wave * 256) * 4;
@@ -188,6 +197,7 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
             smem[L::E + e * S::ACT + (q >= LDC ? (F1 + 1) * LDC + (q - LDC) : q)] = 0.0f;
         }
         if (tid < N / 2) tw[tid] = twv;
+        if (tid < 4) smem[W8::MXF + tid] = 0.0f;          // (the mixed tile's hand-over counters: ints, 0)
         st0.commit();
         if constexpr (!PERSIST) {
             st1.commit();
@@ -638,7 +648,75 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
                             else hg[row * C2 + ch] = hn[r];
                         }
                     }
-                } else if (wave < 6) {
+                }
+#if FE_WG8_MIXSPLIT
+                else {
+                    // r6: the mixed tile (the left-over R channels' r | z | n columns) of row tile g_rt, x half on waves 4 / 5, h half on waves
+                    // 6 / 7: 9 MFMAs each next to the 54 of their SIMD's channel-group job - 63 MFMAs per SIMD.  Each half goes to LDS as a
+                    // [16 rows][3 R columns] matrix; the h-half wave waits for its partner's counter (a wave's LDS operations execute in order)
+                    // and finishes the R channels one (row, channel) per lane.  Same chains, same summation order, same gate arithmetic as the
+                    // one-wave form (bit-identical results).
+                    constexpr int R = S::G8_R, LDM = W8::LDM;
+                    const bool hhalf = wave >= 6;
+                    float* mx = smem + W8::MXB + ((hhalf ? 2 : 0) + g_rt) * (16 * LDM);
+                    int* mflag = reinterpret_cast<int*>(smem + W8::MXF) + g_rt;
+                    const int seq = fc * S::KB + k + 1;
+                    f32x4 s0, s1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    __builtin_amdgcn_s_setprio(3);
+                    if (!hhalf) {
+                        const float b0 = bx[0];
+                        s0 = f32x4{b0, b0, b0, b0};
+                        mma_panel_sel<1, 1, K2, PDK>([&](int, int, int ks) -> f32x4& { return (ks & 1) ? s1 : s0; },
+                                                     [&](int, int ks) { return FE8_A(xa[4 * ks], ks); }, [&](int, int ks) { return FE8_B(wx[ks * 64], ks); }, sideg);
+                    } else {
+                        const float b1 = bh[0];
+                        s0 = f32x4{b1, b1, b1, b1};
+                        // (the one-wave form ran x and h as ONE 2 K2-step panel with chains by the parity of the global k-step: K2 is odd here,
+                        // so the biased chain took the h half's odd local steps)
+                        mma_panel_sel<1, 1, K2, PDK>([&](int, int, int ks) -> f32x4& { return ((ks + K2) & 1) ? s1 : s0; },
+                                                     [&](int, int ks) { return FE8_A(ha[4 * ks], ks); }, [&](int, int ks) { return FE8_B(wh_[ks * 64], ks); }, sideg);
+                    }
+                    // (the priority stays raised through the hand-over and the gate math: at priority 0 every instruction of this dependent chain
+                    // waited for a gap between the MFMAs of the SIMD's 54-MFMA job - 1.5 k cycles for ~35 instructions, and this wave arrived last)
+                    s0 += s1;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k == 0) FE_CLK(46);
+                    if (li < 3 * R) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx[(4 * lg + r) * LDM + li] = s0[r];
+                    }
+                    if (!hhalf) {
+                        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the writes above are in LDS
+                        if (lane == 0) __hip_atomic_store(mflag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                    } else {
+                        const int row = lane >> 2, c = lane & 3;
+                        static_assert(R == 4, "one (row, channel) per lane: sixteen rows x four channels");
+                        const int ch = 16 * S::G8_NG + c;
+                        const bool live = 16 * g_rt + row < F2;
+                        const float hprev = Hs[(16 * g_rt + row) * LDX + ch];
+                        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(mflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < seq) {}
+                        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                        const float* mxx = smem + W8::MXB + g_rt * (16 * LDM) + row * LDM + c;
+                        const float* mxh = mx + row * LDM + c;
+                        const float sxr = mxx[0], sxz = mxx[R], sxn = mxx[2 * R];
+                        const float shr = mxh[0], shz = mxh[R], shn = mxh[2 * R];
+                        const float rr = sigmoid_pre(sxr + shr);
+                        const float zz = sigmoid_pre(sxz + shz);
+                        const float nn = tanh_pre(__builtin_fmaf(rr, shn, sxn));
+                        const float hn = __builtin_fmaf(zz, hprev - nn, nn);          // (1 - z) n + z h
+                        if (live) {
+                            Hl[(16 * g_rt + row) * LDX + ch] = hn;
+                            if constexpr (W8::HSTASH) smem[W8::HST + k * (F2 * C2) + (16 * g_rt + row) * C2 + ch] = hn;
+                            else hg[(16 * g_rt + row) * C2 + ch] = hn;
+                        }
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                }
+#else
+                else if (wave < 6) {
                     // the mixed tile: lanes li < R hold r, R .. 2 R - 1 z, 2 R .. 3 R - 1 n of channel 16 NG + li % R; the z and n values
                     // move down to the r lanes (DPP row shifts), which finish the R channels.  (18 dependent MFMAs next to the 54
                     // independent ones of this SIMD's big job: two chains per half, and a raised priority - arbitrated oldest-first,
@@ -706,6 +784,7 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
                     for (int g = 0; g < NSG; ++g) sideg(g, NSG);
                 }
+#endif
 #endif
                 st1.commit();
                 st2.commit();

@@ -202,8 +202,13 @@ int fe_set_step_kernel(fe_handle* h, int kernel);
  *   "fspen_stream_batch_min"   0 .. 2^24  1536     FSPEN: from this many streams the middle of the network runs batched over the streams; 0 = never
  *   "low_lds_companion"        0 | 1      1        FastEnhancer per-hop step above one stream per CU: the low-LDS companion kernel (two workgroups
  *                                                  per CU) where one is compiled; 0 = persistent workgroups of the shape's own kernel
+ *   "bsrnn_fused_step"         0 | 1      0        BSRNN, num_channels 16, up to one stream per CU (r6): the whole per-hop step in ONE cooperative launch -
+ *                                                  the workgroups of a sixteen-stream tile meet at a barrier after the layers, run the mask decoder for
+ *                                                  their tile, meet again and finish their own streams; 0 = three launches (a launch the runtime
+ *                                                  refuses falls back to them by itself).  Bit-identical results; MEASURED SLOWER (barriers across XCDs,
+ *                                                  cooperative launch: profiles/r6_bsrnn_fused_step.txt), hence off by default
  * A/B scripts (tools/ab_*.sh) preset the values NEW handles start with through FE_BSRNN_OV, FE_BSRNN_SB, FE_BSRNN_SPLIT, FE_BSRNN_OV_PROF,
- * FE_FSPEN_SB, FE_LOWLDS (FE_NO_LOWLDS) and FE_WG8 (the step kernel): read once, in fe_create, validated against the same ranges (anything else
+ * FE_FSPEN_SB, FE_LOWLDS (FE_NO_LOWLDS), FE_BSRNN_FUSED and FE_WG8 (the step kernel): read once, in fe_create, validated against the same ranges (anything else
  * is ignored).  The reference has one forward per model and nothing to select (models/fastenhancer/default/model.py:677-710). */
 int fe_set_option(fe_handle* h, const char* name, int value);
 int fe_get_option(const fe_handle* h, const char* name, int* value);

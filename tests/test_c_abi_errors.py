@@ -218,7 +218,7 @@ def test_options_are_enumerable_validated_and_preset_by_their_environment_variab
     import re
     lib = _lib.load()
     names = [lib.fe_option_name(i).decode() for i in range(lib.fe_options())]
-    assert names == ["bsrnn_role_split", "bsrnn_stream_batch_min", "bsrnn_three_launch_step", "bsrnn_ov_profile", "fspen_stream_batch_min", "low_lds_companion"]
+    assert names == ["bsrnn_role_split", "bsrnn_stream_batch_min", "bsrnn_three_launch_step", "bsrnn_ov_profile", "fspen_stream_batch_min", "low_lds_companion", "bsrnn_fused_step"]
     assert lib.fe_option_name(len(names)) is None and lib.fe_option_name(-1) is None
     header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fastenhancer_hip.h")).read()
     integration = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
@@ -227,8 +227,8 @@ def test_options_are_enumerable_validated_and_preset_by_their_environment_variab
         assert n in integration, n
     assert "fe_last_step_kernel" in header and "fe_last_step_kernel" in integration
     defaults = {"bsrnn_role_split": 1, "bsrnn_stream_batch_min": 2048, "bsrnn_three_launch_step": 1, "bsrnn_ov_profile": 0,
-                "fspen_stream_batch_min": 1536, "low_lds_companion": 1}
-    for v in ("FE_BSRNN_OV", "FE_BSRNN_SB", "FE_BSRNN_SPLIT", "FE_BSRNN_OV_PROF", "FE_FSPEN_SB", "FE_LOWLDS", "FE_NO_LOWLDS", "FE_WG8"):
+                "fspen_stream_batch_min": 1536, "low_lds_companion": 1, "bsrnn_fused_step": 0}
+    for v in ("FE_BSRNN_OV", "FE_BSRNN_SB", "FE_BSRNN_SPLIT", "FE_BSRNN_OV_PROF", "FE_FSPEN_SB", "FE_LOWLDS", "FE_NO_LOWLDS", "FE_WG8", "FE_BSRNN_FUSED"):
         monkeypatch.delenv(v, raising=False)
     rc, h = _create(_cfg())
     assert rc == 0
@@ -414,6 +414,9 @@ def test_last_step_kernel_names_what_was_dispatched():
         return beng.last_step_kernel()
 
     assert bstep(4) == "bsrnn_ov_kernel + bsrnn_mlp_kernel<one 16-stream tile per workgroup> + bsrnn_frame_kernel<PART 2> [shape xt]"
+    beng.set_option("bsrnn_fused_step", 1)                                                  # r6 (measured negative, off by default): the whole step in one cooperative launch
+    assert bstep(4) == "bsrnn_ov_kernel<fused step> [shape xt]"
+    beng.set_option("bsrnn_fused_step", 0)
     beng.set_option("bsrnn_role_split", 0)
     assert bstep(4) == "bsrnn_frame_kernel<PART 1> + bsrnn_mlp_kernel<one 16-stream tile per workgroup> + bsrnn_frame_kernel<PART 2> [shape xt]"
     beng.set_option("bsrnn_role_split", 1)

@@ -86,10 +86,10 @@ def test_graph_launch_mode_under_torchrun_matches_the_eager_run():
 # BASELINE.json's four GPU configurations exactly as bench.py times them: (workload, streams, the kernels the library must report, parity
 # bound of the family, roofline fraction of the kept matrix - profiles/r5_bench_matrix.txt / r6)
 BASELINE_GPU = [
-    ("fe_b", 256, "fe_frame8_kernel [shape B]", 3e-6, 0.43),
+    ("fe_b", 256, "fe_frame8_kernel [shape B]", 3e-6, 0.445),
     ("fe_l", 256, "fe_frame_kernel<per-hop> [shape L]", 3e-6, 0.73),
     ("fe48_b_h480", 512, "fe_frame_kernel<LOW=2, per-hop> [shape B48H480LOW]", 3e-6, 0.51),
-    ("bsrnn_xt", 256, "bsrnn_ov_kernel + bsrnn_mlp_kernel<one 16-stream tile per workgroup> + bsrnn_frame_kernel<PART 2> [shape xt]", 1e-5, 0.16),
+    ("bsrnn_xt", 256, "bsrnn_ov_kernel + bsrnn_mlp_kernel<one 16-stream tile per workgroup> + bsrnn_frame_kernel<PART 2> [shape xt]", 1e-5, 0.165),
 ]
 
 

@@ -624,6 +624,16 @@ def test_bsrnn_role_split_part1_agrees_with_the_phase_by_phase_kernel(name, B):
         outs = [eng.step(xd[:, t * H:(t + 1) * H].contiguous(), state, T=1).cpu().numpy() for t in range(hops)]
         res[kern] = (np.concatenate(outs, 1), [c.cpu().numpy() for c in eng.split_state(state, B)])
     eng.set_step_kernel("wg8")
+    # r6: the same step as ONE cooperative launch (fe_set_option("bsrnn_fused_step", 1): barriers over the workgroups of each sixteen-stream
+    # tile instead of two kernel boundaries; measured slower and off by default) - bit for bit the three launches, short last tile included
+    eng.set_option("bsrnn_fused_step", 1)
+    state = eng.new_state(B)
+    outs = [eng.step(xd[:, t * H:(t + 1) * H].contiguous(), state, T=1).cpu().numpy() for t in range(hops)]
+    assert eng.last_step_kernel().startswith("bsrnn_ov_kernel<fused step>"), eng.last_step_kernel()
+    eng.set_option("bsrnn_fused_step", 0)
+    assert np.array_equal(np.concatenate(outs, 1), res["wg8"][0]), "fused step differs from the three launches"
+    for a_, b_ in zip([c.cpu().numpy() for c in eng.split_state(state, B)], res["wg8"][1]):
+        assert np.array_equal(a_, b_)
     sel = sorted(set([0, 1, B // 2, B - 1]))
     caches = orc.initialize_cache(len(sel))
     refs = []
