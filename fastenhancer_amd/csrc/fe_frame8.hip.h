@@ -36,6 +36,14 @@ namespace fe {
 #ifndef FE_WG8_MIXSPLIT
 #define FE_WG8_MIXSPLIT 1
 #endif
+// r6: dec_post's 1x1 conv and the transposed conv behind it in ONE phase (one stream per workgroup).  The transposed conv of row tile ws reads the 1x1's
+// outputs of that row tile only - the tiles of waves (ws, 0) and (ws, 1), the two waves of SIMD ws - so the pair hands over through an LDS counter instead of
+// a workgroup barrier, and wave (ws, 0) runs the 12 MFMAs with the weight fragments it fetched into registers at the top of the phase (the phase of its own
+// cost ~1.4 k cycles for 0.4 k of matrix-pipe time).  Same chain, same summation order: bit-identical.  MEASURED NEGATIVE (30.86 -> 30.96 us, same box, parity
+// green): the 12 dependent MFMAs now trail the HEAVY wave of each SIMD alone (a lone wave's dependent 16x16x4 chain runs at ~64 cycles per MFMA) - off by default.
+#ifndef FE_WG8_FUSEPOST
+#define FE_WG8_FUSEPOST 0
+#endif
 constexpr int kThreads8 = 512;
 constexpr int kWaves8 = 8;
 
@@ -65,7 +73,7 @@ struct Wg8 {
     // of 72 / 72 / 54 / 54); both write their raw sums here, [half][row tile][16 rows][LDM], and the h-half wave finishes the tile's gate math
     // one element per lane.  + 4 words: the x-half waves' "written" counters per row tile (monotonic: frame * KB + block + 1)
     static constexpr int LDM = 13;
-    static constexpr int MXB = L::NOSTAGE_TOTAL + 4 * SLOT, MX_FLOATS = round_up(4 * 16 * LDM + 4, 4), MXF = MXB + 4 * 16 * LDM;
+    static constexpr int MXB = L::NOSTAGE_TOTAL + 4 * SLOT, MX_FLOATS = round_up(4 * 16 * LDM + 8, 4), MXF = MXB + 4 * 16 * LDM;      // (+ 4 words: FE_WG8_FUSEPOST's counters per SIMD pair)
     static constexpr int HST = MXB + MX_FLOATS;
     static constexpr bool HSTASH = (size_t)(HST + S::KB * S::F2 * S::C2) * 4 <= 160 * 1024;
     static constexpr size_t BYTES = (size_t)(HST + (HSTASH ? S::KB * S::F2 * S::C2 : 0)) * 4;
@@ -197,7 +205,7 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
             smem[L::E + e * S::ACT + (q >= LDC ? (F1 + 1) * LDC + (q - LDC) : q)] = 0.0f;
         }
         if (tid < N / 2) tw[tid] = twv;
-        if (tid < 4) smem[W8::MXF + tid] = 0.0f;          // (the mixed tile's hand-over counters: ints, 0)
+        if (tid < 8) smem[W8::MXF + tid] = 0.0f;          // (the hand-over counters of the mixed tile / the dec_post pairs: ints, 0)
         st0.commit();
         if constexpr (!PERSIST) {
             st1.commit();
@@ -964,6 +972,51 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
         FE_CLK(9);
         // =========================== dec_post (a15) ===========================
         float* PT = smem + L::PT;
+        typename Dft<S>::InvConst idc;
+        constexpr bool FUSEP = FE_WG8_FUSEPOST && !PERSIST;
+        float mb0 = 0.0f, mb1 = 0.0f;                  // the mask's two biases (FUSEP: the transposed conv's unit is not staged)
+        if constexpr (FUSEP) {
+            FE8_BEGIN_UNIT(S::U_POST);
+            (void)stage;
+            float wt[S::KS_C];
+            if (wh == 0) {
+#pragma unroll
+                for (int ks = 0; ks < S::KS_C; ++ks) wt[ks] = wb.at_g(o.post_t_w + ks * 64);
+            }
+            mb0 = wp[o.post_t_b];
+            mb1 = wp[o.post_t_b + 1];
+            {
+                const float* xa = Wx + (16 * ws + li + 1) * LDC + lg;
+                const float* sk = Ebuf + (16 * ws + li + 1) * LDC + lg;
+                conv8_pair<S, W8::NTA, W8::NTB, 2 * S::KS_C, C1, LDC, true>(
+                    wh, [&](int ks) { return ks < S::KS_C ? xa[4 * ks] : sk[4 * (ks - S::KS_C)]; },
+                    [&](int j, int ks) { return wb.at(o.post1_w + (j * (2 * S::KS_C) + ks) * 64); },
+                    [&](int j) { return wb.at16x4(o.post1_b + j * 64); }, NoSide{}, Wy, 1, ws, lane);
+            }
+            int* pflag = reinterpret_cast<int*>(smem + W8::MXF) + 4 + ws;
+            const int seq = fc + 1;
+            if (wh == 1) {
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's tile is in LDS
+                if (lane == 0) __hip_atomic_store(pflag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            } else {
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(pflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < seq) {}
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                // transposed conv as a GEMM: P[i][co * 8 + j] = sum_ci x[i][ci] w[ci][co][j]   (rows of tile ws; a wave's own LDS writes are visible to it in order)
+                const float* xa = Wy + (16 * ws + li + 1) * LDC + lg;
+                float av[S::KS_C];
+#pragma unroll
+                for (int ks = 0; ks < S::KS_C; ++ks) av[ks] = xa[4 * ks];
+                f32x4 pacc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int ks = 0; ks < S::KS_C; ++ks) pacc = FE_MFMA(av[ks], wt[ks], pacc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) PT[(16 * ws + 4 * lg + r) * S::LDP + li] = pacc[r];
+                Dft<S>::load(idc, wb, o, wave);               // iSTFT constants, in flight during the mask phase
+            }
+        } else {
         {
             FE8_BEGIN_UNIT(S::U_POST);
             const float* xa = Wx + (16 * ws + li + 1) * LDC + lg;
@@ -974,7 +1027,6 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
                 [&](int j) { return wb.at16x4(o.post1_b + j * 64); }, stage, Wy, 1, ws, lane);
         }
         __syncthreads();
-        typename Dft<S>::InvConst idc;
         {
             // transposed conv as a GEMM: P[i][co * 8 + j] = sum_ci x[i][ci] w[ci][co][j]   (one channel tile: the wh = 0 waves)
             FE8_BEGIN_UNIT(S::U_POST + 1);
@@ -983,13 +1035,16 @@ __global__ void __launch_bounds__(kThreads8) __attribute__((amdgpu_waves_per_eu(
                 wh, [&](int ks) { return xa[4 * ks]; }, [&](int j, int ks) { return wb.at(o.post_t_w + (j * S::KS_C + ks) * 64); },
                 [&](int) { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }, stage, PT, 0, ws, lane);
             if (wave < 4) Dft<S>::load(idc, wb, o, wave);         // iSTFT constants, in flight during the mask phase
+            mb0 = wb.scalar(o.post_t_b);
+            mb1 = wb.scalar(o.post_t_b + 1);
+        }
         }
         __syncthreads();
 
         FE_CLK(10);
         // =========================== mask, un-compress (a16, a17) ===========================
         {
-            const float b0 = wb.scalar(o.post_t_b), b1 = wb.scalar(o.post_t_b + 1);
+            const float b0 = mb0, b1 = mb1;
             for (int f = tid; f < F0; f += NTH) {
                 const int q = f + 2, j1 = q & 3, i1 = q >> 2;
                 float m0 = b0, m1 = b1;

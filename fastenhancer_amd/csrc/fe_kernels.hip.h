@@ -470,6 +470,7 @@ struct StageSide {
 struct NoSide {
     static constexpr int loads(int, int) { return 0; }
     __device__ __forceinline__ void operator()(int, int) const {}
+    __device__ __forceinline__ void commit() const {}
 };
 template <class A, class B>
 struct Side2 {
