@@ -373,10 +373,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
             float yf[2 * KSH];
 #pragma unroll
             for (int ks = 0; ks < 2 * KSH; ++ks) yf[ks] = ya[4 * ks];
-            f32x4 c0 = x + Wf2b, c1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            // (r6: four accumulator chains of four instead of two of eight - a lone wave's dependent 16x16x4 chain runs at ~64 cycles per MFMA, and
+            // tile B's chain is serial with the scans; the order is the same on both waves of a pair, whose x must agree bit for bit)
+            f32x4 c0 = x + Wf2b, c1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, c2 = c1, c3 = c1;
 #pragma unroll
-            for (int ks = 0; ks < 2 * KSH; ks += 2) { c0 = FE_MFMA(Wf2[ks], yf[ks], c0); c1 = FE_MFMA(Wf2[ks + 1], yf[ks + 1], c1); }
-            x = c0 + c1;
+            for (int ks = 0; ks < 2 * KSH; ks += 4) {
+                c0 = FE_MFMA(Wf2[ks], yf[ks], c0); c1 = FE_MFMA(Wf2[ks + 1], yf[ks + 1], c1);
+                c2 = FE_MFMA(Wf2[ks + 2], yf[ks + 2], c2); c3 = FE_MFMA(Wf2[ks + 3], yf[ks + 3], c3);
+            }
+            x = (c0 + c1) + (c2 + c3);
         }
         cclk(1);
         if constexpr (!TIME) {
@@ -389,13 +394,15 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         }
         else {
         // time-LSTM gates (LSTMCell over the bands; :371-381): the x half on top of the accumulated h half, gate math in the epilogue
-        f32x4 acc[4];
+        f32x4 acc[4], acc2[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = hh[T][g];
+        for (int g = 0; g < 4; ++g) { acc[g] = hh[T][g]; acc2[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; r += 2)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = FE_MFMA(Wtx[g][r], x[r], acc[g]);
+            for (int g = 0; g < 4; ++g) { acc[g] = FE_MFMA(Wtx[g][r], x[r], acc[g]); acc2[g] = FE_MFMA(Wtx[g][r + 1], x[r + 1], acc2[g]); }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] += acc2[g];
         cclk(2);
         f32x4 hn, cn;
 #pragma unroll
@@ -427,10 +434,13 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1
         // 16..31 into c1, whoever produced them): their x must agree bit for bit - either one's copy is read by other waves
         {
             const f32x4 hlo = ct ? hp : hn, hhi = ct ? hn : hp;
-            f32x4 c0 = x + Wf1b, c1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            f32x4 c0 = x + Wf1b, c1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, c2 = c1, c3 = c1;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { c0 = FE_MFMA(Wf1lo[r], hlo[r], c0); c1 = FE_MFMA(Wf1hi[r], hhi[r], c1); }
-            x = c0 + c1;
+            for (int r = 0; r < 4; r += 2) {
+                c0 = FE_MFMA(Wf1lo[r], hlo[r], c0); c1 = FE_MFMA(Wf1hi[r], hhi[r], c1);
+                c2 = FE_MFMA(Wf1lo[r + 1], hlo[r + 1], c2); c3 = FE_MFMA(Wf1hi[r + 1], hhi[r + 1], c3);
+            }
+            x = (c0 + c2) + (c1 + c3);
             xr[T] = x;
         }
         *reinterpret_cast<f32x4*>(XT + (T * 64 + lane) * 4) = x;          // (for the waves that take part of this tile's work without having computed x)
