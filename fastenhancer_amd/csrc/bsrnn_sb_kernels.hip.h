@@ -35,16 +35,24 @@ constexpr int kSbWaves = 8;
 
 template <class S>
 struct SbLds {
+    // r6: num_channels = 32 (bsrnn_t).  A layer's time-LSTM fragments - 4 HH x (C + HH) = 96 KiB - fit neither a wave's registers (384 per lane) nor
+    // the LDS next to the band features: TSPLIT - the eight waves split the GATE TILES (hidden units) of every band instead of the bands, and the
+    // new h of a group of GB bands meets in LDS for fc_time (see the kernel).
+    static constexpr bool TSPLIT = S::C > 16;
+    static constexpr int GB = 8;                                          // bands per group of the TSPLIT time part (one fc_time band per wave)
     static constexpr int XS = 0;                                         // [31][C][16]   band features, position p = 4 ks + lg <-> channel KSC lg + ks
     static constexpr int HB = XS + kBands * S::C * kSbStreams;            // [2 directions][2][HH][16]   h of the running step (double buffer)
+                                                                          // TSPLIT, time part: [GB][HH][16] new h of a band group (position 4 t + lg <-> unit KSH lg + t)
+    static constexpr int HB_N = (TSPLIT && GB > 4 ? GB : 4) * S::HH * kSbStreams;
     // the time LSTM's and fc_time's fragments + start values of the running layer - the same for all eight waves: copied once per workgroup
     // (each wave fetching its own copy: 1.1 k wave-level loads per workgroup and layer on the CU's vector-memory path)
-    static constexpr int WT = HB + 4 * S::HH * kSbStreams;
+    static constexpr int WT = HB + HB_N;
     static constexpr int WT_W = 0, WT_FC = WT_W + (S::HH / 4) * (S::C / 4 + S::HH / 4) * 64, WT_B = WT_FC + (S::C / 16) * (S::HH / 4) * 64,
                          WT_FCB = WT_B + (S::HH / 4) * 16, WT_N = WT_FCB + (S::C / 16) * 16;
-    static constexpr int TOTAL = WT + WT_N;
+    static constexpr int TOTAL = WT + (TSPLIT ? 0 : WT_N);
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
-    static constexpr bool FITS = S::C == 16;      // (the register plan - a layer's gate fragments per wave - is for num_channels = 16)
+    // (num_channels = 64: the band features of sixteen streams alone are 127 KiB and a direction's gate fragments 384 registers per lane - the per-stream kernel keeps it)
+    static constexpr bool FITS = (S::C == 16 || S::C == 32) && BYTES <= 160 * 1024;
 };
 
 // offsets (floats) of the stream-batched layer weights inside the packed buffer (host: fe_api.hip::pack_weights_bsrnn)
@@ -71,7 +79,7 @@ __device__ __forceinline__ float sb_tanh_pre(float pre) { return __builtin_fmaf(
 
 template <class S>
 __global__ void __launch_bounds__(kSbThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) bsrnn_sb_layers_kernel(SbArgs a) {
-    static_assert(SbLds<S>::FITS, "stream-batched BSRNN layers: built for num_channels = 16");
+    static_assert(SbLds<S>::FITS, "stream-batched BSRNN layers: built for num_channels = 16 / 32");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = SbLds<S>;
     constexpr int C = S::C, HH = S::HH, KSC = S::KSC, KSH = S::KSH, KS1 = KSC + KSH, NS = kSbStreams;
@@ -118,6 +126,7 @@ __global__ void __launch_bounds__(kSbThreads) __attribute__((amdgpu_waves_per_eu
 #pragma unroll 1
     for (int l = 0; l < S::NLAY; ++l) {
         // ======================================= time LSTM + fc_time: bands over the waves, no barrier =======================================
+        if constexpr (!L::TSPLIT)
         {
             float* wtl = smem + L::WT;
             {
@@ -196,6 +205,101 @@ __global__ void __launch_bounds__(kSbThreads) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
                     for (int r = 0; r < 4; ++r) xs[(j * C + 4 * (4 * to + r) + lg) * NS + li] = xb[4 * to + r] + a2[r];
                 }
+            }
+        }
+        else {
+            // ======================================= TSPLIT (num_channels = 32): gate tiles over the waves, bands in groups of GB =======================================
+            // wave w owns gate tiles t = TPW w .. TPW w + TPW - 1 (hidden units KSH lg + t of lane group lg) of EVERY band: its fragments are TPW x KS1
+            // registers.  Per group of GB bands: every wave runs its tiles of the group's bands (h_{t-1} of a band straight from the state tensor - a lane's
+            // KSH units are contiguous there -, the next band's in flight under this band's MFMAs; c stays with the owning lane), the new h goes to LDS
+            // [band][position 4 t + lg][16 streams]; barrier; wave w then takes band g0 + w: reads the band's whole new h back as B operands (k-step t <-> unit
+            // KSH lg + t), writes it to the state tensor as 16-byte pieces (only now: the other waves have read h_{t-1} of this band before the barrier) and
+            // runs fc_time + the residual; barrier (the next group overwrites the h buffer).
+            constexpr int TPW = KSH / kSbWaves, GB = L::GB;
+            static_assert(KSH % kSbWaves == 0 && (TPW == 1 || TPW == 2 || TPW == 4), "gate tiles per wave");
+            float* hnl = smem + L::HB;
+            float Wt[TPW][KS1], Wf1[NTO][KSH];
+            f32x4 Wtb[TPW], Wf1b[NTO];
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt) {
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) Wt[tt][ks] = afrag(o.t_w[l], wave * TPW + tt, KS1, ks);
+                Wtb[tt] = bias4(o.t_b[l], wave * TPW + tt);
+            }
+#pragma unroll
+            for (int to = 0; to < NTO; ++to) {
+#pragma unroll
+                for (int ks = 0; ks < KSH; ++ks) Wf1[to][ks] = afrag(o.tfc_w[l], to, KSH, ks);
+                Wf1b[to] = bias4(o.tfc_b[l], to);
+            }
+            float* hg = a.lstm + (size_t)(2 * l) * a.B * (kBands * HH);
+            float* cg = a.lstm + (size_t)(2 * l + 1) * a.B * (kBands * HH);
+            f32x4 hq[KSH / 4];
+            float cq[TPW];
+            auto fetch_state = [&](int j) {
+#pragma unroll
+                for (int q = 0; q < KSH / 4; ++q) hq[q] = *reinterpret_cast<const f32x4*>(hg + soff(j) + 4 * q);
+#pragma unroll
+                for (int tt = 0; tt < TPW; ++tt) cq[tt] = cg[soff(j) + wave * TPW + tt];
+            };
+#pragma unroll 1
+            for (int g0 = 0; g0 < kBands; g0 += GB) {
+                const int nb = kBands - g0 < GB ? kBands - g0 : GB;
+                fetch_state(g0);
+#pragma unroll 1
+                for (int jl = 0; jl < nb; ++jl) {
+                    const int j = g0 + jl;
+                    float hp[KSH], cp[TPW], xb[KSC];
+#pragma unroll
+                    for (int ks = 0; ks < KSH; ++ks) hp[ks] = hq[ks / 4][ks % 4];
+#pragma unroll
+                    for (int tt = 0; tt < TPW; ++tt) cp[tt] = cq[tt];
+                    if (jl + 1 < nb) fetch_state(j + 1);
+#pragma unroll
+                    for (int ks = 0; ks < KSC; ++ks) xb[ks] = xs[(j * C + 4 * ks + lg) * NS + li];
+                    f32x4 acc[TPW];
+#pragma unroll
+                    for (int tt = 0; tt < TPW; ++tt) acc[tt] = Wtb[tt];
+#pragma unroll
+                    for (int ks = 0; ks < KSC; ++ks)
+#pragma unroll
+                        for (int tt = 0; tt < TPW; ++tt) acc[tt] = FE_MFMA(Wt[tt][ks], xb[ks], acc[tt]);
+#pragma unroll
+                    for (int ks = 0; ks < KSH; ++ks)
+#pragma unroll
+                        for (int tt = 0; tt < TPW; ++tt) acc[tt] = FE_MFMA(Wt[tt][KSC + ks], hp[ks], acc[tt]);
+#pragma unroll
+                    for (int tt = 0; tt < TPW; ++tt) {                           // gate order i, f, g, o (nn.LSTMCell)
+                        const float ig = sb_sig(acc[tt][0]), fg = sb_sig(acc[tt][1]), gg = sb_tanh_pre(acc[tt][2]), og = sb_sig(acc[tt][3]);
+                        const float cn = fg * cp[tt] + ig * gg;
+                        const float hn = og * tanh_f(cn);
+                        if (sok) cg[soff(j) + wave * TPW + tt] = cn;
+                        hnl[((jl * HH) + 4 * (wave * TPW + tt) + lg) * NS + li] = hn;
+                    }
+                }
+                __syncthreads();
+                if (wave < nb) {
+                    const int j = g0 + wave;
+                    float hn[KSH], xb[KSC];
+#pragma unroll
+                    for (int ks = 0; ks < KSH; ++ks) hn[ks] = hnl[((wave * HH) + 4 * ks + lg) * NS + li];
+#pragma unroll
+                    for (int ks = 0; ks < KSC; ++ks) xb[ks] = xs[(j * C + 4 * ks + lg) * NS + li];
+                    if (sok) {
+#pragma unroll
+                        for (int q = 0; q < KSH / 4; ++q)
+                            *reinterpret_cast<f32x4*>(hg + soff(j) + 4 * q) = f32x4{hn[4 * q], hn[4 * q + 1], hn[4 * q + 2], hn[4 * q + 3]};
+                    }
+#pragma unroll
+                    for (int to = 0; to < NTO; ++to) {
+                        f32x4 a2 = Wf1b[to];
+#pragma unroll
+                        for (int ks = 0; ks < KSH; ++ks) a2 = FE_MFMA(Wf1[to][ks], hn[ks], a2);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xs[(j * C + 4 * (4 * to + r) + lg) * NS + li] = xb[4 * to + r] + a2[r];
+                    }
+                }
+                __syncthreads();
             }
         }
         __syncthreads();

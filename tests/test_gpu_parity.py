@@ -1400,10 +1400,11 @@ def test_bsrnn_more_streams_than_cus():
     _full_size_check(m, orc, cfg, sr, 300, 3, [0, 1, 43, 44, 255, 256, 257, 299], "bsrnn_xxt B=300")
 
 
-@pytest.mark.parametrize("name,B", [("bsrnn_xt", 2605), ("bsrnn_xxt", 4096)])
+@pytest.mark.parametrize("name,B", [("bsrnn_xt", 2605), ("bsrnn_xxt", 4096), ("bsrnn_t", 2093)])
 def test_bsrnn_stream_batched_layers_above_2048_streams(name, B):
     """From 2048 streams the per-hop step runs its LSTM layers batched over the streams on the matrix cores (bsrnn_sb_kernels.hip.h:
     front per stream, sixteen streams per workgroup through the layers, batched mask-decoder MLP, tail per stream).  2605 streams = a
+    last tile of 13; r6: bsrnn_t (num_channels = 32: the time LSTM's gate tiles split over the waves, bands in groups of eight), 2093 streams = a
     last tile of 13.  Oracle parity (outputs and every time-LSTM cache) on a sample that covers first / last tiles and columns, and
     bitwise position independence on all streams (_full_size_check runs the batch again in reversed order: every stream then sits
     in another tile and another column)."""
