@@ -22,8 +22,8 @@ LIB = os.path.join(HERE, "libfastenhancer_hip.so") if not _TAG else os.path.join
 FE_DEPS = ["fe_kernels.hip.h", "fe_frame8.hip.h", "fe_impl.h", "tb_kernels.hip.h"]
 BSRNN_DEPS = ["fe_kernels.hip.h", "bsrnn_kernels.hip.h", "bsrnn_sb_kernels.hip.h", "bsrnn_ov_kernels.hip.h"]
 FSPEN_DEPS = ["fe_kernels.hip.h", "fspen_kernels.hip.h", "fspen_sb_kernels.hip.h"]
-LISENNET_DEPS = ["fe_kernels.hip.h", "fspen_kernels.hip.h", "fspen_sb_kernels.hip.h", "lisennet_kernels.hip.h"]
-API_DEPS = ["fe_kernels.hip.h", "fe_frame8.hip.h", "fe_impl.h", "tb_kernels.hip.h", "fe_shapes.def", "bsrnn_kernels.hip.h", "bsrnn_sb_kernels.hip.h", "bsrnn_ov_kernels.hip.h", "fe_bsrnn_shapes.def", "stft_kernels.hip.h", "fspen_kernels.hip.h", "fspen_sb_kernels.hip.h", "lisennet_kernels.hip.h",
+LISENNET_DEPS = ["fe_kernels.hip.h", "fspen_kernels.hip.h", "fspen_sb_kernels.hip.h", "lisennet_kernels.hip.h", "lisennet_sb_kernels.hip.h"]
+API_DEPS = ["fe_kernels.hip.h", "fe_frame8.hip.h", "fe_impl.h", "tb_kernels.hip.h", "fe_shapes.def", "bsrnn_kernels.hip.h", "bsrnn_sb_kernels.hip.h", "bsrnn_ov_kernels.hip.h", "fe_bsrnn_shapes.def", "stft_kernels.hip.h", "fspen_kernels.hip.h", "fspen_sb_kernels.hip.h", "lisennet_kernels.hip.h", "lisennet_sb_kernels.hip.h",
             "fe_api_bsrnn.inc", "fe_api_fspen.inc", "fe_api_lisennet.inc",
             os.path.join("..", "..", "include", "fastenhancer_hip.h")]
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in VGPRs instead of AGPRs - every epilogue read of an AGPR accumulator is a

@@ -38,7 +38,7 @@ thread_local std::string g_err;
 
 // fe_set_option / fe_get_option.  `env`: the environment variable that sets the value NEW handles start with (A/B scripts under tools/);
 // out-of-range or non-numeric values are ignored.
-enum { OPT_BSRNN_ROLE_SPLIT = 0, OPT_BSRNN_SB_MIN, OPT_BSRNN_THREE_LAUNCH, OPT_BSRNN_OV_PROFILE, OPT_FSPEN_SB_MIN, OPT_LOW_LDS_COMPANION, OPT_BSRNN_FUSED, OPT_COUNT };
+enum { OPT_BSRNN_ROLE_SPLIT = 0, OPT_BSRNN_SB_MIN, OPT_BSRNN_THREE_LAUNCH, OPT_BSRNN_OV_PROFILE, OPT_FSPEN_SB_MIN, OPT_LOW_LDS_COMPANION, OPT_BSRNN_FUSED, OPT_LISENNET_SB_MIN, OPT_COUNT };
 struct OptionDef { const char* name; const char* env; int dflt, lo, hi; };
 constexpr OptionDef kOptions[OPT_COUNT] = {
     {"bsrnn_role_split", "FE_BSRNN_OV", 1, 0, 1},
@@ -48,6 +48,7 @@ constexpr OptionDef kOptions[OPT_COUNT] = {
     {"fspen_stream_batch_min", "FE_FSPEN_SB", 1536, 0, 1 << 24},
     {"low_lds_companion", "FE_LOWLDS", 1, 0, 1},
     {"bsrnn_fused_step", "FE_BSRNN_FUSED", 0, 0, 1},      // (measured negative: profiles/r6_bsrnn_fused_step.txt)
+    {"lisennet_stream_batch_min", "FE_LISENNET_SB", 1024, 0, 1 << 24},
 };
 int env_int(const char* name, int dflt, int lo, int hi) {
     const char* e = std::getenv(name);
@@ -1059,6 +1060,10 @@ int fe_state_init(fe_handle* h, float* state_dev, int B, void* stream) {
     }
     if (h->fimpl) {
         const int rc = ensure_fsplit(h, B);
+        if (rc != FE_OK) return rc;
+    }
+    if (h->limpl) {
+        const int rc = ensure_lsplit(h, B);
         if (rc != FE_OK) return rc;
     }
     return FE_OK;

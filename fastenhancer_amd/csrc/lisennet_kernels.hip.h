@@ -87,6 +87,7 @@ struct LArgs {
     float* ring;              // [B][pipe_p + 2][CACHE_FLOATS]: the caches of the frames in flight (one slot per frame, cache layout)
     float* frames;            // [B][T][N] windowed output frames (summed / envelope-normalised by istft_ola_kernel)
     int pipe_p;
+    float* carry;             // r6, the three-launch per-hop step of large batches (lisennet_sb_kernels.hip.h): [tiles][LCarry::TILE] [B][LCarry::SP]
 };
 
 // debug stages: 0 spec_in [257][2], 1 compressed [257][2], 2 features [3][257], 3 encoder.conv_1 [4][257], 4 encoder.conv_2 [8][128],
@@ -156,14 +157,21 @@ __device__ __forceinline__ float mish_f(float x) {
 
 #define LS_CLK(i) do { if constexpr (PROF) { if (blockIdx.x == 0 && threadIdx.x == 0) a.clk[(i)] = __builtin_readcyclecounter(); } } while (0)
 
+}  // namespace fe
+#include "lisennet_sb_kernels.hip.h"
+namespace fe {
+
 // PIPE: time pipelining of an offline launch.  A frame needs the previous frame's value of NINE caches (the phase, three encoder frames,
 // per block the GRU state and the ConvGLU's two frames, the decoder frame) - each is read and replaced at ONE place of the frame.  The
 // frames in flight keep their caches in a ring of pipe_p + 2 slots per utterance (slot = frame mod RS, cache layout); a site waits for
 // the previous frame's count of that cache, reads slot t - 1 (the ConvGLU: t - 2 and t - 1), writes slot t and counts it - agent-scope
 // accesses on both sides, one counter per (utterance, cache).
-template <class S, bool PROF, bool DBG, bool PIPE = false>
+// PART (r6): 0 = the whole frame; 1 = STFT .. encoder.conv_2 of a per-hop step whose middle runs batched over the streams (lisennet_sb_kernel): x2, its
+// cached frame and the compressed spectrum go to the carry; 2 = that step's tail (decoder cache, mask conv .. iSTFT) from the carry's up3 output.
+template <class S, bool PROF, bool DBG, bool PIPE = false, int PART = 0>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) lisennet_frame_kernel(LArgs a) {
     static_assert(!PIPE || (!PROF && !DBG), "the time-pipelined instantiation is the plain offline kernel");
+    static_assert(PART == 0 || !PIPE, "the split step is a streaming step");
     __shared__ __attribute__((aligned(16))) float smem[LLds::TOTAL];
     using L = LLds;
     using P = LPk;
@@ -281,6 +289,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
         // ============================ STFT + compress + phase features (models/lisennet/model.py:441-456 / :512-524) ============================
         float* feat = smem + L::FEAT;
         float* phs = smem + L::PHA;
+        float* x1 = smem + L::X1;
+        float* x1p = smem + L::X1P;
+        if constexpr (PART != 2) {
         if (mode != FE_MODE_SPEC) {
             const float* win = wp + P::WINDOW;
             float* cst = a.cache_stft + (size_t)b * OVL;
@@ -351,8 +362,6 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
 
         LS_CLK(1);
         // ============================ encoder (Encoder.forward, :269-274) ============================
-        float* x1 = smem + L::X1;
-        float* x1p = smem + L::X1P;
         {   // conv_1: 1x1 (3 -> 4), LayerNorm over (channel, freq) with a per-frequency affine, PReLU   (FFT buffers are dead: x1 aliases them)
             float v[5];
             int cnt = 0;
@@ -385,6 +394,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
         if constexpr (PIPE) cpub(1); else
         __syncthreads();
         dump(3, [&](int r, int c) { return x1[r * 260 + c]; });
+        }   // PART != 2
         // DSConv (:190-208): causal two-frame conv, the bins split into a low quarter (k 3, stride 1) and the rest (k 5, stride 3), both
         // zero padded by one bin AFTER the split; LayerNorm over (channel, freq), per-frequency affine, PReLU
         auto dsconv = [&](auto CIN_, auto COUT_, auto FIN_, const float* cur, const float* prev, int ld_in, float* out, float* cache_io, float* prev_out,
@@ -466,8 +476,32 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
         using I128 = std::integral_constant<int, 128>;
         using I257 = std::integral_constant<int, 257>;
         float* xp = smem + L::XP;
+        constexpr int OFF_BLK = S::K_PHA + S::K_E2 + S::K_E3 + S::K_E4;
+        if constexpr (PART != 2) {
         dsconv(I4{}, I8{}, I257{}, x1, x1p, 260, x2, cache_ptr(S::K_PHA + S::K_E2, S::K_E3), xp, P::D2_LO, P::D2_HI, P::D2_BL, P::D2_BH, P::D2_G, P::D2_BE, P::D2_P, 2, S::K_PHA + S::K_E2);
         dump(4, [&](int r, int c) { return x2[r * 128 + c]; });
+        }
+        if constexpr (PART == 1) {
+            // x2 [8][128] of this frame (in conv_3's and in up3's slicing) and of the cached frame, as [position][channel group][16 streams][4] of the
+            // stream's tile; the zero rows around the slices; the compressed spectrum for the tail
+            using A = LCarry;
+            float* ct = a.carry + (size_t)(b >> 4) * A::TILE + (b & 15) * 4;
+            for (int i = tid; i < 8 * 128; i += kThreads) {
+                const int c = i >> 7, f = i & 127, o = (c >> 2) * 64 + (c & 3);
+                const float v = x2[i];
+                ct[A::X2C::row(f) + o] = v;
+                ct[A::X2S::row(f) + o] = v;
+                ct[A::X2P::row(f) + o] = xp[i];
+            }
+            if (tid < 96) {
+                const int k = tid >> 3, q = tid & 7, buf = k >> 2, h4 = k & 3, o = (q >> 2) * 64 + (q & 3);
+                const int base = buf == 0 ? A::X2C::halo(h4) : buf == 1 ? A::X2P::halo(h4) : A::X2S::halo(h4);
+                ct[base + o] = 0.0f;
+            }
+            float* spc = a.carry + (size_t)((a.B + 15) >> 4) * A::TILE + (size_t)b * A::SP;
+            for (int i = tid; i < 2 * BINS; i += kThreads) spc[i] = sp[i];
+        }
+        if constexpr (PART == 0) {
         {
             float* xq = smem + L::Y;       // previous frame of x3's input is in xp (x2's cache); x3's own cache lands in xq
             dsconv(I8{}, I12{}, I128{}, x2, xp, 128, x3, cache_ptr(S::K_PHA + S::K_E2 + S::K_E3, S::K_E4), xq, P::D3_LO, P::D3_HI, P::D3_BL, P::D3_BH, P::D3_G, P::D3_BE, P::D3_P, 3, S::K_PHA + S::K_E2 + S::K_E3);
@@ -488,7 +522,6 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
         // tokens [f][d] of the block input (b, d, t, f) -> (b, t, f, d)
         for (int q = 0; q < 2; ++q) { const int i = tid + 256 * q, f = i >> 4, d = i & 15; xt[i] = x4[d * 32 + f]; }
         __syncthreads();
-        constexpr int OFF_BLK = S::K_PHA + S::K_E2 + S::K_E3 + S::K_E4;
 #pragma unroll 1
         for (int blk = 0; blk < S::NB; ++blk) {
             const float* wd = wp + P::BLK + blk * P::B_SIZE;
@@ -761,17 +794,30 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
         };
         float* u1 = smem + L::U1;
         float* u2 = smem + L::U2;
-        float* u3 = smem + L::U3;
-        float* u3p = smem + L::U3P;
         {   // yd lives at SB + 6144: u1 / u2 / u3 below it
             using I32 = std::integral_constant<int, 32>;
             usconv(I16{}, I12{}, I32{}, yd, x4, u1, P::U1_LO, P::U1_HI, P::U1_BL, P::U1_BH);
             usconv(I12{}, I8{}, I64{}, u1, x3, u2, P::U2_LO, P::U2_HI, P::U2_BL, P::U2_BH);
-            usconv(I8{}, I4{}, I128{}, u2, x2, u3, P::U3_LO, P::U3_HI, P::U3_BL, P::U3_BH);
+            usconv(I8{}, I4{}, I128{}, u2, x2, smem + L::U3, P::U3_LO, P::U3_HI, P::U3_BL, P::U3_BH);
         }
-        dump(13, [&](int r, int c) { return u3[r * 256 + c]; });
+        dump(13, [&](int r, int c) { return smem[L::U3 + r * 256 + c]; });
+        }   // PART == 0
+        float* u3 = smem + L::U3;
+        float* u3p = smem + L::U3P;
+        if constexpr (PART == 2) {      // the stream-batched middle's up3 output [256 f][16 n][4 c] and PART 1's compressed spectrum
+            using A = LCarry;
+            const float* cu = a.carry + (size_t)(b >> 4) * A::TILE + A::U3 + (b & 15) * 4;
+            for (int f = tid; f < 256; f += kThreads) {
+                const float4 v = *reinterpret_cast<const float4*>(cu + f * 64);
+                u3[f] = v.x; u3[256 + f] = v.y; u3[512 + f] = v.z; u3[768 + f] = v.w;
+            }
+            const float* spc = a.carry + (size_t)((a.B + 15) >> 4) * A::TILE + (size_t)b * A::SP;
+            for (int i = tid; i < 2 * BINS; i += kThreads) sp[i] = spc[i];
+            __syncthreads();
+        }
         float* my = smem + L::MY;
         float* mk = smem + L::MK;
+        if constexpr (PART != 1) {
         {
             float* cd = cache_ptr(OFF_BLK + S::NB * (S::K_H + S::K_GLU), S::K_DEC);
             if constexpr (PIPE) {
@@ -890,6 +936,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
             __syncthreads();
             }
         }
+        }   // PART != 1
         LS_CLK(5);
     }
     if constexpr (PIPE) break;
@@ -909,6 +956,7 @@ struct LImpl {
     void (*launch_pipe)(const LArgs&, hipStream_t, hipError_t*);       // time-pipelined offline launch (cooperative: B * pipe_p workgroups)
     int occ;                  // workgroups per CU
     int nsite;                // caches handed from frame to frame (counters per stream)
+    void (*launch_sb)(const LArgs&, int max_wgs, hipStream_t, hipError_t*);      // r6: the per-hop step of a large batch in three launches, the middle batched over the streams
 };
 
 template <class S>
@@ -932,6 +980,29 @@ void llaunch_impl(const LArgs& a, int max_wgs, hipStream_t st, hipError_t* err) 
     *err = hipGetLastError();
 }
 
+// the per-hop step of a LARGE batch: front per stream (PART 1), conv_3 .. up3 for sixteen streams per workgroup on the matrix cores
+// (lisennet_sb_kernel), tail per stream (PART 2).  fe_debug_step: the same three launches with per-stage dumps; fe_profile_step: the middle's counters.
+template <class S>
+void llaunch_sb_impl(const LArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
+    constexpr int OCC_LDS = (160 * 1024) / (LLds::TOTAL * 4);
+    constexpr int OCC = OCC_LDS < 2 ? OCC_LDS : 2;
+    const int slots = max_wgs * OCC;
+    const int grid = a.B < slots ? a.B : slots;
+    note_kernel(a.dbg != nullptr ? "lisennet_frame_kernel<PART 1, debug>" : "lisennet_frame_kernel<PART 1>");
+    if (a.dbg != nullptr) hipLaunchKernelGGL((lisennet_frame_kernel<S, false, true, false, 1>), dim3(grid), dim3(kThreads), 0, st, a);
+    else hipLaunchKernelGGL((lisennet_frame_kernel<S, false, false, false, 1>), dim3(grid), dim3(kThreads), 0, st, a);
+    *err = hipGetLastError();
+    if (*err != hipSuccess) return;
+    LSbArgs sa{};
+    sa.wp = a.wp; sa.wp_floats = LPk::TOTAL + LSbPk::TOTAL; sa.carry = a.carry; sa.cache = a.cache; sa.dbg = a.dbg; sa.dbg_stride = a.dbg_stride; sa.B = a.B; sa.clk = a.clk;
+    *err = lisennet_sb_launch<S>(sa, st);
+    if (*err != hipSuccess) return;
+    note_kernel(a.dbg != nullptr ? "lisennet_frame_kernel<PART 2, debug>" : "lisennet_frame_kernel<PART 2>");
+    if (a.dbg != nullptr) hipLaunchKernelGGL((lisennet_frame_kernel<S, false, true, false, 2>), dim3(grid), dim3(kThreads), 0, st, a);
+    else hipLaunchKernelGGL((lisennet_frame_kernel<S, false, false, false, 2>), dim3(grid), dim3(kThreads), 0, st, a);
+    *err = hipGetLastError();
+}
+
 inline void ldbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
     *rows = LDebugLayout::rows(s);
     *cols = LDebugLayout::cols(s);
@@ -941,8 +1012,8 @@ inline void ldbg_stage_impl(int s, int* rows, int* cols, size_t* off) {
 template <class S>
 LImpl make_limpl() {
     constexpr int OCC_LDS = (160 * 1024) / (LLds::TOTAL * 4);
-    return LImpl{S::HOP, (size_t)LLds::TOTAL * 4, LDebugLayout::total(), LDebugLayout::n_stages, (size_t)LPk::TOTAL, (size_t)S::CACHE_FLOATS,
-                 &llaunch_impl<S>, &ldbg_stage_impl, &llaunch_pipe_impl<S>, OCC_LDS < 2 ? OCC_LDS : 2, 5 + 2 * S::NB};
+    return LImpl{S::HOP, (size_t)LLds::TOTAL * 4, LDebugLayout::total(), LDebugLayout::n_stages, (size_t)LPk::TOTAL + LSbPk::TOTAL, (size_t)S::CACHE_FLOATS,
+                 &llaunch_impl<S>, &ldbg_stage_impl, &llaunch_pipe_impl<S>, OCC_LDS < 2 ? OCC_LDS : 2, 5 + 2 * S::NB, &llaunch_sb_impl<S>};
 }
 
 }  // namespace fe
