@@ -146,6 +146,10 @@ struct LLds {
     static constexpr int WST = SB + 6656;           // weight staging area of the conv phases (one layer's weights at a time)
     static constexpr int WST_SIZE = 4672;
     static constexpr int TOTAL = WST + WST_SIZE;
+    // r6: the two per-stream parts of the three-launch step use a prefix of the plan (PART 1: up to conv_2, its staged weights at WST1; PART 2: the
+    // decoder tail) - 33 KB instead of 59: four workgroups per CU
+    static constexpr int WST1 = SB + 4200;
+    static constexpr int total(int part) { return part == 1 ? WST1 + 800 : part == 2 ? MK + 520 : TOTAL; }
     static_assert(SB % 2 == 0 && TW % 2 == 0, "float2 alignment");
     static_assert((size_t)TOTAL * 4 <= 64 * 1024, "static LDS");
 };
@@ -169,10 +173,10 @@ namespace fe {
 // PART (r6): 0 = the whole frame; 1 = STFT .. encoder.conv_2 of a per-hop step whose middle runs batched over the streams (lisennet_sb_kernel): x2, its
 // cached frame and the compressed spectrum go to the carry; 2 = that step's tail (decoder cache, mask conv .. iSTFT) from the carry's up3 output.
 template <class S, bool PROF, bool DBG, bool PIPE = false, int PART = 0>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) lisennet_frame_kernel(LArgs a) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PART == 0 ? 2 : 4, PART == 0 ? 2 : 4))) lisennet_frame_kernel(LArgs a) {
     static_assert(!PIPE || (!PROF && !DBG), "the time-pipelined instantiation is the plain offline kernel");
     static_assert(PART == 0 || !PIPE, "the split step is a streaming step");
-    __shared__ __attribute__((aligned(16))) float smem[LLds::TOTAL];
+    __shared__ __attribute__((aligned(16))) float smem[LLds::total(PART)];
     using L = LLds;
     using P = LPk;
     constexpr int N = S::NFFT, H = S::HOP, OVL = S::OVL, BINS = S::BINS;
@@ -279,7 +283,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
 
         // a conv layer's weights (a contiguous block of the packed buffer) -> LDS in one coalesced burst: the layers then read them
         // with LDS latency instead of an L2 round trip per tap (all threads call; ends with a barrier)
-        float* wst = smem + L::WST;
+        float* wst = smem + (PART == 1 ? L::WST1 : L::WST);
         auto stage = [&](int base, int n) {
             for (int i = tid; i < n; i += kThreads) wst[i] = wp[base + i];
             __syncthreads();
@@ -482,22 +486,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2
         dump(4, [&](int r, int c) { return x2[r * 128 + c]; });
         }
         if constexpr (PART == 1) {
-            // x2 [8][128] of this frame (in conv_3's and in up3's slicing) and of the cached frame, as [position][channel group][16 streams][4] of the
-            // stream's tile; the zero rows around the slices; the compressed spectrum for the tail
+            // x2 [8][128] of this frame and of the cached frame, per stream as they stand (coalesced: the middle's prologue regroups them for its sixteen
+            // streams - scattered from here into the tiles' [position][channel group][16 streams][4] layout they were 3 072 partial-line writes per stream,
+            // 100 of this launch's 163 us at 4096 streams); the compressed spectrum for the tail
             using A = LCarry;
-            float* ct = a.carry + (size_t)(b >> 4) * A::TILE + (b & 15) * 4;
-            for (int i = tid; i < 8 * 128; i += kThreads) {
-                const int c = i >> 7, f = i & 127, o = (c >> 2) * 64 + (c & 3);
-                const float v = x2[i];
-                ct[A::X2C::row(f) + o] = v;
-                ct[A::X2S::row(f) + o] = v;
-                ct[A::X2P::row(f) + o] = xp[i];
-            }
-            if (tid < 96) {
-                const int k = tid >> 3, q = tid & 7, buf = k >> 2, h4 = k & 3, o = (q >> 2) * 64 + (q & 3);
-                const int base = buf == 0 ? A::X2C::halo(h4) : buf == 1 ? A::X2P::halo(h4) : A::X2S::halo(h4);
-                ct[base + o] = 0.0f;
-            }
+            float* xn = a.carry + A::x2n(a.B) + (size_t)b * 2048;
+            for (int i = tid; i < 8 * 128; i += kThreads) { xn[i] = x2[i]; xn[1024 + i] = xp[i]; }
             float* spc = a.carry + (size_t)((a.B + 15) >> 4) * A::TILE + (size_t)b * A::SP;
             for (int i = tid; i < 2 * BINS; i += kThreads) spc[i] = sp[i];
         }
@@ -984,8 +978,8 @@ void llaunch_impl(const LArgs& a, int max_wgs, hipStream_t st, hipError_t* err) 
 // (lisennet_sb_kernel), tail per stream (PART 2).  fe_debug_step: the same three launches with per-stage dumps; fe_profile_step: the middle's counters.
 template <class S>
 void llaunch_sb_impl(const LArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
-    constexpr int OCC_LDS = (160 * 1024) / (LLds::TOTAL * 4);
-    constexpr int OCC = OCC_LDS < 2 ? OCC_LDS : 2;
+    constexpr int OCC = 4;                                         // (33 KB of LDS, <= 128 VGPRs: the parts run four workgroups per CU)
+    static_assert(LLds::total(1) * 4 * OCC <= 160 * 1024 && LLds::total(2) * 4 * OCC <= 160 * 1024, "LDS of the parts");
     const int slots = max_wgs * OCC;
     const int grid = a.B < slots ? a.B : slots;
     note_kernel(a.dbg != nullptr ? "lisennet_frame_kernel<PART 1, debug>" : "lisennet_frame_kernel<PART 1>");

@@ -48,7 +48,7 @@ struct LSl {
 };
 
 struct LCarry {
-    using X2C = LSl<2, 32, 96, 0>;             // conv_2 output [8][128], this frame, in conv_3's slicing (written by PART 1)
+    using X2C = LSl<2, 32, 96, 0>;             // conv_2 output [8][128], this frame, in conv_3's slicing
     using X2P = LSl<2, 32, 96, X2C::END>;      // ... the cached frame
     using X2S = LSl<2, 64, 64, X2P::END>;      // ... this frame in up3's slicing (skip)
     using X3C = LSl<3, 16, 48, X2S::END>;      // conv_3 output [12][64] in conv_4's slicing
@@ -61,7 +61,9 @@ struct LCarry {
     static constexpr int U3 = U2::END;         // up3 output [256 f][16 n][4 c] (read by PART 2)
     static constexpr int TILE = U3 + 256 * 64;
     static constexpr int SP = 516;             // per stream, behind the tiles: the compressed spectrum [257][2] (PART 1 -> PART 2)
-    __host__ __device__ static constexpr size_t floats(int B) { return (size_t)((B + 15) / 16) * TILE + (size_t)B * SP; }
+    // ... and behind those, per stream: conv_2's output [8][128] of this frame and of the cached frame as PART 1 leaves them (regrouped by the middle's prologue)
+    __host__ __device__ static constexpr size_t x2n(int B) { return (size_t)((B + 15) / 16) * TILE + (size_t)((B + 15) / 16) * 16 * SP; }
+    __host__ __device__ static constexpr size_t floats(int B) { return x2n(B) + (size_t)((B + 15) / 16) * 16 * 2048; }
 };
 
 // packed weights of the stream-batched kernel (floats, relative to LPk::TOTAL); A fragments in k4 order [tile][quad][lane][4]
@@ -82,7 +84,7 @@ struct LSbPk {
     static constexpr int D2_W = XB + 4 * 2 * 16, D2_B = D2_W + 2 * 256;       // inter dense
     static constexpr int GG = D2_B + 16, GBE = GG + 512;                      // conv_glu norm gamma / beta, TRANSPOSED to [f][d]
     static constexpr int F1_W = GBE + 512, F1_B = F1_W + 4 * 256;             // fc1 [tile][256], bias [4][16]
-    static constexpr int DW = F1_B + 64, DWB = DW + 2 * 9 * 16;               // dwconv [t][dt * 3 + df][lg][r], bias [t][lg][r]
+    static constexpr int DW = F1_B + 64, DWB = DW + 2 * 4 * 3 * 16;          // dwconv [t][r][q < 3][lg][e]: tap dt * 3 + df = 4 q + e of channel 16 t + 4 lg + r; bias [t][lg][r]
     static constexpr int F2_W = DWB + 32, F2_B = F2_W + 2 * 256;              // fc2 [quad][256], bias [16]
     static constexpr int B_SIZE = F2_B + 16;
     static constexpr int TOTAL = BLK + 2 * B_SIZE;
@@ -92,7 +94,9 @@ struct LSbPk {
 struct LSbLds {
     static constexpr int X = 0;                        // tokens [32 f][16 slots][16 n]: slot 4 r + lg <-> channel 4 lg + r
     static constexpr int HS = X + 32 * 16 * 16;        // intra h sequences [2 d][32 f][16 slots (12 units)][16 n]; conv_glu: the waves' edge columns [8][2][32][16]
-    static constexpr int RED = HS + 2 * 32 * 16 * 16;  // [2][8 waves][16 n]
+    // prologue: [channel][16 n][positions + 1] staging of the tensors that arrive per stream (x2: 8 x 16 x 129, the cached x3: 12 x 16 x 65 behind it)
+    static constexpr int T2 = 0, T3 = T2 + 8 * 16 * 129, TEND = T3 + 12 * 16 * 65;
+    static constexpr int RED = (HS + 2 * 32 * 16 * 16 > TEND ? HS + 2 * 32 * 16 * 16 : TEND);  // [2][8 waves][16 n]
     static constexpr int TOTAL = RED + 256;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
 };
@@ -110,6 +114,16 @@ struct LSbArgs {
 
 __device__ __forceinline__ float lsb_sig(float pre) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre)); }                              // pre = -log2e x
 __device__ __forceinline__ float lsb_tanh(float pre) { return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre)), 1.0f); }   // pre = 2 log2e x
+// mish(x) = x tanh(softplus(x)) with tanh(ln(1 + n)) = n (n + 2) / (n (n + 2) + 2), n = e^x: one exponential and one reciprocal (lisennet_frame_kernel's
+// mish_f goes through log1p, exp and tanh: ~8 x the vector instructions, and the conv_glu of sixteen streams is 16 384 evaluations per block);
+// no cancellation for x -> -inf (n (n + 2) -> 2 n), x > 20: the factor is 1 to fp32 (and n^2 would overflow from x = 44)
+__device__ __forceinline__ float lsb_mish(float x) {
+    const float n = __builtin_amdgcn_exp2f(1.4426950408889634f * fminf(x, 20.0f));
+    const float t = n * (n + 2.0f);
+    float y = x * (t * __builtin_amdgcn_rcpf(t + 2.0f));
+    asm volatile("" : "+v"(y));          // (keeps the evaluations in program order: scheduled freely, the conv_glu passes - straight-line code - spilled 58 registers)
+    return y;
+}
 __device__ __forceinline__ float lsb_sum_lg(float v) {
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
@@ -177,12 +191,73 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
                 *reinterpret_cast<f32x4*>(ct + SL::halo(h) + 4 * q) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             }
         };
+        zero_halo(A::X2C{}); zero_halo(A::X2P{}); zero_halo(A::X2S{});
         zero_halo(A::X3C{}); zero_halo(A::X3P{}); zero_halo(A::X3S{}); zero_halo(A::X4S{}); zero_halo(A::XD{}); zero_halo(A::U1{}); zero_halo(A::U2{});
+        // The tensors that arrive per stream - conv_2's output of this frame and of the cached frame (PART 1), the cached conv_3 frame (the cache tensor) -
+        // regrouped for the sixteen streams through LDS: coalesced 16-byte reads along f -> [channel][n][f (+ 1 pad)] -> one 16-byte element
+        // (four channels of a position and stream) per thread, whole 256-byte pieces per sixteen lanes.
+        float* T2 = smem + L::T2;
+        float* T3 = smem + L::T3;
+        const float* x2n = a.carry + A::x2n(a.B);
         const float* c4 = a.cache + (size_t)(S::K_PHA + S::K_E2 + S::K_E3) * a.B;
-        for (int i = tid; i < kLsbStreams * S::K_E4; i += kLsbThreads) {
-            const int n = i / S::K_E4, e = i - n * S::K_E4, c = e >> 6, f = e & 63;
-            const int bs = b0 + n < a.B ? b0 + n : a.B - 1;
-            ct[A::X3P::row(f) + (c >> 2) * 64 + n * 4 + (c & 3)] = c4[(size_t)bs * S::K_E4 + e];
+        auto stage_x2 = [&](int which) {            // 16 streams x [8][128]: 4096 16-byte pieces
+            f32x4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = tid + k * kLsbThreads, n = i >> 8, e = (i & 255) * 4;
+                const int bs = b0 + n < a.B ? b0 + n : a.B - 1;
+                v[k] = *reinterpret_cast<const f32x4*>(x2n + (size_t)bs * 2048 + which * 1024 + e);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = tid + k * kLsbThreads, n = i >> 8, e = (i & 255) * 4, c = e >> 7, f = e & 127;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) T2[(c * 16 + n) * 129 + f + j] = v[k][j];
+            }
+        };
+        auto emit_x2 = [&](auto sl) {               // 128 positions x 2 groups x 16 streams
+            using SL = decltype(sl);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = tid + k * kLsbThreads, n = i & 15, g = (i >> 4) & 1, f = i >> 5;
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = T2[((4 * g + j) * 16 + n) * 129 + f];
+                *reinterpret_cast<f32x4*>(ct + SL::row(f) + g * 64 + n * 4) = o;
+            }
+        };
+        stage_x2(0);
+        __syncthreads();
+        emit_x2(A::X2C{});
+        emit_x2(A::X2S{});
+        __syncthreads();
+        stage_x2(1);
+        {   // the cached conv_3 frame: 16 streams x [12][64]: 3072 16-byte pieces
+            constexpr int NV = kLsbStreams * S::K_E4 / 4 / kLsbThreads;
+            static_assert(kLsbStreams * S::K_E4 == 4 * NV * kLsbThreads, "whole 16-byte pieces per thread");
+            f32x4 v[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int i = tid + k * kLsbThreads, n = i / (S::K_E4 / 4), e = (i - n * (S::K_E4 / 4)) * 4;
+                const int bs = b0 + n < a.B ? b0 + n : a.B - 1;
+                v[k] = *reinterpret_cast<const f32x4*>(c4 + (size_t)bs * S::K_E4 + e);
+            }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int i = tid + k * kLsbThreads, n = i / (S::K_E4 / 4), e = (i - n * (S::K_E4 / 4)) * 4, c = e >> 6, f = e & 63;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) T3[(c * 16 + n) * 65 + f + j] = v[k][j];
+            }
+        }
+        __syncthreads();
+        emit_x2(A::X2P{});
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {               // 64 positions x 3 groups x 16 streams
+            const int i = tid + k * kLsbThreads, n = i & 15, gf = i >> 4, f = gf / 3, g = gf - 3 * f;
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = T3[((4 * g + j) * 16 + n) * 65 + f];
+            *reinterpret_cast<f32x4*>(ct + A::X3P::row(f) + g * 64 + n * 4) = o;
         }
     }
     __syncthreads();
@@ -220,6 +295,12 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
         LSB_CONV(3, 1, 4, accL, WL, offL, pL);
         LSB_CONV(5, 1, 4, accH, WH, offH, pH);
         const bool val = lg < 3;                                   // rows 12 .. 15 of the tile are idle
+        float gam[8], bet[8];                                      // the per-frequency affine of this wave's positions (requested before the statistics' barriers)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int P = i < 4 ? 4 * wave + i : 32 + 4 * wave + (i - 4);
+            gam[i] = a.wp[SB + Q::C3_G + P]; bet[i] = a.wp[SB + Q::C3_BE + P];
+        }
         float s0 = 0.0f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) s0 += ((accL[i][0][0] + accL[i][0][1]) + (accL[i][0][2] + accL[i][0][3])) + ((accH[i][0][0] + accH[i][0][1]) + (accH[i][0][2] + accH[i][0][3]));
@@ -238,7 +319,7 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int P = i < 4 ? 4 * wave + i : 32 + 4 * wave + (i - 4);
-            const float ga = a.wp[SB + Q::C3_G + P] * rstd, be = a.wp[SB + Q::C3_BE + P];
+            const float ga = gam[i] * rstd, be = bet[i];
             f32x4 y;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -278,6 +359,12 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
         for (int i = 0; i < 2; ++i) { accL[i][0] = bL; accH[i][0] = bH; pL[i] = (2 * wave + i) * A::X3C::ROW; pH[i] = (2 * wave + i) * 3 * A::X3C::ROW; }
         LSB_CONV(5, 1, 2, accL, WL, offL, pL);
         LSB_CONV(8, 1, 2, accH, WH, offH, pH);
+        float gam[4], bet[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int P = i < 2 ? 2 * wave + i : 16 + 2 * wave + (i - 2);
+            gam[i] = a.wp[SB + Q::C4_G + P]; bet[i] = a.wp[SB + Q::C4_BE + P];
+        }
         float s0 = 0.0f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) s0 += ((accL[i][0][0] + accL[i][0][1]) + (accL[i][0][2] + accL[i][0][3])) + ((accH[i][0][0] + accH[i][0][1]) + (accH[i][0][2] + accH[i][0][3]));
@@ -295,7 +382,7 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int P = i < 2 ? 2 * wave + i : 16 + 2 * wave + (i - 2);
-            const float ga = a.wp[SB + Q::C4_G + P] * rstd, be = a.wp[SB + Q::C4_BE + P];
+            const float ga = gam[i] * rstd, be = bet[i];
             f32x4 y;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -537,26 +624,28 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
             f32x4 nw[4], nb[4];
 #pragma unroll
             for (int fl = 0; fl < 4; ++fl) { nw[fl] = row4(D + Q::GG + (4 * wave + fl) * 16); nb[fl] = row4(D + Q::GBE + (4 * wave + fl) * 16); }
-            f32x4 f1w[4], f1b[4];
+            f32x4 f1w[2], f1b[2];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { f1w[t] = frag(D + Q::F1_W + t * 256); f1b[t] = row4(D + Q::F1_B + t * 16); }
+            for (int t = 0; t < 2; ++t) { f1w[t] = frag(D + Q::F1_W + t * 256); f1b[t] = row4(D + Q::F1_B + t * 16); }
             const float rstd = ln512(zn);
 #pragma unroll
             for (int fl = 0; fl < 4; ++fl)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) zn[fl][r] = __builtin_fmaf(zn[fl][r] * rstd, nw[fl][r], nb[fl][r]);
-            f32x4 xc[2][4], vv[2][4];                   // fc1 outputs: [t][fl] = channels 16 t + 4 lg + r (first half: conv input, second half: gate)
+            __builtin_amdgcn_sched_barrier(0);
+            // fc1's first half (the conv input, channels 16 t + 4 lg + r) of the wave's EDGE sub-bands only, for the neighbour waves; a pass below computes
+            // its channel tile for all four sub-bands again (16 more MFMAs per block: keeping both tiles across the passes is what spilled)
+            f32x4 xe[2][2];
 #pragma unroll
-            for (int fl = 0; fl < 4; ++fl) {
-                f32x4 acc[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = f1b[t];
+            for (int e = 0; e < 2; ++e) {
+                f32x4 acc[2] = {f1b[0], f1b[1]};
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = FE_MFMA(f1w[t][j], zn[fl][j], acc[t]);
-                xc[0][fl] = acc[0]; xc[1][fl] = acc[1]; vv[0][fl] = acc[2]; vv[1][fl] = acc[3];
+                    for (int t = 0; t < 2; ++t) acc[t] = FE_MFMA(f1w[t][j], zn[3 * e][j], acc[t]);
+                xe[0][e] = acc[0]; xe[1][e] = acc[1];
             }
+            __builtin_amdgcn_sched_barrier(0);          // (keeps the edge-column section's loads and address arithmetic below fc1: one long basic block otherwise, scheduled into spills)
             // the three frames' edge columns of every wave's four sub-bands meet in LDS (tokens and h sequences are dead: the statistics' barriers lie
             // in between): [wave][side][frame][slot 16 t + 4 r + lg][16 n] - no wave reads another wave's columns of the cache tensor, so each
             // wave replaces its own columns as soon as it has read them
@@ -573,19 +662,26 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
                     halo[(((wave * 2 + 1) * 3 + 0) * 32 + sl) * 16 + li] = o0[3];
                     halo[(((wave * 2 + 0) * 3 + 1) * 32 + sl) * 16 + li] = o1[0];
                     halo[(((wave * 2 + 1) * 3 + 1) * 32 + sl) * 16 + li] = o1[3];
-                    halo[(((wave * 2 + 0) * 3 + 2) * 32 + sl) * 16 + li] = xc[t][0][r];
-                    halo[(((wave * 2 + 1) * 3 + 2) * 32 + sl) * 16 + li] = xc[t][3][r];
+                    halo[(((wave * 2 + 0) * 3 + 2) * 32 + sl) * 16 + li] = xe[t][0][r];
+                    halo[(((wave * 2 + 1) * 3 + 2) * 32 + sl) * 16 + li] = xe[t][1][r];
                 }
-            const f32x4 f2w0 = frag(D + Q::F2_W), f2w1 = frag(D + Q::F2_W + 256), f2b = row4(D + Q::F2_B);
             f32x4 gg[2][4];
             __syncthreads();
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 __builtin_amdgcn_sched_barrier(0);
-                f32x4 wq[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) wq[k] = row4(D + Q::DW + (t * 9 + k) * 16);
                 const f32x4 wbq = row4(D + Q::DWB + t * 16);
+                // fc1 for this pass's channels: the conv half (tile t) and the gate half (tile 2 + t)
+                f32x4 xc[4], vv[4];
+                {
+                    const f32x4 gw = frag(D + Q::F1_W + (2 + t) * 256), gb = row4(D + Q::F1_B + (2 + t) * 16);
+#pragma unroll
+                    for (int fl = 0; fl < 4; ++fl) { xc[fl] = f1b[t]; vv[fl] = gb; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int fl = 0; fl < 4; ++fl) { xc[fl] = FE_MFMA(f1w[t][j], zn[fl][j], xc[fl]); vv[fl] = FE_MFMA(gw[j], zn[fl][j], vv[fl]); }
+                }
                 f32x4 old0[4], old1[4];                 // (read again: a pass keeps one channel tile's frames in registers)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -599,30 +695,39 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
                     float el[3], er[3];                 // columns 4 w - 1 / 4 w + 4 of the three frames (zero padding at the ends of the 32 sub-bands)
 #pragma unroll
                     for (int fr = 0; fr < 3; ++fr) {
-                        el[fr] = wave > 0 ? halo[((((wave - 1) * 2 + 1) * 3 + fr) * 32 + sl) * 16 + li] : 0.0f;
-                        er[fr] = wave < 7 ? halo[((((wave + 1) * 2 + 0) * 3 + fr) * 32 + sl) * 16 + li] : 0.0f;
+                        // (unconditional reads of a clamped slot, then a select: as conditional reads they became wave-uniform branches whose loads were hoisted to the top of the pass)
+                        const float tl = halo[((((wave > 0 ? wave - 1 : 0) * 2 + 1) * 3 + fr) * 32 + sl) * 16 + li];
+                        const float tr = halo[((((wave < 7 ? wave + 1 : 7) * 2 + 0) * 3 + fr) * 32 + sl) * 16 + li];
+                        el[fr] = wave > 0 ? tl : 0.0f;
+                        er[fr] = wave < 7 ? tr : 0.0f;
                     }
                     const float c0[6] = {el[0], old0[r][0], old0[r][1], old0[r][2], old0[r][3], er[0]};
                     const float c1[6] = {el[1], old1[r][0], old1[r][1], old1[r][2], old1[r][3], er[1]};
-                    const float c2[6] = {el[2], xc[t][0][r], xc[t][1][r], xc[t][2][r], xc[t][3][r], er[2]};
+                    const float c2[6] = {el[2], xc[0][r], xc[1][r], xc[2][r], xc[3][r], er[2]};
+                    f32x4 wq[3];                        // this channel's nine taps (dt * 3 + df = 4 q + e)
+#pragma unroll
+                    for (int q3 = 0; q3 < 3; ++q3) wq[q3] = row4(D + Q::DW + ((t * 4 + r) * 3 + q3) * 16);
 #pragma unroll
                     for (int fl = 0; fl < 4; ++fl) {
                         float acc = wbq[r];
 #pragma unroll
                         for (int df = 0; df < 3; ++df) {
-                            acc = __builtin_fmaf(wq[df][r], c0[fl + df], acc);
-                            acc = __builtin_fmaf(wq[3 + df][r], c1[fl + df], acc);
-                            acc = __builtin_fmaf(wq[6 + df][r], c2[fl + df], acc);
+                            acc = __builtin_fmaf(wq[df / 4][df % 4], c0[fl + df], acc);
+                            acc = __builtin_fmaf(wq[(3 + df) / 4][(3 + df) % 4], c1[fl + df], acc);
+                            acc = __builtin_fmaf(wq[(6 + df) / 4][(6 + df) % 4], c2[fl + df], acc);
                         }
-                        gg[t][fl][r] = mish_f(acc) * vv[t][fl][r];
+                        gg[t][fl][r] = lsb_mish(acc) * vv[fl][r];
                     }
                     if (live) {         // the new cache: frames (t - 1, t) - this wave's own columns, which no other wave reads from the tensor
                         float* dst = cgp + (16 * t + 4 * lg + r) * 64 + 4 * wave;
                         *reinterpret_cast<f32x4*>(dst) = old1[r];
-                        *reinterpret_cast<f32x4*>(dst + 32) = f32x4{xc[t][0][r], xc[t][1][r], xc[t][2][r], xc[t][3][r]};
+                        *reinterpret_cast<f32x4*>(dst + 32) = f32x4{xc[0][r], xc[1][r], xc[2][r], xc[3][r]};
                     }
+                    __builtin_amdgcn_sched_barrier(0);  // (one channel at a time: sixteen short independent Mish chains interleaved were scheduled into spills)
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 f2w0 = frag(D + Q::F2_W), f2w1 = frag(D + Q::F2_W + 256), f2b = row4(D + Q::F2_B);
 #pragma unroll
             for (int fl = 0; fl < 4; ++fl) {
                 f32x4 o = f2b;
