@@ -109,20 +109,23 @@ struct LDebugLayout {
     __host__ __device__ static constexpr size_t total() { return offset(n_stages); }
 };
 
-struct LLds {
+// PART (r6): the plan of lisennet_frame_kernel<.., PART>: 0 = the whole frame; the two per-stream parts of the three-launch step keep only what they
+// touch (PART 1: up to conv_2 - 23.9 KB, six workgroups per CU; PART 2: the decoder tail, u3 / u3p under the iSTFT's buffers - 16.5 KB)
+template <int PART>
+struct LLdsT {
     static constexpr int SP = 0;                    // compressed spectrum [257][2]
     static constexpr int TW = SP + 516;
     static constexpr int X2 = TW + 512;             // encoder.conv_2 out [8][128]   (skip of up3)
-    static constexpr int X3 = X2 + 1024;            // encoder.conv_3 out [12][64]   (skip of up2)
-    static constexpr int X4 = X3 + 768;             // encoder.conv_4 out [16][32]   (skip of up1)
-    static constexpr int RED = X4 + 512;            // block-reduction slots [16]
+    static constexpr int X3 = X2 + (PART == 2 ? 0 : 1024);            // encoder.conv_3 out [12][64]   (skip of up2)
+    static constexpr int X4 = X3 + (PART == 0 ? 768 : 0);             // encoder.conv_4 out [16][32]   (skip of up1)
+    static constexpr int RED = X4 + (PART == 0 ? 512 : 0);            // block-reduction slots [16]
     static constexpr int SB = RED + 16;             // ---- phase scratch
     static constexpr int FA = SB, FB = SB + 1024;
     static constexpr int FEAT = SB + 2048;          // features [3][260]  /  phases [260] behind them
     static constexpr int PHA = FEAT + 780;
     static constexpr int X1 = SB;                   // conv_1 out, current frame [4][260] (after the FFT buffers are dead)
     static constexpr int X1P = SB + 1040;           // previous frame (cache)
-    static constexpr int XP = SB + 3100;            // previous-frame copy of the current DSConv's input [<= 12 x 64 .. 8 x 128 = 1024]
+    static constexpr int XP = SB + (PART == 1 ? 2080 : 3100);            // previous-frame copy of the current DSConv's input [<= 12 x 64 .. 8 x 128 = 1024]
     static constexpr int Y = SB + 4200;             // DSConv pre-norm output [<= 1024]
     // DPR blocks
     static constexpr int XT = SB;                   // tokens [32 f][16 d]
@@ -139,20 +142,17 @@ struct LLds {
     // decoder
     static constexpr int U1 = SB;                   // [12][64]
     static constexpr int U2 = SB + 768;             // [8][128]
-    static constexpr int U3 = SB + 1792;            // [4][256]
-    static constexpr int U3P = SB + 2816;           // previous frame (cache) [4][256]
-    static constexpr int MY = SB + 3840;            // mask conv out [2][260]
-    static constexpr int MK = SB + 4360;            // mask [2][260]
-    static constexpr int WST = SB + 6656;           // weight staging area of the conv phases (one layer's weights at a time)
+    static constexpr int U3 = SB + (PART == 2 ? 0 : 1792);            // [4][256]
+    static constexpr int U3P = SB + (PART == 2 ? 1024 : 2816);           // previous frame (cache) [4][256]
+    static constexpr int MY = SB + (PART == 2 ? 2048 : 3840);            // mask conv out [2][260]
+    static constexpr int MK = SB + (PART == 2 ? 2568 : 4360);            // mask [2][260]
+    static constexpr int WST = SB + (PART == 1 ? 3104 : 6656);           // weight staging area of the conv phases (one layer's weights at a time; PART 1: conv_2's 792 floats)
     static constexpr int WST_SIZE = 4672;
-    static constexpr int TOTAL = WST + WST_SIZE;
-    // r6: the two per-stream parts of the three-launch step use a prefix of the plan (PART 1: up to conv_2, its staged weights at WST1; PART 2: the
-    // decoder tail) - 33 KB instead of 59: four workgroups per CU
-    static constexpr int WST1 = SB + 4200;
-    static constexpr int total(int part) { return part == 1 ? WST1 + 800 : part == 2 ? MK + 520 : TOTAL; }
+    static constexpr int TOTAL = PART == 1 ? WST + 800 : PART == 2 ? MK + 520 : WST + WST_SIZE;
     static_assert(SB % 2 == 0 && TW % 2 == 0, "float2 alignment");
     static_assert((size_t)TOTAL * 4 <= 64 * 1024, "static LDS");
 };
+using LLds = LLdsT<0>;
 
 __device__ __forceinline__ float mish_f(float x) {
     const float sp_ = x > 20.0f ? x : log1pf(__expf(x));       // softplus (torch's threshold 20)
@@ -173,11 +173,11 @@ namespace fe {
 // PART (r6): 0 = the whole frame; 1 = STFT .. encoder.conv_2 of a per-hop step whose middle runs batched over the streams (lisennet_sb_kernel): x2, its
 // cached frame and the compressed spectrum go to the carry; 2 = that step's tail (decoder cache, mask conv .. iSTFT) from the carry's up3 output.
 template <class S, bool PROF, bool DBG, bool PIPE = false, int PART = 0>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PART == 0 ? 2 : 4, PART == 0 ? 2 : 4))) lisennet_frame_kernel(LArgs a) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((PART == 0 || DBG) ? 2 : PART == 1 ? 6 : 5, (PART == 0 || DBG) ? 2 : PART == 1 ? 6 : 5))) lisennet_frame_kernel(LArgs a) {
     static_assert(!PIPE || (!PROF && !DBG), "the time-pipelined instantiation is the plain offline kernel");
     static_assert(PART == 0 || !PIPE, "the split step is a streaming step");
-    __shared__ __attribute__((aligned(16))) float smem[LLds::total(PART)];
-    using L = LLds;
+    __shared__ __attribute__((aligned(16))) float smem[LLdsT<PART>::TOTAL];
+    using L = LLdsT<PART>;
     using P = LPk;
     constexpr int N = S::NFFT, H = S::HOP, OVL = S::OVL, BINS = S::BINS;
     const int tid0 = threadIdx.x;
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(P
 
         // a conv layer's weights (a contiguous block of the packed buffer) -> LDS in one coalesced burst: the layers then read them
         // with LDS latency instead of an L2 round trip per tap (all threads call; ends with a barrier)
-        float* wst = smem + (PART == 1 ? L::WST1 : L::WST);
+        float* wst = smem + L::WST;
         auto stage = [&](int base, int n) {
             for (int i = tid; i < n; i += kThreads) wst[i] = wp[base + i];
             __syncthreads();
@@ -978,10 +978,10 @@ void llaunch_impl(const LArgs& a, int max_wgs, hipStream_t st, hipError_t* err) 
 // (lisennet_sb_kernel), tail per stream (PART 2).  fe_debug_step: the same three launches with per-stage dumps; fe_profile_step: the middle's counters.
 template <class S>
 void llaunch_sb_impl(const LArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
-    constexpr int OCC = 4;                                         // (33 KB of LDS, <= 128 VGPRs: the parts run four workgroups per CU)
-    static_assert(LLds::total(1) * 4 * OCC <= 160 * 1024 && LLds::total(2) * 4 * OCC <= 160 * 1024, "LDS of the parts");
-    const int slots = max_wgs * OCC;
-    const int grid = a.B < slots ? a.B : slots;
+    constexpr int OCC1 = 6, OCC2 = 5;                              // (24 / 16.5 KB of LDS, <= 85 / 102 VGPRs: the parts run six / five workgroups per CU)
+    static_assert(LLdsT<1>::TOTAL * 4 * OCC1 <= 160 * 1024 && LLdsT<2>::TOTAL * 4 * OCC2 <= 160 * 1024, "LDS of the parts");
+    const int grid = a.B < max_wgs * OCC1 ? a.B : max_wgs * OCC1;
+    const int grid2 = a.B < max_wgs * OCC2 ? a.B : max_wgs * OCC2;
     note_kernel(a.dbg != nullptr ? "lisennet_frame_kernel<PART 1, debug>" : "lisennet_frame_kernel<PART 1>");
     if (a.dbg != nullptr) hipLaunchKernelGGL((lisennet_frame_kernel<S, false, true, false, 1>), dim3(grid), dim3(kThreads), 0, st, a);
     else hipLaunchKernelGGL((lisennet_frame_kernel<S, false, false, false, 1>), dim3(grid), dim3(kThreads), 0, st, a);
@@ -992,8 +992,8 @@ void llaunch_sb_impl(const LArgs& a, int max_wgs, hipStream_t st, hipError_t* er
     *err = lisennet_sb_launch<S>(sa, st);
     if (*err != hipSuccess) return;
     note_kernel(a.dbg != nullptr ? "lisennet_frame_kernel<PART 2, debug>" : "lisennet_frame_kernel<PART 2>");
-    if (a.dbg != nullptr) hipLaunchKernelGGL((lisennet_frame_kernel<S, false, true, false, 2>), dim3(grid), dim3(kThreads), 0, st, a);
-    else hipLaunchKernelGGL((lisennet_frame_kernel<S, false, false, false, 2>), dim3(grid), dim3(kThreads), 0, st, a);
+    if (a.dbg != nullptr) hipLaunchKernelGGL((lisennet_frame_kernel<S, false, true, false, 2>), dim3(grid2), dim3(kThreads), 0, st, a);
+    else hipLaunchKernelGGL((lisennet_frame_kernel<S, false, false, false, 2>), dim3(grid2), dim3(kThreads), 0, st, a);
     *err = hipGetLastError();
 }
 

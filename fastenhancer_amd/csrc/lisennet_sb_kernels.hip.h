@@ -315,7 +315,6 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
                 s1 = __builtin_fmaf(accH[i][0][r], accH[i][0][r], s1);
             }
         const float rstd = 1.0f / sqrtf(tile_sum(val ? s1 : 0.0f, 1) * (1.0f / 768.0f) + 1.0e-5f);
-        float* c4 = cache_ptr(S::K_PHA + S::K_E2 + S::K_E3, S::K_E4);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int P = i < 4 ? 4 * wave + i : 32 + 4 * wave + (i - 4);
@@ -329,10 +328,10 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
             if (val) {
                 *reinterpret_cast<f32x4*>(ct + A::X3C::row(P) + lg * 64 + li * 4) = y;
                 *reinterpret_cast<f32x4*>(ct + A::X3S::row(P) + lg * 64 + li * 4) = y;
-                if (live) {
+                // the new cache frame [12][64] per stream: through LDS ([channel][n][f + 1 pad], the prologue's staging area) and out as whole rows below -
+                // stored from here, one float per (channel, position, stream), it was 12 288 partial-line writes per tile: 35 k of this phase's 54 k cycles
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) c4[(4 * lg + r) * 64 + P] = y[r];
-                }
+                for (int r = 0; r < 4; ++r) smem[L::T3 + ((4 * lg + r) * 16 + li) * 65 + P] = y[r];
                 if (dbg) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dbg[LDebugLayout::offset(5) + (4 * lg + r) * 64 + P] = y[r];
@@ -341,6 +340,15 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
         }
     }
     __syncthreads();
+    {
+        float* c4 = a.cache + (size_t)(S::K_PHA + S::K_E2 + S::K_E3) * a.B;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int i = tid + k * kLsbThreads, n = i / (S::K_E4 / 4), e = (i - n * (S::K_E4 / 4)) * 4, c = e >> 6, f = e & 63;
+            const float* t3 = smem + L::T3 + (c * 16 + n) * 65 + f;
+            if (b0 + n < a.B) *reinterpret_cast<f32x4*>(c4 + (size_t)(b0 + n) * S::K_E4 + e) = f32x4{t3[0], t3[1], t3[2], t3[3]};
+        }
+    }
     LSB_CLK(2);
     // ---------------- encoder.conv_4: DSConv(12 -> 16, 64 bins -> 32) -> the up1 skip and the blocks' tokens ----------------
     {
@@ -443,6 +451,7 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
 #pragma unroll
                 for (int r = 0; r < 4; ++r) X[((4 * wave + fl) * 16 + 4 * r + lg) * 16 + li] = __builtin_fmaf(v[fl][r] * rstd, nw[fl][r], nb[fl][r]);
         }
+        float pf[3];
         const f32x4 awx = frag(D + Q::I_W + (wave * 2 + 0) * 256), awh = frag(D + Q::I_W + (wave * 2 + 1) * 256);
         const f32x4 ibias = row4(D + Q::I_B + wave * 16);
         __syncthreads();
@@ -476,6 +485,14 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
             accx = accn;
             xload(xb, f0 + 2 * fstep);
             __syncthreads();
+            // the block's cache tensors (inter GRU state 3 KB, conv_glu frames 8 KB per stream: first touched this step, so in HBM) are requested HERE - behind the
+                // recurrence's own fragment fetches (vmcnt completes in order), one dword per 128-byte line and thread - and land in L2 under its 29 k cycles
+            {
+                const int pn = tid >> 5, pj = tid & 31, pbs = b0 + pn < a.B ? b0 + pn : a.B - 1;
+                const float* pg = a.cache + (size_t)(OFF_BLK + blk * (S::K_H + S::K_GLU) + S::K_H) * a.B + (size_t)pbs * S::K_GLU;
+                const float* ph = a.cache + (size_t)(OFF_BLK + blk * (S::K_H + S::K_GLU)) * a.B + (size_t)pbs * S::K_H;
+                pf[0] = pg[(2 * pj) * 32]; pf[1] = pg[(2 * pj + 1) * 32]; pf[2] = ph[(pj < 24 ? pj : 23) * 32];
+            }
             int f = f0 + fstep;
 #pragma unroll 1
             for (int s = 1; s < 32; ++s) {
@@ -495,6 +512,7 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
                 __syncthreads();
             }
         }
+        asm volatile("" :: "v"(pf[0]), "v"(pf[1]), "v"(pf[2]));         // (the touches above: consumed here so that they are not dropped)
         LSB_CLK(5 + 6 * blk);
         // the inter GRU state of this wave's sub-bands: unit 16 t + 4 lg + r (24 units: tile 1's lane groups 2, 3 are idle)
         f32x4 hp[4][2];
@@ -633,6 +651,7 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
 #pragma unroll
                 for (int r = 0; r < 4; ++r) zn[fl][r] = __builtin_fmaf(zn[fl][r] * rstd, nw[fl][r], nb[fl][r]);
             __builtin_amdgcn_sched_barrier(0);
+            if (blk == 0) LSB_CLK(20);
             // fc1's first half (the conv input, channels 16 t + 4 lg + r) of the wave's EDGE sub-bands only, for the neighbour waves; a pass below computes
             // its channel tile for all four sub-bands again (16 more MFMAs per block: keeping both tiles across the passes is what spilled)
             f32x4 xe[2][2];
@@ -667,9 +686,11 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
                 }
             f32x4 gg[2][4];
             __syncthreads();
+            if (blk == 0) LSB_CLK(21);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 __builtin_amdgcn_sched_barrier(0);
+                if (blk == 0 && t == 1) LSB_CLK(22);
                 const f32x4 wbq = row4(D + Q::DWB + t * 16);
                 // fc1 for this pass's channels: the conv half (tile t) and the gate half (tile 2 + t)
                 f32x4 xc[4], vv[4];
@@ -727,6 +748,7 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (blk == 0) LSB_CLK(23);
             const f32x4 f2w0 = frag(D + Q::F2_W), f2w1 = frag(D + Q::F2_W + 256), f2b = row4(D + Q::F2_B);
 #pragma unroll
             for (int fl = 0; fl < 4; ++fl) {

@@ -267,7 +267,8 @@ class Engine:
 
     def set_option(self, name: str, value: int):
         """fe_set_option: the other kernel-selection switches of the handle by name ("bsrnn_role_split", "bsrnn_stream_batch_min",
-        "bsrnn_three_launch_step", "bsrnn_ov_profile", "fspen_stream_batch_min", "low_lds_companion"; include/fastenhancer_hip.h)."""
+        "bsrnn_three_launch_step", "bsrnn_ov_profile", "fspen_stream_batch_min", "low_lds_companion", "bsrnn_fused_step", "lisennet_stream_batch_min";
+        include/fastenhancer_hip.h)."""
         _lib.check(self.lib.fe_set_option(self._h, name.encode(), int(value)), "fe_set_option")
 
     def get_option(self, name: str) -> int:

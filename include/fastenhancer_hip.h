@@ -195,7 +195,7 @@ int fe_set_step_kernel(fe_handle* h, int kernel);
  *   name                       range      default  meaning
  *   "bsrnn_role_split"         0 | 1      1        BSRNN, num_channels 16, up to one stream per CU: PART 1 of the per-hop step on the role-split
  *                                                  kernel (bsrnn_ov_kernels.hip.h); 0 = the phase-by-phase kernel (what fe_set_step_kernel(WAVES4) selects too)
- *   "bsrnn_stream_batch_min"   0 .. 2^24  2048     BSRNN, num_channels 16: from this many streams the layers run batched over the streams
+ *   "bsrnn_stream_batch_min"   0 .. 2^24  2048     BSRNN, num_channels 16 and (r6) 32: from this many streams the layers run batched over the streams
  *                                                  (bsrnn_sb_kernels.hip.h); 0 = never
  *   "bsrnn_three_launch_step"  0 | 1      1        BSRNN per-hop step as PART 1 -> batched mask decoder -> PART 2; 0 = one fused kernel per stream
  *   "bsrnn_ov_profile"         0 | 1      0        fe_profile_step probes the role-split PART 1 instead of the fused kernel's phases
@@ -207,8 +207,10 @@ int fe_set_step_kernel(fe_handle* h, int kernel);
  *                                                  their tile, meet again and finish their own streams; 0 = three launches (a launch the runtime
  *                                                  refuses falls back to them by itself).  Bit-identical results; MEASURED SLOWER (barriers across XCDs,
  *                                                  cooperative launch: profiles/r6_bsrnn_fused_step.txt), hence off by default
+ *   "lisennet_stream_batch_min" 0 .. 2^24 1024     LiSenNet (r6): from this many streams the per-hop step runs encoder.conv_3 .. decoder.up3 batched over the streams on
+ *                                                  the matrix cores (lisennet_sb_kernels.hip.h: front per stream, sixteen streams per workgroup, tail per stream); 0 = never
  * A/B scripts (tools/ab_*.sh) preset the values NEW handles start with through FE_BSRNN_OV, FE_BSRNN_SB, FE_BSRNN_SPLIT, FE_BSRNN_OV_PROF,
- * FE_FSPEN_SB, FE_LOWLDS (FE_NO_LOWLDS), FE_BSRNN_FUSED and FE_WG8 (the step kernel): read once, in fe_create, validated against the same ranges (anything else
+ * FE_FSPEN_SB, FE_LOWLDS (FE_NO_LOWLDS), FE_BSRNN_FUSED, FE_LISENNET_SB and FE_WG8 (the step kernel): read once, in fe_create, validated against the same ranges (anything else
  * is ignored).  The reference has one forward per model and nothing to select (models/fastenhancer/default/model.py:677-710). */
 int fe_set_option(fe_handle* h, const char* name, int value);
 int fe_get_option(const fe_handle* h, const char* name, int* value);

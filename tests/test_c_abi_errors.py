@@ -218,7 +218,7 @@ def test_options_are_enumerable_validated_and_preset_by_their_environment_variab
     import re
     lib = _lib.load()
     names = [lib.fe_option_name(i).decode() for i in range(lib.fe_options())]
-    assert names == ["bsrnn_role_split", "bsrnn_stream_batch_min", "bsrnn_three_launch_step", "bsrnn_ov_profile", "fspen_stream_batch_min", "low_lds_companion", "bsrnn_fused_step"]
+    assert names == ["bsrnn_role_split", "bsrnn_stream_batch_min", "bsrnn_three_launch_step", "bsrnn_ov_profile", "fspen_stream_batch_min", "low_lds_companion", "bsrnn_fused_step", "lisennet_stream_batch_min"]
     assert lib.fe_option_name(len(names)) is None and lib.fe_option_name(-1) is None
     header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fastenhancer_hip.h")).read()
     integration = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
@@ -227,8 +227,8 @@ def test_options_are_enumerable_validated_and_preset_by_their_environment_variab
         assert n in integration, n
     assert "fe_last_step_kernel" in header and "fe_last_step_kernel" in integration
     defaults = {"bsrnn_role_split": 1, "bsrnn_stream_batch_min": 2048, "bsrnn_three_launch_step": 1, "bsrnn_ov_profile": 0,
-                "fspen_stream_batch_min": 1536, "low_lds_companion": 1, "bsrnn_fused_step": 0}
-    for v in ("FE_BSRNN_OV", "FE_BSRNN_SB", "FE_BSRNN_SPLIT", "FE_BSRNN_OV_PROF", "FE_FSPEN_SB", "FE_LOWLDS", "FE_NO_LOWLDS", "FE_WG8", "FE_BSRNN_FUSED"):
+                "fspen_stream_batch_min": 1536, "low_lds_companion": 1, "bsrnn_fused_step": 0, "lisennet_stream_batch_min": 1024}
+    for v in ("FE_BSRNN_OV", "FE_BSRNN_SB", "FE_BSRNN_SPLIT", "FE_BSRNN_OV_PROF", "FE_FSPEN_SB", "FE_LOWLDS", "FE_NO_LOWLDS", "FE_WG8", "FE_BSRNN_FUSED", "FE_LISENNET_SB"):
         monkeypatch.delenv(v, raising=False)
     rc, h = _create(_cfg())
     assert rc == 0
@@ -249,7 +249,8 @@ def test_options_are_enumerable_validated_and_preset_by_their_environment_variab
         lib.fe_destroy(h)
     # presets: a valid value is taken, garbage and out-of-range values are ignored
     for env, opt, good, bad in (("FE_BSRNN_OV", "bsrnn_role_split", "0", ("2", "x", "-1", "")), ("FE_BSRNN_SB", "bsrnn_stream_batch_min", "512", ("-5", "1e3", "99999999999")),
-                                ("FE_FSPEN_SB", "fspen_stream_batch_min", "0", ("no",)), ("FE_LOWLDS", "low_lds_companion", "0", ("3",))):
+                                ("FE_FSPEN_SB", "fspen_stream_batch_min", "0", ("no",)), ("FE_LOWLDS", "low_lds_companion", "0", ("3",)),
+                                ("FE_LISENNET_SB", "lisennet_stream_batch_min", "1", ("-2", "many"))):
         for v in (good,) + bad:
             monkeypatch.setenv(env, v)
             rc, h = _create(_cfg())

@@ -32,6 +32,7 @@ def main():
         prev = q[3] if b == 0 else q[o - 3]
         print(f"  block {b}: intra_norm {q[o] - prev}, intra GRU (32 steps x 2 directions) {q[o + 1] - q[o]}, dense + inter_norm + inter GRU + dense {q[o + 2] - q[o + 1]}, "
               f"conv_glu {q[o + 3] - q[o + 2]}")
+    print(f"  block 0 conv_glu: statistics + affine {q[20] - q[6]}, fc1 edges + cached frames + edge columns + barrier {q[21] - q[20]}, pass 0 {q[22] - q[21]}, pass 1 {q[23] - q[22]}, fc2 + barrier {q[7] - q[23]}")
     print(f"  block output -> carry {q[16] - q[13]}, up1 {q[17] - q[16]}, up2 {q[18] - q[17]}, up3 {q[19] - q[18]}")
     # wall time of the step
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
