@@ -1393,7 +1393,7 @@ BImpl make_bimpl() {
     return BImpl{S::C, S::NLAY, S::HOP, BLds<S>::BYTES, S::XPG ? (size_t)2 * 32 * S::G4 : (size_t)0,
                  BDebugLayout<S>::total(), BDebugLayout<S>::n_stages, S::WREG, S::KSPLIT, S::NTD, &blaunch_impl<S>, &bdbg_stage_impl<S>,
                  &blaunch_pipe_impl<S>, 1,       // (the PIPE instantiation is compiled for one workgroup per CU: waves_per_eu(1, 1))
-                 &blaunch_split_impl<S>, SbLds<S>::FITS ? &blaunch_sb_impl<S> : nullptr};
+                 &blaunch_split_impl<S>, (SbLds<S>::FITS || Sb64Lds<S>::FITS) ? &blaunch_sb_impl<S> : nullptr};
 }
 
 }  // namespace fe

@@ -52,7 +52,7 @@ struct SbLds {
     static constexpr int TOTAL = WT + (TSPLIT ? 0 : WT_N);
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
     // (num_channels = 64: the band features of sixteen streams alone are 127 KiB and a direction's gate fragments 384 registers per lane - the per-stream kernel keeps it)
-    static constexpr bool FITS = (S::C == 16 || S::C == 32) && BYTES <= 160 * 1024;
+    static constexpr bool FITS = (S::C == 16 || S::C == 32) && BYTES <= 160 * 1024;     // (num_channels = 64: bsrnn_sb64_layers_kernel below, Sb64Lds)
 };
 
 // offsets (floats) of the stream-batched layer weights inside the packed buffer (host: fe_api.hip::pack_weights_bsrnn)
@@ -61,6 +61,9 @@ struct SbOffsets {
     int tfc_w[8], tfc_b[8];       // fc_time: A fragments [tile < C / 16][k-step < KSH][64]; bias [tile][lg][r]
     int f_w[8][2], f_b[8][2];     // band LSTM per direction: as the time LSTM's
     int ffc_w[8][2], ffc_b[8];    // fc_freq per direction half: A fragments [tile][k-step < KSH][64]; bias
+    // num_channels = 64 (bsrnn_sb64_layers_kernel): every matrix once more in k4 order [tile][k-step / 4][lane][4] - 16-byte fragment fetches
+    int f_wx4[8][2], f_wh4[8][2];  // band LSTM: the x k-steps (streamed every step), the h k-steps
+    int t_w4[8], tfc_w4[8], ffc_w4[8][2];
 };
 
 struct SbArgs {
@@ -415,13 +418,256 @@ __global__ void __launch_bounds__(kSbThreads) __attribute__((amdgpu_waves_per_eu
     }
 }
 
+
+// ======================================================================== num_channels = 64 (bsrnn_s), r6
+// The band features of sixteen streams are 127 KiB and a direction's gate fragments 384 registers per lane: neither the LDS-resident features nor
+// the register-resident direction of the kernel above carry over.  What does: the transposed products and the packer's row / k orders.
+//   * the band features stay in global memory ([B][31][C], L2): a lane's B operands of a band - channels KSC lg .. KSC lg + 15 - are 64 contiguous
+//     bytes there (four 16-byte loads), and an fc layer's accumulator quadruple (channels KSC lg + 4 to + r) is one 16-byte store: no regrouping at all
+//   * time LSTM: wave w owns gate tiles 4 w .. 4 w + 3 of every band, two at a time (96 fragment registers); bands in two groups of sixteen, the new
+//     h of a group in LDS (128 KiB) for fc_time, whose (band, output tile) jobs are spread over the waves
+//   * band LSTM: ONE direction at a time on all eight waves (62 barrier steps per layer): a wave's four gate tiles keep their h fragments in registers
+//     (128); the x fragments (64) are streamed from L2 every step as 16-byte pieces of a k4-ordered copy, for the NEXT step's x half
+//   * fc_freq: (band, output tile) jobs over the waves, y through the global scratch
+template <class S>
+struct Sb64Lds {
+    static constexpr int GB = 16;
+    static constexpr int HN = 0;                                         // time part: [GB][HH][16] new h of a band group (position 4 t + lg <-> unit KSH lg + t)
+    static constexpr int HB = 0;                                         // band LSTM: [2][HH][16] h of the running step (double buffer), start values [KSH][16] behind it
+    static constexpr int BB = HB + 2 * S::HH * kSbStreams;
+    static constexpr int TOTAL = GB * S::HH * kSbStreams;
+    static constexpr size_t BYTES = (size_t)TOTAL * 4;
+    static constexpr bool FITS = S::C == 64 && BYTES <= 160 * 1024;
+};
+
+template <class S>
+__global__ void __launch_bounds__(kSbThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) bsrnn_sb64_layers_kernel(SbArgs a) {
+    static_assert(S::C == 64, "the num_channels = 64 plan");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using L = Sb64Lds<S>;
+    constexpr int C = S::C, HH = S::HH, KSC = S::KSC, KSH = S::KSH, KS1 = KSC + KSH, NS = kSbStreams, GB = L::GB;
+    static_assert(KSC == 16 && KSH == 32, "tile plans below");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const SbOffsets& o = a.off;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, a.total * 4, 0x00020000);
+    // (a section's base is the instruction's scalar offset; tile and k-step go into the vector offset, whose constant part the instruction carries:
+    //  with everything in the scalar offset every fragment had a scalar register of its own - 148 of them spilled)
+    //  `lzv`: an opaque zero, renewed before every fetch burst - the vector offsets' bases are loop-invariant, and hoisted out of the layer loop they
+    //  stayed live through the whole kernel: 205 spilled registers.  Fragments come as 16-byte pieces of the k4-ordered copies: a quarter of the fetches.)
+    int lzv = 0;
+    auto frag4 = [&](int off, int tile, int nq, int q) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (lane + lzv) * 16 + (tile * nq + q) * 1024, off * 4, 0)); };
+    auto bias4 = [&](int off, int tile) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (lg + lzv) * 16 + tile * 64, off * 4, 0)); };
+#define SB64_RENEW() asm volatile("" : "+v"(lzv))
+    const int b0 = (int)blockIdx.x * NS;
+    const int bs = b0 + li < a.B ? b0 + li : a.B - 1;          // this lane's stream (the last tile's idle columns shadow the last stream)
+    const bool sok = b0 + li < a.B;
+    float* const xg = a.x + (size_t)bs * kBands * C + KSC * lg;                    // + j * C: this lane's sixteen channels of band j
+    auto soff = [&](int j) { return ((size_t)bs * kBands + j) * HH + KSH * lg; };
+    auto yoff = [&](int d, int j) { return (((size_t)bs * 2 + d) * kBands + j) * HH + KSH * lg; };
+    const int to = wave & 3, jw = wave >> 2;                   // fc layers: this wave's output tile, its bands jw, jw + 2, ..
+
+#pragma unroll 1
+    for (int l = 0; l < S::NLAY; ++l) {
+        float* hg = a.lstm + (size_t)(2 * l) * a.B * (kBands * HH);
+        float* cg = a.lstm + (size_t)(2 * l + 1) * a.B * (kBands * HH);
+        // ======================================= time LSTM + fc_time =======================================
+        {
+            float* hnl = smem + L::HN;
+#pragma unroll 1
+            for (int g0 = 0; g0 < kBands; g0 += GB) {
+                const int nb = kBands - g0 < GB ? kBands - g0 : GB;
+#pragma unroll 1
+                for (int sp = 0; sp < 2; ++sp) {
+                    const int t0 = wave * 4 + sp * 2;
+                    SB64_RENEW();
+                    f32x4 Wt[2][KS1 / 4];
+                    f32x4 Wtb[2];
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+                        for (int q = 0; q < KS1 / 4; ++q) Wt[tt][q] = frag4(o.t_w4[l], t0 + tt, KS1 / 4, q);
+                        Wtb[tt] = bias4(o.t_b[l], t0 + tt);
+                    }
+                    f32x4 xq[KSC / 4], hq[KSH / 4];
+                    float cq[2];
+                    auto fetch = [&](int j) {
+#pragma unroll
+                        for (int q = 0; q < KSC / 4; ++q) xq[q] = *reinterpret_cast<const f32x4*>(xg + j * C + 4 * q);
+#pragma unroll
+                        for (int q = 0; q < KSH / 4; ++q) hq[q] = *reinterpret_cast<const f32x4*>(hg + soff(j) + 4 * q);
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt) cq[tt] = cg[soff(j) + t0 + tt];
+                    };
+                    fetch(g0);
+#pragma unroll 1
+                    for (int jl = 0; jl < nb; ++jl) {
+                        const int j = g0 + jl;
+                        float xb[KSC], hp[KSH], cp[2];
+#pragma unroll
+                        for (int ks = 0; ks < KSC; ++ks) xb[ks] = xq[ks / 4][ks % 4];
+#pragma unroll
+                        for (int ks = 0; ks < KSH; ++ks) hp[ks] = hq[ks / 4][ks % 4];
+                        cp[0] = cq[0]; cp[1] = cq[1];
+                        if (jl + 1 < nb) fetch(j + 1);                  // the next band's operands: in flight under this band's MFMAs
+                        f32x4 acc[2] = {Wtb[0], Wtb[1]};
+#pragma unroll
+                        for (int ks = 0; ks < KSC; ++ks)
+#pragma unroll
+                            for (int tt = 0; tt < 2; ++tt) acc[tt] = FE_MFMA(Wt[tt][ks / 4][ks % 4], xb[ks], acc[tt]);
+#pragma unroll
+                        for (int ks = 0; ks < KSH; ++ks)
+#pragma unroll
+                            for (int tt = 0; tt < 2; ++tt) acc[tt] = FE_MFMA(Wt[tt][(KSC + ks) / 4][ks % 4], hp[ks], acc[tt]);
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt) {                   // gate order i, f, g, o (nn.LSTMCell)
+                            const float ig = sb_sig(acc[tt][0]), fg = sb_sig(acc[tt][1]), gg = sb_tanh_pre(acc[tt][2]), og = sb_sig(acc[tt][3]);
+                            const float cn = fg * cp[tt] + ig * gg;
+                            const float hn = og * tanh_f(cn);
+                            if (sok) cg[soff(j) + t0 + tt] = cn;
+                            hnl[((jl * HH) + 4 * (t0 + tt) + lg) * NS + li] = hn;
+                        }
+                    }
+                }
+                // fc_time's fragments of this wave's output tile (fetched per group: next to the gate fragments they would not fit)
+                SB64_RENEW();
+                f32x4 Wf1[KSH / 4];
+#pragma unroll
+                for (int q = 0; q < KSH / 4; ++q) Wf1[q] = frag4(o.tfc_w4[l], to, KSH / 4, q);
+                const f32x4 Wf1b = bias4(o.tfc_b[l], to);
+                __syncthreads();
+                // fc_time + residual: (band, output tile) jobs; the tile-0 wave of a band writes the band's new h to the state tensor (only now: every
+                // wave has read h_{t-1} of this group before the barrier)
+#pragma unroll 1
+                for (int jl = jw; jl < nb; jl += 2) {
+                    const int j = g0 + jl;
+                    float hn[KSH];
+#pragma unroll
+                    for (int ks = 0; ks < KSH; ++ks) hn[ks] = hnl[((jl * HH) + 4 * ks + lg) * NS + li];
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(xg + j * C + 4 * to);
+                    if (sok && to == 0) {
+#pragma unroll
+                        for (int q = 0; q < KSH / 4; ++q)
+                            *reinterpret_cast<f32x4*>(hg + soff(j) + 4 * q) = f32x4{hn[4 * q], hn[4 * q + 1], hn[4 * q + 2], hn[4 * q + 3]};
+                    }
+                    f32x4 a2 = Wf1b;
+#pragma unroll
+                    for (int ks = 0; ks < KSH; ++ks) a2 = FE_MFMA(Wf1[ks / 4][ks % 4], hn[ks], a2);
+                    if (sok) *reinterpret_cast<f32x4*>(xg + j * C + 4 * to) = f32x4{xv[0] + a2[0], xv[1] + a2[1], xv[2] + a2[2], xv[3] + a2[3]};
+                }
+                __syncthreads();
+            }
+        }
+        // ======================================= band LSTM: one direction at a time, all eight waves, 31 steps each =======================================
+#pragma unroll 1
+        for (int d = 0; d < 2; ++d) {
+            float* hb = smem + L::HB;
+            float* bb = smem + L::BB;
+            SB64_RENEW();
+            f32x4 Wh[4][KSH / 4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int q = 0; q < KSH / 4; ++q) Wh[tt][q] = frag4(o.f_wh4[l][d], wave * 4 + tt, KSH / 4, q);
+            // (start values [tile][lg][r] -> LDS: they would not fit next to the fragments)
+            for (int i = tid; i < KSH * 16; i += kSbThreads) bb[i] = a.wp[o.f_b[l][d] + i];
+            for (int i = tid; i < HH * NS; i += kSbThreads) hb[i] = 0.0f;          // h = 0 (buffer 0)
+            float cst[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            f32x4 accx[4];
+            const int wx = o.f_wx4[l][d] + (wave * 4) * (KSC / 4) * 256;
+            __syncthreads();
+            auto xpart = [&](int j) {                         // the x half of a step's gates: the fragments streamed from L2 (k4 order)
+                SB64_RENEW();
+                f32x4 xq[KSC / 4];
+#pragma unroll
+                for (int q = 0; q < KSC / 4; ++q) xq[q] = *reinterpret_cast<const f32x4*>(xg + j * C + 4 * q);
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) accx[tt] = *reinterpret_cast<const f32x4*>(bb + (wave * 4 + tt) * 16 + 4 * lg);
+#pragma unroll
+                for (int q = 0; q < KSC / 4; ++q) {
+                    f32x4 w4[4];
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) w4[tt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (lane + lzv) * 16 + (tt * (KSC / 4) + q) * 1024, wx * 4, 0));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) accx[tt] = FE_MFMA(w4[tt][e], xq[q][e], accx[tt]);
+                    __builtin_amdgcn_sched_barrier(0);          // (four fragment quadruples in flight at a time: all sixteen hoisted were 64 registers)
+                }
+            };
+            xpart(d ? kBands - 1 : 0);
+            int cur = 0;
+#pragma unroll 1
+            for (int s = 0; s < kBands; ++s) {
+                const int j = d ? kBands - 1 - s : s;
+                const float* hc = hb + cur * (HH * NS);
+                f32x4 acc[4];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) acc[tt] = accx[tt];
+#pragma unroll
+                for (int hf2 = 0; hf2 < 2; ++hf2) {
+                    float hf[KSH / 2];
+#pragma unroll
+                    for (int ks = 0; ks < KSH / 2; ++ks) hf[ks] = hc[(4 * (16 * hf2 + ks) + lg) * NS + li];
+#pragma unroll
+                    for (int ks = 0; ks < KSH / 2; ++ks)
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) acc[tt] = FE_MFMA(Wh[tt][(16 * hf2 + ks) / 4][ks % 4], hf[ks], acc[tt]);
+                }
+                float* hnx = hb + (cur ^ 1) * (HH * NS);
+                f32x4 yv;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const float ig = sb_sig(acc[tt][0]), fg = sb_sig(acc[tt][1]), gg = sb_tanh_pre(acc[tt][2]), og = sb_sig(acc[tt][3]);
+                    cst[tt] = fg * cst[tt] + ig * gg;
+                    const float hv = og * tanh_f(cst[tt]);
+                    hnx[(4 * (wave * 4 + tt) + lg) * NS + li] = hv;         // unit KSH lg + t <-> position 4 t + lg
+                    yv[tt] = hv;
+                }
+                *reinterpret_cast<f32x4*>(a.y + yoff(d, j) + 4 * wave) = yv;      // (the last tile's idle columns shadow the last stream: same value)
+                if (s + 1 < kBands) xpart(d ? kBands - 2 - s : s + 1);      // the x half of the next step: before the barrier
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+        // ======================================= fc_freq + residual: x += b + W [y_fwd | y_bwd], (band, output tile) jobs =======================================
+        {
+            SB64_RENEW();
+            f32x4 Wf2[2][KSH / 4];
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                for (int q = 0; q < KSH / 4; ++q) Wf2[dd][q] = frag4(o.ffc_w4[l][dd], to, KSH / 4, q);
+            const f32x4 Wf2b = bias4(o.ffc_b[l], to);
+#pragma unroll 1
+            for (int j = jw; j < kBands; j += 2) {
+                f32x4 yq[2][KSH / 4];
+#pragma unroll
+                for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                    for (int q = 0; q < KSH / 4; ++q) yq[dd][q] = *reinterpret_cast<const f32x4*>(a.y + yoff(dd, j) + 4 * q);
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xg + j * C + 4 * to);
+                f32x4 a2 = Wf2b;
+#pragma unroll
+                for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                    for (int ks = 0; ks < KSH; ++ks) a2 = FE_MFMA(Wf2[dd][ks / 4][ks % 4], yq[dd][ks / 4][ks % 4], a2);
+                if (sok) *reinterpret_cast<f32x4*>(xg + j * C + 4 * to) = f32x4{xv[0] + a2[0], xv[1] + a2[1], xv[2] + a2[2], xv[3] + a2[3]};
+            }
+        }
+        __syncthreads();
+    }
+#undef SB64_RENEW
+}
+
 template <class S>
 void sb_launch_layers(const SbArgs& a, hipStream_t st, hipError_t* err) {
+    static std::atomic<bool> attr_set[64];      // (more than 64 KB of dynamic LDS; per device: a process may drive several)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if constexpr (SbLds<S>::FITS) {
         auto* fn = &bsrnn_sb_layers_kernel<S>;
-        static std::atomic<bool> attr_set[64];      // (more than 64 KB of dynamic LDS; per device: a process may drive several)
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
         if (!attr_set[dev].load(std::memory_order_relaxed)) {
             *err = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SbLds<S>::BYTES);
             if (*err != hipSuccess) return;
@@ -429,6 +675,16 @@ void sb_launch_layers(const SbArgs& a, hipStream_t st, hipError_t* err) {
         }
         note_kernel("bsrnn_sb_layers_kernel");
         hipLaunchKernelGGL(fn, dim3((a.B + kSbStreams - 1) / kSbStreams), dim3(kSbThreads), SbLds<S>::BYTES, st, a);
+        *err = hipGetLastError();
+    } else if constexpr (Sb64Lds<S>::FITS) {
+        auto* fn = &bsrnn_sb64_layers_kernel<S>;
+        if (!attr_set[dev].load(std::memory_order_relaxed)) {
+            *err = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Sb64Lds<S>::BYTES);
+            if (*err != hipSuccess) return;
+            attr_set[dev].store(true, std::memory_order_relaxed);
+        }
+        note_kernel("bsrnn_sb64_layers_kernel");
+        hipLaunchKernelGGL(fn, dim3((a.B + kSbStreams - 1) / kSbStreams), dim3(kSbThreads), Sb64Lds<S>::BYTES, st, a);
         *err = hipGetLastError();
     } else {
         *err = hipErrorNotSupported;

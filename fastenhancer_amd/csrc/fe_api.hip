@@ -786,7 +786,10 @@ int launch_bsrnn(fe_handle* h, const fe::BArgs& a_in, void* stream) {
             a.gsync = (h->opt[OPT_BSRNN_FUSED] && a.clk == nullptr && (a.B + 15) / 16 <= kSyncTiles) ? h->bsync_dev : nullptr;
             // large batches: the LSTM layers batched over the streams on the matrix cores (sixteen streams per workgroup) - from the batch
             // size where sixteen-stream workgroups fill the chip better than one stream per workgroup (FE_BSRNN_SB: that threshold; 0 = never)
-            const int sb_min = h->opt[OPT_BSRNN_SB_MIN];      // (default 2048; measured crossover on 256 CUs: ~1900 streams, profiles/r4c_bsrnn_stream_batched.txt)
+            // (default 2048; measured crossover on 256 CUs: ~1900 streams, profiles/r4c_bsrnn_stream_batched.txt.  num_channels = 64 (r6): a sixteen-stream tile takes 5.8 ms
+            //  whatever the batch and the per-stream kernel 2.3 us per stream - crossover at ~2700 streams: the threshold counts 11 / 8 there)
+            const int sb_opt = h->opt[OPT_BSRNN_SB_MIN];
+            const int sb_min = h->cfg.channels == 64 ? (int)((long long)sb_opt * 11 / 8) : sb_opt;
             if (h->bimpl->launch_sb && sb_min > 0 && a.B >= sb_min) h->bimpl->launch_sb(a, h->sboff, h->packed_floats, h->max_wgs, (hipStream_t)stream, &e);
             else
             h->bimpl->launch_split(a, h->max_wgs, (hipStream_t)stream, &e);

@@ -1400,16 +1400,18 @@ def test_bsrnn_more_streams_than_cus():
     _full_size_check(m, orc, cfg, sr, 300, 3, [0, 1, 43, 44, 255, 256, 257, 299], "bsrnn_xxt B=300")
 
 
-@pytest.mark.parametrize("name,B", [("bsrnn_xt", 2605), ("bsrnn_xxt", 4096), ("bsrnn_t", 2093)])
+@pytest.mark.parametrize("name,B", [("bsrnn_xt", 2605), ("bsrnn_xxt", 4096), ("bsrnn_t", 2093), ("bsrnn_s", 2829)])
 def test_bsrnn_stream_batched_layers_above_2048_streams(name, B):
     """From 2048 streams the per-hop step runs its LSTM layers batched over the streams on the matrix cores (bsrnn_sb_kernels.hip.h:
     front per stream, sixteen streams per workgroup through the layers, batched mask-decoder MLP, tail per stream).  2605 streams = a
     last tile of 13; r6: bsrnn_t (num_channels = 32: the time LSTM's gate tiles split over the waves, bands in groups of eight), 2093 streams = a
-    last tile of 13.  Oracle parity (outputs and every time-LSTM cache) on a sample that covers first / last tiles and columns, and
+    last tile of 13, and bsrnn_s (num_channels = 64, bsrnn_sb64_layers_kernel: band features in global memory, one direction at a time, x fragments
+    streamed; from 2816 streams - the threshold counts 11 / 8 there), 2829 = a last tile of 13.  Oracle parity (outputs and every time-LSTM cache) on a sample that covers first / last tiles and columns, and
     bitwise position independence on all streams (_full_size_check runs the batch again in reversed order: every stream then sits
     in another tile and another column)."""
     m, orc, cfg, sr, seed = _bsrnn(name)
-    _full_size_check(m, orc, cfg, sr, B, 3, [0, 1, 15, 16, 17, 1000, 2047, B - 14, B - 13, B - 2, B - 1], f"{name} B={B}")
+    _full_size_check(m, orc, cfg, sr, B, 3 if name != "bsrnn_s" else 2, [0, 1, 15, 16, 17, 1000, 2047, B - 14, B - 13, B - 2, B - 1], f"{name} B={B}")
+    assert "bsrnn_sb" in m.engine.last_step_kernel(), m.engine.last_step_kernel()
 
 
 def test_bsrnn_split_step_with_ragged_stream_tiles():
