@@ -141,8 +141,10 @@ struct BDebugLayout {
     __host__ __device__ static constexpr size_t total() { return offset(n_stages); }
 };
 
-template <class S>
+template <class S, int PART = 0>
 struct BLds {
+    // PART (r6): the per-stream front (3) and tail (2) of the split per-hop steps keep only what they touch - 14.6 / 20.5 KB (xt) instead of the whole
+    // frame's plan: four workgroups per CU (they are memory round trips and barriers, not throughput)
     static constexpr int cmax(int a, int b) { return a > b ? a : b; }
     static constexpr int SP = 0;                              // compressed spectrum [257][2]
     static constexpr int TW = SP + 2 * kBins + 2;             // twiddles
@@ -157,8 +159,8 @@ struct BLds {
     static constexpr int XP_SIZE = S::XPG ? 0 : 2 * 32 * S::LDP;
     // after the layers the HS / HN / YF / XP region is dead: the MLP hidden layer and the layer-2 pre-activations alias it
     static constexpr int H1 = (HS + 3) / 4 * 4;               // [2 kinds][31][LDH1]
-    static constexpr int PRE = H1 + 2 * kBands * S::LDH1;     // [2][1028]
-    static constexpr int TOTAL = cmax(XP + XP_SIZE, PRE + 2 * kMlpRows);
+    static constexpr int PRE = PART == 2 ? X : H1 + 2 * kBands * S::LDH1;     // [2][1028]
+    static constexpr int TOTAL = PART == 3 ? X + 32 * S::LDX : PART == 2 ? PRE + 2 * kMlpRows : cmax(XP + XP_SIZE, PRE + 2 * kMlpRows);
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
     static_assert(BYTES <= 160 * 1024, "BSRNN LDS plan exceeds 160 KiB");
 };
@@ -184,14 +186,14 @@ struct BLds {
 // PART = 1 runs the frame up to the last layer and leaves the band features and the compressed spectrum in global memory,
 // bsrnn_mlp_kernel computes the two MLP layers for all streams, PART = 2 applies GLU / mask / residual and runs the iSTFT.
 template <class S, bool HOT, bool PROF, bool DBG, bool OCC2 = false, bool PIPE = false, int PART = 0>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, OCC2 ? 2 : 1))) bsrnn_frame_kernel(BArgs a) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, (PART == 2 || PART == 3) ? 4 : OCC2 ? 2 : 1))) bsrnn_frame_kernel(BArgs a) {
     static_assert(!PIPE || (!HOT && !PROF && !DBG), "the time-pipelined instantiation is the plain offline kernel");
     static_assert(PART == 0 || (HOT && !PROF && !DBG && !PIPE), "the split step is the per-hop streaming step");
     // PART = 3: the front of the frame alone (STFT, compress, band split -> mlp_x / mlp_sp): the stream-batched step
     // (bsrnn_sb_kernels.hip.h) runs the layers for sixteen streams per workgroup on the matrix cores
     const int aT = HOT ? 1 : a.T;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    using L = BLds<S>;
+    using L = BLds<S, (PART == 2 || PART == 3) ? PART : 0>;
     constexpr int N = S::NFFT, H = S::HOP, OVL = S::OVL, C = S::C, HH = S::HH, G4 = S::G4;
     constexpr int LDX = S::LDX, LDH = S::LDH, LDY = S::LDY, LDP = S::LDP, LDH1 = S::LDH1;
     constexpr int KSC = S::KSC, KSH = S::KSH, KS1 = S::KS1;
@@ -1263,19 +1265,26 @@ void blaunch_impl(const BArgs& a, int max_wgs, hipStream_t st, hipError_t* err) 
 template <class S, bool OCC2, int PART>
 void blaunch_part(const BArgs& a, int grid, hipStream_t st, hipError_t* err) {
     auto* fn = &bsrnn_frame_kernel<S, true, false, false, OCC2, false, PART>;
+    using LP = BLds<S, (PART == 2 || PART == 3) ? PART : 0>;
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev].load(std::memory_order_relaxed)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BLds<S>::BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LP::BYTES);
         if (e != hipSuccess) { *err = e; return; }
         attr_set[dev].store(true, std::memory_order_relaxed);
     }
     note_kernel(PART == 1 ? (OCC2 ? "bsrnn_frame_kernel<PART 1, two workgroups per CU>" : "bsrnn_frame_kernel<PART 1>")
-                : PART == 2 ? (OCC2 ? "bsrnn_frame_kernel<PART 2, two workgroups per CU>" : "bsrnn_frame_kernel<PART 2>")
-                : (OCC2 ? "bsrnn_frame_kernel<PART 3, two workgroups per CU>" : "bsrnn_frame_kernel<PART 3>"));
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), BLds<S>::BYTES, st, a);
+                : PART == 2 ? "bsrnn_frame_kernel<PART 2>" : "bsrnn_frame_kernel<PART 3>");      // (r6: their own LDS plans, up to four workgroups per CU)
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), LP::BYTES, st, a);
     *err = hipGetLastError();
+}
+
+// grid of a per-stream front / tail launch (PART 3 / 2): their own LDS plans fit four times per CU
+template <class S>
+int bpart_grid(int B, int max_wgs) {
+    static_assert(4 * BLds<S, 2>::BYTES <= 160 * 1024 && 4 * BLds<S, 3>::BYTES <= 160 * 1024, "four front / tail workgroups per CU");
+    return B < 4 * max_wgs ? B : 4 * max_wgs;
 }
 
 }  // namespace fe
@@ -1323,8 +1332,8 @@ void blaunch_split_impl(const BArgs& a, int max_wgs, hipStream_t st, hipError_t*
         *err = hipGetLastError();
         if (*err != hipSuccess) return;
     }
-    if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 2>(a, a.B < 2 * max_wgs ? a.B : 2 * max_wgs, st, err);
-    else blaunch_part<S, false, 2>(a, a.B < max_wgs ? a.B : max_wgs, st, err);
+    if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 2>(a, bpart_grid<S>(a.B, max_wgs), st, err);
+    else blaunch_part<S, false, 2>(a, bpart_grid<S>(a.B, max_wgs), st, err);
 }
 
 template <class S>
@@ -1351,8 +1360,8 @@ void blaunch_mlp(const BArgs& a, hipStream_t st, hipError_t* err) {
 template <class S>
 void blaunch_sb_impl(const BArgs& a, const SbOffsets& so, int total_floats, int max_wgs, hipStream_t st, hipError_t* err) {
     constexpr bool FITS2 = 2 * BLds<S>::BYTES <= 160 * 1024 && !S::XPG;
-    if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 3>(a, a.B < 2 * max_wgs ? a.B : 2 * max_wgs, st, err);
-    else blaunch_part<S, false, 3>(a, a.B < max_wgs ? a.B : max_wgs, st, err);
+    if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 3>(a, bpart_grid<S>(a.B, max_wgs), st, err);
+    else blaunch_part<S, false, 3>(a, bpart_grid<S>(a.B, max_wgs), st, err);
     if (*err != hipSuccess) return;
     SbArgs sa{};
     sa.wp = a.wp; sa.off = so; sa.x = a.mlp_x; sa.lstm = a.lstm; sa.y = a.sb_y; sa.B = a.B; sa.total = total_floats;
@@ -1360,8 +1369,8 @@ void blaunch_sb_impl(const BArgs& a, const SbOffsets& so, int total_floats, int 
     if (*err != hipSuccess) return;
     blaunch_mlp<S>(a, st, err);
     if (*err != hipSuccess) return;
-    if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 2>(a, a.B < 2 * max_wgs ? a.B : 2 * max_wgs, st, err);
-    else blaunch_part<S, false, 2>(a, a.B < max_wgs ? a.B : max_wgs, st, err);
+    if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 2>(a, bpart_grid<S>(a.B, max_wgs), st, err);
+    else blaunch_part<S, false, 2>(a, bpart_grid<S>(a.B, max_wgs), st, err);
 }
 
 template <class S>
