@@ -980,7 +980,7 @@ template <class S>
 void llaunch_sb_impl(const LArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
     constexpr int OCC1 = 6, OCC2 = 5;                              // (24 / 16.5 KB of LDS, <= 85 / 102 VGPRs: the parts run six / five workgroups per CU)
     static_assert(LLdsT<1>::TOTAL * 4 * OCC1 <= 160 * 1024 && LLdsT<2>::TOTAL * 4 * OCC2 <= 160 * 1024, "LDS of the parts");
-    const int grid = a.B < max_wgs * OCC1 ? a.B : max_wgs * OCC1;
+    const int grid = a.B < max_wgs * OCC1 ? a.B : max_wgs * OCC1;          // (one workgroup per stream instead of persistent ones: measured neutral, 328 / 334 us at 4096 streams)
     const int grid2 = a.B < max_wgs * OCC2 ? a.B : max_wgs * OCC2;
     note_kernel(a.dbg != nullptr ? "lisennet_frame_kernel<PART 1, debug>" : "lisennet_frame_kernel<PART 1>");
     if (a.dbg != nullptr) hipLaunchKernelGGL((lisennet_frame_kernel<S, false, true, false, 1>), dim3(grid), dim3(kThreads), 0, st, a);
