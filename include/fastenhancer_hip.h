@@ -121,7 +121,8 @@ int fe_load_weights(fe_handle* h, const float* blob_dev, size_t nfloats, void* s
  *                         [B,32,2,32] ConvGLU frames) | [B,4,1,256] decoder frame     (models/lisennet/model.py:380-396)
  * FE_ARCH_BSRNN: fe_state_init also sizes the handle's scratch for the per-hop step of B streams (that step runs as three launches with
  * 10.6 KB per stream between them); a step of a larger batch than any fe_state_init has seen grows it on its first call (a device
- * allocation: not inside a stream capture). */
+ * allocation: not inside a stream capture).  FE_ARCH_FSPEN / FE_ARCH_LISENNET likewise from their "..._stream_batch_min" streams (LiSenNet, r6: three
+ * launches with 49 KB per stream between them - the activation tensors of each sixteen-stream tile in the layout the matrix-core kernel reads). */
 size_t fe_state_floats(const fe_handle* h, int B);
 int fe_state_init(fe_handle* h, float* state_dev, int B, void* stream);
 
