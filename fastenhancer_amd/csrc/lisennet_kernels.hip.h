@@ -110,13 +110,13 @@ struct LDebugLayout {
 };
 
 // PART (r6): the plan of lisennet_frame_kernel<.., PART>: 0 = the whole frame; the two per-stream parts of the three-launch step keep only what they
-// touch (PART 1: up to conv_2 - 23.9 KB, six workgroups per CU; PART 2: the decoder tail, u3 / u3p under the iSTFT's buffers - 16.5 KB)
+// touch (PART 1: STFT + features - 16.5 KB, eight workgroups per CU; PART 2: the decoder tail, u3 / u3p under the iSTFT's buffers - 16.5 KB)
 template <int PART>
 struct LLdsT {
     static constexpr int SP = 0;                    // compressed spectrum [257][2]
     static constexpr int TW = SP + 516;
     static constexpr int X2 = TW + 512;             // encoder.conv_2 out [8][128]   (skip of up3)
-    static constexpr int X3 = X2 + (PART == 2 ? 0 : 1024);            // encoder.conv_3 out [12][64]   (skip of up2)
+    static constexpr int X3 = X2 + (PART == 0 ? 1024 : 0);            // encoder.conv_3 out [12][64]   (skip of up2)
     static constexpr int X4 = X3 + (PART == 0 ? 768 : 0);             // encoder.conv_4 out [16][32]   (skip of up1)
     static constexpr int RED = X4 + (PART == 0 ? 512 : 0);            // block-reduction slots [16]
     static constexpr int SB = RED + 16;             // ---- phase scratch
@@ -148,7 +148,7 @@ struct LLdsT {
     static constexpr int MK = SB + (PART == 2 ? 2568 : 4360);            // mask [2][260]
     static constexpr int WST = SB + (PART == 1 ? 3104 : 6656);           // weight staging area of the conv phases (one layer's weights at a time; PART 1: conv_2's 792 floats)
     static constexpr int WST_SIZE = 4672;
-    static constexpr int TOTAL = PART == 1 ? WST + 800 : PART == 2 ? MK + 520 : WST + WST_SIZE;
+    static constexpr int TOTAL = PART == 1 ? PHA + 264 : PART == 2 ? MK + 520 : WST + WST_SIZE;
     static_assert(SB % 2 == 0 && TW % 2 == 0, "float2 alignment");
     static_assert((size_t)TOTAL * 4 <= 64 * 1024, "static LDS");
 };
@@ -173,7 +173,7 @@ namespace fe {
 // PART (r6): 0 = the whole frame; 1 = STFT .. encoder.conv_2 of a per-hop step whose middle runs batched over the streams (lisennet_sb_kernel): x2, its
 // cached frame and the compressed spectrum go to the carry; 2 = that step's tail (decoder cache, mask conv .. iSTFT) from the carry's up3 output.
 template <class S, bool PROF, bool DBG, bool PIPE = false, int PART = 0>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((PART == 0 || DBG) ? 2 : PART == 1 ? 6 : 5, (PART == 0 || DBG) ? 2 : PART == 1 ? 6 : 5))) lisennet_frame_kernel(LArgs a) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((PART == 0 || DBG) ? 2 : PART == 1 ? 8 : 5, (PART == 0 || DBG) ? 2 : PART == 1 ? 8 : 5))) lisennet_frame_kernel(LArgs a) {
     static_assert(!PIPE || (!PROF && !DBG), "the time-pipelined instantiation is the plain offline kernel");
     static_assert(PART == 0 || !PIPE, "the split step is a streaming step");
     __shared__ __attribute__((aligned(16))) float smem[LLdsT<PART>::TOTAL];
@@ -366,6 +366,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((
 
         LS_CLK(1);
         // ============================ encoder (Encoder.forward, :269-274) ============================
+        if constexpr (PART == 0)
         {   // conv_1: 1x1 (3 -> 4), LayerNorm over (channel, freq) with a per-frequency affine, PReLU   (FFT buffers are dead: x1 aliases them)
             float v[5];
             int cnt = 0;
@@ -395,9 +396,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((
                 x1[o * 260 + f] = y;
             }
         }
+        if constexpr (PART == 0) {
         if constexpr (PIPE) cpub(1); else
         __syncthreads();
         dump(3, [&](int r, int c) { return x1[r * 260 + c]; });
+        }
         }   // PART != 2
         // DSConv (:190-208): causal two-frame conv, the bins split into a low quarter (k 3, stride 1) and the rest (k 5, stride 3), both
         // zero padded by one bin AFTER the split; LayerNorm over (channel, freq), per-frequency affine, PReLU
@@ -481,17 +484,17 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((
         using I257 = std::integral_constant<int, 257>;
         float* xp = smem + L::XP;
         constexpr int OFF_BLK = S::K_PHA + S::K_E2 + S::K_E3 + S::K_E4;
-        if constexpr (PART != 2) {
+        if constexpr (PART == 0) {
         dsconv(I4{}, I8{}, I257{}, x1, x1p, 260, x2, cache_ptr(S::K_PHA + S::K_E2, S::K_E3), xp, P::D2_LO, P::D2_HI, P::D2_BL, P::D2_BH, P::D2_G, P::D2_BE, P::D2_P, 2, S::K_PHA + S::K_E2);
         dump(4, [&](int r, int c) { return x2[r * 128 + c]; });
         }
         if constexpr (PART == 1) {
-            // x2 [8][128] of this frame and of the cached frame, per stream as they stand (coalesced: the middle's prologue regroups them for its sixteen
-            // streams - scattered from here into the tiles' [position][channel group][16 streams][4] layout they were 3 072 partial-line writes per stream,
-            // 100 of this launch's 163 us at 4096 streams); the compressed spectrum for the tail
+            // the input features [3][260] and the compressed spectrum, per stream as they stand (coalesced): the middle's prologue regroups the features for its
+            // sixteen streams and runs the encoder from conv_1 on (r6, first version: conv_1 / conv_2 here and x2 written scattered into the tiles' layout -
+            // 3 072 partial-line writes per stream, 100 of this launch's 163 us at 4096 streams; then coalesced: 86 us; without the two convolutions: see DESIGN 3e)
             using A = LCarry;
-            float* xn = a.carry + A::x2n(a.B) + (size_t)b * 2048;
-            for (int i = tid; i < 8 * 128; i += kThreads) { xn[i] = x2[i]; xn[1024 + i] = xp[i]; }
+            float* fn = a.carry + A::feat(a.B) + (size_t)b * A::FEAT;
+            for (int i = tid; i < 3 * 260; i += kThreads) fn[i] = feat[i];
             float* spc = a.carry + (size_t)((a.B + 15) >> 4) * A::TILE + (size_t)b * A::SP;
             for (int i = tid; i < 2 * BINS; i += kThreads) spc[i] = sp[i];
         }
@@ -978,7 +981,7 @@ void llaunch_impl(const LArgs& a, int max_wgs, hipStream_t st, hipError_t* err) 
 // (lisennet_sb_kernel), tail per stream (PART 2).  fe_debug_step: the same three launches with per-stage dumps; fe_profile_step: the middle's counters.
 template <class S>
 void llaunch_sb_impl(const LArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
-    constexpr int OCC1 = 6, OCC2 = 5;                              // (24 / 16.5 KB of LDS, <= 85 / 102 VGPRs: the parts run six / five workgroups per CU)
+    constexpr int OCC1 = 8, OCC2 = 5;                              // (16.5 KB of LDS each, <= 64 / 102 VGPRs: the parts run eight / five workgroups per CU)
     static_assert(LLdsT<1>::TOTAL * 4 * OCC1 <= 160 * 1024 && LLdsT<2>::TOTAL * 4 * OCC2 <= 160 * 1024, "LDS of the parts");
     const int grid = a.B < max_wgs * OCC1 ? a.B : max_wgs * OCC1;          // (one workgroup per stream instead of persistent ones: measured neutral, 328 / 334 us at 4096 streams)
     const int grid2 = a.B < max_wgs * OCC2 ? a.B : max_wgs * OCC2;

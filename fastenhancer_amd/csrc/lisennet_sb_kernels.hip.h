@@ -48,11 +48,13 @@ struct LSl {
 };
 
 struct LCarry {
-    using X2C = LSl<2, 32, 96, 0>;             // conv_2 output [8][128], this frame, in conv_3's slicing
+    using X1C = LSl<1, 64, 193, 0>;            // conv_1 output [4][257], this frame, in conv_2's slicing
+    using X1P = LSl<1, 64, 193, X1C::END>;     // ... the cached frame
+    using X2C = LSl<2, 32, 96, X1P::END>;      // conv_2 output [8][128], this frame, in conv_3's slicing
     using X2P = LSl<2, 32, 96, X2C::END>;      // ... the cached frame
     using X2S = LSl<2, 64, 64, X2P::END>;      // ... this frame in up3's slicing (skip)
     using X3C = LSl<3, 16, 48, X2S::END>;      // conv_3 output [12][64] in conv_4's slicing
-    using X3P = LSl<3, 16, 48, X3C::END>;      // ... the cached frame (converted from the cache tensor at the top of the kernel)
+    using X3P = LSl<3, 16, 48, X3C::END>;      // ... the cached frame
     using X3S = LSl<3, 32, 32, X3P::END>;      // ... in up2's slicing
     using X4S = LSl<4, 16, 16, X3S::END>;      // conv_4 output [16][32] in up1's slicing
     using XD = LSl<4, 16, 16, X4S::END>;       // output of the DPR blocks
@@ -61,14 +63,16 @@ struct LCarry {
     static constexpr int U3 = U2::END;         // up3 output [256 f][16 n][4 c] (read by PART 2)
     static constexpr int TILE = U3 + 256 * 64;
     static constexpr int SP = 516;             // per stream, behind the tiles: the compressed spectrum [257][2] (PART 1 -> PART 2)
-    // ... and behind those, per stream: conv_2's output [8][128] of this frame and of the cached frame as PART 1 leaves them (regrouped by the middle's prologue)
-    __host__ __device__ static constexpr size_t x2n(int B) { return (size_t)((B + 15) / 16) * TILE + (size_t)((B + 15) / 16) * 16 * SP; }
-    __host__ __device__ static constexpr size_t floats(int B) { return x2n(B) + (size_t)((B + 15) / 16) * 16 * 2048; }
+    static constexpr int FEAT = 784;           // ... and behind those, per stream: the input features [3][260] (PART 1 -> the middle's conv_1)
+    __host__ __device__ static constexpr size_t feat(int B) { return (size_t)((B + 15) / 16) * TILE + (size_t)((B + 15) / 16) * 16 * SP; }
+    __host__ __device__ static constexpr size_t floats(int B) { return feat(B) + (size_t)((B + 15) / 16) * 16 * FEAT; }
 };
 
 // packed weights of the stream-batched kernel (floats, relative to LPk::TOTAL); A fragments in k4 order [tile][quad][lane][4]
 struct LSbPk {
-    static constexpr int C3_LO = 0, C3_HI = C3_LO + 3 * 256, C3_BL = C3_HI + 5 * 256, C3_BH = C3_BL + 16, C3_G = C3_BH + 16, C3_BE = C3_G + 64, C3_P = C3_BE + 64;
+    static constexpr int C1_W = 0, C1_G = 16, C1_BE = C1_G + 260, C1_P = C1_BE + 260;             // conv_1: [c < 3][4 o] | bias [4], gamma / beta [257], PReLU [4]
+    static constexpr int C2_LO = C1_P + 4, C2_HI = C2_LO + 2 * 256, C2_BL = C2_HI + 3 * 256, C2_BH = C2_BL + 16, C2_G = C2_BH + 16, C2_BE = C2_G + 128, C2_P = C2_BE + 128;
+    static constexpr int C3_LO = C2_P + 16, C3_HI = C3_LO + 3 * 256, C3_BL = C3_HI + 5 * 256, C3_BH = C3_BL + 16, C3_G = C3_BH + 16, C3_BE = C3_G + 64, C3_P = C3_BE + 64;
     static constexpr int C4_LO = C3_P + 16, C4_HI = C4_LO + 5 * 256, C4_BL = C4_HI + 8 * 256, C4_BH = C4_BL + 16, C4_G = C4_BH + 16, C4_BE = C4_G + 32, C4_P = C4_BE + 32;
     static constexpr int U1_LO = C4_P + 16, U1_HI = U1_LO + 6 * 256, U1_BL = U1_HI + 3 * 6 * 256, U1_BH = U1_BL + 16;
     static constexpr int U2_LO = U1_BH + 48, U2_HI = U2_LO + 5 * 256, U2_BL = U2_HI + 2 * 5 * 256, U2_BH = U2_BL + 16;
@@ -88,14 +92,16 @@ struct LSbPk {
     static constexpr int F2_W = DWB + 32, F2_B = F2_W + 2 * 256;              // fc2 [quad][256], bias [16]
     static constexpr int B_SIZE = F2_B + 16;
     static constexpr int TOTAL = BLK + 2 * B_SIZE;
-    static_assert(BLK % 4 == 0 && B_SIZE % 4 == 0 && I_W % 4 == 0 && XR % 4 == 0 && F1_W % 4 == 0 && DW % 4 == 0, "16-byte fragment loads");
+    static_assert(BLK % 4 == 0 && B_SIZE % 4 == 0 && I_W % 4 == 0 && XR % 4 == 0 && F1_W % 4 == 0 && DW % 4 == 0 && C2_LO % 4 == 0 && C3_LO % 4 == 0 && C1_P % 4 == 0, "16-byte fragment loads");
 };
 
 struct LSbLds {
     static constexpr int X = 0;                        // tokens [32 f][16 slots][16 n]: slot 4 r + lg <-> channel 4 lg + r
     static constexpr int HS = X + 32 * 16 * 16;        // intra h sequences [2 d][32 f][16 slots (12 units)][16 n]; conv_glu: the waves' edge columns [8][2][32][16]
-    // prologue: [channel][16 n][positions + 1] staging of the tensors that arrive per stream (x2: 8 x 16 x 129, the cached x3: 12 x 16 x 65 behind it)
-    static constexpr int T2 = 0, T3 = T2 + 8 * 16 * 129, TEND = T3 + 12 * 16 * 65;
+    // prologue: [channel][16 n][positions + pad] staging of the tensors that arrive per stream, two areas (features / x1 [4][16][261] | cached x1; then cached x2
+    // [8][16][129] | cached x3 [12][16][65]; later the new cache frames on their way out)
+    static constexpr int TA = 0, TB = TA + 4 * 16 * 261, TEND = TB + 4 * 16 * 261;
+    static constexpr int T3 = TA;                      // conv_3's new cache frame [12][16][65]
     static constexpr int RED = (HS + 2 * 32 * 16 * 16 > TEND ? HS + 2 * 32 * 16 * 16 : TEND);  // [2][8 waves][16 n]
     static constexpr int TOTAL = RED + 256;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
@@ -182,8 +188,9 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
         return t;
     };
 
-    // ---------------- halos of the tensors this kernel writes; the cached conv_3 frame [12][64] of the sixteen streams -> X3P ----------------
-    {
+    // ---------------- halos of the sliced tensors; what arrives per stream - the input features (PART 1), the cached conv_1 / conv_2 / conv_3 frames (the cache
+    // tensors) - regrouped for the sixteen streams through LDS: coalesced reads along f -> [channel][n][f (+ pad)] -> one 16-byte element (four channels of a
+    // position and stream) per thread, whole 256-byte pieces per sixteen lanes; encoder.conv_1 (1x1, 3 -> 4: vector FMAs) + LayerNorm + PReLU on the way ----------------
         auto zero_halo = [&](auto sl) {
             using SL = decltype(sl);
             for (int i = tid; i < 4 * (SL::ROW / 4); i += kLsbThreads) {
@@ -191,75 +198,134 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
                 *reinterpret_cast<f32x4*>(ct + SL::halo(h) + 4 * q) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             }
         };
-        zero_halo(A::X2C{}); zero_halo(A::X2P{}); zero_halo(A::X2S{});
+        zero_halo(A::X1C{}); zero_halo(A::X1P{}); zero_halo(A::X2C{}); zero_halo(A::X2P{}); zero_halo(A::X2S{});
         zero_halo(A::X3C{}); zero_halo(A::X3P{}); zero_halo(A::X3S{}); zero_halo(A::X4S{}); zero_halo(A::XD{}); zero_halo(A::U1{}); zero_halo(A::U2{});
-        // The tensors that arrive per stream - conv_2's output of this frame and of the cached frame (PART 1), the cached conv_3 frame (the cache tensor) -
-        // regrouped for the sixteen streams through LDS: coalesced 16-byte reads along f -> [channel][n][f (+ 1 pad)] -> one 16-byte element
-        // (four channels of a position and stream) per thread, whole 256-byte pieces per sixteen lanes.
-        float* T2 = smem + L::T2;
-        float* T3 = smem + L::T3;
-        const float* x2n = a.carry + A::x2n(a.B);
-        const float* c4 = a.cache + (size_t)(S::K_PHA + S::K_E2 + S::K_E3) * a.B;
-        auto stage_x2 = [&](int which) {            // 16 streams x [8][128]: 4096 16-byte pieces
-            f32x4 v[8];
+        float* TA = smem + L::TA;
+        float* TB = smem + L::TB;
+        // a tensor [NCH][NF] per stream (NCH * NF floats at stride `per`, a multiple of 4) of the sixteen streams -> T[(c * 16 + n) * LDT + f]: the stream's tensor read
+        // as a flat run of 16-byte pieces (a piece may straddle two channels: NF = 257), eight of a thread in flight
+        auto stage = [&](float* T, const float* src, size_t per, auto nch_, auto nf_, auto ldt_) {
+            constexpr int NCH = decltype(nch_)::value, NF = decltype(nf_)::value, LDT = decltype(ldt_)::value, NE = NCH * NF, NE4 = NE / 4, TOT = 16 * NE4;
+            static_assert(NE % 4 == 0, "whole 16-byte pieces per stream");
+#pragma unroll 1
+            for (int i0 = 0; i0 < TOT; i0 += 8 * kLsbThreads) {
+                f32x4 v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = tid + k * kLsbThreads, n = i >> 8, e = (i & 255) * 4;
-                const int bs = b0 + n < a.B ? b0 + n : a.B - 1;
-                v[k] = *reinterpret_cast<const f32x4*>(x2n + (size_t)bs * 2048 + which * 1024 + e);
-            }
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + tid + k * kLsbThreads, ic = i < TOT ? i : TOT - 1, n = ic / NE4, e = (ic - n * NE4) * 4;
+                    const int bs = b0 + n < a.B ? b0 + n : a.B - 1;
+                    v[k] = *reinterpret_cast<const f32x4*>(src + (size_t)bs * per + e);
+                }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = tid + k * kLsbThreads, n = i >> 8, e = (i & 255) * 4, c = e >> 7, f = e & 127;
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + tid + k * kLsbThreads, n = i / NE4, e = (i - n * NE4) * 4;
+                    if (i < TOT) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) T2[(c * 16 + n) * 129 + f + j] = v[k][j];
+                        for (int j = 0; j < 4; ++j) { const int c = (e + j) / NF, f = (e + j) - c * NF; T[(c * 16 + n) * LDT + f] = v[k][j]; }
+                    }
+                }
             }
         };
-        auto emit_x2 = [&](auto sl) {               // 128 positions x 2 groups x 16 streams
+        // T -> a sliced tensor of the carry: NF positions x G groups x 16 streams
+        auto emit = [&](auto sl, const float* T, auto nf_, auto ldt_) {
             using SL = decltype(sl);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = tid + k * kLsbThreads, n = i & 15, g = (i >> 4) & 1, f = i >> 5;
+            constexpr int NF = decltype(nf_)::value, LDT = decltype(ldt_)::value, G = SL::G, TOT = NF * G * 16;
+#pragma unroll 1
+            for (int i0 = 0; i0 < TOT; i0 += kLsbThreads) {
+                const int i = i0 + tid, ic = i < TOT ? i : TOT - 1, n = ic & 15, gf = ic >> 4, f = gf / G, g = gf - G * f;
                 f32x4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = T2[((4 * g + j) * 16 + n) * 129 + f];
-                *reinterpret_cast<f32x4*>(ct + SL::row(f) + g * 64 + n * 4) = o;
+                for (int j = 0; j < 4; ++j) o[j] = T[((4 * g + j) * 16 + n) * LDT + f];
+                if (i < TOT) *reinterpret_cast<f32x4*>(ct + SL::row(f) + g * 64 + n * 4) = o;
             }
         };
-        stage_x2(0);
-        __syncthreads();
-        emit_x2(A::X2C{});
-        emit_x2(A::X2S{});
-        __syncthreads();
-        stage_x2(1);
-        {   // the cached conv_3 frame: 16 streams x [12][64]: 3072 16-byte pieces
-            constexpr int NV = kLsbStreams * S::K_E4 / 4 / kLsbThreads;
-            static_assert(kLsbStreams * S::K_E4 == 4 * NV * kLsbThreads, "whole 16-byte pieces per thread");
-            f32x4 v[NV];
+        // T -> a cache tensor [NCH][NF] per stream, as a flat run of 16-byte pieces (coalesced)
+        auto unstage = [&](float* dst, size_t per, const float* T, auto nch_, auto nf_, auto ldt_) {
+            constexpr int NCH = decltype(nch_)::value, NF = decltype(nf_)::value, LDT = decltype(ldt_)::value, NE = NCH * NF, NE4 = NE / 4, TOT = 16 * NE4;
+            static_assert(NE % 4 == 0, "whole 16-byte pieces per stream");
+#pragma unroll 1
+            for (int i0 = 0; i0 < TOT; i0 += kLsbThreads) {
+                const int i = i0 + tid, ic = i < TOT ? i : TOT - 1, n = ic / NE4, e = (ic - n * NE4) * 4;
+                f32x4 o;
 #pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                const int i = tid + k * kLsbThreads, n = i / (S::K_E4 / 4), e = (i - n * (S::K_E4 / 4)) * 4;
-                const int bs = b0 + n < a.B ? b0 + n : a.B - 1;
-                v[k] = *reinterpret_cast<const f32x4*>(c4 + (size_t)bs * S::K_E4 + e);
+                for (int j = 0; j < 4; ++j) { const int c = (e + j) / NF, f = (e + j) - c * NF; o[j] = T[(c * 16 + n) * LDT + f]; }
+                if (i < TOT && b0 + n < a.B) *reinterpret_cast<f32x4*>(dst + (size_t)(b0 + n) * per + e) = o;
             }
+        };
+        using I3 = std::integral_constant<int, 3>;
+        using I4 = std::integral_constant<int, 4>;
+        using I8 = std::integral_constant<int, 8>;
+        using I12 = std::integral_constant<int, 12>;
+        using I64 = std::integral_constant<int, 64>;
+        using I65 = std::integral_constant<int, 65>;
+        using I128 = std::integral_constant<int, 128>;
+        using I129 = std::integral_constant<int, 129>;
+        using I257 = std::integral_constant<int, 257>;
+        using I260 = std::integral_constant<int, 260>;
+        using I261 = std::integral_constant<int, 261>;
+        float* const c2g = a.cache + (size_t)S::K_PHA * a.B;                                   // cached conv_1 frames [B][4][257]
+        float* const c3g = a.cache + (size_t)(S::K_PHA + S::K_E2) * a.B;                       // cached conv_2 frames [B][8][128]
+        float* const c4g = a.cache + (size_t)(S::K_PHA + S::K_E2 + S::K_E3) * a.B;             // cached conv_3 frames [B][12][64]
+        // features [3][260] -> area A, the cached conv_1 frame -> area B
+        stage(TA, a.carry + A::feat(a.B), A::FEAT, I3{}, I260{}, I261{});
+        stage(TB, c2g, S::K_E2, I4{}, I257{}, I261{});
+        __syncthreads();
+        emit(A::X1P{}, TB, I257{}, I261{});
+        // conv_1 + LayerNorm over (channel, freq) + per-frequency affine + PReLU: thread (n = tid % 16, p = tid / 16 + 32 k); same lane structure as the tiles
+        {
+            const f32x4 w0 = ldw4(SB + Q::C1_W, 0), w1 = ldw4(SB + Q::C1_W + 4, 0), w2 = ldw4(SB + Q::C1_W + 8, 0), cb = ldw4(SB + Q::C1_W + 12, 0), pr = ldw4(SB + Q::C1_P, 0);
+            f32x4 v[9];
+            float s0 = 0.0f;
 #pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                const int i = tid + k * kLsbThreads, n = i / (S::K_E4 / 4), e = (i - n * (S::K_E4 / 4)) * 4, c = e >> 6, f = e & 63;
+            for (int k = 0; k < 9; ++k) {
+                const int pp = (tid >> 4) + 32 * k, pc = pp < 257 ? pp : 256;
+                const float f0 = TA[(0 * 16 + li) * 261 + pc], f1 = TA[(1 * 16 + li) * 261 + pc], f2 = TA[(2 * 16 + li) * 261 + pc];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) T3[(c * 16 + n) * 65 + f + j] = v[k][j];
+                for (int r = 0; r < 4; ++r) v[k][r] = __builtin_fmaf(w2[r], f2, __builtin_fmaf(w1[r], f1, __builtin_fmaf(w0[r], f0, cb[r])));
+                if (pp < 257) s0 += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+            }
+            float gam[9], bet[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int pp = (tid >> 4) + 32 * k, pc = pp < 257 ? pp : 256;
+                gam[k] = a.wp[SB + Q::C1_G + pc]; bet[k] = a.wp[SB + Q::C1_BE + pc];
+            }
+            const float mean = tile_sum(s0, 0) * (1.0f / 1028.0f);
+            float s1 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int pp = (tid >> 4) + 32 * k;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[k][r] -= mean; if (pp < 257) s1 = __builtin_fmaf(v[k][r], v[k][r], s1); }
+            }
+            const float rstd = 1.0f / sqrtf(tile_sum(s1, 1) * (1.0f / 1028.0f) + 1.0e-5f);
+            __syncthreads();                        // (every thread has read the features / emitted the cached frame: the areas are free)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int pp = (tid >> 4) + 32 * k;
+                if (pp < 257) {
+                    const float ga = gam[k] * rstd, be = bet[k];
+                    f32x4 y;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float t = __builtin_fmaf(v[k][r], ga, be); y[r] = t >= 0.0f ? t : t * pr[r]; }
+                    *reinterpret_cast<f32x4*>(ct + A::X1C::row(pp) + li * 4) = y;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) TA[(r * 16 + li) * 261 + pp] = y[r];
+                    if (dbg) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dbg[LDebugLayout::offset(3) + r * 257 + pp] = y[r];
+                    }
+                }
             }
         }
+        stage(TB, c3g, S::K_E3, I8{}, I128{}, I129{});                  // the cached conv_2 frame -> area B
         __syncthreads();
-        emit_x2(A::X2P{});
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {               // 64 positions x 3 groups x 16 streams
-            const int i = tid + k * kLsbThreads, n = i & 15, gf = i >> 4, f = gf / 3, g = gf - 3 * f;
-            f32x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = T3[((4 * g + j) * 16 + n) * 65 + f];
-            *reinterpret_cast<f32x4*>(ct + A::X3P::row(f) + g * 64 + n * 4) = o;
-        }
-    }
+        unstage(c2g, S::K_E2, TA, I4{}, I257{}, I261{});                // the new conv_1 cache frame
+        emit(A::X2P{}, TB, I128{}, I129{});
+        __syncthreads();
+        stage(TA, c4g, S::K_E4, I12{}, I64{}, I65{});                   // the cached conv_3 frame -> area A
+        __syncthreads();
+        emit(A::X3P{}, TA, I64{}, I65{});
     __syncthreads();
     LSB_CLK(1);
 
@@ -277,6 +343,73 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
                         acc_[i_][t_] = FE_MFMA(W_[t_][m_][j_], bq_[i_][m_][j_], acc_[i_][t_]);                             \
     } while (0)
 
+    // ---------------- encoder.conv_2: DSConv(4 -> 8, 257 bins -> 128), LayerNorm over (channel, freq), per-frequency affine, PReLU ----------------
+    {
+        int offL[2], offH[3];
+        lsb_src<1, 3, 2>(offL, A::X1P::LO, A::X1C::LO, lg, li);
+        lsb_src<1, 5, 3>(offH, A::X1P::HI, A::X1C::HI, lg, li);
+        f32x4 WL[1][2], WH[1][3];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) WL[0][m] = frag(SB + Q::C2_LO + m * 256);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) WH[0][m] = frag(SB + Q::C2_HI + m * 256);
+        const f32x4 bL = row4(SB + Q::C2_BL), bH = row4(SB + Q::C2_BH), pr = row4(SB + Q::C2_P);
+        f32x4 accA[4][1], accB[4][1], accC[4][1], accD[4][1];           // low positions 8 w .. + 3 | .. + 7, high positions likewise
+        int pA[4], pB[4], pC[4], pD[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            accA[i][0] = bL; accB[i][0] = bL; accC[i][0] = bH; accD[i][0] = bH;
+            pA[i] = (8 * wave + i) * A::X1C::ROW; pB[i] = (8 * wave + 4 + i) * A::X1C::ROW;
+            pC[i] = (8 * wave + i) * 3 * A::X1C::ROW; pD[i] = (8 * wave + 4 + i) * 3 * A::X1C::ROW;
+        }
+        LSB_CONV(2, 1, 4, accA, WL, offL, pA);
+        LSB_CONV(2, 1, 4, accB, WL, offL, pB);
+        LSB_CONV(3, 1, 4, accC, WH, offH, pC);
+        LSB_CONV(3, 1, 4, accD, WH, offH, pD);
+        const bool val = lg < 2;                                   // rows 8 .. 15 of the tile are idle
+        float gam[16], bet[16];                                    // (requested before the statistics' barriers)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int P = i < 8 ? 8 * wave + i : 64 + 8 * wave + (i - 8);
+            gam[i] = a.wp[SB + Q::C2_G + P]; bet[i] = a.wp[SB + Q::C2_BE + P];
+        }
+        auto acc_of = [&](int i) -> f32x4& { return i < 4 ? accA[i][0] : i < 8 ? accB[i - 4][0] : i < 12 ? accC[i - 8][0] : accD[i - 12][0]; };
+        float s0 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const f32x4& v = acc_of(i); s0 += (v[0] + v[1]) + (v[2] + v[3]); }
+        const float mean = tile_sum(val ? s0 : 0.0f, 0) * (1.0f / 1024.0f);
+        float s1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            f32x4& v = acc_of(i);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] -= mean; s1 = __builtin_fmaf(v[r], v[r], s1); }
+        }
+        const float rstd = 1.0f / sqrtf(tile_sum(val ? s1 : 0.0f, 1) * (1.0f / 1024.0f) + 1.0e-5f);
+        float* TBo = smem + L::TB;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int P = i < 8 ? 8 * wave + i : 64 + 8 * wave + (i - 8);
+            const float ga = gam[i] * rstd, be = bet[i];
+            const f32x4& v = acc_of(i);
+            f32x4 y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float t = __builtin_fmaf(v[r], ga, be); y[r] = t >= 0.0f ? t : t * pr[r]; }
+            if (val) {
+                *reinterpret_cast<f32x4*>(ct + A::X2C::row(P) + lg * 64 + li * 4) = y;
+                *reinterpret_cast<f32x4*>(ct + A::X2S::row(P) + lg * 64 + li * 4) = y;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) TBo[((4 * lg + r) * 16 + li) * 129 + P] = y[r];      // (the new cache frame: out as whole rows below)
+                if (dbg) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dbg[LDebugLayout::offset(4) + (4 * lg + r) * 128 + P] = y[r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    unstage(c3g, S::K_E3, smem + L::TB, I8{}, I128{}, I129{});          // the new conv_2 cache frame
+    LSB_CLK(24);
     // ---------------- encoder.conv_3: DSConv(8 -> 12, 128 bins -> 64), LayerNorm over (channel, freq), per-frequency affine, PReLU ----------------
     {
         int offL[3], offH[5];

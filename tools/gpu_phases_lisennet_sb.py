@@ -26,7 +26,7 @@ def main():
     torch.cuda.synchronize()
     q = clk.cpu().numpy()[32:]
     print(f"lisennet B={B}: lisennet_sb_kernel, workgroup 0 = {q[19] - q[0]} cycles")
-    print(f"  halos + cached conv_3 frame {q[1] - q[0]}, conv_3 {q[2] - q[1]}, conv_4 {q[3] - q[2]}")
+    print(f"  halos + regrouping + conv_1 {q[1] - q[0]}, conv_2 {q[24] - q[1]}, conv_3 {q[2] - q[24]}, conv_4 {q[3] - q[2]}")
     for b in range(2):
         o = 4 + 6 * b
         prev = q[3] if b == 0 else q[o - 3]
