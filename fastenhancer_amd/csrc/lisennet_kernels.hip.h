@@ -110,7 +110,7 @@ struct LDebugLayout {
 };
 
 // PART (r6): the plan of lisennet_frame_kernel<.., PART>: 0 = the whole frame; the two per-stream parts of the three-launch step keep only what they
-// touch (PART 1: STFT + features - 16.5 KB, eight workgroups per CU; PART 2: the decoder tail, u3 / u3p under the iSTFT's buffers - 16.5 KB)
+// touch (PART 1: STFT + features - 16.5 KB, eight workgroups per CU; PART 2: mask + iSTFT - 14.4 KB)
 template <int PART>
 struct LLdsT {
     static constexpr int SP = 0;                    // compressed spectrum [257][2]
@@ -144,8 +144,8 @@ struct LLdsT {
     static constexpr int U2 = SB + 768;             // [8][128]
     static constexpr int U3 = SB + (PART == 2 ? 0 : 1792);            // [4][256]
     static constexpr int U3P = SB + (PART == 2 ? 1024 : 2816);           // previous frame (cache) [4][256]
-    static constexpr int MY = SB + (PART == 2 ? 2048 : 3840);            // mask conv out [2][260]
-    static constexpr int MK = SB + (PART == 2 ? 2568 : 4360);            // mask [2][260]
+    static constexpr int MY = SB + (PART == 2 ? 2048 : 3840);            // mask conv out [2][260]  (PART 2: unused)
+    static constexpr int MK = SB + (PART == 2 ? 2048 : 4360);            // mask [2][260]
     static constexpr int WST = SB + (PART == 1 ? 3104 : 6656);           // weight staging area of the conv phases (one layer's weights at a time; PART 1: conv_2's 792 floats)
     static constexpr int WST_SIZE = 4672;
     static constexpr int TOTAL = PART == 1 ? PHA + 264 : PART == 2 ? MK + 520 : WST + WST_SIZE;
@@ -173,7 +173,7 @@ namespace fe {
 // PART (r6): 0 = the whole frame; 1 = STFT .. encoder.conv_2 of a per-hop step whose middle runs batched over the streams (lisennet_sb_kernel): x2, its
 // cached frame and the compressed spectrum go to the carry; 2 = that step's tail (decoder cache, mask conv .. iSTFT) from the carry's up3 output.
 template <class S, bool PROF, bool DBG, bool PIPE = false, int PART = 0>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((PART == 0 || DBG) ? 2 : PART == 1 ? 8 : 5, (PART == 0 || DBG) ? 2 : PART == 1 ? 8 : 5))) lisennet_frame_kernel(LArgs a) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((PART == 0 || DBG) ? 2 : 8, (PART == 0 || DBG) ? 2 : 8))) lisennet_frame_kernel(LArgs a) {
     static_assert(!PIPE || (!PROF && !DBG), "the time-pipelined instantiation is the plain offline kernel");
     static_assert(PART == 0 || !PIPE, "the split step is a streaming step");
     __shared__ __attribute__((aligned(16))) float smem[LLdsT<PART>::TOTAL];
@@ -801,20 +801,21 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((
         }   // PART == 0
         float* u3 = smem + L::U3;
         float* u3p = smem + L::U3P;
-        if constexpr (PART == 2) {      // the stream-batched middle's up3 output [256 f][16 n][4 c] and PART 1's compressed spectrum
+        float* my = smem + L::MY;
+        float* mk = smem + L::MK;
+        if constexpr (PART == 2) {      // the stream-batched middle's mask [257 f][16 n][2] and PART 1's compressed spectrum
             using A = LCarry;
-            const float* cu = a.carry + (size_t)(b >> 4) * A::TILE + A::U3 + (b & 15) * 4;
-            for (int f = tid; f < 256; f += kThreads) {
-                const float4 v = *reinterpret_cast<const float4*>(cu + f * 64);
-                u3[f] = v.x; u3[256 + f] = v.y; u3[512 + f] = v.z; u3[768 + f] = v.w;
+            const float* cm = a.carry + (size_t)(b >> 4) * A::TILE + A::MK + (b & 15) * 2;
+            for (int f = tid; f < BINS; f += kThreads) {
+                const float2 v = *reinterpret_cast<const float2*>(cm + f * 32);
+                mk[f] = v.x; mk[260 + f] = v.y;
             }
             const float* spc = a.carry + (size_t)((a.B + 15) >> 4) * A::TILE + (size_t)b * A::SP;
             for (int i = tid; i < 2 * BINS; i += kThreads) sp[i] = spc[i];
             __syncthreads();
         }
-        float* my = smem + L::MY;
-        float* mk = smem + L::MK;
         if constexpr (PART != 1) {
+        if constexpr (PART == 0)
         {
             float* cd = cache_ptr(OFF_BLK + S::NB * (S::K_H + S::K_GLU), S::K_DEC);
             if constexpr (PIPE) {
@@ -981,7 +982,7 @@ void llaunch_impl(const LArgs& a, int max_wgs, hipStream_t st, hipError_t* err) 
 // (lisennet_sb_kernel), tail per stream (PART 2).  fe_debug_step: the same three launches with per-stage dumps; fe_profile_step: the middle's counters.
 template <class S>
 void llaunch_sb_impl(const LArgs& a, int max_wgs, hipStream_t st, hipError_t* err) {
-    constexpr int OCC1 = 8, OCC2 = 5;                              // (16.5 KB of LDS each, <= 64 / 102 VGPRs: the parts run eight / five workgroups per CU)
+    constexpr int OCC1 = 8, OCC2 = 8;                              // (16.5 / 14.4 KB of LDS, <= 64 VGPRs: the parts run eight workgroups per CU)
     static_assert(LLdsT<1>::TOTAL * 4 * OCC1 <= 160 * 1024 && LLdsT<2>::TOTAL * 4 * OCC2 <= 160 * 1024, "LDS of the parts");
     const int grid = a.B < max_wgs * OCC1 ? a.B : max_wgs * OCC1;          // (one workgroup per stream instead of persistent ones: measured neutral, 328 / 334 us at 4096 streams)
     const int grid2 = a.B < max_wgs * OCC2 ? a.B : max_wgs * OCC2;

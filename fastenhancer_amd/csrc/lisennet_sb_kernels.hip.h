@@ -60,8 +60,10 @@ struct LCarry {
     using XD = LSl<4, 16, 16, X4S::END>;       // output of the DPR blocks
     using U1 = LSl<3, 32, 32, XD::END>;        // up1 output [12][64] in up2's slicing
     using U2 = LSl<2, 64, 64, U1::END>;        // up2 output [8][128] in up3's slicing
-    static constexpr int U3 = U2::END;         // up3 output [256 f][16 n][4 c] (read by PART 2)
-    static constexpr int TILE = U3 + 256 * 64;
+    using U3S = LSl<1, 256, 0, U2::END>;       // up3 output [4][256] in mask_conv's "slicing" (one slice: zero rows at -1 and 256)
+    using U3P = LSl<1, 256, 0, U3S::END>;      // ... the cached frame
+    static constexpr int MK = U3P::END;        // the mask [257 f][16 n][2] (read by PART 2)
+    static constexpr int TILE = MK + 258 * 32;
     static constexpr int SP = 516;             // per stream, behind the tiles: the compressed spectrum [257][2] (PART 1 -> PART 2)
     static constexpr int FEAT = 784;           // ... and behind those, per stream: the input features [3][260] (PART 1 -> the middle's conv_1)
     __host__ __device__ static constexpr size_t feat(int B) { return (size_t)((B + 15) / 16) * TILE + (size_t)((B + 15) / 16) * 16 * SP; }
@@ -77,7 +79,9 @@ struct LSbPk {
     static constexpr int U1_LO = C4_P + 16, U1_HI = U1_LO + 6 * 256, U1_BL = U1_HI + 3 * 6 * 256, U1_BH = U1_BL + 16;
     static constexpr int U2_LO = U1_BH + 48, U2_HI = U2_LO + 5 * 256, U2_BL = U2_HI + 2 * 5 * 256, U2_BH = U2_BL + 16;
     static constexpr int U3_LO = U2_BH + 32, U3_HI = U3_LO + 3 * 256, U3_BL = U3_HI + 3 * 256, U3_BH = U3_BL + 16;
-    static constexpr int BLK = U3_BH + 16;
+    // mask_conv.0 (2, 4, 2, 2) as a DSConv-like tile | bias; LayerNorm affine [257]; PReLU [2]; mask_conv.3 [o][c] | bias; learnable sigmoid slope [257]
+    static constexpr int M0_W = U3_BH + 16, M0_B = M0_W + 256, M_G = M0_B + 16, M_BE = M_G + 260, M_SL = M_BE + 260, M_P = M_SL + 260, M3 = M_P + 4;
+    static constexpr int BLK = M3 + 8;
     // per DPR block
     static constexpr int N1W = 0, N1B = 512;                                  // intra_norm [f][d]
     static constexpr int I_W = 1024, I_B = I_W + 8 * 2 * 256;                 // intra GRU: [wave = 4 d + q][quad x | h][256], start values [wave][16]
@@ -199,30 +203,32 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
             }
         };
         zero_halo(A::X1C{}); zero_halo(A::X1P{}); zero_halo(A::X2C{}); zero_halo(A::X2P{}); zero_halo(A::X2S{});
-        zero_halo(A::X3C{}); zero_halo(A::X3P{}); zero_halo(A::X3S{}); zero_halo(A::X4S{}); zero_halo(A::XD{}); zero_halo(A::U1{}); zero_halo(A::U2{});
+        zero_halo(A::X3C{}); zero_halo(A::X3P{}); zero_halo(A::X3S{}); zero_halo(A::X4S{}); zero_halo(A::XD{}); zero_halo(A::U1{}); zero_halo(A::U2{}); zero_halo(A::U3S{}); zero_halo(A::U3P{});
         float* TA = smem + L::TA;
         float* TB = smem + L::TB;
         // a tensor [NCH][NF] per stream (NCH * NF floats at stride `per`, a multiple of 4) of the sixteen streams -> T[(c * 16 + n) * LDT + f]: the stream's tensor read
-        // as a flat run of 16-byte pieces (a piece may straddle two channels: NF = 257), eight of a thread in flight
-        auto stage = [&](float* T, const float* src, size_t per, auto nch_, auto nf_, auto ldt_) {
-            constexpr int NCH = decltype(nch_)::value, NF = decltype(nf_)::value, LDT = decltype(ldt_)::value, NE = NCH * NF, NE4 = NE / 4, TOT = 16 * NE4;
-            static_assert(NE % 4 == 0, "whole 16-byte pieces per stream");
-#pragma unroll 1
-            for (int i0 = 0; i0 < TOT; i0 += 8 * kLsbThreads) {
-                f32x4 v[8];
+        // as a flat run of 16-byte pieces (a piece may straddle two channels: NF = 257).  Two steps - ALL four tensors are requested at the top of the kernel
+        // (30 pieces per thread in flight: one memory round trip instead of four), each goes to LDS when its staging area is free
+        auto stage_load = [&](auto& v, const float* src, size_t per, auto ne_) {
+            constexpr int NE4 = decltype(ne_)::value / 4, TOT = 16 * NE4, NV = (TOT + kLsbThreads - 1) / kLsbThreads;
+            static_assert(decltype(ne_)::value % 4 == 0 && sizeof(v) == NV * sizeof(f32x4), "whole 16-byte pieces per stream");
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int i = i0 + tid + k * kLsbThreads, ic = i < TOT ? i : TOT - 1, n = ic / NE4, e = (ic - n * NE4) * 4;
-                    const int bs = b0 + n < a.B ? b0 + n : a.B - 1;
-                    v[k] = *reinterpret_cast<const f32x4*>(src + (size_t)bs * per + e);
-                }
+            for (int k = 0; k < NV; ++k) {
+                const int i = tid + k * kLsbThreads, ic = i < TOT ? i : TOT - 1, n = ic / NE4, e = (ic - n * NE4) * 4;
+                const int bs = b0 + n < a.B ? b0 + n : a.B - 1;
+                v[k] = *reinterpret_cast<const f32x4*>(src + (size_t)bs * per + e);
+            }
+        };
+        auto stage_put = [&](float* T, const auto& v, auto nch_, auto nf_, auto ldt_) {
+            constexpr int NCH = decltype(nch_)::value, NF = decltype(nf_)::value, LDT = decltype(ldt_)::value, NE4 = NCH * NF / 4, TOT = 16 * NE4, NV = (TOT + kLsbThreads - 1) / kLsbThreads;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int i = i0 + tid + k * kLsbThreads, n = i / NE4, e = (i - n * NE4) * 4;
-                    if (i < TOT) {
+            for (int k = 0; k < NV; ++k) {
+                const int i = tid + k * kLsbThreads, n = i / NE4, e = (i - n * NE4) * 4;
+                if (i < TOT) {      // (one division per piece: element j sits at f0 + j of channel c0, or - NF = 257 only - wraps into the next channel's row)
+                    const int c0 = e / NF, f0 = e - c0 * NF;
+                    float* t0 = T + (c0 * 16 + n) * LDT + f0;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { const int c = (e + j) / NF, f = (e + j) - c * NF; T[(c * 16 + n) * LDT + f] = v[k][j]; }
-                    }
+                    for (int j = 0; j < 4; ++j) t0[(NF % 4 != 0 && f0 + j >= NF) ? j + 16 * LDT - NF : j] = v[k][j];
                 }
             }
         };
@@ -246,9 +252,11 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
 #pragma unroll 1
             for (int i0 = 0; i0 < TOT; i0 += kLsbThreads) {
                 const int i = i0 + tid, ic = i < TOT ? i : TOT - 1, n = ic / NE4, e = (ic - n * NE4) * 4;
+                const int c0 = e / NF, f0 = e - c0 * NF;
+                const float* t0 = T + (c0 * 16 + n) * LDT + f0;
                 f32x4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const int c = (e + j) / NF, f = (e + j) - c * NF; o[j] = T[(c * 16 + n) * LDT + f]; }
+                for (int j = 0; j < 4; ++j) o[j] = t0[(NF % 4 != 0 && f0 + j >= NF) ? j + 16 * LDT - NF : j];
                 if (i < TOT && b0 + n < a.B) *reinterpret_cast<f32x4*>(dst + (size_t)(b0 + n) * per + e) = o;
             }
         };
@@ -260,16 +268,25 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
         using I65 = std::integral_constant<int, 65>;
         using I128 = std::integral_constant<int, 128>;
         using I129 = std::integral_constant<int, 129>;
+        using I256 = std::integral_constant<int, 256>;
         using I257 = std::integral_constant<int, 257>;
         using I260 = std::integral_constant<int, 260>;
         using I261 = std::integral_constant<int, 261>;
         float* const c2g = a.cache + (size_t)S::K_PHA * a.B;                                   // cached conv_1 frames [B][4][257]
         float* const c3g = a.cache + (size_t)(S::K_PHA + S::K_E2) * a.B;                       // cached conv_2 frames [B][8][128]
         float* const c4g = a.cache + (size_t)(S::K_PHA + S::K_E2 + S::K_E3) * a.B;             // cached conv_3 frames [B][12][64]
+        float* const cdg = a.cache + (size_t)(S::K_PHA + S::K_E2 + S::K_E3 + S::K_E4 + S::NB * (S::K_H + S::K_GLU)) * a.B;      // cached up3 frames [B][4][256]
+        f32x4 vf[(16 * 780 / 4 + kLsbThreads - 1) / kLsbThreads], v1[(16 * S::K_E2 / 4 + kLsbThreads - 1) / kLsbThreads], v2[16 * S::K_E3 / 4 / kLsbThreads], v3[16 * S::K_E4 / 4 / kLsbThreads], v4[16 * S::K_DEC / 4 / kLsbThreads];
+        stage_load(vf, a.carry + A::feat(a.B), A::FEAT, std::integral_constant<int, 780>{});
+        stage_load(v1, c2g, S::K_E2, std::integral_constant<int, S::K_E2>{});
+        stage_load(v2, c3g, S::K_E3, std::integral_constant<int, S::K_E3>{});
+        stage_load(v3, c4g, S::K_E4, std::integral_constant<int, S::K_E4>{});
+        stage_load(v4, cdg, S::K_DEC, std::integral_constant<int, S::K_DEC>{});
         // features [3][260] -> area A, the cached conv_1 frame -> area B
-        stage(TA, a.carry + A::feat(a.B), A::FEAT, I3{}, I260{}, I261{});
-        stage(TB, c2g, S::K_E2, I4{}, I257{}, I261{});
+        stage_put(TA, vf, I3{}, I260{}, I261{});
+        stage_put(TB, v1, I4{}, I257{}, I261{});
         __syncthreads();
+        LSB_CLK(26);
         emit(A::X1P{}, TB, I257{}, I261{});
         // conv_1 + LayerNorm over (channel, freq) + per-frequency affine + PReLU: thread (n = tid % 16, p = tid / 16 + 32 k); same lane structure as the tiles
         {
@@ -318,14 +335,20 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
                 }
             }
         }
-        stage(TB, c3g, S::K_E3, I8{}, I128{}, I129{});                  // the cached conv_2 frame -> area B
+        LSB_CLK(27);
+        stage_put(TB, v2, I8{}, I128{}, I129{});                        // the cached conv_2 frame -> area B
         __syncthreads();
+        LSB_CLK(28);
         unstage(c2g, S::K_E2, TA, I4{}, I257{}, I261{});                // the new conv_1 cache frame
         emit(A::X2P{}, TB, I128{}, I129{});
         __syncthreads();
-        stage(TA, c4g, S::K_E4, I12{}, I64{}, I65{});                   // the cached conv_3 frame -> area A
+        LSB_CLK(29);
+        stage_put(TA, v3, I12{}, I64{}, I65{});                         // the cached conv_3 frame -> area A
+        stage_put(TB, v4, I4{}, I256{}, I257{});                        // the cached up3 frame -> area B
         __syncthreads();
+        LSB_CLK(30);
         emit(A::X3P{}, TA, I64{}, I65{});
+        emit(A::U3P{}, TB, I256{}, I257{});
     __syncthreads();
     LSB_CLK(1);
 
@@ -1016,8 +1039,13 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int p = 8 * wave + 4 * hlf + i;
-                if (lg == 0) *reinterpret_cast<f32x4*>(ct + A::U3 + (p * 16 + li) * 4) = accL[i][0];
-                if (lg < 3) *reinterpret_cast<f32x4*>(ct + A::U3 + ((64 + 3 * p + lg) * 16 + li) * 4) = accH[i][0];
+                if (lg == 0) *reinterpret_cast<f32x4*>(ct + A::U3S::row(p) + li * 4) = accL[i][0];
+                if (lg < 3) *reinterpret_cast<f32x4*>(ct + A::U3S::row(64 + 3 * p + lg) + li * 4) = accH[i][0];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {               // the new cache frame [4][256] per stream: out as whole rows below
+                    if (lg == 0) smem[L::TA + (r * 16 + li) * 257 + p] = accL[i][0][r];
+                    if (lg < 3) smem[L::TA + (r * 16 + li) * 257 + 64 + 3 * p + lg] = accH[i][0][r];
+                }
                 if (dbg) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -1028,7 +1056,70 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
             }
         }
     }
+    __syncthreads();
     LSB_CLK(19);
+    unstage(cdg, S::K_DEC, smem + L::TA, I4{}, I256{}, I257{});         // the new up3 cache frame
+    // ---------------- mask_conv (:283-288, :304-308): Conv2d(4 -> 2, (2, 2), padding (0, 1)) over (cached, this) frame, LayerNorm over (channel, freq), PReLU, 1x1, learnable sigmoid ----------------
+    {
+        int offM[1];
+        lsb_src<1, 2, 1>(offM, A::U3P::LO, A::U3S::LO, lg, li);
+        f32x4 WM[1][1] = {{frag(SB + Q::M0_W)}};
+        const f32x4 bM = row4(SB + Q::M0_B);
+        // wave w takes bins w, w + 8, ..: 33 of them (past bin 256: clamped, not kept); rows 0, 1 of a tile = the two channels, in lane group 0 - they go to LDS
+        // [channel][bin][16 n] and the rest of the head (LayerNorm, PReLU, 1x1, sigmoid) runs one (stream, bin) pair per thread like conv_1: from lane group 0
+        // alone it was 33 dependent rounds of three parameter loads per wave (36 k cycles for 1028 MFMAs)
+        float* M = smem + L::TB;
+#pragma unroll
+        for (int c8 = 0; c8 < 5; ++c8) {
+            f32x4 acc[8][1];
+            int pp[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const int p = wave + 8 * (8 * c8 + i); acc[i][0] = bM; pp[i] = (p < 257 ? p : 256) * A::U3S::ROW; }
+            if (c8 < 4 || wave == 0) {                         // (the fifth round is bin 256 alone: wave 0)
+                LSB_CONV(1, 1, 8, acc, WM, offM, pp);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int p = wave + 8 * (8 * c8 + i);
+                    if (lg == 0 && p < 257) { M[(0 * 257 + p) * 16 + li] = acc[i][0][0]; M[(1 * 257 + p) * 16 + li] = acc[i][0][1]; }
+                }
+            }
+        }
+        __syncthreads();
+        float y0[9], y1[9], gam[9], bet[9], slo[9];
+        float s0 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int p = (tid >> 4) + 32 * k, pc = p < 257 ? p : 256;
+            y0[k] = M[(0 * 257 + pc) * 16 + li]; y1[k] = M[(1 * 257 + pc) * 16 + li];
+            gam[k] = a.wp[SB + Q::M_G + pc]; bet[k] = a.wp[SB + Q::M_BE + pc]; slo[k] = a.wp[SB + Q::M_SL + pc];
+            if (p < 257) s0 += y0[k] + y1[k];
+        }
+        const float mean = tile_sum(s0, 0) * (1.0f / 514.0f);
+        float s1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int p = (tid >> 4) + 32 * k;
+            y0[k] -= mean; y1[k] -= mean;
+            if (p < 257) s1 = __builtin_fmaf(y0[k], y0[k], __builtin_fmaf(y1[k], y1[k], s1));
+        }
+        const float rstd = 1.0f / sqrtf(tile_sum(s1, 1) * (1.0f / 514.0f) + 1.0e-5f);
+        const f32x4 prm = ldw4(SB + Q::M_P, 0), m3a = ldw4(SB + Q::M3, 0), m3b = ldw4(SB + Q::M3 + 4, 0);      // PReLU [2]; W3 [o][c] (4); b3 [2]
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int p = (tid >> 4) + 32 * k;
+            if (p < 257) {
+                const float ga = gam[k] * rstd;
+                float u0 = __builtin_fmaf(y0[k], ga, bet[k]), u1 = __builtin_fmaf(y1[k], ga, bet[k]);
+                u0 = u0 >= 0.0f ? u0 : u0 * prm[0];
+                u1 = u1 >= 0.0f ? u1 : u1 * prm[1];
+                const float z0 = m3b[0] + m3a[0] * u0 + m3a[1] * u1, z1 = m3b[1] + m3a[2] * u0 + m3a[3] * u1;
+                const float k0 = sigmoid_f(slo[k] * z0), k1 = sigmoid_f(slo[k] * z1);
+                *reinterpret_cast<float2*>(ct + A::MK + (p * 16 + li) * 2) = make_float2(k0, k1);
+                if (dbg) { dbg[LDebugLayout::offset(14) + 2 * p] = k0; dbg[LDebugLayout::offset(14) + 2 * p + 1] = k1; }
+            }
+        }
+    }
+    LSB_CLK(25);
 #undef LSB_CONV
 #undef LSB_CLK
 }

@@ -25,15 +25,17 @@ def main():
         clk = eng.profile_step(x, st, T=1)
     torch.cuda.synchronize()
     q = clk.cpu().numpy()[32:]
-    print(f"lisennet B={B}: lisennet_sb_kernel, workgroup 0 = {q[19] - q[0]} cycles")
+    print(f"lisennet B={B}: lisennet_sb_kernel, workgroup 0 = {q[25] - q[0]} cycles")
     print(f"  halos + regrouping + conv_1 {q[1] - q[0]}, conv_2 {q[24] - q[1]}, conv_3 {q[2] - q[24]}, conv_4 {q[3] - q[2]}")
+    print(f"    prologue: halos + four tensors' loads + features / cached x1 -> LDS {q[26] - q[0]}, X1P out + conv_1 + LayerNorm + x1 out {q[27] - q[26]}, cached x2 -> LDS {q[28] - q[27]}, "
+          f"x1 cache out + X2P out {q[29] - q[28]}, cached x3 / u3 -> LDS {q[30] - q[29]}, X3P / U3P out {q[1] - q[30]}")
     for b in range(2):
         o = 4 + 6 * b
         prev = q[3] if b == 0 else q[o - 3]
         print(f"  block {b}: intra_norm {q[o] - prev}, intra GRU (32 steps x 2 directions) {q[o + 1] - q[o]}, dense + inter_norm + inter GRU + dense {q[o + 2] - q[o + 1]}, "
               f"conv_glu {q[o + 3] - q[o + 2]}")
     print(f"  block 0 conv_glu: statistics + affine {q[20] - q[6]}, fc1 edges + cached frames + edge columns + barrier {q[21] - q[20]}, pass 0 {q[22] - q[21]}, pass 1 {q[23] - q[22]}, fc2 + barrier {q[7] - q[23]}")
-    print(f"  block output -> carry {q[16] - q[13]}, up1 {q[17] - q[16]}, up2 {q[18] - q[17]}, up3 {q[19] - q[18]}")
+    print(f"  block output -> carry {q[16] - q[13]}, up1 {q[17] - q[16]}, up2 {q[18] - q[17]}, up3 {q[19] - q[18]}, up3 cache out + mask_conv {q[25] - q[19]}")
     # wall time of the step
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     for _ in range(5):
