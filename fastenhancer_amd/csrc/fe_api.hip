@@ -48,7 +48,7 @@ constexpr OptionDef kOptions[OPT_COUNT] = {
     {"fspen_stream_batch_min", "FE_FSPEN_SB", 1536, 0, 1 << 24},
     {"low_lds_companion", "FE_LOWLDS", 1, 0, 1},
     {"bsrnn_fused_step", "FE_BSRNN_FUSED", 0, 0, 1},      // (measured negative: profiles/r6_bsrnn_fused_step.txt)
-    {"lisennet_stream_batch_min", "FE_LISENNET_SB", 1024, 0, 1 << 24},
+    {"lisennet_stream_batch_min", "FE_LISENNET_SB", 513, 0, 1 << 24},      // (2 x 256 + 1: from where the per-stream kernel needs a second round of workgroups - 219 us against the tiles' 193)
 };
 int env_int(const char* name, int dflt, int lo, int hi) {
     const char* e = std::getenv(name);

@@ -208,8 +208,8 @@ int fe_set_step_kernel(fe_handle* h, int kernel);
  *                                                  their tile, meet again and finish their own streams; 0 = three launches (a launch the runtime
  *                                                  refuses falls back to them by itself).  Bit-identical results; MEASURED SLOWER (barriers across XCDs,
  *                                                  cooperative launch: profiles/r6_bsrnn_fused_step.txt), hence off by default
- *   "lisennet_stream_batch_min" 0 .. 2^24 1024     LiSenNet (r6): from this many streams the per-hop step runs encoder.conv_3 .. decoder.up3 batched over the streams on
- *                                                  the matrix cores (lisennet_sb_kernels.hip.h: front per stream, sixteen streams per workgroup, tail per stream); 0 = never
+ *   "lisennet_stream_batch_min" 0 .. 2^24 513      LiSenNet (r6): from this many streams the per-hop step runs encoder.conv_1 .. the mask head batched over the streams on
+ *                                                  the matrix cores (lisennet_sb_kernels.hip.h: STFT + features per stream, sixteen streams per workgroup, mask + iSTFT per stream); 0 = never
  * A/B scripts (tools/ab_*.sh) preset the values NEW handles start with through FE_BSRNN_OV, FE_BSRNN_SB, FE_BSRNN_SPLIT, FE_BSRNN_OV_PROF,
  * FE_FSPEN_SB, FE_LOWLDS (FE_NO_LOWLDS), FE_BSRNN_FUSED, FE_LISENNET_SB and FE_WG8 (the step kernel): read once, in fe_create, validated against the same ranges (anything else
  * is ignored).  The reference has one forward per model and nothing to select (models/fastenhancer/default/model.py:677-710). */

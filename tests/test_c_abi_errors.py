@@ -227,7 +227,7 @@ def test_options_are_enumerable_validated_and_preset_by_their_environment_variab
         assert n in integration, n
     assert "fe_last_step_kernel" in header and "fe_last_step_kernel" in integration
     defaults = {"bsrnn_role_split": 1, "bsrnn_stream_batch_min": 2048, "bsrnn_three_launch_step": 1, "bsrnn_ov_profile": 0,
-                "fspen_stream_batch_min": 1536, "low_lds_companion": 1, "bsrnn_fused_step": 0, "lisennet_stream_batch_min": 1024}
+                "fspen_stream_batch_min": 1536, "low_lds_companion": 1, "bsrnn_fused_step": 0, "lisennet_stream_batch_min": 513}
     for v in ("FE_BSRNN_OV", "FE_BSRNN_SB", "FE_BSRNN_SPLIT", "FE_BSRNN_OV_PROF", "FE_FSPEN_SB", "FE_LOWLDS", "FE_NO_LOWLDS", "FE_WG8", "FE_BSRNN_FUSED", "FE_LISENNET_SB"):
         monkeypatch.delenv(v, raising=False)
     rc, h = _create(_cfg())
