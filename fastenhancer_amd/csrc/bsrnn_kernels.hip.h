@@ -186,7 +186,7 @@ struct BLds {
 // PART = 1 runs the frame up to the last layer and leaves the band features and the compressed spectrum in global memory,
 // bsrnn_mlp_kernel computes the two MLP layers for all streams, PART = 2 applies GLU / mask / residual and runs the iSTFT.
 template <class S, bool HOT, bool PROF, bool DBG, bool OCC2 = false, bool PIPE = false, int PART = 0>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, (PART == 2 || PART == 3) ? 4 : OCC2 ? 2 : 1))) bsrnn_frame_kernel(BArgs a) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, PART == 2 ? 6 : PART == 3 ? 4 : OCC2 ? 2 : 1))) bsrnn_frame_kernel(BArgs a) {
     static_assert(!PIPE || (!HOT && !PROF && !DBG), "the time-pipelined instantiation is the plain offline kernel");
     static_assert(PART == 0 || (HOT && !PROF && !DBG && !PIPE), "the split step is the per-hop streaming step");
     // PART = 3: the front of the frame alone (STFT, compress, band split -> mlp_x / mlp_sp): the stream-batched step
@@ -1281,10 +1281,11 @@ void blaunch_part(const BArgs& a, int grid, hipStream_t st, hipError_t* err) {
 }
 
 // grid of a per-stream front / tail launch (PART 3 / 2): their own LDS plans fit four times per CU
-template <class S>
+template <class S, int PART>
 int bpart_grid(int B, int max_wgs) {
-    static_assert(4 * BLds<S, 2>::BYTES <= 160 * 1024 && 4 * BLds<S, 3>::BYTES <= 160 * 1024, "four front / tail workgroups per CU");
-    return B < 4 * max_wgs ? B : 4 * max_wgs;
+    constexpr int OCC = PART == 2 ? 6 : 4;          // (tail: 82 VGPRs, 20.5 KB (xt); front: 106 VGPRs, 14.6 KB)
+    static_assert(OCC * BLds<S, PART>::BYTES <= 160 * 1024, "front / tail workgroups per CU");
+    return B < OCC * max_wgs ? B : OCC * max_wgs;
 }
 
 }  // namespace fe
@@ -1332,8 +1333,8 @@ void blaunch_split_impl(const BArgs& a, int max_wgs, hipStream_t st, hipError_t*
         *err = hipGetLastError();
         if (*err != hipSuccess) return;
     }
-    if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 2>(a, bpart_grid<S>(a.B, max_wgs), st, err);
-    else blaunch_part<S, false, 2>(a, bpart_grid<S>(a.B, max_wgs), st, err);
+    if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 2>(a, bpart_grid<S, 2>(a.B, max_wgs), st, err);
+    else blaunch_part<S, false, 2>(a, bpart_grid<S, 2>(a.B, max_wgs), st, err);
 }
 
 template <class S>
@@ -1360,8 +1361,8 @@ void blaunch_mlp(const BArgs& a, hipStream_t st, hipError_t* err) {
 template <class S>
 void blaunch_sb_impl(const BArgs& a, const SbOffsets& so, int total_floats, int max_wgs, hipStream_t st, hipError_t* err) {
     constexpr bool FITS2 = 2 * BLds<S>::BYTES <= 160 * 1024 && !S::XPG;
-    if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 3>(a, bpart_grid<S>(a.B, max_wgs), st, err);
-    else blaunch_part<S, false, 3>(a, bpart_grid<S>(a.B, max_wgs), st, err);
+    if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 3>(a, bpart_grid<S, 3>(a.B, max_wgs), st, err);
+    else blaunch_part<S, false, 3>(a, bpart_grid<S, 3>(a.B, max_wgs), st, err);
     if (*err != hipSuccess) return;
     SbArgs sa{};
     sa.wp = a.wp; sa.off = so; sa.x = a.mlp_x; sa.lstm = a.lstm; sa.y = a.sb_y; sa.B = a.B; sa.total = total_floats;
@@ -1369,8 +1370,8 @@ void blaunch_sb_impl(const BArgs& a, const SbOffsets& so, int total_floats, int 
     if (*err != hipSuccess) return;
     blaunch_mlp<S>(a, st, err);
     if (*err != hipSuccess) return;
-    if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 2>(a, bpart_grid<S>(a.B, max_wgs), st, err);
-    else blaunch_part<S, false, 2>(a, bpart_grid<S>(a.B, max_wgs), st, err);
+    if (FITS2 && a.B > max_wgs) blaunch_part<S, FITS2, 2>(a, bpart_grid<S, 2>(a.B, max_wgs), st, err);
+    else blaunch_part<S, false, 2>(a, bpart_grid<S, 2>(a.B, max_wgs), st, err);
 }
 
 template <class S>
