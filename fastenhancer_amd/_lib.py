@@ -67,6 +67,7 @@ SYMBOLS = {
     "fe_debug_poison_lds": (c_int, [c_void_p]),
     "fe_last_error": (c_char_p, []),
     "fe_version": (c_char_p, []),
+    "fe_build_key": (c_char_p, []),
 }
 
 _lib = None
@@ -90,6 +91,12 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)       # AttributeError if the ABI drifted
         fn.restype = res
         fn.argtypes = args
+    # the in-tree library must be built from the tree's sources (a side build loaded through FASTENHANCER_HIP_LIB is its author's business)
+    if not os.environ.get("FASTENHANCER_HIP_LIB"):
+        from .build import source_key
+        have, want = lib.fe_build_key().decode(), source_key()
+        if have != want:
+            raise FEError(f"{LIB_PATH} was built from other sources (fe_build_key {have}, tree {want}): rebuild it with `python -m fastenhancer_amd.build`")
     _lib = lib
     return lib
 

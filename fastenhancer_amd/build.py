@@ -104,6 +104,14 @@ def _digest(paths, extra="") -> str:
     return h.hexdigest()[:16]
 
 
+def source_key() -> str:
+    """Digest of every source the library is built from (csrc/*, the C-ABI header): libfastenhancer_hip.so carries it as fe_build_key(), and
+    fastenhancer_amd._lib.load() refuses an in-tree library whose key is not the tree's - a stale build cannot pass for the shipped sources."""
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".inc", ".in", ".def")))
+    files.append(os.path.join(os.path.dirname(HERE), "include", "fastenhancer_hip.h"))
+    return _digest(files)
+
+
 def _compile(job):
     src, obj, defs, stamp, key = job
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == key:
@@ -154,6 +162,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
     lsn = os.path.join(CSRC, "fe_lisennet.hip")
     jobs.append((lsn, os.path.join(OBJ, "fe_lisennet.o"), valu_defs, os.path.join(OBJ, "fe_lisennet.stamp"),
                  _digest([os.path.join(CSRC, d) for d in LISENNET_DEPS] + [lsn], " ".join(FLAGS + valu_defs))))
+    # fe_build_key(): the digest of the sources, compiled into the library (a translation unit of its own: seconds)
+    bk = os.path.join(OBJ, "fe_build_key.cpp")
+    skey = source_key()
+    bk_src = '#include "../../../include/fastenhancer_hip.h"\nextern "C" const char* fe_build_key(void) { return "%s"; }\n' % skey
+    if not os.path.exists(bk) or open(bk).read() != bk_src:
+        open(bk, "w").write(bk_src)
+    jobs.append((bk, os.path.join(OBJ, "fe_build_key.o"), [], os.path.join(OBJ, "fe_build_key.stamp"), _digest([bk], " ".join(FLAGS))))
     if force:
         for j in jobs:
             if os.path.exists(j[3]):

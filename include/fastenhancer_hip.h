@@ -306,6 +306,9 @@ int fe_debug_poison_lds(void* stream);
 
 const char* fe_last_error(void);
 const char* fe_version(void);
+/* r6: the digest of the sources this library was built from (fastenhancer_amd/build.py::source_key: csrc/* and this header).  The Python binding refuses an
+ * in-tree library whose key is not the tree's, and __graft_entry__.build() checks it after building: a stale object cache cannot pass for the shipped sources. */
+const char* fe_build_key(void);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,21 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.fe_version()
 
 
+def test_library_carries_the_digest_of_the_sources_it_was_built_from(monkeypatch):
+    """r6 (engineering): fe_build_key() is fastenhancer_amd.build.source_key() of the tree - csrc/* and the C-ABI header - and the binding refuses an
+    in-tree library built from other sources (a stale object cache cannot pass for the shipped sources); a side build named by FASTENHANCER_HIP_LIB is not checked."""
+    from fastenhancer_amd import build as fbuild
+    lib = _lib.load()
+    assert lib.fe_build_key().decode() == fbuild.source_key()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(fbuild, "source_key", lambda: "0000000000000000")
+    with pytest.raises(_lib.FEError, match="built from other sources"):
+        _lib.load()
+    monkeypatch.setenv("FASTENHANCER_HIP_LIB", _lib.LIB_PATH)          # (a side build: loaded as it is)
+    assert _lib.load().fe_build_key() == lib.fe_build_key()
+    monkeypatch.setattr(_lib, "_lib", lib)
+
+
 @pytest.mark.parametrize("name", ["fe_t", "fe_b", "fe_s", "fe_m", "fe_l", "fe48_t", "fe48_b", "fe48_s", "fe48_m", "fe48_l", "fe48_b_h480", "fe_tk_b",
                                   "fe_dprnn_t", "fe_dprnn_b", "fe_dprnn_s", "fe_dprnn_m", "fe_dprnn_l", "fe_dpt_t", "fe_dpt_b", "fe_dpt_s", "fe_dpt_m", "fe_ln_b",
                                   "fe_nc", "fe_nc24", "fe48_nc"])
