@@ -1069,7 +1069,7 @@ struct BMlpLds {
 // it0, it0 + its, ... (nitw of them; an item = a column tile of the band's rows x a burst of KB k-steps) of `tpw` consecutive stream tiles.
 // AGENT (r6, the fused per-hop step: bsrnn_ov_kernels.hip.h): the band features were written, and the pre-activations will be read, by
 // OTHER workgroups of the same launch - agent-scope loads / stores (the hand-over protocol of the time-pipelined kernels: no fences).
-template <class S, bool AGENT>
+template <class S, bool AGENT, bool MULTI = false>
 __device__ __forceinline__ void bsrnn_mlp_wave(const BArgs& a, float* h1, int kind, int band, int tile0, int tpw, int it0, int its, int nitw, int lane) {
     constexpr int C = S::C, O1 = 4 * C, R4 = C / 4, NT1 = O1 / 16, KS2 = O1 / 4, LDH = BMlpLds<S>::LDH;
     const int li = lane & 15, lg = lane >> 4;
@@ -1094,32 +1094,53 @@ __device__ __forceinline__ void bsrnn_mlp_wave(const BArgs& a, float* h1, int ki
     float ring[D][KB], rbias[D];
 #pragma unroll
     for (int jj = 0; jj < D; ++jj) { rbias[jj] = 0.0f; load_item(jj, ring[jj], rbias[jj]); }
+    // r6: a wave that walks several stream tiles (C = 16, large batches) keeps layer 1's fragments in registers too and requests the NEXT tile's rows of x before
+    // it stores this tile's pre-activations: vmcnt completes in order, so every tile's fetches - 20 of them - used to wait for the previous tile's stores to drain
+    constexpr bool HOIST1 = MULTI && (NT1 * R4 <= 16);        // (MULTI: the instantiation of the waves that walk several tiles; a one-tile wave keeps its fetch order: x first)
+    const float* w1 = wp + o.m_w1[kind] + (size_t)band * R4 * O1 * 4 + li * 4 + lg;
+    const float* b1 = wp + o.m_b1[kind] + band * O1 + li;
+    float wvh[HOIST1 ? NT1 : 1][HOIST1 ? R4 : 1], bjh[HOIST1 ? NT1 : 1];
+    if constexpr (HOIST1) {
+#pragma unroll
+        for (int j = 0; j < NT1; ++j) {
+            bjh[j] = b1[16 * j];
+#pragma unroll
+            for (int ks = 0; ks < R4; ++ks) wvh[j][ks] = w1[((size_t)ks * O1 + 16 * j) * 4];
+        }
+    }
+    auto load_x = [&](float (&av)[R4], int s0) {
+        const int srow = s0 + li < a.B ? s0 + li : a.B - 1;   // (rows past the batch shadow its last stream; their results are not stored)
+        const float* xa = a.mlp_x + ((size_t)srow * kBands + band) * C + lg;
+#pragma unroll
+        for (int ks = 0; ks < R4; ++ks) {
+            if constexpr (AGENT) av[ks] = __hip_atomic_load(xa + 4 * ks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else av[ks] = xa[4 * ks];
+        }
+    };
+    float avn[R4];
+    if constexpr (MULTI) load_x(avn, tile0 * 16 < a.B ? tile0 * 16 : 0);
 #pragma unroll 1
     for (int tl = 0; tl < tpw; ++tl) {
     const int s0 = (tile0 + tl) * 16;
     if (s0 >= a.B) break;
     // ---- layer 1
     {
-        const int srow = s0 + li < a.B ? s0 + li : a.B - 1;   // (rows past the batch shadow its last stream; their results are not stored)
-        const float* xa = a.mlp_x + ((size_t)srow * kBands + band) * C + lg;
         float av[R4];
+        if constexpr (MULTI) {
 #pragma unroll
-        for (int ks = 0; ks < R4; ++ks) {
-            if constexpr (AGENT) av[ks] = __hip_atomic_load(xa + 4 * ks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else av[ks] = xa[4 * ks];
-        }
-        const float* w1 = wp + o.m_w1[kind] + (size_t)band * R4 * O1 * 4 + li * 4 + lg;
-        const float* b1 = wp + o.m_b1[kind] + band * O1 + li;
+            for (int ks = 0; ks < R4; ++ks) av[ks] = avn[ks];
+            if (tl + 1 < tpw && s0 + 16 < a.B) load_x(avn, s0 + 16);      // the next tile's rows: in flight under this tile's MFMAs, ahead of its stores
+        } else load_x(av, s0);
 #pragma unroll
         for (int nt0 = 0; nt0 < NT1; nt0 += 4) {              // four column tiles at a time (C = 64: 16 tiles)
             f32x4 acc[4];
             float wv[4][R4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float bj = b1[16 * (nt0 + j)];
+                const float bj = HOIST1 ? bjh[HOIST1 ? nt0 + j : 0] : b1[16 * (nt0 + j)];
                 acc[j] = f32x4{bj, bj, bj, bj};
 #pragma unroll
-                for (int ks = 0; ks < R4; ++ks) wv[j][ks] = w1[((size_t)ks * O1 + 16 * (nt0 + j)) * 4];
+                for (int ks = 0; ks < R4; ++ks) wv[j][ks] = HOIST1 ? wvh[HOIST1 ? nt0 + j : 0][HOIST1 ? ks : 0] : w1[((size_t)ks * O1 + 16 * (nt0 + j)) * 4];
             }
 #pragma unroll
             for (int ks = 0; ks < R4; ++ks)
@@ -1178,7 +1199,9 @@ __device__ __forceinline__ void bsrnn_mlp_wave(const BArgs& a, float* h1, int ki
     }
 }
 
-template <class S>
+// MULTI (r6): the instantiation for waves that walk several stream tiles (a.mlp_tpw > 1) - a kernel of its own: its 188 registers in one kernel with the one-tile
+// path (142) cost that path a wave per SIMD (BASELINE config 5: 77.3 -> 79.2 us)
+template <class S, bool MULTI = false>
 __global__ void __launch_bounds__(kThreads) bsrnn_mlp_kernel(BArgs a) {
     constexpr int O1 = 4 * S::C, KS2 = O1 / 4, LDH = BMlpLds<S>::LDH;
     constexpr int KB = KS2 < 16 ? KS2 : 16, NB = KS2 / KB;
@@ -1202,7 +1225,8 @@ __global__ void __launch_bounds__(kThreads) bsrnn_mlp_kernel(BArgs a) {
     const bool wsplit = split && NB == 1;
     const int nit = wsplit ? (nit_all - wave + kWaves - 1) / kWaves : nit_all;
     if (wsplit && nit <= 0) return;                           // (a narrow band: fewer column tiles than waves)
-    bsrnn_mlp_wave<S, false>(a, smem + wave * (16 * LDH), kind, band, tile0, tpw, wsplit ? wave : 0, wsplit ? kWaves : 1, nit, lane);
+    if constexpr (MULTI) bsrnn_mlp_wave<S, false, true>(a, smem + wave * (16 * LDH), kind, band, tile0, tpw, 0, 1, nit, lane);
+    else bsrnn_mlp_wave<S, false>(a, smem + wave * (16 * LDH), kind, band, tile0, tpw, wsplit ? wave : 0, wsplit ? kWaves : 1, nit, lane);
 }
 
 struct SbOffsets;
@@ -1337,9 +1361,9 @@ void blaunch_split_impl(const BArgs& a, int max_wgs, hipStream_t st, hipError_t*
     else blaunch_part<S, false, 2>(a, bpart_grid<S, 2>(a.B, max_wgs), st, err);
 }
 
-template <class S>
-void blaunch_mlp(const BArgs& a, hipStream_t st, hipError_t* err) {
-    auto* fn = &bsrnn_mlp_kernel<S>;
+template <class S, bool MULTI>
+void blaunch_mlp_one(const BArgs& am, int groups, hipStream_t st, hipError_t* err) {
+    auto* fn = &bsrnn_mlp_kernel<S, MULTI>;
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -1348,12 +1372,18 @@ void blaunch_mlp(const BArgs& a, hipStream_t st, hipError_t* err) {
         if (e != hipSuccess) { *err = e; return; }
         attr_set[dev].store(true, std::memory_order_relaxed);
     }
+    hipLaunchKernelGGL(fn, dim3(2 * kBands * groups), dim3(kThreads), BMlpLds<S>::BYTES, st, am);
+    *err = hipGetLastError();
+}
+
+template <class S>
+void blaunch_mlp(const BArgs& a, hipStream_t st, hipError_t* err) {
     BArgs am = a;
     am.mlp_tpw = (S::C == 16 && a.B >= 2048) ? 4 : 1;       // (C = 16: KS2 = 16 k-steps = one burst per item, at most five items = the ring)
     const int groups = (a.B + 16 * kWaves * am.mlp_tpw - 1) / (16 * kWaves * am.mlp_tpw);
     note_kernel(am.mlp_tpw == 4 ? "bsrnn_mlp_kernel<four tiles per wave>" : "bsrnn_mlp_kernel");
-    hipLaunchKernelGGL(fn, dim3(2 * kBands * groups), dim3(kThreads), BMlpLds<S>::BYTES, st, am);
-    *err = hipGetLastError();
+    if (am.mlp_tpw > 1) blaunch_mlp_one<S, true>(am, groups, st, err);
+    else blaunch_mlp_one<S, false>(am, groups, st, err);
 }
 
 // the per-hop step of a LARGE batch: front per stream (PART 3), the LSTM layers for sixteen streams per workgroup on the matrix
