@@ -1069,8 +1069,119 @@ struct BMlpLds {
 // it0, it0 + its, ... (nitw of them; an item = a column tile of the band's rows x a burst of KB k-steps) of `tpw` consecutive stream tiles.
 // AGENT (r6, the fused per-hop step: bsrnn_ov_kernels.hip.h): the band features were written, and the pre-activations will be read, by
 // OTHER workgroups of the same launch - agent-scope loads / stores (the hand-over protocol of the time-pipelined kernels: no fences).
-template <class S, bool AGENT, bool MULTI = false>
+template <class S, bool AGENT>
 __device__ __forceinline__ void bsrnn_mlp_wave(const BArgs& a, float* h1, int kind, int band, int tile0, int tpw, int it0, int its, int nitw, int lane) {
+    constexpr int C = S::C, O1 = 4 * C, R4 = C / 4, NT1 = O1 / 16, KS2 = O1 / 4, LDH = BMlpLds<S>::LDH;
+    const int li = lane & 15, lg = lane >> 4;
+    const float* __restrict__ wp = a.wp;
+    const BOffsets& o = a.off;
+    const int n2 = 4 * bsrnn_band_sub(band), row0 = 4 * bsrnn_band_bin0(band);
+    constexpr int KB = KS2 < 16 ? KS2 : 16, NB = KS2 / KB, D = NB == 1 ? 5 : 8;   // (C = 16: a band has at most five items - all in flight at once)
+    const int nit = nitw;
+    auto row_of = [&](int nt) { const int c = 16 * nt + li; return row0 + (c < n2 ? c : n2 - 1); };
+    // layer 2's work list: the items' weights ride D items ahead of the MFMAs in a register ring, and the first D are requested before layer 1
+    // (a wave per SIMD: nothing else hides the L2 round trips)
+    auto load_item = [&](int itl, float (&wv)[KB], float& bias) {
+        if (itl < nit) {
+            const int it = it0 + its * itl;
+            const int nt = it / NB, kbi = it - nt * NB, row = row_of(nt);
+            const float* w2 = wp + o.m_w2[kind] + (size_t)row * 4 + lg + (size_t)(kbi * KB) * kMlpRows * 4;
+#pragma unroll
+            for (int ks = 0; ks < KB; ++ks) wv[ks] = w2[(size_t)ks * kMlpRows * 4];
+            bias = wp[o.m_b2[kind] + row];
+        }
+    };
+    float ring[D][KB], rbias[D];
+#pragma unroll
+    for (int jj = 0; jj < D; ++jj) { rbias[jj] = 0.0f; load_item(jj, ring[jj], rbias[jj]); }
+#pragma unroll 1
+    for (int tl = 0; tl < tpw; ++tl) {
+    const int s0 = (tile0 + tl) * 16;
+    if (s0 >= a.B) break;
+    // ---- layer 1
+    {
+        const int srow = s0 + li < a.B ? s0 + li : a.B - 1;   // (rows past the batch shadow its last stream; their results are not stored)
+        const float* xa = a.mlp_x + ((size_t)srow * kBands + band) * C + lg;
+        float av[R4];
+#pragma unroll
+        for (int ks = 0; ks < R4; ++ks) {
+            if constexpr (AGENT) av[ks] = __hip_atomic_load(xa + 4 * ks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else av[ks] = xa[4 * ks];
+        }
+        const float* w1 = wp + o.m_w1[kind] + (size_t)band * R4 * O1 * 4 + li * 4 + lg;
+        const float* b1 = wp + o.m_b1[kind] + band * O1 + li;
+#pragma unroll
+        for (int nt0 = 0; nt0 < NT1; nt0 += 4) {              // four column tiles at a time (C = 64: 16 tiles)
+            f32x4 acc[4];
+            float wv[4][R4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float bj = b1[16 * (nt0 + j)];
+                acc[j] = f32x4{bj, bj, bj, bj};
+#pragma unroll
+                for (int ks = 0; ks < R4; ++ks) wv[j][ks] = w1[((size_t)ks * O1 + 16 * (nt0 + j)) * 4];
+            }
+#pragma unroll
+            for (int ks = 0; ks < R4; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = FE_MFMA(av[ks], wv[j][ks], acc[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h1[(4 * lg + r) * LDH + 16 * (nt0 + j) + li] = tanh_f(acc[j][r]);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- layer 2: the band's 4 sub rows (value rows, then gate rows)
+    {
+        float av[KS2];
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) av[ks] = h1[li * LDH + 4 * ks + lg];
+        float* pre = a.mlp_pre + (size_t)kind * kMlpRows;
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+        for (int g = 0; g * D < nit; ++g) {
+#pragma unroll
+            for (int jj = 0; jj < D; ++jj) {
+                const int itl = g * D + jj;
+                if (itl < nit) {
+                    const int it = it0 + its * itl;
+                    const int nt = it / NB, kbi = it - nt * NB;
+                    if (kbi == 0) acc = f32x4{rbias[jj], rbias[jj], rbias[jj], rbias[jj]};
+                    // (av is indexed by compile-time k-steps: one unrolled body per burst position)
+                    static_for<NB>([&](auto kb_) {
+                        constexpr int kbc = decltype(kb_)::value;
+                        if (NB == 1 || kbi == kbc) {
+#pragma unroll
+                            for (int ks = 0; ks < KB; ++ks) acc = FE_MFMA(av[kbc * KB + ks], ring[jj][ks], acc);
+                        }
+                    });
+                    if (kbi == NB - 1) {
+                        const bool cok = 16 * nt + li < n2;
+                        const int row = row_of(nt);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int st = s0 + 4 * lg + r;
+                            if (cok && st < a.B) {
+                                if constexpr (AGENT) __hip_atomic_store(pre + (size_t)st * (2 * kMlpRows) + row, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                else pre[(size_t)st * (2 * kMlpRows) + row] = acc[r];
+                            }
+                        }
+                    }
+                }
+                load_item(itl + D, ring[jj], rbias[jj]);
+            }
+        }
+    }
+    }
+}
+
+// r6: the walk of SEVERAL stream tiles by one wave (a.mlp_tpw > 1: C = 16, large batches) - a function of its own: folded into bsrnn_mlp_wave as a compile-time
+// variant it still changed the register allocation of the one-tile instantiations (num_channels = 64: 270 registers -> 512 + 198 spilled; bsrnn_s 610 -> 671 us)
+template <class S, bool AGENT, bool MULTI = true>
+__device__ __forceinline__ void bsrnn_mlp_wave_multi(const BArgs& a, float* h1, int kind, int band, int tile0, int tpw, int it0, int its, int nitw, int lane) {
     constexpr int C = S::C, O1 = 4 * C, R4 = C / 4, NT1 = O1 / 16, KS2 = O1 / 4, LDH = BMlpLds<S>::LDH;
     const int li = lane & 15, lg = lane >> 4;
     const float* __restrict__ wp = a.wp;
@@ -1225,7 +1336,7 @@ __global__ void __launch_bounds__(kThreads) bsrnn_mlp_kernel(BArgs a) {
     const bool wsplit = split && NB == 1;
     const int nit = wsplit ? (nit_all - wave + kWaves - 1) / kWaves : nit_all;
     if (wsplit && nit <= 0) return;                           // (a narrow band: fewer column tiles than waves)
-    if constexpr (MULTI) bsrnn_mlp_wave<S, false, true>(a, smem + wave * (16 * LDH), kind, band, tile0, tpw, 0, 1, nit, lane);
+    if constexpr (MULTI) bsrnn_mlp_wave_multi<S, false>(a, smem + wave * (16 * LDH), kind, band, tile0, tpw, 0, 1, nit, lane);
     else bsrnn_mlp_wave<S, false>(a, smem + wave * (16 * LDH), kind, band, tile0, tpw, wsplit ? wave : 0, wsplit ? kWaves : 1, nit, lane);
 }
 
@@ -1382,8 +1493,10 @@ void blaunch_mlp(const BArgs& a, hipStream_t st, hipError_t* err) {
     am.mlp_tpw = (S::C == 16 && a.B >= 2048) ? 4 : 1;       // (C = 16: KS2 = 16 k-steps = one burst per item, at most five items = the ring)
     const int groups = (a.B + 16 * kWaves * am.mlp_tpw - 1) / (16 * kWaves * am.mlp_tpw);
     note_kernel(am.mlp_tpw == 4 ? "bsrnn_mlp_kernel<four tiles per wave>" : "bsrnn_mlp_kernel");
-    if (am.mlp_tpw > 1) blaunch_mlp_one<S, true>(am, groups, st, err);
-    else blaunch_mlp_one<S, false>(am, groups, st, err);
+    if constexpr (S::C == 16) {         // (the multi-tile instantiation exists for the shapes that use it)
+        if (am.mlp_tpw > 1) { blaunch_mlp_one<S, true>(am, groups, st, err); return; }
+    }
+    blaunch_mlp_one<S, false>(am, groups, st, err);
 }
 
 // the per-hop step of a LARGE batch: front per stream (PART 3), the LSTM layers for sixteen streams per workgroup on the matrix
