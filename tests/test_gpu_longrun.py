@@ -96,3 +96,62 @@ def test_long_run_at_full_batch_is_finite_exact_and_reproducible_from_poisoned_l
     want = {"bsrnn_xt": "bsrnn_ov_kernel + ", "fe_b": "fe_frame8_kernel [shape B]" if kernel == "wg8" else "fe_frame_kernel<per-hop> [shape B]", "fe_l": "fe_frame_kernel<per-hop> [shape L]"}[name]
     assert launched.startswith(want), launched
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]), f"{name} B={B} {kernel}: two runs from fresh, poisoned state differ"
+
+
+def _fresh_lisennet():
+    from common import LISENNET_KWARGS, build_lisennet_oracle
+    kw, sr, seed = LISENNET_KWARGS
+    cfg, sd, _, orc = build_lisennet_oracle()
+    mod = importlib.import_module("fastenhancer_amd.models.lisennet.model")
+    m = mod.ONNXModel(**kw).to(torch.device("cuda:0")).eval()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return m, orc, cfg, None, sr, seed
+
+
+@pytest.mark.parametrize("name,B,hops,want", [("lisennet", 601, 240, "lisennet_sb_kernel"), ("bsrnn_t", 2093, 64, "bsrnn_sb_layers_kernel"), ("bsrnn_s", 2829, 16, "bsrnn_sb64_layers_kernel")])
+def test_stream_batched_steps_long_run_from_poisoned_lds(name, B, hops, want):
+    """r6: the stream-batched steps built this round (LiSenNet from conv_1 to the mask head - all of its caches but the phase travel through LDS staging and a carry in
+    global memory; the BSRNN layers for num_channels = 32 / 64) over many hops with the state carried: every hop finite, sampled streams (first tile, a middle tile,
+    the partly filled last tile) against the oracle in windows, the final state's sampled rows against the oracle's caches, and the whole run twice from a fresh handle with
+    NaN in every CU's LDS first - bit for bit the same.  Reference: scripts/export_onnx.py:48-58, models/lisennet/model.py:398-474, models/bsrnn/model.py:367-390."""
+    dev = torch.device("cuda:0")
+    runs = []
+    ref = sel = ref_caches = None
+    window = max(4, hops // 4)
+    for rep in range(2):
+        m, orc, cfg, fused, sr, seed = _fresh_lisennet() if name == "lisennet" else _fresh_model(name)
+        eng, H = m.engine, cfg.hop_size
+        x = make_input(B, hops * H, seed + 777, sr)
+        if ref is None:
+            sel = sorted({0, 17, B // 2, B - 14, B - 1})
+            caches = orc.initialize_cache(len(sel))
+            outs = []
+            for t in range(hops):
+                o, *caches = orc.step(x[sel, t * H:(t + 1) * H], *caches)
+                outs.append(o)
+            ref, ref_caches = np.concatenate(outs, 1), caches
+        xd = torch.from_numpy(x).to(dev)
+        eng.poison_lds()
+        state = eng.new_state(B)
+        out = torch.empty(B, hops * H, device=dev)
+        bad = torch.zeros((), dtype=torch.int64, device=dev)
+        for t in range(hops):
+            o = out[:, t * H:(t + 1) * H]
+            eng.step(xd[:, t * H:(t + 1) * H], state, o, T=1)
+            bad += (~torch.isfinite(o).all()).to(torch.int64)
+        bad += (~torch.isfinite(state).all()).to(torch.int64)
+        assert want in eng.last_step_kernel(), eng.last_step_kernel()
+        assert int(bad) == 0, f"{name} B={B} run {rep}: {int(bad)} hops / state checks with non-finite values"
+        got = out.cpu().numpy()
+        bound = 1e-5 if name.startswith("bsrnn") else 5e-6 * 4        # (LiSenNet: the family bound of tests/test_gpu_parity.py x the drift allowance of a 240-hop run: observed 4e-7)
+        for w0 in range(0, hops, window):
+            w1 = min(hops, w0 + window)
+            g, r = got[sel][:, w0 * H:w1 * H], ref[:, w0 * H:w1 * H]
+            rel = rms(g - r) / max(rms(r), 1e-3)
+            assert rel < bound, f"{name} B={B} run {rep}, hops {w0}-{w1}: rel rms {rel:.3e}"
+        for a_, b_ in zip(eng.split_state(state, B), ref_caches):
+            g = a_.reshape(B, -1)[sel].reshape(b_.shape).cpu().numpy()
+            rel = rms(g - b_) / max(rms(b_), 1e-3)
+            assert rel < 10 * bound, f"{name} B={B} run {rep}: final cache {tuple(b_.shape)} rel rms {rel:.3e}"
+        runs.append((got, state.cpu().numpy()))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]), f"{name} B={B}: two runs from fresh, poisoned state differ"
