@@ -1132,10 +1132,10 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
     a.dbg_stride = h->impl->dbg_floats;
     hipError_t e = hipSuccess;
     a.mode = fe::FE_MODE_STREAM;
-    // per-hop launches above #CUs streams: the low-LDS companion (two workgroups per CU; same packed weights - Pack<S> does
-    // not depend on LOW), where one is compiled and measured faster
+    // per-hop launches above the streams the shape's own plan holds at once (#CUs; 2 x #CUs for T): the low-LDS companion (two workgroups per CU, three
+    // for the T shapes; same packed weights - Pack<S> does not depend on LOW), where one is compiled and measured faster
     const fe::Impl* im = h->impl;
-    if (h->impl_many && h->opt[OPT_LOW_LDS_COMPANION] && T == 1 && B > h->max_wgs && (h->impl_many->many_persist || B <= h->max_wgs * h->impl_many->occ) && !dbg && !clk &&
+    if (h->impl_many && h->opt[OPT_LOW_LDS_COMPANION] && T == 1 && B > h->max_wgs * h->impl->occ && (h->impl_many->many_persist || B <= h->max_wgs * h->impl_many->occ) && !dbg && !clk &&
         !(h->step_kernel == FE_STEP_KERNEL_WG8_PERSIST && h->impl->wg8))
         im = h->impl_many;
     h->last_shape = im->name;

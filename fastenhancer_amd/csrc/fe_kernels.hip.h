@@ -24,6 +24,9 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef FE_OCC_SMALL
+#define FE_OCC_SMALL 3
+#endif
 namespace fe {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -818,7 +821,10 @@ struct Lds {
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
     // workgroups per CU: small shapes (FastEnhancer_T: 62 KiB) fit twice - with more streams than CUs two workgroups share a
     // CU and fill each other's barrier / latency stalls (one wave per SIMD each); everything else owns its CU
-    static constexpr int OCC = (2 * BYTES <= 160 * 1024) ? 2 : 1;
+    // r6: the low-LDS companions of the SMALLEST shapes (C1 <= 32: T, 48 kHz T - ~45 KB without the staging buffers, < 170 registers per lane) fit three
+    // times (FE_OCC_SMALL): three one-stream workgroups per CU, three waves per SIMD
+    static constexpr int OCC_FIT = (int)((160 * 1024) / BYTES);
+    static constexpr int OCC = (S::LOW != 0 && S::C1 <= 32 && OCC_FIT > 2) ? (OCC_FIT < FE_OCC_SMALL ? OCC_FIT : FE_OCC_SMALL) : ((2 * BYTES <= 160 * 1024) ? 2 : 1);
     // a companion's PERSISTENT instantiation (more streams than 2 x #CUs) is only used where it beats the shape's own
     // kernel: S spills 92 VGPRs there (3.54 M frames/s at 1024 streams against 3.65 M), B / 48 kHz B gain 8 % / 5 %
     static constexpr bool MANY_PERSIST = !(S::LOW == 2 && S::C1 >= 64);

@@ -201,8 +201,9 @@ int fe_set_step_kernel(fe_handle* h, int kernel);
  *   "bsrnn_three_launch_step"  0 | 1      1        BSRNN per-hop step as PART 1 -> batched mask decoder -> PART 2; 0 = one fused kernel per stream
  *   "bsrnn_ov_profile"         0 | 1      0        fe_profile_step probes the role-split PART 1 instead of the fused kernel's phases
  *   "fspen_stream_batch_min"   0 .. 2^24  1536     FSPEN: from this many streams the middle of the network runs batched over the streams; 0 = never
- *   "low_lds_companion"        0 | 1      1        FastEnhancer per-hop step above one stream per CU: the low-LDS companion kernel (two workgroups
- *                                                  per CU) where one is compiled; 0 = persistent workgroups of the shape's own kernel
+ *   "low_lds_companion"        0 | 1      1        FastEnhancer per-hop step above the streams the shape's own LDS plan holds at once (one per CU; two for
+ *                                                  FastEnhancer_T): the low-LDS companion kernel (two workgroups per CU, three for the T shapes) where one
+ *                                                  is compiled; 0 = persistent workgroups of the shape's own kernel
  *   "bsrnn_fused_step"         0 | 1      0        BSRNN, num_channels 16, up to one stream per CU (r6): the whole per-hop step in ONE cooperative launch -
  *                                                  the workgroups of a sixteen-stream tile meet at a barrier after the layers, run the mask decoder for
  *                                                  their tile, meet again and finish their own streams; 0 = three launches (a launch the runtime
