@@ -1135,7 +1135,8 @@ static int run_step(fe_handle* h, const float* wav_in, size_t in_stride, float* 
     // per-hop launches above the streams the shape's own plan holds at once (#CUs; 2 x #CUs for T): the low-LDS companion (two workgroups per CU, three
     // for the T shapes; same packed weights - Pack<S> does not depend on LOW), where one is compiled and measured faster
     const fe::Impl* im = h->impl;
-    if (h->impl_many && h->opt[OPT_LOW_LDS_COMPANION] && T == 1 && B > h->max_wgs * h->impl->occ && (h->impl_many->many_persist || B <= h->max_wgs * h->impl_many->occ) && !dbg && !clk &&
+    if (h->impl_many && h->opt[OPT_LOW_LDS_COMPANION] && T == 1 && B > h->max_wgs * h->impl->occ && (h->impl_many->many_persist || B <= h->max_wgs * h->impl_many->occ) &&
+        (h->impl_many->many_one_round || B > h->max_wgs * h->impl_many->occ) && !dbg && !clk &&
         !(h->step_kernel == FE_STEP_KERNEL_WG8_PERSIST && h->impl->wg8))
         im = h->impl_many;
     h->last_shape = im->name;

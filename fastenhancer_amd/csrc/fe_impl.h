@@ -30,6 +30,7 @@ struct Impl {
     void (*launch_pipe)(const FrameArgs&, hipStream_t, hipError_t*);     // time-pipelined offline / spec launch (a.pipe_p workgroups per stream)
     void (*dbg_stage)(int, int*, int*, size_t*);
     const char* name = nullptr;      // the line of fe_shapes.def this record was compiled from (fe_shape.hip.in): part of fe_last_step_kernel's answer
+    bool many_one_round = true;      // companion: used from the first stream above the shape's own plan (false: only beyond occ x #CUs streams, as persistent workgroups)
 };
 
 // the instantiation a launcher picked, as fe_last_step_kernel reports it
@@ -153,9 +154,11 @@ Impl make_impl() {
         return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, S::KT, S::LOW, 0, 0, 0, 1, tbp, (size_t)0, 1, false, false, S::NU, Pack<S>::umax(), false,
                     (size_t)0, DebugLayout<S>::total(), DebugLayout<S>::n_stages, &Pack<S>::v, nullptr, nullptr, &dbg_stage_impl<S>};
     } else {
-    return Impl{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, S::KT, S::LOW, S::FRNN ? 1 : 0, S::LB, S::LN ? 1 : 0, 0, tbp, Lds<S>::BYTES, Lds<S>::OCC, Lds<S>::MANY_PERSIST, Wg8<S>::OK, S::NU, Pack<S>::umax(), Lds<S>::STAGED,
-                Lds<S>::SKIPS_LDS ? (size_t)0 : (size_t)(S::NL + 1) * S::F1 * S::C1,
-                DebugLayout<S>::total(), DebugLayout<S>::n_stages, &Pack<S>::v, &launch_impl<S>, &launch_pipe_impl<S>, &dbg_stage_impl<S>};
+    Impl im{S::C1, S::NL, S::C2, S::F2, S::KB, S::NFFT, S::HOP, S::KT, S::LOW, S::FRNN ? 1 : 0, S::LB, S::LN ? 1 : 0, 0, tbp, Lds<S>::BYTES, Lds<S>::OCC, Lds<S>::MANY_PERSIST, Wg8<S>::OK, S::NU, Pack<S>::umax(), Lds<S>::STAGED,
+            Lds<S>::SKIPS_LDS ? (size_t)0 : (size_t)(S::NL + 1) * S::F1 * S::C1,
+            DebugLayout<S>::total(), DebugLayout<S>::n_stages, &Pack<S>::v, &launch_impl<S>, &launch_pipe_impl<S>, &dbg_stage_impl<S>};
+    im.many_one_round = Lds<S>::MANY_ONE_ROUND;
+    return im;
     }
 }
 

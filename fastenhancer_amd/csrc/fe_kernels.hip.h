@@ -828,6 +828,9 @@ struct Lds {
     // a companion's PERSISTENT instantiation (more streams than 2 x #CUs) is only used where it beats the shape's own
     // kernel: S spills 92 VGPRs there (3.54 M frames/s at 1024 streams against 3.65 M), B / 48 kHz B gain 8 % / 5 %
     static constexpr bool MANY_PERSIST = !(S::LOW == 2 && S::C1 >= 64);
+    // ... and the dptransformer B companion only THERE: its one-stream-per-workgroup instantiation spills (the K / V window in registers next to the streamed weight
+    // fragments: 384 / 512 streams 167 / 183 us against the shape's own 106 / 124), the persistent one does not (1024 / 2048 streams 249 -> 216 / 483 -> 410 us)
+    static constexpr bool MANY_ONE_ROUND = !(S::TATT && S::C1 >= 48);
     static_assert(2 * S::ACT >= 4 * S::NFFT, "the FFT buffers must not reach the transposed-conv partials");
     static_assert(PERHEAD || S::F2P * S::LDC <= S::F2P * S::LDG, "rf_pre intermediate must fit in the qkv buffer");
     static_assert(!PERHEAD || !SKIPS_LDS, "per-head qkv implies global skips");

@@ -582,13 +582,18 @@ def test_time_kernel_spec_chunks_run_on_the_time_pipeline(B, T):
             _assert_close(b_.cpu().numpy(), c_, f"caches after serial chunk {i}")
 
 
-@pytest.mark.parametrize("name,B,hops", [("fe_ln_b", 300, 3), ("fe_dprnn_b", 256, 3), ("fe_dprnn_l", 300, 2), ("fe_dpt_b", 256, 35), ("fe_dpt_t", 700, 4), ("fe_dpt_m", 260, 2)])
+@pytest.mark.parametrize("name,B,hops", [("fe_ln_b", 300, 3), ("fe_dprnn_b", 256, 3), ("fe_dprnn_l", 300, 2), ("fe_dpt_b", 256, 35), ("fe_dpt_t", 700, 4), ("fe_dpt_m", 260, 2),
+                                            ("fe_dpt_t", 800, 35), ("fe_dpt_b", 1100, 34), ("fe_dprnn_b", 600, 3), ("fe_dprnn_t", 1100, 3), ("fe_dpt_b", 400, 3)])
 def test_full_size_block_variants(name, B, hops):
     """the dprnn / dptransformer variants at full batch sizes (one workgroup per stream, and persistent workgroups above #CUs):
     oracle parity on sample streams, bitwise position independence on all; 35 hops of dpt_b take its K / V rings (31 slots)
     through a wrap."""
     m, orc, cfg, sr, seed = _model(name)
     _full_size_check(m, orc, cfg, sr, B, hops, [0, 1, 17, B // 2, B - 2, B - 1], f"{name} B={B}")
+    # r6: the T- and B-sized dprnn / dptransformer shapes have low-LDS companions (fe_shapes.def DPTLOW ... DTBLOW); dpt_b's takes over beyond two rounds only
+    want_low = {("fe_dpt_t", 700): True, ("fe_dpt_t", 800): True, ("fe_dpt_b", 1100): True, ("fe_dprnn_b", 600): True, ("fe_dprnn_t", 1100): True, ("fe_dpt_b", 400): False}.get((name, B))
+    if want_low is not None:
+        assert ("LOW=" in m.engine.last_step_kernel()) == want_low, m.engine.last_step_kernel()
 
 
 @pytest.mark.parametrize("name,B", [("fe_b", 300), ("fe_b", 1100), ("fe_s", 520), ("fe48_t", 700), ("fe48_t", 1100), ("fe_t", 700), ("fe_t", 1100), ("fe48_b", 600), ("fe48_b_h480", 1030)])
