@@ -109,6 +109,9 @@ void launch_impl(const FrameArgs& a, int max_wgs, hipStream_t st, hipError_t* er
     if (a.dbg != nullptr || a.clk != nullptr) launch_one<S, true, -1, false, true>(a, grid, st, err);     // fe_debug_step / fe_profile_step
 #endif
     else if (a.mode == FE_MODE_STREAM && a.T == 1) {                                   // the per-hop hot path
+#ifdef FE_EXP_NONPERSIST      // experiment: one workgroup per stream at any batch (the hardware queues what is not resident); LOW = 1 keeps nothing per workgroup in global memory
+        if (S::LOW == 1) { launch_one<S, false, FE_MODE_STREAM, true, false>(a, a.B, st, err); return; }
+#endif
         if (grid == a.B) launch_one<S, false, FE_MODE_STREAM, true, false>(a, grid, st, err);
         else launch_one<S, false, FE_MODE_STREAM, true, true>(a, grid, st, err);
     }
