@@ -111,6 +111,25 @@ struct LSbLds {
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
 };
 
+// r6d experiment (FE_LSB_NT=1): the per-stream cache tensors - read once and written once per step - as non-temporal accesses, so that they do not displace the carry in L2
+#ifndef FE_LSB_NT
+#define FE_LSB_NT 0
+#endif
+__device__ __forceinline__ f32x4 lsb_ld_state4(const float* p) {
+#if FE_LSB_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#else
+    return *reinterpret_cast<const f32x4*>(p);
+#endif
+}
+__device__ __forceinline__ void lsb_st_state4(float* p, f32x4 v) {
+#if FE_LSB_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+    *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
+
 struct LSbArgs {
     const float* wp;          // the packed buffer of lisennet_frame_kernel; the stream-batched region starts at LPk::TOTAL
     int wp_floats;
@@ -216,7 +235,7 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
             for (int k = 0; k < NV; ++k) {
                 const int i = tid + k * kLsbThreads, ic = i < TOT ? i : TOT - 1, n = ic / NE4, e = (ic - n * NE4) * 4;
                 const int bs = b0 + n < a.B ? b0 + n : a.B - 1;
-                v[k] = *reinterpret_cast<const f32x4*>(src + (size_t)bs * per + e);
+                v[k] = lsb_ld_state4(src + (size_t)bs * per + e);
             }
         };
         auto stage_put = [&](float* T, const auto& v, auto nch_, auto nf_, auto ldt_) {
@@ -257,7 +276,7 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = t0[(NF % 4 != 0 && f0 + j >= NF) ? j + 16 * LDT - NF : j];
-                if (i < TOT && b0 + n < a.B) *reinterpret_cast<f32x4*>(dst + (size_t)(b0 + n) * per + e) = o;
+                if (i < TOT && b0 + n < a.B) lsb_st_state4(dst + (size_t)(b0 + n) * per + e, o);
             }
         };
         using I3 = std::integral_constant<int, 3>;
@@ -502,7 +521,7 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
         for (int k = 0; k < 6; ++k) {
             const int i = tid + k * kLsbThreads, n = i / (S::K_E4 / 4), e = (i - n * (S::K_E4 / 4)) * 4, c = e >> 6, f = e & 63;
             const float* t3 = smem + L::T3 + (c * 16 + n) * 65 + f;
-            if (b0 + n < a.B) *reinterpret_cast<f32x4*>(c4 + (size_t)(b0 + n) * S::K_E4 + e) = f32x4{t3[0], t3[1], t3[2], t3[3]};
+            if (b0 + n < a.B) lsb_st_state4(c4 + (size_t)(b0 + n) * S::K_E4 + e, f32x4{t3[0], t3[1], t3[2], t3[3]});
         }
     }
     LSB_CLK(2);
@@ -770,7 +789,7 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
                             hn[r] = __builtin_fmaf(zg, hp[fl][t][r] - ng, ng);
                         }
                         // (the old state of both tiles is in registers; no other lane reads these rows)
-                        if (live && (t == 0 || lg < 2)) *reinterpret_cast<f32x4*>(chp + (4 * wave + fl) * 24 + 16 * t + 4 * lg) = hn;
+                        if (live && (t == 0 || lg < 2)) lsb_st_state4(chp + (4 * wave + fl) * 24 + 16 * t + 4 * lg, hn);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) o[fl] = FE_MFMA(cw[j], hn[j], o[fl]);
                     }
@@ -897,8 +916,8 @@ __global__ void __launch_bounds__(kLsbThreads) __attribute__((amdgpu_waves_per_e
                     }
                     if (live) {         // the new cache: frames (t - 1, t) - this wave's own columns, which no other wave reads from the tensor
                         float* dst = cgp + (16 * t + 4 * lg + r) * 64 + 4 * wave;
-                        *reinterpret_cast<f32x4*>(dst) = old1[r];
-                        *reinterpret_cast<f32x4*>(dst + 32) = f32x4{xc[0][r], xc[1][r], xc[2][r], xc[3][r]};
+                        lsb_st_state4(dst, old1[r]);
+                        lsb_st_state4(dst + 32, f32x4{xc[0][r], xc[1][r], xc[2][r], xc[3][r]});
                     }
                     __builtin_amdgcn_sched_barrier(0);  // (one channel at a time: sixteen short independent Mish chains interleaved were scheduled into spills)
                 }
