@@ -5,22 +5,22 @@
 import os, sys, numpy as np, torch, importlib
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
-from common import BSRNN_KWARGS, MODEL_KWARGS, make_input, build_bsrnn_oracle, build_oracle
+from common import BSRNN_KWARGS, MODEL_KWARGS, MODEL_MODULE, make_input, build_bsrnn_oracle, build_oracle
 dev = torch.device("cuda:0")
-names = sys.argv[1:] or ["bsrnn_xt", "bsrnn_xxt", "bsrnn_t", "fe_b", "fe_t", "fe48_b_h480"]
+names = sys.argv[1:] or ["bsrnn_xt", "bsrnn_xxt", "bsrnn_t", "fe_b", "fe_t", "fe48_t", "fe48_b_h480", "fe_dpt_b", "fe_dpt_t", "fe_dprnn_b", "fe_dprnn_t"]
 for name in names:
     if name.startswith("bsrnn"):
         kw, sr, seed = BSRNN_KWARGS[name]; cfg, sd, fused, orc = build_bsrnn_oracle(name)
         mod = importlib.import_module("fastenhancer_amd.models.bsrnn.model")
     else:
         kw, sr, seed = MODEL_KWARGS[name]; cfg, sd, fused, orc = build_oracle(name)
-        mod = importlib.import_module("fastenhancer_amd.models.fastenhancer.default.model")
+        mod = importlib.import_module(f"fastenhancer_amd.models.{MODEL_MODULE[name]}.model")
     m = mod.ONNXModel(**kw).to(dev).eval()
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     eng = m.engine
     H, hops = cfg.hop_size, 3
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    sizes = [1, 2, 3, 15, 16, 17, 31, 33, 63, 64, 65, 100, cus - 1, cus, cus + 1, 2 * cus - 1, 2 * cus, 2 * cus + 1, 700]
+    sizes = [1, 2, 3, 15, 16, 17, 31, 33, 63, 64, 65, 100, cus - 1, cus, cus + 1, 2 * cus - 1, 2 * cus, 2 * cus + 1, 700, 3 * cus - 1, 3 * cus, 3 * cus + 1, 1100]      # (3 x #CUs: the T shapes' companions hold three workgroups per CU)
     xall = torch.from_numpy(make_input(max(sizes), hops * H, seed + 17, sr)).to(dev)
     ref = None; bad = []
     for B in sizes:
